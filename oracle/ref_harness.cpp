@@ -1,0 +1,170 @@
+/* ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (part of oracle/; never linked into the product).
+ *
+ * Our own main() around the REFERENCE's headers (compiled from /root/reference where they lie, see Makefile.ref).
+ * It drives the reference's RAS path exactly like examples/schwarz.cpp:81-131 does (generate -> Subdomain::initialize
+ * -> multiplicityScaling -> initialize(d) -> [setVectors + buildTwo] -> callNumfact -> IterativeMethod::solve) and
+ * dumps, per MPI rank, the inputs and outputs of every function on the hot path so that tests/golden/ can pin our
+ * restatement (oracle/) and the HIP path against the real thing:
+ *   CSR matrix, d (after multiplicityScaling, include/HPDDM_schwarz.hpp:381-404), map_ (include/HPDDM_subdomain.hpp:54),
+ *   Schwarz::exchange (schwarz.hpp:180-188), Schwarz::GMV (:726-747), Solver::solve (LAPACK.hpp:388-400),
+ *   Schwarz::apply (:527-612), Schwarz::deflation (:1602-1622), IterativeMethod::solve (iterative.hpp:1013) and
+ *   computeResidual (:761).
+ * Output: one text file per rank, sections "@name kind count" followed by one value per line (%.17g / %d).
+ *
+ * usage: mpiexec -n P ref_harness -out DIR -case NAME -mu M [reference options: -Nx -Ny -overlap -symmetric_csr ...
+ *        -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0 ...]
+ */
+#include "schwarz.hpp" /* the reference's examples/schwarz.hpp: typedef K, symCoarse, generate() prototype */
+#include <cstdio>
+#include <random>
+#include <string>
+
+typedef HPDDM::Schwarz<SUBDOMAIN, COARSEOPERATOR, symCoarse, K> RefSchwarzBase;
+/* s_ (the local Solver<K>, include/HPDDM_preconditioner.hpp:98) is protected: expose Solver::solve for the dump */
+struct RefSchwarz : public RefSchwarzBase {
+  void localSolve(const K *b, K *x, unsigned short mu) const { this->s_.solve(b, x, mu); }
+};
+
+static FILE *g_out = nullptr;
+static void  dumpd(const char *name, const double *v, long n)
+{
+  fprintf(g_out, "@%s f %ld\n", name, n);
+  for (long i = 0; i < n; ++i) fprintf(g_out, "%.17g\n", v[i]);
+}
+static void dumpi(const char *name, const int *v, long n)
+{
+  fprintf(g_out, "@%s i %ld\n", name, n);
+  for (long i = 0; i < n; ++i) fprintf(g_out, "%d\n", v[i]);
+}
+
+int main(int argc, char **argv)
+{
+  MPI_Init(&argc, &argv);
+  int rank, size;
+  MPI_Comm_size(MPI_COMM_WORLD, &size);
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  HPDDM::Option &opt = *HPDDM::Option::get();
+  opt.parse(argc, argv, false,
+            {std::forward_as_tuple("overlap=<1>", "", HPDDM::Option::Arg::positive), std::forward_as_tuple("Nx=<100>", "", HPDDM::Option::Arg::positive), std::forward_as_tuple("Ny=<100>", "", HPDDM::Option::Arg::positive),
+             std::forward_as_tuple("generate_random_rhs=<0>", "", HPDDM::Option::Arg::integer), std::forward_as_tuple("symmetric_csr=(0|1)", "", HPDDM::Option::Arg::argument),
+             std::forward_as_tuple("mu=<1>", "number of harness right-hand sides", HPDDM::Option::Arg::positive), std::forward_as_tuple("out=<dir>", "", HPDDM::Option::Arg::argument),
+             std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument)});
+  if (rank != 0) opt.remove("verbosity");
+  const std::string dir  = opt.prefix("out");
+  const std::string name = opt.prefix("case");
+  const int         mu   = opt.app()["mu"];
+  {
+    const std::string fn = dir + "/" + name + "_r" + std::to_string(rank) + ".txt";
+    g_out                = fopen(fn.c_str(), "w");
+    if (!g_out) {
+      fprintf(stderr, "cannot open %s\n", fn.c_str());
+      MPI_Abort(MPI_COMM_WORLD, 2);
+    }
+  }
+  std::vector<std::vector<int>> mapping;
+  std::list<int>                o;
+  HPDDM::MatrixCSR<K>          *Mat, *MatNeumann = nullptr;
+  K                            *f1, *sol1;
+  double                       *d = nullptr;
+  int                           ndof;
+  generate(rank, size, o, mapping, ndof, Mat, MatNeumann, d, f1, sol1); /* reference generator, analytic RHS (mu=0) */
+  /* multi-RHS block: column 0 = the reference's analytic RHS, the others = a seeded, reproducible perturbation of it
+   * (the reference's own random RHS uses std::random_device, examples/generate.cpp:88-91, hence is not reproducible) */
+  K *f   = new K[mu * ndof];
+  K *sol = new K[mu * ndof]();
+  std::copy_n(f1, ndof, f);
+  {
+    std::mt19937 gen(1234 + 17 * rank);
+    for (int nu = 1; nu < mu; ++nu)
+      for (int i = 0; i < ndof; ++i) f[nu * ndof + i] = f1[i] * (0.5 + (gen() >> 8) * (1.0 / 16777216.0));
+  }
+  int meta[8] = {rank, size, ndof, Mat->nnz_, Mat->sym_ ? 1 : 0, mu, (int)opt.app()["overlap"], 0};
+  dumpd("d_in", d, ndof); /* the generator's weights, before multiplicityScaling */
+  dumpi("ia", Mat->ia_, ndof + 1);
+  dumpi("ja", Mat->ja_, Mat->nnz_);
+  dumpd("a", Mat->a_, Mat->nnz_);
+  {
+    std::vector<int> nb(o.begin(), o.end());
+    dumpi("neighbors_in", nb.data(), nb.size());
+    for (size_t k = 0; k < mapping.size(); ++k) dumpi(("mapping_in_" + std::to_string(k)).c_str(), mapping[k].data(), mapping[k].size());
+  }
+
+  RefSchwarz A;
+  A.Subdomain::initialize(Mat, o, mapping);
+  A.multiplicityScaling(d);
+  A.initialize(d);
+  dumpd("d", d, ndof);
+  {
+    const HPDDM::vectorNeighbor &map = A.getMap();
+    std::vector<int>             nb;
+    for (const auto &p : map) nb.push_back(p.first);
+    dumpi("neighbors", nb.data(), nb.size());
+    for (size_t k = 0; k < map.size(); ++k) dumpi(("map_" + std::to_string(k)).c_str(), map[k].second.data(), map[k].second.size());
+  }
+  /* the harness' extra RHS columns must be consistent on the overlap like the analytic one: make them so with the
+   * reference's own exchange (what examples/schwarz.cpp:98 does for random RHS) */
+  if (mu > 1) A.exchange<true>(f + ndof, mu - 1);
+  dumpd("f", f, (long)mu * ndof);
+
+  unsigned short nu = 0;
+  if (opt.set("schwarz_coarse_correction")) {
+    nu            = 1; /* constant deflation vector, examples/schwarz.cpp:115-121 (no EIGENSOLVER in this build) */
+    K **deflation = new K *[1];
+    *deflation    = new K[ndof];
+    std::fill(*deflation, *deflation + ndof, 1.0);
+    A.setVectors(deflation);
+    A.super::initialize(nu);
+    A.buildTwo(MPI_COMM_WORLD);
+  }
+  meta[7] = nu;
+  dumpi("meta", meta, 8);
+  A.callNumfact();
+
+  /* --- per-function dumps (buffers set like IterativeMethod::initializeNorm -> Schwarz::start does) --- */
+  const int n    = mu * ndof;
+  K        *x    = new K[n]();
+  K        *out  = new K[n];
+  K        *work = new K[n];
+  bool      alloc = A.start(f, x, mu);
+  /* exchange: x <- sum_j R_j^T D_j x_j */
+  std::copy_n(f, n, out);
+  A.exchange(out, mu);
+  dumpd("exchange_out", out, n);
+  /* GMV: out = exchange(A f) */
+  A.GMV(f, out, mu);
+  dumpd("gmv_out", out, n);
+  /* local solve only */
+  A.localSolve(f, out, mu);
+  dumpd("solve_out", out, n);
+  /* full preconditioner apply (one- or two-level depending on the options) */
+  A.apply(f, out, mu, work);
+  dumpd("apply_out", out, n);
+  if (nu) {
+    A.deflation<false>(f, out, mu);
+    dumpd("deflation_out", out, n);
+  }
+  A.end(alloc);
+  delete[] x;
+  delete[] out;
+  delete[] work;
+
+  /* --- the Krylov solve and the residual check of examples/schwarz.cpp:128-131 --- */
+  int     it      = HPDDM::IterativeMethod::solve(A, f, sol, mu, A.getCommunicator());
+  double *storage = new double[2 * mu];
+  A.computeResidual(sol, f, storage, mu);
+  dumpi("iterations", &it, 1);
+  dumpd("sol", sol, n);
+  dumpd("residual", storage, 2 * mu);
+  if (rank == 0)
+    for (int k = 0; k < mu; ++k) printf(" --- residual = %e / %e (it = %d)\n", storage[1 + 2 * k], storage[2 * k], it);
+  delete[] storage;
+  fclose(g_out);
+  delete[] d;
+  delete MatNeumann;
+  delete[] sol;
+  delete[] f;
+  delete[] sol1;
+  delete[] f1;
+  MPI_Finalize();
+  return 0;
+}
