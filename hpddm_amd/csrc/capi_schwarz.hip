@@ -1,0 +1,323 @@
+// C ABI, Schwarz-operator part (include/hpddm_hip.h).  Reference binding: interface/hpddm_c.cpp:172-225.
+#include "../../include/hpddm_hip.h"
+#include "capi_common.hpp"
+#include "schwarz.hpp"
+#include <cstring>
+#include <sstream>
+
+using namespace hpddm_hip;
+
+struct HpddmHipSchwarz {
+  Schwarz op;
+  HpddmHipSchwarz(int a, int b, int c) : op(a, b, c) { }
+};
+struct HpddmHipSubdomain; // defined in capi_subdomain.hip (first member is the LocalSolver)
+
+namespace {
+// run a device operation on host arrays: in -> hin, op, hout -> out
+template <class F>
+void host_roundtrip(Schwarz &A, const double *in, double *out, int mu, F &&f)
+{
+  A.build_device();
+  A.reserve(mu);
+  hipStream_t  st  = library_stream();
+  const size_t cnt = (size_t)A.ntot * mu;
+  HIP_OK(hipMemcpyAsync(A.hin.p, in, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+  f(A.hin.p, A.hout.p);
+  HIP_OK(hipMemcpyAsync(out, A.hout.p, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+}
+// the reference's enumerated option values (include/HPDDM_option_impl.hpp:41-178)
+double parse_value(const std::string &key, const std::string &val)
+{
+  static const std::map<std::string, std::map<std::string, double>> enums = {
+    {"variant", {{"left", 0}, {"right", 1}, {"flexible", 2}}},
+    {"orthogonalization", {{"cgs", 0}, {"mgs", 1}}},
+    {"schwarz_method", {{"ras", 0}, {"oras", 1}, {"soras", 2}, {"asm", 3}, {"osm", 4}, {"none", 5}}},
+    {"schwarz_coarse_correction", {{"deflated", 0}, {"additive", 1}, {"balanced", 2}}},
+    {"krylov_method", {{"gmres", 0}, {"bgmres", 1}, {"cg", 2}, {"bcg", 3}, {"gcrodr", 4}, {"bgcrodr", 5}, {"bfbcg", 6}, {"richardson", 7}, {"none", 8}}},
+  };
+  auto it = enums.find(key);
+  if (it != enums.end()) {
+    auto jt = it->second.find(val);
+    if (jt != it->second.end()) return jt->second;
+  }
+  char  *end = nullptr;
+  double v   = std::strtod(val.c_str(), &end);
+  HH_CHECK(end != val.c_str(), "option " + key + ": cannot parse value '" + val + "'");
+  return v;
+}
+} // namespace
+
+extern "C" {
+
+HpddmHipSchwarz *HpddmHipSchwarzCreate(int nsub, int first_global, int nglobal)
+{
+  try {
+    return new HpddmHipSchwarz(nsub, first_global, nglobal);
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return nullptr;
+  }
+}
+void HpddmHipSchwarzDestroy(HpddmHipSchwarz *A) { delete A; }
+
+int HpddmHipSchwarzSetSubdomain(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity)
+{
+  HH_TRY(
+    HH_CHECK(A && ia && ja && a, "null argument");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    A->op.set_subdomain(s, n, ia, ja, a, sym != 0, numbering == 'F', neighbors, list, sizes, connectivity);
+    return 0;)
+}
+int HpddmHipSchwarzMultiplicityScaling(HpddmHipSchwarz *A, double *const *d)
+{
+  HH_TRY(
+    HH_CHECK(A && d, "null argument");
+    A->op.multiplicity_scaling(d);
+    return 0;)
+}
+int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d)
+{
+  HH_TRY(
+    HH_CHECK(A && d, "null argument");
+    A->op.initialize(s, d);
+    return 0;)
+}
+int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z)
+{
+  HH_TRY(
+    HH_CHECK(A && (Z || nu == 0), "null argument");
+    A->op.set_vectors(s, nu, Z);
+    return 0;)
+}
+int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A)
+{
+  HH_TRY(
+    HH_CHECK(A, "null argument");
+    A->op.build_coarse();
+    return 0;)
+}
+int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A)
+{
+  HH_TRY(
+    HH_CHECK(A, "null argument");
+    A->op.call_numfact();
+    return 0;)
+}
+int HpddmHipSchwarzSetOption(HpddmHipSchwarz *A, const char *key, double value)
+{
+  HH_TRY(
+    HH_CHECK(A && key, "null argument");
+    A->op.opt[key] = value;
+    return 0;)
+}
+double HpddmHipSchwarzGetOption(const HpddmHipSchwarz *A, const char *key)
+{
+  if (!A || !key) return 0.0;
+  auto it = A->op.opt.find(key);
+  return it == A->op.opt.end() ? 0.0 : it->second;
+}
+int HpddmHipSchwarzOptionParse(HpddmHipSchwarz *A, const char *args)
+{
+  HH_TRY(
+    HH_CHECK(A && args, "null argument");
+    std::istringstream       is(args);
+    std::vector<std::string> tok;
+    for (std::string t; is >> t;) tok.push_back(t);
+    for (size_t i = 0; i < tok.size(); ++i) {
+      std::string t = tok[i];
+      if (t.rfind("-hpddm_", 0) != 0) continue;
+      t = t.substr(7);
+      std::string val;
+      const size_t eq = t.find('=');
+      if (eq != std::string::npos) {
+        val = t.substr(eq + 1);
+        t   = t.substr(0, eq);
+      } else if (i + 1 < tok.size() && tok[i + 1].rfind("-hpddm_", 0) != 0 && !(tok[i + 1][0] == '-' && tok[i + 1].size() > 1 && std::isalpha((unsigned char)tok[i + 1][1]))) val = tok[++i];
+      A->op.opt[t] = val.empty() ? 1.0 : parse_value(t, val);
+    }
+    return 0;)
+}
+long long HpddmHipSchwarzGetDof(const HpddmHipSchwarz *A, int s)
+{
+  if (!A) return -1;
+  if (s < 0) {
+    long long t = 0;
+    for (const auto &S : A->op.subs) t += S.n;
+    return t;
+  }
+  return s < A->op.nsub ? A->op.subs[s].n : -1;
+}
+
+int HpddmHipSchwarzExchange(HpddmHipSchwarz *A, double *x, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && x, "null argument");
+    host_roundtrip(A->op, x, x, mu, [&](double *i, double *o) { A->op.exchange(i, o, mu, true); });
+    return 0;)
+}
+int HpddmHipSchwarzGMV(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    host_roundtrip(A->op, in, out, mu, [&](double *i, double *o) { A->op.gmv(i, o, mu); });
+    return 0;)
+}
+int HpddmHipSchwarzApply(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    host_roundtrip(A->op, in, out, mu, [&](double *i, double *o) { A->op.apply(i, o, mu); });
+    return 0;)
+}
+int HpddmHipSchwarzDeflation(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    host_roundtrip(A->op, in, out, mu, [&](double *i, double *o) { A->op.deflation(i, o, mu); });
+    return 0;)
+}
+int HpddmHipSchwarzLocalSolve(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    host_roundtrip(A->op, in, out, mu, [&](double *i, double *o) { A->op.local_solve(i, o, mu); });
+    return 0;)
+}
+int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && sol && f && storage, "null argument");
+    Schwarz &op = A->op;
+    op.build_device();
+    op.reserve(mu);
+    hipStream_t    st  = library_stream();
+    const size_t   cnt = (size_t)op.ntot * mu;
+    DevBuf<double> fd;
+    fd.alloc(cnt);
+    HIP_OK(hipMemcpyAsync(op.hin.p, sol, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(fd.p, f, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    op.compute_residual(op.hin.p, fd.p, storage, mu);
+    return 0;)
+}
+int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap)
+{
+  try {
+    HH_CHECK(A && b && sol && mu >= 1, "bad argument");
+    Schwarz &op = A->op;
+    op.build_device();
+    op.reserve(mu);
+    hipStream_t    st  = library_stream();
+    const size_t   cnt = (size_t)op.ntot * mu;
+    DevBuf<double> bd, xd;
+    bd.alloc(cnt);
+    xd.alloc(cnt);
+    HIP_OK(hipMemcpyAsync(bd.p, b, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(xd.p, sol, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    const int it = op.gmres(bd.p, xd.p, mu, history, history_cap);
+    HIP_OK(hipMemcpyAsync(sol, xd.p, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return it;
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+
+int HpddmHipSchwarzApplyDevice(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    A->op.build_device();
+    A->op.apply(in, out, mu);
+    return 0;)
+}
+int HpddmHipSchwarzGMVDevice(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(A && in && out, "null argument");
+    A->op.build_device();
+    A->op.gmv(in, out, mu);
+    return 0;)
+}
+int HpddmHipSolveDevice(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap)
+{
+  try {
+    HH_CHECK(A && b && sol && mu >= 1, "bad argument");
+    A->op.build_device();
+    return A->op.gmres(b, sol, mu, history, history_cap);
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+
+int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup, int reps, double *seconds)
+{
+  HH_TRY(
+    HH_CHECK(A && what && seconds && mu >= 1 && reps >= 1, "bad argument");
+    Schwarz &op = A->op;
+    op.build_device();
+    op.reserve(mu);
+    hipStream_t         st  = library_stream();
+    const size_t        cnt = (size_t)op.ntot * mu;
+    std::vector<double> ones(cnt, 1.0);
+    DevBuf<double>      in, out;
+    in.upload(ones, st);
+    out.alloc(cnt);
+    const std::string w(what);
+    auto              run = [&]() {
+      if (w == "apply") op.apply(in.p, out.p, mu);
+      else if (w == "solve") op.local_solve(in.p, out.p, mu);
+      else if (w == "gmv") op.gmv(in.p, out.p, mu);
+      else if (w == "deflation") op.deflation(in.p, out.p, mu);
+      else if (w == "exchange") op.exchange(in.p, out.p, mu, true);
+      else HH_CHECK(false, "Time: unknown operation " + w);
+    };
+    for (int i = 0; i < warmup; ++i) run();
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) run();
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_OK(hipEventDestroy(e0));
+    HIP_OK(hipEventDestroy(e1));
+    *seconds = (double)ms * 1e-3 / reps;
+    return 0;)
+}
+
+int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
+{
+  HH_TRY(
+    HH_CHECK(A && stats, "null argument");
+    const Schwarz &op = A->op;
+    double         n = 0, nnzl = 0, stored = 0;
+    for (const auto &S : op.subs) {
+      n += S.n;
+      nnzl += (double)S.ls->host.sym.nnz_exact;
+      stored += (double)S.ls->host.sym.nnz_stored;
+    }
+    stats[0] = n;
+    stats[1] = nnzl;
+    stats[2] = stored;
+    stats[3] = 2.0 * nnzl * 8.0 + 4.0 * n * 8.0;
+    stats[4] = op.plan.nlev;
+    stats[5] = op.plan.launches_per_solve;
+    stats[6] = (double)op.nnzA;
+    stats[7] = op.cdim;
+    return 0;)
+}
+
+HpddmHipSubdomain *HpddmHipSchwarzGetSubdomain(HpddmHipSchwarz *A, int s)
+{
+  if (!A || s < 0 || s >= A->op.nsub) return nullptr;
+  // HpddmHipSubdomain is a struct whose only member is a LocalSolver (capi_subdomain.hip)
+  return reinterpret_cast<HpddmHipSubdomain *>(A->op.subs[s].ls.get());
+}
+
+} // extern "C"

@@ -1,0 +1,223 @@
+// Dense host kernels for the one-time multifrontal factorisation (row-major storage throughout).
+//
+// Everything is expressed through one packed GEMM core (GotoBLAS-style: B packed k-major into NR-wide slivers,
+// MR x NR register tile, AVX2/FMA via GCC vector extensions) plus small unblocked kernels on NB x NB diagonal tiles.
+// No BLAS/LAPACK dependency: the factorisation must run on any host the MI355X box has.
+//
+// Reference concept: the numerical phase of Solver<K>::numfact (include/HPDDM_MUMPS.hpp:286, job=4/2;
+// include/HPDDM_LAPACK.hpp:362-382 potrf/sytrf/getrf for the dense oracle back-end).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace hpddm_hip {
+namespace dense {
+
+typedef double v4d __attribute__((vector_size(32), aligned(8)));
+
+static const int MR = 4, NR = 12, KC = 256;
+
+// pack B(k0:k0+kc, j0:j0+nr) into Bp[k*NR + j]; transB: element (k, j) is read from B[j*ldb + k] instead of B[k*ldb + j]
+static inline void pack_b(const double *B, long ldb, bool transB, int k0, int kc, int j0, int nr, double *Bp)
+{
+  if (!transB) {
+    for (int k = 0; k < kc; ++k) {
+      const double *src = B + (long)(k0 + k) * ldb + j0;
+      double       *dst = Bp + (long)k * NR;
+      int           j   = 0;
+      for (; j < nr; ++j) dst[j] = src[j];
+      for (; j < NR; ++j) dst[j] = 0.0;
+    }
+  } else {
+    for (int j = 0; j < NR; ++j) {
+      if (j < nr) {
+        const double *src = B + (long)(j0 + j) * ldb + k0;
+        for (int k = 0; k < kc; ++k) Bp[(long)k * NR + j] = src[k];
+      } else
+        for (int k = 0; k < kc; ++k) Bp[(long)k * NR + j] = 0.0;
+    }
+  }
+}
+
+// C(mr x nr) += alpha * A(mr x kc) * Bp(kc x NR)
+static inline void micro(int mr, int nr, int kc, double alpha, const double *A, long lda, const double *Bp, double *C, long ldc)
+{
+  v4d c[MR][3];
+  for (int i = 0; i < MR; ++i)
+    for (int v = 0; v < 3; ++v) c[i][v] = (v4d){0, 0, 0, 0};
+  const double *a0 = A, *a1 = A + (mr > 1 ? lda : 0), *a2 = A + (mr > 2 ? 2 * lda : 0), *a3 = A + (mr > 3 ? 3 * lda : 0);
+  for (int k = 0; k < kc; ++k) {
+    const v4d b0 = *(const v4d *)(Bp + (long)k * NR), b1 = *(const v4d *)(Bp + (long)k * NR + 4), b2 = *(const v4d *)(Bp + (long)k * NR + 8);
+    v4d       a;
+    a       = (v4d){a0[k], a0[k], a0[k], a0[k]};
+    c[0][0] += a * b0;
+    c[0][1] += a * b1;
+    c[0][2] += a * b2;
+    a       = (v4d){a1[k], a1[k], a1[k], a1[k]};
+    c[1][0] += a * b0;
+    c[1][1] += a * b1;
+    c[1][2] += a * b2;
+    a       = (v4d){a2[k], a2[k], a2[k], a2[k]};
+    c[2][0] += a * b0;
+    c[2][1] += a * b1;
+    c[2][2] += a * b2;
+    a       = (v4d){a3[k], a3[k], a3[k], a3[k]};
+    c[3][0] += a * b0;
+    c[3][1] += a * b1;
+    c[3][2] += a * b2;
+  }
+  if (mr == MR && nr == NR) {
+    for (int i = 0; i < MR; ++i) {
+      double *cr = C + (long)i * ldc;
+      for (int v = 0; v < 3; ++v) {
+        v4d t = *(v4d *)(cr + 4 * v);
+        t += alpha * c[i][v];
+        *(v4d *)(cr + 4 * v) = t;
+      }
+    }
+  } else {
+    for (int i = 0; i < mr; ++i)
+      for (int j = 0; j < nr; ++j) C[(long)i * ldc + j] += alpha * c[i][j / 4][j % 4];
+  }
+}
+
+// C(M x N) += alpha * A(M x K) * op(B),  op(B) = B (K x N) or B^T (B is N x K) ; all row-major.
+// lower_only: C is square-ish and only blocks touching the lower triangle (col <= row, with global offsets ci0/cj0) are needed.
+// par: use OpenMP over row panels.
+static inline void gemm(int M, int N, int K, double alpha, const double *A, long lda, const double *B, long ldb, bool transB, double *C, long ldc, bool par, bool lower_only = false, int ci0 = 0, int cj0 = 0)
+{
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  const int NC = 20 * NR; // B block of KC x NC doubles = 480 KB stays in L2 while the rows of A stream by
+#pragma omp parallel if (par)
+  {
+    static thread_local std::vector<double> Bpv; // packed B block, allocated once per thread
+    if (Bpv.size() < (size_t)KC * NC) Bpv.resize((size_t)KC * NC);
+    double *const Bp = Bpv.data();
+    for (int jc = 0; jc < N; jc += NC) {
+      const int nc   = std::min(NC, N - jc);
+      const int nslv = (nc + NR - 1) / NR;
+      // first row that touches the lower triangle for this column block
+      int ifirst = 0;
+      if (lower_only) ifirst = std::max(0, ((cj0 + jc - ci0) / MR) * MR);
+      if (ifirst >= M) continue;
+      for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kc = std::min(KC, K - k0);
+        // every thread packs its own copy of the B block: cheap relative to the M-loop, avoids sharing
+        for (int s = 0; s < nslv; ++s) pack_b(B, ldb, transB, k0, kc, jc + s * NR, std::min(NR, nc - s * NR), Bp + (size_t)s * KC * NR);
+#pragma omp for schedule(dynamic, 8)
+        for (int i0 = ifirst; i0 < M; i0 += MR) {
+          const int mr = std::min(MR, M - i0);
+          for (int s = 0; s < nslv; ++s) {
+            const int j0 = jc + s * NR;
+            if (lower_only && cj0 + j0 > ci0 + i0 + mr - 1) break;
+            micro(mr, std::min(NR, N - j0), kc, alpha, A + (long)i0 * lda + k0, lda, Bp + (size_t)s * KC * NR, C + (long)i0 * ldc + j0, ldc);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- small unblocked kernels on a diagonal tile T (nb x nb, row-major, ld) ----
+// Cholesky T = L L^T (lower, in place); returns false on a non-positive pivot
+static inline bool potf2(int nb, double *T, long ld)
+{
+  for (int j = 0; j < nb; ++j) {
+    double d = T[(long)j * ld + j];
+    for (int k = 0; k < j; ++k) d -= T[(long)j * ld + k] * T[(long)j * ld + k];
+    if (!(d > 0.0)) return false;
+    d                  = std::sqrt(d);
+    T[(long)j * ld + j] = d;
+    const double inv    = 1.0 / d;
+    for (int i = j + 1; i < nb; ++i) {
+      double s = T[(long)i * ld + j];
+      for (int k = 0; k < j; ++k) s -= T[(long)i * ld + k] * T[(long)j * ld + k];
+      T[(long)i * ld + j] = s * inv;
+    }
+  }
+  return true;
+}
+// LDL^T without pivoting: T = L D L^T, unit lower L stored strictly below the diagonal, D on the diagonal
+static inline bool ldlf2(int nb, double *T, long ld)
+{
+  std::vector<double> w(nb);
+  for (int j = 0; j < nb; ++j) {
+    double d = T[(long)j * ld + j];
+    for (int k = 0; k < j; ++k) {
+      w[k] = T[(long)j * ld + k] * T[(long)k * ld + k];
+      d -= T[(long)j * ld + k] * w[k];
+    }
+    if (d == 0.0 || d != d) return false;
+    T[(long)j * ld + j] = d;
+    const double inv    = 1.0 / d;
+    for (int i = j + 1; i < nb; ++i) {
+      double s = T[(long)i * ld + j];
+      for (int k = 0; k < j; ++k) s -= T[(long)i * ld + k] * w[k];
+      T[(long)i * ld + j] = s * inv;
+    }
+  }
+  return true;
+}
+// LU without pivoting: T = L U, unit lower L strictly below, U on and above the diagonal
+static inline bool getf2(int nb, double *T, long ld)
+{
+  for (int j = 0; j < nb; ++j) {
+    const double p = T[(long)j * ld + j];
+    if (p == 0.0 || p != p) return false;
+    const double inv = 1.0 / p;
+    for (int i = j + 1; i < nb; ++i) {
+      const double l     = T[(long)i * ld + j] * inv;
+      T[(long)i * ld + j] = l;
+      for (int k = j + 1; k < nb; ++k) T[(long)i * ld + k] -= l * T[(long)j * ld + k];
+    }
+  }
+  return true;
+}
+// rows X(m x nb) <- X * L^{-T}  (L lower nb x nb; unit = implicit ones on the diagonal), optionally then * D^{-1}
+static inline void trsm_right_lower_trans(int m, int nb, const double *L, long ldl, bool unit, const double *dscale, double *X, long ldx, bool par)
+{
+#pragma omp parallel for if (par) schedule(static)
+  for (int i = 0; i < m; ++i) {
+    double *x = X + (long)i * ldx;
+    for (int j = 0; j < nb; ++j) {
+      double s = x[j];
+      for (int k = 0; k < j; ++k) s -= x[k] * L[(long)j * ldl + k];
+      x[j] = unit ? s : s / L[(long)j * ldl + j];
+    }
+    if (dscale)
+      for (int j = 0; j < nb; ++j) x[j] /= dscale[(long)j * (ldl + 1)];
+  }
+}
+// rows X(m x nb) <- X * U^{-1}  (U upper nb x nb, non-unit)
+static inline void trsm_right_upper(int m, int nb, const double *U, long ldu, double *X, long ldx, bool par)
+{
+#pragma omp parallel for if (par) schedule(static)
+  for (int i = 0; i < m; ++i) {
+    double *x = X + (long)i * ldx;
+    for (int j = 0; j < nb; ++j) {
+      double s = x[j];
+      for (int k = 0; k < j; ++k) s -= x[k] * U[(long)k * ldu + j];
+      x[j] = s / U[(long)j * ldu + j];
+    }
+  }
+}
+// in-place inverse of a small lower-triangular tile (unit: implicit ones, result also unit with ones NOT stored)
+static inline void trti2_lower(int nb, double *T, long ld, bool unit)
+{
+  for (int j = 0; j < nb; ++j) {
+    const double djj = unit ? 1.0 : 1.0 / T[(long)j * ld + j];
+    if (!unit) T[(long)j * ld + j] = djj;
+    // column j of the inverse below the diagonal: X(i,j) = -X(i,i) * sum_{k=j..i-1} L(i,k) X(k,j)
+    for (int i = j + 1; i < nb; ++i) {
+      double s = T[(long)i * ld + j] * djj;
+      for (int k = j + 1; k < i; ++k) s += T[(long)i * ld + k] * T[(long)k * ld + j];
+      // note: T(k,j) for j<k<i already holds X(k,j); T(i,k) for k>j is still L(i,k) because columns are done left to right
+      T[(long)i * ld + j] = -s * (unit ? 1.0 : 1.0 / T[(long)i * ld + i]);
+    }
+  }
+}
+
+} // namespace dense
+} // namespace hpddm_hip

@@ -1,0 +1,104 @@
+// Device-side objects of the RAS apply: resident factors, batched SpTRSV plans (sptrsv.hip) and the
+// multi-subdomain Schwarz operator (schwarz.hip).  gfx950 only.
+#pragma once
+#include "factor.hpp"
+#include <hip/hip_runtime.h>
+#include <memory>
+
+namespace hpddm_hip {
+
+#define HIP_OK(call)                                                                                              \
+  do {                                                                                                            \
+    hipError_t e_ = (call);                                                                                       \
+    if (e_ != hipSuccess) throw ::hpddm_hip::Error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + #call + " -> " + hipGetErrorString(e_)); \
+  } while (0)
+
+// RAII device buffer
+template <class T>
+struct DevBuf {
+  T     *p = nullptr;
+  size_t n = 0;
+  DevBuf() { }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count)
+  {
+    if (count == n && p) return;
+    release();
+    n = count;
+    if (count) HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void upload(const T *h, size_t count, hipStream_t s = nullptr)
+  {
+    alloc(count);
+    if (count) HIP_OK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &h, hipStream_t s = nullptr) { upload(h.data(), h.size(), s); }
+};
+
+// One supernode as the kernels see it (absolute device pointers; indices local to the subdomain).
+struct SnDesc {
+  const double *F;     // forward panel  (h x ldw, row-major)
+  const double *G;     // backward panel (== F unless LU)
+  const double *dinv;  // LDL^T: 1/D (permuted numbering) or nullptr
+  const int    *rows;  // nb sorted rows below the block (permuted numbering)
+  const int    *gptr;  // h+1 gather pointers into gsrc
+  const int    *gsrc;  // sources inside the subdomain's update pool
+  const int    *perm;  // perm[new] = old (whole subdomain)
+  long long     voff;  // offset (in vector elements, to be multiplied by mu) of the subdomain in batched multi-vectors
+  long long     uoff;  // same for the update pool
+  int           n;     // subdomain size (leading dimension of its multi-vectors)
+  int           usize; // subdomain update-pool size
+  int           c0, w, nb, ldw;
+  int           u_off; // offset of this supernode's update vector inside the subdomain pool
+  int           pad_;
+};
+
+struct Tile {
+  int sn; // index into the batch SnDesc array
+  int r0; // forward: first row of the tile; backward: first column
+  int nr; // rows (forward) / columns (backward) in the tile
+};
+
+// A factor resident in HBM.
+struct DeviceFactor {
+  idx_t    n = 0;
+  FactKind kind = FACT_CHOL;
+  idx_t    nblk = 0, nlev = 0;
+  int64_t  f_size = 0, u_size = 0, nnz_exact = 0, nnz_stored = 0;
+  DevBuf<double> F, G, dinv;
+  DevBuf<int>    rows, gptr, gsrc, perm;
+  // host copies of what the plan builder needs
+  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
+  std::vector<int64_t> f_off, row_ptr, goff;
+  void upload(const HostFactor &hf, hipStream_t s);
+};
+
+// Batched level-scheduled SpTRSV over a set of factors (all subdomains of one GPU advance level by level together).
+struct SolvePlan {
+  std::vector<const DeviceFactor *> factors;
+  std::vector<long long>            voff; // per factor: element offset in the batched vectors
+  long long                         ntot = 0, utot = 0;
+  int                               nlev = 0;
+  DevBuf<SnDesc> sn;
+  DevBuf<Tile>   ftiles, btiles;
+  std::vector<int> flev_ptr, blev_ptr; // per level tile ranges
+  // workspaces sized for mu_cap right-hand sides
+  int            mu_cap = 0;
+  DevBuf<double> y, xw, U;
+  double         bytes_alg_per_rhs1 = 0; // 2*nnz(L)*8 + 4*n*8 summed over the factors, mu = 1
+  void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
+  void reserve(int mu);
+  // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b
+  void solve(const double *b, double *x, int mu, hipStream_t s);
+  int  launches_per_solve = 0;
+};
+
+} // namespace hpddm_hip

@@ -1,0 +1,65 @@
+// Host-side representation of one subdomain's factorisation, as produced by numfact and consumed by the HIP SpTRSV.
+//
+// Replaces what MumpsSub/MklPardisoSub/SuiteSparseSub keep inside their third-party handles after
+// Solver<K>::numfact (reference: include/HPDDM_MUMPS.hpp:206-318, include/HPDDM_LAPACK.hpp:326-401).
+//
+// Layout ("level-scheduled, colour-packed block CSR"):
+//   * columns are permuted by nested dissection and grouped into supernodes J = [c0, c0+w),
+//   * supernode J owns one dense row-major panel  F_J  of h = w + nb rows and ldw >= w columns:
+//         rows 0..w-1   :  inv(L_JJ)                       (lower triangular, zeros above the diagonal)
+//         rows w..h-1   :  L_{below,J} * inv(L_JJ)         (one row per entry of rows(J), the sorted row list)
+//     so that the forward sweep is ONE dense row-parallel product per supernode,  t = F_J * f_top,
+//     and the backward sweep is its transpose,  x_J = F_J^T [ z_J ; -x_below ]  (G_J instead of F_J for LU),
+//   * supernodes are grouped by height in the assembly tree (= level); panels of a level are contiguous in the pool
+//     ("colour-packed") so a level is one contiguous HBM stream,
+//   * children -> parent contributions of the forward sweep go through per-supernode update vectors u_J (length nb)
+//     gathered by the parent (multifrontal solve): no atomics, bitwise reproducible.
+#pragma once
+#include "common.hpp"
+
+namespace hpddm_hip {
+
+enum FactKind { FACT_CHOL = 0, FACT_LDLT = 1, FACT_LU = 2 };
+
+struct HostFactor {
+  idx_t    n = 0;
+  FactKind kind = FACT_CHOL;
+  Ordering ord;
+  Symbolic sym;
+  // block order used for storage: blocks sorted by (height, index); pos_of[k] = position of block k in that order
+  std::vector<idx_t>   level_ptr;  // nlevels+1, into level_blk
+  std::vector<idx_t>   level_blk;  // blocks by ascending height
+  std::vector<idx_t>   ldw;        // nblk: padded panel width
+  std::vector<int64_t> f_off;      // nblk: offset of the panel in F (and G)
+  int64_t              f_size = 0; // doubles in F
+  std::vector<double>  F;          // forward panels
+  std::vector<double>  G;          // backward panels (LU only; empty otherwise: G == F)
+  std::vector<double>  dinv;       // LDLT only: 1/D in the permuted numbering
+  // multifrontal-solve gather lists: entry i (0..h-1) of supernode k sums U[gsrc[p]] for p in gptr[goff[k]+i .. goff[k]+i+1)
+  std::vector<int64_t> u_off;      // nblk: offset of u_k in the update pool (size sum nb)
+  int64_t              u_size = 0;
+  std::vector<int64_t> goff;       // nblk: offset into gptr
+  std::vector<int64_t> gptr;       // sum (h+1)
+  std::vector<int64_t> gsrc;       // sum nb
+  // optional: the plain supernodal L (and D / U) kept for export to a CPU substitution (oracle cpu_baseline)
+  bool                keep_plain = false;
+  std::vector<double> Lplain, Uplain; // same panel layout as F/G but holding L_JJ, L_below (U_JJ^T, U_{J,right}^T)
+  double              t_order = 0, t_symbolic = 0, t_numeric = 0;
+  int                 info = 0; // 0 ok, >0: zero/negative pivot in that (1-based) block
+};
+
+// CSR input as HPDDM hands it over (include/HPDDM_matrix.hpp:32-394): sym => only the lower triangle is stored.
+struct CsrView {
+  idx_t         n;
+  const idx_t  *ia, *ja;
+  const double *a;
+  bool          sym;
+  int           base; // 0 ('C') or 1 ('F')
+};
+
+// analysis (ordering + symbolic + layout); leaf_size <= 0 selects the default
+void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf);
+// numerical factorisation on the host (multifrontal, OpenMP); may be called again for a matrix with the same pattern
+void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf);
+
+} // namespace hpddm_hip

@@ -1,0 +1,106 @@
+// LocalSolver: numfact (host analysis + multifrontal factorisation, upload) and solve (HIP SpTRSV).
+// Reference: Solver<K>::numfact / solve / dtor (include/HPDDM_MUMPS.hpp:216-317).
+#include "local_solver.hpp"
+#include <chrono>
+#include <cmath>
+
+namespace hpddm_hip {
+
+hipStream_t library_stream()
+{
+  static hipStream_t s = nullptr;
+  if (!s) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+
+static size_t hash_pattern(const CsrView &A)
+{
+  // same role as MatrixCSR::hashIndices (include/HPDDM_matrix.hpp:90): detect a change of sparsity pattern
+  size_t      h   = 1469598103934665603ull;
+  auto        mix = [&](size_t v) { h = (h ^ v) * 1099511628211ull; };
+  const idx_t nnz = A.ia[A.n] - A.base;
+  mix((size_t)A.n);
+  mix((size_t)nnz);
+  mix((size_t)A.sym);
+  for (idx_t i = 0; i <= A.n; ++i) mix((size_t)(A.ia[i] - A.base));
+  for (idx_t p = 0; p < nnz; ++p) mix((size_t)(A.ja[p] - A.base));
+  return h;
+}
+
+// exact symmetry test of a matrix given in full storage (values and pattern)
+static bool is_symmetric(const CsrView &A)
+{
+  const idx_t n = A.n;
+  for (idx_t i = 0; i < n; ++i)
+    for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+      const idx_t j = A.ja[p] - A.base;
+      if (j == i) continue;
+      // find (j, i) by binary search if the row is sorted, linear otherwise
+      const idx_t *b = A.ja + (A.ia[j] - A.base), *e = A.ja + (A.ia[j + 1] - A.base);
+      const idx_t *it = std::lower_bound(b, e, i + A.base);
+      if (it == e || *it != i + A.base) {
+        it = std::find(b, e, i + A.base);
+        if (it == e) return false;
+      }
+      if (A.a[it - A.ja] != A.a[p]) return false;
+    }
+  return true;
+}
+
+// Panel pools are recycled between solvers: a fresh GiB-sized allocation costs more in page faults than the
+// factorisation of a mid-size subdomain.
+static std::vector<double> g_spare_panels;
+
+void LocalSolver::numfact(const CsrView &A, int spd)
+{
+  const size_t h = hash_pattern(A);
+  if (!analysed || h != pattern_hash) {
+    factor_analyse(A, leaf_size, host);
+    pattern_hash = h;
+    analysed     = true;
+  }
+  FactKind kind;
+  if (A.sym || is_symmetric(A)) kind = spd ? FACT_CHOL : FACT_LDLT;
+  else kind = FACT_LU;
+  if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
+  factor_numeric(A, kind, host);
+  if (host.info != 0 && kind == FACT_CHOL) {
+    // not positive definite after all: fall back to LDL^T like sym=2 in the reference (HPDDM_MUMPS.hpp:236)
+    factor_numeric(A, FACT_LDLT, host);
+  }
+  HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivoting in this solver)");
+  uploaded = false;
+  if (!host_only) {
+    const auto t0 = std::chrono::steady_clock::now();
+    dev.upload(host, library_stream());
+    plan.build({&dev}, library_stream());
+    uploaded = true;
+    t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (release_host) {
+      host.F.clear();
+      if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);
+      std::vector<double>().swap(host.F);
+      std::vector<double>().swap(host.G);
+    }
+  }
+}
+
+void LocalSolver::solve_device(const double *b, double *x, int mu)
+{
+  HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");
+  plan.solve(b, x, mu, library_stream());
+}
+
+void LocalSolver::solve_host(const double *b, double *x, int mu)
+{
+  HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");
+  const size_t cnt = (size_t)host.n * mu;
+  hipStream_t  s   = library_stream();
+  bdev.alloc(cnt);
+  HIP_OK(hipMemcpyAsync(bdev.p, b, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+  plan.solve(bdev.p, bdev.p, mu, s);
+  HIP_OK(hipMemcpyAsync(x, bdev.p, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+}
+
+} // namespace hpddm_hip

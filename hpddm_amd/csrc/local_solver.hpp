@@ -1,0 +1,26 @@
+// LocalSolver: the Solver<K> concept of the reference (include/HPDDM_MUMPS.hpp:206-318) on MI355X.
+#pragma once
+#include "device.hpp"
+#include <map>
+
+namespace hpddm_hip {
+
+hipStream_t library_stream();
+
+struct LocalSolver {
+  HostFactor   host;
+  DeviceFactor dev;
+  SolvePlan    plan;       // single-subdomain plan (used by the Solver-level API)
+  bool         analysed = false, uploaded = false;
+  size_t       pattern_hash = 0;
+  int          leaf_size = 32;
+  bool         host_only = false;
+  bool         release_host = false; // drop the host panels after upload (Schwarz operator does this)
+  double       t_upload = 0;
+  DevBuf<double> bdev, xdev;         // staging for the host-pointer API
+  void numfact(const CsrView &A, int spd);
+  void solve_host(const double *b, double *x, int mu);
+  void solve_device(const double *b, double *x, int mu);
+};
+
+} // namespace hpddm_hip

@@ -1,0 +1,517 @@
+// One-time factorisation of a local subdomain matrix on the host: analysis (nested dissection + block symbolic +
+// level-packed panel layout) and a multifrontal numerical factorisation (Cholesky / LDL^T / LU on a symmetric
+// pattern, no pivoting), finished by the "solve-ready" transformation of every panel:
+//      [ L_JJ ; L_below ]  ->  [ inv(L_JJ) ; L_below inv(L_JJ) ]
+// which turns both sweeps of the SpTRSV into dense, row-parallel panel products (see factor.hpp).
+//
+// Reference concept: Solver<K>::numfact (include/HPDDM_MUMPS.hpp:228-291: analysis+factorisation job=4, refactorise
+// job=2; sym=1 when -hpddm_operator_spd, sym=2 for symmetric indefinite, sym=0 otherwise), reached from
+// Schwarz::callNumfact (include/HPDDM_schwarz.hpp:337-368).
+#include "dense_host.hpp"
+#include "factor.hpp"
+#include <chrono>
+#include <cstring>
+#include <omp.h>
+
+namespace hpddm_hip {
+
+static double now()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static idx_t padded_width(idx_t w)
+{
+  if (w <= 128) {
+    idx_t p = 2;
+    while (p < w) p <<= 1;
+    return p;
+  }
+  return (w + 15) / 16 * 16;
+}
+
+void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf)
+{
+  const idx_t n = A.n;
+  hf.n          = n;
+  double t0     = now();
+  // ---- symmetric-pattern adjacency graph (A + A^T, no diagonal) ----
+  Graph g;
+  g.n = n;
+  {
+    std::vector<idx_t> deg(n, 0);
+    for (idx_t i = 0; i < n; ++i)
+      for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+        const idx_t j = A.ja[p] - A.base;
+        HH_CHECK(j >= 0 && j < n, "numfact: column index out of range");
+        if (j != i) {
+          ++deg[i];
+          ++deg[j];
+        }
+      }
+    std::vector<int64_t> ptr(n + 1, 0);
+    for (idx_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + deg[i];
+    std::vector<idx_t> adj((size_t)ptr[n]);
+    std::vector<int64_t> pos(ptr.begin(), ptr.end() - 1);
+    for (idx_t i = 0; i < n; ++i)
+      for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+        const idx_t j = A.ja[p] - A.base;
+        if (j != i) {
+          adj[pos[i]++] = j;
+          adj[pos[j]++] = i;
+        }
+      }
+    // sort + unique per vertex (a full CSR contributes every edge twice)
+    g.xadj.assign(n + 1, 0);
+    g.adjncy.reserve(adj.size() / (A.sym ? 1 : 2) + n);
+    for (idx_t i = 0; i < n; ++i) {
+      std::sort(adj.begin() + ptr[i], adj.begin() + ptr[i + 1]);
+      idx_t last = -1;
+      for (int64_t p = ptr[i]; p < ptr[i + 1]; ++p)
+        if (adj[p] != last) {
+          last = adj[p];
+          g.adjncy.push_back(last);
+        }
+      HH_CHECK(g.adjncy.size() < (size_t)2147483647, "numfact: graph too large for 32-bit indices");
+      g.xadj[i + 1] = (idx_t)g.adjncy.size();
+    }
+  }
+  nested_dissection(g, leaf_size > 0 ? leaf_size : 32, hf.ord);
+  hf.t_order = now() - t0;
+  t0         = now();
+  symbolic_factorization(g, hf.ord, hf.sym);
+  const Symbolic &s    = hf.sym;
+  const idx_t     nblk = s.nblk;
+  // ---- level (height) order and colour-packed panel layout ----
+  idx_t nlev = 0;
+  for (idx_t k = 0; k < nblk; ++k) nlev = std::max(nlev, s.height[k] + 1);
+  hf.level_ptr.assign(nlev + 1, 0);
+  for (idx_t k = 0; k < nblk; ++k) ++hf.level_ptr[s.height[k] + 1];
+  for (idx_t l = 0; l < nlev; ++l) hf.level_ptr[l + 1] += hf.level_ptr[l];
+  hf.level_blk.assign(nblk, 0);
+  {
+    std::vector<idx_t> pos(hf.level_ptr.begin(), hf.level_ptr.end() - 1);
+    for (idx_t k = 0; k < nblk; ++k) hf.level_blk[pos[s.height[k]]++] = k;
+  }
+  hf.ldw.assign(nblk, 0);
+  hf.f_off.assign(nblk, 0);
+  hf.u_off.assign(nblk, 0);
+  int64_t off = 0, uoff = 0;
+  for (idx_t q = 0; q < nblk; ++q) {
+    const idx_t k  = hf.level_blk[q];
+    const idx_t w  = s.blk_ptr[k + 1] - s.blk_ptr[k];
+    const idx_t nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+    hf.ldw[k]      = padded_width(w);
+    hf.f_off[k]    = off;
+    off += (int64_t)(w + nb) * hf.ldw[k];
+    off = (off + 15) / 16 * 16; // 128-byte aligned panels
+    hf.u_off[k] = uoff;
+    uoff += nb;
+  }
+  hf.f_size = off;
+  hf.u_size = uoff;
+  // ---- gather lists of the multifrontal forward sweep ----
+  hf.goff.assign(nblk, 0);
+  {
+    int64_t g0 = 0;
+    for (idx_t k = 0; k < nblk; ++k) {
+      hf.goff[k] = g0;
+      g0 += (s.blk_ptr[k + 1] - s.blk_ptr[k]) + (s.row_ptr[k + 1] - s.row_ptr[k]) + 1;
+    }
+    hf.gptr.assign(g0, 0);
+    hf.gsrc.assign(uoff, 0);
+    // local position of row r inside parent p: r - c0 if r < c1 else w + index in rows(p)
+    std::vector<idx_t> where(s.n, -1);
+    std::vector<std::vector<idx_t>> children(nblk);
+    for (idx_t k = 0; k < nblk; ++k)
+      if (s.parent[k] >= 0) children[s.parent[k]].push_back(k);
+    int64_t filled = 0;
+    for (idx_t p = 0; p < nblk; ++p) {
+      const idx_t c0 = s.blk_ptr[p], w = s.blk_ptr[p + 1] - c0;
+      const idx_t nb = (idx_t)(s.row_ptr[p + 1] - s.row_ptr[p]);
+      int64_t    *gp = hf.gptr.data() + hf.goff[p];
+      if (children[p].empty()) {
+        for (idx_t i = 0; i <= w + nb; ++i) gp[i] = filled;
+        continue;
+      }
+      for (idx_t i = 0; i < w; ++i) where[c0 + i] = i;
+      for (idx_t i = 0; i < nb; ++i) where[s.rows[s.row_ptr[p] + i]] = w + i;
+      std::vector<idx_t> cnt(w + nb + 1, 0);
+      for (idx_t ch : children[p])
+        for (int64_t q = s.row_ptr[ch]; q < s.row_ptr[ch + 1]; ++q) {
+          const idx_t li = where[s.rows[q]];
+          HH_CHECK(li >= 0, "symbolic: child row outside the parent front");
+          ++cnt[li + 1];
+        }
+      gp[0] = filled;
+      for (idx_t i = 0; i < w + nb; ++i) gp[i + 1] = gp[i] + cnt[i + 1];
+      std::vector<int64_t> pos(gp, gp + w + nb);
+      for (idx_t ch : children[p])
+        for (int64_t q = s.row_ptr[ch]; q < s.row_ptr[ch + 1]; ++q) {
+          const idx_t li        = where[s.rows[q]];
+          hf.gsrc[pos[li]++] = hf.u_off[ch] + (q - s.row_ptr[ch]);
+        }
+      filled = gp[w + nb];
+      for (idx_t i = 0; i < w; ++i) where[c0 + i] = -1;
+      for (idx_t i = 0; i < nb; ++i) where[s.rows[s.row_ptr[p] + i]] = -1;
+    }
+  }
+  hf.t_symbolic = now() - t0;
+}
+
+namespace {
+
+// Contribution blocks come and go by the thousand; going through malloc/free (mmap/munmap + page faults under the
+// process-wide mm lock) serialises the level-parallel phase.  Power-of-two size classes, reused until the end.
+struct BlockPool {
+  std::vector<std::vector<double *>> free_list = std::vector<std::vector<double *>>(48);
+  std::vector<double *>              all;
+  static int cls(size_t doubles)
+  {
+    int c = 9; // 512 doubles = 4 KiB minimum
+    while (((size_t)1 << c) < doubles) ++c;
+    return c;
+  }
+  double *get(size_t doubles)
+  {
+    const int c = cls(doubles);
+    double   *p = nullptr;
+#pragma omp critical(hpddm_hip_pool)
+    {
+      if (!free_list[c].empty()) {
+        p = free_list[c].back();
+        free_list[c].pop_back();
+      }
+    }
+    if (!p) {
+      p = (double *)malloc(((size_t)1 << c) * sizeof(double));
+      HH_CHECK(p != nullptr, "numfact: out of host memory for a contribution block");
+#pragma omp critical(hpddm_hip_pool)
+      all.push_back(p);
+    }
+    return p;
+  }
+  void put(double *p, size_t doubles)
+  {
+    const int c = cls(doubles);
+#pragma omp critical(hpddm_hip_pool)
+    free_list[c].push_back(p);
+  }
+  ~BlockPool()
+  {
+    for (double *p : all) free(p);
+  }
+};
+
+struct PermutedMatrix {
+  // entries of the permuted matrix with row >= col, grouped by column ("low"), and row < col grouped by row ("upp", LU only)
+  std::vector<int64_t> lptr, uptr;
+  std::vector<idx_t>   lrow, ucol;
+  std::vector<double>  lval, uval;
+};
+
+void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, PermutedMatrix &P)
+{
+  const idx_t n = A.n;
+  P.lptr.assign(n + 1, 0);
+  P.uptr.assign(n + 1, 0);
+  auto visit = [&](auto &&f) {
+    for (idx_t i = 0; i < n; ++i)
+      for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+        const idx_t j  = A.ja[p] - A.base;
+        const idx_t pi = ord.iperm[i], pj = ord.iperm[j];
+        if (A.sym) {
+          // stored entry stands for (i,j) and (j,i)
+          f(std::max(pi, pj), std::min(pi, pj), A.a[p]);
+          if (need_upper && pi != pj) f(std::min(pi, pj), std::max(pi, pj), A.a[p]);
+        } else if (pi >= pj || need_upper) f(pi, pj, A.a[p]);
+      }
+  };
+  visit([&](idx_t r, idx_t c, double) {
+    if (r >= c) ++P.lptr[c + 1];
+    else ++P.uptr[r + 1];
+  });
+  for (idx_t i = 0; i < n; ++i) {
+    P.lptr[i + 1] += P.lptr[i];
+    P.uptr[i + 1] += P.uptr[i];
+  }
+  P.lrow.resize(P.lptr[n]);
+  P.lval.resize(P.lptr[n]);
+  P.ucol.resize(P.uptr[n]);
+  P.uval.resize(P.uptr[n]);
+  std::vector<int64_t> lp(P.lptr.begin(), P.lptr.end() - 1), up(P.uptr.begin(), P.uptr.end() - 1);
+  visit([&](idx_t r, idx_t c, double v) {
+    if (r >= c) {
+      P.lrow[lp[c]]   = r;
+      P.lval[lp[c]++] = v;
+    } else {
+      P.ucol[up[r]]   = c;
+      P.uval[up[r]++] = v;
+    }
+  });
+}
+
+// in-place inverse of the lower-triangular w x w block T (row-major, ld), strictly-upper part must be zero
+void invert_lower(idx_t w, double *T, long ld, bool unit, bool par, std::vector<double> &tmp)
+{
+  const int NB = 64;
+  for (idx_t i0 = 0; i0 < w; i0 += NB) {
+    const idx_t ib = std::min<idx_t>(NB, w - i0);
+    double     *Ti = T + (long)i0 * ld;
+    if (i0 > 0) {
+      tmp.assign((size_t)ib * i0, 0.0);
+      dense::gemm(ib, i0, i0, 1.0, Ti, ld, T, ld, false, tmp.data(), i0, par);
+    }
+    dense::trti2_lower(ib, Ti + i0, ld, unit);
+    if (unit)
+      for (idx_t i = 0; i < ib; ++i) Ti[(long)i * ld + i0 + i] = 1.0;
+    if (i0 > 0) {
+      for (idx_t i = 0; i < ib; ++i) std::fill_n(Ti + (long)i * ld, i0, 0.0);
+      dense::gemm(ib, i0, ib, -1.0, Ti + i0, ld, tmp.data(), i0, false, Ti, ld, par);
+    }
+  }
+}
+
+// B(m x w) <- B * X, X lower-triangular w x w (row-major)
+void right_multiply_lower(idx_t m, idx_t w, double *B, long ldb, const double *X, long ldx, bool par)
+{
+  const idx_t RB = 128;
+  const idx_t nchunk = (m + RB - 1) / RB;
+#pragma omp parallel if (par)
+  {
+    static thread_local std::vector<double> tmp;
+    if (tmp.size() < (size_t)RB * w) tmp.resize((size_t)RB * w);
+#pragma omp for schedule(dynamic, 1)
+    for (idx_t c = 0; c < nchunk; ++c) {
+      const idx_t r0 = c * RB, rb = std::min(RB, m - r0);
+      std::fill(tmp.begin(), tmp.begin() + (size_t)rb * w, 0.0);
+      dense::gemm(rb, w, w, 1.0, B + (long)r0 * ldb, ldb, X, ldx, false, tmp.data(), w, false);
+      for (idx_t i = 0; i < rb; ++i) std::copy_n(tmp.data() + (size_t)i * w, w, B + (long)(r0 + i) * ldb);
+    }
+  }
+}
+
+} // namespace
+
+void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
+{
+  const double    t0   = now();
+  const Symbolic &s    = hf.sym;
+  const idx_t     nblk = s.nblk, n = s.n;
+  hf.kind              = kind;
+  hf.info              = 0;
+  const bool lu        = (kind == FACT_LU);
+  PermutedMatrix P;
+  build_permuted(A, hf.ord, lu, P);
+  hf.F.assign((size_t)hf.f_size, 0.0);
+  if (lu) hf.G.assign((size_t)hf.f_size, 0.0);
+  else std::vector<double>().swap(hf.G);
+  if (kind == FACT_LDLT) hf.dinv.assign(n, 0.0);
+  else std::vector<double>().swap(hf.dinv);
+  if (hf.keep_plain) {
+    hf.Lplain.assign((size_t)hf.f_size, 0.0);
+    if (lu) hf.Uplain.assign((size_t)hf.f_size, 0.0);
+  }
+  std::vector<double *> cb(nblk, nullptr);
+  static BlockPool      pool; // persistent across calls: later factorisations reuse already-faulted memory
+  std::vector<std::vector<idx_t>> children(nblk);
+  for (idx_t k = 0; k < nblk; ++k)
+    if (s.parent[k] >= 0) children[s.parent[k]].push_back(k);
+  // The GPU hosts expose hundreds of hardware threads; this factorisation stops scaling long before that, and
+  // oversubscribed barriers are very slow.  HPDDM_HIP_NUM_THREADS overrides the default cap of 32.
+  const int saved_threads = omp_get_max_threads();
+  int       cap           = 32;
+  if (const char *e = getenv("HPDDM_HIP_NUM_THREADS")) cap = std::max(1, atoi(e));
+  const int nthreads = std::max(1, std::min(saved_threads, cap));
+  omp_set_num_threads(nthreads);
+  std::vector<std::vector<idx_t>> relidx_t(nthreads);
+  int                             bad = 0;
+
+  const bool prof = getenv("HPDDM_HIP_PROFILE") != nullptr;
+  double     tph[5] = {0, 0, 0, 0, 0};
+  auto process = [&](idx_t k, bool par) {
+    double              tp0 = prof ? now() : 0.0;
+    auto                lap = [&](int ph) {
+      if (!prof) return;
+      const double t1 = now();
+#pragma omp atomic
+      tph[ph] += t1 - tp0;
+      tp0 = t1;
+    };
+    const int           tid = omp_get_thread_num();
+    std::vector<idx_t> &rel = relidx_t[par ? 0 : tid];
+    if ((idx_t)rel.size() != n) rel.assign(n, -1);
+    const idx_t  c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0;
+    const idx_t  nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+    const idx_t  h = w + nb, ld = hf.ldw[k];
+    const idx_t *rows = s.rows.data() + s.row_ptr[k];
+    double      *Pn   = hf.F.data() + hf.f_off[k];
+    double      *Gn   = lu ? hf.G.data() + hf.f_off[k] : nullptr;
+    double      *C    = nullptr; // contribution block nb x nb (lower for symmetric kinds, full for LU)
+    if (nb) {
+      C = pool.get((size_t)nb * nb);
+#pragma omp parallel for if (par) schedule(static)
+      for (idx_t i = 0; i < nb; ++i) std::memset(C + (size_t)i * nb, 0, (size_t)(lu ? nb : i + 1) * sizeof(double));
+    }
+    for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
+    for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
+    // ---- assemble the original entries ----
+    for (idx_t c = c0; c < c0 + w; ++c) {
+      for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) Pn[(long)rel[P.lrow[p]] * ld + (c - c0)] += P.lval[p];
+      if (lu)
+        for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) {
+          // entry (row c, col cc > c): inside the diagonal block it belongs to U11 (kept in the F top block, upper part)
+          const idx_t lc = rel[P.ucol[p]];
+          if (lc < w) Pn[(long)(c - c0) * ld + lc] += P.uval[p];
+          else Gn[(long)lc * ld + (c - c0)] += P.uval[p];
+        }
+    }
+    // ---- extend-add the children's contribution blocks ----
+    for (idx_t ch : children[k]) {
+      const idx_t  nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+      const idx_t *rc  = s.rows.data() + s.row_ptr[ch];
+      const double *Cc = cb[ch];
+#pragma omp parallel for if (par && nbc > 256) schedule(dynamic, 16)
+      for (idx_t i = 0; i < nbc; ++i) {
+        const idx_t   li = rel[rc[i]];
+        const double *ci = Cc + (size_t)i * nbc;
+        if (!lu) {
+          if (li < w) {
+            double *dst = Pn + (long)li * ld;
+            for (idx_t j = 0; j <= i; ++j) dst[rel[rc[j]]] += ci[j];
+          } else {
+            double *dst = C + (size_t)(li - w) * nb;
+            for (idx_t j = 0; j <= i; ++j) {
+              const idx_t lj = rel[rc[j]];
+              if (lj < w) Pn[(long)li * ld + lj] += ci[j];
+              else dst[lj - w] += ci[j];
+            }
+          }
+        } else {
+          for (idx_t j = 0; j < nbc; ++j) {
+            const idx_t lj = rel[rc[j]];
+            if (li < w) {
+              if (lj < w) Pn[(long)li * ld + lj] += ci[j];   // inside A11 (both triangles live in the F top block)
+              else Gn[(long)lj * ld + li] += ci[j];           // A12 -> stored transposed in G
+            } else if (lj < w) Pn[(long)li * ld + lj] += ci[j]; // A21
+            else C[(size_t)(li - w) * nb + (lj - w)] += ci[j];
+          }
+        }
+      }
+      pool.put(cb[ch], (size_t)nbc * nbc);
+      cb[ch] = nullptr;
+    }
+    for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
+    for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
+    lap(0);
+    // ---- partial factorisation of the front: columns 0..w-1 ----
+    const int           NB = 64;
+    std::vector<double> wt;
+    bool                ok = true;
+    for (idx_t kb = 0; kb < w && ok; kb += NB) {
+      const idx_t jb = std::min<idx_t>(NB, w - kb);
+      double     *Pk = Pn + (long)kb * ld;
+      if (kind == FACT_CHOL) {
+        dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, true, Pk + kb, ld, par);
+        ok = dense::potf2(jb, Pk + kb, ld);
+        if (ok) dense::trsm_right_lower_trans(h - kb - jb, jb, Pk + kb, ld, false, nullptr, Pk + (long)jb * ld + kb, ld, par);
+      } else if (kind == FACT_LDLT) {
+        // W = L(kb:kb+jb, 0:kb) * D(0:kb)
+        wt.assign((size_t)jb * std::max<idx_t>(kb, 1), 0.0);
+        for (idx_t i = 0; i < jb; ++i)
+          for (idx_t c = 0; c < kb; ++c) wt[(size_t)i * kb + c] = Pk[(long)i * ld + c] * Pn[(long)c * ld + c];
+        dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, wt.data(), kb, true, Pk + kb, ld, par);
+        ok = dense::ldlf2(jb, Pk + kb, ld);
+        if (ok) dense::trsm_right_lower_trans(h - kb - jb, jb, Pk + kb, ld, true, Pk + kb, Pk + (long)jb * ld + kb, ld, par);
+      } else {
+        // column block of [A11;A21]:  P(kb:h, kb:kb+jb) -= P(kb:h, 0:kb) * U(0:kb, kb:kb+jb)
+        dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, Pn + kb, ld, false, Pk + kb, ld, par);
+        // row block of U inside A11: U(kb:kb+jb, kb+jb:w) -= L(kb:kb+jb, 0:kb) * U(0:kb, kb+jb:w)
+        dense::gemm(jb, w - kb - jb, kb, -1.0, Pk, ld, Pn + kb + jb, ld, false, Pk + kb + jb, ld, par);
+        // row block of U12 (stored transposed in G):  G(w:h, kb:kb+jb) -= G(w:h, 0:kb) * L(kb:kb+jb, 0:kb)^T
+        dense::gemm(nb, jb, kb, -1.0, Gn + (long)w * ld, ld, Pk, ld, true, Gn + (long)w * ld + kb, ld, par);
+        ok = dense::getf2(jb, Pk + kb, ld);
+        if (ok) {
+          dense::trsm_right_upper(h - kb - jb, jb, Pk + kb, ld, Pk + (long)jb * ld + kb, ld, par);
+          // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)   (unit lower, row by row)
+          for (idx_t r = 1; r < jb; ++r)
+            for (idx_t q = 0; q < r; ++q) {
+              const double l = Pk[(long)r * ld + kb + q];
+              if (l != 0.0) {
+                double       *dst = Pk + (long)r * ld + kb + jb;
+                const double *src = Pk + (long)q * ld + kb + jb;
+                for (idx_t c = 0; c < w - kb - jb; ++c) dst[c] -= l * src[c];
+              }
+            }
+          dense::trsm_right_lower_trans(nb, jb, Pk + kb, ld, true, nullptr, Gn + (long)w * ld + kb, ld, par);
+        }
+      }
+    }
+    if (!ok) {
+#pragma omp critical
+      if (!bad) bad = k + 1;
+    }
+    lap(1);
+    // ---- Schur complement -> contribution block ----
+    if (nb && ok) {
+      double *P21 = Pn + (long)w * ld;
+      if (kind == FACT_CHOL) dense::gemm(nb, nb, w, -1.0, P21, ld, P21, ld, true, C, nb, par, true);
+      else if (kind == FACT_LDLT) {
+        wt.assign((size_t)nb * w, 0.0);
+        for (idx_t i = 0; i < nb; ++i)
+          for (idx_t c = 0; c < w; ++c) wt[(size_t)i * w + c] = P21[(long)i * ld + c] * Pn[(long)c * ld + c];
+        dense::gemm(nb, nb, w, -1.0, P21, ld, wt.data(), w, true, C, nb, par, true);
+      } else dense::gemm(nb, nb, w, -1.0, P21, ld, Gn + (long)w * ld, ld, true, C, nb, par);
+    }
+    cb[k] = C;
+    lap(2);
+    if (!ok) return;
+    // ---- split U11 out of the F top block (LU), record D (LDLT), keep the plain factor if asked ----
+    if (lu) {
+      for (idx_t i = 0; i < w; ++i)
+        for (idx_t j = i; j < w; ++j) {
+          Gn[(long)j * ld + i] = Pn[(long)i * ld + j]; // G top = U11^T (lower, non-unit)
+          if (j > i) Pn[(long)i * ld + j] = 0.0;
+        }
+      for (idx_t i = 0; i < w; ++i) Pn[(long)i * ld + i] = 1.0; // L11 unit diagonal made explicit
+    } else {
+      for (idx_t i = 0; i < w; ++i)
+        for (idx_t j = i + 1; j < w; ++j) Pn[(long)i * ld + j] = 0.0;
+      if (kind == FACT_LDLT)
+        for (idx_t i = 0; i < w; ++i) {
+          hf.dinv[c0 + i]       = 1.0 / Pn[(long)i * ld + i];
+          Pn[(long)i * ld + i] = 1.0;
+        }
+    }
+    if (hf.keep_plain) {
+      std::copy_n(Pn, (size_t)h * ld, hf.Lplain.data() + hf.f_off[k]);
+      if (lu) std::copy_n(Gn, (size_t)h * ld, hf.Uplain.data() + hf.f_off[k]);
+    }
+    // ---- solve-ready panels: top <- inverse, bottom <- bottom * inverse ----
+    std::vector<double> tmp;
+    invert_lower(w, Pn, ld, false, par, tmp); // unit diagonals are stored explicitly as 1.0, so the general path is exact
+    right_multiply_lower(nb, w, Pn + (long)w * ld, ld, Pn, ld, par);
+    if (lu) {
+      invert_lower(w, Gn, ld, false, par, tmp);
+      right_multiply_lower(nb, w, Gn + (long)w * ld, ld, Gn, ld, par);
+    }
+    lap(3);
+  };
+
+  const idx_t nlev = (idx_t)hf.level_ptr.size() - 1;
+  for (idx_t l = 0; l < nlev; ++l) {
+    const idx_t b0 = hf.level_ptr[l], b1 = hf.level_ptr[l + 1];
+    const double tl0 = now();
+    if (b1 - b0 >= std::max(2, nthreads - 1)) {
+#pragma omp parallel for schedule(dynamic, 1)
+      for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], false);
+    } else
+      for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
+    if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
+  }
+  omp_set_num_threads(saved_threads);
+  hf.info      = bad;
+  hf.t_numeric = now() - t0;
+}
+
+} // namespace hpddm_hip

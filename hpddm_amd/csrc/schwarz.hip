@@ -1,0 +1,623 @@
+// Device-resident RAS operator: partition-of-unity scaling + halo sum, GMV, one- and two-level apply.
+// Reference: Schwarz::{exchange, GMV, apply, deflation, multiplicityScaling, callNumfact, computeResidual}
+// (include/HPDDM_schwarz.hpp:180-188, 726-747, 527-612, 1602-1622, 381-404, 337-368, 761-803),
+// Subdomain::exchange (include/HPDDM_subdomain.hpp:115-130), Wrapper::diag/csrmm (include/HPDDM_wrapper.hpp:820-831, 697-733).
+//
+// All subdomains of the GPU live in one batched multi-vector ([sub][mu][n_sub]); every operation is ONE launch over
+// (subdomain, dof) with the right-hand sides looped inside, so the 8 subdomains of a config fill the 256 CUs together.
+// The halo sum of co-located subdomains is a gather (no message, no atomics): dof i of subdomain s reads the D-scaled
+// values of its duplicates in the neighbours through a CSR list built once from Subdomain::map_.
+#include "schwarz.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace hpddm_hip {
+
+
+// ------------------------------------------------------------------ kernels ------------------------------------
+// grid: (ceil(nmax/256), nsub); every thread owns dof i of subdomain s for all right-hand sides
+__global__ void k_exchange(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const int *__restrict__ ex_ptr, const int *__restrict__ ex_sub, const int *__restrict__ ex_idx, const double *__restrict__ in, double *__restrict__ out, int mu, int scale)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double di = scale ? d[v0 + i] : 1.0;
+    const int    p0 = ex_ptr[v0 + i], p1 = ex_ptr[v0 + i + 1];
+    for (int nu = 0; nu < mu; ++nu) {
+      double acc = di * in[v0 * mu + (long long)nu * n + i];
+      for (int p = p0; p < p1; ++p) {
+        const int       t = ex_sub[p], j = ex_idx[p];
+        const long long vt = voff[t];
+        acc += (scale ? d[vt + j] : 1.0) * in[vt * mu + (long long)nu * nn[t] + j];
+      }
+      out[v0 * mu + (long long)nu * n + i] = acc;
+    }
+  }
+}
+
+__global__ void k_diag(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const double *__restrict__ in, double *__restrict__ out, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double di = d[v0 + i];
+    for (int nu = 0; nu < mu; ++nu) out[v0 * mu + (long long)nu * n + i] = di * in[v0 * mu + (long long)nu * n + i];
+  }
+}
+
+// y = beta*y + alpha*A*x ; 8 lanes per row (7-point / 27-point stencil rows), rows of all subdomains in one launch
+__global__ void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0  = voff[s];
+  const int      *ias = ia + iaoff[s];
+  const int       lane = threadIdx.x & 7;
+  for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < n; r += (gridDim.x * blockDim.x) >> 3) {
+    const int p0 = ias[r], p1 = ias[r + 1];
+    for (int nu = 0; nu < mu; ++nu) {
+      const double *xs  = x + v0 * mu + (long long)nu * n;
+      double        acc = 0.0;
+      for (int p = p0 + lane; p < p1; p += 8) acc = fma(a[p], xs[ja[p]], acc);
+      acc += __shfl_xor(acc, 4);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 1);
+      if (lane == 0) {
+        double *yp = y + v0 * mu + (long long)nu * n + r;
+        *yp        = (beta == 0.0 ? 0.0 : beta * *yp) + alpha * acc;
+      }
+    }
+  }
+}
+
+__global__ void k_axpy(long long cnt, double alpha, const double *__restrict__ x, double *__restrict__ y)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) y[i] = fma(alpha, x[i], y[i]);
+}
+
+// D-weighted inner products against k basis blocks: out[(kk*mu + nu)] = sum_s sum_i d V_kk[s][nu][i] w[s][nu][i]
+// grid: (blocks, k*mu); partial sums per block go to `partial`, a second tiny kernel adds them in a fixed order
+__global__ void k_wdots(const long long *__restrict__ voff, const int *__restrict__ nn, int nsub, const double *__restrict__ d, const double *__restrict__ V, long long ldv, const double *__restrict__ w, int mu, double *__restrict__ partial)
+{
+  const int kk = blockIdx.y / mu, nu = blockIdx.y % mu;
+  double    acc = 0.0;
+  for (int s = 0; s < nsub; ++s) {
+    const int       n  = nn[s];
+    const long long v0 = voff[s];
+    const double   *vp = V + (long long)kk * ldv + v0 * mu + (long long)nu * n;
+    const double   *wp = w + v0 * mu + (long long)nu * n;
+    const double   *dp = d ? d + v0 : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc = fma((dp ? dp[i] : 1.0) * vp[i], wp[i], acc);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(long long)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void k_sum_partials(const double *__restrict__ partial, int nblk, double *__restrict__ out)
+{
+  // one thread per output: fixed summation order => reproducible
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  double    s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(long long)o * nblk + b];
+  out[o] = s;
+}
+
+// ---- deflation panel (first version: wave reductions; the MFMA version lives in deflation_mfma.hip) ----
+// uc[coff[s] + k][nu] = sum_i Z_s[i,k] * d_s[i] * in[s][nu][i] ; grid: (nu_max, nsub), one workgroup per (k, s)
+__global__ void k_zt(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ uc, int mu, int cdim)
+{
+  const int s = blockIdx.y, k = blockIdx.x;
+  if (k >= nus[s]) return;
+  const int       n  = nn[s];
+  const long long v0 = voff[s];
+  const double   *zk = Z + zoff[s] + (long long)k * n;
+  __shared__ double red[256];
+  for (int nu = 0; nu < mu; ++nu) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = fma(zk[i] * d[v0 + i], in[v0 * mu + (long long)nu * n + i], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) uc[(long long)nu * cdim + coff[s] + k] = red[0];
+    __syncthreads();
+  }
+}
+// y = Einv * x for mu columns (cdim x cdim row-major Einv), one workgroup per column block
+__global__ void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int mu)
+{
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < cdim * mu; o += gridDim.x * blockDim.x) {
+    const int     nu = o / cdim, r = o - nu * cdim;
+    const double *er = Einv + (long long)r * cdim;
+    const double *xc = x + (long long)nu * cdim;
+    double        acc = 0.0;
+    for (int c = 0; c < cdim; ++c) acc = fma(er[c], xc[c], acc);
+    y[o] = acc;
+  }
+}
+// out[s][nu][i] = sum_k Z_s[i,k] uc[coff[s]+k][nu]
+__global__ void k_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ uc, double *__restrict__ out, int mu, int cdim)
+{
+  const int s = blockIdx.y, n = nn[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int nu = 0; nu < mu; ++nu) {
+      double acc = 0.0;
+      for (int k = 0; k < nu_s; ++k) acc = fma(Z[zoff[s] + (long long)k * n + i], uc[(long long)nu * cdim + coff[s] + k], acc);
+      out[v0 * mu + (long long)nu * n + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ host side ----------------------------------
+Schwarz::Schwarz(int nsub_, int first_, int nglobal_) : nsub(nsub_), first(first_), nglobal(nglobal_), subs(nsub_)
+{
+  HH_CHECK(nsub_ >= 1 && first_ >= 0 && first_ + nsub_ <= nglobal_, "SchwarzCreate: bad subdomain range");
+  for (auto &s : subs) s.ls.reset(new LocalSolver());
+}
+
+void Schwarz::set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn)
+{
+  HH_CHECK(s >= 0 && s < nsub, "SetSubdomain: bad local index");
+  SchwarzSub &S = subs[s];
+  S.n           = n;
+  const int nnz = ia[n] - base;
+  S.ia0.assign(ia, ia + n + 1);
+  S.ja0.assign(ja, ja + nnz);
+  S.a0.assign(a, a + nnz);
+  S.sym0  = sym;
+  S.base0 = base;
+  // full 0-based CSR
+  if (!sym) {
+    S.ia.resize(n + 1);
+    for (int i = 0; i <= n; ++i) S.ia[i] = ia[i] - base;
+    S.ja.resize(nnz);
+    for (int p = 0; p < nnz; ++p) S.ja[p] = ja[p] - base;
+    S.a = S.a0;
+  } else {
+    std::vector<int> cnt(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+      for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
+        const int j = ja[p] - base;
+        ++cnt[i + 1];
+        if (j != i) ++cnt[j + 1];
+      }
+    S.ia.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) S.ia[i + 1] = S.ia[i] + cnt[i + 1];
+    S.ja.resize(S.ia[n]);
+    S.a.resize(S.ia[n]);
+    std::vector<int> pos(S.ia.begin(), S.ia.end() - 1);
+    // row-major order of the full matrix: first pass lower entries of row i, then transposes land in increasing row order
+    for (int i = 0; i < n; ++i)
+      for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
+        const int j  = ja[p] - base;
+        S.ja[pos[i]] = j;
+        S.a[pos[i]++] = a[p];
+        if (j != i) {
+          S.ja[pos[j]]  = i;
+          S.a[pos[j]++] = a[p];
+        }
+      }
+  }
+  // Subdomain::initialize (include/HPDDM_subdomain.hpp:238-259): neighbours sorted by number, empty lists dropped
+  std::vector<int> idx(nneigh);
+  for (int k = 0; k < nneigh; ++k) idx[k] = k;
+  std::stable_sort(idx.begin(), idx.end(), [&](int l, int r) { return list[l] < list[r]; });
+  S.map.clear();
+  for (int k : idx)
+    if (sizes[k] > 0) {
+      HH_CHECK(list[k] >= 0 && list[k] < nglobal, "SetSubdomain: neighbour out of range");
+      S.map.emplace_back(list[k], std::vector<int>(conn[k], conn[k] + sizes[k]));
+      for (int v : S.map.back().second) HH_CHECK(v >= 0 && v < n, "SetSubdomain: connectivity index out of range");
+    }
+  S.d.assign(n, 1.0);
+  device_ready = factored = coarse_ready = false;
+}
+
+static const std::vector<int> &peer_list(const Schwarz &A, int t_local, int gid_s)
+{
+  for (const auto &pr : A.subs[t_local].map)
+    if (pr.first == gid_s) return pr.second;
+  throw Error("neighbour lists are not symmetric: subdomain " + std::to_string(A.first + t_local) + " does not list " + std::to_string(gid_s));
+}
+
+void Schwarz::multiplicity_scaling(double *const *dd)
+{
+  // Schwarz::multiplicityScaling (include/HPDDM_schwarz.hpp:381-404): the sends carry the caller's weights
+  std::vector<std::vector<double>> w(nsub);
+  for (int s = 0; s < nsub; ++s) w[s].assign(dd[s], dd[s] + subs[s].n);
+  for (int s = 0; s < nsub; ++s) {
+    SchwarzSub &S = subs[s];
+    double     *d = dd[s];
+    std::fill_n(d, S.n, 1.0);
+    for (const auto &pr : S.map) {
+      const int t = pr.first - first;
+      HH_CHECK(t >= 0 && t < nsub, "MultiplicityScaling needs every neighbour on this GPU (pass the final d to Initialize for multi-GPU runs)");
+      const std::vector<int> &mine = pr.second, &theirs = peer_list(*this, t, first + s);
+      HH_CHECK(mine.size() == theirs.size(), "neighbour lists of different lengths");
+      for (size_t j = 0; j < mine.size(); ++j) {
+        const double send = w[s][mine[j]], recv = w[t][theirs[j]];
+        if (std::abs(send) < HPDDM_EPS) d[mine[j]] = 0.0;
+        else d[mine[j]] /= 1.0 + d[mine[j]] * recv / send;
+      }
+    }
+  }
+}
+
+void Schwarz::initialize(int s, const double *d)
+{
+  HH_CHECK(s >= 0 && s < nsub, "Initialize: bad local index");
+  subs[s].d.assign(d, d + subs[s].n);
+  device_ready = false;
+}
+
+void Schwarz::set_vectors(int s, int nu, const double *Z)
+{
+  HH_CHECK(s >= 0 && s < nsub && nu >= 0, "SetVectors: bad argument");
+  subs[s].nu = nu;
+  subs[s].Z.assign(Z, Z + (size_t)nu * subs[s].n);
+  coarse_ready = false;
+}
+
+void Schwarz::build_device()
+{
+  if (device_ready) return;
+  hipStream_t st = library_stream();
+  voff.assign(nsub + 1, 0);
+  nmax = 0;
+  std::vector<int> nn(nsub);
+  for (int s = 0; s < nsub; ++s) {
+    nn[s]       = subs[s].n;
+    voff[s + 1] = voff[s] + subs[s].n;
+    nmax        = std::max(nmax, subs[s].n);
+  }
+  ntot = voff[nsub];
+  HH_CHECK(ntot < 2147483647LL, "more than 2^31 dofs on one GPU");
+  voff_d.upload(voff.data(), nsub + 1, st);
+  n_d.upload(nn, st);
+  std::vector<double>    dcat((size_t)ntot);
+  std::vector<int>       iacat, jacat;
+  std::vector<double>    acat;
+  std::vector<long long> iaoff(nsub);
+  for (int s = 0; s < nsub; ++s) {
+    std::copy(subs[s].d.begin(), subs[s].d.end(), dcat.begin() + voff[s]);
+    iaoff[s]          = (long long)iacat.size();
+    const int shift   = (int)jacat.size();
+    HH_CHECK((long long)jacat.size() + subs[s].ia[subs[s].n] < 2147483647LL, "more than 2^31 matrix entries on one GPU");
+    for (int i = 0; i <= subs[s].n; ++i) iacat.push_back(subs[s].ia[i] + shift);
+    jacat.insert(jacat.end(), subs[s].ja.begin(), subs[s].ja.end());
+    acat.insert(acat.end(), subs[s].a.begin(), subs[s].a.end());
+  }
+  nnzA = (long long)acat.size();
+  d_d.upload(dcat, st);
+  ia_d.upload(iacat, st);
+  ja_d.upload(jacat, st);
+  a_d.upload(acat, st);
+  iaoff_d.upload(iaoff, st);
+  // halo gather lists
+  std::vector<int> cnt((size_t)ntot + 1, 0);
+  for (int s = 0; s < nsub; ++s)
+    for (const auto &pr : subs[s].map) {
+      const int t = pr.first - first;
+      HH_CHECK(t >= 0 && t < nsub, "this build keeps all neighbours of a subdomain on one GPU (multi-GPU halo: see DESIGN.md)");
+      HH_CHECK(pr.second.size() == peer_list(*this, t, first + s).size(), "neighbour lists of different lengths");
+      for (int i : pr.second) ++cnt[voff[s] + i + 1];
+    }
+  for (long long i = 0; i < ntot; ++i) cnt[i + 1] += cnt[i];
+  std::vector<int> esub(cnt[ntot]), eidx(cnt[ntot]);
+  {
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int s = 0; s < nsub; ++s)
+      for (const auto &pr : subs[s].map) {
+        const int               t      = pr.first - first;
+        const std::vector<int> &theirs = peer_list(*this, t, first + s);
+        for (size_t j = 0; j < pr.second.size(); ++j) {
+          const long long g = voff[s] + pr.second[j];
+          esub[pos[g]]      = t;
+          eidx[pos[g]++]    = theirs[j];
+        }
+      }
+  }
+  ex_ptr.upload(cnt, st);
+  ex_sub.upload(esub, st);
+  ex_idx.upload(eidx, st);
+  HIP_OK(hipStreamSynchronize(st));
+  device_ready = true;
+}
+
+void Schwarz::reserve(int mu)
+{
+  if (mu <= mu_cap) return;
+  const size_t cnt = (size_t)ntot * mu;
+  w1.alloc(cnt);
+  w2.alloc(cnt);
+  w3.alloc(cnt);
+  hin.alloc(cnt);
+  hout.alloc(cnt);
+  if (cdim) {
+    uc_d.alloc((size_t)cdim * mu);
+    uc2_d.alloc((size_t)cdim * mu);
+  }
+  mu_cap = mu;
+}
+
+void Schwarz::call_numfact()
+{
+  // Schwarz::callNumfact (include/HPDDM_schwarz.hpp:337-368)
+  build_device();
+  const int m = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS);
+  switch (m) {
+  case SCHWARZ_METHOD_SORAS: type = PRC_SY; break; // no optimized matrix A supplied => SY, as in the reference
+  case SCHWARZ_METHOD_ASM: type = PRC_SY; break;
+  case SCHWARZ_METHOD_NONE:
+    type     = PRC_NO;
+    factored = true;
+    return;
+  default: type = PRC_GE;
+  }
+  const int reuse = (int)getopt("reuse_preconditioner", 0);
+  if (reuse <= 1 || !factored) {
+    const int spd = (int)getopt("operator_spd", 0);
+    std::vector<const DeviceFactor *> fs;
+    for (int s = 0; s < nsub; ++s) {
+      SchwarzSub &S          = subs[s];
+      S.ls->leaf_size        = (int)getopt("leaf_size", 32);
+      S.ls->release_host     = getopt("keep_host_factor", 0) == 0;
+      S.ls->host.keep_plain  = getopt("keep_plain", 0) != 0;
+      CsrView A{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
+      S.ls->numfact(A, spd);
+      fs.push_back(&S.ls->dev);
+    }
+    plan.build(fs, library_stream());
+  }
+  if (reuse >= 1) opt["reuse_preconditioner"] = reuse + 1;
+  factored = true;
+}
+
+// dense LU with partial pivoting -> explicit inverse (coarse dimension is at most a few hundred)
+static void invert_dense(int n, std::vector<double> &A, std::vector<double> &Ainv)
+{
+  Ainv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Ainv[(size_t)i * n + i] = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::abs(A[(size_t)r * n + c]) > std::abs(A[(size_t)piv * n + c])) piv = r;
+    HH_CHECK(A[(size_t)piv * n + c] != 0.0, "coarse operator is singular");
+    if (piv != c)
+      for (int k = 0; k < n; ++k) {
+        std::swap(A[(size_t)piv * n + k], A[(size_t)c * n + k]);
+        std::swap(Ainv[(size_t)piv * n + k], Ainv[(size_t)c * n + k]);
+      }
+    const double inv = 1.0 / A[(size_t)c * n + c];
+    for (int k = 0; k < n; ++k) {
+      A[(size_t)c * n + k] *= inv;
+      Ainv[(size_t)c * n + k] *= inv;
+    }
+    for (int r = 0; r < n; ++r)
+      if (r != c) {
+        const double f = A[(size_t)r * n + c];
+        if (f != 0.0)
+          for (int k = 0; k < n; ++k) {
+            A[(size_t)r * n + k] -= f * A[(size_t)c * n + k];
+            Ainv[(size_t)r * n + k] -= f * Ainv[(size_t)c * n + k];
+          }
+      }
+  }
+}
+
+void Schwarz::build_coarse()
+{
+  // Preconditioner::buildTwo with MatrixMultiplication (include/HPDDM_preconditioner.hpp:124-257,
+  // include/HPDDM_operator.hpp:378-562):  E = W^T A W,  W_j = R_j^T D_j Z_j,  A W_j = R_j^T (A_j D_j Z_j).
+  build_device();
+  coff.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
+  cdim = coff[nsub];
+  HH_CHECK(cdim > 0, "BuildCoarseOperator: no deflation vector was set");
+  // T_s = A_s (D_s Z_s), DZ_s = D_s Z_s
+  std::vector<std::vector<double>> T(nsub), DZ(nsub);
+  for (int s = 0; s < nsub; ++s) {
+    const SchwarzSub &S = subs[s];
+    DZ[s].assign((size_t)S.n * S.nu, 0.0);
+    T[s].assign((size_t)S.n * S.nu, 0.0);
+    for (int k = 0; k < S.nu; ++k) {
+      double *dz = DZ[s].data() + (size_t)k * S.n, *t = T[s].data() + (size_t)k * S.n;
+      for (int i = 0; i < S.n; ++i) dz[i] = S.d[i] * S.Z[(size_t)k * S.n + i];
+      for (int i = 0; i < S.n; ++i) {
+        double acc = 0.0;
+        for (int p = S.ia[i]; p < S.ia[i + 1]; ++p) acc += S.a[p] * dz[S.ja[p]];
+        t[i] = acc;
+      }
+    }
+  }
+  E.assign((size_t)cdim * cdim, 0.0);
+  for (int i = 0; i < nsub; ++i) {
+    const SchwarzSub &Si = subs[i];
+    // diagonal block: Z_i^T D_i T_i  (the reference scales the local product by D, include/HPDDM_operator.hpp:524, and
+    // the neighbours' rows by D in applyFromNeighbor, :398-404)
+    for (int ki = 0; ki < Si.nu; ++ki)
+      for (int kj = 0; kj < Si.nu; ++kj) {
+        double acc = 0.0;
+        for (int r = 0; r < Si.n; ++r) acc += DZ[i][(size_t)ki * Si.n + r] * T[i][(size_t)kj * Si.n + r];
+        E[(size_t)(coff[i] + ki) * cdim + coff[i] + kj] = acc;
+      }
+    for (const auto &pr : Si.map) {
+      const int               j      = pr.first - first;
+      const SchwarzSub       &Sj     = subs[j];
+      const std::vector<int> &mine   = pr.second;
+      const std::vector<int> &theirs = peer_list(*this, j, first + i);
+      for (int ki = 0; ki < Si.nu; ++ki)
+        for (int kj = 0; kj < Sj.nu; ++kj) {
+          double acc = 0.0;
+          for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * T[j][(size_t)kj * Sj.n + theirs[q]];
+          E[(size_t)(coff[i] + ki) * cdim + coff[j] + kj] = acc;
+        }
+    }
+  }
+  // symCoarse == 'S' (real scalars, examples/schwarz.hpp:75-79): the reference assembles only the upper triangle of E
+  // (row block of rank i towards neighbours j >= i) and its coarse solver mirrors it.  Same here unless
+  // -hpddm_hip_general_co is set ('G', what GENERAL_CO selects in the reference).
+  if (getopt("hip_general_co", 0) == 0)
+    for (int r = 0; r < cdim; ++r)
+      for (int c = 0; c < r; ++c) E[(size_t)r * cdim + c] = E[(size_t)c * cdim + r];
+  std::vector<double> Ecopy(E);
+  invert_dense(cdim, Ecopy, Einv);
+  hipStream_t st = library_stream();
+  std::vector<double>    zcat;
+  std::vector<long long> zoff(nsub);
+  std::vector<int>       nus(nsub);
+  for (int s = 0; s < nsub; ++s) {
+    zoff[s] = (long long)zcat.size();
+    nus[s]  = subs[s].nu;
+    zcat.insert(zcat.end(), subs[s].Z.begin(), subs[s].Z.end());
+  }
+  Z_d.upload(zcat, st);
+  zoff_d.upload(zoff, st);
+  nu_d.upload(nus, st);
+  coff_d.upload(coff.data(), nsub, st);
+  Einv_d.upload(Einv, st);
+  HIP_OK(hipStreamSynchronize(st));
+  mu_cap       = 0; // uc buffers depend on cdim
+  coarse_ready = true;
+}
+
+static inline dim3 grid2(int nmax, int nsub) { return dim3((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub); }
+
+void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
+{
+  HH_CHECK(in != out, "exchange: out-of-place only");
+  hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+}
+void Schwarz::exchange_inplace(double *x, int mu, bool scale)
+{
+  reserve(mu);
+  HIP_OK(hipMemcpyAsync(w3.p, x, (size_t)ntot * mu * sizeof(double), hipMemcpyDeviceToDevice, library_stream()));
+  exchange(w3.p, x, mu, scale);
+}
+void Schwarz::diag(const double *in, double *out, int mu)
+{
+  hipLaunchKernelGGL(k_diag, grid2(nmax, nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, d_d.p, in, out, mu);
+}
+void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta)
+{
+  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 8 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta);
+}
+void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
+{
+  hipLaunchKernelGGL(k_axpy, dim3((unsigned)std::min<long long>(2048, (cnt + 255) / 256)), dim3(256), 0, library_stream(), cnt, alpha, x, y);
+}
+void Schwarz::gmv(const double *in, double *out, int mu)
+{
+  // Schwarz::GMV (include/HPDDM_schwarz.hpp:740-744): out = exchange(A in)
+  reserve(mu);
+  csrmm(in, w3.p, mu, 1.0, 0.0);
+  exchange(w3.p, out, mu, true);
+}
+void Schwarz::local_solve(const double *in, double *out, int mu)
+{
+  HH_CHECK(factored && type != PRC_NO, "local solve before CallNumfact");
+  plan.solve(in, out, mu, library_stream());
+}
+void Schwarz::deflation(const double *in, double *out, int mu)
+{
+  // Schwarz::deflation (include/HPDDM_schwarz.hpp:1602-1622): out = exchange(Z E^{-1} Z^T D in)
+  HH_CHECK(coarse_ready, "deflation before BuildCoarseOperator");
+  reserve(mu);
+  hipStream_t st = library_stream();
+  int numax = 0;
+  for (const auto &S : subs) numax = std::max(numax, S.nu);
+  hipLaunchKernelGGL(k_zt, dim3((unsigned)numax, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, in, uc_d.p, mu, cdim);
+  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, st, Einv_d.p, uc_d.p, uc2_d.p, cdim, mu);
+  hipLaunchKernelGGL(k_z, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, w3.p, mu, cdim);
+  exchange(w3.p, out, mu, true);
+}
+
+void Schwarz::apply(const double *in, double *out, int mu)
+{
+  // Schwarz::apply (include/HPDDM_schwarz.hpp:527-612)
+  HH_CHECK(factored, "apply before CallNumfact");
+  reserve(mu);
+  hipStream_t  st  = library_stream();
+  const size_t cnt = (size_t)ntot * mu;
+  const int    correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  if (!coarse_ready || correction == COARSE_CORRECTION_NONE) {
+    if (type == PRC_NO) HIP_OK(hipMemcpyAsync(out, in, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+    else if (type == PRC_GE || type == PRC_OG) {
+      plan.solve(in, w1.p, mu, st);
+      exchange(w1.p, out, mu, true); // out = sum R^T D A^{-1} in
+    } else {
+      if (type == PRC_OS) {
+        diag(in, w1.p, mu);
+        plan.solve(w1.p, w1.p, mu, st);
+        diag(w1.p, w1.p, mu);
+      } else plan.solve(in, w1.p, mu, st);
+      exchange(w1.p, out, mu, false); // Subdomain::exchange: no scaling (ASM)
+    }
+    return;
+  }
+  HH_CHECK(type != PRC_NO, "two-level apply needs a local solver");
+  if (correction == COARSE_CORRECTION_ADDITIVE) {
+    deflation(in, out, mu);                 // :565
+    plan.solve(in, w1.p, mu, st);           // :567
+    axpy(1.0, w1.p, out, (long long)cnt);   // :568
+    exchange_inplace(out, mu, true);        // :569
+    return;
+  }
+  deflation(in, out, mu);                                                       // :573
+  HIP_OK(hipMemcpyAsync(w1.p, in, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+  csrmm(out, w1.p, mu, -1.0, 1.0);                                              // :581-586  work = in - A out
+  exchange(w1.p, w2.p, mu, true);                                               // :588
+  if (type == PRC_OS) diag(w2.p, w2.p, mu);                                     // :589
+  plan.solve(w2.p, w2.p, mu, st);                                               // :590
+  exchange(w2.p, w1.p, mu, true);                                               // :591   work now in w1
+  if (correction == COARSE_CORRECTION_BALANCED) {
+    gmv(w1.p, w2.p, mu);                                                        // :596  (uses w3)
+    DevBuf<double> tmp;
+    tmp.alloc(cnt);
+    deflation(w2.p, tmp.p, mu);                                                 // :601
+    axpy(-1.0, tmp.p, w1.p, (long long)cnt);                                    // :602
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  axpy(1.0, w1.p, out, (long long)cnt);                                         // :607
+}
+
+void Schwarz::wdots(const double *V, long long ldv, int k, const double *w, int mu, double *out_host)
+{
+  static DevBuf<double> partial, outd;
+  const int nb = 128;
+  partial.alloc((size_t)nb * 4096);
+  outd.alloc(4096);
+  HH_CHECK(k * mu <= 4096, "too many simultaneous inner products");
+  hipStream_t st = library_stream();
+  hipLaunchKernelGGL(k_wdots, dim3(nb, (unsigned)(k * mu)), dim3(256), 0, st, voff_d.p, n_d.p, nsub, d_d.p, V, ldv, w, mu, partial.p);
+  hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((k * mu + 63) / 64)), dim3(64), 0, st, partial.p, nb, outd.p);
+  HIP_OK(hipMemcpyAsync(out_host, outd.p, sizeof(double) * k * mu, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+}
+
+void Schwarz::compute_residual(const double *x, const double *f, double *storage, int mu)
+{
+  // Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: storage[2nu] = ||f||_D, storage[2nu+1] = ||A x - f||_D
+  // (penalised boundary rows of the reference's HPDDM_PEN convention do not occur with the generators of this path and are
+  //  treated as ordinary rows)
+  reserve(mu);
+  const size_t cnt = (size_t)ntot * mu;
+  gmv(x, w1.p, mu);
+  axpy(-1.0, f, w1.p, (long long)cnt);
+  std::vector<double> r(mu), b(mu);
+  wdots(w1.p, 0, 1, w1.p, mu, r.data());
+  wdots(f, 0, 1, f, mu, b.data());
+  for (int nu = 0; nu < mu; ++nu) {
+    storage[2 * nu]     = std::sqrt(b[nu]);
+    storage[2 * nu + 1] = std::sqrt(r[nu]);
+  }
+}
+
+} // namespace hpddm_hip

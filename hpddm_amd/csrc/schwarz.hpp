@@ -1,0 +1,99 @@
+// The multi-subdomain Schwarz operator resident on one MI355X: HPDDM::Schwarz<Solver, CoarseSolver, S, K>
+// (include/HPDDM_schwarz.hpp) + Preconditioner (include/HPDDM_preconditioner.hpp) + Subdomain
+// (include/HPDDM_subdomain.hpp) for ALL subdomains mapped to this GPU.
+#pragma once
+#include "local_solver.hpp"
+#include <map>
+#include <memory>
+#include <string>
+
+namespace hpddm_hip {
+
+static constexpr double HPDDM_EPS = 1.0e-12; // include/HPDDM_define.hpp
+static constexpr double HPDDM_PEN = 1.0e+30;
+
+// enumerations of the reference (include/HPDDM_define.hpp:46-199)
+enum { SCHWARZ_METHOD_RAS = 0, SCHWARZ_METHOD_ORAS = 1, SCHWARZ_METHOD_SORAS = 2, SCHWARZ_METHOD_ASM = 3, SCHWARZ_METHOD_OSM = 4, SCHWARZ_METHOD_NONE = 5 };
+enum { COARSE_CORRECTION_NONE = -1, COARSE_CORRECTION_DEFLATED = 0, COARSE_CORRECTION_ADDITIVE = 1, COARSE_CORRECTION_BALANCED = 2 };
+enum { VARIANT_LEFT = 0, VARIANT_RIGHT = 1, VARIANT_FLEXIBLE = 2 };
+enum { ORTHO_CGS = 0, ORTHO_MGS = 1 };
+enum PrcndtnrType { PRC_NO = 0, PRC_SY = 1, PRC_GE = 2, PRC_OS = 3, PRC_OG = 4 }; // Prcndtnr of include/HPDDM_schwarz.hpp:100-110
+
+struct SchwarzSub {
+  int n = 0;
+  // the matrix as handed over (kept for numfact) ...
+  std::vector<int>    ia0, ja0;
+  std::vector<double> a0;
+  bool                sym0 = false;
+  int                 base0 = 0;
+  // ... and expanded to full 0-based CSR (GMV, coarse operator, residual)
+  std::vector<int>    ia, ja;
+  std::vector<double> a;
+  std::vector<std::pair<int, std::vector<int>>> map; // Subdomain::map_: (global neighbour, shared dofs), sorted by neighbour
+  std::vector<double> d;                             // Schwarz::d_
+  std::vector<double> Z;                             // Preconditioner::ev_: n x nu column-major
+  int                 nu = 0;
+  std::unique_ptr<LocalSolver> ls;
+};
+
+struct Schwarz {
+  int nsub, first, nglobal;
+  std::vector<SchwarzSub>       subs;
+  std::map<std::string, double> opt;
+  PrcndtnrType                  type = PRC_GE;
+  bool                          device_ready = false, factored = false, coarse_ready = false;
+  // ---- device-resident batched data ----
+  long long              ntot = 0;
+  std::vector<long long> voff; // nsub+1
+  int                    nmax = 0;
+  DevBuf<long long>      voff_d;
+  DevBuf<int>            n_d;
+  DevBuf<double>         d_d;                 // concatenated partition of unity
+  DevBuf<int>            ia_d, ja_d;          // concatenated CSR: ia_d holds nsub blocks of (n_s+1) entries, offsets into the shared ja/a pools
+  DevBuf<long long>      iaoff_d;             // per subdomain offset into ia_d
+  DevBuf<double>         a_d;
+  long long              nnzA = 0;
+  DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
+  SolvePlan              plan;
+  // coarse level
+  int                 cdim = 0;
+  std::vector<int>    coff; // nsub+1
+  DevBuf<int>         coff_d, nu_d;
+  DevBuf<long long>   zoff_d;
+  DevBuf<double>      Z_d, Einv_d, uc_d, uc2_d;
+  std::vector<double> E, Einv;
+  // work vectors
+  int            mu_cap = 0;
+  DevBuf<double> w1, w2, w3, hin, hout;
+
+  Schwarz(int nsub_, int first_, int nglobal_);
+  double getopt(const std::string &k, double def) const
+  {
+    auto it = opt.find(k);
+    return it == opt.end() ? def : it->second;
+  }
+  void set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
+  void multiplicity_scaling(double *const *d);
+  void initialize(int s, const double *d);
+  void set_vectors(int s, int nu, const double *Z);
+  void build_device();           // uploads matrices, d, halo lists (lazy)
+  void call_numfact();
+  void build_coarse();
+  void reserve(int mu);
+  // device-pointer operations on the library stream (batched layout, see hpddm_hip.h)
+  void exchange(const double *in, double *out, int mu, bool scale); // out = halo_sum((scale ? D : I) in), out != in
+  void exchange_inplace(double *x, int mu, bool scale);
+  void csrmm(const double *x, double *y, int mu, double alpha, double beta); // y = beta*y + alpha*A*x
+  void gmv(const double *in, double *out, int mu);
+  void local_solve(const double *in, double *out, int mu);
+  void deflation(const double *in, double *out, int mu);
+  void apply(const double *in, double *out, int mu);
+  void diag(const double *in, double *out, int mu);
+  void axpy(double alpha, const double *x, double *y, long long cnt);
+  void compute_residual(const double *x, const double *f, double *storage, int mu);
+  int  gmres(const double *b, double *x, int mu, double *history, int history_cap);
+  // D-weighted reductions used by GMRES and computeResidual: out[k*mu+nu] = sum_s sum_i d_s[i] V_k[s][nu][i] w[s][nu][i]
+  void wdots(const double *V, long long ldv, int k, const double *w, int mu, double *out_host);
+};
+
+} // namespace hpddm_hip

@@ -1,0 +1,249 @@
+"""Problem generators for the RAS path (host logic, numpy only).
+
+* :func:`generate2d` restates the reference generator ``examples/generate.cpp:43-311`` (same as ``generate.c`` /
+  ``generate.py``): 2-D Poisson on [0,10]^2, cell-centred 5-point stencil, box partition with ``overlap`` layers,
+  neighbour lists, shared-dof lists, partition-of-unity ramp and the analytic right-hand side -- including the
+  reference's quirk that the vertical stencil offset is ``k +- Nx/xGrid`` (generate.cpp:202,219,233), which only
+  equals the local row width when the subdomain does not own an overlap layer.
+* :func:`generate3d` is the 3-D extension used by configs 2-3 of BASELINE.json (7-point Laplacian on N^3 cells of the
+  unit cube, px x py x pz boxes grown by ``overlap`` layers, product-of-ramps partition of unity), for which the
+  reference has no generator.
+
+Every function returns one dict per subdomain with the arguments of ``HpddmSchwarzCreate`` (interface/HPDDM.h:101):
+``n, ia, ja, a, sym, neighbors, connectivity, d`` (weights BEFORE multiplicityScaling), ``f`` and ``box``.
+"""
+import math
+
+import numpy as np
+
+PI = 3.141592653589793238463
+
+
+def _rhs2d(xs, ys):
+    """analytic right-hand side of examples/generate.cpp:71-86"""
+    xsc, ysc, rsc, asc = (6.5, 2.0, 7.0), (8.0, 7.0, 3.0), (0.3, 0.3, 0.4), (0.3, 0.2, -0.1)
+    frs = np.ones((len(ys), len(xs)))
+    X, Y = np.meshgrid(xs, ys)
+    for n in range(3):
+        xd, yd = X - xsc[n], Y - ysc[n]
+        inside = np.sqrt(xd * xd + yd * yd) <= rsc[n]
+        frs = np.where(inside, frs - asc[n] * np.cos(0.5 * PI * xd / rsc[n]) * np.cos(0.5 * PI * yd / rsc[n]), frs)
+    return frs.reshape(-1)
+
+
+def generate2d(Nx, Ny, size, overlap=1, sym=False, numbering="C"):
+    """All ``size`` subdomains of the reference's 2-D example (one per MPI rank there)."""
+    F = 1 if numbering == "F" else 0
+    xGrid = int(math.sqrt(size))
+    while size % xGrid != 0:
+        xGrid -= 1
+    yGrid = size // xGrid
+    dx, dy = 10.0 / Nx, 10.0 / Ny
+    subs = []
+    for rank in range(size):
+        y, x = divmod(rank, xGrid)
+        iStart, iEnd = max(x * Nx // xGrid - overlap, 0), min((x + 1) * Nx // xGrid + overlap, Nx)
+        jStart, jEnd = max(y * Ny // yGrid - overlap, 0), min((y + 1) * Ny // yGrid + overlap, Ny)
+        w, h = iEnd - iStart, jEnd - jStart
+        ndof = w * h
+        f = _rhs2d(dx * (np.arange(iStart, iEnd) + 0.5), dy * (np.arange(jStart, jEnd) + 0.5))
+        d = np.ones(ndof)
+        o, mapping = [], []
+        ov = float(overlap)
+        if jStart != 0:
+            if iStart != 0:
+                o.append(rank - xGrid - 1)
+                mapping.append([i - iStart + w * j for j in range(2 * overlap) for i in range(iStart, iStart + 2 * overlap)])
+                for j in range(overlap):
+                    for i in range(overlap - j):
+                        d[i + j + j * w] = j / ov
+                    for i in range(j):
+                        d[i + j * w] = i / ov
+            else:
+                for j in range(overlap):
+                    for i in range(overlap):
+                        d[i + j * w] = j / ov
+            o.append(rank - xGrid)
+            mapping.append([i - iStart + w * j for j in range(2 * overlap) for i in range(iStart, iEnd)])
+            for j in range(overlap):
+                for i in range(iStart + overlap, iEnd - overlap):
+                    d[i - iStart + w * j] = j / ov
+            if iEnd != Nx:
+                o.append(rank - xGrid + 1)
+                mapping.append([w * (i + 1) - 2 * overlap + j for i in range(2 * overlap) for j in range(2 * overlap)])
+                for j in range(overlap):
+                    for i in range(overlap - j):
+                        d[w * (j + 1) - overlap + i] = j / ov
+                    for i in range(j):
+                        d[w * (j + 1) - i - 1] = i / ov
+            else:
+                for j in range(overlap):
+                    for i in range(overlap):
+                        d[w * (j + 1) - overlap + i] = j / ov
+        if iStart != 0:
+            o.append(rank - 1)
+            mapping.append([j + (i - jStart) * w for i in range(jStart, jEnd) for j in range(2 * overlap)])
+            for i in range(jStart + (jStart != 0) * overlap, jEnd - (jEnd != Ny) * overlap):
+                for j in range(overlap):
+                    d[j + (i - jStart) * w] = j / ov
+        if iEnd != Nx:
+            o.append(rank + 1)
+            mapping.append([w * (i + 1 - jStart) - 2 * overlap + j for i in range(jStart, jEnd) for j in range(2 * overlap)])
+            for i in range(jStart + (jStart != 0) * overlap, jEnd - (jEnd != Ny) * overlap):
+                for j in range(overlap):
+                    d[w * (i + 1 - jStart) - j - 1] = j / ov
+        if jEnd != Ny:
+            base = ndof - overlap * w
+            if iStart != 0:
+                o.append(rank + xGrid - 1)
+                mapping.append([ndof - 2 * overlap * w + i - iStart + w * j for j in range(2 * overlap) for i in range(iStart, iStart + 2 * overlap)])
+                for j in range(overlap):
+                    for i in range(overlap - j):
+                        d[base + i + w * j] = i / ov
+                    for i in range(overlap - j, overlap):
+                        d[base + i + w * j] = (overlap - 1 - j) / ov
+            else:
+                for j in range(overlap):
+                    for i in range(overlap):
+                        d[base + w * j + i] = (overlap - j - 1) / ov
+            o.append(rank + xGrid)
+            mapping.append([ndof - 2 * overlap * w + i - iStart + w * j for j in range(2 * overlap) for i in range(iStart, iEnd)])
+            for j in range(overlap):
+                for i in range(iStart + overlap, iEnd - overlap):
+                    d[base + i - iStart + w * j] = (overlap - 1 - j) / ov
+            if iEnd != Nx:
+                o.append(rank + xGrid + 1)
+                mapping.append([ndof - 2 * overlap * w + i - iStart + w * j + (w - 2 * overlap) for j in range(2 * overlap) for i in range(iStart, iStart + 2 * overlap)])
+                for j in range(overlap):
+                    for i in range(j, overlap):
+                        d[base + i + w * (j + 1) - overlap] = (overlap - 1 - i) / ov
+                    for i in range(j):
+                        d[base + i + w * (j + 1) - overlap] = (overlap - 1 - j) / ov
+            else:
+                for j in range(overlap):
+                    for i in range(overlap):
+                        d[base + i + w * (j + 1) - overlap] = (overlap - j - 1) / ov
+        # ---- matrix (examples/generate.cpp:188-241): note the +-Nx/xGrid vertical offset of the reference ----
+        voff = Nx // xGrid
+        ia, ja, a = [F], [], []
+        k = 0
+        for j in range(jStart, jEnd):
+            for i in range(iStart, iEnd):
+                if j > jStart:
+                    a.append(-1 / (dy * dy)); ja.append(k - voff + F)
+                if i > iStart:
+                    a.append(-1 / (dx * dx)); ja.append(k - 1 + F)
+                a.append(2 / (dx * dx) + 2 / (dy * dy)); ja.append(k + F)
+                if not sym:
+                    if i < iEnd - 1:
+                        a.append(-1 / (dx * dx)); ja.append(k + 1 + F)
+                    if j < jEnd - 1:
+                        a.append(-1 / (dy * dy)); ja.append(k + voff + F)
+                k += 1
+                ia.append(len(a) + F)
+        subs.append(dict(n=ndof, ia=np.array(ia, dtype=np.int32), ja=np.array(ja, dtype=np.int32), a=np.array(a), sym=bool(sym),
+                         numbering=numbering, neighbors=np.array(o, dtype=np.int32), connectivity=[np.array(m, dtype=np.int32) for m in mapping],
+                         d=d, f=f, box=(iStart, iEnd, jStart, jEnd)))
+    return subs
+
+
+def _factor3(p):
+    """px*py*pz = p as cubic as possible"""
+    best = None
+    for a in range(1, p + 1):
+        if p % a:
+            continue
+        for b in range(1, p // a + 1):
+            if (p // a) % b:
+                continue
+            c = p // a // b
+            key = max(a, b, c) - min(a, b, c)
+            if best is None or key < best[0]:
+                best = (key, (a, b, c))
+    return best[1]
+
+
+def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None):
+    """7-point Laplacian on N^3 cells of the unit cube (h = 1/N, homogeneous Dirichlet through the stencil, like the
+    2-D reference problem), split into ``parts`` boxes grown by ``overlap`` layers.  Returns the subdomains
+    ``first .. first+count-1`` (default: all).  ``d`` is the product of the 1-D ramps of the reference generator
+    (0, 1/overlap, ..., on the layers owned by a neighbour) -- multiplicityScaling turns it into a partition of unity.
+    ``sym`` selects HPDDM's symmetric storage (lower triangle, diagonal last in row)."""
+    F = 1 if numbering == "F" else 0
+    px, py, pz = grid if grid is not None else _factor3(parts)
+    assert px * py * pz == parts
+    dims, P = (N, N, N) if np.isscalar(N) else tuple(N), (px, py, pz)
+    h2 = [float(dims[a]) ** 2 for a in range(3)]  # 1/h^2 per direction on the unit cube
+    count = parts - first if count is None else count
+
+    def coords(r):
+        z, rem = divmod(r, px * py)
+        y, x = divmod(rem, px)
+        return (x, y, z)
+
+    boxes = {}
+    for r in range(parts):
+        c = coords(r)
+        boxes[r] = [(max(c[a] * dims[a] // P[a] - overlap, 0), min((c[a] + 1) * dims[a] // P[a] + overlap, dims[a])) for a in range(3)]
+    subs = []
+    for r in range(first, first + count):
+        c = coords(r)
+        (i0, i1), (j0, j1), (k0, k1) = boxes[r]
+        nx, ny, nz = i1 - i0, j1 - j0, k1 - k0
+        n = nx * ny * nz
+        idx = np.arange(n, dtype=np.int64).reshape(nz, ny, nx)
+        # ---- matrix ----
+        rows, cols, vals = [], [], []
+        diag = 2.0 * (h2[0] + h2[1] + h2[2])
+        rows.append(idx.ravel()); cols.append(idx.ravel()); vals.append(np.full(n, diag))
+        for axis, hh in ((2, h2[0]), (1, h2[1]), (0, h2[2])):
+            lo = np.take(idx, np.arange(0, idx.shape[axis] - 1), axis=axis).ravel()
+            hi = np.take(idx, np.arange(1, idx.shape[axis]), axis=axis).ravel()
+            rows.append(hi); cols.append(lo); vals.append(np.full(lo.size, -hh))      # lower triangle
+            if not sym:
+                rows.append(lo); cols.append(hi); vals.append(np.full(lo.size, -hh))
+        rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+        order = np.lexsort((cols, rows))  # row-major, ascending columns => symmetric storage has the diagonal last in row
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        ia = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ia, rows + 1, 1)
+        ia = np.cumsum(ia)
+        # ---- partition-of-unity weights: product of the 1-D ramps ----
+        ramps = []
+        for a, (s, e) in enumerate(boxes[r]):
+            t = np.ones(e - s)
+            if overlap > 0:
+                if s != 0:  # a neighbour owns the first layers: 0, 1/ov, ...
+                    t[:overlap] = np.arange(overlap) / float(overlap)
+                if e != dims[a]:
+                    t[-overlap:] = np.arange(overlap)[::-1] / float(overlap)
+            ramps.append(t)
+        d = (ramps[2][:, None, None] * ramps[1][None, :, None] * ramps[0][None, None, :]).reshape(-1)
+        # ---- neighbours and shared dofs (intersection of the grown boxes, lexicographic order on both sides) ----
+        neigh, conn = [], []
+        for dz in (-1, 0, 1):
+            for dy_ in (-1, 0, 1):
+                for dx_ in (-1, 0, 1):
+                    if dx_ == dy_ == dz == 0:
+                        continue
+                    cx, cy, cz = c[0] + dx_, c[1] + dy_, c[2] + dz
+                    if not (0 <= cx < px and 0 <= cy < py and 0 <= cz < pz):
+                        continue
+                    q = cx + px * (cy + py * cz)
+                    inter = [(max(boxes[r][a][0], boxes[q][a][0]), min(boxes[r][a][1], boxes[q][a][1])) for a in range(3)]
+                    if any(lo >= hi for lo, hi in inter):
+                        continue
+                    sl = idx[inter[2][0] - k0:inter[2][1] - k0, inter[1][0] - j0:inter[1][1] - j0, inter[0][0] - i0:inter[0][1] - i0]
+                    neigh.append(q)
+                    conn.append(sl.reshape(-1).astype(np.int32))
+        if rhs == "ones":
+            f = np.ones(n)
+        else:  # smooth analytic right-hand side
+            X = (np.arange(i0, i1) + 0.5) / dims[0]
+            Y = (np.arange(j0, j1) + 0.5) / dims[1]
+            Z = (np.arange(k0, k1) + 0.5) / dims[2]
+            f = (1.0 + np.sin(PI * Z)[:, None, None] * np.sin(2 * PI * Y)[None, :, None] * np.cos(PI * X)[None, None, :]).reshape(-1)
+        subs.append(dict(n=n, ia=(ia + F).astype(np.int32), ja=(cols + F).astype(np.int32), a=vals.astype(np.float64), sym=bool(sym),
+                         numbering=numbering, neighbors=np.array(neigh, dtype=np.int32), connectivity=conn, d=d, f=f,
+                         box=(i0, i1, j0, j1, k0, k1)))
+    return subs

@@ -1,0 +1,306 @@
+"""Python host side of the MI355X RAS path, mirroring the reference's own ctypes binding ``interface/hpddm.py``
+(names ``subdomainNumfact``/``subdomainSolve``/``schwarzCreate``/... , hpddm.py:175-275) on top of the C ABI of
+``include/hpddm_hip.h``.  numpy arrays are host memory; device-resident variants take raw device pointers
+(e.g. ``torch.Tensor.data_ptr()``).
+
+Difference with the reference that the hardware imposes: ONE process drives ALL subdomains of a GPU, so a
+:class:`Schwarz` object is created for ``nsub`` subdomains and multi-vectors are lists of per-subdomain arrays
+(each ``(n_s,)`` or ``(n_s, mu)`` Fortran-ordered, exactly what one MPI rank of the reference holds).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import HpddmHipError, check
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as_f(a, dtype=np.float64):
+    return np.asfortranarray(a, dtype=dtype)
+
+
+def device_count():
+    return _lib.load().HpddmHipDeviceCount()
+
+
+def require_device():
+    """The product has no CPU path: fail loudly when no MI355X is visible."""
+    if device_count() < 1:
+        raise HpddmHipError("no HIP device visible: libhpddm_hip.so needs an MI355X (there is no CPU fallback)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Subdomain:
+    """Local solver: ``SUBDOMAIN<K>`` of the reference (Solver concept, include/HPDDM_MUMPS.hpp:206-318)."""
+
+    def __init__(self, **options):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self._owned = True
+        for k, v in options.items():
+            check(self._lib.HpddmHipSubdomainSetOption(ctypes.byref(self._h), k.encode(), float(v)))
+        self.n = 0
+
+    @classmethod
+    def _borrow(cls, handle):
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p(handle)
+        self._owned = False
+        self.n = int(self.info()["n"])
+        return self
+
+    def numfact(self, n, ia, ja, a, sym=False, numbering="C", spd=False):
+        """subdomainNumfact (interface/hpddm.py:185, HpddmSubdomainNumfact interface/HPDDM.h:88)."""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ja = np.ascontiguousarray(ja, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        check(self._lib.HpddmHipSubdomainNumfact(ctypes.byref(self._h), int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)),
+                                                 numbering.encode(), int(bool(spd))))
+        self.n = int(n)
+
+    def solve(self, f, sol=None):
+        """subdomainSolve (interface/hpddm.py:191): sol = A^{-1} f; f is (n,) or (n, mu) Fortran-ordered."""
+        f = _as_f(f)
+        mu = 1 if f.ndim == 1 else f.shape[1]
+        if sol is None:
+            sol = np.empty_like(f, order="F")
+        assert sol.flags.f_contiguous and sol.shape == f.shape
+        check(self._lib.HpddmHipSubdomainSolve(self._h, _dptr(f), _dptr(sol), mu))
+        return sol
+
+    def solve_device(self, b_ptr, x_ptr, mu=1):
+        check(self._lib.HpddmHipSubdomainSolveDevice(self._h, ctypes.c_void_p(b_ptr), ctypes.c_void_p(x_ptr), mu))
+
+    def info(self):
+        info = np.zeros(12, dtype=np.int64)
+        times = np.zeros(4)
+        check(self._lib.HpddmHipSubdomainInfo(self._h, _dptr(info), _dptr(times)))
+        keys = ("n", "supernodes", "levels", "nnz_L", "stored", "pool", "update_pool", "kind", "launches", "flops")
+        out = {k: int(v) for k, v in zip(keys, info)}
+        out.update(t_order=times[0], t_symbolic=times[1], t_numeric=times[2], t_upload=times[3])
+        return out
+
+    def export(self, which):
+        ints = which not in ("F", "G", "dinv", "Lplain", "Uplain")
+        cnt = self._lib.HpddmHipSubdomainExport(self._h, which.encode(), None, 0)
+        if cnt < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        out = np.zeros(cnt, dtype=np.int64 if ints else np.float64)
+        if cnt:
+            check(self._lib.HpddmHipSubdomainExport(self._h, which.encode(), _dptr(out), cnt))
+        return out
+
+    def time_solve(self, mu=1, warmup=2, reps=10):
+        sec = ctypes.c_double()
+        check(self._lib.HpddmHipSubdomainTimeSolve(self._h, mu, warmup, reps, ctypes.byref(sec)))
+        return sec.value
+
+    def destroy(self):
+        if self._owned and self._h:
+            self._lib.HpddmHipSubdomainDestroy(self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# reference-style free functions (interface/hpddm.py:183-199)
+def subdomainNumfact(S, n, ia, ja, a, sym=False, numbering="C", spd=False):
+    if S is None:
+        S = Subdomain()
+    S.numfact(n, ia, ja, a, sym, numbering, spd)
+    return S
+
+
+def subdomainSolve(S, f, sol):
+    S.solve(f, sol)
+
+
+def subdomainDestroy(S):
+    S.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Schwarz:
+    """``HPDDM::Schwarz`` for all the subdomains of one GPU (HpddmSchwarz* of interface/HPDDM.h:101-112)."""
+
+    def __init__(self, nsub, first_global=0, nglobal=None):
+        self._lib = _lib.load()
+        nglobal = first_global + nsub if nglobal is None else nglobal
+        self._h = self._lib.HpddmHipSchwarzCreate(nsub, first_global, nglobal)
+        if not self._h:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        self.nsub, self.first, self.nglobal = nsub, first_global, nglobal
+        self.n = [0] * nsub
+
+    # -- construction, same order as examples/schwarz.cpp:90-126 --
+    def set_subdomain(self, s, n, ia, ja, a, sym, neighbors, connectivity, numbering="C"):
+        """schwarzCreate(Mat, o, connectivity) (interface/hpddm.py:216) for local subdomain s."""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ja = np.ascontiguousarray(ja, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        neighbors = np.ascontiguousarray(neighbors, dtype=np.int32)
+        conn = [np.ascontiguousarray(c, dtype=np.int32) for c in connectivity]
+        sizes = np.array([c.size for c in conn], dtype=np.int32)
+        ptrs = (ctypes.c_void_p * max(1, len(conn)))(*[c.ctypes.data for c in conn])
+        check(self._lib.HpddmHipSchwarzSetSubdomain(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode(),
+                                                    len(conn), _dptr(neighbors), _dptr(sizes), ctypes.cast(ptrs, ctypes.c_void_p)))
+        self.n[s] = int(n)
+
+    def multiplicity_scaling(self, d):
+        """schwarzMultiplicityScaling: d is a list of per-subdomain weight arrays, overwritten by the partition of unity."""
+        d = [np.ascontiguousarray(x, dtype=np.float64) for x in d]
+        ptrs = (ctypes.c_void_p * self.nsub)(*[x.ctypes.data for x in d])
+        check(self._lib.HpddmHipSchwarzMultiplicityScaling(self._h, ctypes.cast(ptrs, ctypes.c_void_p)))
+        return d
+
+    def initialize(self, d):
+        """schwarzInitialize for every subdomain."""
+        for s, x in enumerate(d):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            check(self._lib.HpddmHipSchwarzInitialize(self._h, s, _dptr(x)))
+
+    def set_vectors(self, s, Z):
+        """setVectors + initializeCoarseOperator (interface/hpddm.py:203-208): Z is (n_s, nu)."""
+        Z = _as_f(Z)
+        Z = Z.reshape(Z.shape[0], -1, order="F")
+        check(self._lib.HpddmHipSchwarzSetVectors(self._h, s, Z.shape[1], _dptr(Z)))
+
+    def build_coarse_operator(self):
+        check(self._lib.HpddmHipSchwarzBuildCoarseOperator(self._h))
+
+    def call_numfact(self):
+        check(self._lib.HpddmHipSchwarzCallNumfact(self._h))
+
+    def option_parse(self, args):
+        """optionParse (interface/hpddm.py:124): '-hpddm_key value' strings with the reference's names."""
+        check(self._lib.HpddmHipSchwarzOptionParse(self._h, args.encode()))
+
+    def set_option(self, key, value):
+        check(self._lib.HpddmHipSchwarzSetOption(self._h, key.encode(), float(value)))
+
+    def get_option(self, key):
+        return self._lib.HpddmHipSchwarzGetOption(self._h, key.encode())
+
+    # -- batched layout helpers --
+    def pack(self, xs):
+        """list of per-subdomain (n_s,) / (n_s, mu) arrays -> one flat array in the library's batched layout."""
+        xs = [_as_f(x) for x in xs]
+        mu = 1 if xs[0].ndim == 1 else xs[0].shape[1]
+        return np.concatenate([x.reshape(-1, order="F") for x in xs]), mu
+
+    def unpack(self, flat, mu):
+        out, off = [], 0
+        for n in self.n:
+            blk = flat[off:off + n * mu]
+            out.append(blk.copy() if mu == 1 else blk.reshape(n, mu, order="F").copy(order="F"))
+            off += n * mu
+        return out
+
+    def _op(self, fn, xs):
+        flat, mu = self.pack(xs)
+        out = np.empty_like(flat)
+        check(fn(self._h, _dptr(flat), _dptr(out), mu))
+        return self.unpack(out, mu)
+
+    # -- the hot-path operations on host arrays --
+    def exchange(self, xs):
+        """schwarzExchange: returns sum_j R^T D x (the reference works in place)."""
+        flat, mu = self.pack(xs)
+        check(self._lib.HpddmHipSchwarzExchange(self._h, _dptr(flat), mu))
+        return self.unpack(flat, mu)
+
+    def gmv(self, xs):
+        return self._op(self._lib.HpddmHipSchwarzGMV, xs)
+
+    def apply(self, xs):
+        return self._op(self._lib.HpddmHipSchwarzApply, xs)
+
+    def deflation(self, xs):
+        return self._op(self._lib.HpddmHipSchwarzDeflation, xs)
+
+    def local_solve(self, xs):
+        return self._op(self._lib.HpddmHipSchwarzLocalSolve, xs)
+
+    def compute_residual(self, sol, f):
+        """schwarzComputeResidual: array of 2*mu values, [||f||, ||A x - f||] per right-hand side."""
+        fs, mu = self.pack(f)
+        ss, _ = self.pack(sol)
+        storage = np.zeros(2 * mu)
+        check(self._lib.HpddmHipSchwarzComputeResidual(self._h, _dptr(ss), _dptr(fs), _dptr(storage), mu))
+        return storage
+
+    def solve(self, f, sol=None, history=False):
+        """solve(A, f, sol, comm) (interface/hpddm.py:267 -> HpddmSolve): returns (iterations, sol[, history])."""
+        fs, mu = self.pack(f)
+        xs = np.zeros_like(fs) if sol is None else self.pack(sol)[0]
+        hist = np.zeros(4096)
+        it = self._lib.HpddmHipSolve(self._h, _dptr(fs), _dptr(xs), mu, _dptr(hist), hist.size)
+        if it < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        out = self.unpack(xs, mu)
+        return (it, out, hist[:it]) if history else (it, out)
+
+    # -- device-resident variants (raw HBM pointers) --
+    def apply_device(self, in_ptr, out_ptr, mu=1):
+        check(self._lib.HpddmHipSchwarzApplyDevice(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), mu))
+
+    def gmv_device(self, in_ptr, out_ptr, mu=1):
+        check(self._lib.HpddmHipSchwarzGMVDevice(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), mu))
+
+    def solve_device(self, b_ptr, x_ptr, mu=1):
+        it = self._lib.HpddmHipSolveDevice(self._h, ctypes.c_void_p(b_ptr), ctypes.c_void_p(x_ptr), mu, None, 0)
+        if it < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        return it
+
+    def synchronize(self):
+        check(self._lib.HpddmHipSynchronize())
+
+    def time(self, what, mu=1, warmup=2, reps=10):
+        sec = ctypes.c_double()
+        check(self._lib.HpddmHipSchwarzTime(self._h, what.encode(), mu, warmup, reps, ctypes.byref(sec)))
+        return sec.value
+
+    def stats(self):
+        st = np.zeros(8)
+        check(self._lib.HpddmHipSchwarzStats(self._h, _dptr(st)))
+        keys = ("n", "nnz_L", "stored", "sptrsv_bytes_alg", "levels", "launches", "nnz_A", "coarse_dim")
+        return dict(zip(keys, st))
+
+    def subdomain(self, s):
+        h = self._lib.HpddmHipSchwarzGetSubdomain(self._h, s)
+        return Subdomain._borrow(h)
+
+    def destroy(self):
+        if self._h:
+            self._lib.HpddmHipSchwarzDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def schwarz_from_subdomains(subs, first_global=0, nglobal=None, options="", multiplicity=True):
+    """examples/schwarz.cpp:90-97 in one call: create, set every subdomain, multiplicityScaling, initialize."""
+    A = Schwarz(len(subs), first_global, nglobal)
+    if options:
+        A.option_parse(options)
+    for s, sd in enumerate(subs):
+        A.set_subdomain(s, sd["n"], sd["ia"], sd["ja"], sd["a"], sd["sym"], sd["neighbors"], sd["connectivity"], sd.get("numbering", "C"))
+    d = [np.array(sd["d"], dtype=np.float64) for sd in subs]
+    if multiplicity:
+        d = A.multiplicity_scaling(d)
+    A.initialize(d)
+    return A, d

@@ -1,0 +1,138 @@
+/* hpddm_hip.h -- C ABI of libhpddm_hip.so, the MI355X-native implementation of HPDDM's Restricted Additive Schwarz
+ * preconditioner-apply hot path.  Plain pointers and sizes only (no C++ / torch / MPI types), scalar K = double.
+ *
+ * Every entry point names the reference interface it replaces (hpddm/hpddm 2.4.0, paths relative to the reference
+ * root).  Conventions shared with the reference:
+ *   - multi-vectors are column-major with leading dimension n (right-hand side nu at x + nu*n), HPDDM.h:89,105,112;
+ *   - CSR with 0-based ('C') or 1-based ('F') indices; sym != 0 means only the lower triangle is stored
+ *     (include/HPDDM_matrix.hpp:32-394);
+ *   - errors never throw across the boundary: functions return 0 on success, a negative code otherwise, and
+ *     HpddmHipLastError() returns the message (the reference prints to std::cerr, include/HPDDM_MUMPS.hpp:288).
+ *
+ * Pointers named *_dev are device (HBM) pointers, everything else is host memory.
+ */
+#ifndef HPDDM_HIP_H
+#define HPDDM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *HpddmHipLastError(void);
+/* number of visible HIP devices (0 when there is none); the library is useless without one and says so */
+int HpddmHipDeviceCount(void);
+int HpddmHipSetDevice(int device);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Local solver: the Solver<K> concept (include/HPDDM_MUMPS.hpp:206-318, include/HPDDM_LAPACK.hpp:326-401) and its
+ * C binding HpddmSubdomainNumfact / HpddmSubdomainSolve / HpddmSubdomainDestroy (interface/HPDDM.h:88-90,
+ * interface/hpddm_c.cpp:136-153).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct HpddmHipSubdomain HpddmHipSubdomain;
+
+/* Analysis + numerical factorisation of the local matrix, factor uploaded to HBM.  If *S is not NULL the existing
+ * object is re-factorised (same pattern => symbolic phase reused, like MUMPS job=2, HPDDM_MUMPS.hpp:285).
+ *   numbering : 'C' or 'F'                    (template parameter N of Solver::numfact)
+ *   sym       : MatrixCSR::sym_               (lower triangle only)
+ *   spd       : value of -hpddm_operator_spd  (Cholesky instead of LDL^T, HPDDM_MUMPS.hpp:236)
+ * A matrix given in full storage whose values are exactly symmetric is factorised as a symmetric one. */
+int HpddmHipSubdomainNumfact(HpddmHipSubdomain **S, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int spd);
+/* x = A^{-1} b, n right-hand sides, host pointers (Solver::solve(b, x, n), HPDDM.h:89); b == x allowed (in place) */
+int HpddmHipSubdomainSolve(HpddmHipSubdomain *S, const double *b, double *x, unsigned short n);
+/* same with device pointers, asynchronous on the library stream */
+int HpddmHipSubdomainSolveDevice(HpddmHipSubdomain *S, const double *b_dev, double *x_dev, unsigned short n);
+void HpddmHipSubdomainDestroy(HpddmHipSubdomain *S);
+/* Tuning knobs read at the next Numfact: "leaf_size" (dissection leaf, default 32), "keep_plain" (keep the plain
+ * supernodal L on the host for HpddmHipSubdomainExportPlain), "host_only" (do not upload: analysis/inspection) */
+int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double value);
+/* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
+ *               update-pool size, kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, 0, 0, 0
+ * times[0..3] = ordering, symbolic, numeric factorisation, upload (seconds) */
+int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
+/* Raw factor arrays for inspection / tests / the CPU baseline of bench.py (host copies; sizes from Info + the
+ * arrays themselves).  which: "perm" "blk_ptr" "ldw" "f_off" "row_ptr" "rows" "height" "u_off" "goff" "gptr" "gsrc"
+ * (int64 output), "F" "G" "dinv" "Lplain" "Uplain" (double output).  Returns the element count; out may be NULL. */
+long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which, void *out, long long capacity);
+
+/* average duration (seconds) of one batched SpTRSV (forward + backward sweep, all levels) measured with HIP events
+ * on the library stream over `reps` repetitions after `warmup` untimed ones; mu right-hand sides of ones */
+int HpddmHipSubdomainTimeSolve(HpddmHipSubdomain *S, int mu, int warmup, int reps, double *seconds);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The Schwarz operator: HPDDM::Schwarz<...> (include/HPDDM_schwarz.hpp) through its C binding HpddmSchwarz*
+ * (interface/HPDDM.h:101-112).  One object owns ALL subdomains resident on one GPU (the reference has one
+ * subdomain per MPI rank); "neighbors" are global subdomain numbers.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct HpddmHipSchwarz HpddmHipSchwarz;
+
+/* nsub local subdomains, numbered first_global .. first_global+nsub-1 among nglobal subdomains in total */
+HpddmHipSchwarz *HpddmHipSchwarzCreate(int nsub, int first_global, int nglobal);
+void             HpddmHipSchwarzDestroy(HpddmHipSchwarz *A);
+/* HpddmSchwarzCreate(Mat, neighbors, list, sizes, connectivity) (HPDDM.h:101, Subdomain::initialize
+ * include/HPDDM_subdomain.hpp:238-259) for local subdomain s; the matrix is copied (and uploaded). */
+int HpddmHipSchwarzSetSubdomain(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity);
+/* HpddmSchwarzMultiplicityScaling (HPDDM.h:104, Schwarz::multiplicityScaling include/HPDDM_schwarz.hpp:381-404):
+ * d[s] (length n_s) holds the caller's weights on entry and the partition of unity on exit.  Needs every neighbour
+ * to be local (single-GPU); multi-GPU callers pass the final d to HpddmHipSchwarzInitialize instead. */
+int HpddmHipSchwarzMultiplicityScaling(HpddmHipSchwarz *A, double *const *d);
+/* HpddmSchwarzInitialize (HPDDM.h:102, Schwarz::initialize include/HPDDM_schwarz.hpp:178): d is copied */
+int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d);
+/* HpddmSetVectors + HpddmInitializeCoarseOperator (HPDDM.h:95-96): nu deflation vectors of subdomain s, column-major n_s x nu */
+int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z);
+/* HpddmSchwarzBuildCoarseOperator (HPDDM.h:108, Preconditioner::buildTwo include/HPDDM_preconditioner.hpp:124-257):
+ * E = Z^T A Z assembled from the local products and factorised (dense, replicated). */
+int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A);
+/* HpddmSchwarzCallNumfact (HPDDM.h:106, Schwarz::callNumfact include/HPDDM_schwarz.hpp:337-368) */
+int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A);
+/* Options of the path, same names and values as the reference's -hpddm_* flags (include/HPDDM_option_impl.hpp:41-178):
+ * "tol" "max_it" "gmres_restart" "variant" (0 left,1 right,2 flexible) "orthogonalization" (0 cgs,1 mgs)
+ * "schwarz_method" (0 ras,1 oras,2 soras,3 asm,4 osm,5 none) "schwarz_coarse_correction" (-1 none,0 deflated,
+ * 1 additive,2 balanced) "operator_spd" "verbosity" "reuse_preconditioner" "leaf_size" */
+int    HpddmHipSchwarzSetOption(HpddmHipSchwarz *A, const char *key, double value);
+double HpddmHipSchwarzGetOption(const HpddmHipSchwarz *A, const char *key);
+/* "-hpddm_key value" / "-hpddm_key=value" strings with the reference's enumerations (e.g. "-hpddm_variant right") */
+int HpddmHipSchwarzOptionParse(HpddmHipSchwarz *A, const char *args);
+
+/* Batched multi-vector layout of the operator: subdomain s, right-hand side nu, dof i lives at
+ *     offset(s) * mu + nu * n_s + i ,   offset(s) = n_0 + ... + n_{s-1}          (total length = mu * sum n_s)
+ * i.e. the per-rank arrays of the reference stored one after the other. */
+long long HpddmHipSchwarzGetDof(const HpddmHipSchwarz *A, int s); /* s < 0: sum over the local subdomains */
+
+/* HpddmSchwarzExchange (HPDDM.h:105; Schwarz::exchange = Wrapper::diag + Subdomain::exchange,
+ * include/HPDDM_schwarz.hpp:180-188, include/HPDDM_subdomain.hpp:115-130), in place */
+int HpddmHipSchwarzExchange(HpddmHipSchwarz *A, double *x, unsigned short mu);
+/* Schwarz::GMV (include/HPDDM_schwarz.hpp:726-747): out = exchange(A in) */
+int HpddmHipSchwarzGMV(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu);
+/* Schwarz::apply (include/HPDDM_schwarz.hpp:527-612): out = M^{-1} in */
+int HpddmHipSchwarzApply(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu);
+/* Schwarz::deflation (include/HPDDM_schwarz.hpp:1602-1622): out = exchange(Z E^{-1} Z^T D in) */
+int HpddmHipSchwarzDeflation(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu);
+/* local solves only (Solver::solve on every subdomain, no exchange) */
+int HpddmHipSchwarzLocalSolve(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu);
+/* HpddmSchwarzComputeResidual (HPDDM.h:109, include/HPDDM_schwarz.hpp:761): storage[2*nu] = ||f||^2-ish norms
+ * exactly as the reference returns them (storage[2nu] = ||f_nu||, storage[2nu+1] = ||A x_nu - f_nu||, D-weighted) */
+int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu);
+/* HpddmSolve (HPDDM.h:112, IterativeMethod::solve include/HPDDM_iterative.hpp:1013 -> GMRES include/HPDDM_GMRES.hpp:30):
+ * returns the iteration count (negative on error); sol holds the initial guess on entry.
+ * history, if not NULL, receives up to history_cap residual norms (one per iteration, largest over the rhs). */
+int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap);
+
+/* Device-pointer variants of the hot calls (vectors already resident in HBM, asynchronous on the library stream) */
+int HpddmHipSchwarzApplyDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);
+int HpddmHipSchwarzGMVDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);
+int HpddmHipSolveDevice(HpddmHipSchwarz *A, const double *b_dev, double *sol_dev, int mu, double *history, int history_cap);
+int HpddmHipSynchronize(void);
+
+/* Measurement hooks used by bench.py (HIP events on the library stream; vectors resident in HBM):
+ * what = "apply" | "solve" (local SpTRSV only) | "gmv" | "deflation" | "exchange"; seconds = average per call */
+int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup, int reps, double *seconds);
+/* stats[0..7] = sum n, sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at mu=1
+ *               (2*nnz(L)*8 + 4*n*8), #levels, kernel launches per SpTRSV, sum nnz(A), coarse dimension */
+int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats);
+/* access to subdomain s' local solver (for Export / Info) */
+HpddmHipSubdomain *HpddmHipSchwarzGetSubdomain(HpddmHipSchwarz *A, int s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPDDM_HIP_H */

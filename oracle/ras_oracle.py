@@ -1,0 +1,261 @@
+"""CPU restatement of the reference's RAS preconditioner-apply path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(hpddm_amd/, libhpddm_hip.so) never does.  Plain numpy; the local sparse direct solve, which the reference delegates
+to MUMPS / PARDISO / CHOLMOD / LAPACK (third-party, not in the reference tree; no version pinned there), is restated
+with scipy's SuperLU (`splu`) -- a direct solve is unique up to round-off, so parity is pinned at the Solver<K>
+boundary.
+
+Pinned against the compiled reference: tests/test_oracle_golden.py checks every function below against the golden
+vectors of tests/golden/*.npz (dumped by oracle/ref_harness.cpp from the real HPDDM code, see oracle/make_golden.py).
+
+One "rank" of the reference = one entry of the python lists used here.
+Reference anchors (hpddm/hpddm 2.4.0):
+  multiplicity_scaling  Schwarz::multiplicityScaling      include/HPDDM_schwarz.hpp:381-404
+  exchange              Schwarz::exchange + Subdomain::exchange   include/HPDDM_schwarz.hpp:180-188, HPDDM_subdomain.hpp:115-130
+  csrmm                 Wrapper::csrmm                    include/HPDDM_wrapper.hpp:697-733
+  gmv                   Schwarz::GMV                      include/HPDDM_schwarz.hpp:726-747
+  coarse operator       MatrixMultiplication / buildTwo   include/HPDDM_operator.hpp:378-562, HPDDM_preconditioner.hpp:124-257
+  deflation             Schwarz::deflation                include/HPDDM_schwarz.hpp:1602-1622
+  apply                 Schwarz::apply                    include/HPDDM_schwarz.hpp:527-612
+  gmres                 IterativeMethod::GMRES + Arnoldi  include/HPDDM_GMRES.hpp:30-158, HPDDM_iterative.hpp:441-522,669-710,272-336
+  compute_residual      Schwarz::computeResidual          include/HPDDM_schwarz.hpp:761-803
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+HPDDM_EPS = 1.0e-12
+
+
+def csr_full(sd):
+    """scipy CSR of a subdomain dict (expands HPDDM's symmetric lower-triangular storage)."""
+    base = 1 if sd.get("numbering", "C") == "F" else 0
+    A = sp.csr_matrix((sd["a"], sd["ja"] - base, sd["ia"] - base), shape=(sd["n"], sd["n"]))
+    if sd["sym"]:
+        A = A + sp.tril(A, -1).T
+    return A.tocsr()
+
+
+class Oracle:
+    def __init__(self, subs, correction=None, method="ras"):
+        self.subs = subs
+        self.P = len(subs)
+        self.A = [csr_full(s) for s in subs]
+        # Subdomain::initialize (include/HPDDM_subdomain.hpp:238-259): neighbours sorted, empty lists dropped
+        self.map = []
+        for s in subs:
+            order = np.argsort(np.asarray(s["neighbors"]), kind="stable")
+            self.map.append([(int(s["neighbors"][k]), np.asarray(s["connectivity"][k])) for k in order if len(s["connectivity"][k])])
+        self.d = None
+        self.lu = None
+        self.Z = None
+        self.Einv = None
+        self.correction = correction  # None, "deflated", "additive", "balanced"
+        self.method = method          # "ras" (GE) or "asm" (SY)
+
+    def _peer(self, t, s):
+        for q, idx in self.map[t]:
+            if q == s:
+                return idx
+        raise KeyError((t, s))
+
+    # ---- Schwarz::multiplicityScaling ----
+    def multiplicity_scaling(self, d_in):
+        out = []
+        for s in range(self.P):
+            d = np.ones(self.subs[s]["n"])
+            for t, idx in self.map[s]:
+                send, recv = d_in[s][idx], d_in[t][self._peer(t, s)]
+                for j, i in enumerate(idx):
+                    if abs(send[j]) < HPDDM_EPS:
+                        d[i] = 0.0
+                    else:
+                        d[i] /= 1.0 + d[i] * recv[j] / send[j]
+            out.append(d)
+        self.d = out
+        return out
+
+    # ---- Schwarz::exchange: x <- D x, then sum of the neighbours' D-scaled duplicates ----
+    def exchange(self, xs, scale=True):
+        sc = [((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s]) if scale else xs[s].copy() for s in range(self.P)]
+        out = [v.copy() for v in sc]
+        for s in range(self.P):
+            for t, idx in self.map[s]:
+                out[s][idx] += sc[t][self._peer(t, s)]
+        return out
+
+    def csrmm(self, xs):
+        return [self.A[s] @ xs[s] for s in range(self.P)]
+
+    def gmv(self, xs):
+        return self.exchange(self.csrmm(xs))
+
+    # ---- Solver<K>::numfact / solve ----
+    def numfact(self):
+        self.lu = [spl.splu(sp.csc_matrix(A)) for A in self.A]
+
+    def local_solve(self, xs):
+        return [self.lu[s].solve(np.asarray(xs[s], dtype=np.float64)) for s in range(self.P)]
+
+    # ---- coarse level ----
+    def set_vectors(self, Z):
+        self.Z = [np.asarray(z, dtype=np.float64).reshape(self.subs[s]["n"], -1) for s, z in enumerate(Z)]
+
+    def build_coarse(self, symmetric=True):
+        off = np.concatenate([[0], np.cumsum([z.shape[1] for z in self.Z])])
+        DZ = [self.d[s][:, None] * self.Z[s] for s in range(self.P)]
+        T = [self.A[s] @ DZ[s] for s in range(self.P)]
+        E = np.zeros((off[-1], off[-1]))
+        for i in range(self.P):
+            E[off[i]:off[i + 1], off[i]:off[i + 1]] = DZ[i].T @ T[i]
+            for j, idx in self.map[i]:
+                E[off[i]:off[i + 1], off[j]:off[j + 1]] = DZ[i][idx].T @ T[j][self._peer(j, i)]
+        # symCoarse == 'S' for real scalars (examples/schwarz.hpp:75-79): only the upper triangle of E is assembled
+        # (each rank contributes its own row block towards higher-numbered neighbours) and the coarse solver treats
+        # E as symmetric.  Verified bit-for-bit against the reference on the golden vectors.
+        if symmetric:
+            E = np.triu(E) + np.triu(E, 1).T
+        self.E, self.coff = E, off
+        self.Einv = np.linalg.inv(E)
+
+    def deflation(self, xs):
+        # out = exchange(Z E^{-1} Z^T D in)
+        uc = np.concatenate([self.Z[s].T @ ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s]) for s in range(self.P)])
+        y = self.Einv @ uc
+        return self.exchange([self.Z[s] @ y[self.coff[s]:self.coff[s + 1]] for s in range(self.P)])
+
+    # ---- Schwarz::apply ----
+    def apply(self, xs):
+        if self.correction is None:
+            if self.method == "asm":
+                return self.exchange(self.local_solve(xs), scale=False)
+            return self.exchange(self.local_solve(xs))
+        if self.correction == "additive":
+            out = self.deflation(xs)
+            work = self.local_solve(xs)
+            return self.exchange([o + w for o, w in zip(out, work)])
+        out = self.deflation(xs)
+        Aout = self.csrmm(out)
+        work = self.exchange([x - a for x, a in zip(xs, Aout)])
+        work = self.exchange(self.local_solve(work))
+        if self.correction == "balanced":
+            tmp = self.deflation(self.gmv(work))
+            work = [w - t for w, t in zip(work, tmp)]
+        return [o + w for o, w in zip(out, work)]
+
+    # ---- D-weighted inner products over all ranks (MPI_Allreduce in the reference) ----
+    def wdot(self, xs, ys):
+        mu = 1 if xs[0].ndim == 1 else xs[0].shape[1]
+        acc = np.zeros(mu)
+        for s in range(self.P):
+            acc += ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s] * ys[s]).sum(axis=0)
+        return acc
+
+    def compute_residual(self, sol, f):
+        r = [a - b for a, b in zip(self.gmv(sol), f)]
+        nb, nr = np.sqrt(self.wdot(f, f)), np.sqrt(self.wdot(r, r))
+        out = np.zeros(2 * len(nb))
+        out[0::2], out[1::2] = nb, nr
+        return out
+
+    # ---- IterativeMethod::GMRES (right or left preconditioning, CGS or MGS) ----
+    def gmres(self, b, x0=None, tol=1e-6, max_it=100, restart=40, variant="right", ortho="cgs"):
+        P = self.P
+        b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+        mu = b[0].shape[1]
+        x = [np.zeros_like(v) for v in b] if x0 is None else [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1).copy() for v in x0]
+        m = max(1, min(restart, max_it))
+        x = self.exchange(x)                                        # A.start
+        norm = self.wdot(self.apply(b), self.apply(b)) if variant == "left" else self.wdot(b, b)
+        conv = np.full(mu, -m)
+        hist = []
+        j = 1
+        H = np.zeros((mu, m + 1, m))
+        cs, sn = np.zeros((mu, m)), np.zeros((mu, m))
+        V = [None] * (m + 1)
+
+        def update_sol(x):
+            y = np.zeros((m, mu))
+            dmax = 0
+            for nu in range(mu):
+                dim = abs(int(conv[nu]))
+                dmax = max(dmax, dim)
+                for r in range(dim - 1, -1, -1):
+                    y[r, nu] = (s[r, nu] - H[nu, r, r + 1:dim] @ y[r + 1:dim, nu]) / H[nu, r, r]
+            if dmax == 0:
+                return x
+            comb = [sum(V[k][p] * y[k] for k in range(dmax)) for p in range(P)]
+            if variant == "left":
+                return [xx + c for xx, c in zip(x, comb)]
+            corr = self.apply(comb)
+            mask = (conv != 0).astype(float)
+            return [xx + c * mask for xx, c in zip(x, corr)]
+
+        while j <= max_it:
+            r0 = [bb - g for bb, g in zip(b, self.gmv(x))]
+            if variant == "left":
+                r0 = self.apply(r0)
+            s0 = self.wdot(r0, r0)
+            if j == 1:
+                norm = np.sqrt(norm)
+                norm[norm < HPDDM_EPS] = 1.0
+                if np.any(s0 < np.finfo(float).eps ** 2):
+                    return 0, [v if mu > 1 else v[:, 0] for v in x], hist
+            conv[conv > 0] = 0
+            s = np.zeros((m + 1, mu))
+            s[0] = np.sqrt(s0)
+            V[0] = [r / s[0] for r in r0]
+            i = 0
+            while i < m and j <= max_it:
+                if variant == "left":
+                    w = self.apply(self.gmv(V[i]))
+                else:
+                    w = self.gmv(self.apply(V[i]))
+                if ortho == "mgs":
+                    for k in range(i + 1):
+                        h = self.wdot(V[k], w)
+                        H[:, k, i] = h
+                        w = [ww - vv * h for ww, vv in zip(w, V[k])]
+                else:
+                    hs = [self.wdot(V[k], w) for k in range(i + 1)]
+                    for k in range(i + 1):
+                        H[:, k, i] = hs[k]
+                    w = [ww - sum(V[k][p] * hs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
+                nrm = np.sqrt(self.wdot(w, w))
+                H[:, i + 1, i] = nrm
+                V[i + 1] = [ww / nrm for ww in w] if i < m - 1 else w
+                for nu in range(mu):
+                    for k in range(i):
+                        gamma = cs[nu, k] * H[nu, k, i] + sn[nu, k] * H[nu, k + 1, i]
+                        H[nu, k + 1, i] = -sn[nu, k] * H[nu, k, i] + cs[nu, k] * H[nu, k + 1, i]
+                        H[nu, k, i] = gamma
+                    delta = np.hypot(H[nu, i, i], H[nu, i + 1, i])
+                    sn[nu, i] = H[nu, i + 1, i] / delta
+                    cs[nu, i] = H[nu, i, i] / delta
+                    H[nu, i, i] = delta
+                    s[i + 1, nu] = -sn[nu, i] * s[i, nu]
+                    s[i, nu] *= cs[nu, i]
+                i += 1
+                res = np.abs(s[i])
+                newly = (conv == -m) & (res / norm <= tol)
+                conv[newly] = i
+                beta, which = res[0], 0
+                for nu in range(mu):
+                    if conv[nu] == -m and res[nu] > beta:
+                        beta, which = res[nu], nu
+                hist.append((j, beta, norm[which]))
+                if not np.any(conv == -m):
+                    i = 0
+                    break
+                j += 1
+            if j != max_it + 1 and i == m:
+                x = update_sol(x)
+                H[:] = 0
+            else:
+                if j == max_it + 1:
+                    rem = max_it % m
+                    conv[conv < 0] = rem if rem > 0 else -conv[conv < 0]
+                x = update_sol(x)
+                break
+        return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist

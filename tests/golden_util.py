@@ -1,0 +1,84 @@
+"""Loading the golden fixtures dumped from the compiled reference (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SMALL_CASES = ["p40_onelevel", "p40_onelevel_mu3", "p40_sym_spd", "p40_sym_ldlt", "p40_overlap2", "p40_deflated",
+               "p40_deflated_mu2_ov2", "p40_additive", "p40_balanced", "p36x60_9ranks", "p30_6ranks_mgs_left"]
+
+
+def load(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: g[k] for k in g.files}
+
+
+def options(g):
+    """reference command line of the case -> dict of the options the path reads"""
+    toks = str(g["options"]).split()
+    out = {"tol": 1e-6, "max_it": 100, "restart": 40, "variant": "right", "ortho": "cgs", "correction": None, "spd": False}
+    i = 0
+    while i < len(toks):
+        t = toks[i]
+        if t.startswith("-hpddm_"):
+            key = t[7:]
+            val = None
+            if "=" in key:
+                key, val = key.split("=", 1)
+            elif i + 1 < len(toks) and not toks[i + 1].startswith("-"):
+                i += 1
+                val = toks[i]
+            if key == "gmres_restart":
+                out["restart"] = int(val)
+            elif key == "max_it":
+                out["max_it"] = int(val)
+            elif key == "tol":
+                out["tol"] = float(val)
+            elif key == "variant":
+                out["variant"] = val
+            elif key == "orthogonalization":
+                out["ortho"] = val
+            elif key == "schwarz_coarse_correction":
+                out["correction"] = val
+            elif key == "operator_spd":
+                out["spd"] = True
+        i += 1
+    return out
+
+
+def hpddm_args(g):
+    """the -hpddm_* part of the reference command line (passed verbatim to HpddmHipSchwarzOptionParse)"""
+    toks = str(g["options"]).split()
+    out, i = [], 0
+    while i < len(toks):
+        if toks[i].startswith("-hpddm_"):
+            out.append(toks[i])
+            if "=" not in toks[i] and i + 1 < len(toks) and not toks[i + 1].startswith("-"):
+                i += 1
+                out.append(toks[i])
+        i += 1
+    return " ".join(out)
+
+
+def subdomains(g):
+    """per-rank dicts (same keys as hpddm_amd.generate) rebuilt from a fixture that carries its matrices"""
+    subs = []
+    for r in range(int(g["ranks"])):
+        meta = g[f"meta_r{r}"]
+        nb = g[f"neighbors_in_r{r}"]
+        subs.append(dict(n=int(meta[2]), ia=g[f"ia_r{r}"], ja=g[f"ja_r{r}"], a=g[f"a_r{r}"], sym=bool(meta[4]), numbering="C",
+                         neighbors=nb, connectivity=[g[f"mapping_in_{k}_r{r}"] for k in range(len(nb))], d=g[f"d_in_r{r}"],
+                         f=g[f"f_r{r}"]))
+    return subs
+
+
+def vec(g, key, r, mu):
+    n = int(g[f"meta_r{r}"][2])
+    v = g[f"{key}_r{r}"]
+    return v.copy() if mu == 1 else v.reshape(n, mu, order="F").copy(order="F")
+
+
+def vecs(g, key):
+    mu = int(g["mu"])
+    return [vec(g, key, r, mu) for r in range(int(g["ranks"]))]

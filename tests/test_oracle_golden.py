@@ -1,0 +1,83 @@
+"""The CPU restatement (oracle/ras_oracle.py) against the golden vectors dumped from the compiled reference.
+
+This is what pins the oracle: every function of the hot path, on every fixture, plus the 45-iteration run of
+BASELINE.json's config 1.  CPU only.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from hpddm_amd.generate import generate2d
+from oracle.ras_oracle import Oracle
+
+
+def _setup(g, subs):
+    opt = gu.options(g)
+    orc = Oracle(subs, correction=opt["correction"])
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    orc.numfact()
+    if opt["correction"]:
+        orc.set_vectors([np.ones((s["n"], 1)) for s in subs])  # constant vector, examples/schwarz.cpp:115-121
+        orc.build_coarse()
+    return orc, opt
+
+
+def _close(a, b, rtol, what):
+    scale = max(np.abs(np.concatenate([np.ravel(x) for x in b])).max(), 1e-300)
+    err = max(np.abs(np.ravel(x) - np.ravel(y)).max() for x, y in zip(a, b)) / scale
+    assert err <= rtol, f"{what}: relative error {err:.3e} > {rtol:.1e}"
+
+
+@pytest.mark.parametrize("name", gu.SMALL_CASES)
+def test_functions_match_reference(name):
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    orc, opt = _setup(g, subs)
+    P, mu = int(g["ranks"]), int(g["mu"])
+    # Subdomain::initialize + multiplicityScaling
+    for r in range(P):
+        assert [q for q, _ in orc.map[r]] == list(g[f"neighbors_r{r}"])
+        for k, (_, idx) in enumerate(orc.map[r]):
+            assert np.array_equal(idx, g[f"map_{k}_r{r}"])
+        assert np.abs(orc.d[r] - g[f"d_r{r}"]).max() <= 1e-15
+    f = gu.vecs(g, "f")
+    _close(orc.exchange(f), gu.vecs(g, "exchange_out"), 1e-14, "exchange")
+    _close(orc.gmv(f), gu.vecs(g, "gmv_out"), 1e-13, "GMV")
+    _close(orc.local_solve(f), gu.vecs(g, "solve_out"), 1e-11, "Solver::solve")
+    _close(orc.apply(f), gu.vecs(g, "apply_out"), 1e-10, "apply")
+    if opt["correction"]:
+        _close(orc.deflation(f), gu.vecs(g, "deflation_out"), 1e-10, "deflation")
+
+
+@pytest.mark.parametrize("name", gu.SMALL_CASES)
+def test_gmres_matches_reference(name):
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    orc, opt = _setup(g, subs)
+    it, sol, hist = orc.gmres(gu.vecs(g, "f"), tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], variant=opt["variant"], ortho=opt["ortho"])
+    assert it == int(g["iterations_r0"][0])
+    ref_hist = g["history"]
+    assert len(hist) == len(ref_hist)
+    for (j, beta, nrm), row in zip(hist, ref_hist):
+        assert j == int(row[0])
+        assert abs(beta - row[1]) <= 2e-6 * row[1] + 1e-300   # the log prints 7 significant digits
+    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
+    res = orc.compute_residual(sol, gu.vecs(g, "f"))
+    assert np.allclose(res, g["residual_r0"], rtol=1e-5)
+
+
+def test_config1_45_iterations():
+    """BASELINE.json config 1: 2-D Poisson 200x200, 4 subdomains, one-level RAS -> 45 iterations"""
+    g = gu.load("c1_p200_onelevel")
+    subs = generate2d(200, 200, 4)
+    orc = Oracle(subs)
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    orc.numfact()
+    f = [s["f"] for s in subs]
+    _close(orc.apply(f), [g[f"apply_out_r{r}"] for r in range(4)], 1e-10, "apply")
+    it, sol, hist = orc.gmres(f)
+    assert it == 45 == int(g["iterations_r0"][0])
+    for (j, beta, nrm), row in zip(hist, g["history"]):
+        assert abs(beta - row[1]) <= 2e-6 * row[1]
+    _close(sol, [g[f"sol_r{r}"] for r in range(4)], 1e-8, "solution")
+    assert np.allclose(orc.compute_residual(sol, f), g["residual_r0"], rtol=1e-5)
