@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- RAS preconditioner applies/s on MI355X (BASELINE.json metric), config 2 of BASELINE.json:
+3-D Poisson 128^3, 8 subdomains on one GPU, one-level RAS, HIP local SpTRSV.
+
+A "step" = one apply of the preconditioner,  out = sum_i R_i^T D_i A_i^{-1} R_i in,  for all 8 subdomains of the GPU
+(8 level-scheduled SpTRSV + fused D-scaling/halo sum), vectors resident in HBM.  With N GPUs every rank owns its own
+128^3 block of 8 subdomains (weak scaling, replicas: the cross-GPU halo is not built this round), and
+`value` is the aggregate number of 8-subdomain applies per second.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (batched SpTRSV against HBM peak, algorithmic bytes of
+SURVEY 8(d)), "cpu_baseline" (oracle substitution on the same factors, one host thread per subdomain like the
+reference's one-rank-per-subdomain layout), "gmres" (iterations/s of the device-resident GMRES on the same operator).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=128, help="global grid is n^3 cells per GPU")
+    ap.add_argument("--subdomains", type=int, default=8)
+    ap.add_argument("--mu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gmres", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from hpddm_amd import _lib, hpddm
+    from hpddm_amd.generate import generate3d
+
+    hpddm.require_device()
+    _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
+
+    # ---- build the operator (one-time: generator, analysis, factorisation, upload) ----
+    t0 = time.time()
+    subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth")
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    opts = "-hpddm_operator_spd" + (" -hpddm_keep_plain 1" if want_cpu else "")
+    A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
+    A.call_numfact()
+    t_setup = time.time() - t0
+    st = A.stats()
+    ntot, mu = int(st["n"]), args.mu
+
+    x = torch.ones(ntot * mu, dtype=torch.float64, device=dev)
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+
+    def step():
+        A.apply_device(x.data_ptr(), y.data_ptr(), mu)
+
+    for _ in range(args.warmup):
+        step()
+    A.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    A.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed  # every rank applies its own 8-subdomain operator once per step
+
+    out = {
+        "metric": "ras_precond_applies_per_sec", "value": value, "unit": "applies/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: 3-D Poisson {args.n}^3 per GPU, {args.subdomains} subdomains per GPU, one-level RAS, "
+                               f"HIP level-scheduled SpTRSV, overlap 1, mu={mu}",
+                   "parallelism": "replicas (one 8-subdomain block per GPU, no cross-GPU halo this round)" if world > 1 else "1 GPU, 8 subdomains batched",
+                   "n_dof_per_gpu": ntot, "nnz_L_per_gpu": st["nnz_L"], "levels": st["levels"], "launches_per_sptrsv": st["launches"],
+                   "setup_seconds": round(t_setup, 2)},
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel pair (batched SpTRSV), HIP events on the library stream ----
+        reps = max(5, min(50, args.steps))
+        t_solve = A.time("solve", mu=mu, warmup=2, reps=reps)
+        bytes_alg = 2.0 * st["nnz_L"] * 8.0 + 4.0 * st["n"] * mu * 8.0   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
+        achieved = bytes_alg / t_solve / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                           "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep = %d launches)" % int(st["launches"]),
+                           "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve,
+                           "stored_bytes_per_sweep": 2.0 * st["stored"] * 8.0}
+        out["phases_ms"] = {"sptrsv": t_solve * 1e3, "exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3}
+        if not args.no_gmres:
+            f = [s["f"] for s in subs]
+            fb = torch.from_numpy(np.concatenate(f)).to(dev)
+            xs = torch.zeros_like(fb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            it = A.solve_device(fb.data_ptr(), xs.data_ptr(), 1)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - t0
+            out["gmres"] = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(A, subs, d, args, np)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(A, subs, d, args, np):
+    """the oracle's substitution (plain C, oracle/sptrsv_oracle.c) on the SAME factors, one host thread per subdomain
+    (the reference runs one MPI rank per subdomain with a sequential local solve), plus the numpy halo sum"""
+    from oracle import sptrsv_oracle
+    from oracle.ras_oracle import Oracle
+    nsub = len(subs)
+    threads = min(nsub, os.cpu_count() or 1)
+    factors = [sptrsv_oracle.PlainFactor(A.subdomain(s)) for s in range(nsub)]
+    orc = Oracle(subs)
+    orc.d = d
+    f = [np.ones(s["n"]) for s in subs]
+    sptrsv_oracle.time_batch(factors, f, reps=1, threads=threads)  # warm-up
+    reps = 0
+    tsolve = tex = 0.0
+    t_begin = time.perf_counter()
+    while time.perf_counter() - t_begin < 12.0 and reps < 20:
+        sec, xs = sptrsv_oracle.time_batch(factors, f, reps=1, threads=threads)
+        t1 = time.perf_counter()
+        orc.exchange(xs)
+        tex += time.perf_counter() - t1
+        tsolve += sec
+        reps += 1
+    per_apply = (tsolve + tex) / reps
+    return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} full applies of the same {nsub}-subdomain operator (all {nsub} local substitutions on {threads} threads, "
+                      f"one per subdomain, + numpy halo sum); substitution {tsolve / reps * 1e3:.1f} ms, halo {tex / reps * 1e3:.1f} ms per apply",
+            "seconds_per_apply": per_apply}
+
+
+if __name__ == "__main__":
+    main()

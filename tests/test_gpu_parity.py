@@ -1,0 +1,193 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors of the compiled reference and with the oracle.
+
+Tolerances (fp64): vectors within 1e-10 relative per apply; iteration counts equal; residual
+histories within the 7 printed digits of the reference log.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from hpddm_amd import hpddm
+from hpddm_amd.generate import generate2d, generate3d
+from oracle.ras_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, what):
+    scale = max(np.abs(np.concatenate([np.ravel(x) for x in b])).max(), 1e-300)
+    err = max(np.abs(np.ravel(x) - np.ravel(y)).max() for x, y in zip(a, b)) / scale
+    assert err <= rtol, f"{what}: relative error {err:.3e} > {rtol:.1e}"
+
+
+def _build(g, subs):
+    hpddm.require_device()
+    A, d = hpddm.schwarz_from_subdomains(subs, options=gu.hpddm_args(g))
+    opt = gu.options(g)
+    if opt["correction"]:
+        for s, sd in enumerate(subs):
+            A.set_vectors(s, np.ones((sd["n"], 1)))
+        A.build_coarse_operator()
+    A.call_numfact()
+    return A, d, opt
+
+
+@pytest.mark.parametrize("name", gu.SMALL_CASES)
+def test_functions_match_reference(name):
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    for r in range(len(subs)):
+        assert np.abs(d[r] - g[f"d_r{r}"]).max() <= 1e-15, "multiplicityScaling"
+    f = gu.vecs(g, "f")
+    _close(A.exchange(f), gu.vecs(g, "exchange_out"), 1e-14, "exchange")
+    _close(A.gmv(f), gu.vecs(g, "gmv_out"), 1e-13, "GMV")
+    _close(A.local_solve(f), gu.vecs(g, "solve_out"), 1e-10, "Solver::solve")
+    _close(A.apply(f), gu.vecs(g, "apply_out"), 1e-10, "apply")
+    if opt["correction"]:
+        _close(A.deflation(f), gu.vecs(g, "deflation_out"), 1e-10, "deflation")
+    A.destroy()
+
+
+@pytest.mark.parametrize("name", gu.SMALL_CASES)
+def test_gmres_matches_reference(name):
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0])
+    ref = g["history"]
+    assert len(hist) == len(ref)
+    assert np.all(np.abs(hist - ref[:, 1]) <= 2e-6 * ref[:, 1])
+    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-5)
+    A.destroy()
+
+
+def test_config1_45_iterations():
+    """BASELINE.json configs[0]: examples/schwarz.cpp 2-D Poisson 200x200, 4 subdomains, one-level RAS -> 45 iterations"""
+    g = gu.load("c1_p200_onelevel")
+    subs = generate2d(200, 200, 4)
+    A, d = hpddm.schwarz_from_subdomains(subs)
+    A.call_numfact()
+    f = [s["f"] for s in subs]
+    _close(A.apply(f), [g[f"apply_out_r{r}"] for r in range(4)], 1e-10, "apply")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == 45
+    assert np.all(np.abs(hist - g["history"][:, 1]) <= 1e-4 * g["history"][:, 1])
+    _close(sol, [g[f"sol_r{r}"] for r in range(4)], 1e-8, "solution")
+    res = A.compute_residual(sol, f)
+    assert np.allclose(res, g["residual_r0"], rtol=1e-5)
+    assert res[1] / res[0] <= 1e-2  # the reference's own acceptance test, examples/schwarz.cpp:140-144
+    A.destroy()
+
+
+@pytest.mark.parametrize("N,parts,overlap,sym,mu", [(12, 8, 1, True, 1), (14, 8, 2, True, 3), (10, 4, 1, False, 2), (16, 2, 1, True, 5)])
+def test_3d_against_oracle(N, parts, overlap, sym, mu):
+    """3-D Poisson (configs 2-3 family) at sizes the oracle finishes in seconds: every hot-path function + GMRES"""
+    subs = generate3d(N, parts, overlap, sym=sym, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd" if sym else "")
+    A.call_numfact()
+    orc = Oracle(subs)
+    dd = orc.multiplicity_scaling([s["d"] for s in subs])
+    for a, b in zip(d, dd):
+        assert np.abs(a - b).max() <= 1e-15
+    orc.numfact()
+    rng = np.random.default_rng(7)
+    f = [rng.random((s["n"], mu)) if mu > 1 else rng.random(s["n"]) for s in subs]
+    f = orc.exchange(f)  # consistent on the overlap
+    _close(A.exchange(f), orc.exchange(f), 1e-14, "exchange")
+    _close(A.gmv(f), orc.gmv(f), 1e-13, "GMV")
+    _close(A.local_solve(f), orc.local_solve(f), 1e-10, "Solver::solve")
+    _close(A.apply(f), orc.apply(f), 1e-10, "apply")
+    it, sol = A.solve(f)
+    it_o, sol_o, _ = orc.gmres(f)
+    assert it == it_o
+    _close(sol, sol_o, 1e-8, "solution")
+    A.destroy()
+
+
+def test_3d_two_level_against_oracle():
+    """deflated two-level apply with several deflation vectors per subdomain (low-order polynomials x partition of unity)"""
+    N, parts = 12, 8
+    subs = generate3d(N, parts, 2, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated")
+    orc = Oracle(subs, correction="deflated")
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    Z = []
+    for s, sd in enumerate(subs):
+        i0, i1, j0, j1, k0, k1 = sd["box"]
+        z, y, x = np.meshgrid(np.arange(k0, k1) / N, np.arange(j0, j1) / N, np.arange(i0, i1) / N, indexing="ij")
+        Zs = np.stack([np.ones(sd["n"]), x.ravel(), y.ravel(), z.ravel()], axis=1)
+        Z.append(np.asfortranarray(Zs))
+        A.set_vectors(s, Zs)
+    A.build_coarse_operator()
+    A.call_numfact()
+    orc.set_vectors(Z)
+    orc.build_coarse()
+    orc.numfact()
+    f = orc.exchange([np.random.default_rng(3).random(sd["n"]) for sd in subs])
+    _close(A.deflation(f), orc.deflation(f), 1e-10, "deflation")
+    _close(A.apply(f), orc.apply(f), 1e-10, "apply")
+    it, sol = A.solve(f)
+    it_o, sol_o, _ = orc.gmres(f)
+    assert it == it_o
+    _close(sol, sol_o, 1e-8, "solution")
+    A.destroy()
+
+
+def test_local_solver_kinds_and_properties():
+    """Solver concept: Cholesky / LDL^T / LU, 'C' and 'F' numbering, in-place solve, multiple right-hand sides, linearity"""
+    import scipy.sparse as sp
+    N = 9
+    I = sp.identity(N)
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    A0 = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
+    n = A0.shape[0]
+    rng = np.random.default_rng(0)
+    cases = {
+        "chol": (A0, True, True),
+        "ldlt": ((A0 - 1.7 * sp.identity(n)).tocsr(), True, False),
+        "lu": ((A0 + sp.diags(rng.random(n)) + 0.3 * sp.triu(A0, 1)).tocsr(), False, False),
+    }
+    for kind, (M, sym, spd) in cases.items():
+        Min = sp.tril(M).tocsr() if sym else M
+        Min.sort_indices()
+        for numbering in ("C", "F"):
+            base = 1 if numbering == "F" else 0
+            S = hpddm.Subdomain()
+            S.numfact(n, Min.indptr + base, Min.indices + base, Min.data, sym=sym, numbering=numbering, spd=spd)
+            for mu in (1, 2, 3, 7, 8, 9):
+                b = np.asfortranarray(rng.random((n, mu)))
+                x = S.solve(b)
+                r = np.abs(M @ x - b).max() / np.abs(b).max()
+                assert r < 1e-10, (kind, numbering, mu, r)
+            # in place + linearity
+            b1, b2 = rng.random(n), rng.random(n)
+            x1, x2 = S.solve(b1), S.solve(b2)
+            y = 2.0 * b1 - 3.0 * b2
+            S.solve(y, y)
+            assert np.abs(y - (2 * x1 - 3 * x2)).max() <= 1e-11 * np.abs(y).max()
+            S.destroy()
+
+
+def test_larger_size_properties():
+    """size-independent checks at a larger size (no oracle): residual of the direct solve, D-weighted partition of unity,
+    exchange idempotence on consistent vectors, GMRES residual threshold of the reference"""
+    subs = generate3d(32, 8, 1, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    A.call_numfact()
+    import scipy.sparse as sp
+    f = [s["f"] for s in subs]
+    x = A.local_solve(f)
+    for sd, xs, fs in zip(subs, x, f):
+        M = sp.csr_matrix((sd["a"], sd["ja"], sd["ia"]), shape=(sd["n"], sd["n"]))
+        M = M + sp.tril(M, -1).T
+        assert np.linalg.norm(M @ xs - fs) / np.linalg.norm(fs) < 1e-11
+    ones = [np.ones(s["n"]) for s in subs]
+    _close(A.exchange(ones), ones, 1e-14, "partition of unity")   # sum_j R_j^T D_j R_j = I
+    it, sol = A.solve(f)
+    res = A.compute_residual(sol, f)
+    assert it <= 45 and res[1] / res[0] <= 1e-2
+    A.destroy()
