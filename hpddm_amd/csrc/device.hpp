@@ -88,8 +88,12 @@ struct SolvePlan {
   long long                         ntot = 0, utot = 0;
   int                               nlev = 0;
   DevBuf<SnDesc> sn;
-  DevBuf<Tile>   ftiles, btiles;
-  std::vector<int> flev_ptr, blev_ptr; // per level tile ranges
+  // per level, four tile lists: forward / backward x wave-level (narrow panels, one wavefront per tile, no LDS) /
+  // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS)
+  enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3 };
+  DevBuf<Tile>     tiles;
+  std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
+  std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U;

@@ -318,9 +318,14 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
   for (idx_t k = 0; k < nblk; ++k)
     if (s.parent[k] >= 0) children[s.parent[k]].push_back(k);
   // The GPU hosts expose hundreds of hardware threads; this factorisation stops scaling long before that, and
-  // oversubscribed barriers are very slow.  HPDDM_HIP_NUM_THREADS overrides the default cap of 32.
+  // oversubscribed barriers are very slow.  The cap is the container's CPU quota if there is one, else 32; HPDDM_HIP_NUM_THREADS overrides it.
   const int saved_threads = omp_get_max_threads();
   int       cap           = 32;
+  if (FILE *fc = fopen("/sys/fs/cgroup/cpu.max", "r")) { // container CPU quota ("max" or "<quota> <period>")
+    long long quota = 0, period = 0;
+    if (fscanf(fc, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) cap = std::max<int>(1, (int)((quota + period - 1) / period));
+    fclose(fc);
+  }
   if (const char *e = getenv("HPDDM_HIP_NUM_THREADS")) cap = std::max(1, atoi(e));
   const int nthreads = std::max(1, std::min(saved_threads, cap));
   omp_set_num_threads(nthreads);

@@ -18,119 +18,243 @@
 namespace hpddm_hip {
 
 static constexpr int WG_THREADS  = 256;
-static constexpr int LDS_DOUBLES = 4096; // 32 KiB staging per workgroup -> 5 workgroups (20 waves) per CU
-static constexpr int FWD_PASSES  = 4;    // rows per wavefront per tile (register accumulators)
+static constexpr int LDS_DOUBLES = 4096; // 32 KiB staging per workgroup of the block-level path -> 5 workgroups (20 waves) per CU
+static constexpr int FWD_PASSES  = 4;    // rows per wavefront per batch (register accumulators, loads in flight)
+static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
+static constexpr int WAVE_ROWS   = 256;  // at most this many rows per wave-level tile (LDS: WAVE_ROWS * MU doubles per wavefront)
 
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; }
 
-template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
+// LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
+__device__ static inline void wave_lds_sync()
 {
-  __shared__ __attribute__((aligned(16))) double lds[LDS_DOUBLES];
-  const Tile   t    = tiles[blockIdx.x];
-  const SnDesc d    = sns[t.sn];
-  const int    tid  = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int    w = d.w, ldw = d.ldw;
-  const int    g    = lanes_per_row(ldw); // lanes cooperating on one row
-  const int    R    = 64 / g;             // rows per wavefront pass
-  const int    sub = lane / g, gl = lane - sub * g;
-  constexpr int CW  = LDS_DOUBLES / MU;   // columns staged per chunk
-  const double *bb  = b + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *yb  = y + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *Ub  = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-  const int     rend = t.r0 + t.nr;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
-  int    row[FWD_PASSES], lim[FWD_PASSES];
-  double acc[FWD_PASSES][MU];
+// store the result of panel row r (after reduction): top rows give y, rows below hand their update to the parent
+template <int MU>
+__device__ static inline void fwd_store_row(const SnDesc &d, int r, const double *s, int sstride, double *yb, double *Ub)
+{
+  if (r < d.w) {
 #pragma unroll
-  for (int p = 0; p < FWD_PASSES; ++p) {
-    row[p] = t.r0 + (p * 4 + wave) * R + sub;
-    lim[p] = row[p] < rend ? (row[p] < w ? row[p] + 1 : w) : 0; // triangular top block: columns <= row only
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
-  }
-  int lmax = lim[0];
-#pragma unroll
-  for (int p = 1; p < FWD_PASSES; ++p) lmax = max(lmax, lim[p]);
-  // wave-uniform upper bound of the column loop
-  for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
-
-  // columns needed by this tile: [0, tile_lim) ; rows of the top block never look right of their diagonal
-  const int tile_lim = min(w, rend);
-  for (int k0 = 0; k0 < tile_lim; k0 += CW) {
-    const int kend = min(k0 + CW, ldw); // stage zero padding up to ldw so that 16-byte reads past w see zeros
-    for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
-      const int nu = idx / (kend - k0), i = idx - nu * (kend - k0);
-      const int col = k0 + i;
-      double    v   = 0.0;
-      if (col < w) {
-        v = bb[(long long)nu * d.n + d.perm[d.c0 + col]];
-        for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
-      }
-      lds[nu * CW + i] = v;
-    }
-    __syncthreads();
-    const int cmax = min(lmax, k0 + CW);
-    for (int c = k0 + 2 * gl; c < cmax; c += 2 * g) {
-      double2 a[FWD_PASSES];
-#pragma unroll
-      for (int p = 0; p < FWD_PASSES; ++p) {
-        if (c < lim[p]) a[p] = *reinterpret_cast<const double2 *>(d.F + (long long)row[p] * ldw + c);
-        else a[p] = make_double2(0.0, 0.0);
-      }
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        const double2 l = *reinterpret_cast<const double2 *>(&lds[nu * CW + (c - k0)]);
-#pragma unroll
-        for (int p = 0; p < FWD_PASSES; ++p) acc[p][nu] = fma(a[p].x, l.x, fma(a[p].y, l.y, acc[p][nu]));
-      }
-    }
-    __syncthreads();
-  }
-  // in-register reduction over the g lanes of each row
-#pragma unroll
-  for (int p = 0; p < FWD_PASSES; ++p)
+    for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = s[nu * sstride];
+  } else {
+    const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
-      double s = acc[p][nu];
-      for (int off = g >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-      acc[p][nu] = s;
+      double v = s[nu * sstride];
+      for (int q = q0; q < q1; ++q) v += Ub[(long long)nu * d.usize + d.gsrc[q]];
+      Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v;
     }
-  if (gl == 0) {
+  }
+}
+
+// =========================== narrow panels (ldw <= 128): one wavefront per tile ====================================
+// lane (sub, gl): row-in-group sub = lane / g, column pair gl = lane % g with g = ldw/2 lanes per row, R = 64/g rows
+// per wave-instruction: a wavefront always moves 1 KiB of contiguous panel per load.  lds: WAVE_ROWS*MU doubles, private.
+template <int MU>
+__device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int lane, double *lds, const double *bb, double *yb, double *Ub)
+{
+  const int w = d.w, ldw = d.ldw;
+  const int g = ldw >> 1, R = 64 / g;
+  const int sub = lane / g, gl = lane - sub * g;
+  // right-hand side of the supernode for this lane's two columns: b - (updates handed up by the children)
+  double l0[MU], l1[MU];
+  {
+    const int c = 2 * gl;
 #pragma unroll
-    for (int p = 0; p < FWD_PASSES; ++p) {
-      const int r = row[p];
-      if (r >= rend) continue;
-      if (r < w) {
+    for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 0.0;
+    if (c < w) {
+      const int pc = d.perm[d.c0 + c], q0 = d.gptr[c], q1 = d.gptr[c + 1];
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = acc[p][nu];
-      } else {
-        const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
+      for (int nu = 0; nu < MU; ++nu) {
+        double v = bb[(long long)nu * d.n + pc];
+        for (int q = q0; q < q1; ++q) v -= Ub[(long long)nu * d.usize + d.gsrc[q]];
+        l0[nu] = v;
+      }
+      if (c + 1 < w) {
+        const int pc1 = d.perm[d.c0 + c + 1], q2 = d.gptr[c + 2];
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
-          double s = acc[p][nu];
-          for (int q = q0; q < q1; ++q) s += Ub[(long long)nu * d.usize + d.gsrc[q]];
-          Ub[(long long)nu * d.usize + d.u_off + (r - w)] = s;
+          double v = bb[(long long)nu * d.n + pc1];
+          for (int q = q1; q < q2; ++q) v -= Ub[(long long)nu * d.usize + d.gsrc[q]];
+          l1[nu] = v;
         }
+      }
+    }
+  }
+  const int     rend = t.r0 + t.nr;
+  const double *Fp   = d.F + 2 * gl;
+  for (int rb = t.r0 + sub; rb < rend; rb += FWD_PASSES * R) {
+    double2 a[FWD_PASSES];
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int r = rb + p * R;
+      a[p]        = r < rend ? *reinterpret_cast<const double2 *>(Fp + (long long)r * ldw) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int r = rb + p * R;
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        double s = fma(a[p].x, l0[nu], a[p].y * l1[nu]);
+        for (int off = g >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (gl == 0 && r < rend) lds[nu * WAVE_ROWS + (r - t.r0)] = s;
+      }
+    }
+  }
+  // epilogue, one lane per row: the dependent index chains (gptr -> gsrc -> U) of 64 rows overlap
+  wave_lds_sync();
+  for (int j = lane; j < t.nr; j += 64) fwd_store_row<MU>(d, t.r0 + j, lds + j, WAVE_ROWS, yb, Ub);
+}
+
+template <int MU>
+__device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *lds, const double *yb, double *xb, double *xo)
+{
+  const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
+  const int g = ldw >> 1, R = 64 / g;
+  const int sub = lane / g, gl = lane - sub * g;
+  // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
+  for (int i = lane; i < h; i += 64) {
+    if (i < w) {
+      const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
+    } else {
+      const int ri = d.rows[i - w];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + i] = -xb[(long long)nu * d.n + ri];
+    }
+  }
+  wave_lds_sync();
+  double acc0[MU], acc1[MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+  const double *Gp = d.G + 2 * gl;
+  for (int ib = sub; ib < h; ib += FWD_PASSES * R) {
+    double2 a[FWD_PASSES];
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int i = ib + p * R;
+      a[p]        = i < h ? *reinterpret_cast<const double2 *>(Gp + (long long)i * ldw) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int i = min(ib + p * R, h - 1); // out-of-range passes carry a = 0
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        const double v = lds[nu * WAVE_ROWS + i];
+        acc0[nu]       = fma(a[p].x, v, acc0[nu]);
+        acc1[nu]       = fma(a[p].y, v, acc1[nu]);
+      }
+    }
+  }
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu)
+    for (int off = g; off < 64; off <<= 1) {
+      acc0[nu] += __shfl_xor(acc0[nu], off);
+      acc1[nu] += __shfl_xor(acc1[nu], off);
+    }
+  if (sub == 0) {
+    const int c = 2 * gl;
+    if (c < w) {
+      const int pc = d.perm[d.c0 + c];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
+        xo[(long long)nu * d.n + pc]       = acc0[nu];
+      }
+    }
+    if (c + 1 < w) {
+      const int pc = d.perm[d.c0 + c + 1];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
+        xo[(long long)nu * d.n + pc]           = acc1[nu];
       }
     }
   }
 }
 
+// =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
 template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0)
+__device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *bb, double *yb, double *Ub)
 {
-  __shared__ __attribute__((aligned(16))) double lds[LDS_DOUBLES];
-  const Tile   t    = tiles[blockIdx.x];
-  const SnDesc d    = sns[t.sn];
-  const int    tid  = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int    w = d.w, ldw = d.ldw, h = d.w + d.nb;
-  const int    g    = lanes_per_row(ldw);
-  const int    R    = 64 / g;
-  const int    sub = lane / g, gl = lane - sub * g;
+  const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int     w = d.w, ldw = d.ldw;
+  constexpr int CW  = (LDS_DOUBLES - 64 * MU) / MU; // columns staged per chunk (the tail of the LDS holds the row sums)
+  double       *sums = lds + MU * CW;                // [MU][64]
+  const int     rend = t.r0 + t.nr;
+  const int     tile_lim = min(w, rend); // rows of the top block never look right of their diagonal
+  const bool    single   = tile_lim <= CW;
+  // row batches: every wavefront owns FWD_PASSES rows per batch (one wave per row, 16-byte loads, 1 KiB per instruction)
+  for (int rb = t.r0; rb < rend; rb += 4 * FWD_PASSES) {
+    int    row[FWD_PASSES], lim[FWD_PASSES];
+    double acc[FWD_PASSES][MU];
+    int    lmax = 0;
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      row[p] = rb + p * 4 + wave;
+      lim[p] = row[p] < rend ? (row[p] < w ? row[p] + 1 : w) : 0;
+      lmax   = max(lmax, lim[p]);
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
+    }
+    for (int k0 = 0; k0 < tile_lim; k0 += CW) {
+      if (!single || rb == t.r0) {
+        // stage f = b - children's updates for columns [k0, kend), zero padding up to ldw (16-byte reads past w see zeros)
+        if (!single) __syncthreads();
+        const int kend = min(k0 + CW, ldw);
+        for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
+          const int nu = idx / (kend - k0), i = idx - nu * (kend - k0);
+          const int col = k0 + i;
+          double    v   = 0.0;
+          if (col < w) {
+            v = bb[(long long)nu * d.n + d.perm[d.c0 + col]];
+            for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
+          }
+          lds[nu * CW + i] = v;
+        }
+        __syncthreads();
+      }
+      const int cmax = min(lmax, k0 + CW);
+      for (int c = k0 + 2 * lane; c < cmax; c += 128) {
+        double2 a[FWD_PASSES];
+#pragma unroll
+        for (int p = 0; p < FWD_PASSES; ++p) a[p] = c < lim[p] ? *reinterpret_cast<const double2 *>(d.F + (long long)row[p] * ldw + c) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) {
+          const double2 l = *reinterpret_cast<const double2 *>(&lds[nu * CW + (c - k0)]);
+#pragma unroll
+          for (int p = 0; p < FWD_PASSES; ++p) acc[p][nu] = fma(a[p].x, l.x, fma(a[p].y, l.y, acc[p][nu]));
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p)
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        double s = acc[p][nu];
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0 && row[p] < rend) sums[nu * 64 + (row[p] - t.r0)] = s;
+      }
+  }
+  // epilogue: one thread per row of the tile (tiles have at most 64 rows)
+  __syncthreads();
+  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+}
+
+template <int MU>
+__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *yb, double *xb, double *xo)
+{
+  const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int     w = d.w, ldw = d.ldw, h = d.w + d.nb;
+  const int     g    = lanes_per_row(ldw);
+  const int     R    = 64 / g;
+  const int     sub = lane / g, gl = lane - sub * g;
   constexpr int RCH = LDS_DOUBLES / MU; // rows of v staged per chunk
-  const double *yb  = y + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *xb  = xw + d.voff * mu_total + (long long)nu0 * d.n;
   const int     col = t.r0 + 2 * gl;    // this lane owns columns col, col+1
   const bool    colok = col < ldw;
   double        acc[MU][2];
@@ -197,7 +321,6 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
   }
   __syncthreads();
   if (wave == 0 && sub == 0 && colok) {
-    double *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
@@ -212,6 +335,50 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
         }
       }
   }
+}
+
+// One launch per level and direction: the first nblock workgroups take block-level tiles, the others four wave-level
+// tiles each (the two kinds of one level run side by side).
+template <int MU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  Tile t;
+  int  lane = -1;
+  if ((int)blockIdx.x < nblock) t = btiles[blockIdx.x];
+  else {
+    const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
+    if (tix >= nwave) return; // whole wavefront leaves; the wave-level path has no workgroup barrier
+    t    = wtiles[tix];
+    lane = threadIdx.x & 63;
+  }
+  const SnDesc  d  = sns[t.sn];
+  const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+  double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+  double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+  if (lane < 0) fwd_block_tile<MU>(d, t, lds, bb, yb, Ub);
+  else fwd_wave_tile<MU>(d, t, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), bb, yb, Ub);
+}
+
+template <int MU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  Tile t;
+  int  lane = -1;
+  if ((int)blockIdx.x < nblock) t = btiles[blockIdx.x];
+  else {
+    const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
+    if (tix >= nwave) return;
+    t    = wtiles[tix];
+    lane = threadIdx.x & 63;
+  }
+  const SnDesc  d  = sns[t.sn];
+  const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+  double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+  double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
+  if (lane < 0) bwd_block_tile<MU>(d, t, lds, yb, xb, xo);
+  else bwd_wave_tile<MU>(d, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), yb, xb, xo);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -273,7 +440,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     bytes_alg_per_rhs1 += 2.0 * (double)fs[f]->nnz_exact * 8.0 + 4.0 * (double)fs[f]->n * 8.0;
   }
   std::vector<SnDesc>           descs;
-  std::vector<std::vector<Tile>> ft(nlev), bt(nlev);
+  std::vector<std::vector<Tile>> tl[4];
+  for (auto &v : tl) v.assign(nlev, {});
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     for (idx_t k = 0; k < D.nblk; ++k) {
@@ -297,32 +465,47 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.pad_  = 0;
       const int id = (int)descs.size();
       descs.push_back(d);
-      const int h = d.w + d.nb, g = lanes_per_row(d.ldw), R = 64 / g, TR = 4 * R * FWD_PASSES;
-      const int lev = D.height[k];
-      for (int r0 = 0; r0 < h; r0 += TR) ft[lev].push_back(Tile{id, r0, std::min(TR, h - r0)});
-      if (d.ldw <= 128) bt[lev].push_back(Tile{id, 0, d.ldw});
-      else
-        for (int c0 = 0; c0 < d.w; c0 += 128) bt[lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0)});
+      const int h = d.w + d.nb, lev = D.height[k];
+      if (d.ldw <= NARROW) {
+        // forward: ~16 KiB of panel per wavefront tile (at most WAVE_ROWS rows)
+        const int R   = 64 / (d.ldw / 2);
+        int       trw = std::max(FWD_PASSES * R, (2048 / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
+        trw           = std::min(trw, WAVE_ROWS);
+        for (int r0 = 0; r0 < h; r0 += trw) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(trw, h - r0)});
+        // backward: whole supernode per wavefront while it is small, else one workgroup
+        if (h <= WAVE_ROWS && (long long)h * d.ldw <= 4096) tl[BWD_WAVE][lev].push_back(Tile{id, 0, d.ldw});
+        else tl[BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw});
+      } else {
+        // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
+        const int trb = d.w <= 960 ? 64 : (d.w <= 3968 ? 32 : 16);
+        for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0)});
+        for (int c0 = 0; c0 < d.w; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0)});
+      }
     }
   }
-  std::vector<Tile> fall, ball;
-  flev_ptr.assign(nlev + 1, 0);
-  blev_ptr.assign(nlev + 1, 0);
-  for (int l = 0; l < nlev; ++l) {
-    // largest tiles first inside a level: the long streams start early, the small ones fill the tail
-    auto cost = [&](const Tile &t) { return (long long)t.nr * descs[t.sn].ldw; };
-    std::stable_sort(ft[l].begin(), ft[l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
-    fall.insert(fall.end(), ft[l].begin(), ft[l].end());
-    ball.insert(ball.end(), bt[l].begin(), bt[l].end());
-    flev_ptr[l + 1] = (int)fall.size();
-    blev_ptr[l + 1] = (int)ball.size();
+  std::vector<Tile> all;
+  for (int kd = 0; kd < 4; ++kd) {
+    lev_ptr[kd].assign(nlev + 1, 0);
+    lev_lds[kd].assign(nlev, 0);
   }
-  sn.upload(descs, s);
-  ftiles.upload(fall, s);
-  btiles.upload(ball, s);
-  HIP_OK(hipStreamSynchronize(s));
   launches_per_solve = 0;
-  for (int l = 0; l < nlev; ++l) launches_per_solve += (flev_ptr[l + 1] > flev_ptr[l]) + (blev_ptr[l + 1] > blev_ptr[l]);
+  for (int kd = 0; kd < 4; ++kd)
+    for (int l = 0; l < nlev; ++l) {
+      // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
+      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(descs[t.sn].w + descs[t.sn].nb) * t.nr; };
+      std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
+      lev_ptr[kd][l] = (int)all.size();
+      all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
+    }
+  for (int kd = 0; kd < 4; ++kd) {
+    // lev_ptr[kd][l]..lev_end: store the end of each range in a parallel array (ranges of different kinds interleave)
+    lev_end[kd].assign(nlev, 0);
+    for (int l = 0; l < nlev; ++l) lev_end[kd][l] = lev_ptr[kd][l] + (int)tl[kd][l].size();
+  }
+  for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty());
+  sn.upload(descs, s);
+  tiles.upload(all, s);
+  HIP_OK(hipStreamSynchronize(s));
 }
 
 void SolvePlan::reserve(int mu)
@@ -338,13 +521,16 @@ template <int MU>
 static void solve_block(SolvePlan &P, const double *b, double *x, int mu_total, int nu0, hipStream_t s)
 {
   // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels
+  const size_t lds_block = (size_t)LDS_DOUBLES * sizeof(double), lds_wave = (size_t)4 * WAVE_ROWS * MU * sizeof(double);
+  static_assert(4 * WAVE_ROWS * MU <= LDS_DOUBLES || MU > 4, "wave-level LDS must fit the block-level allocation");
+  auto cnt = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   for (int l = 0; l < P.nlev; ++l) {
-    const int nt = P.flev_ptr[l + 1] - P.flev_ptr[l];
-    if (nt) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU>), dim3(nt), dim3(WG_THREADS), 0, s, P.sn.p, P.ftiles.p + P.flev_ptr[l], b, P.y.p, P.U.p, mu_total, nu0);
+    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
+    if (nb + nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), nb ? std::max(lds_block, lds_wave) : lds_wave, s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nt = P.blev_ptr[l + 1] - P.blev_ptr[l];
-    if (nt) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU>), dim3(nt), dim3(WG_THREADS), 0, s, P.sn.p, P.btiles.p + P.blev_ptr[l], P.y.p, P.xw.p, x, mu_total, nu0);
+    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
+    if (nb + nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), nb ? std::max(lds_block, lds_wave) : lds_wave, s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0);
   }
 }
 
