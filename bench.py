@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--n", type=int, default=128, help="global grid is n^3 cells per GPU")
     ap.add_argument("--subdomains", type=int, default=8)
     ap.add_argument("--mu", type=int, default=1)
+    ap.add_argument("--leaf", type=int, default=0, help="nested-dissection leaf size (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gmres", action="store_true")
     args = ap.parse_args()
@@ -59,7 +60,7 @@ def main():
     t0 = time.time()
     subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth")
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    opts = "-hpddm_operator_spd" + (" -hpddm_keep_plain 1" if want_cpu else "")
+    opts = "-hpddm_operator_spd" + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "")
     A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
     A.call_numfact()
     t_setup = time.time() - t0

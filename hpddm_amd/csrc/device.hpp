@@ -62,9 +62,13 @@ struct SnDesc {
 };
 
 struct Tile {
-  int sn; // index into the batch SnDesc array
-  int r0; // forward: first row of the tile; backward: first column
-  int nr; // rows (forward) / columns (backward) in the tile
+  int sn;     // index into the batch SnDesc array
+  int r0;     // forward: first row of the tile; backward: first column
+  int nr;     // rows (forward) / columns (backward) in the tile
+  int part;   // backward, wide panels: this workgroup sums rows [rbeg, rend) only ...
+  int nparts; // ... as one of nparts workgroups; the last one to arrive adds the partial sums in a fixed order
+  int group;  // index of the arrival counter / partial-sum slot shared by the parts
+  int rbeg, rend;
 };
 
 // A factor resident in HBM.
@@ -97,6 +101,9 @@ struct SolvePlan {
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U;
+  int            ngroups = 0, max_parts = 1; // split-row backward tiles
+  DevBuf<double> partials;                    // [group][part][MU][128]
+  DevBuf<int>    arrivals;                    // [group], zero between solves
   double         bytes_alg_per_rhs1 = 0; // 2*nnz(L)*8 + 4*n*8 summed over the factors, mu = 1
   void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
   void reserve(int mu);

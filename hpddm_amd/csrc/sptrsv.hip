@@ -247,10 +247,10 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
 }
 
 template <int MU>
-__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *yb, double *xb, double *xo)
+__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int     w = d.w, ldw = d.ldw, h = d.w + d.nb;
+  const int     w = d.w, ldw = d.ldw;
   const int     g    = lanes_per_row(ldw);
   const int     R    = 64 / g;
   const int     sub = lane / g, gl = lane - sub * g;
@@ -260,10 +260,9 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   double        acc[MU][2];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc[nu][0] = acc[nu][1] = 0.0;
-  // rows above the tile's first column hold zeros in these columns (triangular top block)
-  const int istart = (t.r0 / (4 * R)) * (4 * R);
-  for (int i0 = istart; i0 < h; i0 += RCH) {
-    const int rch = min(RCH, h - i0);
+  // rows above the tile's first column hold zeros in these columns (triangular top block): rows [t.rbeg, t.rend) only
+  for (int i0 = t.rbeg; i0 < t.rend; i0 += RCH) {
+    const int rch = min(RCH, t.rend - i0);
     for (int idx = tid; idx < rch * MU; idx += WG_THREADS) {
       const int nu = idx / rch, ii = idx - nu * rch;
       const int i = i0 + ii;
@@ -320,32 +319,73 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
     }
   }
   __syncthreads();
-  if (wave == 0 && sub == 0 && colok) {
+  if (t.nparts == 1) {
+    if (wave == 0 && sub == 0 && colok) {
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu)
+      for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = col + k;
-        if (c < w) {
-          double s = 0.0;
+        for (int k = 0; k < 2; ++k) {
+          const int c = col + k;
+          if (c < w) {
+            double s = 0.0;
 #pragma unroll
-          for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
-          xb[(long long)nu * d.n + d.c0 + c]         = s;
-          xo[(long long)nu * d.n + d.perm[d.c0 + c]] = s;
+            for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
+            xb[(long long)nu * d.n + d.c0 + c]         = s;
+            xo[(long long)nu * d.n + d.perm[d.c0 + c]] = s;
+          }
         }
+    }
+    return;
+  }
+  // ---- split rows: publish this part's sums write-through, the last part to arrive (agent-scope counter) reduces ----
+  double *slot = partials + ((long long)t.group * max_parts) * (128 * MU);
+  if (tid < 128) {
+    const int gl2 = tid >> 1, k = tid & 1; // wide panels: g = 64, one column pair per lane of wave 0..1 -> thread tid owns column t.r0 + tid
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double s = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl2) * 2 + k];
+      // write-through (sc1) store: reaches memory without a release fence (one L2 write-back per workgroup would stall the XCD)
+      __hip_atomic_store(slot + ((long long)t.part * MU + nu) * 128 + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // (no static __shared__ here: it would shift the 16-byte alignment of the dynamic LDS base)
+  volatile int *s_last = reinterpret_cast<volatile int *>(lds + LDS_DOUBLES - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the barrier
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (old == t.nparts - 1);
+    *s_last        = last;
+    if (last) {
+      __hip_atomic_store(arrivals + t.group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next solve
+    }
+  }
+  __syncthreads();
+  if (*s_last && tid < 128) {
+    const int c = t.r0 + tid;
+    if (c < w) {
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        double s = 0.0;
+        for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * MU + nu) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
+        xb[(long long)nu * d.n + d.c0 + c]         = s;
+        xo[(long long)nu * d.n + d.perm[d.c0 + c]] = s;
       }
+    }
   }
 }
 
 // One launch per level and direction: the first nblock workgroups take block-level tiles, the others four wave-level
 // tiles each (the two kinds of one level run side by side).
-template <int MU>
+template <int MU, bool HAS_BLOCK>
 __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   Tile t;
   int  lane = -1;
-  if ((int)blockIdx.x < nblock) t = btiles[blockIdx.x];
+  if (HAS_BLOCK && (int)blockIdx.x < nblock) t = btiles[blockIdx.x];
   else {
     const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
     if (tix >= nwave) return; // whole wavefront leaves; the wave-level path has no workgroup barrier
@@ -356,17 +396,17 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
   const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
   double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
   double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-  if (lane < 0) fwd_block_tile<MU>(d, t, lds, bb, yb, Ub);
+  if (HAS_BLOCK && lane < 0) fwd_block_tile<MU>(d, t, lds, bb, yb, Ub);
   else fwd_wave_tile<MU>(d, t, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), bb, yb, Ub);
 }
 
-template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0)
+template <int MU, bool HAS_BLOCK>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   Tile t;
   int  lane = -1;
-  if ((int)blockIdx.x < nblock) t = btiles[blockIdx.x];
+  if (HAS_BLOCK && (int)blockIdx.x < nblock) t = btiles[blockIdx.x];
   else {
     const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
     if (tix >= nwave) return;
@@ -377,7 +417,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
   const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
   double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
   double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-  if (lane < 0) bwd_block_tile<MU>(d, t, lds, yb, xb, xo);
+  if (HAS_BLOCK && lane < 0) bwd_block_tile<MU>(d, t, lds, yb, xb, xo, partials, arrivals, max_parts);
   else bwd_wave_tile<MU>(d, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), yb, xb, xo);
 }
 
@@ -471,17 +511,53 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         const int R   = 64 / (d.ldw / 2);
         int       trw = std::max(FWD_PASSES * R, (2048 / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
         trw           = std::min(trw, WAVE_ROWS);
-        for (int r0 = 0; r0 < h; r0 += trw) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(trw, h - r0)});
+        for (int r0 = 0; r0 < h; r0 += trw) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(trw, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
-        if (h <= WAVE_ROWS && (long long)h * d.ldw <= 4096) tl[BWD_WAVE][lev].push_back(Tile{id, 0, d.ldw});
-        else tl[BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw});
+        if (h <= WAVE_ROWS && (long long)h * d.ldw <= 4096) tl[BWD_WAVE][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
+        else tl[BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         const int trb = d.w <= 960 ? 64 : (d.w <= 3968 ? 32 : 16);
-        for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0)});
-        for (int c0 = 0; c0 < d.w; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0)});
+        for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
+        for (int c0 = 0; c0 < d.w; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / 4) * 4, h});
       }
     }
+  }
+  // Backward sweep of the upper levels: few, long column tiles.  Split their rows over several workgroups so that a
+  // level still fields >= ~1024 workgroups; the parts meet through an arrival counter and the last one adds the partial
+  // sums in part order (deterministic).
+  ngroups   = 0;
+  max_parts = 1;
+  for (int l = 0; l < nlev; ++l) {
+    std::vector<Tile> &v = tl[BWD_BLOCK][l];
+    const int          T = (int)v.size();
+    if (T == 0 || T >= 512) continue;
+    const int want = std::min(16, (768 + T - 1) / T);
+    std::vector<Tile> out;
+    for (const Tile &t : v) {
+      const int rows = t.rend - t.rbeg;
+      const int np   = std::max(1, std::min(want, rows / 256));
+      if (np == 1) {
+        out.push_back(t);
+        continue;
+      }
+      const int len = ((rows + np - 1) / np + 63) / 64 * 64;
+      const int grp = ngroups++;
+      int       cnt = 0;
+      for (int p = 0; p < np; ++p)
+        if (t.rbeg + p * len < t.rend) ++cnt;
+      for (int p = 0; p < cnt; ++p) {
+        Tile q   = t;
+        q.part   = p;
+        q.nparts = cnt;
+        q.group  = grp;
+        q.rbeg   = t.rbeg + p * len;
+        q.rend   = std::min(t.rend, t.rbeg + (p + 1) * len);
+        out.push_back(q);
+      }
+      max_parts = std::max(max_parts, cnt);
+    }
+    v.swap(out);
   }
   std::vector<Tile> all;
   for (int kd = 0; kd < 4; ++kd) {
@@ -492,7 +568,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   for (int kd = 0; kd < 4; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
-      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(descs[t.sn].w + descs[t.sn].nb) * t.nr; };
+      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
@@ -505,6 +581,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty());
   sn.upload(descs, s);
   tiles.upload(all, s);
+  {
+    std::vector<int> zeros(std::max(1, ngroups), 0);
+    arrivals.upload(zeros, s);
+  }
   HIP_OK(hipStreamSynchronize(s));
 }
 
@@ -514,6 +594,7 @@ void SolvePlan::reserve(int mu)
   y.alloc((size_t)ntot * mu);
   xw.alloc((size_t)ntot * mu);
   U.alloc((size_t)std::max<long long>(utot, 1) * mu);
+  partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 8));
   mu_cap = mu;
 }
 
@@ -526,11 +607,13 @@ static void solve_block(SolvePlan &P, const double *b, double *x, int mu_total, 
   auto cnt = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
-    if (nb + nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), nb ? std::max(lds_block, lds_wave) : lds_wave, s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), std::max(lds_block, lds_wave), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), lds_wave, s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
-    if (nb + nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), nb ? std::max(lds_block, lds_wave) : lds_wave, s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0);
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), std::max(lds_block, lds_wave), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), lds_wave, s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts);
   }
 }
 
