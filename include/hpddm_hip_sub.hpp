@@ -1,0 +1,71 @@
+/* hpddm_hip_sub.hpp -- HPDDM::HipSub<K>: the MI355X local solver as a drop-in `Solver<K>` plug-in for the reference.
+ *
+ * The reference selects its local solver at compile time through the SUBDOMAIN macro (include/HPDDM.hpp:592-601,
+ * 639-644; examples/schwarz.cpp:90,158; interface/hpddm_c.cpp:139).  This header provides the concept that
+ * MumpsSub / MklPardisoSub / SuiteSparseSub / LapackTRSub implement (include/HPDDM_MUMPS.hpp:206-318,
+ * include/HPDDM_LAPACK.hpp:326-401) on top of the C ABI of libhpddm_hip.so (include/hpddm_hip.h):
+ *
+ *     g++ ... -include hpddm_hip_sub.hpp -DSUBDOMAIN=HPDDM::HipSub -DDLAPACK examples/schwarz.cpp ... -lhpddm_hip
+ *
+ * compiles the UNCHANGED reference driver with the factorisation on the host and every Solver::solve on the GPU
+ * (host vectors are staged through PCIe here; the device-resident path is HpddmHipSchwarz*).
+ * K = double only in this round.
+ */
+#ifndef HPDDM_HIP_SUB_HPP_
+#define HPDDM_HIP_SUB_HPP_
+
+#include <iostream>
+#include <type_traits>
+#include "hpddm_hip.h"
+
+namespace HPDDM {
+template <class K>
+class MatrixCSR;
+class Option;
+
+template <class K>
+class HipSub {
+  static_assert(std::is_same<K, double>::value, "HipSub: only K = double is built in this round");
+
+private:
+  HpddmHipSubdomain *S_;
+
+public:
+  HipSub() : S_() { }
+  HipSub(const HipSub &) = delete;
+  ~HipSub() { dtor(); }
+  static constexpr char numbering_ = 'C';
+  void                  dtor()
+  {
+    if (S_) HpddmHipSubdomainDestroy(S_);
+    S_ = nullptr;
+  }
+  /* Solver::numfact (include/HPDDM_MUMPS.hpp:228-291): called again on the same object => refactorisation */
+  template <char N = 'C'>
+  void numfact(MatrixCSR<K> *const &A, bool detection = false, K *const &schur = nullptr)
+  {
+    static_assert(N == 'C' || N == 'F', "Unknown numbering");
+    (void)schur;
+    /* Option is incomplete here (this header is force-included first): make the lookup dependent on K */
+    typedef typename std::conditional<std::is_same<K, double>::value, Option, void>::type Opt;
+    const bool spd = Opt::get()->template val<char>("operator_spd", 0) && !detection;
+    if (HpddmHipSubdomainNumfact(&S_, A->n_, A->ia_, A->ja_, A->a_, A->sym_ ? 1 : 0, N, spd ? 1 : 0) != 0) std::cerr << "BUG HipSub, numfact: " << HpddmHipLastError() << std::endl; /* same error style as HPDDM_MUMPS.hpp:288 */
+  }
+  template <char N = 'C'>
+  int inertia(MatrixCSR<K> *const &)
+  {
+    return 0;
+  }
+  unsigned short deficiency() const { return 0; }
+  /* Solver::solve, in place and out of place (include/HPDDM_MUMPS.hpp:304-317) */
+  void solve(K *const x, const unsigned short &n = 1) const
+  {
+    if (HpddmHipSubdomainSolve(S_, x, x, n) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
+  }
+  void solve(const K *const b, K *const x, const unsigned short &n = 1) const
+  {
+    if (HpddmHipSubdomainSolve(S_, b, x, n) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
+  }
+};
+} // namespace HPDDM
+#endif /* HPDDM_HIP_SUB_HPP_ */

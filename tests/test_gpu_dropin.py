@@ -1,0 +1,55 @@
+"""Drop-in check: the UNCHANGED reference programs, compiled around our local solver through the Solver<K> plug-in
+(include/hpddm_hip_sub.hpp, -DSUBDOMAIN=HPDDM::HipSub; recipe oracle/Makefile.ref), run under MPI on the GPU box and
+reproduce the reference's own results (iteration counts of BASELINE.md section 2)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def _have():
+    return os.path.exists(os.path.join(REF, "schwarz_hipsub")) and os.path.exists(MPIEXEC)
+
+
+def _run(np_, args, exe="schwarz_hipsub"):
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", HPDDM_HIP_NUM_THREADS="4")
+    cmd = [MPIEXEC, "-n", str(np_), os.path.join(REF, exe)] + args.split()
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "BUG HipSub" not in res.stderr, res.stderr[-2000:]
+    return res.stdout
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref/schwarz_hipsub not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("args,its,resid", [
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -hpddm_gmres_restart=25 -hpddm_max_it 80", 19, 1.428088e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -symmetric_csr=1 -hpddm_operator_spd", 19, 1.747862e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0", 17, 3.415834e-05),
+    ("-hpddm_verbosity=1 -Nx 200 -Ny 200", 45, 1.660748e-04),
+])
+def test_unchanged_schwarz_cpp_with_hip_local_solver(args, its, resid):
+    out = _run(4, args)
+    m = re.search(r"GMRES converges after (\d+) iteration", out)
+    assert m and int(m.group(1)) == its, out[-1500:]
+    r = re.search(r"--- residual = (\S+) / (\S+)", out)
+    assert r and abs(float(r.group(1)) - resid) <= 5e-4 * resid, out[-500:]
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref not built")
+def test_unchanged_single_rank_direct_solve_and_local_solver_benchmark(tmp_path):
+    mat = str(tmp_path / "mat.txt")
+    out = _run(1, f"-Nx 40 -Ny 40 -hpddm_dump_matrices={mat}")
+    r = re.search(r"--- residual = (\S+) / (\S+)", out)
+    assert r and float(r.group(1)) / float(r.group(2)) <= 1e-6  # examples/schwarz.cpp:178
+    assert os.path.exists(mat)
+    # benchmark/local_solver.cpp:92-127 protocol: one line per trial, seconds for nu = 1, 2, 4
+    out = _run(1, f"{mat} -rhs=4 -solve_phase_only=1", exe="local_solver_hipsub")
+    rows = [re.findall(r"\d\.\d+e[-+]\d+", ln) for ln in out.strip().splitlines() if re.match(r"^\s*\d\.\d+e[-+]\d+", ln)]
+    assert len(rows) == 3 and all(len(r) == 3 for r in rows), out  # 3 trials x (nu = 1, 2, 4)
