@@ -1,0 +1,143 @@
+// The two tall-skinny dense contractions of the coarse correction on the MFMA pipe (v_mfma_f64_16x16x4_f64):
+//      uc  = Z^T (D r)      (nu x n) . (n x mu)            Schwarz::deflation, include/HPDDM_schwarz.hpp:1613-1616 (Wrapper::diag + Blas::gemm "T","N")
+//      out = Z y            (n x nu) . (nu x mu)           include/HPDDM_schwarz.hpp:1618                            (Blas::gemm "N","N")
+// Z is column-major n x nu (leading dimension n, Preconditioner::ev_), batched over the subdomains of the GPU.
+// Arithmetic intensity is mu/4 flop/B, so both stay HBM-bound for mu <= 8: the MFMA unit is used because
+// the operation IS a dense contraction (the 16 x 16 x 4 tile contracts 4 rows of Z against the right-hand sides of
+// all mu columns at once); what is reported is both GB/s and MFMA busy cycles.
+//
+// f64 MFMA fragment layout on gfx950 (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], C/D[row = (lane>>4) + 4*reg][col = lane&15].
+#include "schwarz.hpp"
+
+namespace hpddm_hip {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+static constexpr int ZT_ROWS = 128;           // rows of Z staged per workgroup tile
+static constexpr int ZT_LD   = ZT_ROWS + 4;   // LDS leading dimension: column stride of 8 dwords mod 64 -> <= 2-way conflicts
+static constexpr int ZT_NU   = 32;            // deflation vectors per pass (two 16-wide M tiles)
+static constexpr int ZT_MU   = 16;            // right-hand sides per pass (one N tile)
+
+// partial[s][blk][m][nn] = sum over the rows of the block of Z[i, m0+m] * d[i] * in[i, nu0+nn]
+// grid: (blocks per subdomain, nsub); 256 threads = 4 wavefronts, each contracting 32 rows of a 128-row tile per tile
+__global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int mu, int m0, int nu0)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *zs = lds;                    // [ZT_NU][ZT_LD]
+  double *rs = lds + ZT_NU * ZT_LD;    // [ZT_MU][ZT_LD]   d * in
+  const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  const int       tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int       mcols = min(ZT_NU, nu_s - m0), ncols = min(ZT_MU, mu - nu0);
+  v4f64           acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  const double   *Zs = Z + zoff[s] + (long long)m0 * n;
+  if (mcols > 0) {
+    for (int i0 = blockIdx.x * ZT_ROWS; i0 < n; i0 += gridDim.x * ZT_ROWS) {
+      // stage: consecutive threads read consecutive rows of one column (coalesced), zero beyond n / beyond the live columns
+      for (int idx = tid; idx < ZT_NU * ZT_ROWS; idx += 256) {
+        const int c = idx / ZT_ROWS, r = idx - c * ZT_ROWS;
+        zs[c * ZT_LD + r] = (c < mcols && i0 + r < n) ? Zs[(long long)c * n + i0 + r] : 0.0;
+      }
+      for (int idx = tid; idx < ZT_MU * ZT_ROWS; idx += 256) {
+        const int c = idx / ZT_ROWS, r = idx - c * ZT_ROWS;
+        rs[c * ZT_LD + r] = (c < ncols && i0 + r < n) ? d[v0 + i0 + r] * in[v0 * mu + (long long)(nu0 + c) * n + i0 + r] : 0.0;
+      }
+      __syncthreads();
+      const int m = lane & 15, k = lane >> 4, rb = wave * (ZT_ROWS / 4);
+#pragma unroll
+      for (int j = 0; j < ZT_ROWS / 16; ++j) {
+        const int    r  = rb + 4 * j + k;
+        const double b  = rs[m * ZT_LD + r];          // B[k][j = lane&15] = (d r)[row, rhs m]
+        const double a0 = zs[m * ZT_LD + r];          // A[i = lane&15][k]  = Z[row, m]
+        const double a1 = zs[(16 + m) * ZT_LD + r];
+        acc0            = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+        acc1            = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // D[row = (lane>>4) + 4*reg][col = lane&15]: row = deflation vector, col = right-hand side; add the 4 wavefronts
+  double *red = lds; // [4][2][16][16]
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+    red[((wave * 2 + 0) * 16 + row) * 16 + col] = acc0[reg];
+    red[((wave * 2 + 1) * 16 + row) * 16 + col] = acc1[reg];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * 16 * 16; idx += 256) {
+    double v = 0.0;
+    for (int w = 0; w < 4; ++w) v += red[w * 512 + idx];
+    partial[((long long)(s * gridDim.x + blockIdx.x)) * 512 + idx] = v; // [mt][row][col]
+  }
+}
+
+// uc[nu][coff[s] + m] = sum_blk partial[s][blk][m - m0][nu - nu0]   (fixed order => reproducible)
+__global__ void k_zt_reduce(const double *__restrict__ partial, int nblk, const int *__restrict__ nus, const int *__restrict__ coff, double *__restrict__ uc, int mu, int cdim, int m0, int nu0)
+{
+  const int s = blockIdx.x;
+  for (int idx = threadIdx.x; idx < 512; idx += blockDim.x) {
+    const int m = m0 + idx / 16, nn = nu0 + (idx & 15);
+    if (m >= nus[s] || nn >= mu) continue;
+    double v = 0.0;
+    for (int b = 0; b < nblk; ++b) v += partial[((long long)(s * nblk + b)) * 512 + idx];
+    uc[(long long)nn * cdim + coff[s] + m] = v;
+  }
+}
+
+// out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu] ; each wavefront produces 64 rows x (<= 16 rhs)
+__global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0)
+{
+  const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int       m = lane & 15, k = lane >> 4;
+  const double   *Zs = Z + zoff[s];
+  const int       ncols = min(ZT_MU, mu - nu0);
+  for (int i0 = (blockIdx.x * 4 + wave) * 64; i0 < n; i0 += gridDim.x * 256) {
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
+    for (int k0 = 0; k0 < nu_s; k0 += 4) {
+      const int    kk = k0 + k;
+      const double b  = (kk < nu_s && m < ncols) ? y[(long long)(nu0 + m) * cdim + coff[s] + kk] : 0.0; // B[k][j = lane&15]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int    r = i0 + 16 * t + m;
+        const double a = (kk < nu_s && r < n) ? Zs[(long long)kk * n + r] : 0.0;                            // A[i = lane&15][k]
+        acc[t]         = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    // D[row = (lane>>4) + 4*reg][col = lane&15]
+    if (m < ncols) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = i0 + 16 * t + (lane >> 4) + 4 * reg;
+          if (r < n) out[v0 * mu + (long long)(nu0 + m) * n + r] = acc[t][reg];
+        }
+    }
+  }
+}
+
+void Schwarz::deflation_panel(const double *in, double *zy, int mu)
+{
+  hipStream_t st = library_stream();
+  int         numax = 0;
+  for (const auto &S : subs) numax = std::max(numax, S.nu);
+  const int    nblk = std::max(1, std::min(128, (nmax + ZT_ROWS - 1) / ZT_ROWS));
+  const size_t lds  = (size_t)(ZT_NU + ZT_MU) * ZT_LD * sizeof(double);
+  zt_partial.alloc((size_t)nsub * nblk * 512);
+  for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
+    for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
+      hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc_d.p, mu, cdim, m0, nu0);
+    }
+  coarse_solve(uc_d.p, uc2_d.p, mu);
+  for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
+    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, mu, cdim, nu0);
+}
+
+} // namespace hpddm_hip

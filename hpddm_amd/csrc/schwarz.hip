@@ -107,29 +107,6 @@ __global__ void k_sum_partials(const double *__restrict__ partial, int nblk, dou
   out[o] = s;
 }
 
-// ---- deflation panel (first version: wave reductions; the MFMA version lives in deflation_mfma.hip) ----
-// uc[coff[s] + k][nu] = sum_i Z_s[i,k] * d_s[i] * in[s][nu][i] ; grid: (nu_max, nsub), one workgroup per (k, s)
-__global__ void k_zt(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ uc, int mu, int cdim)
-{
-  const int s = blockIdx.y, k = blockIdx.x;
-  if (k >= nus[s]) return;
-  const int       n  = nn[s];
-  const long long v0 = voff[s];
-  const double   *zk = Z + zoff[s] + (long long)k * n;
-  __shared__ double red[256];
-  for (int nu = 0; nu < mu; ++nu) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = fma(zk[i] * d[v0 + i], in[v0 * mu + (long long)nu * n + i], acc);
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) uc[(long long)nu * cdim + coff[s] + k] = red[0];
-    __syncthreads();
-  }
-}
 // y = Einv * x for mu columns (cdim x cdim row-major Einv), one workgroup per column block
 __global__ void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int mu)
 {
@@ -142,19 +119,6 @@ __global__ void k_coarse(const double *__restrict__ Einv, const double *__restri
     y[o] = acc;
   }
 }
-// out[s][nu][i] = sum_k Z_s[i,k] uc[coff[s]+k][nu]
-__global__ void k_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ uc, double *__restrict__ out, int mu, int cdim)
-{
-  const int s = blockIdx.y, n = nn[s], nu_s = nus[s];
-  const long long v0 = voff[s];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    for (int nu = 0; nu < mu; ++nu) {
-      double acc = 0.0;
-      for (int k = 0; k < nu_s; ++k) acc = fma(Z[zoff[s] + (long long)k * n + i], uc[(long long)nu * cdim + coff[s] + k], acc);
-      out[v0 * mu + (long long)nu * n + i] = acc;
-    }
-}
-
 // ------------------------------------------------------------------ host side ----------------------------------
 Schwarz::Schwarz(int nsub_, int first_, int nglobal_) : nsub(nsub_), first(first_), nglobal(nglobal_), subs(nsub_)
 {
@@ -530,13 +494,13 @@ void Schwarz::deflation(const double *in, double *out, int mu)
   // Schwarz::deflation (include/HPDDM_schwarz.hpp:1602-1622): out = exchange(Z E^{-1} Z^T D in)
   HH_CHECK(coarse_ready, "deflation before BuildCoarseOperator");
   reserve(mu);
-  hipStream_t st = library_stream();
-  int numax = 0;
-  for (const auto &S : subs) numax = std::max(numax, S.nu);
-  hipLaunchKernelGGL(k_zt, dim3((unsigned)numax, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, in, uc_d.p, mu, cdim);
-  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, st, Einv_d.p, uc_d.p, uc2_d.p, cdim, mu);
-  hipLaunchKernelGGL(k_z, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, w3.p, mu, cdim);
+  deflation_panel(in, w3.p, mu);
   exchange(w3.p, out, mu, true);
+}
+
+void Schwarz::coarse_solve(const double *uc, double *y, int mu)
+{
+  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, library_stream(), Einv_d.p, uc, y, cdim, mu);
 }
 
 void Schwarz::apply(const double *in, double *out, int mu)

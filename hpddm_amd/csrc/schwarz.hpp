@@ -60,7 +60,7 @@ struct Schwarz {
   std::vector<int>    coff; // nsub+1
   DevBuf<int>         coff_d, nu_d;
   DevBuf<long long>   zoff_d;
-  DevBuf<double>      Z_d, Einv_d, uc_d, uc2_d;
+  DevBuf<double>      Z_d, Einv_d, uc_d, uc2_d, zt_partial;
   std::vector<double> E, Einv;
   // work vectors
   int            mu_cap = 0;
@@ -87,6 +87,8 @@ struct Schwarz {
   void gmv(const double *in, double *out, int mu);
   void local_solve(const double *in, double *out, int mu);
   void deflation(const double *in, double *out, int mu);
+  void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip)
+  void coarse_solve(const double *uc, double *y, int mu);     // y = E^{-1} uc
   void apply(const double *in, double *out, int mu);
   void diag(const double *in, double *out, int mu);
   void axpy(double alpha, const double *x, double *y, long long cnt);
