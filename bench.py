@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=128, help="global grid is n^3 cells per GPU")
+    ap.add_argument("--grid", dest="n", type=int, default=128, help="global grid is grid^3 cells per GPU")
     ap.add_argument("--subdomains", type=int, default=8)
     ap.add_argument("--mu", type=int, default=1)
     ap.add_argument("--leaf", type=int, default=0, help="nested-dissection leaf size (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gmres", action="store_true")
+    ap.add_argument("--no-two-level", action="store_true")
+    ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -40,15 +42,25 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # BENCH_SHARE_GPU=1 (development only): all ranks use GPU 0 and rendezvous over gloo, to exercise the multi-process
+    # code path on a single-GPU box
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
+        local = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local)
+    cpu_coll = share and world > 1
 
     from hpddm_amd import _lib, hpddm
     from hpddm_amd.generate import generate3d
@@ -89,7 +101,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if cpu_coll else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -126,12 +138,39 @@ def main():
             torch.cuda.synchronize()
             tg = time.perf_counter() - t0
             out["gmres"] = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
+        if not args.no_two_level:
+            out["two_level"] = two_level(A, subs, args, np, mu, reps)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(A, subs, d, args, np)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def two_level(A, subs, args, np, mu, reps):
+    """configs[2] flavour on the same operator: deflated two-level apply with nu deflation vectors per subdomain.  GenEO's
+    eigensolver is a later row of SURVEY section 8(f); for kernel timing the vectors are the 20 monomials of degree <= 3 in
+    the local coordinates, the coarse operator E = Z^T A Z is assembled and inverted as in the reference."""
+    nu = args.geneo_nu
+    expo = [(a, b, c) for deg in range(8) for a in range(deg + 1) for b in range(deg + 1 - a) for c in [deg - a - b]][:nu]
+    for s, sd in enumerate(subs):
+        i0, i1, j0, j1, k0, k1 = sd["box"]
+        z, y, x = np.meshgrid(np.linspace(-1, 1, k1 - k0), np.linspace(-1, 1, j1 - j0), np.linspace(-1, 1, i1 - i0), indexing="ij")
+        Z = np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo], axis=1)
+        A.set_vectors(s, Z)
+    t0 = time.time()
+    A.build_coarse_operator()
+    t_coarse = time.time() - t0
+    A.set_option("schwarz_coarse_correction", 0)  # deflated
+    t_defl = A.time("deflation", mu=mu, warmup=2, reps=reps)
+    t_apply = A.time("apply", mu=mu, warmup=2, reps=reps)
+    A.set_option("schwarz_coarse_correction", -1)
+    n = A.stats()["n"]
+    bytes_panel = 2.0 * n * nu * 8.0 + 3.0 * n * mu * 8.0   # SURVEY 8(d): Z read twice + D r read, Z y written, ...
+    return {"geneo_nu": nu, "coarse_dim": int(A.stats()["coarse_dim"]), "deflation_ms": t_defl * 1e3, "apply_ms": t_apply * 1e3,
+            "applies_per_sec": 1.0 / t_apply, "deflation_panel_GBps": bytes_panel / t_defl / 1e9, "deflation_flops": 4.0 * n * nu * mu,
+            "coarse_setup_seconds": round(t_coarse, 2), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64)"}
 
 
 def cpu_baseline(A, subs, d, args, np):
