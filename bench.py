@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--subdomains", type=int, default=8)
     ap.add_argument("--mu", type=int, default=1)
     ap.add_argument("--leaf", type=int, default=0, help="nested-dissection leaf size (0 = library default)")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent 8-subdomain blocks per GPU instead of one global problem with a cross-GPU halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gmres", action="store_true")
     ap.add_argument("--no-two-level", action="store_true")
@@ -70,10 +71,22 @@ def main():
 
     # ---- build the operator (one-time: generator, analysis, factorisation, upload) ----
     t0 = time.time()
-    subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth")
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     opts = "-hpddm_operator_spd" + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "")
-    A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
+    sharded = world > 1 and not args.replicas
+    if sharded:
+        # ONE global problem: grid^2 x (grid * N) cells, 2 x 2 x 2N boxes; rank r owns the 8 subdomains of its z-slab and
+        # exchanges the halo of the two slab faces with ranks r-1 / r+1 (RCCL point-to-point over xGMI)
+        assert args.subdomains == 8
+        parts = 8 * world
+        subs = generate3d((args.n, args.n, args.n * world), parts, overlap=1, sym=True, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8,
+                          normalize=True)
+        A, d = hpddm.schwarz_from_subdomains(subs, first_global=8 * rank, nglobal=parts, options=opts, multiplicity=False,
+                                             partition=(rank, [8 * r for r in range(world + 1)]))
+        A.enable_distributed(dist, dev, mu_cap=max(1, args.mu), host_staging=cpu_coll)
+    else:
+        subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth")
+        A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
     A.call_numfact()
     t_setup = time.time() - t0
     st = A.stats()
@@ -113,11 +126,30 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: 3-D Poisson {args.n}^3 per GPU, {args.subdomains} subdomains per GPU, one-level RAS, "
                                f"HIP level-scheduled SpTRSV, overlap 1, mu={mu}",
-                   "parallelism": "replicas (one 8-subdomain block per GPU, no cross-GPU halo this round)" if world > 1 else "1 GPU, 8 subdomains batched",
+                   "parallelism": ("1 GPU, 8 subdomains batched" if world == 1 else
+                                   (f"{world} GPUs, one global {args.n}x{args.n}x{args.n * world} problem, 8 subdomains per GPU, cross-GPU halo by RCCL send/recv" if sharded
+                                    else "replicas (one independent 8-subdomain block per GPU)")),
                    "n_dof_per_gpu": ntot, "nnz_L_per_gpu": st["nnz_L"], "levels": st["levels"], "launches_per_sptrsv": st["launches"],
                    "setup_seconds": round(t_setup, 2)},
     }
+    gm = None
+    if sharded and not args.no_gmres:
+        # GMRES on the global problem: every rank takes part (halo + all-reduce inside)
+        fb = torch.from_numpy(np.concatenate([s["f"] for s in subs])).to(dev)
+        xs = torch.zeros_like(fb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = A.solve_device(fb.data_ptr(), xs.data_ptr(), 1)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - t0
+        gm = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
+    ph = None
+    if sharded:
+        # collective: every rank runs the same calls
+        ph = {"exchange": A.time("exchange", mu=mu, reps=10) * 1e3, "gmv": A.time("gmv", mu=mu, reps=10) * 1e3}
     if rank == 0:
+        if gm:
+            out["gmres"] = gm
         # ---- roofline of the dominant kernel pair (batched SpTRSV), HIP events on the library stream ----
         reps = max(5, min(50, args.steps))
         t_solve = A.time("solve", mu=mu, warmup=2, reps=reps)
@@ -127,8 +159,12 @@ def main():
                            "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep = %d launches)" % int(st["launches"]),
                            "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve,
                            "stored_bytes_per_sweep": 2.0 * st["stored"] * 8.0}
-        out["phases_ms"] = {"sptrsv": t_solve * 1e3, "exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3}
-        if not args.no_gmres:
+        out["phases_ms"] = {"sptrsv": t_solve * 1e3}
+        if not sharded:  # exchange / GMV of a sharded operator are collective: timed on all ranks below
+            out["phases_ms"].update({"exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3})
+        elif ph:
+            out["phases_ms"].update(ph)
+        if not args.no_gmres and world == 1:
             f = [s["f"] for s in subs]
             fb = torch.from_numpy(np.concatenate(f)).to(dev)
             xs = torch.zeros_like(fb)
@@ -138,7 +174,7 @@ def main():
             torch.cuda.synchronize()
             tg = time.perf_counter() - t0
             out["gmres"] = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
-        if not args.no_two_level:
+        if not args.no_two_level and world == 1:
             out["two_level"] = two_level(A, subs, args, np, mu, reps)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(A, subs, d, args, np)

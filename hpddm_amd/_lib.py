@@ -56,6 +56,10 @@ def _declare(lib):
         "HpddmHipSchwarzLocalSolve": (I, [P, P, P, US]),
         "HpddmHipSchwarzComputeResidual": (I, [P, P, P, P, US]),
         "HpddmHipSolve": (I, [P, P, P, I, P, I]),
+        "HpddmHipSchwarzSetPartition": (I, [P, I, I, P]),
+        "HpddmHipSchwarzHaloPeers": (I, [P, I, P, P, P]),
+        "HpddmHipSchwarzSetTransport": (I, [P, P, P, P, P, P, I]),
+        "HpddmHipSchwarzHaloExport": (LL, [P, C, P, LL]),
         "HpddmHipSchwarzApplyDevice": (I, [P, P, P, US]),
         "HpddmHipSchwarzGMVDevice": (I, [P, P, P, US]),
         "HpddmHipSolveDevice": (I, [P, P, P, I, P, I]),

@@ -225,6 +225,72 @@ int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, doub
   }
 }
 
+int HpddmHipSchwarzSetPartition(HpddmHipSchwarz *A, int nranks, int rank, const int *firsts)
+{
+  HH_TRY(
+    HH_CHECK(A && firsts, "null argument");
+    A->op.set_partition(nranks, rank, firsts);
+    return 0;)
+}
+int HpddmHipSchwarzHaloPeers(HpddmHipSchwarz *A, int cap, int *peer_ranks, long long *counts, long long *offsets)
+{
+  try {
+    HH_CHECK(A, "null argument");
+    A->op.build_halo_lists();
+    const int np = (int)A->op.peers.size();
+    if (peer_ranks && counts && offsets) {
+      HH_CHECK(cap >= np, "HaloPeers: arrays too small");
+      for (int p = 0; p < np; ++p) {
+        peer_ranks[p] = A->op.peers[p].rank;
+        counts[p]     = A->op.peers[p].count;
+        offsets[p]    = A->op.peers[p].off;
+      }
+    }
+    return np;
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+int HpddmHipSchwarzSetTransport(HpddmHipSchwarz *A, int (*halo)(void *, int), int (*allreduce)(void *, double *, int), void *ctx, double *sendbuf, double *recvbuf, int mu_cap)
+{
+  HH_TRY(
+    HH_CHECK(A, "null argument");
+    A->op.halo_fn      = halo;
+    A->op.allreduce_fn = allreduce;
+    A->op.cb_ctx       = ctx;
+    A->op.sendbuf      = sendbuf;
+    A->op.recvbuf      = recvbuf;
+    A->op.halo_mu_cap  = mu_cap;
+    return 0;)
+}
+long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity)
+{
+  try {
+    HH_CHECK(A && which, "null argument");
+    A->op.build_halo_lists();
+    const std::string k(which);
+    const std::vector<int> *v = nullptr;
+    if (k == "send_sub") v = &A->op.h_send_sub;
+    else if (k == "send_idx") v = &A->op.h_send_idx;
+    else if (k == "send_po") v = &A->op.h_send_po;
+    else if (k == "send_pc") v = &A->op.h_send_pc;
+    else if (k == "rx_ptr") v = &A->op.h_rx_ptr;
+    else if (k == "rx_k") v = &A->op.h_rx_k;
+    else if (k == "rx_po") v = &A->op.h_rx_po;
+    else if (k == "rx_pc") v = &A->op.h_rx_pc;
+    HH_CHECK(v != nullptr, "HaloExport: unknown array " + k);
+    if (out) {
+      HH_CHECK((long long)v->size() <= capacity, "HaloExport: buffer too small");
+      std::copy(v->begin(), v->end(), out);
+    }
+    return (long long)v->size();
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+
 int HpddmHipSchwarzApplyDevice(HpddmHipSchwarz *A, const double *in, double *out, unsigned short mu)
 {
   HH_TRY(

@@ -10,6 +10,7 @@
 #include "schwarz.hpp"
 #include <algorithm>
 #include <cmath>
+#include <array>
 #include <cstring>
 
 namespace hpddm_hip {
@@ -31,6 +32,32 @@ __global__ void k_exchange(const long long *__restrict__ voff, const int *__rest
         const long long vt = voff[t];
         acc += (scale ? d[vt + j] : 1.0) * in[vt * mu + (long long)nu * nn[t] + j];
       }
+      out[v0 * mu + (long long)nu * n + i] = acc;
+    }
+  }
+}
+
+// cross-GPU part of the halo: sendbuf[po*mu + nu*pc + (k - po)] = (scale ? d : 1) * in[sub][nu][idx]
+__global__ void k_halo_pack(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const int *__restrict__ ssub, const int *__restrict__ sidx, const int *__restrict__ spo, const int *__restrict__ spc, long long total, const double *__restrict__ in, double *__restrict__ sendbuf, int mu, int scale)
+{
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long long)gridDim.x * blockDim.x) {
+    const int       s = ssub[k], i = sidx[k];
+    const long long v0 = voff[s], po = spo[k], pc = spc[k];
+    const double    di = scale ? d[v0 + i] : 1.0;
+    for (int nu = 0; nu < mu; ++nu) sendbuf[po * mu + (long long)nu * pc + (k - po)] = di * in[v0 * mu + (long long)nu * nn[s] + i];
+  }
+}
+// out[sub][nu][i] += sum over the received duplicates of dof i (fixed order: neighbour number)
+__global__ void k_halo_unpack(const long long *__restrict__ voff, const int *__restrict__ nn, const int *__restrict__ rptr, const int *__restrict__ rk, const int *__restrict__ rpo, const int *__restrict__ rpc, const double *__restrict__ recvbuf, double *__restrict__ out, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int p0 = rptr[v0 + i], p1 = rptr[v0 + i + 1];
+    if (p0 == p1) continue;
+    for (int nu = 0; nu < mu; ++nu) {
+      double acc = out[v0 * mu + (long long)nu * n + i];
+      for (int p = p0; p < p1; ++p) acc += recvbuf[(long long)rpo[p] * mu + (long long)nu * rpc[p] + (rk[p] - rpo[p])];
       out[v0 * mu + (long long)nu * n + i] = acc;
     }
   }
@@ -124,6 +151,87 @@ Schwarz::Schwarz(int nsub_, int first_, int nglobal_) : nsub(nsub_), first(first
 {
   HH_CHECK(nsub_ >= 1 && first_ >= 0 && first_ + nsub_ <= nglobal_, "SchwarzCreate: bad subdomain range");
   for (auto &s : subs) s.ls.reset(new LocalSolver());
+  rank_first = {0, nglobal_};
+  if (!(first_ == 0 && nsub_ == nglobal_)) rank_first = {first_, first_ + nsub_}; // until SetPartition says who owns the rest
+}
+
+int Schwarz::owner(int gid) const
+{
+  for (int r = 0; r + 1 < (int)rank_first.size(); ++r)
+    if (gid >= rank_first[r] && gid < rank_first[r + 1]) return r;
+  return -1;
+}
+
+void Schwarz::set_partition(int nranks_, int rank_, const int *firsts)
+{
+  HH_CHECK(nranks_ >= 1 && rank_ >= 0 && rank_ < nranks_, "SetPartition: bad rank");
+  rank_first.assign(firsts, firsts + nranks_ + 1);
+  HH_CHECK(rank_first[rank_] == first && rank_first[rank_ + 1] == first + nsub && rank_first[nranks_] == nglobal, "SetPartition: inconsistent with SchwarzCreate");
+  nranks = nranks_;
+  rank   = rank_;
+  halo_lists_ready = device_ready = false;
+}
+
+void Schwarz::build_halo_lists()
+{
+  // Remote neighbours (owned by another GPU).  Link a -> b carries, for every pair (s on a, t on b) in increasing
+  // (s, t) order, the shared dofs in the order of s' list; b consumes them in increasing (source, destination) order,
+  // dof j of the message landing on entry j of its own list for that neighbour (the lists of a pair have the same
+  // length and order: contract of Subdomain::initialize, include/HPDDM_subdomain.hpp:115-130).
+  if (halo_lists_ready) return;
+  voff.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) voff[s + 1] = voff[s] + subs[s].n;
+  ntot = voff[nsub];
+  struct Pair { int s, t, k; };
+  std::map<int, std::vector<Pair>> by_peer; // peer rank -> pairs
+  for (int s = 0; s < nsub; ++s)
+    for (int k = 0; k < (int)subs[s].map.size(); ++k) {
+      const int t = subs[s].map[k].first;
+      if (t >= first && t < first + nsub) continue;
+      const int o = owner(t);
+      HH_CHECK(o >= 0 && o != rank, "neighbour " + std::to_string(t) + " is neither local nor owned by a known rank (call SetPartition)");
+      by_peer[o].push_back(Pair{s, t, k});
+    }
+  peers.clear();
+  h_send_sub.clear(); h_send_idx.clear(); h_send_po.clear(); h_send_pc.clear();
+  std::vector<std::vector<std::array<int, 3>>> rx((size_t)ntot); // per dof: (k, po, pc)
+  long long off = 0;
+  for (auto &kv : by_peer) {
+    std::vector<Pair> &pr = kv.second;
+    long long          cnt = 0;
+    for (const Pair &p : pr) cnt += (long long)subs[p.s].map[p.k].second.size();
+    HH_CHECK(off + cnt < 2147483647LL, "halo too large for 32-bit offsets");
+    // send order: (local s, remote t)
+    std::sort(pr.begin(), pr.end(), [](const Pair &a, const Pair &b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
+    for (const Pair &p : pr)
+      for (int i : subs[p.s].map[p.k].second) {
+        h_send_sub.push_back(p.s);
+        h_send_idx.push_back(i);
+        h_send_po.push_back((int)off);
+        h_send_pc.push_back((int)cnt);
+      }
+    // receive order = the peer's send order: (remote t, local s)
+    std::sort(pr.begin(), pr.end(), [](const Pair &a, const Pair &b) { return a.t != b.t ? a.t < b.t : a.s < b.s; });
+    long long pos = off;
+    for (const Pair &p : pr)
+      for (int i : subs[p.s].map[p.k].second) rx[voff[p.s] + i].push_back({(int)pos++, (int)off, (int)cnt});
+    peers.push_back(HaloPeer{kv.first, cnt, off});
+    off += cnt;
+  }
+  halo_total = off;
+  h_rx_ptr.assign((size_t)ntot + 1, 0);
+  h_rx_k.clear(); h_rx_po.clear(); h_rx_pc.clear();
+  for (long long g = 0; g < ntot; ++g) {
+    // neighbour order inside a dof: entries were appended peer by peer; sort by position so the order is fixed
+    std::sort(rx[g].begin(), rx[g].end());
+    for (const auto &e : rx[g]) {
+      h_rx_k.push_back(e[0]);
+      h_rx_po.push_back(e[1]);
+      h_rx_pc.push_back(e[2]);
+    }
+    h_rx_ptr[g + 1] = (int)h_rx_k.size();
+  }
+  halo_lists_ready = true;
 }
 
 void Schwarz::set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn)
@@ -264,12 +372,13 @@ void Schwarz::build_device()
   ja_d.upload(jacat, st);
   a_d.upload(acat, st);
   iaoff_d.upload(iaoff, st);
-  // halo gather lists
+  // halo gather lists (co-located neighbours); neighbours on other GPUs go through the pack / transport / unpack path
+  build_halo_lists();
   std::vector<int> cnt((size_t)ntot + 1, 0);
   for (int s = 0; s < nsub; ++s)
     for (const auto &pr : subs[s].map) {
       const int t = pr.first - first;
-      HH_CHECK(t >= 0 && t < nsub, "this build keeps all neighbours of a subdomain on one GPU (multi-GPU halo: see DESIGN.md)");
+      if (t < 0 || t >= nsub) continue;
       HH_CHECK(pr.second.size() == peer_list(*this, t, first + s).size(), "neighbour lists of different lengths");
       for (int i : pr.second) ++cnt[voff[s] + i + 1];
     }
@@ -279,7 +388,8 @@ void Schwarz::build_device()
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
     for (int s = 0; s < nsub; ++s)
       for (const auto &pr : subs[s].map) {
-        const int               t      = pr.first - first;
+        const int t = pr.first - first;
+        if (t < 0 || t >= nsub) continue;
         const std::vector<int> &theirs = peer_list(*this, t, first + s);
         for (size_t j = 0; j < pr.second.size(); ++j) {
           const long long g = voff[s] + pr.second[j];
@@ -291,6 +401,16 @@ void Schwarz::build_device()
   ex_ptr.upload(cnt, st);
   ex_sub.upload(esub, st);
   ex_idx.upload(eidx, st);
+  if (halo_total) {
+    send_sub_d.upload(h_send_sub, st);
+    send_idx_d.upload(h_send_idx, st);
+    send_po_d.upload(h_send_po, st);
+    send_pc_d.upload(h_send_pc, st);
+    rx_ptr_d.upload(h_rx_ptr, st);
+    rx_k_d.upload(h_rx_k, st);
+    rx_po_d.upload(h_rx_po, st);
+    rx_pc_d.upload(h_rx_pc, st);
+  }
   HIP_OK(hipStreamSynchronize(st));
   device_ready = true;
 }
@@ -381,6 +501,7 @@ void Schwarz::build_coarse()
   // Preconditioner::buildTwo with MatrixMultiplication (include/HPDDM_preconditioner.hpp:124-257,
   // include/HPDDM_operator.hpp:378-562):  E = W^T A W,  W_j = R_j^T D_j Z_j,  A W_j = R_j^T (A_j D_j Z_j).
   build_device();
+  HH_CHECK(halo_total == 0 && nranks == 1, "BuildCoarseOperator: the coarse operator is assembled on one GPU in this round (all subdomains local)");
   coff.assign(nsub + 1, 0);
   for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
   cdim = coff[nsub];
@@ -457,7 +578,15 @@ static inline dim3 grid2(int nmax, int nsub) { return dim3((unsigned)std::min(10
 void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
 {
   HH_CHECK(in != out, "exchange: out-of-place only");
-  hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+  hipStream_t st = library_stream();
+  hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+  if (halo_total) {
+    HH_CHECK(halo_fn && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport and buffers first (HpddmHipSchwarzSetTransport)");
+    hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, in, sendbuf, mu, scale ? 1 : 0);
+    HIP_OK(hipStreamSynchronize(st));
+    HH_CHECK(halo_fn(cb_ctx, mu) == 0, "halo transport failed");
+    hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
+  }
 }
 void Schwarz::exchange_inplace(double *x, int mu, bool scale)
 {
@@ -564,6 +693,11 @@ void Schwarz::wdots(const double *V, long long ldv, int k, const double *w, int 
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((k * mu + 63) / 64)), dim3(64), 0, st, partial.p, nb, outd.p);
   HIP_OK(hipMemcpyAsync(out_host, outd.p, sizeof(double) * k * mu, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+  // MPI_Allreduce of the reference (include/HPDDM_iterative.hpp:518,684; include/HPDDM_GMRES.hpp:71,80)
+  if (nranks > 1) {
+    HH_CHECK(allreduce_fn != nullptr, "several ranks but no all-reduce registered (HpddmHipSchwarzSetTransport)");
+    HH_CHECK(allreduce_fn(cb_ctx, out_host, k * mu) == 0, "all-reduce failed");
+  }
 }
 
 void Schwarz::compute_residual(const double *x, const double *f, double *storage, int mu)

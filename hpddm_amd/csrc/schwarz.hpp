@@ -36,8 +36,38 @@ struct SchwarzSub {
   std::unique_ptr<LocalSolver> ls;
 };
 
+// Transport of the cross-GPU part of the halo and of the Krylov reductions.  The library packs / unpacks on the device
+// and calls back into the host framework, which owns the communicator (RCCL through torch.distributed in bench.py).
+//   halo(ctx, mu): send sendbuf[off_p*mu .. (off_p+cnt_p)*mu) to peer p and receive the same range of recvbuf from it,
+//                  for every peer; must return once the receive buffers are complete (0 = ok)
+//   allreduce(ctx, buf, count): in-place sum of `count` host doubles over all ranks
+typedef int (*HaloTransportFn)(void *ctx, int mu);
+typedef int (*AllreduceFn)(void *ctx, double *buf, int count);
+
+struct HaloPeer {
+  int       rank;
+  long long count, off; // entries per right-hand side, offset (entries) of the peer's block in the send/recv buffers
+};
+
 struct Schwarz {
   int nsub, first, nglobal;
+  // ---- distribution over GPUs: rank r owns the subdomains [rank_first[r], rank_first[r+1]) ----
+  int                   rank = 0, nranks = 1;
+  std::vector<int>      rank_first;
+  std::vector<HaloPeer> peers;
+  long long             halo_total = 0;
+  std::vector<int>      h_send_sub, h_send_idx, h_send_po, h_send_pc; // per send entry: local subdomain, dof, peer offset, peer count
+  std::vector<int>      h_rx_ptr, h_rx_k, h_rx_po, h_rx_pc;           // CSR per concatenated dof -> entries of the recv buffer
+  DevBuf<int>           send_sub_d, send_idx_d, send_po_d, send_pc_d, rx_ptr_d, rx_k_d, rx_po_d, rx_pc_d;
+  double               *sendbuf = nullptr, *recvbuf = nullptr; // device buffers owned by the host framework
+  int                   halo_mu_cap = 0;
+  HaloTransportFn       halo_fn = nullptr;
+  AllreduceFn           allreduce_fn = nullptr;
+  void                 *cb_ctx = nullptr;
+  bool                  halo_lists_ready = false;
+  int                   owner(int gid) const;
+  void                  set_partition(int nranks_, int rank_, const int *firsts);
+  void                  build_halo_lists(); // host only
   std::vector<SchwarzSub>       subs;
   std::map<std::string, double> opt;
   PrcndtnrType                  type = PRC_GE;

@@ -163,12 +163,14 @@ def _factor3(p):
     return best[1]
 
 
-def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None):
+def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False):
     """7-point Laplacian on N^3 cells of the unit cube (h = 1/N, homogeneous Dirichlet through the stencil, like the
     2-D reference problem), split into ``parts`` boxes grown by ``overlap`` layers.  Returns the subdomains
     ``first .. first+count-1`` (default: all).  ``d`` is the product of the 1-D ramps of the reference generator
     (0, 1/overlap, ..., on the layers owned by a neighbour) -- multiplicityScaling turns it into a partition of unity.
-    ``sym`` selects HPDDM's symmetric storage (lower triangle, diagonal last in row)."""
+    ``sym`` selects HPDDM's symmetric storage (lower triangle, diagonal last in row).  ``normalize`` returns in ``d``
+    the final partition of unity w_i / sum_j w_j instead of the raw weights (what multiplicityScaling computes; needed
+    when the neighbours of a subdomain live on another GPU)."""
     F = 1 if numbering == "F" else 0
     px, py, pz = grid if grid is not None else _factor3(parts)
     assert px * py * pz == parts
@@ -185,6 +187,24 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
     for r in range(parts):
         c = coords(r)
         boxes[r] = [(max(c[a] * dims[a] // P[a] - overlap, 0), min((c[a] + 1) * dims[a] // P[a] + overlap, dims[a])) for a in range(3)]
+    def weights(r):
+        ramps = []
+        for a, (s, e) in enumerate(boxes[r]):
+            t = np.ones(e - s)
+            if overlap > 0:
+                if s != 0:  # a neighbour owns the first layers: 0, 1/ov, ...
+                    t[:overlap] = np.arange(overlap) / float(overlap)
+                if e != dims[a]:
+                    t[-overlap:] = np.arange(overlap)[::-1] / float(overlap)
+            ramps.append(t)
+        return ramps[2][:, None, None] * ramps[1][None, :, None] * ramps[0][None, None, :]
+
+    wsum = None
+    if normalize:
+        wsum = np.zeros((dims[2], dims[1], dims[0]))
+        for r in range(parts):
+            (a0, a1), (b0, b1), (c0, c1) = boxes[r]
+            wsum[c0:c1, b0:b1, a0:a1] += weights(r)
     subs = []
     for r in range(first, first + count):
         c = coords(r)
@@ -209,16 +229,10 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
         np.add.at(ia, rows + 1, 1)
         ia = np.cumsum(ia)
         # ---- partition-of-unity weights: product of the 1-D ramps ----
-        ramps = []
-        for a, (s, e) in enumerate(boxes[r]):
-            t = np.ones(e - s)
-            if overlap > 0:
-                if s != 0:  # a neighbour owns the first layers: 0, 1/ov, ...
-                    t[:overlap] = np.arange(overlap) / float(overlap)
-                if e != dims[a]:
-                    t[-overlap:] = np.arange(overlap)[::-1] / float(overlap)
-            ramps.append(t)
-        d = (ramps[2][:, None, None] * ramps[1][None, :, None] * ramps[0][None, None, :]).reshape(-1)
+        d = weights(r)
+        if normalize:
+            d = d / wsum[k0:k1, j0:j1, i0:i1]
+        d = d.reshape(-1)
         # ---- neighbours and shared dofs (intersection of the grown boxes, lexicographic order on both sides) ----
         neigh, conn = [], []
         for dz in (-1, 0, 1):

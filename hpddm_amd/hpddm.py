@@ -190,6 +190,79 @@ class Schwarz:
     def get_option(self, key):
         return self._lib.HpddmHipSchwarzGetOption(self._h, key.encode())
 
+    # -- several GPUs (one process per GPU): SURVEY 8(e) --
+    def set_partition(self, rank, firsts):
+        """rank r owns the global subdomains firsts[r] .. firsts[r+1]-1"""
+        firsts = np.ascontiguousarray(firsts, dtype=np.int32)
+        check(self._lib.HpddmHipSchwarzSetPartition(self._h, len(firsts) - 1, int(rank), _dptr(firsts)))
+
+    def halo_peers(self):
+        """[(peer rank, values per right-hand side, offset)] of the cross-GPU halo"""
+        n = self._lib.HpddmHipSchwarzHaloPeers(self._h, 0, None, None, None)
+        if n < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        ranks, counts, offs = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+        check(self._lib.HpddmHipSchwarzHaloPeers(self._h, n, _dptr(ranks), _dptr(counts), _dptr(offs)))
+        return [(int(ranks[p]), int(counts[p]), int(offs[p])) for p in range(n)]
+
+    def halo_export(self, which):
+        cnt = self._lib.HpddmHipSchwarzHaloExport(self._h, which.encode(), None, 0)
+        if cnt < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        out = np.zeros(max(cnt, 1), dtype=np.int32)
+        check(self._lib.HpddmHipSchwarzHaloExport(self._h, which.encode(), _dptr(out), cnt))
+        return out[:cnt]
+
+    def enable_distributed(self, dist, device, mu_cap=8, host_staging=False):
+        """Register the transport of the cross-GPU halo and of the Krylov reductions on a torch.distributed process
+        group (backend "nccl" = RCCL over xGMI: grouped point-to-point send/recv per neighbouring GPU, the counterpart of
+        the MPI_Isend/Irecv pairs of Subdomain::exchange, and a small all-reduce for the inner products).
+        host_staging=True moves the buffers through host memory (gloo), used to test the path on a single-GPU box."""
+        import torch
+        peers = self.halo_peers()
+        total = sum(c for _, c, _ in peers)
+        self._send = torch.zeros(max(1, total * mu_cap), dtype=torch.float64, device=device)
+        self._recv = torch.zeros_like(self._send)
+        self._red = torch.zeros(4096, dtype=torch.float64, device="cpu" if host_staging else device)
+
+        def halo(ctx, mu):
+            try:
+                ops, stage = [], []
+                for rank, cnt, off in peers:
+                    sb, rb = self._send[off * mu:(off + cnt) * mu], self._recv[off * mu:(off + cnt) * mu]
+                    if host_staging:
+                        sb_h, rb_h = sb.cpu(), torch.empty(cnt * mu, dtype=torch.float64)
+                        stage.append((rb, rb_h))
+                        sb, rb = sb_h, rb_h
+                    ops.append(dist.P2POp(dist.isend, sb, rank))
+                    ops.append(dist.P2POp(dist.irecv, rb, rank))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                for rb, rb_h in stage:
+                    rb.copy_(rb_h)
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("halo transport failed:", e, flush=True)
+                return -1
+
+        def allreduce(ctx, buf, count):
+            try:
+                host = np.ctypeslib.as_array(buf, shape=(count,))
+                t = self._red[:count]
+                t.copy_(torch.from_numpy(host))
+                dist.all_reduce(t)
+                host[:] = t.cpu().numpy()
+                return 0
+            except Exception as e:
+                print("all-reduce failed:", e, flush=True)
+                return -1
+
+        self._halo_cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)(halo)
+        self._red_cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int)(allreduce)
+        check(self._lib.HpddmHipSchwarzSetTransport(self._h, ctypes.cast(self._halo_cb, ctypes.c_void_p), ctypes.cast(self._red_cb, ctypes.c_void_p), None,
+                                                    ctypes.c_void_p(self._send.data_ptr()), ctypes.c_void_p(self._recv.data_ptr()), mu_cap))
+
     # -- batched layout helpers --
     def pack(self, xs):
         """list of per-subdomain (n_s,) / (n_s, mu) arrays -> one flat array in the library's batched layout."""
@@ -292,11 +365,15 @@ class Schwarz:
             pass
 
 
-def schwarz_from_subdomains(subs, first_global=0, nglobal=None, options="", multiplicity=True):
-    """examples/schwarz.cpp:90-97 in one call: create, set every subdomain, multiplicityScaling, initialize."""
+def schwarz_from_subdomains(subs, first_global=0, nglobal=None, options="", multiplicity=True, partition=None):
+    """examples/schwarz.cpp:90-97 in one call: create, set every subdomain, multiplicityScaling, initialize.
+    partition = (rank, firsts) when the subdomains are sharded over several GPUs (then pass multiplicity=False and the
+    final partition of unity in sd["d"])."""
     A = Schwarz(len(subs), first_global, nglobal)
     if options:
         A.option_parse(options)
+    if partition is not None:
+        A.set_partition(*partition)
     for s, sd in enumerate(subs):
         A.set_subdomain(s, sd["n"], sd["ia"], sd["ja"], sd["a"], sd["sym"], sd["neighbors"], sd["connectivity"], sd.get("numbering", "C"))
     d = [np.array(sd["d"], dtype=np.float64) for sd in subs]

@@ -117,6 +117,21 @@ int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const 
  * history, if not NULL, receives up to history_cap residual norms (one per iteration, largest over the rhs). */
 int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap);
 
+/* ---- several GPUs: one process (rank) per GPU, subdomains sharded by contiguous ranges ----
+ * firsts[r] .. firsts[r+1]-1 are the global subdomain numbers owned by rank r (nranks+1 entries). */
+int HpddmHipSchwarzSetPartition(HpddmHipSchwarz *A, int nranks, int rank, const int *firsts);
+/* Halo layout towards the other GPUs: returns the number of peers; peer p exchanges counts[p] values per right-hand
+ * side, stored at offset offsets[p]*mu in both buffers (arrays of capacity `cap`, may be NULL to query the count). */
+int HpddmHipSchwarzHaloPeers(HpddmHipSchwarz *A, int cap, int *peer_ranks, long long *counts, long long *offsets);
+/* Transport callbacks (replace MPI_Isend/Irecv of Subdomain::exchange include/HPDDM_subdomain.hpp:119-128 and the
+ * MPI_Allreduce of the Krylov method): the library packs into sendbuf_dev and unpacks from recvbuf_dev (device
+ * buffers of mu_cap * sum(counts) doubles owned by the caller); halo(ctx, mu) must move, for every peer p, the range
+ * [offsets[p]*mu, (offsets[p]+counts[p])*mu) of the send buffer into the same range of the peer's receive buffer
+ * and return 0 once the receive buffer is complete; allreduce(ctx, buf, n) sums n host doubles over the ranks. */
+int HpddmHipSchwarzSetTransport(HpddmHipSchwarz *A, int (*halo)(void *, int), int (*allreduce)(void *, double *, int), void *ctx, double *sendbuf_dev, double *recvbuf_dev, int mu_cap);
+/* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc" */
+long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity);
+
 /* Device-pointer variants of the hot calls (vectors already resident in HBM, asynchronous on the library stream) */
 int HpddmHipSchwarzApplyDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);
 int HpddmHipSchwarzGMVDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);

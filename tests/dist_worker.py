@@ -1,0 +1,120 @@
+"""Worker of the multi-process tests (launched by torch.distributed.run, gloo rendezvous on 127.0.0.1).
+
+mode "lists": CPU only.  Every rank builds its shard of the Schwarz operator in the product library (host side:
+Subdomain::initialize sorting, SetPartition, cross-GPU halo lists), then the halo sum is replayed in numpy with the
+library's lists -- pack, gloo send/recv with the library's peer layout, unpack -- and compared with the oracle's global
+exchange.  This pins the ordering contract of the N>1 path without a GPU.
+
+mode "gpu": all ranks share GPU 0 (host-staged gloo transport).  apply / GMV / GMRES of the sharded operator are
+compared with the oracle on the global problem.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hpddm_amd import hpddm  # noqa: E402
+from hpddm_amd.generate import generate3d  # noqa: E402
+from oracle.ras_oracle import Oracle  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    parts, grid, dims = 4 * world, (2, 2, world), (8, 8, 6 * world)
+    per = parts // world
+    firsts = [r * per for r in range(world + 1)]
+    allsubs = generate3d(dims, parts, overlap=1, sym=True, rhs="smooth", grid=grid, normalize=True)
+    mine = allsubs[firsts[rank]:firsts[rank + 1]]
+    orc = Oracle(allsubs)
+    orc.d = [s["d"] for s in allsubs]
+    A, d = hpddm.schwarz_from_subdomains(mine, first_global=firsts[rank], nglobal=parts, options="-hpddm_operator_spd", multiplicity=False,
+                                         partition=(rank, firsts))
+    rng = np.random.default_rng(5)
+    mu = 2
+    xg = [rng.random((s["n"], mu)) for s in allsubs]
+    ref = orc.exchange(xg)
+    peers = A.halo_peers()
+    assert len(peers) == (1 if rank in (0, world - 1) else 2), peers  # slabs along z: neighbours are the ranks above/below
+    if mode == "lists":
+        L = {k: A.halo_export(k) for k in ("send_sub", "send_idx", "send_po", "send_pc", "rx_ptr", "rx_k", "rx_po", "rx_pc")}
+        total = sum(c for _, c, _ in peers)
+        assert len(L["send_sub"]) == total
+        voff = np.concatenate([[0], np.cumsum([s["n"] for s in mine])])
+        x = xg[firsts[rank]:firsts[rank + 1]]
+        # local part (what k_exchange does): D x + co-located neighbours in neighbour order
+        out = [d[s][:, None] * x[s] for s in range(per)]
+        sc = [o.copy() for o in out]
+        for s, sd in enumerate(mine):
+            order = np.argsort(sd["neighbors"], kind="stable")
+            for k in order:
+                t = int(sd["neighbors"][k]) - firsts[rank]
+                if 0 <= t < per:
+                    kt = list(mine[t]["neighbors"]).index(firsts[rank] + s)
+                    out[s][sd["connectivity"][k]] += sc[t][mine[t]["connectivity"][kt]]
+        # remote part with the library's lists: pack
+        send = np.zeros(total * mu)
+        for k in range(total):
+            s, i, po, pc = L["send_sub"][k], L["send_idx"][k], L["send_po"][k], L["send_pc"][k]
+            for nu in range(mu):
+                send[po * mu + nu * pc + (k - po)] = d[s][i] * x[s][i, nu]
+        recv = np.zeros_like(send)
+        ops, bufs = [], []
+        for prank, cnt, off in peers:
+            sb = torch.from_numpy(send[off * mu:(off + cnt) * mu].copy())
+            rb = torch.zeros(cnt * mu, dtype=torch.float64)
+            bufs.append((off, cnt, rb))
+            ops += [dist.P2POp(dist.isend, sb, prank), dist.P2POp(dist.irecv, rb, prank)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for off, cnt, rb in bufs:
+            recv[off * mu:(off + cnt) * mu] = rb.numpy()
+        # unpack
+        for s in range(per):
+            for i in range(mine[s]["n"]):
+                g = voff[s] + i
+                for p in range(L["rx_ptr"][g], L["rx_ptr"][g + 1]):
+                    k, po, pc = L["rx_k"][p], L["rx_po"][p], L["rx_pc"][p]
+                    for nu in range(mu):
+                        out[s][i, nu] += recv[po * mu + nu * pc + (k - po)]
+        err = max(np.abs(o - r).max() for o, r in zip(out, ref[firsts[rank]:firsts[rank + 1]]))
+        assert err < 1e-14, err
+    else:
+        hpddm.require_device()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        A.enable_distributed(dist, dev, mu_cap=4, host_staging=True)
+        A.call_numfact()
+        orc.numfact()
+        x = xg[firsts[rank]:firsts[rank + 1]]
+        sl = slice(firsts[rank], firsts[rank + 1])
+
+        def close(a, b, tol, what):
+            scale = max(np.abs(v).max() for v in b)
+            err = max(np.abs(u - v).max() for u, v in zip(a, b)) / scale
+            assert err < tol, (what, err)
+
+        close(A.exchange(x), ref[sl], 1e-14, "exchange")
+        close(A.gmv(x), orc.gmv(xg)[sl], 1e-13, "gmv")
+        f = orc.exchange(xg)
+        close(A.apply(f[sl]), orc.apply(f)[sl], 1e-10, "apply")
+        it, sol = A.solve(f[sl])
+        it_o, sol_o, _ = orc.gmres(f)
+        assert it == it_o, (it, it_o)
+        close(sol, sol_o[sl], 1e-8, "solution")
+        res = A.compute_residual(sol, f[sl])
+        assert np.allclose(res, orc.compute_residual(sol_o, f), rtol=1e-4), res
+    dist.barrier()
+    if rank == 0:
+        print(f"DIST_WORKER_OK mode={mode} world={world} peers={peers}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
