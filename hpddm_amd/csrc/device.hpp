@@ -51,14 +51,13 @@ struct SnDesc {
   const int    *rows;  // nb sorted rows below the block (permuted numbering)
   const int    *gptr;  // h+1 gather pointers into gsrc
   const int    *gsrc;  // sources inside the subdomain's update pool
-  const int    *perm;  // perm[new] = old (whole subdomain)
   long long     voff;  // offset (in vector elements, to be multiplied by mu) of the subdomain in batched multi-vectors
   long long     uoff;  // same for the update pool
   int           n;     // subdomain size (leading dimension of its multi-vectors)
   int           usize; // subdomain update-pool size
   int           c0, w, nb, ldw;
   int           u_off; // offset of this supernode's update vector inside the subdomain pool
-  int           pad_;
+  int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
 };
 
 struct Tile {
@@ -81,6 +80,7 @@ struct DeviceFactor {
   DevBuf<int>    rows, gptr, gsrc, perm;
   // host copies of what the plan builder needs
   std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
+  std::vector<char>    has_src;
   std::vector<int64_t> f_off, row_ptr, goff;
   void upload(const HostFactor &hf, hipStream_t s);
 };
@@ -100,7 +100,11 @@ struct SolvePlan {
   std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
-  DevBuf<double> y, xw, U;
+  DevBuf<double> y, xw, U, bperm;
+  DevBuf<long long> pvoff; // per factor: vector offset
+  DevBuf<int>       pn;    // per factor: n
+  DevBuf<const int *> pperm; // per factor: perm array
+  int               nmax = 0;
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves

@@ -33,6 +33,29 @@ __device__ static inline void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// b (original numbering) -> permuted numbering of the factor, and back for x: two streaming passes over n that take the
+// perm[] indirection out of every tile of the sweeps
+__global__ void k_perm_in(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = pm[i];
+    for (int nu = 0; nu < mu; ++nu) bp[v0 * mu + (long long)nu * n + i] = b[v0 * mu + (long long)nu * n + o];
+  }
+}
+__global__ void k_perm_out(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = pm[i];
+    for (int nu = 0; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + o] = xp[v0 * mu + (long long)nu * n + i];
+  }
+}
+
 // store the result of panel row r (after reduction): top rows give y, rows below hand their update to the parent
 template <int MU>
 __device__ static inline void fwd_store_row(const SnDesc &d, int r, const double *s, int sstride, double *yb, double *Ub)
@@ -40,6 +63,9 @@ __device__ static inline void fwd_store_row(const SnDesc &d, int r, const double
   if (r < d.w) {
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = s[nu * sstride];
+  } else if (!d.has_src) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = s[nu * sstride];
   } else {
     const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
 #pragma unroll
@@ -67,20 +93,18 @@ __device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int 
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 0.0;
     if (c < w) {
-      const int pc = d.perm[d.c0 + c], q0 = d.gptr[c], q1 = d.gptr[c + 1];
+      // bb is already in the permuted numbering: columns c0+c, c0+c+1 are adjacent
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
-        double v = bb[(long long)nu * d.n + pc];
-        for (int q = q0; q < q1; ++q) v -= Ub[(long long)nu * d.usize + d.gsrc[q]];
-        l0[nu] = v;
+        l0[nu] = bb[(long long)nu * d.n + d.c0 + c];
+        l1[nu] = c + 1 < w ? bb[(long long)nu * d.n + d.c0 + c + 1] : 0.0;
       }
-      if (c + 1 < w) {
-        const int pc1 = d.perm[d.c0 + c + 1], q2 = d.gptr[c + 2];
+      if (d.has_src) {
+        const int q0 = d.gptr[c], q1 = d.gptr[c + 1], q2 = c + 1 < w ? d.gptr[c + 2] : q1;
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
-          double v = bb[(long long)nu * d.n + pc1];
-          for (int q = q1; q < q2; ++q) v -= Ub[(long long)nu * d.usize + d.gsrc[q]];
-          l1[nu] = v;
+          for (int q = q0; q < q1; ++q) l0[nu] -= Ub[(long long)nu * d.usize + d.gsrc[q]];
+          for (int q = q1; q < q2; ++q) l1[nu] -= Ub[(long long)nu * d.usize + d.gsrc[q]];
         }
       }
     }
@@ -160,20 +184,12 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
   if (sub == 0) {
     const int c = 2 * gl;
     if (c < w) {
-      const int pc = d.perm[d.c0 + c];
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
-        xo[(long long)nu * d.n + pc]       = acc0[nu];
-      }
+      for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
     }
     if (c + 1 < w) {
-      const int pc = d.perm[d.c0 + c + 1];
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
-        xo[(long long)nu * d.n + pc]           = acc1[nu];
-      }
+      for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
     }
   }
 }
@@ -212,8 +228,9 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
           const int col = k0 + i;
           double    v   = 0.0;
           if (col < w) {
-            v = bb[(long long)nu * d.n + d.perm[d.c0 + col]];
-            for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
+            v = bb[(long long)nu * d.n + d.c0 + col];
+            if (d.has_src)
+              for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
           }
           lds[nu * CW + i] = v;
         }
@@ -330,8 +347,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
             double s = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
-            xb[(long long)nu * d.n + d.c0 + c]         = s;
-            xo[(long long)nu * d.n + d.perm[d.c0 + c]] = s;
+            xb[(long long)nu * d.n + d.c0 + c] = s;
           }
         }
     }
@@ -370,8 +386,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
       for (int nu = 0; nu < MU; ++nu) {
         double s = 0.0;
         for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * MU + nu) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
-        xb[(long long)nu * d.n + d.c0 + c]         = s;
-        xo[(long long)nu * d.n + d.perm[d.c0 + c]] = s;
+        xb[(long long)nu * d.n + d.c0 + c] = s;
       }
     }
   }
@@ -460,7 +475,12 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   row_ptr   = hf.sym.row_ptr;
   goff      = hf.goff;
   u_off.assign(nblk, 0);
-  for (idx_t k = 0; k < nblk; ++k) u_off[k] = (idx_t)hf.u_off[k];
+  has_src.assign(nblk, 0);
+  for (idx_t k = 0; k < nblk; ++k) {
+    u_off[k]      = (idx_t)hf.u_off[k];
+    const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
+    has_src[k]    = hf.gptr[hf.goff[k] + hh] > hf.gptr[hf.goff[k]];
+  }
 }
 
 void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s)
@@ -492,7 +512,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.rows  = D.rows.p + D.row_ptr[k];
       d.gptr  = D.gptr.p + D.goff[k];
       d.gsrc  = D.gsrc.p;
-      d.perm  = D.perm.p;
       d.voff  = voff[f];
       d.uoff  = uoffs[f];
       d.n     = D.n;
@@ -502,7 +521,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.nb    = (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
       d.ldw   = D.ldw[k];
       d.u_off = D.u_off[k];
-      d.pad_  = 0;
+      d.has_src = D.has_src[k] ? 1 : 0;
       const int id = (int)descs.size();
       descs.push_back(d);
       const int h = d.w + d.nb, lev = D.height[k];
@@ -564,7 +583,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_ptr[kd].assign(nlev + 1, 0);
     lev_lds[kd].assign(nlev, 0);
   }
-  launches_per_solve = 0;
+  launches_per_solve = 2; // the two permutation passes
   for (int kd = 0; kd < 4; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
@@ -579,6 +598,22 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     for (int l = 0; l < nlev; ++l) lev_end[kd][l] = lev_ptr[kd][l] + (int)tl[kd][l].size();
   }
   for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty());
+  {
+    std::vector<long long>   pv(fs.size());
+    std::vector<int>         pnn(fs.size());
+    std::vector<const int *> pp(fs.size());
+    nmax = 0;
+    for (size_t f = 0; f < fs.size(); ++f) {
+      pv[f]  = voff[f];
+      pnn[f] = fs[f]->n;
+      pp[f]  = fs[f]->perm.p;
+      nmax   = std::max<int>(nmax, fs[f]->n);
+    }
+    pvoff.upload(pv, s);
+    pn.upload(pnn, s);
+    pperm.upload(pp, s);
+    HIP_OK(hipStreamSynchronize(s));
+  }
   sn.upload(descs, s);
   tiles.upload(all, s);
   {
@@ -593,6 +628,7 @@ void SolvePlan::reserve(int mu)
   if (mu <= mu_cap) return;
   y.alloc((size_t)ntot * mu);
   xw.alloc((size_t)ntot * mu);
+  bperm.alloc((size_t)ntot * mu);
   U.alloc((size_t)std::max<long long>(utot, 1) * mu);
   partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 8));
   mu_cap = mu;
@@ -622,6 +658,11 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
   HH_CHECK(mu >= 1, "solve: mu must be >= 1");
   reserve(mu);
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
+  const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
+  hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+  b = bperm.p;
+  double *const xout = x;
+  x                  = xw.p; // the sweeps stay in the permuted numbering; one pass scatters the result at the end
   int nu0 = 0;
   while (nu0 < mu) {
     const int left = mu - nu0;
@@ -639,6 +680,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
       nu0 += 1;
     }
   }
+  hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, xout, mu);
   HIP_OK(hipGetLastError());
 }
 

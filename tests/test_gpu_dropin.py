@@ -51,5 +51,5 @@ def test_unchanged_single_rank_direct_solve_and_local_solver_benchmark(tmp_path)
     assert os.path.exists(mat)
     # benchmark/local_solver.cpp:92-127 protocol: one line per trial, seconds for nu = 1, 2, 4
     out = _run(1, f"{mat} -rhs=4 -solve_phase_only=1", exe="local_solver_hipsub")
-    rows = [re.findall(r"\d\.\d+e[-+]\d+", ln) for ln in out.strip().splitlines() if re.match(r"^\s*\d\.\d+e[-+]\d+", ln)]
+    rows = [re.findall(r"\d\.\d{5}e[-+]\d{2}", ln) for ln in out.strip().splitlines() if re.match(r"^\s*\d\.\d+e[-+]\d+", ln)]
     assert len(rows) == 3 and all(len(r) == 3 for r in rows), out  # 3 trials x (nu = 1, 2, 4)
