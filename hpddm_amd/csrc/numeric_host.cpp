@@ -22,11 +22,9 @@ static double now()
 
 static idx_t padded_width(idx_t w)
 {
-  if (w <= 128) {
-    idx_t p = 2;
-    while (p < w) p <<= 1;
-    return p;
-  }
+  // narrow panels: even width (16-byte row alignment; the wave-level kernels take any even ldw <= 128);
+  // wide panels: rows aligned to 128 bytes
+  if (w <= 128) return (w + 1) / 2 * 2;
   return (w + 15) / 16 * 16;
 }
 

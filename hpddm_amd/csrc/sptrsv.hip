@@ -23,7 +23,32 @@ static constexpr int FWD_PASSES  = 4;    // rows per wavefront per batch (regist
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // at most this many rows per wave-level tile (LDS: WAVE_ROWS * MU doubles per wavefront)
 
-__host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; }
+__host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
+
+// sum over the g lanes of a row group (g = any value <= 64, lanes gl = 0..g-1 are contiguous); result valid in gl == 0
+__device__ static inline double reduce_group(double v, int gl, int g)
+{
+  int width = g, off = 1;
+  while (off < g) off <<= 1;
+  for (off >>= 1; off >= 1; off >>= 1) {
+    const double t = __shfl_down(v, off);
+    if (gl + off < width) v += t;
+    width = min(width, off);
+  }
+  return v;
+}
+// sum over the R row groups of a wavefront for one column pair (lanes sub*g + gl, sub = 0..R-1); result valid in sub == 0
+__device__ static inline double reduce_across(double v, int lane, int sub, int g, int R)
+{
+  int width = R, off = 1;
+  while (off < R) off <<= 1;
+  for (off >>= 1; off >= 1; off >>= 1) {
+    const double t = __shfl(v, min(63, lane + off * g));
+    if (sub + off < width) v += t;
+    width = min(width, off);
+  }
+  return v;
+}
 
 // LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
 __device__ static inline void wave_lds_sync()
@@ -84,8 +109,9 @@ template <int MU>
 __device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int lane, double *lds, const double *bb, double *yb, double *Ub)
 {
   const int w = d.w, ldw = d.ldw;
-  const int g = ldw >> 1, R = 64 / g;
+  const int g = ldw >> 1, R = 64 / g; // any even ldw <= 128: R*g <= 64 lanes work, the others idle
   const int sub = lane / g, gl = lane - sub * g;
+  const bool active = sub < R;
   // right-hand side of the supernode for this lane's two columns: b - (updates handed up by the children)
   double l0[MU], l1[MU];
   {
@@ -111,21 +137,21 @@ __device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int 
   }
   const int     rend = t.r0 + t.nr;
   const double *Fp   = d.F + 2 * gl;
-  for (int rb = t.r0 + sub; rb < rend; rb += FWD_PASSES * R) {
-    double2 a[FWD_PASSES];
+  for (int rb0 = t.r0; rb0 < rend; rb0 += FWD_PASSES * R) { // wave-uniform trip count (the reductions shuffle across lanes)
+    const int rb = rb0 + sub;
+    double2   a[FWD_PASSES];
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
       const int r = rb + p * R;
-      a[p]        = r < rend ? *reinterpret_cast<const double2 *>(Fp + (long long)r * ldw) : make_double2(0.0, 0.0);
+      a[p]        = (active && r < rend) ? *reinterpret_cast<const double2 *>(Fp + (long long)r * ldw) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
       const int r = rb + p * R;
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
-        double s = fma(a[p].x, l0[nu], a[p].y * l1[nu]);
-        for (int off = g >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-        if (gl == 0 && r < rend) lds[nu * WAVE_ROWS + (r - t.r0)] = s;
+        const double s = reduce_group(fma(a[p].x, l0[nu], a[p].y * l1[nu]), gl, g);
+        if (active && gl == 0 && r < rend) lds[nu * WAVE_ROWS + (r - t.r0)] = s;
       }
     }
   }
@@ -140,6 +166,7 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
   const int g = ldw >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
+  const bool active = sub < R;
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
   for (int i = lane; i < h; i += 64) {
     if (i < w) {
@@ -157,12 +184,13 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
   const double *Gp = d.G + 2 * gl;
-  for (int ib = sub; ib < h; ib += FWD_PASSES * R) {
-    double2 a[FWD_PASSES];
+  for (int ib0 = 0; ib0 < h; ib0 += FWD_PASSES * R) {
+    const int ib = ib0 + sub;
+    double2   a[FWD_PASSES];
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
       const int i = ib + p * R;
-      a[p]        = i < h ? *reinterpret_cast<const double2 *>(Gp + (long long)i * ldw) : make_double2(0.0, 0.0);
+      a[p]        = (active && i < h) ? *reinterpret_cast<const double2 *>(Gp + (long long)i * ldw) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
@@ -176,11 +204,10 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
     }
   }
 #pragma unroll
-  for (int nu = 0; nu < MU; ++nu)
-    for (int off = g; off < 64; off <<= 1) {
-      acc0[nu] += __shfl_xor(acc0[nu], off);
-      acc1[nu] += __shfl_xor(acc1[nu], off);
-    }
+  for (int nu = 0; nu < MU; ++nu) {
+    acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
+    acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
+  }
   if (sub == 0) {
     const int c = 2 * gl;
     if (c < w) {
@@ -273,7 +300,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   const int     sub = lane / g, gl = lane - sub * g;
   constexpr int RCH = LDS_DOUBLES / MU; // rows of v staged per chunk
   const int     col = t.r0 + 2 * gl;    // this lane owns columns col, col+1
-  const bool    colok = col < ldw;
+  const bool    colok = col < ldw && sub < R;
   double        acc[MU][2];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc[nu][0] = acc[nu][1] = 0.0;
@@ -324,9 +351,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      double s = acc[nu][k];
-      for (int off = g; off < 64; off <<= 1) s += __shfl_xor(s, off);
-      acc[nu][k] = s;
+      acc[nu][k] = reduce_across(acc[nu][k], lane, sub, g, R);
     }
   if (sub == 0) {
 #pragma unroll
