@@ -223,11 +223,11 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
 
 // =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
 template <int MU>
-__device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *bb, double *yb, double *Ub)
+__device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, ldw = d.ldw;
-  constexpr int CW  = (LDS_DOUBLES - 64 * MU) / MU; // columns staged per chunk (the tail of the LDS holds the row sums)
+  const int     CW  = ((lds_dbl - 64 * MU) / MU) & ~1; // columns staged per chunk (the tail of the LDS holds the row sums)
   double       *sums = lds + MU * CW;                // [MU][64]
   const int     rend = t.r0 + t.nr;
   const int     tile_lim = min(w, rend); // rows of the top block never look right of their diagonal
@@ -291,14 +291,14 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
 }
 
 template <int MU>
-__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts)
+__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, ldw = d.ldw;
   const int     g    = lanes_per_row(ldw);
   const int     R    = 64 / g;
   const int     sub = lane / g, gl = lane - sub * g;
-  constexpr int RCH = LDS_DOUBLES / MU; // rows of v staged per chunk
+  const int     RCH = lds_dbl / MU; // rows of v staged per chunk
   const int     col = t.r0 + 2 * gl;    // this lane owns columns col, col+1
   const bool    colok = col < ldw && sub < R;
   double        acc[MU][2];
@@ -392,7 +392,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
     }
   }
   // (no static __shared__ here: it would shift the 16-byte alignment of the dynamic LDS base)
-  volatile int *s_last = reinterpret_cast<volatile int *>(lds + LDS_DOUBLES - 1);
+  volatile int *s_last = reinterpret_cast<volatile int *>(lds + lds_dbl - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the barrier
   __syncthreads();
   if (tid == 0) {
@@ -420,7 +420,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
 // One launch per level and direction: the first nblock workgroups take block-level tiles, the others four wave-level
 // tiles each (the two kinds of one level run side by side).
 template <int MU, bool HAS_BLOCK>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   Tile t;
@@ -436,12 +436,12 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
   const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
   double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
   double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-  if (HAS_BLOCK && lane < 0) fwd_block_tile<MU>(d, t, lds, bb, yb, Ub);
+  if (HAS_BLOCK && lane < 0) fwd_block_tile<MU>(d, t, lds, lds_dbl, bb, yb, Ub);
   else fwd_wave_tile<MU>(d, t, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), bb, yb, Ub);
 }
 
 template <int MU, bool HAS_BLOCK>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   Tile t;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
   const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
   double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
   double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-  if (HAS_BLOCK && lane < 0) bwd_block_tile<MU>(d, t, lds, yb, xb, xo, partials, arrivals, max_parts);
+  if (HAS_BLOCK && lane < 0) bwd_block_tile<MU>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts);
   else bwd_wave_tile<MU>(d, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), yb, xb, xo);
 }
 
@@ -551,9 +551,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       descs.push_back(d);
       const int h = d.w + d.nb, lev = D.height[k];
       if (d.ldw <= NARROW) {
-        // forward: ~16 KiB of panel per wavefront tile (at most WAVE_ROWS rows)
-        const int R   = 64 / (d.ldw / 2);
-        int       trw = std::max(FWD_PASSES * R, (2048 / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
+        // forward: 16-64 KiB of panel per wavefront tile (at most WAVE_ROWS rows): every tile re-stages the right-hand side
+        // of its supernode (w gathers), so wider panels get more rows per tile
+        const int R      = 64 / (d.ldw / 2);
+        const int budget = 2048; // doubles (16 KiB): larger tiles measured slower (fewer wavefronts in flight)
+        int       trw    = std::max(FWD_PASSES * R, (budget / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
         trw           = std::min(trw, WAVE_ROWS);
         for (int r0 = 0; r0 < h; r0 += trw) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(trw, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
@@ -616,6 +618,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
+      int need = 0;
+      for (const Tile &t : tl[kd][l]) need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : 0));
+      lev_lds[kd][l] = need;
     }
   for (int kd = 0; kd < 4; ++kd) {
     // lev_ptr[kd][l]..lev_end: store the end of each range in a parallel array (ranges of different kinds interleave)
@@ -662,19 +667,23 @@ void SolvePlan::reserve(int mu)
 template <int MU>
 static void solve_block(SolvePlan &P, const double *b, double *x, int mu_total, int nu0, hipStream_t s)
 {
-  // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels
-  const size_t lds_block = (size_t)LDS_DOUBLES * sizeof(double), lds_wave = (size_t)4 * WAVE_ROWS * MU * sizeof(double);
-  static_assert(4 * WAVE_ROWS * MU <= LDS_DOUBLES || MU > 4, "wave-level LDS must fit the block-level allocation");
-  auto cnt = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
+  // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels.
+  // Dynamic LDS per launch: what the widest block-level tile of the level needs (capped at 32 KiB), so that the levels
+  // mixing block-level and wave-level tiles keep more workgroups per CU.
+  const int lds_wave = 4 * WAVE_ROWS * MU;
+  auto      cnt      = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
+  auto      clampd   = [&](int need) { return std::max(std::max(512 * MU, lds_wave), std::min(LDS_DOUBLES, (need + 63) / 64 * 64)); };
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), std::max(lds_block, lds_wave), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), lds_wave, s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0);
+    const int ld = clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU);
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, lds_wave);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), std::max(lds_block, lds_wave), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), lds_wave, s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts);
+    const int ld = clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU);
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, lds_wave);
   }
 }
 
