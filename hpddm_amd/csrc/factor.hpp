@@ -32,6 +32,7 @@ struct HostFactor {
   std::vector<idx_t>   ldw;        // nblk: padded panel width
   std::vector<int64_t> f_off;      // nblk: offset of the panel in F (and G)
   int64_t              f_size = 0; // doubles in F
+  int64_t              f_host = 0; // panels [0, f_host) were computed on the host (hf.F holds exactly those)
   std::vector<double>  F;          // forward panels
   std::vector<double>  G;          // backward panels (LU only; empty otherwise: G == F)
   std::vector<double>  dinv;       // LDLT only: 1/D in the permuted numbering
@@ -57,9 +58,23 @@ struct CsrView {
   int           base; // 0 ('C') or 1 ('F')
 };
 
+// Upper levels of the elimination tree factorised on the device (numeric_device.hip).  numeric_host.cpp drives it through
+// this interface so that the host code carries no HIP types.
+struct DeviceLevels {
+  virtual ~DeviceLevels() { }
+  virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t max_h, idx_t max_w) = 0;
+  virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child
+  // front k: panelA = its panel with the original entries assembled (h x ldw); rel[c][i] = position of row i of child c
+  virtual void process(idx_t k, const double *panelA, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
+  virtual int end() = 0; // != 0: a pivot was not positive
+};
+
 // analysis (ordering + symbolic + layout); leaf_size <= 0 selects the default
 void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf);
 // numerical factorisation on the host (multifrontal, OpenMP); may be called again for a matrix with the same pattern
-void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf);
+// levels >= first_device_level go through dev (Cholesky only); hf.F then only holds the panels of the host levels
+void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev = nullptr, idx_t first_device_level = 2147483647);
+// first level whose fronts are large enough to be worth the device (all levels above go with it); nlev if none
+idx_t pick_first_device_level(const HostFactor &hf);
 
 } // namespace hpddm_hip

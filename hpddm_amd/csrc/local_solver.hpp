@@ -6,6 +6,7 @@
 namespace hpddm_hip {
 
 hipStream_t library_stream();
+DeviceLevels *make_device_levels(DeviceFactor &D); // numeric_device.hip
 
 struct LocalSolver {
   HostFactor   host;

@@ -291,7 +291,20 @@ void right_multiply_lower(idx_t m, idx_t w, double *B, long ldb, const double *X
 
 } // namespace
 
-void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
+idx_t pick_first_device_level(const HostFactor &hf)
+{
+  const Symbolic &s    = hf.sym;
+  const idx_t     nlev = (idx_t)hf.level_ptr.size() - 1;
+  for (idx_t l = 0; l < nlev; ++l)
+    for (idx_t q = hf.level_ptr[l]; q < hf.level_ptr[l + 1]; ++q) {
+      const idx_t k = hf.level_blk[q];
+      const idx_t h = (s.blk_ptr[k + 1] - s.blk_ptr[k]) + (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+      if (h >= 768) return l;
+    }
+  return nlev;
+}
+
+void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev, idx_t first_device_level)
 {
   const double    t0   = now();
   const Symbolic &s    = hf.sym;
@@ -301,7 +314,11 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
   const bool lu        = (kind == FACT_LU);
   PermutedMatrix P;
   build_permuted(A, hf.ord, lu, P);
-  hf.F.assign((size_t)hf.f_size, 0.0);
+  const idx_t nlev_all = (idx_t)hf.level_ptr.size() - 1;
+  if (!dev || kind != FACT_CHOL) first_device_level = nlev_all;
+  first_device_level = std::min(first_device_level, nlev_all);
+  hf.f_host = first_device_level >= nlev_all ? hf.f_size : hf.f_off[hf.level_blk[hf.level_ptr[first_device_level]]]; // panels are packed level by level
+  hf.F.assign((size_t)hf.f_host, 0.0);
   if (lu) hf.G.assign((size_t)hf.f_size, 0.0);
   else std::vector<double>().swap(hf.G);
   if (kind == FACT_LDLT) hf.dinv.assign(n, 0.0);
@@ -501,7 +518,7 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
     lap(3);
   };
 
-  const idx_t nlev = (idx_t)hf.level_ptr.size() - 1;
+  const idx_t nlev = first_device_level;
   for (idx_t l = 0; l < nlev; ++l) {
     const idx_t b0 = hf.level_ptr[l], b1 = hf.level_ptr[l + 1];
     const double tl0 = now();
@@ -511,6 +528,58 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf)
     } else
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
     if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
+  }
+  if (first_device_level < nlev_all && !bad) {
+    // ---- hand-over: the remaining levels run on the device ----
+    const double td0 = now();
+    size_t cbd = 0;
+    idx_t  max_h = 0, max_w = 0;
+    for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q) {
+      const idx_t k = hf.level_blk[q], w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+      cbd += ((size_t)nb * nb + 15) / 16 * 16;
+      max_h = std::max(max_h, w + nb);
+      max_w = std::max(max_w, w);
+      for (idx_t ch : children[k])
+        if (s.height[ch] < first_device_level) {
+          const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+          cbd += (nbc * nbc + 15) / 16 * 16;
+        }
+    }
+    dev->begin(hf, cbd, max_h, max_w);
+    std::vector<double>           staging;
+    std::vector<idx_t>           &rel = relidx_t[0];
+    if ((idx_t)rel.size() != n) rel.assign(n, -1);
+    std::vector<std::vector<int>> maps;
+    for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q) {
+      const idx_t  k  = hf.level_blk[q];
+      const idx_t  c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+      const idx_t  h = w + nb, ld = hf.ldw[k];
+      const idx_t *rows = s.rows.data() + s.row_ptr[k];
+      for (idx_t ch : children[k])
+        if (cb[ch]) { // computed on the host: move it to the device once
+          const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+          // the host keeps lower triangles only: make sure the upper part is defined (zero) before the copy
+          for (idx_t i = 0; i < nbc; ++i) std::fill(cb[ch] + (size_t)i * nbc + i + 1, cb[ch] + (size_t)(i + 1) * nbc, 0.0);
+          dev->upload_cb(ch, cb[ch], nbc);
+          pool.put(cb[ch], (size_t)nbc * nbc);
+          cb[ch] = nullptr;
+        }
+      staging.assign((size_t)h * ld, 0.0);
+      for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
+      for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
+      for (idx_t c = c0; c < c0 + w; ++c)
+        for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) staging[(size_t)rel[P.lrow[p]] * ld + (c - c0)] += P.lval[p];
+      maps.assign(children[k].size(), {});
+      for (size_t c = 0; c < children[k].size(); ++c) {
+        const idx_t ch = children[k][c];
+        for (int64_t p = s.row_ptr[ch]; p < s.row_ptr[ch + 1]; ++p) maps[c].push_back((int)rel[s.rows[p]]);
+      }
+      for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
+      for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
+      dev->process(k, staging.data(), children[k], maps);
+    }
+    if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive
+    if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
   }
   omp_set_num_threads(saved_threads);
   hf.info      = bad;

@@ -474,7 +474,9 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   u_size     = hf.u_size;
   nnz_exact  = hf.sym.nnz_exact;
   nnz_stored = hf.sym.nnz_stored;
-  F.upload(hf.F, s);
+  F.alloc((size_t)hf.f_size);
+  HH_CHECK((int64_t)hf.F.size() >= hf.f_host, "host panel pool smaller than its prefix");
+  if (hf.f_host) HIP_OK(hipMemcpyAsync(F.p, hf.F.data(), (size_t)hf.f_host * sizeof(double), hipMemcpyHostToDevice, s)); // the rest was built in place by the device levels
   if (kind == FACT_LU) G.upload(hf.G, s);
   else G.release();
   if (kind == FACT_LDLT) dinv.upload(hf.dinv, s);

@@ -15,7 +15,10 @@ def poisson3d(N):
 
 print('devices', lib.HpddmHipDeviceCount())
 ok = True
-for N, mode, mus in [(8, 'chol', [1, 2, 3, 4, 5, 8, 11]), (12, 'ldlt', [1, 4]), (11, 'lu', [1, 2]), (24, 'chol', [1, 8]), (40, 'chol', [1])] + ([(65, 'chol', [1, 4])] if len(sys.argv) > 1 else []):
+cases = [(8, 'chol', [1, 2, 3, 4, 5, 8, 11]), (12, 'ldlt', [1, 4]), (11, 'lu', [1, 2]), (24, 'chol', [1, 8]), (40, 'chol', [1])] + ([(65, 'chol', [1, 4])] if len(sys.argv) > 1 else [])
+if len(sys.argv) > 2:
+    cases = [(int(v), 'chol', [1]) for v in sys.argv[2:]]
+for N, mode, mus in cases:
     A = poisson3d(N)
     if mode == 'lu':
         rng = np.random.default_rng(0)

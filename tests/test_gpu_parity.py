@@ -191,3 +191,25 @@ def test_larger_size_properties():
     res = A.compute_residual(sol, f)
     assert it <= 45 and res[1] / res[0] <= 1e-2
     A.destroy()
+
+
+def test_device_levels_of_the_factorisation():
+    """fronts with >= 768 rows are factorised on the device (numeric_device.hip, MFMA f64): a 40^3 subdomain has a
+    1600-wide top separator.  Direct-solve residual (examples/schwarz.cpp:178 asks 1e-6) and agreement with SuperLU."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    N = 40
+    I = sp.identity(N)
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    A = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
+    n = A.shape[0]
+    L = sp.tril(A).tocsr()
+    L.sort_indices()
+    S = hpddm.Subdomain()
+    S.numfact(n, L.indptr, L.indices, L.data, sym=True, spd=True)
+    b = np.asfortranarray(np.random.default_rng(11).random((n, 2)))
+    x = S.solve(b)
+    assert np.abs(A @ x - b).max() / np.abs(b).max() < 1e-10
+    ref = spl.splu(sp.csc_matrix(A)).solve(b)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    S.destroy()
