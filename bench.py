@@ -124,7 +124,8 @@ def main():
         "metric": "ras_precond_applies_per_sec", "value": value, "unit": "applies/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: 3-D Poisson {args.n}^3 per GPU, {args.subdomains} subdomains per GPU, one-level RAS, "
+        "config": {"workload": f"BASELINE.json configs[{1 if args.n == 128 else (2 if args.n == 256 else '1-like')}]: 3-D Poisson {args.n}^3 per GPU, "
+                               f"{args.subdomains} subdomains per GPU, one-level RAS (two-level leg reported under 'two_level'), "
                                f"HIP level-scheduled SpTRSV, overlap 1, mu={mu}",
                    "parallelism": ("1 GPU, 8 subdomains batched" if world == 1 else
                                    (f"{world} GPUs, one global {args.n}x{args.n}x{args.n * world} problem, 8 subdomains per GPU, cross-GPU halo by RCCL send/recv" if sharded
