@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--no-gmres", action="store_true")
     ap.add_argument("--no-two-level", action="store_true")
     ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level leg")
+    ap.add_argument("--geneo", action="store_true", help="two-level leg: compute the real GenEO vectors (solveGEVP) instead of the polynomial stand-ins")
     args = ap.parse_args()
 
     import numpy as np
@@ -85,7 +86,7 @@ def main():
                                              partition=(rank, [8 * r for r in range(world + 1)]))
         A.enable_distributed(dist, dev, mu_cap=max(1, args.mu), host_staging=cpu_coll)
     else:
-        subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth")
+        subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth", neumann=args.geneo)
         A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
     A.call_numfact()
     t_setup = time.time() - t0
@@ -191,23 +192,41 @@ def two_level(A, subs, args, np, mu, reps):
     the local coordinates, the coarse operator E = Z^T A Z is assembled and inverted as in the reference."""
     nu = args.geneo_nu
     expo = [(a, b, c) for deg in range(8) for a in range(deg + 1) for b in range(deg + 1 - a) for c in [deg - a - b]][:nu]
+    tg = time.time()
+    lam_max = None
     for s, sd in enumerate(subs):
+        if args.geneo:
+            A.set_option("geneo_nu", nu)
+            lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], sd["sym"])
+            lam_max = max(lam_max or 0.0, float(lam[-1]))
+            continue
         i0, i1, j0, j1, k0, k1 = sd["box"]
         z, y, x = np.meshgrid(np.linspace(-1, 1, k1 - k0), np.linspace(-1, 1, j1 - j0), np.linspace(-1, 1, i1 - i0), indexing="ij")
         Z = np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo], axis=1)
         A.set_vectors(s, Z)
+    tg = time.time() - tg
     t0 = time.time()
     A.build_coarse_operator()
     t_coarse = time.time() - t0
     A.set_option("schwarz_coarse_correction", 0)  # deflated
     t_defl = A.time("deflation", mu=mu, warmup=2, reps=reps)
     t_apply = A.time("apply", mu=mu, warmup=2, reps=reps)
+    import torch
+    f = torch.from_numpy(np.concatenate([s["f"] for s in subs])).cuda()
+    xs = torch.zeros_like(f)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    it2 = A.solve_device(f.data_ptr(), xs.data_ptr(), 1)
+    torch.cuda.synchronize()
+    t_gm = time.perf_counter() - t1
     A.set_option("schwarz_coarse_correction", -1)
     n = A.stats()["n"]
     bytes_panel = 2.0 * n * nu * 8.0 + 3.0 * n * mu * 8.0   # SURVEY 8(d): Z read twice + D r read, Z y written, ...
     return {"geneo_nu": nu, "coarse_dim": int(A.stats()["coarse_dim"]), "deflation_ms": t_defl * 1e3, "apply_ms": t_apply * 1e3,
             "applies_per_sec": 1.0 / t_apply, "deflation_panel_GBps": bytes_panel / t_defl / 1e9, "deflation_flops": 4.0 * n * nu * mu,
-            "coarse_setup_seconds": round(t_coarse, 2), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64)"}
+            "coarse_setup_seconds": round(t_coarse, 2), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64)",
+            "coarse_space": ("GenEO (solveGEVP), largest kept eigenvalue %.3f, %.1f s" % (lam_max, tg)) if args.geneo else "monomials of degree <= 3 (stand-in)",
+            "gmres": {"iterations": it2, "seconds": t_gm, "iters_per_sec": it2 / t_gm}}
 
 
 def cpu_baseline(A, subs, d, args, np):

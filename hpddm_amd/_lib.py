@@ -43,6 +43,8 @@ def _declare(lib):
         "HpddmHipSchwarzMultiplicityScaling": (I, [P, P]),
         "HpddmHipSchwarzInitialize": (I, [P, I, P]),
         "HpddmHipSchwarzSetVectors": (I, [P, I, I, P]),
+        "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
+        "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),
         "HpddmHipSchwarzBuildCoarseOperator": (I, [P]),
         "HpddmHipSchwarzCallNumfact": (I, [P]),
         "HpddmHipSchwarzSetOption": (I, [P, C, D]),

@@ -91,6 +91,22 @@ int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z
     A->op.set_vectors(s, nu, Z);
     return 0;)
 }
+int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering)
+{
+  HH_TRY(
+    HH_CHECK(A && ia && ja && a, "null argument");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F');
+    return 0;)
+}
+int HpddmHipSchwarzGetEigenvalues(HpddmHipSchwarz *A, int s, double *out, int capacity)
+{
+  if (!A || s < 0 || s >= A->op.nsub) return -1;
+  const std::vector<double> &ev = A->op.subs[s].eigenvalues;
+  if (out)
+    for (int i = 0; i < (int)ev.size() && i < capacity; ++i) out[i] = ev[i];
+  return (int)ev.size();
+}
 int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A)
 {
   HH_TRY(

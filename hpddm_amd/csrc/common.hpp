@@ -53,4 +53,6 @@ struct Symbolic {
 
 void symbolic_factorization(const Graph &g, const Ordering &ord, Symbolic &sym);
 
+int host_thread_cap(); // OpenMP threads the host-side phases may use (numeric_host.cpp)
+
 } // namespace hpddm_hip

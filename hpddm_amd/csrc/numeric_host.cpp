@@ -20,6 +20,29 @@ static double now()
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// The GPU hosts expose hundreds of hardware threads while the container may only be scheduled on a few: an OpenMP team
+// of 256 spinning threads on 16 CPUs turns every parallel region into milliseconds.  The cap is the container's CPU
+// quota if there is one, else 32; HPDDM_HIP_NUM_THREADS overrides it.  Applied once when the library is loaded.
+int host_thread_cap()
+{
+  static const int cap = [] {
+    int c = 32;
+    if (FILE *fc = fopen("/sys/fs/cgroup/cpu.max", "r")) { // "max" or "<quota> <period>"
+      long long quota = 0, period = 0;
+      if (fscanf(fc, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) c = std::max<int>(1, (int)((quota + period - 1) / period));
+      fclose(fc);
+    }
+    if (const char *e = getenv("HPDDM_HIP_NUM_THREADS")) c = std::max(1, atoi(e));
+    return std::max(1, std::min(omp_get_num_procs(), c));
+  }();
+  return cap;
+}
+namespace {
+struct ThreadCapAtLoad {
+  ThreadCapAtLoad() { omp_set_num_threads(host_thread_cap()); }
+} g_thread_cap_at_load;
+} // namespace
+
 static idx_t padded_width(idx_t w)
 {
   // narrow panels: even width (16-byte row alignment; the wave-level kernels take any even ldw <= 128);
@@ -332,17 +355,7 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
   std::vector<std::vector<idx_t>> children(nblk);
   for (idx_t k = 0; k < nblk; ++k)
     if (s.parent[k] >= 0) children[s.parent[k]].push_back(k);
-  // The GPU hosts expose hundreds of hardware threads; this factorisation stops scaling long before that, and
-  // oversubscribed barriers are very slow.  The cap is the container's CPU quota if there is one, else 32; HPDDM_HIP_NUM_THREADS overrides it.
-  const int saved_threads = omp_get_max_threads();
-  int       cap           = 32;
-  if (FILE *fc = fopen("/sys/fs/cgroup/cpu.max", "r")) { // container CPU quota ("max" or "<quota> <period>")
-    long long quota = 0, period = 0;
-    if (fscanf(fc, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) cap = std::max<int>(1, (int)((quota + period - 1) / period));
-    fclose(fc);
-  }
-  if (const char *e = getenv("HPDDM_HIP_NUM_THREADS")) cap = std::max(1, atoi(e));
-  const int nthreads = std::max(1, std::min(saved_threads, cap));
+  const int nthreads = host_thread_cap();
   omp_set_num_threads(nthreads);
   std::vector<std::vector<idx_t>> relidx_t(nthreads);
   int                             bad = 0;
@@ -581,7 +594,6 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
     if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive
     if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
   }
-  omp_set_num_threads(saved_threads);
   hf.info      = bad;
   hf.t_numeric = now() - t0;
 }

@@ -33,6 +33,8 @@ struct SchwarzSub {
   std::vector<double> d;                             // Schwarz::d_
   std::vector<double> Z;                             // Preconditioner::ev_: n x nu column-major
   int                 nu = 0;
+  std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B)
+  int                 gevp_iterations = 0;
   std::unique_ptr<LocalSolver> ls;
 };
 
@@ -106,6 +108,7 @@ struct Schwarz {
   void multiplicity_scaling(double *const *d);
   void initialize(int s, const double *d);
   void set_vectors(int s, int nu, const double *Z);
+  void solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base); // geneo.hip
   void build_device();           // uploads matrices, d, halo lists (lazy)
   void call_numfact();
   void build_coarse();

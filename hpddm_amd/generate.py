@@ -163,7 +163,7 @@ def _factor3(p):
     return best[1]
 
 
-def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False):
+def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False, neumann=False):
     """7-point Laplacian on N^3 cells of the unit cube (h = 1/N, homogeneous Dirichlet through the stencil, like the
     2-D reference problem), split into ``parts`` boxes grown by ``overlap`` layers.  Returns the subdomains
     ``first .. first+count-1`` (default: all).  ``d`` is the product of the 1-D ramps of the reference generator
@@ -228,6 +228,21 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
         ia = np.zeros(n + 1, dtype=np.int64)
         np.add.at(ia, rows + 1, 1)
         ia = np.cumsum(ia)
+        a_neumann = None
+        if neumann:
+            # Neumann matrix of the subdomain (MatNeumann of examples/generate.cpp:243-291 in spirit): same pattern, no
+            # coupling through the artificial interfaces -- the diagonal loses 1/h^2 per missing in-domain neighbour
+            miss = np.zeros((nz, ny, nx))
+            for axis, (lo, hi), hh, dim in ((2, (i0, i1), h2[0], dims[0]), (1, (j0, j1), h2[1], dims[1]), (0, (k0, k1), h2[2], dims[2])):
+                sl_lo = [slice(None)] * 3
+                sl_hi = [slice(None)] * 3
+                sl_lo[axis], sl_hi[axis] = 0, -1
+                if lo != 0:
+                    miss[tuple(sl_lo)] += hh
+                if hi != dim:
+                    miss[tuple(sl_hi)] += hh
+            a_neumann = vals.astype(np.float64).copy()
+            a_neumann[rows == cols] -= miss.reshape(-1)
         # ---- partition-of-unity weights: product of the 1-D ramps ----
         d = weights(r)
         if normalize:
@@ -260,4 +275,6 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
         subs.append(dict(n=n, ia=(ia + F).astype(np.int32), ja=(cols + F).astype(np.int32), a=vals.astype(np.float64), sym=bool(sym),
                          numbering=numbering, neighbors=np.array(neigh, dtype=np.int32), connectivity=conn, d=d, f=f,
                          box=(i0, i1, j0, j1, k0, k1)))
+        if neumann:
+            subs[-1]["a_neumann"] = a_neumann
     return subs

@@ -174,6 +174,17 @@ class Schwarz:
         Z = Z.reshape(Z.shape[0], -1, order="F")
         check(self._lib.HpddmHipSchwarzSetVectors(self._h, s, Z.shape[1], _dptr(Z)))
 
+    def solve_gevp(self, s, n, ia, ja, a, sym, numbering="C"):
+        """schwarzSolveGEVP(A, MatNeumann) (interface/hpddm.py:244): GenEO vectors of local subdomain s; returns the eigenvalues."""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ja = np.ascontiguousarray(ja, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        check(self._lib.HpddmHipSchwarzSolveGEVP(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
+        k = self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, None, 0)
+        ev = np.zeros(max(k, 1))
+        self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)
+        return ev[:k]
+
     def build_coarse_operator(self):
         check(self._lib.HpddmHipSchwarzBuildCoarseOperator(self._h))
 

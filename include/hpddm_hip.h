@@ -79,6 +79,14 @@ int HpddmHipSchwarzMultiplicityScaling(HpddmHipSchwarz *A, double *const *d);
 int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d);
 /* HpddmSetVectors + HpddmInitializeCoarseOperator (HPDDM.h:95-96): nu deflation vectors of subdomain s, column-major n_s x nu */
 int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z);
+/* HpddmSchwarzSolveGEVP (HPDDM.h:107, Schwarz::solveGEVP include/HPDDM_schwarz.hpp:665-715): GenEO coarse space of local
+ * subdomain s from its Neumann matrix (same CSR conventions as SetSubdomain): the -hpddm_geneo_nu (default 20) lowest
+ * eigenvectors of A_N x = lambda B x, B = scaleIntoOverlap(A_N), kept below -hpddm_geneo_threshold if it is set.
+ * Replaces SetVectors.  The reference runs ARPACK in shift-invert mode on the local Solver; here a shift-invert
+ * subspace iteration whose solves are the HIP SpTRSV. */
+int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering);
+/* eigenvalues kept for subdomain s (returns their number; out may be NULL) */
+int HpddmHipSchwarzGetEigenvalues(HpddmHipSchwarz *A, int s, double *out, int capacity);
 /* HpddmSchwarzBuildCoarseOperator (HPDDM.h:108, Preconditioner::buildTwo include/HPDDM_preconditioner.hpp:124-257):
  * E = Z^T A Z assembled from the local products and factorised (dense, replicated). */
 int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A);

@@ -102,6 +102,32 @@ class Oracle:
     def set_vectors(self, Z):
         self.Z = [np.asarray(z, dtype=np.float64).reshape(self.subs[s]["n"], -1) for s, z in enumerate(Z)]
 
+    # ---- GenEO: Schwarz::scaleIntoOverlap + solveGEVP (include/HPDDM_schwarz.hpp:622-715); the reference hands the
+    # pencil to ARPACK in shift-invert mode (include/HPDDM_ARPACK.hpp:84-148) -- restated with scipy's ARPACK wrapper ----
+    def scale_into_overlap(self, s, AN):
+        ovl = np.zeros(self.subs[s]["n"], dtype=bool)
+        for _, idx in self.map[s]:
+            ovl[idx[self.d[s][idx] > HPDDM_EPS]] = True
+        D = sp.diags(self.d[s] * ovl)
+        B = (D @ AN @ D).tocsr()
+        B.data[np.abs(B.data) <= HPDDM_EPS] = 0.0
+        B.eliminate_zeros()
+        return B
+
+    def geneo(self, neumann, nu, shift=1.0e-2):
+        """neumann: list of scipy matrices A_N; returns eigenvalues per subdomain and sets the deflation vectors"""
+        lams, Z = [], []
+        for s in range(self.P):
+            AN = sp.csr_matrix(neumann[s])
+            B = self.scale_into_overlap(s, AN)
+            k = min(nu, max(1, self.subs[s]["n"] // 4))
+            w, v = spl.eigsh(AN.tocsc(), k=k, M=B.tocsc(), sigma=-shift, which="LM", tol=1e-12)
+            order = np.argsort(w)
+            lams.append(w[order])
+            Z.append(v[:, order])
+        self.set_vectors(Z)
+        return lams
+
     def build_coarse(self, symmetric=True):
         off = np.concatenate([[0], np.cumsum([z.shape[1] for z in self.Z])])
         DZ = [self.d[s][:, None] * self.Z[s] for s in range(self.P)]

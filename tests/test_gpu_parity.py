@@ -213,3 +213,35 @@ def test_device_levels_of_the_factorisation():
     ref = spl.splu(sp.csc_matrix(A)).solve(b)
     assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
     S.destroy()
+
+
+def test_geneo_coarse_space_against_arpack():
+    """GenEO: eigenvalues of (A_N, scaleIntoOverlap(A_N)) against scipy's ARPACK (what the reference calls),
+    then the deflated two-level operator built on them (invariant under a change of basis of each local space)."""
+    N, parts, ov, nu = 14, 8, 2, 6
+    subs = generate3d(N, parts, ov, sym=True, rhs="smooth", neumann=True)
+    A, d = hpddm.schwarz_from_subdomains(subs, options=f"-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu {nu} -hpddm_eigensolver_tol 1e-9")
+    orc = Oracle(subs, correction="deflated")
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    neumann = []
+    for sd in subs:
+        sn = dict(sd)
+        sn["a"] = sd["a_neumann"]
+        from oracle.ras_oracle import csr_full
+        neumann.append(csr_full(sn))
+    lam_ref = orc.geneo(neumann, nu)
+    for s, sd in enumerate(subs):
+        lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], sd["sym"])
+        assert len(lam) == nu
+        assert np.all(np.abs(lam - lam_ref[s]) <= 1e-6 * np.maximum(np.abs(lam_ref[s]), 1e-3)), (s, lam, lam_ref[s])
+    A.build_coarse_operator()
+    A.call_numfact()
+    orc.build_coarse()
+    orc.numfact()
+    f = orc.exchange([np.random.default_rng(9).random(sd["n"]) for sd in subs])
+    _close(A.deflation(f), orc.deflation(f), 1e-6, "deflation on the GenEO space")
+    _close(A.apply(f), orc.apply(f), 1e-6, "two-level apply")
+    it, sol = A.solve(f)
+    it_o, sol_o, _ = orc.gmres(f)
+    assert abs(it - it_o) <= 1 and it < 20
+    A.destroy()
