@@ -1,0 +1,367 @@
+// Device-resident Block GMRES: IterativeMethod::BGMRES (include/HPDDM_GMRES.hpp:159-313) with BlockArnoldi
+// (include/HPDDM_iterative.hpp:713-734), blockOrthogonalization (:523-556, classical block Gram-Schmidt), CholQR (:622-640,
+// VR :559-582), checkBlockConvergence (:128-182), updateSol/computeMin/addSol (:272-336), same conventions as the
+// reference: D-weighted block inner products, Householder QR of the (2 mu x mu) blocks of the block Hessenberg matrix,
+// right preconditioning by default.  Built without right-hand-side deflation (-hpddm_deflation_tol, default -1 = off in
+// the reference as well) and with the CholQR factorisation (the reference's default -hpddm_qr).
+//
+// The basis blocks, the operator and the preconditioner stay in HBM; the host only sees (i+1) mu x mu Gram blocks.
+#include "schwarz.hpp"
+#include <cmath>
+#include <limits>
+
+namespace hpddm_hip {
+
+// partial[kk][blk][a][b] = sum over the rows of the block of d V_kk[.,a] W[.,b]  (kk-th basis block, all subdomains)
+template <int MU>
+__global__ __launch_bounds__(256) void k_block_gram(const long long *__restrict__ voff, const int *__restrict__ nn, int nsub, const double *__restrict__ d, const double *__restrict__ V, long long ldv, const double *__restrict__ W, double *__restrict__ partial)
+{
+  const int kk = blockIdx.y;
+  double    acc[MU][MU];
+#pragma unroll
+  for (int a = 0; a < MU; ++a)
+#pragma unroll
+    for (int b = 0; b < MU; ++b) acc[a][b] = 0.0;
+  for (int s = 0; s < nsub; ++s) {
+    const int       n  = nn[s];
+    const long long v0 = voff[s];
+    const double   *vp = V + (long long)kk * ldv + v0 * MU, *wp = W + v0 * MU;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const double di = d[v0 + i];
+      double       w[MU];
+#pragma unroll
+      for (int b = 0; b < MU; ++b) w[b] = wp[(long long)b * n + i];
+#pragma unroll
+      for (int a = 0; a < MU; ++a) {
+        const double va = di * vp[(long long)a * n + i];
+#pragma unroll
+        for (int b = 0; b < MU; ++b) acc[a][b] = fma(va, w[b], acc[a][b]);
+      }
+    }
+  }
+  __shared__ double red[4][MU * MU];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < MU; ++a)
+#pragma unroll
+    for (int b = 0; b < MU; ++b) {
+      double v = acc[a][b];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) red[wave][a * MU + b] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < MU * MU) partial[((long long)kk * gridDim.x + blockIdx.x) * (MU * MU) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// out[kk][a][b] = sum_blk partial[kk][blk][a][b] in block order
+__global__ void k_block_gram_reduce(const double *__restrict__ partial, int nblk, int mm, double *__restrict__ out)
+{
+  const int o = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;
+  if (o >= mm) return;
+  double v = 0.0;
+  for (int b = 0; b < nblk; ++b) v += partial[((long long)kk * nblk + b) * mm + o];
+  out[(long long)kk * mm + o] = v;
+}
+// W[., b] = beta * W[., b] + sign * sum_kk sum_a V_kk[., a] C[(kk*MU + a) * MU + b]      (C in global memory, k*MU x MU row-major)
+template <int MU>
+__global__ __launch_bounds__(256) void k_block_axpy(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ V, long long ldv, int k, const double *__restrict__ C, double sign, double beta, double *__restrict__ W)
+{
+  extern __shared__ double cs[];
+  for (int idx = threadIdx.x; idx < k * MU * MU; idx += blockDim.x) cs[idx] = C[idx];
+  __syncthreads();
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double acc[MU];
+#pragma unroll
+    for (int b = 0; b < MU; ++b) acc[b] = 0.0;
+    for (int kk = 0; kk < k; ++kk) {
+      const double *vp = V + (long long)kk * ldv + v0 * MU + i;
+#pragma unroll
+      for (int a = 0; a < MU; ++a) {
+        const double va = vp[(long long)a * n];
+#pragma unroll
+        for (int b = 0; b < MU; ++b) acc[b] = fma(va, cs[(kk * MU + a) * MU + b], acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MU; ++b) {
+      double *wp = W + v0 * MU + (long long)b * n + i;
+      *wp        = (beta == 0.0 ? 0.0 : beta * *wp) + sign * acc[b];
+    }
+  }
+}
+__global__ void k_axpby2(long long cnt, double a, const double *__restrict__ x, double b, const double *__restrict__ y, double *__restrict__ out)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) out[i] = a * x[i] + b * y[i];
+}
+
+namespace {
+// ---- small dense helpers (column-major with leading dimension ld, like the reference's H and s) ----
+// Householder QR of the m x n block A (m >= n): R in the upper triangle, reflectors below, tau[n]   (LAPACK geqr2 conventions)
+void geqr2(int m, int n, double *A, int ld, double *tau)
+{
+  for (int j = 0; j < n; ++j) {
+    double nrm = 0.0;
+    for (int i = j + 1; i < m; ++i) nrm += A[i + (size_t)j * ld] * A[i + (size_t)j * ld];
+    const double alpha = A[j + (size_t)j * ld];
+    if (nrm == 0.0) {
+      tau[j] = 0.0;
+      continue;
+    }
+    const double beta = -std::copysign(std::sqrt(alpha * alpha + nrm), alpha);
+    tau[j]            = (beta - alpha) / beta;
+    const double sc   = 1.0 / (alpha - beta);
+    for (int i = j + 1; i < m; ++i) A[i + (size_t)j * ld] *= sc;
+    A[j + (size_t)j * ld] = beta;
+    for (int c = j + 1; c < n; ++c) { // apply H_j to the trailing columns
+      double w = A[j + (size_t)c * ld];
+      for (int i = j + 1; i < m; ++i) w += A[i + (size_t)j * ld] * A[i + (size_t)c * ld];
+      w *= tau[j];
+      A[j + (size_t)c * ld] -= w;
+      for (int i = j + 1; i < m; ++i) A[i + (size_t)c * ld] -= w * A[i + (size_t)j * ld];
+    }
+  }
+}
+// C (m x nc, ldc) <- Q^T C with the nr reflectors stored in A (m x nr, lda) / tau       (LAPACK orm2r 'L','T')
+void orm2r_lt(int m, int nc, int nr, const double *A, int lda, const double *tau, double *C, int ldc)
+{
+  for (int j = 0; j < nr; ++j) {
+    if (tau[j] == 0.0) continue;
+    for (int c = 0; c < nc; ++c) {
+      double w = C[j + (size_t)c * ldc];
+      for (int i = j + 1; i < m; ++i) w += A[i + (size_t)j * lda] * C[i + (size_t)c * ldc];
+      w *= tau[j];
+      C[j + (size_t)c * ldc] -= w;
+      for (int i = j + 1; i < m; ++i) C[i + (size_t)c * ldc] -= w * A[i + (size_t)j * lda];
+    }
+  }
+}
+} // namespace
+
+template <int MU>
+static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
+{
+  constexpr int mu = MU;
+  A.reserve(mu);
+  hipStream_t  st        = library_stream();
+  const double tol       = A.getopt("tol", 1.0e-6);
+  const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int    m         = std::max(1, std::min((int)A.getopt("gmres_restart", 40), max_it));
+  const int    variant   = (int)A.getopt("variant", VARIANT_RIGHT);
+  const int    verbosity = (int)A.getopt("verbosity", 0);
+  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGMRES: only the left and right variants are built");
+  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGMRES: right-hand-side deflation (-hpddm_deflation_tol) is not built");
+  const long long cnt = A.ntot * mu;
+  const int       ldh = mu * (m + 1);
+  const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  const int       nblk = 64;
+  DevBuf<double>  V, Ax, partial, gram_d, coef_d;
+  V.alloc((size_t)cnt * (m + 1));
+  Ax.alloc((size_t)cnt);
+  partial.alloc((size_t)(m + 1) * nblk * mu * mu);
+  gram_d.alloc((size_t)(m + 1) * mu * mu);
+  coef_d.alloc((size_t)(m + 1) * mu * mu);
+  auto vk = [&](int k) { return V.p + (size_t)k * cnt; };
+  // G[(kk*mu + a)*mu + b] = <V_kk[.,a], W[.,b]>_D for kk < k
+  auto gram = [&](const double *Vb, int k, const double *W, std::vector<double> &G) {
+    G.resize((size_t)k * mu * mu);
+    hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, (unsigned)k), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, Vb, cnt, W, partial.p);
+    hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)k), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * k * mu * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (A.nranks > 1) {
+      HH_CHECK(A.allreduce_fn != nullptr, "several ranks but no all-reduce registered");
+      HH_CHECK(A.allreduce_fn(A.cb_ctx, G.data(), k * mu * mu) == 0, "all-reduce failed");
+    }
+  };
+  // W = beta W + sign * V(0..k) C,  C given as (k*mu) x mu row-major
+  auto axpy_blocks = [&](const double *Vb, int k, const std::vector<double> &C, double sign, double beta, double *W) {
+    HIP_OK(hipMemcpyAsync(coef_d.p, C.data(), sizeof(double) * k * mu * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * k * mu * mu, st, A.voff_d.p, A.n_d.p, Vb, cnt, k, coef_d.p, sign, beta, W);
+  };
+  // CholQR of the block W (n x mu): R (mu x mu upper, row-major r[a*mu+b]); W <- W R^{-1} if update; returns the rank
+  auto cholqr = [&](double *W, std::vector<double> &R, bool update) {
+    std::vector<double> G;
+    gram(W, 1, W, G);
+    R.assign((size_t)mu * mu, 0.0);
+    int rank = mu;
+    for (int j = 0; j < mu; ++j) { // potrf "U": G = R^T R
+      double dj = G[(size_t)j * mu + j];
+      for (int k = 0; k < j; ++k) dj -= R[(size_t)k * mu + j] * R[(size_t)k * mu + j];
+      if (!(dj > 0.0)) {
+        rank = j;
+        break;
+      }
+      dj                    = std::sqrt(dj);
+      R[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        double v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= R[(size_t)k * mu + j] * R[(size_t)k * mu + c];
+        R[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    if (rank == mu && update) {
+      std::vector<double> Rinv((size_t)mu * mu, 0.0); // upper
+      for (int c = 0; c < mu; ++c)
+        for (int i = c; i >= 0; --i) {
+          double v = (i == c) ? 1.0 : 0.0;
+          for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
+          Rinv[(size_t)i * mu + c] = v / R[(size_t)i * mu + i];
+        }
+      HIP_OK(hipMemcpyAsync(Ax.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st)); // W <- W Rinv needs a copy of W
+      axpy_blocks(Ax.p, 1, Rinv, 1.0, 0.0, W);
+    }
+    return rank;
+  };
+  std::vector<double> H((size_t)ldh * mu * m, 0.0), s((size_t)ldh * mu, 0.0), tau((size_t)m * 2 * mu, 0.0), norm(mu), G, R;
+  auto                Hc = [&](int i) { return H.data() + (size_t)i * mu * ldh; };
+  // ---- initializeNorm ----
+  A.exchange_inplace(x, mu, true);
+  {
+    std::vector<double> nb;
+    if (variant == VARIANT_LEFT) {
+      A.apply(b, vk(0), mu);
+      gram(vk(0), 1, vk(0), nb);
+    } else gram(b, 1, b, nb);
+    for (int nu = 0; nu < mu; ++nu) {
+      norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu]);
+      if (norm[nu] < HPDDM_EPS) norm[nu] = 1.0;
+    }
+  }
+  int  j = 1, dim = mu * m, nhist = 0;
+  bool breakdown = false;
+  auto update_sol = [&](int dimc) {
+    // computeMin: H y = s (upper triangular dimc x dimc, mu right-hand sides), then x += M^{-1} (V y)
+    if (dimc <= 0) return;
+    std::vector<double> Y((size_t)dimc * mu, 0.0); // row-major dimc x mu
+    for (int c = 0; c < mu; ++c)
+      for (int r = dimc - 1; r >= 0; --r) {
+        double v = s[r + (size_t)c * ldh];
+        for (int k = r + 1; k < dimc; ++k) v -= H[r + (size_t)k * ldh] * Y[(size_t)k * mu + c];
+        Y[(size_t)r * mu + c] = v / H[r + (size_t)r * ldh];
+      }
+    const int kblocks = dimc / mu;
+    if (variant == VARIANT_LEFT) axpy_blocks(vk(0), kblocks, Y, 1.0, 1.0, x);
+    else {
+      axpy_blocks(vk(0), kblocks, Y, 1.0, 0.0, Ax.p);
+      A.apply(Ax.p, vk(m), mu);
+      hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, vk(m), x);
+    }
+  };
+  while (j <= max_it) {
+    double *r0 = variant == VARIANT_LEFT ? Ax.p : vk(0);
+    A.gmv(x, r0, mu);
+    hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, r0, r0);
+    if (variant == VARIANT_LEFT) A.apply(Ax.p, vk(0), mu);
+    const int N = cholqr(vk(0), R, true); // RRQR with tol < -0.9 = plain QR (include/HPDDM_iterative.hpp:585)
+    if (N != mu) {
+      breakdown = true;
+      break;
+    }
+    dim     = mu * (j - 1 + m > max_it ? max_it - j + 1 : m);
+    std::fill(s.begin(), s.end(), 0.0);
+    for (int c = 0; c < mu; ++c)
+      for (int r = 0; r <= c; ++r) s[r + (size_t)c * ldh] = R[(size_t)r * mu + c];
+    std::fill(H.begin(), H.end(), 0.0);
+    std::fill(tau.begin(), tau.end(), 0.0);
+    int i = 0;
+    while (i < m && j <= max_it) {
+      if (variant == VARIANT_LEFT) {
+        A.gmv(vk(i), Ax.p, mu);
+        A.apply(Ax.p, vk(i + 1), mu);
+      } else {
+        A.apply(vk(i), Ax.p, mu);
+        A.gmv(Ax.p, vk(i + 1), mu);
+      }
+      // ---- BlockArnoldi ----
+      gram(vk(0), i + 1, vk(i + 1), G);                   // classical block Gram-Schmidt
+      axpy_blocks(vk(0), i + 1, G, -1.0, 1.0, vk(i + 1));
+      double *Hi = Hc(i);
+      for (int kk = 0; kk <= i; ++kk)
+        for (int a = 0; a < mu; ++a)
+          for (int c = 0; c < mu; ++c) Hi[(kk * mu + a) + (size_t)c * ldh] = G[((size_t)kk * mu + a) * mu + c];
+      const int rk = cholqr(vk(i + 1), R, i < m - 1);
+      if (rk != mu) { // rank-deficient block: the reference drops this cycle and restarts with GMRES (include/HPDDM_GMRES.hpp:268-272,311)
+        breakdown = true;
+        break;
+      }
+      for (int c = 0; c < mu; ++c)
+        for (int r = 0; r < mu; ++r) Hi[((i + 1) * mu + r) + (size_t)c * ldh] = r <= c ? R[(size_t)r * mu + c] : 0.0;
+      for (int k = 0; k < i; ++k) orm2r_lt(2 * mu, mu, mu, Hc(k) + k * mu, ldh, tau.data() + (size_t)k * 2 * mu, Hi + k * mu, ldh);
+      geqr2(2 * mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu);
+      orm2r_lt(2 * mu, mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu, s.data() + i * mu, ldh);
+      ++i;
+      // ---- checkBlockConvergence<1> with t = 1 ----
+      int    conv = 0, which = 0;
+      double best = -1.0;
+      for (int nu = 0; nu < mu; ++nu) {
+        double nrm = 0.0;
+        for (int r = 0; r <= nu; ++r) nrm += s[(mu * i + r) + (size_t)nu * ldh] * s[(mu * i + r) + (size_t)nu * ldh];
+        nrm = std::sqrt(nrm);
+        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / norm[nu] > best) {
+          best  = nrm / norm[nu];
+          which = nu;
+        }
+      }
+      const double beta = best * norm[which];
+      if (history && nhist < history_cap) history[nhist] = beta;
+      ++nhist;
+      if (verbosity > 2) printf("BGMRES: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
+      if (conv == mu) {
+        dim = mu * i;
+        i   = 0;
+        break;
+      }
+      ++j;
+    }
+    if (breakdown) break;
+    if (j != max_it + 1 && i == m) {
+      update_sol(dim);
+      if (verbosity > 1) printf("BGMRES restart(%d)\n", m);
+    } else break;
+  }
+  if (breakdown) return -2; // caller falls back to GMRES from the current iterate (include/HPDDM_GMRES.hpp:311)
+  if (j == max_it + 1 && m > 0) {
+    const int rem = max_it % m;
+    if (rem != 0) dim = mu * rem;
+  }
+  update_sol(dim);
+  if (verbosity) {
+    if (j != max_it + 1) printf("BGMRES converges after %d iteration%s\n", j, j > 1 ? "s" : "");
+    else printf("BGMRES does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(j, max_it);
+}
+
+int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  int it;
+  switch (mu) {
+  case 1: it = bgmres_impl<1>(*this, b, x, history, history_cap); break;
+  case 2: it = bgmres_impl<2>(*this, b, x, history, history_cap); break;
+  case 3: it = bgmres_impl<3>(*this, b, x, history, history_cap); break;
+  case 4: it = bgmres_impl<4>(*this, b, x, history, history_cap); break;
+  case 5: it = bgmres_impl<5>(*this, b, x, history, history_cap); break;
+  case 6: it = bgmres_impl<6>(*this, b, x, history, history_cap); break;
+  case 7: it = bgmres_impl<7>(*this, b, x, history, history_cap); break;
+  case 8: it = bgmres_impl<8>(*this, b, x, history, history_cap); break;
+  default: HH_CHECK(false, "BGMRES: 1 <= mu <= 8 in this build"); it = -1;
+  }
+  if (it == -2) return gmres(b, x, mu, history, history_cap); // breakdown of the first QR: GMRES, as the reference does
+  return it;
+}
+
+// IterativeMethod::solve dispatch (include/HPDDM_iterative.hpp:1013-1111) for the methods built here
+int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  const int method = (int)getopt("krylov_method", 0);
+  if (method == 1) return bgmres(b, x, mu, history, history_cap);
+  HH_CHECK(method == 0, "krylov_method: only gmres and bgmres are built");
+  return gmres(b, x, mu, history, history_cap);
+}
+
+} // namespace hpddm_hip

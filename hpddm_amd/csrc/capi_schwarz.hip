@@ -231,7 +231,7 @@ int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, doub
     xd.alloc(cnt);
     HIP_OK(hipMemcpyAsync(bd.p, b, cnt * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(xd.p, sol, cnt * sizeof(double), hipMemcpyHostToDevice, st));
-    const int it = op.gmres(bd.p, xd.p, mu, history, history_cap);
+    const int it = op.krylov_solve(bd.p, xd.p, mu, history, history_cap);
     HIP_OK(hipMemcpyAsync(sol, xd.p, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return it;
@@ -328,7 +328,7 @@ int HpddmHipSolveDevice(HpddmHipSchwarz *A, const double *b, double *sol, int mu
   try {
     HH_CHECK(A && b && sol && mu >= 1, "bad argument");
     A->op.build_device();
-    return A->op.gmres(b, sol, mu, history, history_cap);
+    return A->op.krylov_solve(b, sol, mu, history, history_cap);
   } catch (const std::exception &e) {
     last_error() = e.what();
     return -1;

@@ -245,3 +245,20 @@ def test_geneo_coarse_space_against_arpack():
     it_o, sol_o, _ = orc.gmres(f)
     assert abs(it - it_o) <= 1 and it < 20
     A.destroy()
+
+
+@pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3"])
+def test_bgmres_matches_reference(name):
+    """Block GMRES: iteration count, residual history and solution of the compiled reference"""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0])
+    ref = g["history"]
+    assert len(hist) == len(ref)
+    assert np.all(np.abs(hist - ref[:, 1]) <= 2e-4 * ref[:, 1])  # five restarts amplify round-off in the last entries
+    _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-4)
+    A.destroy()
