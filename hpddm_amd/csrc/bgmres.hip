@@ -360,7 +360,8 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
 {
   const int method = (int)getopt("krylov_method", 0);
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: only gmres and bgmres are built");
+  if (method == 2) return cg(b, x, mu, history, history_cap);
+  HH_CHECK(method == 0, "krylov_method: only gmres, bgmres and cg are built");
   return gmres(b, x, mu, history, history_cap);
 }
 

@@ -226,4 +226,97 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
   return std::min(j, max_it);
 }
 
+// Preconditioned conjugate gradient: IterativeMethod::CG (include/HPDDM_CG.hpp:30-165), non-flexible variant.  Same
+// conventions: D-weighted inner products, convergence on ||M^{-1} r||_D relative to its initial value, and -- like the
+// reference (:40-42) -- GMRES is used instead when the preconditioner is not symmetric (RAS/ORAS, or the deflated
+// coarse correction).
+int Schwarz::cg(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  reserve(mu);
+  hipStream_t     st  = library_stream();
+  const double    tol = getopt("tol", 1.0e-6);
+  const int       max_it = std::min<int>((int)getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int       verbosity = (int)getopt("verbosity", 0);
+  const long long cnt = ntot * mu;
+  const dim3      g2((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  DevBuf<double>  z, r, p, coef;
+  z.alloc((size_t)cnt);
+  r.alloc((size_t)cnt);
+  p.alloc((size_t)cnt);
+  coef.alloc((size_t)mu);
+  std::vector<double> dir(2 * mu), res(mu), tmp(mu);
+  std::vector<short>  conv(mu, (short)-max_it);
+  auto scaled_axpy = [&](const std::vector<double> &alpha, const double *v, double *w) { // w[.,nu] += alpha[nu] * v[.,nu]
+    HIP_OK(hipMemcpyAsync(coef.p, alpha.data(), sizeof(double) * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, v, 0LL, 1, coef.p, 1.0, 1.0, w, mu);
+  };
+  exchange_inplace(x, mu, true);                                             // A.start
+  gmv(x, z.p, mu);
+  hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, z.p, r.p);
+  apply(r.p, p.p, mu);
+  wdots(p.p, 0, 1, p.p, mu, dir.data());                                     // p^T D p
+  for (int nu = 0; nu < mu; ++nu) res[nu] = std::sqrt(dir[nu]);
+  int  i = 0, nhist = 0;
+  bool skip = false;
+  for (int nu = 0; nu < mu; ++nu) skip |= dir[nu] < std::pow(std::numeric_limits<double>::epsilon(), 2);
+  // D-weighted "r^T z" of the reference is computed against the last preconditioned vector: p at the first iteration, z afterwards
+  const double *last = p.p;
+  if (!skip) {
+    while (i < max_it) {
+      wdots(r.p, 0, 1, last, mu, dir.data());                                // r^T D (M^{-1} r)
+      gmv(p.p, z.p, mu);
+      wdots(z.p, 0, 1, p.p, mu, dir.data() + mu);                            // (A p)^T D p
+      ++i;
+      for (int nu = 0; nu < mu; ++nu) tmp[nu] = conv[nu] == -max_it ? dir[nu] / dir[mu + nu] : 0.0;
+      scaled_axpy(tmp, p.p, x);
+      for (int nu = 0; nu < mu; ++nu) tmp[nu] = -tmp[nu];
+      scaled_axpy(tmp, z.p, r.p);
+      apply(r.p, z.p, mu);
+      std::vector<double> rz(mu), zz(mu);
+      wdots(r.p, 0, 1, z.p, mu, rz.data());
+      wdots(z.p, 0, 1, z.p, mu, zz.data());
+      for (int nu = 0; nu < mu; ++nu) tmp[nu] = rz[nu] / dir[nu];             // beta
+      // p = z + beta p
+      HIP_OK(hipMemcpyAsync(coef.p, tmp.data(), sizeof(double) * mu, hipMemcpyHostToDevice, st));
+      HIP_OK(hipStreamSynchronize(st));
+      hipLaunchKernelGGL(k_scale, g2, dim3(256), 0, st, voff_d.p, n_d.p, coef.p, p.p, mu);
+      hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, cnt, 1.0, z.p, 1.0, p.p, p.p);
+      last = z.p;
+      double beta = 0.0;
+      int    which = 0;
+      for (int nu = 0; nu < mu; ++nu) {
+        const double nz = std::sqrt(zz[nu]);
+        if (conv[nu] == -max_it && ((tol > 0.0 && nz / res[nu] <= tol) || (tol < 0.0 && nz <= -tol))) conv[nu] = (short)i;
+        dir[nu] = nz;
+      }
+      beta = dir[0];
+      for (int nu = 0; nu < mu; ++nu)
+        if (conv[nu] == -max_it && dir[nu] > beta) {
+          beta  = dir[nu];
+          which = nu;
+        }
+      if (history && nhist < history_cap) history[nhist] = beta;
+      ++nhist;
+      if (verbosity > 2) printf("CG: %3d %e %e %e < %e\n", i, beta, res[which], beta / res[which], tol);
+      bool all = true;
+      for (int nu = 0; nu < mu; ++nu) all &= (conv[nu] != -max_it);
+      if (all) {
+        --i;
+        break;
+      }
+    }
+  } else i = -1;
+  ++i;
+  if (verbosity) {
+    if (i != max_it + 1) printf("CG converges after %d iteration%s\n", i, i > 1 ? "s" : "");
+    else printf("CG does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(i, max_it);
+}
+
 } // namespace hpddm_hip

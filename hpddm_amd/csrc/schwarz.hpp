@@ -127,6 +127,7 @@ struct Schwarz {
   void axpy(double alpha, const double *x, double *y, long long cnt);
   void compute_residual(const double *x, const double *f, double *storage, int mu);
   int  gmres(const double *b, double *x, int mu, double *history, int history_cap);
+  int  cg(const double *b, double *x, int mu, double *history, int history_cap);           // gmres.hip
   int  bgmres(const double *b, double *x, int mu, double *history, int history_cap);       // bgmres.hip
   int  krylov_solve(const double *b, double *x, int mu, double *history, int history_cap); // -hpddm_krylov_method dispatch
   // D-weighted reductions used by GMRES and computeResidual: out[k*mu+nu] = sum_s sum_i d_s[i] V_k[s][nu][i] w[s][nu][i]

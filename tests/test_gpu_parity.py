@@ -262,3 +262,18 @@ def test_bgmres_matches_reference(name):
     _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
     assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-4)
     A.destroy()
+
+
+def test_cg_matches_reference():
+    """PCG with the (symmetric) additive Schwarz preconditioner: the reference's 40 iterations"""
+    g = gu.load("p40_cg_asm")
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0]) == 40
+    ref = g["history"]
+    assert len(hist) == len(ref) and np.all(np.abs(hist - ref[:, 1]) <= 1e-4 * ref[:, 1])
+    _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
+    _close(A.apply(f), gu.vecs(g, "apply_out"), 1e-10, "ASM apply")
+    A.destroy()
