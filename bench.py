@@ -81,10 +81,10 @@ def main():
         assert args.subdomains == 8
         parts = 8 * world
         subs = generate3d((args.n, args.n, args.n * world), parts, overlap=1, sym=True, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8,
-                          normalize=True)
+                          normalize=True, neumann=args.geneo)
         A, d = hpddm.schwarz_from_subdomains(subs, first_global=8 * rank, nglobal=parts, options=opts, multiplicity=False,
                                              partition=(rank, [8 * r for r in range(world + 1)]))
-        A.enable_distributed(dist, dev, mu_cap=max(1, args.mu), host_staging=cpu_coll)
+        A.enable_distributed(dist, dev, mu_cap=max(1, args.mu, 0 if args.no_two_level else args.geneo_nu), host_staging=cpu_coll)
     else:
         subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth", neumann=args.geneo)
         A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
@@ -149,6 +149,10 @@ def main():
     if sharded:
         # collective: every rank runs the same calls
         ph = {"exchange": A.time("exchange", mu=mu, reps=10) * 1e3, "gmv": A.time("gmv", mu=mu, reps=10) * 1e3}
+    tl = None
+    if sharded and not args.no_two_level:
+        # the coarse operator spans the ranks (assembly through the halo transport, coarse gather = all-reduce): collective
+        tl = two_level(A, subs, args, np, mu, 10)
     if rank == 0:
         if gm:
             out["gmres"] = gm
@@ -178,6 +182,8 @@ def main():
             out["gmres"] = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
         if not args.no_two_level and world == 1:
             out["two_level"] = two_level(A, subs, args, np, mu, reps)
+        elif tl:
+            out["two_level"] = tl
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(A, subs, d, args, np)
         print(json.dumps(out), flush=True)
@@ -212,7 +218,7 @@ def two_level(A, subs, args, np, mu, reps):
     t_defl = A.time("deflation", mu=mu, warmup=2, reps=reps)
     t_apply = A.time("apply", mu=mu, warmup=2, reps=reps)
     import torch
-    f = torch.from_numpy(np.concatenate([s["f"] for s in subs])).cuda()
+    f = torch.from_numpy(np.concatenate([s["f"] for s in subs])).to(torch.device("cuda", torch.cuda.current_device()))
     xs = torch.zeros_like(f)
     torch.cuda.synchronize()
     t1 = time.perf_counter()

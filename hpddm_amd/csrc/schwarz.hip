@@ -135,14 +135,15 @@ __global__ void k_sum_partials(const double *__restrict__ partial, int nblk, dou
 }
 
 // y = Einv * x for mu columns (cdim x cdim row-major Einv), one workgroup per column block
-__global__ void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int mu)
+__global__ void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int cdim_g, int mu)
 {
+  // y (cdim local rows) = Einv (cdim x cdim_g, the rows of the local subdomains) * x (cdim_g)
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < cdim * mu; o += gridDim.x * blockDim.x) {
     const int     nu = o / cdim, r = o - nu * cdim;
-    const double *er = Einv + (long long)r * cdim;
-    const double *xc = x + (long long)nu * cdim;
+    const double *er = Einv + (long long)r * cdim_g;
+    const double *xc = x + (long long)nu * cdim_g;
     double        acc = 0.0;
-    for (int c = 0; c < cdim; ++c) acc = fma(er[c], xc[c], acc);
+    for (int c = 0; c < cdim_g; ++c) acc = fma(er[c], xc[c], acc);
     y[o] = acc;
   }
 }
@@ -193,6 +194,7 @@ void Schwarz::build_halo_lists()
       by_peer[o].push_back(Pair{s, t, k});
     }
   peers.clear();
+  h_pairs.clear();
   h_send_sub.clear(); h_send_idx.clear(); h_send_po.clear(); h_send_pc.clear();
   std::vector<std::vector<std::array<int, 3>>> rx((size_t)ntot); // per dof: (k, po, pc)
   long long off = 0;
@@ -213,8 +215,10 @@ void Schwarz::build_halo_lists()
     // receive order = the peer's send order: (remote t, local s)
     std::sort(pr.begin(), pr.end(), [](const Pair &a, const Pair &b) { return a.t != b.t ? a.t < b.t : a.s < b.s; });
     long long pos = off;
-    for (const Pair &p : pr)
+    for (const Pair &p : pr) {
+      h_pairs.push_back(RemotePair{p.s, p.k, pos, off, cnt});
       for (int i : subs[p.s].map[p.k].second) rx[voff[p.s] + i].push_back({(int)pos++, (int)off, (int)cnt});
+    }
     peers.push_back(HaloPeer{kv.first, cnt, off});
     off += cnt;
   }
@@ -500,18 +504,32 @@ void Schwarz::build_coarse()
 {
   // Preconditioner::buildTwo with MatrixMultiplication (include/HPDDM_preconditioner.hpp:124-257,
   // include/HPDDM_operator.hpp:378-562):  E = W^T A W,  W_j = R_j^T D_j Z_j,  A W_j = R_j^T (A_j D_j Z_j).
+  // Every rank computes the row blocks of its own subdomains (the products with the neighbours' A_j D_j Z_j restricted to
+  // the shared dofs, fetched through the halo transport when the neighbour lives on another GPU); the rows are summed
+  // over the ranks and E^{-1} is replicated.
   build_device();
-  HH_CHECK(halo_total == 0 && nranks == 1, "BuildCoarseOperator: the coarse operator is assembled on one GPU in this round (all subdomains local)");
+  hipStream_t st = library_stream();
   coff.assign(nsub + 1, 0);
   for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
   cdim = coff[nsub];
-  HH_CHECK(cdim > 0, "BuildCoarseOperator: no deflation vector was set");
+  // global coarse numbering
+  std::vector<double> gnu(nglobal, 0.0);
+  for (int s = 0; s < nsub; ++s) gnu[first + s] = subs[s].nu;
+  if (nranks > 1) HH_CHECK(allreduce_fn != nullptr && allreduce_fn(cb_ctx, gnu.data(), nglobal) == 0, "BuildCoarseOperator: all-reduce failed");
+  gcoff.assign(nglobal + 1, 0);
+  for (int g = 0; g < nglobal; ++g) gcoff[g + 1] = gcoff[g] + (int)std::lround(gnu[g]);
+  cdim_g  = gcoff[nglobal];
+  coff_g0 = gcoff[first];
+  HH_CHECK(cdim_g > 0, "BuildCoarseOperator: no deflation vector was set");
+  int numax = 0;
+  for (int g = 0; g < nglobal; ++g) numax = std::max(numax, gcoff[g + 1] - gcoff[g]);
   // T_s = A_s (D_s Z_s), DZ_s = D_s Z_s
   std::vector<std::vector<double>> T(nsub), DZ(nsub);
   for (int s = 0; s < nsub; ++s) {
     const SchwarzSub &S = subs[s];
     DZ[s].assign((size_t)S.n * S.nu, 0.0);
     T[s].assign((size_t)S.n * S.nu, 0.0);
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < S.nu; ++k) {
       double *dz = DZ[s].data() + (size_t)k * S.n, *t = T[s].data() + (size_t)k * S.n;
       for (int i = 0; i < S.n; ++i) dz[i] = S.d[i] * S.Z[(size_t)k * S.n + i];
@@ -522,39 +540,85 @@ void Schwarz::build_coarse()
       }
     }
   }
-  E.assign((size_t)cdim * cdim, 0.0);
+  // values of the neighbours' T on the shared dofs, for the neighbours owned by other ranks: halo fetch, numax columns
+  std::vector<double> remote; // [col][halo_total]
+  if (halo_total) {
+    HH_CHECK(halo_fn && sendbuf && recvbuf && halo_mu_cap >= 1, "BuildCoarseOperator: register the halo transport first");
+    remote.assign((size_t)numax * halo_total, 0.0);
+    const int      chunk = halo_mu_cap;
+    DevBuf<double> tb;
+    std::vector<double> host((size_t)ntot * chunk), rb((size_t)halo_total * chunk);
+    for (int c0 = 0; c0 < numax; c0 += chunk) {
+      const int cc = std::min(chunk, numax - c0);
+      std::fill(host.begin(), host.end(), 0.0);
+      for (int s = 0; s < nsub; ++s)
+        for (int c = 0; c < cc; ++c)
+          if (c0 + c < subs[s].nu) std::copy_n(T[s].data() + (size_t)(c0 + c) * subs[s].n, subs[s].n, host.data() + (size_t)voff[s] * cc + (size_t)c * subs[s].n);
+      tb.upload(host.data(), (size_t)ntot * cc, st);
+      hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, tb.p, sendbuf, cc, 0);
+      HIP_OK(hipStreamSynchronize(st));
+      HH_CHECK(halo_fn(cb_ctx, cc) == 0, "halo transport failed");
+      HIP_OK(hipMemcpyAsync(rb.data(), recvbuf, sizeof(double) * halo_total * cc, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      for (const RemotePair &pr : h_pairs) {
+        const long long len = (long long)subs[pr.s].map[pr.k].second.size();
+        for (int c = 0; c < cc; ++c)
+          for (long long q = 0; q < len; ++q) remote[(size_t)(c0 + c) * halo_total + pr.pos + q] = rb[(size_t)pr.po * cc + (size_t)c * pr.pc + (pr.pos - pr.po) + q];
+      }
+    }
+  }
+  E.assign((size_t)cdim_g * cdim_g, 0.0);
   for (int i = 0; i < nsub; ++i) {
     const SchwarzSub &Si = subs[i];
+    const int         ri = gcoff[first + i];
     // diagonal block: Z_i^T D_i T_i  (the reference scales the local product by D, include/HPDDM_operator.hpp:524, and
     // the neighbours' rows by D in applyFromNeighbor, :398-404)
     for (int ki = 0; ki < Si.nu; ++ki)
       for (int kj = 0; kj < Si.nu; ++kj) {
         double acc = 0.0;
         for (int r = 0; r < Si.n; ++r) acc += DZ[i][(size_t)ki * Si.n + r] * T[i][(size_t)kj * Si.n + r];
-        E[(size_t)(coff[i] + ki) * cdim + coff[i] + kj] = acc;
+        E[(size_t)(ri + ki) * cdim_g + ri + kj] = acc;
       }
-    for (const auto &pr : Si.map) {
-      const int               j      = pr.first - first;
-      const SchwarzSub       &Sj     = subs[j];
-      const std::vector<int> &mine   = pr.second;
-      const std::vector<int> &theirs = peer_list(*this, j, first + i);
-      for (int ki = 0; ki < Si.nu; ++ki)
-        for (int kj = 0; kj < Sj.nu; ++kj) {
-          double acc = 0.0;
-          for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * T[j][(size_t)kj * Sj.n + theirs[q]];
-          E[(size_t)(coff[i] + ki) * cdim + coff[j] + kj] = acc;
-        }
+    for (int k = 0; k < (int)Si.map.size(); ++k) {
+      const auto             &pr   = Si.map[k];
+      const std::vector<int> &mine = pr.second;
+      const int               gj = pr.first, j = gj - first, rj = gcoff[gj], nuj = gcoff[gj + 1] - gcoff[gj];
+      if (j >= 0 && j < nsub) {
+        const SchwarzSub       &Sj     = subs[j];
+        const std::vector<int> &theirs = peer_list(*this, j, first + i);
+        for (int ki = 0; ki < Si.nu; ++ki)
+          for (int kj = 0; kj < nuj; ++kj) {
+            double acc = 0.0;
+            for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * T[j][(size_t)kj * Sj.n + theirs[q]];
+            E[(size_t)(ri + ki) * cdim_g + rj + kj] = acc;
+          }
+      } else {
+        long long pos = -1;
+        for (const RemotePair &rp : h_pairs)
+          if (rp.s == i && rp.k == k) pos = rp.pos;
+        HH_CHECK(pos >= 0, "BuildCoarseOperator: remote pair not found");
+        for (int ki = 0; ki < Si.nu; ++ki)
+          for (int kj = 0; kj < nuj; ++kj) {
+            double acc = 0.0;
+            for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * remote[(size_t)kj * halo_total + pos + q];
+            E[(size_t)(ri + ki) * cdim_g + rj + kj] = acc;
+          }
+      }
     }
+  }
+  if (nranks > 1) {
+    // rows of the other ranks: one sum over the ranks
+    const size_t total = E.size();
+    for (size_t o = 0; o < total; o += (1u << 24)) HH_CHECK(allreduce_fn(cb_ctx, E.data() + o, (int)std::min<size_t>(1u << 24, total - o)) == 0, "BuildCoarseOperator: all-reduce failed");
   }
   // symCoarse == 'S' (real scalars, examples/schwarz.hpp:75-79): the reference assembles only the upper triangle of E
   // (row block of rank i towards neighbours j >= i) and its coarse solver mirrors it.  Same here unless
   // -hpddm_hip_general_co is set ('G', what GENERAL_CO selects in the reference).
   if (getopt("hip_general_co", 0) == 0)
-    for (int r = 0; r < cdim; ++r)
-      for (int c = 0; c < r; ++c) E[(size_t)r * cdim + c] = E[(size_t)c * cdim + r];
+    for (int r = 0; r < cdim_g; ++r)
+      for (int c = 0; c < r; ++c) E[(size_t)r * cdim_g + c] = E[(size_t)c * cdim_g + r];
   std::vector<double> Ecopy(E);
-  invert_dense(cdim, Ecopy, Einv);
-  hipStream_t st = library_stream();
+  invert_dense(cdim_g, Ecopy, Einv);
   std::vector<double>    zcat;
   std::vector<long long> zoff(nsub);
   std::vector<int>       nus(nsub);
@@ -567,7 +631,7 @@ void Schwarz::build_coarse()
   zoff_d.upload(zoff, st);
   nu_d.upload(nus, st);
   coff_d.upload(coff.data(), nsub, st);
-  Einv_d.upload(Einv, st);
+  Einv_d.upload(Einv.data() + (size_t)coff_g0 * cdim_g, (size_t)cdim * cdim_g, st); // the rows of the local subdomains
   HIP_OK(hipStreamSynchronize(st));
   mu_cap       = 0; // uc buffers depend on cdim
   coarse_ready = true;
@@ -629,7 +693,23 @@ void Schwarz::deflation(const double *in, double *out, int mu)
 
 void Schwarz::coarse_solve(const double *uc, double *y, int mu)
 {
-  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, library_stream(), Einv_d.p, uc, y, cdim, mu);
+  // CoarseOperator::callSolver (include/HPDDM_coarse_operator_impl.hpp:1630-1732): gather -> E^{-1} -> scatter.  Here E^{-1}
+  // is replicated, so the scatter disappears; with several ranks the gather is one small all-reduce of the zero-padded
+  // right-hand side.
+  hipStream_t st = library_stream();
+  const double *rhs = uc;
+  if (nranks > 1) {
+    std::vector<double> loc((size_t)cdim * mu), glob((size_t)cdim_g * mu, 0.0);
+    HIP_OK(hipMemcpyAsync(loc.data(), uc, sizeof(double) * cdim * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int nu = 0; nu < mu; ++nu) std::copy_n(loc.data() + (size_t)nu * cdim, cdim, glob.data() + (size_t)nu * cdim_g + coff_g0);
+    HH_CHECK(allreduce_fn != nullptr && allreduce_fn(cb_ctx, glob.data(), cdim_g * mu) == 0, "coarse gather failed");
+    ucg_d.alloc((size_t)cdim_g * mu);
+    HIP_OK(hipMemcpyAsync(ucg_d.p, glob.data(), sizeof(double) * cdim_g * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    rhs = ucg_d.p;
+  }
+  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, st, Einv_d.p, rhs, y, cdim, cdim_g, mu);
 }
 
 void Schwarz::apply(const double *in, double *out, int mu)

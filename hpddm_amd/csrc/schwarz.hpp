@@ -60,6 +60,8 @@ struct Schwarz {
   long long             halo_total = 0;
   std::vector<int>      h_send_sub, h_send_idx, h_send_po, h_send_pc; // per send entry: local subdomain, dof, peer offset, peer count
   std::vector<int>      h_rx_ptr, h_rx_k, h_rx_po, h_rx_pc;           // CSR per concatenated dof -> entries of the recv buffer
+  struct RemotePair { int s, k; long long pos, po, pc; };               // remote pair (local s, map entry k): first position of its block in the recv buffer
+  std::vector<RemotePair> h_pairs;
   DevBuf<int>           send_sub_d, send_idx_d, send_po_d, send_pc_d, rx_ptr_d, rx_k_d, rx_po_d, rx_pc_d;
   double               *sendbuf = nullptr, *recvbuf = nullptr; // device buffers owned by the host framework
   int                   halo_mu_cap = 0;
@@ -88,8 +90,10 @@ struct Schwarz {
   DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
   SolvePlan              plan;
   // coarse level
-  int                 cdim = 0;
+  int                 cdim = 0, cdim_g = 0, coff_g0 = 0; // local / global coarse dimension, global offset of the local block
   std::vector<int>    coff; // nsub+1
+  std::vector<int>    gcoff; // nglobal+1: coarse offsets of every subdomain (all ranks)
+  DevBuf<double>      ucg_d; // gathered coarse right-hand side (several ranks)
   DevBuf<int>         coff_d, nu_d;
   DevBuf<long long>   zoff_d;
   DevBuf<double>      Z_d, Einv_d, uc_d, uc2_d, zt_partial;

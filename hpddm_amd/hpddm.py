@@ -260,6 +260,8 @@ class Schwarz:
         def allreduce(ctx, buf, count):
             try:
                 host = np.ctypeslib.as_array(buf, shape=(count,))
+                if count > self._red.numel():
+                    self._red = torch.zeros(count, dtype=torch.float64, device=self._red.device)
                 t = self._red[:count]
                 t.copy_(torch.from_numpy(host))
                 dist.all_reduce(t)

@@ -110,6 +110,24 @@ def main():
         close(sol, sol_o[sl], 1e-8, "solution")
         res = A.compute_residual(sol, f[sl])
         assert np.allclose(res, orc.compute_residual(sol_o, f), rtol=1e-4), res
+        # two-level: the coarse operator is assembled across the ranks (neighbours' A D Z fetched through the halo
+        # transport, more columns than the transport's mu_cap -> chunked), E^{-1} replicated, coarse gather = all-reduce
+        zr = np.random.default_rng(11)
+        Zg = [np.column_stack([np.ones(s["n"])] + [zr.random(s["n"]) for _ in range(4 + k % 3)]) for k, s in enumerate(allsubs)]
+        for k in range(per):
+            A.set_vectors(k, Zg[firsts[rank] + k])
+        A.build_coarse_operator()
+        orc.set_vectors(Zg)
+        orc.build_coarse()
+        close(A.deflation(f[sl]), orc.deflation(f)[sl], 1e-9, "deflation")
+        for corr in ("deflated", "additive", "balanced"):
+            A.option_parse("-hpddm_schwarz_coarse_correction " + corr)
+            orc.correction = corr
+            close(A.apply(f[sl]), orc.apply(f)[sl], 1e-9, "apply " + corr)
+        it2, sol2 = A.solve(f[sl])
+        it2_o, sol2_o, _ = orc.gmres(f)
+        assert it2 == it2_o and it2 < it, (it2, it2_o, it)
+        close(sol2, sol2_o[sl], 1e-8, "two-level solution")
     dist.barrier()
     if rank == 0:
         print(f"DIST_WORKER_OK mode={mode} world={world} peers={peers}")
