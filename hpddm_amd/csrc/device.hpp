@@ -79,7 +79,7 @@ struct DeviceFactor {
   DevBuf<double> F, G, dinv;
   DevBuf<int>    rows, gptr, gsrc, perm;
   // host copies of what the plan builder needs
-  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
+  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk, parent;
   std::vector<char>    has_src;
   std::vector<int64_t> f_off, row_ptr, goff;
   void upload(const HostFactor &hf, hipStream_t s);
@@ -98,6 +98,13 @@ struct SolvePlan {
   DevBuf<Tile>     tiles;
   std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
+  // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
+  // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
+  std::vector<int> gat_ptr, gat_end;
+  // bottom of the elimination trees: every maximal subtree of height <= sub_h made of narrow supernodes is swept by ONE
+  // workgroup (its levels separated by workgroup barriers instead of kernel boundaries)
+  int              nsubtrees = 0, sub_phases = 0; // phases = sub_h + 1
+  DevBuf<int>      sub_ptr;                        // [nsubtrees][3][phases + 1]: forward wave tiles / backward block tiles / backward wave tiles
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U, bperm;
@@ -105,6 +112,9 @@ struct SolvePlan {
   DevBuf<int>       pn;    // per factor: n
   DevBuf<const int *> pperm; // per factor: perm array
   int               nmax = 0;
+  int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
+  int               persist = 0; // workgroups per CU of the persistent sweep launches
+  int               fp = 4, cu = 1, lds_cap = 4096; // loads in flight per lane (rows x column chunks), LDS staging doubles per workgroup
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves

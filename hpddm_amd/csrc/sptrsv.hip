@@ -19,9 +19,33 @@ namespace hpddm_hip {
 
 static constexpr int WG_THREADS  = 256;
 static constexpr int LDS_DOUBLES = 4096; // 32 KiB staging per workgroup of the block-level path -> 5 workgroups (20 waves) per CU
-static constexpr int FWD_PASSES  = 4;    // rows per wavefront per batch (register accumulators, loads in flight)
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // at most this many rows per wave-level tile (LDS: WAVE_ROWS * MU doubles per wavefront)
+
+// Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
+// tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef const double __attribute__((address_space(1))) *gcd_t;
+typedef const dbl2 __attribute__((address_space(1)))   *gcd2_t;
+typedef const int __attribute__((address_space(1)))    *gci_t;
+struct SnView {
+  gcd_t     F, G, dinv;
+  gci_t     rows, gptr, gsrc;
+  long long voff, uoff;
+  int       n, usize, c0, w, nb, ldw, u_off, has_src;
+};
+__device__ static inline SnView view(const SnDesc &d)
+{
+  SnView v;
+  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv;
+  v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
+  v.voff = d.voff, v.uoff = d.uoff;
+  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.u_off = d.u_off, v.has_src = d.has_src;
+  return v;
+}
+// developer aid (HPDDM_HIP_DBG, wrong results): 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand
+// side staging, 8 skip the panel loads
+enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8 };
 
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
 
@@ -36,6 +60,23 @@ __device__ static inline double reduce_group(double v, int gl, int g)
     width = min(width, off);
   }
   return v;
+}
+// the same for N independent values at once: the N shuffle chains overlap instead of running one after the other
+template <int N>
+__device__ static inline void reduce_group_n(double (&v)[N], int gl, int g)
+{
+  int width = g, off = 1;
+  while (off < g) off <<= 1;
+  for (off >>= 1; off >= 1; off >>= 1) {
+    double t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = __shfl_down(v[k], off);
+    const bool take = gl + off < width;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (take) v[k] += t[k];
+    width = min(width, off);
+  }
 }
 // sum over the R row groups of a wavefront for one column pair (lanes sub*g + gl, sub = 0..R-1); result valid in sub == 0
 __device__ static inline double reduce_across(double v, int lane, int sub, int g, int R)
@@ -83,7 +124,7 @@ __global__ void k_perm_out(const long long *__restrict__ voff, const int *__rest
 
 // store the result of panel row r (after reduction): top rows give y, rows below hand their update to the parent
 template <int MU>
-__device__ static inline void fwd_store_row(const SnDesc &d, int r, const double *s, int sstride, double *yb, double *Ub)
+__device__ static inline void fwd_store_row(const SnView &d, int r, const double *s, int sstride, double *yb, double *Ub)
 {
   if (r < d.w) {
 #pragma unroll
@@ -105,20 +146,33 @@ __device__ static inline void fwd_store_row(const SnDesc &d, int r, const double
 // =========================== narrow panels (ldw <= 128): one wavefront per tile ====================================
 // lane (sub, gl): row-in-group sub = lane / g, column pair gl = lane % g with g = ldw/2 lanes per row, R = 64/g rows
 // per wave-instruction: a wavefront always moves 1 KiB of contiguous panel per load.  lds: WAVE_ROWS*MU doubles, private.
-template <int MU>
-__device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int lane, double *lds, const double *bb, double *yb, double *Ub)
+template <int MU, int FWD_PASSES>
+__device__ static inline void fwd_wave_tile(const SnView &d, const Tile &t, int lane, double *lds, const double *bb, double *yb, double *Ub, int dbg)
 {
   const int w = d.w, ldw = d.ldw;
   const int g = ldw >> 1, R = 64 / g; // any even ldw <= 128: R*g <= 64 lanes work, the others idle
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
+  const int   rend = t.r0 + t.nr;
+  const gcd_t Fp   = d.F + 2 * gl;
+  // the first rows of the panel are requested before the right-hand side is gathered: the stream starts while the
+  // dependent index chain (gptr -> gsrc -> U) is walked
+  dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
+#pragma unroll
+  for (int p = 0; p < FWD_PASSES; ++p) {
+    const int r = t.r0 + sub + p * R;
+    cur[p]      = (active && r < rend && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)r * ldw) : dbl2{0.0, 0.0};
+  }
   // right-hand side of the supernode for this lane's two columns: b - (updates handed up by the children)
   double l0[MU], l1[MU];
   {
     const int c = 2 * gl;
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 0.0;
-    if (c < w) {
+    if (dbg & DBG_NORHS) {
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 1.0;
+    } else if (c < w) {
       // bb is already in the permuted numbering: columns c0+c, c0+c+1 are adjacent
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
@@ -135,40 +189,58 @@ __device__ static inline void fwd_wave_tile(const SnDesc &d, const Tile &t, int 
       }
     }
   }
-  const int     rend = t.r0 + t.nr;
-  const double *Fp   = d.F + 2 * gl;
   for (int rb0 = t.r0; rb0 < rend; rb0 += FWD_PASSES * R) { // wave-uniform trip count (the reductions shuffle across lanes)
-    const int rb = rb0 + sub;
-    double2   a[FWD_PASSES];
+    const int  rb   = rb0 + sub;
+    const bool more = rb0 + FWD_PASSES * R < rend;
+    if (more) { // next batch in flight while this one is reduced
 #pragma unroll
-    for (int p = 0; p < FWD_PASSES; ++p) {
-      const int r = rb + p * R;
-      a[p]        = (active && r < rend) ? *reinterpret_cast<const double2 *>(Fp + (long long)r * ldw) : make_double2(0.0, 0.0);
-    }
-#pragma unroll
-    for (int p = 0; p < FWD_PASSES; ++p) {
-      const int r = rb + p * R;
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        const double s = reduce_group(fma(a[p].x, l0[nu], a[p].y * l1[nu]), gl, g);
-        if (active && gl == 0 && r < rend) lds[nu * WAVE_ROWS + (r - t.r0)] = s;
+      for (int p = 0; p < FWD_PASSES; ++p) {
+        const int r = rb + (FWD_PASSES + p) * R;
+        nxt[p]      = (active && r < rend && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)r * ldw) : dbl2{0.0, 0.0};
       }
+    }
+    double sv[FWD_PASSES * MU];
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p)
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) sv[p * MU + nu] = fma(cur[p].x, l0[nu], cur[p].y * l1[nu]);
+    if (!(dbg & DBG_NORED)) reduce_group_n<FWD_PASSES * MU>(sv, gl, g);
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int r = rb + p * R;
+      if (active && gl == 0 && r < rend) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + (r - t.r0)] = sv[p * MU + nu];
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
   // epilogue, one lane per row: the dependent index chains (gptr -> gsrc -> U) of 64 rows overlap
   wave_lds_sync();
+  if (dbg & DBG_NOSTORE) return;
   for (int j = lane; j < t.nr; j += 64) fwd_store_row<MU>(d, t.r0 + j, lds + j, WAVE_ROWS, yb, Ub);
 }
 
-template <int MU>
-__device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *lds, const double *yb, double *xb, double *xo)
+template <int MU, int FWD_PASSES>
+__device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, const double *yb, double *xb, double *xo, int dbg)
 {
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
   const int g = ldw >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
+  const gcd_t Gp = d.G + 2 * gl;
+  // first rows of the panel requested before v is gathered (rows -> x is a dependent chain)
+  dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
+#pragma unroll
+  for (int p = 0; p < FWD_PASSES; ++p) {
+    const int i = sub + p * R;
+    cur[p]      = (active && i < h && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+  }
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
-  for (int i = lane; i < h; i += 64) {
+  for (int i = lane; i < h && !(dbg & DBG_NORHS); i += 64) {
     if (i < w) {
       const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
 #pragma unroll
@@ -183,14 +255,15 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
   double acc0[MU], acc1[MU];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
-  const double *Gp = d.G + 2 * gl;
   for (int ib0 = 0; ib0 < h; ib0 += FWD_PASSES * R) {
-    const int ib = ib0 + sub;
-    double2   a[FWD_PASSES];
+    const int  ib   = ib0 + sub;
+    const bool more = ib0 + FWD_PASSES * R < h;
+    if (more) {
 #pragma unroll
-    for (int p = 0; p < FWD_PASSES; ++p) {
-      const int i = ib + p * R;
-      a[p]        = (active && i < h) ? *reinterpret_cast<const double2 *>(Gp + (long long)i * ldw) : make_double2(0.0, 0.0);
+      for (int p = 0; p < FWD_PASSES; ++p) {
+        const int i = ib + (FWD_PASSES + p) * R;
+        nxt[p]      = (active && i < h && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+      }
     }
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
@@ -198,17 +271,23 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         const double v = lds[nu * WAVE_ROWS + i];
-        acc0[nu]       = fma(a[p].x, v, acc0[nu]);
-        acc1[nu]       = fma(a[p].y, v, acc1[nu]);
+        acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+        acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
       }
     }
-  }
+    if (more) {
 #pragma unroll
-  for (int nu = 0; nu < MU; ++nu) {
-    acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
-    acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
+      for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
+    }
   }
-  if (sub == 0) {
+  if (!(dbg & DBG_NORED)) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
+      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
+    }
+  }
+  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
     const int c = 2 * gl;
     if (c < w) {
 #pragma unroll
@@ -222,8 +301,8 @@ __device__ static inline void bwd_wave_tile(const SnDesc &d, int lane, double *l
 }
 
 // =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
-template <int MU>
-__device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub)
+template <int MU, int FWD_PASSES, int CU>
+__device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered, int dbg)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, ldw = d.ldw;
@@ -246,7 +325,7 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
       for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
     }
     for (int k0 = 0; k0 < tile_lim; k0 += CW) {
-      if (!single || rb == t.r0) {
+      if ((!single || rb == t.r0) && !(dbg & DBG_NORHS)) {
         // stage f = b - children's updates for columns [k0, kend), zero padding up to ldw (16-byte reads past w see zeros)
         if (!single) __syncthreads();
         const int kend = min(k0 + CW, ldw);
@@ -256,7 +335,7 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
           double    v   = 0.0;
           if (col < w) {
             v = bb[(long long)nu * d.n + d.c0 + col];
-            if (d.has_src)
+            if (d.has_src && !pregathered)
               for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
           }
           lds[nu * CW + i] = v;
@@ -264,15 +343,21 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
         __syncthreads();
       }
       const int cmax = min(lmax, k0 + CW);
-      for (int c = k0 + 2 * lane; c < cmax; c += 128) {
-        double2 a[FWD_PASSES];
+      for (int c = k0 + 2 * lane; c < cmax; c += 128 * CU) {
+        dbl2 a[CU][FWD_PASSES];
 #pragma unroll
-        for (int p = 0; p < FWD_PASSES; ++p) a[p] = c < lim[p] ? *reinterpret_cast<const double2 *>(d.F + (long long)row[p] * ldw + c) : make_double2(0.0, 0.0);
+        for (int u = 0; u < CU; ++u)
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) {
-          const double2 l = *reinterpret_cast<const double2 *>(&lds[nu * CW + (c - k0)]);
+          for (int p = 0; p < FWD_PASSES; ++p) a[u][p] = (c + 128 * u < lim[p] && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(d.F + (long long)row[p] * ldw + c + 128 * u) : dbl2{0.0, 0.0};
 #pragma unroll
-          for (int p = 0; p < FWD_PASSES; ++p) acc[p][nu] = fma(a[p].x, l.x, fma(a[p].y, l.y, acc[p][nu]));
+        for (int u = 0; u < CU; ++u) {
+          const int ci = c + 128 * u < cmax ? c + 128 * u - k0 : 0; // columns past the chunk carry a = 0
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) {
+            const double2 l = *reinterpret_cast<const double2 *>(&lds[nu * CW + ci]);
+#pragma unroll
+            for (int p = 0; p < FWD_PASSES; ++p) acc[p][nu] = fma(a[u][p].x, l.x, fma(a[u][p].y, l.y, acc[p][nu]));
+          }
         }
       }
     }
@@ -281,17 +366,18 @@ __device__ static inline void fwd_block_tile(const SnDesc &d, const Tile &t, dou
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         double s = acc[p][nu];
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (!(dbg & DBG_NORED))
+          for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0 && row[p] < rend) sums[nu * 64 + (row[p] - t.r0)] = s;
       }
   }
   // epilogue: one thread per row of the tile (tiles have at most 64 rows)
   __syncthreads();
-  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+  if (tid < t.nr && !(dbg & DBG_NOSTORE)) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
 }
 
-template <int MU>
-__device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts)
+template <int MU, int FP>
+__device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts, int dbg)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, ldw = d.ldw;
@@ -307,7 +393,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   // rows above the tile's first column hold zeros in these columns (triangular top block): rows [t.rbeg, t.rend) only
   for (int i0 = t.rbeg; i0 < t.rend; i0 += RCH) {
     const int rch = min(RCH, t.rend - i0);
-    for (int idx = tid; idx < rch * MU; idx += WG_THREADS) {
+    for (int idx = tid; idx < rch * MU && !(dbg & DBG_NORHS); idx += WG_THREADS) {
       const int nu = idx / rch, ii = idx - nu * rch;
       const int i = i0 + ii;
       double    v;
@@ -319,23 +405,25 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
     }
     __syncthreads();
     if (colok) {
-      const double *Gp = d.G + (long long)i0 * ldw + col;
+      const gcd_t Gp = d.G + (long long)i0 * ldw + col;
       int           ii = wave * R + sub;
-      // 4 independent row loads in flight per lane
-      for (; ii + 12 * R < rch; ii += 16 * R) {
-        const double2 a0 = *reinterpret_cast<const double2 *>(Gp + (long long)ii * ldw);
-        const double2 a1 = *reinterpret_cast<const double2 *>(Gp + (long long)(ii + 4 * R) * ldw);
-        const double2 a2 = *reinterpret_cast<const double2 *>(Gp + (long long)(ii + 8 * R) * ldw);
-        const double2 a3 = *reinterpret_cast<const double2 *>(Gp + (long long)(ii + 12 * R) * ldw);
+      // FP independent row loads in flight per lane
+      for (; ii + (FP - 1) * 4 * R < rch; ii += FP * 4 * R) {
+        dbl2 a[FP];
+#pragma unroll
+        for (int p = 0; p < FP; ++p) a[p] = (dbg & DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)(ii + p * 4 * R) * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
-          const double v0 = lds[nu * RCH + ii], v1 = lds[nu * RCH + ii + 4 * R], v2 = lds[nu * RCH + ii + 8 * R], v3 = lds[nu * RCH + ii + 12 * R];
-          acc[nu][0] = fma(a0.x, v0, fma(a1.x, v1, fma(a2.x, v2, fma(a3.x, v3, acc[nu][0]))));
-          acc[nu][1] = fma(a0.y, v0, fma(a1.y, v1, fma(a2.y, v2, fma(a3.y, v3, acc[nu][1]))));
+#pragma unroll
+          for (int p = 0; p < FP; ++p) {
+            const double v = lds[nu * RCH + ii + p * 4 * R];
+            acc[nu][0]     = fma(a[p].x, v, acc[nu][0]);
+            acc[nu][1]     = fma(a[p].y, v, acc[nu][1]);
+          }
         }
       }
       for (; ii < rch; ii += 4 * R) {
-        const double2 a0 = *reinterpret_cast<const double2 *>(Gp + (long long)ii * ldw);
+        const dbl2 a0 = (dbg & DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)ii * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
           const double v0 = lds[nu * RCH + ii];
@@ -351,7 +439,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      acc[nu][k] = reduce_across(acc[nu][k], lane, sub, g, R);
+      if (!(dbg & DBG_NORED)) acc[nu][k] = reduce_across(acc[nu][k], lane, sub, g, R);
     }
   if (sub == 0) {
 #pragma unroll
@@ -362,7 +450,7 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   }
   __syncthreads();
   if (t.nparts == 1) {
-    if (wave == 0 && sub == 0 && colok) {
+    if (wave == 0 && sub == 0 && colok && !(dbg & DBG_NOSTORE)) {
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
@@ -417,48 +505,152 @@ __device__ static inline void bwd_block_tile(const SnDesc &d, const Tile &t, dou
   }
 }
 
-// One launch per level and direction: the first nblock workgroups take block-level tiles, the others four wave-level
-// tiles each (the two kinds of one level run side by side).
-template <int MU, bool HAS_BLOCK>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl)
+// One launch per level and direction.  The grid is capped at what the chip holds at once (persistent workgroups): every
+// workgroup walks the level's block-level tiles g, g + G, ... with its four wavefronts together, then its wavefronts walk
+// the wave-level tiles on their own.  Tiles are sorted by decreasing cost, so the round-robin deal is balanced, and no
+// workgroup is dispatched for less than a full share of the level.
+template <int MU, bool HAS_BLOCK, int FP, int CU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int pregathered, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  Tile t;
-  int  lane = -1;
-  if (HAS_BLOCK && (int)blockIdx.x < nblock) t = btiles[blockIdx.x];
-  else {
-    const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
-    if (tix >= nwave) return; // whole wavefront leaves; the wave-level path has no workgroup barrier
-    t    = wtiles[tix];
-    lane = threadIdx.x & 63;
+  const int G = gridDim.x;
+  if (HAS_BLOCK) {
+    for (int bt = blockIdx.x; bt < nblock; bt += G) {
+      const Tile    t  = btiles[bt];
+      const SnView  d  = view(sns[t.sn]);
+      const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+      fwd_block_tile<MU, FP, CU>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+      __syncthreads(); // the staging area is reused by the next tile
+    }
   }
-  const SnDesc  d  = sns[t.sn];
-  const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-  if (HAS_BLOCK && lane < 0) fwd_block_tile<MU>(d, t, lds, lds_dbl, bb, yb, Ub);
-  else fwd_wave_tile<MU>(d, t, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), bb, yb, Ub);
+  // wave-uniform tile index in a scalar register: the tile and its supernode descriptor come through the scalar cache
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double   *wl = lds + wv * (WAVE_ROWS * MU);
+  // the wave-level deal starts where the block-level deal stopped
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
+    const Tile    t  = wtiles[tix];
+    const SnView  d  = view(sns[t.sn]);
+    const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+    fwd_wave_tile<MU, FP>(d, t, lane, wl, bb, yb, Ub, dbg);
+    wave_lds_sync(); // the epilogue's reads land before the next tile reuses the wavefront's LDS
+  }
 }
 
-template <int MU, bool HAS_BLOCK>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl)
+template <int MU, bool HAS_BLOCK, int FP>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  Tile t;
-  int  lane = -1;
-  if (HAS_BLOCK && (int)blockIdx.x < nblock) t = btiles[blockIdx.x];
-  else {
-    const int tix = ((int)blockIdx.x - nblock) * (WG_THREADS / 64) + (threadIdx.x >> 6);
-    if (tix >= nwave) return;
-    t    = wtiles[tix];
-    lane = threadIdx.x & 63;
+  const int G = gridDim.x;
+  if (HAS_BLOCK) {
+    for (int bt = blockIdx.x; bt < nblock; bt += G) {
+      const Tile    t  = btiles[bt];
+      const SnView  d  = view(sns[t.sn]);
+      const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
+      bwd_block_tile<MU, FP>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts, dbg);
+      __syncthreads();
+    }
   }
-  const SnDesc  d  = sns[t.sn];
-  const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
-  double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-  if (HAS_BLOCK && lane < 0) bwd_block_tile<MU>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts);
-  else bwd_wave_tile<MU>(d, lane, lds + (threadIdx.x >> 6) * (WAVE_ROWS * MU), yb, xb, xo);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double   *wl = lds + wv * (WAVE_ROWS * MU);
+  // the wave-level deal starts where the block-level deal stopped
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
+    const Tile    t  = wtiles[tix];
+    const SnView  d  = view(sns[t.sn]);
+    const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
+    bwd_wave_tile<MU, FP>(d, lane, wl, yb, xb, xo, dbg);
+    wave_lds_sync();
+  }
+}
+
+// Right-hand side of the wide supernodes of a level, formed once: b_J <- b_J - (updates handed up by the children), in
+// place in the permuted copy of b (only the tiles of J read these entries).  One thread per column: the dependent index
+// chains gptr -> gsrc -> U of a whole level overlap instead of being walked by every row tile of the supernode.
+template <int MU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_gather_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ gtiles, double *__restrict__ b, const double *__restrict__ U, int mu_total, int nu0)
+{
+  const Tile   t = gtiles[blockIdx.x];
+  const SnView d = view(sns[t.sn]);
+  const int    col = t.r0 + (int)threadIdx.x;
+  if (col >= t.r0 + t.nr) return;
+  double       *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+  const double *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+  const int     q0 = d.gptr[col], q1 = d.gptr[col + 1];
+  if (q0 == q1) return;
+  double v[MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + col];
+  for (int q = q0; q < q1; ++q) {
+    const int src = d.gsrc[q];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
+  }
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) bb[(long long)nu * d.n + d.c0 + col] = v[nu];
+}
+
+// Bottom subtrees: one workgroup sweeps a whole subtree of narrow supernodes, height by height; the four wavefronts share
+// the tiles of a height, a workgroup barrier (all the wavefronts sit on one CU and share its L1) replaces the kernel
+// boundary between levels.
+template <int MU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_subtree_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ sub_ptr, int phases, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int  wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double    *wl = lds + wave * (WAVE_ROWS * MU);
+  const int *p  = sub_ptr + (long long)blockIdx.x * 3 * (phases + 1);
+  for (int h = 0; h < phases; ++h) {
+    const int t1 = p[h + 1];
+    for (int ti = p[h] + wave; ti < t1; ti += WG_THREADS / 64) {
+      const Tile    t  = tiles[ti];
+      const SnView  d  = view(sns[t.sn]);
+      const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+      fwd_wave_tile<MU, 4>(d, t, lane, wl, bb, yb, Ub, 0);
+      wave_lds_sync(); // the epilogue's reads land before the next tile reuses the wavefront's LDS
+    }
+    if (h + 1 < phases) __syncthreads();
+  }
+}
+
+template <int MU>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_subtree_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ sub_ptr, int phases, const double *__restrict__ y, double *__restrict__ xw, int mu_total, int nu0, int lds_dbl)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int  wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double    *wl = lds + wave * (WAVE_ROWS * MU);
+  const int *pb = sub_ptr + ((long long)blockIdx.x * 3 + 1) * (phases + 1), *pw = pb + (phases + 1);
+  for (int h = phases - 1; h >= 0; --h) {
+    // supernodes too tall for one wavefront: the whole workgroup, one after the other
+    for (int ti = pb[h]; ti < pb[h + 1]; ++ti) {
+      const Tile    t  = tiles[ti];
+      const SnView  d  = view(sns[t.sn]);
+      const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+      bwd_block_tile<MU, 4>(d, t, lds, lds_dbl, yb, xb, xb, nullptr, nullptr, 1, 0);
+      __syncthreads();
+    }
+    const int t1 = pw[h + 1];
+    for (int ti = pw[h] + wave; ti < t1; ti += WG_THREADS / 64) {
+      const Tile    t  = tiles[ti];
+      const SnView  d  = view(sns[t.sn]);
+      const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+      double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+      bwd_wave_tile<MU, 4>(d, lane, wl, yb, xb, xb, 0);
+      wave_lds_sync();
+    }
+    if (h > 0) __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -496,6 +688,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   blk_ptr   = hf.sym.blk_ptr;
   ldw       = hf.ldw;
   height    = hf.sym.height;
+  parent    = hf.sym.parent;
   level_ptr = hf.level_ptr;
   level_blk = hf.level_blk;
   f_off     = hf.f_off;
@@ -529,8 +722,61 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   std::vector<SnDesc>           descs;
   std::vector<std::vector<Tile>> tl[4];
   for (auto &v : tl) v.assign(nlev, {});
+  std::vector<std::vector<Tile>> gat(nlev);
+  const char *env_h = getenv("HPDDM_HIP_SUBTREE_H"), *env_g = getenv("HPDDM_HIP_PREGATHER");
+  const int   hmax      = env_h ? atoi(env_h) : -1; // -1: no subtree kernels
+  auto        envi      = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
+  fp                    = envi("HPDDM_HIP_FP", 4) == 8 ? 8 : 4;
+  cu                    = envi("HPDDM_HIP_CU", 1) == 2 ? 2 : 1;
+  dbg                   = envi("HPDDM_HIP_DBG", 0);
+  persist               = envi("HPDDM_HIP_PERSIST", 0); // workgroups per CU of the persistent sweep launches (0: one workgroup per tile share)
+  lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
+  const int fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: aim at this many workgroups per level (0: fixed rule)
+  const int bwd_want    = envi("HPDDM_HIP_BWD_WANT", 768);   // wide panels, backward: split rows until a level fields this many workgroups
+  const int bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
+  const int bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 16);
+  const int FWD_PASSES  = fp;
+  const bool pregather  = env_g ? atoi(env_g) != 0 : true;
+  const int wtile       = std::max(512, envi("HPDDM_HIP_WTILE", 2048));
+  const int sort_mode   = envi("HPDDM_HIP_SORT", 1); // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
+  // entries of the wide panels per level (the forward tile area follows the level's total)
+  std::vector<long long> wide_cost(nlev, 0);
+  if (fwd_target > 0)
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      for (idx_t k = 0; k < D.nblk; ++k)
+        if (D.ldw[k] > NARROW) {
+          const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
+          wide_cost[D.height[k]] += w * (w + 1) / 2 + nb * w;
+        }
+    }
+  struct SubtreeTiles {
+    std::vector<std::vector<Tile>> k[3]; // forward wave / backward block / backward wave, per height
+    long long                      cost = 0;
+  };
+  std::vector<SubtreeTiles> subtrees;
+  sub_phases = 0;
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
+    // heights 0..hf of this factor hold narrow supernodes only: they are swept subtree by subtree
+    int hf = -1;
+    for (int l = 0; l <= hmax && l < D.nlev; ++l) {
+      bool narrow = true;
+      for (idx_t q = D.level_ptr[l]; q < D.level_ptr[l + 1] && narrow; ++q) narrow = D.ldw[D.level_blk[q]] <= NARROW;
+      if (!narrow) break;
+      hf = l;
+    }
+    sub_phases = std::max(sub_phases, hf + 1);
+    std::vector<int> st_of(D.nblk, -1);
+    for (idx_t k = D.nblk - 1; k >= 0; --k) { // parents come after their children
+      if (D.height[k] > hf) continue;
+      const idx_t pa = D.parent[k];
+      if (pa >= 0 && D.height[pa] <= hf) st_of[k] = st_of[pa];
+      else {
+        st_of[k] = (int)subtrees.size();
+        subtrees.emplace_back();
+      }
+    }
     for (idx_t k = 0; k < D.nblk; ++k) {
       SnDesc d;
       d.F     = D.F.p + D.f_off[k];
@@ -552,22 +798,46 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       const int id = (int)descs.size();
       descs.push_back(d);
       const int h = d.w + d.nb, lev = D.height[k];
+      SubtreeTiles *st = st_of[k] >= 0 ? &subtrees[st_of[k]] : nullptr;
+      if (st)
+        for (auto &v : st->k)
+          if ((int)v.size() <= lev) v.resize(lev + 1);
       if (d.ldw <= NARROW) {
         // forward: 16-64 KiB of panel per wavefront tile (at most WAVE_ROWS rows): every tile re-stages the right-hand side
         // of its supernode (w gathers), so wider panels get more rows per tile
         const int R      = 64 / (d.ldw / 2);
-        const int budget = 2048; // doubles (16 KiB): larger tiles measured slower (fewer wavefronts in flight)
+        const int budget = wtile; // doubles (16 KiB by default): larger tiles measured slower (fewer wavefronts in flight)
         int       trw    = std::max(FWD_PASSES * R, (budget / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
         trw           = std::min(trw, WAVE_ROWS);
-        for (int r0 = 0; r0 < h; r0 += trw) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(trw, h - r0), 0, 1, 0, 0, 0});
+        std::vector<Tile> &fw = st ? st->k[0][lev] : tl[FWD_WAVE][lev];
+        for (int r0 = 0; r0 < h; r0 += trw) fw.push_back(Tile{id, r0, std::min(trw, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
-        if (h <= WAVE_ROWS && (long long)h * d.ldw <= 4096) tl[BWD_WAVE][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
-        else tl[BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
+        const bool small = h <= WAVE_ROWS && (long long)h * d.ldw <= 4096;
+        (st ? st->k[small ? 2 : 1][lev] : tl[small ? BWD_WAVE : BWD_BLOCK][lev]).push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
+        if (st) st->cost += (long long)h * d.ldw;
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         const int trb = d.w <= 960 ? 64 : (d.w <= 3968 ? 32 : 16);
-        for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
+        if (fwd_target > 0) {
+          // tiles of equal AREA: the rows of the triangular top block are short, so the tiles there are taller (at most
+          // 64 rows); the area follows the level's total so that a level of few, huge supernodes still fields fwd_target
+          // workgroups
+          const long long area = std::max<long long>(8LL * d.w, std::min<long long>((long long)trb * d.w, wide_cost[lev] / fwd_target));
+          for (int r0 = 0; r0 < h;) {
+            long long acc = 0;
+            int       nr  = 0;
+            while (nr < 64 && r0 + nr < h && (acc < area || (nr & 7))) {
+              acc += std::min(r0 + nr + 1, d.w);
+              ++nr;
+            }
+            tl[FWD_BLOCK][lev].push_back(Tile{id, r0, nr, 0, 1, 0, 0, 0});
+            r0 += nr;
+          }
+        } else
+          for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
         for (int c0 = 0; c0 < d.w; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / 4) * 4, h});
+        if (pregather && d.has_src)
+          for (int c0 = 0; c0 < d.w; c0 += WG_THREADS) gat[lev].push_back(Tile{id, c0, std::min(WG_THREADS, d.w - c0), 0, 1, 0, 0, 0});
       }
     }
   }
@@ -579,12 +849,14 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   for (int l = 0; l < nlev; ++l) {
     std::vector<Tile> &v = tl[BWD_BLOCK][l];
     const int          T = (int)v.size();
-    if (T == 0 || T >= 512) continue;
-    const int want = std::min(16, (768 + T - 1) / T);
+    if (T == 0 || T >= bwd_want) continue;
+    long long lcost = 0;
+    for (const Tile &t : v) lcost += (long long)(t.rend - t.rbeg);
+    const long long rows_per_part = std::max<long long>(bwd_minrows, lcost / bwd_want); // every part sums about this many rows of its 128 columns
     std::vector<Tile> out;
     for (const Tile &t : v) {
       const int rows = t.rend - t.rbeg;
-      const int np   = std::max(1, std::min(want, rows / 256));
+      const int np   = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(bwd_maxpart, rows / bwd_minrows), (rows + rows_per_part / 2) / rows_per_part));
       if (np == 1) {
         out.push_back(t);
         continue;
@@ -617,13 +889,46 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
-      std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
+      if (sort_mode == 1 || kd == FWD_BLOCK || kd == BWD_BLOCK) std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
+      else if (sort_mode == 2) { // narrow tiles: by size class only, memory order inside a class
+        auto cls = [&](const Tile &t) { int c = 0; for (long long v = cost(t); v > 1; v >>= 1) ++c; return c; };
+        std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cls(a) > cls(b2); });
+      }
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       int need = 0;
       for (const Tile &t : tl[kd][l]) need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : 0));
       lev_lds[kd][l] = need;
     }
+  gat_ptr.assign(nlev, 0);
+  gat_end.assign(nlev, 0);
+  for (int l = 0; l < nlev; ++l) {
+    gat_ptr[l] = (int)all.size();
+    all.insert(all.end(), gat[l].begin(), gat[l].end());
+    gat_end[l] = (int)all.size();
+    launches_per_solve += !gat[l].empty();
+  }
+  {
+    // longest subtrees first
+    std::vector<int> order(subtrees.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return subtrees[a].cost > subtrees[b2].cost; });
+    nsubtrees = (int)subtrees.size();
+    std::vector<int> sp((size_t)nsubtrees * 3 * (sub_phases + 1), 0);
+    for (int i = 0; i < nsubtrees; ++i) {
+      const SubtreeTiles &st = subtrees[order[i]];
+      for (int kd = 0; kd < 3; ++kd) {
+        int *p = sp.data() + ((size_t)i * 3 + kd) * (sub_phases + 1);
+        for (int h = 0; h < sub_phases; ++h) {
+          p[h] = (int)all.size();
+          if (h < (int)st.k[kd].size()) all.insert(all.end(), st.k[kd][h].begin(), st.k[kd][h].end());
+        }
+        p[sub_phases] = (int)all.size();
+      }
+    }
+    sub_ptr.upload(sp, s);
+    if (nsubtrees) launches_per_solve += 2;
+  }
   for (int kd = 0; kd < 4; ++kd) {
     // lev_ptr[kd][l]..lev_end: store the end of each range in a parallel array (ranges of different kinds interleave)
     lev_end[kd].assign(nlev, 0);
@@ -666,26 +971,48 @@ void SolvePlan::reserve(int mu)
   mu_cap = mu;
 }
 
-template <int MU>
-static void solve_block(SolvePlan &P, const double *b, double *x, int mu_total, int nu0, hipStream_t s)
+template <int MU, int FP, int CU>
+static void solve_block_v(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
 {
   // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels.
-  // Dynamic LDS per launch: what the widest block-level tile of the level needs (capped at 32 KiB), so that the levels
+  // Dynamic LDS per launch: what the widest block-level tile of the level needs (capped), so that the levels
   // mixing block-level and wave-level tiles keep more workgroups per CU.
   const int lds_wave = 4 * WAVE_ROWS * MU;
   auto      cnt      = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
-  auto      clampd   = [&](int need) { return std::max(std::max(512 * MU, lds_wave), std::min(LDS_DOUBLES, (need + 63) / 64 * 64)); };
+  auto      clampd   = [&](int need) { return std::max(std::max(512 * MU, lds_wave), std::min(P.lds_cap, (need + 63) / 64 * 64)); };
+  // persistent grids: at most what the 256 CUs hold at once (LDS-limited for the launches that stage in LDS)
+  auto grid = [&](int nb, int nw, int ld_dbl) {
+    const int want = nb + (nw + 3) / 4;
+    if (P.persist <= 0) return want;
+    const int per_cu = std::max(1, std::min(P.persist, (int)((160 * 1024) / ((size_t)ld_dbl * sizeof(double)))));
+    return std::max(1, std::min(want, 256 * per_cu));
+  };
+  if (P.nsubtrees) hipLaunchKernelGGL((sptrsv_fwd_subtree_kernel<MU>), dim3(P.nsubtrees), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, P.sub_ptr.p, P.sub_phases, b, P.y.p, P.U.p, mu_total, nu0);
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
+    const int ng = P.gat_end[l] - P.gat_ptr[l];
+    if (ng) hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
     const int ld = clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU);
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, lds_wave);
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FP, CU>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, ng ? 1 : 0, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FP, 1>), dim3(grid(0, nw, lds_wave)), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, lds_wave, 0, P.dbg);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
     const int ld = clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU);
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false>), dim3((nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, lds_wave);
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FP>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FP>), dim3(grid(0, nw, lds_wave)), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, lds_wave, P.dbg);
+  }
+  if (P.nsubtrees) hipLaunchKernelGGL((sptrsv_bwd_subtree_kernel<MU>), dim3(P.nsubtrees), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, P.sub_ptr.p, P.sub_phases, P.y.p, P.xw.p, mu_total, nu0, lds_wave);
+}
+template <int MU>
+static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
+{
+  if (P.fp == 8) {
+    if (P.cu == 2) solve_block_v<MU, 8, 2>(P, b, x, mu_total, nu0, s);
+    else solve_block_v<MU, 8, 1>(P, b, x, mu_total, nu0, s);
+  } else {
+    if (P.cu == 2) solve_block_v<MU, 4, 2>(P, b, x, mu_total, nu0, s);
+    else solve_block_v<MU, 4, 1>(P, b, x, mu_total, nu0, s);
   }
 }
 
@@ -696,23 +1023,23 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
   const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
   hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
-  b = bperm.p;
+  double *const bp = bperm.p; // private permuted copy: the gather pass updates it in place
   double *const xout = x;
   x                  = xw.p; // the sweeps stay in the permuted numbering; one pass scatters the result at the end
   int nu0 = 0;
   while (nu0 < mu) {
     const int left = mu - nu0;
     if (left >= 8) {
-      solve_block<8>(*this, b, x, mu, nu0, s);
+      solve_block<8>(*this, bp, x, mu, nu0, s);
       nu0 += 8;
     } else if (left >= 4) {
-      solve_block<4>(*this, b, x, mu, nu0, s);
+      solve_block<4>(*this, bp, x, mu, nu0, s);
       nu0 += 4;
     } else if (left >= 2) {
-      solve_block<2>(*this, b, x, mu, nu0, s);
+      solve_block<2>(*this, bp, x, mu, nu0, s);
       nu0 += 2;
     } else {
-      solve_block<1>(*this, b, x, mu, nu0, s);
+      solve_block<1>(*this, bp, x, mu, nu0, s);
       nu0 += 1;
     }
   }
