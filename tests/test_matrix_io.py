@@ -1,0 +1,68 @@
+"""The reference's matrix dump format (include/HPDDM_matrix.hpp:121-135, :173-244): reader and writer against files dumped
+by the compiled reference (tests/golden/dump/out_{r}_4.txt: examples/schwarz.cpp -Nx 20 -Ny 20 on 4 ranks with
+-hpddm_dump_matrices=out), and the P-row harness (examples/solver.py protocol) on them."""
+import filecmp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hpddm_amd.generate import generate2d
+from hpddm_amd.matrix_io import csrmv, read_matrix, write_matrix
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+DUMP = os.path.join(HERE, "golden", "dump")
+
+
+@pytest.mark.parametrize("rank", range(4))
+def test_reader_matches_generator_and_writer_is_byte_identical(rank, tmp_path):
+    path = os.path.join(DUMP, f"out_{rank}_4.txt")
+    mat = read_matrix(path)
+    assert (mat["n"], mat["m"], mat["sym"], mat["nnz"], mat["numbering"]) == (121, 121, False, 561, "C")
+    sub = generate2d(20, 20, 4, overlap=1)[rank]  # bit-exact restatement of examples/generate.cpp
+    assert np.array_equal(mat["ia"], sub["ia"]) and np.array_equal(mat["ja"], sub["ja"]) and np.array_equal(mat["a"], sub["a"])
+    out = tmp_path / "rt.txt"
+    write_matrix(out, mat["n"], mat["ia"], mat["ja"], mat["a"], sym=mat["sym"], numbering=mat["numbering"])
+    assert filecmp.cmp(path, out, shallow=False)
+
+
+def test_symmetric_storage_roundtrip(tmp_path):
+    sub = generate2d(12, 12, 1, overlap=1, sym=True)[0]
+    p = tmp_path / "s.txt"
+    write_matrix(p, sub["n"], sub["ia"], sub["ja"], sub["a"], sym=True)
+    mat = read_matrix(p)
+    assert mat["sym"] and np.array_equal(mat["ja"], sub["ja"]) and np.array_equal(mat["a"], sub["a"])
+    full = generate2d(12, 12, 1, overlap=1, sym=False)[0]
+    x = np.random.default_rng(0).random(sub["n"])
+    assert np.allclose(csrmv(mat, x), csrmv({**full, "sym": False}, x), rtol=1e-14)
+
+
+def test_reader_rejects_malformed(tmp_path):
+    p = tmp_path / "bad.txt"
+    p.write_text("# c\n# c\n2 2 0  2 C\n1 1 1.0\n")
+    with pytest.raises(ValueError):
+        read_matrix(p)
+    p.write_text("# c\n# c\n2 2 0  1 C\n3 1 1.0\n")
+    with pytest.raises(ValueError):
+        read_matrix(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank", [0, 3])
+def test_solver_py_protocol(rank):
+    """examples/solver.py:32-50: numfact + solve of a random right-hand side, residual <= 1e-8, exit status 0"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "solver.py"), os.path.join(DUMP, f"out_{rank}_4.txt")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "--- residual" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_local_solver_benchmark_protocol():
+    """benchmark/local_solver.cpp: one row per trial, one column per nu"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "local_solver.py"), os.path.join(DUMP, "out_1_4.txt"), "--rhs", "4", "--solve-phase-only"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    rows = [ln for ln in res.stdout.splitlines() if "|" in ln]
+    assert len(rows) == 3 and all(len(r.split("|")[0].split()) == 3 for r in rows), res.stdout
