@@ -165,6 +165,15 @@ def main():
                            "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep = %d launches)" % int(st["launches"]),
                            "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve,
                            "stored_bytes_per_sweep": 2.0 * st["stored"] * 8.0}
+        # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # runs of this command, scripts/final_profiles.sh): only quoted for the workload it was collected on
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if args.n == 128 and args.subdomains == 8 and mu == 1 and os.path.exists(pmc):
+            with open(pmc) as fh:
+                tr = json.load(fh)
+            if abs(tr.get("algorithmic_bytes", 0.0) - bytes_alg) < 1e-6 * bytes_alg:
+                out["roofline"]["traffic"] = tr["traffic_bytes"]
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json ((2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc, separate passes)"
         out["phases_ms"] = {"sptrsv": t_solve * 1e3}
         if not sharded:  # exchange / GMV of a sharded operator are collective: timed on all ranks below
             out["phases_ms"].update({"exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3})
