@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--no-gmres", action="store_true")
     ap.add_argument("--no-two-level", action="store_true")
     ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level leg")
+    ap.add_argument("--problem", choices=("poisson", "elasticity"), default="poisson",
+                    help="poisson: 7-point Laplacian, grid^3 cells per GPU (configs[1], configs[2]); elasticity: trilinear hexahedra, 3 dofs per "
+                         "node, grid^3 nodes per GPU (configs[3] is --problem elasticity --grid 64 on 8 GPUs)")
     ap.add_argument("--geneo", action="store_true", help="two-level leg: compute the real GenEO vectors (solveGEVP) instead of the polynomial stand-ins")
     args = ap.parse_args()
 
@@ -65,7 +68,14 @@ def main():
     cpu_coll = share and world > 1
 
     from hpddm_amd import _lib, hpddm
-    from hpddm_amd.generate import generate3d
+    from hpddm_amd.generate import generate3d, generate_elasticity3d
+
+    def generate(dims, parts, **kw):
+        if args.problem == "elasticity":
+            kw.pop("rhs", None)
+            kw.setdefault("normalize", True)
+            return generate_elasticity3d(dims, parts, overlap=1, sym=True, **kw)
+        return generate3d(dims, parts, overlap=1, sym=True, **kw)
 
     hpddm.require_device()
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
@@ -80,14 +90,13 @@ def main():
         # exchanges the halo of the two slab faces with ranks r-1 / r+1 (RCCL point-to-point over xGMI)
         assert args.subdomains == 8
         parts = 8 * world
-        subs = generate3d((args.n, args.n, args.n * world), parts, overlap=1, sym=True, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8,
-                          normalize=True, neumann=args.geneo)
+        subs = generate((args.n, args.n, args.n * world), parts, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8, normalize=True, neumann=args.geneo)
         A, d = hpddm.schwarz_from_subdomains(subs, first_global=8 * rank, nglobal=parts, options=opts, multiplicity=False,
                                              partition=(rank, [8 * r for r in range(world + 1)]))
         A.enable_distributed(dist, dev, mu_cap=max(1, args.mu, 0 if args.no_two_level else args.geneo_nu), host_staging=cpu_coll)
     else:
-        subs = generate3d(args.n, args.subdomains, overlap=1, sym=True, rhs="smooth", neumann=args.geneo)
-        A, d = hpddm.schwarz_from_subdomains(subs, options=opts)
+        subs = generate(args.n, args.subdomains, rhs="smooth", neumann=args.geneo)
+        A, d = hpddm.schwarz_from_subdomains(subs, options=opts, multiplicity=args.problem != "elasticity")
     A.call_numfact()
     t_setup = time.time() - t0
     st = A.stats()
@@ -125,7 +134,9 @@ def main():
         "metric": "ras_precond_applies_per_sec", "value": value, "unit": "applies/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{1 if args.n == 128 else (2 if args.n == 256 else '1-like')}]: 3-D Poisson {args.n}^3 per GPU, "
+        "config": {"workload": (f"BASELINE.json configs[{1 if args.n == 128 else (2 if args.n == 256 else '1-like')}]: 3-D Poisson {args.n}^3 per GPU, "
+                                if args.problem == "poisson" else
+                                f"BASELINE.json configs[3]-like: 3-D linear elasticity (block-3 CSR), {args.n}^3 nodes per GPU, ") +
                                f"{args.subdomains} subdomains per GPU, one-level RAS (two-level leg reported under 'two_level'), "
                                f"HIP level-scheduled SpTRSV, overlap 1, mu={mu}",
                    "parallelism": ("1 GPU, 8 subdomains batched" if world == 1 else
@@ -212,12 +223,20 @@ def two_level(A, subs, args, np, mu, reps):
     for s, sd in enumerate(subs):
         if args.geneo:
             A.set_option("geneo_nu", nu)
-            lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], sd["sym"])
+            lam = A.solve_gevp(s, sd["n"], sd.get("ia_neumann", sd["ia"]), sd.get("ja_neumann", sd["ja"]), sd["a_neumann"], sd["sym"])
             lam_max = max(lam_max or 0.0, float(lam[-1]))
             continue
         i0, i1, j0, j1, k0, k1 = sd["box"]
         z, y, x = np.meshgrid(np.linspace(-1, 1, k1 - k0), np.linspace(-1, 1, j1 - j0), np.linspace(-1, 1, i1 - i0), indexing="ij")
-        Z = np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo], axis=1)
+        if sd.get("block", 1) == 3:
+            # stand-in for elasticity: monomials on each displacement component (the first 12 span the rigid-body modes)
+            P = np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo[:(nu + 2) // 3]], axis=1)
+            Z = np.zeros((sd["n"], 3 * P.shape[1]))
+            for comp in range(3):
+                Z[comp::3, comp::3] = P
+            Z = Z[:, :nu]
+        else:
+            Z = np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo], axis=1)
         A.set_vectors(s, Z)
     tg = time.time() - tg
     t0 = time.time()

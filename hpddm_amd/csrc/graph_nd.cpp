@@ -224,7 +224,7 @@ struct NDWork {
 
 } // namespace
 
-void nested_dissection(const Graph &g, int leaf_size, Ordering &ord)
+static void nested_dissection_plain(const Graph &g, int leaf_size, Ordering &ord)
 {
   NDWork w(g, std::max(1, leaf_size));
   std::vector<idx_t> all(g.n);
@@ -235,6 +235,102 @@ void nested_dissection(const Graph &g, int leaf_size, Ordering &ord)
   ord.blk_ptr.swap(w.blk_ptr);
   ord.iperm.assign(g.n, 0);
   for (idx_t i = 0; i < g.n; ++i) ord.iperm[ord.perm[i]] = i;
+}
+
+// Vertices with the same closed neighbourhood (the dofs of one node of a vector-valued problem: 3 per node in
+// elasticity) are indistinguishable for the elimination: the graph is compressed to one supervariable per class, dissected,
+// and the ordering expanded.  Separators then cut between nodes instead of between the components of a node.
+void nested_dissection(const Graph &g, int leaf_size, Ordering &ord)
+{
+  const idx_t n = g.n;
+  // hash of the closed neighbourhood {i} U adj(i)
+  std::vector<uint64_t> key(n);
+  for (idx_t i = 0; i < n; ++i) {
+    uint64_t sum = (uint64_t)i * 0x9E3779B97F4A7C15ull + 1, cnt = 1;
+    uint64_t x   = ((uint64_t)i + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    uint64_t acc = x;
+    for (idx_t p = g.xadj[i]; p < g.xadj[i + 1]; ++p) {
+      uint64_t y = ((uint64_t)g.adjncy[p] + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull;
+      y ^= y >> 29;
+      acc += y; // order-independent
+      ++cnt;
+    }
+    (void)sum;
+    key[i] = acc * 31 + cnt;
+  }
+  // candidates: neighbours with the same key; verify by comparing sorted closed neighbourhoods
+  std::vector<idx_t> cls(n, -1), rep;
+  std::vector<idx_t> a, b;
+  auto closed = [&](idx_t v, std::vector<idx_t> &out) {
+    out.assign(g.adjncy.begin() + g.xadj[v], g.adjncy.begin() + g.xadj[v + 1]);
+    out.push_back(v);
+    std::sort(out.begin(), out.end());
+  };
+  for (idx_t i = 0; i < n; ++i) {
+    if (cls[i] >= 0) continue;
+    const idx_t c = (idx_t)rep.size();
+    cls[i]        = c;
+    rep.push_back(i);
+    bool have = false;
+    for (idx_t p = g.xadj[i]; p < g.xadj[i + 1]; ++p) {
+      const idx_t j = g.adjncy[p];
+      if (j <= i || cls[j] >= 0 || key[j] != key[i] || g.xadj[j + 1] - g.xadj[j] != g.xadj[i + 1] - g.xadj[i]) continue;
+      if (!have) {
+        closed(i, a);
+        have = true;
+      }
+      closed(j, b);
+      if (a == b) cls[j] = c;
+    }
+  }
+  const idx_t nc = (idx_t)rep.size();
+  if (getenv("HPDDM_HIP_VERBOSE")) fprintf(stderr, "nested_dissection: %d vertices, %d supervariables\n", (int)n, (int)nc);
+  if ((double)n < 1.5 * (double)nc) { // nothing (or too little) to compress
+    nested_dissection_plain(g, leaf_size, ord);
+    return;
+  }
+  // members of every class, quotient graph
+  std::vector<idx_t> mptr(nc + 1, 0), mem(n);
+  for (idx_t i = 0; i < n; ++i) ++mptr[cls[i] + 1];
+  for (idx_t c = 0; c < nc; ++c) mptr[c + 1] += mptr[c];
+  {
+    std::vector<idx_t> pos(mptr.begin(), mptr.end() - 1);
+    for (idx_t i = 0; i < n; ++i) mem[pos[cls[i]]++] = i;
+  }
+  Graph q;
+  q.n = nc;
+  q.xadj.assign(nc + 1, 0);
+  std::vector<idx_t> mark(nc, -1);
+  for (idx_t c = 0; c < nc; ++c) {
+    const idx_t v = rep[c];
+    mark[c]       = c;
+    for (idx_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+      const idx_t d = cls[g.adjncy[p]];
+      if (mark[d] != c) {
+        mark[d] = c;
+        q.adjncy.push_back(d);
+      }
+    }
+    q.xadj[c + 1] = (idx_t)q.adjncy.size();
+  }
+  Ordering oq;
+  const int avg = (int)((n + nc - 1) / nc);
+  nested_dissection_plain(q, std::max(4, leaf_size / avg), oq);
+  // expand
+  ord.perm.clear();
+  ord.perm.reserve(n);
+  ord.blk_ptr.assign(1, 0);
+  for (size_t k = 0; k + 1 < oq.blk_ptr.size(); ++k) {
+    for (idx_t t = oq.blk_ptr[k]; t < oq.blk_ptr[k + 1]; ++t) {
+      const idx_t c = oq.perm[t];
+      for (idx_t m = mptr[c]; m < mptr[c + 1]; ++m) ord.perm.push_back(mem[m]);
+    }
+    ord.blk_ptr.push_back((idx_t)ord.perm.size());
+  }
+  HH_CHECK((idx_t)ord.perm.size() == n, "nested_dissection: lost vertices in the expansion");
+  ord.iperm.assign(n, 0);
+  for (idx_t i = 0; i < n; ++i) ord.iperm[ord.perm[i]] = i;
 }
 
 } // namespace hpddm_hip

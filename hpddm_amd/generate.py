@@ -278,3 +278,162 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
         if neumann:
             subs[-1]["a_neumann"] = a_neumann
     return subs
+
+
+def _q1_elasticity_stiffness(h, E, nu):
+    """24 x 24 stiffness matrix of a trilinear hexahedron of edge h (isotropic Hooke law, 2x2x2 Gauss points); local
+    node a = (ax, ay, az) in {0,1}^3 numbered ax + 2*ay + 4*az, dof 3*a + component."""
+    lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    C = np.zeros((6, 6))
+    C[:3, :3] = lam
+    C[np.arange(3), np.arange(3)] += 2 * mu
+    C[np.arange(3, 6), np.arange(3, 6)] = mu
+    gp = np.array([-1.0, 1.0]) / np.sqrt(3.0)
+    corners = np.array([[(a & 1), (a >> 1) & 1, (a >> 2) & 1] for a in range(8)]) * 2.0 - 1.0
+    Ke = np.zeros((24, 24))
+    for gx in gp:
+        for gy in gp:
+            for gz in gp:
+                g = np.array([gx, gy, gz])
+                # derivatives of N_a = prod (1 + s_ad xi_d) / 8 w.r.t. physical coordinates (x = h (xi + 1) / 2)
+                dN = np.zeros((8, 3))
+                for a in range(8):
+                    for dd in range(3):
+                        t = corners[a, dd] / 8.0
+                        for o in range(3):
+                            if o != dd:
+                                t *= 1 + corners[a, o] * g[o]
+                        dN[a, dd] = t * 2.0 / h
+                B = np.zeros((6, 24))
+                for a in range(8):
+                    bx, by, bz = dN[a]
+                    B[:, 3 * a:3 * a + 3] = [[bx, 0, 0], [0, by, 0], [0, 0, bz], [by, bx, 0], [0, bz, by], [bz, 0, bx]]
+                Ke += B.T @ C @ B * (h / 2.0) ** 3
+    return 0.5 * (Ke + Ke.T)
+
+
+def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, grid=None, normalize=True, neumann=False, E=1.0, nu=0.3):
+    """Linear elasticity (3 dofs per node, trilinear hexahedra, h = 1/N) on N^3 nodes of a cube clamped on the face x = 0
+    (a layer of elements between the clamped plane and the first nodes), the other faces free; node boxes grown by
+    ``overlap`` layers -- the block-3 workload of BASELINE.json configs[3].  Same conventions as generate3d: subdomain
+    matrices R_i A R_i^T (``a_neumann``: the unassembled local matrix, elements inside the box only), ``d`` the
+    partition of unity on the nodes repeated on the 3 components, neighbours / shared dofs in lexicographic order."""
+    import scipy.sparse as sp
+    px, py, pz = grid if grid is not None else _factor3(parts)
+    assert px * py * pz == parts
+    dims, P = (N, N, N) if np.isscalar(N) else tuple(N), (px, py, pz)
+    h = 1.0 / dims[0]
+    Ke = _q1_elasticity_stiffness(h, E, nu)
+    count = parts - first if count is None else count
+
+    def coords(r):
+        z, rem = divmod(r, px * py)
+        y, x = divmod(rem, px)
+        return (x, y, z)
+
+    boxes = {}
+    for r in range(parts):
+        c = coords(r)
+        boxes[r] = [(max(c[a] * dims[a] // P[a] - overlap, 0), min((c[a] + 1) * dims[a] // P[a] + overlap, dims[a])) for a in range(3)]
+
+    def weights(r):
+        ramps = []
+        for a, (s, e) in enumerate(boxes[r]):
+            t = np.ones(e - s)
+            if overlap > 0:
+                if s != 0:
+                    t[:overlap] = np.arange(overlap) / float(overlap)
+                if e != dims[a]:
+                    t[-overlap:] = np.arange(overlap)[::-1] / float(overlap)
+            ramps.append(t)
+        return ramps[2][:, None, None] * ramps[1][None, :, None] * ramps[0][None, None, :]
+
+    wsum = None
+    if normalize:
+        wsum = np.zeros((dims[2], dims[1], dims[0]))
+        for r in range(parts):
+            (a0, a1), (b0, b1), (c0, c1) = boxes[r]
+            wsum[c0:c1, b0:b1, a0:a1] += weights(r)
+
+    def assemble(box, inside_only):
+        (i0, i1), (j0, j1), (k0, k1) = box
+        nx, ny, nz = i1 - i0, j1 - j0, k1 - k0
+        nn = nx * ny * nz
+        if inside_only:  # elements whose free nodes all lie in the box (the clamped layer counts when the box touches x = 0)
+            ex = np.arange(-1 if i0 == 0 else i0, i1 - 1)
+            ey, ez = np.arange(j0, j1 - 1), np.arange(k0, k1 - 1)
+        else:            # every element touching a node of the box
+            ex = np.arange(max(i0 - 1, -1), min(i1, dims[0] - 1))
+            ey, ez = np.arange(max(j0 - 1, 0), min(j1, dims[1] - 1)), np.arange(max(k0 - 1, 0), min(k1, dims[2] - 1))
+        EZ, EY, EX = np.meshgrid(ez, ey, ex, indexing="ij")
+        EX, EY, EZ = EX.ravel(), EY.ravel(), EZ.ravel()
+        rows, cols, vals = [], [], []
+
+        def local(a):
+            x, y, z = EX + (a & 1), EY + ((a >> 1) & 1), EZ + ((a >> 2) & 1)
+            ok = (x >= i0) & (x < i1) & (y >= j0) & (y < j1) & (z >= k0) & (z < k1)
+            return ok, (x - i0) + nx * ((y - j0) + ny * (z - k0))
+
+        loc = [local(a) for a in range(8)]
+        for a in range(8):
+            oka, na = loc[a]
+            for b in range(8):
+                okb, nb = loc[b]
+                ok = oka & okb
+                if not ok.any():
+                    continue
+                ra, cb = na[ok], nb[ok]
+                for ca in range(3):
+                    for cc in range(3):
+                        # full 3 x 3 blocks (block-3 CSR): couplings that vanish on this regular grid stay as stored zeros
+                        rows.append(3 * ra + ca)
+                        cols.append(3 * cb + cc)
+                        vals.append(np.full(ra.size, Ke[3 * a + ca, 3 * b + cc]))
+        M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(3 * nn, 3 * nn)).tocsr()
+        M.sum_duplicates()
+        M.sort_indices()
+        return M
+
+    def to_storage(M):
+        M = sp.tril(M, format="csr") if sym else M
+        M.sort_indices()
+        return M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+
+    subs = []
+    for r in range(first, first + count):
+        c = coords(r)
+        (i0, i1), (j0, j1), (k0, k1) = boxes[r]
+        nx, ny, nz = i1 - i0, j1 - j0, k1 - k0
+        nn = nx * ny * nz
+        idx = np.arange(nn, dtype=np.int64).reshape(nz, ny, nx)
+        A = assemble(boxes[r], False)
+        ia, ja, a = to_storage(A)
+        d = weights(r)
+        if normalize:
+            d = d / wsum[k0:k1, j0:j1, i0:i1]
+        d = np.repeat(d.reshape(-1), 3)
+        neigh, conn = [], []
+        for dz in (-1, 0, 1):
+            for dy_ in (-1, 0, 1):
+                for dx_ in (-1, 0, 1):
+                    if dx_ == dy_ == dz == 0:
+                        continue
+                    cx, cy, cz = c[0] + dx_, c[1] + dy_, c[2] + dz
+                    if not (0 <= cx < px and 0 <= cy < py and 0 <= cz < pz):
+                        continue
+                    q = cx + px * (cy + py * cz)
+                    inter = [(max(boxes[r][t][0], boxes[q][t][0]), min(boxes[r][t][1], boxes[q][t][1])) for t in range(3)]
+                    if any(lo >= hi for lo, hi in inter):
+                        continue
+                    nodes = idx[inter[2][0] - k0:inter[2][1] - k0, inter[1][0] - j0:inter[1][1] - j0, inter[0][0] - i0:inter[0][1] - i0].reshape(-1)
+                    neigh.append(q)
+                    conn.append((3 * nodes[:, None] + np.arange(3)[None, :]).reshape(-1).astype(np.int32))
+        f = np.zeros(3 * nn)
+        f[2::3] = -h ** 3  # gravity along -z, lumped
+        sub = dict(n=3 * nn, ia=ia, ja=ja, a=a, sym=bool(sym), numbering="C", neighbors=np.array(neigh, dtype=np.int32), connectivity=conn, d=d, f=f,
+                   box=(i0, i1, j0, j1, k0, k1), block=3)
+        if neumann:
+            ian, jan, an = to_storage(assemble(boxes[r], True))
+            sub["ia_neumann"], sub["ja_neumann"], sub["a_neumann"] = ian, jan, an
+        subs.append(sub)
+    return subs
