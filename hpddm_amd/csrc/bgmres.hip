@@ -149,14 +149,15 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   const int    m         = std::max(1, std::min((int)A.getopt("gmres_restart", 40), max_it));
   const int    variant   = (int)A.getopt("variant", VARIANT_RIGHT);
   const int    verbosity = (int)A.getopt("verbosity", 0);
-  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGMRES: only the left and right variants are built");
+  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT || variant == VARIANT_FLEXIBLE, "BGMRES: unknown variant");
+  const bool flexible = variant == VARIANT_FLEXIBLE; // Z_i = M^{-1} V_i kept at v[i + m + 1] (include/HPDDM_GMRES.hpp:254-255)
   HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGMRES: right-hand-side deflation (-hpddm_deflation_tol) is not built");
   const long long cnt = A.ntot * mu;
   const int       ldh = mu * (m + 1);
   const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
   const int       nblk = 64;
   DevBuf<double>  V, Ax, partial, gram_d, coef_d;
-  V.alloc((size_t)cnt * (m + 1));
+  V.alloc((size_t)cnt * ((flexible ? 2 * m : m) + 1));
   Ax.alloc((size_t)cnt);
   partial.alloc((size_t)(m + 1) * nblk * mu * mu);
   gram_d.alloc((size_t)(m + 1) * mu * mu);
@@ -243,6 +244,7 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
       }
     const int kblocks = dimc / mu;
     if (variant == VARIANT_LEFT) axpy_blocks(vk(0), kblocks, Y, 1.0, 1.0, x);
+    else if (flexible) axpy_blocks(vk(m + 1), kblocks, Y, 1.0, 1.0, x);
     else {
       axpy_blocks(vk(0), kblocks, Y, 1.0, 0.0, Ax.p);
       A.apply(Ax.p, vk(m), mu);
@@ -271,8 +273,9 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
         A.gmv(vk(i), Ax.p, mu);
         A.apply(Ax.p, vk(i + 1), mu);
       } else {
-        A.apply(vk(i), Ax.p, mu);
-        A.gmv(Ax.p, vk(i + 1), mu);
+        double *zi = flexible ? vk(i + m + 1) : Ax.p;
+        A.apply(vk(i), zi, mu);
+        A.gmv(zi, vk(i + 1), mu);
       }
       // ---- BlockArnoldi ----
       gram(vk(0), i + 1, vk(i + 1), G);                   // classical block Gram-Schmidt

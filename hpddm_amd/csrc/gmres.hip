@@ -50,11 +50,12 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
   const int    variant = (int)getopt("variant", VARIANT_RIGHT);
   const int    ortho   = (int)getopt("orthogonalization", ORTHO_CGS);
   const int    verbosity = (int)getopt("verbosity", 0);
-  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "GMRES: only the left and right variants are built");
+  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT || variant == VARIANT_FLEXIBLE, "GMRES: unknown variant");
+  const bool flexible = variant == VARIANT_FLEXIBLE; // the preconditioned basis Z_i = M^{-1} v_i is kept (v[i + m + 1] in the reference, include/HPDDM_GMRES.hpp:116-117)
   const long long cnt = ntot * mu;
   const dim3      g2((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
   DevBuf<double>  V, Ax, coef;
-  V.alloc((size_t)cnt * (m + 1));
+  V.alloc((size_t)cnt * ((flexible ? 2 * m : m) + 1));
   Ax.alloc((size_t)cnt);
   coef.alloc((size_t)(m + 1) * mu);
   auto vk = [&](int k) { return V.p + (size_t)k * cnt; };
@@ -110,8 +111,9 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
         gmv(vk(i), Ax.p, mu);
         apply(Ax.p, vk(i + 1), mu);
       } else {
-        apply(vk(i), Ax.p, mu);
-        gmv(Ax.p, vk(i + 1), mu);
+        double *zi = flexible ? vk(i + m + 1) : Ax.p;
+        apply(vk(i), zi, mu);
+        gmv(zi, vk(i + 1), mu);
       }
       // ---- Arnoldi (include/HPDDM_iterative.hpp:669-710) ----
       const int k = i + 1;
@@ -193,7 +195,14 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
       if (dmax == 0) return;
       upload_coef(yk.data(), dmax * mu);
       if (variant == VARIANT_LEFT) hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, vk(0), cnt, dmax, coef.p, 1.0, 1.0, x, mu);
-      else {
+      else if (flexible) {
+        // x += Z y for the right-hand sides that moved (updateSol on v + m + 1, include/HPDDM_GMRES.hpp:139)
+        hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, vk(m + 1), cnt, dmax, coef.p, 1.0, 0.0, Ax.p, mu);
+        std::vector<double> one(mu);
+        for (int nu = 0; nu < mu; ++nu) one[nu] = conv[nu] != 0 ? 1.0 : 0.0;
+        upload_coef(one.data(), mu);
+        hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, Ax.p, cnt, 1, coef.p, 1.0, 1.0, x, mu);
+      } else {
         hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, vk(0), cnt, dmax, coef.p, 1.0, 0.0, Ax.p, mu);
         apply(Ax.p, vk(m), mu); // correction lands in the last basis slot, like the reference (v[ldh/mu - 1])
         // x += correction for the right-hand sides that moved

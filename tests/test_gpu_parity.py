@@ -65,6 +65,21 @@ def test_gmres_matches_reference(name):
     A.destroy()
 
 
+def test_flexible_gmres_matches_reference():
+    """-hpddm_variant flexible (include/HPDDM_GMRES.hpp:116-117,139): restart 8, two right-hand sides, 27 iterations"""
+    g = gu.load("p40_fgmres_restart8_mu2")
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0]) == 27
+    ref = g["history"]
+    assert len(hist) == len(ref) and np.all(np.abs(hist - ref[:, 1]) <= 1e-4 * ref[:, 1])
+    _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-4)
+    A.destroy()
+
+
 def test_config1_45_iterations():
     """BASELINE.json configs[0]: examples/schwarz.cpp 2-D Poisson 200x200, 4 subdomains, one-level RAS -> 45 iterations"""
     g = gu.load("c1_p200_onelevel")
@@ -247,7 +262,7 @@ def test_geneo_coarse_space_against_arpack():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3"])
+@pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3"])
 def test_bgmres_matches_reference(name):
     """Block GMRES: iteration count, residual history and solution of the compiled reference"""
     g = gu.load(name)
