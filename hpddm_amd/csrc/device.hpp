@@ -58,6 +58,8 @@ struct SnDesc {
   int           c0, w, nb, ldw;
   int           u_off; // offset of this supernode's update vector inside the subdomain pool
   int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
+  const double *FT;    // narrow panels: the forward panel once more, transposed (w x ldh, row-major), or nullptr
+  int           ldh;   // its leading dimension (h rounded up to 2)
 };
 
 struct Tile {
@@ -77,9 +79,12 @@ struct DeviceFactor {
   idx_t    nblk = 0, nlev = 0;
   int64_t  f_size = 0, u_size = 0, nnz_exact = 0, nnz_stored = 0;
   DevBuf<double> F, G, dinv;
+  DevBuf<double> FT;                 // transposed copies of the narrow forward panels (reduction-free forward sweep)
+  std::vector<int64_t> ft_off;       // per supernode, -1 when it has none
+  std::vector<idx_t>   ldh;
   DevBuf<int>    rows, gptr, gsrc, perm;
   // host copies of what the plan builder needs
-  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk, parent;
+  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
   std::vector<char>    has_src;
   std::vector<int64_t> f_off, row_ptr, goff;
   void upload(const HostFactor &hf, hipStream_t s);
@@ -101,10 +106,6 @@ struct SolvePlan {
   // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
   // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
   std::vector<int> gat_ptr, gat_end;
-  // bottom of the elimination trees: every maximal subtree of height <= sub_h made of narrow supernodes is swept by ONE
-  // workgroup (its levels separated by workgroup barriers instead of kernel boundaries)
-  int              nsubtrees = 0, sub_phases = 0; // phases = sub_h + 1
-  DevBuf<int>      sub_ptr;                        // [nsubtrees][3][phases + 1]: forward wave tiles / backward block tiles / backward wave tiles
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U, bperm;
@@ -114,7 +115,7 @@ struct SolvePlan {
   int               nmax = 0;
   int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
   int               persist = 0; // workgroups per CU of the persistent sweep launches
-  int               fp = 4, cu = 1, lds_cap = 4096; // loads in flight per lane (rows x column chunks), LDS staging doubles per workgroup
+  int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves

@@ -18,9 +18,8 @@
 namespace hpddm_hip {
 
 static constexpr int WG_THREADS  = 256;
-static constexpr int LDS_DOUBLES = 4096; // 32 KiB staging per workgroup of the block-level path -> 5 workgroups (20 waves) per CU
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
-static constexpr int WAVE_ROWS   = 256;  // at most this many rows per wave-level tile (LDS: WAVE_ROWS * MU doubles per wavefront)
+static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
 
 // Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
 // tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
@@ -29,15 +28,16 @@ typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef const dbl2 __attribute__((address_space(1)))   *gcd2_t;
 typedef const int __attribute__((address_space(1)))    *gci_t;
 struct SnView {
-  gcd_t     F, G, dinv;
+  gcd_t     F, G, dinv, FT;
   gci_t     rows, gptr, gsrc;
   long long voff, uoff;
-  int       n, usize, c0, w, nb, ldw, u_off, has_src;
+  int       n, usize, c0, w, nb, ldw, u_off, has_src, ldh;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
   SnView v;
-  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv;
+  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT;
+  v.ldh = d.ldh;
   v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
   v.voff = d.voff, v.uoff = d.uoff;
   v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.u_off = d.u_off, v.has_src = d.has_src;
@@ -49,35 +49,6 @@ enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8 };
 
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
 
-// sum over the g lanes of a row group (g = any value <= 64, lanes gl = 0..g-1 are contiguous); result valid in gl == 0
-__device__ static inline double reduce_group(double v, int gl, int g)
-{
-  int width = g, off = 1;
-  while (off < g) off <<= 1;
-  for (off >>= 1; off >= 1; off >>= 1) {
-    const double t = __shfl_down(v, off);
-    if (gl + off < width) v += t;
-    width = min(width, off);
-  }
-  return v;
-}
-// the same for N independent values at once: the N shuffle chains overlap instead of running one after the other
-template <int N>
-__device__ static inline void reduce_group_n(double (&v)[N], int gl, int g)
-{
-  int width = g, off = 1;
-  while (off < g) off <<= 1;
-  for (off >>= 1; off >= 1; off >>= 1) {
-    double t[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) t[k] = __shfl_down(v[k], off);
-    const bool take = gl + off < width;
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-      if (take) v[k] += t[k];
-    width = min(width, off);
-  }
-}
 // sum over the R row groups of a wavefront for one column pair (lanes sub*g + gl, sub = 0..R-1); result valid in sub == 0
 __device__ static inline double reduce_across(double v, int lane, int sub, int g, int R)
 {
@@ -144,73 +115,63 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
 }
 
 // =========================== narrow panels (ldw <= 128): one wavefront per tile ====================================
-// lane (sub, gl): row-in-group sub = lane / g, column pair gl = lane % g with g = ldw/2 lanes per row, R = 64/g rows
-// per wave-instruction: a wavefront always moves 1 KiB of contiguous panel per load.  lds: WAVE_ROWS*MU doubles, private.
+// lane (sub, gl): row-in-group sub = lane / g, column pair gl = lane % g with g lanes per panel row, R = 64/g rows per
+// wave-instruction: a wavefront always moves ~1 KiB of contiguous panel per load.  lds: wr*MU doubles, private.
+// Forward product of a narrow panel WITHOUT per-row reductions: the panel is read through its transposed copy FT (w x ldh),
+// lanes own pairs of OUTPUT rows and walk down the w columns of F (= rows of FT), exactly as the backward sweep walks the
+// rows of G; the only cross-lane step is one reduction over the R column groups at the end.  Tile = nr <= 128 output rows.
 template <int MU, int FWD_PASSES>
-__device__ static inline void fwd_wave_tile(const SnView &d, const Tile &t, int lane, double *lds, const double *bb, double *yb, double *Ub, int dbg)
+__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg)
 {
-  const int w = d.w, ldw = d.ldw;
-  const int g = ldw >> 1, R = 64 / g; // any even ldw <= 128: R*g <= 64 lanes work, the others idle
+  const int w = d.w, ldh = d.ldh;
+  const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
-  const int   rend = t.r0 + t.nr;
-  const gcd_t Fp   = d.F + 2 * gl;
-  // the first rows of the panel are requested before the right-hand side is gathered: the stream starts while the
-  // dependent index chain (gptr -> gsrc -> U) is walked
+  const gcd_t Fp = d.FT + t.r0 + 2 * gl;
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
-    const int r = t.r0 + sub + p * R;
-    cur[p]      = (active && r < rend && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)r * ldw) : dbl2{0.0, 0.0};
+    const int i = sub + p * R;
+    cur[p]      = (active && i < w && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
   }
-  // right-hand side of the supernode for this lane's two columns: b - (updates handed up by the children)
-  double l0[MU], l1[MU];
-  {
-    const int c = 2 * gl;
+  // f = b_J - (updates handed up by the children), one lane per column, into the wavefront's LDS
+  for (int c = lane; c < w && !(dbg & DBG_NORHS); c += 64) {
+    double v[MU];
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 0.0;
-    if (dbg & DBG_NORHS) {
+    for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
+    if (d.has_src) {
+      const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
+      for (int q = q0; q < q1; ++q) {
+        const int src = d.gsrc[q];
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) l0[nu] = l1[nu] = 1.0;
-    } else if (c < w) {
-      // bb is already in the permuted numbering: columns c0+c, c0+c+1 are adjacent
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        l0[nu] = bb[(long long)nu * d.n + d.c0 + c];
-        l1[nu] = c + 1 < w ? bb[(long long)nu * d.n + d.c0 + c + 1] : 0.0;
-      }
-      if (d.has_src) {
-        const int q0 = d.gptr[c], q1 = d.gptr[c + 1], q2 = c + 1 < w ? d.gptr[c + 2] : q1;
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) {
-          for (int q = q0; q < q1; ++q) l0[nu] -= Ub[(long long)nu * d.usize + d.gsrc[q]];
-          for (int q = q1; q < q2; ++q) l1[nu] -= Ub[(long long)nu * d.usize + d.gsrc[q]];
-        }
+        for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
       }
     }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
   }
-  for (int rb0 = t.r0; rb0 < rend; rb0 += FWD_PASSES * R) { // wave-uniform trip count (the reductions shuffle across lanes)
-    const int  rb   = rb0 + sub;
-    const bool more = rb0 + FWD_PASSES * R < rend;
-    if (more) { // next batch in flight while this one is reduced
+  wave_lds_sync();
+  double acc0[MU], acc1[MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+  for (int ib0 = 0; ib0 < w; ib0 += FWD_PASSES * R) {
+    const int  ib   = ib0 + sub;
+    const bool more = ib0 + FWD_PASSES * R < w;
+    if (more) {
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
-        const int r = rb + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && r < rend && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)r * ldw) : dbl2{0.0, 0.0};
+        const int i = ib + (FWD_PASSES + p) * R;
+        nxt[p]      = (active && i < w && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
-    double sv[FWD_PASSES * MU];
-#pragma unroll
-    for (int p = 0; p < FWD_PASSES; ++p)
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) sv[p * MU + nu] = fma(cur[p].x, l0[nu], cur[p].y * l1[nu]);
-    if (!(dbg & DBG_NORED)) reduce_group_n<FWD_PASSES * MU>(sv, gl, g);
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
-      const int r = rb + p * R;
-      if (active && gl == 0 && r < rend) {
+      const int i = min(ib + p * R, w - 1); // out-of-range passes carry a = 0
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + (r - t.r0)] = sv[p * MU + nu];
+      for (int nu = 0; nu < MU; ++nu) {
+        const double v = lds[nu * wr + i];
+        acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+        acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
       }
     }
     if (more) {
@@ -218,14 +179,22 @@ __device__ static inline void fwd_wave_tile(const SnView &d, const Tile &t, int 
       for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
-  // epilogue, one lane per row: the dependent index chains (gptr -> gsrc -> U) of 64 rows overlap
-  wave_lds_sync();
-  if (dbg & DBG_NOSTORE) return;
-  for (int j = lane; j < t.nr; j += 64) fwd_store_row<MU>(d, t.r0 + j, lds + j, WAVE_ROWS, yb, Ub);
+  if (!(dbg & DBG_NORED)) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
+      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
+    }
+  }
+  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
+    const int r = t.r0 + 2 * gl, rend = t.r0 + t.nr;
+    if (r < rend) fwd_store_row<MU>(d, r, acc0, 1, yb, Ub);
+    if (r + 1 < rend) fwd_store_row<MU>(d, r + 1, acc1, 1, yb, Ub);
+  }
 }
 
 template <int MU, int FWD_PASSES>
-__device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, const double *yb, double *xb, double *xo, int dbg)
+__device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb, double *xo, int dbg)
 {
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
   const int g = ldw >> 1, R = 64 / g;
@@ -244,11 +213,11 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
     if (i < w) {
       const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
+      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
     } else {
       const int ri = d.rows[i - w];
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) lds[nu * WAVE_ROWS + i] = -xb[(long long)nu * d.n + ri];
+      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = -xb[(long long)nu * d.n + ri];
     }
   }
   wave_lds_sync();
@@ -270,7 +239,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
       const int i = min(ib + p * R, h - 1); // out-of-range passes carry a = 0
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
-        const double v = lds[nu * WAVE_ROWS + i];
+        const double v = lds[nu * wr + i];
         acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
         acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
       }
@@ -505,12 +474,11 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   }
 }
 
-// One launch per level and direction.  The grid is capped at what the chip holds at once (persistent workgroups): every
-// workgroup walks the level's block-level tiles g, g + G, ... with its four wavefronts together, then its wavefronts walk
-// the wave-level tiles on their own.  Tiles are sorted by decreasing cost, so the round-robin deal is balanced, and no
-// workgroup is dispatched for less than a full share of the level.
-template <int MU, bool HAS_BLOCK, int FP, int CU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int pregathered, int dbg)
+// One launch per level and direction: every workgroup takes block-level tiles g, g + G, ... with its four wavefronts
+// together, then its wavefronts take wave-level tiles on their own (G = grid size; by default one share per workgroup).
+// Tiles are sorted by decreasing cost.  wr = rows of right-hand side a wavefront stages in LDS (the level's maximum).
+template <int MU, bool HAS_BLOCK, int FP>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -521,13 +489,13 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
       const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
       double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-      fwd_block_tile<MU, FP, CU>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+      fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
   // wave-uniform tile index in a scalar register: the tile and its supernode descriptor come through the scalar cache
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  double   *wl = lds + wv * (WAVE_ROWS * MU);
+  double   *wl = lds + wv * (wr * MU);
   // the wave-level deal starts where the block-level deal stopped
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
   for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
@@ -536,13 +504,13 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    fwd_wave_tile<MU, FP>(d, t, lane, wl, bb, yb, Ub, dbg);
-    wave_lds_sync(); // the epilogue's reads land before the next tile reuses the wavefront's LDS
+    fwd_wave_tile_t<MU, FP>(d, t, lane, wl, wr, bb, yb, Ub, dbg);
+    wave_lds_sync(); // the last reads of the staged right-hand side land before the next tile overwrites it
   }
 }
 
 template <int MU, bool HAS_BLOCK, int FP>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int dbg)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -558,8 +526,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
     }
   }
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  double   *wl = lds + wv * (WAVE_ROWS * MU);
-  // the wave-level deal starts where the block-level deal stopped
+  double   *wl = lds + wv * (wr * MU);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
   for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
     const Tile    t  = wtiles[tix];
@@ -567,7 +534,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-    bwd_wave_tile<MU, FP>(d, lane, wl, yb, xb, xo, dbg);
+    bwd_wave_tile<MU, FP>(d, lane, wl, wr, yb, xb, xo, dbg);
     wave_lds_sync();
   }
 }
@@ -598,62 +565,22 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_gather_kernel(const SnDesc 
   for (int nu = 0; nu < MU; ++nu) bb[(long long)nu * d.n + d.c0 + col] = v[nu];
 }
 
-// Bottom subtrees: one workgroup sweeps a whole subtree of narrow supernodes, height by height; the four wavefronts share
-// the tiles of a height, a workgroup barrier (all the wavefronts sit on one CU and share its L1) replaces the kernel
-// boundary between levels.
-template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_subtree_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ sub_ptr, int phases, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0)
-{
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int  wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  double    *wl = lds + wave * (WAVE_ROWS * MU);
-  const int *p  = sub_ptr + (long long)blockIdx.x * 3 * (phases + 1);
-  for (int h = 0; h < phases; ++h) {
-    const int t1 = p[h + 1];
-    for (int ti = p[h] + wave; ti < t1; ti += WG_THREADS / 64) {
-      const Tile    t  = tiles[ti];
-      const SnView  d  = view(sns[t.sn]);
-      const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
-      double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-      double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-      fwd_wave_tile<MU, 4>(d, t, lane, wl, bb, yb, Ub, 0);
-      wave_lds_sync(); // the epilogue's reads land before the next tile reuses the wavefront's LDS
-    }
-    if (h + 1 < phases) __syncthreads();
-  }
-}
-
-template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_subtree_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ sub_ptr, int phases, const double *__restrict__ y, double *__restrict__ xw, int mu_total, int nu0, int lds_dbl)
-{
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int  wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  double    *wl = lds + wave * (WAVE_ROWS * MU);
-  const int *pb = sub_ptr + ((long long)blockIdx.x * 3 + 1) * (phases + 1), *pw = pb + (phases + 1);
-  for (int h = phases - 1; h >= 0; --h) {
-    // supernodes too tall for one wavefront: the whole workgroup, one after the other
-    for (int ti = pb[h]; ti < pb[h + 1]; ++ti) {
-      const Tile    t  = tiles[ti];
-      const SnView  d  = view(sns[t.sn]);
-      const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-      double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
-      bwd_block_tile<MU, 4>(d, t, lds, lds_dbl, yb, xb, xb, nullptr, nullptr, 1, 0);
-      __syncthreads();
-    }
-    const int t1 = pw[h + 1];
-    for (int ti = pw[h] + wave; ti < t1; ti += WG_THREADS / 64) {
-      const Tile    t  = tiles[ti];
-      const SnView  d  = view(sns[t.sn]);
-      const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-      double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
-      bwd_wave_tile<MU, 4>(d, lane, wl, yb, xb, xb, 0);
-      wave_lds_sync();
-    }
-    if (h > 0) __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
+
+// one-time: FT = F^T for the narrow panels (one workgroup per panel; reads strided, writes coalesced)
+__global__ void k_transpose_panels(const double *__restrict__ F, double *__restrict__ FT, const long long *__restrict__ foff, const long long *__restrict__ ftoff, const int *__restrict__ hh, const int *__restrict__ ww, const int *__restrict__ ldws, const int *__restrict__ ldhs)
+{
+  const int       k = blockIdx.x;
+  const long long fo = ftoff[k];
+  if (fo < 0) return;
+  const int     h = hh[k], w = ww[k], ldw = ldws[k], ldh = ldhs[k];
+  const double *src = F + foff[k];
+  double       *dst = FT + fo;
+  for (int o = threadIdx.x; o < w * ldh; o += blockDim.x) {
+    const int c = o / ldh, r = o - c * ldh;
+    dst[o]      = r < h ? src[(long long)r * ldw + c] : 0.0;
+  }
+}
 
 void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 {
@@ -688,12 +615,42 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   blk_ptr   = hf.sym.blk_ptr;
   ldw       = hf.ldw;
   height    = hf.sym.height;
-  parent    = hf.sym.parent;
   level_ptr = hf.level_ptr;
   level_blk = hf.level_blk;
   f_off     = hf.f_off;
   row_ptr   = hf.sym.row_ptr;
   goff      = hf.goff;
+  // transposed copies of the narrow forward panels
+  ft_off.assign(nblk, -1);
+  ldh.assign(nblk, 0);
+  {
+    int64_t tot = 0;
+    for (idx_t k = 0; k < nblk; ++k) {
+        if (ldw[k] > NARROW) continue;
+        const int64_t w = blk_ptr[k + 1] - blk_ptr[k], hgt = w + (row_ptr[k + 1] - row_ptr[k]);
+        ldh[k]    = (idx_t)((hgt + 1) / 2 * 2);
+        ft_off[k] = tot;
+        tot += (w * ldh[k] + 1) / 2 * 2; // 16-byte aligned starts
+      }
+    FT.alloc((size_t)tot);
+    if (tot) {
+      std::vector<long long> fo(nblk), fto(nblk);
+      std::vector<int>       hh(nblk), ww(nblk), lw(nblk), lh(nblk);
+      for (idx_t k = 0; k < nblk; ++k) {
+        fo[k]  = f_off[k];
+        fto[k] = ft_off[k];
+        ww[k]  = blk_ptr[k + 1] - blk_ptr[k];
+        hh[k]  = ww[k] + (int)(row_ptr[k + 1] - row_ptr[k]);
+        lw[k]  = ldw[k];
+        lh[k]  = ldh[k];
+      }
+      DevBuf<long long> dfo, dfto;
+      DevBuf<int>       dh, dw, dlw, dlh;
+      dfo.upload(fo, s), dfto.upload(fto, s), dh.upload(hh, s), dw.upload(ww, s), dlw.upload(lw, s), dlh.upload(lh, s);
+      hipLaunchKernelGGL(k_transpose_panels, dim3((unsigned)nblk), dim3(256), 0, s, F.p, FT.p, dfo.p, dfto.p, dh.p, dw.p, dlw.p, dlh.p);
+      HIP_OK(hipStreamSynchronize(s));
+    }
+  }
   u_off.assign(nblk, 0);
   has_src.assign(nblk, 0);
   for (idx_t k = 0; k < nblk; ++k) {
@@ -723,24 +680,18 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   std::vector<std::vector<Tile>> tl[4];
   for (auto &v : tl) v.assign(nlev, {});
   std::vector<std::vector<Tile>> gat(nlev);
-  const char *env_h = getenv("HPDDM_HIP_SUBTREE_H"), *env_g = getenv("HPDDM_HIP_PREGATHER");
-  const int   hmax      = env_h ? atoi(env_h) : -1; // -1: no subtree kernels
-  auto        envi      = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
-  fp                    = envi("HPDDM_HIP_FP", 4) == 8 ? 8 : 4;
-  cu                    = envi("HPDDM_HIP_CU", 1) == 2 ? 2 : 1;
+  // developer knobs of the plan (defaults = what measured best on the bench workloads)
+  auto envi             = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
   dbg                   = envi("HPDDM_HIP_DBG", 0);
-  persist               = envi("HPDDM_HIP_PERSIST", 0); // workgroups per CU of the persistent sweep launches (0: one workgroup per tile share)
+  persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
-  const int fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: aim at this many workgroups per level (0: fixed rule)
-  const int bwd_want    = envi("HPDDM_HIP_BWD_WANT", 768);   // wide panels, backward: split rows until a level fields this many workgroups
-  const int bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
-  const int bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 16);
-  const int FWD_PASSES  = fp;
-  const bool pregather  = env_g ? atoi(env_g) != 0 : true;
-  const int wtile       = std::max(512, envi("HPDDM_HIP_WTILE", 2048));
-  const int sort_mode   = envi("HPDDM_HIP_SORT", 1); // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
-  // entries of the wide panels per level (the forward tile area follows the level's total)
-  std::vector<long long> wide_cost(nlev, 0);
+  const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
+  const int  bwd_want    = envi("HPDDM_HIP_BWD_WANT", 768);   // wide panels, backward: split rows until a level fields this many workgroups
+  const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
+  const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 16);
+  const bool pregather   = envi("HPDDM_HIP_PREGATHER", 1) != 0;
+  const int  sort_mode   = envi("HPDDM_HIP_SORT", 1);         // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
+  std::vector<long long> wide_cost(nlev, 0);                  // entries of the wide panels per level
   if (fwd_target > 0)
     for (size_t f = 0; f < fs.size(); ++f) {
       const DeviceFactor &D = *fs[f];
@@ -750,33 +701,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
           wide_cost[D.height[k]] += w * (w + 1) / 2 + nb * w;
         }
     }
-  struct SubtreeTiles {
-    std::vector<std::vector<Tile>> k[3]; // forward wave / backward block / backward wave, per height
-    long long                      cost = 0;
-  };
-  std::vector<SubtreeTiles> subtrees;
-  sub_phases = 0;
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
-    // heights 0..hf of this factor hold narrow supernodes only: they are swept subtree by subtree
-    int hf = -1;
-    for (int l = 0; l <= hmax && l < D.nlev; ++l) {
-      bool narrow = true;
-      for (idx_t q = D.level_ptr[l]; q < D.level_ptr[l + 1] && narrow; ++q) narrow = D.ldw[D.level_blk[q]] <= NARROW;
-      if (!narrow) break;
-      hf = l;
-    }
-    sub_phases = std::max(sub_phases, hf + 1);
-    std::vector<int> st_of(D.nblk, -1);
-    for (idx_t k = D.nblk - 1; k >= 0; --k) { // parents come after their children
-      if (D.height[k] > hf) continue;
-      const idx_t pa = D.parent[k];
-      if (pa >= 0 && D.height[pa] <= hf) st_of[k] = st_of[pa];
-      else {
-        st_of[k] = (int)subtrees.size();
-        subtrees.emplace_back();
-      }
-    }
     for (idx_t k = 0; k < D.nblk; ++k) {
       SnDesc d;
       d.F     = D.F.p + D.f_off[k];
@@ -795,26 +721,19 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.ldw   = D.ldw[k];
       d.u_off = D.u_off[k];
       d.has_src = D.has_src[k] ? 1 : 0;
+      d.FT      = D.ft_off[k] >= 0 ? D.FT.p + D.ft_off[k] : nullptr;
+      d.ldh     = D.ldh[k];
       const int id = (int)descs.size();
       descs.push_back(d);
       const int h = d.w + d.nb, lev = D.height[k];
-      SubtreeTiles *st = st_of[k] >= 0 ? &subtrees[st_of[k]] : nullptr;
-      if (st)
-        for (auto &v : st->k)
-          if ((int)v.size() <= lev) v.resize(lev + 1);
       if (d.ldw <= NARROW) {
-        // forward: 16-64 KiB of panel per wavefront tile (at most WAVE_ROWS rows): every tile re-stages the right-hand side
-        // of its supernode (w gathers), so wider panels get more rows per tile
-        const int R      = 64 / (d.ldw / 2);
-        const int budget = wtile; // doubles (16 KiB by default): larger tiles measured slower (fewer wavefronts in flight)
-        int       trw    = std::max(FWD_PASSES * R, (budget / d.ldw) / (FWD_PASSES * R) * (FWD_PASSES * R));
-        trw           = std::min(trw, WAVE_ROWS);
-        std::vector<Tile> &fw = st ? st->k[0][lev] : tl[FWD_WAVE][lev];
-        for (int r0 = 0; r0 < h; r0 += trw) fw.push_back(Tile{id, r0, std::min(trw, h - r0), 0, 1, 0, 0, 0});
+        HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
+        // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
+        const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
+        for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
         const bool small = h <= WAVE_ROWS && (long long)h * d.ldw <= 4096;
-        (st ? st->k[small ? 2 : 1][lev] : tl[small ? BWD_WAVE : BWD_BLOCK][lev]).push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
-        if (st) st->cost += (long long)h * d.ldw;
+        tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         const int trb = d.w <= 960 ? 64 : (d.w <= 3968 ? 32 : 16);
@@ -896,8 +815,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       }
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
+      // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the
+      // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront
       int need = 0;
-      for (const Tile &t : tl[kd][l]) need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : 0));
+      for (const Tile &t : tl[kd][l])
+        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].w : descs[t.sn].w + descs[t.sn].nb)));
       lev_lds[kd][l] = need;
     }
   gat_ptr.assign(nlev, 0);
@@ -907,27 +829,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     all.insert(all.end(), gat[l].begin(), gat[l].end());
     gat_end[l] = (int)all.size();
     launches_per_solve += !gat[l].empty();
-  }
-  {
-    // longest subtrees first
-    std::vector<int> order(subtrees.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return subtrees[a].cost > subtrees[b2].cost; });
-    nsubtrees = (int)subtrees.size();
-    std::vector<int> sp((size_t)nsubtrees * 3 * (sub_phases + 1), 0);
-    for (int i = 0; i < nsubtrees; ++i) {
-      const SubtreeTiles &st = subtrees[order[i]];
-      for (int kd = 0; kd < 3; ++kd) {
-        int *p = sp.data() + ((size_t)i * 3 + kd) * (sub_phases + 1);
-        for (int h = 0; h < sub_phases; ++h) {
-          p[h] = (int)all.size();
-          if (h < (int)st.k[kd].size()) all.insert(all.end(), st.k[kd][h].begin(), st.k[kd][h].end());
-        }
-        p[sub_phases] = (int)all.size();
-      }
-    }
-    sub_ptr.upload(sp, s);
-    if (nsubtrees) launches_per_solve += 2;
   }
   for (int kd = 0; kd < 4; ++kd) {
     // lev_ptr[kd][l]..lev_end: store the end of each range in a parallel array (ranges of different kinds interleave)
@@ -971,48 +872,39 @@ void SolvePlan::reserve(int mu)
   mu_cap = mu;
 }
 
-template <int MU, int FP, int CU>
-static void solve_block_v(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
+template <int MU>
+static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
 {
   // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels.
-  // Dynamic LDS per launch: what the widest block-level tile of the level needs (capped), so that the levels
-  // mixing block-level and wave-level tiles keep more workgroups per CU.
-  const int lds_wave = 4 * WAVE_ROWS * MU;
-  auto      cnt      = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
-  auto      clampd   = [&](int need) { return std::max(std::max(512 * MU, lds_wave), std::min(P.lds_cap, (need + 63) / 64 * 64)); };
-  // persistent grids: at most what the 256 CUs hold at once (LDS-limited for the launches that stage in LDS)
-  auto grid = [&](int nb, int nw, int ld_dbl) {
+  // Dynamic LDS per launch: what the level needs -- the staged right-hand side of its widest block-level tile (capped) and,
+  // per wavefront, of its widest wave-level tile -- so that the small levels keep many workgroups per CU even with 8
+  // right-hand sides.  Forward, wide panels: 4 rows in flight per wavefront, 2 with 8 right-hand sides (accumulators
+  // within 128 VGPRs); backward: 4.
+  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4;
+  auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
+  auto wrows  = [&](int kd, int l) { return std::max(16, (P.lev_lds[kd][l] + 15) / 16 * 16); };
+  auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(P.lds_cap, (need + 63) / 64 * 64)); };
+  auto grid   = [&](int nb, int nw, int ld_dbl) {
     const int want = nb + (nw + 3) / 4;
     if (P.persist <= 0) return want;
     const int per_cu = std::max(1, std::min(P.persist, (int)((160 * 1024) / ((size_t)ld_dbl * sizeof(double)))));
     return std::max(1, std::min(want, 256 * per_cu));
   };
-  if (P.nsubtrees) hipLaunchKernelGGL((sptrsv_fwd_subtree_kernel<MU>), dim3(P.nsubtrees), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, P.sub_ptr.p, P.sub_phases, b, P.y.p, P.U.p, mu_total, nu0);
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
     const int ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
-    const int ld = clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU);
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FP, CU>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, ng ? 1 : 0, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FP, 1>), dim3(grid(0, nw, lds_wave)), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, lds_wave, 0, P.dbg);
+    const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
+    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU, lds_wave) : lds_wave;
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
-    const int ld = clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU);
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FP>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FP>), dim3(grid(0, nw, lds_wave)), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, lds_wave, P.dbg);
-  }
-  if (P.nsubtrees) hipLaunchKernelGGL((sptrsv_bwd_subtree_kernel<MU>), dim3(P.nsubtrees), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, P.sub_ptr.p, P.sub_phases, P.y.p, P.xw.p, mu_total, nu0, lds_wave);
-}
-template <int MU>
-static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
-{
-  if (P.fp == 8) {
-    if (P.cu == 2) solve_block_v<MU, 8, 2>(P, b, x, mu_total, nu0, s);
-    else solve_block_v<MU, 8, 1>(P, b, x, mu_total, nu0, s);
-  } else {
-    if (P.cu == 2) solve_block_v<MU, 4, 2>(P, b, x, mu_total, nu0, s);
-    else solve_block_v<MU, 4, 1>(P, b, x, mu_total, nu0, s);
+    const int wr = nw ? wrows(SolvePlan::BWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
+    const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
   }
 }
 

@@ -5,6 +5,6 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-two-level --no-gmres 2>&1 | tail -1 |
+  env $cfg timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-two-level --no-gmres $BENCH_EXTRA 2>&1 | tail -1 |
     python -c 'import sys, json; d = json.loads(sys.stdin.readline()); print("ms/apply %.3f  sptrsv %.3f ms  frac %.3f  launches %d" % (d["ms_per_step"], d["phases_ms"]["sptrsv"], d["roofline"]["frac"], d["config"]["launches_per_sptrsv"]))'
 done 2>&1 | tee -a gpurun_out/sweep.log

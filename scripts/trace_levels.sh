@@ -6,7 +6,7 @@ name=$1; shift
 out=gpurun_out/trace_$name
 rm -rf "$out" && mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-env "$@" HPDDM_HIP_LEVEL_STATS=$OLDPWD/$out/levels.txt rocprofv3 --kernel-trace -d $OLDPWD/$out -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gmres --no-two-level > $OLDPWD/$out/bench.log 2>&1
+env "$@" HPDDM_HIP_LEVEL_STATS=$OLDPWD/$out/levels.txt rocprofv3 --kernel-trace -d $OLDPWD/$out -o t -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gmres --no-two-level $BENCH_EXTRA > $OLDPWD/$out/bench.log 2>&1
 cd $OLDPWD
 db=$(find "$out" -name "*.db" | head -1)
 n=$(grep '^{"metric"' "$out/bench.log" | tail -1 | python -c 'import sys, json; print(int(json.loads(sys.stdin.readline())["config"]["launches_per_sptrsv"]) - 2)')
