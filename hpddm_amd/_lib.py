@@ -30,7 +30,9 @@ def _declare(lib):
         "HpddmHipSetDevice": (I, [I]),
         "HpddmHipSynchronize": (I, []),
         "HpddmHipSubdomainNumfact": (I, [c_void_pp, I, P, P, P, I, ctypes.c_char, I]),
+        "HpddmHipSubdomainNumfactZ": (I, [c_void_pp, I, P, P, P, I, ctypes.c_char, I]),
         "HpddmHipSubdomainSolve": (I, [P, P, P, US]),
+        "HpddmHipSubdomainSolveZ": (I, [P, P, P, US]),
         "HpddmHipSubdomainSolveDevice": (I, [P, P, P, US]),
         "HpddmHipSubdomainDestroy": (None, [P]),
         "HpddmHipSubdomainSetOption": (I, [c_void_pp, C, D]),

@@ -55,22 +55,29 @@ class Subdomain:
         return self
 
     def numfact(self, n, ia, ja, a, sym=False, numbering="C", spd=False):
-        """subdomainNumfact (interface/hpddm.py:185, HpddmSubdomainNumfact interface/HPDDM.h:88)."""
+        """subdomainNumfact (interface/hpddm.py:185, HpddmSubdomainNumfact interface/HPDDM.h:88).  A complex ``a`` takes
+        the complex128 entry point (the reference built with a complex scalar type)."""
         ia = np.ascontiguousarray(ia, dtype=np.int32)
         ja = np.ascontiguousarray(ja, dtype=np.int32)
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        check(self._lib.HpddmHipSubdomainNumfact(ctypes.byref(self._h), int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)),
-                                                 numbering.encode(), int(bool(spd))))
+        self.complex = np.iscomplexobj(a)
+        if self.complex:
+            a = np.ascontiguousarray(a, dtype=np.complex128)
+            fn = self._lib.HpddmHipSubdomainNumfactZ
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            fn = self._lib.HpddmHipSubdomainNumfact
+        check(fn(ctypes.byref(self._h), int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode(), int(bool(spd))))
         self.n = int(n)
 
     def solve(self, f, sol=None):
         """subdomainSolve (interface/hpddm.py:191): sol = A^{-1} f; f is (n,) or (n, mu) Fortran-ordered."""
-        f = _as_f(f)
+        cplx = getattr(self, "complex", False)
+        f = _as_f(f, np.complex128 if cplx else np.float64)
         mu = 1 if f.ndim == 1 else f.shape[1]
         if sol is None:
             sol = np.empty_like(f, order="F")
-        assert sol.flags.f_contiguous and sol.shape == f.shape
-        check(self._lib.HpddmHipSubdomainSolve(self._h, _dptr(f), _dptr(sol), mu))
+        assert sol.flags.f_contiguous and sol.shape == f.shape and sol.dtype == f.dtype
+        check((self._lib.HpddmHipSubdomainSolveZ if cplx else self._lib.HpddmHipSubdomainSolve)(self._h, _dptr(f), _dptr(sol), mu))
         return sol
 
     def solve_device(self, b_ptr, x_ptr, mu=1):

@@ -40,6 +40,12 @@ int HpddmHipSubdomainNumfact(HpddmHipSubdomain **S, int n, const int *ia, const 
 /* x = A^{-1} b, n right-hand sides, host pointers (Solver::solve(b, x, n), HPDDM.h:89); b == x allowed (in place) */
 int HpddmHipSubdomainSolve(HpddmHipSubdomain *S, const double *b, double *x, unsigned short n);
 /* same with device pointers, asynchronous on the library stream */
+/* complex128 scalars (the reference built with K = std::complex<double>, e.g. examples/schwarz.cpp -DFORCE_COMPLEX,
+ * binds the same two functions with complex arrays: interface/HPDDM.h:88-89, interface/hpddm_c.cpp:136-147).
+ * `a`, `b`, `x` are interleaved (re, im) pairs, i.e. std::complex<double> / double _Complex arrays; `sym` = lower
+ * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  Real-equivalent embedding on the real kernels. */
+int HpddmHipSubdomainNumfactZ(HpddmHipSubdomain **S, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int spd);
+int HpddmHipSubdomainSolveZ(HpddmHipSubdomain *S, const double *b, double *x, unsigned short n);
 int HpddmHipSubdomainSolveDevice(HpddmHipSubdomain *S, const double *b_dev, double *x_dev, unsigned short n);
 void HpddmHipSubdomainDestroy(HpddmHipSubdomain *S);
 /* Tuning knobs read at the next Numfact: "leaf_size" (dissection leaf, default 32), "keep_plain" (keep the plain

@@ -9,11 +9,12 @@
  *
  * compiles the UNCHANGED reference driver with the factorisation on the host and every Solver::solve on the GPU
  * (host vectors are staged through PCIe here; the device-resident path is HpddmHipSchwarz*).
- * K = double only in this round.
+ * K = double, and K = std::complex<double> through the real-equivalent embedding of HpddmHipSubdomainNumfactZ.
  */
 #ifndef HPDDM_HIP_SUB_HPP_
 #define HPDDM_HIP_SUB_HPP_
 
+#include <complex>
 #include <iostream>
 #include <type_traits>
 #include "hpddm_hip.h"
@@ -25,7 +26,10 @@ class Option;
 
 template <class K>
 class HipSub {
-  static_assert(std::is_same<K, double>::value, "HipSub: only K = double is built in this round");
+  static_assert(std::is_same<K, double>::value || std::is_same<K, std::complex<double>>::value, "HipSub: K = double or std::complex<double>");
+  static constexpr bool is_complex_ = !std::is_same<K, double>::value;
+  static const double *dptr(const K *p) { return reinterpret_cast<const double *>(p); } /* std::complex<double> is an (re, im) pair of doubles */
+  static double       *dptr(K *p) { return reinterpret_cast<double *>(p); }
 
 private:
   HpddmHipSubdomain *S_;
@@ -47,9 +51,11 @@ public:
     static_assert(N == 'C' || N == 'F', "Unknown numbering");
     (void)schur;
     /* Option is incomplete here (this header is force-included first): make the lookup dependent on K */
-    typedef typename std::conditional<std::is_same<K, double>::value, Option, void>::type Opt;
+    typedef typename std::conditional<std::is_same<K, K>::value, Option, void>::type Opt;
     const bool spd = Opt::get()->template val<char>("operator_spd", 0) && !detection;
-    if (HpddmHipSubdomainNumfact(&S_, A->n_, A->ia_, A->ja_, A->a_, A->sym_ ? 1 : 0, N, spd ? 1 : 0) != 0) std::cerr << "BUG HipSub, numfact: " << HpddmHipLastError() << std::endl; /* same error style as HPDDM_MUMPS.hpp:288 */
+    const int  rc  = is_complex_ ? HpddmHipSubdomainNumfactZ(&S_, A->n_, A->ia_, A->ja_, dptr(A->a_), A->sym_ ? 1 : 0, N, spd ? 1 : 0)
+                                 : HpddmHipSubdomainNumfact(&S_, A->n_, A->ia_, A->ja_, dptr(A->a_), A->sym_ ? 1 : 0, N, spd ? 1 : 0);
+    if (rc != 0) std::cerr << "BUG HipSub, numfact: " << HpddmHipLastError() << std::endl; /* same error style as HPDDM_MUMPS.hpp:288 */
   }
   template <char N = 'C'>
   int inertia(MatrixCSR<K> *const &)
@@ -60,11 +66,11 @@ public:
   /* Solver::solve, in place and out of place (include/HPDDM_MUMPS.hpp:304-317) */
   void solve(K *const x, const unsigned short &n = 1) const
   {
-    if (HpddmHipSubdomainSolve(S_, x, x, n) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
+    if ((is_complex_ ? HpddmHipSubdomainSolveZ(S_, dptr(x), dptr(x), n) : HpddmHipSubdomainSolve(S_, dptr(x), dptr(x), n)) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
   }
   void solve(const K *const b, K *const x, const unsigned short &n = 1) const
   {
-    if (HpddmHipSubdomainSolve(S_, b, x, n) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
+    if ((is_complex_ ? HpddmHipSubdomainSolveZ(S_, dptr(b), dptr(x), n) : HpddmHipSubdomainSolve(S_, dptr(b), dptr(x), n)) != 0) std::cerr << "BUG HipSub, solve: " << HpddmHipLastError() << std::endl;
   }
 };
 } // namespace HPDDM

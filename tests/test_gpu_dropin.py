@@ -53,3 +53,20 @@ def test_unchanged_single_rank_direct_solve_and_local_solver_benchmark(tmp_path)
     out = _run(1, f"{mat} -rhs=4 -solve_phase_only=1", exe="local_solver_hipsub")
     rows = [re.findall(r"\d\.\d{5}e[-+]\d{2}", ln) for ln in out.strip().splitlines() if re.match(r"^\s*\d\.\d+e[-+]\d+", ln)]
     assert len(rows) == 3 and all(len(r) == 3 for r in rows), out  # 3 trials x (nu = 1, 2, 4)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "schwarz_hipsub_z")), reason="oracle/_ref/schwarz_hipsub_z not built")
+@pytest.mark.parametrize("args,pat,its,resid", [
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40", "GMRES", 19, 1.428088e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -symmetric_csr=1", "GMRES", 19, None),
+])
+def test_unchanged_schwarz_cpp_complex_scalars(args, pat, its, resid):
+    """K = std::complex<double> (examples/schwarz.hpp -DFORCE_COMPLEX): HipSub<std::complex<double>> behind the unchanged
+    driver; the complex LAPACK build of the reference (oracle/_ref/schwarz_cpp_z) gives 19 iterations, 1.428088e-05"""
+    out = _run(4, args, exe="schwarz_hipsub_z")
+    m = re.search(pat + r" converges after (\d+) iteration", out)
+    assert m and int(m.group(1)) == its, out[-1500:]
+    r = re.search(r"--- residual = (\S+) / (\S+)", out)
+    assert r and float(r.group(1)) / float(r.group(2)) <= 1e-6
+    if resid:
+        assert abs(float(r.group(1)) - resid) <= 5e-4 * resid, out[-500:]
