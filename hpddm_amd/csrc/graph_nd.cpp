@@ -28,6 +28,8 @@ struct NDWork {
   std::vector<idx_t> perm;    // output: perm[new] = old
   std::vector<idx_t> blk_ptr; // output
   idx_t              next_region = 1;
+  idx_t              merge       = 0;       // separators inside a piece of at most this many vertices are merged into one block
+  std::vector<idx_t> *sink       = nullptr; // where those separators are collected while such a piece is dissected
   idx_t              next_num    = 0;
   explicit NDWork(const Graph &gr, int lf) : g(gr), leaf(lf), label(gr.n, 0), level(gr.n, -1), queue(gr.n) { perm.reserve(gr.n); blk_ptr.push_back(0); }
 
@@ -73,6 +75,26 @@ struct NDWork {
   {
     const idx_t nv = (idx_t)verts.size();
     if (nv == 0) return;
+    // bottom of the tree: the tiny separators of a small piece (a few levels of 5-30 vertices each) become ONE trailing
+    // block -- fewer levels in the level schedule and fewer tiny supernodes, for a little more fill in that block
+    std::vector<idx_t> local_sink;
+    bool               owner = false;
+    if (!sink && merge > 0 && nv <= merge && nv > leaf) {
+      sink  = &local_sink;
+      owner = true;
+    }
+    struct Flush {
+      NDWork &w;
+      bool    owner;
+      std::vector<idx_t> &ls;
+      ~Flush()
+      {
+        if (owner) {
+          w.sink = nullptr;
+          if (!ls.empty()) w.emit_block(ls.data(), (idx_t)ls.size());
+        }
+      }
+    } flush{*this, owner, local_sink};
     if (nv <= leaf) {
       // leaf: one block, BFS order component by component (keeps the in-block profile small)
       std::vector<idx_t> order;
@@ -217,7 +239,8 @@ struct NDWork {
         order.insert(order.end(), queue.begin(), queue.begin() + c);
       }
       for (idx_t v : order) level[v] = -1;
-      emit_block(order.data(), (idx_t)order.size());
+      if (sink) sink->insert(sink->end(), order.begin(), order.end());
+      else emit_block(order.data(), (idx_t)order.size());
     }
   }
 };
@@ -227,6 +250,7 @@ struct NDWork {
 static void nested_dissection_plain(const Graph &g, int leaf_size, Ordering &ord)
 {
   NDWork w(g, std::max(1, leaf_size));
+  if (const char *e = getenv("HPDDM_HIP_ND_MERGE")) w.merge = atoi(e);
   std::vector<idx_t> all(g.n);
   for (idx_t i = 0; i < g.n; ++i) all[i] = i;
   w.dissect(all, 0);
