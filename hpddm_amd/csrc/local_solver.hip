@@ -51,35 +51,40 @@ static bool is_symmetric(const CsrView &A)
 // factorisation of a mid-size subdomain.
 static std::vector<double> g_spare_panels;
 
-void LocalSolver::numfact(const CsrView &A, int spd)
+void LocalSolver::analyse(const CsrView &A)
 {
   const size_t h = hash_pattern(A);
-  if (!analysed || h != pattern_hash) {
-    factor_analyse(A, leaf_size, host);
-    pattern_hash = h;
-    analysed     = true;
-    if (const char *path = getenv("HPDDM_HIP_LEVEL_STATS")) {
-      // developer aid: per-level panel sizes of the level schedule (scripts/level_stats.py)
-      if (FILE *fp = fopen(path, "a")) {
-        const idx_t nl = (idx_t)host.level_ptr.size() - 1;
-        for (idx_t l = 0; l < nl; ++l) {
-          long long dbl = 0, narrow = 0, wmin = 1 << 30, wmax = 0, hsum = 0, rd = 0;
-          for (idx_t q = host.level_ptr[l]; q < host.level_ptr[l + 1]; ++q) {
-            const idx_t     k = host.level_blk[q];
-            const long long w = host.sym.blk_ptr[k + 1] - host.sym.blk_ptr[k], nb = host.sym.row_ptr[k + 1] - host.sym.row_ptr[k];
-            dbl += (w + nb) * host.ldw[k];
-            rd += w * (w + 1) / 2 + nb * w;
-            hsum += w + nb;
-            narrow += host.ldw[k] <= 128;
-            wmin = std::min(wmin, w);
-            wmax = std::max(wmax, w);
-          }
-          fprintf(fp, "%d %d %lld %lld %lld %lld %lld %lld\n", (int)l, (int)(host.level_ptr[l + 1] - host.level_ptr[l]), narrow, wmin, wmax, hsum, dbl, rd);
+  if (analysed && h == pattern_hash) return;
+  factor_analyse(A, leaf_size, host);
+  pattern_hash = h;
+  analysed     = true;
+  if (const char *path = getenv("HPDDM_HIP_LEVEL_STATS")) {
+    // developer aid: per-level panel sizes of the level schedule (scripts/prof_levels.py, scripts/pmc_levels.py)
+#pragma omp critical(hpddm_hip_level_stats)
+    if (FILE *fp = fopen(path, "a")) {
+      const idx_t nl = (idx_t)host.level_ptr.size() - 1;
+      for (idx_t l = 0; l < nl; ++l) {
+        long long dbl = 0, narrow = 0, wmin = 1 << 30, wmax = 0, hsum = 0, rd = 0;
+        for (idx_t q = host.level_ptr[l]; q < host.level_ptr[l + 1]; ++q) {
+          const idx_t     k = host.level_blk[q];
+          const long long w = host.sym.blk_ptr[k + 1] - host.sym.blk_ptr[k], nb = host.sym.row_ptr[k + 1] - host.sym.row_ptr[k];
+          dbl += (w + nb) * host.ldw[k];
+          rd += w * (w + 1) / 2 + nb * w;
+          hsum += w + nb;
+          narrow += host.ldw[k] <= 128;
+          wmin = std::min(wmin, w);
+          wmax = std::max(wmax, w);
         }
-        fclose(fp);
+        fprintf(fp, "%d %d %lld %lld %lld %lld %lld %lld\n", (int)l, (int)(host.level_ptr[l + 1] - host.level_ptr[l]), narrow, wmin, wmax, hsum, dbl, rd);
       }
+      fclose(fp);
     }
   }
+}
+
+void LocalSolver::numfact(const CsrView &A, int spd)
+{
+  analyse(A);
   FactKind kind;
   if (A.sym || is_symmetric(A)) kind = spd ? FACT_CHOL : FACT_LDLT;
   else kind = FACT_LU;
