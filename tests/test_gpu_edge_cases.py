@@ -1,0 +1,158 @@
+"""Edge cases of the boundary: tiny and ragged inputs, error behaviour, refactorisation on the same pattern, wide panels
+in the LDL^T / LU kinds (host factorisation, device sweeps), many right-hand sides through the Schwarz layer."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from hpddm_amd import hpddm
+from hpddm_amd._lib import HpddmHipError
+from hpddm_amd.generate import generate2d, generate3d
+from oracle.ras_oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _lap(N):
+    I = sp.identity(N)
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    return (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
+
+
+def test_one_by_one_diagonal_and_disconnected_matrices():
+    rng = np.random.default_rng(0)
+    for M in (sp.csr_matrix(np.array([[4.0]])), sp.diags(1.0 + rng.random(37)).tocsr(),
+              sp.block_diag([_lap(3), sp.identity(2) * 3.0, _lap(2)]).tocsr()):
+        n = M.shape[0]
+        M.sort_indices()
+        S = hpddm.Subdomain()
+        S.numfact(n, M.indptr, M.indices, M.data, sym=False)
+        b = np.asfortranarray(rng.random((n, 3)))
+        x = S.solve(b)
+        assert np.abs(M @ x - b).max() < 1e-12
+        S.destroy()
+
+
+def test_zero_pivot_is_reported_not_hidden():
+    M = sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 0.0]]))  # needs pivoting: the pivot-free factorisation must refuse it
+    S = hpddm.Subdomain()
+    with pytest.raises(HpddmHipError, match="pivot"):
+        S.numfact(2, M.indptr, M.indices, M.data, sym=False)
+    S.destroy()
+
+
+def test_malformed_input_is_rejected():
+    S = hpddm.Subdomain()
+    with pytest.raises(HpddmHipError):
+        S.numfact(2, np.array([0, 1, 2], dtype=np.int32), np.array([0, 5], dtype=np.int32), np.array([1.0, 1.0]))  # column out of range
+    with pytest.raises(HpddmHipError):
+        hpddm.Subdomain().solve(np.ones(3))  # solve before numfact
+    S.destroy()
+
+
+def test_refactorisation_same_pattern_new_values():
+    """Solver::numfact called again on the same object (MUMPS job=2, include/HPDDM_MUMPS.hpp:280-286)"""
+    A = _lap(8)
+    n = A.shape[0]
+    L = sp.tril(A).tocsr()
+    L.sort_indices()
+    S = hpddm.Subdomain()
+    rng = np.random.default_rng(1)
+    b = rng.random(n)
+    for scale in (1.0, 3.5, 0.25):
+        S.numfact(n, L.indptr, L.indices, L.data * scale, sym=True, spd=True)
+        x = S.solve(b)
+        assert np.abs(scale * (A @ x) - b).max() < 1e-11 * np.abs(b).max()
+    info = S.info()
+    assert info["n"] == n
+    S.destroy()
+
+
+@pytest.mark.parametrize("kind", ["ldlt", "lu"])
+def test_wide_panels_in_the_host_factorised_kinds(kind):
+    """22^3: top separator 484 wide (block-level tiles, split-row backward tiles) with the LDL^T and LU kinds"""
+    A = _lap(22)
+    n = A.shape[0]
+    rng = np.random.default_rng(2)
+    if kind == "ldlt":
+        M = (A - 0.9 * sp.identity(n)).tocsr()   # symmetric indefinite
+        Min = sp.tril(M).tocsr()
+        sym = True
+    else:
+        M = (A + 0.2 * sp.triu(A, 1) + sp.diags(rng.random(n))).tocsr()   # unsymmetric values, symmetric pattern
+        Min = M
+        sym = False
+    Min.sort_indices()
+    S = hpddm.Subdomain()
+    S.numfact(n, Min.indptr, Min.indices, Min.data, sym=sym)
+    assert S.info()["kind"] == (1 if kind == "ldlt" else 2)
+    b = np.asfortranarray(rng.random((n, 5)))
+    x = S.solve(b)
+    ref = spl.splu(sp.csc_matrix(M)).solve(b)
+    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    S.destroy()
+
+
+def test_structurally_unsymmetric_matrix():
+    """pattern of A + A^T is used for the analysis; entries missing on one side are zeros"""
+    rng = np.random.default_rng(5)
+    A = _lap(7).tolil()
+    n = A.shape[0]
+    for _ in range(40):
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+            A[i, j] = 0.05 * rng.random()
+    M = (A.tocsr() + 6.0 * sp.identity(n)).tocsr()
+    M.eliminate_zeros()
+    M.sort_indices()
+    S = hpddm.Subdomain()
+    S.numfact(n, M.indptr, M.indices, M.data, sym=False)
+    b = rng.random(n)
+    x = S.solve(b)
+    assert np.abs(M @ x - b).max() < 1e-11
+    S.destroy()
+
+
+def test_schwarz_with_many_right_hand_sides_and_single_subdomain():
+    # one subdomain, no neighbour: apply = direct solve; 11 right-hand sides = blocks of 8 + 2 + 1
+    sub = generate2d(24, 24, 1)
+    A, d = hpddm.schwarz_from_subdomains(sub)
+    A.call_numfact()
+    rng = np.random.default_rng(3)
+    f = [rng.random((sub[0]["n"], 11))]
+    x = A.apply(f)
+    M = sp.csr_matrix((sub[0]["a"], sub[0]["ja"], sub[0]["ia"]), shape=(sub[0]["n"],) * 2)
+    assert np.abs(M @ x[0] - f[0]).max() < 1e-10 * np.abs(f[0]).max()
+    A.destroy()
+    # 8 subdomains, 11 right-hand sides, against the oracle
+    subs = generate3d(10, 8, 1, sym=True)
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    orc = Oracle(subs)
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    A.call_numfact()
+    orc.numfact()
+    xs = [rng.random((s["n"], 11)) for s in subs]
+    got, ref = A.apply(xs), orc.apply(xs)
+    assert max(np.abs(g - r).max() for g, r in zip(got, ref)) < 1e-10 * max(np.abs(r).max() for r in ref)
+    A.destroy()
+
+
+def test_ragged_partition_with_empty_connectivity_entries():
+    """neighbour entries with an empty shared-dof list are dropped like Subdomain::initialize does (include/HPDDM_subdomain.hpp:238-259)"""
+    subs = generate3d(9, 4, 1, sym=True)
+    other = [q for q in range(4) if q != 0 and q not in list(subs[0]["neighbors"])]
+    for sd in subs:   # add a fake neighbour with no shared dof to every subdomain
+        sd["neighbors"] = np.append(sd["neighbors"], np.int32(other[0] if other and sd is subs[0] else 0 if sd is not subs[0] and 0 not in list(sd["neighbors"]) else sd["neighbors"][0]))
+        sd["connectivity"] = list(sd["connectivity"]) + [np.zeros(0, dtype=np.int32)]
+    # duplicates of an existing neighbour with an empty list must also be harmless
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    clean = generate3d(9, 4, 1, sym=True)
+    orc = Oracle(clean)
+    orc.multiplicity_scaling([s["d"] for s in clean])
+    A.call_numfact()
+    orc.numfact()
+    rng = np.random.default_rng(8)
+    x = [rng.random(s["n"]) for s in clean]
+    got, ref = A.apply(x), orc.apply(x)
+    assert max(np.abs(g - r).max() for g, r in zip(got, ref)) < 1e-10 * max(np.abs(r).max() for r in ref)
+    A.destroy()
