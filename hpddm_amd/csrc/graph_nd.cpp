@@ -14,9 +14,11 @@
 // Numbering is children-first (both halves, then the separator), so blocks come out in a topological order.
 #include "common.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace hpddm_hip {
+void multilevel_bisect(const Graph &g, const std::vector<idx_t> &verts, std::vector<idx_t> &loc, double balance, std::vector<char> &side); // graph_ml.cpp
 namespace {
 
 struct NDWork {
@@ -30,6 +32,9 @@ struct NDWork {
   idx_t              next_region = 1;
   idx_t              merge       = 0;       // separators inside a piece of at most this many vertices are merged into one block
   std::vector<idx_t> *sink       = nullptr; // where those separators are collected while such a piece is dissected
+  idx_t              ml_min      = 0;       // pieces of at least this many vertices also try a multilevel bisection (0: never)
+  std::vector<idx_t> loc;                   // scratch of the multilevel bisection (-1 everywhere between calls)
+  bool               dense_stencil = false; // more than 8 neighbours per vertex on average
   idx_t              next_num    = 0;
   explicit NDWork(const Graph &gr, int lf) : g(gr), leaf(lf), label(gr.n, 0), level(gr.n, -1), queue(gr.n) { perm.reserve(gr.n); blk_ptr.push_back(0); }
 
@@ -225,6 +230,83 @@ struct NDWork {
       }
       sep.swap(keep);
     }
+    // --- second candidate: multilevel edge bisection + greedy cover of the cut (graph_ml.cpp).  Level sets are nearly
+    // optimal on 7-point grids but 1.5-1.9x too large on 27-point / finite-element graphs; keep the smaller separator ---
+    // (always on graphs with more than 8 neighbours per vertex on average -- finite elements, 27-point stencils --,
+    // otherwise only when the level set is visibly larger than a plane through a cube of nv vertices would be)
+    if (ml_min > 0 && nv >= ml_min && (dense_stencil || (double)sep.size() > 1.1 * std::pow((double)nv, 2.0 / 3.0))) {
+      std::vector<idx_t> all;
+      all.reserve(nv);
+      all.insert(all.end(), p1.begin(), p1.end());
+      all.insert(all.end(), p2.begin(), p2.end());
+      all.insert(all.end(), sep.begin(), sep.end());
+      if (loc.empty()) loc.assign(g.n, -1);
+      std::vector<char> side;
+      multilevel_bisect(g, all, loc, 0.56, side);
+      // vertex cover of the cut edges, greedily by the number of still uncovered cut edges
+      const idx_t na = (idx_t)all.size();
+      for (idx_t i = 0; i < na; ++i) loc[all[i]] = i;
+      std::vector<idx_t> unc(na, 0);
+      std::vector<char>  insep(na, 0);
+      for (idx_t i = 0; i < na; ++i)
+        for (idx_t p = g.xadj[all[i]]; p < g.xadj[all[i] + 1]; ++p) {
+          const idx_t j = loc[g.adjncy[p]];
+          if (j >= 0 && side[j] != side[i]) ++unc[i];
+        }
+      std::vector<std::pair<idx_t, idx_t>> heap; // (uncovered edges, vertex), lazy
+      for (idx_t i = 0; i < na; ++i)
+        if (unc[i] > 0) heap.emplace_back(unc[i], i);
+      std::make_heap(heap.begin(), heap.end());
+      idx_t nsep = 0;
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end());
+        const auto top = heap.back();
+        heap.pop_back();
+        const idx_t i = top.second;
+        if (insep[i] || top.first != unc[i] || unc[i] == 0) continue;
+        insep[i] = 1;
+        ++nsep;
+        for (idx_t p = g.xadj[all[i]]; p < g.xadj[all[i] + 1]; ++p) {
+          const idx_t j = loc[g.adjncy[p]];
+          if (j >= 0 && side[j] != side[i] && !insep[j] && unc[j] > 0) {
+            --unc[j];
+            if (unc[j] > 0) {
+              heap.emplace_back(unc[j], j);
+              std::push_heap(heap.begin(), heap.end());
+            }
+          }
+        }
+        unc[i] = 0;
+      }
+      idx_t n0 = 0, n1 = 0;
+      for (idx_t i = 0; i < na; ++i)
+        if (!insep[i]) (side[i] ? n1 : n0) += 1;
+      auto cost = [](idx_t s, idx_t a, idx_t b) {
+        const double bal = (double)std::max(a, b) / (double)std::max<idx_t>(1, std::min(a, b));
+        return (double)s * (bal <= 1.5 ? 1.0 : bal / 1.5 * bal / 1.5);
+      };
+      if (getenv("HPDDM_HIP_VERBOSE") && nv > 1000) fprintf(stderr, "nd: piece %d  level-set sep %d (%d|%d)  multilevel sep %d (%d|%d)\n", (int)nv, (int)sep.size(), (int)p1.size(), (int)p2.size(), (int)nsep, (int)n0, (int)n1);
+      const bool take = n0 > 0 && n1 > 0 && cost(nsep, n0, n1) < 0.95 * cost((idx_t)sep.size(), (idx_t)p1.size(), (idx_t)p2.size());
+      if (take) {
+        p1.clear();
+        p2.clear();
+        sep.clear();
+        for (idx_t i = 0; i < na; ++i) {
+          const idx_t v = all[i];
+          if (insep[i]) {
+            label[v] = reg;
+            sep.push_back(v);
+          } else if (side[i] == 0) {
+            label[v] = r1;
+            p1.push_back(v);
+          } else {
+            label[v] = r2;
+            p2.push_back(v);
+          }
+        }
+      }
+      for (idx_t i = 0; i < na; ++i) loc[all[i]] = -1;
+    }
     std::vector<idx_t>().swap(verts);
     dissect(p1, r1);
     dissect(p2, r2);
@@ -251,6 +333,9 @@ static void nested_dissection_plain(const Graph &g, int leaf_size, Ordering &ord
 {
   NDWork w(g, std::max(1, leaf_size));
   if (const char *e = getenv("HPDDM_HIP_ND_MERGE")) w.merge = atoi(e);
+  w.ml_min        = 60;
+  w.dense_stencil = g.n > 0 && (double)g.adjncy.size() > 8.0 * (double)g.n;
+  if (const char *e = getenv("HPDDM_HIP_ND_ML")) w.ml_min = atoi(e);
   std::vector<idx_t> all(g.n);
   for (idx_t i = 0; i < g.n; ++i) all[i] = i;
   w.dissect(all, 0);
