@@ -112,6 +112,99 @@ void gram(int n, int m, const double *X, const double *Y, std::vector<double> &G
     }
 }
 
+
+// ---- device-side block operations of the eigensolver: tall-skinny blocks n x k, column-major, leading dimension n ----
+constexpr int GE_ROWS = 1024; // rows of a block handled by one workgroup of k_tn
+
+// Y = B X for a CSR matrix (most rows of B are empty: it lives on the overlap)
+__global__ void k_ge_spmm(int n, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ X, double *__restrict__ Y, int cols)
+{
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    double acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int p = ia[r]; p < ia[r + 1]; ++p) {
+      const int    c = ja[p];
+      const double v = a[p];
+      for (int j = 0; j < cols; ++j) acc[j] = fma(v, X[(size_t)j * n + c], acc[j]);
+    }
+    for (int j = 0; j < cols; ++j) Y[(size_t)j * n + r] = acc[j];
+  }
+}
+// partial[chunk][i][8] = sum over the chunk's rows of A(:, i) * Bm(:, j), j < cb <= 8; fixed summation order
+__global__ __launch_bounds__(256) void k_ge_tn(int n, const double *__restrict__ A, int ra, const double *__restrict__ Bm, int cb, double *__restrict__ partial)
+{
+  extern __shared__ double bs[]; // [cb][GE_ROWS]
+  const int r0 = blockIdx.x * GE_ROWS, rows = min(GE_ROWS, n - r0);
+  for (int idx = threadIdx.x; idx < cb * GE_ROWS; idx += 256) {
+    const int j = idx / GE_ROWS, r = idx - j * GE_ROWS;
+    bs[idx]     = r < rows ? Bm[(size_t)j * n + r0 + r] : 0.0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wave; i < ra; i += 4) {
+    double acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    const double *col = A + (size_t)i * n + r0;
+    for (int rr = lane; rr < rows; rr += 64) {
+      const double av = col[rr];
+      for (int j = 0; j < cb; ++j) acc[j] = fma(av, bs[j * GE_ROWS + rr], acc[j]);
+    }
+    for (int j = 0; j < cb; ++j) {
+      double v = acc[j];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) partial[((size_t)blockIdx.x * ra + i) * 8 + j] = v;
+    }
+  }
+}
+__global__ void k_ge_tn_reduce(int chunks, int ra, int cb, const double *__restrict__ partial, double *__restrict__ C)
+{
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ra * cb) return;
+  const int i = o / cb, j = o - i * cb;
+  double    acc = 0.0;
+  for (int c = 0; c < chunks; ++c) acc += partial[((size_t)c * ra + i) * 8 + j];
+  C[o] = acc;
+}
+// Out(:, j) = beta * Y(:, j) + alpha * sum_i A(:, i) S(i, j),  j < cb <= 8, S row-major ra x cb (Out may alias Y)
+__global__ __launch_bounds__(256) void k_ge_mul(int n, const double *__restrict__ A, int ra, const double *__restrict__ S, int cb, double alpha, double beta, const double *Y, double *Out)
+{
+  extern __shared__ double ss[]; // ra * cb
+  for (int idx = threadIdx.x; idx < ra * cb; idx += 256) ss[idx] = S[idx];
+  __syncthreads();
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    double acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int i = 0; i < ra; ++i) {
+      const double av = A[(size_t)i * n + r];
+      for (int j = 0; j < cb; ++j) acc[j] = fma(av, ss[i * cb + j], acc[j]);
+    }
+    for (int j = 0; j < cb; ++j) Out[(size_t)j * n + r] = (beta != 0.0 ? beta * Y[(size_t)j * n + r] : 0.0) + alpha * acc[j];
+  }
+}
+// per column c < cols:  out[2c] = sum (WX - th_c X)^2 ,  out[2c+1] = sum (th_c X)^2   (one workgroup per column, fixed order)
+__global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restrict__ WX, const double *__restrict__ X, const double *__restrict__ th, double *__restrict__ out)
+{
+  __shared__ double red[2][256];
+  const int    c = blockIdx.x;
+  const double t = th[c];
+  double       rr = 0.0, xx = 0.0;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double x = X[(size_t)c * n + r], res = WX[(size_t)c * n + r] - t * x;
+    rr += res * res;
+    xx += t * x * t * x;
+  }
+  red[0][threadIdx.x] = rr;
+  red[1][threadIdx.x] = xx;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[2 * c] = red[0][0], out[2 * c + 1] = red[1][0];
+}
 } // namespace
 
 void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base)
@@ -164,6 +257,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   shifted.release_host = true;
   {
     CsrView V{n, sia.data(), sja.data(), sa.data(), true, 0};
+    shifted.adopt_analysis(*S.ls, V); // the Neumann matrix usually has the pattern of the subdomain matrix: reuse its ordering + symbolic factorisation
     shifted.numfact(V, 1);
   }
   // ---- block Krylov subspace of OP = (A_N + sigma B)^{-1} B with full B-reorthogonalisation, Rayleigh-Ritz on it ----
@@ -171,50 +265,46 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   const int    p      = std::min(8, n);
   const int    kmax   = std::min(n, (int)getopt("geneo_max_basis", 320));
   const double tol    = getopt("eigensolver_tol", 1.0e-6); // same key and default as the reference (include/HPDDM_eigensolver.hpp)
-  std::vector<double> Q, BQ, W, lam;   // n x dim, column-major, grown block by block
+  std::vector<double> lam;
   std::vector<double> T;               // dim x dim (row-major, ld kmax), T = Q^T B OP Q
   T.assign((size_t)kmax * kmax, 0.0);
-  hipStream_t    st = library_stream();
-  DevBuf<double> xd;
-  xd.alloc((size_t)n * p);
-  auto solve_block = [&](const double *rhs, double *out, int cols) { // out = (A_N + sigma B)^{-1} rhs
-    HIP_OK(hipMemcpyAsync(xd.p, rhs, sizeof(double) * n * cols, hipMemcpyHostToDevice, st));
-    shifted.plan.solve(xd.p, xd.p, cols, st);
-    HIP_OK(hipMemcpyAsync(out, xd.p, sizeof(double) * n * cols, hipMemcpyDeviceToHost, st));
+  hipStream_t st = library_stream();
+  // everything n-sized stays on the device: the basis Q, B Q, W = OP Q (n x kmax each) and the working blocks
+  const size_t   nn = (size_t)n;
+  DevBuf<double> Qd, BQd, Wd, Vd, BVd, T1d, T2d, Cd, Pd, Xd, small_d;
+  DevBuf<int>    bia_d, bja_d;
+  DevBuf<double> ba_d;
+  Qd.alloc(nn * kmax), BQd.alloc(nn * kmax), Wd.alloc(nn * kmax);
+  Vd.alloc(nn * p), BVd.alloc(nn * p), T1d.alloc(nn * p), T2d.alloc(nn * p);
+  const int chunks = (n + GE_ROWS - 1) / GE_ROWS;
+  Pd.alloc((size_t)chunks * kmax * 8);
+  Cd.alloc((size_t)kmax * 8);
+  small_d.alloc((size_t)kmax * 8 + 64);
+  bia_d.upload(B.ia, st), bja_d.upload(B.ja.empty() ? std::vector<int>(1, 0) : B.ja, st), ba_d.upload(B.a.empty() ? std::vector<double>(1, 0.0) : B.a, st);
+  HIP_OK(hipStreamSynchronize(st));
+  const dim3 grow((unsigned)std::min(4096, (n + 255) / 256));
+  auto       bmult = [&](const double *X, double *Y, int cols) { hipLaunchKernelGGL(k_ge_spmm, grow, dim3(256), 0, st, n, bia_d.p, bja_d.p, ba_d.p, X, Y, cols); };
+  // C(ra x cb, row-major, host) = A^T Bm
+  auto tn = [&](const double *Ad, int ra, const double *Bd, int cb, std::vector<double> &C) {
+    C.assign((size_t)ra * cb, 0.0);
+    hipLaunchKernelGGL(k_ge_tn, dim3((unsigned)chunks), dim3(256), (size_t)cb * GE_ROWS * sizeof(double), st, n, Ad, ra, Bd, cb, Pd.p);
+    hipLaunchKernelGGL(k_ge_tn_reduce, dim3((unsigned)((ra * cb + 255) / 256)), dim3(256), 0, st, chunks, ra, cb, Pd.p, Cd.p);
+    HIP_OK(hipMemcpyAsync(C.data(), Cd.p, sizeof(double) * ra * cb, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
   };
-  // C(rowsA x colsB) = A^T B for n x rowsA, n x colsB column-major blocks
-  auto tn = [&](const double *Ab, int ra, const double *Bb, int cb, std::vector<double> &C) {
-    C.assign((size_t)ra * cb, 0.0);
-#pragma omp parallel for schedule(static) collapse(2)
-    for (int i = 0; i < ra; ++i)
-      for (int j = 0; j < cb; ++j) {
-        double        acc = 0.0;
-        const double *x = Ab + (size_t)i * n, *y = Bb + (size_t)j * n;
-        for (int r = 0; r < n; ++r) acc += x[r] * y[r];
-        C[(size_t)i * cb + j] = acc;
-      }
+  // Out = beta * Y + alpha * A S   (S: ra x cb row-major on the host, cb <= 8)
+  auto mul = [&](const double *Ad, int ra, const std::vector<double> &S, int cb, double alpha, double beta, const double *Yd, double *Outd) {
+    HIP_OK(hipMemcpyAsync(small_d.p, S.data(), sizeof(double) * ra * cb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_ge_mul, grow, dim3(256), (size_t)ra * cb * sizeof(double), st, n, Ad, ra, small_d.p, cb, alpha, beta, Yd, Outd);
+    HIP_OK(hipStreamSynchronize(st)); // S may be a temporary
   };
-  // Y(n x cb) -= A(n x ra) * C(ra x cb)
-  auto sub = [&](double *Y, int cb, const double *Ab, int ra, const std::vector<double> &C) {
-#pragma omp parallel for schedule(static)
-    for (int r = 0; r < n; ++r)
-      for (int j = 0; j < cb; ++j) {
-        double acc = 0.0;
-        for (int i = 0; i < ra; ++i) acc += Ab[(size_t)i * n + r] * C[(size_t)i * cb + j];
-        Y[(size_t)j * n + r] -= acc;
-      }
-  };
-  // B-orthonormalise the columns of R (n x cols) in place (Cholesky of the B-Gram matrix, rank-revealing by dropping);
-  // BR receives B R; returns the number of columns kept
-  auto b_orth = [&](std::vector<double> &R, std::vector<double> &BR, int cols) {
+  // B-orthonormalise the cols columns of Rd in place (Cholesky of the B-Gram matrix, rank-revealing by dropping); BRd
+  // receives B R; returns the number of columns kept
+  auto b_orth = [&](double *Rd, double *BRd, int cols) {
     for (int pass = 0; pass < 2; ++pass) {
-      BR.resize((size_t)n * cols);
-      B.mult(R.data(), BR.data(), cols);
+      bmult(Rd, BRd, cols);
       std::vector<double> Gm;
-      tn(R.data(), cols, BR.data(), cols, Gm);
-      // modified Gram-Schmidt on the Gram matrix = Cholesky; columns with a tiny pivot are dropped
-      std::vector<double> U((size_t)cols * cols, 0.0); // R_new = R * U, U upper triangular
+      tn(Rd, cols, BRd, cols, Gm);
       std::vector<int>    kept;
       std::vector<double> L((size_t)cols * cols, 0.0);
       for (int j = 0; j < cols; ++j) {
@@ -230,48 +320,57 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
         }
         kept.push_back(j);
       }
-      // forward-substitute to orthonormalise: q_j = (r_j - sum_{k<j kept} L_jk q_k) / L_jj
-      std::vector<double> Rn((size_t)n * kept.size());
-#pragma omp parallel for schedule(static)
-      for (int r = 0; r < n; ++r)
-        for (size_t a2 = 0; a2 < kept.size(); ++a2) {
-          const int j = kept[a2];
-          double    v = R[(size_t)j * n + r];
-          for (size_t b2 = 0; b2 < a2; ++b2) v -= L[(size_t)j * cols + kept[b2]] * Rn[b2 * n + r];
-          Rn[a2 * n + r] = v / L[(size_t)j * cols + j];
+      const int nk = (int)kept.size();
+      if (nk == 0) return 0;
+      // R_new = R U with U = inverse transpose of the kept Cholesky factor: q_a = (r_{k_a} - sum_{b<a} L[k_a][k_b] q_b) / L[k_a][k_a]
+      std::vector<double> Lk((size_t)nk * nk, 0.0), U((size_t)cols * nk, 0.0); // Lk lower triangular nk x nk; U: cols x nk
+      for (int a2 = 0; a2 < nk; ++a2)
+        for (int b2 = 0; b2 <= a2; ++b2) Lk[(size_t)a2 * nk + b2] = L[(size_t)kept[a2] * cols + kept[b2]];
+      // columns of Lk^{-T}: solve Lk^T u = e  <=>  Q = R_kept Lk^{-T}
+      std::vector<double> Linv((size_t)nk * nk, 0.0); // Lk^{-1}, lower triangular
+      for (int c = 0; c < nk; ++c) {
+        Linv[(size_t)c * nk + c] = 1.0 / Lk[(size_t)c * nk + c];
+        for (int r = c + 1; r < nk; ++r) {
+          double v = 0.0;
+          for (int k = c; k < r; ++k) v -= Lk[(size_t)r * nk + k] * Linv[(size_t)k * nk + c];
+          Linv[(size_t)r * nk + c] = v / Lk[(size_t)r * nk + r];
         }
-      R.swap(Rn);
-      cols = (int)kept.size();
-      if (cols == 0) break;
+      }
+      for (int a2 = 0; a2 < nk; ++a2)       // q_a = sum_b Linv[a][b] r_{k_b}
+        for (int b2 = 0; b2 <= a2; ++b2) U[(size_t)kept[b2] * nk + a2] = Linv[(size_t)a2 * nk + b2];
+      mul(Rd, cols, U, nk, 1.0, 0.0, nullptr, T2d.p);
+      HIP_OK(hipMemcpyAsync(Rd, T2d.p, sizeof(double) * nn * nk, hipMemcpyDeviceToDevice, st));
+      cols = nk;
     }
-    BR.resize((size_t)n * cols);
-    if (cols) B.mult(R.data(), BR.data(), cols);
+    bmult(Rd, BRd, cols);
     return cols;
   };
   // start block: OP applied to a random block (lands in the range of OP, where B is definite)
   std::mt19937                           gen(12345 + 31 * (first + s));
   std::uniform_real_distribution<double> dis(-1.0, 1.0);
-  std::vector<double>                    V((size_t)n * p), BV, tmpb((size_t)n * p);
-  for (auto &v : V) v = dis(gen);
-  B.mult(V.data(), tmpb.data(), p);
-  solve_block(tmpb.data(), V.data(), p);
-  int cur = b_orth(V, BV, p);
+  {
+    std::vector<double> V0(nn * p);
+    for (auto &v : V0) v = dis(gen);
+    HIP_OK(hipMemcpyAsync(Vd.p, V0.data(), sizeof(double) * nn * p, hipMemcpyHostToDevice, st));
+    bmult(Vd.p, T1d.p, p);
+    shifted.plan.solve(T1d.p, Vd.p, p, st);
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  int cur = b_orth(Vd.p, BVd.p, p);
   HH_CHECK(cur > 0, "SolveGEVP: B vanishes on this subdomain (no overlap?)");
-  int dim = 0, it = 0;
-  std::vector<double> Xritz;
+  int dim = 0, it = 0, nritz = 0;
   bool converged = false;
   while (cur > 0 && dim + cur <= kmax) {
     // append the block
-    Q.insert(Q.end(), V.begin(), V.begin() + (size_t)n * cur);
-    BQ.insert(BQ.end(), BV.begin(), BV.begin() + (size_t)n * cur);
     const int j0 = dim;
+    HIP_OK(hipMemcpyAsync(Qd.p + nn * j0, Vd.p, sizeof(double) * nn * cur, hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(BQd.p + nn * j0, BVd.p, sizeof(double) * nn * cur, hipMemcpyDeviceToDevice, st));
     dim += cur;
-    std::vector<double> Wj((size_t)n * cur), BWj((size_t)n * cur);
-    solve_block(BQ.data() + (size_t)j0 * n, Wj.data(), cur);
-    W.insert(W.end(), Wj.begin(), Wj.end());
-    B.mult(Wj.data(), BWj.data(), cur);
+    double *Wj = Wd.p + nn * j0;
+    shifted.plan.solve(BQd.p + nn * j0, Wj, cur, st); // W_j = OP Q_j
+    bmult(Wj, T1d.p, cur);
     std::vector<double> Tc;
-    tn(Q.data(), dim, BWj.data(), cur, Tc); // T(0:dim, j0:j0+cur)
+    tn(Qd.p, dim, T1d.p, cur, Tc); // T(0:dim, j0:j0+cur)
     for (int i = 0; i < dim; ++i)
       for (int c = 0; c < cur; ++c) T[(size_t)i * kmax + j0 + c] = T[(size_t)(j0 + c) * kmax + i] = Tc[(size_t)i * cur + c];
     ++it;
@@ -285,50 +384,47 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
       for (int i = 0; i < dim; ++i) order[i] = i;
       std::sort(order.begin(), order.end(), [&](int l, int r) { return th[l] > th[r]; }); // largest theta = lowest lambda
       const int want = std::min(nu, dim);
-      // Ritz vectors x = Q s and residuals OP x - theta x = W s - theta Q s
-      Xritz.assign((size_t)n * want, 0.0);
+      // Ritz vectors x = Q s and residuals OP x - theta x = W s - theta Q s, 8 columns at a time
+      Xd.alloc(nn * want);
       lam.assign(want, 0.0);
       double worst = 0.0;
-#pragma omp parallel for schedule(static) reduction(max : worst)
-      for (int c = 0; c < want; ++c) {
-        const int    e  = order[c];
-        const double th_e = th[e];
-        double       rr = 0.0, xx = 0.0;
-        double      *xc = Xritz.data() + (size_t)c * n;
-        for (int i = 0; i < dim; ++i) {
-          const double sv = Sv[(size_t)i * dim + e];
-          if (sv == 0.0) continue;
-          const double *q = Q.data() + (size_t)i * n;
-          for (int r = 0; r < n; ++r) xc[r] += sv * q[r];
+      for (int c0 = 0; c0 < want; c0 += 8) {
+        const int           cc = std::min(8, want - c0);
+        std::vector<double> Sel((size_t)dim * cc), thc(cc), out(2 * cc);
+        for (int c = 0; c < cc; ++c) {
+          const int e = order[c0 + c];
+          thc[c]      = th[e];
+          for (int i = 0; i < dim; ++i) Sel[(size_t)i * cc + c] = Sv[(size_t)i * dim + e];
+          lam[c0 + c] = 1.0 / th[e] - sigma;
         }
-        std::vector<double> wx(n, 0.0);
-        for (int i = 0; i < dim; ++i) {
-          const double  sv = Sv[(size_t)i * dim + e];
-          const double *wv = W.data() + (size_t)i * n;
-          for (int r = 0; r < n; ++r) wx[r] += sv * wv[r];
-        }
-        for (int r = 0; r < n; ++r) {
-          const double res = wx[r] - th_e * xc[r];
-          rr += res * res;
-          xx += th_e * xc[r] * th_e * xc[r];
-        }
-        lam[c] = 1.0 / th_e - sigma;
-        worst  = std::max(worst, std::sqrt(rr / std::max(xx, 1e-300)));
+        mul(Qd.p, dim, Sel, cc, 1.0, 0.0, nullptr, Xd.p + nn * c0);
+        mul(Wd.p, dim, Sel, cc, 1.0, 0.0, nullptr, T2d.p);
+        HIP_OK(hipMemcpyAsync(small_d.p, thc.data(), sizeof(double) * cc, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_ge_resid, dim3((unsigned)cc), dim3(256), 0, st, n, T2d.p, Xd.p + nn * c0, small_d.p, small_d.p + 16);
+        HIP_OK(hipMemcpyAsync(out.data(), small_d.p + 16, sizeof(double) * 2 * cc, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        for (int c = 0; c < cc; ++c) worst = std::max(worst, std::sqrt(out[2 * c] / std::max(out[2 * c + 1], 1e-300)));
       }
+      nritz = want;
       if (want == std::min(nu, n) && worst < tol) {
         converged = true;
         break;
       }
     }
     // next block: W_j made B-orthogonal to the whole basis (twice), then B-orthonormalised
-    V = Wj;
+    HIP_OK(hipMemcpyAsync(Vd.p, Wj, sizeof(double) * nn * cur, hipMemcpyDeviceToDevice, st));
     for (int pass = 0; pass < 2; ++pass) {
-      std::vector<double> BVt((size_t)n * cur), Cc;
-      B.mult(V.data(), BVt.data(), cur);
-      tn(Q.data(), dim, BVt.data(), cur, Cc);
-      sub(V.data(), cur, Q.data(), dim, Cc);
+      std::vector<double> Cc;
+      bmult(Vd.p, T1d.p, cur);
+      tn(Qd.p, dim, T1d.p, cur, Cc);
+      mul(Qd.p, dim, Cc, cur, -1.0, 1.0, Vd.p, Vd.p);
     }
-    cur = b_orth(V, BV, cur);
+    cur = b_orth(Vd.p, BVd.p, cur);
+  }
+  std::vector<double> Xritz(nn * nritz);
+  if (nritz) {
+    HIP_OK(hipMemcpyAsync(Xritz.data(), Xd.p, sizeof(double) * nn * nritz, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
   }
   HH_CHECK(!Xritz.empty(), "SolveGEVP: no Ritz pair was computed");
   if (!converged && getopt("verbosity", 0) >= 1) printf("GenEO subdomain %d: eigensolver stopped at basis size %d without reaching tol %.1e\n", first + s, dim, tol);

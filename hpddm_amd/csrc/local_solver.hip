@@ -51,6 +51,30 @@ static bool is_symmetric(const CsrView &A)
 // factorisation of a mid-size subdomain.
 static std::vector<double> g_spare_panels;
 
+bool LocalSolver::adopt_analysis(const LocalSolver &o, const CsrView &A)
+{
+  if (!o.analysed || o.leaf_size != leaf_size) return false;
+  const size_t h = hash_pattern(A);
+  if (h != o.pattern_hash || o.host.n != A.n) return false;
+  host.n         = o.host.n;
+  host.ord       = o.host.ord;
+  host.sym       = o.host.sym;
+  host.level_ptr = o.host.level_ptr;
+  host.level_blk = o.host.level_blk;
+  host.ldw       = o.host.ldw;
+  host.f_off     = o.host.f_off;
+  host.f_size    = o.host.f_size;
+  host.u_off     = o.host.u_off;
+  host.u_size    = o.host.u_size;
+  host.goff      = o.host.goff;
+  host.gptr      = o.host.gptr;
+  host.gsrc      = o.host.gsrc;
+  host.t_order = host.t_symbolic = 0.0;
+  pattern_hash = h;
+  analysed     = true;
+  return true;
+}
+
 void LocalSolver::analyse(const CsrView &A)
 {
   const size_t h = hash_pattern(A);

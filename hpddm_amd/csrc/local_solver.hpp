@@ -19,6 +19,7 @@ struct LocalSolver {
   bool         release_host = false; // drop the host panels after upload (Schwarz operator does this)
   double       t_upload = 0;
   DevBuf<double> bdev, xdev;         // staging for the host-pointer API
+  bool adopt_analysis(const LocalSolver &other, const CsrView &A); // same sparsity pattern as a solver already analysed: copy its ordering and symbolic factorisation
   void analyse(const CsrView &A); // ordering + symbolic factorisation (host only, thread-safe across solvers); numfact calls it if needed
   void numfact(const CsrView &A, int spd);
   void solve_host(const double *b, double *x, int mu);
