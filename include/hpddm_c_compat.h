@@ -1,0 +1,71 @@
+/* hpddm_c_compat.h -- the reference's own C API (interface/HPDDM.h:66-118), K = double, exported by libhpddm_c_hip.so
+ * on top of libhpddm_hip.so, so that a C program written against HPDDM.h (examples/schwarz.c + examples/generate.c)
+ * links and runs UNCHANGED with every subdomain factorised and solved on the MI355X.
+ *
+ * Mapping to the reference's execution model: one MPI rank owns one subdomain (HpddmSchwarzCreate is called once per
+ * rank with that rank's matrix and neighbour lists, examples/schwarz.c:72); here every rank drives a one-subdomain
+ * HpddmHipSchwarz whose halo and reductions travel through MPI (the transport callbacks of hpddm_hip.h filled with
+ * MPI_Isend/Irecv and MPI_Allreduce -- the calls Subdomain::exchange and the Krylov methods make in the reference).
+ * Ranks may share a GPU or own one each (HPDDM_HIP_DEVICE=<n>, default rank % device count).
+ *
+ * Only what the RAS path needs is implemented; HpddmCustomOperatorSolve and the PETSc hook are not.  A program includes
+ * the reference's HPDDM.h as before -- this header only documents what the shim exports (same names, same argument
+ * meaning) and lets the shim be compiled without the reference tree.
+ */
+#ifndef HPDDM_C_COMPAT_H_
+#define HPDDM_C_COMPAT_H_
+#include <mpi.h>
+#include <stdbool.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct HpddmOption         HpddmOption;         /* interface/HPDDM.h:66-67 */
+typedef struct HpddmMatrixCSR      HpddmMatrixCSR;      /* :80-81 */
+typedef struct HpddmSubdomain      HpddmSubdomain;      /* :86-87 */
+typedef struct HpddmPreconditioner HpddmPreconditioner; /* :92-93 */
+typedef struct HpddmSchwarz        HpddmSchwarz;        /* :99-100 */
+
+const HpddmOption *HpddmOptionGet(void);                                                      /* :68 */
+int                HpddmOptionParse(const HpddmOption *, int, char **, bool);                 /* :69  -hpddm_* flags */
+int                HpddmOptionParseString(const HpddmOption *, const char *);                 /* :70 */
+int                HpddmOptionParseInt(const HpddmOption *, int, char **, char *, char *);    /* :71  application flags "name=<default>" */
+int                HpddmOptionParseInts(const HpddmOption *, int, char **, int, char *[], char *[]); /* :72 */
+int                HpddmOptionParseArgs(const HpddmOption *, int, char **, int, char *[], char *[]); /* :73  "name=(0|1)" */
+bool               HpddmOptionSet(const HpddmOption *, const char *);                         /* :74 */
+void               HpddmOptionRemove(const HpddmOption *, const char *);                      /* :75 */
+double             HpddmOptionVal(const HpddmOption *, const char *);                         /* :76 */
+double            *HpddmOptionAddr(const HpddmOption *, const char *);                        /* :77 */
+double             HpddmOptionApp(const HpddmOption *, const char *);                         /* :78 */
+
+HpddmMatrixCSR *HpddmMatrixCSRCreate(int n, int m, int nnz, double *a, int *ia, int *ja, bool sym, bool takeOwnership); /* :82 */
+void            HpddmMatrixCSRDestroy(HpddmMatrixCSR *);                                      /* :83 */
+void            HpddmCSRMM(HpddmMatrixCSR *, const double *, double *, int);                  /* :84 */
+
+void HpddmSubdomainNumfact(HpddmSubdomain **, HpddmMatrixCSR *);                              /* :88 */
+void HpddmSubdomainSolve(HpddmSubdomain *, const double *, double *, unsigned short);         /* :89 */
+void HpddmSubdomainDestroy(HpddmSubdomain *);                                                 /* :90 */
+
+void            HpddmInitializeCoarseOperator(HpddmPreconditioner *, unsigned short);         /* :94 */
+void            HpddmSetVectors(HpddmPreconditioner *, double **);                            /* :95 */
+void            HpddmDestroyVectors(HpddmPreconditioner *);                                   /* :96 */
+const MPI_Comm *HpddmGetCommunicator(HpddmPreconditioner *);                                  /* :97 */
+
+HpddmSchwarz        *HpddmSchwarzCreate(HpddmMatrixCSR *, int neighbors, int *list, int *sizes, int **connectivity); /* :101 */
+void                 HpddmSchwarzInitialize(HpddmSchwarz *, double *d);                       /* :102 */
+HpddmPreconditioner *HpddmSchwarzPreconditioner(HpddmSchwarz *);                              /* :103 */
+void                 HpddmSchwarzMultiplicityScaling(HpddmSchwarz *, double *d);              /* :104 */
+void                 HpddmSchwarzExchange(HpddmSchwarz *, double *, unsigned short);          /* :105 */
+void                 HpddmSchwarzCallNumfact(HpddmSchwarz *);                                 /* :106 */
+void                 HpddmSchwarzSolveGEVP(HpddmSchwarz *, HpddmMatrixCSR *neumann);          /* :107 */
+void                 HpddmSchwarzBuildCoarseOperator(HpddmSchwarz *, MPI_Comm);               /* :108 */
+void                 HpddmSchwarzComputeResidual(HpddmSchwarz *, const double *sol, const double *f, double *storage, unsigned short); /* :109 */
+void                 HpddmSchwarzDestroy(HpddmSchwarz *);                                     /* :110 */
+
+int HpddmSolve(HpddmSchwarz *, const double *b, double *sol, int mu, const MPI_Comm *);       /* :112 */
+
+double nrm2(const int *, const double *, const int *);                                        /* :117 */
+void   axpy(const int *, const double *, const double *, const int *, double *, const int *); /* :118 */
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -70,3 +70,37 @@ def test_unchanged_schwarz_cpp_complex_scalars(args, pat, its, resid):
     assert r and float(r.group(1)) / float(r.group(2)) <= 1e-6
     if resid:
         assert abs(float(r.group(1)) - resid) <= 5e-4 * resid, out[-500:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "schwarz_c_hip")), reason="oracle/_ref/schwarz_c_hip not built")
+@pytest.mark.parametrize("args,its,resid", [
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40", 19, 1.428088e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -symmetric_csr=1 -hpddm_operator_spd", 19, 1.747862e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0", 17, 3.415834e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -generate_random_rhs 3 -hpddm_krylov_method bgmres", None, None),
+    ("-hpddm_verbosity=1 -Nx 200 -Ny 200", 45, 1.660748e-04),
+])
+def test_unchanged_c_example_against_the_c_api_shim(args, its, resid):
+    """examples/schwarz.c + generate.c (written against interface/HPDDM.h) linked with libhpddm_c_hip.so instead of
+    interface/hpddm_c.cpp: 4 MPI ranks, one subdomain each, halo and reductions through MPI, every solve on the GPU.
+    The C++ example of the reference gives the same iteration counts / residuals."""
+    out = _run(4, args, exe="schwarz_c_hip")
+    r = re.findall(r"residual = (\S+) / (\S+)|^\s+(\S+) / (\S+) \(rhs", out, re.M)
+    assert r, out[-1500:]
+    if its is not None:
+        m = re.search(r"GMRES converges after (\d+) iteration", out)
+        assert m and int(m.group(1)) == its, out[-1500:]
+        first = [v for v in r[0] if v]
+        assert abs(float(first[0]) - resid) <= 5e-4 * resid, out[-500:]
+    else:
+        assert re.search(r"BGMRES converges after \d+ iteration", out), out[-1500:]
+        for grp in r:
+            vals = [float(v) for v in grp if v]
+            assert vals[0] / vals[1] <= 1e-2   # the example's own check (examples/schwarz.c:120)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "schwarz_c_hip")), reason="oracle/_ref/schwarz_c_hip not built")
+def test_unchanged_c_example_single_rank_direct_solve():
+    out = _run(1, "-Nx 40 -Ny 40", exe="schwarz_c_hip")
+    r = re.search(r"--- residual = (\S+) / (\S+)", out)
+    assert r and float(r.group(1)) / float(r.group(2)) <= 1e-6
