@@ -121,3 +121,19 @@ def test_no_cpu_fallback():
     S2.numfact(A.shape[0], L.indptr, L.indices, L.data, sym=True, spd=True)
     with pytest.raises(_lib.HpddmHipError):
         S2.solve(np.ones(A.shape[0]))
+
+
+def test_c_api_shim_exports_the_reference_names():
+    """libhpddm_c_hip.so (built by oracle/Makefile.ref where MPI is available) exports every function include/hpddm_c_compat.h
+    declares -- the names of the reference's interface/HPDDM.h"""
+    so = os.path.join(ROOT, "hpddm_amd", "libhpddm_c_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("libhpddm_c_hip.so not built (needs MPI: make -C oracle ref)")
+    header = open(os.path.join(ROOT, "include", "hpddm_c_compat.h")).read()
+    declared = set(re.findall(r"\b(Hpddm\w+|nrm2|axpy)\s*\(", header))
+    assert len(declared) >= 30
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    missing = sorted(declared - exported)
+    assert not missing, missing
