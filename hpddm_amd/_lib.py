@@ -46,6 +46,7 @@ def _declare(lib):
         "HpddmHipSchwarzInitialize": (I, [P, I, P]),
         "HpddmHipSchwarzSetVectors": (I, [P, I, I, P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
+        "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),
         "HpddmHipSchwarzBuildCoarseOperator": (I, [P]),
         "HpddmHipSchwarzCallNumfact": (I, [P]),

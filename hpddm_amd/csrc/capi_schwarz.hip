@@ -114,6 +114,26 @@ int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A)
     A->op.build_coarse();
     return 0;)
 }
+int HpddmHipSchwarzSetOptimizedMatrix(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering)
+{
+  HH_TRY(
+    HH_CHECK(A && s >= 0 && s < A->op.nsub, "bad subdomain");
+    SchwarzSub &S = A->op.subs[s];
+    if (!ia) { // back to the subdomain matrix
+      S.has1 = false;
+      return 0;
+    }
+    HH_CHECK(ja && a && n == S.n, "optimised matrix: wrong size or null argument");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    const int base = numbering == 'F' ? 1 : 0, nnz = ia[n] - base;
+    S.ia1.assign(ia, ia + n + 1);
+    S.ja1.assign(ja, ja + nnz);
+    S.a1.assign(a, a + nnz);
+    S.sym1  = sym != 0;
+    S.base1 = base;
+    S.has1  = true;
+    return 0;)
+}
 int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A)
 {
   HH_TRY(

@@ -440,15 +440,19 @@ void Schwarz::call_numfact()
   // Schwarz::callNumfact (include/HPDDM_schwarz.hpp:337-368)
   build_device();
   const int m = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS);
+  // an optimised matrix was supplied for every local subdomain (HpddmHipSchwarzSetOptimizedMatrix) <=> callNumfact(A)
+  bool optimized = nsub > 0;
+  for (int s = 0; s < nsub; ++s) optimized = optimized && subs[s].has1;
   switch (m) {
-  case SCHWARZ_METHOD_SORAS: type = PRC_SY; break; // no optimized matrix A supplied => SY, as in the reference
+  case SCHWARZ_METHOD_SORAS: type = optimized ? PRC_OS : PRC_SY; break;
   case SCHWARZ_METHOD_ASM: type = PRC_SY; break;
   case SCHWARZ_METHOD_NONE:
     type     = PRC_NO;
     factored = true;
     return;
-  default: type = PRC_GE;
+  default: type = (optimized && (m == SCHWARZ_METHOD_ORAS || m == SCHWARZ_METHOD_OSM)) ? PRC_OG : PRC_GE;
   }
+  const bool use1 = type == PRC_OS || type == PRC_OG; // factorise the optimised matrices instead of the subdomain matrices
   const int reuse = (int)getopt("reuse_preconditioner", 0);
   if (reuse <= 1 || !factored) {
     const int spd = (int)getopt("operator_spd", 0);
@@ -466,7 +470,7 @@ void Schwarz::call_numfact()
             S.ls->leaf_size = leaf;
             S.ls->analysed  = false;
           }
-          CsrView A{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
+          CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
           S.ls->analyse(A);
         } catch (const std::exception &e) {
 #pragma omp critical(hpddm_hip_analyse_err)
@@ -480,7 +484,7 @@ void Schwarz::call_numfact()
       S.ls->leaf_size        = (int)getopt("leaf_size", 32);
       S.ls->release_host     = getopt("keep_host_factor", 0) == 0;
       S.ls->host.keep_plain  = getopt("keep_plain", 0) != 0;
-      CsrView A{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
+      CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
       S.ls->numfact(A, spd);
       fs.push_back(&S.ls->dev);
     }

@@ -26,6 +26,11 @@ struct SchwarzSub {
   std::vector<double> a0;
   bool                sym0 = false;
   int                 base0 = 0;
+  // optional optimised local matrix (ORAS / SORAS / OSM: callNumfact(A), include/HPDDM_schwarz.hpp:337-368), same conventions
+  std::vector<int>    ia1, ja1;
+  std::vector<double> a1;
+  bool                sym1 = false, has1 = false;
+  int                 base1 = 0;
   // ... and expanded to full 0-based CSR (GMV, coarse operator, residual)
   std::vector<int>    ia, ja;
   std::vector<double> a;

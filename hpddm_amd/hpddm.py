@@ -192,6 +192,13 @@ class Schwarz:
         self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)
         return ev[:k]
 
+    def set_optimized_matrix(self, s, n, ia, ja, a, sym, numbering="C"):
+        """callNumfact(A) of the reference: optimised local matrix of subdomain s for -hpddm_schwarz_method oras / soras / osm"""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ja = np.ascontiguousarray(ja, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        check(self._lib.HpddmHipSchwarzSetOptimizedMatrix(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
+
     def build_coarse_operator(self):
         check(self._lib.HpddmHipSchwarzBuildCoarseOperator(self._h))
 

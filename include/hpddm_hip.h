@@ -97,6 +97,10 @@ int HpddmHipSchwarzGetEigenvalues(HpddmHipSchwarz *A, int s, double *out, int ca
  * E = Z^T A Z assembled from the local products and factorised (dense, replicated). */
 int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A);
 /* HpddmSchwarzCallNumfact (HPDDM.h:106, Schwarz::callNumfact include/HPDDM_schwarz.hpp:337-368) */
+/* Schwarz::callNumfact(A) with an optimised local matrix (include/HPDDM_schwarz.hpp:337-368; C++ only in the reference):
+ * once every local subdomain has one, -hpddm_schwarz_method oras|osm gives type OG (factor of A_opt, D-scaled exchange),
+ * soras gives OS (D A_opt^{-1} D, plain exchange).  ia == NULL removes it. */
+int HpddmHipSchwarzSetOptimizedMatrix(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering);
 int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A);
 /* Options of the path, same names and values as the reference's -hpddm_* flags (include/HPDDM_option_impl.hpp:41-178):
  * "tol" "max_it" "gmres_restart" "variant" (0 left,1 right,2 flexible) "orthogonalization" (0 cgs,1 mgs)

@@ -40,6 +40,9 @@ CASES = [
     ("p30_6ranks_bgmres_left_mu3", 6, 3, "-Nx 30 -Ny 30 -hpddm_krylov_method bgmres -hpddm_variant left"),
     ("p40_fgmres_restart8_mu2", 4, 2, "-Nx 40 -Ny 40 -hpddm_variant flexible -hpddm_gmres_restart=8"),
     ("p40_fbgmres_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bgmres -hpddm_variant flexible -hpddm_gmres_restart=6"),
+    ("p40_oras_og", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method oras -optimized_shift 30"),
+    ("p40_soras_os_sym", 4, 1, "-Nx 40 -Ny 40 -overlap 2 -symmetric_csr=1 -hpddm_schwarz_method soras -optimized_shift 30"),
+    ("p40_soras_os_deflated", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method soras -optimized_shift 20 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),

@@ -92,8 +92,13 @@ class Oracle:
         return self.exchange(self.csrmm(xs))
 
     # ---- Solver<K>::numfact / solve ----
-    def numfact(self):
-        self.lu = [spl.splu(sp.csc_matrix(A)) for A in self.A]
+    def numfact(self, optimized=None):
+        """Schwarz::callNumfact (include/HPDDM_schwarz.hpp:337-368): with optimised matrices the factor is theirs and the type
+        becomes OG (method oras/osm) or OS (soras)"""
+        mats = self.A if optimized is None else optimized
+        self.lu = [spl.splu(sp.csc_matrix(A)) for A in mats]
+        if optimized is not None:
+            self.method = {"oras": "og", "osm": "og", "soras": "os"}.get(self.method, self.method)
 
     def local_solve(self, xs):
         return [self.lu[s].solve(np.asarray(xs[s], dtype=np.float64)) for s in range(self.P)]
@@ -154,9 +159,12 @@ class Oracle:
     # ---- Schwarz::apply ----
     def apply(self, xs):
         if self.correction is None:
-            if self.method == "asm":
+            if self.method in ("asm", "soras"):   # SY: plain exchange (include/HPDDM_schwarz.hpp:546-548)
                 return self.exchange(self.local_solve(xs), scale=False)
-            return self.exchange(self.local_solve(xs))
+            if self.method == "os":               # OS: D A_opt^{-1} D, plain exchange (:541-545)
+                dd = [self.d[s][:, None] if xs[s].ndim == 2 else self.d[s] for s in range(self.P)]
+                return self.exchange([dd[s] * y for s, y in enumerate(self.local_solve([dd[s] * x for s, x in enumerate(xs)]))], scale=False)
+            return self.exchange(self.local_solve(xs))   # GE / OG
         if self.correction == "additive":
             out = self.deflation(xs)
             work = self.local_solve(xs)
@@ -164,6 +172,8 @@ class Oracle:
         out = self.deflation(xs)
         Aout = self.csrmm(out)
         work = self.exchange([x - a for x, a in zip(xs, Aout)])
+        if self.method == "os":                   # :589
+            work = [(self.d[s][:, None] if w.ndim == 2 else self.d[s]) * w for s, w in enumerate(work)]
         work = self.exchange(self.local_solve(work))
         if self.correction == "balanced":
             tmp = self.deflation(self.gmv(work))

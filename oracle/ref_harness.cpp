@@ -48,7 +48,8 @@ int main(int argc, char **argv)
             {std::forward_as_tuple("overlap=<1>", "", HPDDM::Option::Arg::positive), std::forward_as_tuple("Nx=<100>", "", HPDDM::Option::Arg::positive), std::forward_as_tuple("Ny=<100>", "", HPDDM::Option::Arg::positive),
              std::forward_as_tuple("generate_random_rhs=<0>", "", HPDDM::Option::Arg::integer), std::forward_as_tuple("symmetric_csr=(0|1)", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("mu=<1>", "number of harness right-hand sides", HPDDM::Option::Arg::positive), std::forward_as_tuple("out=<dir>", "", HPDDM::Option::Arg::argument),
-             std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument)});
+             std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument),
+             std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
   const std::string dir  = opt.prefix("out");
   const std::string name = opt.prefix("case");
@@ -118,7 +119,24 @@ int main(int argc, char **argv)
   }
   meta[7] = nu;
   dumpi("meta", meta, 8);
-  A.callNumfact();
+  {
+    /* optimised local matrix (ORAS / SORAS / OSM, include/HPDDM_schwarz.hpp:337-368): a deterministic Robin-like perturbation
+     * of the diagonal on the overlap, A_opt = A + (shift / 100) * diag((1 - d_i) a_ii); dumped so that the fixtures carry it */
+    const int shift = opt.app()["optimized_shift"];
+    if (shift > 0) {
+      K   *ao  = new K[Mat->nnz_];
+      int *iao = new int[ndof + 1], *jao = new int[Mat->nnz_];
+      std::copy_n(Mat->a_, Mat->nnz_, ao);
+      std::copy_n(Mat->ia_, ndof + 1, iao);
+      std::copy_n(Mat->ja_, Mat->nnz_, jao);
+      for (int i = 0; i < ndof; ++i)
+        for (int p = iao[i] - (HPDDM_NUMBERING == 'F'); p < iao[i + 1] - (HPDDM_NUMBERING == 'F'); ++p)
+          if (jao[p] - (HPDDM_NUMBERING == 'F') == i) ao[p] += 0.01 * shift * (1.0 - d[i]) * ao[p];
+      HPDDM::MatrixCSR<K> *Aopt = new HPDDM::MatrixCSR<K>(ndof, ndof, Mat->nnz_, ao, iao, jao, Mat->sym_, true);
+      dumpd("a_opt", ao, Mat->nnz_);
+      A.callNumfact(Aopt);
+    } else A.callNumfact();
+  }
 
   /* --- per-function dumps (buffers set like IterativeMethod::initializeNorm -> Schwarz::start does) --- */
   const int n    = mu * ndof;

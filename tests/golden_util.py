@@ -17,7 +17,7 @@ def load(name):
 def options(g):
     """reference command line of the case -> dict of the options the path reads"""
     toks = str(g["options"]).split()
-    out = {"tol": 1e-6, "max_it": 100, "restart": 40, "variant": "right", "ortho": "cgs", "correction": None, "spd": False}
+    out = {"tol": 1e-6, "max_it": 100, "restart": 40, "variant": "right", "ortho": "cgs", "correction": None, "spd": False, "method": "ras"}
     i = 0
     while i < len(toks):
         t = toks[i]
@@ -43,7 +43,22 @@ def options(g):
                 out["correction"] = val
             elif key == "operator_spd":
                 out["spd"] = True
+            elif key == "schwarz_method":
+                out["method"] = val
         i += 1
+    return out
+
+
+OPTIMIZED_CASES = ["p40_oras_og", "p40_soras_os_sym", "p40_soras_os_deflated"]
+
+
+def optimized_matrices(g, subs):
+    """the optimised local matrices the harness handed to callNumfact(A) (same pattern as the subdomain matrices, values a_opt)"""
+    out = []
+    for r, s in enumerate(subs):
+        t = dict(s)
+        t["a"] = g[f"a_opt_r{r}"]
+        out.append(t)
     return out
 
 

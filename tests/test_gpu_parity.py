@@ -28,11 +28,14 @@ def _build(g, subs):
         for s, sd in enumerate(subs):
             A.set_vectors(s, np.ones((sd["n"], 1)))
         A.build_coarse_operator()
+    if "a_opt_r0" in g:   # callNumfact(A_opt): ORAS / SORAS with an optimised local matrix
+        for s, t in enumerate(gu.optimized_matrices(g, subs)):
+            A.set_optimized_matrix(s, t["n"], t["ia"], t["ja"], t["a"], t["sym"])
     A.call_numfact()
     return A, d, opt
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
 def test_functions_match_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -49,7 +52,7 @@ def test_functions_match_reference(name):
     A.destroy()
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
 def test_gmres_matches_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)

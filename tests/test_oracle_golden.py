@@ -12,10 +12,14 @@ from oracle.ras_oracle import Oracle
 
 
 def _setup(g, subs):
+    from oracle.ras_oracle import csr_full
     opt = gu.options(g)
-    orc = Oracle(subs, correction=opt["correction"])
+    orc = Oracle(subs, correction=opt["correction"], method=opt["method"])
     orc.multiplicity_scaling([s["d"] for s in subs])
-    orc.numfact()
+    if "a_opt_r0" in g:   # callNumfact(A_opt): ORAS / SORAS with an optimised local matrix
+        orc.numfact([csr_full(t) for t in gu.optimized_matrices(g, subs)])
+    else:
+        orc.numfact()
     if opt["correction"]:
         orc.set_vectors([np.ones((s["n"], 1)) for s in subs])  # constant vector, examples/schwarz.cpp:115-121
         orc.build_coarse()
@@ -28,7 +32,7 @@ def _close(a, b, rtol, what):
     assert err <= rtol, f"{what}: relative error {err:.3e} > {rtol:.1e}"
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
 def test_functions_match_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -49,7 +53,7 @@ def test_functions_match_reference(name):
         _close(orc.deflation(f), gu.vecs(g, "deflation_out"), 1e-10, "deflation")
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
 def test_gmres_matches_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
