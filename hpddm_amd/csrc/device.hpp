@@ -3,6 +3,7 @@
 #pragma once
 #include "factor.hpp"
 #include <hip/hip_runtime.h>
+#include <map>
 #include <memory>
 
 namespace hpddm_hip {
@@ -120,6 +121,10 @@ struct SolvePlan {
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves
   double         bytes_alg_per_rhs1 = 0; // 2*nnz(L)*8 + 4*n*8 summed over the factors, mu = 1
+  bool                           use_graph = false;
+  std::map<int, hipGraphExec_t>  graphs; // per mu: the captured level launches of one solve
+  void drop_graphs();
+  ~SolvePlan() { drop_graphs(); }
   void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
   void reserve(int mu);
   // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b
