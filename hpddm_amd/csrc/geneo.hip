@@ -3,10 +3,10 @@
 //
 // Reference: Schwarz::solveGEVP (include/HPDDM_schwarz.hpp:665-715), Schwarz::scaleIntoOverlap (:622-657) and the ARPACK
 // driver (include/HPDDM_ARPACK.hpp:84-148: shift-and-invert mode 3, OP = A_N^{-1} B with the local Solver<K>).  ARPACK is
-// not part of the reference tree (and not installed here); the eigensolver below is our own: shift-and-invert
-// subspace iteration with Rayleigh-Ritz on  (A_N + s B)^{-1} B,  s > 0 -- the shifted matrix is symmetric positive
-// definite, so it goes through the same Cholesky numfact + HIP SpTRSV as the preconditioner, mu = block size
-// right-hand sides at a time (the SpTRSV is HBM-bound: 8 right-hand sides cost little more than one).
+// not part of the reference tree (and not installed here); the eigensolver below is our own: shift-and-invert block
+// Krylov iteration with Rayleigh-Ritz on  (A_N + s B)^{-1} B,  s > 0 -- the shifted matrix is symmetric positive
+// definite, so it goes through the same Cholesky numfact + HIP SpTRSV as the preconditioner, 8 right-hand sides at a
+// time (one sweep over L for the block).  The basis and all n-sized blocks live in HBM; the host sees k x k matrices.
 #include "schwarz.hpp"
 #include <algorithm>
 #include <cmath>
@@ -21,16 +21,6 @@ struct Csr {
   int                 n = 0;
   std::vector<int>    ia, ja;
   std::vector<double> a;
-  void mult(const double *x, double *y, int m) const // y = A x for m columns (column-major, ld n)
-  {
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i)
-      for (int c = 0; c < m; ++c) {
-        double acc = 0.0;
-        for (int p = ia[i]; p < ia[i + 1]; ++p) acc += a[p] * x[(size_t)c * n + ja[p]];
-        y[(size_t)c * n + i] = acc;
-      }
-  }
 };
 
 // full 0-based CSR from HPDDM storage (sym => lower triangle given)
@@ -97,21 +87,6 @@ void jacobi_eig(int m, std::vector<double> &A, std::vector<double> &V, std::vect
   w.resize(m);
   for (int i = 0; i < m; ++i) w[i] = A[(size_t)i * m + i];
 }
-
-// G(m x m) = X^T Y for n x m column-major blocks
-void gram(int n, int m, const double *X, const double *Y, std::vector<double> &G)
-{
-  G.assign((size_t)m * m, 0.0);
-#pragma omp parallel for schedule(dynamic, 1) collapse(2)
-  for (int i = 0; i < m; ++i)
-    for (int j = 0; j < m; ++j) {
-      double        acc = 0.0;
-      const double *x = X + (size_t)i * n, *y = Y + (size_t)j * n;
-      for (int k = 0; k < n; ++k) acc += x[k] * y[k];
-      G[(size_t)i * m + j] = acc;
-    }
-}
-
 
 // ---- device-side block operations of the eigensolver: tall-skinny blocks n x k, column-major, leading dimension n ----
 constexpr int GE_ROWS = 1024; // rows of a block handled by one workgroup of k_tn

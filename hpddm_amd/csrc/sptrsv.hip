@@ -6,12 +6,15 @@
 // Data layout (factor.hpp): every supernode J owns a dense row-major panel [inv(L_JJ) ; L_below inv(L_JJ)].
 //   forward  (levels bottom-up):  f = b_J - gathered children updates ;  t = F_J f ;  y_J = t[0:w] ;  u_J = t[w:h] + gathered
 //   backward (levels top-down):   x_J = G_J^T [ D^{-1} y_J ; -x_below ]
-// Mapping to CDNA4: one 256-thread workgroup (4 wavefronts) per tile of a panel; the right-hand-side tile of the
-// supernode is staged in LDS once per workgroup and every wavefront streams whole panel rows with 16-byte loads
-// (1 KiB per wave-instruction, rows are contiguous => fully coalesced); narrow supernodes pack several rows into one
-// wavefront; reductions are in-register (DPP shuffles).  All subdomains of the GPU advance level by level in the same
-// launches, so a level exposes (#subdomains x #supernodes x #row tiles) >> 256 workgroups.  No atomics: children
-// hand their updates to the parent through per-supernode update vectors (bitwise reproducible).
+// Mapping to CDNA4.  Wide panels (more than 128 columns): one 256-thread workgroup per tile; the right-hand-side tile of
+// the supernode is staged in LDS once per workgroup and every wavefront streams whole panel rows with 16-byte loads
+// (1 KiB per wave-instruction, rows are contiguous => fully coalesced), one in-register reduction per row.  Narrow
+// panels: one wavefront per tile, lanes own pairs of outputs and walk down the panel (the backward sweep on the row-major
+// panel, the forward sweep on a transposed copy), so neither sweep reduces across lanes until the very end.  All
+// subdomains of the GPU advance level by level in the same launches, so a level exposes (#subdomains x #supernodes x
+// #tiles) >> 256 workgroups.  No atomics on the data path: children hand their updates to the parent through
+// per-supernode update vectors (bitwise reproducible); the split-row tiles of the upper backward levels meet at an
+// arrival counter and the last one adds the partial sums in a fixed order.
 #include "device.hpp"
 #include <algorithm>
 
