@@ -599,6 +599,7 @@ void Schwarz::build_coarse()
     const int         ri = gcoff[first + i];
     // diagonal block: Z_i^T D_i T_i  (the reference scales the local product by D, include/HPDDM_operator.hpp:524, and
     // the neighbours' rows by D in applyFromNeighbor, :398-404)
+#pragma omp parallel for schedule(static) collapse(2)
     for (int ki = 0; ki < Si.nu; ++ki)
       for (int kj = 0; kj < Si.nu; ++kj) {
         double acc = 0.0;
