@@ -22,7 +22,8 @@ static double now()
 
 // The GPU hosts expose hundreds of hardware threads while the container may only be scheduled on a few: an OpenMP team
 // of 256 spinning threads on 16 CPUs turns every parallel region into milliseconds.  The cap is the container's CPU
-// quota if there is one, else 32; HPDDM_HIP_NUM_THREADS overrides it.  Applied once when the library is loaded.
+// quota if there is one, else 32, divided by the number of processes of the job on this node; HPDDM_HIP_NUM_THREADS
+// overrides it.  Applied once when the library is loaded.
 int host_thread_cap()
 {
   static const int cap = [] {
@@ -32,8 +33,16 @@ int host_thread_cap()
       if (fscanf(fc, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) c = std::max<int>(1, (int)((quota + period - 1) / period));
       fclose(fc);
     }
+    c = std::min(omp_get_num_procs(), c);
+    // several processes of one job on this node (one per GPU under torch.distributed.run / mpiexec) share those CPUs
+    for (const char *k : {"LOCAL_WORLD_SIZE", "MPI_LOCALNRANKS", "OMPI_COMM_WORLD_LOCAL_SIZE"})
+      if (const char *e = getenv(k)) {
+        const int r = atoi(e);
+        if (r > 1) c = std::max(1, c / r);
+        break;
+      }
     if (const char *e = getenv("HPDDM_HIP_NUM_THREADS")) c = std::max(1, atoi(e));
-    return std::max(1, std::min(omp_get_num_procs(), c));
+    return std::max(1, c);
   }();
   return cap;
 }
