@@ -131,11 +131,12 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
   const gcd_t Fp = d.FT + t.r0 + 2 * gl;
+  const int   rtop = t.r0 + 2 * gl + 1; // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < w && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < w && i <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
   }
   // f = b_J - (updates handed up by the children), one lane per column, into the wavefront's LDS
   for (int c = lane; c < w && !(dbg & DBG_NORHS); c += 64) {
@@ -164,7 +165,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < w && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < w && i <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -209,7 +210,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < h && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < h && i >= 2 * gl && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
   }
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
   for (int i = lane; i < h && !(dbg & DBG_NORHS); i += 64) {
@@ -234,7 +235,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < h && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < h && i >= 2 * gl && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
