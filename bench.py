@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N>1: independent 8-subdomain blocks per GPU instead of one global problem with a cross-GPU halo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gmres", action="store_true")
+    ap.add_argument("--bgmres", type=int, default=0, metavar="MU", help="extra leg: Block GMRES on MU consistent random right-hand sides (configs[4] solves 8 at a time)")
     ap.add_argument("--no-two-level", action="store_true")
     ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level leg")
     ap.add_argument("--problem", choices=("poisson", "elasticity"), default="poisson",
@@ -200,6 +201,21 @@ def main():
             torch.cuda.synchronize()
             tg = time.perf_counter() - t0
             out["gmres"] = {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
+        if args.bgmres > 1 and world == 1:
+            # Block GMRES (IterativeMethod::BGMRES) on args.bgmres right-hand sides made consistent by one exchange
+            rng = np.random.default_rng(1)
+            rhs = A.exchange([rng.random((s["n"], args.bgmres)) for s in subs])
+            flat, _ = A.pack(rhs)
+            fb = torch.from_numpy(flat).to(dev)
+            xs = torch.zeros_like(fb)
+            A.option_parse("-hpddm_krylov_method bgmres")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            it = A.solve_device(fb.data_ptr(), xs.data_ptr(), args.bgmres)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - t0
+            A.option_parse("-hpddm_krylov_method gmres")
+            out["bgmres"] = {"rhs": args.bgmres, "iterations": it, "seconds": tg, "iters_per_sec": it / tg, "rhs_iters_per_sec": it * args.bgmres / tg, "tol": 1e-6}
         if not args.no_two_level and world == 1:
             out["two_level"] = two_level(A, subs, args, np, mu, reps)
         elif tl:
