@@ -274,7 +274,8 @@ def two_level(A, subs, args, np, mu, reps):
     bytes_panel = 2.0 * n * nu * 8.0 + 3.0 * n * mu * 8.0   # Z read twice + D r read, Z y written, ...
     return {"geneo_nu": nu, "coarse_dim": int(A.stats()["coarse_dim"]), "deflation_ms": t_defl * 1e3, "apply_ms": t_apply * 1e3,
             "applies_per_sec": 1.0 / t_apply, "deflation_panel_GBps": bytes_panel / t_defl / 1e9, "deflation_flops": 4.0 * n * nu * mu,
-            "coarse_setup_seconds": round(t_coarse, 2), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64)",
+            "coarse_setup_seconds": round(t_coarse, 2),
+            "kernel": "k_zt_stream + k_z_stream (GEMV-shaped: streaming VALU)" if mu <= 2 else "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64)",
             "coarse_space": ("GenEO (solveGEVP), largest kept eigenvalue %.3f, %.1f s" % (lam_max, tg)) if args.geneo else "monomials of degree <= 3 (stand-in)",
             "gmres": {"iterations": it2, "seconds": t_gm, "iters_per_sec": it2 / t_gm}}
 

@@ -122,6 +122,74 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
   }
 }
 
+// ---- one or two right-hand sides: the contraction is a (block) GEMV, 0.25-0.5 flop/B -- plain streaming kernels read Z
+// once with every thread on its own row (columns of Z are contiguous: coalesced), no LDS staging ----
+// partial[s][blk][m - m0][nu] (same layout as k_zt_mfma) for the 8 deflation vectors [m0 + 8 z, m0 + 8 z + 8), z = blockIdx.z
+template <int MU>
+__global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int m0)
+{
+  const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  const int       k0 = m0 + 8 * blockIdx.z, kc = min(8, nu_s - k0);
+  double          acc[8][MU];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc[k][nu] = 0.0;
+  if (kc > 0) {
+    const double *Zs = Z + zoff[s] + (long long)k0 * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+      double dr[MU];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) dr[nu] = d[v0 + i] * in[v0 * MU + (long long)nu * n + i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double z = k < kc ? Zs[(long long)k * n + i] : 0.0;
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) acc[k][nu] = fma(z, dr[nu], acc[k][nu]);
+      }
+    }
+  }
+  __shared__ double red[4][8 * MU];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double v = acc[k][nu];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) red[wave][k * MU + nu] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 8 * MU) {
+    const int k = threadIdx.x / MU, nu = threadIdx.x - k * MU;
+    partial[((long long)(s * gridDim.x + blockIdx.x)) * 512 + (8 * blockIdx.z + k) * 16 + nu] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+// out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu], one thread per row
+template <int MU>
+__global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim)
+{
+  extern __shared__ double ys[]; // [nu_s][MU]
+  const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  for (int idx = threadIdx.x; idx < nu_s * MU; idx += 256) ys[idx] = y[(long long)(idx % MU) * cdim + coff[s] + idx / MU];
+  __syncthreads();
+  const double *Zs = Z + zoff[s];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    double acc[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc[nu] = 0.0;
+    for (int k = 0; k < nu_s; ++k) {
+      const double z = Zs[(long long)k * n + i];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) acc[nu] = fma(z, ys[k * MU + nu], acc[nu]);
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) out[v0 * MU + (long long)nu * n + i] = acc[nu];
+  }
+}
+
 void Schwarz::deflation_panel(const double *in, double *zy, int mu)
 {
   hipStream_t st = library_stream();
@@ -130,6 +198,21 @@ void Schwarz::deflation_panel(const double *in, double *zy, int mu)
   const int    nblk = std::max(1, std::min(128, (nmax + ZT_ROWS - 1) / ZT_ROWS));
   const size_t lds  = (size_t)(ZT_NU + ZT_MU) * ZT_LD * sizeof(double);
   zt_partial.alloc((size_t)nsub * nblk * 512);
+  if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
+    // GEMV-shaped: streaming kernels (the MFMA tiles would carry 14-15 empty right-hand-side columns)
+    for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
+      const dim3 g((unsigned)nblk, (unsigned)nsub, (unsigned)((std::min(ZT_NU, numax - m0) + 7) / 8));
+      if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
+      else hipLaunchKernelGGL(k_zt_stream<2>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc_d.p, mu, cdim, m0, 0);
+    }
+    coarse_solve(uc_d.p, uc2_d.p, mu);
+    const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
+    const size_t l2 = (size_t)numax * mu * sizeof(double);
+    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, cdim);
+    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, cdim);
+    return;
+  }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
