@@ -250,21 +250,31 @@ class Schwarz:
         self._recv = torch.zeros_like(self._send)
         self._red = torch.zeros(4096, dtype=torch.float64, device="cpu" if host_staging else device)
 
+        plans = {}  # per mu: the (send, recv, peer) views of the two buffers, built once
+
         def halo(ctx, mu):
             try:
-                ops, stage = [], []
-                for rank, cnt, off in peers:
-                    sb, rb = self._send[off * mu:(off + cnt) * mu], self._recv[off * mu:(off + cnt) * mu]
+                plan = plans.get(mu)
+                if plan is None:
+                    plan = []
+                    for rank, cnt, off in peers:
+                        sb, rb = self._send[off * mu:(off + cnt) * mu], self._recv[off * mu:(off + cnt) * mu]
+                        rb_h = torch.empty(cnt * mu, dtype=torch.float64) if host_staging else None
+                        plan.append((rank, sb, rb, rb_h))
+                    plans[mu] = plan
+                ops = []
+                for rank, sb, rb, rb_h in plan:
                     if host_staging:
-                        sb_h, rb_h = sb.cpu(), torch.empty(cnt * mu, dtype=torch.float64)
-                        stage.append((rb, rb_h))
-                        sb, rb = sb_h, rb_h
-                    ops.append(dist.P2POp(dist.isend, sb, rank))
-                    ops.append(dist.P2POp(dist.irecv, rb, rank))
+                        ops.append(dist.P2POp(dist.isend, sb.cpu(), rank))
+                        ops.append(dist.P2POp(dist.irecv, rb_h, rank))
+                    else:
+                        ops.append(dist.P2POp(dist.isend, sb, rank))
+                        ops.append(dist.P2POp(dist.irecv, rb, rank))
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-                for rb, rb_h in stage:
-                    rb.copy_(rb_h)
+                if host_staging:
+                    for rank, sb, rb, rb_h in plan:
+                        rb.copy_(rb_h)
                 torch.cuda.synchronize(device)
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
