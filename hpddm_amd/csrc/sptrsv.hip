@@ -48,7 +48,7 @@ __device__ static inline SnView view(const SnDesc &d)
 }
 // developer aid (HPDDM_HIP_DBG, wrong results): 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand
 // side staging, 8 skip the panel loads
-enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8 };
+enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8, DBG_NOMFMA = 16 }; // 16: the VALU tiles instead of the MFMA ones (exact, for comparison)
 
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
 
@@ -349,6 +349,87 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
   if (tid < t.nr && !(dbg & DBG_NOSTORE)) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
 }
 
+// Forward tile of a wide panel with 4 or 8 right-hand sides on the f64 MFMA pipe: T(rows x MU) = F(rows x w) f(w x MU) is a
+// GEMM with N = MU, so the accumulators of a 16-row group live in ONE MFMA fragment (4 registers per lane instead of
+// 16 x 8 / 64 x ... per-row sums) and a chunk of the right-hand side is staged once for ALL the rows of the tile.
+// v_mfma_f64_16x16x4: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[(lane >> 4) + 4 reg][lane & 15].
+// Here i = panel row, k = panel column, j = right-hand side (16 - MU columns of the tile stay empty).  A lane loads 4
+// consecutive panel entries (32 bytes; a wavefront covers 16 rows x 128 bytes) and feeds them to 4 MFMAs whose k index
+// stands for the columns 4g + q, q = 0..3.  (The backward tiles stay on the VALU: there the lanes already own their
+// outputs, and on gfx950 the f64 MFMA rate equals the VALU rate, so a half-empty tile costs twice the arithmetic --
+// measured 5.6 vs 5.3 ms per sweep pair at mu = 8.)
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <int MU>
+__device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
+{
+  const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int     w = d.w, ldw = d.ldw;
+  const int     rend = t.r0 + t.nr;
+  const int     nrg  = (t.nr + 15) >> 4;                 // 16-row groups of the tile: 1..4
+  const int     nrgp = nrg == 3 ? 4 : nrg, wpg = 4 / nrgp; // wavefronts per row group split the columns
+  const int     rg = wave % nrgp, ks = wave / nrgp;
+  const bool    busy = rg < nrg;
+  const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
+  const bool    rvalid = busy && row < rend;
+  double       *red  = lds + (lds_dbl - 512);            // [4 wavefronts][16 rows][8]
+  double       *sums = red - 64 * MU;                    // [MU][64]
+  const int     CW   = ((lds_dbl - 512 - 64 * MU) / MU) & ~15; // columns of the right-hand side staged per chunk
+  const int     tile_lim = min(w, rend);                 // rows of the top block never look right of their diagonal
+  const int     my_lim   = busy ? min(w, R0 + 16) : 0;   // ... and this row group stops at its own last diagonal entry
+  const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
+  v4f64         acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < tile_lim; k0 += CW) {
+    __syncthreads();
+    const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
+    for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
+      const int nu = idx / (kend - k0), i = idx - nu * (kend - k0), col = k0 + i;
+      double    v  = 0.0;
+      if (col < w) {
+        v = bb[(long long)nu * d.n + d.c0 + col];
+        if (d.has_src && !pregathered)
+          for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
+      }
+      lds[i * MU + nu] = v;
+    }
+    __syncthreads();
+    const int cend = min(kend, (my_lim + 15) & ~15);
+    for (int cb = k0 + 16 * ks; cb < cend; cb += 16 * wpg) {
+      dbl2 a01 = {0.0, 0.0}, a23 = {0.0, 0.0};
+      if (rvalid) {
+        a01 = *(gcd2_t)(Frow + cb);
+        a23 = *(gcd2_t)(Frow + cb + 2);
+      }
+      const int c = cb + 4 * g; // this lane's first column
+      if (row < w) {            // triangular top block: nothing right of the diagonal
+        a01.x = c <= row ? a01.x : 0.0;
+        a01.y = c + 1 <= row ? a01.y : 0.0;
+        a23.x = c + 2 <= row ? a23.x : 0.0;
+        a23.y = c + 3 <= row ? a23.y : 0.0;
+      }
+      const double *fl = lds + (c - k0) * MU + j;
+      const double  b0 = j < MU ? fl[0] : 0.0, b1 = j < MU ? fl[MU] : 0.0, b2 = j < MU ? fl[2 * MU] : 0.0, b3 = j < MU ? fl[3 * MU] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b3, acc, 0, 0, 0);
+    }
+  }
+  // D[(lane >> 4) + 4 reg][lane & 15] -> per-wavefront partial sums, then one sum per row over the column split
+  if (j < MU) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[(wave * 16 + g + 4 * reg) * MU + j] = acc[reg];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < t.nr * MU; idx += WG_THREADS) {
+    const int rl = idx / MU, nu = idx - rl * MU, rgx = rl >> 4;
+    double    v  = 0.0;
+    for (int k = 0; k < wpg; ++k) v += red[((rgx + nrgp * k) * 16 + (rl & 15)) * MU + nu];
+    sums[nu * 64 + rl] = v;
+  }
+  __syncthreads();
+  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+}
+
 template <int MU, int FP>
 __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts, int dbg)
 {
@@ -493,7 +574,10 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
       const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
       double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-      fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+      if constexpr (MU >= 4) {
+        if (dbg & DBG_NOMFMA) fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+        else fwd_block_tile_mfma<MU>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0);
+      } else fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -912,7 +996,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
-    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU, lds_wave) : lds_wave;
+    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 512 : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
     if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
     else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
   }

@@ -86,10 +86,12 @@ def test_wide_panels_in_the_host_factorised_kinds(kind):
     S = hpddm.Subdomain()
     S.numfact(n, Min.indptr, Min.indices, Min.data, sym=sym)
     assert S.info()["kind"] == (1 if kind == "ldlt" else 2)
-    b = np.asfortranarray(rng.random((n, 5)))
-    x = S.solve(b)
-    ref = spl.splu(sp.csc_matrix(M)).solve(b)
-    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max()
+    lu = spl.splu(sp.csc_matrix(M))
+    for mu in (5, 8, 17):   # 8: the MFMA tiles of the forward sweep; 17 = 8 + 8 + 1
+        b = np.asfortranarray(rng.random((n, mu)))
+        x = S.solve(b)
+        ref = lu.solve(b)
+        assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max(), (kind, mu)
     S.destroy()
 
 

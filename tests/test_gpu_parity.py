@@ -225,11 +225,13 @@ def test_device_levels_of_the_factorisation():
     L.sort_indices()
     S = hpddm.Subdomain()
     S.numfact(n, L.indptr, L.indices, L.data, sym=True, spd=True)
-    b = np.asfortranarray(np.random.default_rng(11).random((n, 2)))
-    x = S.solve(b)
-    assert np.abs(A @ x - b).max() / np.abs(b).max() < 1e-10
-    ref = spl.splu(sp.csc_matrix(A)).solve(b)
-    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    lu = spl.splu(sp.csc_matrix(A))
+    for mu in (2, 8):   # 8 right-hand sides take the MFMA tiles on the wide panels
+        b = np.asfortranarray(np.random.default_rng(11).random((n, mu)))
+        x = S.solve(b)
+        assert np.abs(A @ x - b).max() / np.abs(b).max() < 1e-10
+        ref = lu.solve(b)
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
     S.destroy()
 
 
