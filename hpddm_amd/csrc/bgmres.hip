@@ -339,6 +339,202 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   return std::min(j, max_it);
 }
 
+// Block conjugate gradient: IterativeMethod::BCG (include/HPDDM_CG.hpp:169-337) -- the variant that keeps the block of search
+// directions D-orthonormal by a CholQR every iteration (gamma), with D-weighted block inner products.  Small matrices are
+// row-major here: M[a * mu + b].  Returns -2 when the reference would hand over to CG (rank-deficient block).
+template <int MU>
+static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
+{
+  constexpr int mu = MU;
+  A.reserve(mu);
+  hipStream_t     st        = library_stream();
+  const double    tol       = A.getopt("tol", 1.0e-6);
+  const int       max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int       verbosity = (int)A.getopt("verbosity", 0);
+  const long long cnt       = A.ntot * mu;
+  const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  const int       nblk = 64;
+  DevBuf<double>  P, Z, R, T, partial, gram_d, coef_d;
+  P.alloc((size_t)cnt), Z.alloc((size_t)cnt), R.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  partial.alloc((size_t)nblk * mu * mu), gram_d.alloc((size_t)mu * mu), coef_d.alloc((size_t)mu * mu);
+  // G[a * mu + b] = <V[., a], W[., b]>_D
+  auto gram = [&](const double *V, const double *W, std::vector<double> &G) {
+    G.resize((size_t)mu * mu);
+    hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, 1), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, V, cnt, W, partial.p);
+    hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), mu * mu) == 0, "all-reduce failed");
+  };
+  // the reference forms the upper triangle (gemmt "U") and mirrors it
+  auto sym_upper = [&](std::vector<double> &G) {
+    for (int a = 0; a < mu; ++a)
+      for (int c = 0; c < a; ++c) G[(size_t)a * mu + c] = G[(size_t)c * mu + a];
+  };
+  // W = beta W + sign * V C
+  auto axpy_block = [&](const double *V, const std::vector<double> &C, double sign, double beta, double *W) {
+    HIP_OK(hipMemcpyAsync(coef_d.p, C.data(), sizeof(double) * mu * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * mu * mu, st, A.voff_d.p, A.n_d.p, V, cnt, 1, coef_d.p, sign, beta, W);
+  };
+  // Cholesky G = U^T U (upper, row-major); false on a non-positive pivot
+  auto chol_upper = [&](const std::vector<double> &G, std::vector<double> &U) {
+    U.assign((size_t)mu * mu, 0.0);
+    for (int j = 0; j < mu; ++j) {
+      double dj = G[(size_t)j * mu + j];
+      for (int k = 0; k < j; ++k) dj -= U[(size_t)k * mu + j] * U[(size_t)k * mu + j];
+      if (!(dj > 0.0)) return false;
+      dj                    = std::sqrt(dj);
+      U[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        double v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= U[(size_t)k * mu + j] * U[(size_t)k * mu + c];
+        U[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    return true;
+  };
+  // X <- U^{-T} X  (U upper: forward substitution with U^T), X <- U^{-1} X (backward), both column by column
+  auto solve_ut = [&](const std::vector<double> &U, std::vector<double> &X) {
+    for (int c = 0; c < mu; ++c)
+      for (int i = 0; i < mu; ++i) {
+        double v = X[(size_t)i * mu + c];
+        for (int k = 0; k < i; ++k) v -= U[(size_t)k * mu + i] * X[(size_t)k * mu + c];
+        X[(size_t)i * mu + c] = v / U[(size_t)i * mu + i];
+      }
+  };
+  auto solve_u = [&](const std::vector<double> &U, std::vector<double> &X) {
+    for (int c = 0; c < mu; ++c)
+      for (int i = mu - 1; i >= 0; --i) {
+        double v = X[(size_t)i * mu + c];
+        for (int k = i + 1; k < mu; ++k) v -= U[(size_t)i * mu + k] * X[(size_t)k * mu + c];
+        X[(size_t)i * mu + c] = v / U[(size_t)i * mu + i];
+      }
+  };
+  // QR of the block W in the D inner product: gamma (upper), W <- W gamma^{-1}; false when rank deficient
+  auto cholqr = [&](double *W, std::vector<double> &gamma) {
+    std::vector<double> G;
+    gram(W, W, G);
+    if (!chol_upper(G, gamma)) return false;
+    std::vector<double> Ginv((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) Ginv[(size_t)c * mu + c] = 1.0;
+    solve_u(gamma, Ginv); // gamma^{-1}
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    axpy_block(T.p, Ginv, 1.0, 0.0, W);
+    return true;
+  };
+  std::vector<double> rho, rho2, rhs, gamma, norm(mu), zz(mu);
+  A.exchange_inplace(x, mu, true); // A.start
+  A.gmv(x, Z.p, mu);
+  hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, Z.p, R.p);
+  A.apply(R.p, P.p, mu);
+  gram(R.p, P.p, rho);
+  sym_upper(rho);
+  rho2 = rho;
+  {
+    double big = 0.0;
+    for (double v : rho) big = std::max(big, std::abs(v));
+    if (!(big > 10.0 * std::numeric_limits<double>::epsilon())) return -2;
+  }
+  if (!cholqr(P.p, gamma)) return -2;
+  for (int nu = 0; nu < mu; ++nu) {
+    double v = 0.0;
+    for (int k = 0; k <= nu; ++k) v += gamma[(size_t)k * mu + nu] * gamma[(size_t)k * mu + nu];
+    norm[nu] = std::sqrt(v);
+  }
+  int i = 1, nhist = 0;
+  while (i <= max_it) {
+    A.gmv(P.p, Z.p, mu);
+    solve_ut(gamma, rho2);                    // rho2 <- gamma^{-T} rho2
+    gram(P.p, Z.p, rhs);                      // p^T D A p
+    sym_upper(rhs);
+    {
+      std::vector<double> U;
+      if (!chol_upper(rhs, U)) return -2;     // ppsv
+      solve_ut(U, rho2);
+      solve_u(U, rho2);                       // rho2 = alpha
+    }
+    axpy_block(P.p, rho2, 1.0, 1.0, x);       // x += p alpha
+    axpy_block(Z.p, rho2, -1.0, 1.0, R.p);    // r -= A p alpha
+    A.apply(R.p, Z.p, mu);                    // z = M^{-1} r
+    gram(R.p, Z.p, rhs);                      // new rho = r^T D z
+    sym_upper(rhs);
+    {
+      std::vector<double> G;
+      gram(Z.p, Z.p, G);
+      for (int nu = 0; nu < mu; ++nu) zz[nu] = G[(size_t)nu * mu + nu];
+    }
+    int    conv = 0, which = 0;
+    double worst = -1.0;
+    for (int nu = 0; nu < mu; ++nu) {
+      const double pt = std::sqrt(zz[nu]);
+      if ((tol > 0.0 && pt / norm[nu] <= tol) || (tol < 0.0 && pt <= -tol)) ++conv;
+      const double key = tol > 0.0 ? pt / norm[nu] : pt;
+      if (key > worst) {
+        worst = key;
+        which = nu;
+      }
+    }
+    const double beta = std::sqrt(zz[which]);
+    if (history && nhist < history_cap) history[nhist] = beta;
+    ++nhist;
+    if (verbosity > 2) printf("BCG: %3d %e %e %e < %e\n", i, beta, norm[which], beta / norm[which], tol);
+    if (conv == mu) break;
+    if (++i <= max_it) {
+      rho2 = rhs;                             // the new rho, kept for the next iteration
+      std::vector<double> U;
+      if (!chol_upper(rho, U)) return -2;     // posv: rhs <- rho_old^{-1} rho_new
+      solve_ut(U, rhs);
+      solve_u(U, rhs);
+      std::vector<double> brhs((size_t)mu * mu, 0.0); // trmm: gamma * rhs
+      for (int a = 0; a < mu; ++a)
+        for (int c = 0; c < mu; ++c) {
+          double v = 0.0;
+          for (int k = a; k < mu; ++k) v += gamma[(size_t)a * mu + k] * rhs[(size_t)k * mu + c];
+          brhs[(size_t)a * mu + c] = v;
+        }
+      // p <- z + p brhs
+      HIP_OK(hipMemcpyAsync(T.p, P.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipMemcpyAsync(P.p, Z.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      DevBuf<double> Told;
+      Told.alloc((size_t)cnt);
+      HIP_OK(hipMemcpyAsync(Told.p, T.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_block(Told.p, brhs, 1.0, 1.0, P.p);
+      if (!cholqr(P.p, gamma)) return -2;
+      rho = rho2;
+    }
+  }
+  if (verbosity) {
+    if (i != max_it + 1) printf("BCG converges after %d iteration%s\n", i, i > 1 ? "s" : "");
+    else printf("BCG does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(i, max_it);
+}
+
+int Schwarz::bcg(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  // same hand-over as the reference (include/HPDDM_CG.hpp:180-186): not a symmetric preconditioner -> GMRES; flexible -> CG
+  const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
+  int it;
+  switch (mu) {
+  case 1: it = bcg_impl<1>(*this, b, x, history, history_cap); break;
+  case 2: it = bcg_impl<2>(*this, b, x, history, history_cap); break;
+  case 3: it = bcg_impl<3>(*this, b, x, history, history_cap); break;
+  case 4: it = bcg_impl<4>(*this, b, x, history, history_cap); break;
+  case 5: it = bcg_impl<5>(*this, b, x, history, history_cap); break;
+  case 6: it = bcg_impl<6>(*this, b, x, history, history_cap); break;
+  case 7: it = bcg_impl<7>(*this, b, x, history, history_cap); break;
+  case 8: it = bcg_impl<8>(*this, b, x, history, history_cap); break;
+  default: HH_CHECK(false, "BCG: 1 <= mu <= 8 in this build"); it = -1;
+  }
+  if (it == -2) return cg(b, x, mu, history, history_cap); // rank-deficient block: CG, as the reference does
+  return it;
+}
+
 int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int history_cap)
 {
   HH_CHECK(factored, "solve before CallNumfact");
@@ -364,7 +560,8 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   const int method = (int)getopt("krylov_method", 0);
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
   if (method == 2) return cg(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: only gmres, bgmres and cg are built");
+  if (method == 3) return bcg(b, x, mu, history, history_cap);
+  HH_CHECK(method == 0, "krylov_method: only gmres, bgmres, cg and bcg are built");
   return gmres(b, x, mu, history, history_cap);
 }
 

@@ -43,6 +43,8 @@ CASES = [
     ("p40_oras_og", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method oras -optimized_shift 30"),
     ("p40_soras_os_sym", 4, 1, "-Nx 40 -Ny 40 -overlap 2 -symmetric_csr=1 -hpddm_schwarz_method soras -optimized_shift 30"),
     ("p40_soras_os_deflated", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method soras -optimized_shift 20 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    ("p40_bcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bcg -hpddm_schwarz_method asm"),
+    ("p30_6ranks_bcg_asm_sym_mu2", 6, 2, "-Nx 30 -Ny 30 -symmetric_csr=1 -hpddm_krylov_method bcg -hpddm_schwarz_method asm -hpddm_operator_spd"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),
@@ -76,7 +78,7 @@ def run_case(name, ranks, mu, opts, tmp):
         print(res.stdout[-2000:], res.stderr[-2000:])
         raise SystemExit(f"{name}: harness failed")
     hist = []
-    for m in re.finditer(r"^(?:B?GMRES|CG):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
+    for m in re.finditer(r"^(?:B?GMRES|B?CG):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
         hist.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))))
     data = {"ranks": np.int32(ranks), "mu": np.int32(mu), "options": np.array(opts),
             "history": np.array(hist, dtype=np.float64).reshape(-1, 4)}

@@ -297,3 +297,23 @@ def test_cg_matches_reference():
     _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
     _close(A.apply(f), gu.vecs(g, "apply_out"), 1e-10, "ASM apply")
     A.destroy()
+
+
+@pytest.mark.parametrize("name,skip", [("p30_6ranks_bcg_asm_sym_mu2", 0), ("p40_bcg_asm_mu3", 4)])
+def test_bcg_matches_reference(name, skip):
+    """Block CG (include/HPDDM_CG.hpp:169-337).  On these inputs the reference's own BCG does not reach 1e-6 in 100 iterations
+    (first case) or meets a rank-deficient block after 4 iterations and hands over to CG (second case, `skip` = the BCG lines
+    of its log before the hand-over): what is pinned is that we do exactly the same -- iteration count, residual history,
+    final residuals.  The history prints the right-hand side with the largest relative residual; with two that are equal to
+    4 digits the pick flips between the runs, hence the few-percent band on the history and the tight one on the result."""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0])
+    ref = g["history"][skip:]
+    assert len(hist) == len(ref)
+    assert np.all(np.abs(hist - ref[:, 1]) <= 0.05 * ref[:, 1])
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3)
+    A.destroy()
