@@ -317,3 +317,36 @@ def test_bcg_matches_reference(name, skip):
     assert np.all(np.abs(hist - ref[:, 1]) <= 0.05 * ref[:, 1])
     assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3)
     A.destroy()
+
+
+def test_full_size_properties_config2():
+    """BASELINE.json configs[1] at its full size (128^3, 8 subdomains of 65^3): size-independent properties, no oracle --
+    residual of the direct solves, partition of unity, linearity of the apply, agreement of the 8-right-hand-side sweep
+    (MFMA forward tiles, register blocks) with eight single sweeps, GMRES iteration count and true residual."""
+    import scipy.sparse as sp
+    subs = generate3d(128, 8, 1, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    A.call_numfact()
+    rng = np.random.default_rng(17)
+    f = [s["f"] for s in subs]
+    x = A.local_solve(f)
+    for sd, xs, fs in zip(subs[:2], x[:2], f[:2]):
+        M = sp.csr_matrix((sd["a"], sd["ja"], sd["ia"]), shape=(sd["n"], sd["n"]))
+        M = M + sp.tril(M, -1).T
+        assert np.linalg.norm(M @ xs - fs) / np.linalg.norm(fs) < 1e-10
+    ones = [np.ones(s["n"]) for s in subs]
+    _close(A.exchange(ones), ones, 1e-14, "partition of unity")
+    u = [rng.random(s["n"]) for s in subs]
+    v = [rng.random(s["n"]) for s in subs]
+    au, av = A.apply(u), A.apply(v)
+    comb = A.apply([2.0 * a - 3.0 * b for a, b in zip(u, v)])
+    _close(comb, [2.0 * a - 3.0 * b for a, b in zip(au, av)], 1e-11, "linearity of the apply")
+    X = [rng.random((s["n"], 8)) for s in subs]
+    Y = A.local_solve(X)
+    for k in (0, 3, 7):
+        single = A.local_solve([np.ascontiguousarray(xs[:, k]) for xs in X])
+        _close([ys[:, k] for ys in Y], single, 1e-11, f"column {k} of the 8-right-hand-side sweep")
+    it, sol = A.solve(f)
+    res = A.compute_residual(sol, f)
+    assert it == 26 and res[1] / res[0] <= 2e-6
+    A.destroy()
