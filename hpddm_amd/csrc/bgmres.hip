@@ -218,13 +218,16 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   std::vector<double> H((size_t)ldh * mu * m, 0.0), s((size_t)ldh * mu, 0.0), tau((size_t)m * 2 * mu, 0.0), norm(mu), G, R;
   auto                Hc = [&](int i) { return H.data() + (size_t)i * mu * ldh; };
   // ---- initializeNorm ----
-  A.exchange_inplace(x, mu, true);
+  A.start(b, x, mu);
   {
     std::vector<double> nb;
     if (variant == VARIANT_LEFT) {
       A.apply(b, vk(0), mu);
       gram(vk(0), 1, vk(0), nb);
-    } else gram(b, 1, b, nb);
+    } else {
+      const double *bn = A.norm_rhs(b, Ax.p, mu);
+      gram(bn, 1, bn, nb);
+    }
     for (int nu = 0; nu < mu; ++nu) {
       norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu]);
       if (norm[nu] < HPDDM_EPS) norm[nu] = 1.0;
@@ -424,7 +427,7 @@ static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int
     return true;
   };
   std::vector<double> rho, rho2, rhs, gamma, norm(mu), zz(mu);
-  A.exchange_inplace(x, mu, true); // A.start
+  A.start(b, x, mu); // A.start
   A.gmv(x, Z.p, mu);
   hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, Z.p, R.p);
   A.apply(R.p, P.p, mu);

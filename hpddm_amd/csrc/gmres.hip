@@ -68,11 +68,14 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
   auto                Hn = [&](int nu, int r, int c) -> double & { return H[((size_t)nu * m + c) * (m + 1) + r]; };
   std::vector<short>  conv(mu, (short)-m);
   // ---- initializeNorm: A.start = exchange(x) (include/HPDDM_schwarz.hpp:505) and the norm of b (right) or M^{-1} b (left) ----
-  exchange_inplace(x, mu, true);
+  start(b, x, mu);
   if (variant == VARIANT_LEFT) {
     apply(b, vk(0), mu);
     wdots(vk(0), 0, 1, vk(0), mu, norm.data());
-  } else wdots(b, 0, 1, b, mu, norm.data());
+  } else {
+    const double *bn = norm_rhs(b, Ax.p, mu); // penalised entries count divided by HPDDM_PEN (include/HPDDM_iterative.hpp:463-467)
+    wdots(bn, 0, 1, bn, mu, norm.data());
+  }
   int  j     = 1;
   int  nhist = 0;
   bool breakdown = false;
@@ -263,7 +266,7 @@ int Schwarz::cg(const double *b, double *x, int mu, double *history, int history
     HIP_OK(hipStreamSynchronize(st));
     hipLaunchKernelGGL(k_lincomb, g2, dim3(256), 0, st, voff_d.p, n_d.p, v, 0LL, 1, coef.p, 1.0, 1.0, w, mu);
   };
-  exchange_inplace(x, mu, true);                                             // A.start
+  start(b, x, mu);                                                           // A.start
   gmv(x, z.p, mu);
   hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, z.p, r.p);
   apply(r.p, p.p, mu);

@@ -417,6 +417,7 @@ void Schwarz::build_device()
   }
   HIP_OK(hipStreamSynchronize(st));
   device_ready = true;
+  build_boundary_conditions();
 }
 
 void Schwarz::reserve(int mu)
@@ -807,18 +808,106 @@ void Schwarz::wdots(const double *V, long long ldv, int k, const double *w, int 
   }
 }
 
+// ---- penalised Dirichlet rows (HPDDM_PEN convention of FreeFEM-style inputs) ----
+static constexpr double HPDDM_PEN_ = 1.0e30;
+// x = b / bc on the boundary-condition rows
+__global__ void k_bc_start(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ bc, const double *__restrict__ b, double *__restrict__ x, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = bc[v0 + i];
+    if (v != 0.0)
+      for (int nu = 0; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + i] = b[v0 * mu + (long long)nu * n + i] / v;
+  }
+}
+// mode 0: out = b with the penalised entries (|b| > PEN * EPS on a boundary-condition row) divided by PEN   (initializeNorm)
+// mode 1: out = f with every entry |f| > EPS * PEN divided by PEN                                          (computeResidual, ||f||)
+// mode 2: out = r with the boundary-condition rows zeroed                                                 (computeResidual, ||A x - f||)
+__global__ void k_bc_filter(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ bc, const double *__restrict__ in, double *__restrict__ out, int mu, int mode)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const bool on = bc[v0 + i] != 0.0;
+    for (int nu = 0; nu < mu; ++nu) {
+      const long long o = v0 * mu + (long long)nu * n + i;
+      double          v = in[o];
+      if (mode == 0) v = (on && fabs(v) > HPDDM_PEN_ * HPDDM_EPS) ? v / HPDDM_PEN_ : v;
+      else if (mode == 1) v = fabs(v) > HPDDM_EPS * HPDDM_PEN_ ? v / HPDDM_PEN_ : v;
+      else v = on ? 0.0 : v;
+      out[o] = v;
+    }
+  }
+}
+
+void Schwarz::build_boundary_conditions()
+{
+  // Subdomain::boundaryCond (include/HPDDM_subdomain.hpp:310-329) on the matrix as it was handed over: the diagonal entry when
+  // it is at least HPDDM_EPS * HPDDM_PEN, or when the stored row up to the diagonal is that of the identity
+  std::vector<double> bc((size_t)ntot, 0.0);
+  has_bc = false;
+  for (int s = 0; s < nsub; ++s) {
+    const SchwarzSub &S = subs[s];
+    const int         base = S.base0;
+    for (int i = 0; i < S.n; ++i) {
+      const int lo = S.ia0[i] - base, hi = S.ia0[i + 1] - base;
+      if (lo == hi) continue;
+      int stop = hi;
+      if (!S.sym0) stop = (int)(std::upper_bound(S.ja0.begin() + lo, S.ja0.begin() + hi, i + base) - S.ja0.begin());
+      if ((S.sym0 || stop < hi || S.ja0[hi - 1] - base == i) && S.ja0[std::max(1, stop) - 1] - base == i && std::abs(S.a0[stop - 1]) < HPDDM_EPS * HPDDM_PEN_) {
+        bool identity = true;
+        for (int p = lo; p < stop && identity; ++p) {
+          const int j = S.ja0[p] - base;
+          if ((j != i && std::abs(S.a0[p]) > HPDDM_EPS) || (j == i && std::abs(S.a0[p] - 1.0) > HPDDM_EPS)) identity = false;
+        }
+        if (!identity) continue;
+      }
+      const double v = S.a0[stop - 1];
+      if (std::abs(v) > HPDDM_EPS) {
+        bc[(size_t)voff[s] + i] = v;
+        has_bc                  = true;
+      }
+    }
+  }
+  if (has_bc) {
+    bc_d.upload(bc, library_stream());
+    HIP_OK(hipStreamSynchronize(library_stream()));
+  }
+}
+
+void Schwarz::start(const double *b, double *x, int mu)
+{
+  // Schwarz::start (include/HPDDM_schwarz.hpp:496-514)
+  if (has_bc) hipLaunchKernelGGL(k_bc_start, grid2(nmax, nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, bc_d.p, b, x, mu);
+  exchange_inplace(x, mu, true);
+}
+
+const double *Schwarz::norm_rhs(const double *b, double *scratch, int mu)
+{
+  if (!has_bc) return b;
+  hipLaunchKernelGGL(k_bc_filter, grid2(nmax, nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, bc_d.p, b, scratch, mu, 0);
+  return scratch;
+}
+
 void Schwarz::compute_residual(const double *x, const double *f, double *storage, int mu)
 {
-  // Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: storage[2nu] = ||f||_D, storage[2nu+1] = ||A x - f||_D
-  // (penalised boundary rows of the reference's HPDDM_PEN convention do not occur with the generators of this path and are
-  //  treated as ordinary rows)
+  // Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: storage[2nu] = ||f||_D, storage[2nu+1] = ||A x - f||_D;
+  // boundary-condition rows do not count in the residual and penalised entries of f are divided by HPDDM_PEN
   reserve(mu);
   const size_t cnt = (size_t)ntot * mu;
   gmv(x, w1.p, mu);
   axpy(-1.0, f, w1.p, (long long)cnt);
+  const double *fn = f;
+  if (has_bc) {
+    hipStream_t st = library_stream();
+    hipLaunchKernelGGL(k_bc_filter, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, bc_d.p, w1.p, w1.p, mu, 2);
+    hipLaunchKernelGGL(k_bc_filter, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, bc_d.p, f, w2.p, mu, 1);
+    fn = w2.p;
+  }
   std::vector<double> r(mu), b(mu);
   wdots(w1.p, 0, 1, w1.p, mu, r.data());
-  wdots(f, 0, 1, f, mu, b.data());
+  wdots(fn, 0, 1, fn, mu, b.data());
   for (int nu = 0; nu < mu; ++nu) {
     storage[2 * nu]     = std::sqrt(b[nu]);
     storage[2 * nu + 1] = std::sqrt(r[nu]);

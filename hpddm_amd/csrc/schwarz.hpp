@@ -135,6 +135,13 @@ struct Schwarz {
   void diag(const double *in, double *out, int mu);
   void axpy(double alpha, const double *x, double *y, long long cnt);
   void compute_residual(const double *x, const double *f, double *storage, int mu);
+  // penalised Dirichlet rows (Subdomain::boundaryConditions, include/HPDDM_subdomain.hpp:310-336): bc_d[i] = diagonal entry of the
+  // rows that carry a boundary condition, 0 elsewhere; has_bc false when there is none (then nothing below does anything)
+  DevBuf<double> bc_d;
+  bool           has_bc = false;
+  void           build_boundary_conditions();
+  void           start(const double *b, double *x, int mu);                 // Schwarz::start: x = b / a_ii on those rows, then exchange
+  const double  *norm_rhs(const double *b, double *scratch, int mu);        // initializeNorm: penalised entries of b divided by HPDDM_PEN
   int  gmres(const double *b, double *x, int mu, double *history, int history_cap);
   int  cg(const double *b, double *x, int mu, double *history, int history_cap);           // gmres.hip
   int  bgmres(const double *b, double *x, int mu, double *history, int history_cap);       // bgmres.hip

@@ -45,6 +45,9 @@ CASES = [
     ("p40_soras_os_deflated", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method soras -optimized_shift 20 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_bcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bcg -hpddm_schwarz_method asm"),
     ("p30_6ranks_bcg_asm_sym_mu2", 6, 2, "-Nx 30 -Ny 30 -symmetric_csr=1 -hpddm_krylov_method bcg -hpddm_schwarz_method asm -hpddm_operator_spd"),
+    ("p40_penalized_mu2", 4, 2, "-Nx 40 -Ny 40 -penalize 1"),
+    ("p40_penalized_left_mu2_ov2", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -penalize 1 -hpddm_variant left"),
+    ("p40_penalized_sym_left", 4, 1, "-Nx 40 -Ny 40 -symmetric_csr=1 -penalize 1 -hpddm_variant left"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),

@@ -26,6 +26,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spl
 
 HPDDM_EPS = 1.0e-12
+HPDDM_PEN = 1.0e30
 
 
 def csr_full(sd):
@@ -188,9 +189,55 @@ class Oracle:
             acc += ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s] * ys[s]).sum(axis=0)
         return acc
 
+    # ---- penalised Dirichlet rows: Subdomain::boundaryCond / boundaryConditions (include/HPDDM_subdomain.hpp:310-336) ----
+    def boundary_conditions(self):
+        """per subdomain, array of n values: the diagonal entry of the rows that carry a boundary condition (a diagonal of
+        at least HPDDM_EPS * HPDDM_PEN, or an identity row), 0 elsewhere.  Follows the reference's test on the stored row
+        up to the diagonal, storage conventions included."""
+        if getattr(self, "_bc", None) is not None:
+            return self._bc
+        out = []
+        for sd in self.subs:
+            n, base = sd["n"], (1 if sd.get("numbering", "C") == "F" else 0)
+            ia, ja, a = np.asarray(sd["ia"]) - base, np.asarray(sd["ja"]) - base, np.asarray(sd["a"], dtype=np.float64)
+            bc = np.zeros(n)
+            for i in range(n):
+                lo, hi = ia[i], ia[i + 1]
+                if lo == hi:
+                    continue
+                stop = hi if sd["sym"] else lo + int(np.searchsorted(ja[lo:hi], i, side="right"))
+                if (sd["sym"] or stop < hi or ja[hi - 1] == i) and ja[max(1, stop) - 1] == i and abs(a[stop - 1]) < HPDDM_EPS * HPDDM_PEN:
+                    row_ok = True
+                    for p in range(lo, stop):
+                        if (ja[p] != i and abs(a[p]) > HPDDM_EPS) or (ja[p] == i and abs(a[p] - 1.0) > HPDDM_EPS):
+                            row_ok = False
+                            break
+                    if not row_ok:
+                        continue
+                bc[i] = a[stop - 1]
+            bc[np.abs(bc) <= HPDDM_EPS] = 0.0
+            out.append(bc)
+        self._bc = out
+        return out
+
+    def start(self, b, x):
+        """Schwarz::start (include/HPDDM_schwarz.hpp:496-514): x_i = b_i / a_ii on the boundary-condition rows, then exchange"""
+        bc = self.boundary_conditions()
+        x = [v.copy() for v in x]
+        for s in range(self.P):
+            m = bc[s] != 0.0
+            if m.any():
+                x[s][m] = (b[s][m].T / bc[s][m]).T
+        return self.exchange(x)
+
     def compute_residual(self, sol, f):
+        # Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: boundary-condition rows do not count in the
+        # residual, and penalised right-hand-side entries are divided by HPDDM_PEN in the norm of f
+        bc = self.boundary_conditions()
         r = [a - b for a, b in zip(self.gmv(sol), f)]
-        nb, nr = np.sqrt(self.wdot(f, f)), np.sqrt(self.wdot(r, r))
+        r = [np.where((bc[s] != 0.0)[:, None] if rr.ndim == 2 else bc[s] != 0.0, 0.0, rr) for s, rr in enumerate(r)]
+        fs = [np.where(np.abs(ff) > HPDDM_EPS * HPDDM_PEN, ff / HPDDM_PEN, ff) for ff in f]
+        nb, nr = np.sqrt(self.wdot(fs, fs)), np.sqrt(self.wdot(r, r))
         out = np.zeros(2 * len(nb))
         out[0::2], out[1::2] = nb, nr
         return out
@@ -202,8 +249,13 @@ class Oracle:
         mu = b[0].shape[1]
         x = [np.zeros_like(v) for v in b] if x0 is None else [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1).copy() for v in x0]
         m = max(1, min(restart, max_it))
-        x = self.exchange(x)                                        # A.start
-        norm = self.wdot(self.apply(b), self.apply(b)) if variant == "left" else self.wdot(b, b)
+        x = self.start(b, x)                                        # A.start
+        if variant == "left":
+            norm = self.wdot(self.apply(b), self.apply(b))
+        else:  # initializeNorm (include/HPDDM_iterative.hpp:441-471): penalised entries of b count divided by HPDDM_PEN
+            bc = self.boundary_conditions()
+            bs = [np.where((np.abs(bb) > HPDDM_PEN * HPDDM_EPS) & (bc[s] != 0.0)[:, None], bb / HPDDM_PEN, bb) for s, bb in enumerate(b)]
+            norm = self.wdot(bs, bs)
         conv = np.full(mu, -m)
         hist = []
         j = 1

@@ -15,6 +15,7 @@
  *        -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0 ...]
  */
 #include "schwarz.hpp" /* the reference's examples/schwarz.hpp: typedef K, symCoarse, generate() prototype */
+#include <cmath>
 #include <cstdio>
 #include <random>
 #include <string>
@@ -49,6 +50,7 @@ int main(int argc, char **argv)
              std::forward_as_tuple("generate_random_rhs=<0>", "", HPDDM::Option::Arg::integer), std::forward_as_tuple("symmetric_csr=(0|1)", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("mu=<1>", "number of harness right-hand sides", HPDDM::Option::Arg::positive), std::forward_as_tuple("out=<dir>", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument),
+             std::forward_as_tuple("penalize=<0>", "penalised Dirichlet rows: a_ii = HPDDM_PEN, f_i = HPDDM_PEN * f_i on a deterministic subset of the dofs", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
   const std::string dir  = opt.prefix("out");
@@ -78,6 +80,25 @@ int main(int argc, char **argv)
     std::mt19937 gen(1234 + 17 * rank);
     for (int nu = 1; nu < mu; ++nu)
       for (int i = 0; i < ndof; ++i) f[nu * ndof + i] = f1[i] * (0.5 + (gen() >> 8) * (1.0 / 16777216.0));
+  }
+  if (opt.app()["penalize"] > 0) {
+    /* FreeFEM-style Dirichlet rows (HPDDM_PEN on the diagonal, HPDDM_PEN * g on the right-hand side) on every global grid
+     * point whose number is a multiple of 11: the box of this rank is recomputed like examples/generate.cpp:53-62 does, so
+     * the choice is the same on every rank that holds a copy of the point */
+    const int base = (HPDDM_NUMBERING == 'F');
+    const int Nx = opt.app()["Nx"], Ny = opt.app()["Ny"], ov = opt.app()["overlap"];
+    int       xGrid = (int)std::sqrt((double)size);
+    while (size % xGrid != 0) --xGrid;
+    const int yGrid = size / xGrid, py = rank / xGrid, px = rank - xGrid * py;
+    const int iStart = std::max(px * Nx / xGrid - ov, 0), iEnd = std::min((px + 1) * Nx / xGrid + ov, Nx);
+    const int jStart = std::max(py * Ny / yGrid - ov, 0);
+    for (int i = 0; i < ndof; ++i) {
+      const int gi = (jStart + i / (iEnd - iStart)) * Nx + iStart + i % (iEnd - iStart);
+      if (gi % 11 != 0) continue;
+      for (int p = Mat->ia_[i] - base; p < Mat->ia_[i + 1] - base; ++p)
+        if (Mat->ja_[p] - base == i) Mat->a_[p] = HPDDM_PEN;
+      for (int nu = 0; nu < mu; ++nu) f[nu * ndof + i] *= HPDDM_PEN * (1.0 + 0.25 * std::sin(0.37 * gi));
+    }
   }
   int meta[8] = {rank, size, ndof, Mat->nnz_, Mat->sym_ ? 1 : 0, mu, (int)opt.app()["overlap"], 0};
   dumpd("d_in", d, ndof); /* the generator's weights, before multiplicityScaling */

@@ -50,6 +50,7 @@ def options(g):
 
 
 OPTIMIZED_CASES = ["p40_oras_og", "p40_soras_os_sym", "p40_soras_os_deflated"]
+PENALIZED_CASES = ["p40_penalized_mu2", "p40_penalized_sym_left", "p40_penalized_left_mu2_ov2"]
 
 
 def optimized_matrices(g, subs):

@@ -158,3 +158,29 @@ def test_ragged_partition_with_empty_connectivity_entries():
     got, ref = A.apply(x), orc.apply(x)
     assert max(np.abs(g - r).max() for g, r in zip(got, ref)) < 1e-10 * max(np.abs(r).max() for r in ref)
     A.destroy()
+
+
+def test_penalised_dirichlet_rows():
+    """FreeFEM-style Dirichlet conditions: diagonal entries of 1e30 (HPDDM_PEN, include/HPDDM_define.hpp:48) and right-hand
+    side 1e30 * g on those rows.  The factorisation must keep the 30 orders of magnitude apart."""
+    A = _lap(16).tolil()
+    n = A.shape[0]
+    rng = np.random.default_rng(9)
+    bnd = rng.choice(n, size=n // 10, replace=False)
+    g = rng.random(n)
+    b = rng.random(n)
+    for i in bnd:
+        A[i, i] = 1.0e30
+        b[i] = 1.0e30 * g[i]
+    M = A.tocsr()
+    L = sp.tril(M).tocsr()
+    L.sort_indices()
+    for spd in (True, False):
+        S = hpddm.Subdomain()
+        S.numfact(n, L.indptr, L.indices, L.data, sym=True, spd=spd)
+        x = S.solve(b)
+        assert np.abs(x[bnd] - g[bnd]).max() < 1e-12                        # the Dirichlet values
+        free = np.setdiff1d(np.arange(n), bnd)
+        r = (M @ x - b)[free]
+        assert np.abs(r).max() < 1e-10 * np.abs(b[free]).max()             # the equations of the free dofs
+        S.destroy()

@@ -35,7 +35,7 @@ def _build(g, subs):
     return A, d, opt
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.PENALIZED_CASES)
 def test_functions_match_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -349,4 +349,24 @@ def test_full_size_properties_config2():
     it, sol = A.solve(f)
     res = A.compute_residual(sol, f)
     assert it == 26 and res[1] / res[0] <= 2e-6
+    A.destroy()
+
+
+@pytest.mark.parametrize("name", gu.PENALIZED_CASES)
+def test_penalised_dirichlet_rows_match_reference(name):
+    """same contract as tests/test_oracle_golden.py::test_penalised_dirichlet_rows_match_reference, for the HIP path"""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    ref = g["history"]
+    assert it == int(g["iterations_r0"][0]) and len(hist) == len(ref)
+    if opt["variant"] == "left":
+        assert np.all(np.abs(hist - ref[:, 1]) <= 2e-6 * ref[:, 1])
+        _close(sol, gu.vecs(g, "sol"), 1e-9, "solution")
+        assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-5)
+    else:
+        assert np.all(np.abs(hist[:2] - ref[:2, 1]) <= 1e-4 * ref[:2, 1])
+        assert np.allclose(A.compute_residual(sol, f)[0::2], g["residual_r0"][0::2], rtol=1e-9)
     A.destroy()
