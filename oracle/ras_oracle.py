@@ -20,6 +20,11 @@ Reference anchors (hpddm/hpddm 2.4.0):
   apply                 Schwarz::apply                    include/HPDDM_schwarz.hpp:527-612
   gmres                 IterativeMethod::GMRES + Arnoldi  include/HPDDM_GMRES.hpp:30-158, HPDDM_iterative.hpp:441-522,669-710,272-336
   compute_residual      Schwarz::computeResidual          include/HPDDM_schwarz.hpp:761-803
+  boundary_conditions / start   Subdomain::boundaryConditions, Schwarz::start   include/HPDDM_subdomain.hpp:310-336, HPDDM_schwarz.hpp:496-514
+  numfact(optimized)    Schwarz::callNumfact(A)           include/HPDDM_schwarz.hpp:337-368
+  scale_into_overlap / geneo   Schwarz::scaleIntoOverlap / solveGEVP   include/HPDDM_schwarz.hpp:622-715
+  cg, bcg (module level)   IterativeMethod::CG / BCG      include/HPDDM_CG.hpp:31-168, 169-337
+  bgmres (module level) IterativeMethod::BGMRES + BlockArnoldi   include/HPDDM_GMRES.hpp:159-313, HPDDM_iterative.hpp:523-556,622-640,713-734
 """
 import numpy as np
 import scipy.sparse as sp
@@ -347,3 +352,246 @@ class Oracle:
                 x = update_sol(x)
                 break
         return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist
+
+
+# ======================================================================================================================
+# The other Krylov methods of the path, restated in numpy (test infrastructure, like everything in oracle/): block vectors
+# are lists of (n_s, mu) arrays, block inner products are D-weighted sums over the subdomains.
+# ======================================================================================================================
+def _gram(orc, V, W):
+    """G[a, b] = sum_s sum_i d_i V_s[i, a] W_s[i, b]   (VR / gemmt with Wrapper::diag, include/HPDDM_iterative.hpp:559-582)"""
+    G = np.zeros((V[0].shape[1], W[0].shape[1]))
+    for s in range(orc.P):
+        G += V[s].T @ (orc.d[s][:, None] * W[s])
+    return G
+
+
+def cg(orc, b, tol=1e-6, max_it=100):
+    """IterativeMethod::CG (include/HPDDM_CG.hpp:31-168), non-flexible: one D-weighted preconditioned CG per right-hand side,
+    all advanced together; a right-hand side that has converged keeps its iterate.  Returns (iterations, solution, history)."""
+    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    mu, P = b[0].shape[1], orc.P
+    x = orc.start(b, [np.zeros_like(v) for v in b])
+    r = [bb - g for bb, g in zip(b, orc.gmv(x))]
+    p = orc.apply(r)
+    res = np.sqrt(orc.wdot(p, p))
+    conv = np.full(mu, -max_it)
+    hist = []
+    if np.any(res ** 2 < np.finfo(float).eps ** 2):
+        return 0, [v if mu > 1 else v[:, 0] for v in x], hist
+    last = p
+    i = 0
+    while i < max_it:
+        rz = orc.wdot(r, last)
+        z = orc.gmv(p)
+        pap = orc.wdot(z, p)
+        i += 1
+        alpha = np.where(conv == -max_it, rz / pap, 0.0)
+        x = [xx + pp * alpha for xx, pp in zip(x, p)]
+        r = [rr - zz * alpha for rr, zz in zip(r, z)]
+        z = orc.apply(r)
+        beta = orc.wdot(r, z) / rz
+        nz = np.sqrt(orc.wdot(z, z))
+        p = [zz + pp * beta for zz, pp in zip(z, p)]
+        last = z
+        newly = (conv == -max_it) & (nz / res <= tol)
+        conv[newly] = i
+        worst, which = nz[0], 0
+        for nu in range(mu):
+            if conv[nu] == -max_it and nz[nu] > worst:
+                worst, which = nz[nu], nu
+        hist.append((i, worst, res[which]))
+        if not np.any(conv == -max_it):
+            i -= 1
+            break
+    i += 1
+    return min(i, max_it), [v if mu > 1 else v[:, 0] for v in x], hist
+
+
+def bcg(orc, b, tol=1e-6, max_it=100):
+    """IterativeMethod::BCG (include/HPDDM_CG.hpp:169-337): block CG whose search directions are kept D-orthonormal by a CholQR
+    (gamma) every iteration.  Returns (iterations, solution, history, handed_over): on a rank-deficient block the reference
+    restarts with CG from the current iterate -- reported through `handed_over`, with CG's own count and history."""
+    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    mu = b[0].shape[1]
+
+    def sym_upper(G):
+        return np.triu(G) + np.triu(G, 1).T        # gemmt "U" + mirror
+
+    def cholqr(W):
+        G = _gram(orc, W, W)
+        try:
+            U = np.linalg.cholesky(G).T            # G = U^T U, U upper
+        except np.linalg.LinAlgError:
+            return None, W
+        Ui = np.linalg.inv(U)
+        return U, [w @ Ui for w in W]
+
+    def fallback(x):
+        it, sol, hist = _cg_from(orc, b, x, tol, max_it)
+        return it, sol, hist, True
+
+    x = orc.start(b, [np.zeros_like(v) for v in b])
+    r = [bb - g for bb, g in zip(b, orc.gmv(x))]
+    p = orc.apply(r)
+    rho = sym_upper(_gram(orc, r, p))
+    rho2 = rho.copy()
+    if not np.abs(rho).max() > 10 * np.finfo(float).eps:
+        return fallback(x)
+    gamma, p = cholqr(p)
+    if gamma is None:
+        return fallback(x)
+    norm = np.array([np.linalg.norm(gamma[:nu + 1, nu]) for nu in range(mu)])
+    hist = []
+    i = 1
+    while i <= max_it:
+        z = orc.gmv(p)
+        rho2 = np.linalg.solve(gamma.T, rho2)
+        pap = sym_upper(_gram(orc, p, z))
+        try:
+            np.linalg.cholesky(pap)
+        except np.linalg.LinAlgError:
+            return fallback(x)
+        alpha = np.linalg.solve(pap, rho2)
+        x = [xx + pp @ alpha for xx, pp in zip(x, p)]
+        r = [rr - zz @ alpha for rr, zz in zip(r, z)]
+        z = orc.apply(r)
+        rhs = sym_upper(_gram(orc, r, z))
+        pt = np.sqrt(np.diag(_gram(orc, z, z)))
+        conv = int(np.sum(pt / norm <= tol))
+        which = int(np.argmax(pt / norm))
+        hist.append((i, pt[which], norm[which]))
+        if conv == mu:
+            break
+        i += 1
+        if i <= max_it:
+            rho2 = rhs.copy()
+            try:
+                np.linalg.cholesky(rho)
+            except np.linalg.LinAlgError:
+                return fallback(x)
+            beta = gamma @ np.linalg.solve(rho, rhs)
+            pnew = [zz + pp @ beta for zz, pp in zip(z, p)]
+            gamma, p = cholqr(pnew)
+            if gamma is None:
+                return fallback(x)
+            rho = rho2.copy()
+    return min(i, max_it), [v if mu > 1 else v[:, 0] for v in x], hist, False
+
+
+def _cg_from(orc, b, x0, tol, max_it):
+    """CG restarted from an iterate (the hand-over of BCG): Schwarz::start is applied to x0 again, like the reference does"""
+    saved = orc.start
+    try:
+        orc.start = lambda bb, xx: saved(bb, x0)
+        return cg(orc, b, tol=tol, max_it=max_it)
+    finally:
+        orc.start = saved
+
+
+def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right"):
+    """IterativeMethod::BGMRES (include/HPDDM_GMRES.hpp:159-313) without right-hand-side deflation: BlockArnoldi with classical
+    block Gram-Schmidt (include/HPDDM_iterative.hpp:523-556, 713-734), CholQR of every new block (:622-640), Householder QR
+    of the block Hessenberg matrix, checkBlockConvergence<1> (:128-182), updateSol (:272-336).  variant: right | left | flexible.
+    Returns (iterations, solution, history); iterations == -2 when the first CholQR breaks down (the reference then calls GMRES)."""
+    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    mu, P = b[0].shape[1], orc.P
+    m = max(1, min(restart, max_it))
+    ldh = mu * (m + 1)
+
+    def cholqr(W):
+        G = _gram(orc, W, W)
+        try:
+            R = np.linalg.cholesky(G).T
+        except np.linalg.LinAlgError:
+            return None, W
+        Ri = np.linalg.inv(R)
+        return R, [w @ Ri for w in W]
+
+    x = orc.start(b, [np.zeros_like(v) for v in b])
+    if variant == "left":
+        nb = _gram(orc, orc.apply(b), orc.apply(b))
+    else:
+        bc = orc.boundary_conditions()
+        bs = [np.where((np.abs(bb) > HPDDM_PEN * HPDDM_EPS) & (bc[s] != 0.0)[:, None], bb / HPDDM_PEN, bb) for s, bb in enumerate(b)]
+        nb = _gram(orc, bs, bs)
+    norm = np.sqrt(np.diag(nb))
+    norm[norm < HPDDM_EPS] = 1.0
+    hist = []
+    j = 1
+    while j <= max_it:
+        r0 = [bb - g for bb, g in zip(b, orc.gmv(x))]
+        if variant == "left":
+            r0 = orc.apply(r0)
+        R, v0 = cholqr(r0)
+        if R is None:
+            return -2, [v if mu > 1 else v[:, 0] for v in x], hist
+        V, Zb = [v0], []
+        H = np.zeros((ldh, mu * m))
+        s = np.zeros((ldh, mu))
+        s[:mu, :] = R
+        taus = []
+        dim = mu * (max_it - j + 1 if j - 1 + m > max_it else m)
+        i = 0
+        done = False
+        while i < m and j <= max_it:
+            if variant == "left":
+                w = orc.apply(orc.gmv(V[i]))
+            else:
+                zi = orc.apply(V[i])
+                if variant == "flexible":
+                    Zb.append(zi)
+                w = orc.gmv(zi)
+            Gs = [_gram(orc, V[k], w) for k in range(i + 1)]           # classical block Gram-Schmidt
+            w = [ww - sum(V[k][p] @ Gs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
+            col = slice(mu * i, mu * (i + 1))
+            for k in range(i + 1):
+                H[mu * k:mu * (k + 1), col] = Gs[k]
+            Rn, wq = cholqr(w)
+            if Rn is None:
+                return -2, [v if mu > 1 else v[:, 0] for v in x], hist
+            if i < m - 1:
+                V.append(wq)
+            else:
+                V.append(w)
+            H[mu * (i + 1):mu * (i + 2), col] = Rn
+            for k in range(i):                                          # previous Householder blocks
+                Qk = taus[k]
+                H[mu * k:mu * (k + 2), col] = Qk.T @ H[mu * k:mu * (k + 2), col]
+            Q, Rh = np.linalg.qr(H[mu * i:mu * (i + 2), col], mode="complete")
+            taus.append(Q)
+            H[mu * i:mu * (i + 2), col] = Rh
+            s[mu * i:mu * (i + 2), :] = Q.T @ s[mu * i:mu * (i + 2), :]
+            i += 1
+            res = np.array([np.linalg.norm(s[mu * i:mu * i + nu + 1, nu]) for nu in range(mu)])
+            conv = int(np.sum(res / norm <= tol))
+            which = int(np.argmax(res / norm))
+            hist.append((j, res[which], norm[which]))
+            if conv == mu:
+                dim = mu * i
+                i = 0
+                done = True
+                break
+            j += 1
+
+        def update_sol(dimc, x):
+            if dimc <= 0:
+                return x
+            Y = np.linalg.solve(np.triu(H[:dimc, :dimc]), s[:dimc, :])
+            k = dimc // mu
+            if variant == "left":
+                return [xx + sum(V[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p, xx in enumerate(x)]
+            if variant == "flexible":
+                return [xx + sum(Zb[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p, xx in enumerate(x)]
+            comb = [sum(V[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p in range(P)]
+            corr = orc.apply(comb)
+            return [xx + c for xx, c in zip(x, corr)]
+
+        if not done and j != max_it + 1 and i == m:
+            x = update_sol(dim, x)
+            continue
+        if j == max_it + 1 and m > 0 and max_it % m != 0:
+            dim = mu * (max_it % m)
+        x = update_sol(dim, x)
+        break
+    return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist
