@@ -48,6 +48,8 @@ CASES = [
     ("p40_penalized_mu2", 4, 2, "-Nx 40 -Ny 40 -penalize 1"),
     ("p40_penalized_left_mu2_ov2", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -penalize 1 -hpddm_variant left"),
     ("p40_penalized_sym_left", 4, 1, "-Nx 40 -Ny 40 -symmetric_csr=1 -penalize 1 -hpddm_variant left"),
+    ("p40_bgmres_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-6"),
+    ("p40_bgmres_rhs_deflation_restart_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-4 -hpddm_gmres_restart=6"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),

@@ -489,15 +489,42 @@ def _cg_from(orc, b, x0, tol, max_it):
         orc.start = saved
 
 
-def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right"):
-    """IterativeMethod::BGMRES (include/HPDDM_GMRES.hpp:159-313) without right-hand-side deflation: BlockArnoldi with classical
-    block Gram-Schmidt (include/HPDDM_iterative.hpp:523-556, 713-734), CholQR of every new block (:622-640), Householder QR
-    of the block Hessenberg matrix, checkBlockConvergence<1> (:128-182), updateSol (:272-336).  variant: right | left | flexible.
-    Returns (iterations, solution, history); iterations == -2 when the first CholQR breaks down (the reference then calls GMRES)."""
+def _pstrf_upper(G):
+    """Cholesky with complete pivoting, P^T G P = U^T U (LAPACK dpstrf 'U' with tol = 0: stops at the first non-positive
+    pivot).  Returns U (rows beyond the rank are zero), the permutation (0-based) and the rank."""
+    n = G.shape[0]
+    A = G.copy()
+    piv = np.arange(n)
+    U = np.zeros((n, n))
+    rank = n
+    for j in range(n):
+        dj = np.array([A[i, i] - U[:j, i] @ U[:j, i] for i in range(j, n)])
+        q = j + int(np.argmax(dj))
+        if not dj[q - j] > 0.0:
+            rank = j
+            break
+        if q != j:
+            A[[j, q], :] = A[[q, j], :]
+            A[:, [j, q]] = A[:, [q, j]]
+            U[:, [j, q]] = U[:, [q, j]]
+            piv[[j, q]] = piv[[q, j]]
+        U[j, j] = np.sqrt(dj[q - j])
+        for i in range(j + 1, n):
+            U[j, i] = (A[j, i] - U[:j, j] @ U[:j, i]) / U[j, j]
+    return U, piv, rank
+
+
+def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_tol=-1.0):
+    """IterativeMethod::BGMRES (include/HPDDM_GMRES.hpp:159-313): BlockArnoldi with classical block Gram-Schmidt
+    (include/HPDDM_iterative.hpp:523-556, 713-734), CholQR of every new block (:622-640), Householder QR of the block Hessenberg
+    matrix, checkBlockConvergence<1> (:128-182), updateSol (:272-336).  variant: right | left | flexible.
+    deflation_tol > -0.9 switches on the right-hand-side deflation: at every restart the residual block goes through a
+    rank-revealing QR (RRQR :583-595: pivoted Cholesky of its Gram matrix), the iteration runs on the `deflated` leading
+    columns only, and the other right-hand sides receive the correction times R11^{-1} R12.
+    Returns (iterations, solution, history); iterations == -2 when a CholQR breaks down (the reference then calls GMRES)."""
     b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
     mu, P = b[0].shape[1], orc.P
     m = max(1, min(restart, max_it))
-    ldh = mu * (m + 1)
 
     def cholqr(W):
         G = _gram(orc, W, W)
@@ -515,23 +542,38 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right"):
         bc = orc.boundary_conditions()
         bs = [np.where((np.abs(bb) > HPDDM_PEN * HPDDM_EPS) & (bc[s] != 0.0)[:, None], bb / HPDDM_PEN, bb) for s, bb in enumerate(b)]
         nb = _gram(orc, bs, bs)
-    norm = np.sqrt(np.diag(nb))
-    norm[norm < HPDDM_EPS] = 1.0
+    norm0 = np.sqrt(np.diag(nb))
+    norm0[norm0 < HPDDM_EPS] = 1.0
     hist = []
     j = 1
     while j <= max_it:
         r0 = [bb - g for bb, g in zip(b, orc.gmv(x))]
         if variant == "left":
             r0 = orc.apply(r0)
-        R, v0 = cholqr(r0)
-        if R is None:
-            return -2, [v if mu > 1 else v[:, 0] for v in x], hist
+        if deflation_tol > -0.9:
+            R, piv, d = _pstrf_upper(_gram(orc, r0, r0))
+            while d > 1 and abs(R[d - 1, d - 1] / R[0, 0]) <= deflation_tol:
+                d -= 1
+            if d == 0:
+                return 0, [v if mu > 1 else v[:, 0] for v in x], hist
+            Ri = np.linalg.inv(R[:d, :d])
+            v0 = [r[:, piv][:, :d] @ Ri for r in r0]
+            S12 = Ri @ R[:d, d:]
+            R = R[:d, :d]
+        else:
+            piv, d = np.arange(mu), mu
+            R, v0 = cholqr(r0)
+            if R is None:
+                return -2, [v if mu > 1 else v[:, 0] for v in x], hist
+            S12 = np.zeros((mu, 0))
+        norm = norm0[piv]
+        ldh = d * (m + 1)
         V, Zb = [v0], []
-        H = np.zeros((ldh, mu * m))
-        s = np.zeros((ldh, mu))
-        s[:mu, :] = R
+        H = np.zeros((ldh, d * m))
+        s = np.zeros((ldh, d))
+        s[:d, :] = R
         taus = []
-        dim = mu * (max_it - j + 1 if j - 1 + m > max_it else m)
+        dim = d * (max_it - j + 1 if j - 1 + m > max_it else m)
         i = 0
         done = False
         while i < m and j <= max_it:
@@ -544,31 +586,27 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right"):
                 w = orc.gmv(zi)
             Gs = [_gram(orc, V[k], w) for k in range(i + 1)]           # classical block Gram-Schmidt
             w = [ww - sum(V[k][p] @ Gs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
-            col = slice(mu * i, mu * (i + 1))
+            col = slice(d * i, d * (i + 1))
             for k in range(i + 1):
-                H[mu * k:mu * (k + 1), col] = Gs[k]
+                H[d * k:d * (k + 1), col] = Gs[k]
             Rn, wq = cholqr(w)
             if Rn is None:
                 return -2, [v if mu > 1 else v[:, 0] for v in x], hist
-            if i < m - 1:
-                V.append(wq)
-            else:
-                V.append(w)
-            H[mu * (i + 1):mu * (i + 2), col] = Rn
+            V.append(wq if i < m - 1 else w)
+            H[d * (i + 1):d * (i + 2), col] = Rn
             for k in range(i):                                          # previous Householder blocks
-                Qk = taus[k]
-                H[mu * k:mu * (k + 2), col] = Qk.T @ H[mu * k:mu * (k + 2), col]
-            Q, Rh = np.linalg.qr(H[mu * i:mu * (i + 2), col], mode="complete")
+                H[d * k:d * (k + 2), col] = taus[k].T @ H[d * k:d * (k + 2), col]
+            Q, Rh = np.linalg.qr(H[d * i:d * (i + 2), col], mode="complete")
             taus.append(Q)
-            H[mu * i:mu * (i + 2), col] = Rh
-            s[mu * i:mu * (i + 2), :] = Q.T @ s[mu * i:mu * (i + 2), :]
+            H[d * i:d * (i + 2), col] = Rh
+            s[d * i:d * (i + 2), :] = Q.T @ s[d * i:d * (i + 2), :]
             i += 1
-            res = np.array([np.linalg.norm(s[mu * i:mu * i + nu + 1, nu]) for nu in range(mu)])
-            conv = int(np.sum(res / norm <= tol))
-            which = int(np.argmax(res / norm))
+            res = np.array([np.linalg.norm(s[d * i:d * i + nu + 1, nu]) for nu in range(d)])
+            conv = (mu - d) + int(np.sum(res / norm[:d] <= tol))
+            which = int(np.argmax(res / norm[:d]))
             hist.append((j, res[which], norm[which]))
             if conv == mu:
-                dim = mu * i
+                dim = d * i
                 i = 0
                 done = True
                 break
@@ -578,20 +616,26 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right"):
             if dimc <= 0:
                 return x
             Y = np.linalg.solve(np.triu(H[:dimc, :dimc]), s[:dimc, :])
-            k = dimc // mu
-            if variant == "left":
-                return [xx + sum(V[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p, xx in enumerate(x)]
-            if variant == "flexible":
-                return [xx + sum(Zb[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p, xx in enumerate(x)]
-            comb = [sum(V[q][p] @ Y[mu * q:mu * (q + 1)] for q in range(k)) for p in range(P)]
-            corr = orc.apply(comb)
-            return [xx + c for xx, c in zip(x, corr)]
+            k = dimc // d
+            basis = V if variant != "flexible" else Zb
+            comb = [sum(basis[q][p] @ Y[d * q:d * (q + 1)] for q in range(k)) for p in range(P)]
+            corr = orc.apply(comb) if variant == "right" else comb
+            out = []
+            for xx, c in zip(x, corr):
+                xp = xx[:, piv].copy()                                   # lapmt forward
+                xp[:, :d] += c
+                if d < mu:
+                    xp[:, d:] += c @ S12
+                xn = np.empty_like(xx)
+                xn[:, piv] = xp                                          # lapmt backward
+                out.append(xn)
+            return out
 
         if not done and j != max_it + 1 and i == m:
             x = update_sol(dim, x)
             continue
         if j == max_it + 1 and m > 0 and max_it % m != 0:
-            dim = mu * (max_it % m)
+            dim = d * (max_it % m)
         x = update_sol(dim, x)
         break
     return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist

@@ -50,6 +50,7 @@ int main(int argc, char **argv)
              std::forward_as_tuple("generate_random_rhs=<0>", "", HPDDM::Option::Arg::integer), std::forward_as_tuple("symmetric_csr=(0|1)", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("mu=<1>", "number of harness right-hand sides", HPDDM::Option::Arg::positive), std::forward_as_tuple("out=<dir>", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument),
+             std::forward_as_tuple("dependent_rhs=<0>", "the last right-hand side is f_0 + 2 f_1 (Block GMRES right-hand-side deflation; the weights avoid a tie in the pivoting)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("penalize=<0>", "penalised Dirichlet rows: a_ii = HPDDM_PEN, f_i = HPDDM_PEN * f_i on a deterministic subset of the dofs", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
@@ -81,6 +82,8 @@ int main(int argc, char **argv)
     for (int nu = 1; nu < mu; ++nu)
       for (int i = 0; i < ndof; ++i) f[nu * ndof + i] = f1[i] * (0.5 + (gen() >> 8) * (1.0 / 16777216.0));
   }
+  if (opt.app()["dependent_rhs"] > 0 && mu >= 3)
+    for (int i = 0; i < ndof; ++i) f[(mu - 1) * ndof + i] = f[i] + 2.0 * f[ndof + i];
   if (opt.app()["penalize"] > 0) {
     /* FreeFEM-style Dirichlet rows (HPDDM_PEN on the diagonal, HPDDM_PEN * g on the right-hand side) on every global grid
      * point whose number is a multiple of 11: the box of this rank is recomputed like examples/generate.cpp:53-62 does, so
