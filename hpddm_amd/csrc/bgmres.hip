@@ -2,8 +2,11 @@
 // (include/HPDDM_iterative.hpp:713-734), blockOrthogonalization (:523-556, classical block Gram-Schmidt), CholQR (:622-640,
 // VR :559-582), checkBlockConvergence (:128-182), updateSol/computeMin/addSol (:272-336), same conventions as the
 // reference: D-weighted block inner products, Householder QR of the (2 mu x mu) blocks of the block Hessenberg matrix,
-// right preconditioning by default.  Built without right-hand-side deflation (-hpddm_deflation_tol, default -1 = off in
-// the reference as well) and with the CholQR factorisation (the reference's default -hpddm_qr).
+// right preconditioning by default, the CholQR factorisation (the reference's default -hpddm_qr).
+// Right-hand-side deflation (-hpddm_deflation_tol > -0.9, include/HPDDM_GMRES.hpp:201-205,278-296; RRQR
+// include/HPDDM_iterative.hpp:583-595): at every restart the residual block goes through a pivoted Cholesky of its Gram
+// matrix, the iteration runs on the d leading columns of the permuted block and the other right-hand sides get the correction
+// times R11^{-1} R12.  On the device the blocks keep their mu columns: the mu - d deflated ones are zero columns.
 //
 // The basis blocks, the operator and the preconditioner stay in HBM; the host only sees (i+1) mu x mu Gram blocks.
 #include "schwarz.hpp"
@@ -151,7 +154,8 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   const int    verbosity = (int)A.getopt("verbosity", 0);
   HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT || variant == VARIANT_FLEXIBLE, "BGMRES: unknown variant");
   const bool flexible = variant == VARIANT_FLEXIBLE; // Z_i = M^{-1} V_i kept at v[i + m + 1] (include/HPDDM_GMRES.hpp:254-255)
-  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGMRES: right-hand-side deflation (-hpddm_deflation_tol) is not built");
+  const double defl_tol  = A.getopt("deflation_tol", -1.0);
+  const bool   deflation = defl_tol > -0.9;
   const long long cnt = A.ntot * mu;
   const int       ldh = mu * (m + 1);
   const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
@@ -182,12 +186,13 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
     hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * k * mu * mu, st, A.voff_d.p, A.n_d.p, Vb, cnt, k, coef_d.p, sign, beta, W);
   };
   // CholQR of the block W (n x mu): R (mu x mu upper, row-major r[a*mu+b]); W <- W R^{-1} if update; returns the rank
-  auto cholqr = [&](double *W, std::vector<double> &R, bool update) {
+  // (only the d leading columns of W are active, the others are zero columns and stay so)
+  auto cholqr = [&](double *W, std::vector<double> &R, bool update, int d) {
     std::vector<double> G;
     gram(W, 1, W, G);
     R.assign((size_t)mu * mu, 0.0);
-    int rank = mu;
-    for (int j = 0; j < mu; ++j) { // potrf "U": G = R^T R
+    int rank = d;
+    for (int j = 0; j < d; ++j) { // potrf "U": G = R^T R
       double dj = G[(size_t)j * mu + j];
       for (int k = 0; k < j; ++k) dj -= R[(size_t)k * mu + j] * R[(size_t)k * mu + j];
       if (!(dj > 0.0)) {
@@ -196,15 +201,15 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
       }
       dj                    = std::sqrt(dj);
       R[(size_t)j * mu + j] = dj;
-      for (int c = j + 1; c < mu; ++c) {
+      for (int c = j + 1; c < d; ++c) {
         double v = G[(size_t)j * mu + c];
         for (int k = 0; k < j; ++k) v -= R[(size_t)k * mu + j] * R[(size_t)k * mu + c];
         R[(size_t)j * mu + c] = v / dj;
       }
     }
-    if (rank == mu && update) {
+    if (rank == d && update) {
       std::vector<double> Rinv((size_t)mu * mu, 0.0); // upper
-      for (int c = 0; c < mu; ++c)
+      for (int c = 0; c < d; ++c)
         for (int i = c; i >= 0; --i) {
           double v = (i == c) ? 1.0 : 0.0;
           for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
@@ -215,8 +220,64 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
     }
     return rank;
   };
+  // RRQR with deflation: pstrf "U" of the Gram matrix of W (complete pivoting, stops at the first non-positive pivot), rank
+  // trimmed while |R[rank-1][rank-1] / R[0][0]| <= tol; W <- (W P)(:, :rank) R11^{-1} in its leading columns, zero elsewhere.
+  // R (row-major, mu x mu) holds R11 and R12 in its first `rank` rows, piv the permutation (0-based).
+  auto rrqr = [&](double *W, std::vector<double> &R, std::vector<int> &piv) {
+    std::vector<double> G;
+    gram(W, 1, W, G);
+    R.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int j = 0; j < mu; ++j) {
+      int    q    = j;
+      double best = 0.0;
+      for (int c = j; c < mu; ++c) {
+        double dj = G[(size_t)c * mu + c];
+        for (int k = 0; k < j; ++k) dj -= R[(size_t)k * mu + c] * R[(size_t)k * mu + c];
+        if (c == j || dj > best) best = dj, q = c;
+      }
+      if (!(best > 0.0)) {
+        rank = j;
+        break;
+      }
+      if (q != j) {
+        for (int c = 0; c < mu; ++c) std::swap(G[(size_t)j * mu + c], G[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(G[(size_t)r * mu + j], G[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(R[(size_t)r * mu + j], R[(size_t)r * mu + q]);
+        std::swap(piv[j], piv[q]);
+      }
+      const double dj       = std::sqrt(best);
+      R[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        double v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= R[(size_t)k * mu + j] * R[(size_t)k * mu + c];
+        R[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    for (int r = rank; r < mu; ++r)
+      for (int c = 0; c < mu; ++c) R[(size_t)r * mu + c] = 0.0;
+    while (rank > 1 && std::abs(R[(size_t)(rank - 1) * mu + rank - 1] / R[0]) <= defl_tol) --rank;
+    if (rank > 0) {
+      std::vector<double> Rinv((size_t)mu * mu, 0.0), C((size_t)mu * mu, 0.0);
+      for (int c = 0; c < rank; ++c)
+        for (int i = c; i >= 0; --i) {
+          double v = (i == c) ? 1.0 : 0.0;
+          for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
+          Rinv[(size_t)i * mu + c] = v / R[(size_t)i * mu + i];
+        }
+      for (int k = 0; k < rank; ++k)
+        for (int c = 0; c < rank; ++c) C[(size_t)piv[k] * mu + c] = Rinv[(size_t)k * mu + c];
+      HIP_OK(hipMemcpyAsync(Ax.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_blocks(Ax.p, 1, C, 1.0, 0.0, W);
+    }
+    return rank;
+  };
+  std::vector<int>    piv(mu);
+  std::vector<double> normp(mu), S12, T;
+  int                 d = mu; // columns the current cycle iterates on ("deflated" in the reference)
   std::vector<double> H((size_t)ldh * mu * m, 0.0), s((size_t)ldh * mu, 0.0), tau((size_t)m * 2 * mu, 0.0), norm(mu), G, R;
-  auto                Hc = [&](int i) { return H.data() + (size_t)i * mu * ldh; };
+  auto                Hc = [&](int i) { return H.data() + (size_t)i * d * ldh; };
   // ---- initializeNorm ----
   A.start(b, x, mu);
   {
@@ -238,14 +299,39 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   auto update_sol = [&](int dimc) {
     // computeMin: H y = s (upper triangular dimc x dimc, mu right-hand sides), then x += M^{-1} (V y)
     if (dimc <= 0) return;
-    std::vector<double> Y((size_t)dimc * mu, 0.0); // row-major dimc x mu
-    for (int c = 0; c < mu; ++c)
+    std::vector<double> Y((size_t)dimc * d, 0.0); // row-major dimc x d
+    for (int c = 0; c < d; ++c)
       for (int r = dimc - 1; r >= 0; --r) {
         double v = s[r + (size_t)c * ldh];
-        for (int k = r + 1; k < dimc; ++k) v -= H[r + (size_t)k * ldh] * Y[(size_t)k * mu + c];
-        Y[(size_t)r * mu + c] = v / H[r + (size_t)r * ldh];
+        for (int k = r + 1; k < dimc; ++k) v -= H[r + (size_t)k * ldh] * Y[(size_t)k * d + c];
+        Y[(size_t)r * d + c] = v / H[r + (size_t)r * ldh];
       }
-    const int kblocks = dimc / mu;
+    const int kblocks = dimc / d;
+    if (deflation) {
+      // x P gets [corr, corr R11^{-1} R12] (include/HPDDM_iterative.hpp:318-333): x += corr T with T[k][piv[k]] = 1, T[k][piv[d + q]] = S12[k][q]
+      T.assign((size_t)mu * mu, 0.0);
+      for (int k = 0; k < d; ++k) {
+        T[(size_t)k * mu + piv[k]] = 1.0;
+        for (int q = 0; q < mu - d; ++q) T[(size_t)k * mu + piv[d + q]] = S12[(size_t)k * (mu - d) + q];
+      }
+      std::vector<double> C((size_t)kblocks * mu * mu, 0.0);
+      const bool          direct = variant != VARIANT_RIGHT; // left / flexible: no preconditioner between the combination and x
+      for (int k = 0; k < kblocks; ++k)
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) {
+            const double y = Y[((size_t)k * d + a) * d + c];
+            if (!direct) C[((size_t)k * mu + a) * mu + c] = y;
+            else
+              for (int col = 0; col < mu; ++col) C[((size_t)k * mu + a) * mu + col] += y * T[(size_t)c * mu + col];
+          }
+      if (direct) axpy_blocks(flexible ? vk(m + 1) : vk(0), kblocks, C, 1.0, 1.0, x);
+      else {
+        axpy_blocks(vk(0), kblocks, C, 1.0, 0.0, Ax.p);
+        A.apply(Ax.p, vk(m), mu);
+        axpy_blocks(vk(m), 1, T, 1.0, 1.0, x);
+      }
+      return;
+    }
     if (variant == VARIANT_LEFT) axpy_blocks(vk(0), kblocks, Y, 1.0, 1.0, x);
     else if (flexible) axpy_blocks(vk(m + 1), kblocks, Y, 1.0, 1.0, x);
     else {
@@ -259,14 +345,31 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
     A.gmv(x, r0, mu);
     hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, r0, r0);
     if (variant == VARIANT_LEFT) A.apply(Ax.p, vk(0), mu);
-    const int N = cholqr(vk(0), R, true); // RRQR with tol < -0.9 = plain QR (include/HPDDM_iterative.hpp:585)
-    if (N != mu) {
-      breakdown = true;
-      break;
+    if (deflation) {
+      d = rrqr(vk(0), R, piv);
+      if (d == 0) { // zero residual block (include/HPDDM_GMRES.hpp:206-216)
+        j = 0;
+        break;
+      }
+      S12.assign((size_t)d * (mu - d), 0.0); // R11^{-1} R12 (trtrs, include/HPDDM_GMRES.hpp:222-227)
+      for (int q = 0; q < mu - d; ++q)
+        for (int r = d - 1; r >= 0; --r) {
+          double v = R[(size_t)r * mu + d + q];
+          for (int k = r + 1; k < d; ++k) v -= R[(size_t)r * mu + k] * S12[(size_t)k * (mu - d) + q];
+          S12[(size_t)r * (mu - d) + q] = v / R[(size_t)r * mu + r];
+        }
+      for (int k = 0; k < mu; ++k) normp[k] = norm[piv[k]];
+    } else {
+      const int N = cholqr(vk(0), R, true, mu); // RRQR with tol < -0.9 = plain QR (include/HPDDM_iterative.hpp:585)
+      if (N != mu) {
+        breakdown = true;
+        break;
+      }
+      normp = norm;
     }
-    dim     = mu * (j - 1 + m > max_it ? max_it - j + 1 : m);
+    dim     = d * (j - 1 + m > max_it ? max_it - j + 1 : m);
     std::fill(s.begin(), s.end(), 0.0);
-    for (int c = 0; c < mu; ++c)
+    for (int c = 0; c < d; ++c)
       for (int r = 0; r <= c; ++r) s[r + (size_t)c * ldh] = R[(size_t)r * mu + c];
     std::fill(H.begin(), H.end(), 0.0);
     std::fill(tau.begin(), tau.end(), 0.0);
@@ -285,38 +388,42 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
       axpy_blocks(vk(0), i + 1, G, -1.0, 1.0, vk(i + 1));
       double *Hi = Hc(i);
       for (int kk = 0; kk <= i; ++kk)
-        for (int a = 0; a < mu; ++a)
-          for (int c = 0; c < mu; ++c) Hi[(kk * mu + a) + (size_t)c * ldh] = G[((size_t)kk * mu + a) * mu + c];
-      const int rk = cholqr(vk(i + 1), R, i < m - 1);
-      if (rk != mu) { // rank-deficient block: the reference drops this cycle and restarts with GMRES (include/HPDDM_GMRES.hpp:268-272,311)
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) Hi[(kk * d + a) + (size_t)c * ldh] = G[((size_t)kk * mu + a) * mu + c];
+      const int rk = cholqr(vk(i + 1), R, i < m - 1, d);
+      if (rk != d) { // rank-deficient block: the reference drops this cycle and restarts with GMRES (include/HPDDM_GMRES.hpp:268-272,311)
         breakdown = true;
         break;
       }
-      for (int c = 0; c < mu; ++c)
-        for (int r = 0; r < mu; ++r) Hi[((i + 1) * mu + r) + (size_t)c * ldh] = r <= c ? R[(size_t)r * mu + c] : 0.0;
-      for (int k = 0; k < i; ++k) orm2r_lt(2 * mu, mu, mu, Hc(k) + k * mu, ldh, tau.data() + (size_t)k * 2 * mu, Hi + k * mu, ldh);
-      geqr2(2 * mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu);
-      orm2r_lt(2 * mu, mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu, s.data() + i * mu, ldh);
+      for (int c = 0; c < d; ++c)
+        for (int r = 0; r < d; ++r) Hi[((i + 1) * d + r) + (size_t)c * ldh] = r <= c ? R[(size_t)r * mu + c] : 0.0;
+      for (int k = 0; k < i; ++k) orm2r_lt(2 * d, d, d, Hc(k) + k * d, ldh, tau.data() + (size_t)k * 2 * mu, Hi + k * d, ldh);
+      geqr2(2 * d, d, Hi + i * d, ldh, tau.data() + (size_t)i * 2 * mu);
+      orm2r_lt(2 * d, d, d, Hi + i * d, ldh, tau.data() + (size_t)i * 2 * mu, s.data() + i * d, ldh);
       ++i;
-      // ---- checkBlockConvergence<1> with t = 1 ----
-      int    conv = 0, which = 0;
+      // ---- checkBlockConvergence<1> with t = 1: the mu - d deflated right-hand sides count as converged ----
+      int    conv = mu - d, which = 0;
       double best = -1.0;
-      for (int nu = 0; nu < mu; ++nu) {
+      for (int nu = 0; nu < d; ++nu) {
         double nrm = 0.0;
-        for (int r = 0; r <= nu; ++r) nrm += s[(mu * i + r) + (size_t)nu * ldh] * s[(mu * i + r) + (size_t)nu * ldh];
+        for (int r = 0; r <= nu; ++r) nrm += s[(d * i + r) + (size_t)nu * ldh] * s[(d * i + r) + (size_t)nu * ldh];
         nrm = std::sqrt(nrm);
-        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
-        if (nrm / norm[nu] > best) {
-          best  = nrm / norm[nu];
+        if ((tol > 0.0 && nrm / normp[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / normp[nu] > best) {
+          best  = nrm / normp[nu];
           which = nu;
         }
       }
-      const double beta = best * norm[which];
+      const double beta = best * normp[which];
       if (history && nhist < history_cap) history[nhist] = beta;
       ++nhist;
-      if (verbosity > 2) printf("BGMRES: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
+      if (verbosity > 2) {
+        printf("BGMRES: %3d %e %e %e < %e", j, beta, normp[which], best, tol);
+        if (d != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - d);
+        printf("\n");
+      }
       if (conv == mu) {
-        dim = mu * i;
+        dim = d * i;
         i   = 0;
         break;
       }
@@ -331,9 +438,9 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   if (breakdown) return -2; // caller falls back to GMRES from the current iterate (include/HPDDM_GMRES.hpp:311)
   if (j == max_it + 1 && m > 0) {
     const int rem = max_it % m;
-    if (rem != 0) dim = mu * rem;
+    if (rem != 0) dim = d * rem;
   }
-  update_sol(dim);
+  if (j != 0) update_sol(dim);
   if (verbosity) {
     if (j != max_it + 1) printf("BGMRES converges after %d iteration%s\n", j, j > 1 ? "s" : "");
     else printf("BGMRES does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");

@@ -267,9 +267,12 @@ def test_geneo_coarse_space_against_arpack():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3"])
+@pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3",
+                                  "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4"])
 def test_bgmres_matches_reference(name):
-    """Block GMRES: iteration count, residual history and solution of the compiled reference"""
+    """Block GMRES: iteration count, residual history and solution of the compiled reference.  The two
+    rhs_deflation fixtures run with -hpddm_deflation_tol and a last right-hand side f_0 + 2 f_1: one column is deflated at
+    every restart (include/HPDDM_GMRES.hpp:201-205)."""
     g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
