@@ -50,6 +50,14 @@ CASES = [
     ("p40_penalized_sym_left", 4, 1, "-Nx 40 -Ny 40 -symmetric_csr=1 -penalize 1 -hpddm_variant left"),
     ("p40_bgmres_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-6"),
     ("p40_bgmres_rhs_deflation_restart_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-4 -hpddm_gmres_restart=6"),
+    # K = std::complex<double> (ref_harness_z, symCoarse 'G'): diagonal times (1 + re/100 + i im/100), complex right-hand sides
+    ("z_p30_gmres_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3"),
+    ("z_p30_gmres_left_deflated", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    ("z_p30_6ranks_bgmres_mu3_balanced", 6, 3, "-Nx 30 -Ny 30 -overlap 2 -complex_shift_re -5 -complex_shift_im 3 -hpddm_krylov_method bgmres -hpddm_schwarz_coarse_correction balanced -hpddm_geneo_nu=0"),
+    ("z_p30_bgmres_mu8", 4, 8, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_gmres_restart=10"),
+    ("z_p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    # several deflation vectors per subdomain (the constant one + smooth local ones, dumped as ev): coarse blocks larger than 1 x 1
+    ("p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),
@@ -67,7 +75,11 @@ def parse_dump(path):
             name, kind, cnt = ln[1:].split()
             cnt = int(cnt)
             vals = lines[i + 1 : i + 1 + cnt]
-            out[name] = np.array(vals, dtype=np.float64 if kind == "f" else np.int32)
+            if kind == "z":   # complex K: "re im" pairs
+                pairs = np.array([v.split() for v in vals], dtype=np.float64).reshape(-1, 2)
+                out[name] = pairs[:, 0] + 1j * pairs[:, 1]
+            else:
+                out[name] = np.array(vals, dtype=np.float64 if kind == "f" else np.int32)
             i += 1 + cnt
         else:
             i += 1
@@ -76,7 +88,7 @@ def parse_dump(path):
 
 def run_case(name, ranks, mu, opts, tmp):
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
-    cmd = ["/opt/conda/bin/mpiexec", "-n", str(ranks), os.path.join(REF, "ref_harness"), "-out", tmp, "-case", name,
+    cmd = ["/opt/conda/bin/mpiexec", "-n", str(ranks), os.path.join(REF, "ref_harness_z" if name.startswith("z_") else "ref_harness"), "-out", tmp, "-case", name,
            "-mu", str(mu), "-hpddm_verbosity=3"] + opts.split()
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
     if res.returncode != 0:

@@ -34,6 +34,12 @@ HPDDM_EPS = 1.0e-12
 HPDDM_PEN = 1.0e30
 
 
+def _arr(v):
+    """float64 array, or complex128 when the input is complex (K = std::complex<double> in the reference)"""
+    v = np.asarray(v)
+    return v.astype(np.complex128) if np.iscomplexobj(v) else v.astype(np.float64)
+
+
 def csr_full(sd):
     """scipy CSR of a subdomain dict (expands HPDDM's symmetric lower-triangular storage)."""
     base = 1 if sd.get("numbering", "C") == "F" else 0
@@ -107,11 +113,12 @@ class Oracle:
             self.method = {"oras": "og", "osm": "og", "soras": "os"}.get(self.method, self.method)
 
     def local_solve(self, xs):
-        return [self.lu[s].solve(np.asarray(xs[s], dtype=np.float64)) for s in range(self.P)]
+        cplx = np.iscomplexobj(self.A[0].data)
+        return [self.lu[s].solve(_arr(xs[s]).astype(np.complex128) if cplx else _arr(xs[s])) for s in range(self.P)]
 
     # ---- coarse level ----
     def set_vectors(self, Z):
-        self.Z = [np.asarray(z, dtype=np.float64).reshape(self.subs[s]["n"], -1) for s, z in enumerate(Z)]
+        self.Z = [_arr(z).reshape(self.subs[s]["n"], -1) for s, z in enumerate(Z)]
 
     # ---- GenEO: Schwarz::scaleIntoOverlap + solveGEVP (include/HPDDM_schwarz.hpp:622-715); the reference hands the
     # pencil to ARPACK in shift-invert mode (include/HPDDM_ARPACK.hpp:84-148) -- restated with scipy's ARPACK wrapper ----
@@ -139,26 +146,41 @@ class Oracle:
         self.set_vectors(Z)
         return lams
 
-    def build_coarse(self, symmetric=True):
+    def build_coarse(self, symmetric=None, lapacktr=True):
+        """E = Z^H A Z by neighbour products (MatrixMultiplication, include/HPDDM_operator.hpp:378-562): block (i, j) =
+        Z_i^H D_i (A_j D_j Z_j) on the shared unknowns.  symmetric=None: 'S' for real scalars, 'G' for complex ones
+        (examples/schwarz.hpp:48-79).  What the compiled reference then solves with, pinned on the fixtures with three
+        deflation vectors per subdomain and the generator's non-symmetric 6-rank matrices:
+          'S': only the block rows towards higher-numbered neighbours are assembled, and of the diagonal blocks the
+               triangle that is the LOWER one in the orientation used here; the rest is the mirror image;
+          'G': every rank assembles its whole block row, and the dense back-end of this build (LapackTR::numfact calls
+               LapackTRSub::numfact<'C', true>, include/HPDDM_LAPACK.hpp:417 -> :348-352) lays the CSR rows out as COLUMNS:
+               the factorised matrix is E^T -- unless every subdomain neighbours every other one, in which case the CSR
+               is full (nnz = n^2) and the branch at :345-347 copies it the right way round.  Invisible on symmetric
+               operators; lapacktr=False gives the plain E whatever the connectivity."""
+        if symmetric is None:
+            symmetric = not (np.iscomplexobj(self.A[0].data) or np.iscomplexobj(self.Z[0]))
         off = np.concatenate([[0], np.cumsum([z.shape[1] for z in self.Z])])
         DZ = [self.d[s][:, None] * self.Z[s] for s in range(self.P)]
         T = [self.A[s] @ DZ[s] for s in range(self.P)]
-        E = np.zeros((off[-1], off[-1]))
+        E = np.zeros((off[-1], off[-1]), dtype=np.result_type(T[0].dtype, DZ[0].dtype))
         for i in range(self.P):
-            E[off[i]:off[i + 1], off[i]:off[i + 1]] = DZ[i].T @ T[i]
+            E[off[i]:off[i + 1], off[i]:off[i + 1]] = DZ[i].conj().T @ T[i]
             for j, idx in self.map[i]:
-                E[off[i]:off[i + 1], off[j]:off[j + 1]] = DZ[i][idx].T @ T[j][self._peer(j, i)]
-        # symCoarse == 'S' for real scalars (examples/schwarz.hpp:75-79): only the upper triangle of E is assembled
-        # (each rank contributes its own row block towards higher-numbered neighbours) and the coarse solver treats
-        # E as symmetric.  Verified bit-for-bit against the reference on the golden vectors.
+                E[off[i]:off[i + 1], off[j]:off[j + 1]] = DZ[i][idx].conj().T @ T[j][self._peer(j, i)]
         if symmetric:
-            E = np.triu(E) + np.triu(E, 1).T
+            for i in range(self.P):
+                blk = E[off[i]:off[i + 1], off[i]:off[i + 1]]
+                E[off[i]:off[i + 1], off[i]:off[i + 1]] = np.tril(blk) + np.tril(blk, -1).T
+                E[off[i + 1]:, off[i]:off[i + 1]] = E[off[i]:off[i + 1], off[i + 1]:].T
+        elif lapacktr and any(len(self.map[i]) != self.P - 1 for i in range(self.P)):
+            E = E.T.copy()
         self.E, self.coff = E, off
         self.Einv = np.linalg.inv(E)
 
     def deflation(self, xs):
         # out = exchange(Z E^{-1} Z^T D in)
-        uc = np.concatenate([self.Z[s].T @ ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s]) for s in range(self.P)])
+        uc = np.concatenate([self.Z[s].conj().T @ ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s]) for s in range(self.P)])
         y = self.Einv @ uc
         return self.exchange([self.Z[s] @ y[self.coff[s]:self.coff[s + 1]] for s in range(self.P)])
 
@@ -189,9 +211,9 @@ class Oracle:
     # ---- D-weighted inner products over all ranks (MPI_Allreduce in the reference) ----
     def wdot(self, xs, ys):
         mu = 1 if xs[0].ndim == 1 else xs[0].shape[1]
-        acc = np.zeros(mu)
+        acc = np.zeros(mu, dtype=np.result_type(xs[0].dtype, ys[0].dtype))
         for s in range(self.P):
-            acc += ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * xs[s] * ys[s]).sum(axis=0)
+            acc += ((self.d[s][:, None] if xs[s].ndim == 2 else self.d[s]) * np.conj(xs[s]) * ys[s]).sum(axis=0)
         return acc
 
     # ---- penalised Dirichlet rows: Subdomain::boundaryCond / boundaryConditions (include/HPDDM_subdomain.hpp:310-336) ----
@@ -204,8 +226,8 @@ class Oracle:
         out = []
         for sd in self.subs:
             n, base = sd["n"], (1 if sd.get("numbering", "C") == "F" else 0)
-            ia, ja, a = np.asarray(sd["ia"]) - base, np.asarray(sd["ja"]) - base, np.asarray(sd["a"], dtype=np.float64)
-            bc = np.zeros(n)
+            ia, ja, a = np.asarray(sd["ia"]) - base, np.asarray(sd["ja"]) - base, _arr(sd["a"])
+            bc = np.zeros(n, dtype=a.dtype)
             for i in range(n):
                 lo, hi = ia[i], ia[i + 1]
                 if lo == hi:
@@ -242,7 +264,7 @@ class Oracle:
         r = [a - b for a, b in zip(self.gmv(sol), f)]
         r = [np.where((bc[s] != 0.0)[:, None] if rr.ndim == 2 else bc[s] != 0.0, 0.0, rr) for s, rr in enumerate(r)]
         fs = [np.where(np.abs(ff) > HPDDM_EPS * HPDDM_PEN, ff / HPDDM_PEN, ff) for ff in f]
-        nb, nr = np.sqrt(self.wdot(fs, fs)), np.sqrt(self.wdot(r, r))
+        nb, nr = np.sqrt(self.wdot(fs, fs).real), np.sqrt(self.wdot(r, r).real)
         out = np.zeros(2 * len(nb))
         out[0::2], out[1::2] = nb, nr
         return out
@@ -250,26 +272,28 @@ class Oracle:
     # ---- IterativeMethod::GMRES (right or left preconditioning, CGS or MGS) ----
     def gmres(self, b, x0=None, tol=1e-6, max_it=100, restart=40, variant="right", ortho="cgs"):
         P = self.P
-        b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+        cplx = np.iscomplexobj(self.A[0].data) or any(np.iscomplexobj(v) for v in b)
+        dt = np.complex128 if cplx else np.float64
+        b = [_arr(v).astype(dt).reshape(np.shape(v)[0], -1) for v in b]
         mu = b[0].shape[1]
-        x = [np.zeros_like(v) for v in b] if x0 is None else [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1).copy() for v in x0]
+        x = [np.zeros_like(v) for v in b] if x0 is None else [_arr(v).astype(dt).reshape(np.shape(v)[0], -1).copy() for v in x0]
         m = max(1, min(restart, max_it))
         x = self.start(b, x)                                        # A.start
         if variant == "left":
-            norm = self.wdot(self.apply(b), self.apply(b))
+            norm = self.wdot(self.apply(b), self.apply(b)).real
         else:  # initializeNorm (include/HPDDM_iterative.hpp:441-471): penalised entries of b count divided by HPDDM_PEN
             bc = self.boundary_conditions()
             bs = [np.where((np.abs(bb) > HPDDM_PEN * HPDDM_EPS) & (bc[s] != 0.0)[:, None], bb / HPDDM_PEN, bb) for s, bb in enumerate(b)]
-            norm = self.wdot(bs, bs)
+            norm = self.wdot(bs, bs).real
         conv = np.full(mu, -m)
         hist = []
         j = 1
-        H = np.zeros((mu, m + 1, m))
-        cs, sn = np.zeros((mu, m)), np.zeros((mu, m))
+        H = np.zeros((mu, m + 1, m), dtype=dt)
+        cs, sn = np.zeros((mu, m), dtype=dt), np.zeros((mu, m))     # the cosines are complex for complex K, the sines real
         V = [None] * (m + 1)
 
         def update_sol(x):
-            y = np.zeros((m, mu))
+            y = np.zeros((m, mu), dtype=dt)
             dmax = 0
             for nu in range(mu):
                 dim = abs(int(conv[nu]))
@@ -289,14 +313,14 @@ class Oracle:
             r0 = [bb - g for bb, g in zip(b, self.gmv(x))]
             if variant == "left":
                 r0 = self.apply(r0)
-            s0 = self.wdot(r0, r0)
+            s0 = self.wdot(r0, r0).real
             if j == 1:
                 norm = np.sqrt(norm)
                 norm[norm < HPDDM_EPS] = 1.0
                 if np.any(s0 < np.finfo(float).eps ** 2):
                     return 0, [v if mu > 1 else v[:, 0] for v in x], hist
             conv[conv > 0] = 0
-            s = np.zeros((m + 1, mu))
+            s = np.zeros((m + 1, mu), dtype=dt)
             s[0] = np.sqrt(s0)
             V[0] = [r / s[0] for r in r0]
             i = 0
@@ -315,20 +339,20 @@ class Oracle:
                     for k in range(i + 1):
                         H[:, k, i] = hs[k]
                     w = [ww - sum(V[k][p] * hs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
-                nrm = np.sqrt(self.wdot(w, w))
+                nrm = np.sqrt(self.wdot(w, w).real)
                 H[:, i + 1, i] = nrm
                 V[i + 1] = [ww / nrm for ww in w] if i < m - 1 else w
                 for nu in range(mu):
                     for k in range(i):
-                        gamma = cs[nu, k] * H[nu, k, i] + sn[nu, k] * H[nu, k + 1, i]
+                        gamma = np.conj(cs[nu, k]) * H[nu, k, i] + sn[nu, k] * H[nu, k + 1, i]
                         H[nu, k + 1, i] = -sn[nu, k] * H[nu, k, i] + cs[nu, k] * H[nu, k + 1, i]
                         H[nu, k, i] = gamma
-                    delta = np.hypot(H[nu, i, i], H[nu, i + 1, i])
-                    sn[nu, i] = H[nu, i + 1, i] / delta
+                    delta = np.hypot(abs(H[nu, i, i]), abs(H[nu, i + 1, i]))
+                    sn[nu, i] = H[nu, i + 1, i].real / delta
                     cs[nu, i] = H[nu, i, i] / delta
                     H[nu, i, i] = delta
                     s[i + 1, nu] = -sn[nu, i] * s[i, nu]
-                    s[i, nu] *= cs[nu, i]
+                    s[i, nu] *= np.conj(cs[nu, i])
                 i += 1
                 res = np.abs(s[i])
                 newly = (conv == -m) & (res / norm <= tol)
@@ -360,9 +384,9 @@ class Oracle:
 # ======================================================================================================================
 def _gram(orc, V, W):
     """G[a, b] = sum_s sum_i d_i V_s[i, a] W_s[i, b]   (VR / gemmt with Wrapper::diag, include/HPDDM_iterative.hpp:559-582)"""
-    G = np.zeros((V[0].shape[1], W[0].shape[1]))
+    G = np.zeros((V[0].shape[1], W[0].shape[1]), dtype=np.result_type(V[0].dtype, W[0].dtype))
     for s in range(orc.P):
-        G += V[s].T @ (orc.d[s][:, None] * W[s])
+        G += V[s].conj().T @ (orc.d[s][:, None] * W[s])
     return G
 
 
@@ -495,10 +519,10 @@ def _pstrf_upper(G):
     n = G.shape[0]
     A = G.copy()
     piv = np.arange(n)
-    U = np.zeros((n, n))
+    U = np.zeros((n, n), dtype=G.dtype)
     rank = n
     for j in range(n):
-        dj = np.array([A[i, i] - U[:j, i] @ U[:j, i] for i in range(j, n)])
+        dj = np.array([(A[i, i] - np.vdot(U[:j, i], U[:j, i])).real for i in range(j, n)])
         q = j + int(np.argmax(dj))
         if not dj[q - j] > 0.0:
             rank = j
@@ -510,7 +534,7 @@ def _pstrf_upper(G):
             piv[[j, q]] = piv[[q, j]]
         U[j, j] = np.sqrt(dj[q - j])
         for i in range(j + 1, n):
-            U[j, i] = (A[j, i] - U[:j, j] @ U[:j, i]) / U[j, j]
+            U[j, i] = (A[j, i] - np.vdot(U[:j, j], U[:j, i])) / U[j, j]
     return U, piv, rank
 
 
@@ -522,14 +546,16 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
     rank-revealing QR (RRQR :583-595: pivoted Cholesky of its Gram matrix), the iteration runs on the `deflated` leading
     columns only, and the other right-hand sides receive the correction times R11^{-1} R12.
     Returns (iterations, solution, history); iterations == -2 when a CholQR breaks down (the reference then calls GMRES)."""
-    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    cplx = np.iscomplexobj(orc.A[0].data) or any(np.iscomplexobj(v) for v in b)
+    dt = np.complex128 if cplx else np.float64
+    b = [_arr(v).astype(dt).reshape(np.shape(v)[0], -1) for v in b]
     mu, P = b[0].shape[1], orc.P
     m = max(1, min(restart, max_it))
 
     def cholqr(W):
         G = _gram(orc, W, W)
         try:
-            R = np.linalg.cholesky(G).T
+            R = np.linalg.cholesky(G).conj().T         # G = R^H R, R upper
         except np.linalg.LinAlgError:
             return None, W
         Ri = np.linalg.inv(R)
@@ -542,7 +568,7 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
         bc = orc.boundary_conditions()
         bs = [np.where((np.abs(bb) > HPDDM_PEN * HPDDM_EPS) & (bc[s] != 0.0)[:, None], bb / HPDDM_PEN, bb) for s, bb in enumerate(b)]
         nb = _gram(orc, bs, bs)
-    norm0 = np.sqrt(np.diag(nb))
+    norm0 = np.sqrt(np.diag(nb).real)
     norm0[norm0 < HPDDM_EPS] = 1.0
     hist = []
     j = 1
@@ -565,12 +591,12 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
             R, v0 = cholqr(r0)
             if R is None:
                 return -2, [v if mu > 1 else v[:, 0] for v in x], hist
-            S12 = np.zeros((mu, 0))
+            S12 = np.zeros((mu, 0), dtype=dt)
         norm = norm0[piv]
         ldh = d * (m + 1)
         V, Zb = [v0], []
-        H = np.zeros((ldh, d * m))
-        s = np.zeros((ldh, d))
+        H = np.zeros((ldh, d * m), dtype=dt)
+        s = np.zeros((ldh, d), dtype=dt)
         s[:d, :] = R
         taus = []
         dim = d * (max_it - j + 1 if j - 1 + m > max_it else m)
@@ -595,11 +621,11 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
             V.append(wq if i < m - 1 else w)
             H[d * (i + 1):d * (i + 2), col] = Rn
             for k in range(i):                                          # previous Householder blocks
-                H[d * k:d * (k + 2), col] = taus[k].T @ H[d * k:d * (k + 2), col]
+                H[d * k:d * (k + 2), col] = taus[k].conj().T @ H[d * k:d * (k + 2), col]
             Q, Rh = np.linalg.qr(H[d * i:d * (i + 2), col], mode="complete")
             taus.append(Q)
             H[d * i:d * (i + 2), col] = Rh
-            s[d * i:d * (i + 2), :] = Q.T @ s[d * i:d * (i + 2), :]
+            s[d * i:d * (i + 2), :] = Q.conj().T @ s[d * i:d * (i + 2), :]
             i += 1
             res = np.array([np.linalg.norm(s[d * i:d * i + nu + 1, nu]) for nu in range(d)])
             conv = (mu - d) + int(np.sum(res / norm[:d] <= tol))

@@ -32,6 +32,12 @@ static void  dumpd(const char *name, const double *v, long n)
   fprintf(g_out, "@%s f %ld\n", name, n);
   for (long i = 0; i < n; ++i) fprintf(g_out, "%.17g\n", v[i]);
 }
+/* complex K (-DFORCE_COMPLEX build): section kind "z", one "re im" pair per line */
+static void dumpd(const char *name, const std::complex<double> *v, long n)
+{
+  fprintf(g_out, "@%s z %ld\n", name, n);
+  for (long i = 0; i < n; ++i) fprintf(g_out, "%.17g %.17g\n", v[i].real(), v[i].imag());
+}
 static void dumpi(const char *name, const int *v, long n)
 {
   fprintf(g_out, "@%s i %ld\n", name, n);
@@ -51,6 +57,9 @@ int main(int argc, char **argv)
              std::forward_as_tuple("mu=<1>", "number of harness right-hand sides", HPDDM::Option::Arg::positive), std::forward_as_tuple("out=<dir>", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("case=<name>", "", HPDDM::Option::Arg::argument),
              std::forward_as_tuple("dependent_rhs=<0>", "the last right-hand side is f_0 + 2 f_1 (Block GMRES right-hand-side deflation; the weights avoid a tie in the pivoting)", HPDDM::Option::Arg::integer),
+             std::forward_as_tuple("complex_shift_re=<0>", "complex builds: a_ii *= 1 + re / 100 + i im / 100 (consistent on the overlap: the diagonal is the same in every copy)", HPDDM::Option::Arg::integer),
+             std::forward_as_tuple("complex_shift_im=<0>", "see complex_shift_re; the right-hand sides also get a phase exp(i 0.7 (nu + 1)) and a smooth complex modulation", HPDDM::Option::Arg::integer),
+             std::forward_as_tuple("deflation_nu=<1>", "number of deflation vectors per subdomain: the constant one, then deterministic smooth ones (dumped as ev)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("penalize=<0>", "penalised Dirichlet rows: a_ii = HPDDM_PEN, f_i = HPDDM_PEN * f_i on a deterministic subset of the dofs", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
@@ -82,6 +91,19 @@ int main(int argc, char **argv)
     for (int nu = 1; nu < mu; ++nu)
       for (int i = 0; i < ndof; ++i) f[nu * ndof + i] = f1[i] * (0.5 + (gen() >> 8) * (1.0 / 16777216.0));
   }
+#ifdef FORCE_COMPLEX
+  {
+    const double sre = opt.app()["complex_shift_re"], sim = opt.app()["complex_shift_im"];
+    if (sre != 0.0 || sim != 0.0) {
+      const int base = (HPDDM_NUMBERING == 'F');
+      for (int i = 0; i < ndof; ++i)
+        for (int p = Mat->ia_[i] - base; p < Mat->ia_[i + 1] - base; ++p)
+          if (Mat->ja_[p] - base == i) Mat->a_[p] *= K(1.0 + 0.01 * sre, 0.01 * sim);
+      for (int nu = 0; nu < mu; ++nu)
+        for (int i = 0; i < ndof; ++i) f[nu * ndof + i] *= std::polar(1.0, 0.7 * (nu + 1)) * K(1.0, 0.3 * std::sin(0.01 * std::real(f1[i]) + nu));
+    }
+  }
+#endif
   if (opt.app()["dependent_rhs"] > 0 && mu >= 3)
     for (int i = 0; i < ndof; ++i) f[(mu - 1) * ndof + i] = f[i] + 2.0 * f[ndof + i];
   if (opt.app()["penalize"] > 0) {
@@ -133,10 +155,23 @@ int main(int argc, char **argv)
 
   unsigned short nu = 0;
   if (opt.set("schwarz_coarse_correction")) {
-    nu            = 1; /* constant deflation vector, examples/schwarz.cpp:115-121 (no EIGENSOLVER in this build) */
-    K **deflation = new K *[1];
-    *deflation    = new K[ndof];
-    std::fill(*deflation, *deflation + ndof, 1.0);
+    /* constant deflation vector, examples/schwarz.cpp:115-121 (no EIGENSOLVER in this build); -deflation_nu adds smooth local
+     * vectors (complex-valued in the complex build) so that the coarse blocks are not 1 x 1 */
+    nu            = std::max(1, (int)opt.app()["deflation_nu"]);
+    K **deflation = new K *[nu];
+    *deflation    = new K[nu * ndof]; /* contiguous, like the eigensolvers allocate them (include/HPDDM_ARPACK.hpp:154-156) */
+    for (unsigned short k = 0; k < nu; ++k) {
+      deflation[k] = *deflation + k * ndof;
+      for (int i = 0; i < ndof; ++i) {
+        const double t = 0.3 * k * (1.0 + 0.01 * i) + 0.5 * rank;
+#ifdef FORCE_COMPLEX
+        deflation[k][i] = k == 0 ? K(1.0) : K(1.0 + 0.5 * std::sin(t), 0.4 * std::cos(1.7 * t));
+#else
+        deflation[k][i] = k == 0 ? 1.0 : 1.0 + 0.5 * std::sin(t);
+#endif
+      }
+    }
+    if (nu > 1) dumpd("ev", *deflation, (long)nu * ndof);
     A.setVectors(deflation);
     A.super::initialize(nu);
     A.buildTwo(MPI_COMM_WORLD);

@@ -92,6 +92,19 @@ def subdomains(g):
     return subs
 
 
+COMPLEX_CASES = ["z_p30_gmres_mu2", "z_p30_gmres_left_deflated", "z_p30_6ranks_deflated_nu3"]          # K = std::complex<double>, GMRES
+COMPLEX_BGMRES_CASES = ["z_p30_6ranks_bgmres_mu3_balanced", "z_p30_bgmres_mu8"]
+MULTI_VECTOR_CASES = ["p30_6ranks_deflated_nu3"]   # three deflation vectors per subdomain, non-symmetric local matrices
+
+
+def deflation_vectors(g, subs):
+    """the vectors the harness handed to setVectors: the constant one (examples/schwarz.cpp:115-121), or the dumped `ev`
+    block (n x nu, column-major) of the fixtures made with -deflation_nu"""
+    if "ev_r0" in g:
+        return [g[f"ev_r{r}"].reshape(-1, sd["n"]).T.copy() for r, sd in enumerate(subs)]
+    return [np.ones((sd["n"], 1)) for sd in subs]
+
+
 def vec(g, key, r, mu):
     n = int(g[f"meta_r{r}"][2])
     v = g[f"{key}_r{r}"]

@@ -21,7 +21,7 @@ def _setup(g, subs):
     else:
         orc.numfact()
     if opt["correction"]:
-        orc.set_vectors([np.ones((s["n"], 1)) for s in subs])  # constant vector, examples/schwarz.cpp:115-121
+        orc.set_vectors(gu.deflation_vectors(g, subs))
         orc.build_coarse()
     return orc, opt
 
@@ -32,7 +32,8 @@ def _close(a, b, rtol, what):
     assert err <= rtol, f"{what}: relative error {err:.3e} > {rtol:.1e}"
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.PENALIZED_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.PENALIZED_CASES + gu.MULTI_VECTOR_CASES + gu.COMPLEX_CASES
+                         + gu.COMPLEX_BGMRES_CASES)
 def test_functions_match_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -48,12 +49,13 @@ def test_functions_match_reference(name):
     _close(orc.exchange(f), gu.vecs(g, "exchange_out"), 1e-14, "exchange")
     _close(orc.gmv(f), gu.vecs(g, "gmv_out"), 1e-13, "GMV")
     _close(orc.local_solve(f), gu.vecs(g, "solve_out"), 1e-11, "Solver::solve")
-    _close(orc.apply(f), gu.vecs(g, "apply_out"), 1e-10, "apply")
+    loose = 1e-8 if "nu3" in name else 1e-10   # three smooth vectors per subdomain: the coarse matrix is ill-conditioned
+    _close(orc.apply(f), gu.vecs(g, "apply_out"), loose, "apply")
     if opt["correction"]:
-        _close(orc.deflation(f), gu.vecs(g, "deflation_out"), 1e-10, "deflation")
+        _close(orc.deflation(f), gu.vecs(g, "deflation_out"), loose, "deflation")
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.MULTI_VECTOR_CASES + gu.COMPLEX_CASES)
 def test_gmres_matches_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -64,8 +66,8 @@ def test_gmres_matches_reference(name):
     assert len(hist) == len(ref_hist)
     for (j, beta, nrm), row in zip(hist, ref_hist):
         assert j == int(row[0])
-        assert abs(beta - row[1]) <= 2e-6 * row[1] + 1e-300   # the log prints 7 significant digits
-    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
+        assert abs(beta - row[1]) <= (2e-3 if "nu3" in name else 2e-6) * row[1] + 1e-300   # the log prints 7 significant digits
+    _close(sol, gu.vecs(g, "sol"), 1e-6 if "nu3" in name else 1e-8, "solution")
     res = orc.compute_residual(sol, gu.vecs(g, "f"))
     assert np.allclose(res, g["residual_r0"], rtol=1e-5)
 
@@ -120,6 +122,7 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("p40_cg_asm", "cg", 2e-6), ("p40_bgmres_mu4", "bgmres", 2e-6), ("p40_bgmres_deflated_mu2", "bgmres", 2e-4),
     ("p30_6ranks_bgmres_left_mu3", "bgmres", 2e-6), ("p40_fbgmres_mu3", "bgmres", 2e-4),
     ("p40_bgmres_rhs_deflation_mu4", "bgmres", 2e-6), ("p40_bgmres_rhs_deflation_restart_mu4", "bgmres", 5e-5),
+    ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6),
     ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-2), ("p40_bcg_asm_mu3", "bcg", 2e-6)])
 def test_other_krylov_methods_match_reference(name, method, tol_hist):
     """CG, Block CG and Block GMRES restated in numpy (oracle/ras_oracle.py: cg, bcg, bgmres) against the runs of the compiled
