@@ -45,6 +45,9 @@ def _declare(lib):
         "HpddmHipSchwarzMultiplicityScaling": (I, [P, P]),
         "HpddmHipSchwarzInitialize": (I, [P, I, P]),
         "HpddmHipSchwarzSetVectors": (I, [P, I, I, P]),
+        "HpddmHipSchwarzSetSubdomainZ": (I, [P, I, I, P, P, P, I, ctypes.c_char, I, P, P, P]),
+        "HpddmHipSchwarzSetVectorsZ": (I, [P, I, I, P]),
+        "HpddmHipSchwarzIsComplex": (I, [P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),

@@ -668,6 +668,10 @@ int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int his
 int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, int history_cap)
 {
   const int method = (int)getopt("krylov_method", 0);
+  if (is_complex) { // K = std::complex<double>: krylov_complex.hip
+    HH_CHECK(method == 0 || method == 1, "krylov_method: gmres and bgmres are built for complex scalars");
+    return method == 1 ? bgmres_z(b, x, mu, history, history_cap) : gmres_z(b, x, mu, history, history_cap);
+  }
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
   if (method == 2) return cg(b, x, mu, history, history_cap);
   if (method == 3) return bcg(b, x, mu, history, history_cap);

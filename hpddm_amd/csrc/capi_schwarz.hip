@@ -70,18 +70,57 @@ int HpddmHipSchwarzSetSubdomain(HpddmHipSchwarz *A, int s, int n, const int *ia,
     A->op.set_subdomain(s, n, ia, ja, a, sym != 0, numbering == 'F', neighbors, list, sizes, connectivity);
     return 0;)
 }
+int HpddmHipSchwarzSetSubdomainZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity)
+{
+  HH_TRY(
+    HH_CHECK(A && ia && ja && a, "null argument");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    A->op.set_subdomain_z(s, n, ia, ja, a, sym != 0, numbering == 'F', neighbors, list, sizes, connectivity);
+    return 0;)
+}
+int HpddmHipSchwarzIsComplex(const HpddmHipSchwarz *A) { return A && A->op.is_complex ? 1 : 0; }
+// the partition of unity is real whatever K is (underlying_type<K>, include/HPDDM_schwarz.hpp:87): one weight per unknown in
+// the interface, duplicated on the (re, im) pair inside
 int HpddmHipSchwarzMultiplicityScaling(HpddmHipSchwarz *A, double *const *d)
 {
   HH_TRY(
     HH_CHECK(A && d, "null argument");
-    A->op.multiplicity_scaling(d);
+    if (!A->op.is_complex) {
+      A->op.multiplicity_scaling(d);
+      return 0;
+    }
+    std::vector<std::vector<double>> w(A->op.nsub);
+    std::vector<double *>            p(A->op.nsub);
+    for (int s = 0; s < A->op.nsub; ++s) {
+      const int n = A->op.subs[s].n / 2;
+      w[s].resize(2 * (size_t)n);
+      for (int i = 0; i < n; ++i) w[s][2 * i] = w[s][2 * i + 1] = d[s][i];
+      p[s] = w[s].data();
+    }
+    A->op.multiplicity_scaling(p.data());
+    for (int s = 0; s < A->op.nsub; ++s)
+      for (int i = 0; i < A->op.subs[s].n / 2; ++i) d[s][i] = w[s][2 * i];
     return 0;)
 }
 int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d)
 {
   HH_TRY(
-    HH_CHECK(A && d, "null argument");
-    A->op.initialize(s, d);
+    HH_CHECK(A && d && s >= 0 && s < A->op.nsub, "null argument or bad subdomain");
+    if (!A->op.is_complex) {
+      A->op.initialize(s, d);
+      return 0;
+    }
+    const int           n = A->op.subs[s].n / 2;
+    std::vector<double> w(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) w[2 * i] = w[2 * i + 1] = d[i];
+    A->op.initialize(s, w.data());
+    return 0;)
+}
+int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z)
+{
+  HH_TRY(
+    HH_CHECK(A && (Z || nu == 0), "null argument");
+    A->op.set_vectors_z(s, nu, Z);
     return 0;)
 }
 int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z)

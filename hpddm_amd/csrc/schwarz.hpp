@@ -41,6 +41,10 @@ struct SchwarzSub {
   std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B)
   int                 gevp_iterations = 0;
   std::unique_ptr<LocalSolver> ls;
+  // complex128 operators (Schwarz::is_complex): everything above is the real-equivalent embedding, n = 2 x (complex rows);
+  // zphase holds, per complex row, the unit phase conj(a_ii) / |a_ii| the rows are multiplied by before the pivot-free
+  // factorisation (same device as HpddmHipSubdomainNumfactZ, capi_subdomain.hip)
+  std::vector<double> zphase;
 };
 
 // Transport of the cross-GPU part of the halo and of the Krylov reductions.  The library packs / unpacks on the device
@@ -81,6 +85,12 @@ struct Schwarz {
   std::map<std::string, double> opt;
   PrcndtnrType                  type = PRC_GE;
   bool                          device_ready = false, factored = false, coarse_ready = false;
+  // K = std::complex<double>: subdomains handed over with set_subdomain_z.  Matrices, vectors and deflation vectors live in
+  // the real-equivalent embedding (entry a -> [a_r, -a_i; a_i, a_r] on interleaved (re, im) vectors, which is the memory
+  // layout of std::complex<double> arrays), so every operator of the path runs on the real kernels; only the Krylov
+  // methods differ (complex inner products and coefficients, krylov_complex.hip)
+  bool           is_complex = false;
+  DevBuf<double> zphase_d, wz;
   // ---- device-resident batched data ----
   long long              ntot = 0;
   std::vector<long long> voff; // nsub+1
@@ -113,6 +123,10 @@ struct Schwarz {
     auto it = opt.find(k);
     return it == opt.end() ? def : it->second;
   }
+  void set_subdomain_z(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
+  void set_vectors_z(int s, int nu, const double *Z); // n x nu complex, column-major
+  int  gmres_z(const double *b, double *x, int mu, double *history, int history_cap);  // krylov_complex.hip
+  int  bgmres_z(const double *b, double *x, int mu, double *history, int history_cap);
   void set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
   void multiplicity_scaling(double *const *d);
   void initialize(int s, const double *d);
@@ -128,6 +142,7 @@ struct Schwarz {
   void csrmm(const double *x, double *y, int mu, double alpha, double beta); // y = beta*y + alpha*A*x
   void gmv(const double *in, double *out, int mu);
   void local_solve(const double *in, double *out, int mu);
+  void solve_factor(const double *in, double *out, int mu); // plan.solve, plus the row phases of complex operators
   void deflation(const double *in, double *out, int mu);
   void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip)
   void coarse_solve(const double *uc, double *y, int mu);     // y = E^{-1} uc

@@ -147,18 +147,24 @@ class Schwarz:
             raise HpddmHipError(self._lib.HpddmHipLastError().decode())
         self.nsub, self.first, self.nglobal = nsub, first_global, nglobal
         self.n = [0] * nsub
+        self.complex = False   # K = std::complex<double>: set by the first complex subdomain matrix
 
     # -- construction, same order as examples/schwarz.cpp:90-126 --
     def set_subdomain(self, s, n, ia, ja, a, sym, neighbors, connectivity, numbering="C"):
         """schwarzCreate(Mat, o, connectivity) (interface/hpddm.py:216) for local subdomain s."""
         ia = np.ascontiguousarray(ia, dtype=np.int32)
         ja = np.ascontiguousarray(ja, dtype=np.int32)
-        a = np.ascontiguousarray(a, dtype=np.float64)
+        cplx = np.iscomplexobj(a)
+        if cplx != self.complex and any(self.n):
+            raise HpddmHipError("real and complex subdomain matrices cannot be mixed")
+        self.complex = cplx
+        a = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)   # complex128 = interleaved (re, im) doubles
         neighbors = np.ascontiguousarray(neighbors, dtype=np.int32)
         conn = [np.ascontiguousarray(c, dtype=np.int32) for c in connectivity]
         sizes = np.array([c.size for c in conn], dtype=np.int32)
         ptrs = (ctypes.c_void_p * max(1, len(conn)))(*[c.ctypes.data for c in conn])
-        check(self._lib.HpddmHipSchwarzSetSubdomain(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode(),
+        setter = self._lib.HpddmHipSchwarzSetSubdomainZ if cplx else self._lib.HpddmHipSchwarzSetSubdomain
+        check(setter(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode(),
                                                     len(conn), _dptr(neighbors), _dptr(sizes), ctypes.cast(ptrs, ctypes.c_void_p)))
         self.n[s] = int(n)
 
@@ -177,9 +183,10 @@ class Schwarz:
 
     def set_vectors(self, s, Z):
         """setVectors + initializeCoarseOperator (interface/hpddm.py:203-208): Z is (n_s, nu)."""
-        Z = _as_f(Z)
+        Z = _as_f(Z, np.complex128 if self.complex else np.float64)
         Z = Z.reshape(Z.shape[0], -1, order="F")
-        check(self._lib.HpddmHipSchwarzSetVectors(self._h, s, Z.shape[1], _dptr(Z)))
+        setter = self._lib.HpddmHipSchwarzSetVectorsZ if self.complex else self._lib.HpddmHipSchwarzSetVectors
+        check(setter(self._h, s, Z.shape[1], _dptr(Z)))
 
     def solve_gevp(self, s, n, ia, ja, a, sym, numbering="C"):
         """schwarzSolveGEVP(A, MatNeumann) (interface/hpddm.py:244): GenEO vectors of local subdomain s; returns the eigenvalues."""
@@ -303,11 +310,14 @@ class Schwarz:
     # -- batched layout helpers --
     def pack(self, xs):
         """list of per-subdomain (n_s,) / (n_s, mu) arrays -> one flat array in the library's batched layout."""
-        xs = [_as_f(x) for x in xs]
+        xs = [_as_f(x, np.complex128 if self.complex else np.float64) for x in xs]
         mu = 1 if xs[0].ndim == 1 else xs[0].shape[1]
-        return np.concatenate([x.reshape(-1, order="F") for x in xs]), mu
+        flat = np.concatenate([x.reshape(-1, order="F") for x in xs])
+        return (flat.view(np.float64) if self.complex else flat), mu   # complex blocks travel as interleaved (re, im) doubles
 
     def unpack(self, flat, mu):
+        if self.complex:
+            flat = flat.view(np.complex128)
         out, off = [], 0
         for n in self.n:
             blk = flat[off:off + n * mu]

@@ -85,6 +85,20 @@ int HpddmHipSchwarzMultiplicityScaling(HpddmHipSchwarz *A, double *const *d);
 int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d);
 /* HpddmSetVectors + HpddmInitializeCoarseOperator (HPDDM.h:95-96): nu deflation vectors of subdomain s, column-major n_s x nu */
 int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z);
+/* ---- K = std::complex<double> (interface/HPDDM.h is compiled for one scalar type K, HPDDM.h:34-50; FORCE_COMPLEX builds) ----
+ * HpddmHipSchwarzSetSubdomainZ replaces SetSubdomain for complex operators: `a` holds nnz (re, im) pairs, sym != 0 is the lower
+ * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  The operator then lives in the real-equivalent embedding
+ * (entry a -> [a_r, -a_i; a_i, a_r] on interleaved (re, im) vectors), so that every vector entry point of this header
+ * (Exchange, GMV, Apply, Deflation, Solve, ComputeResidual and the *Device variants) takes std::complex<double> arrays --
+ * n_s complex values per right-hand side, i.e. 2 n_s doubles -- through the same double pointers.  GetDof returns 2 n_s.
+ * MultiplicityScaling / Initialize keep their real d of length n_s (the partition of unity is real,
+ * include/HPDDM_schwarz.hpp:87).  SetVectorsZ: column-major n_s x nu complex deflation vectors.  The coarse operator is
+ * always 'G' (examples/schwarz.hpp:48-79); GMRES and BGMRES run with complex inner products and coefficients
+ * (include/HPDDM_GMRES.hpp instantiated for complex K).  GenEO, CG/BCG, the optimised matrices and the penalised rows are
+ * real-only in this build. */
+int HpddmHipSchwarzSetSubdomainZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity);
+int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z);
+int HpddmHipSchwarzIsComplex(const HpddmHipSchwarz *A);
 /* HpddmSchwarzSolveGEVP (HPDDM.h:107, Schwarz::solveGEVP include/HPDDM_schwarz.hpp:665-715): GenEO coarse space of local
  * subdomain s from its Neumann matrix (same CSR conventions as SetSubdomain): the -hpddm_geneo_nu (default 20) lowest
  * eigenvectors of A_N x = lambda B x, B = scaleIntoOverlap(A_N), kept below -hpddm_geneo_threshold if it is set.

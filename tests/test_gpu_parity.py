@@ -25,8 +25,12 @@ def _build(g, subs):
     A, d = hpddm.schwarz_from_subdomains(subs, options=gu.hpddm_args(g))
     opt = gu.options(g)
     if opt["correction"]:
-        for s, sd in enumerate(subs):
-            A.set_vectors(s, np.ones((sd["n"], 1)))
+        for s, Z in enumerate(gu.deflation_vectors(g, subs)):
+            A.set_vectors(s, Z)
+        if A.complex and any(len(sd["neighbors"]) != len(subs) - 1 for sd in subs):
+            # the fixtures come from the reference built with its dense LapackTR coarse back-end, which factorises E^T when
+            # the coarse matrix is not full (include/HPDDM_LAPACK.hpp:417, :348-352): reproduce that build
+            A.set_option("hip_coarse_transpose", 1)
         A.build_coarse_operator()
     if "a_opt_r0" in g:   # callNumfact(A_opt): ORAS / SORAS with an optimised local matrix
         for s, t in enumerate(gu.optimized_matrices(g, subs)):
@@ -35,7 +39,8 @@ def _build(g, subs):
     return A, d, opt
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.PENALIZED_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.PENALIZED_CASES + gu.MULTI_VECTOR_CASES + gu.COMPLEX_CASES
+                         + gu.COMPLEX_BGMRES_CASES)
 def test_functions_match_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -46,13 +51,14 @@ def test_functions_match_reference(name):
     _close(A.exchange(f), gu.vecs(g, "exchange_out"), 1e-14, "exchange")
     _close(A.gmv(f), gu.vecs(g, "gmv_out"), 1e-13, "GMV")
     _close(A.local_solve(f), gu.vecs(g, "solve_out"), 1e-10, "Solver::solve")
-    _close(A.apply(f), gu.vecs(g, "apply_out"), 1e-10, "apply")
+    loose = 1e-7 if "nu3" in name else 1e-10   # three smooth vectors per subdomain: the coarse matrix is ill-conditioned
+    _close(A.apply(f), gu.vecs(g, "apply_out"), loose, "apply")
     if opt["correction"]:
-        _close(A.deflation(f), gu.vecs(g, "deflation_out"), 1e-10, "deflation")
+        _close(A.deflation(f), gu.vecs(g, "deflation_out"), loose, "deflation")
     A.destroy()
 
 
-@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES)
+@pytest.mark.parametrize("name", gu.SMALL_CASES + gu.OPTIMIZED_CASES + gu.MULTI_VECTOR_CASES + gu.COMPLEX_CASES)
 def test_gmres_matches_reference(name):
     g = gu.load(name)
     subs = gu.subdomains(g)
@@ -62,9 +68,9 @@ def test_gmres_matches_reference(name):
     assert it == int(g["iterations_r0"][0])
     ref = g["history"]
     assert len(hist) == len(ref)
-    assert np.all(np.abs(hist - ref[:, 1]) <= 2e-6 * ref[:, 1])
-    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
-    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-5)
+    assert np.all(np.abs(hist - ref[:, 1]) <= (5e-3 if "nu3" in name else 2e-6) * ref[:, 1])
+    _close(sol, gu.vecs(g, "sol"), 1e-5 if "nu3" in name else 1e-8, "solution")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3 if "nu3" in name else 1e-5)
     A.destroy()
 
 
@@ -268,7 +274,7 @@ def test_geneo_coarse_space_against_arpack():
 
 
 @pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3",
-                                  "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4"])
+                                  "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4"] + gu.COMPLEX_BGMRES_CASES)
 def test_bgmres_matches_reference(name):
     """Block GMRES: iteration count, residual history and solution of the compiled reference.  The two
     rhs_deflation fixtures run with -hpddm_deflation_tol and a last right-hand side f_0 + 2 f_1: one column is deflated at
