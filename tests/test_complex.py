@@ -58,3 +58,68 @@ def test_hermitian_positive_definite_takes_the_symmetric_path():
     H = (K + 1j * 0.3 * float(n * n) * (G - G.T)).tocsr()   # Hermitian: real symmetric + i * skew
     assert abs(H - H.getH()).max() < 1e-12
     assert _check(H, spd=True, mu=2) == 0      # Cholesky of the real-equivalent SPD matrix
+
+
+def _helmholtz3d(N, parts, overlap, shift):
+    """3-D shifted Laplacian with absorption, split like configs[4] (BASELINE.json): the 7-point stencil of generate3d with the
+    diagonal times `shift` (complex, |shift| < 1: indefinite real part), complex right-hand sides, and per subdomain a
+    plane-wave coarse space (constant + two complex exponentials), the textbook stand-in for the DtN vectors"""
+    from hpddm_amd.generate import generate3d
+    subs = generate3d(N, parts, overlap, sym=False, rhs="smooth")
+    rng = np.random.default_rng(5)
+    out, Z = [], []
+    for r, sd in enumerate(subs):
+        sd = dict(sd)
+        a = sd["a"].astype(np.complex128)
+        ia, ja = sd["ia"], sd["ja"]
+        for i in range(sd["n"]):
+            p = ia[i] + np.nonzero(ja[ia[i]:ia[i + 1]] == i)[0][0]
+            a[p] *= shift
+        sd["a"] = a
+        out.append(sd)
+        t = np.arange(sd["n"], dtype=np.float64)
+        Z.append(np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * r)], axis=1))
+    return out, Z
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("correction", ["deflated", "balanced"])
+def test_helmholtz_like_two_level_block_gmres_against_oracle(correction):
+    """configs[4] of BASELINE.json scaled down: complex 3-D operator on 8 subdomains, two-level RAS with complex deflation
+    vectors, Block GMRES with 8 right-hand sides -- device path against the numpy oracle (which is pinned on the reference's
+    complex build, tests/test_oracle_golden.py)"""
+    from hpddm_amd import hpddm
+    from oracle import ras_oracle as ro
+    subs, Z = _helmholtz3d(12, 8, 1, 0.8 + 0.02j)   # one restart: 23 / 22 iterations
+    mu = 8
+    rng = np.random.default_rng(17)
+    A, d = hpddm.schwarz_from_subdomains(subs, options=f"-hpddm_schwarz_coarse_correction {correction} -hpddm_krylov_method bgmres -hpddm_gmres_restart 12")
+    assert A.complex
+    for s, z in enumerate(Z):
+        A.set_vectors(s, z)
+    A.build_coarse_operator()
+    A.call_numfact()
+    orc = ro.Oracle(subs, correction=correction)
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    orc.numfact()
+    orc.set_vectors(Z)
+    orc.build_coarse(lapacktr=False)   # the plain E, the library's default
+    f = orc.exchange([rng.standard_normal((sd["n"], mu)) + 1j * rng.standard_normal((sd["n"], mu)) for sd in subs])
+
+    def close(a, b, tol, what):
+        sc = max(np.abs(x).max() for x in b)
+        err = max(np.abs(x - y).max() for x, y in zip(a, b)) / sc
+        assert err <= tol, (what, err)
+
+    close(A.gmv(f), orc.gmv(f), 1e-13, "GMV")
+    close(A.local_solve(f), orc.local_solve(f), 1e-10, "local solve")
+    close(A.deflation(f), orc.deflation(f), 1e-9, "deflation")
+    close(A.apply(f), orc.apply(f), 1e-9, "apply")
+    it, sol, hist = A.solve(f, history=True)
+    it_o, sol_o, hist_o = ro.bgmres(orc, f, restart=12)
+    assert it == it_o and it < 60
+    assert np.allclose(hist, [h[1] for h in hist_o], rtol=1e-4)
+    close(sol, sol_o, 1e-7, "solution")
+    res = A.compute_residual(sol, f)
+    assert np.all(res[1::2] <= 2e-6 * res[0::2] * 50)   # right-preconditioned: true residual within the usual factor of the estimate
+    A.destroy()
