@@ -622,6 +622,247 @@ static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int
   return std::min(i, max_it);
 }
 
+// Breakdown-free block CG: IterativeMethod::BFBCG (include/HPDDM_CG.hpp:342-482).  Every iteration the block of search
+// directions goes through RRQR (include/HPDDM_iterative.hpp:583-595: CholQR keeping its rank, or with -hpddm_deflation_tol the
+// pivoted Cholesky of the Gram matrix trimmed at that tolerance); the recurrences run on the d leading directions while all mu
+// solutions and residuals are updated, their columns permuted by the pivots in between.  On the device the blocks keep mu
+// columns: deflated directions are zero columns, column permutations are block updates with a permutation matrix.
+// Returns -2 if the d x d matrix P^T A P is not positive definite (the caller then runs CG).
+template <int MU>
+static int bfbcg_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
+{
+  constexpr int mu = MU;
+  A.reserve(mu);
+  hipStream_t     st        = library_stream();
+  const double    tol       = A.getopt("tol", 1.0e-6), defl_tol = A.getopt("deflation_tol", -1.0);
+  const bool      deflation = defl_tol > -0.9;
+  const int       max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int       verbosity = (int)A.getopt("verbosity", 0);
+  const long long cnt       = A.ntot * mu;
+  const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  const int       nblk = 64;
+  DevBuf<double>  P, Q, Z, R, T, partial, gram_d, coef_d;
+  P.alloc((size_t)cnt), Q.alloc((size_t)cnt), Z.alloc((size_t)cnt), R.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  partial.alloc((size_t)nblk * mu * mu), gram_d.alloc((size_t)mu * mu), coef_d.alloc((size_t)mu * mu);
+  auto gram = [&](const double *V, const double *W, std::vector<double> &G) { // G[a * mu + b] = <V[., a], W[., b]>_D
+    G.resize((size_t)mu * mu);
+    hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, 1), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, V, cnt, W, partial.p);
+    hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), mu * mu) == 0, "all-reduce failed");
+  };
+  auto axpy_block = [&](const double *V, const std::vector<double> &C, double sign, double beta, double *W) { // W = beta W + sign V C
+    HIP_OK(hipMemcpyAsync(coef_d.p, C.data(), sizeof(double) * mu * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * mu * mu, st, A.voff_d.p, A.n_d.p, V, cnt, 1, coef_d.p, sign, beta, W);
+  };
+  // columns of V permuted in place: forward = new column k is old column piv[k] (lapmt forwrd = 1), backward its inverse
+  auto permute = [&](double *V, const std::vector<int> &piv, bool forward) {
+    std::vector<double> Pm((size_t)mu * mu, 0.0);
+    for (int k = 0; k < mu; ++k) {
+      if (forward) Pm[(size_t)piv[k] * mu + k] = 1.0;
+      else Pm[(size_t)k * mu + piv[k]] = 1.0;
+    }
+    HIP_OK(hipMemcpyAsync(T.p, V, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    axpy_block(T.p, Pm, 1.0, 0.0, V);
+  };
+  auto permute_host = [&](std::vector<double> &v, const std::vector<int> &piv, bool forward) {
+    std::vector<double> o(mu);
+    for (int k = 0; k < mu; ++k) {
+      if (forward) o[k] = v[piv[k]];
+      else o[piv[k]] = v[k];
+    }
+    v = o;
+  };
+  // RRQR of the block W: R (row-major), piv, returns the rank d; W <- (W Pi)(:, :d) R11^{-1}, zero columns beyond
+  std::vector<double> Rm;
+  std::vector<int>    piv(mu);
+  auto rrqr = [&](double *W) {
+    std::vector<double> G;
+    gram(W, W, G);
+    Rm.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int j = 0; j < mu; ++j) {
+      int    q    = j;
+      double best = G[(size_t)j * mu + j];
+      for (int k = 0; k < j; ++k) best -= Rm[(size_t)k * mu + j] * Rm[(size_t)k * mu + j];
+      if (deflation)
+        for (int c = j + 1; c < mu; ++c) {
+          double dj = G[(size_t)c * mu + c];
+          for (int k = 0; k < j; ++k) dj -= Rm[(size_t)k * mu + c] * Rm[(size_t)k * mu + c];
+          if (dj > best) best = dj, q = c;
+        }
+      if (!(best > 0.0)) {
+        rank = j;
+        break;
+      }
+      if (q != j) {
+        for (int c = 0; c < mu; ++c) std::swap(G[(size_t)j * mu + c], G[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(G[(size_t)r * mu + j], G[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(Rm[(size_t)r * mu + j], Rm[(size_t)r * mu + q]);
+        std::swap(piv[j], piv[q]);
+      }
+      const double dj        = std::sqrt(best);
+      Rm[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        double v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= Rm[(size_t)k * mu + j] * Rm[(size_t)k * mu + c];
+        Rm[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    if (!deflation) // potrf leaves the rest of the upper triangle as it was: the norms below read it
+      for (int r = rank; r < mu; ++r)
+        for (int c = r; c < mu; ++c) Rm[(size_t)r * mu + c] = G[(size_t)r * mu + c];
+    if (deflation)
+      while (rank > 1 && std::abs(Rm[(size_t)(rank - 1) * mu + rank - 1] / Rm[0]) <= defl_tol) --rank;
+    std::vector<double> Rinv((size_t)mu * mu, 0.0), C((size_t)mu * mu, 0.0);
+    for (int c = 0; c < rank; ++c)
+      for (int i = c; i >= 0; --i) {
+        double v = (i == c) ? 1.0 : 0.0;
+        for (int k = i + 1; k <= c; ++k) v -= Rm[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
+        Rinv[(size_t)i * mu + c] = v / Rm[(size_t)i * mu + i];
+      }
+    for (int k = 0; k < rank; ++k)
+      for (int c = 0; c < rank; ++c) C[(size_t)piv[k] * mu + c] = Rinv[(size_t)k * mu + c];
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    axpy_block(T.p, C, 1.0, 0.0, W);
+    return rank;
+  };
+  // Cholesky of the leading d x d block of G (upper, row-major in U); false on a non-positive pivot
+  auto chol_d = [&](const std::vector<double> &G, int d, std::vector<double> &U) {
+    U.assign((size_t)mu * mu, 0.0);
+    for (int j = 0; j < d; ++j) {
+      double dj = G[(size_t)j * mu + j];
+      for (int k = 0; k < j; ++k) dj -= U[(size_t)k * mu + j] * U[(size_t)k * mu + j];
+      if (!(dj > 0.0)) return false;
+      dj                    = std::sqrt(dj);
+      U[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < d; ++c) {
+        double v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= U[(size_t)k * mu + j] * U[(size_t)k * mu + c];
+        U[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    return true;
+  };
+  // X (d rows used, mu columns) <- (U^T U)^{-1} X; rows beyond d are set to zero
+  auto potrs_d = [&](const std::vector<double> &U, int d, std::vector<double> &X) {
+    for (int c = 0; c < mu; ++c) {
+      for (int i = 0; i < d; ++i) {
+        double v = X[(size_t)i * mu + c];
+        for (int k = 0; k < i; ++k) v -= U[(size_t)k * mu + i] * X[(size_t)k * mu + c];
+        X[(size_t)i * mu + c] = v / U[(size_t)i * mu + i];
+      }
+      for (int i = d - 1; i >= 0; --i) {
+        double v = X[(size_t)i * mu + c];
+        for (int k = i + 1; k < d; ++k) v -= U[(size_t)i * mu + k] * X[(size_t)k * mu + c];
+        X[(size_t)i * mu + c] = v / U[(size_t)i * mu + i];
+      }
+      for (int i = d; i < mu; ++i) X[(size_t)i * mu + c] = 0.0;
+    }
+  };
+  A.start(b, x, mu);
+  A.gmv(x, T.p, mu);
+  hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, T.p, R.p);
+  A.apply(R.p, P.p, mu);
+  int                 d = rrqr(P.p);
+  std::vector<double> norm(mu), G, U, alpha, beta;
+  for (int nu = 0; nu < mu; ++nu) {
+    double v = 0.0;
+    for (int r = 0; r <= nu; ++r) v += Rm[(size_t)r * mu + nu] * Rm[(size_t)r * mu + nu];
+    norm[nu] = std::sqrt(v);
+  }
+  if (deflation) {
+    // (the columns of R are in pivoted order already; the reference permutes `norm` once more with x and r,
+    // include/HPDDM_CG.hpp:395-399 -- reproduced, the convergence test depends on it)
+    permute(x, piv, true);
+    permute(R.p, piv, true);
+    permute_host(norm, piv, true);
+  }
+  int i = d != 0 ? 1 : 0, nhist = 0;
+  while (i <= max_it && d != 0) {
+    A.gmv(P.p, Q.p, mu);
+    gram(P.p, Q.p, G);
+    for (int a = 0; a < d; ++a)
+      for (int c = 0; c < a; ++c) G[(size_t)a * mu + c] = G[(size_t)c * mu + a]; // gemmt "U"
+    gram(P.p, R.p, alpha);
+    if (!chol_d(G, d, U)) return -2;
+    potrs_d(U, d, alpha);
+    axpy_block(P.p, alpha, 1.0, 1.0, x);
+    axpy_block(Q.p, alpha, -1.0, 1.0, R.p);
+    A.apply(R.p, Z.p, mu);
+    gram(Q.p, Z.p, beta);
+    std::vector<double> zz;
+    gram(Z.p, Z.p, zz);
+    int    conv = 0, which = 0;
+    double best = -1.0;
+    for (int nu = 0; nu < mu; ++nu) {
+      const double pt = std::sqrt(zz[(size_t)nu * mu + nu]);
+      if ((tol > 0.0 && pt / norm[nu] <= tol) || (tol < 0.0 && pt <= -tol)) ++conv;
+      if (nu < d && pt / norm[nu] > best) best = pt / norm[nu], which = nu;
+    }
+    const double res = best * norm[which];
+    if (history && nhist < history_cap) history[nhist] = res;
+    ++nhist;
+    if (verbosity > 2) {
+      printf("BFBCG: %3d %e %e %e < %e", i, res, norm[which], best, tol);
+      if (d != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - d);
+      printf("\n");
+    }
+    if (conv == mu) break;
+    if (++i <= max_it) {
+      potrs_d(U, d, beta);
+      HIP_OK(hipMemcpyAsync(Q.p, P.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st)); // Q is free again: the old directions
+      HIP_OK(hipMemcpyAsync(P.p, Z.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_block(Q.p, beta, -1.0, 1.0, P.p);
+      if (deflation) {
+        permute(x, piv, false);
+        permute(P.p, piv, false);
+        permute(R.p, piv, false);
+        permute_host(norm, piv, false);
+      }
+      d = rrqr(P.p);
+      if (deflation) {
+        permute(x, piv, true);
+        permute(R.p, piv, true);
+        permute_host(norm, piv, true);
+      }
+    }
+  }
+  if (deflation) permute(x, piv, false);
+  if (verbosity) {
+    if (i != max_it + 1) printf("BFBCG converges after %d iteration%s\n", i, i > 1 ? "s" : "");
+    else printf("BFBCG does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(i, max_it);
+}
+
+int Schwarz::bfbcg(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  // same hand-over as the reference (include/HPDDM_CG.hpp:351-357): not a symmetric preconditioner -> GMRES; flexible -> CG
+  const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
+  int it;
+  switch (mu) {
+  case 1: it = bfbcg_impl<1>(*this, b, x, history, history_cap); break;
+  case 2: it = bfbcg_impl<2>(*this, b, x, history, history_cap); break;
+  case 3: it = bfbcg_impl<3>(*this, b, x, history, history_cap); break;
+  case 4: it = bfbcg_impl<4>(*this, b, x, history, history_cap); break;
+  case 5: it = bfbcg_impl<5>(*this, b, x, history, history_cap); break;
+  case 6: it = bfbcg_impl<6>(*this, b, x, history, history_cap); break;
+  case 7: it = bfbcg_impl<7>(*this, b, x, history, history_cap); break;
+  case 8: it = bfbcg_impl<8>(*this, b, x, history, history_cap); break;
+  default: HH_CHECK(false, "BFBCG: 1 <= mu <= 8 in this build"); it = -1;
+  }
+  if (it == -2) return cg(b, x, mu, history, history_cap);
+  return it;
+}
+
 int Schwarz::bcg(const double *b, double *x, int mu, double *history, int history_cap)
 {
   HH_CHECK(factored, "solve before CallNumfact");
@@ -675,7 +916,8 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
   if (method == 2) return cg(b, x, mu, history, history_cap);
   if (method == 3) return bcg(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: only gmres, bgmres, cg and bcg are built");
+  if (method == 6) return bfbcg(b, x, mu, history, history_cap);
+  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg and bfbcg are built");
   return gmres(b, x, mu, history, history_cap);
 }
 

@@ -58,6 +58,8 @@ CASES = [
     ("z_p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     # several deflation vectors per subdomain (the constant one + smooth local ones, dumped as ev): coarse blocks larger than 1 x 1
     ("p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    ("p40_bfbcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_tol 1e-4"),
+    ("p40_bfbcg_asm_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_deflation_tol 1e-6 -hpddm_tol 1e-4"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),
@@ -95,7 +97,7 @@ def run_case(name, ranks, mu, opts, tmp):
         print(res.stdout[-2000:], res.stderr[-2000:])
         raise SystemExit(f"{name}: harness failed")
     hist = []
-    for m in re.finditer(r"^(?:B?GMRES|B?CG):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
+    for m in re.finditer(r"^(?:B?GMRES|B?CG|BFBCG):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
         hist.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))))
     data = {"ranks": np.int32(ranks), "mu": np.int32(mu), "options": np.array(opts),
             "history": np.array(hist, dtype=np.float64).reshape(-1, 4)}

@@ -308,6 +308,25 @@ def test_cg_matches_reference():
     A.destroy()
 
 
+@pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4"])
+def test_bfbcg_matches_reference(name):
+    """Breakdown-free block CG (include/HPDDM_CG.hpp:342-482), plain and with -hpddm_deflation_tol on a block whose last
+    right-hand side is f_0 + 2 f_1 (one direction deflated at every iteration): the reference's 31 / 32 iterations,
+    residual history, solution and final residuals"""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist = A.solve(f, history=True)
+    assert it == int(g["iterations_r0"][0])
+    ref = g["history"]
+    assert len(hist) == len(ref)
+    assert np.all(np.abs(hist - ref[:, 1]) <= 1e-4 * ref[:, 1])
+    _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3)
+    A.destroy()
+
+
 @pytest.mark.parametrize("name,skip", [("p30_6ranks_bcg_asm_sym_mu2", 0), ("p40_bcg_asm_mu3", 4)])
 def test_bcg_matches_reference(name, skip):
     """Block CG (include/HPDDM_CG.hpp:169-337).  On these inputs the reference's own BCG does not reach 1e-6 in 100 iterations

@@ -123,12 +123,14 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("p30_6ranks_bgmres_left_mu3", "bgmres", 2e-6), ("p40_fbgmres_mu3", "bgmres", 2e-4),
     ("p40_bgmres_rhs_deflation_mu4", "bgmres", 2e-6), ("p40_bgmres_rhs_deflation_restart_mu4", "bgmres", 5e-5),
     ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6),
+    ("p40_bfbcg_asm_mu3", "bfbcg", 1e-5), ("p40_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-5),
     ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-2), ("p40_bcg_asm_mu3", "bcg", 2e-6)])
 def test_other_krylov_methods_match_reference(name, method, tol_hist):
     """CG, Block CG and Block GMRES restated in numpy (oracle/ras_oracle.py: cg, bcg, bgmres) against the runs of the compiled
     reference: iteration counts, residual histories, final residuals.  (BCG prints the right-hand side with the largest
     relative residual; with two that agree to 4 digits the pick flips, hence the few-percent band on that one history.  In
     the second BCG fixture the reference meets a rank-deficient block after 4 iterations and hands over to CG: so do we.
+    The BFBCG fixtures (breakdown-free block CG, include/HPDDM_CG.hpp:342-482) stop at 1e-4, before CG's round-off drift.
     The two rhs_deflation fixtures have a last right-hand side f_0 + 2 f_1 and -hpddm_deflation_tol set: one column is
     deflated at every restart, include/HPDDM_GMRES.hpp:201-205.)"""
     from oracle import ras_oracle as ro
@@ -142,6 +144,8 @@ def test_other_krylov_methods_match_reference(name, method, tol_hist):
     elif method == "bgmres":
         it, sol, hist = ro.bgmres(orc, f, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], variant=opt["variant"],
                                   deflation_tol=opt["deflation_tol"])
+    elif method == "bfbcg":
+        it, sol, hist = ro.bfbcg(orc, f, tol=opt["tol"], max_it=opt["max_it"], deflation_tol=opt["deflation_tol"])
     else:
         it, sol, hist, handed_over = ro.bcg(orc, f, tol=opt["tol"], max_it=opt["max_it"])
         assert handed_over == (name == "p40_bcg_asm_mu3")
