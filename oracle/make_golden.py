@@ -60,6 +60,10 @@ CASES = [
     ("p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_bfbcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_tol 1e-4"),
     ("p40_bfbcg_asm_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_deflation_tol 1e-6 -hpddm_tol 1e-4"),
+    # GCRO-DR: GMRES(10) recycling 4 harmonic Ritz vectors, two successive solves (the second one starts from the recycled space)
+    ("p40_gcrodr_two_solves", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10"),
+    ("p40_gcrodr_same_system", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_same_system 1"),
+    ("p30_6ranks_gcrodr_left_deflated_mu2", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),
@@ -97,7 +101,7 @@ def run_case(name, ranks, mu, opts, tmp):
         print(res.stdout[-2000:], res.stderr[-2000:])
         raise SystemExit(f"{name}: harness failed")
     hist = []
-    for m in re.finditer(r"^(?:B?GMRES|B?CG|BFBCG):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
+    for m in re.finditer(r"^(?:B?GMRES|B?CG|BFBCG|GCRODR):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
         hist.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))))
     data = {"ranks": np.int32(ranks), "mu": np.int32(mu), "options": np.array(opts),
             "history": np.array(hist, dtype=np.float64).reshape(-1, 4)}

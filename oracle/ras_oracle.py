@@ -25,6 +25,8 @@ Reference anchors (hpddm/hpddm 2.4.0):
   scale_into_overlap / geneo   Schwarz::scaleIntoOverlap / solveGEVP   include/HPDDM_schwarz.hpp:622-715
   cg, bcg (module level)   IterativeMethod::CG / BCG      include/HPDDM_CG.hpp:31-168, 169-337
   bgmres (module level) IterativeMethod::BGMRES + BlockArnoldi   include/HPDDM_GMRES.hpp:159-313, HPDDM_iterative.hpp:523-556,622-640,713-734
+  bfbcg (module level)  IterativeMethod::BFBCG            include/HPDDM_CG.hpp:342-482
+  gcrodr (module level) IterativeMethod::GCRODR           include/HPDDM_GCRODR.hpp:34-443
 """
 import numpy as np
 import scipy.sparse as sp
@@ -747,3 +749,195 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
         x = update_sol(dim, x)
         break
     return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist
+
+
+# ======================================================================================================================
+# GCRO-DR (IterativeMethod::GCRODR, include/HPDDM_GCRODR.hpp:34-443): GMRES with deflated restarting and recycling of a
+# k-dimensional subspace (U, C = A M^{-1} U with C^H D C = I) between the cycles and between successive solves.
+# Restated for one right-hand side at a time -- the reference runs several in lock-step, which changes nothing to the
+# iterates of each (the recurrences of the non-block method are independent per right-hand side).
+# ======================================================================================================================
+def _harmonic_select(theta, vecs, k):
+    """k columns spanning the eigenvectors of the k eigenvalues of smallest modulus (recycle_target SM, selectNu,
+    include/HPDDM_specifications.hpp:90-126), real arithmetic: a complex pair gives (Re v, Im v); a pair cut by the limit k
+    gives its real part only, like the first k columns of the reference's eigenvector array"""
+    order = sorted(range(len(theta)), key=lambda t: (abs(theta[t]), -np.imag(theta[t])))
+    cols = []
+    used = set()
+    for t in order:
+        if len(cols) >= k:
+            break
+        if t in used:
+            continue
+        v = vecs[:, t]
+        if abs(np.imag(theta[t])) <= HPDDM_EPS * max(1.0, abs(theta[t])):
+            cols.append(np.real(v))
+            used.add(t)
+        else:
+            conj = [u for u in order if u not in used and u != t and abs(theta[u] - np.conj(theta[t])) <= 1e-8 * abs(theta[t])]
+            used.add(t)
+            if conj:
+                used.add(conj[0])
+            cols.append(np.real(v))
+            if len(cols) < k:
+                cols.append(np.imag(v))
+    return np.stack(cols[:k], axis=1)
+
+
+def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right", ortho="cgs", state=None, same_system=0):
+    """returns (iterations, solution, history, state); `state` = (U, C) to hand to the next solve (OptionsPrefix::storage_).
+    same_system = value of -hpddm_recycle_same_system when the solve starts: non-zero skips the re-orthonormalisation of C
+    against the (unchanged) operator, and from 2 on -- the reference increments the option after every converged solve,
+    include/HPDDM_GCRODR.hpp:433 -- the recycled subspace is frozen (:241)."""
+    import scipy.linalg as sla
+    if recycle <= 0:
+        it, sol, hist = orc.gmres(b, tol=tol, max_it=max_it, restart=restart, variant=variant, ortho=ortho)
+        return it, sol, hist, None
+    P = orc.P
+    b = [np.asarray(v, dtype=np.float64).reshape(-1) for v in b]
+    m = max(1, min(restart, max_it))
+    k = min(m - 1, recycle)
+    dot = lambda u, v: float(orc.wdot(u, v)[0]) if u[0].ndim == 2 else float(sum((orc.d[s] * u[s] * v[s]).sum() for s in range(P)))
+    lin = lambda cs, vs: [sum(c * v[p] for c, v in zip(cs, vs)) for p in range(P)]
+    op = (lambda v: orc.apply(orc.gmv(v))) if variant == "left" else (lambda v: orc.gmv(orc.apply(v)))
+    prec = (lambda v: v) if variant == "left" else orc.apply
+    x = orc.start([v[:, None] for v in b], [np.zeros((v.shape[0], 1)) for v in b])
+    x = [v[:, 0] for v in x]
+    if variant == "left":
+        pb = orc.apply(b)
+        norm = np.sqrt(dot(pb, pb))
+    else:
+        norm = np.sqrt(dot(b, b))
+    if norm < HPDDM_EPS:
+        norm = 1.0
+    U, C = (None, None) if state is None else ([list(u) for u in state[0]], [list(c) for c in state[1]])
+    if U is not None:
+        k = len(U)
+    hist = []
+    j = 1
+    while j <= max_it:
+        r = [bb - g for bb, g in zip(b, orc.gmv(x))]
+        if variant == "left":
+            r = orc.apply(r)
+        i0 = k if U is not None else 0
+        if j == 1 and U is not None:
+            pt = [prec(u) for u in U] if variant != "left" else U
+            if not same_system:
+                C = [orc.gmv(p) if variant != "left" else orc.apply(orc.gmv(p)) for p in pt]
+                G = np.array([[dot(ci, cj) for cj in C] for ci in C])
+                R = np.linalg.cholesky(G).T                       # CholQR (QR<excluded>, include/HPDDM_iterative.hpp:622-640)
+                Ri = np.linalg.inv(R)
+                C = [lin(Ri[:, c], C) for c in range(k)]
+                pt = [lin(Ri[:, c], pt) for c in range(k)]
+                U = [lin(Ri[:, c], U) for c in range(k)]
+            h = np.array([dot(c, r) for c in C])
+            r = [rr - cc for rr, cc in zip(r, lin(h, C))]
+            if variant != "left" and same_system:
+                corr = orc.apply(lin(h, U))
+            else:
+                corr = lin(h, pt)
+            x = [xx + cc for xx, cc in zip(x, corr)]
+        s0 = dot(r, r)
+        if j == 1 and s0 < np.finfo(float).eps ** 2:
+            return 0, x, hist, (U, C) if U is not None else None
+        V = [None] * (m + 1)
+        Hbar = np.zeros((m + 1, m))                              # the Hessenberg matrix before the rotations (`save`)
+        Bm = np.zeros((k, m))                                     # C^H A M^{-1} V
+        beta0 = np.sqrt(s0)
+        V[i0] = [rr / beta0 for rr in r]
+        i = i0
+        dim = None
+        converged = False
+        while i < m and j <= max_it:
+            w = op(V[i])
+            if U is not None:
+                hb = np.array([dot(c, w) for c in C])
+                Bm[:, i] = hb
+                w = [ww - cc for ww, cc in zip(w, lin(hb, C))]
+            if ortho == "mgs":
+                for q in range(i0, i + 1):
+                    Hbar[q, i] = dot(V[q], w)
+                    w = [ww - Hbar[q, i] * vv for ww, vv in zip(w, V[q])]
+            else:
+                hs = [dot(V[q], w) for q in range(i0, i + 1)]
+                Hbar[i0:i + 1, i] = hs
+                w = [ww - cc for ww, cc in zip(w, lin(hs, V[i0:i + 1]))]
+            Hbar[i + 1, i] = np.sqrt(dot(w, w))
+            V[i + 1] = [ww / Hbar[i + 1, i] for ww in w]
+            i += 1
+            # the residual norm of the least-squares problem on the Krylov part (what the rotations of Arnoldi maintain)
+            Hk = Hbar[i0:i + 1, i0:i]
+            e1 = np.zeros(i + 1 - i0)
+            e1[0] = beta0
+            y2 = np.linalg.lstsq(Hk, e1, rcond=None)[0]
+            res = np.linalg.norm(e1 - Hk @ y2)
+            hist.append((j, res, norm))
+            if res / norm <= tol:
+                dim = i
+                converged = True
+                break
+            j += 1
+        if dim is None:
+            dim = i
+        if not converged and not (j != max_it + 1 and i == m):
+            converged = True                                      # max_it reached
+        # ---- updateSolRecycling: y2 minimises the Krylov part, y1 = C^H r - B y2 (include/HPDDM_iterative.hpp:338-393) ----
+        Hk = Hbar[i0:dim + 1, i0:dim]
+        e1 = np.zeros(dim + 1 - i0)
+        e1[0] = beta0
+        y2 = np.linalg.lstsq(Hk, e1, rcond=None)[0]
+        comb = lin(y2, V[i0:dim])
+        if U is not None:
+            y1 = (np.zeros(k) if same_system else beta0 * np.array([dot(c, V[i0]) for c in C])) - Bm[:, i0:dim] @ y2
+            comb = [a + c for a, c in zip(comb, lin(y1, U))]
+        x = [xx + cc for xx, cc in zip(x, comb if variant == "left" else orc.apply(comb))]
+        # ---- the recycled subspace ----
+        if same_system > 1:
+            pass
+        elif U is None:
+            kk = min(k, dim) if (j < k or dim < k) else k
+            Hm = Hbar[:dim, :dim]
+            hlast = Hbar[dim, dim - 1]
+            em = np.zeros(dim)
+            em[-1] = 1.0
+            f = np.linalg.solve(Hm.T, em)
+            # The reference builds this vector from the rotations of Arnoldi (include/HPDDM_GCRODR.hpp:249-261) and what its
+            # recurrence yields is c^2 H_m^{-H} e_m, c the cosine of the last rotation -- not the plain harmonic Ritz
+            # problem of the GCRO-DR paper.  Reproduced: the recycled subspace depends on it.
+            Rg = Hbar[:dim + 1, :dim].copy()
+            for q in range(dim):
+                rho = np.hypot(Rg[q, q], Rg[q + 1, q])
+                cq, sq = Rg[q, q] / rho, Rg[q + 1, q] / rho
+                Rg[[q, q + 1], q:] = np.array([[cq, sq], [-sq, cq]]) @ Rg[[q, q + 1], q:]
+            f = cq ** 2 * f
+            theta, vecs = np.linalg.eig(Hm + hlast ** 2 * np.outer(f, em))
+            Pk = _harmonic_select(theta, vecs, kk)
+            Q, R = np.linalg.qr(Hbar[:dim + 1, :dim] @ Pk)
+            Y = [lin(Pk[:, c], V[:dim]) for c in range(kk)]
+            Ri = np.linalg.inv(R)
+            U = [lin(Ri[:, c], Y) for c in range(kk)]
+            C = [lin(Q[:, c], V[:dim + 1]) for c in range(kk)]
+            k = kk
+        elif j > m - k:
+            un = np.array([1.0 / np.sqrt(dot(u, u)) for u in U])
+            Uh = [[un[c] * up for up in U[c]] for c in range(k)]
+            G = np.zeros((dim + 1, dim))
+            G[:k, :k] = np.diag(un)
+            G[:k, k:dim] = Bm[:, k:dim]
+            G[k:dim + 1, k:dim] = Hbar[k:dim + 1, k:dim]
+            W = C + V[k:dim + 1]
+            Vh = Uh + V[k:dim]
+            WV = np.array([[dot(wv, vv) for vv in Vh] for wv in W])
+            WV[:, k:] = 0.0
+            for q in range(dim - k):                              # V_{m-k+1}^H V_{m-k}: identity on top of a zero row; C^H V = 0
+                WV[k + q, k + q] = 1.0
+            theta, vecs = sla.eig(G.T @ G, G.T @ WV)
+            Pk = _harmonic_select(theta, vecs, k)
+            Q, R = np.linalg.qr(G @ Pk)
+            Y = [lin(Pk[:, c], Vh) for c in range(k)]
+            Ri = np.linalg.inv(R)
+            U = [lin(Ri[:, c], Y) for c in range(k)]
+            C = [lin(Q[:, c], W) for c in range(k)]
+        if converged:
+            break
+    return min(j, max_it), x, hist, (U, C)

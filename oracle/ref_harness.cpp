@@ -60,6 +60,7 @@ int main(int argc, char **argv)
              std::forward_as_tuple("complex_shift_re=<0>", "complex builds: a_ii *= 1 + re / 100 + i im / 100 (consistent on the overlap: the diagonal is the same in every copy)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("complex_shift_im=<0>", "see complex_shift_re; the right-hand sides also get a phase exp(i 0.7 (nu + 1)) and a smooth complex modulation", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("deflation_nu=<1>", "number of deflation vectors per subdomain: the constant one, then deterministic smooth ones (dumped as ev)", HPDDM::Option::Arg::integer),
+             std::forward_as_tuple("second_solve=<0>", "solve a second system with the right-hand side f (1 + sin(f) / 2) after the first one (subspace recycling between solves)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("penalize=<0>", "penalised Dirichlet rows: a_ii = HPDDM_PEN, f_i = HPDDM_PEN * f_i on a deterministic subset of the dofs", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
@@ -235,6 +236,17 @@ int main(int argc, char **argv)
   if (rank == 0)
     for (int k = 0; k < mu; ++k) printf(" --- residual = %e / %e (it = %d)\n", storage[1 + 2 * k], storage[2 * k], it);
   delete[] storage;
+  if (opt.app()["second_solve"] > 0) {
+    /* a second right-hand side, consistent on the overlap because it is a pointwise function of the first one */
+    K *f2 = new K[n], *sol2 = new K[n]();
+    for (int i = 0; i < n; ++i) f2[i] = f[i] * (1.0 + 0.5 * std::sin(std::real(f[i])));
+    int it2 = HPDDM::IterativeMethod::solve(A, f2, sol2, mu, A.getCommunicator());
+    dumpi("iterations2", &it2, 1);
+    dumpd("f2", f2, n);
+    dumpd("sol2", sol2, n);
+    delete[] sol2;
+    delete[] f2;
+  }
   fclose(g_out);
   delete[] d;
   delete MatNeumann;

@@ -154,3 +154,43 @@ def test_other_krylov_methods_match_reference(name, method, tol_hist):
     for (j, beta, nrm), row in zip(hist, ref):
         assert abs(beta - row[1]) <= tol_hist * row[1]
     assert np.allclose(orc.compute_residual(sol, f), g["residual_r0"], rtol=1e-3)
+
+
+def _gcrodr_block(orc, f, opt, recycle, state, same_system):
+    """the non-block method one right-hand side at a time (the reference runs them in lock-step: same iterates); history =
+    per iteration, the largest residual among the right-hand sides still iterating (checkConvergence)"""
+    from oracle import ras_oracle as ro
+    mu = 1 if f[0].ndim == 1 else f[0].shape[1]
+    runs = []
+    for nu in range(mu):
+        fn = [v if v.ndim == 1 else v[:, nu] for v in f]
+        runs.append(ro.gcrodr(orc, fn, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], recycle=recycle, variant=opt["variant"],
+                              ortho=opt["ortho"], state=None if state is None else state[nu], same_system=same_system))
+    it = max(r[0] for r in runs)
+    hist = []
+    for j in range(it):   # checkConvergence prints the residual of the first right-hand side unless one still iterating has a larger one
+        beta = runs[0][2][min(j, len(runs[0][2]) - 1)][1]
+        hist.append(max([beta] + [r[2][j][1] for r in runs if len(r[2]) > j + 1]))
+    sol = [np.stack([r[1][s] for r in runs], axis=1) if mu > 1 else runs[0][1][s] for s in range(orc.P)]
+    return it, sol, hist, [r[3] for r in runs]
+
+
+@pytest.mark.parametrize("name,recycle,same", [("p40_gcrodr_two_solves", 4, 0), ("p40_gcrodr_same_system", 4, 1),
+                                               ("p30_6ranks_gcrodr_left_deflated_mu2", 3, 0)])
+def test_gcrodr_matches_reference(name, recycle, same):
+    """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443) on two successive solves: the first builds the recycled subspace from the
+    harmonic Ritz vectors of its first cycle and updates it at every restart, the second starts from it (19 then 15
+    iterations instead of GMRES(10)'s 24).  With -hpddm_recycle_same_system the reference increments the option after the
+    first solve, which freezes the subspace during the second one."""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    orc, opt = _setup(g, subs)
+    f, f2 = gu.vecs(g, "f"), gu.vecs(g, "f2")
+    it, sol, hist, state = _gcrodr_block(orc, f, opt, recycle, None, same)
+    it2, sol2, hist2, _ = _gcrodr_block(orc, f2, opt, recycle, state, 2 * same)
+    assert it == int(g["iterations_r0"][0]) and it2 == int(g["iterations2_r0"][0])
+    ref = g["history"][:, 1]
+    assert len(ref) == it + it2
+    assert np.allclose(hist, ref[:it], rtol=1e-5) and np.allclose(hist2, ref[it:], rtol=1e-5)
+    _close(sol, gu.vecs(g, "sol"), 1e-9, "solution")
+    _close(sol2, gu.vecs(g, "sol2"), 1e-9, "second solution")
