@@ -48,6 +48,7 @@ def _declare(lib):
         "HpddmHipSchwarzSetSubdomainZ": (I, [P, I, I, P, P, P, I, ctypes.c_char, I, P, P, P]),
         "HpddmHipSchwarzSetVectorsZ": (I, [P, I, I, P]),
         "HpddmHipSchwarzIsComplex": (I, [P]),
+        "HpddmHipDenseEig": (I, [I, P, P, P, P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),

@@ -2,6 +2,7 @@
 #include "../../include/hpddm_hip.h"
 #include "capi_common.hpp"
 #include "schwarz.hpp"
+#include "dense_eig.hpp"
 #include <cstring>
 #include <sstream>
 
@@ -114,6 +115,17 @@ int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d)
     std::vector<double> w(2 * (size_t)n);
     for (int i = 0; i < n; ++i) w[2 * i] = w[2 * i + 1] = d[i];
     A->op.initialize(s, w.data());
+    return 0;)
+}
+int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V)
+{
+  HH_TRY(
+    HH_CHECK(n >= 0 && (n == 0 || (A && wr && wi && V)), "null argument");
+    std::vector<double> a(A, A + (size_t)n * n), r, i, v;
+    HH_CHECK(dense_eig(n, a, r, i, v), "dense_eig: the QR iteration did not converge");
+    std::copy(r.begin(), r.end(), wr);
+    std::copy(i.begin(), i.end(), wi);
+    std::copy(v.begin(), v.end(), V);
     return 0;)
 }
 int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z)

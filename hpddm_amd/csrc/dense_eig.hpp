@@ -1,0 +1,9 @@
+// Small dense real eigenproblems on the host (dense_eig.cpp)
+#pragma once
+#include <vector>
+
+namespace hpddm_hip {
+// A: n x n row-major (destroyed).  wr/wi: eigenvalues.  V: n x n row-major; for a complex pair (wi[j] > 0 > wi[j+1]) columns j and
+// j+1 hold the real and imaginary parts of the eigenvector.  false if the QR iteration fails to converge.
+bool dense_eig(int n, std::vector<double> &A, std::vector<double> &wr, std::vector<double> &wi, std::vector<double> &V);
+} // namespace hpddm_hip

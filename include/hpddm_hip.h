@@ -99,6 +99,11 @@ int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z
 int HpddmHipSchwarzSetSubdomainZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity);
 int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z);
 int HpddmHipSchwarzIsComplex(const HpddmHipSchwarz *A);
+/* Utility, exported for the tests: eigenvalues (wr + i wi) and eigenvectors of the n x n real general matrix A (row-major) by
+ * Householder-Hessenberg + shifted QR on the host; V is n x n row-major, a complex pair (wi[j] > 0 > wi[j+1]) has the real and
+ * imaginary parts of its vector in columns j and j+1.  This is what GCRO-DR's harmonic Ritz problems go through
+ * (the reference calls LAPACK's hseqr/hsein and ggev, include/HPDDM_GCRODR.hpp:262-303, 384-392). */
+int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V);
 /* HpddmSchwarzSolveGEVP (HPDDM.h:107, Schwarz::solveGEVP include/HPDDM_schwarz.hpp:665-715): GenEO coarse space of local
  * subdomain s from its Neumann matrix (same CSR conventions as SetSubdomain): the -hpddm_geneo_nu (default 20) lowest
  * eigenvectors of A_N x = lambda B x, B = scaleIntoOverlap(A_N), kept below -hpddm_geneo_threshold if it is set.
