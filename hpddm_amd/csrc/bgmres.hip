@@ -916,8 +916,9 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
   if (method == 2) return cg(b, x, mu, history, history_cap);
   if (method == 3) return bcg(b, x, mu, history, history_cap);
+  if (method == 4) return gcrodr(b, x, mu, history, history_cap);
   if (method == 6) return bfbcg(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg and bfbcg are built");
+  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg, gcrodr and bfbcg are built");
   return gmres(b, x, mu, history, history_cap);
 }
 

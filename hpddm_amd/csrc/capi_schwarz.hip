@@ -117,6 +117,15 @@ int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d)
     A->op.initialize(s, w.data());
     return 0;)
 }
+int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A)
+{
+  // OptionsPrefix::destroy (include/HPDDM_option.hpp:431-443): free the recycled subspace, recycle_same_system back to 1 if it had grown
+  HH_TRY(
+    HH_CHECK(A, "null argument");
+    A->op.recycled.clear();
+    if (A->op.getopt("recycle_same_system", 0) > 1) A->op.opt["recycle_same_system"] = 1;
+    return 0;)
+}
 int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V)
 {
   HH_TRY(

@@ -159,6 +159,14 @@ struct Schwarz {
   const double  *norm_rhs(const double *b, double *scratch, int mu);        // initializeNorm: penalised entries of b divided by HPDDM_PEN
   int  gmres(const double *b, double *x, int mu, double *history, int history_cap);
   int  cg(const double *b, double *x, int mu, double *history, int history_cap);           // gmres.hip
+  // GCRO-DR: the subspace recycled between the cycles and between successive solves, per right-hand-side index
+  // (OptionsPrefix::storage_ of the reference, include/HPDDM_option.hpp:445-455; destroyRecycling frees it)
+  struct Recycled {
+    DevBuf<double> U, C; // k vectors each, single right-hand-side layout (ntot doubles per vector)
+    int            k = 0;
+  };
+  std::vector<std::unique_ptr<Recycled>> recycled;
+  int  gcrodr(const double *b, double *x, int mu, double *history, int history_cap);       // gmres.hip
   int  bgmres(const double *b, double *x, int mu, double *history, int history_cap);       // bgmres.hip
   int  bcg(const double *b, double *x, int mu, double *history, int history_cap);          // bgmres.hip
   int  bfbcg(const double *b, double *x, int mu, double *history, int history_cap);        // bgmres.hip

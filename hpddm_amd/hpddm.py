@@ -206,6 +206,10 @@ class Schwarz:
         a = np.ascontiguousarray(a, dtype=np.float64)
         check(self._lib.HpddmHipSchwarzSetOptimizedMatrix(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
 
+    def destroy_recycling(self):
+        """OptionsPrefix::destroy: drop the subspace GCRO-DR recycles between successive solves"""
+        check(self._lib.HpddmHipSchwarzDestroyRecycling(self._h))
+
     def build_coarse_operator(self):
         check(self._lib.HpddmHipSchwarzBuildCoarseOperator(self._h))
 

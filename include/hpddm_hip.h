@@ -99,6 +99,9 @@ int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z
 int HpddmHipSchwarzSetSubdomainZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity);
 int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z);
 int HpddmHipSchwarzIsComplex(const HpddmHipSchwarz *A);
+/* OptionsPrefix::destroy (include/HPDDM_option.hpp:431-443): frees the subspace GCRO-DR recycles between successive solves
+ * (-hpddm_krylov_method gcrodr -hpddm_recycle k [-hpddm_recycle_same_system]); the next solve starts a new one */
+int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A);
 /* Utility, exported for the tests: eigenvalues (wr + i wi) and eigenvectors of the n x n real general matrix A (row-major) by
  * Householder-Hessenberg + shifted QR on the host; V is n x n row-major, a complex pair (wi[j] > 0 > wi[j+1]) has the real and
  * imaginary parts of its vector in columns j and j+1.  This is what GCRO-DR's harmonic Ritz problems go through

@@ -308,6 +308,27 @@ def test_cg_matches_reference():
     A.destroy()
 
 
+@pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2"])
+def test_gcrodr_matches_reference(name):
+    """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443), two successive solves on one operator: the first one builds the recycled
+    subspace (harmonic Ritz vectors after its first cycle, generalised eigenproblem at every later restart), the second one
+    starts from it -- the reference's 19 then 15 iterations where GMRES(10) needs 24, and its residual histories.  With
+    -hpddm_recycle_same_system the subspace is frozen during the second solve, like in the reference."""
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f, f2 = gu.vecs(g, "f"), gu.vecs(g, "f2")
+    it, sol, hist = A.solve(f, history=True)
+    it2, sol2, hist2 = A.solve(f2, history=True)
+    assert it == int(g["iterations_r0"][0]) and it2 == int(g["iterations2_r0"][0])
+    ref = g["history"][:, 1]
+    assert len(ref) == it + it2
+    assert np.allclose(hist, ref[:it], rtol=1e-4) and np.allclose(hist2, ref[it:], rtol=1e-4)
+    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
+    _close(sol2, gu.vecs(g, "sol2"), 1e-8, "second solution")
+    A.destroy()
+
+
 @pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4"])
 def test_bfbcg_matches_reference(name):
     """Breakdown-free block CG (include/HPDDM_CG.hpp:342-482), plain and with -hpddm_deflation_tol on a block whose last
