@@ -356,8 +356,30 @@ __global__ void k_column(const long long *__restrict__ voff, const int *__restri
 namespace {
 struct GcroOptions {
   double tol;
-  int    max_it, m, k, variant, ortho, verbosity, same_system;
+  int    max_it, m, k, variant, ortho, verbosity, same_system, target;
 };
+// order of the eigenvalues theta = (tr, ti) for -hpddm_recycle_target (selectNu, include/HPDDM_specifications.hpp:90-126):
+// SM 0, LM 1, SR 2, LR 3, SI 4, LI 5; ties keep the index order
+std::vector<int> target_order(int target, const std::vector<double> &tr, const std::vector<double> &ti)
+{
+  const int           n = (int)tr.size();
+  std::vector<double> key(n);
+  for (int a = 0; a < n; ++a) {
+    const double mod = std::hypot(tr[a], ti[a]);
+    switch (target) {
+    case 1: key[a] = -mod; break;
+    case 2: key[a] = tr[a]; break;
+    case 3: key[a] = -tr[a]; break;
+    case 4: key[a] = ti[a]; break;
+    case 5: key[a] = -ti[a]; break;
+    default: key[a] = mod;
+    }
+  }
+  std::vector<int> order(n);
+  for (int a = 0; a < n; ++a) order[a] = a;
+  std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return key[l] < key[r]; });
+  return order;
+}
 // Householder QR of the rows x cols matrix M (row-major, rows >= cols): Q rows x cols with orthonormal columns, R cols x cols upper
 void small_qr(int rows, int cols, std::vector<double> M, std::vector<double> &Q, std::vector<double> &R)
 {
@@ -682,10 +704,7 @@ static int gcrodr_one(Schwarz &A, const GcroOptions &o, const double *b, double 
         const double clast = cs[dim - 1], hl = Hb(dim, dim - 1);
         for (int a = 0; a < dim; ++a) Hm[(size_t)a * dim + dim - 1] += hl * hl * clast * clast * f[a];
         HH_CHECK(dense_eig(dim, Hm, wr, wi, EV), "GCRODR: the eigen-solver did not converge");
-        std::vector<int> order(dim);
-        for (int a = 0; a < dim; ++a) order[a] = a;
-        std::stable_sort(order.begin(), order.end(), [&](int l, int rgt) { return std::hypot(wr[l], wi[l]) < std::hypot(wr[rgt], wi[rgt]); });
-        Pk = select_vectors(dim, wi, EV, order, kk);
+        Pk = select_vectors(dim, wi, EV, target_order(o.target, wr, wi), kk);
         Gm.assign((size_t)(dim + 1) * dim, 0.0);
         for (int a = 0; a <= dim; ++a)
           for (int c = 0; c < dim; ++c) Gm[(size_t)a * dim + c] = Hb(a, c);
@@ -745,10 +764,13 @@ static int gcrodr_one(Schwarz &A, const GcroOptions &o, const double *b, double 
           }
         }
         HH_CHECK(dense_eig(dim, Mm, wr, wi, EV), "GCRODR: the eigen-solver did not converge");
-        std::vector<int> order(dim);
-        for (int a = 0; a < dim; ++a) order[a] = a;
-        std::stable_sort(order.begin(), order.end(), [&](int l, int rgt) { return std::hypot(wr[l], wi[l]) > std::hypot(wr[rgt], wi[rgt]); });
-        Pk = select_vectors(dim, wi, EV, order, kk);
+        std::vector<double> tr(dim), ti(dim); // theta = 1 / mu (mu = 0: theta = infinity)
+        for (int a = 0; a < dim; ++a) {
+          const double m2 = wr[a] * wr[a] + wi[a] * wi[a];
+          tr[a] = m2 > 0.0 ? wr[a] / m2 : std::numeric_limits<double>::infinity();
+          ti[a] = m2 > 0.0 ? -wi[a] / m2 : 0.0;
+        }
+        Pk = select_vectors(dim, wi, EV, target_order(o.target, tr, ti), kk);
       }
       // [Q, R] = qr(G P); C = W Q; U = Vh P R^{-1}
       std::vector<double> GP((size_t)rowsG * kk, 0.0);
@@ -813,7 +835,11 @@ int Schwarz::gcrodr(const double *b, double *x, int mu, double *history, int his
   o.same_system = std::min((int)getopt("recycle_same_system", 0), 2);
   if (o.k <= 0) return gmres(b, x, mu, history, history_cap); // "please choose a positive number of Ritz vectors" (:52-55)
   HH_CHECK(o.variant == VARIANT_RIGHT || o.variant == VARIANT_LEFT, "GCRODR: left and right preconditioning are built");
-  HH_CHECK(getopt("recycle_strategy", 0) == 0 && getopt("recycle_target", 0) == 0, "GCRODR: recycle_strategy A and recycle_target SM are built");
+  o.target      = (int)getopt("recycle_target", 0);
+  // strategy B is left out on purpose: its pencil has the eigenvalue 1 with multiplicity k, so the vectors the selection returns
+  // depend on the internals of LAPACK's ggev (the reference's own runs of it cannot be reproduced by another eigen-solver)
+  HH_CHECK(getopt("recycle_strategy", 0) == 0, "GCRODR: recycle_strategy A is built");
+  HH_CHECK(o.target >= 0 && o.target <= 5, "GCRODR: unknown recycle_target");
   reserve(mu);
   hipStream_t    st = library_stream();
   const dim3     g2((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub);

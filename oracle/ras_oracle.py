@@ -757,11 +757,17 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
 # Restated for one right-hand side at a time -- the reference runs several in lock-step, which changes nothing to the
 # iterates of each (the recurrences of the non-block method are independent per right-hand side).
 # ======================================================================================================================
-def _harmonic_select(theta, vecs, k):
-    """k columns spanning the eigenvectors of the k eigenvalues of smallest modulus (recycle_target SM, selectNu,
-    include/HPDDM_specifications.hpp:90-126), real arithmetic: a complex pair gives (Re v, Im v); a pair cut by the limit k
+_TARGET_KEYS = {   # selectNu (include/HPDDM_specifications.hpp:90-126)
+    "SM": lambda z: abs(z), "LM": lambda z: -abs(z), "SR": lambda z: np.real(z), "LR": lambda z: -np.real(z),
+    "SI": lambda z: np.imag(z), "LI": lambda z: -np.imag(z)}
+
+
+def _harmonic_select(theta, vecs, k, target="SM"):
+    """k columns spanning the eigenvectors of the k eigenvalues that come first for -hpddm_recycle_target (default SM: smallest
+    modulus; selectNu, include/HPDDM_specifications.hpp:90-126), real arithmetic: a complex pair gives (Re v, Im v); a pair cut by the limit k
     gives its real part only, like the first k columns of the reference's eigenvector array"""
-    order = sorted(range(len(theta)), key=lambda t: (abs(theta[t]), -np.imag(theta[t])))
+    key = _TARGET_KEYS[target]
+    order = sorted(range(len(theta)), key=lambda t: (key(theta[t]), -np.imag(theta[t])))
     cols = []
     used = set()
     for t in order:
@@ -784,7 +790,7 @@ def _harmonic_select(theta, vecs, k):
     return np.stack(cols[:k], axis=1)
 
 
-def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right", ortho="cgs", state=None, same_system=0):
+def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right", ortho="cgs", state=None, same_system=0, target="SM"):
     """returns (iterations, solution, history, state); `state` = (U, C) to hand to the next solve (OptionsPrefix::storage_).
     same_system = value of -hpddm_recycle_same_system when the solve starts: non-zero skips the re-orthonormalisation of C
     against the (unchanged) operator, and from 2 on -- the reference increments the option after every converged solve,
@@ -911,7 +917,7 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
                 Rg[[q, q + 1], q:] = np.array([[cq, sq], [-sq, cq]]) @ Rg[[q, q + 1], q:]
             f = cq ** 2 * f
             theta, vecs = np.linalg.eig(Hm + hlast ** 2 * np.outer(f, em))
-            Pk = _harmonic_select(theta, vecs, kk)
+            Pk = _harmonic_select(theta, vecs, kk, target)
             Q, R = np.linalg.qr(Hbar[:dim + 1, :dim] @ Pk)
             Y = [lin(Pk[:, c], V[:dim]) for c in range(kk)]
             Ri = np.linalg.inv(R)
@@ -919,6 +925,9 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             C = [lin(Q[:, c], V[:dim + 1]) for c in range(kk)]
             k = kk
         elif j > m - k:
+            # recycle strategy A (the default).  Strategy B (:376-382: B = [[I, 0], [B_m^T, H^T]], U not scaled) is left out on
+            # purpose: its pencil has the eigenvalue 1 with multiplicity k, so which vectors come out of the selection depends
+            # on the internals of LAPACK's ggev -- the reference's own runs cannot be pinned.
             un = np.array([1.0 / np.sqrt(dot(u, u)) for u in U])
             Uh = [[un[c] * up for up in U[c]] for c in range(k)]
             G = np.zeros((dim + 1, dim))
@@ -932,7 +941,7 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             for q in range(dim - k):                              # V_{m-k+1}^H V_{m-k}: identity on top of a zero row; C^H V = 0
                 WV[k + q, k + q] = 1.0
             theta, vecs = sla.eig(G.T @ G, G.T @ WV)
-            Pk = _harmonic_select(theta, vecs, k)
+            Pk = _harmonic_select(theta, vecs, k, target)
             Q, R = np.linalg.qr(G @ Pk)
             Y = [lin(Pk[:, c], Vh) for c in range(k)]
             Ri = np.linalg.inv(R)

@@ -308,7 +308,7 @@ def test_cg_matches_reference():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2"])
+@pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2", "p40_gcrodr_target_lm"])
 def test_gcrodr_matches_reference(name):
     """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443), two successive solves on one operator: the first one builds the recycled
     subspace (harmonic Ritz vectors after its first cycle, generalised eigenproblem at every later restart), the second one
