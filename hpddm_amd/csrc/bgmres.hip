@@ -909,8 +909,10 @@ int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int his
 int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, int history_cap)
 {
   const int method = (int)getopt("krylov_method", 0);
+  if (method == 7) return richardson(b, x, mu);
+  if (method == 8) return no_krylov(b, x, mu);
   if (is_complex) { // K = std::complex<double>: krylov_complex.hip
-    HH_CHECK(method == 0 || method == 1, "krylov_method: gmres and bgmres are built for complex scalars");
+    HH_CHECK(method == 0 || method == 1, "krylov_method: gmres, bgmres, richardson and none are built for complex scalars");
     return method == 1 ? bgmres_z(b, x, mu, history, history_cap) : gmres_z(b, x, mu, history, history_cap);
   }
   if (method == 1) return bgmres(b, x, mu, history, history_cap);
@@ -918,7 +920,7 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   if (method == 3) return bcg(b, x, mu, history, history_cap);
   if (method == 4) return gcrodr(b, x, mu, history, history_cap);
   if (method == 6) return bfbcg(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg, gcrodr and bfbcg are built");
+  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg, gcrodr, bfbcg, richardson and none are built (not bgcrodr)");
   return gmres(b, x, mu, history, history_cap);
 }
 

@@ -872,4 +872,37 @@ int Schwarz::gcrodr(const double *b, double *x, int mu, double *history, int his
   return it;
 }
 
+// IterativeMethod::Richardson (include/HPDDM_iterative.hpp:971-993): x += omega M^{-1} (b - A x), max_it times, no convergence
+// test; and -hpddm_krylov_method none (:1056-1066): x = M^{-1} b.  Linear in the vectors: complex operators go through unchanged.
+int Schwarz::richardson(const double *b, double *x, int mu)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  reserve(mu);
+  hipStream_t     st     = library_stream();
+  const int       max_it = std::min<int>((int)getopt("max_it", 100), std::numeric_limits<short>::max());
+  const double    omega  = getopt("richardson_damping_factor", 1.0);
+  const long long cnt    = ntot * mu;
+  const dim3      gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  DevBuf<double>  r, z;
+  r.alloc((size_t)cnt), z.alloc((size_t)cnt);
+  start(b, x, mu);
+  for (int j = 0; j < max_it; ++j) {
+    gmv(x, r.p, mu);
+    hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, r.p, r.p);
+    apply(r.p, z.p, mu);
+    hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, cnt, 1.0, x, omega, z.p, x);
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return max_it;
+}
+int Schwarz::no_krylov(const double *b, double *x, int mu)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  reserve(mu);
+  start(b, x, mu);
+  apply(b, x, mu);
+  HIP_OK(hipStreamSynchronize(library_stream()));
+  return 1;
+}
+
 } // namespace hpddm_hip

@@ -170,6 +170,8 @@ struct Schwarz {
   int  bgmres(const double *b, double *x, int mu, double *history, int history_cap);       // bgmres.hip
   int  bcg(const double *b, double *x, int mu, double *history, int history_cap);          // bgmres.hip
   int  bfbcg(const double *b, double *x, int mu, double *history, int history_cap);        // bgmres.hip
+  int  richardson(const double *b, double *x, int mu);                                      // gmres.hip
+  int  no_krylov(const double *b, double *x, int mu);                                       // gmres.hip (-hpddm_krylov_method none)
   int  krylov_solve(const double *b, double *x, int mu, double *history, int history_cap); // -hpddm_krylov_method dispatch
   // D-weighted reductions used by GMRES and computeResidual: out[k*mu+nu] = sum_s sum_i d_s[i] V_k[s][nu][i] w[s][nu][i]
   void wdots(const double *V, long long ldv, int k, const double *w, int mu, double *out_host);

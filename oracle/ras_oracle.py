@@ -587,6 +587,24 @@ def bfbcg(orc, b, tol=1e-6, max_it=100, deflation_tol=-1.0):
     return min(i, max_it), [v if mu > 1 else v[:, 0] for v in x], hist
 
 
+def richardson(orc, b, max_it=100, damping=1.0):
+    """IterativeMethod::Richardson (include/HPDDM_iterative.hpp:971-993): x += omega M^{-1} (b - A x), max_it times, no test"""
+    b = [_arr(v).reshape(np.shape(v)[0], -1) for v in b]
+    x = orc.start(b, [np.zeros_like(v) for v in b])
+    for _ in range(max_it):
+        r = [bb - g for bb, g in zip(b, orc.gmv(x))]
+        x = [xx + damping * z for xx, z in zip(x, orc.apply(r))]
+    return max_it, [v if v.shape[1] > 1 else v[:, 0] for v in x]
+
+
+def no_krylov(orc, b):
+    """-hpddm_krylov_method none (include/HPDDM_iterative.hpp:1056-1066): x = M^{-1} b, counted as one iteration"""
+    b = [_arr(v).reshape(np.shape(v)[0], -1) for v in b]
+    orc.start(b, [np.zeros_like(v) for v in b])
+    x = orc.apply(b)
+    return 1, [v if v.shape[1] > 1 else v[:, 0] for v in x]
+
+
 def _cg_from(orc, b, x0, tol, max_it):
     """CG restarted from an iterate (the hand-over of BCG): Schwarz::start is applied to x0 again, like the reference does"""
     saved = orc.start

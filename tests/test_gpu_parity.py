@@ -329,6 +329,26 @@ def test_gcrodr_matches_reference(name):
     A.destroy()
 
 
+def test_richardson_and_no_krylov_match_reference():
+    """-hpddm_krylov_method richardson (include/HPDDM_iterative.hpp:971-993) and none (:1056-1066): the reference's solutions"""
+    g = gu.load("p40_richardson_mu2")
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol = A.solve(f)
+    assert it == int(g["iterations_r0"][0]) == 15
+    _close(sol, gu.vecs(g, "sol"), 1e-11, "Richardson")
+    assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-9)
+    A.destroy()
+    g = gu.load("p40_none_deflated_mu2")
+    subs = gu.subdomains(g)
+    A, d, opt = _build(g, subs)
+    it, sol = A.solve(gu.vecs(g, "f"))
+    assert it == int(g["iterations_r0"][0]) == 1
+    _close(sol, gu.vecs(g, "sol"), 1e-11, "one apply")
+    A.destroy()
+
+
 @pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4"])
 def test_bfbcg_matches_reference(name):
     """Breakdown-free block CG (include/HPDDM_CG.hpp:342-482), plain and with -hpddm_deflation_tol on a block whose last
