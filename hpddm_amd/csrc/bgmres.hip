@@ -2,7 +2,8 @@
 // (include/HPDDM_iterative.hpp:713-734), blockOrthogonalization (:523-556, classical block Gram-Schmidt), CholQR (:622-640,
 // VR :559-582), checkBlockConvergence (:128-182), updateSol/computeMin/addSol (:272-336), same conventions as the
 // reference: D-weighted block inner products, Householder QR of the (2 mu x mu) blocks of the block Hessenberg matrix,
-// right preconditioning by default, the CholQR factorisation (the reference's default -hpddm_qr).
+// right preconditioning by default; -hpddm_orthogonalization cgs | mgs for the block Gram-Schmidt, -hpddm_qr cholqr | cgs | mgs for
+// the factorisation of every new block (CholQR by default, like the reference).
 // Right-hand-side deflation (-hpddm_deflation_tol > -0.9, include/HPDDM_GMRES.hpp:201-205,278-296; RRQR
 // include/HPDDM_iterative.hpp:583-595): at every restart the residual block goes through a pivoted Cholesky of its Gram
 // matrix, the iteration runs on the d leading columns of the permuted block and the other right-hand sides get the correction
@@ -156,6 +157,8 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   const bool flexible = variant == VARIANT_FLEXIBLE; // Z_i = M^{-1} V_i kept at v[i + m + 1] (include/HPDDM_GMRES.hpp:254-255)
   const double defl_tol  = A.getopt("deflation_tol", -1.0);
   const bool   deflation = defl_tol > -0.9;
+  const int    ortho     = (int)A.getopt("orthogonalization", ORTHO_CGS); // block Gram-Schmidt against the previous blocks: classical or modified
+  const int    qr_kind   = (int)A.getopt("qr", 0);                        // 0 CholQR, 1 classical, 2 modified Gram-Schmidt, column by column
   const long long cnt = A.ntot * mu;
   const int       ldh = mu * (m + 1);
   const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
@@ -189,6 +192,39 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
   // (only the d leading columns of W are active, the others are zero columns and stay so)
   auto cholqr = [&](double *W, std::vector<double> &R, bool update, int d) {
     std::vector<double> G;
+    if (qr_kind != 0) {
+      // -hpddm_qr cgs | mgs (QR<excluded>, include/HPDDM_iterative.hpp:641-664): W is orthonormalised in place column by column
+      R.assign((size_t)mu * mu, 0.0);
+      std::vector<double> C((size_t)mu * mu);
+      auto update_col = [&](int xi, int a0, int a1) { // W[:, xi] -= sum_{a0 <= a < a1} R[a][xi] W[:, a]
+        std::fill(C.begin(), C.end(), 0.0);
+        for (int a = a0; a < a1; ++a) C[(size_t)a * mu + xi] = R[(size_t)a * mu + xi];
+        HIP_OK(hipMemcpyAsync(Ax.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+        axpy_blocks(Ax.p, 1, C, -1.0, 1.0, W);
+      };
+      for (int xi = 0; xi < d; ++xi) {
+        if (qr_kind == 2) {
+          for (int a = 0; a < xi; ++a) {
+            gram(W, 1, W, G);
+            R[(size_t)a * mu + xi] = G[(size_t)a * mu + xi];
+            update_col(xi, a, a + 1);
+          }
+        } else if (xi > 0) {
+          gram(W, 1, W, G);
+          for (int a = 0; a < xi; ++a) R[(size_t)a * mu + xi] = G[(size_t)a * mu + xi];
+          update_col(xi, 0, xi);
+        }
+        gram(W, 1, W, G);
+        const double nrm = std::sqrt(G[(size_t)xi * mu + xi]);
+        if (nrm < HPDDM_EPS) return xi;
+        R[(size_t)xi * mu + xi] = nrm;
+        std::fill(C.begin(), C.end(), 0.0);
+        C[(size_t)xi * mu + xi] = 1.0 / nrm - 1.0; // W[:, xi] /= nrm
+        HIP_OK(hipMemcpyAsync(Ax.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+        axpy_blocks(Ax.p, 1, C, 1.0, 1.0, W);
+      }
+      return d;
+    }
     gram(W, 1, W, G);
     R.assign((size_t)mu * mu, 0.0);
     int rank = d;
@@ -384,8 +420,18 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
         A.gmv(zi, vk(i + 1), mu);
       }
       // ---- BlockArnoldi ----
-      gram(vk(0), i + 1, vk(i + 1), G);                   // classical block Gram-Schmidt
-      axpy_blocks(vk(0), i + 1, G, -1.0, 1.0, vk(i + 1));
+      if (ortho == ORTHO_MGS) { // blockOrthogonalization id == 1 (include/HPDDM_iterative.hpp:540-546): one previous block at a time
+        std::vector<double> Gk;
+        G.assign((size_t)(i + 1) * mu * mu, 0.0);
+        for (int kk = 0; kk <= i; ++kk) {
+          gram(vk(kk), 1, vk(i + 1), Gk);
+          axpy_blocks(vk(kk), 1, Gk, -1.0, 1.0, vk(i + 1));
+          std::copy(Gk.begin(), Gk.end(), G.begin() + (size_t)kk * mu * mu);
+        }
+      } else {
+        gram(vk(0), i + 1, vk(i + 1), G); // classical block Gram-Schmidt
+        axpy_blocks(vk(0), i + 1, G, -1.0, 1.0, vk(i + 1));
+      }
       double *Hi = Hc(i);
       for (int kk = 0; kk <= i; ++kk)
         for (int a = 0; a < d; ++a)

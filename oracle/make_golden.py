@@ -67,6 +67,8 @@ CASES = [
     ("p30_6ranks_gcrodr_left_deflated_mu2", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_richardson_mu2", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method richardson -hpddm_max_it 15 -hpddm_richardson_damping_factor 0.7"),
     ("p40_none_deflated_mu2", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method none -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    ("p40_bgmres_mgs_qrmgs_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bgmres -hpddm_orthogonalization mgs -hpddm_qr mgs -hpddm_gmres_restart=8"),
+    ("p40_bgmres_qrcgs_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bgmres -hpddm_qr cgs -hpddm_gmres_restart=8"),
     ("p40_cg_asm", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method cg -hpddm_schwarz_method asm"),
     # config 1 of BASELINE.json (45 iterations)
     ("c1_p200_onelevel", 4, 1, "-Nx 200 -Ny 200"),

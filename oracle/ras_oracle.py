@@ -640,7 +640,7 @@ def _pstrf_upper(G):
     return U, piv, rank
 
 
-def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_tol=-1.0):
+def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_tol=-1.0, ortho="cgs", qr="cholqr"):
     """IterativeMethod::BGMRES (include/HPDDM_GMRES.hpp:159-313): BlockArnoldi with classical block Gram-Schmidt
     (include/HPDDM_iterative.hpp:523-556, 713-734), CholQR of every new block (:622-640), Householder QR of the block Hessenberg
     matrix, checkBlockConvergence<1> (:128-182), updateSol (:272-336).  variant: right | left | flexible.
@@ -655,6 +655,28 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
     m = max(1, min(restart, max_it))
 
     def cholqr(W):
+        if qr != "cholqr":   # -hpddm_qr cgs | mgs: column by column (QR<excluded>, include/HPDDM_iterative.hpp:641-664)
+            k = W[0].shape[1]
+            W = [w.copy() for w in W]
+            R = np.zeros((k, k), dtype=W[0].dtype)
+            for xi in range(k):
+                col = lambda V, a: [v[:, a:a + 1] for v in V]
+                if qr == "mgs":
+                    for a in range(xi):
+                        R[a, xi] = _gram(orc, col(W, a), col(W, xi))[0, 0]
+                        for w in W:
+                            w[:, xi] -= R[a, xi] * w[:, a]
+                elif xi > 0:
+                    R[:xi, xi] = _gram(orc, [w[:, :xi] for w in W], col(W, xi))[:, 0]
+                    for w in W:
+                        w[:, xi] -= w[:, :xi] @ R[:xi, xi]
+                nrm = np.sqrt(_gram(orc, col(W, xi), col(W, xi))[0, 0].real)
+                if nrm < HPDDM_EPS:
+                    return None, W
+                R[xi, xi] = nrm
+                for w in W:
+                    w[:, xi] /= nrm
+            return R, W
         G = _gram(orc, W, W)
         try:
             R = np.linalg.cholesky(G).conj().T         # G = R^H R, R upper
@@ -712,8 +734,14 @@ def bgmres(orc, b, tol=1e-6, max_it=100, restart=40, variant="right", deflation_
                 if variant == "flexible":
                     Zb.append(zi)
                 w = orc.gmv(zi)
-            Gs = [_gram(orc, V[k], w) for k in range(i + 1)]           # classical block Gram-Schmidt
-            w = [ww - sum(V[k][p] @ Gs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
+            if ortho == "mgs":                                          # blockOrthogonalization id == 1 (:540-546)
+                Gs = []
+                for k in range(i + 1):
+                    Gs.append(_gram(orc, V[k], w))
+                    w = [ww - V[k][p] @ Gs[k] for p, ww in enumerate(w)]
+            else:                                                       # classical block Gram-Schmidt
+                Gs = [_gram(orc, V[k], w) for k in range(i + 1)]
+                w = [ww - sum(V[k][p] @ Gs[k] for k in range(i + 1)) for p, ww in enumerate(w)]
             col = slice(d * i, d * (i + 1))
             for k in range(i + 1):
                 H[d * k:d * (k + 1), col] = Gs[k]

@@ -18,7 +18,7 @@ def options(g):
     """reference command line of the case -> dict of the options the path reads"""
     toks = str(g["options"]).split()
     out = {"tol": 1e-6, "max_it": 100, "restart": 40, "variant": "right", "ortho": "cgs", "correction": None, "spd": False, "method": "ras",
-           "deflation_tol": -1.0, "recycle_target": "SM"}
+           "deflation_tol": -1.0, "recycle_target": "SM", "qr": "cholqr"}
     i = 0
     while i < len(toks):
         t = toks[i]
@@ -46,6 +46,8 @@ def options(g):
                 out["spd"] = True
             elif key == "schwarz_method":
                 out["method"] = val
+            elif key == "qr":
+                out["qr"] = val
             elif key == "recycle_target":
                 out["recycle_target"] = val
             elif key == "deflation_tol":

@@ -274,7 +274,8 @@ def test_geneo_coarse_space_against_arpack():
 
 
 @pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3",
-                                  "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4"] + gu.COMPLEX_BGMRES_CASES)
+                                  "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4", "p40_bgmres_mgs_qrmgs_mu3",
+                                  "p40_bgmres_qrcgs_mu3"] + gu.COMPLEX_BGMRES_CASES)
 def test_bgmres_matches_reference(name):
     """Block GMRES: iteration count, residual history and solution of the compiled reference.  The two
     rhs_deflation fixtures run with -hpddm_deflation_tol and a last right-hand side f_0 + 2 f_1: one column is deflated at

@@ -123,6 +123,7 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("p30_6ranks_bgmres_left_mu3", "bgmres", 2e-6), ("p40_fbgmres_mu3", "bgmres", 2e-4),
     ("p40_bgmres_rhs_deflation_mu4", "bgmres", 2e-6), ("p40_bgmres_rhs_deflation_restart_mu4", "bgmres", 5e-5),
     ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6),
+    ("p40_bgmres_mgs_qrmgs_mu3", "bgmres", 1e-5), ("p40_bgmres_qrcgs_mu3", "bgmres", 1e-5),
     ("p40_bfbcg_asm_mu3", "bfbcg", 1e-5), ("p40_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-5),
     ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-2), ("p40_bcg_asm_mu3", "bcg", 2e-6)])
 def test_other_krylov_methods_match_reference(name, method, tol_hist):
@@ -143,7 +144,7 @@ def test_other_krylov_methods_match_reference(name, method, tol_hist):
         it, sol, hist = ro.cg(orc, f, tol=opt["tol"], max_it=opt["max_it"])
     elif method == "bgmres":
         it, sol, hist = ro.bgmres(orc, f, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], variant=opt["variant"],
-                                  deflation_tol=opt["deflation_tol"])
+                                  deflation_tol=opt["deflation_tol"], ortho=opt["ortho"], qr=opt["qr"])
     elif method == "bfbcg":
         it, sol, hist = ro.bfbcg(orc, f, tol=opt["tol"], max_it=opt["max_it"], deflation_tol=opt["deflation_tol"])
     else:
