@@ -65,6 +65,7 @@ def _declare(lib):
         "HpddmHipSchwarzDeflation": (I, [P, P, P, US]),
         "HpddmHipSchwarzLocalSolve": (I, [P, P, P, US]),
         "HpddmHipSchwarzComputeResidual": (I, [P, P, P, P, US]),
+        "HpddmHipSchwarzComputeResidualNorm": (I, [P, P, P, P, US, I]),
         "HpddmHipSolve": (I, [P, P, P, I, P, I]),
         "HpddmHipSchwarzSetPartition": (I, [P, I, I, P]),
         "HpddmHipSchwarzHaloPeers": (I, [P, I, P, P, P]),

@@ -286,6 +286,10 @@ int HpddmHipSchwarzLocalSolve(HpddmHipSchwarz *A, const double *in, double *out,
 }
 int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu)
 {
+  return HpddmHipSchwarzComputeResidualNorm(A, sol, f, storage, mu, 0);
+}
+int HpddmHipSchwarzComputeResidualNorm(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu, int norm)
+{
   HH_TRY(
     HH_CHECK(A && sol && f && storage, "null argument");
     Schwarz &op = A->op;
@@ -297,7 +301,7 @@ int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const 
     fd.alloc(cnt);
     HIP_OK(hipMemcpyAsync(op.hin.p, sol, cnt * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(fd.p, f, cnt * sizeof(double), hipMemcpyHostToDevice, st));
-    op.compute_residual(op.hin.p, fd.p, storage, mu);
+    op.compute_residual(op.hin.p, fd.p, storage, mu, norm);
     return 0;)
 }
 int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap)

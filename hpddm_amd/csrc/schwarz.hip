@@ -1027,10 +1027,32 @@ const double *Schwarz::norm_rhs(const double *b, double *scratch, int mu)
   return scratch;
 }
 
-void Schwarz::compute_residual(const double *x, const double *f, double *storage, int mu)
+// in place: w <- sqrt(|w|) (so that the D-weighted sum of squares is the D-weighted l1 norm)
+__global__ void k_sqrt_abs(long long cnt, double *__restrict__ w)
 {
-  // Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: storage[2nu] = ||f||_D, storage[2nu+1] = ||A x - f||_D;
-  // boundary-condition rows do not count in the residual and penalised entries of f are divided by HPDDM_PEN
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) w[i] = sqrt(fabs(w[i]));
+}
+// out[nu] = max_i |w[s][nu][i]| over all subdomains (non-negative doubles order like their bit patterns)
+__global__ void k_absmax(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ w, int mu, unsigned long long *__restrict__ out)
+{
+  const int       s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int nu = 0; nu < mu; ++nu) {
+    double m = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmax(m, fabs(w[v0 * mu + (long long)nu * n + i]));
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + nu, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+void Schwarz::compute_residual(const double *x, const double *f, double *storage, int mu, int norm)
+{
+  // Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803): storage[2nu] = ||f||, storage[2nu+1] = ||A x - f||; boundary-condition
+  // rows do not count in the residual and penalised entries of f are divided by HPDDM_PEN.  norm: 0 = l2 and 1 = l1, both weighted by
+  // the partition of unity (HPDDM_COMPUTE_RESIDUAL_L2 / _L1), 2 = linfty (plain maximum)
+  HH_CHECK(norm >= 0 && norm <= 2, "ComputeResidual: unknown norm");
+  HH_CHECK(norm == 0 || !is_complex, "ComputeResidual: l1 and linfty are built for real scalars");
+  HH_CHECK(norm != 2 || nranks == 1, "ComputeResidual: linfty needs a max-reduction over the ranks, not part of the registered transport");
   reserve(mu);
   const size_t cnt = (size_t)ntot * mu;
   gmv(x, w1.p, mu);
@@ -1043,11 +1065,36 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
     fn = w2.p;
   }
   std::vector<double> r(mu), b(mu);
+  hipStream_t         st = library_stream();
+  if (norm == 2) {
+    DevBuf<unsigned long long> mx;
+    mx.alloc((size_t)2 * mu);
+    HIP_OK(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long) * 2 * mu, st));
+    hipLaunchKernelGGL(k_absmax, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, fn, mu, mx.p);
+    hipLaunchKernelGGL(k_absmax, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, w1.p, mu, mx.p + mu);
+    std::vector<unsigned long long> h((size_t)2 * mu);
+    HIP_OK(hipMemcpyAsync(h.data(), mx.p, sizeof(unsigned long long) * 2 * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int nu = 0; nu < mu; ++nu) {
+      std::memcpy(&storage[2 * nu], &h[nu], sizeof(double));
+      std::memcpy(&storage[2 * nu + 1], &h[mu + nu], sizeof(double));
+    }
+    return;
+  }
+  if (norm == 1) {
+    const dim3 gl((unsigned)std::min<size_t>(2048, (cnt + 255) / 256));
+    if (fn != w2.p) {
+      HIP_OK(hipMemcpyAsync(w2.p, fn, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      fn = w2.p;
+    }
+    hipLaunchKernelGGL(k_sqrt_abs, gl, dim3(256), 0, st, (long long)cnt, w2.p);
+    hipLaunchKernelGGL(k_sqrt_abs, gl, dim3(256), 0, st, (long long)cnt, w1.p);
+  }
   wdots(w1.p, 0, 1, w1.p, mu, r.data());
   wdots(fn, 0, 1, fn, mu, b.data());
   for (int nu = 0; nu < mu; ++nu) {
-    storage[2 * nu]     = std::sqrt(b[nu]);
-    storage[2 * nu + 1] = std::sqrt(r[nu]);
+    storage[2 * nu]     = norm == 0 ? std::sqrt(b[nu]) : b[nu];
+    storage[2 * nu + 1] = norm == 0 ? std::sqrt(r[nu]) : r[nu];
   }
 }
 

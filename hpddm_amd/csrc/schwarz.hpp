@@ -149,7 +149,7 @@ struct Schwarz {
   void apply(const double *in, double *out, int mu);
   void diag(const double *in, double *out, int mu);
   void axpy(double alpha, const double *x, double *y, long long cnt);
-  void compute_residual(const double *x, const double *f, double *storage, int mu);
+  void compute_residual(const double *x, const double *f, double *storage, int mu, int norm = 0);
   // penalised Dirichlet rows (Subdomain::boundaryConditions, include/HPDDM_subdomain.hpp:310-336): bc_d[i] = diagonal entry of the
   // rows that carry a boundary condition, 0 elsewhere; has_bc false when there is none (then nothing below does anything)
   DevBuf<double> bc_d;

@@ -354,12 +354,12 @@ class Schwarz:
     def local_solve(self, xs):
         return self._op(self._lib.HpddmHipSchwarzLocalSolve, xs)
 
-    def compute_residual(self, sol, f):
-        """schwarzComputeResidual: array of 2*mu values, [||f||, ||A x - f||] per right-hand side."""
+    def compute_residual(self, sol, f, norm="l2"):
+        """schwarzComputeResidual: array of 2*mu values, [||f||, ||A x - f||] per right-hand side; norm: l2 | l1 | linfty."""
         fs, mu = self.pack(f)
         ss, _ = self.pack(sol)
         storage = np.zeros(2 * mu)
-        check(self._lib.HpddmHipSchwarzComputeResidual(self._h, _dptr(ss), _dptr(fs), _dptr(storage), mu))
+        check(self._lib.HpddmHipSchwarzComputeResidualNorm(self._h, _dptr(ss), _dptr(fs), _dptr(storage), mu, {"l2": 0, "l1": 1, "linfty": 2}[norm]))
         return storage
 
     def solve(self, f, sol=None, history=False):

@@ -152,6 +152,9 @@ int HpddmHipSchwarzLocalSolve(HpddmHipSchwarz *A, const double *in, double *out,
 /* HpddmSchwarzComputeResidual (HPDDM.h:109, include/HPDDM_schwarz.hpp:761): storage[2*nu] = ||f||^2-ish norms
  * exactly as the reference returns them (storage[2nu] = ||f_nu||, storage[2nu+1] = ||A x_nu - f_nu||, D-weighted) */
 int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu);
+/* the `norm` argument of Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761, 769-789): 0 = l2 (the function above), 1 = l1
+ * (both weighted by the partition of unity), 2 = linfty -- HPDDM_COMPUTE_RESIDUAL_L2 / _L1 / _LINFTY */
+int HpddmHipSchwarzComputeResidualNorm(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu, int norm);
 /* HpddmSolve (HPDDM.h:112, IterativeMethod::solve include/HPDDM_iterative.hpp:1013 -> GMRES include/HPDDM_GMRES.hpp:30):
  * returns the iteration count (negative on error); sol holds the initial guess on entry.
  * history, if not NULL, receives up to history_cap residual norms (one per iteration, largest over the rhs). */

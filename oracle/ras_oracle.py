@@ -259,14 +259,24 @@ class Oracle:
                 x[s][m] = (b[s][m].T / bc[s][m]).T
         return self.exchange(x)
 
-    def compute_residual(self, sol, f):
-        # Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803), l2 norm: boundary-condition rows do not count in the
-        # residual, and penalised right-hand-side entries are divided by HPDDM_PEN in the norm of f
+    def compute_residual(self, sol, f, norm="l2"):
+        # Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761-803): boundary-condition rows do not count in the residual,
+        # and penalised right-hand-side entries are divided by HPDDM_PEN in the norm of f.  l2 and l1 are weighted by the
+        # partition of unity (duplicated unknowns count once), linfty is the plain maximum.
         bc = self.boundary_conditions()
         r = [a - b for a, b in zip(self.gmv(sol), f)]
         r = [np.where((bc[s] != 0.0)[:, None] if rr.ndim == 2 else bc[s] != 0.0, 0.0, rr) for s, rr in enumerate(r)]
         fs = [np.where(np.abs(ff) > HPDDM_EPS * HPDDM_PEN, ff / HPDDM_PEN, ff) for ff in f]
-        nb, nr = np.sqrt(self.wdot(fs, fs).real), np.sqrt(self.wdot(r, r).real)
+        if norm == "l2":
+            nb, nr = np.sqrt(self.wdot(fs, fs).real), np.sqrt(self.wdot(r, r).real)
+        elif norm == "l1":
+            dd = lambda s, v: self.d[s][:, None] if v.ndim == 2 else self.d[s]
+            nb = sum((dd(s, v) * np.abs(v)).sum(axis=0) for s, v in enumerate(fs))
+            nr = sum((dd(s, v) * np.abs(v)).sum(axis=0) for s, v in enumerate(r))
+        else:
+            nb = np.max([np.abs(v).max(axis=0) for v in fs], axis=0)
+            nr = np.max([np.abs(v).max(axis=0) for v in r], axis=0)
+        nb, nr = np.atleast_1d(nb), np.atleast_1d(nr)
         out = np.zeros(2 * len(nb))
         out[0::2], out[1::2] = nb, nr
         return out

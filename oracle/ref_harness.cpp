@@ -233,6 +233,15 @@ int main(int argc, char **argv)
   dumpi("iterations", &it, 1);
   dumpd("sol", sol, n);
   dumpd("residual", storage, 2 * mu);
+  {
+    /* the other two norms of Schwarz::computeResidual (include/HPDDM_schwarz.hpp:769-789) */
+    double *other = new double[2 * mu];
+    A.computeResidual(sol, f, other, mu, HPDDM_COMPUTE_RESIDUAL_L1);
+    dumpd("residual_l1", other, 2 * mu);
+    A.computeResidual(sol, f, other, mu, HPDDM_COMPUTE_RESIDUAL_LINFTY);
+    dumpd("residual_linfty", other, 2 * mu);
+    delete[] other;
+  }
   if (rank == 0)
     for (int k = 0; k < mu; ++k) printf(" --- residual = %e / %e (it = %d)\n", storage[1 + 2 * k], storage[2 * k], it);
   delete[] storage;

@@ -71,6 +71,10 @@ def test_gmres_matches_reference(name):
     assert np.all(np.abs(hist - ref[:, 1]) <= (5e-3 if "nu3" in name else 2e-6) * ref[:, 1])
     _close(sol, gu.vecs(g, "sol"), 1e-5 if "nu3" in name else 1e-8, "solution")
     assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3 if "nu3" in name else 1e-5)
+    if "residual_l1_r0" in g:   # the other norms of Schwarz::computeResidual, on the reference's own solution
+        rs, rf = gu.vecs(g, "sol"), gu.vecs(g, "f")
+        assert np.allclose(A.compute_residual(rs, rf, "l1"), g["residual_l1_r0"], rtol=1e-6)
+        assert np.allclose(A.compute_residual(rs, rf, "linfty"), g["residual_linfty_r0"], rtol=1e-6)
     A.destroy()
 
 
@@ -439,4 +443,8 @@ def test_penalised_dirichlet_rows_match_reference(name):
     else:
         assert np.all(np.abs(hist[:2] - ref[:2, 1]) <= 1e-4 * ref[:2, 1])
         assert np.allclose(A.compute_residual(sol, f)[0::2], g["residual_r0"][0::2], rtol=1e-9)
+    if "residual_l1_r0" in g:   # l1 and linfty norms with penalised rows, on the reference's own solution
+        rs = gu.vecs(g, "sol")
+        assert np.allclose(A.compute_residual(rs, f, "l1"), g["residual_l1_r0"], rtol=1e-6)
+        assert np.allclose(A.compute_residual(rs, f, "linfty"), g["residual_linfty_r0"], rtol=1e-6)
     A.destroy()

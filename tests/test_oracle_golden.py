@@ -70,6 +70,10 @@ def test_gmres_matches_reference(name):
     _close(sol, gu.vecs(g, "sol"), 1e-6 if "nu3" in name else 1e-8, "solution")
     res = orc.compute_residual(sol, gu.vecs(g, "f"))
     assert np.allclose(res, g["residual_r0"], rtol=1e-5)
+    if "residual_l1_r0" in g:   # the other norms of Schwarz::computeResidual, on the reference's own solution
+        rs, rf = gu.vecs(g, "sol"), gu.vecs(g, "f")
+        assert np.allclose(orc.compute_residual(rs, rf, "l1"), g["residual_l1_r0"], rtol=1e-6)
+        assert np.allclose(orc.compute_residual(rs, rf, "linfty"), g["residual_linfty_r0"], rtol=1e-6)
 
 
 def test_config1_45_iterations():
@@ -116,6 +120,10 @@ def test_penalised_dirichlet_rows_match_reference(name):
         for (j, beta, nrm), row in list(zip(hist, ref))[:2]:
             assert abs(beta - row[1]) <= 1e-4 * row[1]
         assert np.allclose(orc.compute_residual(sol, f)[0::2], g["residual_r0"][0::2], rtol=1e-9)   # ||f|| with the penalised entries
+    if "residual_l1_r0" in g:   # l1 and linfty norms with penalised rows, on the reference's own solution
+        rs = gu.vecs(g, "sol")
+        assert np.allclose(orc.compute_residual(rs, f, "l1"), g["residual_l1_r0"], rtol=1e-6)
+        assert np.allclose(orc.compute_residual(rs, f, "linfty"), g["residual_linfty_r0"], rtol=1e-6)
 
 
 @pytest.mark.parametrize("name,method,tol_hist", [
