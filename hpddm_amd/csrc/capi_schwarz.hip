@@ -3,6 +3,7 @@
 #include "capi_common.hpp"
 #include "schwarz.hpp"
 #include "dense_eig.hpp"
+#include <cstdio>
 #include <cstring>
 #include <sstream>
 
@@ -64,7 +65,28 @@ HpddmHipSchwarz *HpddmHipSchwarzCreate(int nsub, int first_global, int nglobal)
     return nullptr;
   }
 }
-void HpddmHipSchwarzDestroy(HpddmHipSchwarz *A) { delete A; }
+void HpddmHipSchwarzDestroy(HpddmHipSchwarz *A)
+{
+  if (!A) return;
+  // -hpddm_dump_matrices=<prefix>: like Subdomain::~Subdomain (include/HPDDM_subdomain.hpp:370-388), every subdomain leaves its
+  // matrix in <prefix>_<global number>_<number of subdomains>.txt, in the text format of MatrixCSR::dump
+  // (include/HPDDM_matrix.hpp:121-135: two comment lines, "n m sym  nnz N", then "i j a_ij" per stored entry, 1-based, %.44e)
+  if (!A->op.dump_prefix.empty())
+    for (int s = 0; s < A->op.nsub; ++s) {
+      const SchwarzSub &S = A->op.subs[s];
+      if (S.ia0.empty() || A->op.is_complex) continue;
+      const std::string fn = A->op.dump_prefix + "_" + std::to_string(A->op.first + s) + "_" + std::to_string(A->op.nglobal) + ".txt";
+      if (FILE *fh = std::fopen(fn.c_str(), "w")) {
+        std::fprintf(fh, "# First line: n m (is symmetric) nnz indexing\n");
+        std::fprintf(fh, "# For each nonzero coefficient: i j a_ij such that (i, j) \\in  {1, ..., n} x {1, ..., m}\n");
+        std::fprintf(fh, "%d %d %d  %d %c\n", S.n, S.n, S.sym0 ? 1 : 0, S.ia0[S.n] - S.base0, S.base0 ? 'F' : 'C');
+        for (int i = 0; i < S.n; ++i)
+          for (int p = S.ia0[i] - S.base0; p < S.ia0[i + 1] - S.base0; ++p) std::fprintf(fh, "%9d %9d %.44e\n", i + 1, S.ja0[p] - S.base0 + 1, S.a0[p]);
+        std::fclose(fh);
+      }
+    }
+  delete A;
+}
 
 int HpddmHipSchwarzSetSubdomain(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity)
 {
@@ -234,6 +256,10 @@ int HpddmHipSchwarzOptionParse(HpddmHipSchwarz *A, const char *args)
         val = t.substr(eq + 1);
         t   = t.substr(0, eq);
       } else if (i + 1 < tok.size() && tok[i + 1].rfind("-hpddm_", 0) != 0 && !(tok[i + 1][0] == '-' && tok[i + 1].size() > 1 && std::isalpha((unsigned char)tok[i + 1][1]))) val = tok[++i];
+      if (t == "dump_matrices") { // the one string-valued option of the path
+        A->op.dump_prefix = val;
+        continue;
+      }
       A->op.opt[t] = val.empty() ? 1.0 : parse_value(t, val);
     }
     return 0;)

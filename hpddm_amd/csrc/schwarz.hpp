@@ -83,6 +83,7 @@ struct Schwarz {
   void                  build_halo_lists(); // host only
   std::vector<SchwarzSub>       subs;
   std::map<std::string, double> opt;
+  std::string                   dump_prefix; // -hpddm_dump_matrices=<prefix>: written when the operator is destroyed
   PrcndtnrType                  type = PRC_GE;
   bool                          device_ready = false, factored = false, coarse_ready = false;
   // K = std::complex<double>: subdomains handed over with set_subdomain_z.  Matrices, vectors and deflation vectors live in

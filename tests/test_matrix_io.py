@@ -66,3 +66,17 @@ def test_local_solver_benchmark_protocol():
     assert res.returncode == 0, res.stdout + res.stderr
     rows = [ln for ln in res.stdout.splitlines() if "|" in ln]
     assert len(rows) == 3 and all(len(r.split("|")[0].split()) == 3 for r in rows), res.stdout
+
+
+def test_dump_matrices_option_writes_the_reference_files(tmp_path):
+    """-hpddm_dump_matrices=<prefix> (include/HPDDM_subdomain.hpp:370-388): destroying the operator leaves one file per subdomain,
+    byte for byte what the compiled reference wrote for the same problem (tests/golden/dump).  Host code only."""
+    from hpddm_amd import hpddm
+    subs = generate2d(20, 20, 4, overlap=1)
+    prefix = str(tmp_path / "out")
+    A, d = hpddm.schwarz_from_subdomains(subs, options=f"-hpddm_dump_matrices={prefix} -hpddm_tol 1e-8")
+    assert A.get_option("tol") == 1e-8
+    A.destroy()
+    for r in range(4):
+        with open(f"{prefix}_{r}_4.txt", "rb") as new, open(os.path.join(DUMP, f"out_{r}_4.txt"), "rb") as ref:
+            assert new.read() == ref.read()
