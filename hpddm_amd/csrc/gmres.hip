@@ -665,6 +665,13 @@ static int gcrodr_one(Schwarz &A, const GcroOptions &o, const double *b, double 
       hipLaunchKernelGGL(k_axpby, gl, dim3(256), 0, st, N, 1.0, x, 1.0, Ax.p, x);
     }
     // ---- the recycled subspace (frozen from the second solve on with -hpddm_recycle_same_system, :241) ----
+    if (converged && dim == m) {
+      // a cycle that converges at its very last step leaves the reference's last basis vector un-normalised (Arnoldi does not scale
+      // v_m and the scaling after the cycle is skipped on convergence, :232-236): its products and its new C are built with that vector
+      const double hm = Hb(m, m - 1);
+      HIP_OK(hipMemcpyAsync(T.p, vk(m), sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+      lincomb(T.p, 1, &hm, 1.0, 0.0, vk(m));
+    }
     if (o.same_system <= 1 && (!have || j > m - k)) {
       std::vector<double> Pk, Q, R, wr, wi, EV;
       int                 kk = k, rowsG = dim + 1;

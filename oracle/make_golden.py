@@ -64,6 +64,9 @@ CASES = [
     ("p40_gcrodr_two_solves", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10"),
     ("p40_gcrodr_same_system", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_same_system 1"),
     ("p40_gcrodr_target_lm", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_target LM"),
+    ("p40_gcrodr_cycle_end", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 8"),
+    ("p40_bgcrodr_two_solves_mu2", 4, 2, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8"),
+    ("p30_6ranks_bgcrodr_left_deflated_mu3", 6, 3, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 2 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p30_6ranks_gcrodr_left_deflated_mu2", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_richardson_mu2", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method richardson -hpddm_max_it 15 -hpddm_richardson_damping_factor 0.7"),
     ("p40_none_deflated_mu2", 4, 2, "-Nx 40 -Ny 40 -hpddm_krylov_method none -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
@@ -106,7 +109,7 @@ def run_case(name, ranks, mu, opts, tmp):
         print(res.stdout[-2000:], res.stderr[-2000:])
         raise SystemExit(f"{name}: harness failed")
     hist = []
-    for m in re.finditer(r"^(?:B?GMRES|B?CG|BFBCG|GCRODR):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
+    for m in re.finditer(r"^(?:B?GMRES|B?CG|BFBCG|B?GCRODR):\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+<", res.stdout, re.M):
         hist.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))))
     data = {"ranks": np.int32(ranks), "mu": np.int32(mu), "options": np.array(opts),
             "history": np.array(hist, dtype=np.float64).reshape(-1, 4)}

@@ -186,7 +186,8 @@ def _gcrodr_block(orc, f, opt, recycle, state, same_system):
 
 
 @pytest.mark.parametrize("name,recycle,same", [("p40_gcrodr_two_solves", 4, 0), ("p40_gcrodr_same_system", 4, 1),
-                                               ("p30_6ranks_gcrodr_left_deflated_mu2", 3, 0), ("p40_gcrodr_target_lm", 4, 0)])
+                                               ("p30_6ranks_gcrodr_left_deflated_mu2", 3, 0), ("p40_gcrodr_target_lm", 4, 0),
+                                               ("p40_gcrodr_cycle_end", 4, 0)])
 def test_gcrodr_matches_reference(name, recycle, same):
     """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443) on two successive solves: the first builds the recycled subspace from the
     harmonic Ritz vectors of its first cycle and updates it at every restart, the second starts from it (19 then 15
@@ -225,3 +226,24 @@ def test_richardson_and_no_krylov_match_reference():
     it, sol = ro.no_krylov(orc, gu.vecs(g, "f"))
     assert it == int(g["iterations_r0"][0]) == 1
     _close(sol, gu.vecs(g, "sol"), 1e-12, "one apply")
+
+
+@pytest.mark.parametrize("name,recycle", [("p40_bgcrodr_two_solves_mu2", 3), ("p30_6ranks_bgcrodr_left_deflated_mu3", 2)])
+def test_block_gcrodr_matches_reference(name, recycle):
+    """Block GCRO-DR (include/HPDDM_GCRODR.hpp:445-905), two successive solves: 18 then 13 iterations for two right-hand sides.
+    In the first fixture a complex pair of harmonic Ritz values is cut by the selection after the first cycle, and the first
+    solve ends on the last step of a cycle (the reference then builds the recycled space with an un-normalised last block):
+    both conventions are reproduced."""
+    from oracle import ras_oracle as ro
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    orc, opt = _setup(g, subs)
+    f, f2 = gu.vecs(g, "f"), gu.vecs(g, "f2")
+    it, sol, hist, state = ro.bgcrodr(orc, f, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], recycle=recycle, variant=opt["variant"])
+    it2, sol2, hist2, _ = ro.bgcrodr(orc, f2, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], recycle=recycle, variant=opt["variant"], state=state)
+    assert it == int(g["iterations_r0"][0]) and it2 == int(g["iterations2_r0"][0])
+    ref = g["history"][:, 1]
+    assert len(ref) == it + it2
+    assert np.allclose([h[1] for h in hist], ref[:it], rtol=1e-4) and np.allclose([h[1] for h in hist2], ref[it:], rtol=1e-4)
+    _close(sol, gu.vecs(g, "sol"), 1e-9, "solution")
+    _close(sol2, gu.vecs(g, "sol2"), 1e-9, "second solution")
