@@ -11,6 +11,8 @@
 //
 // The basis blocks, the operator and the preconditioner stay in HBM; the host only sees (i+1) mu x mu Gram blocks.
 #include "schwarz.hpp"
+#include "dense_eig.hpp"
+#include "krylov_host.hpp"
 #include <cmath>
 #include <limits>
 
@@ -932,6 +934,453 @@ int Schwarz::bcg(const double *b, double *x, int mu, double *history, int histor
   return it;
 }
 
+// Block GCRO-DR: IterativeMethod::BGCRODR (include/HPDDM_GCRODR.hpp:445-905) -- Block GMRES (CholQR, classical block
+// Gram-Schmidt, Householder QR of the block Hessenberg matrix, same conventions as bgmres_impl) whose restarts keep k blocks
+// (U, C = A M^{-1} U, C^T D C = I): harmonic Ritz vectors after the first cycle, the generalised eigenproblem of strategy A after
+// every later one, and the pair seeds the next solve -- the block counterpart of Schwarz::gcrodr (gmres.hip), whose comments
+// describe the conventions reproduced here (the reference's rank-p term built from the QR factors of the whole Hessenberg
+// matrix; the un-normalised last block when a cycle converges on its last step).  No right-hand-side deflation.
+template <int MU>
+static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap, Schwarz::Recycled &rec)
+{
+  constexpr int mu = MU, p = MU;
+  A.reserve(mu);
+  hipStream_t  st        = library_stream();
+  const double tol       = A.getopt("tol", 1.0e-6);
+  const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int    m         = std::max(1, std::min((int)A.getopt("gmres_restart", 40), max_it));
+  const int    variant   = (int)A.getopt("variant", VARIANT_RIGHT);
+  const int    verbosity = (int)A.getopt("verbosity", 0);
+  const int    same      = std::min((int)A.getopt("recycle_same_system", 0), 2);
+  const int    target    = (int)A.getopt("recycle_target", 0);
+  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGCRODR: left and right preconditioning are built");
+  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGCRODR: right-hand-side deflation is not built");
+  HH_CHECK(A.getopt("recycle_strategy", 0) == 0, "BGCRODR: recycle_strategy A is built");
+  const bool      right = variant == VARIANT_RIGHT;
+  const long long cnt   = A.ntot * mu;
+  const int       ldh   = p * (m + 1), ncols = p * m;
+  const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
+  const int       nblk = 64;
+  int             k    = rec.k > 0 ? rec.k : std::min(m - 1, (int)A.getopt("recycle", 0));
+  const int       kcap = std::max(k, m + 1);
+  DevBuf<double>  V, Ax, T, partial, gram_d, coef_d, Un, Cn, PT;
+  V.alloc((size_t)cnt * (m + 1));
+  Ax.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  partial.alloc((size_t)kcap * nblk * mu * mu), gram_d.alloc((size_t)kcap * mu * mu), coef_d.alloc((size_t)kcap * mu * mu);
+  auto vk = [&](int q) { return V.p + (size_t)q * cnt; };
+  auto gram = [&](const double *Vb, int nb, const double *W, std::vector<double> &G) { // G[(kk * mu + a) * mu + b] = <V_kk[., a], W[., b]>_D
+    G.resize((size_t)nb * mu * mu);
+    hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, (unsigned)nb), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, Vb, cnt, W, partial.p);
+    hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)nb), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * nb * mu * mu, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), nb * mu * mu) == 0, "all-reduce failed");
+  };
+  auto axpy_blocks = [&](const double *Vb, int nb, const double *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
+    if (nb <= 0) {
+      if (beta == 0.0) HIP_OK(hipMemsetAsync(W, 0, sizeof(double) * cnt, st));
+      return;
+    }
+    HIP_OK(hipMemcpyAsync(coef_d.p, Cm, sizeof(double) * nb * mu * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * nb * mu * mu, st, A.voff_d.p, A.n_d.p, Vb, cnt, nb, coef_d.p, sign, beta, W);
+  };
+  // block c of a (rows x cols) row-major coefficient matrix, rows = nb blocks of mu: the (nb mu) x mu matrix axpy_blocks wants
+  auto block_of = [&](const std::vector<double> &M, int cols, int row0, int nb, int c, std::vector<double> &out) {
+    out.resize((size_t)nb * mu * mu);
+    for (int q = 0; q < nb; ++q)
+      for (int a = 0; a < mu; ++a)
+        for (int bb = 0; bb < mu; ++bb) out[((size_t)q * mu + a) * mu + bb] = M[(size_t)(row0 + q * mu + a) * cols + c * mu + bb];
+  };
+  auto op = [&](const double *in, double *out) {
+    if (right) {
+      A.apply(in, Ax.p, mu);
+      A.gmv(Ax.p, out, mu);
+    } else {
+      A.gmv(in, Ax.p, mu);
+      A.apply(Ax.p, out, mu);
+    }
+  };
+  // CholQR of one block: R (mu x mu upper, row-major), W <- W R^{-1}; false if the Gram matrix is not positive definite
+  auto cholqr = [&](double *W, std::vector<double> &R) {
+    std::vector<double> G;
+    gram(W, 1, W, G);
+    R.assign((size_t)mu * mu, 0.0);
+    for (int jj = 0; jj < mu; ++jj) {
+      double dj = G[(size_t)jj * mu + jj];
+      for (int q = 0; q < jj; ++q) dj -= R[(size_t)q * mu + jj] * R[(size_t)q * mu + jj];
+      if (!(dj > 0.0)) return false;
+      dj                      = std::sqrt(dj);
+      R[(size_t)jj * mu + jj] = dj;
+      for (int c = jj + 1; c < mu; ++c) {
+        double v = G[(size_t)jj * mu + c];
+        for (int q = 0; q < jj; ++q) v -= R[(size_t)q * mu + jj] * R[(size_t)q * mu + c];
+        R[(size_t)jj * mu + c] = v / dj;
+      }
+    }
+    const std::vector<double> Ri = upper_inverse(mu, R);
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    axpy_blocks(T.p, 1, Ri.data(), 1.0, 0.0, W);
+    return true;
+  };
+  std::vector<double> norm(mu), G, R, S0, blk;
+  A.start(b, x, mu);
+  {
+    std::vector<double> nb;
+    if (!right) {
+      A.apply(b, T.p, mu);
+      gram(T.p, 1, T.p, nb);
+    } else {
+      const double *bn = A.norm_rhs(b, T.p, mu);
+      gram(bn, 1, bn, nb);
+    }
+    for (int nu = 0; nu < mu; ++nu) {
+      norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu]);
+      if (norm[nu] < HPDDM_EPS) norm[nu] = 1.0;
+    }
+  }
+  std::vector<double> Hbar((size_t)(ncols + p) * ncols), Bm, Hr((size_t)ldh * ncols), s((size_t)ldh * p), tau((size_t)m * 2 * p);
+  auto                Hb = [&](int r, int c) -> double & { return Hbar[(size_t)r * ncols + c]; };
+  int                 j = 1, nhist = 0;
+  while (j <= max_it) {
+    const bool have = rec.k > 0;
+    const int  i0 = have ? k : 0, kb = have ? k * p : 0;
+    double    *r0 = vk(i0);
+    if (right) {
+      A.gmv(x, r0, mu);
+      hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, r0, r0);
+    } else {
+      A.gmv(x, T.p, mu);
+      hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, T.p, T.p);
+      A.apply(T.p, r0, mu);
+    }
+    if (j == 1 && have) {
+      // a new solve starts from the recycled space (:516-546): C = A M^{-1} U re-orthonormalised (CholQR over its k p columns) unless
+      // -hpddm_recycle_same_system, then x += M^{-1} U (C^T r), r -= C (C^T r)
+      PT.alloc((size_t)cnt * k);
+      if (right)
+        for (int c = 0; c < k; ++c) A.apply(rec.U.p + (size_t)c * cnt, PT.p + (size_t)c * cnt, mu);
+      double *pt = right ? PT.p : rec.U.p;
+      if (same == 0) {
+        for (int c = 0; c < k; ++c) {
+          if (right) A.gmv(pt + (size_t)c * cnt, rec.C.p + (size_t)c * cnt, mu);
+          else {
+            A.gmv(pt + (size_t)c * cnt, Ax.p, mu);
+            A.apply(Ax.p, rec.C.p + (size_t)c * cnt, mu);
+          }
+        }
+        std::vector<double> Gf((size_t)kb * kb), Rf((size_t)kb * kb, 0.0);
+        for (int c = 0; c < k; ++c) {
+          gram(rec.C.p, k, rec.C.p + (size_t)c * cnt, G);
+          for (int q = 0; q < k; ++q)
+            for (int a2 = 0; a2 < mu; ++a2)
+              for (int bb = 0; bb < mu; ++bb) Gf[(size_t)(q * mu + a2) * kb + c * mu + bb] = G[((size_t)q * mu + a2) * mu + bb];
+        }
+        for (int q = 0; q < kb; ++q) { // potrf "U"
+          double dq = Gf[(size_t)q * kb + q];
+          for (int t = 0; t < q; ++t) dq -= Rf[(size_t)t * kb + q] * Rf[(size_t)t * kb + q];
+          HH_CHECK(dq > 0.0, "BGCRODR: the recycled subspace lost its rank");
+          dq                    = std::sqrt(dq);
+          Rf[(size_t)q * kb + q] = dq;
+          for (int c = q + 1; c < kb; ++c) {
+            double v = Gf[(size_t)q * kb + c];
+            for (int t = 0; t < q; ++t) v -= Rf[(size_t)t * kb + q] * Rf[(size_t)t * kb + c];
+            Rf[(size_t)q * kb + c] = v / dq;
+          }
+        }
+        const std::vector<double> Ri = upper_inverse(kb, Rf);
+        Un.alloc((size_t)cnt * k);
+        auto times_ri = [&](double *W) {
+          HIP_OK(hipMemcpyAsync(Un.p, W, sizeof(double) * cnt * k, hipMemcpyDeviceToDevice, st));
+          for (int c = 0; c < k; ++c) {
+            block_of(Ri, kb, 0, k, c, blk);
+            axpy_blocks(Un.p, k, blk.data(), 1.0, 0.0, W + (size_t)c * cnt);
+          }
+        };
+        times_ri(rec.C.p);
+        times_ri(rec.U.p);
+        if (right) times_ri(PT.p);
+      }
+      gram(rec.C.p, k, r0, G); // (k mu) x mu
+      axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, r0);
+      if (right && same != 0) {
+        axpy_blocks(rec.U.p, k, G.data(), 1.0, 0.0, T.p);
+        A.apply(T.p, Ax.p, mu);
+        hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, Ax.p, x);
+      } else axpy_blocks(pt, k, G.data(), 1.0, 1.0, x);
+    }
+    if (!cholqr(r0, S0)) return -2;
+    std::fill(Hbar.begin(), Hbar.end(), 0.0);
+    Bm.assign((size_t)std::max(kb, 1) * ncols, 0.0);
+    std::fill(Hr.begin(), Hr.end(), 0.0);
+    std::fill(s.begin(), s.end(), 0.0);
+    std::fill(tau.begin(), tau.end(), 0.0);
+    for (int c = 0; c < p; ++c)
+      for (int r = 0; r <= c; ++r) s[(i0 * p + r) + (size_t)c * ldh] = S0[(size_t)r * p + c];
+    auto Hc = [&](int i) { return Hr.data() + (size_t)i * p * ldh; };
+    int  i = i0, dimb = -1;
+    bool converged = false;
+    while (i < m && j <= max_it) {
+      double *W = vk(i + 1);
+      op(vk(i), W);
+      if (have) {
+        gram(rec.C.p, k, W, G);
+        for (int q = 0; q < kb; ++q)
+          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * mu + c];
+        axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, W);
+      }
+      gram(vk(i0), i + 1 - i0, W, G); // classical block Gram-Schmidt
+      axpy_blocks(vk(i0), i + 1 - i0, G.data(), -1.0, 1.0, W);
+      for (int q = 0; q < (i + 1 - i0) * p; ++q)
+        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * mu + c];
+      if (!cholqr(W, R)) return -2;
+      for (int r = 0; r < p; ++r)
+        for (int c = r; c < p; ++c) Hb((i + 1) * p + r, i * p + c) = R[(size_t)r * p + c];
+      // Householder QR of the block Hessenberg matrix (geqrf / mqr, BlockArnoldi include/HPDDM_iterative.hpp:727-729)
+      double *Hi = Hc(i);
+      for (int r = i0 * p; r < (i + 2) * p; ++r)
+        for (int c = 0; c < p; ++c) Hi[r + (size_t)c * ldh] = Hb(r, i * p + c);
+      for (int q = i0; q < i; ++q) orm2r_lt(2 * p, p, p, Hc(q) + q * p, ldh, tau.data() + (size_t)q * 2 * p, Hi + q * p, ldh);
+      geqr2(2 * p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p);
+      orm2r_lt(2 * p, p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p, s.data() + i * p, ldh);
+      ++i;
+      int    conv = 0, which = 0;
+      double best = -1.0;
+      for (int nu = 0; nu < p; ++nu) {
+        double nrm = 0.0;
+        for (int r = 0; r <= nu; ++r) nrm += s[(p * i + r) + (size_t)nu * ldh] * s[(p * i + r) + (size_t)nu * ldh];
+        nrm = std::sqrt(nrm);
+        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / norm[nu] > best) best = nrm / norm[nu], which = nu;
+      }
+      const double beta = best * norm[which];
+      if (history && nhist < history_cap) history[nhist] = beta;
+      ++nhist;
+      if (verbosity > 2) printf("BGCRODR: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
+      if (conv == p) {
+        dimb      = i;
+        converged = true;
+        break;
+      }
+      ++j;
+    }
+    if (dimb < 0) dimb = i;
+    if (!converged && !(j != max_it + 1 && i == m)) converged = true; // max_it reached
+    // ---- updateSolRecycling: Y2 from the triangular system, Y1 = C^T r - B Y2 ----
+    const int           nk = (dimb - i0) * p; // Krylov columns
+    std::vector<double> Y2((size_t)std::max(nk, 1) * p, 0.0); // row-major nk x p
+    for (int c = 0; c < p; ++c)
+      for (int r = nk - 1; r >= 0; --r) {
+        double v = s[(i0 * p + r) + (size_t)c * ldh];
+        for (int q = r + 1; q < nk; ++q) v -= Hr[(i0 * p + r) + (size_t)(i0 * p + q) * ldh] * Y2[(size_t)q * p + c];
+        Y2[(size_t)r * p + c] = v / Hr[(i0 * p + r) + (size_t)(i0 * p + r) * ldh];
+      }
+    axpy_blocks(vk(i0), dimb - i0, Y2.data(), 1.0, 0.0, T.p);
+    if (have) {
+      std::vector<double> Y1((size_t)kb * p, 0.0);
+      if (same == 0) { // C^T D (V_{i0} S0) = (C^T D V_{i0}) S0
+        gram(rec.C.p, k, vk(i0), G);
+        for (int q = 0; q < kb; ++q)
+          for (int c = 0; c < p; ++c) {
+            double v = 0.0;
+            for (int t = 0; t <= c; ++t) v += G[(size_t)q * mu + t] * S0[(size_t)t * p + c];
+            Y1[(size_t)q * p + c] = v;
+          }
+      }
+      for (int q = 0; q < kb; ++q)
+        for (int c = 0; c < p; ++c) {
+          double v = 0.0;
+          for (int t = 0; t < nk; ++t) v += Bm[(size_t)q * ncols + i0 * p + t] * Y2[(size_t)t * p + c];
+          Y1[(size_t)q * p + c] -= v;
+        }
+      axpy_blocks(rec.U.p, k, Y1.data(), 1.0, 1.0, T.p);
+    }
+    if (!right) hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, T.p, x);
+    else {
+      A.apply(T.p, Ax.p, mu);
+      hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, Ax.p, x);
+    }
+    if (converged && dimb == m) { // the reference's un-normalised last block (:660-663 is skipped on convergence)
+      std::vector<double> Rl((size_t)p * p, 0.0);
+      for (int r = 0; r < p; ++r)
+        for (int c = 0; c < p; ++c) Rl[(size_t)r * p + c] = Hb(m * p + r, (m - 1) * p + c);
+      HIP_OK(hipMemcpyAsync(T.p, vk(m), sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_blocks(T.p, 1, Rl.data(), 1.0, 0.0, vk(m));
+    }
+    // ---- the recycled subspace ----
+    if (same <= 1 && (!have || j > m - k)) {
+      const int           nc = dimb * p, rowsG = nc + p;
+      int                 kk = k;
+      std::vector<double> Gm((size_t)rowsG * nc, 0.0), Pk, Q, Rq, wr, wi, EV, un(std::max(kb, 1), 1.0);
+      if (!have) {
+        kk = std::min(k, dimb);
+        for (int r = 0; r < rowsG; ++r)
+          for (int c = 0; c < nc; ++c) Gm[(size_t)r * nc + c] = Hb(r, c);
+        // H_m + F in its last block column, F = (Q [R^{-T} Z; 0])(first nc rows), Z = E_m h^T h, Q R the QR of the whole Hessenberg matrix
+        std::vector<double> Qh, Rh, Z((size_t)nc * p, 0.0), Y((size_t)nc * p, 0.0), Hm((size_t)nc * nc);
+        small_qr(rowsG, nc, Gm, Qh, Rh);
+        for (int a2 = 0; a2 < p; ++a2)
+          for (int c = 0; c < p; ++c) {
+            double v = 0.0;
+            for (int t = 0; t < p; ++t) v += Hb(nc + t, nc - p + a2) * Hb(nc + t, nc - p + c);
+            Z[(size_t)(nc - p + a2) * p + c] = v;
+          }
+        for (int c = 0; c < p; ++c) // R^T Y = Z (forward substitution with the lower triangular R^T)
+          for (int r = 0; r < nc; ++r) {
+            double v = Z[(size_t)r * p + c];
+            for (int t = 0; t < r; ++t) v -= Rh[(size_t)t * nc + r] * Y[(size_t)t * p + c];
+            Y[(size_t)r * p + c] = v / Rh[(size_t)r * nc + r];
+          }
+        for (int r = 0; r < nc; ++r)
+          for (int c = 0; c < nc; ++c) Hm[(size_t)r * nc + c] = Hb(r, c);
+        for (int r = 0; r < nc; ++r)
+          for (int c = 0; c < p; ++c) {
+            double v = 0.0;
+            for (int t = 0; t < nc; ++t) v += Qh[(size_t)r * nc + t] * Y[(size_t)t * p + c];
+            Hm[(size_t)r * nc + nc - p + c] += v;
+          }
+        HH_CHECK(dense_eig(nc, Hm, wr, wi, EV), "BGCRODR: the eigen-solver did not converge");
+        Pk = select_vectors(nc, wi, EV, target_order(target, wr, wi), kk * p);
+      } else {
+        std::vector<double> Guu;
+        for (int c = 0; c < k; ++c) {
+          gram(rec.U.p + (size_t)c * cnt, 1, rec.U.p + (size_t)c * cnt, Guu);
+          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * mu + a2]);
+        }
+        for (int q = 0; q < kb; ++q) {
+          Gm[(size_t)q * nc + q] = un[q];
+          for (int c = kb; c < nc; ++c) Gm[(size_t)q * nc + c] = Bm[(size_t)q * ncols + c];
+        }
+        for (int r = kb; r < rowsG; ++r)
+          for (int c = kb; c < nc; ++c) Gm[(size_t)r * nc + c] = Hb(r, c);
+        std::vector<double> WV((size_t)rowsG * nc, 0.0); // W^T D Vh: its first kb columns, then [0; I; 0]
+        for (int c = 0; c < k; ++c) {
+          gram(rec.C.p, k, rec.U.p + (size_t)c * cnt, G);
+          for (int q = 0; q < kb; ++q)
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+          gram(vk(k), dimb + 1 - k, rec.U.p + (size_t)c * cnt, G);
+          for (int q = 0; q < (dimb + 1 - k) * p; ++q)
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+        }
+        for (int q = 0; q < nc - kb; ++q) WV[(size_t)(kb + q) * nc + kb + q] = 1.0;
+        std::vector<double> Am((size_t)nc * nc), Mm((size_t)nc * nc), Lc((size_t)nc * nc, 0.0);
+        for (int a2 = 0; a2 < nc; ++a2)
+          for (int c = 0; c < nc; ++c) {
+            double va = 0.0, vb = 0.0;
+            for (int q = 0; q < rowsG; ++q) {
+              va += Gm[(size_t)q * nc + a2] * Gm[(size_t)q * nc + c];
+              vb += Gm[(size_t)q * nc + a2] * WV[(size_t)q * nc + c];
+            }
+            Am[(size_t)a2 * nc + c] = va, Mm[(size_t)a2 * nc + c] = vb;
+          }
+        for (int a2 = 0; a2 < nc; ++a2) // A = L L^T
+          for (int c = 0; c <= a2; ++c) {
+            double v = Am[(size_t)a2 * nc + c];
+            for (int q = 0; q < c; ++q) v -= Lc[(size_t)a2 * nc + q] * Lc[(size_t)c * nc + q];
+            if (a2 == c) {
+              HH_CHECK(v > 0.0, "BGCRODR: G^T G is not positive definite");
+              Lc[(size_t)a2 * nc + a2] = std::sqrt(v);
+            } else Lc[(size_t)a2 * nc + c] = v / Lc[(size_t)c * nc + c];
+          }
+        for (int c = 0; c < nc; ++c) { // Mm <- A^{-1} B
+          for (int a2 = 0; a2 < nc; ++a2) {
+            double v = Mm[(size_t)a2 * nc + c];
+            for (int q = 0; q < a2; ++q) v -= Lc[(size_t)a2 * nc + q] * Mm[(size_t)q * nc + c];
+            Mm[(size_t)a2 * nc + c] = v / Lc[(size_t)a2 * nc + a2];
+          }
+          for (int a2 = nc - 1; a2 >= 0; --a2) {
+            double v = Mm[(size_t)a2 * nc + c];
+            for (int q = a2 + 1; q < nc; ++q) v -= Lc[(size_t)q * nc + a2] * Mm[(size_t)q * nc + c];
+            Mm[(size_t)a2 * nc + c] = v / Lc[(size_t)a2 * nc + a2];
+          }
+        }
+        HH_CHECK(dense_eig(nc, Mm, wr, wi, EV), "BGCRODR: the eigen-solver did not converge");
+        std::vector<double> tr(nc), ti(nc); // theta = 1 / mu
+        for (int a2 = 0; a2 < nc; ++a2) {
+          const double m2 = wr[a2] * wr[a2] + wi[a2] * wi[a2];
+          tr[a2] = m2 > 0.0 ? wr[a2] / m2 : std::numeric_limits<double>::infinity();
+          ti[a2] = m2 > 0.0 ? -wi[a2] / m2 : 0.0;
+        }
+        Pk = select_vectors(nc, wi, EV, target_order(target, tr, ti), kb);
+      }
+      const int           kc = kk * p; // columns of the new space
+      std::vector<double> GP((size_t)rowsG * kc, 0.0);
+      for (int r = 0; r < rowsG; ++r)
+        for (int c = 0; c < kc; ++c) {
+          double v = 0.0;
+          for (int q = 0; q < nc; ++q) v += Gm[(size_t)r * nc + q] * Pk[(size_t)q * kc + c];
+          GP[(size_t)r * kc + c] = v;
+        }
+      small_qr(rowsG, kc, GP, Q, Rq);
+      const std::vector<double> Ri = upper_inverse(kc, Rq);
+      std::vector<double>       PR((size_t)nc * kc, 0.0);
+      for (int r = 0; r < nc; ++r)
+        for (int c = 0; c < kc; ++c) {
+          double v = 0.0;
+          for (int q = 0; q <= c; ++q) v += Pk[(size_t)r * kc + q] * Ri[(size_t)q * kc + c];
+          PR[(size_t)r * kc + c] = (have && r < kb ? un[r] : 1.0) * v; // the U part of Vh is U D
+        }
+      Un.alloc((size_t)cnt * kk), Cn.alloc((size_t)cnt * kk);
+      for (int c = 0; c < kk; ++c) {
+        if (!have) {
+          block_of(PR, kc, 0, dimb, c, blk);
+          axpy_blocks(vk(0), dimb, blk.data(), 1.0, 0.0, Un.p + (size_t)c * cnt);
+          block_of(Q, kc, 0, dimb + 1, c, blk);
+          axpy_blocks(vk(0), dimb + 1, blk.data(), 1.0, 0.0, Cn.p + (size_t)c * cnt);
+        } else {
+          block_of(PR, kc, 0, k, c, blk);
+          axpy_blocks(rec.U.p, k, blk.data(), 1.0, 0.0, Un.p + (size_t)c * cnt);
+          block_of(PR, kc, kb, dimb - k, c, blk);
+          axpy_blocks(vk(k), dimb - k, blk.data(), 1.0, 1.0, Un.p + (size_t)c * cnt);
+          block_of(Q, kc, 0, k, c, blk);
+          axpy_blocks(rec.C.p, k, blk.data(), 1.0, 0.0, Cn.p + (size_t)c * cnt);
+          block_of(Q, kc, kb, dimb + 1 - k, c, blk);
+          axpy_blocks(vk(k), dimb + 1 - k, blk.data(), 1.0, 1.0, Cn.p + (size_t)c * cnt);
+        }
+      }
+      rec.U.alloc((size_t)cnt * kk), rec.C.alloc((size_t)cnt * kk);
+      HIP_OK(hipMemcpyAsync(rec.U.p, Un.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipMemcpyAsync(rec.C.p, Cn.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipStreamSynchronize(st));
+      rec.k = k = kk;
+    }
+    if (converged) break;
+    if (verbosity > 1) printf("BGCRODR restart(%d, %d)\n", m, k);
+  }
+  if (verbosity) {
+    if (j != max_it + 1) printf("BGCRODR converges after %d iteration%s\n", j, j > 1 ? "s" : "");
+    else printf("BGCRODR does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(j, max_it);
+}
+
+int Schwarz::bgcrodr(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK(factored, "solve before CallNumfact");
+  if (std::min((int)getopt("gmres_restart", 40) - 1, (int)getopt("recycle", 0)) <= 0) return bgmres(b, x, mu, history, history_cap); // (:460-465)
+  if (!recycled_block || recycled_block_mu != mu) { // the recycled blocks belong to one block width (:477-481)
+    recycled_block.reset(new Recycled());
+    recycled_block_mu = mu;
+  }
+  const int same = (int)getopt("recycle_same_system", 0);
+  int       it;
+  switch (mu) {
+  case 1: it = bgcrodr_impl<1>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 2: it = bgcrodr_impl<2>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 3: it = bgcrodr_impl<3>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 4: it = bgcrodr_impl<4>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 5: it = bgcrodr_impl<5>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 6: it = bgcrodr_impl<6>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 7: it = bgcrodr_impl<7>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 8: it = bgcrodr_impl<8>(*this, b, x, history, history_cap, *recycled_block); break;
+  default: HH_CHECK(false, "BGCRODR: 1 <= mu <= 8 in this build"); it = -1;
+  }
+  if (it == -2) return gmres(b, x, mu, history, history_cap); // breakdown of a CholQR: GMRES, like BGMRES
+  if (it != 0 && same != 0) opt["recycle_same_system"] = same + 1; // (:433 of the non-block method, same rule)
+  return it;
+}
+
 int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int history_cap)
 {
   HH_CHECK(factored, "solve before CallNumfact");
@@ -965,8 +1414,9 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   if (method == 2) return cg(b, x, mu, history, history_cap);
   if (method == 3) return bcg(b, x, mu, history, history_cap);
   if (method == 4) return gcrodr(b, x, mu, history, history_cap);
+  if (method == 5) return bgcrodr(b, x, mu, history, history_cap);
   if (method == 6) return bfbcg(b, x, mu, history, history_cap);
-  HH_CHECK(method == 0, "krylov_method: gmres, bgmres, cg, bcg, gcrodr, bfbcg, richardson and none are built (not bgcrodr)");
+  HH_CHECK(method == 0, "krylov_method: unknown value");
   return gmres(b, x, mu, history, history_cap);
 }
 

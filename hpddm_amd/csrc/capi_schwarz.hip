@@ -148,6 +148,7 @@ int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A)
   HH_TRY(
     HH_CHECK(A, "null argument");
     A->op.recycled.clear();
+    A->op.recycled_block.reset();
     if (A->op.getopt("recycle_same_system", 0) > 1) A->op.opt["recycle_same_system"] = 1;
     return 0;)
 }

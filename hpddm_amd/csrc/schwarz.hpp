@@ -167,6 +167,9 @@ struct Schwarz {
     int            k = 0;
   };
   std::vector<std::unique_ptr<Recycled>> recycled;
+  std::unique_ptr<Recycled>              recycled_block; // block GCRO-DR: k blocks of mu columns each (batched layout)
+  int                                    recycled_block_mu = 0;
+  int  bgcrodr(const double *b, double *x, int mu, double *history, int history_cap);      // bgmres.hip
   int  gcrodr(const double *b, double *x, int mu, double *history, int history_cap);       // gmres.hip
   int  bgmres(const double *b, double *x, int mu, double *history, int history_cap);       // bgmres.hip
   int  bcg(const double *b, double *x, int mu, double *history, int history_cap);          // bgmres.hip

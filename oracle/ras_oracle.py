@@ -842,9 +842,12 @@ def _harmonic_select(theta, vecs, k, target="SM"):
             used.add(t)
             if conj:
                 used.add(conj[0])
-            cols.append(np.real(v))
-            if len(cols) < k:
+            if len(cols) + 1 < k:
+                cols.append(np.real(v))
                 cols.append(np.imag(v))
+            else:   # cut pair: the real part of the vector once its component of largest modulus is real (geev's normalisation)
+                big = int(np.argmax(np.abs(v)))
+                cols.append(np.real(v * np.exp(-1j * np.angle(v[big]))))
     return np.stack(cols[:k], axis=1)
 
 

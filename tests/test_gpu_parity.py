@@ -313,12 +313,15 @@ def test_cg_matches_reference():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2", "p40_gcrodr_target_lm"])
+@pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2", "p40_gcrodr_target_lm",
+                                  "p40_gcrodr_cycle_end", "p40_bgcrodr_two_solves_mu2", "p30_6ranks_bgcrodr_left_deflated_mu3"])
 def test_gcrodr_matches_reference(name):
     """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443), two successive solves on one operator: the first one builds the recycled
     subspace (harmonic Ritz vectors after its first cycle, generalised eigenproblem at every later restart), the second one
     starts from it -- the reference's 19 then 15 iterations where GMRES(10) needs 24, and its residual histories.  With
-    -hpddm_recycle_same_system the subspace is frozen during the second solve, like in the reference."""
+    -hpddm_recycle_same_system the subspace is frozen during the second solve, like in the reference.  The bgcrodr fixtures run
+    the block method (include/HPDDM_GCRODR.hpp:445-905): 18 then 13 iterations for two right-hand sides; cycle_end is a run whose
+    first solve converges on the last step of a cycle (the reference then recycles an un-normalised last vector)."""
     g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
