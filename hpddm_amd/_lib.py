@@ -49,6 +49,7 @@ def _declare(lib):
         "HpddmHipSchwarzSetVectorsZ": (I, [P, I, I, P]),
         "HpddmHipSchwarzIsComplex": (I, [P]),
         "HpddmHipDenseEig": (I, [I, P, P, P, P]),
+        "HpddmHipHostSelfTest": (I, []),
         "HpddmHipSchwarzDestroyRecycling": (I, [P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),

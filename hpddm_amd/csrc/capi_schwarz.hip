@@ -3,6 +3,7 @@
 #include "capi_common.hpp"
 #include "schwarz.hpp"
 #include "dense_eig.hpp"
+#include "krylov_host.hpp"
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -151,6 +152,72 @@ int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A)
     A->op.recycled_block.reset();
     if (A->op.getopt("recycle_same_system", 0) > 1) A->op.opt["recycle_same_system"] = 1;
     return 0;)
+}
+int HpddmHipHostSelfTest(void)
+{
+  // host-only checks of the small dense helpers of the recycling Krylov methods (krylov_host.hpp): returns 0, or the number of the
+  // first check that fails
+  try {
+    const int           rows = 7, cols = 3;
+    std::vector<double> M((size_t)rows * cols), Q, R;
+    for (int i = 0; i < rows * cols; ++i) M[i] = std::sin(1.0 + 0.7 * i) + (i % 4 == 0 ? 1.5 : 0.0);
+    small_qr(rows, cols, M, Q, R);
+    for (int a = 0; a < cols; ++a)
+      for (int b = 0; b < cols; ++b) {
+        double v = 0.0;
+        for (int i = 0; i < rows; ++i) v += Q[(size_t)i * cols + a] * Q[(size_t)i * cols + b];
+        if (std::abs(v - (a == b ? 1.0 : 0.0)) > 1e-13) return 1; // Q^T Q = I
+        if (a > b && R[(size_t)a * cols + b] != 0.0) return 2;    // R upper triangular
+      }
+    for (int i = 0; i < rows; ++i)
+      for (int b = 0; b < cols; ++b) {
+        double v = 0.0;
+        for (int a = 0; a < cols; ++a) v += Q[(size_t)i * cols + a] * R[(size_t)a * cols + b];
+        if (std::abs(v - M[(size_t)i * cols + b]) > 1e-13) return 3; // Q R = M
+      }
+    const std::vector<double> Ri = upper_inverse(cols, R);
+    for (int a = 0; a < cols; ++a)
+      for (int b = 0; b < cols; ++b) {
+        double v = 0.0;
+        for (int c = 0; c < cols; ++c) v += R[(size_t)a * cols + c] * Ri[(size_t)c * cols + b];
+        if (std::abs(v - (a == b ? 1.0 : 0.0)) > 1e-12) return 4; // R R^{-1} = I
+      }
+    // eigenvalues 3, 0.5 +- 2i, -1, 0.2: orders for the six recycle targets
+    const std::vector<double> tr = {3.0, 0.5, 0.5, -1.0, 0.2}, ti = {0.0, 2.0, -2.0, 0.0, 0.0};
+    const std::vector<int>    sm = target_order(0, tr, ti), lm = target_order(1, tr, ti), sr = target_order(2, tr, ti), lr = target_order(3, tr, ti),
+                           si = target_order(4, tr, ti), li = target_order(5, tr, ti);
+    if (sm[0] != 4 || sm[1] != 3 || sm[2] != 1 || sm[3] != 2 || sm[4] != 0) return 5;
+    if (lm[0] != 0 || lm[1] != 1 || lm[2] != 2) return 6;
+    if (sr[0] != 3 || lr[0] != 0 || si[0] != 2 || li[0] != 1) return 7;
+    // selection: a real vector, a whole pair, a pair cut by the limit (rotated so that its largest component is real)
+    const int           n = 5;
+    std::vector<double> V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j ? 2.0 : 0.0) + 0.1 * (i + 1) * (j + 2);
+    std::vector<double> P = select_vectors(n, ti, V, sm, 3); // index 4 (real), 3 (real), then the pair (1, 2) cut: one column
+    for (int i = 0; i < n; ++i)
+      if (P[(size_t)i * 3 + 0] != V[(size_t)i * n + 4] || P[(size_t)i * 3 + 1] != V[(size_t)i * n + 3]) return 8;
+    {
+      int    big = 0;
+      double best = -1.0;
+      for (int i = 0; i < n; ++i) {
+        const double m2 = V[(size_t)i * n + 1] * V[(size_t)i * n + 1] + V[(size_t)i * n + 2] * V[(size_t)i * n + 2];
+        if (m2 > best) best = m2, big = i;
+      }
+      const double phi = std::atan2(V[(size_t)big * n + 2], V[(size_t)big * n + 1]);
+      for (int i = 0; i < n; ++i)
+        if (std::abs(P[(size_t)i * 3 + 2] - (std::cos(phi) * V[(size_t)i * n + 1] + std::sin(phi) * V[(size_t)i * n + 2])) > 1e-14) return 9;
+      // the rotated vector has a real largest component: its imaginary part there vanishes
+      if (std::abs(-std::sin(phi) * V[(size_t)big * n + 1] + std::cos(phi) * V[(size_t)big * n + 2]) > 1e-14) return 10;
+    }
+    P = select_vectors(n, ti, V, sm, 4); // now the pair fits: (Re, Im) = columns 1 and 2 as they are
+    for (int i = 0; i < n; ++i)
+      if (P[(size_t)i * 4 + 2] != V[(size_t)i * n + 1] || P[(size_t)i * 4 + 3] != V[(size_t)i * n + 2]) return 11;
+    return 0;
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
 }
 int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V)
 {

@@ -50,3 +50,9 @@ def test_defective_and_zero_matrices():
     J = np.diag(np.ones(3), 1) + 2.0 * np.eye(4)   # one Jordan block
     lam, V = _eig(J)
     assert np.allclose(lam, 2.0, atol=1e-3)
+
+
+def test_host_helpers_of_the_recycling_methods():
+    """Householder QR, triangular inverse, the six -hpddm_recycle_target orders and the selection of Ritz vectors (whole and cut
+    complex pairs) used by GCRO-DR / Block GCRO-DR: the library's own host self-test"""
+    assert _lib.load().HpddmHipHostSelfTest() == 0
