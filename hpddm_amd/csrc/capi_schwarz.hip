@@ -4,6 +4,7 @@
 #include "schwarz.hpp"
 #include "dense_eig.hpp"
 #include "krylov_host.hpp"
+#include <complex>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -213,6 +214,40 @@ int HpddmHipHostSelfTest(void)
     P = select_vectors(n, ti, V, sm, 4); // now the pair fits: (Re, Im) = columns 1 and 2 as they are
     for (int i = 0; i < n; ++i)
       if (P[(size_t)i * 4 + 2] != V[(size_t)i * n + 1] || P[(size_t)i * 4 + 3] != V[(size_t)i * n + 2]) return 11;
+    // complex operators: the real-equivalent embedding of set_subdomain_z / set_vectors_z against complex arithmetic
+    {
+      typedef std::complex<double> cd;
+      const int                    nc = 3;
+      const int                    ia[] = {0, 2, 5, 7}, ja[] = {0, 1, 0, 1, 2, 1, 2};
+      const cd                     az[] = {{4.0, 1.0}, {-1.0, 0.5}, {-1.0, 0.5}, {0.3, -3.0}, {2.0, 0.0}, {2.0, 0.0}, {-5.0, 0.2}};
+      const cd                     xz[] = {{1.0, -2.0}, {0.5, 0.25}, {-3.0, 1.0}}, zz[] = {{1.0, 0.5}, {-2.0, 1.0}, {0.0, 3.0}, {1.0, 0.0}, {0.0, -1.0}, {2.0, 2.0}};
+      Schwarz                      S(1, 0, 1);
+      S.set_subdomain_z(0, nc, ia, ja, reinterpret_cast<const double *>(az), false, 0, 0, nullptr, nullptr, nullptr);
+      const SchwarzSub &sub = S.subs[0];
+      if (!S.is_complex || sub.n != 2 * nc) return 12;
+      for (int i = 0; i < nc; ++i) { // (A x)_i in complex arithmetic against rows 2i, 2i+1 of the embedding
+        cd ref = 0.0;
+        for (int p = ia[i]; p < ia[i + 1]; ++p) ref += az[p] * xz[ja[p]];
+        double yr = 0.0, yi = 0.0;
+        for (int p = sub.ia[2 * i]; p < sub.ia[2 * i + 1]; ++p) yr += sub.a[p] * reinterpret_cast<const double *>(xz)[sub.ja[p]];
+        for (int p = sub.ia[2 * i + 1]; p < sub.ia[2 * i + 2]; ++p) yi += sub.a[p] * reinterpret_cast<const double *>(xz)[sub.ja[p]];
+        if (std::abs(yr - ref.real()) > 1e-14 || std::abs(yi - ref.imag()) > 1e-14) return 13;
+        const cd ph(sub.zphase[2 * i], sub.zphase[2 * i + 1]), dg = ph * az[i == 0 ? 0 : (i == 1 ? 3 : 6)];
+        if (std::abs(std::abs(ph) - 1.0) > 1e-15 || std::abs(dg.imag()) > 1e-14 || !(dg.real() > 0.0)) return 14; // unit phase, diagonal real positive
+      }
+      S.set_vectors_z(0, 2, reinterpret_cast<const double *>(zz));
+      if (sub.nu != 4) return 15;
+      for (int k = 0; k < 2; ++k) { // Z_real^T r_real = (Re, Im) of z_k^H r
+        cd ref = 0.0;
+        for (int i = 0; i < nc; ++i) ref += std::conj(zz[k * nc + i]) * xz[i];
+        double re = 0.0, im = 0.0;
+        for (int i = 0; i < 2 * nc; ++i) {
+          re += sub.Z[(size_t)(2 * k) * 2 * nc + i] * reinterpret_cast<const double *>(xz)[i];
+          im += sub.Z[(size_t)(2 * k + 1) * 2 * nc + i] * reinterpret_cast<const double *>(xz)[i];
+        }
+        if (std::abs(re - ref.real()) > 1e-14 || std::abs(im - ref.imag()) > 1e-14) return 16;
+      }
+    }
     return 0;
   } catch (const std::exception &e) {
     last_error() = e.what();

@@ -108,7 +108,8 @@ int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A);
  * (the reference calls LAPACK's hseqr/hsein and ggev, include/HPDDM_GCRODR.hpp:262-303, 384-392). */
 int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V);
 /* Utility: host-only self-test of the small dense helpers behind GCRO-DR / Block GCRO-DR (Householder QR, triangular inverse, ordering
- * of the Ritz values for every -hpddm_recycle_target, selection of the vectors with whole and cut complex pairs): 0 if all pass */
+ * of the Ritz values for every -hpddm_recycle_target, selection of the vectors with whole and cut complex pairs) and of the real-equivalent
+ * embedding of complex subdomain matrices and deflation vectors: 0 if all pass, else the number of the first failing check */
 int HpddmHipHostSelfTest(void);
 /* HpddmSchwarzSolveGEVP (HPDDM.h:107, Schwarz::solveGEVP include/HPDDM_schwarz.hpp:665-715): GenEO coarse space of local
  * subdomain s from its Neumann matrix (same CSR conventions as SetSubdomain): the -hpddm_geneo_nu (default 20) lowest

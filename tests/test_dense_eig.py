@@ -54,5 +54,6 @@ def test_defective_and_zero_matrices():
 
 def test_host_helpers_of_the_recycling_methods():
     """Householder QR, triangular inverse, the six -hpddm_recycle_target orders and the selection of Ritz vectors (whole and cut
-    complex pairs) used by GCRO-DR / Block GCRO-DR: the library's own host self-test"""
+    complex pairs) used by GCRO-DR / Block GCRO-DR, and the real-equivalent embedding of complex matrices and deflation vectors against
+    complex arithmetic: the library's own host self-test"""
     assert _lib.load().HpddmHipHostSelfTest() == 0
