@@ -137,3 +137,19 @@ def test_c_api_shim_exports_the_reference_names():
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     missing = sorted(declared - exported)
     assert not missing, missing
+
+
+def test_plain_c_client_of_the_header(tmp_path):
+    """include/hpddm_hip.h is a C header: examples/c_abi_host.c (C99, -Wall -Werror -pedantic) compiles against it, links with the
+    library and runs the host-only part of the life cycle on CPU, matrix dumps included"""
+    import subprocess
+    from hpddm_amd.matrix_io import read_matrix
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_host.c"),
+                           "-o", exe, "-L" + os.path.join(root, "hpddm_amd"), "-lhpddm_hip", "-lm", "-Wl,-rpath," + os.path.join(root, "hpddm_amd")])
+    res = subprocess.run([exe, str(tmp_path / "dump")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.startswith("ok"), res.stdout + res.stderr
+    for s in range(2):
+        mat = read_matrix(str(tmp_path / f"dump_{s}_2.txt"))
+        assert (mat["n"], mat["nnz"], mat["sym"]) == (6, 16, False) and np.allclose(mat["a"][mat["ja"] == np.repeat(np.arange(6), np.diff(mat["ia"]))], 2.0)
