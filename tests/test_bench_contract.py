@@ -1,0 +1,43 @@
+"""The bench contract on the committed line (profiles/r01_bench_default_stdout.log, printed by `python bench.py` on an MI355X):
+every key the driver reads is there and the derived fields are consistent with each other.  CPU only."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_default_stdout.log")) as fh:
+        rows = [ln for ln in fh if ln.startswith('{"metric"')]
+    assert len(rows) == 1, "bench.py prints ONE JSON line"
+    return json.loads(rows[0])
+
+
+def test_contract_keys_and_consistency():
+    d = _line()
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    assert base["metric"].startswith("RAS-precond applies/sec")          # the headline metric of BASELINE.json ...
+    assert d["metric"] == "ras_precond_applies_per_sec" and d["unit"] == "applies/s"   # ... under the name bench.py prints it
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]          # one apply per step
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["bytes_alg_per_sweep"] / r["seconds_per_sweep"] / 1e9) <= 1e-9 * r["achieved"]
+    n, nnz = d["config"]["n_dof_per_gpu"], d["config"]["nnz_L_per_gpu"]
+    assert r["bytes_alg_per_sweep"] == 2.0 * nnz * 8.0 + 4.0 * n * 8.0            # 2 nnz(L) sizeof(K) + 4 n mu sizeof(K), mu = 1
+    assert r["traffic"] is None or r["traffic"] >= r["bytes_alg_per_sweep"]         # measured HBM bytes cannot be below the algorithmic ones
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0 and "sample" in c
+
+
+def test_traffic_profile_matches_the_line():
+    d = _line()
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        t = json.load(fh)
+    assert t["traffic_bytes"] == (2 * t["FETCH_SIZE_KB_per_sweep"] + t["WRITE_SIZE_KB_per_sweep"]) * 1024
+    assert d["roofline"]["traffic"] == t["traffic_bytes"] and t["algorithmic_bytes"] == d["roofline"]["bytes_alg_per_sweep"]
