@@ -153,3 +153,22 @@ def test_plain_c_client_of_the_header(tmp_path):
     for s in range(2):
         mat = read_matrix(str(tmp_path / f"dump_{s}_2.txt"))
         assert (mat["n"], mat["nnz"], mat["sym"]) == (6, 16, False) and np.allclose(mat["a"][mat["ja"] == np.repeat(np.arange(6), np.diff(mat["ia"]))], 2.0)
+
+
+@pytest.mark.parametrize("problem,limit", [("poisson24", 1.46e6), ("elasticity10", 5.9e5)])
+def test_fill_of_the_ordering_does_not_regress(problem, limit):
+    """nnz(L) is the algorithmic byte count of every SpTRSV: guard the ordering (nested dissection with supervariable
+    compression, multilevel bisection for the denser graphs) against regressions, and against a minimum-degree baseline (SuperLU's
+    MMD on A + A^T, the better of its two orderings on these matrices)."""
+    import scipy.sparse.linalg as spl
+    from hpddm_amd.generate import generate3d, generate_elasticity3d
+    from oracle.ras_oracle import csr_full
+    sd = generate3d(24, 1, 0, sym=True)[0] if problem == "poisson24" else generate_elasticity3d(10, 1, 0)[0]
+    S = hpddm.Subdomain(host_only=1)
+    S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a"], sym=sd["sym"], spd=True)
+    info = S.info()
+    assert info["nnz_L"] <= limit, info
+    assert info["stored"] <= 1.18 * info["nnz_L"]            # padding of the panel layout
+    mmd = spl.splu(csr_full(sd).tocsc(), permc_spec="MMD_AT_PLUS_A").L.nnz
+    assert info["nnz_L"] <= 0.75 * mmd
+    S.destroy()
