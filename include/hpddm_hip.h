@@ -159,9 +159,12 @@ int HpddmHipSchwarzComputeResidual(HpddmHipSchwarz *A, const double *sol, const 
 /* the `norm` argument of Schwarz::computeResidual (include/HPDDM_schwarz.hpp:761, 769-789): 0 = l2 (the function above), 1 = l1
  * (both weighted by the partition of unity), 2 = linfty -- HPDDM_COMPUTE_RESIDUAL_L2 / _L1 / _LINFTY */
 int HpddmHipSchwarzComputeResidualNorm(HpddmHipSchwarz *A, const double *sol, const double *f, double *storage, unsigned short mu, int norm);
-/* HpddmSolve (HPDDM.h:112, IterativeMethod::solve include/HPDDM_iterative.hpp:1013 -> GMRES include/HPDDM_GMRES.hpp:30):
- * returns the iteration count (negative on error); sol holds the initial guess on entry.
- * history, if not NULL, receives up to history_cap residual norms (one per iteration, largest over the rhs). */
+/* HpddmSolve (HPDDM.h:112, IterativeMethod::solve include/HPDDM_iterative.hpp:1013-1111): dispatches on -hpddm_krylov_method like the
+ * reference -- gmres (include/HPDDM_GMRES.hpp:30), bgmres (:159), cg / bcg / bfbcg (include/HPDDM_CG.hpp:31, 169, 342), gcrodr / bgcrodr
+ * (include/HPDDM_GCRODR.hpp:34, 445), richardson (include/HPDDM_iterative.hpp:971), none (:1056) -- with the reference's own hand-overs
+ * (BGMRES -> GMRES on a rank-deficient block, (BF)BCG -> GMRES for a non-symmetric preconditioner and -> CG on a breakdown).
+ * Returns the iteration count (negative on error); sol holds the initial guess on entry.
+ * history, if not NULL, receives up to history_cap residual norms, one per iteration: the value the reference prints at verbosity 3. */
 int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap);
 
 /* ---- several GPUs: one process (rank) per GPU, subdomains sharded by contiguous ranges ----
