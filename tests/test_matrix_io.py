@@ -80,3 +80,29 @@ def test_dump_matrices_option_writes_the_reference_files(tmp_path):
     for r in range(4):
         with open(f"{prefix}_{r}_4.txt", "rb") as new, open(os.path.join(DUMP, f"out_{r}_4.txt"), "rb") as ref:
             assert new.read() == ref.read()
+
+
+@pytest.mark.gpu
+def test_schwarz_py_example_reproduces_the_reference_numbers():
+    """examples/schwarz.py, the counterpart of the reference's own Python example: 19 iterations and the residual the reference
+    prints for -Nx 40 -Ny 40 on 4 subdomains (tests/golden/p40_onelevel), exit status 0; Block GMRES on two random right-hand sides
+    with the deflated coarse correction; the single-subdomain direct solve"""
+    ex = os.path.join(ROOT, "examples", "schwarz.py")
+    res = subprocess.run([sys.executable, ex, "--subdomains", "4", "-Nx", "40", "-Ny", "40", "-hpddm_verbosity=1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "--- residual = 1.428088e-05 / 3.998092e+01" in res.stdout and "GMRES converges after 19 iterations" in res.stdout
+    res = subprocess.run([sys.executable, ex, "--subdomains", "4", "-Nx", "40", "-Ny", "40", "-hpddm_schwarz_coarse_correction", "deflated", "-hpddm_geneo_nu=0",
+                          "-generate_random_rhs", "2", "-hpddm_krylov_method", "bgmres", "-hpddm_verbosity=1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "(rhs #2)" in res.stdout and "BGMRES converges" in res.stdout, res.stdout + res.stderr
+    res = subprocess.run([sys.executable, ex, "--subdomains", "1", "-Nx", "30", "-Ny", "30"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "--- residual" in res.stdout, res.stdout + res.stderr
+
+
+def test_schwarz_py_example_fails_loudly_without_a_gpu():
+    """no CPU fallback behind the example either: without a device the first device call raises"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ex = os.path.join(ROOT, "examples", "schwarz.py")
+    res = subprocess.run([sys.executable, ex, "--subdomains", "4", "-Nx", "20", "-Ny", "20"], capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and "no ROCm-capable device" in res.stderr
