@@ -38,6 +38,7 @@ def _declare(lib):
         "HpddmHipSubdomainSetOption": (I, [c_void_pp, C, D]),
         "HpddmHipSubdomainInfo": (I, [P, P, P]),
         "HpddmHipSubdomainExport": (LL, [P, C, P, LL]),
+        "HpddmHipSubdomainExportView": (P, [P, C, c_ll_p]),
         "HpddmHipSubdomainTimeSolve": (I, [P, I, I, I, P]),
         "HpddmHipSchwarzCreate": (P, [I, I, I]),
         "HpddmHipSchwarzDestroy": (None, [P]),
@@ -72,11 +73,16 @@ def _declare(lib):
         "HpddmHipSchwarzHaloPeers": (I, [P, I, P, P, P]),
         "HpddmHipSchwarzSetTransport": (I, [P, P, P, P, P, P, I]),
         "HpddmHipSchwarzHaloExport": (LL, [P, C, P, LL]),
+        "HpddmHipRcclGetUniqueId": (I, [P]),
+        "HpddmHipSchwarzInitRccl": (I, [P, P, I]),
+        "HpddmHipRcclSelfTest": (I, []),
         "HpddmHipSchwarzApplyDevice": (I, [P, P, P, US]),
         "HpddmHipSchwarzGMVDevice": (I, [P, P, P, US]),
         "HpddmHipSolveDevice": (I, [P, P, P, I, P, I]),
         "HpddmHipSchwarzTime": (I, [P, C, I, I, I, P]),
         "HpddmHipSchwarzStats": (I, [P, P]),
+        "HpddmHipSchwarzRebuildPlan": (I, [P]),
+        "HpddmHipSchwarzLevelTimes": (I, [P, I, I, P, I]),
         "HpddmHipSchwarzGetSubdomain": (P, [P, I]),
     }
     missing = []

@@ -179,10 +179,7 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)k), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * k * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (A.nranks > 1) {
-      HH_CHECK(A.allreduce_fn != nullptr, "several ranks but no all-reduce registered");
-      HH_CHECK(A.allreduce_fn(A.cb_ctx, G.data(), k * mu * mu) == 0, "all-reduce failed");
-    }
+    A.allreduce_host(G.data(), (long long)k * mu * mu);
   };
   // W = beta W + sign * V(0..k) C,  C given as (k*mu) x mu row-major
   auto axpy_blocks = [&](const double *Vb, int k, const std::vector<double> &C, double sign, double beta, double *W) {
@@ -522,7 +519,7 @@ static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), mu * mu) == 0, "all-reduce failed");
+    A.allreduce_host(G.data(), (long long)mu * mu);
   };
   // the reference forms the upper triangle (gemmt "U") and mirrors it
   auto sym_upper = [&](std::vector<double> &G) {
@@ -698,7 +695,7 @@ static int bfbcg_impl(Schwarz &A, const double *b, double *x, double *history, i
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), mu * mu) == 0, "all-reduce failed");
+    A.allreduce_host(G.data(), (long long)mu * mu);
   };
   auto axpy_block = [&](const double *V, const std::vector<double> &C, double sign, double beta, double *W) { // W = beta W + sign V C
     HIP_OK(hipMemcpyAsync(coef_d.p, C.data(), sizeof(double) * mu * mu, hipMemcpyHostToDevice, st));
@@ -974,7 +971,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)nb), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * nb * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (A.nranks > 1) HH_CHECK(A.allreduce_fn != nullptr && A.allreduce_fn(A.cb_ctx, G.data(), nb * mu * mu) == 0, "all-reduce failed");
+    A.allreduce_host(G.data(), (long long)nb * mu * mu);
   };
   auto axpy_blocks = [&](const double *Vb, int nb, const double *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
     if (nb <= 0) {

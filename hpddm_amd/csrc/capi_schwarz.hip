@@ -488,12 +488,30 @@ int HpddmHipSchwarzSetTransport(HpddmHipSchwarz *A, int (*halo)(void *, int), in
 {
   HH_TRY(
     HH_CHECK(A, "null argument");
-    A->op.halo_fn      = halo;
-    A->op.allreduce_fn = allreduce;
-    A->op.cb_ctx       = ctx;
+    A->op.transport    = make_callback_transport(halo, allreduce, ctx);
     A->op.sendbuf      = sendbuf;
     A->op.recvbuf      = recvbuf;
     A->op.halo_mu_cap  = mu_cap;
+    return 0;)
+}
+int HpddmHipRcclGetUniqueId(char *id128)
+{
+  HH_TRY(
+    HH_CHECK(id128, "null argument");
+    rccl_unique_id(id128);
+    return 0;)
+}
+int HpddmHipSchwarzInitRccl(HpddmHipSchwarz *A, const char *id128, int mu_cap)
+{
+  HH_TRY(
+    HH_CHECK(A && id128, "null argument");
+    A->op.use_rccl(id128, mu_cap);
+    return 0;)
+}
+int HpddmHipRcclSelfTest(void)
+{
+  HH_TRY(
+    rccl_self_test();
     return 0;)
 }
 long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity)
@@ -587,6 +605,65 @@ int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup
     HIP_OK(hipEventDestroy(e1));
     *seconds = (double)ms * 1e-3 / reps;
     return 0;)
+}
+
+int HpddmHipSchwarzRebuildPlan(HpddmHipSchwarz *A)
+{
+  HH_TRY(
+    HH_CHECK(A && A->op.factored, "RebuildPlan: callNumfact first");
+    Schwarz &op = A->op;
+    std::vector<const DeviceFactor *> fs;
+    for (auto &S : op.subs) fs.push_back(&S.ls->dev);
+    HIP_OK(hipStreamSynchronize(library_stream()));
+    op.plan.build(fs, library_stream());
+    return 0;)
+}
+
+int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out, int cap)
+{
+  HH_TRY(
+    HH_CHECK(A && mu >= 1 && reps >= 1, "bad argument");
+    Schwarz &op = A->op;
+    op.build_device();
+    op.reserve(mu);
+    hipStream_t         st  = library_stream();
+    const size_t        cnt = (size_t)op.ntot * mu;
+    std::vector<double> ones(cnt, 1.0);
+    DevBuf<double>      in, res;
+    in.upload(ones, st);
+    res.alloc(cnt);
+    SolvePlan &P = op.plan;
+    P.solve(in.p, res.p, mu, st); // warm-up
+    std::vector<double> usec;
+    std::vector<int>    tags;
+    for (int r = 0; r < reps; ++r) {
+      P.profile = true;
+      P.solve(in.p, res.p, mu, st);
+      P.profile = false;
+      HIP_OK(hipStreamSynchronize(st));
+      if (r == 0) {
+        tags.assign(P.prof_tag.begin() + 1, P.prof_tag.end());
+        usec.assign(tags.size(), 0.0);
+      }
+      for (size_t i = 1; i < P.prof_ev.size(); ++i) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, P.prof_ev[i - 1], P.prof_ev[i]));
+        usec[i - 1] += (double)ms * 1e3 / reps;
+      }
+      for (hipEvent_t e : P.prof_ev) (void)hipEventDestroy(e);
+      P.prof_ev.clear();
+      P.prof_tag.clear();
+    }
+    const std::vector<double> lb = P.level_bytes(0);
+    const int n = (int)tags.size();
+    if (out)
+      for (int i = 0; i < n && 3 * i + 2 < cap; ++i) {
+        const int kind = tags[i] / 1000, lev = tags[i] % 1000;
+        out[3 * i] = tags[i];
+        out[3 * i + 1] = usec[i];
+        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : 0.0;
+      }
+    return n;)
 }
 
 int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)

@@ -241,6 +241,20 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
   return -1;
 }
 
+const double *HpddmHipSubdomainExportView(const HpddmHipSubdomain *S, const char *which, long long *count)
+{
+  if (!S || !which || !count) return nullptr;
+  const HostFactor          &h = S->ls.host;
+  const std::string          k(which);
+  const std::vector<double> *v = k == "F" ? &h.F : (k == "G" ? &h.G : (k == "dinv" ? &h.dinv : (k == "Lplain" ? &h.Lplain : (k == "Uplain" ? &h.Uplain : nullptr))));
+  if (!v) {
+    last_error() = "ExportView: unknown array " + k;
+    return nullptr;
+  }
+  *count = (long long)v->size();
+  return v->data();
+}
+
 int HpddmHipSubdomainTimeSolve(HpddmHipSubdomain *S, int mu, int warmup, int reps, double *seconds)
 {
   HH_TRY(

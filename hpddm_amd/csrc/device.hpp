@@ -130,6 +130,13 @@ struct SolvePlan {
   // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b
   void solve(const double *b, double *x, int mu, hipStream_t s);
   int  launches_per_solve = 0;
+  // developer aid (HpddmHipSchwarzLevelTimes): one HIP event after every launch of a solve; tag = kind * 1000 + level,
+  // kind 0 permutation in, 1 gather pass, 2 forward, 3 backward, 4 permutation out
+  bool                    profile = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int>        prof_tag;
+  void                    mark(int tag, hipStream_t s);
+  std::vector<double>     level_bytes(int kind) const; // exact panel entries * 8 per level of the forward (2) / backward (3) sweep
 };
 
 } // namespace hpddm_hip

@@ -172,10 +172,7 @@ struct ZBlocks {
     hipLaunchKernelGGL(k_zgram_reduce, dim3((2 * MU * MU + 63) / 64, (unsigned)k), dim3(64), 0, st, partial.p, nblk, 2 * MU * MU, gram_d.p);
     HIP_OK(hipMemcpyAsync(reinterpret_cast<double *>(G.data()), gram_d.p, sizeof(double) * 2 * k * MU * MU, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (A.nranks > 1) {
-      HH_CHECK(A.allreduce_fn != nullptr, "several ranks but no all-reduce registered");
-      HH_CHECK(A.allreduce_fn(A.cb_ctx, reinterpret_cast<double *>(G.data()), 2 * k * MU * MU) == 0, "all-reduce failed");
-    }
+    A.allreduce_host(reinterpret_cast<double *>(G.data()), 2LL * k * MU * MU);
   }
   // W = beta W + sign * V(0..k) C,  C (k MU) x MU row-major
   void axpy(const double *Vb, int k, const std::vector<cplx> &C, double sign, double beta, double *W)

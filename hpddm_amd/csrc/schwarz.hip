@@ -628,7 +628,7 @@ void Schwarz::build_coarse()
   // global coarse numbering
   std::vector<double> gnu(nglobal, 0.0);
   for (int s = 0; s < nsub; ++s) gnu[first + s] = subs[s].nu;
-  if (nranks > 1) HH_CHECK(allreduce_fn != nullptr && allreduce_fn(cb_ctx, gnu.data(), nglobal) == 0, "BuildCoarseOperator: all-reduce failed");
+  allreduce_host(gnu.data(), nglobal);
   gcoff.assign(nglobal + 1, 0);
   for (int g = 0; g < nglobal; ++g) gcoff[g + 1] = gcoff[g] + (int)std::lround(gnu[g]);
   cdim_g  = gcoff[nglobal];
@@ -656,7 +656,7 @@ void Schwarz::build_coarse()
   // values of the neighbours' T on the shared dofs, for the neighbours owned by other ranks: halo fetch, numax columns
   std::vector<double> remote; // [col][halo_total]
   if (halo_total) {
-    HH_CHECK(halo_fn && sendbuf && recvbuf && halo_mu_cap >= 1, "BuildCoarseOperator: register the halo transport first");
+    HH_CHECK(transport && sendbuf && recvbuf && halo_mu_cap >= 1, "BuildCoarseOperator: register the halo transport first");
     remote.assign((size_t)numax * halo_total, 0.0);
     const int      chunk = halo_mu_cap;
     DevBuf<double> tb;
@@ -670,7 +670,7 @@ void Schwarz::build_coarse()
       tb.upload(host.data(), (size_t)ntot * cc, st);
       hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, tb.p, sendbuf, cc, 0);
       HIP_OK(hipStreamSynchronize(st));
-      HH_CHECK(halo_fn(cb_ctx, cc) == 0, "halo transport failed");
+      transport->halo(peers, sendbuf, recvbuf, cc, st);
       HIP_OK(hipMemcpyAsync(rb.data(), recvbuf, sizeof(double) * halo_total * cc, hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st));
       for (const RemotePair &pr : h_pairs) {
@@ -723,7 +723,7 @@ void Schwarz::build_coarse()
   if (nranks > 1) {
     // rows of the other ranks: one sum over the ranks
     const size_t total = E.size();
-    for (size_t o = 0; o < total; o += (1u << 24)) HH_CHECK(allreduce_fn(cb_ctx, E.data() + o, (int)std::min<size_t>(1u << 24, total - o)) == 0, "BuildCoarseOperator: all-reduce failed");
+    allreduce_host(E.data(), (long long)total);
   }
   // symCoarse == 'S' (real scalars, examples/schwarz.hpp:75-79): the reference assembles only the upper triangle of E
   // (row block of rank i towards neighbours j >= i) and its coarse solver mirrors it.  Same here unless
@@ -798,10 +798,9 @@ void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
   hipStream_t st = library_stream();
   hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
   if (halo_total) {
-    HH_CHECK(halo_fn && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport and buffers first (HpddmHipSchwarzSetTransport)");
+    HH_CHECK(transport && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport first (HpddmHipSchwarzInitRccl or HpddmHipSchwarzSetTransport) with room for this many right-hand sides");
     hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, in, sendbuf, mu, scale ? 1 : 0);
-    HIP_OK(hipStreamSynchronize(st));
-    HH_CHECK(halo_fn(cb_ctx, mu) == 0, "halo transport failed");
+    transport->halo(peers, sendbuf, recvbuf, mu, st); // RCCL: grouped send/recv enqueued on the library stream, no host wait
     hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
   }
 }
@@ -864,14 +863,12 @@ void Schwarz::coarse_solve(const double *uc, double *y, int mu)
   hipStream_t st = library_stream();
   const double *rhs = uc;
   if (nranks > 1) {
-    std::vector<double> loc((size_t)cdim * mu), glob((size_t)cdim_g * mu, 0.0);
-    HIP_OK(hipMemcpyAsync(loc.data(), uc, sizeof(double) * cdim * mu, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    for (int nu = 0; nu < mu; ++nu) std::copy_n(loc.data() + (size_t)nu * cdim, cdim, glob.data() + (size_t)nu * cdim_g + coff_g0);
-    HH_CHECK(allreduce_fn != nullptr && allreduce_fn(cb_ctx, glob.data(), cdim_g * mu) == 0, "coarse gather failed");
+    // zero-padded right-hand side of all the ranks, summed on the device in stream order (no host round trip)
+    HH_CHECK(transport != nullptr, "several ranks but no transport registered");
     ucg_d.alloc((size_t)cdim_g * mu);
-    HIP_OK(hipMemcpyAsync(ucg_d.p, glob.data(), sizeof(double) * cdim_g * mu, hipMemcpyHostToDevice, st));
-    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemsetAsync(ucg_d.p, 0, sizeof(double) * cdim_g * mu, st));
+    HIP_OK(hipMemcpy2DAsync(ucg_d.p + coff_g0, sizeof(double) * cdim_g, uc, sizeof(double) * cdim, sizeof(double) * cdim, (size_t)mu, hipMemcpyDeviceToDevice, st));
+    transport->allreduce_device(ucg_d.p, (long long)cdim_g * mu, st);
     rhs = ucg_d.p;
   }
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, st, Einv_d.p, rhs, y, cdim, cdim_g, mu);
@@ -936,13 +933,33 @@ void Schwarz::wdots(const double *V, long long ldv, int k, const double *w, int 
   hipStream_t st = library_stream();
   hipLaunchKernelGGL(k_wdots, dim3(nb, (unsigned)(k * mu)), dim3(256), 0, st, voff_d.p, n_d.p, nsub, d_d.p, V, ldv, w, mu, partial.p);
   hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((k * mu + 63) / 64)), dim3(64), 0, st, partial.p, nb, outd.p);
+  // MPI_Allreduce of the reference (include/HPDDM_iterative.hpp:518,684; include/HPDDM_GMRES.hpp:71,80): on the device,
+  // in stream order, before the one download the host-side Givens / Cholesky steps need anyway
+  if (nranks > 1) {
+    HH_CHECK(transport != nullptr, "several ranks but no transport registered (HpddmHipSchwarzInitRccl / HpddmHipSchwarzSetTransport)");
+    transport->allreduce_device(outd.p, (long long)k * mu, st);
+  }
   HIP_OK(hipMemcpyAsync(out_host, outd.p, sizeof(double) * k * mu, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
-  // MPI_Allreduce of the reference (include/HPDDM_iterative.hpp:518,684; include/HPDDM_GMRES.hpp:71,80)
-  if (nranks > 1) {
-    HH_CHECK(allreduce_fn != nullptr, "several ranks but no all-reduce registered (HpddmHipSchwarzSetTransport)");
-    HH_CHECK(allreduce_fn(cb_ctx, out_host, k * mu) == 0, "all-reduce failed");
-  }
+}
+
+void Schwarz::allreduce_host(double *buf, long long count)
+{
+  if (nranks <= 1) return;
+  HH_CHECK(transport != nullptr, "several ranks but no transport registered (HpddmHipSchwarzInitRccl / HpddmHipSchwarzSetTransport)");
+  transport->allreduce_host(buf, count, library_stream());
+}
+
+void Schwarz::use_rccl(const char *id128, int mu_cap)
+{
+  HH_CHECK(!rank_first.empty(), "InitRccl: call SetPartition first");
+  build_halo_lists();
+  transport   = make_rccl_transport(id128, nranks, rank);
+  halo_mu_cap = std::max(1, mu_cap);
+  own_send.alloc((size_t)std::max<long long>(1, halo_total) * halo_mu_cap);
+  own_recv.alloc((size_t)std::max<long long>(1, halo_total) * halo_mu_cap);
+  sendbuf = own_send.p;
+  recvbuf = own_recv.p;
 }
 
 // ---- penalised Dirichlet rows (HPDDM_PEN convention of FreeFEM-style inputs) ----

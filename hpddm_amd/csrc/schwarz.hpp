@@ -3,6 +3,7 @@
 // (include/HPDDM_subdomain.hpp) for ALL subdomains mapped to this GPU.
 #pragma once
 #include "local_solver.hpp"
+#include "transport.hpp"
 #include <map>
 #include <memory>
 #include <string>
@@ -47,19 +48,6 @@ struct SchwarzSub {
   std::vector<double> zphase;
 };
 
-// Transport of the cross-GPU part of the halo and of the Krylov reductions.  The library packs / unpacks on the device
-// and calls back into the host framework, which owns the communicator (RCCL through torch.distributed in bench.py).
-//   halo(ctx, mu): send sendbuf[off_p*mu .. (off_p+cnt_p)*mu) to peer p and receive the same range of recvbuf from it,
-//                  for every peer; must return once the receive buffers are complete (0 = ok)
-//   allreduce(ctx, buf, count): in-place sum of `count` host doubles over all ranks
-typedef int (*HaloTransportFn)(void *ctx, int mu);
-typedef int (*AllreduceFn)(void *ctx, double *buf, int count);
-
-struct HaloPeer {
-  int       rank;
-  long long count, off; // entries per right-hand side, offset (entries) of the peer's block in the send/recv buffers
-};
-
 struct Schwarz {
   int nsub, first, nglobal;
   // ---- distribution over GPUs: rank r owns the subdomains [rank_first[r], rank_first[r+1]) ----
@@ -72,11 +60,12 @@ struct Schwarz {
   struct RemotePair { int s, k; long long pos, po, pc; };               // remote pair (local s, map entry k): first position of its block in the recv buffer
   std::vector<RemotePair> h_pairs;
   DevBuf<int>           send_sub_d, send_idx_d, send_po_d, send_pc_d, rx_ptr_d, rx_k_d, rx_po_d, rx_pc_d;
-  double               *sendbuf = nullptr, *recvbuf = nullptr; // device buffers owned by the host framework
+  double               *sendbuf = nullptr, *recvbuf = nullptr; // packed halo, mu_cap * halo_total doubles each: owned by the host framework
+  DevBuf<double>        own_send, own_recv;                     // (callback transport) or by the library (RCCL transport)
   int                   halo_mu_cap = 0;
-  HaloTransportFn       halo_fn = nullptr;
-  AllreduceFn           allreduce_fn = nullptr;
-  void                 *cb_ctx = nullptr;
+  std::unique_ptr<Transport> transport;                         // transport.hpp; null while every neighbour is local
+  void                  allreduce_host(double *buf, long long count);   // sum over the ranks (no-op on one rank)
+  void                  use_rccl(const char *id128, int mu_cap);         // the product path on a multi-GPU node
   bool                  halo_lists_ready = false;
   int                   owner(int gid) const;
   void                  set_partition(int nranks_, int rank_, const int *firsts);

@@ -780,9 +780,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
-  const int  bwd_want    = envi("HPDDM_HIP_BWD_WANT", 768);   // wide panels, backward: split rows until a level fields this many workgroups
+  const int  bwd_want    = envi("HPDDM_HIP_BWD_WANT", 3072);  // wide panels, backward: split rows until a level fields this many workgroups (measured at 129^3 per subdomain: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
-  const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 16);
+  const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   const bool pregather   = envi("HPDDM_HIP_PREGATHER", 1) != 0;
   const int  sort_mode   = envi("HPDDM_HIP_SORT", 1);         // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
   std::vector<long long> wide_cost(nlev, 0);                  // entries of the wide panels per level
@@ -955,6 +955,27 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   HIP_OK(hipStreamSynchronize(s));
 }
 
+void SolvePlan::mark(int tag, hipStream_t s)
+{
+  if (!profile) return;
+  hipEvent_t e;
+  HIP_OK(hipEventCreate(&e));
+  HIP_OK(hipEventRecord(e, s));
+  prof_ev.push_back(e);
+  prof_tag.push_back(tag);
+}
+
+std::vector<double> SolvePlan::level_bytes(int) const
+{
+  std::vector<double> out(nlev, 0.0);
+  for (const DeviceFactor *D : factors)
+    for (idx_t k = 0; k < D->nblk; ++k) {
+      const double w = D->blk_ptr[k + 1] - D->blk_ptr[k], nb = (double)(D->row_ptr[k + 1] - D->row_ptr[k]);
+      out[D->height[k]] += (w * (w + 1) / 2 + nb * w) * 8.0;
+    }
+  return out;
+}
+
 void SolvePlan::drop_graphs()
 {
   for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
@@ -994,11 +1015,15 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
     const int ng = P.gat_end[l] - P.gat_ptr[l];
-    if (ng) hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
+    if (ng) {
+      hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
+      P.mark(1000 + l, s);
+    }
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 512 : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
     if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
     else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
+    if (nb || nw) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
@@ -1006,6 +1031,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
     if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    if (nb || nw) P.mark(3000 + l, s);
   }
 }
 
@@ -1015,7 +1041,9 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
   reserve(mu);
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
   const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
+  mark(-1, s);
   hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+  mark(0, s);
   double *const bp = bperm.p; // private permuted copy: the gather pass updates it in place
   double *const xout = x;
   x                  = xw.p; // the sweeps stay in the permuted numbering; one pass scatters the result at the end
@@ -1056,6 +1084,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     HIP_OK(hipGraphLaunch(it->second, s));
   } else sweeps();
   hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, xout, mu);
+  mark(4000, s);
   HIP_OK(hipGetLastError());
 }
 

@@ -27,6 +27,18 @@ def device_count():
     return _lib.load().HpddmHipDeviceCount()
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (HpddmHipRcclGetUniqueId): 128 bytes, to be made on one rank and handed to the others"""
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.load().HpddmHipRcclGetUniqueId(buf))
+    return buf.raw
+
+
+def rccl_self_test():
+    """one-rank check of the RCCL transport on the library stream (HpddmHipRcclSelfTest)"""
+    check(_lib.load().HpddmHipRcclSelfTest())
+
+
 def require_device():
     """The product has no CPU path: fail loudly when no MI355X is visible."""
     if device_count() < 1:
@@ -101,6 +113,16 @@ class Subdomain:
         if cnt:
             check(self._lib.HpddmHipSubdomainExport(self._h, which.encode(), _dptr(out), cnt))
         return out
+
+    def export_view(self, which):
+        """the double arrays of :meth:`export` without a copy (numpy view of the solver's own storage; keep the solver alive)"""
+        cnt = ctypes.c_longlong()
+        ptr = self._lib.HpddmHipSubdomainExportView(self._h, which.encode(), ctypes.byref(cnt))
+        if not ptr:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        if cnt.value == 0:
+            return np.zeros(0)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(cnt.value,))
 
     def time_solve(self, mu=1, warmup=2, reps=10):
         sec = ctypes.c_double()
@@ -249,10 +271,20 @@ class Schwarz:
         check(self._lib.HpddmHipSchwarzHaloExport(self._h, which.encode(), _dptr(out), cnt))
         return out[:cnt]
 
+    def enable_rccl(self, unique_id, mu_cap=8):
+        """The product transport on a multi-GPU node (one process per GPU): RCCL inside the library.  Halo = one grouped
+        ncclSend / ncclRecv pair per neighbouring GPU, coarse gather and Krylov reductions = ncclAllReduce on device buffers,
+        all enqueued on the library stream (HpddmHipSchwarzInitRccl).  ``unique_id``: the 128 bytes returned by
+        :func:`rccl_unique_id` on ONE rank and handed to the others by the host framework (torch.distributed.broadcast_object_list,
+        MPI_Bcast, a file).  Collective; call it after set_partition / set_subdomain."""
+        assert len(unique_id) == 128
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.HpddmHipSchwarzInitRccl(self._h, buf, int(mu_cap)))
+
     def enable_distributed(self, dist, device, mu_cap=8, host_staging=False):
-        """Register the transport of the cross-GPU halo and of the Krylov reductions on a torch.distributed process
-        group (backend "nccl" = RCCL over xGMI: grouped point-to-point send/recv per neighbouring GPU, the counterpart of
-        the MPI_Isend/Irecv pairs of Subdomain::exchange, and a small all-reduce for the inner products).
+        """Test double of :meth:`enable_rccl` (and the way a host framework that owns its communicator plugs in): registers
+        callbacks on a torch.distributed process group -- grouped point-to-point send/recv per neighbouring GPU, the counterpart
+        of the MPI_Isend/Irecv pairs of Subdomain::exchange, and a small all-reduce for the inner products.
         host_staging=True moves the buffers through host memory (gloo), used to test the path on a single-GPU box."""
         import torch
         peers = self.halo_peers()
@@ -393,6 +425,20 @@ class Schwarz:
         sec = ctypes.c_double()
         check(self._lib.HpddmHipSchwarzTime(self._h, what.encode(), mu, warmup, reps, ctypes.byref(sec)))
         return sec.value
+
+    def rebuild_plan(self):
+        """developer aid: build the SpTRSV level schedule again (its HPDDM_HIP_* knobs are read from the environment)"""
+        check(self._lib.HpddmHipSchwarzRebuildPlan(self._h))
+
+    def level_times(self, mu=1, reps=5):
+        """developer aid: [(kind, level, microseconds, panel bytes)] of every launch of one batched SpTRSV; kind is one of
+        'perm_in', 'gather', 'fwd', 'bwd', 'perm_out'"""
+        out = np.zeros(3 * 512)
+        n = self._lib.HpddmHipSchwarzLevelTimes(self._h, mu, reps, _dptr(out), out.size)
+        if n < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        kinds = ("perm_in", "gather", "fwd", "bwd", "perm_out")
+        return [(kinds[int(out[3 * i]) // 1000], int(out[3 * i]) % 1000, out[3 * i + 1], out[3 * i + 2]) for i in range(n)]
 
     def stats(self):
         st = np.zeros(8)

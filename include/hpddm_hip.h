@@ -59,6 +59,9 @@ int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *t
  * arrays themselves).  which: "perm" "blk_ptr" "ldw" "f_off" "row_ptr" "rows" "height" "u_off" "goff" "gptr" "gsrc"
  * (int64 output), "F" "G" "dinv" "Lplain" "Uplain" (double output).  Returns the element count; out may be NULL. */
 long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which, void *out, long long capacity);
+/* the double arrays of the list above without a copy: pointer into the solver's own storage (valid until the next Numfact /
+ * Destroy), *count = number of doubles; NULL on error.  The plain factor of a 129^3 subdomain is 12 GB. */
+const double *HpddmHipSubdomainExportView(const HpddmHipSubdomain *S, const char *which, long long *count);
 
 /* average duration (seconds) of one batched SpTRSV (forward + backward sweep, all levels) measured with HIP events
  * on the library stream over `reps` repetitions after `warmup` untimed ones; mu right-hand sides of ones */
@@ -173,12 +176,27 @@ int HpddmHipSchwarzSetPartition(HpddmHipSchwarz *A, int nranks, int rank, const 
 /* Halo layout towards the other GPUs: returns the number of peers; peer p exchanges counts[p] values per right-hand
  * side, stored at offset offsets[p]*mu in both buffers (arrays of capacity `cap`, may be NULL to query the count). */
 int HpddmHipSchwarzHaloPeers(HpddmHipSchwarz *A, int cap, int *peer_ranks, long long *counts, long long *offsets);
-/* Transport callbacks (replace MPI_Isend/Irecv of Subdomain::exchange include/HPDDM_subdomain.hpp:119-128 and the
+/* Transport callbacks of a host framework that owns the communicator (the reference's C API shim with MPI, the gloo test double;
+ * the product path on a multi-GPU node is HpddmHipSchwarzInitRccl below).  They replace MPI_Isend/Irecv of Subdomain::exchange include/HPDDM_subdomain.hpp:119-128 and the
  * MPI_Allreduce of the Krylov method): the library packs into sendbuf_dev and unpacks from recvbuf_dev (device
  * buffers of mu_cap * sum(counts) doubles owned by the caller); halo(ctx, mu) must move, for every peer p, the range
  * [offsets[p]*mu, (offsets[p]+counts[p])*mu) of the send buffer into the same range of the peer's receive buffer
  * and return 0 once the receive buffer is complete; allreduce(ctx, buf, n) sums n host doubles over the ranks. */
 int HpddmHipSchwarzSetTransport(HpddmHipSchwarz *A, int (*halo)(void *, int), int (*allreduce)(void *, double *, int), void *ctx, double *sendbuf_dev, double *recvbuf_dev, int mu_cap);
+/* The transport of a multi-GPU node: RCCL over xGMI, inside the library (one process per GPU).  The halo of
+ * Subdomain::exchange (include/HPDDM_subdomain.hpp:115-130: one MPI_Isend / MPI_Irecv pair per neighbour) becomes one grouped
+ * ncclSend / ncclRecv pair per neighbouring GPU, the coarse gather of CoarseOperator::callSolver
+ * (include/HPDDM_coarse_operator_impl.hpp:1694-1720) and the MPI_Allreduce of the Krylov methods (include/HPDDM_iterative.hpp:518,
+ * 684) become ncclAllReduce on device buffers -- all enqueued on the library stream, no host synchronisation inside an apply.
+ * librccl.so is bound at run time (HPDDM_HIP_RCCL_LIB overrides the name).  Usage: one rank calls HpddmHipRcclGetUniqueId and hands
+ * the 128 bytes to the others by whatever means the host framework has (MPI_Bcast, a file, torch.distributed); every rank then calls
+ * HpddmHipSchwarzInitRccl after SetPartition and SetSubdomain (collective; buffers for mu_cap right-hand sides per exchange are
+ * allocated by the library).  It replaces HpddmHipSchwarzSetTransport. */
+int HpddmHipRcclGetUniqueId(char *id128);
+int HpddmHipSchwarzInitRccl(HpddmHipSchwarz *A, const char *id128, int mu_cap);
+/* what a single GPU can check of that path: binding, a one-rank communicator, a grouped send/recv pair to the rank itself and an
+ * all-reduce, ordered on the library stream; 0 = ok */
+int HpddmHipRcclSelfTest(void);
 /* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc" */
 long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity);
 
@@ -191,6 +209,13 @@ int HpddmHipSynchronize(void);
 /* Measurement hooks used by bench.py (HIP events on the library stream; vectors resident in HBM):
  * what = "apply" | "solve" (local SpTRSV only) | "gmv" | "deflation" | "exchange"; seconds = average per call */
 int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup, int reps, double *seconds);
+/* Developer aids of the SpTRSV plan.  RebuildPlan: build the level schedule again from the resident factors (the plan
+ * builder reads its HPDDM_HIP_* knobs from the environment).  LevelTimes: duration of every launch of one batched SpTRSV
+ * (HIP events between the launches, averaged over reps): out[3i] = tag (kind * 1000 + level; kind 0 permutation in, 1 gather
+ * pass, 2 forward, 3 backward, 4 permutation out), out[3i+1] = microseconds, out[3i+2] = panel bytes the launch streams
+ * (exact stored entries * 8); returns the number of launches. */
+int HpddmHipSchwarzRebuildPlan(HpddmHipSchwarz *A);
+int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out, int cap);
 /* stats[0..7] = sum n, sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at mu=1
  *               (2*nnz(L)*8 + 4*n*8), #levels, kernel launches per SpTRSV, sum nnz(A), coarse dimension */
 int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats);

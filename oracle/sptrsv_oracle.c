@@ -103,4 +103,199 @@ double oracle_sptrsv_batch(int nsub, const oracle_factor *fs, const double *cons
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The same substitution on ALL host cores: level-scheduled over the assembly tree (height[k] = level of supernode k, as
+ * exported by the product), every subdomain at once.  A level with many supernodes is a parallel loop over them (one thread
+ * per supernode, contributions to ancestors' rows through atomic adds); the few large supernodes near the root are taken one
+ * after the other by the whole team: triangular solve by blocks of TB columns (the diagonal block by one thread, the rows
+ * under it in parallel), then the rows below in parallel.  This is the shape of a threaded MUMPS / PARDISO solve phase
+ * (tree parallelism at the bottom, node parallelism at the top); it is the stronger of the two CPU baselines bench.py
+ * reports.  Results equal solve_one's up to the summation order of the atomic adds.
+ * ------------------------------------------------------------------------------------------------------------------- */
+#define TB 96
+typedef struct { int s; ll k; ll cost; } lv_item;
+static int cmp_item(const void *a, const void *b) { const ll x = ((const lv_item *)a)->cost, y = ((const lv_item *)b)->cost; return x < y ? 1 : (x > y ? -1 : 0); }
+
+static void fwd_small(const oracle_factor *f, ll k, double *y)
+{
+  const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+  const double *P  = f->L + f->f_off[k];
+  const ll     *r  = f->rows + f->row_ptr[k];
+  for (ll i = 0; i < w; ++i) {
+    const double *row = P + i * ld;
+    double        s   = y[c0 + i];
+    for (ll j = 0; j < i; ++j) s -= row[j] * y[c0 + j];
+    y[c0 + i] = s / row[i];
+  }
+  for (ll i = 0; i < nb; ++i) {
+    const double *row = P + (w + i) * ld;
+    double        s   = 0.0;
+    for (ll j = 0; j < w; ++j) s += row[j] * y[c0 + j];
+#pragma omp atomic
+    y[r[i]] -= s;
+  }
+}
+static void bwd_small(const oracle_factor *f, ll k, double *y, double *t)
+{
+  const double *B  = f->kind == 2 ? f->U : f->L;
+  const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+  const double *P  = B + f->f_off[k];
+  const ll     *r  = f->rows + f->row_ptr[k];
+  for (ll j = 0; j < w; ++j) t[j] = y[c0 + j];
+  for (ll i = 0; i < nb; ++i) {
+    const double *row = P + (w + i) * ld;
+    const double  xi  = y[r[i]];
+    for (ll j = 0; j < w; ++j) t[j] -= row[j] * xi;
+  }
+  for (ll i = w - 1; i >= 0; --i) {
+    const double *row = P + i * ld;
+    const double  xi  = t[i] / row[i];
+    y[c0 + i]         = xi;
+    for (ll j = 0; j < i; ++j) t[j] -= row[j] * xi;
+  }
+}
+/* whole team on one supernode; called from inside a parallel region by every thread */
+static void fwd_team(const oracle_factor *f, ll k, double *y)
+{
+  const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+  const double *P  = f->L + f->f_off[k];
+  const ll     *r  = f->rows + f->row_ptr[k];
+  for (ll b0 = 0; b0 < w; b0 += TB) {
+    const ll b1 = b0 + TB < w ? b0 + TB : w;
+#pragma omp single
+    for (ll i = b0; i < b1; ++i) {
+      const double *row = P + i * ld;
+      double        s   = y[c0 + i];
+      for (ll j = b0; j < i; ++j) s -= row[j] * y[c0 + j];
+      y[c0 + i] = s / row[i];
+    } /* implicit barrier */
+#pragma omp for schedule(static)
+    for (ll i = b1; i < w; ++i) {
+      const double *row = P + i * ld;
+      double        s   = 0.0;
+      for (ll j = b0; j < b1; ++j) s += row[j] * y[c0 + j];
+      y[c0 + i] -= s;
+    } /* implicit barrier */
+  }
+#pragma omp for schedule(static)
+  for (ll i = 0; i < nb; ++i) {
+    const double *row = P + (w + i) * ld;
+    double        s   = 0.0;
+    for (ll j = 0; j < w; ++j) s += row[j] * y[c0 + j];
+    y[r[i]] -= s; /* one supernode at a time: its rows are distinct */
+  }
+}
+static void bwd_team(const oracle_factor *f, ll k, double *y, double *t)
+{
+  const double *B  = f->kind == 2 ? f->U : f->L;
+  const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+  const double *P  = B + f->f_off[k];
+  const ll     *r  = f->rows + f->row_ptr[k];
+  /* t = y_J - L_below^T x_below: every thread owns a range of columns */
+#pragma omp for schedule(static)
+  for (ll jb = 0; jb < w; jb += 64) {
+    const ll je = jb + 64 < w ? jb + 64 : w;
+    for (ll j = jb; j < je; ++j) t[j] = y[c0 + j];
+    for (ll i = 0; i < nb; ++i) {
+      const double *row = P + (w + i) * ld;
+      const double  xi  = y[r[i]];
+      for (ll j = jb; j < je; ++j) t[j] -= row[j] * xi;
+    }
+  }
+  /* L_JJ^T x = t by blocks from the bottom: diagonal block by one thread, then its columns' effect on the blocks above */
+  for (ll b1 = w; b1 > 0; b1 -= TB) {
+    const ll b0 = b1 > TB ? b1 - TB : 0;
+#pragma omp single
+    for (ll i = b1 - 1; i >= b0; --i) {
+      const double *row = P + i * ld;
+      const double  xi  = t[i] / row[i];
+      y[c0 + i]         = xi;
+      for (ll j = b0; j < i; ++j) t[j] -= row[j] * xi;
+    }
+#pragma omp for schedule(static)
+    for (ll jb = 0; jb < b0; jb += 64) {
+      const ll je = jb + 64 < b0 ? jb + 64 : b0;
+      for (ll i = b0; i < b1; ++i) {
+        const double *row = P + i * ld;
+        const double  xi  = y[c0 + i];
+        for (ll j = jb; j < je; ++j) t[j] -= row[j] * xi;
+      }
+    }
+  }
+}
+
+/* height[s]: level of every supernode of subdomain s; returns wall seconds of `reps` x (solve every subdomain once), one right-hand side */
+double oracle_sptrsv_batch_levels(int nsub, const oracle_factor *fs, const ll *const *height, const double *const *b, double *const *x, int reps, int threads)
+{
+  ll nlev = 0, total = 0, wmax = 1;
+  for (int s = 0; s < nsub; ++s) {
+    total += fs[s].nblk;
+    for (ll k = 0; k < fs[s].nblk; ++k) {
+      if (height[s][k] + 1 > nlev) nlev = height[s][k] + 1;
+      if (fs[s].blk_ptr[k + 1] - fs[s].blk_ptr[k] > wmax) wmax = fs[s].blk_ptr[k + 1] - fs[s].blk_ptr[k];
+    }
+  }
+  lv_item *items = (lv_item *)malloc(sizeof(lv_item) * (size_t)total);
+  ll      *lptr  = (ll *)calloc((size_t)nlev + 1, sizeof(ll));
+  for (int s = 0; s < nsub; ++s)
+    for (ll k = 0; k < fs[s].nblk; ++k) lptr[height[s][k] + 1]++;
+  for (ll l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+  ll *fill = (ll *)malloc(sizeof(ll) * (size_t)nlev);
+  for (ll l = 0; l < nlev; ++l) fill[l] = lptr[l];
+  for (int s = 0; s < nsub; ++s)
+    for (ll k = 0; k < fs[s].nblk; ++k) {
+      const ll w = fs[s].blk_ptr[k + 1] - fs[s].blk_ptr[k], nb = fs[s].row_ptr[k + 1] - fs[s].row_ptr[k];
+      items[fill[height[s][k]]++] = (lv_item){s, k, w * (w + 1) / 2 + nb * w};
+    }
+  for (ll l = 0; l < nlev; ++l) qsort(items + lptr[l], (size_t)(lptr[l + 1] - lptr[l]), sizeof(lv_item), cmp_item);
+  double **y = (double **)malloc(sizeof(double *) * (size_t)nsub);
+  for (int s = 0; s < nsub; ++s) y[s] = (double *)malloc(sizeof(double) * (size_t)fs[s].n);
+  double *tshared = (double *)malloc(sizeof(double) * (size_t)wmax);
+  const ll BIG = 1 << 18; /* entries: above this a supernode is worth the whole team */
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma omp parallel num_threads(threads)
+    {
+      double *tl = (double *)malloc(sizeof(double) * (size_t)wmax);
+      for (int s = 0; s < nsub; ++s) {
+#pragma omp for schedule(static) nowait
+        for (ll i = 0; i < fs[s].n; ++i) y[s][i] = b[s][fs[s].perm[i]];
+      }
+#pragma omp barrier
+      for (ll l = 0; l < nlev; ++l) {
+        ll nbig = 0;
+        while (lptr[l] + nbig < lptr[l + 1] && items[lptr[l] + nbig].cost >= BIG) ++nbig;
+        for (ll q = lptr[l]; q < lptr[l] + nbig; ++q) fwd_team(&fs[items[q].s], items[q].k, y[items[q].s]);
+#pragma omp for schedule(dynamic, 4)
+        for (ll q = lptr[l] + nbig; q < lptr[l + 1]; ++q) fwd_small(&fs[items[q].s], items[q].k, y[items[q].s]);
+      }
+      for (int s = 0; s < nsub; ++s)
+        if (fs[s].kind == 1) {
+#pragma omp for schedule(static)
+          for (ll i = 0; i < fs[s].n; ++i) y[s][i] *= fs[s].dinv[i];
+        }
+      for (ll l = nlev - 1; l >= 0; --l) {
+        ll nbig = 0;
+        while (lptr[l] + nbig < lptr[l + 1] && items[lptr[l] + nbig].cost >= BIG) ++nbig;
+        for (ll q = lptr[l]; q < lptr[l] + nbig; ++q) {
+          bwd_team(&fs[items[q].s], items[q].k, y[items[q].s], tshared);
+#pragma omp barrier
+        }
+#pragma omp for schedule(dynamic, 4)
+        for (ll q = lptr[l] + nbig; q < lptr[l + 1]; ++q) bwd_small(&fs[items[q].s], items[q].k, y[items[q].s], tl);
+      }
+      for (int s = 0; s < nsub; ++s) {
+#pragma omp for schedule(static) nowait
+        for (ll i = 0; i < fs[s].n; ++i) x[s][fs[s].perm[i]] = y[s][i];
+      }
+      free(tl);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (int s = 0; s < nsub; ++s) free(y[s]);
+  free(y), free(tshared), free(items), free(lptr), free(fill);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 unsigned long oracle_factor_sizeof(void) { return sizeof(oracle_factor); }

@@ -21,6 +21,7 @@ def lib():
             raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         _lib = ctypes.CDLL(path)
         _lib.oracle_sptrsv_batch.restype = ctypes.c_double
+        _lib.oracle_sptrsv_batch_levels.restype = ctypes.c_double
         assert _lib.oracle_factor_sizeof() == ctypes.sizeof(_Factor)
     return _lib
 
@@ -31,10 +32,12 @@ class PlainFactor:
     def __init__(self, sub):
         info = sub.info()
         self.n, self.kind = info["n"], info["kind"]
-        self.arr = {k: sub.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows")}
-        self.arr["L"] = sub.export("Lplain")
-        self.arr["U"] = sub.export("Uplain") if self.kind == 2 else np.zeros(1)
-        self.arr["dinv"] = sub.export("dinv") if self.kind == 1 else np.zeros(1)
+        self.arr = {k: sub.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height")}
+        view = getattr(sub, "export_view", None) or sub.export   # no copy of a multi-GB factor when the binding offers a view
+        self.sub = sub                                            # the views point into the solver's storage
+        self.arr["L"] = view("Lplain")
+        self.arr["U"] = view("Uplain") if self.kind == 2 else np.zeros(1)
+        self.arr["dinv"] = view("dinv") if self.kind == 1 else np.zeros(1)
         assert self.arr["L"].size > 0, "numfact was not run with keep_plain=1"
         self.nnz_bytes = self.arr["L"].nbytes
 
@@ -67,4 +70,18 @@ def time_batch(factors, bs, reps, threads):
     bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
     sec = lib().oracle_sptrsv_batch(n, arr, bp, xp, mu, reps, threads)
+    return sec, xs
+
+
+def time_batch_levels(factors, bs, reps, threads):
+    """the same on `threads` cores: level-scheduled over the assembly tree, all subdomains at once (one right-hand side)"""
+    n = len(factors)
+    arr = (_Factor * n)(*[f.struct() for f in factors])
+    bs = [np.ascontiguousarray(b, dtype=np.float64) for b in bs]
+    assert all(b.ndim == 1 for b in bs)
+    xs = [np.empty_like(b) for b in bs]
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
+    hp = (ctypes.c_void_p * n)(*[f.arr["height"].ctypes.data for f in factors])
+    sec = lib().oracle_sptrsv_batch_levels(n, arr, hp, bp, xp, reps, threads)
     return sec, xs

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""developer aid: factorise the bench operator ONCE, then rebuild the SpTRSV level schedule under several settings of the
+plan-builder knobs (HPDDM_HIP_* environment variables) and time the batched sweep pair for each.
+usage: sweep_plan.py [--grid 256] [--levels] [--mu 1] "K1=v K2=v" "K1=w" ...      ("" = defaults)"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--mu", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--levels", action="store_true", help="print the per-launch table for every setting")
+    ap.add_argument("cfgs", nargs="*", default=[""])
+    args = ap.parse_args()
+    from hpddm_amd import hpddm
+    from hpddm_amd.generate import generate3d
+    hpddm.require_device()
+    t0 = time.time()
+    subs = generate3d(args.grid, 8, overlap=1, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    A.call_numfact()
+    st = A.stats()
+    print(f"setup {time.time() - t0:.1f} s, nnz(L) {st['nnz_L']:.4g}, levels {int(st['levels'])}", flush=True)
+    bytes_alg = 2.0 * st["nnz_L"] * 8.0 + 4.0 * st["n"] * args.mu * 8.0
+    touched = set()
+    for cfg in args.cfgs:
+        for k in touched:
+            os.environ.pop(k, None)
+        for kv in cfg.split():
+            k, v = kv.split("=")
+            os.environ[k] = v
+            touched.add(k)
+        A.rebuild_plan()
+        t = A.time("solve", mu=args.mu, warmup=2, reps=args.reps)
+        print(f"== [{cfg}]  sptrsv {t * 1e3:.3f} ms  frac {bytes_alg / t / 8e12:.4f}  launches {int(A.stats()['launches'])}", flush=True)
+        if args.levels:
+            tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
+            for kind, lev, us, nbytes in A.level_times(mu=args.mu, reps=3):
+                extra = f"  {nbytes / 1e6:9.1f} MB {nbytes / us / 1e3:8.1f} GB/s" if nbytes else ""
+                print(f"   {kind:8s} level {lev:2d} {us:9.1f} us{extra}")
+                if kind in tot:
+                    tot[kind][0] += us
+                    tot[kind][1] += nbytes
+            for k, (us, nb) in tot.items():
+                print(f"   {k} total {us:9.1f} us {nb / 1e6:9.1f} MB {nb / us / 1e3:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

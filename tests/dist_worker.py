@@ -7,6 +7,9 @@ exchange.  This pins the ordering contract of the N>1 path without a GPU.
 
 mode "gpu": all ranks share GPU 0 (host-staged gloo transport).  apply / GMV / GMRES of the sharded operator are
 compared with the oracle on the global problem.
+
+mode "rccl": one GPU per rank, the library's own RCCL transport (HpddmHipSchwarzInitRccl; the ncclUniqueId travels over the
+gloo group), same checks as "gpu".  Needs as many GPUs as ranks.
 """
 import os
 import sys
@@ -87,9 +90,18 @@ def main():
         assert err < 1e-14, err
     else:
         hpddm.require_device()
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(dev)
-        A.enable_distributed(dist, dev, mu_cap=4, host_staging=True)
+        if mode == "rccl":
+            from hpddm_amd import _lib
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            assert hpddm.device_count() > local, "mode rccl needs one GPU per rank"
+            _lib.check(_lib.load().HpddmHipSetDevice(local))
+            box = [hpddm.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            A.enable_rccl(box[0], mu_cap=4)
+        else:
+            dev = torch.device("cuda", 0)
+            torch.cuda.set_device(dev)
+            A.enable_distributed(dist, dev, mu_cap=4, host_staging=True)
         A.call_numfact()
         orc.numfact()
         x = xg[firsts[rank]:firsts[rank + 1]]

@@ -1,6 +1,8 @@
 """The N>1 path (subdomains sharded over several GPUs) with world_size-2/3 multi-process runs:
 CPU: the library's halo lists under a real gloo transport against the oracle's global exchange;
-GPU: the full sharded operator (two processes sharing GPU 0, host-staged transport) against the oracle."""
+GPU: the full sharded operator (two processes sharing GPU 0, host-staged transport) against the oracle; with one GPU per rank
+(skipped on a single-GPU box) the same checks through the library's own RCCL transport; on one GPU the RCCL binding itself
+(one-rank communicator, grouped send/recv to self, all-reduce on the library stream)."""
 import os
 import subprocess
 import sys
@@ -27,3 +29,19 @@ def test_halo_lists_gloo_cpu(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_operator_shared_gpu(world):
     _launch("gpu", world, 29630 + world)
+
+
+@pytest.mark.gpu
+def test_rccl_binding_one_rank():
+    from hpddm_amd import hpddm
+    hpddm.require_device()
+    hpddm.rccl_self_test()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_operator_native_rccl(world):
+    from hpddm_amd import hpddm
+    if hpddm.device_count() < world:
+        pytest.skip(f"native RCCL transport across {world} ranks needs {world} GPUs (one process per GPU)")
+    _launch("rccl", world, 29640 + world)

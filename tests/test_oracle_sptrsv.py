@@ -37,4 +37,28 @@ def test_cpu_substitution_matches_superlu(kind):
     assert np.abs(x - ref).max() <= 1e-11 * np.abs(ref).max()
     sec, xs = sptrsv_oracle.time_batch([pf, pf], [b, b], reps=2, threads=2)
     assert np.abs(xs[0] - ref).max() <= 1e-11 * np.abs(ref).max() and sec > 0
+    # the all-core variant (level-scheduled over the assembly tree, atomic extend-adds): same solution
+    sec, xl = sptrsv_oracle.time_batch_levels([pf, pf], [b[:, 0].copy(), b[:, 1].copy()], reps=2, threads=4)
+    assert np.abs(xl[0] - ref[:, 0]).max() <= 1e-11 * np.abs(ref).max() and np.abs(xl[1] - ref[:, 1]).max() <= 1e-11 * np.abs(ref).max() and sec > 0
+    S.destroy()
+
+
+def test_level_parallel_substitution_large_supernodes():
+    """a size where the team kernels (supernodes of more than 2^18 entries) of the all-core baseline are exercised"""
+    A = _poisson3d(40)
+    n = A.shape[0]
+    Ain = sp.tril(A).tocsr()
+    Ain.sort_indices()
+    S = hpddm.Subdomain(host_only=1, keep_plain=1)
+    S.numfact(n, Ain.indptr, Ain.indices, Ain.data, sym=True, spd=True)
+    pf = sptrsv_oracle.PlainFactor(S)
+    w = np.diff(pf.arr["blk_ptr"])
+    h = w + np.diff(pf.arr["row_ptr"])
+    assert (w * (w + 1) // 2 + (h - w) * w).max() >= 1 << 18
+    b = np.random.default_rng(3).random(n)
+    ref = pf.solve(b)
+    assert np.abs(A @ ref - b).max() < 1e-9
+    for threads in (1, 3, 8):
+        _, xl = sptrsv_oracle.time_batch_levels([pf], [b], reps=1, threads=threads)
+        assert np.abs(xl[0] - ref).max() <= 1e-12 * np.abs(ref).max()
     S.destroy()
