@@ -385,21 +385,33 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         return tsolve / reps, reps, xs
 
     ta, ra, xs = sample(lambda r: sptrsv_oracle.time_batch(factors, f, reps=r, threads=threads))
-    tb, rb, xl = sample(lambda r: sptrsv_oracle.time_batch_levels(factors, f, reps=r, threads=ncores))
+    # (b): the team size that is fastest on this box (barrier cost grows with the team; SMT siblings and container CPU quotas
+    # make "every logical core" the wrong choice more often than not): double it while it pays
+    nthr, best_probe = min(16, ncores), None
+    cand = nthr
+    while cand <= ncores:
+        sptrsv_oracle.time_batch_levels(factors, f, reps=1, threads=cand)
+        sec, _ = sptrsv_oracle.time_batch_levels(factors, f, reps=1, threads=cand)
+        if best_probe is not None and sec > 0.95 * best_probe:
+            break
+        nthr, best_probe = cand, sec
+        cand *= 2
+    tb, rb, xl = sample(lambda r: sptrsv_oracle.time_batch_levels(factors, f, reps=r, threads=nthr))
     agree = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xl))
     t1 = time.perf_counter()
     for _ in range(3):
         orc.exchange(xs)
     tex = (time.perf_counter() - t1) / 3
-    best, cores = (ta, threads) if ta <= tb else (tb, ncores)
+    best, cores = (ta, threads) if ta <= tb else (tb, nthr)
     per_apply = best + tex
     return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "kind": "port",
             "sample": f"one-level apply of the same {nsub}-subdomain operator (all {nsub} local substitutions + numpy halo sum, {tex * 1e3:.1f} ms): "
                       f"(a) one thread per subdomain on {threads} threads, {ra} applies, {ta * 1e3:.1f} ms each; "
-                      f"(b) level-parallel on all {ncores} cores, {rb} applies, {tb * 1e3:.1f} ms each; value = the faster; the two agree to {agree:.1e}",
+                      f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms each; value = the faster; "
+                      f"the two agree to {agree:.1e}",
             "seconds_per_apply": per_apply, "host_cores": ncores,
             "one_thread_per_subdomain": {"threads": threads, "substitution_ms": ta * 1e3, "applies_per_sec": 1.0 / (ta + tex)},
-            "level_parallel_all_cores": {"threads": ncores, "substitution_ms": tb * 1e3, "applies_per_sec": 1.0 / (tb + tex)},
+            "level_parallel": {"threads": nthr, "substitution_ms": tb * 1e3, "applies_per_sec": 1.0 / (tb + tex)},
             "note": "the CPU leg is the ONE-level apply (substitutions + halo); the GPU headline above additionally carries the coarse correction when two-level",
             "gpu_one_level_over_cpu": gpu_value / (1.0 / per_apply)}
 

@@ -612,10 +612,7 @@ int HpddmHipSchwarzRebuildPlan(HpddmHipSchwarz *A)
   HH_TRY(
     HH_CHECK(A && A->op.factored, "RebuildPlan: callNumfact first");
     Schwarz &op = A->op;
-    std::vector<const DeviceFactor *> fs;
-    for (auto &S : op.subs) fs.push_back(&S.ls->dev);
-    HIP_OK(hipStreamSynchronize(library_stream()));
-    op.plan.build(fs, library_stream());
+    op.build_plans();
     return 0;)
 }
 
@@ -632,6 +629,7 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
     DevBuf<double>      in, res;
     in.upload(ones, st);
     res.alloc(cnt);
+    HH_CHECK(op.more_plans.empty(), "LevelTimes: one group of subdomains only (HPDDM_HIP_STREAMS=1, then RebuildPlan)");
     SolvePlan &P = op.plan;
     P.solve(in.p, res.p, mu, st); // warm-up
     std::vector<double> usec;
@@ -661,7 +659,7 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
         const int kind = tags[i] / 1000, lev = tags[i] % 1000;
         out[3 * i] = tags[i];
         out[3 * i + 1] = usec[i];
-        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : 0.0;
+        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : ((kind == 5 || kind == 6) ? P.chain_bytes : 0.0);
       }
     return n;)
 }
@@ -683,6 +681,7 @@ int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
     stats[3] = 2.0 * nnzl * 8.0 + 4.0 * n * 8.0;
     stats[4] = op.plan.nlev;
     stats[5] = op.plan.launches_per_solve;
+    for (const auto &P : op.more_plans) stats[5] += P->launches_per_solve;
     stats[6] = (double)op.nnzA;
     stats[7] = op.cdim;
     return 0;)

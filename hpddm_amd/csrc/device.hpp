@@ -61,6 +61,8 @@ struct SnDesc {
   int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
   const double *FT;    // narrow panels: the forward panel once more, transposed (w x ldh, row-major), or nullptr
   int           ldh;   // its leading dimension (h rounded up to 2)
+  const int    *src4;  // small narrow panels with children: the gather lists once more as 4 fixed slots per entry of the front
+                       // (h x 4 sources inside the update pool, -1 = none), one 16-byte load per entry; or nullptr
 };
 
 struct Tile {
@@ -88,6 +90,10 @@ struct DeviceFactor {
   std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
   std::vector<char>    has_src;
   std::vector<int64_t> f_off, row_ptr, goff;
+  std::vector<idx_t>   parent;               // assembly tree (plan builder: bottom subtrees taken by one wavefront each)
+  DevBuf<int>          src4;                 // fixed-slot gather lists of the chainable supernodes
+  std::vector<int64_t> s4_off;               // per supernode offset into src4 (-1: none; leaves need none)
+  std::vector<char>    chainable;            // narrow, at most CHAIN_MAX_H rows, at most 4 sources per entry
   void upload(const HostFactor &hf, hipStream_t s);
 };
 
@@ -104,6 +110,13 @@ struct SolvePlan {
   DevBuf<Tile>     tiles;
   std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
+  // bottom subtrees ("chains"): every wavefront walks the tiles of one small subtree in dependency order -- forward: children
+  // before parents, ahead of the level launches; backward: parents first, after them -- with the first panel rows of the next
+  // tile in flight while the current one is reduced and stored.  chain_ptr[kd][c] .. [c+1] = tiles of chain c.
+  DevBuf<int>      chain_ptr[2];
+  int              nchains = 0, chain_lds[2] = {0, 0};
+  long long        chain_off[2] = {0, 0};   // first tile of the forward / backward chains in `tiles`
+  double           chain_bytes = 0;         // panel bytes (stored entries * 8) the chain launches stream per direction
   // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
   // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
   std::vector<int> gat_ptr, gat_end;
@@ -130,13 +143,15 @@ struct SolvePlan {
   // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b
   void solve(const double *b, double *x, int mu, hipStream_t s);
   int  launches_per_solve = 0;
+  int  groups = 1; // this plan sweeps one of `groups` sets of subdomains that share the GPU (targets of the plan builder scale with it)
   // developer aid (HpddmHipSchwarzLevelTimes): one HIP event after every launch of a solve; tag = kind * 1000 + level,
-  // kind 0 permutation in, 1 gather pass, 2 forward, 3 backward, 4 permutation out
+  // kind 0 permutation in, 1 gather pass, 2 forward, 3 backward, 4 permutation out, 5 / 6 forward / backward chain launch
   bool                    profile = false;
   std::vector<hipEvent_t> prof_ev;
   std::vector<int>        prof_tag;
   void                    mark(int tag, hipStream_t s);
-  std::vector<double>     level_bytes(int kind) const; // exact panel entries * 8 per level of the forward (2) / backward (3) sweep
+  std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch (chains excluded)
+  std::vector<double>     level_bytes(int kind) const;
 };
 
 } // namespace hpddm_hip

@@ -94,6 +94,17 @@ struct Schwarz {
   long long              nnzA = 0;
   DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
   SolvePlan              plan;
+  // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
+  // of a launch, ramp of the next) the others keep the memory system busy.  plan = the first group (on the library stream),
+  // more_plans[g] = group g + 1 on more_streams[g]; group_first[g] = first subdomain of group g.  HPDDM_HIP_STREAMS=1: one
+  // group.  Results do not depend on the grouping (subdomains are independent).
+  std::vector<std::unique_ptr<SolvePlan>> more_plans;
+  std::vector<hipStream_t>                more_streams;
+  std::vector<hipEvent_t>                 ev_join;
+  hipEvent_t                              ev_fork = nullptr;
+  std::vector<int>                        group_first; // ngroups + 1
+  void                   build_plans();                                            // from the resident factors of the subdomains
+  void                   batched_sptrsv(const double *in, double *out, int mu);    // all local solves, both groups
   // coarse level
   int                 cdim = 0, cdim_g = 0, coff_g0 = 0; // local / global coarse dimension, global offset of the local block
   std::vector<int>    coff; // nsub+1

@@ -23,6 +23,7 @@ namespace hpddm_hip {
 static constexpr int WG_THREADS  = 256;
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
+static constexpr int CHAIN_MAX_H = 160;  // supernodes of the bottom subtrees one wavefront walks on its own (chain kernels): at most this many rows
 
 // Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
 // tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
@@ -30,9 +31,12 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef const dbl2 __attribute__((address_space(1)))   *gcd2_t;
 typedef const int __attribute__((address_space(1)))    *gci_t;
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef const int4v __attribute__((address_space(1)))  *gci4_t;
 struct SnView {
   gcd_t     F, G, dinv, FT;
   gci_t     rows, gptr, gsrc;
+  gci4_t    src4;
   long long voff, uoff;
   int       n, usize, c0, w, nb, ldw, u_off, has_src, ldh;
 };
@@ -42,6 +46,7 @@ __device__ static inline SnView view(const SnDesc &d)
   v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT;
   v.ldh = d.ldh;
   v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
+  v.src4 = (gci4_t)d.src4;
   v.voff = d.voff, v.uoff = d.uoff;
   v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.u_off = d.u_off, v.has_src = d.has_src;
   return v;
@@ -71,6 +76,15 @@ __device__ static inline void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The same without draining the global loads in flight (the workgroup-scope fences above wait for vmcnt(0) as well): the LDS
+// instructions of one wavefront execute in program order, the counter wait makes the writes land, the barrier keeps the
+// compiler from moving LDS accesses across
+__device__ static inline void wave_lds_order()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // b (original numbering) -> permuted numbering of the factor, and back for x: two streaming passes over n that take the
@@ -271,6 +285,306 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
       for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
     }
   }
+}
+
+
+// =========================== bottom subtrees: one wavefront per chain of tiles ========================================
+// The lowest levels of the assembly tree are thousands of panels of a few KB: taken level by level, a tile spends its time in
+// dependent round trips (tile -> descriptor -> gather lists -> update vector -> ... -> store) with a few KB of panel in
+// flight, and every level pays a launch boundary.  Here a wavefront owns a whole small subtree and walks its tiles in
+// dependency order: the descriptor, the gather slots and the first panel rows of the NEXT tile are requested before the
+// current tile is reduced and stored, so a wavefront always has panel bytes in flight.  Children hand their update vectors to
+// their parent through global memory as in the level launches; producer and consumer are the same wavefront, so the hand-over
+// is a wavefront-local ordering of its stores before its later loads (same CU, same L1), no atomics, same summation order
+// as the level launches (bitwise identical results).
+struct WaveGeom { // lane mapping of a narrow tile: sub = row group, gl = pair of outputs, g lanes per panel row
+  int   g, R, sub, gl;
+  bool  active;
+};
+__device__ static inline WaveGeom geom(int lanes_per, int lane)
+{
+  WaveGeom q;
+  q.g      = lanes_per;
+  q.R      = 64 / q.g;
+  q.sub    = lane / q.g;
+  q.gl     = lane - q.sub * q.g;
+  q.active = q.sub < q.R;
+  return q;
+}
+__device__ static inline void chain_fence()
+{
+  // stores of this wavefront (update vectors / x) before its later loads of the same locations, and the LDS staging area free
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int MU, int NP>
+__device__ static inline void chain_fwd(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, int t0, int t1, int lane, double *lds, int wr, const double *b, double *y, double *U, int mu_total, int nu0)
+{
+  Tile     t = tiles[t0];
+  SnView   d = view(sns[t.sn]);
+  WaveGeom q = geom((t.nr + 1) >> 1, lane);
+  gcd_t    Fp = d.FT + t.r0 + 2 * q.gl;
+  int      rtop = t.r0 + 2 * q.gl + 1;
+  dbl2     cur[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = q.sub + p * q.R;
+    cur[p]      = (q.active && i < d.w && i <= rtop) ? *(gcd2_t)(Fp + (long long)i * d.ldh) : dbl2{0.0, 0.0};
+  }
+  // gather slots of the columns (right-hand side of the supernode): lane c and lane c + 64
+  int4v csrc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) csrc[k] = (d.has_src && lane + 64 * k < d.w) ? d.src4[lane + 64 * k] : int4v{-1, -1, -1, -1};
+  for (int tix = t0; tix < t1; ++tix) {
+    const bool has_next = tix + 1 < t1;
+    Tile       tn = t;
+    SnView     dn = d;
+    if (has_next) {
+      tn = tiles[tix + 1];
+      dn = view(sns[tn.sn]);
+    }
+    const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
+    const int     w = d.w;
+    // gather slots of this lane's two output rows (below the diagonal block): static data, lands during the sweep
+    const int r_out = t.r0 + 2 * q.gl, rend = t.r0 + t.nr;
+    int4v     rsrc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rsrc[k] = (d.has_src && q.sub == 0 && r_out + k >= w && r_out + k < rend) ? d.src4[r_out + k] : int4v{-1, -1, -1, -1};
+    if (t.part) { // first tile of its supernode: f = b_J - (updates handed up by the children)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w) {
+          double v[MU];
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int src = csrc[k][j];
+            if (src >= 0) {
+#pragma unroll
+              for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
+            }
+          }
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
+        }
+      }
+      wave_lds_order();
+    }
+    // the next tile: lane mapping, first rows of its panel, gather slots of its columns
+    const WaveGeom qn = geom((tn.nr + 1) >> 1, lane);
+    const gcd_t    Fn = dn.FT + tn.r0 + 2 * qn.gl;
+    const int      rtopn = tn.r0 + 2 * qn.gl + 1;
+    int4v          csrcn[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) csrcn[k] = (has_next && tn.part && dn.has_src && lane + 64 * k < dn.w) ? dn.src4[lane + 64 * k] : int4v{-1, -1, -1, -1};
+    double acc0[MU], acc1[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+    for (int ib0 = 0; ib0 < w; ib0 += NP * q.R) {
+      const int  ib   = ib0 + q.sub;
+      const bool more = ib0 + NP * q.R < w;
+      dbl2       nxt[NP];
+      if (more) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int i = ib + (NP + p) * q.R;
+          nxt[p]      = (q.active && i < w && i <= rtop) ? *(gcd2_t)(Fp + (long long)i * d.ldh) : dbl2{0.0, 0.0};
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int i = qn.sub + p * qn.R;
+          nxt[p]      = (has_next && qn.active && i < dn.w && i <= rtopn) ? *(gcd2_t)(Fn + (long long)i * dn.ldh) : dbl2{0.0, 0.0};
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i = min(ib + p * q.R, w - 1); // out-of-range passes carry a = 0
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) {
+          const double v = lds[nu * wr + i];
+          acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+          acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc0[nu] = reduce_across(acc0[nu], lane, q.sub, q.g, q.R);
+      acc1[nu] = reduce_across(acc1[nu], lane, q.sub, q.g, q.R);
+    }
+    if (q.sub == 0) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = r_out + k;
+        if (r < rend) {
+          if (r < w) {
+#pragma unroll
+            for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = k ? acc1[nu] : acc0[nu];
+          } else {
+#pragma unroll
+            for (int nu = 0; nu < MU; ++nu) {
+              double v = k ? acc1[nu] : acc0[nu];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int src = rsrc[k][j];
+                if (src >= 0) v += Ub[(long long)nu * d.usize + src];
+              }
+              Ub[(long long)nu * d.usize + d.u_off + (r - w)] = v;
+            }
+          }
+        }
+      }
+    }
+    // tn.nparts: the next tile starts a new height of the subtree -- its supernode gathers update vectors stored by earlier
+    // tiles of this chain: those stores must have landed.  Otherwise only the LDS staging area is handed over.
+    if (has_next && tn.nparts) chain_fence();
+    else wave_lds_order();
+    t = tn, d = dn, q = qn, Fp = Fn, rtop = rtopn;
+    csrc[0] = csrcn[0], csrc[1] = csrcn[1];
+  }
+}
+
+template <int MU, int NP>
+__device__ static inline void chain_bwd(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, int t0, int t1, int lane, double *lds, int wr, const double *y, double *xw, int mu_total, int nu0)
+{
+  constexpr int NRW = (CHAIN_MAX_H + 63) / 64; // rows of v a lane stages
+  Tile     t = tiles[t0];
+  SnView   d = view(sns[t.sn]);
+  WaveGeom q = geom(d.ldw >> 1, lane);
+  gcd_t    Gp = d.G + 2 * q.gl;
+  dbl2     cur[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = q.sub + p * q.R;
+    cur[p]      = (q.active && i < d.w + d.nb && i >= 2 * q.gl) ? *(gcd2_t)(Gp + (long long)i * d.ldw) : dbl2{0.0, 0.0};
+  }
+  int rw[NRW]; // the rows below the block this lane stages (static data)
+#pragma unroll
+  for (int k = 0; k < NRW; ++k) {
+    const int i = lane + 64 * k;
+    rw[k]       = (i >= d.w && i < d.w + d.nb) ? d.rows[i - d.w] : 0;
+  }
+  for (int tix = t0; tix < t1; ++tix) {
+    const bool has_next = tix + 1 < t1;
+    Tile       tn = t;
+    SnView     dn = d;
+    if (has_next) {
+      tn = tiles[tix + 1];
+      dn = view(sns[tn.sn]);
+    }
+    const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
+    double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
+    const int     w = d.w, h = d.w + d.nb, ldw = d.ldw;
+    // v = [ D^{-1} y_J ; -x_below ]: x of the ancestors comes from earlier launches or from earlier tiles of this chain
+#pragma unroll
+    for (int k = 0; k < NRW; ++k) {
+      const int i = lane + 64 * k;
+      if (i < h) {
+        if (i < w) {
+          const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
+        } else {
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = -xb[(long long)nu * d.n + rw[k]];
+        }
+      }
+    }
+    wave_lds_order();
+    const WaveGeom qn = geom(dn.ldw >> 1, lane);
+    const gcd_t    Gn = dn.G + 2 * qn.gl;
+    const int      hn = dn.w + dn.nb;
+    int            rwn[NRW];
+#pragma unroll
+    for (int k = 0; k < NRW; ++k) {
+      const int i = lane + 64 * k;
+      rwn[k]      = (has_next && i >= dn.w && i < hn) ? dn.rows[i - dn.w] : 0;
+    }
+    double acc0[MU], acc1[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+    for (int ib0 = 0; ib0 < h; ib0 += NP * q.R) {
+      const int  ib   = ib0 + q.sub;
+      const bool more = ib0 + NP * q.R < h;
+      dbl2       nxt[NP];
+      if (more) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int i = ib + (NP + p) * q.R;
+          nxt[p]      = (q.active && i < h && i >= 2 * q.gl) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int i = qn.sub + p * qn.R;
+          nxt[p]      = (has_next && qn.active && i < hn && i >= 2 * qn.gl) ? *(gcd2_t)(Gn + (long long)i * dn.ldw) : dbl2{0.0, 0.0};
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i = min(ib + p * q.R, h - 1);
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) {
+          const double v = lds[nu * wr + i];
+          acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+          acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc0[nu] = reduce_across(acc0[nu], lane, q.sub, q.g, q.R);
+      acc1[nu] = reduce_across(acc1[nu], lane, q.sub, q.g, q.R);
+    }
+    if (q.sub == 0) {
+      const int c = 2 * q.gl;
+      if (c < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
+      }
+      if (c + 1 < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
+      }
+    }
+    if (has_next && tn.nparts) chain_fence(); // the next tile starts a lower height: it reads x stored by earlier tiles of this chain
+    else wave_lds_order();
+    t = tn, d = dn, q = qn, Gp = Gn;
+#pragma unroll
+    for (int k = 0; k < NRW; ++k) rw[k] = rwn[k];
+  }
+}
+
+template <int MU, int NP>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_chain_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ chain_ptr, int nchains, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int wr)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int c  = (int)blockIdx.x * (WG_THREADS / 64) + wv;
+  if (c >= nchains) return;
+  const int t0 = __builtin_amdgcn_readfirstlane(chain_ptr[c]), t1 = __builtin_amdgcn_readfirstlane(chain_ptr[c + 1]);
+  chain_fwd<MU, NP>(sns, tiles, t0, t1, lane, lds + wv * (wr * MU), wr, b, y, U, mu_total, nu0);
+}
+template <int MU, int NP>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_chain_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ chain_ptr, int nchains, const double *__restrict__ y, double *__restrict__ xw, int mu_total, int nu0, int wr)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int c  = (int)blockIdx.x * (WG_THREADS / 64) + wv;
+  if (c >= nchains) return;
+  const int t0 = __builtin_amdgcn_readfirstlane(chain_ptr[c]), t1 = __builtin_amdgcn_readfirstlane(chain_ptr[c + 1]);
+  chain_bwd<MU, NP>(sns, tiles, t0, t1, lane, lds + wv * (wr * MU), wr, y, xw, mu_total, nu0);
 }
 
 // =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
@@ -746,6 +1060,38 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
     const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
     has_src[k]    = hf.gptr[hf.goff[k] + hh] > hf.gptr[hf.goff[k]];
   }
+  // supernodes a single wavefront can take inside a chain of tiles (chain kernels): narrow, short, and every entry of the
+  // front fed by at most 4 update-vector entries; their gather lists are stored once more as 4 fixed slots per entry
+  parent = hf.sym.parent;
+  chainable.assign(nblk, 0);
+  s4_off.assign(nblk, -1);
+  {
+    int64_t tot = 0;
+    for (idx_t k = 0; k < nblk; ++k) {
+      const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
+      if (ldw[k] > NARROW) continue;
+      const int64_t *gp = hf.gptr.data() + hf.goff[k];
+      bool           ok = true;
+      for (int64_t i = 0; i < hh && ok; ++i) ok = gp[i + 1] - gp[i] <= 4;
+      if (!ok) continue;
+      chainable[k] = hh <= CHAIN_MAX_H;
+      if (has_src[k]) {
+        s4_off[k] = tot;
+        tot += 4 * hh;
+      }
+    }
+    HH_CHECK(tot < (int64_t)2147483647 * 4, "fixed-slot gather lists exceed 32-bit offsets");
+    std::vector<int> s4((size_t)tot, -1);
+    for (idx_t k = 0; k < nblk; ++k) {
+      if (s4_off[k] < 0) continue;
+      const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
+      const int64_t *gp = hf.gptr.data() + hf.goff[k];
+      for (int64_t i = 0; i < hh; ++i)
+        for (int64_t qq = gp[i]; qq < gp[i + 1]; ++qq) s4[(size_t)(s4_off[k] + 4 * i + (qq - gp[i]))] = (int)hf.gsrc[qq];
+    }
+    src4.upload(s4, s);
+    HIP_OK(hipStreamSynchronize(s));
+  }
 }
 
 void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s)
@@ -780,11 +1126,68 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
-  const int  bwd_want    = envi("HPDDM_HIP_BWD_WANT", 3072);  // wide panels, backward: split rows until a level fields this many workgroups (measured at 129^3 per subdomain: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
+  const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   const bool pregather   = envi("HPDDM_HIP_PREGATHER", 1) != 0;
   const int  sort_mode   = envi("HPDDM_HIP_SORT", 1);         // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
+  const bool use_chains  = envi("HPDDM_HIP_CHAINS", 0) != 0;  // bottom subtrees walked by one wavefront each (chain kernels): opt-in, measured 2.6-3.0 TB/s against 3.5 of the level launches at 65^3
+  const long long chain_cap_env = envi("HPDDM_HIP_CHAIN_KB", 0) * 1024LL; // largest chain in bytes (0: from the size of the problem)
+  // ---- which supernodes go into chains: maximal subtrees made of chainable supernodes, at most chain_cap bytes each ----
+  std::vector<std::vector<char>>  in_chain(fs.size());
+  std::vector<std::vector<idx_t>> chain_root(fs.size());
+  std::vector<int>                desc_base(fs.size(), 0);
+  std::vector<Tile> chain_tiles[2];
+  std::vector<int>  cptr[2] = {{0}, {0}};
+  struct ChainRef { int f; idx_t root; long long bytes; };
+  std::vector<ChainRef> chain_list;
+  chain_bytes = 0;
+  if (use_chains) {
+    std::vector<std::vector<long long>> sub_bytes(fs.size());
+    std::vector<std::vector<char>>      sub_ok(fs.size());
+    long long                           total_ok = 0;
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      sub_bytes[f].assign(D.nblk, 0);
+      sub_ok[f].assign(D.nblk, 1);
+      in_chain[f].assign(D.nblk, 0);
+      chain_root[f].assign(D.nblk, -1);
+      for (idx_t k = 0; k < D.nblk; ++k) { // children come before their parent
+        const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
+        sub_bytes[f][k] += (w * (w + 1) / 2 + nb * w) * 8;
+        if (!D.chainable[k]) sub_ok[f][k] = 0;
+        if (sub_ok[f][k]) total_ok += (w * (w + 1) / 2 + nb * w) * 8;
+        const idx_t p = D.parent[k];
+        if (p >= 0) {
+          HH_CHECK(p > k, "assembly tree: parent before child");
+          sub_bytes[f][p] += sub_bytes[f][k];
+          if (!sub_ok[f][k]) sub_ok[f][p] = 0;
+        }
+      }
+    }
+    // large enough to amortise the per-tile round trips, small enough that the chains of the machine (8192 wavefront slots)
+    // finish together: a few rounds of chains per slot
+    const long long chain_cap = chain_cap_env > 0 ? chain_cap_env : std::max<long long>(24 << 10, std::min<long long>(256 << 10, total_ok / (4 * 8192)));
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      for (idx_t k = D.nblk - 1; k >= 0; --k) { // parents first: a supernode joins the chain of its parent, or roots its own
+        const idx_t p    = D.parent[k];
+        const bool  fits = sub_ok[f][k] && sub_bytes[f][k] <= chain_cap;
+        if (p >= 0 && in_chain[f][p]) {
+          in_chain[f][k]  = 1;
+          chain_root[f][k] = chain_root[f][p];
+        } else if (fits) {
+          in_chain[f][k]  = 1;
+          chain_root[f][k] = k;
+          chain_list.push_back(ChainRef{(int)f, k, sub_bytes[f][k]});
+        }
+      }
+    }
+    // longest chains first (workgroups are dispatched in order)
+    std::stable_sort(chain_list.begin(), chain_list.end(), [](const ChainRef &a, const ChainRef &b2) { return a.bytes > b2.bytes; });
+    for (const ChainRef &c : chain_list) chain_bytes += (double)c.bytes;
+  }
+  lev_bytes.assign(nlev, 0.0);
   std::vector<long long> wide_cost(nlev, 0);                  // entries of the wide panels per level
   if (fwd_target > 0)
     for (size_t f = 0; f < fs.size(); ++f) {
@@ -797,6 +1200,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     }
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
+    desc_base[f]          = (int)descs.size();
     for (idx_t k = 0; k < D.nblk; ++k) {
       SnDesc d;
       d.F     = D.F.p + D.f_off[k];
@@ -819,7 +1223,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.ldh     = D.ldh[k];
       const int id = (int)descs.size();
       descs.push_back(d);
+      d.src4 = D.s4_off[k] >= 0 ? D.src4.p + D.s4_off[k] : nullptr;
+      descs.back().src4 = d.src4;
       const int h = d.w + d.nb, lev = D.height[k];
+      if (use_chains && in_chain[f][k]) continue; // taken by a chain kernel (tiles made below)
+      lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0;
       if (d.ldw <= NARROW) {
         HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
         // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
@@ -946,6 +1354,59 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     pperm.upload(pp, s);
     HIP_OK(hipStreamSynchronize(s));
   }
+  // ---- tiles of the chains: forward in dependency order (children first), backward parents first ----
+  nchains      = (int)chain_list.size();
+  chain_lds[0] = chain_lds[1] = 16;
+  if (nchains) {
+    std::vector<std::vector<std::vector<idx_t>>> members(fs.size()); // per factor, per root: supernodes in ascending order
+    std::vector<std::map<idx_t, int>>            slot(fs.size());
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      for (idx_t k = 0; k < D.nblk; ++k) {
+        if (!in_chain[f][k]) continue;
+        const idx_t r  = chain_root[f][k];
+        auto        it = slot[f].find(r);
+        if (it == slot[f].end()) {
+          it = slot[f].emplace(r, (int)members[f].size()).first;
+          members[f].emplace_back();
+        }
+        members[f][it->second].push_back(k);
+      }
+    }
+    for (const ChainRef &c : chain_list) {
+      const DeviceFactor       &D  = *fs[c.f];
+      const std::vector<idx_t> &mb = members[c.f][slot[c.f][c.root]];
+      // height by height inside the chain (forward: lowest first): a supernode and its children are then separated by whole
+      // groups of tiles, and the wavefront only has to wait for its own stores where the height changes (Tile::nparts = 1)
+      std::vector<idx_t> ord(mb);
+      std::stable_sort(ord.begin(), ord.end(), [&](idx_t a, idx_t b2) { return D.height[a] < D.height[b2]; });
+      int prev_h = -1;
+      for (idx_t k : ord) {
+        const int id = desc_base[c.f] + k, w = D.blk_ptr[k + 1] - D.blk_ptr[k], h = w + (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
+        const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
+        for (int r0 = 0; r0 < h; r0 += per) chain_tiles[0].push_back(Tile{id, r0, std::min(per, h - r0), r0 == 0 ? 1 : 0, (r0 == 0 && prev_h >= 0 && D.height[k] != prev_h) ? 1 : 0, 0, 0, 0});
+        prev_h       = D.height[k];
+        chain_lds[0] = std::max(chain_lds[0], w);
+        chain_lds[1] = std::max(chain_lds[1], h);
+      }
+      cptr[0].push_back((int)chain_tiles[0].size());
+      prev_h = -1;
+      for (auto it = ord.rbegin(); it != ord.rend(); ++it) {
+        const idx_t k  = *it;
+        const int   id = desc_base[c.f] + k, w = D.blk_ptr[k + 1] - D.blk_ptr[k], h = w + (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
+        chain_tiles[1].push_back(Tile{id, 0, D.ldw[k], 0, (prev_h >= 0 && D.height[k] != prev_h) ? 1 : 0, 0, 0, h});
+        prev_h = D.height[k];
+      }
+      cptr[1].push_back((int)chain_tiles[1].size());
+    }
+    for (int kd = 0; kd < 2; ++kd) {
+      chain_off[kd] = (long long)all.size();
+      all.insert(all.end(), chain_tiles[kd].begin(), chain_tiles[kd].end());
+      chain_ptr[kd].upload(cptr[kd], s);
+      chain_lds[kd] = (chain_lds[kd] + 15) / 16 * 16;
+    }
+    launches_per_solve += 2;
+  }
   sn.upload(descs, s);
   tiles.upload(all, s);
   {
@@ -965,16 +1426,7 @@ void SolvePlan::mark(int tag, hipStream_t s)
   prof_tag.push_back(tag);
 }
 
-std::vector<double> SolvePlan::level_bytes(int) const
-{
-  std::vector<double> out(nlev, 0.0);
-  for (const DeviceFactor *D : factors)
-    for (idx_t k = 0; k < D->nblk; ++k) {
-      const double w = D->blk_ptr[k + 1] - D->blk_ptr[k], nb = (double)(D->row_ptr[k + 1] - D->row_ptr[k]);
-      out[D->height[k]] += (w * (w + 1) / 2 + nb * w) * 8.0;
-    }
-  return out;
-}
+std::vector<double> SolvePlan::level_bytes(int) const { return lev_bytes; }
 
 void SolvePlan::drop_graphs()
 {
@@ -1012,6 +1464,11 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int per_cu = std::max(1, std::min(P.persist, (int)((160 * 1024) / ((size_t)ld_dbl * sizeof(double)))));
     return std::max(1, std::min(want, 256 * per_cu));
   };
+  constexpr int NPC = MU >= 8 ? 2 : 4; // panel rows in flight per lane of the chain kernels
+  if (P.nchains) {
+    hipLaunchKernelGGL((sptrsv_fwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[0] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[0], P.chain_ptr[0].p, P.nchains, b, P.y.p, P.U.p, mu_total, nu0, P.chain_lds[0]);
+    P.mark(5000, s);
+  }
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
     const int ng = P.gat_end[l] - P.gat_ptr[l];
@@ -1032,6 +1489,10 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     if (nb || nw) P.mark(3000 + l, s);
+  }
+  if (P.nchains) {
+    hipLaunchKernelGGL((sptrsv_bwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[1] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[1], P.chain_ptr[1].p, P.nchains, P.y.p, P.xw.p, mu_total, nu0, P.chain_lds[1]);
+    P.mark(6000, s);
   }
 }
 

@@ -39,14 +39,15 @@ def main():
         A.rebuild_plan()
         t = A.time("solve", mu=args.mu, warmup=2, reps=args.reps)
         print(f"== [{cfg}]  sptrsv {t * 1e3:.3f} ms  frac {bytes_alg / t / 8e12:.4f}  launches {int(A.stats()['launches'])}", flush=True)
-        if args.levels:
+        if args.levels and os.environ.get("HPDDM_HIP_STREAMS") == "1":
             tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
             for kind, lev, us, nbytes in A.level_times(mu=args.mu, reps=3):
                 extra = f"  {nbytes / 1e6:9.1f} MB {nbytes / us / 1e3:8.1f} GB/s" if nbytes else ""
                 print(f"   {kind:8s} level {lev:2d} {us:9.1f} us{extra}")
-                if kind in tot:
-                    tot[kind][0] += us
-                    tot[kind][1] += nbytes
+                k2 = kind.replace("_chain", "")
+                if k2 in tot:
+                    tot[k2][0] += us
+                    tot[k2][1] += nbytes
             for k, (us, nb) in tot.items():
                 print(f"   {k} total {us:9.1f} us {nb / 1e6:9.1f} MB {nb / us / 1e3:8.1f} GB/s")
 
