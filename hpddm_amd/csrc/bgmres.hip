@@ -1391,10 +1391,22 @@ int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int his
   case 6: it = bgmres_impl<6>(*this, b, x, history, history_cap); break;
   case 7: it = bgmres_impl<7>(*this, b, x, history, history_cap); break;
   case 8: it = bgmres_impl<8>(*this, b, x, history, history_cap); break;
-  default: HH_CHECK(false, "BGMRES: 1 <= mu <= 8 in this build"); it = -1;
+  default: HH_CHECK(false, "BGMRES: blocks of 1 to 8 right-hand sides (more are split by Schwarz::krylov_solve)"); it = -1;
   }
   if (it == -2) return gmres(b, x, mu, history, history_cap); // breakdown of the first QR: GMRES, as the reference does
   return it;
+}
+
+// columns [nu0, nu0 + c) of a batched multi-vector with mu columns <-> a batched multi-vector with c columns
+__global__ void k_cols_copy(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ src, double *__restrict__ dst, int mu, int nu0, int c, int put)
+{
+  const int       s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < (long long)n * c; o += (long long)gridDim.x * blockDim.x) {
+    const long long wide = v0 * mu + (long long)nu0 * n + o, narrow = v0 * c + o; // column j of the chunk starts at j * n in both
+    if (put) dst[wide] = src[narrow];
+    else dst[narrow] = src[wide];
+  }
 }
 
 // IterativeMethod::solve dispatch (include/HPDDM_iterative.hpp:1013-1111) for the methods built here
@@ -1403,6 +1415,30 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   const int method = (int)getopt("krylov_method", 0);
   if (method == 7) return richardson(b, x, mu);
   if (method == 8) return no_krylov(b, x, mu);
+  const bool block = method == 1 || method == 3 || method == 5 || method == 6;
+  if (block && mu > 8) {
+    // The block methods keep their mu x mu Gram blocks and block rotations in registers and are built for up to 8 right-hand
+    // sides; the reference has no such limit (any -generate_random_rhs).  More right-hand sides are solved as successive
+    // blocks of at most 8: every block converges to the same tolerance, the Krylov space is shared inside a block only.
+    // Returns the largest iteration count; `history` follows the first block.
+    hipStream_t    st = library_stream();
+    DevBuf<double> bc, xc;
+    bc.alloc((size_t)ntot * 8);
+    xc.alloc((size_t)ntot * 8);
+    const dim3 grid((unsigned)std::min(1024, (nmax * 8 + 255) / 256), (unsigned)nsub);
+    int        worst = 0;
+    for (int nu0 = 0; nu0 < mu; nu0 += 8) {
+      const int c = std::min(8, mu - nu0);
+      hipLaunchKernelGGL(k_cols_copy, grid, dim3(256), 0, st, voff_d.p, n_d.p, b, bc.p, mu, nu0, c, 0);
+      hipLaunchKernelGGL(k_cols_copy, grid, dim3(256), 0, st, voff_d.p, n_d.p, (const double *)x, xc.p, mu, nu0, c, 0);
+      const int it = krylov_solve(bc.p, xc.p, c, nu0 == 0 ? history : nullptr, nu0 == 0 ? history_cap : 0);
+      if (it < 0) return it;
+      worst = std::max(worst, it);
+      hipLaunchKernelGGL(k_cols_copy, grid, dim3(256), 0, st, voff_d.p, n_d.p, (const double *)xc.p, x, mu, nu0, c, 1);
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    return worst;
+  }
   if (is_complex) { // K = std::complex<double>: krylov_complex.hip
     HH_CHECK(method == 0 || method == 1, "krylov_method: gmres, bgmres, richardson and none are built for complex scalars");
     return method == 1 ? bgmres_z(b, x, mu, history, history_cap) : gmres_z(b, x, mu, history, history_cap);

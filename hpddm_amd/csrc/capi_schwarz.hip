@@ -40,6 +40,7 @@ double parse_value(const std::string &key, const std::string &val)
     {"schwarz_method", {{"ras", 0}, {"oras", 1}, {"soras", 2}, {"asm", 3}, {"osm", 4}, {"none", 5}}},
     {"schwarz_coarse_correction", {{"deflated", 0}, {"additive", 1}, {"balanced", 2}}},
     {"qr", {{"cholqr", 0}, {"cgs", 1}, {"mgs", 2}}},
+    {"geneo_force_uniformity", {{"min", 0}, {"max", 1}}},
     {"recycle_target", {{"SM", 0}, {"LM", 1}, {"SR", 2}, {"LR", 3}, {"SI", 4}, {"LI", 5}}},
     {"recycle_strategy", {{"A", 0}, {"B", 1}}},
     {"krylov_method", {{"gmres", 0}, {"bgmres", 1}, {"cg", 2}, {"bcg", 3}, {"gcrodr", 4}, {"bgcrodr", 5}, {"bfbcg", 6}, {"richardson", 7}, {"none", 8}}},

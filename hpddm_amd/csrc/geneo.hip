@@ -402,7 +402,8 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
     HIP_OK(hipStreamSynchronize(st));
   }
   HH_CHECK(!Xritz.empty(), "SolveGEVP: no Ritz pair was computed");
-  if (!converged && getopt("verbosity", 0) >= 1) printf("GenEO subdomain %d: eigensolver stopped at basis size %d without reaching tol %.1e\n", first + s, dim, tol);
+  // always said, whatever the verbosity: the vectors kept are Ritz vectors of an unconverged basis (ARPACK would return info != 0)
+  if (!converged) fprintf(stderr, "GenEO subdomain %d: eigensolver stopped at basis size %d without reaching tol %.1e\n", first + s, dim, tol);
   std::vector<double> &X = Xritz;
   nu                     = (int)lam.size();
   const int m            = dim;
@@ -410,9 +411,11 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   int keep = nu;
   if (threshold > 0.0) {
     keep = 1;
-    while (keep < nu && lam[keep] < threshold) ++keep;
+    while (keep < nu && lam[keep] <= threshold) ++keep; // std::upper_bound of the reference: the values <= threshold are kept, at least one
   }
   S.nu = keep;
+  // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705): visible to HpddmOptionVal / GetOption
+  opt["geneo_nu"] = keep;
   S.Z.assign(X.begin(), X.begin() + (size_t)keep * n);
   S.eigenvalues.assign(lam.begin(), lam.begin() + keep);
   S.gevp_iterations = it;

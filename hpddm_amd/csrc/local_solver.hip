@@ -136,6 +136,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     plan.build({&dev}, library_stream());
     uploaded = true;
     t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (host.kind != FACT_CHOL && !getenv("HPDDM_HIP_NO_PROBE")) probe(A, host.kind);
     if (release_host) {
       host.F.clear();
       if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);
@@ -143,6 +144,48 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       std::vector<double>().swap(host.G);
     }
   }
+}
+
+// The factorisation does not pivot (the reference's local solvers do): one probe solve closes numfact and fails loudly when
+// the factor is not backward stable for this matrix.  b = A * ones, x = solve(b): normwise backward error
+// ||A x - b||_inf / (||A||_inf ||x||_inf + ||b||_inf), which does not depend on the conditioning of A -- only on the
+// growth inside the elimination.  Symmetric-indefinite and general matrices whose pivots collapse (saddle points, shifts
+// close to an eigenvalue of a leading block) end here instead of returning wrong values silently.
+void LocalSolver::probe(const CsrView &A, FactKind kind)
+{
+  const idx_t         n = A.n;
+  std::vector<double> b((size_t)n, 0.0), x((size_t)n), r((size_t)n, 0.0), rowsum((size_t)n, 0.0);
+  auto                spmv = [&](const double *v, double *out, double *absrow) {
+    for (idx_t i = 0; i < n; ++i)
+      for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+        const idx_t  j = A.ja[p] - A.base;
+        const double a = A.a[p];
+        out[i] += a * v[j];
+        if (absrow) absrow[i] += std::abs(a);
+        if (A.sym && j != i) {
+          out[j] += a * v[i];
+          if (absrow) absrow[j] += std::abs(a);
+        }
+      }
+  };
+  std::vector<double> ones((size_t)n, 1.0);
+  spmv(ones.data(), b.data(), rowsum.data());
+  solve_host(b.data(), x.data(), 1);
+  spmv(x.data(), r.data(), nullptr);
+  double rn = 0.0, an = 0.0, xn = 0.0, bn = 0.0;
+  for (idx_t i = 0; i < n; ++i) {
+    rn = std::max(rn, std::abs(r[i] - b[i]));
+    an = std::max(an, rowsum[i]);
+    xn = std::max(xn, std::abs(x[i]));
+    bn = std::max(bn, std::abs(b[i]));
+    if (x[i] != x[i]) rn = INFINITY;
+  }
+  probe_berr = rn / std::max(an * xn + bn, 1e-300);
+  const char *e   = getenv("HPDDM_HIP_PROBE_TOL");
+  const double tol = e ? atof(e) : 1.0e-9;
+  HH_CHECK(probe_berr <= tol, std::string("numfact: the ") + (kind == FACT_LU ? "LU" : (kind == FACT_LDLT ? "LDL^T" : "Cholesky")) +
+                                  " factorisation of this matrix is not backward stable without pivoting (probe solve: backward error " + std::to_string(probe_berr) +
+                                  "); this solver does not pivot -- use a local solver that does for this operator");
 }
 
 void LocalSolver::solve_device(const double *b, double *x, int mu)

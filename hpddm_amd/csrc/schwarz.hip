@@ -242,6 +242,10 @@ void Schwarz::set_subdomain(int s, int n, const int *ia, const int *ja, const do
 {
   HH_CHECK(s >= 0 && s < nsub, "SetSubdomain: bad local index");
   SchwarzSub &S = subs[s];
+  HH_CHECK(n >= 0 && ia && (n == 0 || (ja && a)), "SetSubdomain: null matrix arrays");
+  HH_CHECK(ia[0] == base, "SetSubdomain: ia[0] does not match the numbering");
+  for (int i = 0; i < n; ++i) HH_CHECK(ia[i + 1] >= ia[i], "SetSubdomain: ia is not monotone at row " + std::to_string(i));
+  for (int p = 0; p < ia[n] - base; ++p) HH_CHECK(ja[p] - base >= 0 && ja[p] - base < n, "SetSubdomain: column index out of range at entry " + std::to_string(p));
   S.n           = n;
   const int nnz = ia[n] - base;
   S.ia0.assign(ia, ia + n + 1);
@@ -622,13 +626,29 @@ void Schwarz::build_coarse()
   // over the ranks and E^{-1} is replicated.
   build_device();
   hipStream_t st = library_stream();
-  coff.assign(nsub + 1, 0);
-  for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
-  cdim = coff[nsub];
   // global coarse numbering
   std::vector<double> gnu(nglobal, 0.0);
   for (int s = 0; s < nsub; ++s) gnu[first + s] = subs[s].nu;
   allreduce_host(gnu.data(), nglobal);
+  if (opt.count("geneo_force_uniformity")) {
+    // -hpddm_geneo_force_uniformity min (Eigensolver::selectNu, include/HPDDM_eigensolver.hpp:112-120): every subdomain keeps the
+    // smallest number of vectors any subdomain kept.  "max" pads the short bases with random vectors in the reference: not built.
+    HH_CHECK((int)getopt("geneo_force_uniformity", 0) == 0, "geneo_force_uniformity max (random padding vectors) is not built; use min");
+    double m = gnu[0];
+    for (int g = 0; g < nglobal; ++g) m = std::min(m, gnu[g]);
+    const int keep = (int)std::lround(m);
+    for (int s = 0; s < nsub; ++s)
+      if (subs[s].nu > keep) {
+        subs[s].nu = keep;
+        subs[s].Z.resize((size_t)keep * subs[s].n);
+        if ((int)subs[s].eigenvalues.size() > keep) subs[s].eigenvalues.resize(keep);
+      }
+    std::fill(gnu.begin(), gnu.end(), (double)keep);
+    opt["geneo_nu"] = keep;
+  }
+  coff.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
+  cdim = coff[nsub];
   gcoff.assign(nglobal + 1, 0);
   for (int g = 0; g < nglobal; ++g) gcoff[g + 1] = gcoff[g] + (int)std::lround(gnu[g]);
   cdim_g  = gcoff[nglobal];

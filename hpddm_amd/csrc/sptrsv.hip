@@ -852,10 +852,13 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the barrier
   __syncthreads();
   if (tid == 0) {
-    const int old = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release on the arrival, acquire in the last arriver: the partial sums are write-through stores already drained above, the
+    // ordering is stated in the memory model as well instead of resting on that alone (one fence per split tile)
+    const int old = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (old == t.nparts - 1);
     *s_last        = last;
     if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(arrivals + t.group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next solve
     }
   }

@@ -13,33 +13,80 @@ lower triangle is stored (diagonal last in its row).
 import numpy as np
 
 
+def _is_int(word):
+    try:
+        int(word)
+        return True
+    except ValueError:
+        return False
+
+
 def read_matrix(path):
-    """-> dict(n, m, sym, nnz, numbering, ia, ja, a) with 0-based CSR arrays (int32 / float64)."""
+    """-> dict(n, m, sym, nnz, numbering, ia, ja, a) with 0-based CSR arrays (int32 / float64 or complex128).
+
+    Accepts what the reference's parsing constructor accepts (include/HPDDM_matrix.hpp:173-244): comment lines starting with
+    ``#`` or ``%`` and blank lines anywhere; a header of one field (``n`` on one line, ``nnz`` on a later one: square, not
+    symmetric), three fields (``n m nnz``) or four and more (``n m sym nnz [numbering]``); entries ``i j a`` or, when the first word
+    of the first entry is not an integer, ``a i j`` (:218-222); complex values written ``(re,im)`` (:105-112).  Entries are 1-based."""
+    n = m = nnz = 0
+    sym, numbering = False, "C"
+    entries = []
     with open(path) as fh:
-        line = fh.readline()
-        while line.startswith("#"):
-            line = fh.readline()
-        head = line.split()
-        if len(head) != 5:
-            raise ValueError(f"{path}: malformed header {line!r}")
-        n, m, sym, nnz = (int(v) for v in head[:4])
-        numbering = head[4]
-        if numbering not in ("C", "F"):
-            raise ValueError(f"{path}: unknown numbering {numbering!r}")
-        data = np.loadtxt(fh, dtype=np.float64, ndmin=2) if nnz else np.zeros((0, 3))
-    if data.shape != (nnz, 3):
-        raise ValueError(f"{path}: expected {nnz} entries, found {data.shape[0]}")
-    rows = data[:, 0].astype(np.int64) - 1
-    cols = data[:, 1].astype(np.int64) - 1
+        lines = iter(fh)
+        for line in lines:                       # header: until nnz is known (:182-207)
+            if not line.strip() or line[0] in "#%":
+                continue
+            head = line.split()
+            if len(head) == 1:
+                if n == 0:
+                    n = m = int(head[0])
+                else:
+                    nnz = int(head[0])
+            elif len(head) == 3:
+                n, m, nnz = (int(v) for v in head)
+            elif len(head) > 3:
+                n, m, sym, nnz = int(head[0]), int(head[1]), bool(int(head[2])), int(head[3])
+                if len(head) > 4:
+                    numbering = head[4]
+                    if numbering not in ("C", "F"):
+                        raise ValueError(f"{path}: unknown numbering {numbering!r}")
+            else:
+                raise ValueError(f"{path}: malformed header {line!r}")
+            if nnz:
+                break
+        for line in lines:
+            if line.strip() and line[0] not in "#%":
+                entries.append(line)
+    if n <= 0 or m <= 0:
+        raise ValueError(f"{path}: no header found")
+    if len(entries) != nnz:
+        raise ValueError(f"{path}: expected {nnz} entries, found {len(entries)}")
+    index_first = _is_int(entries[0].split()[0]) if entries else True
+    cplx = any("(" in e for e in entries[:1])
+    rows = np.empty(nnz, dtype=np.int64)
+    cols = np.empty(nnz, dtype=np.int64)
+    vals = np.empty(nnz, dtype=np.complex128 if cplx else np.float64)
+    for k, e in enumerate(entries):
+        w = e.split()
+        if len(w) != 3:
+            raise ValueError(f"{path}: malformed entry {e!r}")
+        iw, jw, vw = (w[0], w[1], w[2]) if index_first else (w[1], w[2], w[0])
+        rows[k], cols[k] = int(iw) - 1, int(jw) - 1
+        if cplx:
+            re, im = vw.strip("()").split(",")
+            vals[k] = complex(float(re), float(im))
+        else:
+            vals[k] = float(vw)
     if nnz and (rows.min() < 0 or rows.max() >= n or cols.min() < 0 or cols.max() >= m):
         raise ValueError(f"{path}: index out of range")
-    if np.any(np.diff(rows) < 0):
-        raise ValueError(f"{path}: rows are not in ascending order")
+    if np.any(np.diff(rows) < 0):                # the reference trusts the file to be row-ordered; a stable sort is a superset
+        order = np.argsort(rows, kind="stable")
+        rows, cols, vals = rows[order], cols[order], vals[order]
     ia = np.zeros(n + 1, dtype=np.int32)
     np.add.at(ia, rows + 1, 1)
     np.cumsum(ia, out=ia)
     return {"n": n, "m": m, "sym": bool(sym), "nnz": nnz, "numbering": numbering, "ia": ia, "ja": cols.astype(np.int32),
-            "a": np.ascontiguousarray(data[:, 2])}
+            "a": np.ascontiguousarray(vals)}
 
 
 def write_matrix(path, n, ia, ja, a, sym=False, m=None, numbering="C"):

@@ -166,6 +166,8 @@ int HpddmHipSchwarzComputeResidualNorm(HpddmHipSchwarz *A, const double *sol, co
  * reference -- gmres (include/HPDDM_GMRES.hpp:30), bgmres (:159), cg / bcg / bfbcg (include/HPDDM_CG.hpp:31, 169, 342), gcrodr / bgcrodr
  * (include/HPDDM_GCRODR.hpp:34, 445), richardson (include/HPDDM_iterative.hpp:971), none (:1056) -- with the reference's own hand-overs
  * (BGMRES -> GMRES on a rank-deficient block, (BF)BCG -> GMRES for a non-symmetric preconditioner and -> CG on a breakdown).
+ * The block methods (bgmres, bcg, bfbcg, bgcrodr) work on blocks of at most 8 right-hand sides: a larger mu is solved as successive
+ * blocks of 8 (the reference builds one block of any size), the return value being the largest iteration count.
  * Returns the iteration count (negative on error); sol holds the initial guess on entry.
  * history, if not NULL, receives up to history_cap residual norms, one per iteration: the value the reference prints at verbosity 3. */
 int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap);

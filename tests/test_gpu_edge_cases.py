@@ -41,6 +41,28 @@ def test_zero_pivot_is_reported_not_hidden():
     S.destroy()
 
 
+def test_collapsed_and_small_pivots_fail_loudly():
+    """The solver does not pivot (the reference's MUMPS / PARDISO do): a pivot that collapses against its tile is a breakdown, a
+    factor that is not backward stable is refused by the probe solve that closes numfact -- never a silently wrong solution."""
+    lap = _lap(4)
+    for eps, sym in ((1e-18, True), (1e-18, False), (3e-9, True), (3e-9, False)):
+        blk = np.array([[eps, 1.0], [1.0, eps]]) if sym else np.array([[eps, 1.0], [2.0, eps]])
+        M = sp.block_diag([lap, sp.csr_matrix(blk)]).tocsr()
+        M.sort_indices()
+        S = hpddm.Subdomain()
+        with pytest.raises(HpddmHipError, match="pivot"):
+            S.numfact(M.shape[0], M.indptr, M.indices, M.data, sym=False)
+        S.destroy()
+    # a symmetric indefinite matrix whose pivots stay healthy goes through (LDL^T kind) and reports a small backward error
+    A = (_lap(6) - 1.7 * sp.identity(216)).tocsr()
+    A.sort_indices()
+    S = hpddm.Subdomain()
+    S.numfact(216, A.indptr, A.indices, A.data, sym=False)
+    x = S.solve(np.ones(216))
+    assert np.abs(A @ x - 1.0).max() < 1e-9
+    S.destroy()
+
+
 def test_malformed_input_is_rejected():
     S = hpddm.Subdomain()
     with pytest.raises(HpddmHipError):

@@ -277,6 +277,22 @@ def test_geneo_coarse_space_against_arpack():
     A.destroy()
 
 
+@pytest.mark.parametrize("method", ["bgmres", "bcg"])
+def test_block_methods_take_more_than_eight_right_hand_sides(method):
+    """The reference's block methods take any number of right-hand sides (examples run with arbitrary -generate_random_rhs); here
+    blocks hold at most 8, so 11 right-hand sides are solved as 8 + 3: every column must meet the tolerance."""
+    subs = generate3d(12, 8, 1, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_krylov_method " + method + (" -hpddm_schwarz_method asm" if method == "bcg" else ""))
+    A.call_numfact()
+    rng = np.random.default_rng(7)
+    f = A.exchange([rng.random((s["n"], 11)) for s in subs])  # consistent right-hand sides
+    it, sol = A.solve(f)
+    assert 0 < it < 60
+    res = A.compute_residual(sol, f).reshape(11, 2)
+    assert np.all(res[:, 1] <= 1e-5 * res[:, 0]), res
+    A.destroy()
+
+
 @pytest.mark.parametrize("name", ["p40_bgmres_mu4", "p40_bgmres_deflated_mu2", "p30_6ranks_bgmres_left_mu3", "p40_fbgmres_mu3",
                                   "p40_bgmres_rhs_deflation_mu4", "p40_bgmres_rhs_deflation_restart_mu4", "p40_bgmres_mgs_qrmgs_mu3",
                                   "p40_bgmres_qrcgs_mu3"] + gu.COMPLEX_BGMRES_CASES)

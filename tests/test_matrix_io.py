@@ -40,6 +40,29 @@ def test_symmetric_storage_roundtrip(tmp_path):
     assert np.allclose(csrmv(mat, x), csrmv({**full, "sym": False}, x), rtol=1e-14)
 
 
+def test_reader_accepts_every_variant_of_the_reference_parser(tmp_path):
+    """include/HPDDM_matrix.hpp:173-244: one-, three- and four-field headers, '%' comments, blank lines, value-first entries,
+    complex values"""
+    ref = {"ia": [0, 2, 3], "ja": [0, 1, 1], "a": [4.0, -1.0, 3.0]}
+    variants = {
+        "five": "# c\n2 2 0  3 C\n1 1 4.0\n1 2 -1.0\n2 2 3.0\n",
+        "four": "% c\n\n2 2 0 3\n1 1 4.0\n1 2 -1.0\n\n2 2 3.0\n",
+        "three": "2 2 3\n% inside\n1 1 4.0\n1 2 -1.0\n2 2 3.0\n",
+        "one": "2\n# then the number of entries\n3\n1 1 4.0\n1 2 -1.0\n2 2 3.0\n",
+        "value_first": "2 2 0 3\n4.0 1 1\n-1.0 1 2\n3.0 2 2\n",
+    }
+    for name, text in variants.items():
+        p = tmp_path / (name + ".txt")
+        p.write_text(text)
+        mat = read_matrix(p)
+        assert (mat["n"], mat["m"], mat["sym"], mat["nnz"]) == (2, 2, False, 3), name
+        assert list(mat["ia"]) == ref["ia"] and list(mat["ja"]) == ref["ja"] and list(mat["a"]) == ref["a"], name
+    p = tmp_path / "z.txt"
+    p.write_text("2 2 1 2\n1 1 (1.5,-2.0)\n2 2 (0.0,1.0)\n")
+    mat = read_matrix(p)
+    assert mat["sym"] and mat["a"].dtype == np.complex128 and mat["a"][0] == 1.5 - 2.0j and mat["a"][1] == 1.0j
+
+
 def test_reader_rejects_malformed(tmp_path):
     p = tmp_path / "bad.txt"
     p.write_text("# c\n# c\n2 2 0  2 C\n1 1 1.0\n")
