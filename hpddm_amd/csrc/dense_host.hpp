@@ -139,47 +139,44 @@ static inline bool potf2(int nb, double *T, long ld)
   }
   return true;
 }
-// Pivot-free LDL^T / LU: a pivot that has collapsed against the entries of its tile (|d| <= PIVOT_TOL * max |T_ij| on entry)
-// is reported as a breakdown instead of being divided by -- the reference's local solvers (MUMPS, PARDISO) would pivot
-// there, this solver does not, and says so (numfact: ... in supernode k).  Pivots that are merely small are caught by the
-// backward-error probe of LocalSolver::numfact.
+// Pivot-free LDL^T / LU: a pivot that has collapsed against the entries it is about to eliminate (|d| <= PIVOT_TOL * max of its
+// column / row inside the tile, the test of threshold pivoting) is reported as a breakdown instead of being divided by -- the
+// reference's local solvers (MUMPS, PARDISO) would pivot there, this solver does not, and says so (numfact: ... in supernode
+// k).  Relative to the pivot's own column, so that rows scaled by 1e30 (penalised Dirichlet rows) next to ordinary ones are
+// fine.  Pivots that are merely small are caught by the backward-error probe of LocalSolver::numfact.
 static constexpr double PIVOT_TOL = 1.0e-13;
-static inline double tile_amax(int nb, const double *T, long ld, bool lower_only)
-{
-  double m = 0.0;
-  for (int i = 0; i < nb; ++i)
-    for (int j = 0; j < (lower_only ? i + 1 : nb); ++j) m = std::max(m, std::abs(T[(long)i * ld + j]));
-  return m;
-}
 // LDL^T without pivoting: T = L D L^T, unit lower L stored strictly below the diagonal, D on the diagonal
 static inline bool ldlf2(int nb, double *T, long ld)
 {
   std::vector<double> w(nb);
-  const double        tiny = PIVOT_TOL * tile_amax(nb, T, ld, true);
   for (int j = 0; j < nb; ++j) {
     double d = T[(long)j * ld + j];
     for (int k = 0; k < j; ++k) {
       w[k] = T[(long)j * ld + k] * T[(long)k * ld + k];
       d -= T[(long)j * ld + k] * w[k];
     }
-    if (!(std::abs(d) > tiny)) return false; // zero, collapsed or NaN
-    T[(long)j * ld + j] = d;
-    const double inv    = 1.0 / d;
+    double cmax = 0.0;
     for (int i = j + 1; i < nb; ++i) {
       double s = T[(long)i * ld + j];
       for (int k = 0; k < j; ++k) s -= T[(long)i * ld + k] * w[k];
-      T[(long)i * ld + j] = s * inv;
+      T[(long)i * ld + j] = s;
+      cmax               = std::max(cmax, std::abs(s));
     }
+    if (!(std::abs(d) > PIVOT_TOL * cmax) || d == 0.0) return false; // zero, collapsed or NaN
+    T[(long)j * ld + j] = d;
+    const double inv    = 1.0 / d;
+    for (int i = j + 1; i < nb; ++i) T[(long)i * ld + j] *= inv;
   }
   return true;
 }
 // LU without pivoting: T = L U, unit lower L strictly below, U on and above the diagonal
 static inline bool getf2(int nb, double *T, long ld)
 {
-  const double tiny = PIVOT_TOL * tile_amax(nb, T, ld, false);
   for (int j = 0; j < nb; ++j) {
     const double p = T[(long)j * ld + j];
-    if (!(std::abs(p) > tiny)) return false; // zero, collapsed or NaN
+    double       cmax = 0.0;
+    for (int i = j + 1; i < nb; ++i) cmax = std::max(cmax, std::max(std::abs(T[(long)i * ld + j]), std::abs(T[(long)j * ld + i])));
+    if (!(std::abs(p) > PIVOT_TOL * cmax) || p == 0.0) return false; // zero, collapsed or NaN
     const double inv = 1.0 / p;
     for (int i = j + 1; i < nb; ++i) {
       const double l     = T[(long)i * ld + j] * inv;

@@ -147,7 +147,8 @@ void LocalSolver::numfact(const CsrView &A, int spd)
 }
 
 // The factorisation does not pivot (the reference's local solvers do): one probe solve closes numfact and fails loudly when
-// the factor is not backward stable for this matrix.  b = A * ones, x = solve(b): normwise backward error
+// the factor is not backward stable for this matrix.  b = A * x0 (x0 in [0.5, 1.5), golden-ratio sequence: a vector of ones
+// lets cancellations come out exact), x = solve(b): normwise backward error
 // ||A x - b||_inf / (||A||_inf ||x||_inf + ||b||_inf), which does not depend on the conditioning of A -- only on the
 // growth inside the elimination.  Symmetric-indefinite and general matrices whose pivots collapse (saddle points, shifts
 // close to an eigenvalue of a leading block) end here instead of returning wrong values silently.
@@ -168,8 +169,12 @@ void LocalSolver::probe(const CsrView &A, FactKind kind)
         }
       }
   };
-  std::vector<double> ones((size_t)n, 1.0);
-  spmv(ones.data(), b.data(), rowsum.data());
+  std::vector<double> x0((size_t)n);
+  for (idx_t i = 0; i < n; ++i) {
+    const double t = 0.6180339887498949 * (double)(i + 1);
+    x0[i]          = 0.5 + (t - std::floor(t));
+  }
+  spmv(x0.data(), b.data(), rowsum.data());
   solve_host(b.data(), x.data(), 1);
   spmv(x.data(), r.data(), nullptr);
   double rn = 0.0, an = 0.0, xn = 0.0, bn = 0.0;
@@ -181,6 +186,7 @@ void LocalSolver::probe(const CsrView &A, FactKind kind)
     if (x[i] != x[i]) rn = INFINITY;
   }
   probe_berr = rn / std::max(an * xn + bn, 1e-300);
+  if (getenv("HPDDM_HIP_VERBOSE")) fprintf(stderr, "numfact probe: n %d kind %d backward error %.3e (|r| %.3e |A| %.3e |x| %.3e |b| %.3e)\n", (int)n, (int)kind, probe_berr, rn, an, xn, bn);
   const char *e   = getenv("HPDDM_HIP_PROBE_TOL");
   const double tol = e ? atof(e) : 1.0e-9;
   HH_CHECK(probe_berr <= tol, std::string("numfact: the ") + (kind == FACT_LU ? "LU" : (kind == FACT_LDLT ? "LDL^T" : "Cholesky")) +

@@ -45,7 +45,7 @@ def test_collapsed_and_small_pivots_fail_loudly():
     """The solver does not pivot (the reference's MUMPS / PARDISO do): a pivot that collapses against its tile is a breakdown, a
     factor that is not backward stable is refused by the probe solve that closes numfact -- never a silently wrong solution."""
     lap = _lap(4)
-    for eps, sym in ((1e-18, True), (1e-18, False), (3e-9, True), (3e-9, False)):
+    for eps, sym in ((1e-18, True), (1e-18, False), (1e-11, True), (1e-11, False)):
         blk = np.array([[eps, 1.0], [1.0, eps]]) if sym else np.array([[eps, 1.0], [2.0, eps]])
         M = sp.block_diag([lap, sp.csr_matrix(blk)]).tocsr()
         M.sort_indices()
