@@ -64,15 +64,16 @@ struct DeviceLevels {
   virtual ~DeviceLevels() { }
   virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t max_h, idx_t max_w) = 0;
   virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child
-  // front k: panelA = its panel with the original entries assembled (h x ldw); rel[c][i] = position of row i of child c
-  virtual void process(idx_t k, const double *panelA, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
-  virtual int end() = 0; // != 0: a pivot was not positive
+  // front k: panelA = its panel with the original entries assembled (h x ldw; LU: panelG = the U12 entries, transposed, same
+  // shape, else nullptr); rel[c][i] = position of row i of child c
+  virtual void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
+  virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
 };
 
 // analysis (ordering + symbolic + layout); leaf_size <= 0 selects the default
 void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf);
 // numerical factorisation on the host (multifrontal, OpenMP); may be called again for a matrix with the same pattern
-// levels >= first_device_level go through dev (Cholesky only); hf.F then only holds the panels of the host levels
+// levels >= first_device_level go through dev; hf.F (and hf.G) then only hold the panels of the host levels
 void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev = nullptr, idx_t first_device_level = 2147483647);
 // first level whose fronts are large enough to be worth the device (all levels above go with it); nlev if none
 idx_t pick_first_device_level(const HostFactor &hf);

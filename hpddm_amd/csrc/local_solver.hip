@@ -113,20 +113,27 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   if (A.sym || is_symmetric(A)) kind = spd ? FACT_CHOL : FACT_LDLT;
   else kind = FACT_LU;
   if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
-  // Cholesky: the upper levels of the tree (large fronts) are factorised on the device, the lower ones on the host
+  // the upper levels of the tree (large fronts) are factorised on the device, the lower ones on the host (all three kinds)
   std::unique_ptr<DeviceLevels> devlev;
   idx_t                         first_dev = (idx_t)host.level_ptr.size() - 1;
-  if (kind == FACT_CHOL && !host_only && !getenv("HPDDM_HIP_HOST_FACTOR")) {
+  const bool                    on_device = !host_only && !getenv("HPDDM_HIP_HOST_FACTOR");
+  auto                          device_levels = [&](FactKind kd) {
+    devlev.reset();
+    first_dev = (idx_t)host.level_ptr.size() - 1;
+    if (!on_device) return;
     first_dev = pick_first_device_level(host);
     if (first_dev < (idx_t)host.level_ptr.size() - 1) {
       dev.F.alloc((size_t)host.f_size);
+      if (kd == FACT_LU) dev.G.alloc((size_t)host.f_size);
       devlev.reset(make_device_levels(dev));
     }
-  }
+  };
+  device_levels(kind);
   factor_numeric(A, kind, host, devlev.get(), first_dev);
   if (host.info != 0 && kind == FACT_CHOL) {
     // not positive definite after all: fall back to LDL^T like sym=2 in the reference (HPDDM_MUMPS.hpp:236)
-    factor_numeric(A, FACT_LDLT, host);
+    device_levels(FACT_LDLT);
+    factor_numeric(A, FACT_LDLT, host, devlev.get(), first_dev);
   }
   HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivoting in this solver)");
   uploaded = false;

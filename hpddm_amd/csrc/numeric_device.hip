@@ -1,4 +1,5 @@
-// Upper levels of the multifrontal factorisation on the MI355X (Cholesky): the large fronts of the separator tree --
+// Upper levels of the multifrontal factorisation on the MI355X (Cholesky, LDL^T and LU, no pivoting -- the kinds of
+// numeric_host.cpp): the large fronts of the separator tree --
 // where > 95 % of the flops of a 3-D factorisation are -- are assembled, factorised, inverted and turned into
 // solve-ready panels directly in HBM, with the dense work on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64).  The lower
 // levels (thousands of small fronts, memory-bound) stay on the host (numeric_host.cpp); their contribution blocks are
@@ -125,6 +126,152 @@ __global__ __launch_bounds__(64) void k_potf2_inv(double *T, long long ld, int n
   }
 }
 
+// Inverse of the lower-triangular factor held in the lower triangle of A (nb <= 64; unit: ones implied on the diagonal).
+// Thread c owns column c of the inverse: X(i, c), i > c, is kept at A[c][i] (the upper triangle), the diagonal in xd.
+__device__ static inline void tri_inverse_lds(double (*A)[65], double *xd, int nb, bool unit, int c)
+{
+  if (c < nb) {
+    xd[c] = unit ? 1.0 : 1.0 / A[c][c];
+    for (int i = c + 1; i < nb; ++i) {
+      double s = A[i][c] * xd[c];
+      for (int k = c + 1; k < i; ++k) s += A[i][k] * A[c][k];
+      A[c][i] = unit ? -s : -s / A[i][i];
+    }
+  }
+}
+// same pivot rule as dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
+static constexpr double DEV_PIVOT_TOL = 1.0e-13;
+
+// LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
+// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One wavefront.
+__global__ __launch_bounds__(64) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
+{
+  __shared__ double L[64][65];
+  __shared__ double xd[64], dd[64], cm[64];
+  const int r = threadIdx.x;
+  for (int c = 0; c < 64; ++c) L[r][c] = (r < nb && c <= r) ? T[(long long)r * ld + c] : 0.0;
+  dd[r] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    double s = 0.0;
+    if (r >= j && r < nb) {
+      s = L[r][j];
+      for (int k = 0; k < j; ++k) s -= L[r][k] * dd[k] * L[j][k];
+    }
+    cm[r] = (r > j && r < nb) ? fabs(s) : 0.0;
+    __syncthreads();
+    if (r == j) {
+      double cmax = 0.0;
+      for (int i = j + 1; i < nb; ++i) cmax = fmax(cmax, cm[i]);
+      if (!(fabs(s) > DEV_PIVOT_TOL * cmax) || s == 0.0) *flag = 1;
+      dd[j] = s;
+    }
+    __syncthreads();
+    if (r > j && r < nb) L[r][j] = s / dd[j];
+    __syncthreads();
+  }
+  for (int c = 0; c < 64; ++c)
+    if (r < nb && c <= r) T[(long long)r * ld + c] = c == r ? dd[r] : L[r][c];
+  __syncthreads();
+  tri_inverse_lds(L, xd, nb, true, r);
+  __syncthreads();
+  for (int c = 0; c < 64; ++c) {
+    const double x = (r < nb && c < nb) ? (c == r ? 1.0 : (c < r ? L[c][r] : 0.0)) : 0.0;
+    Tinv[r * 64 + c]  = x;
+    TinvD[r * 64 + c] = r < nb ? x / dd[r] : 0.0;
+  }
+}
+
+// LU of one diagonal tile (nb <= 64, row-major, in place: unit L strictly below, U on and above the diagonal) and the tile
+// inverses the blocked algorithm multiplies with: TinvL = inv(L), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).
+__global__ __launch_bounds__(64) void k_getf2_inv(double *T, long long ld, int nb, double *TinvL, double *TinvU, double *TinvUT, int *flag)
+{
+  __shared__ double A[64][65];
+  __shared__ double xd[64], cm[64];
+  const int r = threadIdx.x;
+  for (int c = 0; c < 64; ++c) A[r][c] = (r < nb && c < nb) ? T[(long long)r * ld + c] : 0.0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    cm[r] = (r > j && r < nb) ? fmax(fabs(A[r][j]), fabs(A[j][r])) : 0.0;
+    __syncthreads();
+    if (r == j) {
+      double cmax = 0.0;
+      for (int i = j + 1; i < nb; ++i) cmax = fmax(cmax, cm[i]);
+      const double p = A[j][j];
+      if (!(fabs(p) > DEV_PIVOT_TOL * cmax) || p == 0.0) *flag = 1;
+    }
+    if (r > j && r < nb) {
+      const double l = A[r][j] / A[j][j];
+      A[r][j]        = l;
+      for (int k = j + 1; k < nb; ++k) A[r][k] -= l * A[j][k];
+    }
+    __syncthreads();
+  }
+  for (int c = 0; c < 64; ++c)
+    if (r < nb && c < nb) T[(long long)r * ld + c] = A[r][c];
+  __syncthreads();
+  // inv(U)^T = inverse of the lower-triangular U^T: computed first from a transposed copy kept in registers
+  double ut[64]; // row r of U^T = column r of U (entries c <= r)
+  for (int c = 0; c < 64; ++c) ut[c] = (r < nb && c <= r) ? A[c][r] : 0.0;
+  // inverse of the unit lower factor in place (upper triangle no longer needed: U is in `ut` and in T)
+  __syncthreads();
+  tri_inverse_lds(A, xd, nb, true, r);
+  __syncthreads();
+  for (int c = 0; c < 64; ++c) TinvL[r * 64 + c] = (r < nb && c < nb) ? (c == r ? 1.0 : (c < r ? A[c][r] : 0.0)) : 0.0;
+  __syncthreads();
+  for (int c = 0; c < 64; ++c) A[r][c] = c <= r ? ut[c] : 0.0;
+  __syncthreads();
+  tri_inverse_lds(A, xd, nb, false, r);
+  __syncthreads();
+  for (int c = 0; c < 64; ++c) {
+    const double x = (r < nb && c < nb) ? (c == r ? xd[r] : (c < r ? A[c][r] : 0.0)) : 0.0; // (inv(U)^T)(r, c)
+    TinvUT[r * 64 + c] = x;
+    TinvU[c * 64 + r]  = x;
+  }
+}
+
+// dst(m x k, ldd) = src(m x k, lds) * diag(D), D(c) = the diagonal of the panel's top block (Dsrc, ldD)
+__global__ void k_scale_cols(int m, int k, const double *__restrict__ src, long long lds_, const double *__restrict__ Dsrc, long long ldD, double *__restrict__ dst, long long ldd)
+{
+  const int i = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < k; c += gridDim.x * blockDim.x)
+    if (i < m) dst[(long long)i * ldd + c] = src[(long long)i * lds_ + c] * Dsrc[(long long)c * (ldD + 1)];
+}
+// LDL^T: dinv(i) = 1 / D(i), the diagonal of the top block becomes the unit diagonal of L
+__global__ void k_extract_dinv(int w, double *P, long long ld, double *dinv)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < w) {
+    dinv[i]                 = 1.0 / P[(long long)i * (ld + 1)];
+    P[(long long)i * (ld + 1)] = 1.0;
+  }
+}
+// LU: G top block <- U11^T (lower, non-unit), F top block keeps the unit lower L11 (upper part zeroed, ones on the diagonal)
+__global__ void k_split_u11(int w, double *P, double *G, long long ld)
+{
+  const int i = blockIdx.y;
+  for (int j = i + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) {
+    G[(long long)j * ld + i] = P[(long long)i * ld + j];
+    P[(long long)i * ld + j] = j == i ? 1.0 : 0.0;
+  }
+}
+// LU: parent front += child contribution block (full nbc x nbc): A11 and A21 live in F, A12 transposed in G
+__global__ void k_extend_add_full(const double *__restrict__ Cc, int nbc, const int *__restrict__ rel, double *P, double *G, long long ld, int w, double *C, long long ldcb)
+{
+  const int i = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= nbc) return;
+  const int     li = rel[i];
+  const double *ci = Cc + (long long)i * nbc;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nbc; j += gridDim.x * blockDim.x) {
+    const int lj = rel[j];
+    if (li < w) {
+      if (lj < w) P[(long long)li * ld + lj] += ci[j];
+      else G[(long long)lj * ld + li] += ci[j];
+    } else if (lj < w) P[(long long)li * ld + lj] += ci[j];
+    else C[(long long)(li - w) * ldcb + (lj - w)] += ci[j];
+  }
+}
+
 // parent front += child contribution block (lower, nbc x nbc, ld nbc) through the child's row -> parent position map
 __global__ void k_extend_add(const double *__restrict__ Cc, int nbc, const int *__restrict__ rel, double *P, long long ld, int w, double *C, long long ldcb)
 {
@@ -172,7 +319,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   std::map<idx_t, double *> cb;      // contribution blocks resident on the device (block id -> nb x nb)
   DevBuf<double> arena;              // all contribution blocks of the device levels + uploaded children
   size_t         arena_used = 0;
-  DevBuf<double> tinv, tmp;          // inverses of the diagonal tiles of the current panel, scratch
+  DevBuf<double> tinv, tmp, dvec;    // inverses of the diagonal tiles of the current panel, scratch, 1/D of the panel (LDL^T)
   DevBuf<int>    relbuf, flag;
   int            failed = 0;
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
@@ -190,7 +337,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
     hf = &h;
     arena.alloc(cb_doubles + 1024);
     arena_used = 0;
-    tinv.alloc((size_t)((max_w + 63) / 64) * 4096);
+    tinv.alloc((size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
+    dvec.alloc((size_t)max_w + 64);
     tmp.alloc(std::max<size_t>((size_t)max_h * std::max<idx_t>(64, max_w), 4096));
     relbuf.alloc((size_t)max_h + 64);
     std::vector<int> z(1, 0);
@@ -204,13 +352,46 @@ struct DeviceLevelsImpl : public DeviceLevels {
     HIP_OK(hipStreamSynchronize(st)); // the host block goes back to its pool right after
     cb[child] = p;
   }
-  void process(idx_t k, const double *panelA, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
+  // top block (w x w, lower triangular, the inverses of its diagonal tiles in tinvs) <- its inverse, row block by row block
+  void invert_top(double *P, long long ld, int w, const double *tinvs)
+  {
+    const int ntile = (w + 63) / 64;
+    for (int t = 0; t < ntile; ++t) {
+      const int i0 = 64 * t, ib = std::min<int>(64, w - i0);
+      double   *Pi = P + (long long)i0 * ld;
+      if (i0 > 0) {
+        gemm(st, false, ib, i0, i0, 1.0, Pi, ld, P, ld, tmp.p, i0, false);                       // tmp = L(I, 0:i0) * X(0:i0, 0:i0)
+        gemm(st, false, ib, i0, ib, -1.0, tinvs + (size_t)t * 4096, 64, tmp.p, i0, Pi, ld, false); // X(I, 0:i0) = -X_II * tmp
+      }
+      hipLaunchKernelGGL(k_set_diag_tile, dim3(64), dim3(64), 0, st, ib, i0, P, ld, tinvs + (size_t)t * 4096);
+    }
+  }
+  // bottom block (nb x w) <- bottom * top
+  void mult_bottom(double *P, long long ld, int w, int nb)
+  {
+    if (!nb) return;
+    gemm(st, false, nb, w, w, 1.0, P + (long long)w * ld, ld, P, ld, tmp.p, w, false);
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, tmp.p, (long long)w, P + (long long)w * ld, ld);
+  }
+  // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse (through the scratch: the product cannot be formed in place)
+  void right_tile(double *X, long long ld, int m, int jb, const double *B, bool transB)
+  {
+    if (m <= 0) return;
+    gemm(st, transB, m, jb, jb, 1.0, X, ld, B, 64, tmp.p, 64, false);
+    hipLaunchKernelGGL(k_copy2d, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, tmp.p, 64LL, X, ld);
+  }
+
+  void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
   {
     const Symbolic &s  = hf->sym;
-    const idx_t     w  = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
+    const FactKind  kind = hf->kind;
+    const bool      lu = kind == FACT_LU;
+    const idx_t     c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
     const long long ld = hf->ldw[k];
     double         *P  = D.F.p + hf->f_off[k];
+    double         *G  = lu ? D.G.p + hf->f_off[k] : nullptr;
     HIP_OK(hipMemcpyAsync(P, panelA, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
+    if (lu) HIP_OK(hipMemcpyAsync(G, panelG, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
     double *C = nullptr;
     if (nb) {
       C = take((size_t)nb * nb);
@@ -223,42 +404,74 @@ struct DeviceLevelsImpl : public DeviceLevels {
       auto        it  = cb.find(ch);
       HH_CHECK(it != cb.end(), "numfact (device levels): child contribution block not resident");
       HIP_OK(hipMemcpyAsync(relbuf.p, rel[c].data(), sizeof(int) * nbc, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_extend_add, dim3((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4)), dim3(64, 4), 0, st, it->second, nbc, relbuf.p, P, ld, (int)w, C, (long long)nb);
+      const dim3 grid((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4));
+      if (lu) hipLaunchKernelGGL(k_extend_add_full, grid, dim3(64, 4), 0, st, it->second, nbc, relbuf.p, P, G, ld, (int)w, C, (long long)nb);
+      else hipLaunchKernelGGL(k_extend_add, grid, dim3(64, 4), 0, st, it->second, nbc, relbuf.p, P, ld, (int)w, C, (long long)nb);
       HIP_OK(hipStreamSynchronize(st)); // rel[c] is reused by the caller; relbuf by the next child
     }
-    // ---- left-looking blocked Cholesky of the panel, 64 columns at a time ----
+    // ---- left-looking blocked factorisation of the panel, 64 columns at a time ----
     const int ntile = (w + 63) / 64;
+    double   *tinv2 = tinv.p + (size_t)ntile * 4096, *tinv3 = tinv.p + (size_t)2 * ntile * 4096; // LDL^T: D^{-1} inv(L); LU: inv(U), inv(U)^T
     for (int t = 0; t < ntile; ++t) {
-      const int kb = 64 * t, jb = std::min<int>(64, w - kb);
-      double   *Pk = P + (long long)kb * ld;
-      gemm(st, true, h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, Pk + kb, ld, true);
-      hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, tinv.p + (size_t)t * 4096, flag.p);
-      const int below = h - kb - jb;
-      if (below > 0) {
-        // X <- X * inv(L_T)^T through a scratch copy (the product cannot be formed in place)
-        gemm(st, true, below, jb, jb, 1.0, Pk + (long long)jb * ld + kb, ld, tinv.p + (size_t)t * 4096, 64, tmp.p, 64, false);
-        hipLaunchKernelGGL(k_copy2d, dim3(1, (unsigned)below), dim3(64), 0, st, below, jb, tmp.p, 64LL, Pk + (long long)jb * ld + kb, ld);
+      const int kb = 64 * t, jb = std::min<int>(64, w - kb), below = h - kb - jb;
+      double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
+      if (kind == FACT_CHOL) {
+        gemm(st, true, h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, Pk + kb, ld, true);
+        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, flag.p);
+        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, Tt, true); // X <- X * inv(L_T)^T
+      } else if (kind == FACT_LDLT) {
+        if (kb > 0) {
+          // W = L(kb:kb+jb, 0:kb) * D(0:kb);  P(kb:h, kb:kb+jb) -= L(kb:h, 0:kb) * W^T
+          hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((kb + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, kb, Pk, ld, P, ld, tmp.p, (long long)kb);
+          gemm(st, true, h - kb, jb, kb, -1.0, Pk, ld, tmp.p, kb, Pk + kb, ld, true);
+        }
+        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, flag.p);
+        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, true); // X <- X * inv(L_T)^T * D_T^{-1}
+      } else {
+        double *Gb = G + (long long)w * ld; // U12 transposed: rows below the block
+        if (kb > 0) {
+          gemm(st, false, h - kb, jb, kb, -1.0, Pk, ld, P + kb, ld, Pk + kb, ld, true);                                  // column block of [A11; A21]
+          gemm(st, false, jb, (int)w - kb - jb, kb, -1.0, Pk, ld, P + kb + jb, ld, Pk + kb + jb, ld, true);             // row block of U inside A11
+          gemm(st, true, (int)nb, jb, kb, -1.0, Gb, ld, Pk, ld, Gb + kb, ld, true);                                      // row block of U12 (transposed)
+        }
+        hipLaunchKernelGGL(k_getf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
+        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
+        const int right = (int)w - kb - jb;
+        if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)
+          gemm(st, false, jb, right, jb, 1.0, Tt, 64, Pk + kb + jb, ld, tmp.p, right, false);
+          hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, tmp.p, (long long)right, Pk + kb + jb, ld);
+        }
+        right_tile(Gb + kb, ld, (int)nb, jb, Tt, true); // U12^T rows: X <- X * inv(L_T)^T
       }
     }
-    // ---- Schur complement -> contribution block (lower triangle) ----
-    if (nb) gemm(st, true, nb, nb, w, -1.0, P + (long long)w * ld, ld, P + (long long)w * ld, ld, C, nb, true, true);
-    hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
-    if (hf->keep_plain) HIP_OK(hipMemcpyAsync(hf->Lplain.data() + hf->f_off[k], P, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
-    // ---- solve-ready panel: top <- inv(L11) (blocked, row block by row block), bottom <- L21 * inv(L11) ----
-    for (int t = 0; t < ntile; ++t) {
-      const int i0 = 64 * t, ib = std::min<int>(64, w - i0);
-      double   *Pi = P + (long long)i0 * ld;
-      if (i0 > 0) {
-        gemm(st, false, ib, i0, i0, 1.0, Pi, ld, P, ld, tmp.p, i0, false);                             // tmp = L(I, 0:i0) * X(0:i0, 0:i0)
-        gemm(st, false, ib, i0, ib, -1.0, tinv.p + (size_t)t * 4096, 64, tmp.p, i0, Pi, ld, false);    // X(I, 0:i0) = -X_II * tmp
-      }
-      hipLaunchKernelGGL(k_set_diag_tile, dim3(64), dim3(64), 0, st, ib, i0, P, ld, tinv.p + (size_t)t * 4096);
-    }
+    // ---- Schur complement -> contribution block (lower triangle for the symmetric kinds, full for LU) ----
     if (nb) {
-      gemm(st, false, nb, w, w, 1.0, P + (long long)w * ld, ld, P, ld, tmp.p, w, false);
-      hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, tmp.p, (long long)w, P + (long long)w * ld, ld);
+      double *P21 = P + (long long)w * ld;
+      if (kind == FACT_CHOL) gemm(st, true, nb, nb, w, -1.0, P21, ld, P21, ld, C, nb, true, true);
+      else if (kind == FACT_LDLT) {
+        hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((w + 255) / 256), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, P21, ld, P, ld, tmp.p, (long long)w);
+        gemm(st, true, nb, nb, w, -1.0, P21, ld, tmp.p, w, C, nb, true, true);
+      } else gemm(st, true, nb, nb, w, -1.0, P21, ld, G + (long long)w * ld, ld, C, nb, true);
     }
-    HIP_OK(hipStreamSynchronize(st)); // panelA (host staging) is reused by the caller
+    // ---- unit diagonals made explicit, D recorded (LDL^T), U11 split out of the F top block (LU) ----
+    if (lu) hipLaunchKernelGGL(k_split_u11, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, G, ld);
+    else hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
+    if (kind == FACT_LDLT) {
+      hipLaunchKernelGGL(k_extract_dinv, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, dvec.p);
+      HIP_OK(hipMemcpyAsync(hf->dinv.data() + c0, dvec.p, sizeof(double) * w, hipMemcpyDeviceToHost, st));
+    }
+    if (hf->keep_plain) {
+      HIP_OK(hipMemcpyAsync(hf->Lplain.data() + hf->f_off[k], P, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (lu) HIP_OK(hipMemcpyAsync(hf->Uplain.data() + hf->f_off[k], G, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    // ---- solve-ready panels: top <- inverse (blocked, row block by row block), bottom <- bottom * inverse ----
+    invert_top(P, ld, (int)w, tinv.p);
+    mult_bottom(P, ld, (int)w, (int)nb);
+    if (lu) {
+      invert_top(G, ld, (int)w, tinv3); // inverse of U11^T: its diagonal tiles are inv(U_T)^T
+      mult_bottom(G, ld, (int)w, (int)nb);
+    }
+    HIP_OK(hipStreamSynchronize(st)); // the host staging panels are reused by the caller
     cb[k] = C;
   }
   int end() override
@@ -270,6 +483,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     arena.release();
     tmp.release();
     tinv.release();
+    dvec.release();
     cb.clear();
     return f;
   }

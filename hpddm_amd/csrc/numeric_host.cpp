@@ -327,11 +327,13 @@ idx_t pick_first_device_level(const HostFactor &hf)
 {
   const Symbolic &s    = hf.sym;
   const idx_t     nlev = (idx_t)hf.level_ptr.size() - 1;
+  const char     *e    = getenv("HPDDM_HIP_DEVICE_MIN_H"); // fronts with at least this many rows are worth the device (tests lower it)
+  const idx_t     minh = e ? std::max(1, atoi(e)) : 768;
   for (idx_t l = 0; l < nlev; ++l)
     for (idx_t q = hf.level_ptr[l]; q < hf.level_ptr[l + 1]; ++q) {
       const idx_t k = hf.level_blk[q];
       const idx_t h = (s.blk_ptr[k + 1] - s.blk_ptr[k]) + (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
-      if (h >= 768) return l;
+      if (h >= minh) return l;
     }
   return nlev;
 }
@@ -347,11 +349,11 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
   PermutedMatrix P;
   build_permuted(A, hf.ord, lu, P);
   const idx_t nlev_all = (idx_t)hf.level_ptr.size() - 1;
-  if (!dev || kind != FACT_CHOL) first_device_level = nlev_all;
+  if (!dev) first_device_level = nlev_all;
   first_device_level = std::min(first_device_level, nlev_all);
   hf.f_host = first_device_level >= nlev_all ? hf.f_size : hf.f_off[hf.level_blk[hf.level_ptr[first_device_level]]]; // panels are packed level by level
   hf.F.assign((size_t)hf.f_host, 0.0);
-  if (lu) hf.G.assign((size_t)hf.f_size, 0.0);
+  if (lu) hf.G.assign((size_t)hf.f_host, 0.0);
   else std::vector<double>().swap(hf.G);
   if (kind == FACT_LDLT) hf.dinv.assign(n, 0.0);
   else std::vector<double>().swap(hf.dinv);
@@ -568,7 +570,7 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
         }
     }
     dev->begin(hf, cbd, max_h, max_w);
-    std::vector<double>           staging;
+    std::vector<double>           staging, stagingG;
     std::vector<idx_t>           &rel = relidx_t[0];
     if ((idx_t)rel.size() != n) rel.assign(n, -1);
     std::vector<std::vector<int>> maps;
@@ -580,8 +582,9 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
       for (idx_t ch : children[k])
         if (cb[ch]) { // computed on the host: move it to the device once
           const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
-          // the host keeps lower triangles only: make sure the upper part is defined (zero) before the copy
-          for (idx_t i = 0; i < nbc; ++i) std::fill(cb[ch] + (size_t)i * nbc + i + 1, cb[ch] + (size_t)(i + 1) * nbc, 0.0);
+          // the host keeps lower triangles only for the symmetric kinds: make sure the upper part is defined (zero) before the copy
+          if (!lu)
+            for (idx_t i = 0; i < nbc; ++i) std::fill(cb[ch] + (size_t)i * nbc + i + 1, cb[ch] + (size_t)(i + 1) * nbc, 0.0);
           dev->upload_cb(ch, cb[ch], nbc);
           pool.put(cb[ch], (size_t)nbc * nbc);
           cb[ch] = nullptr;
@@ -589,8 +592,16 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
       staging.assign((size_t)h * ld, 0.0);
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
-      for (idx_t c = c0; c < c0 + w; ++c)
+      if (lu) stagingG.assign((size_t)h * ld, 0.0);
+      for (idx_t c = c0; c < c0 + w; ++c) {
         for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) staging[(size_t)rel[P.lrow[p]] * ld + (c - c0)] += P.lval[p];
+        if (lu)
+          for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) { // entry (row c, col cc > c): U11 stays in the F top block, U12 goes transposed into G
+            const idx_t lc = rel[P.ucol[p]];
+            if (lc < w) staging[(size_t)(c - c0) * ld + lc] += P.uval[p];
+            else stagingG[(size_t)lc * ld + (c - c0)] += P.uval[p];
+          }
+      }
       maps.assign(children[k].size(), {});
       for (size_t c = 0; c < children[k].size(); ++c) {
         const idx_t ch = children[k][c];
@@ -598,9 +609,9 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
       }
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
-      dev->process(k, staging.data(), children[k], maps);
+      dev->process(k, staging.data(), lu ? stagingG.data() : nullptr, children[k], maps);
     }
-    if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive
+    if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive (Cholesky) or collapsed
     if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
   }
   hf.info      = bad;

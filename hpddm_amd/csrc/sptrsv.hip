@@ -1001,8 +1001,11 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   F.alloc((size_t)hf.f_size);
   HH_CHECK((int64_t)hf.F.size() >= hf.f_host, "host panel pool smaller than its prefix");
   if (hf.f_host) HIP_OK(hipMemcpyAsync(F.p, hf.F.data(), (size_t)hf.f_host * sizeof(double), hipMemcpyHostToDevice, s)); // the rest was built in place by the device levels
-  if (kind == FACT_LU) G.upload(hf.G, s);
-  else G.release();
+  if (kind == FACT_LU) {
+    G.alloc((size_t)hf.f_size);
+    HH_CHECK((int64_t)hf.G.size() >= hf.f_host, "host panel pool (G) smaller than its prefix");
+    if (hf.f_host) HIP_OK(hipMemcpyAsync(G.p, hf.G.data(), (size_t)hf.f_host * sizeof(double), hipMemcpyHostToDevice, s));
+  } else G.release();
   if (kind == FACT_LDLT) dinv.upload(hf.dinv, s);
   else dinv.release();
   HH_CHECK(hf.sym.rows.size() < (size_t)2147483647 && hf.gsrc.size() < (size_t)2147483647 && hf.gptr.size() < (size_t)2147483647, "factor index pools exceed 32 bits");
