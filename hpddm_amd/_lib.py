@@ -84,6 +84,10 @@ def _declare(lib):
         "HpddmHipSchwarzRebuildPlan": (I, [P]),
         "HpddmHipSchwarzLevelTimes": (I, [P, I, I, P, I]),
         "HpddmHipSchwarzGetSubdomain": (P, [P, I]),
+        "HpddmHipPanelCreate": (P, [I, I, P, P]),
+        "HpddmHipPanelZtD": (I, [P, P, P, US]),
+        "HpddmHipPanelZ": (I, [P, P, P, US]),
+        "HpddmHipPanelDestroy": (None, [P]),
     }
     missing = []
     for name, (res, args) in sig.items():

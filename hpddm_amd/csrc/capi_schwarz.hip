@@ -7,6 +7,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <sstream>
 
 using namespace hpddm_hip;
@@ -687,6 +688,65 @@ int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
     stats[7] = op.cdim;
     return 0;)
 }
+
+// ---- the deflation panel of ONE subdomain (hook boundary B2: Preconditioner::CoarseCorrection, include/hpddm_hip_coarse.hpp) ----
+struct HpddmHipPanel {
+  Schwarz        op; // one subdomain, no neighbour: only its Z, d and the panel kernels are used
+  DevBuf<double> in_d, out_d, uc_d;
+  HpddmHipPanel() : op(1, 0, 1) { }
+};
+HpddmHipPanel *HpddmHipPanelCreate(int n, int nu, const double *Z, const double *d)
+{
+  try {
+    HH_CHECK(n > 0 && nu > 0 && Z && d, "PanelCreate: bad argument");
+    std::unique_ptr<HpddmHipPanel> P(new HpddmHipPanel);
+    // the matrix of the operator is never used by the panel: an identity keeps build_device() unchanged
+    std::vector<int>    ia(n + 1), ja(n);
+    std::vector<double> a(n, 1.0);
+    for (int i = 0; i < n; ++i) ia[i] = ja[i] = i;
+    ia[n] = n;
+    P->op.set_subdomain(0, n, ia.data(), ja.data(), a.data(), false, 0, 0, nullptr, nullptr, nullptr);
+    P->op.initialize(0, d);
+    P->op.set_vectors(0, nu, Z);
+    P->op.build_device();
+    P->op.upload_vectors();
+    return P.release();
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return nullptr;
+  }
+}
+int HpddmHipPanelZtD(HpddmHipPanel *P, const double *in, double *uc, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(P && in && uc && mu >= 1, "bad argument");
+    Schwarz     &op = P->op;
+    hipStream_t  st = library_stream();
+    const size_t cnt = (size_t)op.ntot * mu;
+    P->in_d.alloc(cnt);
+    P->uc_d.alloc((size_t)op.cdim * mu);
+    HIP_OK(hipMemcpyAsync(P->in_d.p, in, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    op.panel_zt(P->in_d.p, P->uc_d.p, mu);
+    HIP_OK(hipMemcpyAsync(uc, P->uc_d.p, (size_t)op.cdim * mu * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;)
+}
+int HpddmHipPanelZ(HpddmHipPanel *P, const double *y, double *out, unsigned short mu)
+{
+  HH_TRY(
+    HH_CHECK(P && y && out && mu >= 1, "bad argument");
+    Schwarz     &op = P->op;
+    hipStream_t  st = library_stream();
+    const size_t cnt = (size_t)op.ntot * mu;
+    P->out_d.alloc(cnt);
+    P->uc_d.alloc((size_t)op.cdim * mu);
+    HIP_OK(hipMemcpyAsync(P->uc_d.p, y, (size_t)op.cdim * mu * sizeof(double), hipMemcpyHostToDevice, st));
+    op.panel_z(P->uc_d.p, P->out_d.p, mu);
+    HIP_OK(hipMemcpyAsync(out, P->out_d.p, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;)
+}
+void HpddmHipPanelDestroy(HpddmHipPanel *P) { delete P; }
 
 HpddmHipSubdomain *HpddmHipSchwarzGetSubdomain(HpddmHipSchwarz *A, int s)
 {

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ 
   }
 }
 
-void Schwarz::deflation_panel(const double *in, double *zy, int mu)
+// uc (cdim x mu, column-major) = Z^T (D in) for the local subdomains: first gemm of Schwarz::deflation (include/HPDDM_schwarz.hpp:1613-1616)
+void Schwarz::panel_zt(const double *in, double *uc, int mu)
 {
   hipStream_t st = library_stream();
   int         numax = 0;
@@ -204,23 +205,39 @@ void Schwarz::deflation_panel(const double *in, double *zy, int mu)
       const dim3 g((unsigned)nblk, (unsigned)nsub, (unsigned)((std::min(ZT_NU, numax - m0) + 7) / 8));
       if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
       else hipLaunchKernelGGL(k_zt_stream<2>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
-      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc_d.p, mu, cdim, m0, 0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, 0);
     }
-    coarse_solve(uc_d.p, uc2_d.p, mu);
-    const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
-    const size_t l2 = (size_t)numax * mu * sizeof(double);
-    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, cdim);
-    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, cdim);
     return;
   }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
-      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc_d.p, mu, cdim, m0, nu0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
     }
-  coarse_solve(uc_d.p, uc2_d.p, mu);
+}
+
+// zy = Z y, y (cdim x mu, column-major): second gemm of Schwarz::deflation (include/HPDDM_schwarz.hpp:1618)
+void Schwarz::panel_z(const double *y, double *zy, int mu)
+{
+  hipStream_t st = library_stream();
+  int         numax = 0;
+  for (const auto &S : subs) numax = std::max(numax, S.nu);
+  if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
+    const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
+    const size_t l2 = (size_t)numax * mu * sizeof(double);
+    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim);
+    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim);
+    return;
+  }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
-    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, uc2_d.p, zy, mu, cdim, nu0);
+    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0);
+}
+
+void Schwarz::deflation_panel(const double *in, double *zy, int mu)
+{
+  panel_zt(in, uc_d.p, mu);
+  coarse_solve(uc_d.p, uc2_d.p, mu);
+  panel_z(uc2_d.p, zy, mu);
 }
 
 } // namespace hpddm_hip

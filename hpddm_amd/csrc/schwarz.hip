@@ -776,6 +776,18 @@ void Schwarz::build_coarse()
   }
   std::vector<double> Ecopy(E);
   invert_dense(cdim_g, Ecopy, Einv);
+  upload_vectors();
+  Einv_d.upload(Einv.data() + (size_t)coff_g0 * cdim_g, (size_t)cdim * cdim_g, st); // the rows of the local subdomains
+  HIP_OK(hipStreamSynchronize(st));
+  coarse_ready = true;
+}
+
+void Schwarz::upload_vectors()
+{
+  hipStream_t st = library_stream();
+  coff.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
+  cdim = coff[nsub];
   std::vector<double>    zcat;
   std::vector<long long> zoff(nsub);
   std::vector<int>       nus(nsub);
@@ -788,10 +800,8 @@ void Schwarz::build_coarse()
   zoff_d.upload(zoff, st);
   nu_d.upload(nus, st);
   coff_d.upload(coff.data(), nsub, st);
-  Einv_d.upload(Einv.data() + (size_t)coff_g0 * cdim_g, (size_t)cdim * cdim_g, st); // the rows of the local subdomains
   HIP_OK(hipStreamSynchronize(st));
-  mu_cap       = 0; // uc buffers depend on cdim
-  coarse_ready = true;
+  mu_cap = 0; // uc buffers depend on cdim
 }
 
 static inline dim3 grid2(int nmax, int nsub) { return dim3((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub); }

@@ -145,7 +145,10 @@ struct Schwarz {
   void local_solve(const double *in, double *out, int mu);
   void solve_factor(const double *in, double *out, int mu); // plan.solve, plus the row phases of complex operators
   void deflation(const double *in, double *out, int mu);
-  void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip)
+  void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip) = the three below
+  void panel_zt(const double *in, double *uc, int mu);        // uc = Z^T (D in)
+  void panel_z(const double *y, double *zy, int mu);          // zy = Z y
+  void upload_vectors();                                      // Z, its offsets and the local coarse numbering to the device
   void coarse_solve(const double *uc, double *y, int mu);     // y = E^{-1} uc
   void apply(const double *in, double *out, int mu);
   void diag(const double *in, double *out, int mu);

@@ -202,6 +202,22 @@ int HpddmHipRcclSelfTest(void);
 /* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc" */
 long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The deflation panel of one subdomain, for the run-time hook of the reference: Preconditioner::CoarseCorrection
+ * (include/HPDDM_preconditioner.hpp:293-303; Schwarz::deflation becomes (*cc_)(in, out, dof_, mu), include/HPDDM_schwarz.hpp:1606-1609).
+ * include/hpddm_hip_coarse.hpp builds HPDDM::HipCoarseCorrection on these: the two tall-skinny contractions of the coarse
+ * correction (the Blas::gemm calls of include/HPDDM_schwarz.hpp:1615 and :1618) run on the MI355X, the coarse solve and the halo
+ * stay with the reference's own CoarseOperator and Subdomain::exchange.  Z (n x nu, column-major = *Preconditioner::ev_) and d
+ * (Schwarz::d_) are copied to HBM once; vectors are host pointers, column-major with leading dimension n (nu for uc / y).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct HpddmHipPanel HpddmHipPanel;
+HpddmHipPanel *HpddmHipPanelCreate(int n, int nu, const double *Z, const double *d);
+/* uc (nu x mu) = Z^T (D in) */
+int HpddmHipPanelZtD(HpddmHipPanel *P, const double *in, double *uc, unsigned short mu);
+/* out (n x mu) = Z y,  y (nu x mu) */
+int  HpddmHipPanelZ(HpddmHipPanel *P, const double *y, double *out, unsigned short mu);
+void HpddmHipPanelDestroy(HpddmHipPanel *P);
+
 /* Device-pointer variants of the hot calls (vectors already resident in HBM, asynchronous on the library stream) */
 int HpddmHipSchwarzApplyDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);
 int HpddmHipSchwarzGMVDevice(HpddmHipSchwarz *A, const double *in_dev, double *out_dev, unsigned short mu);

@@ -15,6 +15,9 @@
  *        -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0 ...]
  */
 #include "schwarz.hpp" /* the reference's examples/schwarz.hpp: typedef K, symCoarse, generate() prototype */
+#ifdef HIP_COARSE_CORRECTION
+  #include "hpddm_hip_coarse.hpp" /* drop-in check of the run-time hook: Preconditioner::cc_ = HPDDM::HipCoarseCorrection (Makefile.ref: ref_harness_hipcc) */
+#endif
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -176,6 +179,9 @@ int main(int argc, char **argv)
     A.setVectors(deflation);
     A.super::initialize(nu);
     A.buildTwo(MPI_COMM_WORLD);
+#ifdef HIP_COARSE_CORRECTION
+    A.cc_ = new HPDDM::HipCoarseCorrection<RefSchwarzBase>(A); /* owned by A (include/HPDDM_preconditioner.hpp:406-407) */
+#endif
   }
   meta[7] = nu;
   dumpi("meta", meta, 8);

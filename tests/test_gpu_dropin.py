@@ -104,3 +104,35 @@ def test_unchanged_c_example_single_rank_direct_solve():
     out = _run(1, "-Nx 40 -Ny 40", exe="schwarz_c_hip")
     r = re.search(r"--- residual = (\S+) / (\S+)", out)
     assert r and float(r.group(1)) / float(r.group(2)) <= 1e-6
+
+
+def _parse_dump(path):
+    import numpy as np
+    out, lines, i = {}, open(path).read().split("\n"), 0
+    while i < len(lines):
+        if lines[i].startswith("@"):
+            name, kind, cnt = lines[i][1:].split()
+            cnt = int(cnt)
+            out[name] = np.array(lines[i + 1:i + 1 + cnt], dtype=np.float64 if kind == "f" else np.int32)
+            i += 1 + cnt
+        else:
+            i += 1
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_harness_hipcc")), reason="oracle/_ref/ref_harness_hipcc not built")
+@pytest.mark.parametrize("name,ranks,mu,its", [("p40_deflated", 4, 1, 17), ("p30_6ranks_deflated_nu3", 6, 2, None), ("p40_bgmres_deflated_mu2", 4, 2, None)])
+def test_coarse_correction_hook_runs_the_deflation_on_the_device(name, ranks, mu, its, tmp_path):
+    """Boundary B2: Preconditioner::cc_ = HPDDM::HipCoarseCorrection (include/hpddm_hip_coarse.hpp) inside the reference's own
+    two-level Schwarz object -- local solves through HipSub, the two contractions of Schwarz::deflation through the panel
+    kernels, coarse solve and halo by the reference.  Same deflation output, preconditioner apply, iteration count and solution
+    as the pure reference run the golden fixture was dumped from (17 iterations on the 40 x 40 case)."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    _run(ranks, f"-out {tmp_path} -case hook -mu {mu} -hpddm_verbosity=1 " + str(g["options"]), exe="ref_harness_hipcc")
+    for r in range(ranks):
+        d = _parse_dump(os.path.join(tmp_path, f"hook_r{r}.txt"))
+        for key, tol in (("deflation_out", 1e-11), ("apply_out", 1e-9), ("sol", 1e-6)):
+            ref = g[f"{key}_r{r}"]
+            assert np.abs(d[key] - ref).max() <= tol * max(1e-300, np.abs(ref).max()), (key, r)
+        assert int(d["iterations"][0]) == int(g["iterations_r0"][0]) and (its is None or int(d["iterations"][0]) == its)

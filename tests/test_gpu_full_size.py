@@ -1,0 +1,130 @@
+"""BASELINE.json configs[2], configs[3] and configs[4] at the sizes they state (for the multi-GPU ones: the share of one GPU),
+through size-independent properties -- the oracle does not reach these sizes: residual of the direct solves, partition of
+unity, linearity of the (two-level) apply, Krylov iteration counts and TRUE residuals.  configs[1] at full size is
+tests/test_gpu_parity.py::test_full_size_properties_config2."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from hpddm_amd import hpddm
+from hpddm_amd.generate import generate3d, generate_elasticity3d
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol, what):
+    scale = max(np.abs(v).max() for v in b)
+    err = max(np.abs(u - v).max() for u, v in zip(a, b)) / scale
+    assert err <= tol, (what, err)
+
+
+def _full(sd, a=None, ia=None, ja=None):
+    a = sd["a"] if a is None else a
+    M = sp.csr_matrix((a, sd["ja"] if ja is None else ja, sd["ia"] if ia is None else ia), shape=(sd["n"], sd["n"]))
+    return M + sp.tril(M, -1).T if sd["sym"] else M
+
+
+def test_configs_2_poisson_256_two_level_geneo():
+    """configs[2]: 3-D Poisson 256^3, 8 subdomains of 129^3 on one GPU, two-level RAS with the GenEO space (nu = 20 per subdomain,
+    Schwarz::solveGEVP on the device, coarse dimension 160).  97 GB of factor; about three minutes."""
+    subs = generate3d(256, 8, 1, sym=True, rhs="smooth", neumann=True)
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    A.call_numfact()
+    st = A.stats()
+    assert st["n"] == 8 * 129 ** 3 and st["nnz_L"] > 1.1e10
+    f = [s["f"] for s in subs]
+    x = A.local_solve(f)
+    M = _full(subs[3])
+    assert np.linalg.norm(M @ x[3] - f[3]) / np.linalg.norm(f[3]) < 1e-10            # the direct solve of a 129^3 subdomain
+    ones = [np.ones(s["n"]) for s in subs]
+    _close(A.exchange(ones), ones, 1e-14, "partition of unity")
+    it1, sol1 = A.solve(f)
+    res1 = A.compute_residual(sol1, f)
+    assert abs(it1 - 38) <= 1 and res1[1] / res1[0] <= 2e-6                            # one-level: 38 iterations
+    # GenEO: the nu lowest eigenpairs of (A_Neumann, B) of every subdomain, checked through their Rayleigh quotients
+    A.set_option("geneo_nu", 20)
+    for s, sd in enumerate(subs):
+        lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], sd["sym"])
+        assert len(lam) == 20 and np.all(np.diff(lam) >= -1e-12) and lam[0] > -1e-10 and lam[-1] < 0.2
+    A.build_coarse_operator()
+    assert int(A.stats()["coarse_dim"]) == 160
+    A.option_parse("-hpddm_schwarz_coarse_correction deflated")
+    rng = np.random.default_rng(3)
+    u = [rng.random(s["n"]) for s in subs]
+    v = [rng.random(s["n"]) for s in subs]
+    au, av = A.apply(u), A.apply(v)
+    comb = A.apply([2.0 * a - 3.0 * b for a, b in zip(u, v)])
+    _close(comb, [2.0 * a - 3.0 * b for a, b in zip(au, av)], 1e-10, "linearity of the two-level apply")
+    it2, sol2 = A.solve(f)
+    res2 = A.compute_residual(sol2, f)
+    assert abs(it2 - 20) <= 1 and res2[1] / res2[0] <= 2e-6                            # two-level: 20 iterations
+    _close(sol2, sol1, 2e-5, "the one- and two-level solutions agree")
+    A.destroy()
+
+
+def test_configs_3_share_elasticity_64_nodes_geneo():
+    """configs[3] (3-D linear elasticity 128^3 nodes, 64 subdomains across 8 GPUs): the share of one GPU, 64^3 nodes = 8 subdomains
+    of 33^3 nodes x 3 dofs (block-3 CSR expanded), two-level RAS + GenEO (nu = 12: 6 of them the rigid-body modes of the floating
+    subdomains).  The cross-GPU layout itself is tests/test_distributed.py."""
+    subs = generate_elasticity3d(64, 8, overlap=1, sym=True, normalize=True, neumann=True)
+    assert all(s["n"] == 3 * 33 ** 3 for s in subs)
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd", multiplicity=False)
+    A.call_numfact()
+    rng = np.random.default_rng(5)
+    f = A.exchange([rng.random(s["n"]) for s in subs])                                 # a consistent right-hand side
+    x = A.local_solve(f)
+    M = _full(subs[0])
+    assert np.linalg.norm(M @ x[0] - f[0]) / np.linalg.norm(f[0]) < 1e-9
+    ones = [np.ones(s["n"]) for s in subs]
+    _close(A.exchange(ones), ones, 1e-13, "partition of unity")
+    it1, sol1 = A.solve(f)
+    A.set_option("geneo_nu", 12)
+    for s, sd in enumerate(subs):
+        lam = A.solve_gevp(s, sd["n"], sd["ia_neumann"], sd["ja_neumann"], sd["a_neumann"], sd["sym"])
+        assert len(lam) == 12
+    A.build_coarse_operator()
+    A.option_parse("-hpddm_schwarz_coarse_correction deflated")
+    it2, sol2 = A.solve(f)
+    res2 = A.compute_residual(sol2, f)
+    assert it2 < it1 and it2 <= 0.6 * it1 and res2[1] / res2[0] <= 5e-6, (it1, it2, res2)
+    _close(sol2, sol1, 1e-4, "the one- and two-level solutions agree")
+    A.destroy()
+
+
+def test_configs_4_share_helmholtz_complex_block_gmres_8_rhs():
+    """configs[4] (Helmholtz 3-D complex<double> 128^3, 32 subdomains on 4 GPUs, Block GMRES with 8 right-hand sides): the share of
+    one GPU, a 64 x 64 x 128 block = 8 subdomains of 32 x 32 x 64 cells, complex symmetric shifted Laplacian with absorption,
+    plane-wave coarse space (the slot the reference fills with DtN vectors, include/HPDDM_schwarz.hpp:665-666)."""
+    base = generate3d((64, 64, 128), 8, 1, sym=False, rhs="smooth", grid=(2, 2, 2))
+    shift = 0.97 + 0.03j   # k h = 0.42 (15 points per wavelength), absorption as in the small case of tests/test_complex.py
+    subs, Z = [], []
+    for r, sd in enumerate(base):
+        sd = dict(sd)
+        a = sd["a"].astype(np.complex128)
+        rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
+        a[rows == sd["ja"]] *= shift
+        sd["a"] = a
+        subs.append(sd)
+        t = np.arange(sd["n"], dtype=np.float64)
+        Z.append(np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * r)], axis=1))
+    mu = 8
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_coarse_correction deflated -hpddm_krylov_method bgmres -hpddm_gmres_restart 30 -hpddm_max_it 200")
+    assert A.complex
+    for s, z in enumerate(Z):
+        A.set_vectors(s, z)
+    A.call_numfact()
+    A.build_coarse_operator()
+    rng = np.random.default_rng(17)
+    f = A.exchange([rng.standard_normal((sd["n"], mu)) + 1j * rng.standard_normal((sd["n"], mu)) for sd in subs])
+    x = A.local_solve(f)
+    M = _full(subs[5])
+    assert np.linalg.norm(M @ x[5] - f[5]) / np.linalg.norm(f[5]) < 1e-9              # complex direct solves, 8 right-hand sides at once
+    u = [rng.standard_normal((sd["n"], 2)) + 1j * rng.standard_normal((sd["n"], 2)) for sd in subs]
+    au = A.apply(u)
+    comb = A.apply([(2.0 - 1.0j) * a for a in u])
+    _close(comb, [(2.0 - 1.0j) * a for a in au], 1e-10, "complex linearity of the two-level apply")
+    it, sol = A.solve(f)
+    assert 0 < it < 200
+    res = A.compute_residual(sol, f).reshape(mu, 2)
+    assert np.all(res[:, 1] <= 1e-4 * res[:, 0]), res                                  # true residuals of the 8 right-hand sides
+    A.destroy()
