@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <vector>
 
@@ -83,12 +84,33 @@ static inline void micro(int mr, int nr, int kc, double alpha, const double *A, 
   }
 }
 
+// complex B, real view: the packed sliver holds the real-equivalent embedding of op(B), element (k, j) of the 2K x 2N real matrix
+//     [ br  bi ]           so that a row (ar, ai) of the real view of A times it gives (ar br - ai bi, ar bi + ai br),
+//     [-bi  br ]           the real view of the complex product: one real GEMM with the optimal 8 flops per complex FMA
+static inline void pack_b_z(const std::complex<double> *B, long ldb, bool transB, int k0, int kc, int j0, int nr, double *Bp)
+{
+  for (int k = 0; k < kc; ++k) {
+    const int kk = (k0 + k) >> 1, p = (k0 + k) & 1;
+    double   *dst = Bp + (long)k * NR;
+    int       j   = 0;
+    for (; j < nr; ++j) {
+      const int                  jj = (j0 + j) >> 1, q = (j0 + j) & 1;
+      const std::complex<double> b  = transB ? B[(long)jj * ldb + kk] : B[(long)kk * ldb + jj];
+      dst[j] = p == q ? b.real() : (p == 0 ? b.imag() : -b.imag());
+    }
+    for (; j < NR; ++j) dst[j] = 0.0;
+  }
+}
+
 // C(M x N) += alpha * A(M x K) * op(B),  op(B) = B (K x N) or B^T (B is N x K) ; all row-major.
 // lower_only: C is square-ish and only blocks touching the lower triangle (col <= row, with global offsets ci0/cj0) are needed.
-// par: use OpenMP over row panels.
-static inline void gemm(int M, int N, int K, double alpha, const double *A, long lda, const double *B, long ldb, bool transB, double *C, long ldc, bool par, bool lower_only = false, int ci0 = 0, int cj0 = 0)
+// par: use OpenMP over row panels.  ZB: B is complex and M, N, K, lda, ldc describe the REAL views (N and K doubled, columns of C
+// in pairs); ldb stays in complex scalars.
+template <bool ZB>
+static inline void gemm_impl(int M, int N, int K, double alpha, const double *A, long lda, const void *Bv, long ldb, bool transB, double *C, long ldc, bool par, bool lower_only, int ci0, int cj0)
 {
   if (M <= 0 || N <= 0 || K <= 0) return;
+  constexpr int CS = ZB ? 2 : 1; // real columns per scalar column (the lower_only tests compare scalar indices)
   const int NC = 20 * NR; // B block of KC x NC doubles = 480 KB stays in L2 while the rows of A stream by
 #pragma omp parallel if (par)
   {
@@ -100,24 +122,36 @@ static inline void gemm(int M, int N, int K, double alpha, const double *A, long
       const int nslv = (nc + NR - 1) / NR;
       // first row that touches the lower triangle for this column block
       int ifirst = 0;
-      if (lower_only) ifirst = std::max(0, ((cj0 + jc - ci0) / MR) * MR);
+      if (lower_only) ifirst = std::max(0, ((cj0 + jc / CS - ci0) / MR) * MR);
       if (ifirst >= M) continue;
       for (int k0 = 0; k0 < K; k0 += KC) {
         const int kc = std::min(KC, K - k0);
         // every thread packs its own copy of the B block: cheap relative to the M-loop, avoids sharing
-        for (int s = 0; s < nslv; ++s) pack_b(B, ldb, transB, k0, kc, jc + s * NR, std::min(NR, nc - s * NR), Bp + (size_t)s * KC * NR);
+        for (int s = 0; s < nslv; ++s) {
+          if (ZB) pack_b_z((const std::complex<double> *)Bv, ldb, transB, k0, kc, jc + s * NR, std::min(NR, nc - s * NR), Bp + (size_t)s * KC * NR);
+          else pack_b((const double *)Bv, ldb, transB, k0, kc, jc + s * NR, std::min(NR, nc - s * NR), Bp + (size_t)s * KC * NR);
+        }
 #pragma omp for schedule(dynamic, 8)
         for (int i0 = ifirst; i0 < M; i0 += MR) {
           const int mr = std::min(MR, M - i0);
           for (int s = 0; s < nslv; ++s) {
             const int j0 = jc + s * NR;
-            if (lower_only && cj0 + j0 > ci0 + i0 + mr - 1) break;
+            if (lower_only && cj0 + j0 / CS > ci0 + i0 + mr - 1) break;
             micro(mr, std::min(NR, N - j0), kc, alpha, A + (long)i0 * lda + k0, lda, Bp + (size_t)s * KC * NR, C + (long)i0 * ldc + j0, ldc);
           }
         }
       }
     }
   }
+}
+static inline void gemm(int M, int N, int K, double alpha, const double *A, long lda, const double *B, long ldb, bool transB, double *C, long ldc, bool par, bool lower_only = false, int ci0 = 0, int cj0 = 0)
+{
+  gemm_impl<false>(M, N, K, alpha, A, lda, B, ldb, transB, C, ldc, par, lower_only, ci0, cj0);
+}
+// complex scalars (op(B) = B or its plain transpose, no conjugation): one real GEMM on the real views of A and C
+static inline void gemm(int M, int N, int K, double alpha, const std::complex<double> *A, long lda, const std::complex<double> *B, long ldb, bool transB, std::complex<double> *C, long ldc, bool par, bool lower_only = false, int ci0 = 0, int cj0 = 0)
+{
+  gemm_impl<true>(M, 2 * N, 2 * K, alpha, reinterpret_cast<const double *>(A), 2 * lda, B, ldb, transB, reinterpret_cast<double *>(C), 2 * ldc, par, lower_only, ci0, cj0);
 }
 
 // ---- small unblocked kernels on a diagonal tile T (nb x nb, row-major, ld) ----
@@ -146,40 +180,42 @@ static inline bool potf2(int nb, double *T, long ld)
 // fine.  Pivots that are merely small are caught by the backward-error probe of LocalSolver::numfact.
 static constexpr double PIVOT_TOL = 1.0e-13;
 // LDL^T without pivoting: T = L D L^T, unit lower L stored strictly below the diagonal, D on the diagonal
-static inline bool ldlf2(int nb, double *T, long ld)
+template <class S>
+static inline bool ldlf2(int nb, S *T, long ld)
 {
-  std::vector<double> w(nb);
+  std::vector<S> w(nb);
   for (int j = 0; j < nb; ++j) {
-    double d = T[(long)j * ld + j];
+    S d = T[(long)j * ld + j];
     for (int k = 0; k < j; ++k) {
       w[k] = T[(long)j * ld + k] * T[(long)k * ld + k];
       d -= T[(long)j * ld + k] * w[k];
     }
     double cmax = 0.0;
     for (int i = j + 1; i < nb; ++i) {
-      double s = T[(long)i * ld + j];
+      S s = T[(long)i * ld + j];
       for (int k = 0; k < j; ++k) s -= T[(long)i * ld + k] * w[k];
       T[(long)i * ld + j] = s;
       cmax               = std::max(cmax, std::abs(s));
     }
-    if (!(std::abs(d) > PIVOT_TOL * cmax) || d == 0.0) return false; // zero, collapsed or NaN
+    if (!(std::abs(d) > PIVOT_TOL * cmax) || d == S(0)) return false; // zero, collapsed or NaN
     T[(long)j * ld + j] = d;
-    const double inv    = 1.0 / d;
+    const S inv         = S(1) / d;
     for (int i = j + 1; i < nb; ++i) T[(long)i * ld + j] *= inv;
   }
   return true;
 }
 // LU without pivoting: T = L U, unit lower L strictly below, U on and above the diagonal
-static inline bool getf2(int nb, double *T, long ld)
+template <class S>
+static inline bool getf2(int nb, S *T, long ld)
 {
   for (int j = 0; j < nb; ++j) {
-    const double p = T[(long)j * ld + j];
+    const S p = T[(long)j * ld + j];
     double       cmax = 0.0;
     for (int i = j + 1; i < nb; ++i) cmax = std::max(cmax, std::max(std::abs(T[(long)i * ld + j]), std::abs(T[(long)j * ld + i])));
-    if (!(std::abs(p) > PIVOT_TOL * cmax) || p == 0.0) return false; // zero, collapsed or NaN
-    const double inv = 1.0 / p;
+    if (!(std::abs(p) > PIVOT_TOL * cmax) || p == S(0)) return false; // zero, collapsed or NaN
+    const S inv = S(1) / p;
     for (int i = j + 1; i < nb; ++i) {
-      const double l     = T[(long)i * ld + j] * inv;
+      const S l          = T[(long)i * ld + j] * inv;
       T[(long)i * ld + j] = l;
       for (int k = j + 1; k < nb; ++k) T[(long)i * ld + k] -= l * T[(long)j * ld + k];
     }
@@ -187,13 +223,14 @@ static inline bool getf2(int nb, double *T, long ld)
   return true;
 }
 // rows X(m x nb) <- X * L^{-T}  (L lower nb x nb; unit = implicit ones on the diagonal), optionally then * D^{-1}
-static inline void trsm_right_lower_trans(int m, int nb, const double *L, long ldl, bool unit, const double *dscale, double *X, long ldx, bool par)
+template <class S>
+static inline void trsm_right_lower_trans(int m, int nb, const S *L, long ldl, bool unit, const S *dscale, S *X, long ldx, bool par)
 {
 #pragma omp parallel for if (par) schedule(static)
   for (int i = 0; i < m; ++i) {
-    double *x = X + (long)i * ldx;
+    S *x = X + (long)i * ldx;
     for (int j = 0; j < nb; ++j) {
-      double s = x[j];
+      S s = x[j];
       for (int k = 0; k < j; ++k) s -= x[k] * L[(long)j * ldl + k];
       x[j] = unit ? s : s / L[(long)j * ldl + j];
     }
@@ -202,30 +239,32 @@ static inline void trsm_right_lower_trans(int m, int nb, const double *L, long l
   }
 }
 // rows X(m x nb) <- X * U^{-1}  (U upper nb x nb, non-unit)
-static inline void trsm_right_upper(int m, int nb, const double *U, long ldu, double *X, long ldx, bool par)
+template <class S>
+static inline void trsm_right_upper(int m, int nb, const S *U, long ldu, S *X, long ldx, bool par)
 {
 #pragma omp parallel for if (par) schedule(static)
   for (int i = 0; i < m; ++i) {
-    double *x = X + (long)i * ldx;
+    S *x = X + (long)i * ldx;
     for (int j = 0; j < nb; ++j) {
-      double s = x[j];
+      S s = x[j];
       for (int k = 0; k < j; ++k) s -= x[k] * U[(long)k * ldu + j];
       x[j] = s / U[(long)j * ldu + j];
     }
   }
 }
 // in-place inverse of a small lower-triangular tile (unit: implicit ones, result also unit with ones NOT stored)
-static inline void trti2_lower(int nb, double *T, long ld, bool unit)
+template <class S>
+static inline void trti2_lower(int nb, S *T, long ld, bool unit)
 {
   for (int j = 0; j < nb; ++j) {
-    const double djj = unit ? 1.0 : 1.0 / T[(long)j * ld + j];
+    const S djj = unit ? S(1) : S(1) / T[(long)j * ld + j];
     if (!unit) T[(long)j * ld + j] = djj;
     // column j of the inverse below the diagonal: X(i,j) = -X(i,i) * sum_{k=j..i-1} L(i,k) X(k,j)
     for (int i = j + 1; i < nb; ++i) {
-      double s = T[(long)i * ld + j] * djj;
+      S s = T[(long)i * ld + j] * djj;
       for (int k = j + 1; k < i; ++k) s += T[(long)i * ld + k] * T[(long)k * ld + j];
       // note: T(k,j) for j<k<i already holds X(k,j); T(i,k) for k>j is still L(i,k) because columns are done left to right
-      T[(long)i * ld + j] = -s * (unit ? 1.0 : 1.0 / T[(long)i * ld + i]);
+      T[(long)i * ld + j] = -s * (unit ? S(1) : S(1) / T[(long)i * ld + i]);
     }
   }
 }

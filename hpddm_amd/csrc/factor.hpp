@@ -24,6 +24,8 @@ enum FactKind { FACT_CHOL = 0, FACT_LDLT = 1, FACT_LU = 2 };
 struct HostFactor {
   idx_t    n = 0;
   FactKind kind = FACT_CHOL;
+  bool     cplx = false; // K = std::complex<double>: n, offsets and leading dimensions count complex scalars, the pools F / G / dinv /
+                         // Lplain / Uplain hold interleaved (re, im) pairs (2 doubles per scalar)
   Ordering ord;
   Symbolic sym;
   // block order used for storage: blocks sorted by (height, index); pos_of[k] = position of block k in that order
@@ -56,6 +58,7 @@ struct CsrView {
   const double *a;
   bool          sym;
   int           base; // 0 ('C') or 1 ('F')
+  bool          cplx = false; // a holds nnz interleaved (re, im) pairs; sym then means complex SYMMETRIC (MatrixCSR::sym_), no conjugation
 };
 
 // Upper levels of the elimination tree factorised on the device (numeric_device.hip).  numeric_host.cpp drives it through

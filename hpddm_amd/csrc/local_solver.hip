@@ -3,6 +3,7 @@
 #include "local_solver.hpp"
 #include <chrono>
 #include <cmath>
+#include <complex>
 
 namespace hpddm_hip {
 
@@ -42,7 +43,8 @@ static bool is_symmetric(const CsrView &A)
         it = std::find(b, e, i + A.base);
         if (it == e) return false;
       }
-      if (A.a[it - A.ja] != A.a[p]) return false;
+      const size_t q = (size_t)(it - A.ja);
+      if (A.cplx ? (A.a[2 * q] != A.a[2 * (size_t)p] || A.a[2 * q + 1] != A.a[2 * (size_t)p + 1]) : A.a[q] != A.a[p]) return false;
     }
   return true;
 }
@@ -110,7 +112,9 @@ void LocalSolver::numfact(const CsrView &A, int spd)
 {
   analyse(A);
   FactKind kind;
-  if (A.sym || is_symmetric(A)) kind = spd ? FACT_CHOL : FACT_LDLT;
+  // complex scalars: a complex SYMMETRIC matrix (MatrixCSR::sym_, or equal values across the diagonal) is factorised as L D L^T
+  // with plain transposes -- also when -hpddm_operator_spd is set --, anything else (Hermitian included) as LU
+  if (A.sym || is_symmetric(A)) kind = (spd && !A.cplx) ? FACT_CHOL : FACT_LDLT;
   else kind = FACT_LU;
   if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
   // the upper levels of the tree (large fronts) are factorised on the device, the lower ones on the host (all three kinds)
@@ -120,7 +124,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   auto                          device_levels = [&](FactKind kd) {
     devlev.reset();
     first_dev = (idx_t)host.level_ptr.size() - 1;
-    if (!on_device) return;
+    if (!on_device || A.cplx) return; // complex scalars: every level on the host
     first_dev = pick_first_device_level(host);
     if (first_dev < (idx_t)host.level_ptr.size() - 1) {
       dev.F.alloc((size_t)host.f_size);
@@ -161,13 +165,17 @@ void LocalSolver::numfact(const CsrView &A, int spd)
 // close to an eigenvalue of a leading block) end here instead of returning wrong values silently.
 void LocalSolver::probe(const CsrView &A, FactKind kind)
 {
-  const idx_t         n = A.n;
-  std::vector<double> b((size_t)n, 0.0), x((size_t)n), r((size_t)n, 0.0), rowsum((size_t)n, 0.0);
-  auto                spmv = [&](const double *v, double *out, double *absrow) {
+  typedef std::complex<double> Z;
+  const idx_t    n = A.n;
+  const int      sc = A.cplx ? 2 : 1;
+  std::vector<Z> b((size_t)n, Z(0)), x((size_t)n), r((size_t)n, Z(0)), x0((size_t)n);
+  std::vector<double> rowsum((size_t)n, 0.0);
+  auto val = [&](idx_t p) { return A.cplx ? Z(A.a[2 * (size_t)p], A.a[2 * (size_t)p + 1]) : Z(A.a[p], 0.0); };
+  auto spmv = [&](const Z *v, Z *out, double *absrow) {
     for (idx_t i = 0; i < n; ++i)
       for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
-        const idx_t  j = A.ja[p] - A.base;
-        const double a = A.a[p];
+        const idx_t j = A.ja[p] - A.base;
+        const Z     a = val(p);
         out[i] += a * v[j];
         if (absrow) absrow[i] += std::abs(a);
         if (A.sym && j != i) {
@@ -176,13 +184,21 @@ void LocalSolver::probe(const CsrView &A, FactKind kind)
         }
       }
   };
-  std::vector<double> x0((size_t)n);
   for (idx_t i = 0; i < n; ++i) {
-    const double t = 0.6180339887498949 * (double)(i + 1);
-    x0[i]          = 0.5 + (t - std::floor(t));
+    const double t = 0.6180339887498949 * (double)(i + 1), u = 0.7548776662466927 * (double)(i + 1);
+    x0[i]          = Z(0.5 + (t - std::floor(t)), A.cplx ? (u - std::floor(u)) - 0.5 : 0.0);
   }
   spmv(x0.data(), b.data(), rowsum.data());
-  solve_host(b.data(), x.data(), 1);
+  {
+    // the solver's vectors: real arrays, or interleaved (re, im) pairs
+    std::vector<double> bb((size_t)n * sc), xx((size_t)n * sc);
+    for (idx_t i = 0; i < n; ++i) {
+      bb[(size_t)sc * i] = b[i].real();
+      if (sc == 2) bb[2 * (size_t)i + 1] = b[i].imag();
+    }
+    solve_host(bb.data(), xx.data(), 1);
+    for (idx_t i = 0; i < n; ++i) x[i] = Z(xx[(size_t)sc * i], sc == 2 ? xx[2 * (size_t)i + 1] : 0.0);
+  }
   spmv(x.data(), r.data(), nullptr);
   double rn = 0.0, an = 0.0, xn = 0.0, bn = 0.0;
   for (idx_t i = 0; i < n; ++i) {
@@ -210,7 +226,7 @@ void LocalSolver::solve_device(const double *b, double *x, int mu)
 void LocalSolver::solve_host(const double *b, double *x, int mu)
 {
   HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");
-  const size_t cnt = (size_t)host.n * mu;
+  const size_t cnt = (size_t)host.n * mu * (host.cplx ? 2 : 1);
   hipStream_t  s   = library_stream();
   bdev.alloc(cnt);
   HIP_OK(hipMemcpyAsync(bdev.p, b, cnt * sizeof(double), hipMemcpyHostToDevice, s));

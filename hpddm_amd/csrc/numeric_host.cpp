@@ -10,6 +10,7 @@
 #include "dense_host.hpp"
 #include "factor.hpp"
 #include <chrono>
+#include <complex>
 #include <cstring>
 #include <omp.h>
 
@@ -233,15 +234,18 @@ struct BlockPool {
   }
 };
 
+template <class T>
 struct PermutedMatrix {
   // entries of the permuted matrix with row >= col, grouped by column ("low"), and row < col grouped by row ("upp", LU only)
   std::vector<int64_t> lptr, uptr;
   std::vector<idx_t>   lrow, ucol;
-  std::vector<double>  lval, uval;
+  std::vector<T>       lval, uval;
 };
 
-void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, PermutedMatrix &P)
+template <class T>
+void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, PermutedMatrix<T> &P)
 {
+  const T *const Aval = reinterpret_cast<const T *>(A.a); // complex matrices: interleaved (re, im) pairs
   const idx_t n = A.n;
   P.lptr.assign(n + 1, 0);
   P.uptr.assign(n + 1, 0);
@@ -252,12 +256,12 @@ void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, Perm
         const idx_t pi = ord.iperm[i], pj = ord.iperm[j];
         if (A.sym) {
           // stored entry stands for (i,j) and (j,i)
-          f(std::max(pi, pj), std::min(pi, pj), A.a[p]);
-          if (need_upper && pi != pj) f(std::min(pi, pj), std::max(pi, pj), A.a[p]);
-        } else if (pi >= pj || need_upper) f(pi, pj, A.a[p]);
+          f(std::max(pi, pj), std::min(pi, pj), Aval[p]);
+          if (need_upper && pi != pj) f(std::min(pi, pj), std::max(pi, pj), Aval[p]);
+        } else if (pi >= pj || need_upper) f(pi, pj, Aval[p]);
       }
   };
-  visit([&](idx_t r, idx_t c, double) {
+  visit([&](idx_t r, idx_t c, const T &) {
     if (r >= c) ++P.lptr[c + 1];
     else ++P.uptr[r + 1];
   });
@@ -270,7 +274,7 @@ void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, Perm
   P.ucol.resize(P.uptr[n]);
   P.uval.resize(P.uptr[n]);
   std::vector<int64_t> lp(P.lptr.begin(), P.lptr.end() - 1), up(P.uptr.begin(), P.uptr.end() - 1);
-  visit([&](idx_t r, idx_t c, double v) {
+  visit([&](idx_t r, idx_t c, const T &v) {
     if (r >= c) {
       P.lrow[lp[c]]   = r;
       P.lval[lp[c]++] = v;
@@ -282,39 +286,41 @@ void build_permuted(const CsrView &A, const Ordering &ord, bool need_upper, Perm
 }
 
 // in-place inverse of the lower-triangular w x w block T (row-major, ld), strictly-upper part must be zero
-void invert_lower(idx_t w, double *T, long ld, bool unit, bool par, std::vector<double> &tmp)
+template <class S>
+void invert_lower(idx_t w, S *T, long ld, bool unit, bool par, std::vector<S> &tmp)
 {
   const int NB = 64;
   for (idx_t i0 = 0; i0 < w; i0 += NB) {
     const idx_t ib = std::min<idx_t>(NB, w - i0);
-    double     *Ti = T + (long)i0 * ld;
+    S          *Ti = T + (long)i0 * ld;
     if (i0 > 0) {
-      tmp.assign((size_t)ib * i0, 0.0);
+      tmp.assign((size_t)ib * i0, S(0));
       dense::gemm(ib, i0, i0, 1.0, Ti, ld, T, ld, false, tmp.data(), i0, par);
     }
     dense::trti2_lower(ib, Ti + i0, ld, unit);
     if (unit)
-      for (idx_t i = 0; i < ib; ++i) Ti[(long)i * ld + i0 + i] = 1.0;
+      for (idx_t i = 0; i < ib; ++i) Ti[(long)i * ld + i0 + i] = S(1);
     if (i0 > 0) {
-      for (idx_t i = 0; i < ib; ++i) std::fill_n(Ti + (long)i * ld, i0, 0.0);
+      for (idx_t i = 0; i < ib; ++i) std::fill_n(Ti + (long)i * ld, i0, S(0));
       dense::gemm(ib, i0, ib, -1.0, Ti + i0, ld, tmp.data(), i0, false, Ti, ld, par);
     }
   }
 }
 
 // B(m x w) <- B * X, X lower-triangular w x w (row-major)
-void right_multiply_lower(idx_t m, idx_t w, double *B, long ldb, const double *X, long ldx, bool par)
+template <class S>
+void right_multiply_lower(idx_t m, idx_t w, S *B, long ldb, const S *X, long ldx, bool par)
 {
   const idx_t RB = 128;
   const idx_t nchunk = (m + RB - 1) / RB;
 #pragma omp parallel if (par)
   {
-    static thread_local std::vector<double> tmp;
+    static thread_local std::vector<S> tmp;
     if (tmp.size() < (size_t)RB * w) tmp.resize((size_t)RB * w);
 #pragma omp for schedule(dynamic, 1)
     for (idx_t c = 0; c < nchunk; ++c) {
       const idx_t r0 = c * RB, rb = std::min(RB, m - r0);
-      std::fill(tmp.begin(), tmp.begin() + (size_t)rb * w, 0.0);
+      std::fill(tmp.begin(), tmp.begin() + (size_t)rb * w, S(0));
       dense::gemm(rb, w, w, 1.0, B + (long)r0 * ldb, ldb, X, ldx, false, tmp.data(), w, false);
       for (idx_t i = 0; i < rb; ++i) std::copy_n(tmp.data() + (size_t)i * w, w, B + (long)(r0 + i) * ldb);
     }
@@ -338,7 +344,8 @@ idx_t pick_first_device_level(const HostFactor &hf)
   return nlev;
 }
 
-void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev, idx_t first_device_level)
+template <class T>
+static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev, idx_t first_device_level)
 {
   const double    t0   = now();
   const Symbolic &s    = hf.sym;
@@ -346,22 +353,24 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
   hf.kind              = kind;
   hf.info              = 0;
   const bool lu        = (kind == FACT_LU);
-  PermutedMatrix P;
-  build_permuted(A, hf.ord, lu, P);
+  constexpr int SC = sizeof(T) / sizeof(double); // doubles per scalar: the pools of the factor are arrays of doubles
+  hf.cplx          = SC == 2;
+  PermutedMatrix<T> P;
+  build_permuted<T>(A, hf.ord, lu, P);
   const idx_t nlev_all = (idx_t)hf.level_ptr.size() - 1;
-  if (!dev) first_device_level = nlev_all;
+  if (!dev || SC != 1) first_device_level = nlev_all; // complex scalars: every level on the host
   first_device_level = std::min(first_device_level, nlev_all);
   hf.f_host = first_device_level >= nlev_all ? hf.f_size : hf.f_off[hf.level_blk[hf.level_ptr[first_device_level]]]; // panels are packed level by level
-  hf.F.assign((size_t)hf.f_host, 0.0);
-  if (lu) hf.G.assign((size_t)hf.f_host, 0.0);
+  hf.F.assign((size_t)hf.f_host * SC, 0.0);
+  if (lu) hf.G.assign((size_t)hf.f_host * SC, 0.0);
   else std::vector<double>().swap(hf.G);
-  if (kind == FACT_LDLT) hf.dinv.assign(n, 0.0);
+  if (kind == FACT_LDLT) hf.dinv.assign((size_t)n * SC, 0.0);
   else std::vector<double>().swap(hf.dinv);
   if (hf.keep_plain) {
-    hf.Lplain.assign((size_t)hf.f_size, 0.0);
-    if (lu) hf.Uplain.assign((size_t)hf.f_size, 0.0);
+    hf.Lplain.assign((size_t)hf.f_size * SC, 0.0);
+    if (lu) hf.Uplain.assign((size_t)hf.f_size * SC, 0.0);
   }
-  std::vector<double *> cb(nblk, nullptr);
+  std::vector<T *> cb(nblk, nullptr);
   static BlockPool      pool; // persistent across calls: later factorisations reuse already-faulted memory
   std::vector<std::vector<idx_t>> children(nblk);
   for (idx_t k = 0; k < nblk; ++k)
@@ -389,13 +398,13 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
     const idx_t  nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
     const idx_t  h = w + nb, ld = hf.ldw[k];
     const idx_t *rows = s.rows.data() + s.row_ptr[k];
-    double      *Pn   = hf.F.data() + hf.f_off[k];
-    double      *Gn   = lu ? hf.G.data() + hf.f_off[k] : nullptr;
-    double      *C    = nullptr; // contribution block nb x nb (lower for symmetric kinds, full for LU)
+    T           *Pn   = reinterpret_cast<T *>(hf.F.data()) + hf.f_off[k];
+    T           *Gn   = lu ? reinterpret_cast<T *>(hf.G.data()) + hf.f_off[k] : nullptr;
+    T           *C    = nullptr; // contribution block nb x nb (lower for symmetric kinds, full for LU)
     if (nb) {
-      C = pool.get((size_t)nb * nb);
+      C = reinterpret_cast<T *>(pool.get((size_t)nb * nb * SC));
 #pragma omp parallel for if (par) schedule(static)
-      for (idx_t i = 0; i < nb; ++i) std::memset(C + (size_t)i * nb, 0, (size_t)(lu ? nb : i + 1) * sizeof(double));
+      for (idx_t i = 0; i < nb; ++i) std::memset(C + (size_t)i * nb, 0, (size_t)(lu ? nb : i + 1) * sizeof(T));
     }
     for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
     for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
@@ -414,17 +423,17 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
     for (idx_t ch : children[k]) {
       const idx_t  nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
       const idx_t *rc  = s.rows.data() + s.row_ptr[ch];
-      const double *Cc = cb[ch];
+      const T      *Cc = cb[ch];
 #pragma omp parallel for if (par && nbc > 256) schedule(dynamic, 16)
       for (idx_t i = 0; i < nbc; ++i) {
         const idx_t   li = rel[rc[i]];
-        const double *ci = Cc + (size_t)i * nbc;
+        const T      *ci = Cc + (size_t)i * nbc;
         if (!lu) {
           if (li < w) {
-            double *dst = Pn + (long)li * ld;
+            T *dst = Pn + (long)li * ld;
             for (idx_t j = 0; j <= i; ++j) dst[rel[rc[j]]] += ci[j];
           } else {
-            double *dst = C + (size_t)(li - w) * nb;
+            T *dst = C + (size_t)(li - w) * nb;
             for (idx_t j = 0; j <= i; ++j) {
               const idx_t lj = rel[rc[j]];
               if (lj < w) Pn[(long)li * ld + lj] += ci[j];
@@ -442,7 +451,7 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
           }
         }
       }
-      pool.put(cb[ch], (size_t)nbc * nbc);
+      pool.put(reinterpret_cast<double *>(cb[ch]), (size_t)nbc * nbc * SC);
       cb[ch] = nullptr;
     }
     for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
@@ -450,18 +459,20 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
     lap(0);
     // ---- partial factorisation of the front: columns 0..w-1 ----
     const int           NB = 64;
-    std::vector<double> wt;
+    std::vector<T> wt;
     bool                ok = true;
     for (idx_t kb = 0; kb < w && ok; kb += NB) {
       const idx_t jb = std::min<idx_t>(NB, w - kb);
-      double     *Pk = Pn + (long)kb * ld;
+      T          *Pk = Pn + (long)kb * ld;
       if (kind == FACT_CHOL) {
-        dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, true, Pk + kb, ld, par);
-        ok = dense::potf2(jb, Pk + kb, ld);
-        if (ok) dense::trsm_right_lower_trans(h - kb - jb, jb, Pk + kb, ld, false, nullptr, Pk + (long)jb * ld + kb, ld, par);
+        if constexpr (SC == 1) { // real scalars only (complex matrices never take this kind)
+          dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, true, Pk + kb, ld, par);
+          ok = dense::potf2(jb, Pk + kb, ld);
+          if (ok) dense::trsm_right_lower_trans<T>(h - kb - jb, jb, Pk + kb, ld, false, nullptr, Pk + (long)jb * ld + kb, ld, par);
+        }
       } else if (kind == FACT_LDLT) {
         // W = L(kb:kb+jb, 0:kb) * D(0:kb)
-        wt.assign((size_t)jb * std::max<idx_t>(kb, 1), 0.0);
+        wt.assign((size_t)jb * std::max<idx_t>(kb, 1), T(0));
         for (idx_t i = 0; i < jb; ++i)
           for (idx_t c = 0; c < kb; ++c) wt[(size_t)i * kb + c] = Pk[(long)i * ld + c] * Pn[(long)c * ld + c];
         dense::gemm(h - kb, jb, kb, -1.0, Pk, ld, wt.data(), kb, true, Pk + kb, ld, par);
@@ -480,14 +491,14 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
           // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)   (unit lower, row by row)
           for (idx_t r = 1; r < jb; ++r)
             for (idx_t q = 0; q < r; ++q) {
-              const double l = Pk[(long)r * ld + kb + q];
-              if (l != 0.0) {
-                double       *dst = Pk + (long)r * ld + kb + jb;
-                const double *src = Pk + (long)q * ld + kb + jb;
+              const T l = Pk[(long)r * ld + kb + q];
+              if (l != T(0)) {
+                T       *dst = Pk + (long)r * ld + kb + jb;
+                const T *src = Pk + (long)q * ld + kb + jb;
                 for (idx_t c = 0; c < w - kb - jb; ++c) dst[c] -= l * src[c];
               }
             }
-          dense::trsm_right_lower_trans(nb, jb, Pk + kb, ld, true, nullptr, Gn + (long)w * ld + kb, ld, par);
+          dense::trsm_right_lower_trans<T>(nb, jb, Pk + kb, ld, true, nullptr, Gn + (long)w * ld + kb, ld, par);
         }
       }
     }
@@ -498,10 +509,10 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
     lap(1);
     // ---- Schur complement -> contribution block ----
     if (nb && ok) {
-      double *P21 = Pn + (long)w * ld;
+      T *P21 = Pn + (long)w * ld;
       if (kind == FACT_CHOL) dense::gemm(nb, nb, w, -1.0, P21, ld, P21, ld, true, C, nb, par, true);
       else if (kind == FACT_LDLT) {
-        wt.assign((size_t)nb * w, 0.0);
+        wt.assign((size_t)nb * w, T(0));
         for (idx_t i = 0; i < nb; ++i)
           for (idx_t c = 0; c < w; ++c) wt[(size_t)i * w + c] = P21[(long)i * ld + c] * Pn[(long)c * ld + c];
         dense::gemm(nb, nb, w, -1.0, P21, ld, wt.data(), w, true, C, nb, par, true);
@@ -515,24 +526,24 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
       for (idx_t i = 0; i < w; ++i)
         for (idx_t j = i; j < w; ++j) {
           Gn[(long)j * ld + i] = Pn[(long)i * ld + j]; // G top = U11^T (lower, non-unit)
-          if (j > i) Pn[(long)i * ld + j] = 0.0;
+          if (j > i) Pn[(long)i * ld + j] = T(0);
         }
-      for (idx_t i = 0; i < w; ++i) Pn[(long)i * ld + i] = 1.0; // L11 unit diagonal made explicit
+      for (idx_t i = 0; i < w; ++i) Pn[(long)i * ld + i] = T(1); // L11 unit diagonal made explicit
     } else {
       for (idx_t i = 0; i < w; ++i)
-        for (idx_t j = i + 1; j < w; ++j) Pn[(long)i * ld + j] = 0.0;
+        for (idx_t j = i + 1; j < w; ++j) Pn[(long)i * ld + j] = T(0);
       if (kind == FACT_LDLT)
         for (idx_t i = 0; i < w; ++i) {
-          hf.dinv[c0 + i]       = 1.0 / Pn[(long)i * ld + i];
-          Pn[(long)i * ld + i] = 1.0;
+          reinterpret_cast<T *>(hf.dinv.data())[c0 + i] = T(1) / Pn[(long)i * ld + i];
+          Pn[(long)i * ld + i]                          = T(1);
         }
     }
     if (hf.keep_plain) {
-      std::copy_n(Pn, (size_t)h * ld, hf.Lplain.data() + hf.f_off[k]);
-      if (lu) std::copy_n(Gn, (size_t)h * ld, hf.Uplain.data() + hf.f_off[k]);
+      std::copy_n(Pn, (size_t)h * ld, reinterpret_cast<T *>(hf.Lplain.data()) + hf.f_off[k]);
+      if (lu) std::copy_n(Gn, (size_t)h * ld, reinterpret_cast<T *>(hf.Uplain.data()) + hf.f_off[k]);
     }
     // ---- solve-ready panels: top <- inverse, bottom <- bottom * inverse ----
-    std::vector<double> tmp;
+    std::vector<T> tmp;
     invert_lower(w, Pn, ld, false, par, tmp); // unit diagonals are stored explicitly as 1.0, so the general path is exact
     right_multiply_lower(nb, w, Pn + (long)w * ld, ld, Pn, ld, par);
     if (lu) {
@@ -553,8 +564,8 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
     if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
   }
-  if (first_device_level < nlev_all && !bad) {
-    // ---- hand-over: the remaining levels run on the device ----
+  if constexpr (SC == 1) if (first_device_level < nlev_all && !bad) {
+    // ---- hand-over: the remaining levels run on the device (real scalars) ----
     const double td0 = now();
     size_t cbd = 0;
     idx_t  max_h = 0, max_w = 0;
@@ -616,6 +627,14 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
   }
   hf.info      = bad;
   hf.t_numeric = now() - t0;
+}
+
+void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev, idx_t first_device_level)
+{
+  if (A.cplx) {
+    HH_CHECK(kind != FACT_CHOL, "numfact: complex matrices are factorised as LDL^T (complex symmetric) or LU");
+    factor_numeric_t<std::complex<double>>(A, kind, hf, nullptr, first_device_level);
+  } else factor_numeric_t<double>(A, kind, hf, dev, first_device_level);
 }
 
 } // namespace hpddm_hip

@@ -852,13 +852,15 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains before the barrier
   __syncthreads();
   if (tid == 0) {
-    // release on the arrival, acquire in the last arriver: the partial sums are write-through stores already drained above, the
-    // ordering is stated in the memory model as well instead of resting on that alone (one fence per split tile)
-    const int old = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // Ordering of the hand-over: the partial sums are 8-byte agent-scope atomic stores (write-through, they bypass this XCD's
+    // L2 on the way out), drained by the s_waitcnt above before the barrier, and the last arriver reads them with 8-byte
+    // agent-scope atomic loads (L1 bypassed) -- "8-byte agent atomics on both sides", one of the valid hand-over forms of
+    // MI355X_MICROARCH.md (inter-workgroup visibility).  A release on this counter / an acquire fence in the last arriver were
+    // measured: +0.6 ms on the 2.8 ms sweep pair at 65^3 (one L2 write-back per split tile), so they are not added on top.
+    const int old = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (old == t.nparts - 1);
     *s_last        = last;
     if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(arrivals + t.group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next solve
     }
   }
