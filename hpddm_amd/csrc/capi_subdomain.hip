@@ -11,11 +11,6 @@ using namespace hpddm_hip;
 
 struct HpddmHipSubdomain {
   LocalSolver ls;
-  // complex128 matrices (HpddmHipSubdomainNumfactZ): unit row phases that make the diagonal real positive, and the
-  // real-equivalent CSR the solver was given
-  std::vector<double> zphase; // n pairs (re, im), empty for real matrices
-  std::vector<int>    zia, zja;
-  std::vector<double> za;
 };
 
 namespace hpddm_hip {
@@ -75,12 +70,11 @@ int HpddmHipSubdomainNumfact(HpddmHipSubdomain **S, int n, const int *ia, const 
     return 0;)
 }
 
-// complex128 through the real-equivalent embedding: (A_r + i A_i)(x_r + i x_i) = b_r + i b_i  <=>  per entry the 2 x 2
-// block [a_r, -a_i; a_i, a_r] acting on the interleaved (re, im) vector -- std::complex<double> arrays ARE that vector,
-// so the right-hand sides need no conversion.  Every row is first multiplied by the unit phase conj(a_ii)/|a_ii|: the
-// diagonal blocks become |a_ii| I, which keeps the pivot-free factorisation away from small real parts on the diagonal.
-// A Hermitian matrix stays symmetric under the embedding (LDL^T / Cholesky); anything else, complex symmetric included,
-// goes through LU.  Cost: twice the bytes of a native complex factor (4 real entries per complex one).
+// complex128, native: the factor holds complex scalars ((re, im) pairs, 16 bytes per entry -- half of what the real-equivalent
+// embedding of round 1 stored), the host factorisation runs in complex arithmetic (LDL^T with plain transposes for a complex
+// symmetric matrix, LU otherwise) and the SpTRSV streams the complex panels with the real tile kernels: a complex right-hand
+// side is two real ones (its planes), the panel row [a_r a_i ...] is applied to [f_r, f_i; -f_i, f_r] (sptrsv.hip).
+// std::complex<double> arrays ARE interleaved pairs, so matrices and vectors need no conversion.
 int HpddmHipSubdomainNumfactZ(HpddmHipSubdomain **S, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int spd)
 {
   HH_TRY(
@@ -88,43 +82,8 @@ int HpddmHipSubdomainNumfactZ(HpddmHipSubdomain **S, int n, const int *ia, const
     HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
     HH_CHECK(n >= 0, "negative dimension");
     if (!*S) *S = new HpddmHipSubdomain();
-    HpddmHipSubdomain &H = **S;
-    const int          base = numbering == 'F' ? 1 : 0;
-    // expand the symmetric storage (lower triangle of a complex SYMMETRIC matrix, like MatrixCSR::sym_) to full rows
-    std::vector<std::vector<std::pair<int, std::pair<double, double>>>> rows(n);
-    for (int i = 0; i < n; ++i)
-      for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
-        const int j = ja[p] - base;
-        HH_CHECK(j >= 0 && j < n, "column index out of range");
-        rows[i].push_back({j, {a[2 * p], a[2 * p + 1]}});
-        if (sym && j != i) rows[j].push_back({i, {a[2 * p], a[2 * p + 1]}});
-      }
-    H.zphase.assign(2 * (size_t)n, 0.0);
-    for (int i = 0; i < n; ++i) {
-      std::sort(rows[i].begin(), rows[i].end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-      double dr = 0.0, di = 0.0;
-      for (const auto &e : rows[i])
-        if (e.first == i) dr += e.second.first, di += e.second.second;
-      const double m = std::hypot(dr, di);
-      HH_CHECK(m > 0.0, "numfact: zero diagonal entry in row " + std::to_string(i));
-      H.zphase[2 * i] = dr / m, H.zphase[2 * i + 1] = -di / m; // conj(a_ii) / |a_ii|
-    }
-    H.zia.assign(2 * (size_t)n + 1, 0);
-    H.zja.clear();
-    H.za.clear();
-    for (int i = 0; i < n; ++i) {
-      const double pr = H.zphase[2 * i], pi = H.zphase[2 * i + 1];
-      for (int half = 0; half < 2; ++half) {
-        for (const auto &e : rows[i]) {
-          const double vr = pr * e.second.first - pi * e.second.second, vi = pr * e.second.second + pi * e.second.first;
-          H.zja.push_back(2 * e.first), H.za.push_back(half == 0 ? vr : vi);
-          H.zja.push_back(2 * e.first + 1), H.za.push_back(half == 0 ? -vi : vr);
-        }
-        H.zia[2 * i + half + 1] = (int)H.zja.size();
-      }
-    }
-    CsrView A{2 * n, H.zia.data(), H.zja.data(), H.za.data(), false, 0};
-    H.ls.numfact(A, spd);
+    CsrView A{n, ia, ja, a, sym != 0, numbering == 'F' ? 1 : 0, true};
+    (*S)->ls.numfact(A, spd);
     return 0;)
 }
 
@@ -132,17 +91,9 @@ int HpddmHipSubdomainSolveZ(HpddmHipSubdomain *S, const double *b, double *x, un
 {
   HH_TRY(
     HH_CHECK(S && b && x, "null argument");
-    HH_CHECK(!S->zphase.empty() || S->ls.host.n == 0, "SolveZ on a subdomain factorised as real");
+    HH_CHECK(S->ls.host.cplx || S->ls.host.n == 0, "SolveZ on a subdomain factorised as real");
     if (n == 0 || S->ls.host.n == 0) return 0;
-    const size_t nc = S->zphase.size() / 2;
-    std::vector<double> pb(2 * nc * n);
-    for (unsigned short nu = 0; nu < n; ++nu)
-      for (size_t i = 0; i < nc; ++i) {
-        const double pr = S->zphase[2 * i], pi = S->zphase[2 * i + 1], br = b[2 * (nu * nc + i)], bi = b[2 * (nu * nc + i) + 1];
-        pb[2 * (nu * nc + i)]     = pr * br - pi * bi;
-        pb[2 * (nu * nc + i) + 1] = pr * bi + pi * br;
-      }
-    S->ls.solve_host(pb.data(), x, n);
+    S->ls.solve_host(b, x, n);
     return 0;)
 }
 
@@ -150,6 +101,7 @@ int HpddmHipSubdomainSolve(HpddmHipSubdomain *S, const double *b, double *x, uns
 {
   HH_TRY(
     HH_CHECK(S && b && x, "null argument");
+    HH_CHECK(!S->ls.host.cplx, "Solve on a subdomain factorised as complex (use SolveZ)");
     if (n == 0 || S->ls.host.n == 0) return 0;
     S->ls.solve_host(b, x, n);
     return 0;)
@@ -263,7 +215,7 @@ int HpddmHipSubdomainTimeSolve(HpddmHipSubdomain *S, int mu, int warmup, int rep
     HH_CHECK(ls.uploaded, "factor not resident");
     hipStream_t         s = library_stream();
     DevBuf<double>      b;
-    std::vector<double> ones((size_t)ls.host.n * mu, 1.0);
+    std::vector<double> ones((size_t)ls.host.n * mu * (ls.host.cplx ? 2 : 1), 1.0);
     b.upload(ones, s);
     DevBuf<double> x;
     x.alloc(ones.size());

@@ -56,7 +56,8 @@ struct SnDesc {
   long long     uoff;  // same for the update pool
   int           n;     // subdomain size (leading dimension of its multi-vectors)
   int           usize; // subdomain update-pool size
-  int           c0, w, nb, ldw;
+  int           c0, w, nb, ldw; // first column, columns (= rows of the top block), rows below, leading dimension of the panel IN DOUBLES
+  int           wc, cs;         // doubles per panel row that carry entries (w, or 2 w for complex scalars) and doubles per scalar (1 / 2)
   int           u_off; // offset of this supernode's update vector inside the subdomain pool
   int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
   const double *FT;    // narrow panels: the forward panel once more, transposed (w x ldh, row-major), or nullptr
@@ -79,6 +80,7 @@ struct Tile {
 struct DeviceFactor {
   idx_t    n = 0;
   FactKind kind = FACT_CHOL;
+  bool     cplx = false; // complex scalars: panels hold (re, im) pairs; n, blk_ptr, ldw, f_off count scalars
   idx_t    nblk = 0, nlev = 0;
   int64_t  f_size = 0, u_size = 0, nnz_exact = 0, nnz_stored = 0;
   DevBuf<double> F, G, dinv;
@@ -140,7 +142,10 @@ struct SolvePlan {
   ~SolvePlan() { drop_graphs(); }
   void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
   void reserve(int mu);
-  // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b
+  // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b.
+  // Complex factors: b / x are arrays of (re, im) pairs (mu complex right-hand sides); inside, a complex right-hand side is two
+  // real ones (its real and imaginary planes) and the sweeps run with 2 mu real columns.
+  bool cplx = false;
   void solve(const double *b, double *x, int mu, hipStream_t s);
   int  launches_per_solve = 0;
   int  groups = 1; // this plan sweeps one of `groups` sets of subdomains that share the GPU (targets of the plan builder scale with it)

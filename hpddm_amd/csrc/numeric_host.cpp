@@ -404,7 +404,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     if (nb) {
       C = reinterpret_cast<T *>(pool.get((size_t)nb * nb * SC));
 #pragma omp parallel for if (par) schedule(static)
-      for (idx_t i = 0; i < nb; ++i) std::memset(C + (size_t)i * nb, 0, (size_t)(lu ? nb : i + 1) * sizeof(T));
+      for (idx_t i = 0; i < nb; ++i) std::memset(static_cast<void *>(C + (size_t)i * nb), 0, (size_t)(lu ? nb : i + 1) * sizeof(T));
     }
     for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
     for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;

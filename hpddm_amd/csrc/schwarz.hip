@@ -314,14 +314,9 @@ void Schwarz::set_subdomain_z(int s, int n, const int *ia, const int *ja, const 
       if (sym && j != i) rows[j].push_back({i, {a[2 * (size_t)p], a[2 * (size_t)p + 1]}});
     }
   std::vector<int>    zia(2 * (size_t)n + 1, 0), zja;
-  std::vector<double> za, phase(2 * (size_t)n, 0.0);
+  std::vector<double> za;
   for (int i = 0; i < n; ++i) {
     std::sort(rows[i].begin(), rows[i].end(), [](const std::pair<int, std::pair<double, double>> &x, const std::pair<int, std::pair<double, double>> &y) { return x.first < y.first; });
-    double dr = 0.0, di = 0.0;
-    for (const auto &e : rows[i])
-      if (e.first == i) dr += e.second.first, di += e.second.second;
-    const double m = std::hypot(dr, di);
-    phase[2 * i] = m > 0.0 ? dr / m : 1.0, phase[2 * i + 1] = m > 0.0 ? -di / m : 0.0; // conj(a_ii) / |a_ii|
     for (int half = 0; half < 2; ++half) {
       for (const auto &e : rows[i]) {
         const double vr = e.second.first, vi = e.second.second;
@@ -341,8 +336,14 @@ void Schwarz::set_subdomain_z(int s, int n, const int *ia, const int *ja, const 
     sz[k] = 2 * sizes[k];
   }
   set_subdomain(s, 2 * n, zia.data(), zja.data(), za.data(), false, 0, nneigh, list, sz.data(), cp.data());
-  subs[s].zphase = std::move(phase);
-  is_complex     = true;
+  // the local solver factorises the complex matrix itself (LocalSolver with complex scalars): keep it as handed over
+  SchwarzSub &S = subs[s];
+  S.zia.assign(ia, ia + n + 1);
+  S.zja.assign(ja, ja + (ia[n] - base));
+  S.za.assign(a, a + 2 * (size_t)(ia[n] - base));
+  S.zsym     = sym;
+  S.zbase    = base;
+  is_complex = true;
 }
 
 void Schwarz::set_vectors_z(int s, int nu, const double *Z)
@@ -437,14 +438,6 @@ void Schwarz::build_device()
   }
   nnzA = (long long)acat.size();
   d_d.upload(dcat, st);
-  if (is_complex) {
-    std::vector<double> pcat((size_t)ntot, 0.0);
-    for (int s = 0; s < nsub; ++s) {
-      HH_CHECK((int)subs[s].zphase.size() == subs[s].n, "complex operator: every subdomain must be set with SetSubdomainZ");
-      std::copy(subs[s].zphase.begin(), subs[s].zphase.end(), pcat.begin() + voff[s]);
-    }
-    zphase_d.upload(pcat, st);
-  }
   ia_d.upload(iacat, st);
   ja_d.upload(jacat, st);
   a_d.upload(acat, st);
@@ -545,7 +538,8 @@ void Schwarz::call_numfact()
             S.ls->analysed  = false;
           }
           CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
-          S.ls->analyse(A); // (complex: the phases below change values only, not the pattern)
+          if (is_complex) A = CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
+          S.ls->analyse(A);
         } catch (const std::exception &e) {
 #pragma omp critical(hpddm_hip_analyse_err)
           err = e.what();
@@ -559,22 +553,9 @@ void Schwarz::call_numfact()
       S.ls->release_host     = getopt("keep_host_factor", 0) == 0;
       S.ls->host.keep_plain  = getopt("keep_plain", 0) != 0;
       CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
-      std::vector<double> phased;
       if (is_complex) {
-        // factorise diag(phase) A: the 2 x 2 diagonal blocks become |a_ii| I (local_solve multiplies the right-hand side by the
-        // same phases).  Row 2i of the embedding holds (v_r, -v_i) per complex entry, row 2i+1 holds (v_i, v_r).
-        HH_CHECK(!use1 && (int)S.zphase.size() == S.n, "complex operators: no optimised local matrix");
-        phased = S.a0;
-        for (int i = 0; i < S.n / 2; ++i) {
-          const double pr = S.zphase[2 * i], pi = S.zphase[2 * i + 1];
-          const int    lo = S.ia0[2 * i], hi = S.ia0[2 * i + 1], lo2 = S.ia0[2 * i + 1];
-          for (int p = lo; p < hi; p += 2) {
-            const double vr = S.a0[p], vi = -S.a0[p + 1], wr = pr * vr - pi * vi, wi = pr * vi + pi * vr;
-            phased[p] = wr, phased[p + 1] = -wi;
-            phased[lo2 + (p - lo)] = wi, phased[lo2 + (p - lo) + 1] = wr;
-          }
-        }
-        A.a = phased.data();
+        HH_CHECK(!use1 && !S.zia.empty(), "complex operators: no optimised local matrix");
+        A = CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
       }
       S.ls->numfact(A, spd);
       fs.push_back(&S.ls->dev);
@@ -806,22 +787,6 @@ void Schwarz::upload_vectors()
 
 static inline dim3 grid2(int nmax, int nsub) { return dim3((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub); }
 
-// complex operators: out = diag(phase) in on the interleaved (re, im) pairs, phase per complex row (concatenated like d)
-__global__ void k_zphase(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ phase, const double *__restrict__ in, double *__restrict__ out, int mu)
-{
-  const int       s = blockIdx.y, n = nn[s], nc = n / 2;
-  const long long v0 = voff[s];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) {
-    const double pr = phase[v0 + 2 * i], pi = phase[v0 + 2 * i + 1];
-    for (int nu = 0; nu < mu; ++nu) {
-      const long long o  = v0 * mu + (long long)nu * n + 2 * i;
-      const double    br = in[o], bi = in[o + 1];
-      out[o]     = pr * br - pi * bi;
-      out[o + 1] = pr * bi + pi * br;
-    }
-  }
-}
-
 void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
 {
   HH_CHECK(in != out, "exchange: out-of-place only");
@@ -866,14 +831,8 @@ void Schwarz::local_solve(const double *in, double *out, int mu)
 }
 void Schwarz::solve_factor(const double *in, double *out, int mu)
 {
-  // the batched SpTRSV; complex operators were factorised as diag(phase) A, so the right-hand side takes the phases first
-  if (is_complex) {
-    hipStream_t st = library_stream();
-    wz.alloc((size_t)ntot * mu);
-    hipLaunchKernelGGL(k_zphase, grid2(nmax / 2, nsub), dim3(256), 0, st, voff_d.p, n_d.p, zphase_d.p, in, wz.p, mu);
-    batched_sptrsv(wz.p, out, mu);
-    return;
-  }
+  // the batched SpTRSV.  Complex operators: the vectors of the embedding ARE arrays of (re, im) pairs, which is what the
+  // complex plans take (n / 2 complex rows per subdomain, mu complex right-hand sides)
   batched_sptrsv(in, out, mu);
 }
 

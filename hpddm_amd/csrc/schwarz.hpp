@@ -42,10 +42,13 @@ struct SchwarzSub {
   std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B)
   int                 gevp_iterations = 0;
   std::unique_ptr<LocalSolver> ls;
-  // complex128 operators (Schwarz::is_complex): everything above is the real-equivalent embedding, n = 2 x (complex rows);
-  // zphase holds, per complex row, the unit phase conj(a_ii) / |a_ii| the rows are multiplied by before the pivot-free
-  // factorisation (same device as HpddmHipSubdomainNumfactZ, capi_subdomain.hip)
-  std::vector<double> zphase;
+  // complex128 operators (Schwarz::is_complex): everything above is the real-equivalent embedding, n = 2 x (complex rows) -- the
+  // layout of std::complex<double> vectors; the LOCAL SOLVER gets the complex matrix itself (native complex panels, half the
+  // bytes of a factor of the embedding), kept here as handed over: n / 2 rows, (re, im) pairs in za
+  std::vector<int>    zia, zja;
+  std::vector<double> za;
+  bool                zsym = false;
+  int                 zbase = 0;
 };
 
 struct Schwarz {
@@ -80,7 +83,6 @@ struct Schwarz {
   // layout of std::complex<double> arrays), so every operator of the path runs on the real kernels; only the Krylov
   // methods differ (complex inner products and coefficients, krylov_complex.hip)
   bool           is_complex = false;
-  DevBuf<double> zphase_d, wz;
   // ---- device-resident batched data ----
   long long              ntot = 0;
   std::vector<long long> voff; // nsub+1

@@ -38,7 +38,7 @@ struct SnView {
   gci_t     rows, gptr, gsrc;
   gci4_t    src4;
   long long voff, uoff;
-  int       n, usize, c0, w, nb, ldw, u_off, has_src, ldh;
+  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
@@ -48,7 +48,7 @@ __device__ static inline SnView view(const SnDesc &d)
   v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
   v.src4 = (gci4_t)d.src4;
   v.voff = d.voff, v.uoff = d.uoff;
-  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.u_off = d.u_off, v.has_src = d.has_src;
+  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
   return v;
 }
 // developer aid (HPDDM_HIP_DBG, wrong results): 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand
@@ -110,6 +110,44 @@ __global__ void k_perm_out(const long long *__restrict__ voff, const int *__rest
   }
 }
 
+// complex scalars: b / x are (re, im) pairs; inside, right-hand side k is the pair of real columns 2k (real parts), 2k + 1 (imaginary parts)
+__global__ void k_perm_in_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = pm[i];
+    for (int k = 0; k < mu; ++k) {
+      const dbl2 z = *reinterpret_cast<const dbl2 *>(b + 2 * (v0 * mu + (long long)k * n + o));
+      bp[v0 * 2 * mu + (long long)(2 * k) * n + i]     = z.x;
+      bp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i] = z.y;
+    }
+  }
+}
+__global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = pm[i];
+    for (int k = 0; k < mu; ++k) {
+      dbl2 z;
+      z.x = xp[v0 * 2 * mu + (long long)(2 * k) * n + i];
+      z.y = xp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i];
+      *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)k * n + o)) = z;
+    }
+  }
+}
+
+// Complex panels on the real tile kernels.  A panel row holds (a_r, a_i) pairs; with the right-hand side of a supernode laid
+// out as the real matrix  R = [ f_r  f_i ; -f_i  f_r ]  (row 2c = column c's real part slot, row 2c + 1 its imaginary part slot;
+// columns = the real / imaginary planes), the real product  P R  is the complex product  (P_r + i P_i)(f_r + i f_i), planes in
+// the two columns.  So the kernels below run unchanged with MU = 2 x (complex right-hand sides) real columns on panels of
+// wc = 2 w doubles per row; only the staging of R (Z = true), the triangular limits (cs = 2 doubles per scalar) and, in the
+// backward sweep -- x = P^T v, lanes own the (a_r, a_i) pair of one column -- the combination of the four partial products differ.
+
 // store the result of panel row r (after reduction): top rows give y, rows below hand their update to the parent
 template <int MU>
 __device__ static inline void fwd_store_row(const SnView &d, int r, const double *s, int sstride, double *yb, double *Ub)
@@ -137,10 +175,10 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
 // Forward product of a narrow panel WITHOUT per-row reductions: the panel is read through its transposed copy FT (w x ldh),
 // lanes own pairs of OUTPUT rows and walk down the w columns of F (= rows of FT), exactly as the backward sweep walks the
 // rows of G; the only cross-lane step is one reduction over the R column groups at the end.  Tile = nr <= 128 output rows.
-template <int MU, int FWD_PASSES>
+template <int MU, int FWD_PASSES, bool Z>
 __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg)
 {
-  const int w = d.w, ldh = d.ldh;
+  const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -150,7 +188,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < w && i <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
   }
   // f = b_J - (updates handed up by the children), one lane per column, into the wavefront's LDS
   for (int c = lane; c < w && !(dbg & DBG_NORHS); c += 64) {
@@ -165,26 +203,34 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
         for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
       }
     }
+    if constexpr (!Z) {
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
+      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
+    } else { // R = [ f_r  f_i ; -f_i  f_r ]: slots 2c, 2c + 1 of the real plane (nu even) and of the imaginary plane (nu odd)
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        lds[nu * wr + 2 * c]     = v[nu];
+        lds[nu * wr + 2 * c + 1] = (nu & 1) ? v[nu - 1] : -v[nu + 1];
+      }
+    }
   }
   wave_lds_sync();
   double acc0[MU], acc1[MU];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
-  for (int ib0 = 0; ib0 < w; ib0 += FWD_PASSES * R) {
+  for (int ib0 = 0; ib0 < wc; ib0 += FWD_PASSES * R) {
     const int  ib   = ib0 + sub;
-    const bool more = ib0 + FWD_PASSES * R < w;
+    const bool more = ib0 + FWD_PASSES * R < wc;
     if (more) {
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < w && i <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
-      const int i = min(ib + p * R, w - 1); // out-of-range passes carry a = 0
+      const int i = min(ib + p * R, wc - 1); // out-of-range passes carry a = 0
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         const double v = lds[nu * wr + i];
@@ -211,7 +257,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
   }
 }
 
-template <int MU, int FWD_PASSES>
+template <int MU, int FWD_PASSES, bool Z>
 __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb, double *xo, int dbg)
 {
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
@@ -224,14 +270,24 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < h && i >= 2 * gl && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
+    cur[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
   }
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
   for (int i = lane; i < h && !(dbg & DBG_NORHS); i += 64) {
     if (i < w) {
-      const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
+      if constexpr (!Z) {
+        const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
+        for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
+      } else { // complex 1 / D on the (real, imaginary) planes of every right-hand side
+        const double dr = d.dinv ? d.dinv[2 * (d.c0 + i)] : 1.0, di = d.dinv ? d.dinv[2 * (d.c0 + i) + 1] : 0.0;
+#pragma unroll
+        for (int k = 0; k < MU / 2; ++k) {
+          const double yr = yb[(long long)(2 * k) * d.n + d.c0 + i], yi = yb[(long long)(2 * k + 1) * d.n + d.c0 + i];
+          lds[(2 * k) * wr + i]     = dr * yr - di * yi;
+          lds[(2 * k + 1) * wr + i] = dr * yi + di * yr;
+        }
+      }
     } else {
       const int ri = d.rows[i - w];
 #pragma unroll
@@ -249,7 +305,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < h && i >= 2 * gl && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -275,14 +331,22 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
     }
   }
   if (sub == 0 && !(dbg & DBG_NOSTORE)) {
-    const int c = 2 * gl;
-    if (c < w) {
+    if constexpr (!Z) {
+      const int c = 2 * gl;
+      if (c < w) {
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
-    }
-    if (c + 1 < w) {
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
+      }
+      if (c + 1 < w) {
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
+      }
+    } else if (gl < w) { // this lane owns column gl: acc0 = P_r^T v, acc1 = P_i^T v for the real (even) and imaginary (odd) planes of v
+#pragma unroll
+      for (int k = 0; k < MU / 2; ++k) {
+        xb[(long long)(2 * k) * d.n + d.c0 + gl]     = acc0[2 * k] - acc1[2 * k + 1];
+        xb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = acc0[2 * k + 1] + acc1[2 * k];
+      }
     }
   }
 }
@@ -588,15 +652,27 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_chain_kernel(const SnDe
 }
 
 // =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
-template <int MU, int FWD_PASSES, int CU>
+// right-hand side entry of panel column `col` (in doubles) for the real column nu: real scalars b_J - updates; complex scalars the
+// entry (col, nu) of R = [ f_r  f_i ; -f_i  f_r ] (one plane of f, possibly negated)
+template <bool Z>
+__device__ static inline double fwd_rhs_entry(const SnView &d, int col, int nu, const double *bb, const double *Ub, bool gather)
+{
+  const int    c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
+  double       v = bb[(long long)plane * d.n + d.c0 + c];
+  if (gather)
+    for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)plane * d.usize + d.gsrc[p]];
+  return (Z && (col & 1) && !(nu & 1)) ? -v : v;
+}
+
+template <int MU, int FWD_PASSES, int CU, bool Z>
 __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered, int dbg)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int     w = d.w, ldw = d.ldw;
+  const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
   const int     CW  = ((lds_dbl - 64 * MU) / MU) & ~1; // columns staged per chunk (the tail of the LDS holds the row sums)
   double       *sums = lds + MU * CW;                // [MU][64]
   const int     rend = t.r0 + t.nr;
-  const int     tile_lim = min(w, rend); // rows of the top block never look right of their diagonal
+  const int     tile_lim = min(wc, cs * rend); // rows of the top block never look right of their diagonal
   const bool    single   = tile_lim <= CW;
   // row batches: every wavefront owns FWD_PASSES rows per batch (one wave per row, 16-byte loads, 1 KiB per instruction)
   for (int rb = t.r0; rb < rend; rb += 4 * FWD_PASSES) {
@@ -606,7 +682,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
       row[p] = rb + p * 4 + wave;
-      lim[p] = row[p] < rend ? (row[p] < w ? row[p] + 1 : w) : 0;
+      lim[p] = row[p] < rend ? (row[p] < w ? cs * (row[p] + 1) : wc) : 0;
       lmax   = max(lmax, lim[p]);
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
@@ -619,13 +695,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
         for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
           const int nu = idx / (kend - k0), i = idx - nu * (kend - k0);
           const int col = k0 + i;
-          double    v   = 0.0;
-          if (col < w) {
-            v = bb[(long long)nu * d.n + d.c0 + col];
-            if (d.has_src && !pregathered)
-              for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
-          }
-          lds[nu * CW + i] = v;
+          lds[nu * CW + i] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
         }
         __syncthreads();
       }
@@ -673,11 +743,11 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 // outputs, and on gfx950 the f64 MFMA rate equals the VALU rate, so a half-empty tile costs twice the arithmetic --
 // measured 5.6 vs 5.3 ms per sweep pair at mu = 8.)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-template <int MU>
+template <int MU, bool Z>
 __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int     w = d.w, ldw = d.ldw;
+  const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
   const int     rend = t.r0 + t.nr;
   const int     nrg  = (t.nr + 15) >> 4;                 // 16-row groups of the tile: 1..4
   const int     nrgp = nrg == 3 ? 4 : nrg, wpg = 4 / nrgp; // wavefronts per row group split the columns
@@ -688,8 +758,8 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
   double       *red  = lds + (lds_dbl - 512);            // [4 wavefronts][16 rows][8]
   double       *sums = red - 64 * MU;                    // [MU][64]
   const int     CW   = ((lds_dbl - 512 - 64 * MU) / MU) & ~15; // columns of the right-hand side staged per chunk
-  const int     tile_lim = min(w, rend);                 // rows of the top block never look right of their diagonal
-  const int     my_lim   = busy ? min(w, R0 + 16) : 0;   // ... and this row group stops at its own last diagonal entry
+  const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
+  const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0; // ... and this row group stops at its own last diagonal entry
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
   v4f64         acc = {0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < tile_lim; k0 += CW) {
@@ -697,13 +767,7 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
     const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
     for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
       const int nu = idx / (kend - k0), i = idx - nu * (kend - k0), col = k0 + i;
-      double    v  = 0.0;
-      if (col < w) {
-        v = bb[(long long)nu * d.n + d.c0 + col];
-        if (d.has_src && !pregathered)
-          for (int p = d.gptr[col]; p < d.gptr[col + 1]; ++p) v -= Ub[(long long)nu * d.usize + d.gsrc[p]];
-      }
-      lds[i * MU + nu] = v;
+      lds[i * MU + nu] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
     }
     __syncthreads();
     const int cend = min(kend, (my_lim + 15) & ~15);
@@ -714,11 +778,12 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
         a23 = *(gcd2_t)(Frow + cb + 2);
       }
       const int c = cb + 4 * g; // this lane's first column
-      if (row < w) {            // triangular top block: nothing right of the diagonal
-        a01.x = c <= row ? a01.x : 0.0;
-        a01.y = c + 1 <= row ? a01.y : 0.0;
-        a23.x = c + 2 <= row ? a23.x : 0.0;
-        a23.y = c + 3 <= row ? a23.y : 0.0;
+      if (row < w) {            // triangular top block: nothing right of the diagonal (entry = cs doubles)
+        const int last = cs * (row + 1) - 1;
+        a01.x = c <= last ? a01.x : 0.0;
+        a01.y = c + 1 <= last ? a01.y : 0.0;
+        a23.x = c + 2 <= last ? a23.x : 0.0;
+        a23.y = c + 3 <= last ? a23.y : 0.0;
       }
       const double *fl = lds + (c - k0) * MU + j;
       const double  b0 = j < MU ? fl[0] : 0.0, b1 = j < MU ? fl[MU] : 0.0, b2 = j < MU ? fl[2 * MU] : 0.0, b3 = j < MU ? fl[3 * MU] : 0.0;
@@ -744,7 +809,7 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
   if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
 }
 
-template <int MU, int FP>
+template <int MU, int FP, bool Z>
 __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts, int dbg)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -767,7 +832,12 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
       double    v;
       if (i < w) {
         v = yb[(long long)nu * d.n + d.c0 + i];
-        if (d.dinv) v *= d.dinv[d.c0 + i];
+        if constexpr (!Z) {
+          if (d.dinv) v *= d.dinv[d.c0 + i];
+        } else if (d.dinv) { // complex 1 / D: this entry is the real (nu even) or imaginary (nu odd) part of (d_r + i d_i)(y_r + i y_i)
+          const double dr = d.dinv[2 * (d.c0 + i)], di = d.dinv[2 * (d.c0 + i) + 1], o = yb[(long long)(nu ^ 1) * d.n + d.c0 + i];
+          v = (nu & 1) ? dr * v + di * o : dr * v - di * o;
+        }
       } else v = -xb[(long long)nu * d.n + d.rows[i - w]];
       lds[nu * RCH + ii] = v;
     }
@@ -819,18 +889,36 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   __syncthreads();
   if (t.nparts == 1) {
     if (wave == 0 && sub == 0 && colok && !(dbg & DBG_NOSTORE)) {
+      if constexpr (!Z) {
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu)
+        for (int nu = 0; nu < MU; ++nu)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int c = col + k;
-          if (c < w) {
+          for (int k = 0; k < 2; ++k) {
+            const int c = col + k;
+            if (c < w) {
+              double s = 0.0;
+#pragma unroll
+              for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
+              xb[(long long)nu * d.n + d.c0 + c] = s;
+            }
+          }
+      } else if ((col >> 1) < w) { // this lane owns the (a_r, a_i) pair of column col / 2
+        double S[MU][2];
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
             double s = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
-            xb[(long long)nu * d.n + d.c0 + c] = s;
+            S[nu][k] = s;
           }
+#pragma unroll
+        for (int k = 0; k < MU / 2; ++k) {
+          xb[(long long)(2 * k) * d.n + d.c0 + (col >> 1)]     = S[2 * k][0] - S[2 * k + 1][1];
+          xb[(long long)(2 * k + 1) * d.n + d.c0 + (col >> 1)] = S[2 * k + 1][0] + S[2 * k][1];
         }
+      }
     }
     return;
   }
@@ -867,12 +955,28 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   __syncthreads();
   if (*s_last && tid < 128) {
     const int c = t.r0 + tid;
-    if (c < w) {
+    if constexpr (!Z) {
+      if (c < w) {
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        double s = 0.0;
-        for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * MU + nu) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
-        xb[(long long)nu * d.n + d.c0 + c] = s;
+        for (int nu = 0; nu < MU; ++nu) {
+          double s = 0.0;
+          for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * MU + nu) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
+          xb[(long long)nu * d.n + d.c0 + c] = s;
+        }
+      }
+    } else if (!(tid & 1) && (c >> 1) < w) { // even thread: the (a_r, a_i) pair of column c / 2 sits in slots tid, tid + 1
+#pragma unroll
+      for (int k = 0; k < MU / 2; ++k) {
+        double rr = 0.0, ii = 0.0, ri = 0.0, ir = 0.0; // (P_r^T v_r), (P_i^T v_i), (P_r^T v_i), (P_i^T v_r), summed in part order
+        for (int p = 0; p < t.nparts; ++p) {
+          const double *sl = slot + ((long long)p * MU + 2 * k) * 128 + tid;
+          rr += __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ir += __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ri += __hip_atomic_load(sl + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ii += __hip_atomic_load(sl + 129, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        xb[(long long)(2 * k) * d.n + d.c0 + (c >> 1)]     = rr - ii;
+        xb[(long long)(2 * k + 1) * d.n + d.c0 + (c >> 1)] = ri + ir;
       }
     }
   }
@@ -881,7 +985,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
 // One launch per level and direction: every workgroup takes block-level tiles g, g + G, ... with its four wavefronts
 // together, then its wavefronts take wave-level tiles on their own (G = grid size; by default one share per workgroup).
 // Tiles are sorted by decreasing cost.  wr = rows of right-hand side a wavefront stages in LDS (the level's maximum).
-template <int MU, bool HAS_BLOCK, int FP>
+template <int MU, bool HAS_BLOCK, int FP, bool Z>
 __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -894,9 +998,9 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
       double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
       if constexpr (MU >= 4) {
-        if (dbg & DBG_NOMFMA) fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
-        else fwd_block_tile_mfma<MU>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0);
-      } else fwd_block_tile<MU, FP, 1>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+        if (dbg & DBG_NOMFMA) fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+        else fwd_block_tile_mfma<MU, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0);
+      } else fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -911,12 +1015,12 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    fwd_wave_tile_t<MU, FP>(d, t, lane, wl, wr, bb, yb, Ub, dbg);
+    fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg);
     wave_lds_sync(); // the last reads of the staged right-hand side land before the next tile overwrites it
   }
 }
 
-template <int MU, bool HAS_BLOCK, int FP>
+template <int MU, bool HAS_BLOCK, int FP, bool Z>
 __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -928,7 +1032,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
       const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
       double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-      bwd_block_tile<MU, FP>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts, dbg);
+      bwd_block_tile<MU, FP, Z>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts, dbg);
       __syncthreads();
     }
   }
@@ -941,7 +1045,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-    bwd_wave_tile<MU, FP>(d, lane, wl, wr, yb, xb, xo, dbg);
+    bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo, dbg);
     wave_lds_sync();
   }
 }
@@ -994,19 +1098,21 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   HH_CHECK(hf.info == 0, "numfact failed (zero or negative pivot in block " + std::to_string(hf.info) + ")");
   n          = hf.n;
   kind       = hf.kind;
+  cplx       = hf.cplx;
+  const int sc = cplx ? 2 : 1; // doubles per scalar
   nblk       = hf.sym.nblk;
   nlev       = (idx_t)hf.level_ptr.size() - 1;
   f_size     = hf.f_size;
   u_size     = hf.u_size;
   nnz_exact  = hf.sym.nnz_exact;
   nnz_stored = hf.sym.nnz_stored;
-  F.alloc((size_t)hf.f_size);
-  HH_CHECK((int64_t)hf.F.size() >= hf.f_host, "host panel pool smaller than its prefix");
-  if (hf.f_host) HIP_OK(hipMemcpyAsync(F.p, hf.F.data(), (size_t)hf.f_host * sizeof(double), hipMemcpyHostToDevice, s)); // the rest was built in place by the device levels
+  F.alloc((size_t)hf.f_size * sc);
+  HH_CHECK((int64_t)hf.F.size() >= hf.f_host * sc, "host panel pool smaller than its prefix");
+  if (hf.f_host) HIP_OK(hipMemcpyAsync(F.p, hf.F.data(), (size_t)hf.f_host * sc * sizeof(double), hipMemcpyHostToDevice, s)); // the rest was built in place by the device levels
   if (kind == FACT_LU) {
-    G.alloc((size_t)hf.f_size);
-    HH_CHECK((int64_t)hf.G.size() >= hf.f_host, "host panel pool (G) smaller than its prefix");
-    if (hf.f_host) HIP_OK(hipMemcpyAsync(G.p, hf.G.data(), (size_t)hf.f_host * sizeof(double), hipMemcpyHostToDevice, s));
+    G.alloc((size_t)hf.f_size * sc);
+    HH_CHECK((int64_t)hf.G.size() >= hf.f_host * sc, "host panel pool (G) smaller than its prefix");
+    if (hf.f_host) HIP_OK(hipMemcpyAsync(G.p, hf.G.data(), (size_t)hf.f_host * sc * sizeof(double), hipMemcpyHostToDevice, s));
   } else G.release();
   if (kind == FACT_LDLT) dinv.upload(hf.dinv, s);
   else dinv.release();
@@ -1036,8 +1142,8 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   {
     int64_t tot = 0;
     for (idx_t k = 0; k < nblk; ++k) {
-        if (ldw[k] > NARROW) continue;
-        const int64_t w = blk_ptr[k + 1] - blk_ptr[k], hgt = w + (row_ptr[k + 1] - row_ptr[k]);
+        if (ldw[k] * sc > NARROW) continue;
+        const int64_t w = (int64_t)(blk_ptr[k + 1] - blk_ptr[k]) * sc, hgt = (blk_ptr[k + 1] - blk_ptr[k]) + (row_ptr[k + 1] - row_ptr[k]); // doubles per panel row, rows
         ldh[k]    = (idx_t)((hgt + 1) / 2 * 2);
         ft_off[k] = tot;
         tot += (w * ldh[k] + 1) / 2 * 2; // 16-byte aligned starts
@@ -1047,11 +1153,11 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
       std::vector<long long> fo(nblk), fto(nblk);
       std::vector<int>       hh(nblk), ww(nblk), lw(nblk), lh(nblk);
       for (idx_t k = 0; k < nblk; ++k) {
-        fo[k]  = f_off[k];
+        fo[k]  = f_off[k] * sc; // the transposition works on the panel as h rows of (ldw * sc) doubles
         fto[k] = ft_off[k];
-        ww[k]  = blk_ptr[k + 1] - blk_ptr[k];
-        hh[k]  = ww[k] + (int)(row_ptr[k + 1] - row_ptr[k]);
-        lw[k]  = ldw[k];
+        ww[k]  = (blk_ptr[k + 1] - blk_ptr[k]) * sc;
+        hh[k]  = (blk_ptr[k + 1] - blk_ptr[k]) + (int)(row_ptr[k + 1] - row_ptr[k]);
+        lw[k]  = ldw[k] * sc;
         lh[k]  = ldh[k];
       }
       DevBuf<long long> dfo, dfto;
@@ -1077,7 +1183,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
     int64_t tot = 0;
     for (idx_t k = 0; k < nblk; ++k) {
       const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
-      if (ldw[k] > NARROW) continue;
+      if (ldw[k] * sc > NARROW) continue;
       const int64_t *gp = hf.gptr.data() + hf.goff[k];
       bool           ok = true;
       for (int64_t i = 0; i < hh && ok; ++i) ok = gp[i + 1] - gp[i] <= 4;
@@ -1122,8 +1228,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     ntot += fs[f]->n;
     utot += fs[f]->u_size;
     nlev = std::max<int>(nlev, fs[f]->nlev);
-    bytes_alg_per_rhs1 += 2.0 * (double)fs[f]->nnz_exact * 8.0 + 4.0 * (double)fs[f]->n * 8.0;
+    bytes_alg_per_rhs1 += (2.0 * (double)fs[f]->nnz_exact * 8.0 + 4.0 * (double)fs[f]->n * 8.0) * (fs[f]->cplx ? 2.0 : 1.0); // sizeof(K) = 16 for complex scalars
+    HH_CHECK(fs[f]->cplx == fs[0]->cplx, "real and complex factors cannot share a plan");
   }
+  cplx = !fs.empty() && fs[0]->cplx;
   std::vector<SnDesc>           descs;
   std::vector<std::vector<Tile>> tl[4];
   for (auto &v : tl) v.assign(nlev, {});
@@ -1139,7 +1247,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   const bool pregather   = envi("HPDDM_HIP_PREGATHER", 1) != 0;
   const int  sort_mode   = envi("HPDDM_HIP_SORT", 1);         // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
-  const bool use_chains  = envi("HPDDM_HIP_CHAINS", 0) != 0;  // bottom subtrees walked by one wavefront each (chain kernels): opt-in, measured 2.6-3.0 TB/s against 3.5 of the level launches at 65^3
+  const bool use_chains  = envi("HPDDM_HIP_CHAINS", 0) != 0 && !cplx;  // bottom subtrees walked by one wavefront each (chain kernels): opt-in, measured 2.6-3.0 TB/s against 3.5 of the level launches at 65^3
   const long long chain_cap_env = envi("HPDDM_HIP_CHAIN_KB", 0) * 1024LL; // largest chain in bytes (0: from the size of the problem)
   // ---- which supernodes go into chains: maximal subtrees made of chainable supernodes, at most chain_cap bytes each ----
   std::vector<std::vector<char>>  in_chain(fs.size());
@@ -1211,8 +1319,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     desc_base[f]          = (int)descs.size();
     for (idx_t k = 0; k < D.nblk; ++k) {
       SnDesc d;
-      d.F     = D.F.p + D.f_off[k];
-      d.G     = (D.kind == FACT_LU ? D.G.p : D.F.p) + D.f_off[k];
+      const int cs = D.cplx ? 2 : 1; // doubles per scalar: offsets and leading dimensions of the factor count scalars
+      d.F     = D.F.p + D.f_off[k] * cs;
+      d.G     = (D.kind == FACT_LU ? D.G.p : D.F.p) + D.f_off[k] * cs;
       d.dinv  = D.kind == FACT_LDLT ? D.dinv.p : nullptr;
       d.rows  = D.rows.p + D.row_ptr[k];
       d.gptr  = D.gptr.p + D.goff[k];
@@ -1224,7 +1333,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.c0    = D.blk_ptr[k];
       d.w     = D.blk_ptr[k + 1] - D.blk_ptr[k];
       d.nb    = (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
-      d.ldw   = D.ldw[k];
+      d.ldw   = D.ldw[k] * cs;
+      d.wc    = d.w * cs;
+      d.cs    = cs;
       d.u_off = D.u_off[k];
       d.has_src = D.has_src[k] ? 1 : 0;
       d.FT      = D.ft_off[k] >= 0 ? D.FT.p + D.ft_off[k] : nullptr;
@@ -1235,7 +1346,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       descs.back().src4 = d.src4;
       const int h = d.w + d.nb, lev = D.height[k];
       if (use_chains && in_chain[f][k]) continue; // taken by a chain kernel (tiles made below)
-      lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0;
+      lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
         HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
         // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
@@ -1246,7 +1357,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
-        const int trb = d.w <= 960 ? 64 : (d.w <= 3968 ? 32 : 16);
+        const int trb = d.wc <= 960 ? 64 : (d.wc <= 3968 ? 32 : 16);
         if (fwd_target > 0) {
           // tiles of equal AREA: the rows of the triangular top block are short, so the tiles there are taller (at most
           // 64 rows); the area follows the level's total so that a level of few, huge supernodes still fields fwd_target
@@ -1264,7 +1375,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
           }
         } else
           for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
-        for (int c0 = 0; c0 < d.w; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / 4) * 4, h});
+        for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h}); // c0: first of 128 doubles of every row; rows above scalar column c0 / cs hold zeros there
         if (pregather && d.has_src)
           for (int c0 = 0; c0 < d.w; c0 += WG_THREADS) gat[lev].push_back(Tile{id, c0, std::min(WG_THREADS, d.w - c0), 0, 1, 0, 0, 0});
       }
@@ -1329,7 +1440,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront
       int need = 0;
       for (const Tile &t : tl[kd][l])
-        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].w : descs[t.sn].w + descs[t.sn].nb)));
+        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : descs[t.sn].w + descs[t.sn].nb)));
       lev_lds[kd][l] = need;
     }
   gat_ptr.assign(nlev, 0);
@@ -1454,7 +1565,7 @@ void SolvePlan::reserve(int mu)
   mu_cap = mu;
 }
 
-template <int MU>
+template <int MU, bool Z>
 static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu0, hipStream_t s)
 {
   // batched layout [sub][mu][n_sub]: a block of MU columns starting at nu0 is addressed inside the kernels.
@@ -1486,16 +1597,16 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     }
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 512 : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
     if (nb || nw) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
     const int wr = nw ? wrows(SolvePlan::BWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     if (nb || nw) P.mark(3000 + l, s);
   }
   if (P.nchains) {
@@ -1507,9 +1618,32 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
 void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
 {
   HH_CHECK(mu >= 1, "solve: mu must be >= 1");
+  const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
+  if (cplx) {
+    // mu complex right-hand sides = 2 mu real columns (planes) inside; register blocks of 8 / 4 / 2 real columns
+    const int mr = 2 * mu;
+    reserve(mr);
+    hipLaunchKernelGGL(k_perm_in_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+    int nu0 = 0;
+    while (nu0 < mr) {
+      const int left = mr - nu0;
+      if (left >= 8) {
+        solve_block<8, true>(*this, bperm.p, xw.p, mr, nu0, s);
+        nu0 += 8;
+      } else if (left >= 4) {
+        solve_block<4, true>(*this, bperm.p, xw.p, mr, nu0, s);
+        nu0 += 4;
+      } else {
+        solve_block<2, true>(*this, bperm.p, xw.p, mr, nu0, s);
+        nu0 += 2;
+      }
+    }
+    hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu);
+    HIP_OK(hipGetLastError());
+    return;
+  }
   reserve(mu);
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
-  const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
   mark(-1, s);
   hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
   mark(0, s);
@@ -1521,16 +1655,16 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     while (nu0 < mu) {
       const int left = mu - nu0;
       if (left >= 8) {
-        solve_block<8>(*this, bp, x, mu, nu0, s);
+        solve_block<8, false>(*this, bp, x, mu, nu0, s);
         nu0 += 8;
       } else if (left >= 4) {
-        solve_block<4>(*this, bp, x, mu, nu0, s);
+        solve_block<4, false>(*this, bp, x, mu, nu0, s);
         nu0 += 4;
       } else if (left >= 2) {
-        solve_block<2>(*this, bp, x, mu, nu0, s);
+        solve_block<2, false>(*this, bp, x, mu, nu0, s);
         nu0 += 2;
       } else {
-        solve_block<1>(*this, bp, x, mu, nu0, s);
+        solve_block<1, false>(*this, bp, x, mu, nu0, s);
         nu0 += 1;
       }
     }

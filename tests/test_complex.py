@@ -1,5 +1,6 @@
-"""complex128 local solver (fp64 + complex128): HpddmHipSubdomainNumfactZ / SolveZ -- the real-equivalent
-embedding on the real HIP kernels -- against SciPy's complex SuperLU on Helmholtz-like matrices."""
+"""complex128 local solver (fp64 + complex128): HpddmHipSubdomainNumfactZ / SolveZ -- native complex panels
+(16 bytes per entry, complex LDL^T / LU on the host, the SpTRSV streams the (re, im) pairs with the real tile kernels on the two
+planes of every right-hand side) -- against SciPy's complex SuperLU on Helmholtz-like matrices."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -39,25 +40,28 @@ def test_helmholtz_complex_symmetric_full_and_lower_storage():
     K = _laplace3d(n)
     k2 = (2.5 * np.pi) ** 2
     A = (K - k2 * sp.identity(n ** 3) + 1j * 0.8 * k2 * sp.identity(n ** 3)).tocsr()  # shifted Laplacian, complex symmetric, not Hermitian
-    assert _check(A) == 2                      # LU
-    assert _check(A, sym_storage=True, mu=3) == 2
+    assert _check(A) == 1                      # complex symmetric: L D L^T with plain transposes (detected from the values)
+    assert _check(A, sym_storage=True, mu=3) == 1
+    assert _check(A, sym_storage=True, mu=5) == 1   # 5 complex right-hand sides = 10 real columns inside: blocks of 8 + 2
 
 
 def test_strongly_imaginary_diagonal():
-    """diagonal with a tiny real part: the row phases keep the pivot-free factorisation stable"""
+    """diagonal with a tiny real part: harmless in complex arithmetic (the pivots are large in modulus)"""
     n = 10
     K = _laplace3d(n)
     A = (1e-6 * K + 1j * (K + 50.0 * sp.identity(n ** 3))).tocsr()
     _check(A, mu=2)
 
 
-def test_hermitian_positive_definite_takes_the_symmetric_path():
+def test_hermitian_and_general_complex_matrices_take_lu():
     n = 9
     K = _laplace3d(n)
     G = sp.random(n ** 3, n ** 3, density=2e-3, random_state=7, format="csr")
     H = (K + 1j * 0.3 * float(n * n) * (G - G.T)).tocsr()   # Hermitian: real symmetric + i * skew
     assert abs(H - H.getH()).max() < 1e-12
-    assert _check(H, spd=True, mu=2) == 0      # Cholesky of the real-equivalent SPD matrix
+    assert _check(H, spd=True, mu=2) == 2      # Hermitian is not complex symmetric: LU (complex Cholesky is not built)
+    nonsym = (K + 0.2 * sp.triu(K, 1) + 1j * 0.1 * float(n * n) * G).tocsr()
+    assert _check(nonsym, mu=4) == 2           # general complex: LU, 4 right-hand sides = the MFMA forward tiles with 8 real columns
 
 
 def _helmholtz3d(N, parts, overlap, shift):
