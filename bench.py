@@ -47,9 +47,11 @@ def parse_args():
     ap.add_argument("--bgmres", type=int, default=0, metavar="MU", help="extra leg: Block GMRES on MU consistent random right-hand sides (configs[4] solves 8 at a time)")
     ap.add_argument("--no-two-level", action="store_true", help="headline = the one-level apply (configs[1] flavour)")
     ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level operator")
-    ap.add_argument("--problem", choices=("poisson", "elasticity"), default="poisson",
+    ap.add_argument("--problem", choices=("poisson", "elasticity", "helmholtz"), default="poisson",
                     help="poisson: 7-point Laplacian, grid^3 cells per GPU (configs[1], configs[2]); elasticity: trilinear hexahedra, 3 dofs per "
-                         "node, grid^3 nodes per GPU (configs[3] is --problem elasticity --grid 64 on 8 GPUs)")
+                         "node, grid^3 nodes per GPU (configs[3] is --problem elasticity --grid 64 on 8 GPUs); helmholtz: complex<double> shifted "
+                         "Laplacian with absorption, grid x grid x 2 grid cells per GPU, plane-wave coarse space, Block GMRES on --mu right-hand "
+                         "sides (configs[4] is --problem helmholtz --grid 64 --mu 8 on 4 GPUs: 128^3, 32 subdomains)")
     ap.add_argument("--no-geneo", action="store_true", help="two-level operator on polynomial stand-in vectors instead of the GenEO eigenvectors (kernel timing only)")
     ap.add_argument("--no-configs-1", action="store_true", help="skip the extra configs[1] (128^3, one-level) object of the default run")
     return ap.parse_args()
@@ -102,6 +104,8 @@ def main():
     from hpddm_amd.generate import generate3d, generate_elasticity3d
 
     def generate(dims, parts, **kw):
+        if args.problem == "helmholtz":
+            return generate_helmholtz(np, generate3d, dims, parts, **kw)
         if args.problem == "elasticity":
             kw.pop("rhs", None)
             kw.setdefault("normalize", True)
@@ -110,21 +114,23 @@ def main():
 
     hpddm.require_device()
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
+    helm = args.problem == "helmholtz"
     two_level = not args.no_two_level
-    geneo = two_level and not args.no_geneo
+    geneo = two_level and not args.no_geneo and not helm   # helmholtz: the coarse space is user-supplied (plane waves)
     mu = args.mu
 
     # ---- build the operator (one-time: generator, analysis, factorisation, upload) ----
     t0 = time.time()
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    opts = "-hpddm_operator_spd" + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "")
+    want_cpu = want_cpu and not helm               # the CPU port is real arithmetic
+    opts = ("" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "")
     sharded = world > 1 and not args.replicas
     if sharded:
         # ONE global problem: grid^2 x (grid * N) cells, 2 x 2 x 2N boxes; rank r owns the 8 subdomains of its z-slab and
         # exchanges the halo of the two slab faces with ranks r-1 / r+1 (RCCL point-to-point over xGMI)
         assert args.subdomains == 8
         parts = 8 * world
-        subs = generate((args.n, args.n, args.n * world), parts, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8, normalize=True, neumann=geneo)
+        subs = generate((args.n, args.n, args.n * (2 if helm else 1) * world), parts, rhs="smooth", grid=(2, 2, 2 * world), first=8 * rank, count=8, normalize=True, neumann=geneo)
         A, d = hpddm.schwarz_from_subdomains(subs, first_global=8 * rank, nglobal=parts, options=opts, multiplicity=False,
                                              partition=(rank, [8 * r for r in range(world + 1)]))
         cap = max(1, mu, args.geneo_nu if two_level else 0)
@@ -135,33 +141,41 @@ def main():
             dist.broadcast_object_list(box, src=0, group=cpu_group)
             A.enable_rccl(box[0], mu_cap=cap)
     else:
-        subs = generate(args.n, args.subdomains, rhs="smooth", neumann=geneo)
+        subs = generate((args.n, args.n, 2 * args.n) if helm else args.n, args.subdomains, rhs="smooth", neumann=geneo, **({"grid": (2, 2, 2)} if helm else {}))
         A, d = hpddm.schwarz_from_subdomains(subs, options=opts, multiplicity=args.problem != "elasticity")
     A.call_numfact()
     t_setup = time.time() - t0
     st = A.stats()
-    ntot = int(st["n"])
+    ntot = int(st["n"])                      # unknowns in scalars K
+    sk = 16.0 if A.complex else 8.0          # sizeof(K)
     reps = max(5, min(50, args.steps))
 
-    def fvec():
+    def fvec(cols=1):
+        if helm:   # consistent random complex right-hand sides (mt19937-style seed 42, uniform re / im), made so by one exchange
+            rng = np.random.default_rng(42)
+            rhs = A.exchange([rng.random((s["n"], cols)) + 1j * rng.random((s["n"], cols)) for s in subs])
+            return torch.from_numpy(A.pack(rhs)[0]).to(dev)
         return torch.from_numpy(np.concatenate([s["f"] for s in subs])).to(dev)
 
     def gmres_leg():
-        fb = fvec()
+        cols = mu if helm else 1             # configs[4]: Block GMRES on all the right-hand sides at once
+        fb = fvec(cols)
         xs = torch.zeros_like(fb)
+        if helm:
+            A.option_parse("-hpddm_krylov_method bgmres -hpddm_max_it 400")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        it = A.solve_device(fb.data_ptr(), xs.data_ptr(), 1)
+        it = A.solve_device(fb.data_ptr(), xs.data_ptr(), cols)
         torch.cuda.synchronize()
         tg = time.perf_counter() - t1
-        return {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}
+        return {"method": "bgmres" if helm else "gmres", "rhs": cols, "iterations": it, "seconds": tg, "iters_per_sec": it / tg, "rhs_iters_per_sec": it * cols / tg, "tol": 1e-6}
 
     # ---- one-level legs first (no coarse operator yet); every rank runs the same calls: they are collective when sharded ----
     one = {"apply_ms": A.time("apply", mu=mu, warmup=2, reps=reps) * 1e3}
     one["applies_per_sec"] = world * 1e3 / one["apply_ms"]
     t_solve = A.time("solve", mu=mu, warmup=2, reps=reps)
     phases = {"sptrsv": t_solve * 1e3, "exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3}
-    if not args.no_gmres:
+    if not args.no_gmres and not helm:   # (helmholtz: the indefinite operator is only solved with its coarse space)
         one["gmres"] = gmres_leg()
 
     # ---- the two-level operator: GenEO vectors, coarse operator ----
@@ -171,7 +185,7 @@ def main():
         A.set_option("schwarz_coarse_correction", 0)   # deflated (HPDDM_SCHWARZ_COARSE_CORRECTION_DEFLATED)
 
     # ---- the timed region of the contract: W warm-up steps, K steps between barriers ----
-    x = torch.ones(ntot * mu, dtype=torch.float64, device=dev)
+    x = torch.ones(ntot * mu * (2 if A.complex else 1), dtype=torch.float64, device=dev)
     y = torch.zeros_like(x)
     torch.cuda.synchronize()
 
@@ -201,12 +215,12 @@ def main():
 
     if two_level:
         n = st["n"]
-        nu = args.geneo_nu
         t_defl = A.time("deflation", mu=mu, warmup=2, reps=reps)
-        bytes_panel = 2.0 * n * nu * 8.0 + 3.0 * n * mu * 8.0   # Z read twice + D r read, Z y written, ...
+        nu = int(tl["geneo_nu"])
+        bytes_panel = 2.0 * n * nu * sk + 3.0 * n * mu * sk      # Z read twice + D r read, Z y written, ...
         tl.update({"deflation_ms": t_defl * 1e3, "apply_ms": ms_per_step, "applies_per_sec": value,
                    "deflation_panel_GBps": bytes_panel / t_defl / 1e9, "deflation_panel_frac_of_hbm_peak": bytes_panel / t_defl / 8e12,
-                   "deflation_flops": 4.0 * n * nu * mu,
+                   "deflation_flops": 4.0 * n * nu * mu * (4.0 if A.complex else 1.0),
                    "kernel": ("k_zt_stream + k_z_stream: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
                               "MFMA utilisation 0 by construction" if mu <= 2 else
                               "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64); MFMA busy 13 % / 25 % of the SIMD cycles at nu = 20 (profiles/r01_pmc_mfma.csv): "
@@ -219,12 +233,15 @@ def main():
         cfg = {128: 1, 256: 2}.get(args.n)
         if args.problem == "poisson":
             wl = ("BASELINE.json configs[%d]" % cfg if cfg and (two_level == (cfg == 2)) else "BASELINE.json configs[%s]-like" % (cfg or 2)) + f": 3-D Poisson {args.n}^3 per GPU, "
+        elif helm:
+            kind = f"two-level RAS + plane-wave coarse space (3 per subdomain, deflated), Block GMRES on {mu} right-hand sides" if two_level else "one-level RAS"
+            wl = f"BASELINE.json configs[4] per-GPU share: Helmholtz-like 3-D complex<double> shifted Laplacian, {args.n}x{args.n}x{2 * args.n} cells per GPU, native complex panels, "
         else:
             wl = f"BASELINE.json configs[3]-like: 3-D linear elasticity (block-3 CSR), {args.n}^3 nodes per GPU, "
         out = {
             "metric": "ras_precond_applies_per_sec", "value": value, "unit": "applies/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "c128" if A.complex else "f64", "data": "synthetic",
             "config": {"workload": wl + f"{args.subdomains} subdomains per GPU, {kind}, HIP level-scheduled SpTRSV, overlap 1, mu={mu}",
                        "parallelism": ("1 GPU, 8 subdomains batched" if world == 1 else
                                        (f"{world} GPUs, one global {args.n}x{args.n}x{args.n * world} problem, 8 subdomains per GPU, cross-GPU halo / coarse gather / reductions by "
@@ -234,7 +251,7 @@ def main():
                        "setup_seconds": round(t_setup, 2)},
         }
         # ---- roofline of the dominant kernel pair (batched SpTRSV), HIP events on the library stream ----
-        bytes_alg = 2.0 * st["nnz_L"] * 8.0 + 4.0 * st["n"] * mu * 8.0   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
+        bytes_alg = 2.0 * st["nnz_L"] * sk + 4.0 * st["n"] * mu * sk   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
         out["roofline"] = roofline(bytes_alg, t_solve, st, args, mu)
         out["phases_ms"] = phases
         out["one_level"] = one
@@ -263,7 +280,7 @@ def roofline(bytes_alg, t_solve, st, args, mu):
     achieved = bytes_alg / t_solve / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
          "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep of the 8 subdomains = %d launches)" % int(st["launches"]),
-         "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve, "stored_bytes_per_sweep": 2.0 * st["stored"] * 8.0}
+         "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve, "stored_bytes_per_sweep": 2.0 * st["stored"] * (16.0 if bytes_alg > 2.0 * st["nnz_L"] * 12.0 else 8.0)}
     # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     # scripts/pmc_traffic.sh): only quoted for the workload it was collected on (same algorithmic bytes)
     for name in ("r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
@@ -286,6 +303,16 @@ def two_level_setup(A, subs, args, np, geneo):
     expo = [(a, b, c) for deg in range(8) for a in range(deg + 1) for b in range(deg + 1 - a) for c in [deg - a - b]][:nu]
     tg = time.time()
     lam_max = None
+    if args.problem == "helmholtz":
+        # the slot the reference fills with DtN vectors (solveGEVP(A, B) with a user-supplied B, include/HPDDM_schwarz.hpp:665-666):
+        # here a constant and two plane waves per subdomain, as in tests/test_complex.py
+        for s, sd in enumerate(subs):
+            t = np.arange(sd["n"], dtype=np.float64)
+            A.set_vectors(s, np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * s)], axis=1))
+        t0 = time.time()
+        A.build_coarse_operator()
+        return {"geneo_nu": 3, "coarse_dim": int(A.stats()["coarse_dim"]), "coarse_setup_seconds": round(time.time() - t0, 2), "coarse_space_seconds": round(time.time() - tg, 2),
+                "coarse_space": "constant + two plane waves per subdomain (user-supplied vectors, the DtN slot of the reference)"}
     for s, sd in enumerate(subs):
         if geneo:
             A.set_option("geneo_nu", nu)
@@ -355,6 +382,21 @@ def configs_1(np, torch, dev, args):
            "gmres": {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}}
     A.destroy()
     return out
+
+
+def generate_helmholtz(np, generate3d, dims, parts, **kw):
+    """complex symmetric shifted Laplacian with absorption: the 7-point stencil of generate3d with the diagonal times 0.97 + 0.03i
+    (k h = 0.42, about 15 points per wavelength), full storage"""
+    kw.pop("neumann", None)
+    subs = []
+    for sd in generate3d(dims, parts, overlap=1, sym=False, **kw):
+        sd = dict(sd)
+        a = sd["a"].astype(np.complex128)
+        rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
+        a[rows == sd["ja"]] *= 0.97 + 0.03j
+        sd["a"] = a
+        subs.append(sd)
+    return subs
 
 
 def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level applies/s of the device path

@@ -677,10 +677,12 @@ int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
       nnzl += (double)S.ls->host.sym.nnz_exact;
       stored += (double)S.ls->host.sym.nnz_stored;
     }
+    const double sk = op.is_complex ? 16.0 : 8.0; // sizeof(K)
+    if (op.is_complex) n /= 2;                     // unknowns are counted in scalars (the embedding has two doubles per complex one)
     stats[0] = n;
     stats[1] = nnzl;
     stats[2] = stored;
-    stats[3] = 2.0 * nnzl * 8.0 + 4.0 * n * 8.0;
+    stats[3] = 2.0 * nnzl * sk + 4.0 * n * sk;
     stats[4] = op.plan.nlev;
     stats[5] = op.plan.launches_per_solve;
     for (const auto &P : op.more_plans) stats[5] += P->launches_per_solve;

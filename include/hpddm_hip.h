@@ -234,8 +234,9 @@ int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup
  * (exact stored entries * 8); returns the number of launches. */
 int HpddmHipSchwarzRebuildPlan(HpddmHipSchwarz *A);
 int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out, int cap);
-/* stats[0..7] = sum n, sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at mu=1
- *               (2*nnz(L)*8 + 4*n*8), #levels, kernel launches per SpTRSV, sum nnz(A), coarse dimension */
+/* stats[0..7] = sum n (unknowns, in scalars K), sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at
+ *               mu=1 (2*nnz(L)*sizeof(K) + 4*n*sizeof(K); sizeof(K) = 16 for complex operators), #levels, kernel
+ *               launches per SpTRSV, sum nnz(A) (of the real-equivalent embedding for complex operators), coarse dimension */
 int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats);
 /* access to subdomain s' local solver (for Export / Info) */
 HpddmHipSubdomain *HpddmHipSchwarzGetSubdomain(HpddmHipSchwarz *A, int s);
