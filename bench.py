@@ -114,6 +114,14 @@ def main():
 
     hpddm.require_device()
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
+    # the extra configs[1] object of the default run goes first: run in the same process AFTER the 97 GB operator (three minutes of
+    # sustained streaming) the same 128^3 sweep was measured 20-25 % slower than on its own (3.1 against 2.45 ms on the same box)
+    c1 = None
+    if rank == 0 and world == 1 and args.n == 256 and args.problem == "poisson" and not args.no_configs_1:
+        try:
+            c1 = configs_1(np, torch, dev, args)
+        except Exception as e:  # the extra object must never cost the headline line
+            c1 = {"error": repr(e)}
     helm = args.problem == "helmholtz"
     two_level = not args.no_two_level
     geneo = two_level and not args.no_geneo and not helm   # helmholtz: the coarse space is user-supplied (plane waves)
@@ -266,11 +274,8 @@ def main():
     A.destroy()
     del A
     if rank == 0:
-        if world == 1 and args.n == 256 and args.problem == "poisson" and not args.no_configs_1:
-            try:
-                out["configs_1"] = configs_1(np, torch, dev, args)
-            except Exception as e:  # the extra object must never cost the headline line
-                out["configs_1"] = {"error": repr(e)}
+        if c1 is not None:
+            out["configs_1"] = c1
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
