@@ -94,6 +94,14 @@ struct Schwarz {
   DevBuf<long long>      iaoff_d;             // per subdomain offset into ia_d
   DevBuf<double>         a_d;
   long long              nnzA = 0;
+  // block CSR of the same matrices (Wrapper::bsrmm, include/HPDDM_wrapper.hpp:734-760) when every local matrix is made of dense
+  // bs x bs blocks (bs = 3: elasticity; bs = 2: the real-equivalent embedding of complex operators): one column index per block
+  int                    bsr_bs = 0;          // 0: scalar CSR only
+  DevBuf<int>            bia_d, bja_d;        // block rows / block columns, concatenated like ia_d / ja_d
+  DevBuf<long long>      biaoff_d;
+  DevBuf<double>         ba_d;                // bs x bs blocks, row-major
+  long long              nnzb = 0;
+  void                   build_bsr();
   DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
   SolvePlan              plan;
   // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
