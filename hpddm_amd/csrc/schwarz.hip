@@ -138,6 +138,15 @@ __global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restric
   }
 }
 
+// out[c * total + e] = in[sub[e]][c][idx[e]]: rows of a batched multi-vector picked by (subdomain, dof) lists (coarse assembly)
+__global__ void k_gather_rows(const long long *__restrict__ voff, const int *__restrict__ nn, const int *__restrict__ sub, const int *__restrict__ idx, long long total, const double *__restrict__ in, double *__restrict__ out, int mu)
+{
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int s = sub[e];
+    for (int c = 0; c < mu; ++c) out[(long long)c * total + e] = in[voff[s] * mu + (long long)c * nn[s] + idx[e]];
+  }
+}
+
 __global__ void k_axpy(long long cnt, double alpha, const double *__restrict__ x, double *__restrict__ y)
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) y[i] = fma(alpha, x[i], y[i]);
@@ -679,22 +688,76 @@ void Schwarz::build_coarse()
   HH_CHECK(cdim_g > 0, "BuildCoarseOperator: no deflation vector was set");
   int numax = 0;
   for (int g = 0; g < nglobal; ++g) numax = std::max(numax, gcoff[g + 1] - gcoff[g]);
-  // T_s = A_s (D_s Z_s), DZ_s = D_s Z_s
+  // T_s = A_s (D_s Z_s), DZ_s = D_s Z_s.  With the same number of vectors in every local subdomain (the usual case: GenEO with
+  // a fixed nu) Z is a batched multi-vector of nu columns, and the products run on the device with the kernels of the apply:
+  // D Z (k_diag), A (D Z) (k_csrmm / k_bsrmm, nu right-hand sides), and ALL the diagonal blocks Z_s^T D_s T_s at once through the
+  // deflation panel (k_zt_mfma); the host keeps the small neighbour blocks.  Otherwise (ragged nu) the host does it all.
   std::vector<std::vector<double>> T(nsub), DZ(nsub);
+  bool uniform = nsub > 0 && subs[0].nu > 0 && getopt("hip_host_coarse_assembly", 0) == 0;
+  for (int s = 1; s < nsub; ++s) uniform = uniform && subs[s].nu == subs[0].nu;
+  std::vector<double> diag_blocks; // uniform: [kj][cdim] with the block of subdomain s at rows coff[s] ..
+  std::vector<double> near;        // uniform, no remote neighbour: rows of the neighbours' T on the shared dofs, [c][near_total]
+  std::vector<std::vector<long long>> pair_off;
+  long long           near_total = 0;
   for (int s = 0; s < nsub; ++s) {
     const SchwarzSub &S = subs[s];
     DZ[s].assign((size_t)S.n * S.nu, 0.0);
-    T[s].assign((size_t)S.n * S.nu, 0.0);
+    if (!uniform || halo_total) T[s].assign((size_t)S.n * S.nu, 0.0);
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < S.nu; ++k) {
-      double *dz = DZ[s].data() + (size_t)k * S.n, *t = T[s].data() + (size_t)k * S.n;
+      double *dz = DZ[s].data() + (size_t)k * S.n, *t = uniform ? nullptr : T[s].data() + (size_t)k * S.n;
       for (int i = 0; i < S.n; ++i) dz[i] = S.d[i] * S.Z[(size_t)k * S.n + i];
+      if (uniform) continue;
       for (int i = 0; i < S.n; ++i) {
         double acc = 0.0;
         for (int p = S.ia[i]; p < S.ia[i + 1]; ++p) acc += S.a[p] * dz[S.ja[p]];
         t[i] = acc;
       }
     }
+  }
+  if (uniform) {
+    const int nu0 = subs[0].nu;
+    upload_vectors(); // Z_d, offsets, local coarse numbering (cdim)
+    DevBuf<double> dz_d, t_d, uc;
+    dz_d.alloc((size_t)ntot * nu0);
+    t_d.alloc((size_t)ntot * nu0);
+    uc.alloc((size_t)cdim * nu0);
+    diag(Z_d.p, dz_d.p, nu0);
+    csrmm(dz_d.p, t_d.p, nu0, 1.0, 0.0);
+    panel_zt(t_d.p, uc.p, nu0); // uc[kj * cdim + coff[s] + ki] = (Z_s^T D_s T_s)(ki, kj)
+    diag_blocks.resize((size_t)cdim * nu0);
+    HIP_OK(hipMemcpyAsync(diag_blocks.data(), uc.p, sizeof(double) * cdim * nu0, hipMemcpyDeviceToHost, st));
+    if (halo_total) { // neighbours on other GPUs: their rows go through the halo transport from the host copy below
+      for (int s = 0; s < nsub; ++s) HIP_OK(hipMemcpyAsync(T[s].data(), t_d.p + voff[s] * nu0, sizeof(double) * subs[s].n * nu0, hipMemcpyDeviceToHost, st));
+    } else {
+      // every neighbour is local: only the rows of T on the shared dofs are needed on the host -- for pair (i, k) the rows
+      // `theirs` of the neighbour j; gathered on the device into near[c][pair_off + q]
+      std::vector<int> esub, eidx;
+      pair_off.assign(nsub, {});
+      for (int i = 0; i < nsub; ++i)
+        for (int k = 0; k < (int)subs[i].map.size(); ++k) {
+          const int               j      = subs[i].map[k].first - first;
+          const std::vector<int> &theirs = peer_list(*this, j, first + i);
+          pair_off[i].push_back((long long)esub.size());
+          for (int q : theirs) {
+            esub.push_back(j);
+            eidx.push_back(q);
+          }
+        }
+      near_total = (long long)esub.size();
+      near.assign((size_t)near_total * nu0, 0.0);
+      if (near_total) {
+        DevBuf<int>    es, ei;
+        DevBuf<double> g;
+        es.upload(esub, st);
+        ei.upload(eidx, st);
+        g.alloc((size_t)near_total * nu0);
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<long long>(2048, (near_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, es.p, ei.p, near_total, t_d.p, g.p, nu0);
+        HIP_OK(hipMemcpyAsync(near.data(), g.p, sizeof(double) * near_total * nu0, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+      }
+    }
+    HIP_OK(hipStreamSynchronize(st));
   }
   // values of the neighbours' T on the shared dofs, for the neighbours owned by other ranks: halo fetch, numax columns
   std::vector<double> remote; // [col][halo_total]
@@ -729,13 +792,18 @@ void Schwarz::build_coarse()
     const int         ri = gcoff[first + i];
     // diagonal block: Z_i^T D_i T_i  (the reference scales the local product by D, include/HPDDM_operator.hpp:524, and
     // the neighbours' rows by D in applyFromNeighbor, :398-404)
+    if (uniform) {
+      for (int ki = 0; ki < Si.nu; ++ki)
+        for (int kj = 0; kj < Si.nu; ++kj) E[(size_t)(ri + ki) * cdim_g + ri + kj] = diag_blocks[(size_t)kj * cdim + coff[i] + ki];
+    } else {
 #pragma omp parallel for schedule(static) collapse(2)
-    for (int ki = 0; ki < Si.nu; ++ki)
-      for (int kj = 0; kj < Si.nu; ++kj) {
-        double acc = 0.0;
-        for (int r = 0; r < Si.n; ++r) acc += DZ[i][(size_t)ki * Si.n + r] * T[i][(size_t)kj * Si.n + r];
-        E[(size_t)(ri + ki) * cdim_g + ri + kj] = acc;
-      }
+      for (int ki = 0; ki < Si.nu; ++ki)
+        for (int kj = 0; kj < Si.nu; ++kj) {
+          double acc = 0.0;
+          for (int r = 0; r < Si.n; ++r) acc += DZ[i][(size_t)ki * Si.n + r] * T[i][(size_t)kj * Si.n + r];
+          E[(size_t)(ri + ki) * cdim_g + ri + kj] = acc;
+        }
+    }
     for (int k = 0; k < (int)Si.map.size(); ++k) {
       const auto             &pr   = Si.map[k];
       const std::vector<int> &mine = pr.second;
@@ -746,7 +814,11 @@ void Schwarz::build_coarse()
         for (int ki = 0; ki < Si.nu; ++ki)
           for (int kj = 0; kj < nuj; ++kj) {
             double acc = 0.0;
-            for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * T[j][(size_t)kj * Sj.n + theirs[q]];
+            if (uniform && !halo_total) {
+              const double *tj = near.data() + (size_t)kj * near_total + pair_off[i][k];
+              for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * tj[q];
+            } else
+              for (size_t q = 0; q < mine.size(); ++q) acc += DZ[i][(size_t)ki * Si.n + mine[q]] * T[j][(size_t)kj * Sj.n + theirs[q]];
             E[(size_t)(ri + ki) * cdim_g + rj + kj] = acc;
           }
       } else {
