@@ -131,6 +131,8 @@ struct SolvePlan {
   int               nmax = 0;
   int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
   int               persist = 0; // workgroups per CU of the persistent sweep launches
+  int               persist_narrow = 0; // launches made of wave tiles only: grid capped at this many workgroups per wavefront slot (0: one per tile)
+  bool              narrow_wave_wg = false; // ... optionally one wavefront per workgroup
   int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
@@ -155,6 +157,8 @@ struct SolvePlan {
   std::vector<hipEvent_t> prof_ev;
   std::vector<int>        prof_tag;
   void                    mark(int tag, hipStream_t s);
+  static unsigned long long *timeline_host;           // developer aid (HPDDM_HIP_DBG & 32): pinned buffer the wave tiles write their clocks to
+  static unsigned int        timeline_count();
   std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch (chains excluded)
   std::vector<double>     level_bytes(int kind) const;
 };

@@ -53,7 +53,20 @@ __device__ static inline SnView view(const SnDesc &d)
 }
 // developer aid (HPDDM_HIP_DBG, wrong results): 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand
 // side staging, 8 skip the panel loads
-enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8, DBG_NOMFMA = 16 }; // 16: the VALU tiles instead of the MFMA ones (exact, for comparison)
+enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8, DBG_NOMFMA = 16, DBG_TIMELINE = 32 };
+// developer aid (HPDDM_HIP_DBG & 32, results stay exact): wave tiles of the narrow panels record the constant-rate clock
+// (100 MHz) at five points -- kernel entry, descriptor in registers, right-hand side staged, panel streamed, results stored --
+// into a device buffer, 8 entries per tile (last three: level-independent tile index, rows, doubles per row)
+__device__ unsigned long long *g_timeline     = nullptr;
+__device__ unsigned int        g_timeline_cap = 0, g_timeline_cnt = 0;
+__device__ static inline void  timeline_put(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3, unsigned long long t4, int rows, int cols, int kind)
+{
+  const unsigned int k = atomicAdd(&g_timeline_cnt, 1u);
+  if (k < g_timeline_cap) {
+    unsigned long long *o = g_timeline + 8ull * k;
+    o[0] = t0, o[1] = t1, o[2] = t2, o[3] = t3, o[4] = t4, o[5] = (unsigned long long)rows, o[6] = (unsigned long long)cols, o[7] = (unsigned long long)kind;
+  }
+} // 16: the VALU tiles instead of the MFMA ones (exact, for comparison)
 
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
 
@@ -158,6 +171,21 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
   } else if (!d.has_src) {
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = s[nu * sstride];
+  } else if (d.src4) {
+    // 4 fixed gather slots per entry of the front: one 16-byte index load, then the (at most 4) update-vector entries in
+    // flight together -- two dependent round trips instead of two per source; same summation order as the list walk below
+    const int4v sr = d.src4[r];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = sr[j] >= 0 ? Ub[(long long)nu * d.usize + sr[j]] : 0.0;
+      double v = s[nu * sstride];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (sr[j] >= 0) v += u[j];
+      Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v;
+    }
   } else {
     const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
 #pragma unroll
@@ -176,7 +204,7 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
 // lanes own pairs of OUTPUT rows and walk down the w columns of F (= rows of FT), exactly as the backward sweep walks the
 // rows of G; the only cross-lane step is one reduction over the R column groups at the end.  Tile = nr <= 128 output rows.
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg)
+__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg, unsigned long long = 0)
 {
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
@@ -254,6 +282,173 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
     const int r = t.r0 + 2 * gl, rend = t.r0 + t.nr;
     if (r < rend) fwd_store_row<MU>(d, r, acc0, 1, yb, Ub);
     if (r + 1 < rend) fwd_store_row<MU>(d, r + 1, acc1, 1, yb, Ub);
+  }
+}
+
+// One right-hand side: the same tile with every load that depends on the descriptor only requested together.
+template <int MU, int FWD_PASSES, bool Z>
+__device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg, unsigned long long tk0 = 0)
+{
+  const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
+  unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
+  if (dbg & DBG_TIMELINE) tk1 = wall_clock64() + (unsigned long long)(w < 0);
+  const int g = (t.nr + 1) >> 1, R = 64 / g;
+  const int sub = lane / g, gl = lane - sub * g;
+  const bool active = sub < R;
+  const gcd_t Fp = d.FT + t.r0 + 2 * gl;
+  const int   rtop = t.r0 + 2 * gl + 1; // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop
+  const int   r_out = t.r0 + 2 * gl, rend = t.r0 + t.nr;
+  // A tile of the bottom levels is a chain of dependent round trips with a few KB of panel behind it, and a level is bound by
+  // (length of that chain) / (tiles in flight).  Everything that depends on the descriptor only is requested together, in the
+  // order it is needed (loads return in order): gather slots of this lane's column and of its two output rows, its right-hand
+  // side entries, the first TWO groups of panel rows; then the update-vector entries the slots point to, for the right-hand
+  // side and for the rows at once.  Three round trips (descriptor / this batch / update entries) instead of one per link of
+  // the lists, twice; the stores drain behind the next tile of the wavefront (sptrsv_fwd_kernel).
+  const bool slots = d.src4 != nullptr; // 4 fixed gather slots per entry of the front (at most 4 sources each)
+  const bool lists = d.has_src && !slots;
+  int4v      csrc = {-1, -1, -1, -1}, rsrc[2];
+  double     fv[MU];
+  const bool mine = lane < w && !(dbg & DBG_NORHS); // lane c stages column c (supernodes wider than 64 take the loop below)
+  if (slots && mine) csrc = d.src4[lane];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) rsrc[k] = (slots && sub == 0 && r_out + k >= w && r_out + k < rend) ? d.src4[r_out + k] : int4v{-1, -1, -1, -1};
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) fv[nu] = mine ? bb[(long long)nu * d.n + d.c0 + lane] : 0.0;
+  dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
+#pragma unroll
+  for (int p = 0; p < FWD_PASSES; ++p) {
+    const int i = sub + p * R, i2 = i + FWD_PASSES * R;
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
+  }
+  double radd[2][MU];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) radd[k][nu] = 0.0;
+  if (slots) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double uc[4], ur[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uc[j]    = csrc[j] >= 0 ? Ub[(long long)nu * d.usize + csrc[j]] : 0.0;
+        ur[0][j] = rsrc[0][j] >= 0 ? Ub[(long long)nu * d.usize + rsrc[0][j]] : 0.0;
+        ur[1][j] = rsrc[1][j] >= 0 ? Ub[(long long)nu * d.usize + rsrc[1][j]] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { // same order as the list walk
+        if (csrc[j] >= 0) fv[nu] -= uc[j];
+        if (rsrc[0][j] >= 0) radd[0][nu] += ur[0][j];
+        if (rsrc[1][j] >= 0) radd[1][nu] += ur[1][j];
+      }
+    }
+  } else if (lists && mine) {
+    const int q0 = d.gptr[lane], q1 = d.gptr[lane + 1];
+    for (int q = q0; q < q1; ++q) {
+      const int src = d.gsrc[q];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) fv[nu] -= Ub[(long long)nu * d.usize + src];
+    }
+  }
+  auto stage = [&](int c, const double *v) {
+    if constexpr (!Z) {
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
+    } else { // R = [ f_r  f_i ; -f_i  f_r ]: slots 2c, 2c + 1 of the real plane (nu even) and of the imaginary plane (nu odd)
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        lds[nu * wr + 2 * c]     = v[nu];
+        lds[nu * wr + 2 * c + 1] = (nu & 1) ? v[nu - 1] : -v[nu + 1];
+      }
+    }
+  };
+  if (mine) stage(lane, fv);
+  for (int c = lane + 64; c < w && !(dbg & DBG_NORHS); c += 64) { // columns 64 .. 127 of the widest narrow supernodes
+    double v[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
+    if (slots) {
+      const int4v sc = d.src4[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (sc[j] >= 0) {
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + sc[j]];
+        }
+    } else if (lists) {
+      const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
+      for (int q = q0; q < q1; ++q) {
+        const int src = d.gsrc[q];
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
+      }
+    }
+    stage(c, v);
+  }
+  wave_lds_order();
+  if (dbg & DBG_TIMELINE) tk2 = wall_clock64();
+  double acc0[MU], acc1[MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+  for (int ib0 = 0; ib0 < wc; ib0 += FWD_PASSES * R) {
+    const int ib = ib0 + sub;
+    // cur = rows of this group, nxt = the next group (already requested); request the one after into nx2
+    dbl2 nx2[FWD_PASSES];
+    const bool more2 = ib0 + 2 * FWD_PASSES * R < wc;
+    if (more2) {
+#pragma unroll
+      for (int p = 0; p < FWD_PASSES; ++p) {
+        const int i = ib + (2 * FWD_PASSES + p) * R;
+        nx2[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      const int i = min(ib + p * R, wc - 1); // out-of-range passes carry a = 0
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        const double v = lds[nu * wr + i];
+        acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+        acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < FWD_PASSES; ++p) {
+      cur[p] = nxt[p];
+      nxt[p] = more2 ? nx2[p] : dbl2{0.0, 0.0};
+    }
+  }
+  if (!(dbg & DBG_NORED)) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
+      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
+    }
+  }
+  if (dbg & DBG_TIMELINE) tk3 = wall_clock64() + (unsigned long long)(acc0[0] == 1.2345e300);
+  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
+    if (!lists) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = r_out + k;
+        if (r < rend) {
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) {
+            const double v = k ? acc1[nu] : acc0[nu];
+            if (r < w) yb[(long long)nu * d.n + d.c0 + r] = v;
+            else Ub[(long long)nu * d.usize + d.u_off + (r - w)] = v + radd[k][nu]; // fixed order: s + ((u0 + u1) + ...)
+          }
+        }
+      }
+    } else {
+      if (r_out < rend) fwd_store_row<MU>(d, r_out, acc0, 1, yb, Ub);
+      if (r_out + 1 < rend) fwd_store_row<MU>(d, r_out + 1, acc1, 1, yb, Ub);
+    }
+  }
+  if ((dbg & DBG_TIMELINE) && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    timeline_put(tk0, tk1, tk2, tk3, wall_clock64(), t.nr, wc, d.has_src ? 1 : 0);
   }
 }
 
@@ -985,10 +1180,13 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
 // One launch per level and direction: every workgroup takes block-level tiles g, g + G, ... with its four wavefronts
 // together, then its wavefronts take wave-level tiles on their own (G = grid size; by default one share per workgroup).
 // Tiles are sorted by decreasing cost.  wr = rows of right-hand side a wavefront stages in LDS (the level's maximum).
+// launches made of wave tiles only (the bottom levels) are bound by (latency of a tile) / (tiles in flight): one or two real
+// right-hand sides are held to 64 VGPRs = 8 wavefronts per SIMD
 template <int MU, bool HAS_BLOCK, int FP, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const unsigned long long tk0 = (dbg & DBG_TIMELINE) ? wall_clock64() : 0ull;
   const int G = gridDim.x;
   if (HAS_BLOCK) {
     for (int bt = blockIdx.x; bt < nblock; bt += G) {
@@ -1009,19 +1207,21 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_kernel(const SnDesc *__
   double   *wl = lds + wv * (wr * MU);
   // the wave-level deal starts where the block-level deal stopped
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
-  for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
+  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup: 4, or 1 in the launches made of wave tiles only
+  for (int tix = gw * wpb + wv; tix < nwave; tix += G * wpb) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg);
-    wave_lds_sync(); // the last reads of the staged right-hand side land before the next tile overwrites it
+    if constexpr (MU == 1) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0);
+    else fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0);
+    wave_lds_order(); // the last reads of the staged right-hand side land before the next tile overwrites it; the stores of this tile drain while the next one starts (tiles of a level are independent)
   }
 }
 
 template <int MU, bool HAS_BLOCK, int FP, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr, int dbg)
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -1039,14 +1239,15 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_kernel(const SnDesc *__
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *wl = lds + wv * (wr * MU);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
-  for (int tix = gw * (WG_THREADS / 64) + wv; tix < nwave; tix += G * (WG_THREADS / 64)) {
+  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup: 4, or 1 in the launches made of wave tiles only
+  for (int tix = gw * wpb + wv; tix < nwave; tix += G * wpb) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
     bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo, dbg);
-    wave_lds_sync();
+    wave_lds_order();
   }
 }
 
@@ -1239,7 +1440,21 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   // developer knobs of the plan (defaults = what measured best on the bench workloads)
   auto envi             = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
   dbg                   = envi("HPDDM_HIP_DBG", 0);
+  if (dbg & DBG_TIMELINE) {
+    static unsigned long long *hostbuf = nullptr;
+    const unsigned int         cap     = 1u << 20;
+    if (!hostbuf) {
+      HIP_OK(hipMalloc((void **)&hostbuf, sizeof(unsigned long long) * 8 * cap)); // device memory: host-mapped writes would perturb the sweeps
+      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &hostbuf, sizeof(hostbuf)));
+      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cap), &cap, sizeof(cap)));
+      timeline_host = hostbuf;
+    }
+    const unsigned int zero = 0;
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cnt), &zero, sizeof(zero)));
+  }
   persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
+  narrow_wave_wg        = envi("HPDDM_HIP_NARROW_WAVE_WG", 0) != 0; // launches of wave tiles only: single-wavefront workgroups (measured: same time)
+  persist_narrow        = envi("HPDDM_HIP_PERSIST_NARROW", 0); // ... and, if > 0, at most this many of them per wavefront slot (each walks several tiles)
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
@@ -1535,6 +1750,14 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   HIP_OK(hipStreamSynchronize(s));
 }
 
+unsigned long long *SolvePlan::timeline_host = nullptr;
+unsigned int        SolvePlan::timeline_count()
+{
+  unsigned int c = 0;
+  HIP_OK(hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_timeline_cnt), sizeof(c)));
+  return c;
+}
+
 void SolvePlan::mark(int tag, hipStream_t s)
 {
   if (!profile) return;
@@ -1573,11 +1796,18 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // per wavefront, of its widest wave-level tile -- so that the small levels keep many workgroups per CU even with 8
   // right-hand sides.  Forward, wide panels: 4 rows in flight per wavefront, 2 with 8 right-hand sides (accumulators
   // within 128 VGPRs); backward: 4.
-  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4;
+  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU == 1 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
   auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   auto wrows  = [&](int kd, int l) { return std::max(16, (P.lev_lds[kd][l] + 15) / 16 * 16); };
   auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(P.lds_cap, (need + 63) / 64 * 64)); };
+  // Launches made of wave tiles only (the bottom levels), optionally with ONE wavefront per workgroup (HPDDM_HIP_NARROW_WAVE_WG):
+  // the tile latencies have a heavy tail (median 7.8 us, p90 two to three times that: per-tile clocks of HPDDM_HIP_DBG=32) and a
+  // 4-wavefront workgroup holds its slot until its slowest tile is done (55-60 % of the wavefront slots busy on average) -- but
+  // single-wavefront workgroups, persistent grids and shorter chains all measured the same level times: these levels are bound
+  // by the bytes they pull (1.3-2 x their panel entries: descriptors, gather lists, line-granular vector accesses), DESIGN.md 4.1.
+  const int  narrow_wpb = P.narrow_wave_wg ? 1 : 4;
   auto grid   = [&](int nb, int nw, int ld_dbl) {
+    if (nb == 0 && narrow_wpb == 1) return P.persist_narrow > 0 ? std::max(1, std::min(nw, 256 * 8 * P.persist_narrow)) : nw;
     const int want = nb + (nw + 3) / 4;
     if (P.persist <= 0) return want;
     const int per_cu = std::max(1, std::min(P.persist, (int)((160 * 1024) / ((size_t)ld_dbl * sizeof(double)))));
@@ -1598,7 +1828,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 512 : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
     if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
     if (nb || nw) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
@@ -1606,7 +1836,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int wr = nw ? wrows(SolvePlan::BWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
     if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     if (nb || nw) P.mark(3000 + l, s);
   }
   if (P.nchains) {
