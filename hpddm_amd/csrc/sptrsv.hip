@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    if constexpr (MU == 1) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0);
+    if constexpr (MU == 1 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
     else fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0);
     wave_lds_order(); // the last reads of the staged right-hand side land before the next tile overwrites it; the stores of this tile drain while the next one starts (tiles of a level are independent)
   }
