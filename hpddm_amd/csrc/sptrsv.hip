@@ -1853,7 +1853,9 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     // mu complex right-hand sides = 2 mu real columns (planes) inside; register blocks of 8 / 4 / 2 real columns
     const int mr = 2 * mu;
     reserve(mr);
+    mark(-1, s);
     hipLaunchKernelGGL(k_perm_in_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+    mark(0, s);
     int nu0 = 0;
     while (nu0 < mr) {
       const int left = mr - nu0;
@@ -1869,6 +1871,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
       }
     }
     hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu);
+    mark(4000, s);
     HIP_OK(hipGetLastError());
     return;
   }
