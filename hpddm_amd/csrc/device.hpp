@@ -133,6 +133,7 @@ struct SolvePlan {
   int               persist = 0; // workgroups per CU of the persistent sweep launches
   int               persist_narrow = 0; // launches made of wave tiles only: grid capped at this many workgroups per wavefront slot (0: one per tile)
   bool              narrow_wave_wg = false; // ... optionally one wavefront per workgroup
+  bool              mu16 = true;            // complex scalars: blocks of 16 real columns (8 right-hand sides) per sweep
   int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]

@@ -82,6 +82,30 @@ __device__ static inline double reduce_across(double v, int lane, int sub, int g
   }
   return v;
 }
+// the same sums for the two accumulators of MU right-hand sides at once: the steps outside, the values inside, so that the
+// 4 MU shuffles of a step are in flight together (step after step per value, a tile pays 2 MU x log2(R) shuffle latencies)
+template <int MU>
+__device__ static inline void reduce_across_pairs(double (&a0)[MU], double (&a1)[MU], int lane, int sub, int g, int R)
+{
+  int width = R, off = 1;
+  while (off < R) off <<= 1;
+  for (off >>= 1; off >= 1; off >>= 1) {
+    const int  from = min(63, lane + off * g);
+    const bool take = sub + off < width;
+    double     t0[MU], t1[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      t0[nu] = __shfl(a0[nu], from);
+      t1[nu] = __shfl(a1[nu], from);
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      a0[nu] = take ? a0[nu] + t0[nu] : a0[nu];
+      a1[nu] = take ? a1[nu] + t1[nu] : a1[nu];
+    }
+    width = min(width, off);
+  }
+}
 
 // LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
 __device__ static inline void wave_lds_sync()
@@ -187,13 +211,18 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
       Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v;
     }
   } else {
+    // sources outside, right-hand sides inside: the MU loads of one source are in flight together (same sums, same order)
     const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
+    double    v[MU];
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      double v = s[nu * sstride];
-      for (int q = q0; q < q1; ++q) v += Ub[(long long)nu * d.usize + d.gsrc[q]];
-      Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v;
+    for (int nu = 0; nu < MU; ++nu) v[nu] = s[nu * sstride];
+    for (int q = q0; q < q1; ++q) {
+      const int src = d.gsrc[q];
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) v[nu] += Ub[(long long)nu * d.usize + src];
     }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v[nu];
   }
 }
 
@@ -224,11 +253,24 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
     if (d.has_src) {
-      const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
-      for (int q = q0; q < q1; ++q) {
-        const int src = d.gsrc[q];
+      if (MU > 1 && d.src4) { // fixed slots: one 16-byte index load, then every update-vector entry in flight (same order as the list)
+        const int4v sr = d.src4[c];
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
+        for (int j = 0; j < 4; ++j) { // empty slots read entry 0 of the pool and subtract 0.0: no branch between the loads
+          const int sj = max(sr[j], 0);
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) {
+            const double u = Ub[(long long)nu * d.usize + sj];
+            v[nu] -= sr[j] >= 0 ? u : 0.0;
+          }
+        }
+      } else {
+        const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
+        for (int q = q0; q < q1; ++q) {
+          const int src = d.gsrc[q];
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
+        }
       }
     }
     if constexpr (!Z) {
@@ -272,11 +314,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
     }
   }
   if (!(dbg & DBG_NORED)) {
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
-      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
-    }
+    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
   if (sub == 0 && !(dbg & DBG_NOSTORE)) {
     const int r = t.r0 + 2 * gl, rend = t.r0 + t.nr;
@@ -420,11 +458,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
     }
   }
   if (!(dbg & DBG_NORED)) {
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
-      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
-    }
+    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
   if (dbg & DBG_TIMELINE) tk3 = wall_clock64() + (unsigned long long)(acc0[0] == 1.2345e300);
   if (sub == 0 && !(dbg & DBG_NOSTORE)) {
@@ -519,11 +553,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
     }
   }
   if (!(dbg & DBG_NORED)) {
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      acc0[nu] = reduce_across(acc0[nu], lane, sub, g, R);
-      acc1[nu] = reduce_across(acc1[nu], lane, sub, g, R);
-    }
+    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
   if (sub == 0 && !(dbg & DBG_NOSTORE)) {
     if constexpr (!Z) {
@@ -675,11 +705,7 @@ __device__ static inline void chain_fwd(const SnDesc *__restrict__ sns, const Ti
 #pragma unroll
       for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
     }
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      acc0[nu] = reduce_across(acc0[nu], lane, q.sub, q.g, q.R);
-      acc1[nu] = reduce_across(acc1[nu], lane, q.sub, q.g, q.R);
-    }
+    reduce_across_pairs<MU>(acc0, acc1, lane, q.sub, q.g, q.R);
     if (q.sub == 0) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -801,11 +827,7 @@ __device__ static inline void chain_bwd(const SnDesc *__restrict__ sns, const Ti
 #pragma unroll
       for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
     }
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      acc0[nu] = reduce_across(acc0[nu], lane, q.sub, q.g, q.R);
-      acc1[nu] = reduce_across(acc1[nu], lane, q.sub, q.g, q.R);
-    }
+    reduce_across_pairs<MU>(acc0, acc1, lane, q.sub, q.g, q.R);
     if (q.sub == 0) {
       const int c = 2 * q.gl;
       if (c < w) {
@@ -950,9 +972,9 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
   const bool    busy = rg < nrg;
   const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
   const bool    rvalid = busy && row < rend;
-  double       *red  = lds + (lds_dbl - 512);            // [4 wavefronts][16 rows][8]
+  double       *red  = lds + (lds_dbl - 64 * MU);        // [4 wavefronts][16 rows][MU]
   double       *sums = red - 64 * MU;                    // [MU][64]
-  const int     CW   = ((lds_dbl - 512 - 64 * MU) / MU) & ~15; // columns of the right-hand side staged per chunk
+  const int     CW   = ((lds_dbl - 128 * MU) / MU) & ~15; // columns of the right-hand side staged per chunk
   const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
   const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0; // ... and this row group stops at its own last diagonal entry
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
@@ -965,27 +987,52 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
       lds[i * MU + nu] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
     }
     __syncthreads();
-    const int cend = min(kend, (my_lim + 15) & ~15);
-    for (int cb = k0 + 16 * ks; cb < cend; cb += 16 * wpg) {
-      dbl2 a01 = {0.0, 0.0}, a23 = {0.0, 0.0};
-      if (rvalid) {
-        a01 = *(gcd2_t)(Frow + cb);
-        a23 = *(gcd2_t)(Frow + cb + 2);
+    const int cend = min(kend, (my_lim + 15) & ~15), step = 16 * wpg;
+    // PF column blocks of the chunk requested together and the next PF behind them: a wavefront keeps 2 x PF x 32 bytes per lane in
+    // flight (levels with few tiles -- the top of a small tree -- are bound by the latency of these loads, not by HBM)
+    constexpr int PF = 4;
+    dbl2          c01[PF], c23[PF], n01[PF], n23[PF];
+    auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
+      if (rvalid && cb < cend) {
+        x = *(gcd2_t)(Frow + cb);
+        y = *(gcd2_t)(Frow + cb + 2);
+      } else x = y = dbl2{0.0, 0.0};
+    };
+    int cb = k0 + 16 * ks;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(cb + u * step, c01[u], c23[u]);
+    for (; cb < cend; cb += PF * step) {
+      const bool more = cb + PF * step < cend;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(cb + (PF + u) * step, n01[u], n23[u]);
       }
-      const int c = cb + 4 * g; // this lane's first column
-      if (row < w) {            // triangular top block: nothing right of the diagonal (entry = cs doubles)
-        const int last = cs * (row + 1) - 1;
-        a01.x = c <= last ? a01.x : 0.0;
-        a01.y = c + 1 <= last ? a01.y : 0.0;
-        a23.x = c + 2 <= last ? a23.x : 0.0;
-        a23.y = c + 3 <= last ? a23.y : 0.0;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (cb + u * step >= cend) break; // wave-uniform
+        dbl2      a01 = c01[u], a23 = c23[u];
+        const int c = cb + u * step + 4 * g; // this lane's first column
+        if (row < w) {                        // triangular top block: nothing right of the diagonal (entry = cs doubles)
+          const int last = cs * (row + 1) - 1;
+          a01.x = c <= last ? a01.x : 0.0;
+          a01.y = c + 1 <= last ? a01.y : 0.0;
+          a23.x = c + 2 <= last ? a23.x : 0.0;
+          a23.y = c + 3 <= last ? a23.y : 0.0;
+        }
+        const double *fl = lds + (c - k0) * MU + j;
+        const double  b0 = j < MU ? fl[0] : 0.0, b1 = j < MU ? fl[MU] : 0.0, b2 = j < MU ? fl[2 * MU] : 0.0, b3 = j < MU ? fl[3 * MU] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b3, acc, 0, 0, 0);
       }
-      const double *fl = lds + (c - k0) * MU + j;
-      const double  b0 = j < MU ? fl[0] : 0.0, b1 = j < MU ? fl[MU] : 0.0, b2 = j < MU ? fl[2 * MU] : 0.0, b3 = j < MU ? fl[3 * MU] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b3, acc, 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          c01[u] = n01[u];
+          c23[u] = n23[u];
+        }
+      }
     }
   }
   // D[(lane >> 4) + 4 reg][lane & 15] -> per-wavefront partial sums, then one sum per row over the column split
@@ -1068,12 +1115,20 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
     __syncthreads();
   }
   // reduce over the R row groups of the wavefront, then over the 4 wavefronts through LDS
+  if (!(dbg & DBG_NORED)) {
+    double a0[MU], a1[MU];
 #pragma unroll
-  for (int nu = 0; nu < MU; ++nu)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (!(dbg & DBG_NORED)) acc[nu][k] = reduce_across(acc[nu][k], lane, sub, g, R);
+    for (int nu = 0; nu < MU; ++nu) {
+      a0[nu] = acc[nu][0];
+      a1[nu] = acc[nu][1];
     }
+    reduce_across_pairs<MU>(a0, a1, lane, sub, g, R);
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      acc[nu][0] = a0[nu];
+      acc[nu][1] = a1[nu];
+    }
+  }
   if (sub == 0) {
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
@@ -1453,9 +1508,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cnt), &zero, sizeof(zero)));
   }
   persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
+  mu16                  = envi("HPDDM_HIP_MU16", 1) != 0;           // complex scalars: 8 right-hand sides = 16 real columns in ONE sweep over L
   narrow_wave_wg        = envi("HPDDM_HIP_NARROW_WAVE_WG", 0) != 0; // launches of wave tiles only: single-wavefront workgroups (measured: same time)
   persist_narrow        = envi("HPDDM_HIP_PERSIST_NARROW", 0); // ... and, if > 0, at most this many of them per wavefront slot (each walks several tiles)
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
+  const int  fwd_want    = envi("HPDDM_HIP_FWD_WANT", 0) / std::max(1, groups); // wide panels, forward: levels with fewer workgroups than this get shorter tiles
   const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
@@ -1520,15 +1577,18 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   }
   lev_bytes.assign(nlev, 0.0);
   std::vector<long long> wide_cost(nlev, 0);                  // entries of the wide panels per level
-  if (fwd_target > 0)
-    for (size_t f = 0; f < fs.size(); ++f) {
-      const DeviceFactor &D = *fs[f];
-      for (idx_t k = 0; k < D.nblk; ++k)
-        if (D.ldw[k] > NARROW) {
-          const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
-          wide_cost[D.height[k]] += w * (w + 1) / 2 + nb * w;
-        }
-    }
+  std::vector<long long> wide_rows(nlev, 0);                  // ... and their rows in units of 16 (the shortest forward tile)
+  auto fwd_tile_rows = [](int wc) { return wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); }; // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
+  for (size_t f = 0; f < fs.size(); ++f) {
+    const DeviceFactor &D = *fs[f];
+    const int           cs = D.cplx ? 2 : 1;
+    for (idx_t k = 0; k < D.nblk; ++k)
+      if (D.ldw[k] * cs > NARROW) {
+        const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
+        wide_cost[D.height[k]] += w * (w + 1) / 2 + nb * w;
+        wide_rows[D.height[k]] += (w + nb + 15) / 16;
+      }
+  }
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     desc_base[f]          = (int)descs.size();
@@ -1572,7 +1632,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
-        const int trb = d.wc <= 960 ? 64 : (d.wc <= 3968 ? 32 : 16);
+        // ... and shorter on a level whose wide panels field fewer than fwd_want workgroups that way (the top of a small tree):
+        // down to 16 rows, the height of one MFMA fragment
+        int trb = fwd_tile_rows(d.wc);
+        while (trb > 16 && fwd_want > 0 && wide_rows[lev] * 16 / trb < fwd_want) trb >>= 1;
         if (fwd_target > 0) {
           // tiles of equal AREA: the rows of the triangular top block are short, so the tiles there are taller (at most
           // 64 rows); the area follows the level's total so that a level of few, huge supernodes still fields fwd_target
@@ -1784,7 +1847,7 @@ void SolvePlan::reserve(int mu)
   xw.alloc((size_t)ntot * mu);
   bperm.alloc((size_t)ntot * mu);
   U.alloc((size_t)std::max<long long>(utot, 1) * mu);
-  partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 8));
+  partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 16));
   mu_cap = mu;
 }
 
@@ -1796,10 +1859,21 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // per wavefront, of its widest wave-level tile -- so that the small levels keep many workgroups per CU even with 8
   // right-hand sides.  Forward, wide panels: 4 rows in flight per wavefront, 2 with 8 right-hand sides (accumulators
   // within 128 VGPRs); backward: 4.
-  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU == 1 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
+  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = (MU == 1 || MU >= 16) ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
   auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   auto wrows  = [&](int kd, int l) { return std::max(16, (P.lev_lds[kd][l] + 15) / 16 * 16); };
-  auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(P.lds_cap, (need + 63) / 64 * 64)); };
+  const int lds_cap = MU > 8 ? std::min(2 * P.lds_cap, 8128) : P.lds_cap; // 16 columns: the same number of staged panel columns as with 8
+  auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(lds_cap, (need + 63) / 64 * 64)); };
+  if constexpr (MU > 8) { // up to 4 x 256 rows x 16 columns of staged right-hand side per workgroup of wave tiles: beyond the default 64 KB
+    static bool once = false;
+    if (!once) {
+      once = true;
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_fwd_kernel<MU, true, FPF, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_fwd_kernel<MU, false, FPN, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_bwd_kernel<MU, true, FPB, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_bwd_kernel<MU, false, FPB, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+  }
   // Launches made of wave tiles only (the bottom levels), optionally with ONE wavefront per workgroup (HPDDM_HIP_NARROW_WAVE_WG):
   // the tile latencies have a heavy tail (median 7.8 us, p90 two to three times that: per-tile clocks of HPDDM_HIP_DBG=32) and a
   // 4-wavefront workgroup holds its slot until its slowest tile is done (55-60 % of the wavefront slots busy on average) -- but
@@ -1814,7 +1888,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     return std::max(1, std::min(want, 256 * per_cu));
   };
   constexpr int NPC = MU >= 8 ? 2 : 4; // panel rows in flight per lane of the chain kernels
-  if (P.nchains) {
+  if constexpr (MU <= 8) if (P.nchains) {
     hipLaunchKernelGGL((sptrsv_fwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[0] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[0], P.chain_ptr[0].p, P.nchains, b, P.y.p, P.U.p, mu_total, nu0, P.chain_lds[0]);
     P.mark(5000, s);
   }
@@ -1826,7 +1900,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
       P.mark(1000 + l, s);
     }
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
-    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 512 : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
+    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
     if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
     else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
     if (nb || nw) P.mark(2000 + l, s);
@@ -1839,7 +1913,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     if (nb || nw) P.mark(3000 + l, s);
   }
-  if (P.nchains) {
+  if constexpr (MU <= 8) if (P.nchains) {
     hipLaunchKernelGGL((sptrsv_bwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[1] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[1], P.chain_ptr[1].p, P.nchains, P.y.p, P.xw.p, mu_total, nu0, P.chain_lds[1]);
     P.mark(6000, s);
   }
@@ -1859,7 +1933,10 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     int nu0 = 0;
     while (nu0 < mr) {
       const int left = mr - nu0;
-      if (left >= 8) {
+      if (left >= 16 && mu16) {
+        solve_block<16, true>(*this, bperm.p, xw.p, mr, nu0, s);
+        nu0 += 16;
+      } else if (left >= 8) {
         solve_block<8, true>(*this, bperm.p, xw.p, mr, nu0, s);
         nu0 += 8;
       } else if (left >= 4) {
