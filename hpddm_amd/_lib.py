@@ -69,6 +69,7 @@ def _declare(lib):
         "HpddmHipSchwarzComputeResidual": (I, [P, P, P, P, US]),
         "HpddmHipSchwarzComputeResidualNorm": (I, [P, P, P, P, US, I]),
         "HpddmHipSolve": (I, [P, P, P, I, P, I]),
+        "HpddmHipSchwarzSetCustomOperator": (I, [P, P, P, P]),
         "HpddmHipSchwarzSetPartition": (I, [P, I, I, P]),
         "HpddmHipSchwarzHaloPeers": (I, [P, I, P, P, P]),
         "HpddmHipSchwarzSetTransport": (I, [P, P, P, P, P, P, I]),

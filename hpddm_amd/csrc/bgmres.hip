@@ -887,10 +887,10 @@ static int bfbcg_impl(Schwarz &A, const double *b, double *x, double *history, i
 
 int Schwarz::bfbcg(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   // same hand-over as the reference (include/HPDDM_CG.hpp:351-357): not a symmetric preconditioner -> GMRES; flexible -> CG
   const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
-  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  if (!custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED))) return gmres(b, x, mu, history, history_cap); // (hpddm_method_id 1 and 4 only: a custom operator goes on)
   if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
   int it;
   switch (mu) {
@@ -910,10 +910,10 @@ int Schwarz::bfbcg(const double *b, double *x, int mu, double *history, int hist
 
 int Schwarz::bcg(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   // same hand-over as the reference (include/HPDDM_CG.hpp:180-186): not a symmetric preconditioner -> GMRES; flexible -> CG
   const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
-  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  if (!custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED))) return gmres(b, x, mu, history, history_cap); // (hpddm_method_id 1 and 4 only: a custom operator goes on)
   if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
   int it;
   switch (mu) {
@@ -1354,7 +1354,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
 
 int Schwarz::bgcrodr(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   if (std::min((int)getopt("gmres_restart", 40) - 1, (int)getopt("recycle", 0)) <= 0) return bgmres(b, x, mu, history, history_cap); // (:460-465)
   if (!recycled_block || recycled_block_mu != mu) { // the recycled blocks belong to one block width (:477-481)
     recycled_block.reset(new Recycled());
@@ -1380,7 +1380,7 @@ int Schwarz::bgcrodr(const double *b, double *x, int mu, double *history, int hi
 
 int Schwarz::bgmres(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   int it;
   switch (mu) {
   case 1: it = bgmres_impl<1>(*this, b, x, history, history_cap); break;

@@ -459,6 +459,16 @@ int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, doub
   }
 }
 
+int HpddmHipSchwarzSetCustomOperator(HpddmHipSchwarz *A, int (*mv)(void *, const double *, double *, int), int (*precond)(void *, const double *, double *, int), void *ctx)
+{
+  HH_TRY(
+    HH_CHECK(A && (mv || !precond), "bad argument (a preconditioner callback needs an operator callback)");
+    HH_CHECK(!A->op.is_complex, "custom operators are built for K = double");
+    A->op.custom_mv      = mv;
+    A->op.custom_precond = precond;
+    A->op.custom_ctx     = ctx;
+    return 0;)
+}
 int HpddmHipSchwarzSetPartition(HpddmHipSchwarz *A, int nranks, int rank, const int *firsts)
 {
   HH_TRY(

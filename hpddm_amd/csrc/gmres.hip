@@ -44,7 +44,7 @@ __global__ void k_axpby(long long cnt, double a, const double *__restrict__ x, d
 
 int Schwarz::gmres(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   reserve(mu);
   hipStream_t  st      = library_stream();
   const double tol     = getopt("tol", 1.0e-6);
@@ -247,9 +247,9 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
 // coarse correction).
 int Schwarz::cg(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
-  if (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED)) return gmres(b, x, mu, history, history_cap);
+  if (!custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED))) return gmres(b, x, mu, history, history_cap); // (hpddm_method_id 1 and 4 only: a custom operator goes on)
   reserve(mu);
   hipStream_t     st  = library_stream();
   const double    tol = getopt("tol", 1.0e-6);
@@ -732,7 +732,7 @@ static int gcrodr_one(Schwarz &A, const GcroOptions &o, const double *b, double 
 
 int Schwarz::gcrodr(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   GcroOptions o;
   o.tol         = getopt("tol", 1.0e-6);
   o.max_it      = std::min<int>((int)getopt("max_it", 100), std::numeric_limits<short>::max());
@@ -785,7 +785,7 @@ int Schwarz::gcrodr(const double *b, double *x, int mu, double *history, int his
 // test; and -hpddm_krylov_method none (:1056-1066): x = M^{-1} b.  Linear in the vectors: complex operators go through unchanged.
 int Schwarz::richardson(const double *b, double *x, int mu)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   reserve(mu);
   hipStream_t     st     = library_stream();
   const int       max_it = std::min<int>((int)getopt("max_it", 100), std::numeric_limits<short>::max());
@@ -806,7 +806,7 @@ int Schwarz::richardson(const double *b, double *x, int mu)
 }
 int Schwarz::no_krylov(const double *b, double *x, int mu)
 {
-  HH_CHECK(factored, "solve before CallNumfact");
+  HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   reserve(mu);
   start(b, x, mu);
   apply(b, x, mu);

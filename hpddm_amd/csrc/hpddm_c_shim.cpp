@@ -274,19 +274,23 @@ void HpddmSubdomainDestroy(HpddmSubdomain *S)
   delete S;
 }
 
-HpddmSchwarz *HpddmSchwarzCreate(HpddmMatrixCSR *M, int neighbors, int *list, int *sizes, int **connectivity)
+static void select_device(int rank)
 {
-  HpddmSchwarz *S = new HpddmSchwarz();
-  MPI_Comm_rank(S->comm, &S->rank);
-  MPI_Comm_size(S->comm, &S->size);
   const int   ndev = HpddmHipDeviceCount();
   const char *dev  = getenv("HPDDM_HIP_DEVICE");
   if (ndev <= 0) {
     fprintf(stderr, "libhpddm_c_hip: no HIP device (there is no CPU fallback)\n");
     MPI_Abort(MPI_COMM_WORLD, 1);
   }
-  CK(HpddmHipSetDevice(dev ? atoi(dev) : S->rank % ndev), "HpddmHipSetDevice");
-  (void)hipSetDevice(dev ? atoi(dev) : S->rank % ndev);
+  CK(HpddmHipSetDevice(dev ? atoi(dev) : rank % ndev), "HpddmHipSetDevice");
+  (void)hipSetDevice(dev ? atoi(dev) : rank % ndev);
+}
+HpddmSchwarz *HpddmSchwarzCreate(HpddmMatrixCSR *M, int neighbors, int *list, int *sizes, int **connectivity)
+{
+  HpddmSchwarz *S = new HpddmSchwarz();
+  MPI_Comm_rank(S->comm, &S->rank);
+  MPI_Comm_size(S->comm, &S->size);
+  select_device(S->rank);
   S->mat = M;
   S->nb.assign(list, list + neighbors);
   S->conn.resize(neighbors);
@@ -385,6 +389,49 @@ int HpddmSolve(HpddmSchwarz *S, const double *b, double *sol, int mu, const MPI_
   ensure_transport(S, mu);
   const int it = HpddmHipSolve(S->A, b, sol, mu, nullptr, 0);
   if (it < 0) fail("HpddmSolve");
+  return it;
+}
+
+// interface/hpddm_c.cpp:41-53, 227-230: CustomOperator (an EmptyOperator of n rows: no neighbours, no scaling) handed to
+// IterativeMethod::solve.  Here: a one-subdomain operator without neighbours whose GMV / apply are the callbacks (d = 1, the
+// identity matrix only gives the operator its size), solved by the same device-resident Krylov methods as HpddmSolve.
+struct HpddmCustomOperator;
+namespace {
+struct CustomCtx {
+  const HpddmCustomOperator *op;
+  int (*mv)(const HpddmCustomOperator *, const double *, double *, int);
+  int (*precond)(const HpddmCustomOperator *, const double *, double *, int);
+};
+int custom_mv_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->mv(((CustomCtx *)ctx)->op, in, out, mu); }
+int custom_pc_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->precond(((CustomCtx *)ctx)->op, in, out, mu); }
+} // namespace
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(const HpddmCustomOperator *, const double *, double *, int), int (*precond)(const HpddmCustomOperator *, const double *, double *, int), const double *b, double *sol, int mu, const MPI_Comm *comm)
+{
+  HpddmSchwarz S;
+  if (comm) S.comm = *comm;
+  MPI_Comm_rank(S.comm, &S.rank);
+  MPI_Comm_size(S.comm, &S.size);
+  select_device(S.rank);
+  std::vector<int>    ia(n + 1), ja(n);
+  std::vector<double> a(n, 1.0), d(n, 1.0);
+  for (int i = 0; i < n; ++i) ia[i] = ja[i] = i;
+  ia[n] = n;
+  S.A   = HpddmHipSchwarzCreate(1, S.rank, S.size);
+  if (!S.A) fail("HpddmCustomOperatorSolve");
+  CK(HpddmHipSchwarzSetSubdomain(S.A, 0, n, ia.data(), ja.data(), a.data(), 0, 'C', 0, nullptr, nullptr, nullptr), "HpddmCustomOperatorSolve");
+  std::vector<int> firsts(S.size + 1);
+  for (int r = 0; r <= S.size; ++r) firsts[r] = r;
+  CK(HpddmHipSchwarzSetPartition(S.A, S.size, S.rank, firsts.data()), "HpddmCustomOperatorSolve");
+  CK(HpddmHipSchwarzInitialize(S.A, 0, d.data()), "HpddmCustomOperatorSolve");
+  CustomCtx ctx{op, mv, precond};
+  CK(HpddmHipSchwarzSetCustomOperator(S.A, mv ? custom_mv_cb : nullptr, precond ? custom_pc_cb : nullptr, &ctx), "HpddmCustomOperatorSolve");
+  sync_options(&S);
+  ensure_transport(&S, mu);
+  const int it = HpddmHipSolve(S.A, b, sol, mu, nullptr, 0);
+  if (it < 0) fail("HpddmCustomOperatorSolve");
+  HpddmHipSchwarzDestroy(S.A);
+  if (S.send_d) (void)hipFree(S.send_d);
+  if (S.recv_d) (void)hipFree(S.recv_d);
   return it;
 }
 

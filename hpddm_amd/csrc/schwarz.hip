@@ -998,8 +998,22 @@ void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {
   hipLaunchKernelGGL(k_axpy, dim3((unsigned)std::min<long long>(2048, (cnt + 255) / 256)), dim3(256), 0, library_stream(), cnt, alpha, x, y);
 }
+void Schwarz::custom_call(CustomFn fn, const char *what, const double *in, double *out, int mu)
+{
+  hipStream_t  st  = library_stream();
+  const size_t cnt = (size_t)ntot * mu;
+  custom_in.resize(cnt);
+  custom_out.resize(cnt);
+  HIP_OK(hipMemcpyAsync(custom_in.data(), in, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  const int rc = fn(custom_ctx, custom_in.data(), custom_out.data(), mu);
+  HH_CHECK(rc == 0, std::string("custom operator: the ") + what + " callback returned " + std::to_string(rc));
+  HIP_OK(hipMemcpyAsync(out, custom_out.data(), cnt * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_OK(hipStreamSynchronize(st)); // the staging vector is reused by the next call
+}
 void Schwarz::gmv(const double *in, double *out, int mu)
 {
+  if (custom_mv) return custom_call(custom_mv, "operator", in, out, mu);
   // Schwarz::GMV (include/HPDDM_schwarz.hpp:740-744): out = exchange(A in)
   reserve(mu);
   csrmm(in, w3.p, mu, 1.0, 0.0);
@@ -1096,6 +1110,11 @@ void Schwarz::coarse_solve(const double *uc, double *y, int mu)
 
 void Schwarz::apply(const double *in, double *out, int mu)
 {
+  if (custom_precond) return custom_call(custom_precond, "preconditioner", in, out, mu);
+  if (custom_mv) { // an operator without preconditioner callback: identity
+    HIP_OK(hipMemcpyAsync(out, in, (size_t)ntot * mu * sizeof(double), hipMemcpyDeviceToDevice, library_stream()));
+    return;
+  }
   // Schwarz::apply (include/HPDDM_schwarz.hpp:527-612)
   HH_CHECK(factored, "apply before CallNumfact");
   reserve(mu);

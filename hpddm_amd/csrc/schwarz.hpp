@@ -152,6 +152,14 @@ struct Schwarz {
   void exchange_inplace(double *x, int mu, bool scale);
   void csrmm(const double *x, double *y, int mu, double alpha, double beta); // y = beta*y + alpha*A*x
   void gmv(const double *in, double *out, int mu);
+  // HpddmCustomOperatorSolve (interface/hpddm_c.cpp:41-53, 227-230: CustomOperator<Operator, K> handed to IterativeMethod::solve): the
+  // operator and the preconditioner of the Krylov methods are callbacks of the caller on HOST vectors (n x mu, column-major); the
+  // vectors of the iteration stay in HBM, every call is one round trip through the staging vectors below
+  typedef int (*CustomFn)(void *ctx, const double *in, double *out, int mu);
+  CustomFn            custom_mv = nullptr, custom_precond = nullptr;
+  void               *custom_ctx = nullptr;
+  std::vector<double> custom_in, custom_out;
+  void                custom_call(CustomFn fn, const char *what, const double *in, double *out, int mu);
   void local_solve(const double *in, double *out, int mu);
   void solve_factor(const double *in, double *out, int mu); // plan.solve, plus the row phases of complex operators
   void deflation(const double *in, double *out, int mu);

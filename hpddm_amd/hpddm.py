@@ -405,6 +405,33 @@ class Schwarz:
         out = self.unpack(xs, mu)
         return (it, out, hist[:it]) if history else (it, out)
 
+    def set_custom_operator(self, mv, precond=None):
+        """HpddmCustomOperatorSolve (interface/HPDDM.h:115): solve() then iterates on mv(in, out) as the operator and precond(in, out)
+        as the preconditioner -- callables on host arrays of shape (n, mu), Fortran-ordered, `out` to be filled in place -- instead
+        of the matrices and factors of this object.  None restores the Schwarz operator."""
+        assert self.nsub == 1, "a custom operator is one block of rows per rank"
+
+        def wrap(fn):
+            if fn is None:
+                return None
+
+            def cb(_ctx, pin, pout, mu):
+                try:
+                    rows = self._custom_n
+                    xin = np.ctypeslib.as_array(pin, shape=(mu * rows,)).reshape((rows, mu), order="F")
+                    xout = np.ctypeslib.as_array(pout, shape=(mu * rows,)).reshape((rows, mu), order="F")
+                    fn(xin, xout)
+                    return 0
+                except Exception:   # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int)(cb)
+        self._custom_n = int(self.n[0])
+        self._custom_cbs = (wrap(mv), wrap(precond))   # kept alive with the operator
+        as_ptr = lambda c: ctypes.cast(c, ctypes.c_void_p) if c is not None else None
+        check(self._lib.HpddmHipSchwarzSetCustomOperator(self._h, as_ptr(self._custom_cbs[0]), as_ptr(self._custom_cbs[1]), None))
+
     # -- device-resident variants (raw HBM pointers) --
     def apply_device(self, in_ptr, out_ptr, mu=1):
         check(self._lib.HpddmHipSchwarzApplyDevice(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), mu))

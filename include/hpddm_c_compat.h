@@ -8,7 +8,7 @@
  * MPI_Isend/Irecv and MPI_Allreduce -- the calls Subdomain::exchange and the Krylov methods make in the reference).
  * Ranks may share a GPU or own one each (HPDDM_HIP_DEVICE=<n>, default rank % device count).
  *
- * Only what the RAS path needs is implemented; HpddmCustomOperatorSolve and the PETSc hook are not.  A program includes
+ * The whole of interface/HPDDM.h:66-118 is exported (the PETSc hook, #if HPDDM_PETSC, is not: no PETSc here).  A program includes
  * the reference's HPDDM.h as before -- this header only documents what the shim exports (same names, same argument
  * meaning) and lets the shim be compiled without the reference tree.
  */
@@ -62,6 +62,11 @@ void                 HpddmSchwarzComputeResidual(HpddmSchwarz *, const double *s
 void                 HpddmSchwarzDestroy(HpddmSchwarz *);                                     /* :110 */
 
 int HpddmSolve(HpddmSchwarz *, const double *b, double *sol, int mu, const MPI_Comm *);       /* :112 */
+/* :113-115: the Krylov methods of -hpddm_krylov_method on an operator and a preconditioner given as callbacks on host vectors
+ * (n x mu, column-major, n rows on this rank; inner products summed over *comm): interface/hpddm_c.cpp:41-53, 227-230.  Returns
+ * the iteration count.  The basis and the recurrences live in HBM; every callback is one round trip over PCIe. */
+typedef struct HpddmCustomOperator HpddmCustomOperator;
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *A, int n, int (*mv)(const HpddmCustomOperator *, const double *, double *, int), int (*precond)(const HpddmCustomOperator *, const double *, double *, int), const double *b, double *sol, int mu, const MPI_Comm *comm);
 
 double nrm2(const int *, const double *, const int *);                                        /* :117 */
 void   axpy(const int *, const double *, const double *, const int *, double *, const int *); /* :118 */

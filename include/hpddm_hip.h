@@ -172,6 +172,14 @@ int HpddmHipSchwarzComputeResidualNorm(HpddmHipSchwarz *A, const double *sol, co
  * history, if not NULL, receives up to history_cap residual norms, one per iteration: the value the reference prints at verbosity 3. */
 int HpddmHipSolve(HpddmHipSchwarz *A, const double *b, double *sol, int mu, double *history, int history_cap);
 
+/* HpddmCustomOperatorSolve (interface/HPDDM.h:115, interface/hpddm_c.cpp:41-53, 227-230: CustomOperator handed to
+ * IterativeMethod::solve): from now on HpddmHipSolve runs its Krylov method on `mv` as the operator (Operator::GMV) and `precond`
+ * as the preconditioner (Operator::apply) instead of the matrices and factors of A.  Both take HOST vectors (n x mu, column-major,
+ * n = the rows of the operator on this rank) and return 0; the vectors of the iteration stay in HBM, every call is one round trip.
+ * Inner products are weighted by the d of HpddmHipSchwarzInitialize (ones for the reference's EmptyOperator, whose getScaling() is
+ * null) and summed over the ranks through the transport.  NULL, NULL restores the Schwarz operator. */
+int HpddmHipSchwarzSetCustomOperator(HpddmHipSchwarz *A, int (*mv)(void *ctx, const double *in, double *out, int mu), int (*precond)(void *ctx, const double *in, double *out, int mu), void *ctx);
+
 /* ---- several GPUs: one process (rank) per GPU, subdomains sharded by contiguous ranges ----
  * firsts[r] .. firsts[r+1]-1 are the global subdomain numbers owned by rank r (nranks+1 entries). */
 int HpddmHipSchwarzSetPartition(HpddmHipSchwarz *A, int nranks, int rank, const int *firsts);

@@ -136,3 +136,24 @@ def test_coarse_correction_hook_runs_the_deflation_on_the_device(name, ranks, mu
             ref = g[f"{key}_r{r}"]
             assert np.abs(d[key] - ref).max() <= tol * max(1e-300, np.abs(ref).max()), (key, r)
         assert int(d["iterations"][0]) == int(g["iterations_r0"][0]) and (its is None or int(d["iterations"][0]) == its)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "custom_operator_c_hip")), reason="oracle/_ref/custom_operator_c_hip not built")
+@pytest.mark.parametrize("ranks,args,method,its", [
+    (1, "", "GMRES", 6),
+    (2, "-n 300 -mu 1", "GMRES", 6),
+    (3, "-n 57 -mu 4 -hpddm_krylov_method bgmres", "BGMRES", 5),
+    (2, "-n 200 -mu 1 -hpddm_krylov_method cg", "CG", 7),
+    (2, "-n 80 -mu 3 -hpddm_krylov_method bcg", "BCG", 6),
+    (4, "-n 50 -mu 2 -hpddm_variant left", "GMRES", 7),
+    (2, "-n 120 -mu 1 -hpddm_krylov_method gcrodr -hpddm_recycle 5 -hpddm_gmres_restart 10 -hpddm_tol 1e-10", "GCRODR", 10),
+])
+def test_unchanged_custom_operator_example_against_the_c_api_shim(ranks, args, method, its):
+    """examples/custom_operator.c (HpddmCustomOperatorSolve, interface/HPDDM.h:115: operator and preconditioner as callbacks, a
+    tridiagonal matrix with its Jacobi preconditioner) linked with libhpddm_c_hip.so instead of interface/hpddm_c.cpp.  The
+    expected iteration counts are those of the same source linked with the reference's own interface/hpddm_c.cpp
+    (oracle/_ref/custom_operator_c_ref, run in the build container); the right-hand sides of the example are seeded by the clock,
+    which moves the count by at most one in both builds."""
+    out = _run(ranks, args, exe="custom_operator_c_hip")
+    m = re.search(method + r" converges after (\d+) iteration", out)
+    assert m and abs(int(m.group(1)) - its) <= 1, out[-1500:]

@@ -467,3 +467,45 @@ def test_penalised_dirichlet_rows_match_reference(name):
         assert np.allclose(A.compute_residual(rs, f, "l1"), g["residual_l1_r0"], rtol=1e-6)
         assert np.allclose(A.compute_residual(rs, f, "linfty"), g["residual_linfty_r0"], rtol=1e-6)
     A.destroy()
+
+
+def test_custom_operator_callbacks():
+    """HpddmHipSchwarzSetCustomOperator (HpddmCustomOperatorSolve, interface/hpddm_c.cpp:41-53, 227-230): the Krylov methods on an
+    operator and a preconditioner given as host callbacks -- the tridiagonal matrix and the Jacobi preconditioner of
+    examples/custom_operator.c:33-53 -- against a direct solve; iteration counts as the reference build of that example (6-7)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, mu = 100, 2
+    diag = np.arange(n) + 2.0
+    T = sp.diags([-0.5 * np.ones(n - 1), diag, -0.5 * np.ones(n - 1)], [-1, 0, 1], format="csr")
+    calls = {"mv": 0, "pc": 0}
+
+    def mv(x, y):
+        calls["mv"] += 1
+        y[:] = T @ x
+
+    def pc(x, y):
+        calls["pc"] += 1
+        y[:] = x / diag[:, None]
+
+    eye = sp.identity(n, format="csr")
+    A = hpddm.Schwarz(1)
+    A.set_subdomain(0, n, eye.indptr, eye.indices, eye.data, False, [], [])
+    A.initialize([np.ones(n)])
+    A.set_custom_operator(mv, pc)
+    rng = np.random.default_rng(11)
+    b = np.asfortranarray(rng.integers(0, 10000, size=(n, mu)) / 100.0)
+    exact = spla.spsolve(T.tocsc(), b)
+    for opts, lo, hi in (("-hpddm_krylov_method gmres", 5, 8), ("-hpddm_krylov_method bgmres", 4, 7), ("-hpddm_krylov_method cg", 5, 9),
+                         ("-hpddm_krylov_method gmres -hpddm_variant left", 5, 8)):
+        A.option_parse(opts + " -hpddm_tol 1e-6")
+        it, sol = A.solve([b])
+        assert lo <= it <= hi, (opts, it)
+        assert np.abs(sol[0] - exact).max() <= 1e-5 * np.abs(exact).max(), opts
+    assert calls["mv"] > 0 and calls["pc"] > 0
+    # without a preconditioner callback: identity
+    A.set_custom_operator(mv, None)
+    A.option_parse("-hpddm_krylov_method gmres -hpddm_variant right -hpddm_tol 1e-8 -hpddm_max_it 200")
+    it, sol = A.solve([b])
+    assert np.abs(sol[0] - exact).max() <= 1e-6 * np.abs(exact).max()
+    A.destroy()
