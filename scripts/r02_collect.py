@@ -11,7 +11,7 @@ names = {"bench_default_stdout.json": "r02_bench_default_stdout.json", "kernel_s
          "sptrsv_sweeps.csv": "r02_bench_c3_sptrsv_sweeps.csv", "trace_bench_line.json": "r02_bench_c3_trace_bench_line.json",
          "pmc_FETCH_SIZE.csv": "r02_pmc_fetch_size_c3.csv", "pmc_WRITE_SIZE.csv": "r02_pmc_write_size_c3.csv",
          "pmc_FETCH_SIZE_last_solve.txt": "r02_pmc_fetch_size_c3_last_solve.txt", "pmc_WRITE_SIZE_last_solve.txt": "r02_pmc_write_size_c3_last_solve.txt",
-         "levels_c3.txt": "r02_bench_c3_sptrsv_levels.txt", "levels_c2.txt": "r02_bench_c2_sptrsv_levels.txt",
+         "levels_c3.txt": "r02_bench_c3_sptrsv_levels.txt", "levels_c2.txt": "r02_bench_c2_sptrsv_levels.txt", "levels_c4share_helmholtz.txt": "r02_bench_c4share_helmholtz_sptrsv_levels.txt",
          "bench_c2_stdout.json": "r02_bench_c2_stdout.json", "bench_c4share_helmholtz_stdout.json": "r02_bench_c4share_helmholtz_stdout.json",
          "bench_c3share_elasticity_stdout.json": "r02_bench_c3share_elasticity_stdout.json"}
 for a, b in names.items():

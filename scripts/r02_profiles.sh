@@ -5,6 +5,7 @@
 cd "$(dirname "$0")/.." || exit 1
 R=$PWD
 out=$R/gpurun_out/r02
+if [ -n "$SECONDARY_ONLY" ]; then mkdir -p "$out"; else
 rm -rf "$out" && mkdir -p "$out"
 if [ -z "$SKIP_DEFAULT" ]; then
   ( time timeout 1200 python bench.py ) > "$out/bench_default_stdout.log" 2> "$out/bench_default_stderr.log"
@@ -30,10 +31,13 @@ done
 cd $R
 timeout 600 python scripts/sweep_plan.py --grid 256 --levels "HPDDM_HIP_STREAMS=1" "" > $out/levels_c3.txt 2>&1
 timeout 300 python scripts/sweep_plan.py --grid 128 --levels --reps 30 "HPDDM_HIP_STREAMS=1" "" > $out/levels_c2.txt 2>&1
+fi   # SECONDARY_ONLY=1: only the three lines below (the other workloads of bench.py), the rest of gpurun_out/r02 is kept
+cd $R
 timeout 300 python bench.py --grid 128 --no-two-level --steps 50 > $out/bench_c2_stdout.log 2>&1
 grep '^{"metric"' $out/bench_c2_stdout.log | tail -1 > $out/bench_c2_stdout.json
 timeout 300 python bench.py --problem helmholtz --grid 64 --mu 8 --steps 20 > $out/bench_c4share_helmholtz_stdout.log 2>&1
 grep '^{"metric"' $out/bench_c4share_helmholtz_stdout.log | tail -1 > $out/bench_c4share_helmholtz_stdout.json
 timeout 300 python bench.py --problem elasticity --grid 64 --geneo-nu 12 --steps 20 --no-cpu-baseline > $out/bench_c3share_elasticity_stdout.log 2>&1
 grep '^{"metric"' $out/bench_c3share_elasticity_stdout.log | tail -1 > $out/bench_c3share_elasticity_stdout.json
+timeout 120 python scripts/sweep_plan.py --helmholtz 64,64,128 --mu 1,4,8 --levels --reps 20 "HPDDM_HIP_STREAMS=1" "" > $out/levels_c4share_helmholtz.txt 2>&1
 ls -la $out; tail -2 $out/sptrsv_sweeps.csv; cat $out/pmc_*_last_solve.txt | head -4; grep "^==" $out/levels_c*.txt
