@@ -261,7 +261,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
           for (int nu = 0; nu < MU; ++nu) {
             const double u = Ub[(long long)nu * d.usize + sj];
-            v[nu] -= sr[j] >= 0 ? u : 0.0;
+            v[nu]          = sr[j] >= 0 ? v[nu] - u : v[nu];
           }
         }
       } else {
