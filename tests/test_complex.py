@@ -43,6 +43,8 @@ def test_helmholtz_complex_symmetric_full_and_lower_storage():
     assert _check(A) == 1                      # complex symmetric: L D L^T with plain transposes (detected from the values)
     assert _check(A, sym_storage=True, mu=3) == 1
     assert _check(A, sym_storage=True, mu=5) == 1   # 5 complex right-hand sides = 10 real columns inside: blocks of 8 + 2
+    assert _check(A, sym_storage=True, mu=8) == 1   # the block of configs[4]: 16 real columns, ONE sweep (wide and narrow tiles)
+    assert _check(A, mu=11) == 1                    # 22 real columns: 16 + 4 + 2
 
 
 def test_strongly_imaginary_diagonal():
