@@ -712,7 +712,7 @@ int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
     stats[5] = op.plan.launches_per_solve;
     for (const auto &P : op.more_plans) stats[5] += P->launches_per_solve;
     stats[6] = (double)op.nnzA;
-    stats[7] = op.cdim;
+    stats[7] = op.cdim_g > 0 ? op.cdim_g : op.cdim; // the coarse operator spans the ranks
     return 0;)
 }
 

@@ -248,7 +248,8 @@ long long HpddmHipDebugTimeline(unsigned long long *out, long long cap_tiles);
 int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out, int cap);
 /* stats[0..7] = sum n (unknowns, in scalars K), sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at
  *               mu=1 (2*nnz(L)*sizeof(K) + 4*n*sizeof(K); sizeof(K) = 16 for complex operators), #levels, kernel
- *               launches per SpTRSV, sum nnz(A) (of the real-equivalent embedding for complex operators), coarse dimension */
+ *               launches per SpTRSV, sum nnz(A) (of the real-equivalent embedding for complex operators), coarse dimension (global: the
+ *               coarse operator spans the ranks; everything else counts the subdomains of this rank) */
 int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats);
 /* access to subdomain s' local solver (for Export / Info) */
 HpddmHipSubdomain *HpddmHipSchwarzGetSubdomain(HpddmHipSchwarz *A, int s);
