@@ -1513,6 +1513,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   persist_narrow        = envi("HPDDM_HIP_PERSIST_NARROW", 0); // ... and, if > 0, at most this many of them per wavefront slot (each walks several tiles)
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  fwd_want    = envi("HPDDM_HIP_FWD_WANT", 0) / std::max(1, groups); // wide panels, forward: levels with fewer workgroups than this get shorter tiles
+  const int  bwd_small   = envi("HPDDM_HIP_BWD_SMALL", 4096);   // narrow panels, backward: one wavefront takes the whole supernode up to this many panel entries (scalars), a workgroup beyond
   const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
@@ -1628,7 +1629,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
         for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
-        const bool small = h <= WAVE_ROWS && (long long)h * d.ldw <= 4096;
+        const bool small = h <= WAVE_ROWS && (long long)h * d.ldw <= bwd_small * cs;
         tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
