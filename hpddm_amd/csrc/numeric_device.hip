@@ -83,6 +83,103 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
       }
 }
 
+// The same product on larger tiles (opt-in, HPDDM_HIP_GEMM=128; NOT yet measured on the device): TM x TN per workgroup (128 x 128,
+// or 128 x 64 for the 64-column panels of the left-looking factorisation), every wavefront a (TM/2) x (TN/2) block of MFMA
+// fragments, the next K-step of 16 on its way from memory into registers while the current one is multiplied out of LDS (two LDS
+// buffers, one barrier per step).  Why: k_gemm64 leaves the f64 MFMA pipe idle most of the time (2 barriers and 16 dependent
+// 8-byte loads per 16 MFMAs per wavefront); the device levels of a 129^3 subdomain take 4.2 s for about 2.5e13 flops with it.
+//   * tiles are dealt to the XCDs in contiguous chunks (workgroup ids go round-robin over the 8 XCDs), so that the workgroups
+//     sharing an L2 share rows of A / columns of B;
+//   * btri: B is lower triangular (B[k][j] = 0 for k < j; the inverted top blocks): column tile j0 starts its K loop at j0.
+template <int TM, int TN, bool TRANSB>
+__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int tiles_x, int tiles_y)
+{
+  constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
+  __shared__ double As[2][TM][KS + 1];
+  __shared__ double Bs[2][KS][TN + 1];
+  // XCD-aware deal: workgroup id -> logical tile, contiguous chunks per XCD
+  const int total = tiles_x * tiles_y, id = (int)blockIdx.x, q8 = total / 8, r8 = total % 8, xcd = id % 8, loc = id / 8;
+  const int lid = xcd * q8 + min(xcd, r8) + loc;
+  const int i0 = (lid / tiles_x) * TM, j0 = (lid % tiles_x) * TN;
+  if (lower_only && cj0 + j0 > ci0 + i0 + TM - 1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
+  v4f64     acc[MI][NJ];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NJ; ++b) acc[a][b] = (v4f64){0, 0, 0, 0};
+  double ra[LA], rb[LB];
+  auto   fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < LA; ++q) { // A tile: 16 consecutive k per row, 16 rows per pass
+      const int e = tid + 256 * q, row = e >> 4, kk = k0 + (e & 15), r = i0 + row;
+      ra[q]       = (r < M && kk < K) ? A[(long long)r * lda + kk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const int e = tid + 256 * q;
+      if (!TRANSB) { // B is K x N: TN consecutive columns per k
+        const int k = e / TN, j = j0 + e % TN, kk = k0 + k;
+        rb[q]       = (kk < K && j < N) ? B[(long long)kk * ldb + j] : 0.0;
+      } else { // B is N x K: 16 consecutive k per column
+        const int j = j0 + (e >> 4), kk = k0 + (e & 15);
+        rb[q]       = (j < N && kk < K) ? B[(long long)j * ldb + kk] : 0.0;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < LA; ++q) {
+      const int e = tid + 256 * q;
+      As[buf][e >> 4][e & 15] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const int e = tid + 256 * q;
+      if (!TRANSB) Bs[buf][e / TN][e % TN] = rb[q];
+      else Bs[buf][e & 15][e >> 4] = rb[q];
+    }
+  };
+  const int kbeg = btri ? (j0 / KS) * KS : 0; // (j0 is a multiple of TN, itself a multiple of KS)
+  if (kbeg < K) {
+    fetch(kbeg);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < K; k0 += KS) {
+    const bool more = k0 + KS < K;
+    if (more) fetch(k0 + KS);
+#pragma unroll
+    for (int k4 = 0; k4 < KS / 4; ++k4) {
+      double a[MI], b[NJ];
+#pragma unroll
+      for (int t = 0; t < MI; ++t) a[t] = As[buf][(TM / 2) * wy + 16 * t + (lane & 15)][4 * k4 + (lane >> 4)];
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) b[t] = Bs[buf][4 * k4 + (lane >> 4)][(TN / 2) * wx + 16 * t + (lane & 15)];
+#pragma unroll
+      for (int ti = 0; ti < MI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NJ; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1); // the other buffer: its readers passed the barrier of the previous step
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int ti = 0; ti < MI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = i0 + (TM / 2) * wy + 16 * ti + (lane >> 4) + 4 * reg, c = j0 + (TN / 2) * wx + 16 * tj + (lane & 15);
+        if (r < M && c < N) {
+          double *p = C + (long long)r * ldc + c;
+          *p        = (beta1 ? *p : 0.0) + alpha * acc[ti][tj][reg];
+        }
+      }
+}
+
 // Cholesky of one diagonal tile (nb <= 64, row-major lower, in place) and the inverse of its factor into Tinv (64 x 64,
 // zeros above the diagonal and beyond nb).  One wavefront.  *flag != 0 on a non-positive pivot.
 __global__ __launch_bounds__(64) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
@@ -304,9 +401,25 @@ __global__ void k_set_diag_tile(int ib, int i0, double *P, long long ld, const d
   if (r < ib && c < ib) P[(long long)(i0 + r) * ld + i0 + c] = Tinv[r * 64 + c];
 }
 
-static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0)
+template <int TM, int TN>
+static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only, int ci0, int cj0, bool btri)
+{
+  const int tx = (N + TN - 1) / TN, ty = (M + TM - 1) / TM;
+  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true>), dim3((unsigned)(tx * ty)), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, tx, ty);
+  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false>), dim3((unsigned)(tx * ty)), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, tx, ty);
+}
+
+// btri: B (not transposed) is lower triangular -- only the tiles of k_gemm_big use it, the result is the same
+static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false)
 {
   if (M <= 0 || N <= 0) return;
+  static const int big = [] { const char *e = getenv("HPDDM_HIP_GEMM"); return e ? atoi(e) : 64; }();
+  if (big == 128 && K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
+    if (M <= 64) gemm_big<64, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // row blocks of the blocked inverse
+    else if (N > 64) gemm_big<128, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB);
+    else gemm_big<128, 64>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // 64-column panels
+    return;
+  }
   const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
   if (transB) hipLaunchKernelGGL(k_gemm64<true>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0);
   else hipLaunchKernelGGL(k_gemm64<false>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0);
@@ -360,7 +473,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
       const int i0 = 64 * t, ib = std::min<int>(64, w - i0);
       double   *Pi = P + (long long)i0 * ld;
       if (i0 > 0) {
-        gemm(st, false, ib, i0, i0, 1.0, Pi, ld, P, ld, tmp.p, i0, false);                       // tmp = L(I, 0:i0) * X(0:i0, 0:i0)
+        gemm(st, false, ib, i0, i0, 1.0, Pi, ld, P, ld, tmp.p, i0, false, false, 0, 0, true);    // tmp = L(I, 0:i0) * X(0:i0, 0:i0), X lower triangular
         gemm(st, false, ib, i0, ib, -1.0, tinvs + (size_t)t * 4096, 64, tmp.p, i0, Pi, ld, false); // X(I, 0:i0) = -X_II * tmp
       }
       hipLaunchKernelGGL(k_set_diag_tile, dim3(64), dim3(64), 0, st, ib, i0, P, ld, tinvs + (size_t)t * 4096);
@@ -370,7 +483,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void mult_bottom(double *P, long long ld, int w, int nb)
   {
     if (!nb) return;
-    gemm(st, false, nb, w, w, 1.0, P + (long long)w * ld, ld, P, ld, tmp.p, w, false);
+    gemm(st, false, nb, w, w, 1.0, P + (long long)w * ld, ld, P, ld, tmp.p, w, false, false, 0, 0, true); // the inverted top block is lower triangular
     hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, tmp.p, (long long)w, P + (long long)w * ld, ld);
   }
   // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse (through the scratch: the product cannot be formed in place)
