@@ -70,6 +70,9 @@ struct DeviceLevels {
   // front k: panelA = its panel with the original entries assembled (h x ldw; LU: panelG = the U12 entries, transposed, same
   // shape, else nullptr); rel[c][i] = position of row i of child c
   virtual void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
+  // the same with the original entries of the front as a list (position row * ldw + column inside the panel, value): the panel is
+  // zeroed on the device and the few entries scattered into it, instead of a dense zero-filled copy travelling over PCIe
+  virtual void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
   virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
 };
 

@@ -394,6 +394,11 @@ __global__ void k_zero_upper(int w, double *P, long long ld)
   const int i = blockIdx.y;
   for (int j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) P[(long long)i * ld + j] = 0.0;
 }
+// the original entries of a front, scattered into its zeroed panel
+__global__ void k_scatter_add(long long cnt, const long long *__restrict__ pos, const double *__restrict__ val, double *P)
+{
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) atomicAdd(P + pos[i], val[i]);
+}
 // rows [i0, i0+ib) of the top block: columns [0, i0) zeroed (before accumulating -Xii*tmp), diagonal tile <- Xii
 __global__ void k_set_diag_tile(int ib, int i0, double *P, long long ld, const double *__restrict__ Tinv)
 {
@@ -494,7 +499,42 @@ struct DeviceLevelsImpl : public DeviceLevels {
     hipLaunchKernelGGL(k_copy2d, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, tmp.p, 64LL, X, ld);
   }
 
+  DevBuf<long long> posbuf;
+  DevBuf<double>    valbuf;
+  void scatter(double *P, size_t panel_doubles, const std::vector<long long> &pos, const std::vector<double> &val)
+  {
+    HIP_OK(hipMemsetAsync(P, 0, panel_doubles * sizeof(double), st));
+    if (pos.empty()) return;
+    if (posbuf.n < pos.size()) {
+      HIP_OK(hipStreamSynchronize(st)); // a previous scatter may still read the old buffers
+      posbuf.alloc(pos.size() + pos.size() / 2);
+      valbuf.alloc(pos.size() + pos.size() / 2);
+    }
+    HIP_OK(hipMemcpyAsync(posbuf.p, pos.data(), pos.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(valbuf.p, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)std::min<size_t>(1024, (pos.size() + 255) / 256)), dim3(256), 0, st, (long long)pos.size(), posbuf.p, valbuf.p, P);
+    HIP_OK(hipStreamSynchronize(st)); // posbuf / valbuf are reused by the next list (G of the same front)
+  }
+  void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
+  {
+    const Symbolic &s = hf->sym;
+    const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
+    const long long ld = hf->ldw[k];
+    scatter(D.F.p + hf->f_off[k], (size_t)h * ld, posF, valF);
+    if (hf->kind == FACT_LU) scatter(D.G.p + hf->f_off[k], (size_t)h * ld, posG, valG);
+    factor_front(k, children, rel);
+  }
   void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
+  {
+    const Symbolic &s = hf->sym;
+    const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
+    const long long ld = hf->ldw[k];
+    HIP_OK(hipMemcpyAsync(D.F.p + hf->f_off[k], panelA, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
+    if (hf->kind == FACT_LU) HIP_OK(hipMemcpyAsync(D.G.p + hf->f_off[k], panelG, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
+    factor_front(k, children, rel);
+  }
+  // the front k with its original entries in place: extend-add of the children, factorisation, solve-ready panels
+  void factor_front(idx_t k, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel)
   {
     const Symbolic &s  = hf->sym;
     const FactKind  kind = hf->kind;
@@ -503,8 +543,6 @@ struct DeviceLevelsImpl : public DeviceLevels {
     const long long ld = hf->ldw[k];
     double         *P  = D.F.p + hf->f_off[k];
     double         *G  = lu ? D.G.p + hf->f_off[k] : nullptr;
-    HIP_OK(hipMemcpyAsync(P, panelA, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
-    if (lu) HIP_OK(hipMemcpyAsync(G, panelG, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
     double *C = nullptr;
     if (nb) {
       C = take((size_t)nb * nb);
