@@ -92,20 +92,67 @@ void symbolic_factorization(const Graph &g, const Ordering &ord, Symbolic &sym)
       }
     }
   }
-  std::vector<idx_t>   flag(n, -1);
-  std::vector<int64_t> colcount(n, 1);
-  for (idx_t i = 0; i < n; ++i) {
-    flag[i]       = i;
-    const idx_t v = ord.perm[i];
-    for (idx_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-      idx_t k = ord.iperm[g.adjncy[p]];
-      if (k >= i) continue;
-      while (flag[k] != i) {
-        flag[k] = i;
-        ++colcount[k]; // L(i,k) != 0
-        k = etree[k];
+  // column counts in O(nnz(A) alpha(n)) (Gilbert, Ng, Peyton 1994: skeleton matrix, first descendants in a postorder of the
+  // elimination tree, least common ancestors by path-compressed disjoint sets) -- the row-subtree walks they replace visit every
+  // entry of L once: 1.5e9 steps, 2.6 of the 3.9 s of the analysis of a 129^3 subdomain
+  std::vector<idx_t> post(n), first(n, -1), maxfirst(n, -1), prevleaf(n, -1);
+  {
+    std::vector<idx_t> head(n, -1), next(n, -1), stack;
+    for (idx_t i = n - 1; i >= 0; --i)
+      if (etree[i] >= 0) {
+        next[i]        = head[etree[i]];
+        head[etree[i]] = i;
+      }
+    idx_t k = 0;
+    for (idx_t r = 0; r < n; ++r) {
+      if (etree[r] >= 0) continue; // roots only
+      stack.push_back(r);
+      while (!stack.empty()) {
+        const idx_t v = stack.back(), c = head[v];
+        if (c < 0) {
+          post[k++] = v;
+          stack.pop_back();
+        } else {
+          head[v] = next[c];
+          stack.push_back(c);
+        }
       }
     }
+  }
+  std::vector<int64_t> colcount(n, 0);
+  for (idx_t k = 0; k < n; ++k) {
+    idx_t j     = post[k];
+    colcount[j] = first[j] < 0 ? 1 : 0; // 1 for a leaf of the elimination tree
+    for (; j >= 0 && first[j] < 0; j = etree[j]) first[j] = k;
+  }
+  for (idx_t i = 0; i < n; ++i) anc[i] = i; // from here on: the disjoint sets
+  for (idx_t k = 0; k < n; ++k) {
+    const idx_t j = post[k];
+    if (etree[j] >= 0) --colcount[etree[j]];
+    const idx_t v = ord.perm[j];
+    for (idx_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+      const idx_t i = ord.iperm[g.adjncy[p]];
+      if (i <= j || first[j] <= maxfirst[i]) continue; // j is not a leaf of the row subtree of i
+      maxfirst[i]       = first[j];
+      const idx_t jprev = prevleaf[i];
+      prevleaf[i]       = j;
+      ++colcount[j]; // A(i, j) is in the skeleton
+      if (jprev >= 0) { // a later leaf: the overlap with the previous one ends at their least common ancestor
+        idx_t q = jprev;
+        while (q != anc[q]) q = anc[q];
+        for (idx_t s = jprev; s != q;) {
+          const idx_t sp = anc[s];
+          anc[s]         = q;
+          s              = sp;
+        }
+        --colcount[q];
+      }
+    }
+    if (etree[j] >= 0) anc[j] = etree[j];
+  }
+  for (idx_t k = 0; k < n; ++k) { // sums over the children, in postorder
+    const idx_t j = post[k];
+    if (etree[j] >= 0) colcount[etree[j]] += colcount[j];
   }
   sym.nnz_exact = std::accumulate(colcount.begin(), colcount.end(), (int64_t)0);
 }
