@@ -104,13 +104,17 @@ def main():
     from hpddm_amd.generate import generate3d, generate_elasticity3d
 
     def generate(dims, parts, **kw):
-        if args.problem == "helmholtz":
-            return generate_helmholtz(np, generate3d, dims, parts, **kw)
-        if args.problem == "elasticity":
-            kw.pop("rhs", None)
-            kw.setdefault("normalize", True)
-            return generate_elasticity3d(dims, parts, overlap=1, sym=True, **kw)
-        return generate3d(dims, parts, overlap=1, sym=True, **kw)
+        tg0 = time.time()
+        try:
+            if args.problem == "helmholtz":
+                return generate_helmholtz(np, generate3d, dims, parts, **kw)
+            if args.problem == "elasticity":
+                kw.pop("rhs", None)
+                kw.setdefault("normalize", True)
+                return generate_elasticity3d(dims, parts, overlap=1, sym=True, **kw)
+            return generate3d(dims, parts, overlap=1, sym=True, **kw)
+        finally:
+            generate.seconds = time.time() - tg0
 
     hpddm.require_device()
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
@@ -151,8 +155,9 @@ def main():
     else:
         subs = generate((args.n, args.n, 2 * args.n) if helm else args.n, args.subdomains, rhs="smooth", neumann=geneo, **({"grid": (2, 2, 2)} if helm else {}))
         A, d = hpddm.schwarz_from_subdomains(subs, options=opts, multiplicity=args.problem != "elasticity")
+    t_gen = getattr(generate, "seconds", 0.0)   # the synthetic matrices (numpy): test infrastructure, not part of the set-up of the operator
     A.call_numfact()
-    t_setup = time.time() - t0
+    t_setup = time.time() - t0 - t_gen
     st = A.stats()
     ntot = int(st["n"])                      # unknowns in scalars K
     sk = 16.0 if A.complex else 8.0          # sizeof(K)
@@ -256,7 +261,7 @@ def main():
                                         + ("RCCL inside the library (ncclSend/ncclRecv/ncclAllReduce on the library stream)" if not share else "the gloo test double (shared GPU)") if sharded
                                         else "replicas (one independent 8-subdomain block per GPU)")),
                        "n_dof_per_gpu": ntot, "nnz_L_per_gpu": st["nnz_L"], "levels": st["levels"], "launches_per_sptrsv": st["launches"],
-                       "setup_seconds": round(t_setup, 2)},
+                       "setup_seconds": round(t_setup, 2), "generator_seconds": round(t_gen, 2)},
         }
         # ---- roofline of the dominant kernel pair (batched SpTRSV), HIP events on the library stream ----
         bytes_alg = 2.0 * st["nnz_L"] * sk + 4.0 * st["n"] * mu * sk   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
@@ -365,8 +370,8 @@ def configs_1(np, torch, dev, args):
     """BASELINE.json configs[1] in the same run: 3-D Poisson 128^3, 8 subdomains, one-level RAS, HIP SpTRSV only"""
     from hpddm_amd import hpddm
     from hpddm_amd.generate import generate3d
-    t0 = time.time()
     subs = generate3d(128, 8, overlap=1, sym=True, rhs="smooth")
+    t0 = time.time()
     A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
     A.call_numfact()
     t_setup = time.time() - t0
