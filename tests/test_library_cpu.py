@@ -172,3 +172,27 @@ def test_fill_of_the_ordering_does_not_regress(problem, limit):
     mmd = spl.splu(csr_full(sd).tocsc(), permc_spec="MMD_AT_PLUS_A").L.nnz
     assert info["nnz_L"] <= 0.75 * mmd
     S.destroy()
+
+
+@pytest.mark.parametrize("seed,n,density", [(0, 150, 0.02), (1, 220, 0.008), (2, 90, 0.06), (3, 300, 0.004)])
+def test_exact_fill_count_on_unstructured_graphs(seed, n, density):
+    """nnz(L) of the analysis (column counts by skeleton matrix + least common ancestors, symbolic.cpp) against a dense symbolic
+    elimination on random sparse SPD matrices: several components, isolated vertices, irregular degrees"""
+    rng = np.random.default_rng(seed)
+    T = sp.triu(sp.random(n, n, density=density, random_state=seed, format="csr"), 1).tocsr()
+    T.data[:] = -rng.random(T.nnz)
+    A = (T + T.T).tocsr()
+    A = (A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + 1.0)).tocsr()   # strictly diagonally dominant: SPD
+    L = sp.tril(A).tocsr()
+    L.sort_indices()
+    S = hpddm.Subdomain(host_only=1)
+    S.numfact(n, L.indptr, L.indices, L.data, sym=True, spd=True)
+    perm = S.export("perm")
+    B = (abs(A) + abs(A.T)).toarray()[np.ix_(perm, perm)] != 0
+    for k in range(n):
+        r = np.nonzero(B[k + 1:, k])[0] + k + 1
+        B[np.ix_(r, r)] = True
+    assert S.info()["nnz_L"] == int(np.tril(B).sum())
+    b = rng.random(n)
+    assert np.allclose(A @ _replay(S, b), b)
+    S.destroy()
