@@ -542,6 +542,8 @@ long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *
     else if (k == "rx_k") v = &A->op.h_rx_k;
     else if (k == "rx_po") v = &A->op.h_rx_po;
     else if (k == "rx_pc") v = &A->op.h_rx_pc;
+    else if (k == "send_pairs") v = &A->op.h_send_pairs;
+    else if (k == "recv_pairs") v = &A->op.h_recv_pairs;
     HH_CHECK(v != nullptr, "HaloExport: unknown array " + k);
     if (out) {
       HH_CHECK((long long)v->size() <= capacity, "HaloExport: buffer too small");

@@ -206,6 +206,18 @@ Schwarz::Schwarz(int nsub_, int first_, int nglobal_) : nsub(nsub_), first(first
   if (!(first_ == 0 && nsub_ == nglobal_)) rank_first = {first_, first_ + nsub_}; // until SetPartition says who owns the rest
 }
 
+Schwarz::~Schwarz()
+{
+  // build_plans creates the extra streams of the subdomain groups and their fork / join events: release them with the operator
+  // (errors ignored: the destructor may run while the runtime is shutting down)
+  for (hipStream_t q : more_streams) {
+    (void)hipStreamSynchronize(q);
+    (void)hipStreamDestroy(q);
+  }
+  for (hipEvent_t e : ev_join) (void)hipEventDestroy(e);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+}
+
 int Schwarz::owner(int gid) const
 {
   for (int r = 0; r + 1 < (int)rank_first.size(); ++r)
@@ -246,6 +258,7 @@ void Schwarz::build_halo_lists()
   peers.clear();
   h_pairs.clear();
   h_send_sub.clear(); h_send_idx.clear(); h_send_po.clear(); h_send_pc.clear();
+  h_send_pairs.clear(); h_recv_pairs.clear();
   std::vector<std::vector<std::array<int, 3>>> rx((size_t)ntot); // per dof: (k, po, pc)
   long long off = 0;
   for (auto &kv : by_peer) {
@@ -255,6 +268,10 @@ void Schwarz::build_halo_lists()
     HH_CHECK(off + cnt < 2147483647LL, "halo too large for 32-bit offsets");
     // send order: (local s, remote t)
     std::sort(pr.begin(), pr.end(), [](const Pair &a, const Pair &b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
+    for (const Pair &p : pr) {
+      const int quad[4] = {kv.first, first + p.s, p.t, (int)subs[p.s].map[p.k].second.size()};
+      h_send_pairs.insert(h_send_pairs.end(), quad, quad + 4);
+    }
     for (const Pair &p : pr)
       for (int i : subs[p.s].map[p.k].second) {
         h_send_sub.push_back(p.s);
@@ -266,6 +283,8 @@ void Schwarz::build_halo_lists()
     std::sort(pr.begin(), pr.end(), [](const Pair &a, const Pair &b) { return a.t != b.t ? a.t < b.t : a.s < b.s; });
     long long pos = off;
     for (const Pair &p : pr) {
+      const int quad[4] = {kv.first, p.t, first + p.s, (int)subs[p.s].map[p.k].second.size()};
+      h_recv_pairs.insert(h_recv_pairs.end(), quad, quad + 4);
       h_pairs.push_back(RemotePair{p.s, p.k, pos, off, cnt});
       for (int i : subs[p.s].map[p.k].second) rx[voff[p.s] + i].push_back({(int)pos++, (int)off, (int)cnt});
     }

@@ -60,6 +60,9 @@ struct Schwarz {
   long long             halo_total = 0;
   std::vector<int>      h_send_sub, h_send_idx, h_send_po, h_send_pc; // per send entry: local subdomain, dof, peer offset, peer count
   std::vector<int>      h_rx_ptr, h_rx_k, h_rx_po, h_rx_pc;           // CSR per concatenated dof -> entries of the recv buffer
+  // the ordering contract of a link, as both of its ends see it: (peer rank, source subdomain, destination subdomain, dofs) per
+  // block of the message, global numbers, in message order -- the send list of a -> b must equal the receive list of b <- a
+  std::vector<int>      h_send_pairs, h_recv_pairs;
   struct RemotePair { int s, k; long long pos, po, pc; };               // remote pair (local s, map entry k): first position of its block in the recv buffer
   std::vector<RemotePair> h_pairs;
   DevBuf<int>           send_sub_d, send_idx_d, send_po_d, send_pc_d, rx_ptr_d, rx_k_d, rx_po_d, rx_pc_d;
@@ -129,6 +132,9 @@ struct Schwarz {
   DevBuf<double> w1, w2, w3, hin, hout;
 
   Schwarz(int nsub_, int first_, int nglobal_);
+  ~Schwarz();   // the streams and events of the groups
+  Schwarz(const Schwarz &) = delete;
+  Schwarz &operator=(const Schwarz &) = delete;
   double getopt(const std::string &k, double def) const
   {
     auto it = opt.find(k);

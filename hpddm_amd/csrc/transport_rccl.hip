@@ -68,7 +68,8 @@ RcclApi &rccl()
   for (const std::string &n : names) {
     api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (api.handle) break;
-    tried += " " + n + " (" + (dlerror() ? dlerror() : "?") + ")";
+    const char *err = dlerror();   // one call: dlerror() clears the message it returns
+    tried += " " + n + " (" + (err ? err : "?") + ")";
   }
   HH_CHECK(api.handle != nullptr, "RCCL transport: cannot load librccl:" + tried);
   auto sym = [&](const char *s) {

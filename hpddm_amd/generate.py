@@ -163,7 +163,50 @@ def _factor3(p):
     return best[1]
 
 
-def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False, neumann=False):
+def _numbering(P, brick):
+    """Subdomain numbering on a px x py x pz grid of boxes: (coords(r), index(cx, cy, cz)).  Without ``brick`` it is the
+    lexicographic order (x fastest).  With ``brick = (bx, by, bz)`` the boxes are numbered brick by brick (bricks in lexicographic
+    order, boxes inside a brick too), so that the contiguous ranges of HpddmHipSchwarzSetPartition are bx x by x bz bricks: the
+    box-contiguous mapping of SURVEY 8(e) -- configs[3] is 4 x 4 x 4 boxes in 2 x 2 x 2 bricks, one brick per GPU, every GPU a
+    neighbour of the 7 others."""
+    px, py, pz = P
+    if brick is None or tuple(brick) == (px, py, pz):
+        def coords(r):
+            z, rem = divmod(r, px * py)
+            y, x = divmod(rem, px)
+            return (x, y, z)
+
+        def index(cx, cy, cz):
+            return cx + px * (cy + py * cz)
+        return coords, index
+    bx, by, bz = brick
+    assert px % bx == 0 and py % by == 0 and pz % bz == 0, "the brick must tile the grid of boxes"
+    gx, gy = px // bx, py // by
+    per = bx * by * bz
+
+    def coords(r):
+        b, w = divmod(r, per)
+        Bz, rem = divmod(b, gx * gy)
+        By, Bx = divmod(rem, gx)
+        wz, rem = divmod(w, bx * by)
+        wy, wx = divmod(rem, bx)
+        return (Bx * bx + wx, By * by + wy, Bz * bz + wz)
+
+    def index(cx, cy, cz):
+        Bx, wx = divmod(cx, bx)
+        By, wy = divmod(cy, by)
+        Bz, wz = divmod(cz, bz)
+        return (Bx + gx * (By + gy * Bz)) * per + wx + bx * (wy + by * wz)
+    return coords, index
+
+
+def gpu_grid(ngpus):
+    """the grid of 2 x 2 x 2 bricks (one per GPU) bench.py and the tests use for ``ngpus`` GPUs: as cubic as possible, long side
+    along z (1: 1x1x1, 2: 1x1x2, 4: 1x2x2, 8: 2x2x2)"""
+    return tuple(sorted(_factor3(ngpus)))
+
+
+def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False, neumann=False, brick=None):
     """7-point Laplacian on N^3 cells of the unit cube (h = 1/N, homogeneous Dirichlet through the stencil, like the
     2-D reference problem), split into ``parts`` boxes grown by ``overlap`` layers.  Returns the subdomains
     ``first .. first+count-1`` (default: all).  ``d`` is the product of the 1-D ramps of the reference generator
@@ -178,10 +221,7 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
     h2 = [float(dims[a]) ** 2 for a in range(3)]  # 1/h^2 per direction on the unit cube
     count = parts - first if count is None else count
 
-    def coords(r):
-        z, rem = divmod(r, px * py)
-        y, x = divmod(rem, px)
-        return (x, y, z)
+    coords, index = _numbering(P, brick)
 
     boxes = {}
     for r in range(parts):
@@ -258,13 +298,15 @@ def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0
                     cx, cy, cz = c[0] + dx_, c[1] + dy_, c[2] + dz
                     if not (0 <= cx < px and 0 <= cy < py and 0 <= cz < pz):
                         continue
-                    q = cx + px * (cy + py * cz)
+                    q = index(cx, cy, cz)
                     inter = [(max(boxes[r][a][0], boxes[q][a][0]), min(boxes[r][a][1], boxes[q][a][1])) for a in range(3)]
                     if any(lo >= hi for lo, hi in inter):
                         continue
                     sl = idx[inter[2][0] - k0:inter[2][1] - k0, inter[1][0] - j0:inter[1][1] - j0, inter[0][0] - i0:inter[0][1] - i0]
                     neigh.append(q)
                     conn.append(sl.reshape(-1).astype(np.int32))
+        order = sorted(range(len(neigh)), key=neigh.__getitem__)   # increasing neighbour number (brick numberings are not lexicographic)
+        neigh, conn = [neigh[k] for k in order], [conn[k] for k in order]
         if rhs == "ones":
             f = np.ones(n)
         else:  # smooth analytic right-hand side
@@ -312,7 +354,7 @@ def _q1_elasticity_stiffness(h, E, nu):
     return 0.5 * (Ke + Ke.T)
 
 
-def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, grid=None, normalize=True, neumann=False, E=1.0, nu=0.3):
+def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, grid=None, normalize=True, neumann=False, E=1.0, nu=0.3, brick=None):
     """Linear elasticity (3 dofs per node, trilinear hexahedra, h = 1/N) on N^3 nodes of a cube clamped on the face x = 0
     (a layer of elements between the clamped plane and the first nodes), the other faces free; node boxes grown by
     ``overlap`` layers -- the block-3 workload of BASELINE.json configs[3].  Same conventions as generate3d: subdomain
@@ -326,10 +368,7 @@ def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, gr
     Ke = _q1_elasticity_stiffness(h, E, nu)
     count = parts - first if count is None else count
 
-    def coords(r):
-        z, rem = divmod(r, px * py)
-        y, x = divmod(rem, px)
-        return (x, y, z)
+    coords, index = _numbering(P, brick)
 
     boxes = {}
     for r in range(parts):
@@ -421,13 +460,15 @@ def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, gr
                     cx, cy, cz = c[0] + dx_, c[1] + dy_, c[2] + dz
                     if not (0 <= cx < px and 0 <= cy < py and 0 <= cz < pz):
                         continue
-                    q = cx + px * (cy + py * cz)
+                    q = index(cx, cy, cz)
                     inter = [(max(boxes[r][t][0], boxes[q][t][0]), min(boxes[r][t][1], boxes[q][t][1])) for t in range(3)]
                     if any(lo >= hi for lo, hi in inter):
                         continue
                     nodes = idx[inter[2][0] - k0:inter[2][1] - k0, inter[1][0] - j0:inter[1][1] - j0, inter[0][0] - i0:inter[0][1] - i0].reshape(-1)
                     neigh.append(q)
                     conn.append((3 * nodes[:, None] + np.arange(3)[None, :]).reshape(-1).astype(np.int32))
+        order = sorted(range(len(neigh)), key=neigh.__getitem__)
+        neigh, conn = [neigh[k] for k in order], [conn[k] for k in order]
         f = np.zeros(3 * nn)
         f[2::3] = -h ** 3  # gravity along -z, lumped
         sub = dict(n=3 * nn, ia=ia, ja=ja, a=a, sym=bool(sym), numbering="C", neighbors=np.array(neigh, dtype=np.int32), connectivity=conn, d=d, f=f,

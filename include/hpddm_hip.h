@@ -207,7 +207,10 @@ int HpddmHipSchwarzInitRccl(HpddmHipSchwarz *A, const char *id128, int mu_cap);
 /* what a single GPU can check of that path: binding, a one-rank communicator, a grouped send/recv pair to the rank itself and an
  * all-reduce, ordered on the library stream; 0 = ok */
 int HpddmHipRcclSelfTest(void);
-/* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc" */
+/* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc";
+ * "send_pairs" / "recv_pairs": the ordering contract of every link as this end sees it -- quadruples (peer rank, source subdomain,
+ * destination subdomain, dofs), global numbers, in message order: the send list of a -> b must equal the receive list of b <- a
+ * (the one-message-per-neighbour-pair order of Subdomain::exchange, include/HPDDM_subdomain.hpp:115-130, grouped per peer GPU) */
 long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *out, long long capacity);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -10,6 +10,13 @@ compared with the oracle on the global problem.
 
 mode "rccl": one GPU per rank, the library's own RCCL transport (HpddmHipSchwarzInitRccl; the ncclUniqueId travels over the
 gloo group), same checks as "gpu".  Needs as many GPUs as ranks.
+
+Layout (every mode): the topology BASELINE.json's multi-GPU configs name -- every rank owns one 2 x 2 x 2 brick of subdomains,
+the bricks form the most cubic grid of `world` GPUs (8 ranks: 4 x 4 x 4 subdomains as 2 x 2 x 2 bricks, every GPU a neighbour of the
+7 others = configs[3]; 4 ranks: 2 x 4 x 4 subdomains = the layout of configs[4]; 2 / 3 ranks: a chain).  Subdomains are numbered
+brick by brick, so the contiguous ranges of HpddmHipSchwarzSetPartition are the bricks.
+
+Optional second argument: "helmholtz" -- complex<double> operator (shifted Laplacian with absorption), Block GMRES on 2 right-hand sides.
 """
 import os
 import sys
@@ -22,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from hpddm_amd import hpddm  # noqa: E402
-from hpddm_amd.generate import generate3d  # noqa: E402
+from hpddm_amd.generate import generate3d, gpu_grid  # noqa: E402
 from oracle.ras_oracle import Oracle  # noqa: E402
 
 
@@ -30,22 +37,51 @@ def main():
     mode = sys.argv[1]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    parts, grid, dims = 4 * world, (2, 2, world), (8, 8, 6 * world)
-    per = parts // world
+    helm = len(sys.argv) > 2 and sys.argv[2] == "helmholtz"
+    gg = gpu_grid(world)                                   # bricks (= GPUs) per direction
+    grid = tuple(2 * g for g in gg)                        # subdomains per direction
+    cells = 3 if world >= 8 else 4                         # cells per subdomain and direction, before the overlap
+    parts, per, dims = 8 * world, 8, tuple(cells * g for g in grid)
     firsts = [r * per for r in range(world + 1)]
-    allsubs = generate3d(dims, parts, overlap=1, sym=True, rhs="smooth", grid=grid, normalize=True)
+    allsubs = generate3d(dims, parts, overlap=1, sym=not helm, rhs="smooth", grid=grid, brick=(2, 2, 2), normalize=True)
+    if helm:
+        for sd in allsubs:
+            a = sd["a"].astype(np.complex128)
+            rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
+            a[rows == sd["ja"]] *= 0.97 + 0.03j
+            sd["a"] = a
     mine = allsubs[firsts[rank]:firsts[rank + 1]]
     orc = Oracle(allsubs)
     orc.d = [s["d"] for s in allsubs]
-    A, d = hpddm.schwarz_from_subdomains(mine, first_global=firsts[rank], nglobal=parts, options="-hpddm_operator_spd", multiplicity=False,
+    A, d = hpddm.schwarz_from_subdomains(mine, first_global=firsts[rank], nglobal=parts, options="" if helm else "-hpddm_operator_spd", multiplicity=False,
                                          partition=(rank, firsts))
     rng = np.random.default_rng(5)
     mu = 2
-    xg = [rng.random((s["n"], mu)) for s in allsubs]
+    xg = [rng.random((s["n"], mu)) + (1j * rng.random((s["n"], mu)) if helm else 0.0) for s in allsubs]
     ref = orc.exchange(xg)
     peers = A.halo_peers()
-    assert len(peers) == (1 if rank in (0, world - 1) else 2), peers  # slabs along z: neighbours are the ranks above/below
+    # the peers of a brick: every brick within distance 1 in each direction (7 xGMI links per GPU on the 2 x 2 x 2 grid of configs[3])
+    me = (rank % gg[0], rank // gg[0] % gg[1], rank // (gg[0] * gg[1]))
+    expect = sorted(x + gg[0] * (y + gg[1] * z) for x in range(gg[0]) for y in range(gg[1]) for z in range(gg[2])
+                    if (x, y, z) != me and max(abs(x - me[0]), abs(y - me[1]), abs(z - me[2])) <= 1)
+    assert [p for p, _, _ in peers] == expect, (peers, expect)
+    if world == 8:
+        assert len(peers) == 7
+    # the ordering contract of every link, checked on both of its ends: what a sends to b, block by block (source subdomain,
+    # destination subdomain, dofs), is what b expects from a
+    sp, rp = A.halo_export("send_pairs").reshape(-1, 4), A.halo_export("recv_pairs").reshape(-1, 4)
+    box = [None] * world
+    dist.all_gather_object(box, (sp.tolist(), rp.tolist()))
+    for a_ in range(world):
+        for b_ in range(world):
+            sent = [q[1:] for q in box[a_][0] if q[0] == b_]
+            want = [q[1:] for q in box[b_][1] if q[0] == a_]
+            assert sent == want, (a_, b_, sent[:4], want[:4])
+            assert all(s // per == a_ and t // per == b_ for s, t, _ in sent)
+            assert sent == sorted(sent), "blocks of a message in increasing (source, destination) order"
+    assert sum(q[3] for q in sp.tolist()) == sum(c for _, c, _ in peers) == sum(q[3] for q in rp.tolist())
     if mode == "lists":
+        assert not helm
         L = {k: A.halo_export(k) for k in ("send_sub", "send_idx", "send_po", "send_pc", "rx_ptr", "rx_k", "rx_po", "rx_pc")}
         total = sum(c for _, c, _ in peers)
         assert len(L["send_sub"]) == total
@@ -116,6 +152,32 @@ def main():
         close(A.gmv(x), orc.gmv(xg)[sl], 1e-13, "gmv")
         f = orc.exchange(xg)
         close(A.apply(f[sl]), orc.apply(f)[sl], 1e-10, "apply")
+        if helm:
+            # configs[4] in small: complex operator, plane-wave coarse space assembled across the ranks, Block GMRES on the block of
+            # right-hand sides (the Gram matrices of the block method are summed over the ranks)
+            from oracle import ras_oracle as ro
+            Zg = []
+            for k, sd in enumerate(allsubs):
+                t = np.arange(sd["n"], dtype=np.float64)
+                Zg.append(np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * k)], axis=1))
+            for k in range(per):
+                A.set_vectors(k, Zg[firsts[rank] + k])
+            A.build_coarse_operator()
+            orc.set_vectors(Zg)
+            orc.build_coarse(lapacktr=False)
+            A.option_parse("-hpddm_schwarz_coarse_correction deflated -hpddm_krylov_method bgmres -hpddm_gmres_restart 20")
+            orc.correction = "deflated"
+            close(A.deflation(f[sl]), orc.deflation(f)[sl], 1e-9, "deflation")
+            close(A.apply(f[sl]), orc.apply(f)[sl], 1e-9, "apply deflated")
+            it, sol = A.solve(f[sl])
+            it_o, sol_o, _ = ro.bgmres(orc, f, restart=20)
+            assert it == it_o, (it, it_o)
+            close(sol, sol_o[sl], 1e-7, "solution")
+            dist.barrier()
+            if rank == 0:
+                print(f"DIST_WORKER_OK mode={mode} helmholtz world={world} peers={peers} bgmres={it}")
+            dist.destroy_process_group()
+            return
         it, sol = A.solve(f[sl])
         it_o, sol_o, _ = orc.gmres(f)
         assert it == it_o, (it, it_o)

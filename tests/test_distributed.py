@@ -12,23 +12,31 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(mode, world, port):
+def _launch(mode, world, port, *extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "dist_worker.py"), mode]
-    env = dict(os.environ, OMP_NUM_THREADS="2", HPDDM_HIP_NUM_THREADS="2")
+           os.path.join(HERE, "dist_worker.py"), mode, *extra]
+    env = dict(os.environ, OMP_NUM_THREADS="1" if world > 4 else "2", HPDDM_HIP_NUM_THREADS="1" if world > 4 else "2")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0 and "DIST_WORKER_OK" in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_lists_gloo_cpu(world):
+    """world 8 = the topology of configs[3]: 4 x 4 x 4 subdomains in 2 x 2 x 2 bricks, one brick per rank, 7 peers each"""
     _launch("lists", world, 29620 + world)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_operator_shared_gpu(world):
+    """world 4 = the layout of configs[4]: 2 x 4 x 4 subdomains, one 2 x 2 x 2 brick per rank"""
     _launch("gpu", world, 29630 + world)
+
+
+@pytest.mark.gpu
+def test_sharded_complex_operator_shared_gpu():
+    """configs[4] in small on its own layout: complex<double> operator on 4 ranks (32 subdomains), two-level, Block GMRES"""
+    _launch("gpu", 4, 29650, "helmholtz")
 
 
 @pytest.mark.gpu
@@ -39,7 +47,7 @@ def test_rccl_binding_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_operator_native_rccl(world):
     from hpddm_amd import hpddm
     if hpddm.device_count() < world:
