@@ -200,10 +200,23 @@ def _numbering(P, brick):
     return coords, index
 
 
-def gpu_grid(ngpus):
-    """the grid of 2 x 2 x 2 bricks (one per GPU) bench.py and the tests use for ``ngpus`` GPUs: as cubic as possible, long side
-    along z (1: 1x1x1, 2: 1x1x2, 4: 1x2x2, 8: 2x2x2)"""
-    return tuple(sorted(_factor3(ngpus)))
+def gpu_grid(ngpus, per_gpu=(1, 1, 1)):
+    """the grid of 2 x 2 x 2 bricks (one per GPU) bench.py and the tests use for ``ngpus`` GPUs: the factorisation that makes the
+    global domain ``per_gpu * grid`` as cubic as possible, ties broken towards z (1: 1x1x1, 2: 1x1x2, 4: 1x2x2, 8: 2x2x2 for a
+    cubic share; a share of 64 x 64 x 128 cells on 4 GPUs gives 2x2x1 = the 128^3 cube of configs[4])"""
+    best = None
+    for a in range(1, ngpus + 1):
+        if ngpus % a:
+            continue
+        for b in range(1, ngpus // a + 1):
+            if (ngpus // a) % b:
+                continue
+            g = (a, b, ngpus // a // b)
+            dims = [per_gpu[k] * g[k] for k in range(3)]
+            key = (max(dims) / min(dims), g[0], g[1])
+            if best is None or key < best[0]:
+                best = (key, g)
+    return best[1]
 
 
 def generate3d(N, parts, overlap=1, sym=True, numbering="C", rhs="ones", first=0, count=None, grid=None, normalize=False, neumann=False, brick=None):
