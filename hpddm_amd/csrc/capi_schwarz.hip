@@ -674,7 +674,7 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
         const int kind = tags[i] / 1000, lev = tags[i] % 1000;
         out[3 * i] = tags[i];
         out[3 * i + 1] = usec[i];
-        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : ((kind == 5 || kind == 6) ? P.chain_bytes : 0.0);
+        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : 0.0;
       }
     return n;)
 }

@@ -92,10 +92,8 @@ struct DeviceFactor {
   std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
   std::vector<char>    has_src;
   std::vector<int64_t> f_off, row_ptr, goff;
-  std::vector<idx_t>   parent;               // assembly tree (plan builder: bottom subtrees taken by one wavefront each)
-  DevBuf<int>          src4;                 // fixed-slot gather lists of the chainable supernodes
+  DevBuf<int>          src4;                 // fixed-slot gather lists of the narrow supernodes with at most 4 sources per entry
   std::vector<int64_t> s4_off;               // per supernode offset into src4 (-1: none; leaves need none)
-  std::vector<char>    chainable;            // narrow, at most CHAIN_MAX_H rows, at most 4 sources per entry
   void upload(const HostFactor &hf, hipStream_t s);
 };
 
@@ -112,13 +110,6 @@ struct SolvePlan {
   DevBuf<Tile>     tiles;
   std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
-  // bottom subtrees ("chains"): every wavefront walks the tiles of one small subtree in dependency order -- forward: children
-  // before parents, ahead of the level launches; backward: parents first, after them -- with the first panel rows of the next
-  // tile in flight while the current one is reduced and stored.  chain_ptr[kd][c] .. [c+1] = tiles of chain c.
-  DevBuf<int>      chain_ptr[2];
-  int              nchains = 0, chain_lds[2] = {0, 0};
-  long long        chain_off[2] = {0, 0};   // first tile of the forward / backward chains in `tiles`
-  double           chain_bytes = 0;         // panel bytes (stored entries * 8) the chain launches stream per direction
   // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
   // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
   std::vector<int> gat_ptr, gat_end;
@@ -130,19 +121,11 @@ struct SolvePlan {
   DevBuf<const int *> pperm; // per factor: perm array
   int               nmax = 0;
   int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
-  int               persist = 0; // workgroups per CU of the persistent sweep launches
-  int               persist_narrow = 0; // launches made of wave tiles only: grid capped at this many workgroups per wavefront slot (0: one per tile)
-  bool              narrow_wave_wg = false; // ... optionally one wavefront per workgroup
-  bool              mu16 = true;            // complex scalars: blocks of 16 real columns (8 right-hand sides) per sweep
   int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves
   double         bytes_alg_per_rhs1 = 0; // 2*nnz(L)*8 + 4*n*8 summed over the factors, mu = 1
-  bool                           use_graph = false;
-  std::map<int, hipGraphExec_t>  graphs; // per mu: the captured level launches of one solve
-  void drop_graphs();
-  ~SolvePlan() { drop_graphs(); }
   void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
   void reserve(int mu);
   // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b.
@@ -153,14 +136,14 @@ struct SolvePlan {
   int  launches_per_solve = 0;
   int  groups = 1; // this plan sweeps one of `groups` sets of subdomains that share the GPU (targets of the plan builder scale with it)
   // developer aid (HpddmHipSchwarzLevelTimes): one HIP event after every launch of a solve; tag = kind * 1000 + level,
-  // kind 0 permutation in, 1 gather pass, 2 forward, 3 backward, 4 permutation out, 5 / 6 forward / backward chain launch
+  // kind 0 permutation in, 1 gather pass, 2 forward, 3 backward, 4 permutation out
   bool                    profile = false;
   std::vector<hipEvent_t> prof_ev;
   std::vector<int>        prof_tag;
   void                    mark(int tag, hipStream_t s);
   static unsigned long long *timeline_host;           // developer aid (HPDDM_HIP_DBG & 32): pinned buffer the wave tiles write their clocks to
   static unsigned int        timeline_count();
-  std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch (chains excluded)
+  std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch
   std::vector<double>     level_bytes(int kind) const;
 };
 

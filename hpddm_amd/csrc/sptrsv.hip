@@ -23,7 +23,6 @@ namespace hpddm_hip {
 static constexpr int WG_THREADS  = 256;
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
-static constexpr int CHAIN_MAX_H = 160;  // supernodes of the bottom subtrees one wavefront walks on its own (chain kernels): at most this many rows
 
 // Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
 // tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
@@ -51,9 +50,16 @@ __device__ static inline SnView view(const SnDesc &d)
   v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
   return v;
 }
-// developer aid (HPDDM_HIP_DBG, wrong results): 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand
-// side staging, 8 skip the panel loads
+// developer aid, compiled in only with -DHPDDM_HIP_ABLATION (make ABLATION=1): the HPDDM_HIP_DBG mask then switches parts of the
+// sweep kernels off (WRONG results: 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand side staging, 8 skip
+// the panel loads, 16 VALU tiles instead of the MFMA ones -- exact) or records per-tile clocks (32, exact).  In the product build
+// DBG_ON is a constant false and the `dbg` arguments of the kernels are dead.
 enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8, DBG_NOMFMA = 16, DBG_TIMELINE = 32 };
+#ifdef HPDDM_HIP_ABLATION
+#define DBG_ON(dbg, bit) (((dbg) & (bit)) != 0)
+#else
+#define DBG_ON(dbg, bit) false
+#endif
 // developer aid (HPDDM_HIP_DBG & 32, results stay exact): wave tiles of the narrow panels record the constant-rate clock
 // (100 MHz) at five points -- kernel entry, descriptor in registers, right-hand side staged, panel streamed, results stored --
 // into a device buffer, 8 entries per tile (last three: level-independent tile index, rows, doubles per row)
@@ -245,10 +251,10 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
   }
   // f = b_J - (updates handed up by the children), one lane per column, into the wavefront's LDS
-  for (int c = lane; c < w && !(dbg & DBG_NORHS); c += 64) {
+  for (int c = lane; c < w && !DBG_ON(dbg, DBG_NORHS); c += 64) {
     double v[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
@@ -295,7 +301,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -313,10 +319,10 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
       for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
-  if (!(dbg & DBG_NORED)) {
+  if (!DBG_ON(dbg, DBG_NORED)) {
     reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
-  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
+  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
     const int r = t.r0 + 2 * gl, rend = t.r0 + t.nr;
     if (r < rend) fwd_store_row<MU>(d, r, acc0, 1, yb, Ub);
     if (r + 1 < rend) fwd_store_row<MU>(d, r + 1, acc1, 1, yb, Ub);
@@ -329,7 +335,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
 {
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
-  if (dbg & DBG_TIMELINE) tk1 = wall_clock64() + (unsigned long long)(w < 0);
+  if (DBG_ON(dbg, DBG_TIMELINE)) tk1 = wall_clock64() + (unsigned long long)(w < 0);
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -346,7 +352,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
   const bool lists = d.has_src && !slots;
   int4v      csrc = {-1, -1, -1, -1}, rsrc[2];
   double     fv[MU];
-  const bool mine = lane < w && !(dbg & DBG_NORHS); // lane c stages column c (supernodes wider than 64 take the loop below)
+  const bool mine = lane < w && !DBG_ON(dbg, DBG_NORHS); // lane c stages column c (supernodes wider than 64 take the loop below)
   if (slots && mine) csrc = d.src4[lane];
 #pragma unroll
   for (int k = 0; k < 2; ++k) rsrc[k] = (slots && sub == 0 && r_out + k >= w && r_out + k < rend) ? d.src4[r_out + k] : int4v{-1, -1, -1, -1};
@@ -356,8 +362,8 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R, i2 = i + FWD_PASSES * R;
-    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
-    nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
   }
   double radd[2][MU];
 #pragma unroll
@@ -402,7 +408,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
     }
   };
   if (mine) stage(lane, fv);
-  for (int c = lane + 64; c < w && !(dbg & DBG_NORHS); c += 64) { // columns 64 .. 127 of the widest narrow supernodes
+  for (int c = lane + 64; c < w && !DBG_ON(dbg, DBG_NORHS); c += 64) { // columns 64 .. 127 of the widest narrow supernodes
     double v[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
@@ -425,7 +431,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
     stage(c, v);
   }
   wave_lds_order();
-  if (dbg & DBG_TIMELINE) tk2 = wall_clock64();
+  if (DBG_ON(dbg, DBG_TIMELINE)) tk2 = wall_clock64();
   double acc0[MU], acc1[MU];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
@@ -438,7 +444,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (2 * FWD_PASSES + p) * R;
-        nx2[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nx2[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -457,11 +463,11 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
       nxt[p] = more2 ? nx2[p] : dbl2{0.0, 0.0};
     }
   }
-  if (!(dbg & DBG_NORED)) {
+  if (!DBG_ON(dbg, DBG_NORED)) {
     reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
-  if (dbg & DBG_TIMELINE) tk3 = wall_clock64() + (unsigned long long)(acc0[0] == 1.2345e300);
-  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
+  if (DBG_ON(dbg, DBG_TIMELINE)) tk3 = wall_clock64() + (unsigned long long)(acc0[0] == 1.2345e300);
+  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
     if (!lists) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -480,7 +486,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
       if (r_out + 1 < rend) fwd_store_row<MU>(d, r_out + 1, acc1, 1, yb, Ub);
     }
   }
-  if ((dbg & DBG_TIMELINE) && lane == 0) {
+  if (DBG_ON(dbg, DBG_TIMELINE) && lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     timeline_put(tk0, tk1, tk2, tk3, wall_clock64(), t.nr, wc, d.has_src ? 1 : 0);
   }
@@ -499,10 +505,10 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
+    cur[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
   }
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
-  for (int i = lane; i < h && !(dbg & DBG_NORHS); i += 64) {
+  for (int i = lane; i < h && !DBG_ON(dbg, DBG_NORHS); i += 64) {
     if (i < w) {
       if constexpr (!Z) {
         const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
@@ -534,7 +540,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -552,10 +558,10 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
       for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
-  if (!(dbg & DBG_NORED)) {
+  if (!DBG_ON(dbg, DBG_NORED)) {
     reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   }
-  if (sub == 0 && !(dbg & DBG_NOSTORE)) {
+  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
     if constexpr (!Z) {
       const int c = 2 * gl;
       if (c < w) {
@@ -576,297 +582,6 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
   }
 }
 
-
-// =========================== bottom subtrees: one wavefront per chain of tiles ========================================
-// The lowest levels of the assembly tree are thousands of panels of a few KB: taken level by level, a tile spends its time in
-// dependent round trips (tile -> descriptor -> gather lists -> update vector -> ... -> store) with a few KB of panel in
-// flight, and every level pays a launch boundary.  Here a wavefront owns a whole small subtree and walks its tiles in
-// dependency order: the descriptor, the gather slots and the first panel rows of the NEXT tile are requested before the
-// current tile is reduced and stored, so a wavefront always has panel bytes in flight.  Children hand their update vectors to
-// their parent through global memory as in the level launches; producer and consumer are the same wavefront, so the hand-over
-// is a wavefront-local ordering of its stores before its later loads (same CU, same L1), no atomics, same summation order
-// as the level launches (bitwise identical results).
-struct WaveGeom { // lane mapping of a narrow tile: sub = row group, gl = pair of outputs, g lanes per panel row
-  int   g, R, sub, gl;
-  bool  active;
-};
-__device__ static inline WaveGeom geom(int lanes_per, int lane)
-{
-  WaveGeom q;
-  q.g      = lanes_per;
-  q.R      = 64 / q.g;
-  q.sub    = lane / q.g;
-  q.gl     = lane - q.sub * q.g;
-  q.active = q.sub < q.R;
-  return q;
-}
-__device__ static inline void chain_fence()
-{
-  // stores of this wavefront (update vectors / x) before its later loads of the same locations, and the LDS staging area free
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <int MU, int NP>
-__device__ static inline void chain_fwd(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, int t0, int t1, int lane, double *lds, int wr, const double *b, double *y, double *U, int mu_total, int nu0)
-{
-  Tile     t = tiles[t0];
-  SnView   d = view(sns[t.sn]);
-  WaveGeom q = geom((t.nr + 1) >> 1, lane);
-  gcd_t    Fp = d.FT + t.r0 + 2 * q.gl;
-  int      rtop = t.r0 + 2 * q.gl + 1;
-  dbl2     cur[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int i = q.sub + p * q.R;
-    cur[p]      = (q.active && i < d.w && i <= rtop) ? *(gcd2_t)(Fp + (long long)i * d.ldh) : dbl2{0.0, 0.0};
-  }
-  // gather slots of the columns (right-hand side of the supernode): lane c and lane c + 64
-  int4v csrc[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) csrc[k] = (d.has_src && lane + 64 * k < d.w) ? d.src4[lane + 64 * k] : int4v{-1, -1, -1, -1};
-  for (int tix = t0; tix < t1; ++tix) {
-    const bool has_next = tix + 1 < t1;
-    Tile       tn = t;
-    SnView     dn = d;
-    if (has_next) {
-      tn = tiles[tix + 1];
-      dn = view(sns[tn.sn]);
-    }
-    const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
-    double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-    double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    const int     w = d.w;
-    // gather slots of this lane's two output rows (below the diagonal block): static data, lands during the sweep
-    const int r_out = t.r0 + 2 * q.gl, rend = t.r0 + t.nr;
-    int4v     rsrc[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) rsrc[k] = (d.has_src && q.sub == 0 && r_out + k >= w && r_out + k < rend) ? d.src4[r_out + k] : int4v{-1, -1, -1, -1};
-    if (t.part) { // first tile of its supernode: f = b_J - (updates handed up by the children)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = lane + 64 * k;
-        if (c < w) {
-          double v[MU];
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int src = csrc[k][j];
-            if (src >= 0) {
-#pragma unroll
-              for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
-            }
-          }
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
-        }
-      }
-      wave_lds_order();
-    }
-    // the next tile: lane mapping, first rows of its panel, gather slots of its columns
-    const WaveGeom qn = geom((tn.nr + 1) >> 1, lane);
-    const gcd_t    Fn = dn.FT + tn.r0 + 2 * qn.gl;
-    const int      rtopn = tn.r0 + 2 * qn.gl + 1;
-    int4v          csrcn[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) csrcn[k] = (has_next && tn.part && dn.has_src && lane + 64 * k < dn.w) ? dn.src4[lane + 64 * k] : int4v{-1, -1, -1, -1};
-    double acc0[MU], acc1[MU];
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
-    for (int ib0 = 0; ib0 < w; ib0 += NP * q.R) {
-      const int  ib   = ib0 + q.sub;
-      const bool more = ib0 + NP * q.R < w;
-      dbl2       nxt[NP];
-      if (more) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int i = ib + (NP + p) * q.R;
-          nxt[p]      = (q.active && i < w && i <= rtop) ? *(gcd2_t)(Fp + (long long)i * d.ldh) : dbl2{0.0, 0.0};
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int i = qn.sub + p * qn.R;
-          nxt[p]      = (has_next && qn.active && i < dn.w && i <= rtopn) ? *(gcd2_t)(Fn + (long long)i * dn.ldh) : dbl2{0.0, 0.0};
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int i = min(ib + p * q.R, w - 1); // out-of-range passes carry a = 0
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) {
-          const double v = lds[nu * wr + i];
-          acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
-          acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
-    }
-    reduce_across_pairs<MU>(acc0, acc1, lane, q.sub, q.g, q.R);
-    if (q.sub == 0) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int r = r_out + k;
-        if (r < rend) {
-          if (r < w) {
-#pragma unroll
-            for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = k ? acc1[nu] : acc0[nu];
-          } else {
-#pragma unroll
-            for (int nu = 0; nu < MU; ++nu) {
-              double v = k ? acc1[nu] : acc0[nu];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int src = rsrc[k][j];
-                if (src >= 0) v += Ub[(long long)nu * d.usize + src];
-              }
-              Ub[(long long)nu * d.usize + d.u_off + (r - w)] = v;
-            }
-          }
-        }
-      }
-    }
-    // tn.nparts: the next tile starts a new height of the subtree -- its supernode gathers update vectors stored by earlier
-    // tiles of this chain: those stores must have landed.  Otherwise only the LDS staging area is handed over.
-    if (has_next && tn.nparts) chain_fence();
-    else wave_lds_order();
-    t = tn, d = dn, q = qn, Fp = Fn, rtop = rtopn;
-    csrc[0] = csrcn[0], csrc[1] = csrcn[1];
-  }
-}
-
-template <int MU, int NP>
-__device__ static inline void chain_bwd(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, int t0, int t1, int lane, double *lds, int wr, const double *y, double *xw, int mu_total, int nu0)
-{
-  constexpr int NRW = (CHAIN_MAX_H + 63) / 64; // rows of v a lane stages
-  Tile     t = tiles[t0];
-  SnView   d = view(sns[t.sn]);
-  WaveGeom q = geom(d.ldw >> 1, lane);
-  gcd_t    Gp = d.G + 2 * q.gl;
-  dbl2     cur[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int i = q.sub + p * q.R;
-    cur[p]      = (q.active && i < d.w + d.nb && i >= 2 * q.gl) ? *(gcd2_t)(Gp + (long long)i * d.ldw) : dbl2{0.0, 0.0};
-  }
-  int rw[NRW]; // the rows below the block this lane stages (static data)
-#pragma unroll
-  for (int k = 0; k < NRW; ++k) {
-    const int i = lane + 64 * k;
-    rw[k]       = (i >= d.w && i < d.w + d.nb) ? d.rows[i - d.w] : 0;
-  }
-  for (int tix = t0; tix < t1; ++tix) {
-    const bool has_next = tix + 1 < t1;
-    Tile       tn = t;
-    SnView     dn = d;
-    if (has_next) {
-      tn = tiles[tix + 1];
-      dn = view(sns[tn.sn]);
-    }
-    const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-    double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
-    const int     w = d.w, h = d.w + d.nb, ldw = d.ldw;
-    // v = [ D^{-1} y_J ; -x_below ]: x of the ancestors comes from earlier launches or from earlier tiles of this chain
-#pragma unroll
-    for (int k = 0; k < NRW; ++k) {
-      const int i = lane + 64 * k;
-      if (i < h) {
-        if (i < w) {
-          const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = yb[(long long)nu * d.n + d.c0 + i] * sc;
-        } else {
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) lds[nu * wr + i] = -xb[(long long)nu * d.n + rw[k]];
-        }
-      }
-    }
-    wave_lds_order();
-    const WaveGeom qn = geom(dn.ldw >> 1, lane);
-    const gcd_t    Gn = dn.G + 2 * qn.gl;
-    const int      hn = dn.w + dn.nb;
-    int            rwn[NRW];
-#pragma unroll
-    for (int k = 0; k < NRW; ++k) {
-      const int i = lane + 64 * k;
-      rwn[k]      = (has_next && i >= dn.w && i < hn) ? dn.rows[i - dn.w] : 0;
-    }
-    double acc0[MU], acc1[MU];
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
-    for (int ib0 = 0; ib0 < h; ib0 += NP * q.R) {
-      const int  ib   = ib0 + q.sub;
-      const bool more = ib0 + NP * q.R < h;
-      dbl2       nxt[NP];
-      if (more) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int i = ib + (NP + p) * q.R;
-          nxt[p]      = (q.active && i < h && i >= 2 * q.gl) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int i = qn.sub + p * qn.R;
-          nxt[p]      = (has_next && qn.active && i < hn && i >= 2 * qn.gl) ? *(gcd2_t)(Gn + (long long)i * dn.ldw) : dbl2{0.0, 0.0};
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int i = min(ib + p * q.R, h - 1);
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) {
-          const double v = lds[nu * wr + i];
-          acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
-          acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) cur[p] = nxt[p];
-    }
-    reduce_across_pairs<MU>(acc0, acc1, lane, q.sub, q.g, q.R);
-    if (q.sub == 0) {
-      const int c = 2 * q.gl;
-      if (c < w) {
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = acc0[nu];
-      }
-      if (c + 1 < w) {
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu];
-      }
-    }
-    if (has_next && tn.nparts) chain_fence(); // the next tile starts a lower height: it reads x stored by earlier tiles of this chain
-    else wave_lds_order();
-    t = tn, d = dn, q = qn, Gp = Gn;
-#pragma unroll
-    for (int k = 0; k < NRW; ++k) rw[k] = rwn[k];
-  }
-}
-
-template <int MU, int NP>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_fwd_chain_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ chain_ptr, int nchains, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int wr)
-{
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int c  = (int)blockIdx.x * (WG_THREADS / 64) + wv;
-  if (c >= nchains) return;
-  const int t0 = __builtin_amdgcn_readfirstlane(chain_ptr[c]), t1 = __builtin_amdgcn_readfirstlane(chain_ptr[c + 1]);
-  chain_fwd<MU, NP>(sns, tiles, t0, t1, lane, lds + wv * (wr * MU), wr, b, y, U, mu_total, nu0);
-}
-template <int MU, int NP>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_bwd_chain_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ tiles, const int *__restrict__ chain_ptr, int nchains, const double *__restrict__ y, double *__restrict__ xw, int mu_total, int nu0, int wr)
-{
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int c  = (int)blockIdx.x * (WG_THREADS / 64) + wv;
-  if (c >= nchains) return;
-  const int t0 = __builtin_amdgcn_readfirstlane(chain_ptr[c]), t1 = __builtin_amdgcn_readfirstlane(chain_ptr[c + 1]);
-  chain_bwd<MU, NP>(sns, tiles, t0, t1, lane, lds + wv * (wr * MU), wr, y, xw, mu_total, nu0);
-}
 
 // =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
 // right-hand side entry of panel column `col` (in doubles) for the real column nu: real scalars b_J - updates; complex scalars the
@@ -905,7 +620,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
       for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
     }
     for (int k0 = 0; k0 < tile_lim; k0 += CW) {
-      if ((!single || rb == t.r0) && !(dbg & DBG_NORHS)) {
+      if ((!single || rb == t.r0) && !DBG_ON(dbg, DBG_NORHS)) {
         // stage f = b - children's updates for columns [k0, kend), zero padding up to ldw (16-byte reads past w see zeros)
         if (!single) __syncthreads();
         const int kend = min(k0 + CW, ldw);
@@ -922,7 +637,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 #pragma unroll
         for (int u = 0; u < CU; ++u)
 #pragma unroll
-          for (int p = 0; p < FWD_PASSES; ++p) a[u][p] = (c + 128 * u < lim[p] && !(dbg & DBG_NOLOAD)) ? *(gcd2_t)(d.F + (long long)row[p] * ldw + c + 128 * u) : dbl2{0.0, 0.0};
+          for (int p = 0; p < FWD_PASSES; ++p) a[u][p] = (c + 128 * u < lim[p] && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(d.F + (long long)row[p] * ldw + c + 128 * u) : dbl2{0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
           const int ci = c + 128 * u < cmax ? c + 128 * u - k0 : 0; // columns past the chunk carry a = 0
@@ -940,14 +655,14 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         double s = acc[p][nu];
-        if (!(dbg & DBG_NORED))
+        if (!DBG_ON(dbg, DBG_NORED))
           for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0 && row[p] < rend) sums[nu * 64 + (row[p] - t.r0)] = s;
       }
   }
   // epilogue: one thread per row of the tile (tiles have at most 64 rows)
   __syncthreads();
-  if (tid < t.nr && !(dbg & DBG_NOSTORE)) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+  if (tid < t.nr && !DBG_ON(dbg, DBG_NOSTORE)) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
 }
 
 // Forward tile of a wide panel with 4 or 8 right-hand sides on the f64 MFMA pipe: T(rows x MU) = F(rows x w) f(w x MU) is a
@@ -1068,7 +783,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   // rows above the tile's first column hold zeros in these columns (triangular top block): rows [t.rbeg, t.rend) only
   for (int i0 = t.rbeg; i0 < t.rend; i0 += RCH) {
     const int rch = min(RCH, t.rend - i0);
-    for (int idx = tid; idx < rch * MU && !(dbg & DBG_NORHS); idx += WG_THREADS) {
+    for (int idx = tid; idx < rch * MU && !DBG_ON(dbg, DBG_NORHS); idx += WG_THREADS) {
       const int nu = idx / rch, ii = idx - nu * rch;
       const int i = i0 + ii;
       double    v;
@@ -1091,7 +806,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
       for (; ii + (FP - 1) * 4 * R < rch; ii += FP * 4 * R) {
         dbl2 a[FP];
 #pragma unroll
-        for (int p = 0; p < FP; ++p) a[p] = (dbg & DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)(ii + p * 4 * R) * ldw);
+        for (int p = 0; p < FP; ++p) a[p] = DBG_ON(dbg, DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)(ii + p * 4 * R) * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
 #pragma unroll
@@ -1103,7 +818,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
         }
       }
       for (; ii < rch; ii += 4 * R) {
-        const dbl2 a0 = (dbg & DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)ii * ldw);
+        const dbl2 a0 = DBG_ON(dbg, DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)ii * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
           const double v0 = lds[nu * RCH + ii];
@@ -1115,7 +830,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
     __syncthreads();
   }
   // reduce over the R row groups of the wavefront, then over the 4 wavefronts through LDS
-  if (!(dbg & DBG_NORED)) {
+  if (!DBG_ON(dbg, DBG_NORED)) {
     double a0[MU], a1[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
@@ -1138,7 +853,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   }
   __syncthreads();
   if (t.nparts == 1) {
-    if (wave == 0 && sub == 0 && colok && !(dbg & DBG_NOSTORE)) {
+    if (wave == 0 && sub == 0 && colok && !DBG_ON(dbg, DBG_NOSTORE)) {
       if constexpr (!Z) {
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu)
@@ -1241,7 +956,7 @@ template <int MU, bool HAS_BLOCK, int FP, bool Z>
 __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const unsigned long long tk0 = (dbg & DBG_TIMELINE) ? wall_clock64() : 0ull;
+  const unsigned long long tk0 = DBG_ON(dbg, DBG_TIMELINE) ? wall_clock64() : 0ull;
   const int G = gridDim.x;
   if (HAS_BLOCK) {
     for (int bt = blockIdx.x; bt < nblock; bt += G) {
@@ -1251,7 +966,7 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
       double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
       if constexpr (MU >= 4) {
-        if (dbg & DBG_NOMFMA) fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+        if (DBG_ON(dbg, DBG_NOMFMA)) fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
         else fwd_block_tile_mfma<MU, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0);
       } else fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
       __syncthreads(); // the staging area is reused by the next tile
@@ -1430,25 +1145,20 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
     const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
     has_src[k]    = hf.gptr[hf.goff[k] + hh] > hf.gptr[hf.goff[k]];
   }
-  // supernodes a single wavefront can take inside a chain of tiles (chain kernels): narrow, short, and every entry of the
-  // front fed by at most 4 update-vector entries; their gather lists are stored once more as 4 fixed slots per entry
-  parent = hf.sym.parent;
-  chainable.assign(nblk, 0);
+  // narrow supernodes whose entries are fed by at most 4 update-vector entries each: their gather lists are stored once more as 4
+  // fixed slots per entry of the front (one 16-byte index load per entry instead of a walk through gptr / gsrc)
   s4_off.assign(nblk, -1);
   {
     int64_t tot = 0;
     for (idx_t k = 0; k < nblk; ++k) {
       const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
-      if (ldw[k] * sc > NARROW) continue;
+      if (ldw[k] * sc > NARROW || !has_src[k]) continue;
       const int64_t *gp = hf.gptr.data() + hf.goff[k];
       bool           ok = true;
       for (int64_t i = 0; i < hh && ok; ++i) ok = gp[i + 1] - gp[i] <= 4;
       if (!ok) continue;
-      chainable[k] = hh <= CHAIN_MAX_H;
-      if (has_src[k]) {
-        s4_off[k] = tot;
-        tot += 4 * hh;
-      }
+      s4_off[k] = tot;
+      tot += 4 * hh;
     }
     HH_CHECK(tot < (int64_t)2147483647 * 4, "fixed-slot gather lists exceed 32-bit offsets");
     std::vector<int> s4((size_t)tot, -1);
@@ -1466,12 +1176,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 
 void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s)
 {
-  drop_graphs();
   mu_cap = 0; // new factors: the workspaces are re-sized on the next solve
-  {
-    const char *e = getenv("HPDDM_HIP_GRAPH");
-    use_graph     = e && atoi(e) != 0; // off by default: replay measured the same as eager launches (dependent kernel boundaries cost the same either way)
-  }
   factors = fs;
   voff.assign(fs.size(), 0);
   ntot = utot = 0;
@@ -1495,7 +1200,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   // developer knobs of the plan (defaults = what measured best on the bench workloads)
   auto envi             = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
   dbg                   = envi("HPDDM_HIP_DBG", 0);
-  if (dbg & DBG_TIMELINE) {
+  if (DBG_ON(dbg, DBG_TIMELINE)) {
     static unsigned long long *hostbuf = nullptr;
     const unsigned int         cap     = 1u << 20;
     if (!hostbuf) {
@@ -1507,92 +1212,15 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     const unsigned int zero = 0;
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cnt), &zero, sizeof(zero)));
   }
-  persist               = envi("HPDDM_HIP_PERSIST", 0);      // > 0: persistent grids of that many workgroups per CU
-  mu16                  = envi("HPDDM_HIP_MU16", 1) != 0;           // complex scalars: 8 right-hand sides = 16 real columns in ONE sweep over L
-  narrow_wave_wg        = envi("HPDDM_HIP_NARROW_WAVE_WG", 0) != 0; // launches of wave tiles only: single-wavefront workgroups (measured: same time)
-  persist_narrow        = envi("HPDDM_HIP_PERSIST_NARROW", 0); // ... and, if > 0, at most this many of them per wavefront slot (each walks several tiles)
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
-  const int  fwd_want    = envi("HPDDM_HIP_FWD_WANT", 0) / std::max(1, groups); // wide panels, forward: levels with fewer workgroups than this get shorter tiles
   const int  bwd_small   = envi("HPDDM_HIP_BWD_SMALL", 4096);   // narrow panels, backward: one wavefront takes the whole supernode up to this many panel entries (scalars), a workgroup beyond
-  const int  fwd_target  = envi("HPDDM_HIP_FWD_TARGET", 0);   // wide panels, forward: equal-area tiles aiming at this many workgroups per level (0: fixed heights)
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
-  const bool pregather   = envi("HPDDM_HIP_PREGATHER", 1) != 0;
-  const int  sort_mode   = envi("HPDDM_HIP_SORT", 1);         // narrow tiles inside a launch: 0 memory order, 1 largest first, 2 by size class
-  const bool use_chains  = envi("HPDDM_HIP_CHAINS", 0) != 0 && !cplx;  // bottom subtrees walked by one wavefront each (chain kernels): opt-in, measured 2.6-3.0 TB/s against 3.5 of the level launches at 65^3
-  const long long chain_cap_env = envi("HPDDM_HIP_CHAIN_KB", 0) * 1024LL; // largest chain in bytes (0: from the size of the problem)
-  // ---- which supernodes go into chains: maximal subtrees made of chainable supernodes, at most chain_cap bytes each ----
-  std::vector<std::vector<char>>  in_chain(fs.size());
-  std::vector<std::vector<idx_t>> chain_root(fs.size());
-  std::vector<int>                desc_base(fs.size(), 0);
-  std::vector<Tile> chain_tiles[2];
-  std::vector<int>  cptr[2] = {{0}, {0}};
-  struct ChainRef { int f; idx_t root; long long bytes; };
-  std::vector<ChainRef> chain_list;
-  chain_bytes = 0;
-  if (use_chains) {
-    std::vector<std::vector<long long>> sub_bytes(fs.size());
-    std::vector<std::vector<char>>      sub_ok(fs.size());
-    long long                           total_ok = 0;
-    for (size_t f = 0; f < fs.size(); ++f) {
-      const DeviceFactor &D = *fs[f];
-      sub_bytes[f].assign(D.nblk, 0);
-      sub_ok[f].assign(D.nblk, 1);
-      in_chain[f].assign(D.nblk, 0);
-      chain_root[f].assign(D.nblk, -1);
-      for (idx_t k = 0; k < D.nblk; ++k) { // children come before their parent
-        const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
-        sub_bytes[f][k] += (w * (w + 1) / 2 + nb * w) * 8;
-        if (!D.chainable[k]) sub_ok[f][k] = 0;
-        if (sub_ok[f][k]) total_ok += (w * (w + 1) / 2 + nb * w) * 8;
-        const idx_t p = D.parent[k];
-        if (p >= 0) {
-          HH_CHECK(p > k, "assembly tree: parent before child");
-          sub_bytes[f][p] += sub_bytes[f][k];
-          if (!sub_ok[f][k]) sub_ok[f][p] = 0;
-        }
-      }
-    }
-    // large enough to amortise the per-tile round trips, small enough that the chains of the machine (8192 wavefront slots)
-    // finish together: a few rounds of chains per slot
-    const long long chain_cap = chain_cap_env > 0 ? chain_cap_env : std::max<long long>(24 << 10, std::min<long long>(256 << 10, total_ok / (4 * 8192)));
-    for (size_t f = 0; f < fs.size(); ++f) {
-      const DeviceFactor &D = *fs[f];
-      for (idx_t k = D.nblk - 1; k >= 0; --k) { // parents first: a supernode joins the chain of its parent, or roots its own
-        const idx_t p    = D.parent[k];
-        const bool  fits = sub_ok[f][k] && sub_bytes[f][k] <= chain_cap;
-        if (p >= 0 && in_chain[f][p]) {
-          in_chain[f][k]  = 1;
-          chain_root[f][k] = chain_root[f][p];
-        } else if (fits) {
-          in_chain[f][k]  = 1;
-          chain_root[f][k] = k;
-          chain_list.push_back(ChainRef{(int)f, k, sub_bytes[f][k]});
-        }
-      }
-    }
-    // longest chains first (workgroups are dispatched in order)
-    std::stable_sort(chain_list.begin(), chain_list.end(), [](const ChainRef &a, const ChainRef &b2) { return a.bytes > b2.bytes; });
-    for (const ChainRef &c : chain_list) chain_bytes += (double)c.bytes;
-  }
   lev_bytes.assign(nlev, 0.0);
-  std::vector<long long> wide_cost(nlev, 0);                  // entries of the wide panels per level
-  std::vector<long long> wide_rows(nlev, 0);                  // ... and their rows in units of 16 (the shortest forward tile)
   auto fwd_tile_rows = [](int wc) { return wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); }; // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
-    const int           cs = D.cplx ? 2 : 1;
-    for (idx_t k = 0; k < D.nblk; ++k)
-      if (D.ldw[k] * cs > NARROW) {
-        const long long w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb = D.row_ptr[k + 1] - D.row_ptr[k];
-        wide_cost[D.height[k]] += w * (w + 1) / 2 + nb * w;
-        wide_rows[D.height[k]] += (w + nb + 15) / 16;
-      }
-  }
-  for (size_t f = 0; f < fs.size(); ++f) {
-    const DeviceFactor &D = *fs[f];
-    desc_base[f]          = (int)descs.size();
     for (idx_t k = 0; k < D.nblk; ++k) {
       SnDesc d;
       const int cs = D.cplx ? 2 : 1; // doubles per scalar: offsets and leading dimensions of the factor count scalars
@@ -1621,7 +1249,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.src4 = D.s4_off[k] >= 0 ? D.src4.p + D.s4_off[k] : nullptr;
       descs.back().src4 = d.src4;
       const int h = d.w + d.nb, lev = D.height[k];
-      if (use_chains && in_chain[f][k]) continue; // taken by a chain kernel (tiles made below)
       lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
         HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
@@ -1633,29 +1260,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
-        // ... and shorter on a level whose wide panels field fewer than fwd_want workgroups that way (the top of a small tree):
-        // down to 16 rows, the height of one MFMA fragment
-        int trb = fwd_tile_rows(d.wc);
-        while (trb > 16 && fwd_want > 0 && wide_rows[lev] * 16 / trb < fwd_want) trb >>= 1;
-        if (fwd_target > 0) {
-          // tiles of equal AREA: the rows of the triangular top block are short, so the tiles there are taller (at most
-          // 64 rows); the area follows the level's total so that a level of few, huge supernodes still fields fwd_target
-          // workgroups
-          const long long area = std::max<long long>(8LL * d.w, std::min<long long>((long long)trb * d.w, wide_cost[lev] / fwd_target));
-          for (int r0 = 0; r0 < h;) {
-            long long acc = 0;
-            int       nr  = 0;
-            while (nr < 64 && r0 + nr < h && (acc < area || (nr & 7))) {
-              acc += std::min(r0 + nr + 1, d.w);
-              ++nr;
-            }
-            tl[FWD_BLOCK][lev].push_back(Tile{id, r0, nr, 0, 1, 0, 0, 0});
-            r0 += nr;
-          }
-        } else
-          for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
+        const int trb = fwd_tile_rows(d.wc);
+        for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
         for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h}); // c0: first of 128 doubles of every row; rows above scalar column c0 / cs hold zeros there
-        if (pregather && d.has_src)
+        if (d.has_src) // its right-hand side b_J - (children's updates) is formed once, ahead of the level (sptrsv_gather_kernel)
           for (int c0 = 0; c0 < d.w; c0 += WG_THREADS) gat[lev].push_back(Tile{id, c0, std::min(WG_THREADS, d.w - c0), 0, 1, 0, 0, 0});
       }
     }
@@ -1708,11 +1316,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
-      if (sort_mode == 1 || kd == FWD_BLOCK || kd == BWD_BLOCK) std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
-      else if (sort_mode == 2) { // narrow tiles: by size class only, memory order inside a class
-        auto cls = [&](const Tile &t) { int c = 0; for (long long v = cost(t); v > 1; v >>= 1) ++c; return c; };
-        std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cls(a) > cls(b2); });
-      }
+      std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the
@@ -1752,59 +1356,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     pperm.upload(pp, s);
     HIP_OK(hipStreamSynchronize(s));
   }
-  // ---- tiles of the chains: forward in dependency order (children first), backward parents first ----
-  nchains      = (int)chain_list.size();
-  chain_lds[0] = chain_lds[1] = 16;
-  if (nchains) {
-    std::vector<std::vector<std::vector<idx_t>>> members(fs.size()); // per factor, per root: supernodes in ascending order
-    std::vector<std::map<idx_t, int>>            slot(fs.size());
-    for (size_t f = 0; f < fs.size(); ++f) {
-      const DeviceFactor &D = *fs[f];
-      for (idx_t k = 0; k < D.nblk; ++k) {
-        if (!in_chain[f][k]) continue;
-        const idx_t r  = chain_root[f][k];
-        auto        it = slot[f].find(r);
-        if (it == slot[f].end()) {
-          it = slot[f].emplace(r, (int)members[f].size()).first;
-          members[f].emplace_back();
-        }
-        members[f][it->second].push_back(k);
-      }
-    }
-    for (const ChainRef &c : chain_list) {
-      const DeviceFactor       &D  = *fs[c.f];
-      const std::vector<idx_t> &mb = members[c.f][slot[c.f][c.root]];
-      // height by height inside the chain (forward: lowest first): a supernode and its children are then separated by whole
-      // groups of tiles, and the wavefront only has to wait for its own stores where the height changes (Tile::nparts = 1)
-      std::vector<idx_t> ord(mb);
-      std::stable_sort(ord.begin(), ord.end(), [&](idx_t a, idx_t b2) { return D.height[a] < D.height[b2]; });
-      int prev_h = -1;
-      for (idx_t k : ord) {
-        const int id = desc_base[c.f] + k, w = D.blk_ptr[k + 1] - D.blk_ptr[k], h = w + (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
-        const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
-        for (int r0 = 0; r0 < h; r0 += per) chain_tiles[0].push_back(Tile{id, r0, std::min(per, h - r0), r0 == 0 ? 1 : 0, (r0 == 0 && prev_h >= 0 && D.height[k] != prev_h) ? 1 : 0, 0, 0, 0});
-        prev_h       = D.height[k];
-        chain_lds[0] = std::max(chain_lds[0], w);
-        chain_lds[1] = std::max(chain_lds[1], h);
-      }
-      cptr[0].push_back((int)chain_tiles[0].size());
-      prev_h = -1;
-      for (auto it = ord.rbegin(); it != ord.rend(); ++it) {
-        const idx_t k  = *it;
-        const int   id = desc_base[c.f] + k, w = D.blk_ptr[k + 1] - D.blk_ptr[k], h = w + (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
-        chain_tiles[1].push_back(Tile{id, 0, D.ldw[k], 0, (prev_h >= 0 && D.height[k] != prev_h) ? 1 : 0, 0, 0, h});
-        prev_h = D.height[k];
-      }
-      cptr[1].push_back((int)chain_tiles[1].size());
-    }
-    for (int kd = 0; kd < 2; ++kd) {
-      chain_off[kd] = (long long)all.size();
-      all.insert(all.end(), chain_tiles[kd].begin(), chain_tiles[kd].end());
-      chain_ptr[kd].upload(cptr[kd], s);
-      chain_lds[kd] = (chain_lds[kd] + 15) / 16 * 16;
-    }
-    launches_per_solve += 2;
-  }
   sn.upload(descs, s);
   tiles.upload(all, s);
   {
@@ -1834,16 +1385,9 @@ void SolvePlan::mark(int tag, hipStream_t s)
 
 std::vector<double> SolvePlan::level_bytes(int) const { return lev_bytes; }
 
-void SolvePlan::drop_graphs()
-{
-  for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
-  graphs.clear();
-}
-
 void SolvePlan::reserve(int mu)
 {
   if (mu <= mu_cap) return;
-  drop_graphs(); // the workspaces move
   y.alloc((size_t)ntot * mu);
   xw.alloc((size_t)ntot * mu);
   bperm.alloc((size_t)ntot * mu);
@@ -1875,24 +1419,10 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_bwd_kernel<MU, false, FPB, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  // Launches made of wave tiles only (the bottom levels), optionally with ONE wavefront per workgroup (HPDDM_HIP_NARROW_WAVE_WG):
-  // the tile latencies have a heavy tail (median 7.8 us, p90 two to three times that: per-tile clocks of HPDDM_HIP_DBG=32) and a
-  // 4-wavefront workgroup holds its slot until its slowest tile is done (55-60 % of the wavefront slots busy on average) -- but
-  // single-wavefront workgroups, persistent grids and shorter chains all measured the same level times: these levels are bound
-  // by the bytes they pull (1.3-2 x their panel entries: descriptors, gather lists, line-granular vector accesses), DESIGN.md 4.1.
-  const int  narrow_wpb = P.narrow_wave_wg ? 1 : 4;
-  auto grid   = [&](int nb, int nw, int ld_dbl) {
-    if (nb == 0 && narrow_wpb == 1) return P.persist_narrow > 0 ? std::max(1, std::min(nw, 256 * 8 * P.persist_narrow)) : nw;
-    const int want = nb + (nw + 3) / 4;
-    if (P.persist <= 0) return want;
-    const int per_cu = std::max(1, std::min(P.persist, (int)((160 * 1024) / ((size_t)ld_dbl * sizeof(double)))));
-    return std::max(1, std::min(want, 256 * per_cu));
-  };
-  constexpr int NPC = MU >= 8 ? 2 : 4; // panel rows in flight per lane of the chain kernels
-  if constexpr (MU <= 8) if (P.nchains) {
-    hipLaunchKernelGGL((sptrsv_fwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[0] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[0], P.chain_ptr[0].p, P.nchains, b, P.y.p, P.U.p, mu_total, nu0, P.chain_lds[0]);
-    P.mark(5000, s);
-  }
+  // one workgroup per block tile, four wave tiles per workgroup.  (Single-wavefront workgroups, persistent grids and one
+  // wavefront per bottom subtree all measured the same level times or worse in rounds 1-2: the bottom levels are bound by the bytes
+  // they pull beside their panel entries)
+  auto grid = [&](int nb, int nw) { return nb + (nw + 3) / 4; };
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
     const int ng = P.gat_end[l] - P.gat_ptr[l];
@@ -1902,21 +1432,17 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     }
     const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
+    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
     if (nb || nw) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
     const int wr = nw ? wrows(SolvePlan::BWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z>), dim3(grid(nb, nw, ld)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw, ld)), dim3(64 * narrow_wpb), (size_t)ld * sizeof(double) / (narrow_wpb == 1 ? 4 : 1), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z>), dim3(grid(nb, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
     if (nb || nw) P.mark(3000 + l, s);
-  }
-  if constexpr (MU <= 8) if (P.nchains) {
-    hipLaunchKernelGGL((sptrsv_bwd_chain_kernel<MU, NPC>), dim3((unsigned)((P.nchains + 3) / 4)), dim3(WG_THREADS), (size_t)4 * P.chain_lds[1] * MU * sizeof(double), s, P.sn.p, P.tiles.p + P.chain_off[1], P.chain_ptr[1].p, P.nchains, P.y.p, P.xw.p, mu_total, nu0, P.chain_lds[1]);
-    P.mark(6000, s);
   }
 }
 
@@ -1934,7 +1460,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     int nu0 = 0;
     while (nu0 < mr) {
       const int left = mr - nu0;
-      if (left >= 16 && mu16) {
+      if (left >= 16) {
         solve_block<16, true>(*this, bperm.p, xw.p, mr, nu0, s);
         nu0 += 16;
       } else if (left >= 8) {
@@ -1980,23 +1506,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
       }
     }
   };
-  // The level launches only touch the plan's own buffers, so they can be captured once per mu into a hipGraph and replayed
-  // (HPDDM_HIP_GRAPH=1).  Measured on MI355X: 0.200 vs 0.193 ms per solve at 17^3 per subdomain, 2.76 vs 2.77 ms at 65^3 --
-  // the GPU-side cost of a dependent kernel boundary is the same, and the host is not the bottleneck -- so it stays opt-in.
-  if (use_graph) {
-    auto it = graphs.find(mu);
-    if (it == graphs.end()) {
-      hipGraph_t g = nullptr;
-      HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      sweeps();
-      HIP_OK(hipStreamEndCapture(s, &g));
-      hipGraphExec_t exec = nullptr;
-      HIP_OK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
-      HIP_OK(hipGraphDestroy(g));
-      it = graphs.emplace(mu, exec).first;
-    }
-    HIP_OK(hipGraphLaunch(it->second, s));
-  } else sweeps();
+  sweeps();
   hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, xout, mu);
   mark(4000, s);
   HIP_OK(hipGetLastError());

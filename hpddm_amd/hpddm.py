@@ -459,12 +459,12 @@ class Schwarz:
 
     def level_times(self, mu=1, reps=5):
         """developer aid: [(kind, level, microseconds, panel bytes)] of every launch of one batched SpTRSV; kind is one of
-        'perm_in', 'gather', 'fwd', 'bwd', 'perm_out', 'fwd_chain', 'bwd_chain'"""
+        'perm_in', 'gather', 'fwd', 'bwd', 'perm_out'"""
         out = np.zeros(3 * 512)
         n = self._lib.HpddmHipSchwarzLevelTimes(self._h, mu, reps, _dptr(out), out.size)
         if n < 0:
             raise HpddmHipError(self._lib.HpddmHipLastError().decode())
-        kinds = ("perm_in", "gather", "fwd", "bwd", "perm_out", "fwd_chain", "bwd_chain")
+        kinds = ("perm_in", "gather", "fwd", "bwd", "perm_out")
         return [(kinds[int(out[3 * i]) // 1000], int(out[3 * i]) % 1000, out[3 * i + 1], out[3 * i + 2]) for i in range(n)]
 
     def stats(self):
