@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer aid: numfact time of one subdomain (N^3 7-point Laplacian) for the three kinds, upper levels on the device or on the host.
-usage: time_numfact.py [N=65]"""
+usage: time_numfact.py [N=65] [kinds=chol,ldlt,lu] [where=device,host]"""
 import os
 import sys
 import time
@@ -19,10 +19,12 @@ n = A.shape[0]
 rng = np.random.default_rng(0)
 cases = {"chol": (sp.tril(A).tocsr(), True, True), "ldlt": (sp.tril(A - 0.05 * sp.identity(n)).tocsr(), True, False),
          "lu": ((A + 0.2 * sp.triu(A, 1) + sp.diags(rng.random(n))).tocsr(), False, False)}
-for where in ("device", "host"):
+kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else list(cases)
+for where in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("device", "host")):
     if where == "host":
         os.environ["HPDDM_HIP_HOST_FACTOR"] = "1"
-    for name, (M, sym, spd) in cases.items():
+    for name in kinds:
+        M, sym, spd = cases[name]
         M.sort_indices()
         S = hpddm.Subdomain()
         S.numfact(n, M.indptr, M.indices, M.data, sym=sym, spd=spd)   # analysis + first factorisation
