@@ -67,11 +67,9 @@ struct DeviceLevels {
   virtual ~DeviceLevels() { }
   virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t max_h, idx_t max_w) = 0;
   virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child
-  // front k: panelA = its panel with the original entries assembled (h x ldw; LU: panelG = the U12 entries, transposed, same
-  // shape, else nullptr); rel[c][i] = position of row i of child c
-  virtual void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
-  // the same with the original entries of the front as a list (position row * ldw + column inside the panel, value): the panel is
-  // zeroed on the device and the few entries scattered into it, instead of a dense zero-filled copy travelling over PCIe
+  // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +
+  // column inside the panel, value; LU: posG / valG = the U12 entries, transposed): the panel is zeroed on the device and the few
+  // entries scattered into it
   virtual void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
   virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
 };

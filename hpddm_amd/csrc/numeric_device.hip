@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
       }
 }
 
-// The same product on larger tiles (opt-in, HPDDM_HIP_GEMM=128; NOT yet measured on the device): TM x TN per workgroup (128 x 128,
+// The same product on larger tiles (every product with K >= 64 and a side of 128 or more): TM x TN per workgroup (128 x 128,
 // or 128 x 64 for the 64-column panels of the left-looking factorisation), every wavefront a (TM/2) x (TN/2) block of MFMA
 // fragments, the next K-step of 16 on its way from memory into registers while the current one is multiplied out of LDS (two LDS
 // buffers, one barrier per step).  Why: k_gemm64 leaves the f64 MFMA pipe idle most of the time (2 barriers and 16 dependent
@@ -418,8 +418,7 @@ static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double al
 static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false)
 {
   if (M <= 0 || N <= 0) return;
-  static const int big = [] { const char *e = getenv("HPDDM_HIP_GEMM"); return e ? atoi(e) : 64; }();
-  if (big == 128 && K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
+  if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
     if (M <= 64) gemm_big<64, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // row blocks of the blocked inverse
     else if (N > 64) gemm_big<128, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB);
     else gemm_big<128, 64>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // 64-column panels
@@ -522,15 +521,6 @@ struct DeviceLevelsImpl : public DeviceLevels {
     const long long ld = hf->ldw[k];
     scatter(D.F.p + hf->f_off[k], (size_t)h * ld, posF, valF);
     if (hf->kind == FACT_LU) scatter(D.G.p + hf->f_off[k], (size_t)h * ld, posG, valG);
-    factor_front(k, children, rel);
-  }
-  void process(idx_t k, const double *panelA, const double *panelG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
-  {
-    const Symbolic &s = hf->sym;
-    const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
-    const long long ld = hf->ldw[k];
-    HIP_OK(hipMemcpyAsync(D.F.p + hf->f_off[k], panelA, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
-    if (hf->kind == FACT_LU) HIP_OK(hipMemcpyAsync(D.G.p + hf->f_off[k], panelG, (size_t)h * ld * sizeof(double), hipMemcpyHostToDevice, st));
     factor_front(k, children, rel);
   }
   // the front k with its original entries in place: extend-add of the children, factorisation, solve-ready panels

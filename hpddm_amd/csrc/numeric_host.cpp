@@ -581,16 +581,17 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
         }
     }
     dev->begin(hf, cbd, max_h, max_w);
-    std::vector<double>           staging, stagingG, valF, valG;
+    std::vector<double>           valF, valG;
     std::vector<long long>        posF, posG;
-    static const bool             sparse_upload = [] { const char *e = getenv("HPDDM_HIP_SPARSE_UPLOAD"); return e && atoi(e) != 0; }();
+    // the original entries of a device-level front travel as a list (position, value) and are scattered into the panel zeroed in
+    // HBM: the zeros never cross PCIe (a dense host copy of every panel was 11 GB per 129^3 subdomain)
     std::vector<idx_t>           &rel = relidx_t[0];
     if ((idx_t)rel.size() != n) rel.assign(n, -1);
     std::vector<std::vector<int>> maps;
     for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q) {
       const idx_t  k  = hf.level_blk[q];
       const idx_t  c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
-      const idx_t  h = w + nb, ld = hf.ldw[k];
+      const idx_t  ld = hf.ldw[k];
       const idx_t *rows = s.rows.data() + s.row_ptr[k];
       for (idx_t ch : children[k])
         if (cb[ch]) { // computed on the host: move it to the device once
@@ -604,29 +605,15 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
         }
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
-      if (sparse_upload) { // opt-in (HPDDM_HIP_SPARSE_UPLOAD=1): the entries as a list, the zeros never leave the device
-        posF.clear(), valF.clear(), posG.clear(), valG.clear();
-        for (idx_t c = c0; c < c0 + w; ++c) {
-          for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) posF.push_back((long long)rel[P.lrow[p]] * ld + (c - c0)), valF.push_back(P.lval[p]);
-          if (lu)
-            for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) {
-              const idx_t lc = rel[P.ucol[p]];
-              if (lc < w) posF.push_back((long long)(c - c0) * ld + lc), valF.push_back(P.uval[p]);
-              else posG.push_back((long long)lc * ld + (c - c0)), valG.push_back(P.uval[p]);
-            }
-        }
-      } else {
-        staging.assign((size_t)h * ld, 0.0);
-        if (lu) stagingG.assign((size_t)h * ld, 0.0);
-        for (idx_t c = c0; c < c0 + w; ++c) {
-          for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) staging[(size_t)rel[P.lrow[p]] * ld + (c - c0)] += P.lval[p];
-          if (lu)
-            for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) { // entry (row c, col cc > c): U11 stays in the F top block, U12 goes transposed into G
-              const idx_t lc = rel[P.ucol[p]];
-              if (lc < w) staging[(size_t)(c - c0) * ld + lc] += P.uval[p];
-              else stagingG[(size_t)lc * ld + (c - c0)] += P.uval[p];
-            }
-        }
+      posF.clear(), valF.clear(), posG.clear(), valG.clear();
+      for (idx_t c = c0; c < c0 + w; ++c) {
+        for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) posF.push_back((long long)rel[P.lrow[p]] * ld + (c - c0)), valF.push_back(P.lval[p]);
+        if (lu)
+          for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) { // entry (row c, col cc > c): U11 stays in the F top block, U12 goes transposed into G
+            const idx_t lc = rel[P.ucol[p]];
+            if (lc < w) posF.push_back((long long)(c - c0) * ld + lc), valF.push_back(P.uval[p]);
+            else posG.push_back((long long)lc * ld + (c - c0)), valG.push_back(P.uval[p]);
+          }
       }
       maps.assign(children[k].size(), {});
       for (size_t c = 0; c < children[k].size(); ++c) {
@@ -635,8 +622,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       }
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
-      if (sparse_upload) dev->process_sparse(k, posF, valF, posG, valG, children[k], maps);
-      else dev->process(k, staging.data(), lu ? stagingG.data() : nullptr, children[k], maps);
+      dev->process_sparse(k, posF, valF, posG, valG, children[k], maps);
     }
     if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive (Cholesky) or collapsed
     if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
