@@ -116,6 +116,7 @@ struct SolvePlan {
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U, bperm;
+  DevBuf<double> b16, y16, x16, U16, partials16; // the 16-column MFMA engine (sptrsv16.hip): interleaved vectors, entry i of column nu at i * 16 + nu
   DevBuf<long long> pvoff; // per factor: vector offset
   DevBuf<int>       pn;    // per factor: n
   DevBuf<const int *> pperm; // per factor: perm array

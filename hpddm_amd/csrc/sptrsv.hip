@@ -15,41 +15,11 @@
 // #tiles) >> 256 workgroups.  No atomics on the data path: children hand their updates to the parent through
 // per-supernode update vectors (bitwise reproducible); the split-row tiles of the upper backward levels meet at an
 // arrival counter and the last one adds the partial sums in a fixed order.
-#include "device.hpp"
+#include "sptrsv_dev.hpp"
 #include <algorithm>
 
 namespace hpddm_hip {
 
-static constexpr int WG_THREADS  = 256;
-static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
-static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
-
-// Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
-// tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-typedef const double __attribute__((address_space(1))) *gcd_t;
-typedef const dbl2 __attribute__((address_space(1)))   *gcd2_t;
-typedef const int __attribute__((address_space(1)))    *gci_t;
-typedef int int4v __attribute__((ext_vector_type(4)));
-typedef const int4v __attribute__((address_space(1)))  *gci4_t;
-struct SnView {
-  gcd_t     F, G, dinv, FT;
-  gci_t     rows, gptr, gsrc;
-  gci4_t    src4;
-  long long voff, uoff;
-  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh;
-};
-__device__ static inline SnView view(const SnDesc &d)
-{
-  SnView v;
-  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT;
-  v.ldh = d.ldh;
-  v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
-  v.src4 = (gci4_t)d.src4;
-  v.voff = d.voff, v.uoff = d.uoff;
-  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
-  return v;
-}
 // developer aid, compiled in only with -DHPDDM_HIP_ABLATION (make ABLATION=1): the HPDDM_HIP_DBG mask then switches parts of the
 // sweep kernels off (WRONG results: 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand side staging, 8 skip
 // the panel loads, 16 VALU tiles instead of the MFMA ones -- exact) or records per-tile clocks (32, exact).  In the product build
@@ -113,69 +83,52 @@ __device__ static inline void reduce_across_pairs(double (&a0)[MU], double (&a1)
   }
 }
 
-// LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
-__device__ static inline void wave_lds_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// The same without draining the global loads in flight (the workgroup-scope fences above wait for vmcnt(0) as well): the LDS
-// instructions of one wavefront execute in program order, the counter wait makes the writes land, the barrier keeps the
-// compiler from moving LDS accesses across
-__device__ static inline void wave_lds_order()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // b (original numbering) -> permuted numbering of the factor, and back for x: two streaming passes over n that take the
 // perm[] indirection out of every tile of the sweeps
-__global__ void k_perm_in(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu)
+__global__ void k_perm_in(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu, int first)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int o = pm[i];
-    for (int nu = 0; nu < mu; ++nu) bp[v0 * mu + (long long)nu * n + i] = b[v0 * mu + (long long)nu * n + o];
+    for (int nu = first; nu < mu; ++nu) bp[v0 * mu + (long long)nu * n + i] = b[v0 * mu + (long long)nu * n + o];
   }
 }
-__global__ void k_perm_out(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu)
+__global__ void k_perm_out(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int o = pm[i];
-    for (int nu = 0; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + o] = xp[v0 * mu + (long long)nu * n + i];
+    for (int nu = first; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + o] = xp[v0 * mu + (long long)nu * n + i];
   }
 }
 
 // complex scalars: b / x are (re, im) pairs; inside, right-hand side k is the pair of real columns 2k (real parts), 2k + 1 (imaginary parts)
-__global__ void k_perm_in_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu)
+__global__ void k_perm_in_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ bp, int mu, int first)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int o = pm[i];
-    for (int k = 0; k < mu; ++k) {
+    for (int k = first; k < mu; ++k) {
       const dbl2 z = *reinterpret_cast<const dbl2 *>(b + 2 * (v0 * mu + (long long)k * n + o));
       bp[v0 * 2 * mu + (long long)(2 * k) * n + i]     = z.x;
       bp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i] = z.y;
     }
   }
 }
-__global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu)
+__global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int o = pm[i];
-    for (int k = 0; k < mu; ++k) {
+    for (int k = first; k < mu; ++k) {
       dbl2 z;
       z.x = xp[v0 * 2 * mu + (long long)(2 * k) * n + i];
       z.y = xp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i];
@@ -674,7 +627,6 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 // stands for the columns 4g + q, q = 0..3.  (The backward tiles stay on the VALU: there the lanes already own their
 // outputs, and on gfx950 the f64 MFMA rate equals the VALU rate, so a half-empty tile costs twice the arithmetic --
 // measured 5.6 vs 5.3 ms per sweep pair at mu = 8.)
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int MU, bool Z>
 __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
 {
@@ -1177,6 +1129,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s)
 {
   mu_cap = 0; // new factors: the workspaces are re-sized on the next solve
+  b16.release(), y16.release(), x16.release(), U16.release(), partials16.release();
   factors = fs;
   voff.assign(fs.size(), 0);
   ntot = utot = 0;
@@ -1404,21 +1357,11 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // per wavefront, of its widest wave-level tile -- so that the small levels keep many workgroups per CU even with 8
   // right-hand sides.  Forward, wide panels: 4 rows in flight per wavefront, 2 with 8 right-hand sides (accumulators
   // within 128 VGPRs); backward: 4.
-  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = (MU == 1 || MU >= 16) ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
+  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU == 1 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
   auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   auto wrows  = [&](int kd, int l) { return std::max(16, (P.lev_lds[kd][l] + 15) / 16 * 16); };
-  const int lds_cap = MU > 8 ? std::min(2 * P.lds_cap, 8128) : P.lds_cap; // 16 columns: the same number of staged panel columns as with 8
+  const int lds_cap = P.lds_cap;
   auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(lds_cap, (need + 63) / 64 * 64)); };
-  if constexpr (MU > 8) { // up to 4 x 256 rows x 16 columns of staged right-hand side per workgroup of wave tiles: beyond the default 64 KB
-    static bool once = false;
-    if (!once) {
-      once = true;
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_fwd_kernel<MU, true, FPF, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_fwd_kernel<MU, false, FPN, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_bwd_kernel<MU, true, FPB, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv_bwd_kernel<MU, false, FPB, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-  }
   // one workgroup per block tile, four wave tiles per workgroup.  (Single-wavefront workgroups, persistent grids and one
   // wavefront per bottom subtree all measured the same level times or worse in rounds 1-2: the bottom levels are bound by the bytes
   // they pull beside their panel entries)
@@ -1450,20 +1393,26 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
 {
   HH_CHECK(mu >= 1, "solve: mu must be >= 1");
   const dim3 gp((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)factors.size());
+  // 16 real columns at a time -- 8 complex right-hand sides, or 16 real ones -- go through the MFMA engine of sptrsv16.hip (its own
+  // interleaved workspaces, its own permutation passes); what is left takes the register-blocked VALU sweeps below
+  const int per16 = cplx ? 8 : 16;
+  int       done  = 0;
+  while (mu - done >= per16) {
+    solve_block16(*this, b, x, mu, done, s);
+    done += per16;
+  }
+  if (done == mu) return;
   if (cplx) {
     // mu complex right-hand sides = 2 mu real columns (planes) inside; register blocks of 8 / 4 / 2 real columns
     const int mr = 2 * mu;
     reserve(mr);
     mark(-1, s);
-    hipLaunchKernelGGL(k_perm_in_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+    hipLaunchKernelGGL(k_perm_in_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu, done);
     mark(0, s);
-    int nu0 = 0;
+    int nu0 = 2 * done;
     while (nu0 < mr) {
       const int left = mr - nu0;
-      if (left >= 16) {
-        solve_block<16, true>(*this, bperm.p, xw.p, mr, nu0, s);
-        nu0 += 16;
-      } else if (left >= 8) {
+      if (left >= 8) {
         solve_block<8, true>(*this, bperm.p, xw.p, mr, nu0, s);
         nu0 += 8;
       } else if (left >= 4) {
@@ -1474,7 +1423,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
         nu0 += 2;
       }
     }
-    hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu);
+    hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done);
     mark(4000, s);
     HIP_OK(hipGetLastError());
     return;
@@ -1482,32 +1431,27 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
   reserve(mu);
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
   mark(-1, s);
-  hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu);
+  hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu, done);
   mark(0, s);
   double *const bp = bperm.p; // private permuted copy: the gather pass updates it in place
-  double *const xout = x;
-  x                  = xw.p; // the sweeps stay in the permuted numbering; one pass scatters the result at the end
-  auto sweeps = [&]() {
-    int nu0 = 0;
-    while (nu0 < mu) {
-      const int left = mu - nu0;
-      if (left >= 8) {
-        solve_block<8, false>(*this, bp, x, mu, nu0, s);
-        nu0 += 8;
-      } else if (left >= 4) {
-        solve_block<4, false>(*this, bp, x, mu, nu0, s);
-        nu0 += 4;
-      } else if (left >= 2) {
-        solve_block<2, false>(*this, bp, x, mu, nu0, s);
-        nu0 += 2;
-      } else {
-        solve_block<1, false>(*this, bp, x, mu, nu0, s);
-        nu0 += 1;
-      }
+  int nu0 = done;
+  while (nu0 < mu) {
+    const int left = mu - nu0;
+    if (left >= 8) {
+      solve_block<8, false>(*this, bp, xw.p, mu, nu0, s);
+      nu0 += 8;
+    } else if (left >= 4) {
+      solve_block<4, false>(*this, bp, xw.p, mu, nu0, s);
+      nu0 += 4;
+    } else if (left >= 2) {
+      solve_block<2, false>(*this, bp, xw.p, mu, nu0, s);
+      nu0 += 2;
+    } else {
+      solve_block<1, false>(*this, bp, xw.p, mu, nu0, s);
+      nu0 += 1;
     }
-  };
-  sweeps();
-  hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, xout, mu);
+  }
+  hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done); // the sweeps stay in the permuted numbering; one pass scatters the result
   mark(4000, s);
   HIP_OK(hipGetLastError());
 }

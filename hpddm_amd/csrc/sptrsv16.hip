@@ -1,0 +1,576 @@
+// The sweeps on 16 real columns at once -- 8 complex right-hand sides, the block of BASELINE.json configs[4] (Block GMRES on 8
+// right-hand sides, K = std::complex<double>), or 16 real ones: every tile on the f64 MFMA pipe, vectors interleaved.
+//
+// Same solve as sptrsv.hip (Solver<K>::solve with n right-hand sides: include/HPDDM_MUMPS.hpp:304-317), same plan (levels, tiles,
+// split-row parts), same panels.  What differs, and why (profiles/r03_call2_helmholtz_mu8_sq_counters_before.csv: with 16 columns
+// the VALU tiles of sptrsv.hip keep 123-158 VGPRs = 3 wavefronts per SIMD, 68 % of their wave cycles parked on memory, and every
+// FMA pair pays one LDS read of the right-hand side):
+//   * v_mfma_f64_16x16x4_f64 with N = 16 is FULL: D[m][nu] += P[k][m] B[k][nu] -- the accumulators of 32 outputs x 16 columns are
+//     two MFMA fragments (16 VGPRs instead of 2 x 16 x 2 per lane), the right-hand side is read from LDS once per 4 panel rows
+//     (one 8-byte read per lane per 2 MFMAs), there is no cross-lane reduction at all.  On gfx950 the f64 MFMA rate equals the VALU
+//     rate, so this buys registers, issue slots and LDS bandwidth, not flops;
+//   * a lane loads the 16-byte pair (P[k][2i], P[k][2i+1]) and feeds two MFMAs (even / odd outputs); for complex panels the pair IS
+//     (a_r, a_i) of one column, so the two fragments are P_r^T v and P_i^T v and the complex combination is one lane swap;
+//   * forward on the transposed copy FT (outputs = panel rows), backward on G (outputs = panel columns): ONE routine
+//     (wave_mfma_steps) does both; the right-hand side of a supernode is staged 64 rows at a time (8 KB per wavefront);
+//   * inside the sweeps the vectors are INTERLEAVED, entry i of column nu at (i * 16 + nu): the 16 values of a row are one 128-byte
+//     line, so the gathers of the multifrontal solve (children's update vectors, x on the row lists) and every store are whole
+//     lines -- with 16 columns in the column-major layout each of them was 16 scattered 8-byte accesses.  Two passes
+//     (k_perm_in16 / k_perm_out16) go between the caller's layout and this one, folded into the permutation passes.
+#include "sptrsv_dev.hpp"
+#include <algorithm>
+
+namespace hpddm_hip {
+
+static constexpr int C16 = 16;  // real columns per sweep
+static constexpr int KC  = 64;  // right-hand-side rows staged per wavefront and pass (8 KB)
+static constexpr int RCB = 256; // ... per workgroup by the backward block tiles (32 KB)
+
+__device__ static inline v4f64 mfma16(double a, double b, v4f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// caller's layout <-> interleaved, permuted numbering.  Real: column c = right-hand side k0 + c; complex: columns 2k, 2k + 1 =
+// real / imaginary part of right-hand side k0 + k (the caller's vectors are (re, im) pairs)
+template <bool Z>
+__global__ void k_perm_in16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ b16, int mu, int k0)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)C16 * n; idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx >> 4), c = (int)(idx & 15), o = pm[i];
+    b16[(v0 + i) * C16 + c] = Z ? b[2 * (v0 * mu + (long long)(k0 + (c >> 1)) * n + o) + (c & 1)] : b[v0 * mu + (long long)(k0 + c) * n + o];
+  }
+}
+template <bool Z>
+__global__ void k_perm_out16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ x16, double *__restrict__ x, int mu, int k0)
+{
+  const int s = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  const int      *pm = perm[s];
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)C16 * n; idx += (long long)gridDim.x * blockDim.x) {
+    const int    i = (int)(idx >> 4), c = (int)(idx & 15), o = pm[i];
+    const double v = x16[(v0 + i) * C16 + c];
+    if (Z) x[2 * (v0 * mu + (long long)(k0 + (c >> 1)) * n + o) + (c & 1)] = v;
+    else x[v0 * mu + (long long)(k0 + c) * n + o] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// D[m][nu] += sum_k P[k][m] B[k][nu] for k in [k0, k1) (k0, k1 multiples of 4), m in NCH chunks of 32 outputs starting at P's
+// column 0, nu = 0..15.  P row-major with leading dimension ld (doubles); rows k >= K and columns m >= mlim are never touched;
+// chunk c only has entries for k in [klo[c], khi[c]) (the triangular top block).  B in LDS, row k at Bl[(k - kbase) * 16].
+// Fragments: aE[c][reg] = D[32 c + 2 p][nu], aO[c][reg] = D[32 c + 2 p + 1][nu] with p = (lane >> 4) + 4 reg, nu = lane & 15.
+// PF steps of panel rows (PF x NCH 16-byte loads per lane) are requested ahead of the step being multiplied.
+template <int NCH, int PF>
+__device__ static inline void wave_mfma_steps(gcd_t P, int ld, int K, int mlim, int k0, int k1, const int (&klo)[NCH], const int (&khi)[NCH], const double *Bl, int kbase, int lane, v4f64 (&aE)[NCH], v4f64 (&aO)[NCH])
+{
+  const int i = lane & 15, kq = lane >> 4;
+  dbl2      cur[PF][NCH], nxt[PF][NCH];
+  auto      fetch = [&](int ks, dbl2(&dst)[PF][NCH]) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int k = ks + 4 * u + kq;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bool ok = k < K && k >= klo[c] && k < khi[c] && ks + 4 * u < k1 && 32 * c + 2 * i < mlim;
+        dst[u][c]     = ok ? *(gcd2_t)(P + (long long)k * ld + 32 * c + 2 * i) : dbl2{0.0, 0.0};
+      }
+    }
+  };
+  fetch(k0, cur);
+  for (int ks = k0; ks < k1; ks += 4 * PF) {
+    const bool more = ks + 4 * PF < k1;
+    if (more) fetch(ks + 4 * PF, nxt);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int kk = ks + 4 * u;
+      if (kk < k1) { // wave-uniform
+        const double b = Bl[(kk - kbase + kq) * C16 + i];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (kk + 4 > klo[c] && kk < khi[c]) { // wave-uniform: this chunk has entries in these 4 rows
+            aE[c] = mfma16(cur[u][c].x, b, aE[c]);
+            aO[c] = mfma16(cur[u][c].y, b, aO[c]);
+          }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cur[u][c] = nxt[u][c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward: entry (col, nu) of the right-hand side of supernode d as the panels need it.  Real: f[col][nu] = b_J - (children's
+// updates).  Complex: R = [ f_r  f_i ; -f_i  f_r ], rows 2c / 2c + 1 = slots of the real / imaginary part of column c, columns =
+// the planes (nu even: real part of right-hand side nu / 2, odd: imaginary part).
+template <bool Z>
+__device__ static inline double rhs_entry16(const SnView &d, int col, int nu, const double *bb, const double *Ub, bool gather)
+{
+  const int c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
+  double    v = bb[(long long)(d.c0 + c) * C16 + plane];
+  if (gather)
+    for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)d.gsrc[p] * C16 + plane];
+  return (Z && (col & 1) && !(nu & 1)) ? -v : v;
+}
+
+// forward: result of panel row r, column nu: top rows give y, rows below hand their update (plus what the children handed to the
+// same entry of the front) to the parent
+__device__ static inline void store_row16(const SnView &d, int r, int nu, double v, double *yb, double *Ub)
+{
+  if (r < d.w) yb[(long long)(d.c0 + r) * C16 + nu] = v;
+  else {
+    if (d.has_src) {
+      if (d.src4) {
+        const int4v sr = d.src4[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (sr[j] >= 0) v += Ub[(long long)sr[j] * C16 + nu];
+      } else
+        for (int q = d.gptr[r]; q < d.gptr[r + 1]; ++q) v += Ub[(long long)d.gsrc[q] * C16 + nu];
+    }
+    Ub[(long long)(d.u_off + (r - d.w)) * C16 + nu] = v;
+  }
+}
+
+// rows [kc, kc + KC) of the forward right-hand side of a narrow supernode into the wavefront's LDS (Bl[(k - kc) * 16 + nu]); rows
+// past the panel's columns are zero (the MFMA steps run in fours)
+template <bool Z>
+__device__ static inline void stage_fwd16(const SnView &d, int kc, int lane, double *Bl, const double *bb, const double *Ub)
+{
+  const int nu = lane & 15, q = lane >> 4;
+  constexpr int CPC = Z ? KC / 2 : KC; // columns of the supernode per chunk
+  const int     cbase = Z ? kc >> 1 : kc;
+#pragma unroll 4
+  for (int pass = 0; pass < CPC / 4; ++pass) {
+    const int c = cbase + 4 * pass + q;
+    double    v = 0.0;
+    if (c < d.w) {
+      v = bb[(long long)(d.c0 + c) * C16 + nu];
+      if (d.has_src) {
+        if (d.src4) {
+          const int4v sr = d.src4[c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (sr[j] >= 0) v -= Ub[(long long)sr[j] * C16 + nu];
+        } else
+          for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)d.gsrc[p] * C16 + nu];
+      }
+    }
+    if constexpr (!Z) Bl[(c - cbase) * C16 + nu] = v;
+    else {
+      const double o = __shfl_xor(v, 1); // the other plane of the same right-hand side
+      Bl[(2 * (c - cbase)) * C16 + nu]     = v;
+      Bl[(2 * (c - cbase) + 1) * C16 + nu] = (nu & 1) ? o : -o;
+    }
+  }
+}
+
+// narrow panels, forward: one wavefront computes the output rows [t.r0, t.r0 + t.nr) (at most 128) through the transposed copy,
+// 64 rows (two chunks of 32 = four fragments, 32 accumulator registers) per pass over the right-hand side
+template <bool Z>
+__device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *bb, double *yb, double *Ub)
+{
+  constexpr int NCH = 2;
+  const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
+  const int nu = lane & 15, kq = lane >> 4;
+  const int rend = t.r0 + t.nr;
+  for (int r0 = t.r0; r0 < rend; r0 += 32 * NCH) {
+    const int   nr   = min(32 * NCH, rend - r0);
+    const gcd_t P    = d.FT + r0;
+    const int   mlim = min((nr + 1) & ~1, ldh - r0);
+    int         klo[NCH], khi[NCH], kmax = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int rl = min(r0 + 32 * c + 31, rend - 1); // last output row of the chunk: rows of the top block stop at their diagonal entry
+      klo[c]       = 0;
+      khi[c]       = 32 * c < nr ? (rl < w ? cs * (rl + 1) : wc) : 0;
+      kmax         = max(kmax, khi[c]);
+    }
+    v4f64 aE[NCH], aO[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int k4 = (kmax + 3) & ~3;
+    for (int kc = 0; kc < k4; kc += KC) {
+      stage_fwd16<Z>(d, kc, lane, Bl, bb, Ub);
+      wave_lds_order();
+      wave_mfma_steps<NCH, 2>(P, ldh, wc, mlim, kc, min(kc + KC, k4), klo, khi, Bl, kc, lane, aE, aO);
+      wave_lds_order(); // the reads of this chunk are done before the next one is staged
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = r0 + 32 * c + 2 * (kq + 4 * reg);
+        if (r < rend) store_row16(d, r, nu, aE[c][reg], yb, Ub);
+        if (r + 1 < rend) store_row16(d, r + 1, nu, aO[c][reg], yb, Ub);
+      }
+  }
+}
+
+// rows [kc, kc + cnt) of v = [ D^{-1} y_J ; -x_below ] into LDS (Bl[(k - kc) * 16 + nu]), `nt` threads working together (64: one
+// wavefront, 256: the workgroup), rows past the front are zero
+template <bool Z>
+__device__ static inline void stage_bwd16(const SnView &d, int kc, int cnt, int tid, int nt, double *Bl, const double *yb, const double *xb)
+{
+  const int nu = tid & 15, w = d.w, h = d.w + d.nb;
+  for (int kk = tid >> 4; kk < cnt; kk += nt >> 4) {
+    const int k = kc + kk;
+    double    v = 0.0;
+    if (k < w) {
+      v = yb[(long long)(d.c0 + k) * C16 + nu];
+      if (d.dinv) {
+        if constexpr (!Z) v *= d.dinv[d.c0 + k];
+        else { // complex 1 / D on the (real, imaginary) planes: (d_r + i d_i)(y_r + i y_i)
+          const double dr = d.dinv[2 * (d.c0 + k)], di = d.dinv[2 * (d.c0 + k) + 1], o = __shfl_xor(v, 1);
+          v = (nu & 1) ? dr * v + di * o : dr * v - di * o;
+        }
+      }
+    } else if (k < h) v = -xb[(long long)d.rows[k - w] * C16 + nu];
+    Bl[kk * C16 + nu] = v;
+  }
+}
+
+// backward: this lane's fragments -> x.  Real: outputs 2 p, 2 p + 1 of the chunk are columns of the supernode.  Complex: they are
+// P_r^T v and P_i^T v of column p; x_r = (P_r^T v)_r - (P_i^T v)_i, x_i = (P_r^T v)_i + (P_i^T v)_r, the other plane sits in lane ^ 1.
+template <bool Z>
+__device__ static inline double combine16(double e, double o, int nu)
+{
+  if constexpr (!Z) return e;
+  else {
+    const double t = __shfl_xor(o, 1);
+    return (nu & 1) ? e + t : e - t;
+  }
+}
+
+// narrow panels, backward: one wavefront takes the whole supernode (h <= WAVE_ROWS rows, at most 128 doubles per row), 64 doubles
+// of every row (two chunks of 32) per pass over v
+template <bool Z>
+__device__ static inline void bwd_wave_tile16(const SnView &d, int lane, double *Bl, const double *yb, double *xb)
+{
+  constexpr int NCH = 2;
+  const int w = d.w, ldw = d.ldw, h = d.w + d.nb, cs = d.cs;
+  const int nu = lane & 15, kq = lane >> 4;
+  const int h4 = (h + 3) & ~3;
+  for (int m0 = 0; m0 < ldw; m0 += 32 * NCH) {
+    int klo[NCH], khi[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      klo[c] = ((m0 + 32 * c) / cs) & ~3; // rows above the diagonal hold zeros in these columns
+      khi[c] = m0 + 32 * c < ldw ? h : 0;
+    }
+    v4f64 aE[NCH], aO[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int kc = klo[0] & ~(KC - 1); kc < h4; kc += KC) {
+      stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
+      wave_lds_order();
+      wave_mfma_steps<NCH, 2>(d.G + m0, ldw, h, ldw - m0, kc, min(kc + KC, h4), klo, khi, Bl, kc, lane, aE, aO);
+      wave_lds_order();
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = kq + 4 * reg;
+        if constexpr (Z) {
+          const int    col = (m0 >> 1) + 16 * c + p;
+          const double v   = combine16<true>(aE[c][reg], aO[c][reg], nu); // (every lane takes part in the swap)
+          if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = v;
+        } else {
+          const int col = m0 + 32 * c + 2 * p;
+          if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[c][reg];
+          if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[c][reg];
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// wide panels, forward: T(rows x 16) = F(rows x wc) f(wc x 16), one workgroup per tile of up to 64 rows.  The tile of sptrsv.hip
+// (fwd_block_tile_mfma: a lane loads 4 consecutive panel entries of its row and feeds 4 MFMAs whose k index stands for those
+// columns; 16-row groups, the wavefronts left over split the columns) on the interleaved vectors.
+template <bool Z>
+__device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
+{
+  const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
+  const int     rend = t.r0 + t.nr;
+  const int     nrg  = (t.nr + 15) >> 4;                 // 16-row groups of the tile: 1..4
+  const int     nrgp = nrg == 3 ? 4 : nrg, wpg = 4 / nrgp; // wavefronts per row group split the columns
+  const int     rg = wave % nrgp, ks = wave / nrgp;
+  const bool    busy = rg < nrg;
+  const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
+  const bool    rvalid = busy && row < rend;
+  double       *red  = lds + (lds_dbl - 64 * C16);       // [4 wavefronts][16 rows][16]
+  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~15; // columns of the right-hand side staged per chunk
+  const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
+  const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0;
+  const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
+  v4f64         acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < tile_lim; k0 += CW) {
+    __syncthreads();
+    const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
+    for (int idx = tid; idx < (kend - k0) * C16; idx += WG_THREADS) {
+      const int i = idx >> 4, nu = idx & 15, col = k0 + i;
+      lds[idx]    = col < wc ? rhs_entry16<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
+    }
+    __syncthreads();
+    const int     cend = min(kend, (my_lim + 15) & ~15), step = 16 * wpg;
+    constexpr int PF = 4;
+    dbl2          c01[PF], c23[PF], n01[PF], n23[PF];
+    auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
+      if (rvalid && cb < cend) {
+        x = *(gcd2_t)(Frow + cb);
+        y = *(gcd2_t)(Frow + cb + 2);
+      } else x = y = dbl2{0.0, 0.0};
+    };
+    int cb = k0 + 16 * ks;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(cb + u * step, c01[u], c23[u]);
+    for (; cb < cend; cb += PF * step) {
+      const bool more = cb + PF * step < cend;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(cb + (PF + u) * step, n01[u], n23[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (cb + u * step >= cend) break; // wave-uniform
+        dbl2      a01 = c01[u], a23 = c23[u];
+        const int c = cb + u * step + 4 * g; // this lane's first column
+        if (row < w) {                        // triangular top block: nothing right of the diagonal (entry = cs doubles)
+          const int last = cs * (row + 1) - 1;
+          a01.x = c <= last ? a01.x : 0.0;
+          a01.y = c + 1 <= last ? a01.y : 0.0;
+          a23.x = c + 2 <= last ? a23.x : 0.0;
+          a23.y = c + 3 <= last ? a23.y : 0.0;
+        }
+        const double *fl = lds + (c - k0) * C16 + j;
+        acc = mfma16(a01.x, fl[0], acc);
+        acc = mfma16(a01.y, fl[C16], acc);
+        acc = mfma16(a23.x, fl[2 * C16], acc);
+        acc = mfma16(a23.y, fl[3 * C16], acc);
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          c01[u] = n01[u];
+          c23[u] = n23[u];
+        }
+      }
+    }
+  }
+  // D[(lane >> 4) + 4 reg][lane & 15] -> per-wavefront partial sums, then one sum per entry over the column split, then the stores
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) red[(wave * 16 + g + 4 * reg) * C16 + j] = acc[reg];
+  __syncthreads();
+  for (int idx = tid; idx < t.nr * C16; idx += WG_THREADS) {
+    const int rl = idx >> 4, nu = idx & 15, rgx = rl >> 4;
+    double    v  = 0.0;
+    for (int k = 0; k < wpg; ++k) v += red[((rgx + nrgp * k) * 16 + (rl & 15)) * C16 + nu];
+    store_row16(d, t.r0 + rl, nu, v, yb, Ub);
+  }
+}
+
+// wide panels, backward: one workgroup per tile of 128 doubles of every row (64 complex columns), rows [t.rbeg, t.rend) -- one
+// of t.nparts parts of the supernode's rows on the upper levels.  Every wavefront owns 32 of the 128 doubles (two fragments), all
+// four read the staged rows of v from LDS (RCB rows at a time); no reduction across wavefronts.  Split rows: the parts publish their
+// sums (already combined for complex scalars) with write-through stores and meet at the arrival counter of sptrsv.hip; the last
+// one adds them in part order.
+template <bool Z>
+__device__ static inline void bwd_block_tile16(const SnView &d, const Tile &t, double *lds, const double *yb, double *xb, double *partials, int *arrivals, int max_parts)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
+  const int nu = lane & 15, kq = lane >> 4;
+  const int m0 = t.r0 + 32 * wave;            // first double of this wavefront's 32
+  const int klo[1] = {t.rbeg}, khi[1] = {m0 < t.r0 + t.nr ? t.rend : 0};
+  v4f64     aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
+  const int rend4 = t.rbeg + ((t.rend - t.rbeg + 3) & ~3);
+  for (int kc = t.rbeg; kc < rend4; kc += RCB) {
+    const int cnt = min(RCB, rend4 - kc);
+    __syncthreads(); // the previous chunk has been read
+    stage_bwd16<Z>(d, kc, cnt, tid, WG_THREADS, lds, yb, xb);
+    __syncthreads();
+    wave_mfma_steps<1, 8>(d.G + m0, ldw, min(h, t.rend), ldw - m0, kc, kc + cnt, klo, khi, lds, kc, lane, aE, aO);
+  }
+  // this lane: outputs 2 p, 2 p + 1 of the wavefront's 32, p = kq + 4 reg, column nu
+  if (t.nparts == 1) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int p = kq + 4 * reg;
+      if constexpr (Z) {
+        const int    col = (m0 >> 1) + p;
+        const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu);
+        if (col < w && m0 + 2 * p < t.r0 + t.nr) xb[(long long)(d.c0 + col) * C16 + nu] = v;
+      } else {
+        const int col = m0 + 2 * p;
+        if (col < w && col < t.r0 + t.nr) xb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg];
+        if (col + 1 < w && col + 1 < t.r0 + t.nr) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg];
+      }
+    }
+    return;
+  }
+  // ---- split rows: slot[part][local output][nu]; local output = complex column (0..63) or real column (0..127) of the tile ----
+  constexpr int NOUT = Z ? 64 : 128;
+  double *slot = partials + ((long long)t.group * max_parts) * (128 * C16);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int p = kq + 4 * reg;
+    if constexpr (Z) {
+      const double v = combine16<true>(aE[0][reg], aO[0][reg], nu);
+      __hip_atomic_store(slot + ((long long)t.part * NOUT + 16 * wave + p) * C16 + nu, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through (sc1)
+    } else {
+      __hip_atomic_store(slot + ((long long)t.part * NOUT + 32 * wave + 2 * p) * C16 + nu, aE[0][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slot + ((long long)t.part * NOUT + 32 * wave + 2 * p + 1) * C16 + nu, aO[0][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  volatile int *s_last = reinterpret_cast<volatile int *>(lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wavefront drains before the barrier
+  __syncthreads();                                   // (also: the last reads of the staged rows are done, lds[0] is free)
+  if (tid == 0) {
+    // the hand-over of sptrsv.hip (bwd_block_tile): 8-byte agent-scope atomics on both sides, drained stores, relaxed counter
+    const int old  = __hip_atomic_fetch_add(arrivals + t.group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (old == t.nparts - 1);
+    *s_last        = last;
+    if (last) __hip_atomic_store(arrivals + t.group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next solve
+  }
+  __syncthreads();
+  if (*s_last) {
+    const int c0t = Z ? t.r0 >> 1 : t.r0; // first column of the supernode in this tile
+    for (int idx = tid; idx < NOUT * C16; idx += WG_THREADS) {
+      const int lo = idx >> 4, c = c0t + lo;
+      if (c >= w || (Z ? 2 * lo : lo) >= t.nr) continue;
+      double s = 0.0;
+      for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * NOUT + lo) * C16 + (idx & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
+      xb[(long long)(d.c0 + c) * C16 + (idx & 15)] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// One launch per level and direction, as in sptrsv.hip: the workgroups take the block tiles (wide panels) with their four
+// wavefronts together, then their wavefronts take wave tiles (narrow panels) on their own.
+template <bool HAS_BLOCK, bool Z>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ U16, int lds_dbl, int pregathered)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int G = gridDim.x;
+  if (HAS_BLOCK) {
+    for (int bt = blockIdx.x; bt < nblock; bt += G) {
+      const Tile   t = btiles[bt];
+      const SnView d = view(sns[t.sn]);
+      fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0);
+      __syncthreads(); // the staging area is reused by the next tile
+    }
+  }
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double   *Bl = lds + wv * (KC * C16);
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
+    const Tile    t  = wtiles[tix];
+    const SnView  d  = view(sns[t.sn]);
+    const double *bb = b16 + d.voff * C16;
+    double       *yb = y16 + d.voff * C16, *Ub = U16 + d.uoff * C16;
+    fwd_wave_tile16<Z>(d, t, lane, Bl, bb, yb, Ub);
+  }
+}
+
+template <bool HAS_BLOCK, bool Z>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int G = gridDim.x;
+  if (HAS_BLOCK) {
+    for (int bt = blockIdx.x; bt < nblock; bt += G) {
+      const Tile   t = btiles[bt];
+      const SnView d = view(sns[t.sn]);
+      bwd_block_tile16<Z>(d, t, lds, y16 + d.voff * C16, x16 + d.voff * C16, partials, arrivals, max_parts);
+      __syncthreads();
+    }
+  }
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  double   *Bl = lds + wv * (KC * C16);
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
+    const Tile    t  = wtiles[tix];
+    const SnView  d  = view(sns[t.sn]);
+    const double *yb = y16 + d.voff * C16;
+    double       *xb = x16 + d.voff * C16;
+    bwd_wave_tile16<Z>(d, lane, Bl, yb, xb);
+  }
+}
+
+// right-hand side of the wide supernodes of a level, formed once (sptrsv_gather_kernel of sptrsv.hip): b_J <- b_J - (updates handed
+// up by the children), in place in the interleaved copy of b; 16 threads per column, whole lines
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_gather_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ gtiles, double *__restrict__ b16, const double *__restrict__ U16)
+{
+  const Tile    t  = gtiles[blockIdx.x];
+  const SnView  d  = view(sns[t.sn]);
+  double       *bb = b16 + d.voff * C16;
+  const double *Ub = U16 + d.uoff * C16;
+  const int     nu = threadIdx.x & 15;
+  for (int col = t.r0 + (int)(threadIdx.x >> 4); col < t.r0 + t.nr; col += WG_THREADS / 16) {
+    const int q0 = d.gptr[col], q1 = d.gptr[col + 1];
+    if (q0 == q1) continue;
+    double v = bb[(long long)(d.c0 + col) * C16 + nu];
+    for (int q = q0; q < q1; ++q) v -= Ub[(long long)d.gsrc[q] * C16 + nu];
+    bb[(long long)(d.c0 + col) * C16 + nu] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool Z>
+static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, hipStream_t s)
+{
+  auto       cnt = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
+  const dim3 gp((unsigned)std::min(2048, (P.nmax * C16 + 255) / 256), (unsigned)P.factors.size());
+  P.mark(-1, s);
+  hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, b, P.b16.p, mu, k0);
+  P.mark(0, s);
+  const int lds_wave = 4 * KC * C16; // doubles: the four wavefronts' staging areas
+  for (int l = 0; l < P.nlev; ++l) {
+    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), ng = P.gat_end[l] - P.gat_ptr[l];
+    if (ng) {
+      hipLaunchKernelGGL(sptrsv16_gather_kernel, dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], P.b16.p, P.U16.p);
+      P.mark(1000 + l, s);
+    }
+    // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
+    const int ld = nb ? std::max(lds_wave, std::min(8128, (P.lev_lds[SolvePlan::FWD_BLOCK][l] * C16 + 64 * C16 + 16 * C16 + 63) / 64 * 64)) : lds_wave;
+    const int grid = nb + (nw + 3) / 4;
+    if (nb) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
+    if (nb || nw) P.mark(2000 + l, s);
+  }
+  const int ldb = std::max(lds_wave, RCB * C16);
+  for (int l = P.nlev - 1; l >= 0; --l) {
+    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
+    const int grid = nb + (nw + 3) / 4;
+    if (nb) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    if (nb || nw) P.mark(3000 + l, s);
+  }
+  hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, P.x16.p, x, mu, k0);
+  P.mark(4000, s);
+}
+
+void solve_block16(SolvePlan &P, const double *b, double *x, int mu, int k0, hipStream_t s)
+{
+  if (!P.b16.p) { // workspaces of the 16-column engine, made on first use
+    P.b16.alloc((size_t)P.ntot * C16);
+    P.y16.alloc((size_t)P.ntot * C16);
+    P.x16.alloc((size_t)P.ntot * C16);
+    P.U16.alloc((size_t)std::max<long long>(P.utot, 1) * C16);
+    P.partials16.alloc((size_t)std::max(1, P.ngroups) * P.max_parts * 128 * C16);
+  }
+  if (P.cplx) sweeps16<true>(P, b, x, mu, k0, s);
+  else sweeps16<false>(P, b, x, mu, k0, s);
+  HIP_OK(hipGetLastError());
+}
+
+} // namespace hpddm_hip

@@ -1,0 +1,62 @@
+// Device-side helpers shared by the sweep kernels (sptrsv.hip: 1 / 2 / 4 / 8 real columns on the VALU with MFMA forward tiles;
+// sptrsv16.hip: 16 real columns = 8 complex right-hand sides, every tile on the f64 MFMA pipe, interleaved vectors).
+#pragma once
+#include "device.hpp"
+
+namespace hpddm_hip {
+
+static constexpr int WG_THREADS  = 256;
+static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
+static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
+
+// Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
+// tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef const double __attribute__((address_space(1))) *gcd_t;
+typedef const dbl2 __attribute__((address_space(1)))   *gcd2_t;
+typedef const int __attribute__((address_space(1)))    *gci_t;
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef const int4v __attribute__((address_space(1)))  *gci4_t;
+struct SnView {
+  gcd_t     F, G, dinv, FT;
+  gci_t     rows, gptr, gsrc;
+  gci4_t    src4;
+  long long voff, uoff;
+  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh;
+};
+__device__ static inline SnView view(const SnDesc &d)
+{
+  SnView v;
+  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT;
+  v.ldh = d.ldh;
+  v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
+  v.src4 = (gci4_t)d.src4;
+  v.voff = d.voff, v.uoff = d.uoff;
+  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
+  return v;
+}
+// LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
+__device__ static inline void wave_lds_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The same without draining the global loads in flight (the workgroup-scope fences above wait for vmcnt(0) as well): the LDS
+// instructions of one wavefront execute in program order, the counter wait makes the writes land, the barrier keeps the
+// compiler from moving LDS accesses across
+__device__ static inline void wave_lds_order()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// the 16-column engine (sptrsv16.hip): one forward + backward sweep of the plan on 16 real columns of b / x (original numbering,
+// batched layout of `mu` user right-hand sides per subdomain; complex factors: the 8 right-hand sides k0 .. k0 + 7, real factors:
+// the 16 right-hand sides k0 .. k0 + 15)
+void solve_block16(SolvePlan &P, const double *b, double *x, int mu, int k0, hipStream_t s);
+
+} // namespace hpddm_hip
