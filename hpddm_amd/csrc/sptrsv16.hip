@@ -61,27 +61,32 @@ __global__ void k_perm_out16(const long long *__restrict__ voff, const int *__re
 // column 0, nu = 0..15.  P row-major with leading dimension ld (doubles); rows k >= K and columns m >= mlim are never touched;
 // chunk c only has entries for k in [klo[c], khi[c]) (the triangular top block).  B in LDS, row k at Bl[(k - kbase) * 16].
 // Fragments: aE[c][reg] = D[32 c + 2 p][nu], aO[c][reg] = D[32 c + 2 p + 1][nu] with p = (lane >> 4) + 4 reg, nu = lane & 15.
-// PF steps of panel rows (PF x NCH 16-byte loads per lane) are requested ahead of the step being multiplied.
+// The panel rows go through a ring of PF steps (4 rows x NCH 16-byte loads per lane each) that stays full: a tile of a narrow
+// panel is a few KB, so its time is (dependent round trips) x (memory latency) -- wave_pipe_prime requests the first PF steps
+// BEFORE the right-hand side is staged (the panel does not depend on it), and every slot is requested again as soon as its
+// MFMAs are issued, across the staging chunks of the right-hand side (kfetch = last row the tile will ever want).
+template <int NCH>
+__device__ static inline void wave_pipe_fetch(dbl2 (&dst)[NCH], gcd_t P, int ld, int K, int mlim, int kk, int kfetch, const int (&klo)[NCH], const int (&khi)[NCH], int lane)
+{
+  const int i = lane & 15, k = kk + (lane >> 4);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const bool ok = kk < kfetch && k < K && k >= klo[c] && k < khi[c] && 32 * c + 2 * i < mlim;
+    dst[c]        = ok ? *(gcd2_t)(P + (long long)k * ld + 32 * c + 2 * i) : dbl2{0.0, 0.0};
+  }
+}
 template <int NCH, int PF>
-__device__ static inline void wave_mfma_steps(gcd_t P, int ld, int K, int mlim, int k0, int k1, const int (&klo)[NCH], const int (&khi)[NCH], const double *Bl, int kbase, int lane, v4f64 (&aE)[NCH], v4f64 (&aO)[NCH])
+__device__ static inline void wave_pipe_prime(dbl2 (&ring)[PF][NCH], gcd_t P, int ld, int K, int mlim, int k0, int kfetch, const int (&klo)[NCH], const int (&khi)[NCH], int lane)
+{
+#pragma unroll
+  for (int u = 0; u < PF; ++u) wave_pipe_fetch<NCH>(ring[u], P, ld, K, mlim, k0 + 4 * u, kfetch, klo, khi, lane);
+}
+// the steps [k0, k1) (a multiple of PF steps after the previous call, or the first call after the prime); B rows relative to kbase
+template <int NCH, int PF>
+__device__ static inline void wave_mfma_steps(dbl2 (&ring)[PF][NCH], gcd_t P, int ld, int K, int mlim, int k0, int k1, int kfetch, const int (&klo)[NCH], const int (&khi)[NCH], const double *Bl, int kbase, int lane, v4f64 (&aE)[NCH], v4f64 (&aO)[NCH])
 {
   const int i = lane & 15, kq = lane >> 4;
-  dbl2      cur[PF][NCH], nxt[PF][NCH];
-  auto      fetch = [&](int ks, dbl2(&dst)[PF][NCH]) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int k = ks + 4 * u + kq;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const bool ok = k < K && k >= klo[c] && k < khi[c] && ks + 4 * u < k1 && 32 * c + 2 * i < mlim;
-        dst[u][c]     = ok ? *(gcd2_t)(P + (long long)k * ld + 32 * c + 2 * i) : dbl2{0.0, 0.0};
-      }
-    }
-  };
-  fetch(k0, cur);
   for (int ks = k0; ks < k1; ks += 4 * PF) {
-    const bool more = ks + 4 * PF < k1;
-    if (more) fetch(ks + 4 * PF, nxt);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int kk = ks + 4 * u;
@@ -90,16 +95,11 @@ __device__ static inline void wave_mfma_steps(gcd_t P, int ld, int K, int mlim, 
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
           if (kk + 4 > klo[c] && kk < khi[c]) { // wave-uniform: this chunk has entries in these 4 rows
-            aE[c] = mfma16(cur[u][c].x, b, aE[c]);
-            aO[c] = mfma16(cur[u][c].y, b, aO[c]);
+            aE[c] = mfma16(ring[u][c].x, b, aE[c]);
+            aO[c] = mfma16(ring[u][c].y, b, aO[c]);
           }
+        wave_pipe_fetch<NCH>(ring[u], P, ld, K, mlim, kk + 4 * PF, kfetch, klo, khi, lane);
       }
-    }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) cur[u][c] = nxt[u][c];
     }
   }
 }
@@ -136,36 +136,113 @@ __device__ static inline void store_row16(const SnView &d, int r, int nu, double
     Ub[(long long)(d.u_off + (r - d.w)) * C16 + nu] = v;
   }
 }
+// the same for NR rows of one lane at once (r[k] < 0: nothing to store): the index loads of all the rows are requested together,
+// then all the update-vector entries they point to -- two round trips for the NR rows instead of two per row (same sums, same order)
+template <int NR>
+__device__ static inline void store_rows16(const SnView &d, const int (&r)[NR], int nu, double (&v)[NR], double *yb, double *Ub)
+{
+  if (d.has_src) {
+    if (d.src4) {
+      int4v sr[NR];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) sr[k] = r[k] >= d.w ? d.src4[r[k]] : int4v{-1, -1, -1, -1};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { // source j of every row (same order as the list walk)
+        double u[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) u[k] = sr[k][j] >= 0 ? Ub[(long long)sr[k][j] * C16 + nu] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+          if (sr[k][j] >= 0) v[k] += u[k];
+      }
+    } else {
+      int q0[NR], q1[NR], qmax = 0;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        q0[k] = r[k] >= d.w ? d.gptr[r[k]] : 0;
+        q1[k] = r[k] >= d.w ? d.gptr[r[k] + 1] : 0;
+        qmax  = max(qmax, q1[k] - q0[k]);
+      }
+      for (int j = 0; j < qmax; ++j) { // the lists of the NR rows walked side by side
+        int src[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) src[k] = q0[k] + j < q1[k] ? d.gsrc[q0[k] + j] : -1;
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+          if (src[k] >= 0) v[k] += Ub[(long long)src[k] * C16 + nu];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    if (r[k] >= 0) {
+      if (r[k] < d.w) yb[(long long)(d.c0 + r[k]) * C16 + nu] = v[k];
+      else Ub[(long long)(d.u_off + (r[k] - d.w)) * C16 + nu] = v[k];
+    }
+}
 
 // rows [kc, kc + KC) of the forward right-hand side of a narrow supernode into the wavefront's LDS (Bl[(k - kc) * 16 + nu]); rows
-// past the panel's columns are zero (the MFMA steps run in fours)
+// past the panel's columns are zero (the MFMA steps run in fours).  Every load that depends on the descriptor only is requested
+// for GP columns of the lane together, then the gather slots, then the update-vector entries.
 template <bool Z>
 __device__ static inline void stage_fwd16(const SnView &d, int kc, int lane, double *Bl, const double *bb, const double *Ub)
 {
   const int nu = lane & 15, q = lane >> 4;
   constexpr int CPC = Z ? KC / 2 : KC; // columns of the supernode per chunk
+  constexpr int GP  = 4;                // columns of a lane in flight together
   const int     cbase = Z ? kc >> 1 : kc;
-#pragma unroll 4
-  for (int pass = 0; pass < CPC / 4; ++pass) {
-    const int c = cbase + 4 * pass + q;
-    double    v = 0.0;
-    if (c < d.w) {
-      v = bb[(long long)(d.c0 + c) * C16 + nu];
-      if (d.has_src) {
-        if (d.src4) {
-          const int4v sr = d.src4[c];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (sr[j] >= 0) v -= Ub[(long long)sr[j] * C16 + nu];
-        } else
-          for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)d.gsrc[p] * C16 + nu];
+  for (int p0 = 0; p0 < CPC / 4; p0 += GP) {
+    if (cbase + 4 * p0 >= d.w) { // wave-uniform: nothing but zeros from here on
+#pragma unroll
+      for (int g = 0; g < GP; ++g) {
+        const int c = 4 * (p0 + g) + q;
+        if constexpr (!Z) Bl[c * C16 + nu] = 0.0;
+        else Bl[(2 * c) * C16 + nu] = Bl[(2 * c + 1) * C16 + nu] = 0.0;
+      }
+      continue;
+    }
+    double v[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      const int c = cbase + 4 * (p0 + g) + q;
+      v[g]        = c < d.w ? bb[(long long)(d.c0 + c) * C16 + nu] : 0.0;
+    }
+    if (d.has_src) {
+      if (d.src4) {
+        int4v sr[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+          const int c = cbase + 4 * (p0 + g) + q;
+          sr[g]       = c < d.w ? d.src4[c] : int4v{-1, -1, -1, -1};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { // same order as the list walk: source j of every column
+          double u[GP];
+#pragma unroll
+          for (int g = 0; g < GP; ++g) u[g] = sr[g][j] >= 0 ? Ub[(long long)sr[g][j] * C16 + nu] : 0.0;
+#pragma unroll
+          for (int g = 0; g < GP; ++g)
+            if (sr[g][j] >= 0) v[g] -= u[g];
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+          const int c = cbase + 4 * (p0 + g) + q;
+          if (c < d.w)
+            for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v[g] -= Ub[(long long)d.gsrc[p] * C16 + nu];
+        }
       }
     }
-    if constexpr (!Z) Bl[(c - cbase) * C16 + nu] = v;
-    else {
-      const double o = __shfl_xor(v, 1); // the other plane of the same right-hand side
-      Bl[(2 * (c - cbase)) * C16 + nu]     = v;
-      Bl[(2 * (c - cbase) + 1) * C16 + nu] = (nu & 1) ? o : -o;
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      const int c = 4 * (p0 + g) + q; // relative to the chunk
+      if constexpr (!Z) Bl[c * C16 + nu] = v[g];
+      else {
+        const double o = __shfl_xor(v[g], 1); // the other plane of the same right-hand side
+        Bl[(2 * c) * C16 + nu]     = v[g];
+        Bl[(2 * c + 1) * C16 + nu] = (nu & 1) ? o : -o;
+      }
     }
   }
 }
@@ -175,7 +252,7 @@ __device__ static inline void stage_fwd16(const SnView &d, int kc, int lane, dou
 template <bool Z>
 __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *bb, double *yb, double *Ub)
 {
-  constexpr int NCH = 2;
+  constexpr int NCH = 2, PF = 8;
   const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
   const int nu = lane & 15, kq = lane >> 4;
   const int rend = t.r0 + t.nr;
@@ -191,47 +268,80 @@ __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, in
       khi[c]       = 32 * c < nr ? (rl < w ? cs * (rl + 1) : wc) : 0;
       kmax         = max(kmax, khi[c]);
     }
+    const int k4 = (kmax + 3) & ~3;
+    dbl2      ring[PF][NCH];
+    wave_pipe_prime<NCH, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
     v4f64 aE[NCH], aO[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
-    const int k4 = (kmax + 3) & ~3;
     for (int kc = 0; kc < k4; kc += KC) {
-      stage_fwd16<Z>(d, kc, lane, Bl, bb, Ub);
-      wave_lds_order();
-      wave_mfma_steps<NCH, 2>(P, ldh, wc, mlim, kc, min(kc + KC, k4), klo, khi, Bl, kc, lane, aE, aO);
-      wave_lds_order(); // the reads of this chunk are done before the next one is staged
+      if (kc > 0 || r0 == t.r0 || k4 > KC) { // a supernode of at most KC panel columns is staged once for all the passes
+        stage_fwd16<Z>(d, kc, lane, Bl, bb, Ub);
+        wave_lds_order();
+      }
+      wave_mfma_steps<NCH, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
+      if (k4 > KC) wave_lds_order(); // the reads of this chunk are done before the next one is staged
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = r0 + 32 * c + 2 * (kq + 4 * reg);
-        if (r < rend) store_row16(d, r, nu, aE[c][reg], yb, Ub);
-        if (r + 1 < rend) store_row16(d, r + 1, nu, aO[c][reg], yb, Ub);
+      for (int eo = 0; eo < 2; ++eo) { // the four even rows of the lane, then the four odd ones: their gather chains together
+        int    rr[4];
+        double vv[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = r0 + 32 * c + 2 * (kq + 4 * reg) + eo;
+          rr[reg]     = r < rend ? r : -1;
+          vv[reg]     = eo ? aO[c][reg] : aE[c][reg];
+        }
+        if (32 * c < nr) store_rows16<4>(d, rr, nu, vv, yb, Ub); // wave-uniform
       }
   }
+  wave_lds_order(); // the staging area goes to the next tile
 }
 
 // rows [kc, kc + cnt) of v = [ D^{-1} y_J ; -x_below ] into LDS (Bl[(k - kc) * 16 + nu]), `nt` threads working together (64: one
-// wavefront, 256: the workgroup), rows past the front are zero
+// wavefront, 256: the workgroup), rows past the front are zero; GP rows of a thread in flight together (row list first, then x)
 template <bool Z>
 __device__ static inline void stage_bwd16(const SnView &d, int kc, int cnt, int tid, int nt, double *Bl, const double *yb, const double *xb)
 {
-  const int nu = tid & 15, w = d.w, h = d.w + d.nb;
-  for (int kk = tid >> 4; kk < cnt; kk += nt >> 4) {
-    const int k = kc + kk;
-    double    v = 0.0;
-    if (k < w) {
-      v = yb[(long long)(d.c0 + k) * C16 + nu];
-      if (d.dinv) {
-        if constexpr (!Z) v *= d.dinv[d.c0 + k];
-        else { // complex 1 / D on the (real, imaginary) planes: (d_r + i d_i)(y_r + i y_i)
-          const double dr = d.dinv[2 * (d.c0 + k)], di = d.dinv[2 * (d.c0 + k) + 1], o = __shfl_xor(v, 1);
-          v = (nu & 1) ? dr * v + di * o : dr * v - di * o;
+  const int nu = tid & 15, w = d.w, h = d.w + d.nb, rpp = nt >> 4; // rows per pass of the team
+  constexpr int GP = 8;
+  for (int k0 = tid >> 4; k0 < cnt; k0 += GP * rpp) {
+    int ri[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      const int k = kc + k0 + g * rpp;
+      ri[g]       = (k0 + g * rpp < cnt && k >= w && k < h) ? d.rows[k - w] : -1;
+    }
+    double v[GP];
+#pragma unroll
+    for (int g = 0; g < GP; ++g) {
+      const int k = kc + k0 + g * rpp;
+      v[g]        = 0.0;
+      if (k0 + g * rpp < cnt) {
+        if (k < w) v[g] = yb[(long long)(d.c0 + k) * C16 + nu];
+        else if (k < h) v[g] = -xb[(long long)ri[g] * C16 + nu];
+      }
+    }
+    if (d.dinv && kc + k0 < w) { // (some of) these rows belong to the diagonal block: 1 / D
+#pragma unroll
+      for (int g = 0; g < GP; ++g) {
+        const int k = kc + k0 + g * rpp;
+        if constexpr (!Z) {
+          if (k < w && k0 + g * rpp < cnt) v[g] *= d.dinv[d.c0 + k];
+        } else { // complex 1 / D on the (real, imaginary) planes: (d_r + i d_i)(y_r + i y_i); the 16 lanes of a row stay together
+          const double o = __shfl_xor(v[g], 1);
+          if (k < w && k0 + g * rpp < cnt) {
+            const double dr = d.dinv[2 * (d.c0 + k)], di = d.dinv[2 * (d.c0 + k) + 1];
+            v[g] = (nu & 1) ? dr * v[g] + di * o : dr * v[g] - di * o;
+          }
         }
       }
-    } else if (k < h) v = -xb[(long long)d.rows[k - w] * C16 + nu];
-    Bl[kk * C16 + nu] = v;
+    }
+#pragma unroll
+    for (int g = 0; g < GP; ++g)
+      if (k0 + g * rpp < cnt) Bl[(k0 + g * rpp) * C16 + nu] = v[g];
   }
 }
 
@@ -252,7 +362,7 @@ __device__ static inline double combine16(double e, double o, int nu)
 template <bool Z>
 __device__ static inline void bwd_wave_tile16(const SnView &d, int lane, double *Bl, const double *yb, double *xb)
 {
-  constexpr int NCH = 2;
+  constexpr int NCH = 2, PF = 8;
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb, cs = d.cs;
   const int nu = lane & 15, kq = lane >> 4;
   const int h4 = (h + 3) & ~3;
@@ -263,13 +373,16 @@ __device__ static inline void bwd_wave_tile16(const SnView &d, int lane, double 
       klo[c] = ((m0 + 32 * c) / cs) & ~3; // rows above the diagonal hold zeros in these columns
       khi[c] = m0 + 32 * c < ldw ? h : 0;
     }
+    const int kc0 = klo[0] & ~(KC - 1);
+    dbl2      ring[PF][NCH];
+    wave_pipe_prime<NCH, PF>(ring, d.G + m0, ldw, h, ldw - m0, kc0, h4, klo, khi, lane);
     v4f64 aE[NCH], aO[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int kc = klo[0] & ~(KC - 1); kc < h4; kc += KC) {
+    for (int kc = kc0; kc < h4; kc += KC) {
       stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
       wave_lds_order();
-      wave_mfma_steps<NCH, 2>(d.G + m0, ldw, h, ldw - m0, kc, min(kc + KC, h4), klo, khi, Bl, kc, lane, aE, aO);
+      wave_mfma_steps<NCH, PF>(ring, d.G + m0, ldw, h, ldw - m0, kc, min(kc + KC, h4), h4, klo, khi, Bl, kc, lane, aE, aO);
       wave_lds_order();
     }
 #pragma unroll
@@ -369,11 +482,19 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) red[(wave * 16 + g + 4 * reg) * C16 + j] = acc[reg];
   __syncthreads();
-  for (int idx = tid; idx < t.nr * C16; idx += WG_THREADS) {
-    const int rl = idx >> 4, nu = idx & 15, rgx = rl >> 4;
-    double    v  = 0.0;
-    for (int k = 0; k < wpg; ++k) v += red[((rgx + nrgp * k) * 16 + (rl & 15)) * C16 + nu];
-    store_row16(d, t.r0 + rl, nu, v, yb, Ub);
+  { // thread -> column nu of the rows (tid >> 4) + 16 k of the tile (at most 64 rows): the four rows' gather chains together
+    const int nu = tid & 15;
+    int       rr[4];
+    double    vv[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int rl = (tid >> 4) + 16 * k4, rgx = rl >> 4;
+      double    v  = 0.0;
+      for (int k = 0; k < wpg; ++k) v += red[((rgx + nrgp * k) * 16 + (rl & 15)) * C16 + nu];
+      rr[k4] = rl < t.nr ? t.r0 + rl : -1;
+      vv[k4] = v;
+    }
+    store_rows16<4>(d, rr, nu, vv, yb, Ub);
   }
 }
 
@@ -392,12 +513,15 @@ __device__ static inline void bwd_block_tile16(const SnView &d, const Tile &t, d
   const int klo[1] = {t.rbeg}, khi[1] = {m0 < t.r0 + t.nr ? t.rend : 0};
   v4f64     aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
   const int rend4 = t.rbeg + ((t.rend - t.rbeg + 3) & ~3);
+  constexpr int PF = 8;
+  dbl2          ring[PF][1];
+  wave_pipe_prime<1, PF>(ring, d.G + m0, ldw, min(h, t.rend), ldw - m0, t.rbeg, rend4, klo, khi, lane);
   for (int kc = t.rbeg; kc < rend4; kc += RCB) {
     const int cnt = min(RCB, rend4 - kc);
     __syncthreads(); // the previous chunk has been read
     stage_bwd16<Z>(d, kc, cnt, tid, WG_THREADS, lds, yb, xb);
     __syncthreads();
-    wave_mfma_steps<1, 8>(d.G + m0, ldw, min(h, t.rend), ldw - m0, kc, kc + cnt, klo, khi, lds, kc, lane, aE, aO);
+    wave_mfma_steps<1, PF>(ring, d.G + m0, ldw, min(h, t.rend), ldw - m0, kc, kc + cnt, rend4, klo, khi, lds, kc, lane, aE, aO);
   }
   // this lane: outputs 2 p, 2 p + 1 of the wavefront's 32, p = kq + 4 reg, column nu
   if (t.nparts == 1) {
@@ -507,21 +631,32 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *
 }
 
 // right-hand side of the wide supernodes of a level, formed once (sptrsv_gather_kernel of sptrsv.hip): b_J <- b_J - (updates handed
-// up by the children), in place in the interleaved copy of b; 16 threads per column, whole lines
+// up by the children), in place in the interleaved copy of b.  A tile of the plan is 256 columns; a workgroup takes 16 of them,
+// 16 threads (one line) per column: the lists are short, the level is bound by the number of dependent chains in flight.
 __global__ __launch_bounds__(WG_THREADS) void sptrsv16_gather_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ gtiles, double *__restrict__ b16, const double *__restrict__ U16)
 {
-  const Tile    t  = gtiles[blockIdx.x];
+  const Tile    t   = gtiles[blockIdx.x >> 4];
+  const int     col = t.r0 + 16 * (int)(blockIdx.x & 15) + (int)(threadIdx.x >> 4);
+  if (col >= t.r0 + t.nr) return;
   const SnView  d  = view(sns[t.sn]);
   double       *bb = b16 + d.voff * C16;
   const double *Ub = U16 + d.uoff * C16;
   const int     nu = threadIdx.x & 15;
-  for (int col = t.r0 + (int)(threadIdx.x >> 4); col < t.r0 + t.nr; col += WG_THREADS / 16) {
-    const int q0 = d.gptr[col], q1 = d.gptr[col + 1];
-    if (q0 == q1) continue;
-    double v = bb[(long long)(d.c0 + col) * C16 + nu];
-    for (int q = q0; q < q1; ++q) v -= Ub[(long long)d.gsrc[q] * C16 + nu];
-    bb[(long long)(d.c0 + col) * C16 + nu] = v;
+  const int     q0 = d.gptr[col], q1 = d.gptr[col + 1];
+  if (q0 == q1) return;
+  double v = bb[(long long)(d.c0 + col) * C16 + nu];
+  for (int q = q0; q < q1; q += 4) { // four sources in flight
+    int    src[4];
+    double u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src[j] = q + j < q1 ? d.gsrc[q + j] : -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = src[j] >= 0 ? Ub[(long long)src[j] * C16 + nu] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (src[j] >= 0) v -= u[j];
   }
+  bb[(long long)(d.c0 + col) * C16 + nu] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -537,7 +672,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
-      hipLaunchKernelGGL(sptrsv16_gather_kernel, dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], P.b16.p, P.U16.p);
+      hipLaunchKernelGGL(sptrsv16_gather_kernel, dim3(16 * ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], P.b16.p, P.U16.p);
       P.mark(1000 + l, s);
     }
     // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
