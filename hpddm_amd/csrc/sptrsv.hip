@@ -1264,12 +1264,19 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_ptr[kd].assign(nlev + 1, 0);
     lev_lds[kd].assign(nlev, 0);
   }
+  lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
   launches_per_solve = 2; // the two permutation passes
   for (int kd = 0; kd < 4; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
+      // narrow tiles one wavefront would walk as a chain of staging passes come first: the 16-column engine (sptrsv16.hip) gives
+      // each of them a whole workgroup ("team tiles"; the other sweeps do not care about the order inside a launch)
+      if (kd == FWD_WAVE || kd == BWD_WAVE) {
+        auto team = [&](const Tile &t) { return kd == FWD_WAVE ? (t.nr > 64 || descs[t.sn].wc > 64) : (t.rend - t.rbeg > 64); };
+        lev_team[kd == BWD_WAVE][l] = (int)(std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), team) - tl[kd][l].begin());
+      }
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the

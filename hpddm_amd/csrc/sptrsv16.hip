@@ -181,40 +181,29 @@ __device__ static inline void store_rows16(const SnView &d, const int (&r)[NR], 
     }
 }
 
-// rows [kc, kc + KC) of the forward right-hand side of a narrow supernode into the wavefront's LDS (Bl[(k - kc) * 16 + nu]); rows
-// past the panel's columns are zero (the MFMA steps run in fours).  Every load that depends on the descriptor only is requested
-// for GP columns of the lane together, then the gather slots, then the update-vector entries.
+// columns [cb0, cb0 + cnt) of the forward right-hand side of a narrow supernode into LDS, `nt` threads working together (64: one
+// wavefront, 256: the workgroup): real scalars row (c - cb0) of Bl, complex scalars rows 2 (c - cb0), 2 (c - cb0) + 1 (the R form);
+// columns past the supernode's are zero (the MFMA steps run in fours).  Every load that depends on the descriptor only is requested
+// for GP columns of the thread together, then the gather slots, then the update-vector entries.
 template <bool Z>
-__device__ static inline void stage_fwd16(const SnView &d, int kc, int lane, double *Bl, const double *bb, const double *Ub)
+__device__ static inline void stage_fwd16(const SnView &d, int cb0, int cnt, int tid, int nt, double *Bl, const double *bb, const double *Ub)
 {
-  const int nu = lane & 15, q = lane >> 4;
-  constexpr int CPC = Z ? KC / 2 : KC; // columns of the supernode per chunk
-  constexpr int GP  = 4;                // columns of a lane in flight together
-  const int     cbase = Z ? kc >> 1 : kc;
-#pragma unroll
-  for (int p0 = 0; p0 < CPC / 4; p0 += GP) {
-    if (cbase + 4 * p0 >= d.w) { // wave-uniform: nothing but zeros from here on
-#pragma unroll
-      for (int g = 0; g < GP; ++g) {
-        const int c = 4 * (p0 + g) + q;
-        if constexpr (!Z) Bl[c * C16 + nu] = 0.0;
-        else Bl[(2 * c) * C16 + nu] = Bl[(2 * c + 1) * C16 + nu] = 0.0;
-      }
-      continue;
-    }
+  const int nu = tid & 15, rpp = nt >> 4; // columns per pass of the team
+  constexpr int GP = 4;                   // columns of a thread in flight together
+  for (int q0 = tid >> 4; q0 < cnt; q0 += GP * rpp) {
     double v[GP];
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
-      const int c = cbase + 4 * (p0 + g) + q;
-      v[g]        = c < d.w ? bb[(long long)(d.c0 + c) * C16 + nu] : 0.0;
+      const int c = cb0 + q0 + g * rpp;
+      v[g]        = (q0 + g * rpp < cnt && c < d.w) ? bb[(long long)(d.c0 + c) * C16 + nu] : 0.0;
     }
-    if (d.has_src) {
+    if (d.has_src && cb0 + q0 - (tid >> 4) < d.w) { // (wave-uniform: some column of this pass belongs to the supernode)
       if (d.src4) {
         int4v sr[GP];
 #pragma unroll
         for (int g = 0; g < GP; ++g) {
-          const int c = cbase + 4 * (p0 + g) + q;
-          sr[g]       = c < d.w ? d.src4[c] : int4v{-1, -1, -1, -1};
+          const int c = cb0 + q0 + g * rpp;
+          sr[g]       = (q0 + g * rpp < cnt && c < d.w) ? d.src4[c] : int4v{-1, -1, -1, -1};
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { // same order as the list walk: source j of every column
@@ -228,20 +217,23 @@ __device__ static inline void stage_fwd16(const SnView &d, int kc, int lane, dou
       } else {
 #pragma unroll
         for (int g = 0; g < GP; ++g) {
-          const int c = cbase + 4 * (p0 + g) + q;
-          if (c < d.w)
+          const int c = cb0 + q0 + g * rpp;
+          if (q0 + g * rpp < cnt && c < d.w)
             for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v[g] -= Ub[(long long)d.gsrc[p] * C16 + nu];
         }
       }
     }
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
-      const int c = 4 * (p0 + g) + q; // relative to the chunk
-      if constexpr (!Z) Bl[c * C16 + nu] = v[g];
-      else {
-        const double o = __shfl_xor(v[g], 1); // the other plane of the same right-hand side
-        Bl[(2 * c) * C16 + nu]     = v[g];
-        Bl[(2 * c + 1) * C16 + nu] = (nu & 1) ? o : -o;
+      const int c = q0 + g * rpp; // relative to the staged range
+      if constexpr (!Z) {
+        if (c < cnt) Bl[c * C16 + nu] = v[g];
+      } else {
+        const double o = __shfl_xor(v[g], 1); // the other plane of the same right-hand side (the 16 lanes of a column stay together)
+        if (c < cnt) {
+          Bl[(2 * c) * C16 + nu]     = v[g];
+          Bl[(2 * c + 1) * C16 + nu] = (nu & 1) ? o : -o;
+        }
       }
     }
   }
@@ -276,7 +268,7 @@ __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, in
     for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
     for (int kc = 0; kc < k4; kc += KC) {
       if (kc > 0 || r0 == t.r0 || k4 > KC) { // a supernode of at most KC panel columns is staged once for all the passes
-        stage_fwd16<Z>(d, kc, lane, Bl, bb, Ub);
+        stage_fwd16<Z>(d, Z ? kc >> 1 : kc, Z ? KC / 2 : KC, lane, 64, Bl, bb, Ub);
         wave_lds_order();
       }
       wave_mfma_steps<NCH, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
@@ -298,6 +290,43 @@ __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, in
       }
   }
   wave_lds_order(); // the staging area goes to the next tile
+}
+
+// narrow panels, forward, the whole workgroup on one tile (tiles of more than 64 rows or of supernodes wider than one staging
+// pass): the right-hand side is staged ONCE by the 256 threads (at most 128 rows of R), every wavefront takes 32 of the output rows.
+// One wavefront alone walks such a tile as a chain of staging passes and 64-row passes -- a dozen dependent round trips where the
+// workgroup needs three; the levels just above the leaves are bound by exactly that.
+template <bool Z>
+__device__ static inline void fwd_team_tile16(const SnView &d, const Tile &t, double *lds, const double *bb, double *yb, double *Ub)
+{
+  constexpr int PF = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
+  const int nu = lane & 15, kq = lane >> 4;
+  const int rend = t.r0 + t.nr, r0 = t.r0 + 32 * wave, nr = max(0, min(32, rend - r0));
+  const int rl = min(r0 + 31, rend - 1);
+  const int klo[1] = {0}, khi[1] = {nr > 0 ? (rl < w ? cs * (rl + 1) : wc) : 0};
+  const int k4 = (khi[0] + 3) & ~3, kall = ((rend - 1 < w ? cs * rend : wc) + 3) & ~3; // this wavefront's rows of R, the tile's
+  const gcd_t P    = d.FT + r0;
+  const int   mlim = min((nr + 1) & ~1, ldh - r0);
+  dbl2        ring[PF][1];
+  wave_pipe_prime<1, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
+  stage_fwd16<Z>(d, 0, Z ? kall >> 1 : kall, tid, WG_THREADS, lds, bb, Ub);
+  __syncthreads();
+  v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
+  wave_mfma_steps<1, PF>(ring, P, ldh, wc, mlim, 0, k4, k4, klo, khi, lds, 0, lane, aE, aO);
+#pragma unroll
+  for (int eo = 0; eo < 2; ++eo) {
+    int    rr[4];
+    double vv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = r0 + 2 * (kq + 4 * reg) + eo;
+      rr[reg]     = r < rend ? r : -1;
+      vv[reg]     = eo ? aO[0][reg] : aE[0][reg];
+    }
+    if (nr > 0) store_rows16<4>(d, rr, nu, vv, yb, Ub); // wave-uniform
+  }
 }
 
 // rows [kc, kc + cnt) of v = [ D^{-1} y_J ; -x_below ] into LDS (Bl[(k - kc) * 16 + nu]), `nt` threads working together (64: one
@@ -581,21 +610,25 @@ __device__ static inline void bwd_block_tile16(const SnView &d, const Tile &t, d
 // One launch per level and direction, as in sptrsv.hip: the workgroups take the block tiles (wide panels) with their four
 // wavefronts together, then their wavefronts take wave tiles (narrow panels) on their own.
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ U16, int lds_dbl, int pregathered)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ U16, int lds_dbl, int pregathered)
 {
+  // workgroup tiles first: the block tiles of the wide panels, then the first nteam tiles of the narrow ones (team tiles); the
+  // other nwave tiles of the narrow panels go one per wavefront
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
   if (HAS_BLOCK) {
-    for (int bt = blockIdx.x; bt < nblock; bt += G) {
-      const Tile   t = btiles[bt];
+    for (int bt = blockIdx.x; bt < nblock + nteam; bt += G) {
+      const Tile   t = bt < nblock ? btiles[bt] : wtiles[bt - nblock];
       const SnView d = view(sns[t.sn]);
-      fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0);
+      if (bt < nblock) fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0);
+      else fwd_team_tile16<Z>(d, t, lds, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16);
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
+  wtiles += nteam;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
-  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
   for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
@@ -606,21 +639,24 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
 }
 
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
 {
+  // workgroup tiles: the block tiles of the wide panels and the first nteam narrow supernodes (those of more than one staging pass
+  // of v: the workgroup stages all their rows at once, every wavefront takes 32 doubles of every row -- the block tile as it is)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
   if (HAS_BLOCK) {
-    for (int bt = blockIdx.x; bt < nblock; bt += G) {
-      const Tile   t = btiles[bt];
+    for (int bt = blockIdx.x; bt < nblock + nteam; bt += G) {
+      const Tile   t = bt < nblock ? btiles[bt] : wtiles[bt - nblock];
       const SnView d = view(sns[t.sn]);
       bwd_block_tile16<Z>(d, t, lds, y16 + d.voff * C16, x16 + d.voff * C16, partials, arrivals, max_parts);
       __syncthreads();
     }
   }
+  wtiles += nteam;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
-  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
+  const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
   for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
@@ -677,17 +713,17 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     }
     // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
     const int ld = nb ? std::max(lds_wave, std::min(8128, (P.lev_lds[SolvePlan::FWD_BLOCK][l] * C16 + 64 * C16 + 16 * C16 + 63) / 64 * 64)) : lds_wave;
-    const int grid = nb + (nw + 3) / 4;
-    if (nb) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
+    const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
     if (nb || nw) P.mark(2000 + l, s);
   }
   const int ldb = std::max(lds_wave, RCB * C16);
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
-    const int grid = nb + (nw + 3) / 4;
-    if (nb) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    const int nt = P.lev_team[1][l], grid = nb + nt + (nw - nt + 3) / 4;
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nt, nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, P.x16.p, x, mu, k0);
