@@ -1172,6 +1172,16 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   lev_bytes.assign(nlev, 0.0);
   auto fwd_tile_rows = [](int wc) { return wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); }; // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
+  // ... and shorter on a level whose wide panels would field fewer than ~4 workgroups per CU that way (the top of a small tree: a
+  // tile there is a long chain of loads, the level is bound by the number of chains in flight): 16-row units of the wide panels per level
+  std::vector<long long> wide_rows16(nlev, 0);
+  for (size_t f = 0; f < fs.size(); ++f) {
+    const DeviceFactor &D = *fs[f];
+    const int           cs = D.cplx ? 2 : 1;
+    for (idx_t k = 0; k < D.nblk; ++k)
+      if (D.ldw[k] * cs > NARROW) wide_rows16[D.height[k]] += ((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k]) + 15) / 16;
+  }
+  const long long fwd_want = 1024 / std::max(1, groups);
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     for (idx_t k = 0; k < D.nblk; ++k) {
@@ -1213,7 +1223,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
-        const int trb = fwd_tile_rows(d.wc);
+        int trb = fwd_tile_rows(d.wc);
+        while (trb > 16 && wide_rows16[lev] * 16 / trb < fwd_want) trb >>= 1;
         for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
         for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h}); // c0: first of 128 doubles of every row; rows above scalar column c0 / cs hold zeros there
         if (d.has_src) // its right-hand side b_J - (children's updates) is formed once, ahead of the level (sptrsv_gather_kernel)
@@ -1274,7 +1285,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       // narrow tiles one wavefront would walk as a chain of staging passes come first: the 16-column engine (sptrsv16.hip) gives
       // each of them a whole workgroup ("team tiles"; the other sweeps do not care about the order inside a launch)
       if (kd == FWD_WAVE || kd == BWD_WAVE) {
-        auto team = [&](const Tile &t) { return kd == FWD_WAVE ? (t.nr > 64 || descs[t.sn].wc > 64) : (t.rend - t.rbeg > 64); };
+        auto team = [&](const Tile &t) { return kd == FWD_WAVE ? t.nr > 64 : (descs[t.sn].ldw > 64 && t.rend - t.rbeg > 64); }; // at least three of the four wavefronts get 32 outputs each
         lev_team[kd == BWD_WAVE][l] = (int)(std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), team) - tl[kd][l].begin());
       }
       lev_ptr[kd][l] = (int)all.size();

@@ -23,7 +23,7 @@
 namespace hpddm_hip {
 
 static constexpr int C16 = 16;  // real columns per sweep
-static constexpr int KC  = 64;  // right-hand-side rows staged per wavefront and pass (8 KB)
+static constexpr int KC  = 128; // right-hand-side rows staged per wavefront and pass (16 KB: every forward tile and every supernode of up to 128 rows in ONE pass; the registers hold the kernels to 2-3 workgroups per CU anyway)
 static constexpr int RCB = 256; // ... per workgroup by the backward block tiles (32 KB)
 
 __device__ static inline v4f64 mfma16(double a, double b, v4f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -449,11 +449,25 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
   const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
   const bool    rvalid = busy && row < rend;
   double       *red  = lds + (lds_dbl - 64 * C16);       // [4 wavefronts][16 rows][16]
-  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~15; // columns of the right-hand side staged per chunk
+  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~511; // columns of the right-hand side staged per chunk: whole rounds of the ring (PF blocks of 16 doubles, up to 4 wavefronts apart)
   const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
   const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0;
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
   v4f64         acc = {0.0, 0.0, 0.0, 0.0};
+  // this wavefront's column blocks (16 doubles each, `step` apart) go through a ring of PF blocks that stays full across the
+  // staging chunks of the right-hand side: the top of a small tree has fewer tiles than CUs, a tile there is a chain of loads
+  constexpr int PF = 8;
+  const int     step = 16 * wpg, cmy = (my_lim + 15) & ~15; // (the row group stops at its own last diagonal entry)
+  dbl2          r01[PF], r23[PF];
+  auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
+    if (rvalid && cb < cmy) {
+      x = *(gcd2_t)(Frow + cb);
+      y = *(gcd2_t)(Frow + cb + 2);
+    } else x = y = dbl2{0.0, 0.0};
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) fetch(16 * ks + u * step, r01[u], r23[u]);
+  int cb = 16 * ks; // next column block of this wavefront (slot 0 of the ring)
   for (int k0 = 0; k0 < tile_lim; k0 += CW) {
     __syncthreads();
     const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
@@ -462,49 +476,30 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
       lds[idx]    = col < wc ? rhs_entry16<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
     }
     __syncthreads();
-    const int     cend = min(kend, (my_lim + 15) & ~15), step = 16 * wpg;
-    constexpr int PF = 4;
-    dbl2          c01[PF], c23[PF], n01[PF], n23[PF];
-    auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
-      if (rvalid && cb < cend) {
-        x = *(gcd2_t)(Frow + cb);
-        y = *(gcd2_t)(Frow + cb + 2);
-      } else x = y = dbl2{0.0, 0.0};
-    };
-    int cb = k0 + 16 * ks;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) fetch(cb + u * step, c01[u], c23[u]);
-    for (; cb < cend; cb += PF * step) {
-      const bool more = cb + PF * step < cend;
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) fetch(cb + (PF + u) * step, n01[u], n23[u]);
-      }
+    const int cend = min(kend, cmy);
+    while (cb < cend) { // PF blocks per round; CW is a multiple of PF * step (16 * 4 * 8 = 512 at most), so the rounds never straddle two chunks
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        if (cb + u * step >= cend) break; // wave-uniform
-        dbl2      a01 = c01[u], a23 = c23[u];
-        const int c = cb + u * step + 4 * g; // this lane's first column
-        if (row < w) {                        // triangular top block: nothing right of the diagonal (entry = cs doubles)
-          const int last = cs * (row + 1) - 1;
-          a01.x = c <= last ? a01.x : 0.0;
-          a01.y = c + 1 <= last ? a01.y : 0.0;
-          a23.x = c + 2 <= last ? a23.x : 0.0;
-          a23.y = c + 3 <= last ? a23.y : 0.0;
-        }
-        const double *fl = lds + (c - k0) * C16 + j;
-        acc = mfma16(a01.x, fl[0], acc);
-        acc = mfma16(a01.y, fl[C16], acc);
-        acc = mfma16(a23.x, fl[2 * C16], acc);
-        acc = mfma16(a23.y, fl[3 * C16], acc);
-      }
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          c01[u] = n01[u];
-          c23[u] = n23[u];
+        const int cu = cb + u * step;
+        if (cu < cend) { // wave-uniform
+          dbl2      a01 = r01[u], a23 = r23[u];
+          const int c = cu + 4 * g; // this lane's first column
+          if (row < w) {             // triangular top block: nothing right of the diagonal (entry = cs doubles)
+            const int last = cs * (row + 1) - 1;
+            a01.x = c <= last ? a01.x : 0.0;
+            a01.y = c + 1 <= last ? a01.y : 0.0;
+            a23.x = c + 2 <= last ? a23.x : 0.0;
+            a23.y = c + 3 <= last ? a23.y : 0.0;
+          }
+          const double *fl = lds + (c - k0) * C16 + j;
+          acc = mfma16(a01.x, fl[0], acc);
+          acc = mfma16(a01.y, fl[C16], acc);
+          acc = mfma16(a23.x, fl[2 * C16], acc);
+          acc = mfma16(a23.y, fl[3 * C16], acc);
+          fetch(cu + PF * step, r01[u], r23[u]);
         }
       }
+      cb += PF * step;
     }
   }
   // D[(lane >> 4) + 4 reg][lane & 15] -> per-wavefront partial sums, then one sum per entry over the column split, then the stores
@@ -705,6 +700,13 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, b, P.b16.p, mu, k0);
   P.mark(0, s);
   const int lds_wave = 4 * KC * C16; // doubles: the four wavefronts' staging areas
+  {
+    static bool once = false; // the forward launches with block tiles stage more than the default 64 KB
+    if (!once) {
+      once = true;
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_fwd_kernel<true, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
+  }
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
@@ -712,7 +714,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
       P.mark(1000 + l, s);
     }
     // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
-    const int ld = nb ? std::max(lds_wave, std::min(8128, (P.lev_lds[SolvePlan::FWD_BLOCK][l] * C16 + 64 * C16 + 16 * C16 + 63) / 64 * 64)) : lds_wave;
+    const int ld = nb ? std::max(lds_wave, 512 * C16 + 64 * C16) : lds_wave; // block tiles: 512 columns of the right-hand side per chunk + the cross-wavefront buffer (72 KB)
     const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
     if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
     else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
