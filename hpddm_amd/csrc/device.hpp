@@ -110,7 +110,7 @@ struct SolvePlan {
   DevBuf<Tile>     tiles;
   std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
-  std::vector<int> lev_team[2];  // forward / backward: the first lev_team[.][l] wave tiles of level l are worth a whole workgroup (sptrsv16.hip)
+  std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the others chunks of 32 outputs (one wavefront each)
   // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
   // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
   std::vector<int> gat_ptr, gat_end;

@@ -1181,7 +1181,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     for (idx_t k = 0; k < D.nblk; ++k)
       if (D.ldw[k] * cs > NARROW) wide_rows16[D.height[k]] += ((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k]) + 15) / 16;
   }
-  const long long fwd_want = 1024 / std::max(1, groups);
+  const long long fwd_want = 512 / std::max(1, groups);
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     for (idx_t k = 0; k < D.nblk; ++k) {
@@ -1282,12 +1282,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
-      // narrow tiles one wavefront would walk as a chain of staging passes come first: the 16-column engine (sptrsv16.hip) gives
-      // each of them a whole workgroup ("team tiles"; the other sweeps do not care about the order inside a launch)
-      if (kd == FWD_WAVE || kd == BWD_WAVE) {
-        auto team = [&](const Tile &t) { return kd == FWD_WAVE ? t.nr > 64 : (descs[t.sn].ldw > 64 && t.rend - t.rbeg > 64); }; // at least three of the four wavefronts get 32 outputs each
-        lev_team[kd == BWD_WAVE][l] = (int)(std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), team) - tl[kd][l].begin());
-      }
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the
@@ -1297,6 +1291,34 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : descs[t.sn].w + descs[t.sn].nb)));
       lev_lds[kd][l] = need;
     }
+  // The narrow tiles once more for the 16-column engine (sptrsv16.hip), whose wavefronts take 32 outputs at a time (two MFMA
+  // fragments: few registers, many wavefronts in flight -- these levels are bound by latency): per level first the TEAM tiles, a
+  // whole workgroup each (backward supernodes that give at least three wavefronts 32 columns each or need more than two staging
+  // passes of v: the workgroup stages the rows of v once), then the tiles cut in chunks
+  // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each.
+  for (int dir = 0; dir < 2; ++dir) {
+    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0);
+    for (int l = 0; l < nlev; ++l) {
+      const std::vector<Tile> &src = tl[dir == 0 ? FWD_WAVE : BWD_WAVE][l];
+      std::vector<Tile>        team, chunk;
+      for (const Tile &t : src) {
+        const SnDesc &d = descs[t.sn];
+        if (dir == 0) {
+          for (int r0 = 0; r0 < t.nr; r0 += 32) chunk.push_back(Tile{t.sn, t.r0 + r0, std::min(32, t.nr - r0), 0, 1, 0, 0, 0}); // (a forward tile stages at most 128 rows of R: no team tiles)
+        } else {
+          const int h = t.rend - t.rbeg;
+          if ((d.ldw > 64 && h > 64) || h > 128) team.push_back(t);
+          else
+            for (int c0 = 0; c0 < d.ldw; c0 += 32) chunk.push_back(Tile{t.sn, c0, std::min(32, d.ldw - c0), 0, 1, 0, ((c0 / d.cs) / 4) * 4, t.rend}); // rows above scalar column c0 / cs hold zeros there
+        }
+      }
+      lev_ptr16[dir][l] = (int)all.size();
+      lev_team[dir][l]  = (int)team.size();
+      all.insert(all.end(), team.begin(), team.end());
+      all.insert(all.end(), chunk.begin(), chunk.end());
+      lev_end16[dir][l] = (int)all.size();
+    }
+  }
   gat_ptr.assign(nlev, 0);
   gat_end.assign(nlev, 0);
   for (int l = 0; l < nlev; ++l) {

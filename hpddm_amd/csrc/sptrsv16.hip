@@ -23,7 +23,7 @@
 namespace hpddm_hip {
 
 static constexpr int C16 = 16;  // real columns per sweep
-static constexpr int KC  = 128; // right-hand-side rows staged per wavefront and pass (16 KB: every forward tile and every supernode of up to 128 rows in ONE pass; the registers hold the kernels to 2-3 workgroups per CU anyway)
+static constexpr int KC  = 64;  // right-hand-side rows staged per wavefront and pass (8 KB; 16 KB measured slower: one workgroup less per CU)
 static constexpr int RCB = 256; // ... per workgroup by the backward block tiles (32 KB)
 
 __device__ static inline v4f64 mfma16(double a, double b, v4f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -239,93 +239,39 @@ __device__ static inline void stage_fwd16(const SnView &d, int cb0, int cnt, int
   }
 }
 
-// narrow panels, forward: one wavefront computes the output rows [t.r0, t.r0 + t.nr) (at most 128) through the transposed copy,
-// 64 rows (two chunks of 32 = four fragments, 32 accumulator registers) per pass over the right-hand side
+// narrow panels, forward: one wavefront computes the (at most 32) output rows [t.r0, t.r0 + t.nr) through the transposed copy: two
+// fragments, 16 accumulator registers
 template <bool Z>
 __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *bb, double *yb, double *Ub)
 {
-  constexpr int NCH = 2, PF = 8;
+  constexpr int PF = 4; // (8 steps in flight cost the forward kernels one wavefront per SIMD: 126 -> 102 VGPRs)
   const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
   const int nu = lane & 15, kq = lane >> 4;
   const int rend = t.r0 + t.nr;
-  for (int r0 = t.r0; r0 < rend; r0 += 32 * NCH) {
-    const int   nr   = min(32 * NCH, rend - r0);
-    const gcd_t P    = d.FT + r0;
-    const int   mlim = min((nr + 1) & ~1, ldh - r0);
-    int         klo[NCH], khi[NCH], kmax = 0;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int rl = min(r0 + 32 * c + 31, rend - 1); // last output row of the chunk: rows of the top block stop at their diagonal entry
-      klo[c]       = 0;
-      khi[c]       = 32 * c < nr ? (rl < w ? cs * (rl + 1) : wc) : 0;
-      kmax         = max(kmax, khi[c]);
-    }
-    const int k4 = (kmax + 3) & ~3;
-    dbl2      ring[PF][NCH];
-    wave_pipe_prime<NCH, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
-    v4f64 aE[NCH], aO[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < k4; kc += KC) {
-      if (kc > 0 || r0 == t.r0 || k4 > KC) { // a supernode of at most KC panel columns is staged once for all the passes
-        stage_fwd16<Z>(d, Z ? kc >> 1 : kc, Z ? KC / 2 : KC, lane, 64, Bl, bb, Ub);
-        wave_lds_order();
-      }
-      wave_mfma_steps<NCH, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
-      if (k4 > KC) wave_lds_order(); // the reads of this chunk are done before the next one is staged
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int eo = 0; eo < 2; ++eo) { // the four even rows of the lane, then the four odd ones: their gather chains together
-        int    rr[4];
-        double vv[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int r = r0 + 32 * c + 2 * (kq + 4 * reg) + eo;
-          rr[reg]     = r < rend ? r : -1;
-          vv[reg]     = eo ? aO[c][reg] : aE[c][reg];
-        }
-        if (32 * c < nr) store_rows16<4>(d, rr, nu, vv, yb, Ub); // wave-uniform
-      }
-  }
-  wave_lds_order(); // the staging area goes to the next tile
-}
-
-// narrow panels, forward, the whole workgroup on one tile (tiles of more than 64 rows or of supernodes wider than one staging
-// pass): the right-hand side is staged ONCE by the 256 threads (at most 128 rows of R), every wavefront takes 32 of the output rows.
-// One wavefront alone walks such a tile as a chain of staging passes and 64-row passes -- a dozen dependent round trips where the
-// workgroup needs three; the levels just above the leaves are bound by exactly that.
-template <bool Z>
-__device__ static inline void fwd_team_tile16(const SnView &d, const Tile &t, double *lds, const double *bb, double *yb, double *Ub)
-{
-  constexpr int PF = 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
-  const int nu = lane & 15, kq = lane >> 4;
-  const int rend = t.r0 + t.nr, r0 = t.r0 + 32 * wave, nr = max(0, min(32, rend - r0));
-  const int rl = min(r0 + 31, rend - 1);
-  const int klo[1] = {0}, khi[1] = {nr > 0 ? (rl < w ? cs * (rl + 1) : wc) : 0};
-  const int k4 = (khi[0] + 3) & ~3, kall = ((rend - 1 < w ? cs * rend : wc) + 3) & ~3; // this wavefront's rows of R, the tile's
-  const gcd_t P    = d.FT + r0;
-  const int   mlim = min((nr + 1) & ~1, ldh - r0);
+  const gcd_t P    = d.FT + t.r0;
+  const int   mlim = min((t.nr + 1) & ~1, ldh - t.r0);
+  const int   klo[1] = {0}, khi[1] = {rend - 1 < w ? cs * rend : wc}; // rows of the top block stop at their diagonal entry
+  const int   k4 = (khi[0] + 3) & ~3;
   dbl2        ring[PF][1];
   wave_pipe_prime<1, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
-  stage_fwd16<Z>(d, 0, Z ? kall >> 1 : kall, tid, WG_THREADS, lds, bb, Ub);
-  __syncthreads();
   v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
-  wave_mfma_steps<1, PF>(ring, P, ldh, wc, mlim, 0, k4, k4, klo, khi, lds, 0, lane, aE, aO);
+  for (int kc = 0; kc < k4; kc += KC) {
+    stage_fwd16<Z>(d, Z ? kc >> 1 : kc, Z ? KC / 2 : KC, lane, 64, Bl, bb, Ub);
+    wave_lds_order();
+    wave_mfma_steps<1, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
+    wave_lds_order(); // the reads of this chunk are done before the staging area is written again
+  }
 #pragma unroll
-  for (int eo = 0; eo < 2; ++eo) {
+  for (int eo = 0; eo < 2; ++eo) { // the four even rows of the lane, then the four odd ones: their gather chains together
     int    rr[4];
     double vv[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int r = r0 + 2 * (kq + 4 * reg) + eo;
+      const int r = t.r0 + 2 * (kq + 4 * reg) + eo;
       rr[reg]     = r < rend ? r : -1;
       vv[reg]     = eo ? aO[0][reg] : aE[0][reg];
     }
-    if (nr > 0) store_rows16<4>(d, rr, nu, vv, yb, Ub); // wave-uniform
+    store_rows16<4>(d, rr, nu, vv, yb, Ub);
   }
 }
 
@@ -386,49 +332,39 @@ __device__ static inline double combine16(double e, double o, int nu)
   }
 }
 
-// narrow panels, backward: one wavefront takes the whole supernode (h <= WAVE_ROWS rows, at most 128 doubles per row), 64 doubles
-// of every row (two chunks of 32) per pass over v
+// narrow panels, backward: one wavefront takes (at most) 32 doubles of every row of the supernode, [t.r0, t.r0 + t.nr), rows
+// [t.rbeg, t.rend) (the rows above hold zeros in these columns)
 template <bool Z>
-__device__ static inline void bwd_wave_tile16(const SnView &d, int lane, double *Bl, const double *yb, double *xb)
+__device__ static inline void bwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *yb, double *xb)
 {
-  constexpr int NCH = 2, PF = 8;
-  const int w = d.w, ldw = d.ldw, h = d.w + d.nb, cs = d.cs;
+  constexpr int PF = 8;
+  const int w = d.w, ldw = d.ldw, h = t.rend;
   const int nu = lane & 15, kq = lane >> 4;
   const int h4 = (h + 3) & ~3;
-  for (int m0 = 0; m0 < ldw; m0 += 32 * NCH) {
-    int klo[NCH], khi[NCH];
+  const int klo[1] = {t.rbeg}, khi[1] = {h};
+  const int kc0 = t.rbeg & ~(KC - 1);
+  const gcd_t P = d.G + t.r0;
+  dbl2        ring[PF][1];
+  wave_pipe_prime<1, PF>(ring, P, ldw, h, ldw - t.r0, kc0, h4, klo, khi, lane);
+  v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
+  for (int kc = kc0; kc < h4; kc += KC) {
+    stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
+    wave_lds_order();
+    wave_mfma_steps<1, PF>(ring, P, ldw, h, ldw - t.r0, kc, min(kc + KC, h4), h4, klo, khi, Bl, kc, lane, aE, aO);
+    wave_lds_order();
+  }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      klo[c] = ((m0 + 32 * c) / cs) & ~3; // rows above the diagonal hold zeros in these columns
-      khi[c] = m0 + 32 * c < ldw ? h : 0;
+  for (int reg = 0; reg < 4; ++reg) {
+    const int p = kq + 4 * reg;
+    if constexpr (Z) {
+      const int    col = (t.r0 >> 1) + p;
+      const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu); // (every lane takes part in the swap)
+      if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = v;
+    } else {
+      const int col = t.r0 + 2 * p;
+      if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg];
+      if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg];
     }
-    const int kc0 = klo[0] & ~(KC - 1);
-    dbl2      ring[PF][NCH];
-    wave_pipe_prime<NCH, PF>(ring, d.G + m0, ldw, h, ldw - m0, kc0, h4, klo, khi, lane);
-    v4f64 aE[NCH], aO[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) aE[c] = aO[c] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int kc = kc0; kc < h4; kc += KC) {
-      stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
-      wave_lds_order();
-      wave_mfma_steps<NCH, PF>(ring, d.G + m0, ldw, h, ldw - m0, kc, min(kc + KC, h4), h4, klo, khi, Bl, kc, lane, aE, aO);
-      wave_lds_order();
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int p = kq + 4 * reg;
-        if constexpr (Z) {
-          const int    col = (m0 >> 1) + 16 * c + p;
-          const double v   = combine16<true>(aE[c][reg], aO[c][reg], nu); // (every lane takes part in the swap)
-          if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = v;
-        } else {
-          const int col = m0 + 32 * c + 2 * p;
-          if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[c][reg];
-          if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[c][reg];
-        }
-      }
   }
 }
 
@@ -449,14 +385,14 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
   const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
   const bool    rvalid = busy && row < rend;
   double       *red  = lds + (lds_dbl - 64 * C16);       // [4 wavefronts][16 rows][16]
-  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~511; // columns of the right-hand side staged per chunk: whole rounds of the ring (PF blocks of 16 doubles, up to 4 wavefronts apart)
+  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~255; // columns of the right-hand side staged per chunk: whole rounds of the ring (PF blocks of 16 doubles, up to 4 wavefronts apart)
   const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
   const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0;
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
   v4f64         acc = {0.0, 0.0, 0.0, 0.0};
   // this wavefront's column blocks (16 doubles each, `step` apart) go through a ring of PF blocks that stays full across the
   // staging chunks of the right-hand side: the top of a small tree has fewer tiles than CUs, a tile there is a chain of loads
-  constexpr int PF = 8;
+  constexpr int PF = 4;
   const int     step = 16 * wpg, cmy = (my_lim + 15) & ~15; // (the row group stops at its own last diagonal entry)
   dbl2          r01[PF], r23[PF];
   auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
@@ -477,7 +413,7 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
     }
     __syncthreads();
     const int cend = min(kend, cmy);
-    while (cb < cend) { // PF blocks per round; CW is a multiple of PF * step (16 * 4 * 8 = 512 at most), so the rounds never straddle two chunks
+    while (cb < cend) { // PF blocks per round; CW is a multiple of PF * step (16 * 4 * 4 = 256 at most), so the rounds never straddle two chunks
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int cu = cb + u * step;
@@ -615,8 +551,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
     for (int bt = blockIdx.x; bt < nblock + nteam; bt += G) {
       const Tile   t = bt < nblock ? btiles[bt] : wtiles[bt - nblock];
       const SnView d = view(sns[t.sn]);
-      if (bt < nblock) fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0);
-      else fwd_team_tile16<Z>(d, t, lds, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16);
+      fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0); // (no forward team tiles: nteam = 0)
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -657,7 +592,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *
     const SnView  d  = view(sns[t.sn]);
     const double *yb = y16 + d.voff * C16;
     double       *xb = x16 + d.voff * C16;
-    bwd_wave_tile16<Z>(d, lane, Bl, yb, xb);
+    bwd_wave_tile16<Z>(d, t, lane, Bl, yb, xb);
   }
 }
 
@@ -708,7 +643,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     }
   }
   for (int l = 0; l < P.nlev; ++l) {
-    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), ng = P.gat_end[l] - P.gat_ptr[l];
+    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = P.lev_end16[0][l] - P.lev_ptr16[0][l], ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
       hipLaunchKernelGGL(sptrsv16_gather_kernel, dim3(16 * ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], P.b16.p, P.U16.p);
       P.mark(1000 + l, s);
@@ -716,16 +651,16 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
     const int ld = nb ? std::max(lds_wave, 512 * C16 + 64 * C16) : lds_wave; // block tiles: 512 columns of the right-hand side per chunk + the cross-wavefront buffer (72 KB)
     const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
     if (nb || nw) P.mark(2000 + l, s);
   }
   const int ldb = std::max(lds_wave, RCB * C16);
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
+    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = P.lev_end16[1][l] - P.lev_ptr16[1][l];
     const int nt = P.lev_team[1][l], grid = nb + nt + (nw - nt + 3) / 4;
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nt, nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, P.x16.p, x, mu, k0);
