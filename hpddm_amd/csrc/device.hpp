@@ -87,7 +87,7 @@ struct DeviceFactor {
   DevBuf<double> FT;                 // transposed copies of the narrow forward panels (reduction-free forward sweep)
   std::vector<int64_t> ft_off;       // per supernode, -1 when it has none
   std::vector<idx_t>   ldh;
-  DevBuf<int>    rows, gptr, gsrc, perm;
+  DevBuf<int>    rows, gptr, gsrc, perm, iperm; // perm[new] = old, iperm[old] = new
   // host copies of what the plan builder needs
   std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
   std::vector<char>    has_src;
@@ -120,7 +120,7 @@ struct SolvePlan {
   DevBuf<double> b16, y16, x16, U16, partials16; // the 16-column MFMA engine (sptrsv16.hip): interleaved vectors, entry i of column nu at i * 16 + nu
   DevBuf<long long> pvoff; // per factor: vector offset
   DevBuf<int>       pn;    // per factor: n
-  DevBuf<const int *> pperm; // per factor: perm array
+  DevBuf<const int *> pperm, piperm; // per factor: perm / iperm array
   int               nmax = 0;
   int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
   int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles

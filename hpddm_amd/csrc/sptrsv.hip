@@ -1050,6 +1050,9 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   gsrc.upload(tmp2, s);
   std::vector<int> tmp3(hf.ord.perm.begin(), hf.ord.perm.end());
   perm.upload(tmp3, s);
+  std::vector<int> tmp4(hf.ord.iperm.begin(), hf.ord.iperm.end());
+  HH_CHECK(tmp4.size() == tmp3.size(), "ordering without its inverse permutation");
+  iperm.upload(tmp4, s);
   HIP_OK(hipStreamSynchronize(s)); // the staging vectors above go out of scope
   blk_ptr   = hf.sym.blk_ptr;
   ldw       = hf.ldw;
@@ -1304,12 +1307,16 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       for (const Tile &t : src) {
         const SnDesc &d = descs[t.sn];
         if (dir == 0) {
-          for (int r0 = 0; r0 < t.nr; r0 += 32) chunk.push_back(Tile{t.sn, t.r0 + r0, std::min(32, t.nr - r0), 0, 1, 0, 0, 0}); // (a forward tile stages at most 128 rows of R: no team tiles)
+          const int per = d.wc <= 64 ? 64 : 32; // (64: the right-hand side of the supernode is one staging pass, shared by the two halves)
+          for (int r0 = 0; r0 < t.nr; r0 += per) chunk.push_back(Tile{t.sn, t.r0 + r0, std::min(per, t.nr - r0), 0, 1, 0, 0, 0}); // (a forward tile stages at most 128 rows of R: no team tiles)
         } else {
           const int h = t.rend - t.rbeg;
           if ((d.ldw > 64 && h > 64) || h > 128) team.push_back(t);
           else
-            for (int c0 = 0; c0 < d.ldw; c0 += 32) chunk.push_back(Tile{t.sn, c0, std::min(32, d.ldw - c0), 0, 1, 0, ((c0 / d.cs) / 4) * 4, t.rend}); // rows above scalar column c0 / cs hold zeros there
+          {
+            const int per = h <= 64 ? 64 : 32; // (64: v is one staging pass, shared by the two halves)
+            for (int c0 = 0; c0 < d.ldw; c0 += per) chunk.push_back(Tile{t.sn, c0, std::min(per, d.ldw - c0), 0, 1, 0, ((c0 / d.cs) / 4) * 4, t.rend}); // rows above scalar column c0 / cs hold zeros there
+          }
         }
       }
       lev_ptr16[dir][l] = (int)all.size();
@@ -1336,17 +1343,19 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   {
     std::vector<long long>   pv(fs.size());
     std::vector<int>         pnn(fs.size());
-    std::vector<const int *> pp(fs.size());
+    std::vector<const int *> pp(fs.size()), pip(fs.size());
     nmax = 0;
     for (size_t f = 0; f < fs.size(); ++f) {
       pv[f]  = voff[f];
       pnn[f] = fs[f]->n;
       pp[f]  = fs[f]->perm.p;
+      pip[f] = fs[f]->iperm.p;
       nmax   = std::max<int>(nmax, fs[f]->n);
     }
     pvoff.upload(pv, s);
     pn.upload(pnn, s);
     pperm.upload(pp, s);
+    piperm.upload(pip, s);
     HIP_OK(hipStreamSynchronize(s));
   }
   sn.upload(descs, s);

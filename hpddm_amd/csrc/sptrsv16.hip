@@ -30,29 +30,73 @@ __device__ static inline v4f64 mfma16(double a, double b, v4f64 c) { return __bu
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // caller's layout <-> interleaved, permuted numbering.  Real: column c = right-hand side k0 + c; complex: columns 2k, 2k + 1 =
-// real / imaginary part of right-hand side k0 + k (the caller's vectors are (re, im) pairs)
+// real / imaginary part of right-hand side k0 + k (the caller's vectors are (re, im) pairs).  A workgroup takes 64 consecutive
+// entries of the ORIGINAL numbering through an LDS tile: the caller's side is read / written along the rows (whole lines per
+// right-hand side), the interleaved side one 128-byte row per entry at its permuted position -- both sides in whole lines (one
+// thread per (entry, column) through perm[] left the caller's side at 16 useful bytes per line: 62 us instead of 30 at 566 k rows).
 template <bool Z>
-__global__ void k_perm_in16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ b, double *__restrict__ b16, int mu, int k0)
+__global__ __launch_bounds__(256) void k_perm_in16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ iperm, const double *__restrict__ b, double *__restrict__ b16, int mu, int k0)
 {
-  const int s = blockIdx.y, n = nn[s];
+  __shared__ double T[64][C16 + 1];
+  const int s = blockIdx.y, n = nn[s], o0 = (int)blockIdx.x * 64, tid = threadIdx.x;
+  if (o0 >= n) return;
   const long long v0 = voff[s];
-  const int      *pm = perm[s];
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)C16 * n; idx += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(idx >> 4), c = (int)(idx & 15), o = pm[i];
-    b16[(v0 + i) * C16 + c] = Z ? b[2 * (v0 * mu + (long long)(k0 + (c >> 1)) * n + o) + (c & 1)] : b[v0 * mu + (long long)(k0 + c) * n + o];
+  const int       oo = tid & 63, o = o0 + oo;
+  if constexpr (Z) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int k = (tid >> 6) + 4 * pass;
+      if (o < n) {
+        const dbl2 z     = *reinterpret_cast<const dbl2 *>(b + 2 * (v0 * mu + (long long)(k0 + k) * n + o));
+        T[oo][2 * k]     = z.x;
+        T[oo][2 * k + 1] = z.y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int c = (tid >> 6) + 4 * pass;
+      if (o < n) T[oo][c] = b[v0 * mu + (long long)(k0 + c) * n + o];
+    }
+  }
+  __syncthreads();
+  const int *ip = iperm[s];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int q = (tid >> 4) + 16 * pass, c = tid & 15;
+    if (o0 + q < n) b16[(v0 + ip[o0 + q]) * C16 + c] = T[q][c];
   }
 }
 template <bool Z>
-__global__ void k_perm_out16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ x16, double *__restrict__ x, int mu, int k0)
+__global__ __launch_bounds__(256) void k_perm_out16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ iperm, const double *__restrict__ x16, double *__restrict__ x, int mu, int k0)
 {
-  const int s = blockIdx.y, n = nn[s];
+  __shared__ double T[64][C16 + 1];
+  const int s = blockIdx.y, n = nn[s], o0 = (int)blockIdx.x * 64, tid = threadIdx.x;
+  if (o0 >= n) return;
   const long long v0 = voff[s];
-  const int      *pm = perm[s];
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)C16 * n; idx += (long long)gridDim.x * blockDim.x) {
-    const int    i = (int)(idx >> 4), c = (int)(idx & 15), o = pm[i];
-    const double v = x16[(v0 + i) * C16 + c];
-    if (Z) x[2 * (v0 * mu + (long long)(k0 + (c >> 1)) * n + o) + (c & 1)] = v;
-    else x[v0 * mu + (long long)(k0 + c) * n + o] = v;
+  const int      *ip = iperm[s];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int q = (tid >> 4) + 16 * pass, c = tid & 15;
+    if (o0 + q < n) T[q][c] = x16[(v0 + ip[o0 + q]) * C16 + c];
+  }
+  __syncthreads();
+  const int oo = tid & 63, o = o0 + oo;
+  if (o >= n) return;
+  if constexpr (Z) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int k = (tid >> 6) + 4 * pass;
+      dbl2      z;
+      z.x = T[oo][2 * k], z.y = T[oo][2 * k + 1];
+      *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)(k0 + k) * n + o)) = z;
+    }
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int c = (tid >> 6) + 4 * pass;
+      x[v0 * mu + (long long)(k0 + c) * n + o] = T[oo][c];
+    }
   }
 }
 
@@ -105,19 +149,6 @@ __device__ static inline void wave_mfma_steps(dbl2 (&ring)[PF][NCH], gcd_t P, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// forward: entry (col, nu) of the right-hand side of supernode d as the panels need it.  Real: f[col][nu] = b_J - (children's
-// updates).  Complex: R = [ f_r  f_i ; -f_i  f_r ], rows 2c / 2c + 1 = slots of the real / imaginary part of column c, columns =
-// the planes (nu even: real part of right-hand side nu / 2, odd: imaginary part).
-template <bool Z>
-__device__ static inline double rhs_entry16(const SnView &d, int col, int nu, const double *bb, const double *Ub, bool gather)
-{
-  const int c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
-  double    v = bb[(long long)(d.c0 + c) * C16 + plane];
-  if (gather)
-    for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)d.gsrc[p] * C16 + plane];
-  return (Z && (col & 1) && !(nu & 1)) ? -v : v;
-}
-
 // forward: result of panel row r, column nu: top rows give y, rows below hand their update (plus what the children handed to the
 // same entry of the front) to the parent
 __device__ static inline void store_row16(const SnView &d, int r, int nu, double v, double *yb, double *Ub)
@@ -239,8 +270,10 @@ __device__ static inline void stage_fwd16(const SnView &d, int cb0, int cnt, int
   }
 }
 
-// narrow panels, forward: one wavefront computes the (at most 32) output rows [t.r0, t.r0 + t.nr) through the transposed copy: two
-// fragments, 16 accumulator registers
+// narrow panels, forward: one wavefront computes the output rows [t.r0, t.r0 + t.nr) through the transposed copy, 32 at a time (two
+// fragments, 16 accumulator registers).  The plan hands over 32 rows per tile, or 64 when the supernode has at most KC panel
+// columns: its right-hand side is then staged once for both halves (the leaves: half the vector traffic, 9 instead of 2 x 6
+// dependent round trips per supernode).
 template <bool Z>
 __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *bb, double *yb, double *Ub)
 {
@@ -248,31 +281,37 @@ __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, in
   const int w = d.w, wc = d.wc, cs = d.cs, ldh = d.ldh;
   const int nu = lane & 15, kq = lane >> 4;
   const int rend = t.r0 + t.nr;
-  const gcd_t P    = d.FT + t.r0;
-  const int   mlim = min((t.nr + 1) & ~1, ldh - t.r0);
-  const int   klo[1] = {0}, khi[1] = {rend - 1 < w ? cs * rend : wc}; // rows of the top block stop at their diagonal entry
-  const int   k4 = (khi[0] + 3) & ~3;
-  dbl2        ring[PF][1];
-  wave_pipe_prime<1, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
-  v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
-  for (int kc = 0; kc < k4; kc += KC) {
-    stage_fwd16<Z>(d, Z ? kc >> 1 : kc, Z ? KC / 2 : KC, lane, 64, Bl, bb, Ub);
-    wave_lds_order();
-    wave_mfma_steps<1, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
-    wave_lds_order(); // the reads of this chunk are done before the staging area is written again
-  }
-#pragma unroll
-  for (int eo = 0; eo < 2; ++eo) { // the four even rows of the lane, then the four odd ones: their gather chains together
-    int    rr[4];
-    double vv[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = t.r0 + 2 * (kq + 4 * reg) + eo;
-      rr[reg]     = r < rend ? r : -1;
-      vv[reg]     = eo ? aO[0][reg] : aE[0][reg];
+  for (int r0 = t.r0; r0 < rend; r0 += 32) {
+    const int   re = min(r0 + 32, rend);
+    const gcd_t P    = d.FT + r0;
+    const int   mlim = min((re - r0 + 1) & ~1, ldh - r0);
+    const int   klo[1] = {0}, khi[1] = {re - 1 < w ? cs * re : wc}; // rows of the top block stop at their diagonal entry
+    const int   k4 = (khi[0] + 3) & ~3;
+    dbl2        ring[PF][1];
+    wave_pipe_prime<1, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
+    v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
+    for (int kc = 0; kc < k4; kc += KC) {
+      if (r0 == t.r0 || wc > KC) { // (a tile of more than 32 rows only comes with wc <= KC: staged once)
+        stage_fwd16<Z>(d, Z ? kc >> 1 : kc, Z ? KC / 2 : KC, lane, 64, Bl, bb, Ub);
+        wave_lds_order();
+      }
+      wave_mfma_steps<1, PF>(ring, P, ldh, wc, mlim, kc, min(kc + KC, k4), k4, klo, khi, Bl, kc, lane, aE, aO);
+      if (wc > KC) wave_lds_order(); // the reads of this chunk are done before the staging area is written again
     }
-    store_rows16<4>(d, rr, nu, vv, yb, Ub);
+#pragma unroll
+    for (int eo = 0; eo < 2; ++eo) { // the four even rows of the lane, then the four odd ones: their gather chains together
+      int    rr[4];
+      double vv[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = r0 + 2 * (kq + 4 * reg) + eo;
+        rr[reg]     = r < re ? r : -1;
+        vv[reg]     = eo ? aO[0][reg] : aE[0][reg];
+      }
+      store_rows16<4>(d, rr, nu, vv, yb, Ub);
+    }
   }
+  wave_lds_order(); // the staging area goes to the next tile of this wavefront
 }
 
 // rows [kc, kc + cnt) of v = [ D^{-1} y_J ; -x_below ] into LDS (Bl[(k - kc) * 16 + nu]), `nt` threads working together (64: one
@@ -332,48 +371,61 @@ __device__ static inline double combine16(double e, double o, int nu)
   }
 }
 
-// narrow panels, backward: one wavefront takes (at most) 32 doubles of every row of the supernode, [t.r0, t.r0 + t.nr), rows
-// [t.rbeg, t.rend) (the rows above hold zeros in these columns)
+// narrow panels, backward: one wavefront takes the doubles [t.r0, t.r0 + t.nr) of every row of the supernode, 32 at a time, rows
+// [t.rbeg, t.rend) (the rows above hold zeros in these columns).  32 doubles per tile, or 64 when the supernode has at most KC rows:
+// v is then staged once for both halves.
 template <bool Z>
 __device__ static inline void bwd_wave_tile16(const SnView &d, const Tile &t, int lane, double *Bl, const double *yb, double *xb)
 {
   constexpr int PF = 8;
-  const int w = d.w, ldw = d.ldw, h = t.rend;
+  const int w = d.w, ldw = d.ldw, h = t.rend, cs = d.cs;
   const int nu = lane & 15, kq = lane >> 4;
   const int h4 = (h + 3) & ~3;
-  const int klo[1] = {t.rbeg}, khi[1] = {h};
-  const int kc0 = t.rbeg & ~(KC - 1);
-  const gcd_t P = d.G + t.r0;
-  dbl2        ring[PF][1];
-  wave_pipe_prime<1, PF>(ring, P, ldw, h, ldw - t.r0, kc0, h4, klo, khi, lane);
-  v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
-  for (int kc = kc0; kc < h4; kc += KC) {
-    stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
-    wave_lds_order();
-    wave_mfma_steps<1, PF>(ring, P, ldw, h, ldw - t.r0, kc, min(kc + KC, h4), h4, klo, khi, Bl, kc, lane, aE, aO);
-    wave_lds_order();
-  }
+  for (int m0 = t.r0; m0 < t.r0 + t.nr; m0 += 32) {
+    const int   klo[1] = {max(t.rbeg, ((m0 / cs) / 4) * 4)}, khi[1] = {h};
+    const int   kc0 = t.nr > 32 ? 0 : (klo[0] & ~(KC - 1)); // (two halves: h <= KC, one chunk from row 0)
+    const gcd_t P = d.G + m0;
+    dbl2        ring[PF][1];
+    wave_pipe_prime<1, PF>(ring, P, ldw, h, ldw - m0, kc0, h4, klo, khi, lane);
+    v4f64 aE[1] = {v4f64{0.0, 0.0, 0.0, 0.0}}, aO[1] = {v4f64{0.0, 0.0, 0.0, 0.0}};
+    for (int kc = kc0; kc < h4; kc += KC) {
+      if (m0 == t.r0 || h > KC) {
+        stage_bwd16<Z>(d, kc, KC, lane, 64, Bl, yb, xb);
+        wave_lds_order();
+      }
+      wave_mfma_steps<1, PF>(ring, P, ldw, h, ldw - m0, kc, min(kc + KC, h4), h4, klo, khi, Bl, kc, lane, aE, aO);
+      if (h > KC) wave_lds_order();
+    }
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int p = kq + 4 * reg;
-    if constexpr (Z) {
-      const int    col = (t.r0 >> 1) + p;
-      const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu); // (every lane takes part in the swap)
-      if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = v;
-    } else {
-      const int col = t.r0 + 2 * p;
-      if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg];
-      if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int p = kq + 4 * reg;
+      if constexpr (Z) {
+        const int    col = (m0 >> 1) + p;
+        const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu); // (every lane takes part in the swap)
+        if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = v;
+      } else {
+        const int col = m0 + 2 * p;
+        if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg];
+        if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg];
+      }
     }
   }
+  wave_lds_order(); // the staging area goes to the next tile of this wavefront
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// wide panels, forward: T(rows x 16) = F(rows x wc) f(wc x 16), one workgroup per tile of up to 64 rows.  The tile of sptrsv.hip
-// (fwd_block_tile_mfma: a lane loads 4 consecutive panel entries of its row and feeds 4 MFMAs whose k index stands for those
-// columns; 16-row groups, the wavefronts left over split the columns) on the interleaved vectors.
+// wide panels, forward: T(rows x 16) = F(rows x wc) f(wc x 16), one workgroup per tile of up to 64 rows.  Lane mapping of the
+// forward MFMA tile of sptrsv.hip: a lane loads 4 consecutive panel entries of its row (a wavefront covers 16 rows x 128 bytes) and
+// feeds 4 MFMAs whose k index stands for those columns; 16-row groups, the wavefronts left over split the columns.  What is new
+// here: the right-hand side does NOT go through LDS.  It is already formed (b_J - children's updates: the gather pass of the level)
+// and interleaved, so the B operand of an MFMA -- f[column][nu], 4 columns x 16 values = four 128-byte lines per instruction -- is
+// read straight from the vector (L1 / L2 hits: every row group of every tile of the supernode reads the same 16 x wc values),
+// through the same ring as the panel entries.  No staging chunks, no workgroup barriers until the final sum over the column split:
+// the top of a small tree has fewer tiles than CUs, and a tile there used to be a chain of (stage, barrier, multiply, barrier) per 256
+// columns.  Complex scalars: R[2c][nu] = f[c][nu], R[2c+1][nu] = f[c][nu ^ 1] with the sign of the embedding; the other plane
+// sits in the neighbouring lane.
 template <bool Z>
-__device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
+__device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, double *lds, const double *bb, double *yb, double *Ub)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
@@ -384,58 +436,56 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
   const bool    busy = rg < nrg;
   const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
   const bool    rvalid = busy && row < rend;
-  double       *red  = lds + (lds_dbl - 64 * C16);       // [4 wavefronts][16 rows][16]
-  const int     CW   = ((lds_dbl - 64 * C16) / C16) & ~255; // columns of the right-hand side staged per chunk: whole rounds of the ring (PF blocks of 16 doubles, up to 4 wavefronts apart)
-  const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
-  const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0;
+  double       *red  = lds;                              // [4 wavefronts][16 rows][16]
+  const int     my_lim = busy ? min(wc, cs * (R0 + 16)) : 0; // the row group stops at its own last diagonal entry
+  const int     step = 16 * wpg, cmy = (my_lim + 15) & ~15;
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
+  const double *fb   = bb + (long long)d.c0 * C16 + j;   // f[c][j] at fb[c * 16]
   v4f64         acc = {0.0, 0.0, 0.0, 0.0};
-  // this wavefront's column blocks (16 doubles each, `step` apart) go through a ring of PF blocks that stays full across the
-  // staging chunks of the right-hand side: the top of a small tree has fewer tiles than CUs, a tile there is a chain of loads
-  constexpr int PF = 4;
-  const int     step = 16 * wpg, cmy = (my_lim + 15) & ~15; // (the row group stops at its own last diagonal entry)
+  constexpr int PF = 4, NB = Z ? 2 : 4; // column blocks in flight; vector entries a lane reads per block (complex: 2 columns of f)
   dbl2          r01[PF], r23[PF];
-  auto          fetch = [&](int cb, dbl2 &x, dbl2 &y) {
+  double        rb[PF][NB];
+  auto          fetch = [&](int cb, dbl2 &x, dbl2 &y, double(&bq)[NB]) {
     if (rvalid && cb < cmy) {
       x = *(gcd2_t)(Frow + cb);
       y = *(gcd2_t)(Frow + cb + 2);
     } else x = y = dbl2{0.0, 0.0};
+    const int col0 = cb + 4 * g; // this lane's first column of the block
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int c = Z ? (col0 >> 1) + q : col0 + q; // column of the supernode
+      bq[q]       = (busy && cb < cmy && c < w) ? fb[(long long)c * C16] : 0.0;
+    }
   };
 #pragma unroll
-  for (int u = 0; u < PF; ++u) fetch(16 * ks + u * step, r01[u], r23[u]);
-  int cb = 16 * ks; // next column block of this wavefront (slot 0 of the ring)
-  for (int k0 = 0; k0 < tile_lim; k0 += CW) {
-    __syncthreads();
-    const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
-    for (int idx = tid; idx < (kend - k0) * C16; idx += WG_THREADS) {
-      const int i = idx >> 4, nu = idx & 15, col = k0 + i;
-      lds[idx]    = col < wc ? rhs_entry16<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
-    }
-    __syncthreads();
-    const int cend = min(kend, cmy);
-    while (cb < cend) { // PF blocks per round; CW is a multiple of PF * step (16 * 4 * 4 = 256 at most), so the rounds never straddle two chunks
+  for (int u = 0; u < PF; ++u) fetch(16 * ks + u * step, r01[u], r23[u], rb[u]);
+  for (int cb = 16 * ks; cb < cmy; cb += PF * step) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int cu = cb + u * step;
-        if (cu < cend) { // wave-uniform
-          dbl2      a01 = r01[u], a23 = r23[u];
-          const int c = cu + 4 * g; // this lane's first column
-          if (row < w) {             // triangular top block: nothing right of the diagonal (entry = cs doubles)
-            const int last = cs * (row + 1) - 1;
-            a01.x = c <= last ? a01.x : 0.0;
-            a01.y = c + 1 <= last ? a01.y : 0.0;
-            a23.x = c + 2 <= last ? a23.x : 0.0;
-            a23.y = c + 3 <= last ? a23.y : 0.0;
-          }
-          const double *fl = lds + (c - k0) * C16 + j;
-          acc = mfma16(a01.x, fl[0], acc);
-          acc = mfma16(a01.y, fl[C16], acc);
-          acc = mfma16(a23.x, fl[2 * C16], acc);
-          acc = mfma16(a23.y, fl[3 * C16], acc);
-          fetch(cu + PF * step, r01[u], r23[u]);
+    for (int u = 0; u < PF; ++u) {
+      const int cu = cb + u * step;
+      if (cu < cmy) { // wave-uniform
+        dbl2      a01 = r01[u], a23 = r23[u];
+        const int c = cu + 4 * g; // this lane's first column
+        if (row < w) {             // triangular top block: nothing right of the diagonal (entry = cs doubles)
+          const int last = cs * (row + 1) - 1;
+          a01.x = c <= last ? a01.x : 0.0;
+          a01.y = c + 1 <= last ? a01.y : 0.0;
+          a23.x = c + 2 <= last ? a23.x : 0.0;
+          a23.y = c + 3 <= last ? a23.y : 0.0;
         }
+        double b0, b1, b2, b3;
+        if constexpr (!Z) b0 = rb[u][0], b1 = rb[u][1], b2 = rb[u][2], b3 = rb[u][3];
+        else { // columns c, c + 1 = (re, im) slots of column c / 2 of the supernode; c + 2, c + 3 of the next one
+          const double o0 = __shfl_xor(rb[u][0], 1), o1 = __shfl_xor(rb[u][1], 1);
+          b0 = rb[u][0], b1 = (j & 1) ? o0 : -o0;
+          b2 = rb[u][1], b3 = (j & 1) ? o1 : -o1;
+        }
+        acc = mfma16(a01.x, b0, acc);
+        acc = mfma16(a01.y, b1, acc);
+        acc = mfma16(a23.x, b2, acc);
+        acc = mfma16(a23.y, b3, acc);
+        fetch(cu + PF * step, r01[u], r23[u], rb[u]);
       }
-      cb += PF * step;
     }
   }
   // D[(lane >> 4) + 4 reg][lane & 15] -> per-wavefront partial sums, then one sum per entry over the column split, then the stores
@@ -551,7 +601,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
     for (int bt = blockIdx.x; bt < nblock + nteam; bt += G) {
       const Tile   t = bt < nblock ? btiles[bt] : wtiles[bt - nblock];
       const SnView d = view(sns[t.sn]);
-      fwd_block_tile16<Z>(d, t, lds, lds_dbl, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16, pregathered != 0); // (no forward team tiles: nteam = 0)
+      fwd_block_tile16<Z>(d, t, lds, b16 + d.voff * C16, y16 + d.voff * C16, U16 + d.uoff * C16); // (no forward team tiles: nteam = 0; the gather pass of the level has formed the right-hand sides)
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -630,18 +680,11 @@ template <bool Z>
 static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, hipStream_t s)
 {
   auto       cnt = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
-  const dim3 gp((unsigned)std::min(2048, (P.nmax * C16 + 255) / 256), (unsigned)P.factors.size());
+  const dim3 gp((unsigned)((P.nmax + 63) / 64), (unsigned)P.factors.size());
   P.mark(-1, s);
-  hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, b, P.b16.p, mu, k0);
+  hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, b, P.b16.p, mu, k0);
   P.mark(0, s);
   const int lds_wave = 4 * KC * C16; // doubles: the four wavefronts' staging areas
-  {
-    static bool once = false; // the forward launches with block tiles stage more than the default 64 KB
-    if (!once) {
-      once = true;
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_fwd_kernel<true, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    }
-  }
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = P.lev_end16[0][l] - P.lev_ptr16[0][l], ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
@@ -649,7 +692,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
       P.mark(1000 + l, s);
     }
     // block tiles: one chunk of the right-hand side (all of it when it fits) + the cross-wavefront buffer
-    const int ld = nb ? std::max(lds_wave, 512 * C16 + 64 * C16) : lds_wave; // block tiles: 512 columns of the right-hand side per chunk + the cross-wavefront buffer (72 KB)
+    const int ld = lds_wave; // (the block tiles only use the cross-wavefront buffer: 4 x 16 x 16 doubles)
     const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
     if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld, ng ? 1 : 0);
     else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld, 0);
@@ -663,7 +706,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
-  hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.pperm.p, P.x16.p, x, mu, k0);
+  hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0);
   P.mark(4000, s);
 }
 
