@@ -7,20 +7,23 @@
 //
 // Reference concept: the numerical phase of Solver<K>::numfact (MUMPS job=4, include/HPDDM_MUMPS.hpp:286).
 #include "local_solver.hpp"
+#include <cstring>
 #include <map>
 
 namespace hpddm_hip {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+static constexpr double DEV_PIVOT_TOL_C = 1.0e-13; // the pivot rule of dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
 
 // C(M x N) = (beta1 ? C : 0) + alpha * A(M x K) * op(B) ; row-major; op(B) = B (K x N) or B^T (B stored N x K).
 // 64 x 64 tile per workgroup, 4 wavefronts of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K staged 16 at a time through LDS.
 // lower_only: tiles entirely above the diagonal of the (ci0, cj0)-shifted matrix are skipped.
 template <bool TRANSB>
-__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0)
+__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, long long sA, long long sB, long long sC)
 {
   __shared__ double As[64][17];
   __shared__ double Bs[16][65];
+  A += (long long)blockIdx.z * sA, B += (long long)blockIdx.z * sB, C += (long long)blockIdx.z * sC; // batch of products, strided operands
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (lower_only && cj0 + j0 > ci0 + i0 + 63) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
@@ -90,13 +93,16 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
 // 8-byte loads per 16 MFMAs per wavefront); the device levels of a 129^3 subdomain take 4.2 s for about 2.5e13 flops with it.
 //   * tiles are dealt to the XCDs in contiguous chunks (workgroup ids go round-robin over the 8 XCDs), so that the workgroups
 //     sharing an L2 share rows of A / columns of B;
-//   * btri: B is lower triangular (B[k][j] = 0 for k < j; the inverted top blocks): column tile j0 starts its K loop at j0.
+//   * btri: B is lower triangular (B[k][j] = 0 for k < j; the inverted top blocks): column tile j0 starts its K loop at j0;
+//     atri: A is lower triangular (A[i][k] = 0 for k > i): row tile i0 stops its K loop at i0 + TM;
+//   * blockIdx.y: batch of products with strided operands (the pairs of one level of the recursive inversion).
 template <int TM, int TN, bool TRANSB>
-__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int atri, int tiles_x, int tiles_y, long long sA, long long sB, long long sC)
 {
   constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
   __shared__ double As[2][TM][KS + 1];
   __shared__ double Bs[2][KS][TN + 1];
+  A += (long long)blockIdx.y * sA, B += (long long)blockIdx.y * sB, C += (long long)blockIdx.y * sC;
   // XCD-aware deal: workgroup id -> logical tile, contiguous chunks per XCD
   const int total = tiles_x * tiles_y, id = (int)blockIdx.x, q8 = total / 8, r8 = total % 8, xcd = id % 8, loc = id / 8;
   const int lid = xcd * q8 + min(xcd, r8) + loc;
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
     }
   };
   const int kbeg = btri ? (j0 / KS) * KS : 0; // (j0 is a multiple of TN, itself a multiple of KS)
+  if (atri) K = min(K, i0 + TM);
   if (kbeg < K) {
     fetch(kbeg);
     stash(0);
@@ -180,46 +187,47 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
       }
 }
 
-// Cholesky of one diagonal tile (nb <= 64, row-major lower, in place) and the inverse of its factor into Tinv (64 x 64,
-// zeros above the diagonal and beyond nb).  One wavefront.  *flag != 0 on a non-positive pivot.
-__global__ __launch_bounds__(64) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
+// Cholesky of one diagonal tile (nb <= 64, row-major lower, in place) and the inverse of its factor into Tinv (64 x 64, zeros
+// above the diagonal and beyond nb).  One workgroup, right-looking: thread (r, q) owns the entries of row r in the columns c = q
+// (mod 4) -- of the factor L and of X = inv(L), which is built alongside by forward substitution on the identity (row j of X is
+// final once column j of L is: X(r, :) -= L(r, j) X(j, :)).  Three barriers and a handful of FMAs per column: about 8 us per tile
+// where one wavefront walking the columns left-looking, then the inverse column by column, took 79 (a third of the kernel time of
+// the device levels at 129^3).  *flag != 0 on a non-positive pivot.
+__global__ __launch_bounds__(256) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
 {
-  // one 64 x 65 tile of LDS: the factor in the lower triangle, the strictly-lower part of its inverse transposed into the
-  // (otherwise unused) upper triangle, the diagonal of the inverse in xd
   __shared__ double L[64][65];
-  __shared__ double xd[64];
-  const int r = threadIdx.x;
-  for (int c = 0; c < 64; ++c) L[r][c] = (r < nb && c <= r) ? T[(long long)r * ld + c] : 0.0;
+  __shared__ double X[64][65];
+  const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    L[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
+    X[i][c]     = i == c ? 1.0 : 0.0;
+  }
   __syncthreads();
   for (int j = 0; j < nb; ++j) {
-    double s = 0.0;
-    if (r >= j && r < nb) {
-      s = L[r][j];
-      for (int k = 0; k < j; ++k) s -= L[r][k] * L[j][k];
+    const double d = L[j][j];
+    if (!(d > 0.0) && tid == 0) *flag = 1;
+    const double sq = sqrt(d), is = 1.0 / sq;
+    __syncthreads(); // everyone has read the pivot
+    if (tid < 64) {
+      if (tid > j && tid < nb) L[tid][j] *= is;
+      else if (tid == j) L[j][j] = sq;
+    } else if (tid < 128) {
+      const int c = tid - 64;
+      if (c <= j) X[j][c] *= is;
     }
     __syncthreads();
-    if (r == j) {
-      if (!(s > 0.0)) *flag = 1;
-      L[j][j] = sqrt(s);
+    if (r > j && r < nb) {
+      const double lrj = L[r][j];
+      for (int c = j + 1 + ((q - (j + 1)) & 3); c <= r; c += 4) L[r][c] = fma(-lrj, L[c][j], L[r][c]);
+      for (int c = q; c <= j; c += 4) X[r][c] = fma(-lrj, X[j][c], X[r][c]);
     }
-    __syncthreads();
-    if (r > j && r < nb) L[r][j] = s / L[j][j];
     __syncthreads();
   }
-  // column c of the inverse by forward substitution, thread c owns column c: X(i,c) is kept at L[c][i] (i > c)
-  if (r < nb) {
-    const int c = r;
-    xd[c]       = 1.0 / L[c][c];
-    for (int i = c + 1; i < nb; ++i) {
-      double s = L[i][c] * xd[c];
-      for (int k = c + 1; k < i; ++k) s += L[i][k] * L[c][k];
-      L[c][i] = -s / L[i][i];
-    }
-  }
-  __syncthreads();
-  for (int c = 0; c < 64; ++c) {
-    if (r < nb && c <= r) T[(long long)r * ld + c] = L[r][c];
-    Tinv[r * 64 + c] = (r < nb && c < nb) ? (c == r ? xd[r] : (c < r ? L[c][r] : 0.0)) : 0.0;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < nb && c <= i) T[(long long)i * ld + c] = L[i][c];
+    Tinv[idx] = (i < nb && c <= i) ? X[i][c] : 0.0;
   }
 }
 
@@ -237,45 +245,51 @@ __device__ static inline void tri_inverse_lds(double (*A)[65], double *xd, int n
   }
 }
 // same pivot rule as dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
-static constexpr double DEV_PIVOT_TOL = 1.0e-13;
+static constexpr double DEV_PIVOT_TOL = DEV_PIVOT_TOL_C;
 
 // LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
-// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One wavefront.
-__global__ __launch_bounds__(64) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
+// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking like
+// k_potf2_inv: column j of the trailing block is the updated column (the entries the pivot eliminates: the pivot test of
+// dense_host.hpp looks at exactly those), L(r, j) = a(r, j) / d_j, a(r, c) -= L(r, j) a(c, j).
+__global__ __launch_bounds__(256) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
 {
   __shared__ double L[64][65];
-  __shared__ double xd[64], dd[64], cm[64];
-  const int r = threadIdx.x;
-  for (int c = 0; c < 64; ++c) L[r][c] = (r < nb && c <= r) ? T[(long long)r * ld + c] : 0.0;
-  dd[r] = 0.0;
+  __shared__ double X[64][65];
+  __shared__ double dd[64], colj[64];
+  const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    L[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
+    X[i][c]     = i == c ? 1.0 : 0.0;
+  }
+  if (tid < 64) dd[tid] = 1.0;
   __syncthreads();
   for (int j = 0; j < nb; ++j) {
-    double s = 0.0;
-    if (r >= j && r < nb) {
-      s = L[r][j];
-      for (int k = 0; k < j; ++k) s -= L[r][k] * dd[k] * L[j][k];
-    }
-    cm[r] = (r > j && r < nb) ? fabs(s) : 0.0;
-    __syncthreads();
-    if (r == j) {
-      double cmax = 0.0;
-      for (int i = j + 1; i < nb; ++i) cmax = fmax(cmax, cm[i]);
-      if (!(fabs(s) > DEV_PIVOT_TOL * cmax) || s == 0.0) *flag = 1;
-      dd[j] = s;
+    const double d = L[j][j];
+    if (tid < 64) { // first wavefront: the largest entry the pivot eliminates, the pivot test, the scaled column
+      const double a = (tid > j && tid < nb) ? L[tid][j] : 0.0;
+      double       cmax = fabs(a);
+      for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+      if (tid == 0 && (!(fabs(d) > DEV_PIVOT_TOL_C * cmax) || d == 0.0)) *flag = 1;
+      colj[tid] = a;
+      if (tid == j) dd[j] = d;
     }
     __syncthreads();
-    if (r > j && r < nb) L[r][j] = s / dd[j];
+    if (tid < 64 && tid > j && tid < nb) L[tid][j] = colj[tid] / d;
+    __syncthreads();
+    if (r > j && r < nb) {
+      const double lrj = L[r][j];
+      for (int c = j + 1 + ((q - (j + 1)) & 3); c <= r; c += 4) L[r][c] = fma(-lrj, colj[c], L[r][c]);
+      for (int c = q; c <= j; c += 4) X[r][c] = fma(-lrj, X[j][c], X[r][c]);
+    }
     __syncthreads();
   }
-  for (int c = 0; c < 64; ++c)
-    if (r < nb && c <= r) T[(long long)r * ld + c] = c == r ? dd[r] : L[r][c];
-  __syncthreads();
-  tri_inverse_lds(L, xd, nb, true, r);
-  __syncthreads();
-  for (int c = 0; c < 64; ++c) {
-    const double x = (r < nb && c < nb) ? (c == r ? 1.0 : (c < r ? L[c][r] : 0.0)) : 0.0;
-    Tinv[r * 64 + c]  = x;
-    TinvD[r * 64 + c] = r < nb ? x / dd[r] : 0.0;
+  for (int idx = tid; idx < 4096; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < nb && c <= i) T[(long long)i * ld + c] = c == i ? dd[i] : L[i][c];
+    const double x = (i < nb && c <= i) ? X[i][c] : 0.0;
+    Tinv[idx]  = x;
+    TinvD[idx] = i < nb ? x / dd[i] : 0.0;
   }
 }
 
@@ -399,34 +413,87 @@ __global__ void k_scatter_add(long long cnt, const long long *__restrict__ pos, 
 {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) atomicAdd(P + pos[i], val[i]);
 }
-// rows [i0, i0+ib) of the top block: columns [0, i0) zeroed (before accumulating -Xii*tmp), diagonal tile <- Xii
-__global__ void k_set_diag_tile(int ib, int i0, double *P, long long ld, const double *__restrict__ Tinv)
+// the diagonal tiles of the top block <- their inverses (from the tile kernels), all tiles in one launch
+__global__ void k_set_diag_tiles(int w, double *P, long long ld, const double *__restrict__ Tinv)
 {
-  const int r = blockIdx.x, c = threadIdx.x;
-  if (r < ib && c < ib) P[(long long)(i0 + r) * ld + i0 + c] = Tinv[r * 64 + c];
+  const int t = blockIdx.x, i0 = 64 * t, ib = min(64, w - i0);
+  for (int idx = threadIdx.x; idx < 4096; idx += blockDim.x) {
+    const int r = idx >> 6, c = idx & 63;
+    if (r < ib && c < ib) P[(long long)(i0 + r) * ld + i0 + c] = Tinv[(size_t)t * 4096 + idx];
+  }
 }
 
+struct GemmBatch { // a batch of products with strided operands (1 = a single product)
+  int       count = 1;
+  long long sA = 0, sB = 0, sC = 0;
+};
 template <int TM, int TN>
-static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only, int ci0, int cj0, bool btri)
+static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only, int ci0, int cj0, bool btri, bool atri, const GemmBatch &bt)
 {
   const int tx = (N + TN - 1) / TN, ty = (M + TM - 1) / TM;
-  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true>), dim3((unsigned)(tx * ty)), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, tx, ty);
-  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false>), dim3((unsigned)(tx * ty)), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, tx, ty);
+  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
+  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
 }
 
-// btri: B (not transposed) is lower triangular -- only the tiles of k_gemm_big use it, the result is the same
-static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false)
+// btri: B (not transposed) is lower triangular; atri: A is lower triangular -- only the tiles of k_gemm_big use them (shorter K
+// ranges), the result is the same
+static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false, bool atri = false, const GemmBatch &bt = GemmBatch())
 {
-  if (M <= 0 || N <= 0) return;
+  if (M <= 0 || N <= 0 || bt.count <= 0) return;
   if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
-    if (M <= 64) gemm_big<64, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // row blocks of the blocked inverse
-    else if (N > 64) gemm_big<128, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB);
-    else gemm_big<128, 64>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB); // 64-column panels
+    if (M <= 64) gemm_big<64, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // row blocks
+    else if (N > 64) gemm_big<128, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt);
+    else gemm_big<128, 64>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // 64-column panels
     return;
   }
-  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
-  if (transB) hipLaunchKernelGGL(k_gemm64<true>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0);
-  else hipLaunchKernelGGL(k_gemm64<false>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0);
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)bt.count);
+  if (transB) hipLaunchKernelGGL(k_gemm64<true>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
+  else hipLaunchKernelGGL(k_gemm64<false>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
+}
+
+// Host -> device hand-over of the small lists of the device levels (row maps of the children, entry lists of the fronts, the
+// contribution blocks of the host-level children): a pinned staging ring mirrored by a device ring.  push() copies into the pinned
+// ring and enqueues ONE asynchronous copy; the host never waits for the stream except when the ring wraps around (everything
+// enqueued before has then been consumed).  hipMemcpyAsync from pageable memory would synchronise the stream on every call -- the
+// device levels used to spend about half of their wall time in such waits.
+struct UploadRing {
+  char  *host = nullptr, *dev = nullptr;
+  size_t cap = 0, head = 0;
+  void   reserve(size_t bytes, hipStream_t st)
+  {
+    if (bytes <= cap) return;
+    HIP_OK(hipStreamSynchronize(st));
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+    HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&dev, bytes));
+    cap  = bytes;
+    head = 0;
+  }
+  void *push(const void *src, size_t bytes, hipStream_t st)
+  {
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (need > cap) reserve(std::max(need, 2 * cap), st);
+    if (head + need > cap) {
+      HIP_OK(hipStreamSynchronize(st)); // wrap-around: what was enqueued has been consumed
+      head = 0;
+    }
+    std::memcpy(host + head, src, bytes);
+    HIP_OK(hipMemcpyAsync(dev + head, host + head, bytes, hipMemcpyHostToDevice, st));
+    void *p = dev + head;
+    head += need;
+    return p;
+  }
+  ~UploadRing()
+  {
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+  }
+};
+static UploadRing &upload_ring()
+{
+  static UploadRing ring; // one per process: pinning memory is expensive, the factorisations of a process follow one another
+  return ring;
 }
 
 struct DeviceLevelsImpl : public DeviceLevels {
@@ -437,7 +504,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   DevBuf<double> arena;              // all contribution blocks of the device levels + uploaded children
   size_t         arena_used = 0;
   DevBuf<double> tinv, tmp, dvec;    // inverses of the diagonal tiles of the current panel, scratch, 1/D of the panel (LDL^T)
-  DevBuf<int>    relbuf, flag;
+  DevBuf<int>    flag;
   int            failed = 0;
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
 
@@ -456,31 +523,52 @@ struct DeviceLevelsImpl : public DeviceLevels {
     arena_used = 0;
     tinv.alloc((size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
     dvec.alloc((size_t)max_w + 64);
-    tmp.alloc(std::max<size_t>((size_t)max_h * std::max<idx_t>(64, max_w), 4096));
-    relbuf.alloc((size_t)max_h + 64);
+    tmp.alloc(std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+    upload_ring().reserve((size_t)64 << 20, st);
     std::vector<int> z(1, 0);
     flag.upload(z, st);
     HIP_OK(hipStreamSynchronize(st));
   }
   void upload_cb(idx_t child, const double *C, idx_t nb) override
   {
-    double *p = take((size_t)nb * nb);
-    HIP_OK(hipMemcpyAsync(p, C, (size_t)nb * nb * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(hipStreamSynchronize(st)); // the host block goes back to its pool right after
+    // through the pinned ring into its place in the arena (device-to-device, stream-ordered): the host block goes back to its
+    // pool right after the call, the stream is not waited for
+    double     *p     = take((size_t)nb * nb);
+    const size_t bytes = (size_t)nb * nb * sizeof(double);
+    const void *src   = upload_ring().push(C, bytes, st);
+    HIP_OK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, st));
     cb[child] = p;
   }
-  // top block (w x w, lower triangular, the inverses of its diagonal tiles in tinvs) <- its inverse, row block by row block
+  // top block (w x w, lower triangular, the inverses of its diagonal tiles in tinvs) <- its inverse, by recursive doubling:
+  // inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11, X22].  The diagonal tiles come inverted from the tile kernels; then blocks of
+  // B = 64, 128, 256, ... rows: every pair (X11, X22) of a level is one entry of a BATCHED product (the pairs are independent and
+  // regularly spaced along the diagonal), T = L21 X11 into the scratch, X21 = -X22 T in place of L21.  log2(w / 64) levels of two
+  // launches each, every one filling the machine -- row block by row block (64 rows x the whole width per launch) the same flops
+  // were 2 x (w / 64) launches of one row of tiles each, the longest serial chain of the device levels.
   void invert_top(double *P, long long ld, int w, const double *tinvs)
   {
     const int ntile = (w + 63) / 64;
-    for (int t = 0; t < ntile; ++t) {
-      const int i0 = 64 * t, ib = std::min<int>(64, w - i0);
-      double   *Pi = P + (long long)i0 * ld;
-      if (i0 > 0) {
-        gemm(st, false, ib, i0, i0, 1.0, Pi, ld, P, ld, tmp.p, i0, false, false, 0, 0, true);    // tmp = L(I, 0:i0) * X(0:i0, 0:i0), X lower triangular
-        gemm(st, false, ib, i0, ib, -1.0, tinvs + (size_t)t * 4096, 64, tmp.p, i0, Pi, ld, false); // X(I, 0:i0) = -X_II * tmp
-      }
-      hipLaunchKernelGGL(k_set_diag_tile, dim3(64), dim3(64), 0, st, ib, i0, P, ld, tinvs + (size_t)t * 4096);
+    hipLaunchKernelGGL(k_set_diag_tiles, dim3((unsigned)ntile), dim3(256), 0, st, w, P, ld, tinvs);
+    for (long long B = 64; B < w; B *= 2) {
+      const int npairs = (int)((w - B + 2 * B - 1) / (2 * B)); // pairs whose second block is not empty
+      const int m_last = (int)std::min<long long>(B, w - ((long long)(npairs - 1) * 2 * B + B)); // rows of the last pair's second block
+      const int nfull  = m_last == B ? npairs : npairs - 1;
+      const long long sP = 2 * B * (ld + 1);
+      auto level = [&](int p0, int cnt, int m2) {
+        if (cnt <= 0) return;
+        const double *L21 = P + ((long long)p0 * 2 * B + B) * ld + (long long)p0 * 2 * B;
+        const double *X11 = P + (long long)p0 * sP;
+        const double *X22 = P + ((long long)p0 * 2 * B + B) * (ld + 1);
+        double       *T   = tmp.p + (long long)p0 * B * B;
+        GemmBatch     b1, b2;
+        b1.count = b2.count = cnt;
+        b1.sA = sP, b1.sB = sP, b1.sC = B * B;
+        b2.sA = sP, b2.sB = B * B, b2.sC = sP;
+        gemm(st, false, m2, (int)B, (int)B, 1.0, L21, ld, X11, ld, T, B, false, false, 0, 0, true, false, b1);                   // T = L21 X11 (X11 lower triangular)
+        gemm(st, false, m2, (int)B, m2, -1.0, X22, ld, T, B, const_cast<double *>(L21), ld, false, false, 0, 0, false, true, b2); // X21 = -X22 T (X22 lower triangular)
+      };
+      level(0, nfull, (int)B);
+      if (nfull < npairs) level(nfull, 1, m_last);
     }
   }
   // bottom block (nb x w) <- bottom * top
@@ -498,21 +586,13 @@ struct DeviceLevelsImpl : public DeviceLevels {
     hipLaunchKernelGGL(k_copy2d, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, tmp.p, 64LL, X, ld);
   }
 
-  DevBuf<long long> posbuf;
-  DevBuf<double>    valbuf;
   void scatter(double *P, size_t panel_doubles, const std::vector<long long> &pos, const std::vector<double> &val)
   {
     HIP_OK(hipMemsetAsync(P, 0, panel_doubles * sizeof(double), st));
     if (pos.empty()) return;
-    if (posbuf.n < pos.size()) {
-      HIP_OK(hipStreamSynchronize(st)); // a previous scatter may still read the old buffers
-      posbuf.alloc(pos.size() + pos.size() / 2);
-      valbuf.alloc(pos.size() + pos.size() / 2);
-    }
-    HIP_OK(hipMemcpyAsync(posbuf.p, pos.data(), pos.size() * sizeof(long long), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(valbuf.p, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)std::min<size_t>(1024, (pos.size() + 255) / 256)), dim3(256), 0, st, (long long)pos.size(), posbuf.p, valbuf.p, P);
-    HIP_OK(hipStreamSynchronize(st)); // posbuf / valbuf are reused by the next list (G of the same front)
+    const long long *dp = (const long long *)upload_ring().push(pos.data(), pos.size() * sizeof(long long), st);
+    const double    *dv = (const double *)upload_ring().push(val.data(), val.size() * sizeof(double), st);
+    hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)std::min<size_t>(1024, (pos.size() + 255) / 256)), dim3(256), 0, st, (long long)pos.size(), dp, dv, P);
   }
   void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
   {
@@ -522,6 +602,74 @@ struct DeviceLevelsImpl : public DeviceLevels {
     scatter(D.F.p + hf->f_off[k], (size_t)h * ld, posF, valF);
     if (hf->kind == FACT_LU) scatter(D.G.p + hf->f_off[k], (size_t)h * ld, posG, valG);
     factor_front(k, children, rel);
+  }
+  // ---- blocked factorisations of the panel P (h rows, w columns, the original entries and the children's blocks assembled) ----
+  // Cholesky, right-looking by panels of NBP columns: inside a panel the 64-column tiles are factorised left-looking (products
+  // with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the large
+  // fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
+  // workgroups each walking a K loop of thousands of steps -- the f64 MFMA pipe below 20 %.
+  static constexpr int NBP = 256;
+  void factor_chol(double *P, long long ld, int w, int h)
+  {
+    for (int j0 = 0; j0 < w; j0 += NBP) {
+      const int jb = std::min(NBP, w - j0);
+      for (int t0 = 0; t0 < jb; t0 += 64) {
+        const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
+        double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096;
+        if (t0 > 0) gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, Pk + j0, ld, Pk + kb, ld, true); // the tiles of this panel to the left
+        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(256), 0, st, Pk + kb, ld, tb, Tt, flag.p);
+        right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
+      }
+      const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
+      if (r1 < w) gemm(st, true, h - r1, w - r1, jb, -1.0, P + (long long)r1 * ld + j0, ld, P + (long long)r1 * ld + j0, ld, P + (long long)r1 * ld + r1, ld, true, true);
+    }
+  }
+  // LDL^T, the same blocking; W = L D (scaled copies in the scratch) feeds the products
+  void factor_ldlt(double *P, long long ld, int w, int h, double *tinv2)
+  {
+    for (int j0 = 0; j0 < w; j0 += NBP) {
+      const int jb = std::min(NBP, w - j0);
+      for (int t0 = 0; t0 < jb; t0 += 64) {
+        const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
+        double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096, *Td = tinv2 + (size_t)(kb / 64) * 4096;
+        if (t0 > 0) {
+          // W = L(kb:kb+tb, j0:kb) * D(j0:kb);  P(kb:h, kb:kb+tb) -= L(kb:h, j0:kb) * W^T
+          hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((t0 + 255) / 256), (unsigned)tb), dim3(256), 0, st, tb, t0, Pk + j0, ld, P + (long long)j0 * (ld + 1), ld, tmp.p, (long long)t0);
+          gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, tmp.p, t0, Pk + kb, ld, true);
+        }
+        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(256), 0, st, Pk + kb, ld, tb, Tt, Td, flag.p);
+        right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Td, true); // X <- X * inv(L_T)^T * D_T^{-1}
+      }
+      const int r1 = j0 + jb;
+      if (r1 < w) {
+        // W = L(r1:w, j0:r1) * D(j0:r1);  P(r1:h, r1:w) -= L(r1:h, j0:r1) * W^T
+        hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((jb + 255) / 256), (unsigned)(w - r1)), dim3(256), 0, st, w - r1, jb, P + (long long)r1 * ld + j0, ld, P + (long long)j0 * (ld + 1), ld, tmp.p, (long long)jb);
+        gemm(st, true, h - r1, w - r1, jb, -1.0, P + (long long)r1 * ld + j0, ld, tmp.p, jb, P + (long long)r1 * ld + r1, ld, true, true);
+      }
+    }
+  }
+  // LU: left-looking by 64 columns (column block of [A11; A21], row block of U inside A11, row block of U12^T)
+  void factor_lu(double *P, double *G, long long ld, int w, int nb, int h, double *tinv2, double *tinv3)
+  {
+    const int ntile = (w + 63) / 64;
+    double   *Gb    = G + (long long)w * ld; // U12 transposed: rows below the block
+    for (int t = 0; t < ntile; ++t) {
+      const int kb = 64 * t, jb = std::min<int>(64, w - kb), below = h - kb - jb;
+      double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
+      if (kb > 0) {
+        gemm(st, false, h - kb, jb, kb, -1.0, Pk, ld, P + kb, ld, Pk + kb, ld, true);                      // column block of [A11; A21]
+        gemm(st, false, jb, w - kb - jb, kb, -1.0, Pk, ld, P + kb + jb, ld, Pk + kb + jb, ld, true);      // row block of U inside A11
+        gemm(st, true, nb, jb, kb, -1.0, Gb, ld, Pk, ld, Gb + kb, ld, true);                               // row block of U12 (transposed)
+      }
+      hipLaunchKernelGGL(k_getf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
+      right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
+      const int right = w - kb - jb;
+      if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)
+        gemm(st, false, jb, right, jb, 1.0, Tt, 64, Pk + kb + jb, ld, tmp.p, right, false);
+        hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, tmp.p, (long long)right, Pk + kb + jb, ld);
+      }
+      right_tile(Gb + kb, ld, nb, jb, Tt, true); // U12^T rows: X <- X * inv(L_T)^T
+    }
   }
   // the front k with its original entries in place: extend-add of the children, factorisation, solve-ready panels
   void factor_front(idx_t k, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel)
@@ -538,53 +686,24 @@ struct DeviceLevelsImpl : public DeviceLevels {
       C = take((size_t)nb * nb);
       HIP_OK(hipMemsetAsync(C, 0, (size_t)nb * nb * sizeof(double), st));
     }
-    // ---- extend-add the children ----
+    // ---- extend-add the children (their row maps travel through the pinned ring: nothing waits for the stream) ----
     for (size_t c = 0; c < children.size(); ++c) {
       const idx_t ch  = children[c];
       const int   nbc = (int)rel[c].size();
       auto        it  = cb.find(ch);
       HH_CHECK(it != cb.end(), "numfact (device levels): child contribution block not resident");
-      HIP_OK(hipMemcpyAsync(relbuf.p, rel[c].data(), sizeof(int) * nbc, hipMemcpyHostToDevice, st));
+      if (!nbc) continue;
+      const int *relp = (const int *)upload_ring().push(rel[c].data(), sizeof(int) * nbc, st);
       const dim3 grid((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4));
-      if (lu) hipLaunchKernelGGL(k_extend_add_full, grid, dim3(64, 4), 0, st, it->second, nbc, relbuf.p, P, G, ld, (int)w, C, (long long)nb);
-      else hipLaunchKernelGGL(k_extend_add, grid, dim3(64, 4), 0, st, it->second, nbc, relbuf.p, P, ld, (int)w, C, (long long)nb);
-      HIP_OK(hipStreamSynchronize(st)); // rel[c] is reused by the caller; relbuf by the next child
+      if (lu) hipLaunchKernelGGL(k_extend_add_full, grid, dim3(64, 4), 0, st, it->second, nbc, relp, P, G, ld, (int)w, C, (long long)nb);
+      else hipLaunchKernelGGL(k_extend_add, grid, dim3(64, 4), 0, st, it->second, nbc, relp, P, ld, (int)w, C, (long long)nb);
     }
-    // ---- left-looking blocked factorisation of the panel, 64 columns at a time ----
+    // ---- blocked factorisation of the panel ----
     const int ntile = (w + 63) / 64;
     double   *tinv2 = tinv.p + (size_t)ntile * 4096, *tinv3 = tinv.p + (size_t)2 * ntile * 4096; // LDL^T: D^{-1} inv(L); LU: inv(U), inv(U)^T
-    for (int t = 0; t < ntile; ++t) {
-      const int kb = 64 * t, jb = std::min<int>(64, w - kb), below = h - kb - jb;
-      double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
-      if (kind == FACT_CHOL) {
-        gemm(st, true, h - kb, jb, kb, -1.0, Pk, ld, Pk, ld, Pk + kb, ld, true);
-        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, flag.p);
-        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, Tt, true); // X <- X * inv(L_T)^T
-      } else if (kind == FACT_LDLT) {
-        if (kb > 0) {
-          // W = L(kb:kb+jb, 0:kb) * D(0:kb);  P(kb:h, kb:kb+jb) -= L(kb:h, 0:kb) * W^T
-          hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((kb + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, kb, Pk, ld, P, ld, tmp.p, (long long)kb);
-          gemm(st, true, h - kb, jb, kb, -1.0, Pk, ld, tmp.p, kb, Pk + kb, ld, true);
-        }
-        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, flag.p);
-        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, true); // X <- X * inv(L_T)^T * D_T^{-1}
-      } else {
-        double *Gb = G + (long long)w * ld; // U12 transposed: rows below the block
-        if (kb > 0) {
-          gemm(st, false, h - kb, jb, kb, -1.0, Pk, ld, P + kb, ld, Pk + kb, ld, true);                                  // column block of [A11; A21]
-          gemm(st, false, jb, (int)w - kb - jb, kb, -1.0, Pk, ld, P + kb + jb, ld, Pk + kb + jb, ld, true);             // row block of U inside A11
-          gemm(st, true, (int)nb, jb, kb, -1.0, Gb, ld, Pk, ld, Gb + kb, ld, true);                                      // row block of U12 (transposed)
-        }
-        hipLaunchKernelGGL(k_getf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
-        right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
-        const int right = (int)w - kb - jb;
-        if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)
-          gemm(st, false, jb, right, jb, 1.0, Tt, 64, Pk + kb + jb, ld, tmp.p, right, false);
-          hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, tmp.p, (long long)right, Pk + kb + jb, ld);
-        }
-        right_tile(Gb + kb, ld, (int)nb, jb, Tt, true); // U12^T rows: X <- X * inv(L_T)^T
-      }
-    }
+    if (kind == FACT_CHOL) factor_chol(P, ld, (int)w, (int)h);
+    else if (kind == FACT_LDLT) factor_ldlt(P, ld, (int)w, (int)h, tinv2);
+    else factor_lu(P, G, ld, (int)w, (int)nb, (int)h, tinv2, tinv3);
     // ---- Schur complement -> contribution block (lower triangle for the symmetric kinds, full for LU) ----
     if (nb) {
       double *P21 = P + (long long)w * ld;
@@ -600,19 +719,19 @@ struct DeviceLevelsImpl : public DeviceLevels {
     if (kind == FACT_LDLT) {
       hipLaunchKernelGGL(k_extract_dinv, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, dvec.p);
       HIP_OK(hipMemcpyAsync(hf->dinv.data() + c0, dvec.p, sizeof(double) * w, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st)); // dvec is reused by the next front
     }
     if (hf->keep_plain) {
       HIP_OK(hipMemcpyAsync(hf->Lplain.data() + hf->f_off[k], P, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
       if (lu) HIP_OK(hipMemcpyAsync(hf->Uplain.data() + hf->f_off[k], G, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    // ---- solve-ready panels: top <- inverse (blocked, row block by row block), bottom <- bottom * inverse ----
+    // ---- solve-ready panels: top <- inverse (recursive doubling), bottom <- bottom * inverse ----
     invert_top(P, ld, (int)w, tinv.p);
     mult_bottom(P, ld, (int)w, (int)nb);
     if (lu) {
       invert_top(G, ld, (int)w, tinv3); // inverse of U11^T: its diagonal tiles are inv(U_T)^T
       mult_bottom(G, ld, (int)w, (int)nb);
     }
-    HIP_OK(hipStreamSynchronize(st)); // the host staging panels are reused by the caller
     cb[k] = C;
   }
   int end() override
