@@ -8,11 +8,19 @@
 // Reference concept: the numerical phase of Solver<K>::numfact (MUMPS job=4, include/HPDDM_MUMPS.hpp:286).
 #include "local_solver.hpp"
 #include <cstring>
+#include <ctime>
 #include <map>
+#include <mutex>
 
 namespace hpddm_hip {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+static double now()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 static constexpr double DEV_PIVOT_TOL_C = 1.0e-13; // the pivot rule of dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
 
 // C(M x N) = (beta1 ? C : 0) + alpha * A(M x K) * op(B) ; row-major; op(B) = B (K x N) or B^T (B stored N x K).
@@ -188,46 +196,43 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
 }
 
 // Cholesky of one diagonal tile (nb <= 64, row-major lower, in place) and the inverse of its factor into Tinv (64 x 64, zeros
-// above the diagonal and beyond nb).  One workgroup, right-looking: thread (r, q) owns the entries of row r in the columns c = q
-// (mod 4) -- of the factor L and of X = inv(L), which is built alongside by forward substitution on the identity (row j of X is
-// final once column j of L is: X(r, :) -= L(r, j) X(j, :)).  Three barriers and a handful of FMAs per column: about 8 us per tile
-// where one wavefront walking the columns left-looking, then the inverse column by column, took 79 (a third of the kernel time of
-// the device levels at 129^3).  *flag != 0 on a non-positive pivot.
-__global__ __launch_bounds__(256) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
+// above the diagonal and beyond nb).  One workgroup of 512 threads, right-looking, ONE barrier per column: thread (r, q) owns the
+// entries of row r in the columns c = q (mod 8) of two working arrays -- W, the trailing block with its columns still UNSCALED
+// (W(r, c) -= W(r, j) W(c, j) / d_j needs nothing but column j, which step j does not write), and Xw, the rows of the inverse built
+// alongside by forward substitution on the identity (Xw(r, :) -= W(r, j) Xw(j, :) / d_j; row j is final when step j starts).  The
+// finished column j of L and row j of inv(L) go straight to memory, scaled by 1 / sqrt(d_j).  The tile kernels sit on the critical
+// path of every front (one per 64 columns, each waiting for the previous one): one wavefront walking the columns left-looking and
+// then the inverse column by column took 79 us per tile, a third of the kernel time of the device levels at 129^3.
+// *flag != 0 on a non-positive pivot.
+static constexpr int TILE_THREADS = 512;
+__global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
 {
-  __shared__ double L[64][65];
-  __shared__ double X[64][65];
-  const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-  for (int idx = tid; idx < 4096; idx += 256) {
+  __shared__ double W[64][65];
+  __shared__ double Xw[64][65];
+  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
-    L[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
-    X[i][c]     = i == c ? 1.0 : 0.0;
+    W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
+    Xw[i][c]    = i == c ? 1.0 : 0.0;
+    if (i >= nb || c > i) Tinv[idx] = 0.0;
   }
   __syncthreads();
   for (int j = 0; j < nb; ++j) {
-    const double d = L[j][j];
+    const double d = W[j][j];
     if (!(d > 0.0) && tid == 0) *flag = 1;
-    const double sq = sqrt(d), is = 1.0 / sq;
-    __syncthreads(); // everyone has read the pivot
-    if (tid < 64) {
-      if (tid > j && tid < nb) L[tid][j] *= is;
-      else if (tid == j) L[j][j] = sq;
-    } else if (tid < 128) {
-      const int c = tid - 64;
-      if (c <= j) X[j][c] *= is;
+    const double sq = sqrt(d), is = 1.0 / sq, id = is * is;
+    if (r >= j && r < nb) {
+      const double wrj = W[r][j];
+      if (q == 0) T[(long long)r * ld + j] = r == j ? sq : wrj * is; // column j of L
+      if (r == j) {
+        for (int c = q; c <= j; c += 8) Tinv[j * 64 + c] = Xw[j][c] * is; // row j of inv(L)
+      } else {
+        const double lr = wrj * id;
+        for (int c = j + 1 + ((q - (j + 1)) & 7); c <= r; c += 8) W[r][c] = fma(-lr, W[c][j], W[r][c]);
+        for (int c = q; c <= j; c += 8) Xw[r][c] = fma(-lr, Xw[j][c], Xw[r][c]);
+      }
     }
     __syncthreads();
-    if (r > j && r < nb) {
-      const double lrj = L[r][j];
-      for (int c = j + 1 + ((q - (j + 1)) & 3); c <= r; c += 4) L[r][c] = fma(-lrj, L[c][j], L[r][c]);
-      for (int c = q; c <= j; c += 4) X[r][c] = fma(-lrj, X[j][c], X[r][c]);
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    if (i < nb && c <= i) T[(long long)i * ld + c] = L[i][c];
-    Tinv[idx] = (i < nb && c <= i) ? X[i][c] : 0.0;
   }
 }
 
@@ -248,48 +253,44 @@ __device__ static inline void tri_inverse_lds(double (*A)[65], double *xd, int n
 static constexpr double DEV_PIVOT_TOL = DEV_PIVOT_TOL_C;
 
 // LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
-// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking like
-// k_potf2_inv: column j of the trailing block is the updated column (the entries the pivot eliminates: the pivot test of
-// dense_host.hpp looks at exactly those), L(r, j) = a(r, j) / d_j, a(r, c) -= L(r, j) a(c, j).
-__global__ __launch_bounds__(256) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
+// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking, one
+// barrier per column like k_potf2_inv: column j of the working array is the updated, unscaled column -- the entries the pivot
+// eliminates, which the pivot test of dense_host.hpp looks at (first wavefront, a shuffle reduction: nobody waits for it).
+__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
 {
-  __shared__ double L[64][65];
-  __shared__ double X[64][65];
-  __shared__ double dd[64], colj[64];
-  const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-  for (int idx = tid; idx < 4096; idx += 256) {
+  __shared__ double W[64][65];
+  __shared__ double Xw[64][65];
+  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
-    L[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
-    X[i][c]     = i == c ? 1.0 : 0.0;
+    W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
+    Xw[i][c]    = i == c ? 1.0 : 0.0;
+    if (i >= nb || c > i) Tinv[idx] = TinvD[idx] = 0.0;
   }
-  if (tid < 64) dd[tid] = 1.0;
   __syncthreads();
   for (int j = 0; j < nb; ++j) {
-    const double d = L[j][j];
-    if (tid < 64) { // first wavefront: the largest entry the pivot eliminates, the pivot test, the scaled column
-      const double a = (tid > j && tid < nb) ? L[tid][j] : 0.0;
-      double       cmax = fabs(a);
+    const double d = W[j][j];
+    if (tid < 64) {
+      double cmax = (tid > j && tid < nb) ? fabs(W[tid][j]) : 0.0;
       for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
       if (tid == 0 && (!(fabs(d) > DEV_PIVOT_TOL_C * cmax) || d == 0.0)) *flag = 1;
-      colj[tid] = a;
-      if (tid == j) dd[j] = d;
+    }
+    const double id = 1.0 / d;
+    if (r >= j && r < nb) {
+      const double lr = W[r][j] * id;
+      if (q == 0) T[(long long)r * ld + j] = r == j ? d : lr; // D on the diagonal, column j of the unit factor below
+      if (r == j) {
+        for (int c = q; c <= j; c += 8) {
+          const double x   = Xw[j][c]; // row j of inv(L) (unit diagonal)
+          Tinv[j * 64 + c]  = x;
+          TinvD[j * 64 + c] = x * id;
+        }
+      } else {
+        for (int c = j + 1 + ((q - (j + 1)) & 7); c <= r; c += 8) W[r][c] = fma(-lr, W[c][j], W[r][c]);
+        for (int c = q; c <= j; c += 8) Xw[r][c] = fma(-lr, Xw[j][c], Xw[r][c]);
+      }
     }
     __syncthreads();
-    if (tid < 64 && tid > j && tid < nb) L[tid][j] = colj[tid] / d;
-    __syncthreads();
-    if (r > j && r < nb) {
-      const double lrj = L[r][j];
-      for (int c = j + 1 + ((q - (j + 1)) & 3); c <= r; c += 4) L[r][c] = fma(-lrj, colj[c], L[r][c]);
-      for (int c = q; c <= j; c += 4) X[r][c] = fma(-lrj, X[j][c], X[r][c]);
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < 4096; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    if (i < nb && c <= i) T[(long long)i * ld + c] = c == i ? dd[i] : L[i][c];
-    const double x = (i < nb && c <= i) ? X[i][c] : 0.0;
-    Tinv[idx]  = x;
-    TinvD[idx] = i < nb ? x / dd[i] : 0.0;
   }
 }
 
@@ -459,6 +460,9 @@ static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha,
 struct UploadRing {
   char  *host = nullptr, *dev = nullptr;
   size_t cap = 0, head = 0;
+  double t_wait = 0, t_copy = 0; // seconds spent waiting for the stream at wrap-arounds / copying into the pinned ring (HPDDM_HIP_PROFILE)
+  size_t bytes_pushed = 0;
+  int    wraps = 0;
   void   reserve(size_t bytes, hipStream_t st)
   {
     if (bytes <= cap) return;
@@ -475,10 +479,16 @@ struct UploadRing {
     const size_t need = (bytes + 255) / 256 * 256;
     if (need > cap) reserve(std::max(need, 2 * cap), st);
     if (head + need > cap) {
+      const double t0 = now();
       HIP_OK(hipStreamSynchronize(st)); // wrap-around: what was enqueued has been consumed
+      t_wait += now() - t0;
+      ++wraps;
       head = 0;
     }
+    const double t1 = now();
     std::memcpy(host + head, src, bytes);
+    t_copy += now() - t1;
+    bytes_pushed += bytes;
     HIP_OK(hipMemcpyAsync(dev + head, host + head, bytes, hipMemcpyHostToDevice, st));
     void *p = dev + head;
     head += need;
@@ -496,15 +506,38 @@ static UploadRing &upload_ring()
   return ring;
 }
 
+// Work space of the device levels, kept by the process between factorisations (it only grows): hipMalloc / hipFree of several GB
+// per factorisation were 1.0 - 2.4 s of the 3 - 4.4 s the device levels of a 129^3 subdomain took.  One factorisation at a time
+// uses it (the mutex is held from begin() to end(); the device levels run on the one library stream anyway).
+struct DeviceScratch {
+  DevBuf<double> arena, tinv, tmp, dvec;
+  std::mutex     busy;
+  static DeviceScratch &get()
+  {
+    static DeviceScratch s;
+    return s;
+  }
+  static void grow(DevBuf<double> &b, size_t count)
+  {
+    if (count > b.n) b.alloc(count + count / 8);
+  }
+};
+
 struct DeviceLevelsImpl : public DeviceLevels {
   DeviceFactor &D;
   HostFactor   *hf = nullptr;
   hipStream_t   st;
   std::map<idx_t, double *> cb;      // contribution blocks resident on the device (block id -> nb x nb)
-  DevBuf<double> arena;              // all contribution blocks of the device levels + uploaded children
-  size_t         arena_used = 0;
-  DevBuf<double> tinv, tmp, dvec;    // inverses of the diagonal tiles of the current panel, scratch, 1/D of the panel (LDL^T)
+  DeviceScratch &scr = DeviceScratch::get();
+  DevBuf<double> &arena = scr.arena; // all contribution blocks of the device levels + uploaded children
+  size_t          arena_used = 0;
+  DevBuf<double> &tinv = scr.tinv, &tmp = scr.tmp, &dvec = scr.dvec; // inverses of the diagonal tiles of the current front, scratch, 1/D of the front (LDL^T)
   DevBuf<int>    flag;
+  bool           locked = false;
+  ~DeviceLevelsImpl()
+  {
+    if (locked) scr.busy.unlock();
+  }
   int            failed = 0;
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
 
@@ -519,11 +552,13 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void begin(HostFactor &h, size_t cb_doubles, idx_t max_h, idx_t max_w) override
   {
     hf = &h;
-    arena.alloc(cb_doubles + 1024);
+    scr.busy.lock();
+    locked = true;
+    DeviceScratch::grow(arena, cb_doubles + 1024);
     arena_used = 0;
-    tinv.alloc((size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
-    dvec.alloc((size_t)max_w + 64);
-    tmp.alloc(std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+    DeviceScratch::grow(tinv, (size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
+    DeviceScratch::grow(dvec, (size_t)max_w + 64);
+    DeviceScratch::grow(tmp, std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
     upload_ring().reserve((size_t)64 << 20, st);
     std::vector<int> z(1, 0);
     flag.upload(z, st);
@@ -617,7 +652,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
         const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
         double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096;
         if (t0 > 0) gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, Pk + j0, ld, Pk + kb, ld, true); // the tiles of this panel to the left
-        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(256), 0, st, Pk + kb, ld, tb, Tt, flag.p);
+        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, flag.p);
         right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
       }
       const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
@@ -637,7 +672,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
           hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((t0 + 255) / 256), (unsigned)tb), dim3(256), 0, st, tb, t0, Pk + j0, ld, P + (long long)j0 * (ld + 1), ld, tmp.p, (long long)t0);
           gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, tmp.p, t0, Pk + kb, ld, true);
         }
-        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(256), 0, st, Pk + kb, ld, tb, Tt, Td, flag.p);
+        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, Td, flag.p);
         right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Td, true); // X <- X * inv(L_T)^T * D_T^{-1}
       }
       const int r1 = j0 + jb;
@@ -737,14 +772,21 @@ struct DeviceLevelsImpl : public DeviceLevels {
   int end() override
   {
     int f = 0;
+    if (getenv("HPDDM_HIP_PROFILE")) {
+      const double t0 = now();
+      HIP_OK(hipStreamSynchronize(st));
+      UploadRing &r = upload_ring();
+      fprintf(stderr, "[numfact] device levels: host ran %.3f s ahead of the stream at the end; ring: %.1f MB pushed, %.3f s copying, %d wrap-arounds waiting %.3f s\n", now() - t0, r.bytes_pushed / 1e6, r.t_copy, r.wraps, r.t_wait);
+      r.bytes_pushed = 0, r.t_copy = r.t_wait = 0, r.wraps = 0;
+    }
     HIP_OK(hipMemcpyAsync(&f, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
-    arena.release();
-    tmp.release();
-    tinv.release();
-    dvec.release();
     cb.clear();
+    if (locked) {
+      locked = false;
+      scr.busy.unlock();
+    }
     return f;
   }
 };

@@ -580,7 +580,10 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           cbd += (nbc * nbc + 15) / 16 * 16;
         }
     }
+    const double tb0 = now();
     dev->begin(hf, cbd, max_h, max_w);
+    const double tb1 = now();
+    double       t_up = 0, t_prep = 0, t_proc = 0;
     std::vector<double>           valF, valG;
     std::vector<long long>        posF, posG;
     // the original entries of a device-level front travel as a list (position, value) and are scattered into the panel zeroed in
@@ -593,6 +596,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       const idx_t  c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
       const idx_t  ld = hf.ldw[k];
       const idx_t *rows = s.rows.data() + s.row_ptr[k];
+      const double tf0 = now();
       for (idx_t ch : children[k])
         if (cb[ch]) { // computed on the host: move it to the device once
           const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
@@ -603,6 +607,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           pool.put(cb[ch], (size_t)nbc * nbc);
           cb[ch] = nullptr;
         }
+      const double tf1 = now();
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
       posF.clear(), valF.clear(), posG.clear(), valG.clear();
@@ -622,9 +627,13 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       }
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
+      const double tf2 = now();
       dev->process_sparse(k, posF, valF, posG, valG, children[k], maps);
+      t_up += tf1 - tf0, t_prep += tf2 - tf1, t_proc += now() - tf2;
     }
+    const double te0 = now();
     if (dev->end() != 0 && !bad) bad = nblk; // a pivot of a device-level front was not positive (Cholesky) or collapsed
+    if (prof) fprintf(stderr, "[numfact] device levels, host side: begin %.3f s, children uploads %.3f s, lists %.3f s, enqueue %.3f s, end %.3f s\n", tb1 - tb0, t_up, t_prep, t_proc, now() - te0);
     if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
   }
   hf.info      = bad;
