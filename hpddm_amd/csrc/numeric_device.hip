@@ -195,6 +195,34 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
       }
 }
 
+// step j of the right-looking tile kernels, thread (r, q), r > j: W(r, c) -= lr W(c, j) for the columns c = q (mod 8) in (j, r],
+// Xw(r, c) -= lr Xw(j, c) for those in [0, j].  All the LDS reads of the thread first, then the FMAs and the writes: written as two
+// loops over the columns the reads and writes of the same arrays alternate and every iteration pays an LDS round trip (the tile
+// kernels are latency chains: 16 of those per step were 50 us per tile).
+__device__ static inline void tile_row_update(double (*W)[65], double (*Xw)[65], int r, int q, int j, double lr)
+{
+  double a[8], b[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = q + 8 * it;
+    if (c > j) {
+      a[it] = c <= r ? W[c][j] : 0.0;
+      b[it] = c <= r ? W[r][c] : 0.0;
+    } else {
+      a[it] = Xw[j][c];
+      b[it] = Xw[r][c];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int    c = q + 8 * it;
+    const double v = fma(-lr, a[it], b[it]);
+    if (c > j) {
+      if (c <= r) W[r][c] = v;
+    } else Xw[r][c] = v;
+  }
+}
+
 // Cholesky of one diagonal tile (nb <= 64, row-major lower, in place) and the inverse of its factor into Tinv (64 x 64, zeros
 // above the diagonal and beyond nb).  One workgroup of 512 threads, right-looking, ONE barrier per column: thread (r, q) owns the
 // entries of row r in the columns c = q (mod 8) of two working arrays -- W, the trailing block with its columns still UNSCALED
@@ -214,25 +242,77 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
     const int i = idx >> 6, c = idx & 63;
     W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
     Xw[i][c]    = i == c ? 1.0 : 0.0;
-    if (i >= nb || c > i) Tinv[idx] = 0.0;
   }
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
+  // Nothing leaves the workgroup inside the loop (a barrier waits for the stores in flight: one memory round trip per column).
+  // Column j of W and row j of Xw are scaled by 1 / sqrt(d_j) one step later, when nobody reads them any more.
+  double sq_prev = 0.0, is_prev = 0.0;
+  for (int j = 0; j <= nb; ++j) {
+    if (j > 0) { // column j - 1 of L, row j - 1 of inv(L): final values
+      const int p = j - 1;
+      if (q == 0 && r >= p && r < nb) W[r][p] = r == p ? sq_prev : W[r][p] * is_prev;
+      if (r == p)
+        for (int c = q; c <= p; c += 8) Xw[p][c] *= is_prev;
+    }
+    if (j == nb) break;
     const double d = W[j][j];
     if (!(d > 0.0) && tid == 0) *flag = 1;
-    const double sq = sqrt(d), is = 1.0 / sq, id = is * is;
-    if (r >= j && r < nb) {
-      const double wrj = W[r][j];
-      if (q == 0) T[(long long)r * ld + j] = r == j ? sq : wrj * is; // column j of L
-      if (r == j) {
-        for (int c = q; c <= j; c += 8) Tinv[j * 64 + c] = Xw[j][c] * is; // row j of inv(L)
-      } else {
-        const double lr = wrj * id;
-        for (int c = j + 1 + ((q - (j + 1)) & 7); c <= r; c += 8) W[r][c] = fma(-lr, W[c][j], W[r][c]);
-        for (int c = q; c <= j; c += 8) Xw[r][c] = fma(-lr, Xw[j][c], Xw[r][c]);
-      }
-    }
+    const double sq = sqrt(d), is = 1.0 / sq;
+    if (r > j && r < nb) tile_row_update(W, Xw, r, q, j, W[r][j] * (is * is));
+    sq_prev = sq, is_prev = is;
     __syncthreads();
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < nb && c <= i) T[(long long)i * ld + c] = W[i][c];
+    Tinv[idx] = (i < nb && c <= i) ? Xw[i][c] : 0.0;
+  }
+}
+
+// LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
+// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking, one
+// barrier per column like k_potf2_inv: column j of the working array is the updated, unscaled column -- the entries the pivot
+// eliminates, which the pivot test of dense_host.hpp looks at (first wavefront, a shuffle reduction: nobody waits for it).
+__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
+{
+  __shared__ double W[64][65];
+  __shared__ double Xw[64][65];
+  __shared__ double dd[64];
+  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
+    const int i = idx >> 6, c = idx & 63;
+    W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
+    Xw[i][c]    = i == c ? 1.0 : 0.0;
+  }
+  if (tid < 64) dd[tid] = 1.0;
+  __syncthreads();
+  double id_prev = 0.0;
+  for (int j = 0; j <= nb; ++j) {
+    if (j > 0) { // column j - 1 of the unit factor: final values (its diagonal entry keeps D)
+      const int p = j - 1;
+      if (q == 0 && r > p && r < nb) W[r][p] *= id_prev;
+    }
+    if (j == nb) break;
+    const double d = W[j][j];
+    if (tid < 64) {
+      double cmax = (tid > j && tid < nb) ? fabs(W[tid][j]) : 0.0;
+      for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+      if (tid == 0 && (!(fabs(d) > DEV_PIVOT_TOL_C * cmax) || d == 0.0)) *flag = 1;
+      if (tid == 0) dd[j] = d;
+    }
+    const double id = 1.0 / d;
+    if (r > j && r < nb) tile_row_update(W, Xw, r, q, j, W[r][j] * id);
+    id_prev = id;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < nb && c <= i) T[(long long)i * ld + c] = W[i][c]; // (the diagonal still holds D)
+    const double x = (i < nb && c <= i) ? Xw[i][c] : 0.0;
+    Tinv[idx]  = x;
+    TinvD[idx] = i < nb ? x / dd[i] : 0.0;
   }
 }
 
@@ -251,48 +331,6 @@ __device__ static inline void tri_inverse_lds(double (*A)[65], double *xd, int n
 }
 // same pivot rule as dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
 static constexpr double DEV_PIVOT_TOL = DEV_PIVOT_TOL_C;
-
-// LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
-// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking, one
-// barrier per column like k_potf2_inv: column j of the working array is the updated, unscaled column -- the entries the pivot
-// eliminates, which the pivot test of dense_host.hpp looks at (first wavefront, a shuffle reduction: nobody waits for it).
-__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
-{
-  __shared__ double W[64][65];
-  __shared__ double Xw[64][65];
-  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
-  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
-    const int i = idx >> 6, c = idx & 63;
-    W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
-    Xw[i][c]    = i == c ? 1.0 : 0.0;
-    if (i >= nb || c > i) Tinv[idx] = TinvD[idx] = 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const double d = W[j][j];
-    if (tid < 64) {
-      double cmax = (tid > j && tid < nb) ? fabs(W[tid][j]) : 0.0;
-      for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
-      if (tid == 0 && (!(fabs(d) > DEV_PIVOT_TOL_C * cmax) || d == 0.0)) *flag = 1;
-    }
-    const double id = 1.0 / d;
-    if (r >= j && r < nb) {
-      const double lr = W[r][j] * id;
-      if (q == 0) T[(long long)r * ld + j] = r == j ? d : lr; // D on the diagonal, column j of the unit factor below
-      if (r == j) {
-        for (int c = q; c <= j; c += 8) {
-          const double x   = Xw[j][c]; // row j of inv(L) (unit diagonal)
-          Tinv[j * 64 + c]  = x;
-          TinvD[j * 64 + c] = x * id;
-        }
-      } else {
-        for (int c = j + 1 + ((q - (j + 1)) & 7); c <= r; c += 8) W[r][c] = fma(-lr, W[c][j], W[r][c]);
-        for (int c = q; c <= j; c += 8) Xw[r][c] = fma(-lr, Xw[j][c], Xw[r][c]);
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // LU of one diagonal tile (nb <= 64, row-major, in place: unit L strictly below, U on and above the diagonal) and the tile
 // inverses the blocked algorithm multiplies with: TinvL = inv(L), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).
