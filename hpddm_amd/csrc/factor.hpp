@@ -65,7 +65,8 @@ struct CsrView {
 // this interface so that the host code carries no HIP types.
 struct DeviceLevels {
   virtual ~DeviceLevels() { }
-  virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t max_h, idx_t max_w) = 0;
+  virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t first_level) = 0; // the levels first_level .. go to the device; cb_doubles: all their contribution blocks and those their host-level children hand up
+  virtual void begin_front(idx_t k) = 0;                                // front k comes next (the fronts arrive level by level): picks the stream its uploads and kernels go to
   virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child
   // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +
   // column inside the panel, value; LU: posG / valG = the U12 entries, transposed): the panel is zeroed on the device and the few

@@ -504,7 +504,7 @@ struct UploadRing {
   void   reserve(size_t bytes, hipStream_t st)
   {
     if (bytes <= cap) return;
-    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipDeviceSynchronize());
     if (host) (void)hipHostFree(host);
     if (dev) (void)hipFree(dev);
     HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
@@ -518,7 +518,7 @@ struct UploadRing {
     if (need > cap) reserve(std::max(need, 2 * cap), st);
     if (head + need > cap) {
       const double t0 = now();
-      HIP_OK(hipStreamSynchronize(st)); // wrap-around: what was enqueued has been consumed
+      HIP_OK(hipDeviceSynchronize()); // wrap-around: what was enqueued (on any stream) has been consumed
       t_wait += now() - t0;
       ++wraps;
       head = 0;
@@ -547,8 +547,12 @@ static UploadRing &upload_ring()
 // Work space of the device levels, kept by the process between factorisations (it only grows): hipMalloc / hipFree of several GB
 // per factorisation were 1.0 - 2.4 s of the 3 - 4.4 s the device levels of a 129^3 subdomain took.  One factorisation at a time
 // uses it (the mutex is held from begin() to end(); the device levels run on the one library stream anyway).
+static constexpr int NSTREAMS = 4; // fronts of one level in flight (the first is the library stream)
 struct DeviceScratch {
-  DevBuf<double> arena, tinv, tmp, dvec;
+  DevBuf<double> arena;
+  DevBuf<double> tinv[NSTREAMS], tmp[NSTREAMS], dvec[NSTREAMS]; // per stream: inverses of the diagonal tiles of its front, scratch, 1/D (LDL^T)
+  hipStream_t    streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t     ev[NSTREAMS]      = {nullptr, nullptr, nullptr, nullptr};
   std::mutex     busy;
   static DeviceScratch &get()
   {
@@ -569,9 +573,38 @@ struct DeviceLevelsImpl : public DeviceLevels {
   DeviceScratch &scr = DeviceScratch::get();
   DevBuf<double> &arena = scr.arena; // all contribution blocks of the device levels + uploaded children
   size_t          arena_used = 0;
-  DevBuf<double> &tinv = scr.tinv, &tmp = scr.tmp, &dvec = scr.dvec; // inverses of the diagonal tiles of the current front, scratch, 1/D of the front (LDL^T)
+  // The fronts of one level are independent: they go round-robin to NSTREAMS streams, each with its own scratch; the streams meet at
+  // every change of level (events).  A front of the middle levels is a chain of small launches -- a tile kernel per 64 columns, each
+  // waiting for the previous one, products of a few dozen workgroups -- that leaves most of the machine idle on its own.
+  int             cur = 0, cur_level = -1, next_rr = 0;
+  bool            used[NSTREAMS] = {false, false, false, false};
+  struct Ptr {
+    double *p = nullptr;
+  } tinv, tmp, dvec; // the scratch of the current front's stream (begin_front sets them, and st)
   DevBuf<int>    flag;
   bool           locked = false;
+  void level_barrier()
+  {
+    for (int s = 0; s < NSTREAMS; ++s)
+      if (used[s]) HIP_OK(hipEventRecord(scr.ev[s], scr.streams[s]));
+    for (int t = 0; t < NSTREAMS; ++t)
+      for (int s = 0; s < NSTREAMS; ++s)
+        if (used[s] && s != t) HIP_OK(hipStreamWaitEvent(scr.streams[t], scr.ev[s], 0));
+    for (int s = 0; s < NSTREAMS; ++s) used[s] = false;
+  }
+  void begin_front(idx_t k) override
+  {
+    const int lvl = (int)hf->sym.height[k];
+    if (lvl != cur_level) {
+      if (cur_level >= 0) level_barrier();
+      cur_level = lvl;
+      next_rr   = 0;
+    }
+    cur       = next_rr++ % NSTREAMS;
+    used[cur] = true;
+    st        = scr.streams[cur];
+    tinv.p = scr.tinv[cur].p, tmp.p = scr.tmp[cur].p, dvec.p = scr.dvec[cur].p;
+  }
   ~DeviceLevelsImpl()
   {
     if (locked) scr.busy.unlock();
@@ -587,16 +620,36 @@ struct DeviceLevelsImpl : public DeviceLevels {
     arena_used += cnt;
     return p;
   }
-  void begin(HostFactor &h, size_t cb_doubles, idx_t max_h, idx_t max_w) override
+  void begin(HostFactor &h, size_t cb_doubles, idx_t first_level) override
   {
     hf = &h;
     scr.busy.lock();
     locked = true;
     DeviceScratch::grow(arena, cb_doubles + 1024);
     arena_used = 0;
-    DeviceScratch::grow(tinv, (size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
-    DeviceScratch::grow(dvec, (size_t)max_w + 64);
-    DeviceScratch::grow(tmp, std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+    // scratch per stream: the first stream takes every level's first front (so the largest ones), the others only see levels of
+    // two fronts or more
+    const Symbolic &s    = h.sym;
+    const idx_t     nlev = (idx_t)h.level_ptr.size() - 1;
+    idx_t           mh[2] = {1, 1}, mw[2] = {1, 1};
+    for (idx_t l = first_level; l < nlev; ++l)
+      for (idx_t q = h.level_ptr[l]; q < h.level_ptr[l + 1]; ++q) {
+        const idx_t k = h.level_blk[q], w = s.blk_ptr[k + 1] - s.blk_ptr[k], hh = w + (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+        for (int c = 0; c < (h.level_ptr[l + 1] - h.level_ptr[l] >= 2 ? 2 : 1); ++c) mh[c] = std::max(mh[c], hh), mw[c] = std::max(mw[c], w);
+      }
+    scr.streams[0] = library_stream();
+    for (int i = 0; i < NSTREAMS; ++i) {
+      if (!scr.streams[i]) HIP_OK(hipStreamCreateWithFlags(&scr.streams[i], hipStreamNonBlocking));
+      if (!scr.ev[i]) HIP_OK(hipEventCreateWithFlags(&scr.ev[i], hipEventDisableTiming));
+      const idx_t max_h = mh[i ? 1 : 0], max_w = mw[i ? 1 : 0];
+      DeviceScratch::grow(scr.tinv[i], (size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
+      DeviceScratch::grow(scr.dvec[i], (size_t)max_w + 64);
+      DeviceScratch::grow(scr.tmp[i], std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+    }
+    st = scr.streams[0];
+    cur = 0, cur_level = -1, next_rr = 0;
+    for (int i = 0; i < NSTREAMS; ++i) used[i] = false;
+    tinv.p = scr.tinv[0].p, tmp.p = scr.tmp[0].p, dvec.p = scr.dvec[0].p;
     upload_ring().reserve((size_t)64 << 20, st);
     std::vector<int> z(1, 0);
     flag.upload(z, st);
@@ -810,6 +863,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
   int end() override
   {
     int f = 0;
+    level_barrier(); // everything meets on every stream, the library stream included
+    st = scr.streams[0];
     if (getenv("HPDDM_HIP_PROFILE")) {
       const double t0 = now();
       HIP_OK(hipStreamSynchronize(st));

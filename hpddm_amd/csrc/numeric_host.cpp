@@ -568,12 +568,9 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     // ---- hand-over: the remaining levels run on the device (real scalars) ----
     const double td0 = now();
     size_t cbd = 0;
-    idx_t  max_h = 0, max_w = 0;
     for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q) {
-      const idx_t k = hf.level_blk[q], w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+      const idx_t k = hf.level_blk[q], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
       cbd += ((size_t)nb * nb + 15) / 16 * 16;
-      max_h = std::max(max_h, w + nb);
-      max_w = std::max(max_w, w);
       for (idx_t ch : children[k])
         if (s.height[ch] < first_device_level) {
           const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
@@ -581,7 +578,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
         }
     }
     const double tb0 = now();
-    dev->begin(hf, cbd, max_h, max_w);
+    dev->begin(hf, cbd, first_device_level);
     const double tb1 = now();
     double       t_up = 0, t_prep = 0, t_proc = 0;
     std::vector<double>           valF, valG;
@@ -597,6 +594,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       const idx_t  ld = hf.ldw[k];
       const idx_t *rows = s.rows.data() + s.row_ptr[k];
       const double tf0 = now();
+      dev->begin_front(k);
       for (idx_t ch : children[k])
         if (cb[ch]) { // computed on the host: move it to the device once
           const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
