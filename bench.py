@@ -185,6 +185,9 @@ def main():
     t_gen = getattr(generate, "seconds", 0.0)   # the synthetic matrices (numpy): test infrastructure, not part of the set-up of the operator
     A.call_numfact()
     t_setup = time.time() - t0 - t_gen
+    # of which: the plain factor kept for the CPU baseline leg (-hpddm_keep_plain: every front copied off the device before it is
+    # inverted -- 97 GB at configs[2]); not part of the set-up of the operator
+    t_plain = sum(A.subdomain(s).info()["plain_export_us"] for s in range(len(subs))) * 1e-6 if want_cpu else 0.0
     st = A.stats()
     ntot = int(st["n"])                      # unknowns in scalars K
     sk = 16.0 if A.complex else 8.0          # sizeof(K)
@@ -300,7 +303,8 @@ def main():
                                         + ("RCCL inside the library (ncclSend/ncclRecv/ncclAllReduce on the library stream)" if not share_gpu else "the gloo test double (shared GPU)") if sharded
                                         else "replicas (one independent 8-subdomain block per GPU)")),
                        "n_dof_per_gpu": ntot, "nnz_L_per_gpu": st["nnz_L"], "levels": st["levels"], "launches_per_sptrsv": st["launches"],
-                       "setup_seconds": round(t_setup, 2), "generator_seconds": round(t_gen, 2)},
+                       "setup_seconds": round(t_setup, 2), "generator_seconds": round(t_gen, 2),
+                       "setup_seconds_of_which_plain_factor_for_cpu_baseline": round(t_plain, 2)},
         }
         if world > 1:
             # `value` counts applies of one GPU's share (weak) or of the global operator (strong); the global rate is always printed

@@ -48,6 +48,7 @@ struct HostFactor {
   bool                keep_plain = false;
   std::vector<double> Lplain, Uplain; // same panel layout as F/G but holding L_JJ, L_below (U_JJ^T, U_{J,right}^T)
   double              t_order = 0, t_symbolic = 0, t_numeric = 0;
+  double              t_plain = 0; // seconds of t_numeric spent keeping the plain factor (keep_plain: allocation, copies out of the fronts / off the device)
   int                 info = 0; // 0 ok, >0: zero/negative pivot in that (1-based) block
 };
 

@@ -847,9 +847,12 @@ struct DeviceLevelsImpl : public DeviceLevels {
       HIP_OK(hipMemcpyAsync(hf->dinv.data() + c0, dvec.p, sizeof(double) * w, hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st)); // dvec is reused by the next front
     }
-    if (hf->keep_plain) {
+    if (hf->keep_plain) { // (the oracle's CPU baseline wants the plain factor: the front leaves the device before it is inverted)
+      const double tp0 = now();
       HIP_OK(hipMemcpyAsync(hf->Lplain.data() + hf->f_off[k], P, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
       if (lu) HIP_OK(hipMemcpyAsync(hf->Uplain.data() + hf->f_off[k], G, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      hf->t_plain += now() - tp0;
     }
     // ---- solve-ready panels: top <- inverse (recursive doubling), bottom <- bottom * inverse ----
     invert_top(P, ld, (int)w, tinv.p);

@@ -366,9 +366,12 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   else std::vector<double>().swap(hf.G);
   if (kind == FACT_LDLT) hf.dinv.assign((size_t)n * SC, 0.0);
   else std::vector<double>().swap(hf.dinv);
+  hf.t_plain = 0;
   if (hf.keep_plain) {
+    const double tp0 = now();
     hf.Lplain.assign((size_t)hf.f_size * SC, 0.0);
     if (lu) hf.Uplain.assign((size_t)hf.f_size * SC, 0.0);
+    hf.t_plain += now() - tp0;
   }
   std::vector<T *> cb(nblk, nullptr);
   static BlockPool      pool; // persistent across calls: later factorisations reuse already-faulted memory

@@ -52,7 +52,8 @@ void HpddmHipSubdomainDestroy(HpddmHipSubdomain *S);
  * supernodal L on the host for HpddmHipSubdomainExportPlain), "host_only" (do not upload: analysis/inspection) */
 int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double value);
 /* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
- *               update-pool size, kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, 0, 0, 0
+ *               update-pool size, kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
+ *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), 0
  * times[0..3] = ordering, symbolic, numeric factorisation, upload (seconds) */
 int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
 /* Raw factor arrays for inspection / tests / the CPU baseline of bench.py (host copies; sizes from Info + the
