@@ -68,11 +68,11 @@ struct DeviceLevels {
   virtual ~DeviceLevels() { }
   virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t first_level) = 0; // the levels first_level .. go to the device; cb_doubles: all their contribution blocks and those their host-level children hand up
   virtual void begin_front(idx_t k) = 0;                                // front k comes next (the fronts arrive level by level): picks the stream its uploads and kernels go to
-  virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child
+  virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child (nb x nb scalars)
   // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +
   // column inside the panel, value; LU: posG / valG = the U12 entries, transposed): the panel is zeroed on the device and the few
   // entries scattered into it
-  virtual void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0;
+  virtual void process_sparse(idx_t k, const long long *posF, const double *valF, size_t nF, const long long *posG, const double *valG, size_t nG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0; // val*: nF / nG scalars (2 doubles each for complex factors)
   virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
 };
 

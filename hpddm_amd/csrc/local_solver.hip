@@ -124,12 +124,13 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   auto                          device_levels = [&](FactKind kd) {
     devlev.reset();
     first_dev = (idx_t)host.level_ptr.size() - 1;
-    if (!on_device || A.cplx) return; // complex scalars: every level on the host
+    if (!on_device) return;
     first_dev = pick_first_device_level(host);
     if (first_dev < (idx_t)host.level_ptr.size() - 1) {
-      dev.F.alloc((size_t)host.f_size);
-      if (kd == FACT_LU) dev.G.alloc((size_t)host.f_size);
-      devlev.reset(make_device_levels(dev));
+      const size_t sc = A.cplx ? 2 : 1; // doubles per scalar
+      dev.F.alloc((size_t)host.f_size * sc);
+      if (kd == FACT_LU) dev.G.alloc((size_t)host.f_size * sc);
+      devlev.reset(make_device_levels(dev, A.cplx));
     }
   };
   device_levels(kind);

@@ -6,7 +6,7 @@
 namespace hpddm_hip {
 
 hipStream_t library_stream();
-DeviceLevels *make_device_levels(DeviceFactor &D); // numeric_device.hip
+DeviceLevels *make_device_levels(DeviceFactor &D, bool cplx); // numeric_device.hip (cplx: K = std::complex<double>)
 
 struct LocalSolver {
   HostFactor   host;

@@ -23,17 +23,33 @@ static double now()
 }
 static constexpr double DEV_PIVOT_TOL_C = 1.0e-13; // the pivot rule of dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
 
+// Entry (kk, j) of op(B) as the products read it.  CS = 1: B real.  CS = 2: B complex (ldb in complex scalars, (re, im) pairs) and
+// (kk, j) index its real-equivalent embedding  [ br  bi ; -bi  br ]  (2K x 2N): with A and C taken as real matrices of (re, im)
+// pairs -- M rows, 2K / 2N columns -- the real product A B~ IS the complex product, with the optimal 4 real FMAs per complex one.
+// So the complex factorisation runs on the same f64 MFMA tiles; only this load differs (numeric_host.cpp: pack_b_z does the same).
+template <bool TRANSB, int CS>
+__device__ static inline double b_entry(const double *__restrict__ B, long long ldb, int kk, int j)
+{
+  if constexpr (CS == 1) return TRANSB ? B[(long long)j * ldb + kk] : B[(long long)kk * ldb + j];
+  else {
+    const int       kc = kk >> 1, p = kk & 1, jc = j >> 1, q = j & 1;
+    const long long e  = TRANSB ? (long long)jc * ldb + kc : (long long)kc * ldb + jc;
+    const double    v  = B[2 * e + (p == q ? 0 : 1)];
+    return (p == 1 && q == 0) ? -v : v;
+  }
+}
+
 // C(M x N) = (beta1 ? C : 0) + alpha * A(M x K) * op(B) ; row-major; op(B) = B (K x N) or B^T (B stored N x K).
 // 64 x 64 tile per workgroup, 4 wavefronts of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K staged 16 at a time through LDS.
 // lower_only: tiles entirely above the diagonal of the (ci0, cj0)-shifted matrix are skipped.
-template <bool TRANSB>
+template <bool TRANSB, int CS>
 __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, long long sA, long long sB, long long sC)
 {
   __shared__ double As[64][17];
   __shared__ double Bs[16][65];
   A += (long long)blockIdx.z * sA, B += (long long)blockIdx.z * sB, C += (long long)blockIdx.z * sC; // batch of products, strided operands
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  if (lower_only && cj0 + j0 > ci0 + i0 + 63) return;
+  if (lower_only && cj0 + j0 / CS > ci0 + i0 + 63) return; // (CS = 2: columns in (re, im) pairs)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
   v4f64     acc[2][2];
 #pragma unroll
@@ -54,14 +70,14 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j   = j0 + jq + q;
-        Bs[k][jq + q] = (kk < K && j < N) ? B[(long long)kk * ldb + j] : 0.0;
+        Bs[k][jq + q] = (kk < K && j < N) ? b_entry<false, CS>(B, ldb, kk, j) : 0.0;
       }
     } else {
       const int j = tid >> 2, kq = (tid & 3) * 4, jj = j0 + j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kk  = k0 + kq + q;
-        Bs[kq + q][j] = (jj < N && kk < K) ? B[(long long)jj * ldb + kk] : 0.0;
+        Bs[kq + q][j] = (jj < N && kk < K) ? b_entry<true, CS>(B, ldb, kk, jj) : 0.0;
       }
     }
     __syncthreads();
@@ -104,7 +120,7 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
 //   * btri: B is lower triangular (B[k][j] = 0 for k < j; the inverted top blocks): column tile j0 starts its K loop at j0;
 //     atri: A is lower triangular (A[i][k] = 0 for k > i): row tile i0 stops its K loop at i0 + TM;
 //   * blockIdx.y: batch of products with strided operands (the pairs of one level of the recursive inversion).
-template <int TM, int TN, bool TRANSB>
+template <int TM, int TN, bool TRANSB, int CS>
 __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int atri, int tiles_x, int tiles_y, long long sA, long long sB, long long sC)
 {
   constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
   const int total = tiles_x * tiles_y, id = (int)blockIdx.x, q8 = total / 8, r8 = total % 8, xcd = id % 8, loc = id / 8;
   const int lid = xcd * q8 + min(xcd, r8) + loc;
   const int i0 = (lid / tiles_x) * TM, j0 = (lid % tiles_x) * TN;
-  if (lower_only && cj0 + j0 > ci0 + i0 + TM - 1) return;
+  if (lower_only && cj0 + j0 / CS > ci0 + i0 + TM - 1) return; // (CS = 2: columns in (re, im) pairs)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
   v4f64     acc[MI][NJ];
 #pragma unroll
@@ -134,10 +150,10 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
       const int e = tid + 256 * q;
       if (!TRANSB) { // B is K x N: TN consecutive columns per k
         const int k = e / TN, j = j0 + e % TN, kk = k0 + k;
-        rb[q]       = (kk < K && j < N) ? B[(long long)kk * ldb + j] : 0.0;
+        rb[q]       = (kk < K && j < N) ? b_entry<false, CS>(B, ldb, kk, j) : 0.0;
       } else { // B is N x K: 16 consecutive k per column
         const int j = j0 + (e >> 4), kk = k0 + (e & 15);
-        rb[q]       = (j < N && kk < K) ? B[(long long)j * ldb + kk] : 0.0;
+        rb[q]       = (j < N && kk < K) ? b_entry<true, CS>(B, ldb, kk, j) : 0.0;
       }
     }
   };
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
     }
   };
   const int kbeg = btri ? (j0 / KS) * KS : 0; // (j0 is a multiple of TN, itself a multiple of KS)
-  if (atri) K = min(K, i0 + TM);
+  if (atri) K = min(K, CS * (i0 + TM)); // (CS = 2: A's columns in (re, im) pairs)
   if (kbeg < K) {
     fetch(kbeg);
     stash(0);
@@ -195,19 +211,41 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
       }
 }
 
-// step j of the right-looking tile kernels, thread (r, q), r > j: W(r, c) -= lr W(c, j) for the columns c = q (mod 8) in (j, r],
-// Xw(r, c) -= lr Xw(j, c) for those in [0, j].  All the LDS reads of the thread first, then the FMAs and the writes: written as two
-// loops over the columns the reads and writes of the same arrays alternate and every iteration pays an LDS round trip (the tile
-// kernels are latency chains: 16 of those per step were 50 us per tile).
-__device__ static inline void tile_row_update(double (*W)[65], double (*Xw)[65], int r, int q, int j, double lr)
+// ---- scalars of the device levels: double, or zd = (re, im) pair laid out like std::complex<double> ----
+struct zd {
+  double x, y;
+};
+__host__ __device__ static inline zd     operator+(zd a, zd b) { return zd{a.x + b.x, a.y + b.y}; }
+__host__ __device__ static inline zd     operator-(zd a, zd b) { return zd{a.x - b.x, a.y - b.y}; }
+__host__ __device__ static inline zd     operator-(zd a) { return zd{-a.x, -a.y}; }
+__host__ __device__ static inline zd     operator*(zd a, zd b) { return zd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__host__ __device__ static inline zd     operator*(zd a, double b) { return zd{a.x * b, a.y * b}; }
+__host__ __device__ static inline zd     operator/(zd a, zd b)
 {
-  double a[8], b[8];
+  const double n = 1.0 / (b.x * b.x + b.y * b.y);
+  return zd{(a.x * b.x + a.y * b.y) * n, (a.y * b.x - a.x * b.y) * n};
+}
+__host__ __device__ static inline double modulus(double a) { return fabs(a); }
+__host__ __device__ static inline double modulus(zd a) { return sqrt(a.x * a.x + a.y * a.y); }
+template <class T> __host__ __device__ static inline T scalar(double v);
+template <> __host__ __device__ inline double          scalar<double>(double v) { return v; }
+template <> __host__ __device__ inline zd              scalar<zd>(double v) { return zd{v, 0.0}; }
+__host__ __device__ static inline bool   is_zero(double a) { return a == 0.0; }
+__host__ __device__ static inline bool   is_zero(zd a) { return a.x == 0.0 && a.y == 0.0; }
+__device__ static inline double shfl_xor_t(double v, int m) { return __shfl_xor(v, m); }
+
+// step j of the right-looking tile kernels, thread (r, q), r > j: W(r, c) -= lr W(c, j) for the columns c = q (mod 8) in (j, r],
+// Xw(r, c) -= lr Xw(j, c) for those in [0, j].  All the LDS reads of the thread first, then the FMAs and the writes.
+template <class T, int LDT>
+__device__ static inline void tile_row_update(T (*W)[LDT], T (*Xw)[LDT], int r, int q, int j, T lr)
+{
+  T a[8], b[8];
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int c = q + 8 * it;
     if (c > j) {
-      a[it] = c <= r ? W[c][j] : 0.0;
-      b[it] = c <= r ? W[r][c] : 0.0;
+      a[it] = c <= r ? W[c][j] : scalar<T>(0.0);
+      b[it] = c <= r ? W[r][c] : scalar<T>(0.0);
     } else {
       a[it] = Xw[j][c];
       b[it] = Xw[r][c];
@@ -215,8 +253,8 @@ __device__ static inline void tile_row_update(double (*W)[65], double (*Xw)[65],
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const int    c = q + 8 * it;
-    const double v = fma(-lr, a[it], b[it]);
+    const int c = q + 8 * it;
+    const T   v = b[it] - lr * a[it];
     if (c > j) {
       if (c <= r) W[r][c] = v;
     } else Xw[r][c] = v;
@@ -227,10 +265,10 @@ __device__ static inline void tile_row_update(double (*W)[65], double (*Xw)[65],
 // above the diagonal and beyond nb).  One workgroup of 512 threads, right-looking, ONE barrier per column: thread (r, q) owns the
 // entries of row r in the columns c = q (mod 8) of two working arrays -- W, the trailing block with its columns still UNSCALED
 // (W(r, c) -= W(r, j) W(c, j) / d_j needs nothing but column j, which step j does not write), and Xw, the rows of the inverse built
-// alongside by forward substitution on the identity (Xw(r, :) -= W(r, j) Xw(j, :) / d_j; row j is final when step j starts).  The
-// finished column j of L and row j of inv(L) go straight to memory, scaled by 1 / sqrt(d_j).  The tile kernels sit on the critical
-// path of every front (one per 64 columns, each waiting for the previous one): one wavefront walking the columns left-looking and
-// then the inverse column by column took 79 us per tile, a third of the kernel time of the device levels at 129^3.
+// alongside by forward substitution on the identity (Xw(r, :) -= W(r, j) Xw(j, :) / d_j; row j is final when step j starts).
+// Column j of W and row j of Xw are scaled by 1 / sqrt(d_j) one step later, when nobody reads them any more; nothing leaves the
+// workgroup inside the loop (a barrier waits for the stores in flight: one memory round trip per column).  The tile kernels sit on
+// the critical path of every front (one per 64 columns, each waiting for the previous one): scripts/micro/potf2_bench.hip.
 // *flag != 0 on a non-positive pivot.
 static constexpr int TILE_THREADS = 512;
 __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
@@ -244,8 +282,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
     Xw[i][c]    = i == c ? 1.0 : 0.0;
   }
   __syncthreads();
-  // Nothing leaves the workgroup inside the loop (a barrier waits for the stores in flight: one memory round trip per column).
-  // Column j of W and row j of Xw are scaled by 1 / sqrt(d_j) one step later, when nobody reads them any more.
   double sq_prev = 0.0, is_prev = 0.0;
   for (int j = 0; j <= nb; ++j) {
     if (j > 0) { // column j - 1 of L, row j - 1 of inv(L): final values
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
     const double d = W[j][j];
     if (!(d > 0.0) && tid == 0) *flag = 1;
     const double sq = sqrt(d), is = 1.0 / sq;
-    if (r > j && r < nb) tile_row_update(W, Xw, r, q, j, W[r][j] * (is * is));
+    if (r > j && r < nb) tile_row_update<double, 65>(W, Xw, r, q, j, W[r][j] * (is * is));
     sq_prev = sq, is_prev = is;
     __syncthreads();
   }
@@ -270,190 +306,215 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
   }
 }
 
-// LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal), the inverse of
-// the unit factor into Tinv and D^{-1} inv(L) into TinvD (both 64 x 64, zeros elsewhere).  One workgroup, right-looking, one
-// barrier per column like k_potf2_inv: column j of the working array is the updated, unscaled column -- the entries the pivot
-// eliminates, which the pivot test of dense_host.hpp looks at (first wavefront, a shuffle reduction: nobody waits for it).
-__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(double *T, long long ld, int nb, double *Tinv, double *TinvD, int *flag)
+// LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal; plain transposes
+// for complex scalars: complex SYMMETRIC matrices), the inverse of the unit factor into Tinv and D^{-1} inv(L) into TinvD (both
+// 64 x 64, zeros elsewhere).  One workgroup, right-looking, one barrier per column like k_potf2_inv: column j of the working array
+// is the updated, unscaled column -- the entries the pivot eliminates, which the pivot test of dense_host.hpp looks at (first
+// wavefront, a shuffle reduction: nobody waits for it).  Dynamic LDS: two 64 x 65 arrays of T and the 64 pivots.
+template <class T>
+__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(T *Tl, long long ld, int nb, T *Tinv, T *TinvD, int *flag)
 {
-  __shared__ double W[64][65];
-  __shared__ double Xw[64][65];
-  __shared__ double dd[64];
+  extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+  T(*W)[65]  = reinterpret_cast<T(*)[65]>(tile_lds);
+  T(*Xw)[65] = W + 64;
+  T *dd      = reinterpret_cast<T *>(Xw + 64);
   const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
   for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
-    W[i][c]     = (i < nb && c <= i) ? T[(long long)i * ld + c] : 0.0;
-    Xw[i][c]    = i == c ? 1.0 : 0.0;
+    W[i][c]     = (i < nb && c <= i) ? Tl[(long long)i * ld + c] : scalar<T>(0.0);
+    Xw[i][c]    = scalar<T>(i == c ? 1.0 : 0.0);
   }
-  if (tid < 64) dd[tid] = 1.0;
+  if (tid < 64) dd[tid] = scalar<T>(1.0);
   __syncthreads();
-  double id_prev = 0.0;
+  T id_prev = scalar<T>(0.0);
   for (int j = 0; j <= nb; ++j) {
     if (j > 0) { // column j - 1 of the unit factor: final values (its diagonal entry keeps D)
       const int p = j - 1;
-      if (q == 0 && r > p && r < nb) W[r][p] *= id_prev;
+      if (q == 0 && r > p && r < nb) W[r][p] = W[r][p] * id_prev;
     }
     if (j == nb) break;
-    const double d = W[j][j];
+    const T d = W[j][j];
     if (tid < 64) {
-      double cmax = (tid > j && tid < nb) ? fabs(W[tid][j]) : 0.0;
+      double cmax = (tid > j && tid < nb) ? modulus(W[tid][j]) : 0.0;
       for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
-      if (tid == 0 && (!(fabs(d) > DEV_PIVOT_TOL_C * cmax) || d == 0.0)) *flag = 1;
+      if (tid == 0 && (!(modulus(d) > DEV_PIVOT_TOL_C * cmax) || is_zero(d))) *flag = 1;
       if (tid == 0) dd[j] = d;
     }
-    const double id = 1.0 / d;
-    if (r > j && r < nb) tile_row_update(W, Xw, r, q, j, W[r][j] * id);
+    const T id = scalar<T>(1.0) / d;
+    if (r > j && r < nb) tile_row_update<T, 65>(W, Xw, r, q, j, W[r][j] * id);
     id_prev = id;
     __syncthreads();
   }
   __syncthreads();
   for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
-    if (i < nb && c <= i) T[(long long)i * ld + c] = W[i][c]; // (the diagonal still holds D)
-    const double x = (i < nb && c <= i) ? Xw[i][c] : 0.0;
+    if (i < nb && c <= i) Tl[(long long)i * ld + c] = W[i][c]; // (the diagonal still holds D)
+    const T x  = (i < nb && c <= i) ? Xw[i][c] : scalar<T>(0.0);
     Tinv[idx]  = x;
-    TinvD[idx] = i < nb ? x / dd[i] : 0.0;
+    TinvD[idx] = i < nb ? x / dd[i] : scalar<T>(0.0);
   }
 }
 
-// Inverse of the lower-triangular factor held in the lower triangle of A (nb <= 64; unit: ones implied on the diagonal).
-// Thread c owns column c of the inverse: X(i, c), i > c, is kept at A[c][i] (the upper triangle), the diagonal in xd.
-__device__ static inline void tri_inverse_lds(double (*A)[65], double *xd, int nb, bool unit, int c)
+// LU of one diagonal tile (nb <= 64, row-major, in place: unit L strictly below, U on and above the diagonal) and the tile inverses
+// the blocked algorithm multiplies with: TinvL = inv(L), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).  One workgroup,
+// right-looking, one barrier per column: thread (r, q) owns the columns c = q (mod 8) of row r.  Step j: l = W(r, j) / u_jj for the
+// rows below, W(r, c) -= l W(j, c) right of the pivot; S(r, c) -= l S(j, c), c <= j -- the rows of inv(L), kept in the strictly
+// lower triangle of S (unit diagonal implied); and, since row j of W is final when step j starts (it IS row j of U), the forward
+// substitution for Y = inv(U^T) with the column U^T(:, j) = W(j, :): Yw(r, c) -= W(j, r) Yw(j, c) / u_jj, c <= j, kept transposed
+// in the upper triangle of S (diagonal included).  Row j of Yw is divided by u_jj one step later.  Pivot test of dense_host.hpp:
+// against the largest entry of its column AND row.
+template <class T>
+__global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld, int nb, T *TinvL, T *TinvU, T *TinvUT, int *flag)
 {
-  if (c < nb) {
-    xd[c] = unit ? 1.0 : 1.0 / A[c][c];
-    for (int i = c + 1; i < nb; ++i) {
-      double s = A[i][c] * xd[c];
-      for (int k = c + 1; k < i; ++k) s += A[i][k] * A[c][k];
-      A[c][i] = unit ? -s : -s / A[i][i];
-    }
+  extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+  T(*W)[65] = reinterpret_cast<T(*)[65]>(tile_lds);
+  T(*S)[65] = W + 64; // S[r][c], c < r: Xw(r, c) = inv(L)(r, c); S[c][r], c <= r: Yw(r, c) = inv(U^T)(r, c)
+  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
+    const int i = idx >> 6, c = idx & 63;
+    W[i][c]     = (i < nb && c < nb) ? Tl[(long long)i * ld + c] : scalar<T>(0.0);
+    S[i][c]     = scalar<T>(i == c ? 1.0 : 0.0); // Yw = identity (its diagonal); Xw's unit diagonal is implied
   }
-}
-// same pivot rule as dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
-static constexpr double DEV_PIVOT_TOL = DEV_PIVOT_TOL_C;
-
-// LU of one diagonal tile (nb <= 64, row-major, in place: unit L strictly below, U on and above the diagonal) and the tile
-// inverses the blocked algorithm multiplies with: TinvL = inv(L), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).
-__global__ __launch_bounds__(64) void k_getf2_inv(double *T, long long ld, int nb, double *TinvL, double *TinvU, double *TinvUT, int *flag)
-{
-  __shared__ double A[64][65];
-  __shared__ double xd[64], cm[64];
-  const int r = threadIdx.x;
-  for (int c = 0; c < 64; ++c) A[r][c] = (r < nb && c < nb) ? T[(long long)r * ld + c] : 0.0;
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    cm[r] = (r > j && r < nb) ? fmax(fabs(A[r][j]), fabs(A[j][r])) : 0.0;
-    __syncthreads();
-    if (r == j) {
-      double cmax = 0.0;
-      for (int i = j + 1; i < nb; ++i) cmax = fmax(cmax, cm[i]);
-      const double p = A[j][j];
-      if (!(fabs(p) > DEV_PIVOT_TOL * cmax) || p == 0.0) *flag = 1;
+  T ip_prev = scalar<T>(0.0);
+  for (int j = 0; j <= nb; ++j) {
+    if (j > 0) { // row j - 1 of inv(U^T): final values
+      const int p = j - 1;
+      if (r == p)
+        for (int c = q; c <= p; c += 8) S[c][p] = S[c][p] * ip_prev;
     }
+    if (j == nb) break;
+    const T piv = W[j][j];
+    if (tid < 64) {
+      double cmax = (tid > j && tid < nb) ? fmax(modulus(W[tid][j]), modulus(W[j][tid])) : 0.0;
+      for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+      if (tid == 0 && (!(modulus(piv) > DEV_PIVOT_TOL_C * cmax) || is_zero(piv))) *flag = 1;
+    }
+    const T ip = scalar<T>(1.0) / piv;
     if (r > j && r < nb) {
-      const double l = A[r][j] / A[j][j];
-      A[r][j]        = l;
-      for (int k = j + 1; k < nb; ++k) A[r][k] -= l * A[j][k];
+      const T l = W[r][j] * ip, ur = W[j][r] * ip; // multiplier of row r; U^T(r, j) / u_jj
+      T       a[8], b[8], ya[8], yb[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) { // all the LDS reads first
+        const int c = q + 8 * it;
+        if (c > j) {
+          a[it] = W[j][c], b[it] = W[r][c];
+        } else {
+          a[it]  = c < j ? S[j][c] : scalar<T>(1.0); // Xw(j, c), unit diagonal
+          b[it]  = S[r][c];                          // Xw(r, c) (c <= j < r: strictly lower)
+          ya[it] = S[c][j];                          // Yw(j, c)
+          yb[it] = S[c][r];                          // Yw(r, c)
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int c = q + 8 * it;
+        if (c > j) {
+          if (c < nb) W[r][c] = b[it] - l * a[it];
+        } else {
+          S[r][c] = b[it] - l * a[it];
+          S[c][r] = yb[it] - ur * ya[it];
+        }
+      }
+      if (q == 0) W[r][j] = l; // the multiplier takes the place of the entry it eliminated (column j is dead: read above by this thread's row only)
     }
+    ip_prev = ip;
     __syncthreads();
   }
-  for (int c = 0; c < 64; ++c)
-    if (r < nb && c < nb) T[(long long)r * ld + c] = A[r][c];
   __syncthreads();
-  // inv(U)^T = inverse of the lower-triangular U^T: computed first from a transposed copy kept in registers
-  double ut[64]; // row r of U^T = column r of U (entries c <= r)
-  for (int c = 0; c < 64; ++c) ut[c] = (r < nb && c <= r) ? A[c][r] : 0.0;
-  // inverse of the unit lower factor in place (upper triangle no longer needed: U is in `ut` and in T)
-  __syncthreads();
-  tri_inverse_lds(A, xd, nb, true, r);
-  __syncthreads();
-  for (int c = 0; c < 64; ++c) TinvL[r * 64 + c] = (r < nb && c < nb) ? (c == r ? 1.0 : (c < r ? A[c][r] : 0.0)) : 0.0;
-  __syncthreads();
-  for (int c = 0; c < 64; ++c) A[r][c] = c <= r ? ut[c] : 0.0;
-  __syncthreads();
-  tri_inverse_lds(A, xd, nb, false, r);
-  __syncthreads();
-  for (int c = 0; c < 64; ++c) {
-    const double x = (r < nb && c < nb) ? (c == r ? xd[r] : (c < r ? A[c][r] : 0.0)) : 0.0; // (inv(U)^T)(r, c)
-    TinvUT[r * 64 + c] = x;
-    TinvU[c * 64 + r]  = x;
+  for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < nb && c < nb) Tl[(long long)i * ld + c] = W[i][c];
+    const bool in = i < nb && c < nb;
+    TinvL[idx]  = in ? (c == i ? scalar<T>(1.0) : (c < i ? S[i][c] : scalar<T>(0.0))) : scalar<T>(0.0);
+    const T y   = (in && c <= i) ? S[c][i] : scalar<T>(0.0); // inv(U)^T (i, c) = Yw(i, c)
+    TinvUT[idx] = y;
+    TinvU[c * 64 + i] = y;
   }
 }
+static constexpr size_t tile_lds_bytes(size_t scalar_bytes) { return (size_t)(2 * 64 * 65 + 64) * scalar_bytes; }
 
 // dst(m x k, ldd) = src(m x k, lds) * diag(D), D(c) = the diagonal of the panel's top block (Dsrc, ldD)
-__global__ void k_scale_cols(int m, int k, const double *__restrict__ src, long long lds_, const double *__restrict__ Dsrc, long long ldD, double *__restrict__ dst, long long ldd)
+template <class T>
+__global__ void k_scale_cols(int m, int k, const T *__restrict__ src, long long lds_, const T *__restrict__ Dsrc, long long ldD, T *__restrict__ dst, long long ldd)
 {
   const int i = blockIdx.y;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < k; c += gridDim.x * blockDim.x)
     if (i < m) dst[(long long)i * ldd + c] = src[(long long)i * lds_ + c] * Dsrc[(long long)c * (ldD + 1)];
 }
 // LDL^T: dinv(i) = 1 / D(i), the diagonal of the top block becomes the unit diagonal of L
-__global__ void k_extract_dinv(int w, double *P, long long ld, double *dinv)
+template <class T>
+__global__ void k_extract_dinv(int w, T *P, long long ld, T *dinv)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < w) {
-    dinv[i]                 = 1.0 / P[(long long)i * (ld + 1)];
-    P[(long long)i * (ld + 1)] = 1.0;
+    dinv[i]                    = scalar<T>(1.0) / P[(long long)i * (ld + 1)];
+    P[(long long)i * (ld + 1)] = scalar<T>(1.0);
   }
 }
 // LU: G top block <- U11^T (lower, non-unit), F top block keeps the unit lower L11 (upper part zeroed, ones on the diagonal)
-__global__ void k_split_u11(int w, double *P, double *G, long long ld)
+template <class T>
+__global__ void k_split_u11(int w, T *P, T *G, long long ld)
 {
   const int i = blockIdx.y;
   for (int j = i + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) {
     G[(long long)j * ld + i] = P[(long long)i * ld + j];
-    P[(long long)i * ld + j] = j == i ? 1.0 : 0.0;
+    P[(long long)i * ld + j] = scalar<T>(j == i ? 1.0 : 0.0);
   }
 }
 // LU: parent front += child contribution block (full nbc x nbc): A11 and A21 live in F, A12 transposed in G
-__global__ void k_extend_add_full(const double *__restrict__ Cc, int nbc, const int *__restrict__ rel, double *P, double *G, long long ld, int w, double *C, long long ldcb)
+template <class T>
+__global__ void k_extend_add_full(const T *__restrict__ Cc, int nbc, const int *__restrict__ rel, T *P, T *G, long long ld, int w, T *C, long long ldcb)
 {
   const int i = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= nbc) return;
-  const int     li = rel[i];
-  const double *ci = Cc + (long long)i * nbc;
+  const int li = rel[i];
+  const T  *ci = Cc + (long long)i * nbc;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nbc; j += gridDim.x * blockDim.x) {
     const int lj = rel[j];
-    if (li < w) {
-      if (lj < w) P[(long long)li * ld + lj] += ci[j];
-      else G[(long long)lj * ld + li] += ci[j];
-    } else if (lj < w) P[(long long)li * ld + lj] += ci[j];
-    else C[(long long)(li - w) * ldcb + (lj - w)] += ci[j];
+    T        *dst;
+    if (li < w) dst = lj < w ? P + (long long)li * ld + lj : G + (long long)lj * ld + li;
+    else dst = lj < w ? P + (long long)li * ld + lj : C + (long long)(li - w) * ldcb + (lj - w);
+    *dst = *dst + ci[j];
   }
 }
-
 // parent front += child contribution block (lower, nbc x nbc, ld nbc) through the child's row -> parent position map
-__global__ void k_extend_add(const double *__restrict__ Cc, int nbc, const int *__restrict__ rel, double *P, long long ld, int w, double *C, long long ldcb)
+template <class T>
+__global__ void k_extend_add(const T *__restrict__ Cc, int nbc, const int *__restrict__ rel, T *P, long long ld, int w, T *C, long long ldcb)
 {
   const int i = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= nbc) return;
-  const int     li = rel[i];
-  const double *ci = Cc + (long long)i * nbc;
+  const int li = rel[i];
+  const T  *ci = Cc + (long long)i * nbc;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= i; j += gridDim.x * blockDim.x) {
-    const int lj = rel[j];
-    if (lj < w) P[(long long)li * ld + lj] += ci[j];
-    else C[(long long)(li - w) * ldcb + (lj - w)] += ci[j];
+    const int lj  = rel[j];
+    T        *dst = lj < w ? P + (long long)li * ld + lj : C + (long long)(li - w) * ldcb + (lj - w);
+    *dst          = *dst + ci[j];
   }
 }
 // dst(m x n, ldd) = src(m x n, lds)
-__global__ void k_copy2d(int m, int n, const double *__restrict__ src, long long lds_, double *__restrict__ dst, long long ldd)
+template <class T>
+__global__ void k_copy2d(int m, int n, const T *__restrict__ src, long long lds_, T *__restrict__ dst, long long ldd)
 {
   const int i = blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
     if (i < m) dst[(long long)i * ldd + j] = src[(long long)i * lds_ + j];
 }
-__global__ void k_zero_upper(int w, double *P, long long ld)
+template <class T>
+__global__ void k_zero_upper(int w, T *P, long long ld)
 {
   const int i = blockIdx.y;
-  for (int j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) P[(long long)i * ld + j] = 0.0;
+  for (int j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) P[(long long)i * ld + j] = scalar<T>(0.0);
 }
-// the original entries of a front, scattered into its zeroed panel
+// the original entries of a front, scattered into its zeroed panel (doubles per scalar SC: val holds SC doubles per entry)
+template <int SC>
 __global__ void k_scatter_add(long long cnt, const long long *__restrict__ pos, const double *__restrict__ val, double *P)
 {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) atomicAdd(P + pos[i], val[i]);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cnt * SC; i += (long long)gridDim.x * blockDim.x) atomicAdd(P + SC * pos[i / SC] + i % SC, val[i]);
 }
 // the diagonal tiles of the top block <- their inverses (from the tile kernels), all tiles in one launch
-__global__ void k_set_diag_tiles(int w, double *P, long long ld, const double *__restrict__ Tinv)
+template <class T>
+__global__ void k_set_diag_tiles(int w, T *P, long long ld, const T *__restrict__ Tinv)
 {
   const int t = blockIdx.x, i0 = 64 * t, ib = min(64, w - i0);
   for (int idx = threadIdx.x; idx < 4096; idx += blockDim.x) {
@@ -462,32 +523,37 @@ __global__ void k_set_diag_tiles(int w, double *P, long long ld, const double *_
   }
 }
 
-struct GemmBatch { // a batch of products with strided operands (1 = a single product)
+struct GemmBatch { // a batch of products with strided operands (1 = a single product); strides in scalars
   int       count = 1;
   long long sA = 0, sB = 0, sC = 0;
 };
-template <int TM, int TN>
+template <int TM, int TN, int CS>
 static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only, int ci0, int cj0, bool btri, bool atri, const GemmBatch &bt)
 {
   const int tx = (N + TN - 1) / TN, ty = (M + TM - 1) / TM;
-  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
-  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
+  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true, CS>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
+  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false, CS>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
 }
 
-// btri: B (not transposed) is lower triangular; atri: A is lower triangular -- only the tiles of k_gemm_big use them (shorter K
-// ranges), the result is the same
-static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false, bool atri = false, const GemmBatch &bt = GemmBatch())
+// C(M x N) = (beta1 ? C : 0) + alpha A(M x K) op(B): every argument in SCALARS of CS doubles (CS = 2: (re, im) pairs, the kernels
+// see the real views of A and C -- 2 K / 2 N columns -- and the embedding of B, b_entry).  btri: B (not transposed) is lower
+// triangular; atri: A is lower triangular -- only the tiles of k_gemm_big use them (shorter K ranges), the result is the same.
+template <int CS>
+static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false, bool atri = false, const GemmBatch &bs = GemmBatch())
 {
-  if (M <= 0 || N <= 0 || bt.count <= 0) return;
+  if (M <= 0 || N <= 0 || bs.count <= 0) return;
+  GemmBatch bt = bs; // strides of the pointers the kernels see: doubles
+  bt.sA *= CS, bt.sB *= CS, bt.sC *= CS;
+  N *= CS, K *= CS, lda *= CS, ldc *= CS; // real views (ldb stays in scalars: b_entry)
   if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
-    if (M <= 64) gemm_big<64, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // row blocks
-    else if (N > 64) gemm_big<128, 128>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt);
-    else gemm_big<128, 64>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // 64-column panels
+    if (M <= 64) gemm_big<64, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // row blocks
+    else if (N > 64) gemm_big<128, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt);
+    else gemm_big<128, 64, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // 64-column panels
     return;
   }
   const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)bt.count);
-  if (transB) hipLaunchKernelGGL(k_gemm64<true>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
-  else hipLaunchKernelGGL(k_gemm64<false>, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
+  if (transB) hipLaunchKernelGGL((k_gemm64<true, CS>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
+  else hipLaunchKernelGGL((k_gemm64<false, CS>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
 }
 
 // Host -> device hand-over of the small lists of the device levels (row maps of the children, entry lists of the fronts, the
@@ -565,11 +631,15 @@ struct DeviceScratch {
   }
 };
 
+// T = double, or zd for complex factors (complex symmetric L D L^T with plain transposes, or LU): the pools of the factor are arrays
+// of doubles, CS doubles per scalar; every offset, leading dimension and count below is in scalars.
+template <class T>
 struct DeviceLevelsImpl : public DeviceLevels {
+  static constexpr int CS = sizeof(T) / sizeof(double);
   DeviceFactor &D;
   HostFactor   *hf = nullptr;
   hipStream_t   st;
-  std::map<idx_t, double *> cb;      // contribution blocks resident on the device (block id -> nb x nb)
+  std::map<idx_t, T *> cb;           // contribution blocks resident on the device (block id -> nb x nb)
   DeviceScratch &scr = DeviceScratch::get();
   DevBuf<double> &arena = scr.arena; // all contribution blocks of the device levels + uploaded children
   size_t          arena_used = 0;
@@ -579,10 +649,15 @@ struct DeviceLevelsImpl : public DeviceLevels {
   int             cur = 0, cur_level = -1, next_rr = 0;
   bool            used[NSTREAMS] = {false, false, false, false};
   struct Ptr {
-    double *p = nullptr;
+    T *p = nullptr;
   } tinv, tmp, dvec; // the scratch of the current front's stream (begin_front sets them, and st)
   DevBuf<int>    flag;
   bool           locked = false;
+  explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
+  ~DeviceLevelsImpl()
+  {
+    if (locked) scr.busy.unlock();
+  }
   void level_barrier()
   {
     for (int s = 0; s < NSTREAMS; ++s)
@@ -592,6 +667,12 @@ struct DeviceLevelsImpl : public DeviceLevels {
         if (used[s] && s != t) HIP_OK(hipStreamWaitEvent(scr.streams[t], scr.ev[s], 0));
     for (int s = 0; s < NSTREAMS; ++s) used[s] = false;
   }
+  void set_slot(int i)
+  {
+    cur = i;
+    st  = scr.streams[i];
+    tinv.p = reinterpret_cast<T *>(scr.tinv[i].p), tmp.p = reinterpret_cast<T *>(scr.tmp[i].p), dvec.p = reinterpret_cast<T *>(scr.dvec[i].p);
+  }
   void begin_front(idx_t k) override
   {
     const int lvl = (int)hf->sym.height[k];
@@ -600,29 +681,21 @@ struct DeviceLevelsImpl : public DeviceLevels {
       cur_level = lvl;
       next_rr   = 0;
     }
-    cur       = next_rr++ % NSTREAMS;
+    set_slot(next_rr++ % NSTREAMS);
     used[cur] = true;
-    st        = scr.streams[cur];
-    tinv.p = scr.tinv[cur].p, tmp.p = scr.tmp[cur].p, dvec.p = scr.dvec[cur].p;
   }
-  ~DeviceLevelsImpl()
+  T *take(size_t cnt)
   {
-    if (locked) scr.busy.unlock();
-  }
-  int            failed = 0;
-  explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
-
-  double *take(size_t cnt)
-  {
-    cnt = (cnt + 15) / 16 * 16;
+    cnt = (cnt * CS + 15) / 16 * 16;
     HH_CHECK(arena_used + cnt <= arena.n, "numfact (device levels): contribution-block arena exhausted");
     double *p = arena.p + arena_used;
     arena_used += cnt;
-    return p;
+    return reinterpret_cast<T *>(p);
   }
   void begin(HostFactor &h, size_t cb_doubles, idx_t first_level) override
   {
     hf = &h;
+    HH_CHECK((h.cplx ? 2 : 1) == CS, "numfact (device levels): scalar type of the factor and of the device levels differ");
     scr.busy.lock();
     locked = true;
     DeviceScratch::grow(arena, cb_doubles + 1024);
@@ -642,14 +715,29 @@ struct DeviceLevelsImpl : public DeviceLevels {
       if (!scr.streams[i]) HIP_OK(hipStreamCreateWithFlags(&scr.streams[i], hipStreamNonBlocking));
       if (!scr.ev[i]) HIP_OK(hipEventCreateWithFlags(&scr.ev[i], hipEventDisableTiming));
       const idx_t max_h = mh[i ? 1 : 0], max_w = mw[i ? 1 : 0];
-      DeviceScratch::grow(scr.tinv[i], (size_t)3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
-      DeviceScratch::grow(scr.dvec[i], (size_t)max_w + 64);
-      DeviceScratch::grow(scr.tmp[i], std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+      DeviceScratch::grow(scr.tinv[i], (size_t)CS * 3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
+      DeviceScratch::grow(scr.dvec[i], (size_t)CS * (max_w + 64));
+      DeviceScratch::grow(scr.tmp[i], (size_t)CS * std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
     }
-    st = scr.streams[0];
-    cur = 0, cur_level = -1, next_rr = 0;
+    cur_level = -1, next_rr = 0;
     for (int i = 0; i < NSTREAMS; ++i) used[i] = false;
-    tinv.p = scr.tinv[0].p, tmp.p = scr.tmp[0].p, dvec.p = scr.dvec[0].p;
+    set_slot(0);
+    if (CS == 2) { // the complex tile kernels keep two 64 x 65 complex arrays in LDS: beyond the default 64 KB
+      static bool once = false;
+      if (!once) {
+        once = true;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
+      }
+    }
+    { // (the real ones use 66.5 KB, also beyond)
+      static bool once = false;
+      if (!once) {
+        once = true;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
+      }
+    }
     upload_ring().reserve((size_t)64 << 20, st);
     std::vector<int> z(1, 0);
     flag.upload(z, st);
@@ -659,22 +747,24 @@ struct DeviceLevelsImpl : public DeviceLevels {
   {
     // through the pinned ring into its place in the arena (device-to-device, stream-ordered): the host block goes back to its
     // pool right after the call, the stream is not waited for
-    double     *p     = take((size_t)nb * nb);
-    const size_t bytes = (size_t)nb * nb * sizeof(double);
-    const void *src   = upload_ring().push(C, bytes, st);
+    T           *p     = take((size_t)nb * nb);
+    const size_t bytes = (size_t)nb * nb * sizeof(T);
+    const void  *src   = upload_ring().push(C, bytes, st);
     HIP_OK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, st));
     cb[child] = p;
   }
+  static const double *cd(const T *p) { return reinterpret_cast<const double *>(p); }
+  static double       *md(T *p) { return reinterpret_cast<double *>(p); }
   // top block (w x w, lower triangular, the inverses of its diagonal tiles in tinvs) <- its inverse, by recursive doubling:
   // inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11, X22].  The diagonal tiles come inverted from the tile kernels; then blocks of
   // B = 64, 128, 256, ... rows: every pair (X11, X22) of a level is one entry of a BATCHED product (the pairs are independent and
   // regularly spaced along the diagonal), T = L21 X11 into the scratch, X21 = -X22 T in place of L21.  log2(w / 64) levels of two
   // launches each, every one filling the machine -- row block by row block (64 rows x the whole width per launch) the same flops
   // were 2 x (w / 64) launches of one row of tiles each, the longest serial chain of the device levels.
-  void invert_top(double *P, long long ld, int w, const double *tinvs)
+  void invert_top(T *P, long long ld, int w, const T *tinvs)
   {
     const int ntile = (w + 63) / 64;
-    hipLaunchKernelGGL(k_set_diag_tiles, dim3((unsigned)ntile), dim3(256), 0, st, w, P, ld, tinvs);
+    hipLaunchKernelGGL(k_set_diag_tiles<T>, dim3((unsigned)ntile), dim3(256), 0, st, w, P, ld, tinvs);
     for (long long B = 64; B < w; B *= 2) {
       const int npairs = (int)((w - B + 2 * B - 1) / (2 * B)); // pairs whose second block is not empty
       const int m_last = (int)std::min<long long>(B, w - ((long long)(npairs - 1) * 2 * B + B)); // rows of the last pair's second block
@@ -682,117 +772,119 @@ struct DeviceLevelsImpl : public DeviceLevels {
       const long long sP = 2 * B * (ld + 1);
       auto level = [&](int p0, int cnt, int m2) {
         if (cnt <= 0) return;
-        const double *L21 = P + ((long long)p0 * 2 * B + B) * ld + (long long)p0 * 2 * B;
-        const double *X11 = P + (long long)p0 * sP;
-        const double *X22 = P + ((long long)p0 * 2 * B + B) * (ld + 1);
-        double       *T   = tmp.p + (long long)p0 * B * B;
-        GemmBatch     b1, b2;
+        T        *L21 = P + ((long long)p0 * 2 * B + B) * ld + (long long)p0 * 2 * B;
+        const T  *X11 = P + (long long)p0 * sP;
+        const T  *X22 = P + ((long long)p0 * 2 * B + B) * (ld + 1);
+        T        *Tm  = tmp.p + (long long)p0 * B * B;
+        GemmBatch b1, b2;
         b1.count = b2.count = cnt;
         b1.sA = sP, b1.sB = sP, b1.sC = B * B;
         b2.sA = sP, b2.sB = B * B, b2.sC = sP;
-        gemm(st, false, m2, (int)B, (int)B, 1.0, L21, ld, X11, ld, T, B, false, false, 0, 0, true, false, b1);                   // T = L21 X11 (X11 lower triangular)
-        gemm(st, false, m2, (int)B, m2, -1.0, X22, ld, T, B, const_cast<double *>(L21), ld, false, false, 0, 0, false, true, b2); // X21 = -X22 T (X22 lower triangular)
+        gemm<CS>(st, false, m2, (int)B, (int)B, 1.0, cd(L21), ld, cd(X11), ld, md(Tm), B, false, false, 0, 0, true, false, b1); // T = L21 X11 (X11 lower triangular)
+        gemm<CS>(st, false, m2, (int)B, m2, -1.0, cd(X22), ld, cd(Tm), B, md(L21), ld, false, false, 0, 0, false, true, b2);     // X21 = -X22 T (X22 lower triangular)
       };
       level(0, nfull, (int)B);
       if (nfull < npairs) level(nfull, 1, m_last);
     }
   }
   // bottom block (nb x w) <- bottom * top
-  void mult_bottom(double *P, long long ld, int w, int nb)
+  void mult_bottom(T *P, long long ld, int w, int nb)
   {
     if (!nb) return;
-    gemm(st, false, nb, w, w, 1.0, P + (long long)w * ld, ld, P, ld, tmp.p, w, false, false, 0, 0, true); // the inverted top block is lower triangular
-    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, tmp.p, (long long)w, P + (long long)w * ld, ld);
+    gemm<CS>(st, false, nb, w, w, 1.0, cd(P + (long long)w * ld), ld, cd(P), ld, md(tmp.p), w, false, false, 0, 0, true); // the inverted top block is lower triangular
+    hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, (const T *)tmp.p, (long long)w, P + (long long)w * ld, ld);
   }
   // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse (through the scratch: the product cannot be formed in place)
-  void right_tile(double *X, long long ld, int m, int jb, const double *B, bool transB)
+  void right_tile(T *X, long long ld, int m, int jb, const T *B, bool transB)
   {
     if (m <= 0) return;
-    gemm(st, transB, m, jb, jb, 1.0, X, ld, B, 64, tmp.p, 64, false);
-    hipLaunchKernelGGL(k_copy2d, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, tmp.p, 64LL, X, ld);
+    gemm<CS>(st, transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64, md(tmp.p), 64, false);
+    hipLaunchKernelGGL(k_copy2d<T>, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, (const T *)tmp.p, 64LL, X, ld);
   }
 
-  void scatter(double *P, size_t panel_doubles, const std::vector<long long> &pos, const std::vector<double> &val)
+  void scatter(T *P, size_t panel_scalars, const long long *pos, const double *val, size_t cnt)
   {
-    HIP_OK(hipMemsetAsync(P, 0, panel_doubles * sizeof(double), st));
-    if (pos.empty()) return;
-    const long long *dp = (const long long *)upload_ring().push(pos.data(), pos.size() * sizeof(long long), st);
-    const double    *dv = (const double *)upload_ring().push(val.data(), val.size() * sizeof(double), st);
-    hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)std::min<size_t>(1024, (pos.size() + 255) / 256)), dim3(256), 0, st, (long long)pos.size(), dp, dv, P);
+    HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
+    if (!cnt) return;
+    const long long *dp = (const long long *)upload_ring().push(pos, cnt * sizeof(long long), st);
+    const double    *dv = (const double *)upload_ring().push(val, cnt * sizeof(T), st);
+    hipLaunchKernelGGL(k_scatter_add<CS>, dim3((unsigned)std::min<size_t>(1024, (cnt * CS + 255) / 256)), dim3(256), 0, st, (long long)cnt, dp, dv, md(P));
   }
-  void process_sparse(idx_t k, const std::vector<long long> &posF, const std::vector<double> &valF, const std::vector<long long> &posG, const std::vector<double> &valG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
+  void process_sparse(idx_t k, const long long *posF, const double *valF, size_t nF, const long long *posG, const double *valG, size_t nG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
   {
     const Symbolic &s = hf->sym;
     const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
     const long long ld = hf->ldw[k];
-    scatter(D.F.p + hf->f_off[k], (size_t)h * ld, posF, valF);
-    if (hf->kind == FACT_LU) scatter(D.G.p + hf->f_off[k], (size_t)h * ld, posG, valG);
+    scatter(reinterpret_cast<T *>(D.F.p) + hf->f_off[k], (size_t)h * ld, posF, valF, nF);
+    if (hf->kind == FACT_LU) scatter(reinterpret_cast<T *>(D.G.p) + hf->f_off[k], (size_t)h * ld, posG, valG, nG);
     factor_front(k, children, rel);
   }
   // ---- blocked factorisations of the panel P (h rows, w columns, the original entries and the children's blocks assembled) ----
-  // Cholesky, right-looking by panels of NBP columns: inside a panel the 64-column tiles are factorised left-looking (products
-  // with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the large
-  // fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
+  // Cholesky (real scalars), right-looking by panels of NBP columns: inside a panel the 64-column tiles are factorised left-looking
+  // (products with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the
+  // large fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
   // workgroups each walking a K loop of thousands of steps -- the f64 MFMA pipe below 20 %.
   static constexpr int NBP = 256;
-  void factor_chol(double *P, long long ld, int w, int h)
+  void factor_chol(T *P, long long ld, int w, int h)
   {
-    for (int j0 = 0; j0 < w; j0 += NBP) {
-      const int jb = std::min(NBP, w - j0);
-      for (int t0 = 0; t0 < jb; t0 += 64) {
-        const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
-        double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096;
-        if (t0 > 0) gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, Pk + j0, ld, Pk + kb, ld, true); // the tiles of this panel to the left
-        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, flag.p);
-        right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
+    if constexpr (CS == 1) {
+      for (int j0 = 0; j0 < w; j0 += NBP) {
+        const int jb = std::min(NBP, w - j0);
+        for (int t0 = 0; t0 < jb; t0 += 64) {
+          const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
+          T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096;
+          if (t0 > 0) gemm<CS>(st, true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(Pk + j0), ld, md(Pk + kb), ld, true); // the tiles of this panel to the left
+          hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, flag.p);
+          right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
+        }
+        const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
+        if (r1 < w) gemm<CS>(st, true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(P + (long long)r1 * ld + j0), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
       }
-      const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
-      if (r1 < w) gemm(st, true, h - r1, w - r1, jb, -1.0, P + (long long)r1 * ld + j0, ld, P + (long long)r1 * ld + j0, ld, P + (long long)r1 * ld + r1, ld, true, true);
-    }
+    } else HH_CHECK(false, "numfact (device levels): complex matrices are factorised as L D L^T or LU");
   }
   // LDL^T, the same blocking; W = L D (scaled copies in the scratch) feeds the products
-  void factor_ldlt(double *P, long long ld, int w, int h, double *tinv2)
+  void factor_ldlt(T *P, long long ld, int w, int h, T *tinv2)
   {
     for (int j0 = 0; j0 < w; j0 += NBP) {
       const int jb = std::min(NBP, w - j0);
       for (int t0 = 0; t0 < jb; t0 += 64) {
         const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
-        double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096, *Td = tinv2 + (size_t)(kb / 64) * 4096;
+        T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096, *Td = tinv2 + (size_t)(kb / 64) * 4096;
         if (t0 > 0) {
           // W = L(kb:kb+tb, j0:kb) * D(j0:kb);  P(kb:h, kb:kb+tb) -= L(kb:h, j0:kb) * W^T
-          hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((t0 + 255) / 256), (unsigned)tb), dim3(256), 0, st, tb, t0, Pk + j0, ld, P + (long long)j0 * (ld + 1), ld, tmp.p, (long long)t0);
-          gemm(st, true, h - kb, tb, t0, -1.0, Pk + j0, ld, tmp.p, t0, Pk + kb, ld, true);
+          hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((t0 + 255) / 256), (unsigned)tb), dim3(256), 0, st, tb, t0, (const T *)(Pk + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)t0);
+          gemm<CS>(st, true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(tmp.p), t0, md(Pk + kb), ld, true);
         }
-        hipLaunchKernelGGL(k_ldlf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, Td, flag.p);
+        hipLaunchKernelGGL(k_ldlf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, tb, Tt, Td, flag.p);
         right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Td, true); // X <- X * inv(L_T)^T * D_T^{-1}
       }
       const int r1 = j0 + jb;
       if (r1 < w) {
         // W = L(r1:w, j0:r1) * D(j0:r1);  P(r1:h, r1:w) -= L(r1:h, j0:r1) * W^T
-        hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((jb + 255) / 256), (unsigned)(w - r1)), dim3(256), 0, st, w - r1, jb, P + (long long)r1 * ld + j0, ld, P + (long long)j0 * (ld + 1), ld, tmp.p, (long long)jb);
-        gemm(st, true, h - r1, w - r1, jb, -1.0, P + (long long)r1 * ld + j0, ld, tmp.p, jb, P + (long long)r1 * ld + r1, ld, true, true);
+        hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((jb + 255) / 256), (unsigned)(w - r1)), dim3(256), 0, st, w - r1, jb, (const T *)(P + (long long)r1 * ld + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)jb);
+        gemm<CS>(st, true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(tmp.p), jb, md(P + (long long)r1 * ld + r1), ld, true, true);
       }
     }
   }
   // LU: left-looking by 64 columns (column block of [A11; A21], row block of U inside A11, row block of U12^T)
-  void factor_lu(double *P, double *G, long long ld, int w, int nb, int h, double *tinv2, double *tinv3)
+  void factor_lu(T *P, T *G, long long ld, int w, int nb, int h, T *tinv2, T *tinv3)
   {
     const int ntile = (w + 63) / 64;
-    double   *Gb    = G + (long long)w * ld; // U12 transposed: rows below the block
+    T        *Gb    = G + (long long)w * ld; // U12 transposed: rows below the block
     for (int t = 0; t < ntile; ++t) {
       const int kb = 64 * t, jb = std::min<int>(64, w - kb), below = h - kb - jb;
-      double   *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
+      T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
       if (kb > 0) {
-        gemm(st, false, h - kb, jb, kb, -1.0, Pk, ld, P + kb, ld, Pk + kb, ld, true);                      // column block of [A11; A21]
-        gemm(st, false, jb, w - kb - jb, kb, -1.0, Pk, ld, P + kb + jb, ld, Pk + kb + jb, ld, true);      // row block of U inside A11
-        gemm(st, true, nb, jb, kb, -1.0, Gb, ld, Pk, ld, Gb + kb, ld, true);                               // row block of U12 (transposed)
+        gemm<CS>(st, false, h - kb, jb, kb, -1.0, cd(Pk), ld, cd(P + kb), ld, md(Pk + kb), ld, true);                 // column block of [A11; A21]
+        gemm<CS>(st, false, jb, w - kb - jb, kb, -1.0, cd(Pk), ld, cd(P + kb + jb), ld, md(Pk + kb + jb), ld, true); // row block of U inside A11
+        gemm<CS>(st, true, nb, jb, kb, -1.0, cd(Gb), ld, cd(Pk), ld, md(Gb + kb), ld, true);                          // row block of U12 (transposed)
       }
-      hipLaunchKernelGGL(k_getf2_inv, dim3(1), dim3(64), 0, st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
+      hipLaunchKernelGGL(k_getf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
       right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
       const int right = w - kb - jb;
       if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)
-        gemm(st, false, jb, right, jb, 1.0, Tt, 64, Pk + kb + jb, ld, tmp.p, right, false);
-        hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, tmp.p, (long long)right, Pk + kb + jb, ld);
+        gemm<CS>(st, false, jb, right, jb, 1.0, cd(Tt), 64, cd(Pk + kb + jb), ld, md(tmp.p), right, false);
+        hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, (const T *)tmp.p, (long long)right, Pk + kb + jb, ld);
       }
       right_tile(Gb + kb, ld, nb, jb, Tt, true); // U12^T rows: X <- X * inv(L_T)^T
     }
@@ -805,12 +897,12 @@ struct DeviceLevelsImpl : public DeviceLevels {
     const bool      lu = kind == FACT_LU;
     const idx_t     c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
     const long long ld = hf->ldw[k];
-    double         *P  = D.F.p + hf->f_off[k];
-    double         *G  = lu ? D.G.p + hf->f_off[k] : nullptr;
-    double *C = nullptr;
+    T              *P  = reinterpret_cast<T *>(D.F.p) + hf->f_off[k];
+    T              *G  = lu ? reinterpret_cast<T *>(D.G.p) + hf->f_off[k] : nullptr;
+    T              *C  = nullptr;
     if (nb) {
       C = take((size_t)nb * nb);
-      HIP_OK(hipMemsetAsync(C, 0, (size_t)nb * nb * sizeof(double), st));
+      HIP_OK(hipMemsetAsync(C, 0, (size_t)nb * nb * sizeof(T), st));
     }
     // ---- extend-add the children (their row maps travel through the pinned ring: nothing waits for the stream) ----
     for (size_t c = 0; c < children.size(); ++c) {
@@ -821,36 +913,36 @@ struct DeviceLevelsImpl : public DeviceLevels {
       if (!nbc) continue;
       const int *relp = (const int *)upload_ring().push(rel[c].data(), sizeof(int) * nbc, st);
       const dim3 grid((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4));
-      if (lu) hipLaunchKernelGGL(k_extend_add_full, grid, dim3(64, 4), 0, st, it->second, nbc, relp, P, G, ld, (int)w, C, (long long)nb);
-      else hipLaunchKernelGGL(k_extend_add, grid, dim3(64, 4), 0, st, it->second, nbc, relp, P, ld, (int)w, C, (long long)nb);
+      if (lu) hipLaunchKernelGGL(k_extend_add_full<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, relp, P, G, ld, (int)w, C, (long long)nb);
+      else hipLaunchKernelGGL(k_extend_add<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, relp, P, ld, (int)w, C, (long long)nb);
     }
     // ---- blocked factorisation of the panel ----
     const int ntile = (w + 63) / 64;
-    double   *tinv2 = tinv.p + (size_t)ntile * 4096, *tinv3 = tinv.p + (size_t)2 * ntile * 4096; // LDL^T: D^{-1} inv(L); LU: inv(U), inv(U)^T
+    T        *tinv2 = tinv.p + (size_t)ntile * 4096, *tinv3 = tinv.p + (size_t)2 * ntile * 4096; // LDL^T: D^{-1} inv(L); LU: inv(U), inv(U)^T
     if (kind == FACT_CHOL) factor_chol(P, ld, (int)w, (int)h);
     else if (kind == FACT_LDLT) factor_ldlt(P, ld, (int)w, (int)h, tinv2);
     else factor_lu(P, G, ld, (int)w, (int)nb, (int)h, tinv2, tinv3);
     // ---- Schur complement -> contribution block (lower triangle for the symmetric kinds, full for LU) ----
     if (nb) {
-      double *P21 = P + (long long)w * ld;
-      if (kind == FACT_CHOL) gemm(st, true, nb, nb, w, -1.0, P21, ld, P21, ld, C, nb, true, true);
+      T *P21 = P + (long long)w * ld;
+      if (kind == FACT_CHOL) gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(P21), ld, md(C), nb, true, true);
       else if (kind == FACT_LDLT) {
-        hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((w + 255) / 256), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, P21, ld, P, ld, tmp.p, (long long)w);
-        gemm(st, true, nb, nb, w, -1.0, P21, ld, tmp.p, w, C, nb, true, true);
-      } else gemm(st, true, nb, nb, w, -1.0, P21, ld, G + (long long)w * ld, ld, C, nb, true);
+        hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((w + 255) / 256), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, (const T *)P21, ld, (const T *)P, ld, tmp.p, (long long)w);
+        gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(tmp.p), w, md(C), nb, true, true);
+      } else gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(G + (long long)w * ld), ld, md(C), nb, true);
     }
     // ---- unit diagonals made explicit, D recorded (LDL^T), U11 split out of the F top block (LU) ----
-    if (lu) hipLaunchKernelGGL(k_split_u11, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, G, ld);
-    else hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
+    if (lu) hipLaunchKernelGGL(k_split_u11<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, G, ld);
+    else hipLaunchKernelGGL(k_zero_upper<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
     if (kind == FACT_LDLT) {
-      hipLaunchKernelGGL(k_extract_dinv, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, dvec.p);
-      HIP_OK(hipMemcpyAsync(hf->dinv.data() + c0, dvec.p, sizeof(double) * w, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipStreamSynchronize(st)); // dvec is reused by the next front
+      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, dvec.p);
+      HIP_OK(hipMemcpyAsync(hf->dinv.data() + (size_t)c0 * CS, dvec.p, sizeof(T) * w, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st)); // dvec is reused by the next front of this stream
     }
     if (hf->keep_plain) { // (the oracle's CPU baseline wants the plain factor: the front leaves the device before it is inverted)
       const double tp0 = now();
-      HIP_OK(hipMemcpyAsync(hf->Lplain.data() + hf->f_off[k], P, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (lu) HIP_OK(hipMemcpyAsync(hf->Uplain.data() + hf->f_off[k], G, (size_t)h * ld * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(hf->Lplain.data() + (size_t)hf->f_off[k] * CS, P, (size_t)h * ld * sizeof(T), hipMemcpyDeviceToHost, st));
+      if (lu) HIP_OK(hipMemcpyAsync(hf->Uplain.data() + (size_t)hf->f_off[k] * CS, G, (size_t)h * ld * sizeof(T), hipMemcpyDeviceToHost, st));
       HIP_OK(hipStreamSynchronize(st));
       hf->t_plain += now() - tp0;
     }
@@ -867,7 +959,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   {
     int f = 0;
     level_barrier(); // everything meets on every stream, the library stream included
-    st = scr.streams[0];
+    set_slot(0);
     if (getenv("HPDDM_HIP_PROFILE")) {
       const double t0 = now();
       HIP_OK(hipStreamSynchronize(st));
@@ -887,6 +979,10 @@ struct DeviceLevelsImpl : public DeviceLevels {
   }
 };
 
-DeviceLevels *make_device_levels(DeviceFactor &D) { return new DeviceLevelsImpl(D); }
+DeviceLevels *make_device_levels(DeviceFactor &D, bool cplx)
+{
+  if (cplx) return new DeviceLevelsImpl<zd>(D);
+  return new DeviceLevelsImpl<double>(D);
+}
 
 } // namespace hpddm_hip

@@ -358,7 +358,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   PermutedMatrix<T> P;
   build_permuted<T>(A, hf.ord, lu, P);
   const idx_t nlev_all = (idx_t)hf.level_ptr.size() - 1;
-  if (!dev || SC != 1) first_device_level = nlev_all; // complex scalars: every level on the host
+  if (!dev) first_device_level = nlev_all;
   first_device_level = std::min(first_device_level, nlev_all);
   hf.f_host = first_device_level >= nlev_all ? hf.f_size : hf.f_off[hf.level_blk[hf.level_ptr[first_device_level]]]; // panels are packed level by level
   hf.F.assign((size_t)hf.f_host * SC, 0.0);
@@ -567,24 +567,24 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
     if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
   }
-  if constexpr (SC == 1) if (first_device_level < nlev_all && !bad) {
-    // ---- hand-over: the remaining levels run on the device (real scalars) ----
+  if (first_device_level < nlev_all && !bad) {
+    // ---- hand-over: the remaining levels run on the device (real and complex scalars: numeric_device.hip) ----
     const double td0 = now();
     size_t cbd = 0;
     for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q) {
       const idx_t k = hf.level_blk[q], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
-      cbd += ((size_t)nb * nb + 15) / 16 * 16;
+      cbd += ((size_t)nb * nb * SC + 15) / 16 * 16;
       for (idx_t ch : children[k])
         if (s.height[ch] < first_device_level) {
           const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
-          cbd += (nbc * nbc + 15) / 16 * 16;
+          cbd += (nbc * nbc * SC + 15) / 16 * 16;
         }
     }
     const double tb0 = now();
     dev->begin(hf, cbd, first_device_level);
     const double tb1 = now();
     double       t_up = 0, t_prep = 0, t_proc = 0;
-    std::vector<double>           valF, valG;
+    std::vector<T>                valF, valG;
     std::vector<long long>        posF, posG;
     // the original entries of a device-level front travel as a list (position, value) and are scattered into the panel zeroed in
     // HBM: the zeros never cross PCIe (a dense host copy of every panel was 11 GB per 129^3 subdomain)
@@ -603,9 +603,9 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
           // the host keeps lower triangles only for the symmetric kinds: make sure the upper part is defined (zero) before the copy
           if (!lu)
-            for (idx_t i = 0; i < nbc; ++i) std::fill(cb[ch] + (size_t)i * nbc + i + 1, cb[ch] + (size_t)(i + 1) * nbc, 0.0);
-          dev->upload_cb(ch, cb[ch], nbc);
-          pool.put(cb[ch], (size_t)nbc * nbc);
+            for (idx_t i = 0; i < nbc; ++i) std::fill(cb[ch] + (size_t)i * nbc + i + 1, cb[ch] + (size_t)(i + 1) * nbc, T(0));
+          dev->upload_cb(ch, reinterpret_cast<const double *>(cb[ch]), nbc);
+          pool.put(reinterpret_cast<double *>(cb[ch]), (size_t)nbc * nbc * SC);
           cb[ch] = nullptr;
         }
       const double tf1 = now();
@@ -629,7 +629,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       for (idx_t i = 0; i < w; ++i) rel[c0 + i] = -1;
       for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
       const double tf2 = now();
-      dev->process_sparse(k, posF, valF, posG, valG, children[k], maps);
+      dev->process_sparse(k, posF.data(), reinterpret_cast<const double *>(valF.data()), posF.size(), posG.data(), reinterpret_cast<const double *>(valG.data()), posG.size(), children[k], maps);
       t_up += tf1 - tf0, t_prep += tf2 - tf1, t_proc += now() - tf2;
     }
     const double te0 = now();
@@ -645,7 +645,7 @@ void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevel
 {
   if (A.cplx) {
     HH_CHECK(kind != FACT_CHOL, "numfact: complex matrices are factorised as LDL^T (complex symmetric) or LU");
-    factor_numeric_t<std::complex<double>>(A, kind, hf, nullptr, first_device_level);
+    factor_numeric_t<std::complex<double>>(A, kind, hf, dev, first_device_level);
   } else factor_numeric_t<double>(A, kind, hf, dev, first_device_level);
 }
 

@@ -129,3 +129,38 @@ def test_helmholtz_like_two_level_block_gmres_against_oracle(correction):
     res = A.compute_residual(sol, f)
     assert np.all(res[1::2] <= 2e-6 * res[0::2] * 50)   # right-preconditioned: true residual within the usual factor of the estimate
     A.destroy()
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_complex_factorisation_upper_levels_on_the_device(where, monkeypatch):
+    """the upper levels of the complex factorisation on the device (numeric_device.hip with T = (re, im) pairs: the real MFMA GEMM on
+    the embedded load of B, complex tile kernels with the host's pivot rule) against the host levels only and SuperLU -- complex
+    symmetric (L D L^T, plain transposes) and general complex (LU), wide separators, 1 / 3 / 8 right-hand sides"""
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where == "device" else "100000")
+    n = 18
+    K = _laplace3d(n)
+    N = n ** 3
+    k2 = (2.5 * np.pi) ** 2
+    A = (K - k2 * sp.identity(N) + 1j * 0.8 * k2 * sp.identity(N)).tocsr()
+    assert _check(A, sym_storage=True, mu=1) == 1
+    assert _check(A, mu=8) == 1
+    G = sp.random(N, N, density=1e-3, random_state=3, format="csr")
+    B = (K + 0.2 * sp.triu(K, 1) + 1j * 0.1 * float(n * n) * G).tocsr()
+    assert _check(B, mu=3) == 2
+
+
+def test_complex_device_levels_refuse_a_collapsed_pivot(monkeypatch):
+    """the pivot rule of the complex tile kernels: a zero diagonal block of a complex symmetric matrix breaks down loudly on the device
+    levels as it does on the host"""
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "64")
+    n = 12
+    K = _laplace3d(n)
+    N = n ** 3
+    A = sp.lil_matrix((K * (1.0 + 0.5j)).tocsr())
+    A.setdiag(0.0)                                  # zero pivots everywhere: L D L^T without pivoting cannot go on
+    S = hpddm.Subdomain()
+    M = A.tocsr()
+    M.sort_indices()
+    with pytest.raises(hpddm.HpddmHipError):
+        S.numfact(N, M.indptr, M.indices, M.data.astype(np.complex128), sym=False)
+    S.destroy()
