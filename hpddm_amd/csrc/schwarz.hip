@@ -8,6 +8,7 @@
 // The halo sum of co-located subdomains is a gather (no message, no atomics): dof i of subdomain s reads the D-scaled
 // values of its duplicates in the neighbours through a CSR list built once from Subdomain::map_.
 #include "schwarz.hpp"
+#include <numeric>
 #include <algorithm>
 #include <cmath>
 #include <array>
@@ -92,6 +93,39 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
       if (lane == 0) {
         double *yp = y + v0 * mu + (long long)nu * n + r;
         *yp        = (beta == 0.0 ? 0.0 : beta * *yp) + alpha * acc;
+      }
+    }
+  }
+}
+
+// the same for K = std::complex<double> on the complex matrix itself (Wrapper::csrmm with complex scalars, include/HPDDM_wrapper.hpp:
+// 697-733): 16 + 4 bytes per entry where the real-equivalent embedding reads 32 + 4 (2 x 2 blocks); the vectors are the (re, im)
+// pairs of the caller either way.  n = 2 x (complex rows) as everywhere in the complex Schwarz layer.
+__global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
+{
+  const int s = blockIdx.y, n = nn[s], nc = n >> 1;
+  const long long v0  = voff[s];
+  const int      *ias = ia + iaoff[s];
+  const int       lane = threadIdx.x & 7;
+  for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < nc; r += (gridDim.x * blockDim.x) >> 3) {
+    const int p0 = ias[r], p1 = ias[r + 1];
+    for (int nu = 0; nu < mu; ++nu) {
+      const double *xs = x + v0 * mu + (long long)nu * n;
+      double        ar = 0.0, ai = 0.0;
+      for (int p = p0 + lane; p < p1; p += 8) {
+        const double2 av = *reinterpret_cast<const double2 *>(a + 2 * (long long)p), xv = *reinterpret_cast<const double2 *>(xs + 2 * (long long)ja[p]);
+        ar = fma(av.x, xv.x, fma(-av.y, xv.y, ar));
+        ai = fma(av.x, xv.y, fma(av.y, xv.x, ai));
+      }
+      ar += __shfl_xor(ar, 4), ai += __shfl_xor(ai, 4);
+      ar += __shfl_xor(ar, 2), ai += __shfl_xor(ai, 2);
+      ar += __shfl_xor(ar, 1), ai += __shfl_xor(ai, 1);
+      if (lane == 0) {
+        double2 *yp = reinterpret_cast<double2 *>(y + v0 * mu + (long long)nu * n + 2 * (long long)r);
+        double2  o  = *yp;
+        o.x = (beta == 0.0 ? 0.0 : beta * o.x) + alpha * ar;
+        o.y = (beta == 0.0 ? 0.0 : beta * o.y) + alpha * ai;
+        *yp = o;
       }
     }
   }
@@ -512,6 +546,51 @@ void Schwarz::build_device()
   a_d.upload(acat, st);
   build_bsr();
   iaoff_d.upload(iaoff, st);
+  zia_d.release(), zja_d.release(), za_d.release(), ziaoff_d.release();
+  if (is_complex && getopt("hip_native_complex_gmv", 1) != 0) {
+    // the complex matrices as handed over (symmetric storage expanded: complex SYMMETRIC, no conjugation), 0-based, concatenated
+    std::vector<int>       zi, zj;
+    std::vector<double>    zv;
+    std::vector<long long> zoff(nsub);
+    bool                   ok = true;
+    for (int s = 0; s < nsub && ok; ++s) {
+      const SchwarzSub &S  = subs[s];
+      const int         nc = S.n / 2;
+      ok                   = (int)S.zia.size() == nc + 1;
+      if (!ok) break;
+      std::vector<int> cnt(nc + 1, 0);
+      for (int i = 0; i < nc; ++i)
+        for (int p = S.zia[i] - S.zbase; p < S.zia[i + 1] - S.zbase; ++p) {
+          const int j = S.zja[p] - S.zbase;
+          ++cnt[i + 1];
+          if (S.zsym && j != i) ++cnt[j + 1];
+        }
+      zoff[s]         = (long long)zi.size();
+      const int shift = (int)zj.size();
+      HH_CHECK((long long)shift + std::accumulate(cnt.begin(), cnt.end(), 0LL) < 2147483647LL, "more than 2^31 matrix entries on one GPU");
+      std::vector<int> rp(nc + 1, 0);
+      for (int i = 0; i < nc; ++i) rp[i + 1] = rp[i] + cnt[i + 1];
+      zj.resize((size_t)shift + rp[nc]);
+      zv.resize(2 * ((size_t)shift + rp[nc]));
+      std::vector<int> pos(rp.begin(), rp.end() - 1);
+      for (int i = 0; i < nc; ++i)
+        for (int p = S.zia[i] - S.zbase; p < S.zia[i + 1] - S.zbase; ++p) {
+          const int j = S.zja[p] - S.zbase;
+          auto      put = [&](int row, int col) {
+            const size_t q = (size_t)shift + pos[row]++;
+            zj[q]          = col;
+            zv[2 * q] = S.za[2 * (size_t)p], zv[2 * q + 1] = S.za[2 * (size_t)p + 1];
+          };
+          put(i, j);
+          if (S.zsym && j != i) put(j, i);
+        }
+      for (int i = 0; i <= nc; ++i) zi.push_back(rp[i] + shift);
+    }
+    if (ok) {
+      zia_d.upload(zi, st), zja_d.upload(zj, st), za_d.upload(zv, st), ziaoff_d.upload(zoff, st);
+      HIP_OK(hipStreamSynchronize(st));
+    }
+  }
   // halo gather lists (co-located neighbours); neighbours on other GPUs go through the pack / transport / unpack path
   build_halo_lists();
   std::vector<int> cnt((size_t)ntot + 1, 0);
@@ -1005,6 +1084,10 @@ void Schwarz::build_bsr()
 
 void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta)
 {
+  if (zia_d.p) { // complex operators: the complex matrix itself
+    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 8 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta);
+    return;
+  }
   if (bsr_bs) {
     const dim3 g((unsigned)std::min(4096, (nmax / bsr_bs * 8 + 255) / 256), (unsigned)nsub);
     if (bsr_bs == 3) hipLaunchKernelGGL(k_bsrmm<3>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta);

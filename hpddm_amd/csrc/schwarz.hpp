@@ -105,6 +105,10 @@ struct Schwarz {
   DevBuf<double>         ba_d;                // bs x bs blocks, row-major
   long long              nnzb = 0;
   void                   build_bsr();
+  // complex operators: the complex matrices themselves for GMV (16 + 4 bytes per entry; the embedding above stays for the coarse assembly)
+  DevBuf<int>            zia_d, zja_d;
+  DevBuf<long long>      ziaoff_d;
+  DevBuf<double>         za_d;
   DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
   SolvePlan              plan;
   // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
