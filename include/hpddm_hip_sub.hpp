@@ -9,7 +9,8 @@
  *
  * compiles the UNCHANGED reference driver with the factorisation on the host and every Solver::solve on the GPU
  * (host vectors are staged through PCIe here; the device-resident path is HpddmHipSchwarz*).
- * K = double, and K = std::complex<double> through the real-equivalent embedding of HpddmHipSubdomainNumfactZ.
+ * K = double, and K = std::complex<double> (HpddmHipSubdomainNumfactZ / SolveZ: native complex panels, 16 bytes per entry, upper
+ * levels of the complex factorisation on the device).
  */
 #ifndef HPDDM_HIP_SUB_HPP_
 #define HPDDM_HIP_SUB_HPP_

@@ -90,3 +90,26 @@ def test_in_place_and_batched_subdomains():
         ref = spl.splu(full.tocsc()).solve(f[s])
         assert np.abs(x[s] - ref).max() <= 1e-10 * np.abs(ref).max()
     A.destroy()
+
+
+@pytest.mark.parametrize("mu", [1, 16])
+def test_split_row_hand_over_is_bitwise_reproducible(mu):
+    """the upper backward levels are split over several workgroups that publish partial sums (write-through stores) and meet at an
+    agent-scope arrival counter; the last arriver adds the parts in part order.  The same solve repeated 150 times, with other
+    work in flight on the same GPU in between, must return the same bits every time (both the VALU tiles, mu = 1, and the
+    16-column engine) -- a stale or torn partial sum would show up as a difference"""
+    from hpddm_amd.generate import generate3d
+    subs = generate3d(40, 8, overlap=1, sym=True, rhs="smooth")     # 21^3 per subdomain: wide separators, split parts on the top levels
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+    A.call_numfact()
+    rng = np.random.default_rng(12)
+    f = [np.asfortranarray(rng.standard_normal((s["n"], mu))) for s in subs]
+    ref = A.local_solve(f)
+    g = [np.asfortranarray(rng.standard_normal((s["n"], 3))) for s in subs]
+    for it in range(150):
+        if it % 3 == 0:
+            A.gmv(g)                                                  # uneven load between the solves
+        x = A.local_solve(f)
+        for a, b in zip(x, ref):
+            assert np.array_equal(a, b), it
+    A.destroy()
