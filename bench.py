@@ -524,12 +524,33 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         cand *= 2
     tb, rb, xl = sample(lambda r: sptrsv_oracle.time_batch_levels(factors, f, reps=r, threads=nthr))
     agree = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xl))
+    # (c) a team of threads per subdomain (nested OpenMP: the row loops of the large supernodes shared by the team).  One core
+    # streams a factor at 12-17 GB/s, so (a) cannot go beyond 8 x that; the team size follows what this process may use -- the
+    # smaller of the affinity mask and the container's CPU quota (cpu.max), which the logical core count ignores
+    quota_cpus = ncores
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+        if q != "max":
+            quota_cpus = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota_cpus = min(quota_cpus, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    team = max(1, min(8, quota_cpus // nsub))
+    tc, rc, xt = (ta, ra, xs)
+    if team > 1:
+        tc, rc, xt = sample(lambda r: sptrsv_oracle.time_batch_teams(factors, f, reps=r, team=team))
+        agree = max(agree, max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xt)))
     t1 = time.perf_counter()
     for _ in range(3):
         orc.exchange(xs)
     tex = (time.perf_counter() - t1) / 3
-    best, cores = (ta, threads) if ta <= tb else (tb, nthr)
+    best, cores = min(((ta, threads), (tb, nthr), (tc, nsub * team)), key=lambda v: v[0])
     per_apply = best + tex
+    bytes_host = 2.0 * A.stats()["nnz_L"] * 8.0   # the plain factor read once per sweep (algorithmic bytes, as for the device)
     try:
         with open("/sys/fs/cgroup/cpu.max") as fh:
             quota = fh.read().strip()
@@ -542,8 +563,11 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "kind": "port", "cgroup_cpu_max": quota, "sched_affinity_cpus": affinity,
             "sample": f"one-level apply of the same {nsub}-subdomain operator (all {nsub} local substitutions + numpy halo sum, {tex * 1e3:.1f} ms): "
                       f"(a) one thread per subdomain on {threads} threads, {ra} applies, {ta * 1e3:.1f} ms each; "
-                      f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms each; value = the faster; "
-                      f"the two agree to {agree:.1e}",
+                      f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms each; "
+                      f"(c) {team} threads per subdomain = {nsub * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs), {rc} applies, {tc * 1e3:.1f} ms each; "
+                      f"value = the fastest; they agree to {agree:.1e}",
+            "host_GBps": bytes_host / best / 1e9, "usable_cpus": quota_cpus,
+            "teams": {"threads_per_subdomain": team, "threads": nsub * team, "substitution_ms": tc * 1e3, "applies_per_sec": 1.0 / (tc + tex)},
             "seconds_per_apply": per_apply, "host_cores": ncores,
             "one_thread_per_subdomain": {"threads": threads, "substitution_ms": ta * 1e3, "applies_per_sec": 1.0 / (ta + tex)},
             "level_parallel": {"threads": nthr, "substitution_ms": tb * 1e3, "applies_per_sec": 1.0 / (tb + tex)},

@@ -104,6 +104,100 @@ double oracle_sptrsv_batch(int nsub, const oracle_factor *fs, const double *cons
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * One TEAM of threads per subdomain (nested OpenMP): the substitution of solve_one with the row loops of the large supernodes
+ * shared by the team -- forward: the rows under the diagonal block are independent dot products; backward: every thread subtracts
+ * its rows from a private copy of the right-hand side of the block, the copies are summed.  A single core streams a factor at
+ * 12-17 GB/s, so one thread per subdomain (the reference's layout) leaves the host at 8 x that whatever the box; with the
+ * container's CPU quota of 16 this is the variant that uses it (2 threads per subdomain).  Same arithmetic as solve_one up to the
+ * order of the sums in the backward sweep.
+ * ------------------------------------------------------------------------------------------------------------------- */
+#define TEAM_MIN_WORK (1 << 15) /* entries of the off-diagonal part from which a supernode is worth the team */
+static void solve_one_team(const oracle_factor *f, const double *b, double *x, double *work, double *tpriv, ll wmax, int team)
+{
+  const ll n = f->n;
+  double  *y = work, *t = work + n;
+  for (ll i = 0; i < n; ++i) y[i] = b[f->perm[i]];
+  for (ll k = 0; k < f->nblk; ++k) {
+    const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const double *P  = f->L + f->f_off[k];
+    const ll     *r  = f->rows + f->row_ptr[k];
+    for (ll i = 0; i < w; ++i) {
+      double        s   = y[c0 + i];
+      const double *row = P + i * ld;
+      for (ll j = 0; j < i; ++j) s -= row[j] * y[c0 + j];
+      y[c0 + i] = s / row[i];
+    }
+#pragma omp parallel for schedule(static) num_threads(team) if (team > 1 && nb * w >= TEAM_MIN_WORK)
+    for (ll i = 0; i < nb; ++i) {
+      const double *row = P + (w + i) * ld;
+      double        s   = 0.0;
+      for (ll j = 0; j < w; ++j) s += row[j] * y[c0 + j];
+      y[r[i]] -= s;
+    }
+  }
+  if (f->kind == 1)
+    for (ll i = 0; i < n; ++i) y[i] *= f->dinv[i];
+  const double *B = f->kind == 2 ? f->U : f->L;
+  for (ll k = f->nblk - 1; k >= 0; --k) {
+    const ll      c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const double *P  = B + f->f_off[k];
+    const ll     *r  = f->rows + f->row_ptr[k];
+    for (ll j = 0; j < w; ++j) t[j] = y[c0 + j];
+    if (team > 1 && nb * w >= TEAM_MIN_WORK) {
+#pragma omp parallel num_threads(team)
+      {
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+        double   *tp  = tpriv + (size_t)tid * wmax;
+        for (ll j = 0; j < w; ++j) tp[j] = 0.0;
+        const ll i0 = nb * tid / nt, i1 = nb * (tid + 1) / nt;
+        for (ll i = i0; i < i1; ++i) {
+          const double *row = P + (w + i) * ld;
+          const double  xi  = y[r[i]];
+          for (ll j = 0; j < w; ++j) tp[j] -= row[j] * xi;
+        }
+      }
+      for (int q = 0; q < team; ++q)
+        for (ll j = 0; j < w; ++j) t[j] += tpriv[(size_t)q * wmax + j];
+    } else
+      for (ll i = 0; i < nb; ++i) {
+        const double *row = P + (w + i) * ld;
+        const double  xi  = y[r[i]];
+        for (ll j = 0; j < w; ++j) t[j] -= row[j] * xi;
+      }
+    for (ll i = w - 1; i >= 0; --i) {
+      const double *row = P + i * ld;
+      const double  xi  = t[i] / row[i];
+      y[c0 + i]         = xi;
+      for (ll j = 0; j < i; ++j) t[j] -= row[j] * xi;
+    }
+  }
+  for (ll i = 0; i < n; ++i) x[f->perm[i]] = y[i];
+}
+
+/* every subdomain at once, `team` threads each (nsub x team threads in all); one right-hand side; wall seconds of `reps` repetitions */
+double oracle_sptrsv_batch_teams(int nsub, const oracle_factor *fs, const double *const *b, double *const *x, int reps, int team)
+{
+  struct timespec t0, t1;
+  omp_set_max_active_levels(2);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma omp parallel for schedule(static, 1) num_threads(nsub)
+    for (int s = 0; s < nsub; ++s) {
+      ll wmax = 1;
+      for (ll k = 0; k < fs[s].nblk; ++k)
+        if (fs[s].blk_ptr[k + 1] - fs[s].blk_ptr[k] > wmax) wmax = fs[s].blk_ptr[k + 1] - fs[s].blk_ptr[k];
+      double *work  = (double *)malloc(sizeof(double) * 2 * (size_t)fs[s].n);
+      double *tpriv = (double *)malloc(sizeof(double) * (size_t)wmax * (size_t)(team > 0 ? team : 1));
+      solve_one_team(&fs[s], b[s], x[s], work, tpriv, wmax, team);
+      free(tpriv);
+      free(work);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * The same substitution on ALL host cores: level-scheduled over the assembly tree (height[k] = level of supernode k, as
  * exported by the product), every subdomain at once.  A level with many supernodes is a parallel loop over them (one thread
  * per supernode, contributions to ancestors' rows through atomic adds); the few large supernodes near the root are taken one

@@ -22,6 +22,7 @@ def lib():
         _lib = ctypes.CDLL(path)
         _lib.oracle_sptrsv_batch.restype = ctypes.c_double
         _lib.oracle_sptrsv_batch_levels.restype = ctypes.c_double
+        _lib.oracle_sptrsv_batch_teams.restype = ctypes.c_double
         assert _lib.oracle_factor_sizeof() == ctypes.sizeof(_Factor)
     return _lib
 
@@ -70,6 +71,19 @@ def time_batch(factors, bs, reps, threads):
     bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
     sec = lib().oracle_sptrsv_batch(n, arr, bp, xp, mu, reps, threads)
+    return sec, xs
+
+
+def time_batch_teams(factors, bs, reps, team):
+    """the same with a team of `team` threads per subdomain (nested OpenMP: the row loops of the large supernodes shared)"""
+    n = len(factors)
+    arr = (_Factor * n)(*[f.struct() for f in factors])
+    bs = [np.ascontiguousarray(b, dtype=np.float64) for b in bs]
+    assert all(b.ndim == 1 for b in bs)
+    xs = [np.empty_like(b) for b in bs]
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
+    sec = lib().oracle_sptrsv_batch_teams(n, arr, bp, xp, reps, team)
     return sec, xs
 
 

@@ -61,4 +61,8 @@ def test_level_parallel_substitution_large_supernodes():
     for threads in (1, 3, 8):
         _, xl = sptrsv_oracle.time_batch_levels([pf], [b], reps=1, threads=threads)
         assert np.abs(xl[0] - ref).max() <= 1e-12 * np.abs(ref).max()
+    # teams of threads per subdomain (nested OpenMP on the row loops of the large supernodes): same solution
+    for team in (1, 2, 3):
+        _, xt = sptrsv_oracle.time_batch_teams([pf, pf], [b, b], reps=1, team=team)
+        assert np.abs(xt[0] - ref).max() <= 1e-12 * np.abs(ref).max() and np.abs(xt[1] - ref).max() <= 1e-12 * np.abs(ref).max()
     S.destroy()
