@@ -14,6 +14,17 @@ namespace hpddm_hip {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// entry (row r, column c) of the deflation vectors of one subdomain (Zs: its first entry, n rows per column).  zc != 0: a complex
+// operator -- the real columns come in pairs (2k: z_k as (re, im) pairs; 2k + 1: i z_k, i.e. (-im, re)) and only the z_k are kept
+// in HBM (16 bytes per complex entry; the full real-equivalent embedding has 32): the odd columns are read off the even ones,
+// from the same lines.
+__device__ static inline double zentry(const double *__restrict__ Zs, int n, int c, int r, int zc)
+{
+  if (!zc) return Zs[(long long)c * n + r];
+  const double *b = Zs + (long long)(c >> 1) * n;
+  return (c & 1) ? ((r & 1) ? b[r - 1] : -b[r + 1]) : b[r];
+}
+
 static constexpr int ZT_ROWS = 128;           // rows of Z staged per workgroup tile
 static constexpr int ZT_LD   = ZT_ROWS + 4;   // LDS leading dimension: column stride of 8 dwords mod 64 -> <= 2-way conflicts
 static constexpr int ZT_NU   = 32;            // deflation vectors per pass (two 16-wide M tiles)
@@ -21,7 +32,7 @@ static constexpr int ZT_MU   = 16;            // right-hand sides per pass (one 
 
 // partial[s][blk][m][nn] = sum over the rows of the block of Z[i, m0+m] * d[i] * in[i, nu0+nn]
 // grid: (blocks per subdomain, nsub); 256 threads = 4 wavefronts, each contracting 32 rows of a 128-row tile per tile
-__global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int mu, int m0, int nu0)
+__global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int mu, int m0, int nu0, int zc)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *zs = lds;                    // [ZT_NU][ZT_LD]
@@ -31,13 +42,13 @@ __global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ v
   const int       tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int       mcols = min(ZT_NU, nu_s - m0), ncols = min(ZT_MU, mu - nu0);
   v4f64           acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-  const double   *Zs = Z + zoff[s] + (long long)m0 * n;
+  const double   *Zs = Z + zoff[s];
   if (mcols > 0) {
     for (int i0 = blockIdx.x * ZT_ROWS; i0 < n; i0 += gridDim.x * ZT_ROWS) {
       // stage: consecutive threads read consecutive rows of one column (coalesced), zero beyond n / beyond the live columns
       for (int idx = tid; idx < ZT_NU * ZT_ROWS; idx += 256) {
         const int c = idx / ZT_ROWS, r = idx - c * ZT_ROWS;
-        zs[c * ZT_LD + r] = (c < mcols && i0 + r < n) ? Zs[(long long)c * n + i0 + r] : 0.0;
+        zs[c * ZT_LD + r] = (c < mcols && i0 + r < n) ? zentry(Zs, n, m0 + c, i0 + r, zc) : 0.0;
       }
       for (int idx = tid; idx < ZT_MU * ZT_ROWS; idx += 256) {
         const int c = idx / ZT_ROWS, r = idx - c * ZT_ROWS;
@@ -87,7 +98,7 @@ __global__ void k_zt_reduce(const double *__restrict__ partial, int nblk, const 
 }
 
 // out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu] ; each wavefront produces 64 rows x (<= 16 rhs)
-__global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0)
+__global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0, int zc)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
   const long long v0 = voff[s];
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int    r = i0 + 16 * t + m;
-        const double a = (kk < nu_s && r < n) ? Zs[(long long)kk * n + r] : 0.0;                            // A[i = lane&15][k]
+        const double a = (kk < nu_s && r < n) ? zentry(Zs, n, kk, r, zc) : 0.0;                            // A[i = lane&15][k]
         acc[t]         = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
       }
     }
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
 // once with every thread on its own row (columns of Z are contiguous: coalesced), no LDS staging ----
 // partial[s][blk][m - m0][nu] (same layout as k_zt_mfma) for the 8 deflation vectors [m0 + 8 z, m0 + 8 z + 8), z = blockIdx.z
 template <int MU>
-__global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int m0)
+__global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int m0, int zc)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
   const long long v0 = voff[s];
@@ -137,14 +148,14 @@ __global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) acc[k][nu] = 0.0;
   if (kc > 0) {
-    const double *Zs = Z + zoff[s] + (long long)k0 * n;
+    const double *Zs = Z + zoff[s];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
       double dr[MU];
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) dr[nu] = d[v0 + i] * in[v0 * MU + (long long)nu * n + i];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const double z = k < kc ? Zs[(long long)k * n + i] : 0.0;
+        const double z = k < kc ? zentry(Zs, n, k0 + k, i, zc) : 0.0;
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) acc[k][nu] = fma(z, dr[nu], acc[k][nu]);
       }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__
 }
 // out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu], one thread per row
 template <int MU>
-__global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim)
+__global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim, int zc)
 {
   extern __shared__ double ys[]; // [nu_s][MU]
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ 
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) acc[nu] = 0.0;
     for (int k = 0; k < nu_s; ++k) {
-      const double z = Zs[(long long)k * n + i];
+      const double z = zentry(Zs, n, k, i, zc);
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) acc[nu] = fma(z, ys[k * MU + nu], acc[nu]);
     }
@@ -203,15 +214,15 @@ void Schwarz::panel_zt(const double *in, double *uc, int mu)
     // GEMV-shaped: streaming kernels (the MFMA tiles would carry 14-15 empty right-hand-side columns)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       const dim3 g((unsigned)nblk, (unsigned)nsub, (unsigned)((std::min(ZT_NU, numax - m0) + 7) / 8));
-      if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
-      else hipLaunchKernelGGL(k_zt_stream<2>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0);
+      if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0, z_compact ? 1 : 0);
+      else hipLaunchKernelGGL(k_zt_stream<2>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0, z_compact ? 1 : 0);
       hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, 0);
     }
     return;
   }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
-      hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
+      hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0, z_compact ? 1 : 0);
       hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
     }
 }
@@ -225,12 +236,12 @@ void Schwarz::panel_z(const double *y, double *zy, int mu)
   if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
     const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
     const size_t l2 = (size_t)numax * mu * sizeof(double);
-    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim);
-    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim);
+    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
+    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
     return;
   }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
-    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0);
+    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, z_compact ? 1 : 0);
 }
 
 void Schwarz::deflation_panel(const double *in, double *zy, int mu)

@@ -463,6 +463,7 @@ void Schwarz::set_vectors_z(int s, int nu, const double *Z)
       R[(size_t)(2 * k + 1) * n2 + 2 * i] = -zi, R[(size_t)(2 * k + 1) * n2 + 2 * i + 1] = zr;
     }
   set_vectors(s, 2 * nu, R.data());
+  subs[s].zpairs = true; // columns 2k, 2k + 1 = z_k, i z_k
 }
 
 static const std::vector<int> &peer_list(const Schwarz &A, int t_local, int gid_s)
@@ -506,6 +507,7 @@ void Schwarz::set_vectors(int s, int nu, const double *Z)
 {
   HH_CHECK(s >= 0 && s < nsub && nu >= 0, "SetVectors: bad argument");
   subs[s].nu = nu;
+  subs[s].zpairs = false;
   subs[s].Z.assign(Z, Z + (size_t)nu * subs[s].n);
   coarse_ready = false;
 }
@@ -815,7 +817,7 @@ void Schwarz::build_coarse()
   }
   if (uniform) {
     const int nu0 = subs[0].nu;
-    upload_vectors(); // Z_d, offsets, local coarse numbering (cdim)
+    upload_vectors(false); // Z_d (whole embedding for complex operators), offsets, local coarse numbering (cdim)
     DevBuf<double> dz_d, t_d, uc;
     dz_d.alloc((size_t)ntot * nu0);
     t_d.alloc((size_t)ntot * nu0);
@@ -969,15 +971,20 @@ void Schwarz::build_coarse()
   }
   std::vector<double> Ecopy(E);
   invert_dense(cdim_g, Ecopy, Einv);
-  upload_vectors();
+  upload_vectors(true);
   Einv_d.upload(Einv.data() + (size_t)coff_g0 * cdim_g, (size_t)cdim * cdim_g, st); // the rows of the local subdomains
   HIP_OK(hipStreamSynchronize(st));
   coarse_ready = true;
 }
 
-void Schwarz::upload_vectors()
+void Schwarz::upload_vectors(bool compact)
 {
+  // compact: complex operators whose deflation vectors all came as complex vectors (set_vectors_z) keep the nu / 2 complex vectors
+  // only (the even columns of the embedding; the panel kernels read the odd ones off them: deflation_mfma.hip, zentry).  The
+  // coarse assembly wants the whole embedding (its kernels take Z as a plain multi-vector): it uploads with compact = false.
   hipStream_t st = library_stream();
+  z_compact      = compact && is_complex && getopt("hip_compact_z", 1) != 0;
+  for (int s = 0; s < nsub && z_compact; ++s) z_compact = subs[s].zpairs && subs[s].nu % 2 == 0 && subs[s].n % 2 == 0;
   coff.assign(nsub + 1, 0);
   for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;
   cdim = coff[nsub];
@@ -987,7 +994,9 @@ void Schwarz::upload_vectors()
   for (int s = 0; s < nsub; ++s) {
     zoff[s] = (long long)zcat.size();
     nus[s]  = subs[s].nu;
-    zcat.insert(zcat.end(), subs[s].Z.begin(), subs[s].Z.end());
+    if (!z_compact) zcat.insert(zcat.end(), subs[s].Z.begin(), subs[s].Z.end());
+    else
+      for (int k = 0; k < subs[s].nu; k += 2) zcat.insert(zcat.end(), subs[s].Z.begin() + (size_t)k * subs[s].n, subs[s].Z.begin() + (size_t)(k + 1) * subs[s].n);
   }
   Z_d.upload(zcat, st);
   zoff_d.upload(zoff, st);

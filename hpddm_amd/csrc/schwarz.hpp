@@ -39,6 +39,7 @@ struct SchwarzSub {
   std::vector<double> d;                             // Schwarz::d_
   std::vector<double> Z;                             // Preconditioner::ev_: n x nu column-major
   int                 nu = 0;
+  bool                zpairs = false; // complex operators: the columns of Z are pairs (z_k, i z_k) (set_vectors_z)
   std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B)
   int                 gevp_iterations = 0;
   std::unique_ptr<LocalSolver> ls;
@@ -176,7 +177,8 @@ struct Schwarz {
   void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip) = the three below
   void panel_zt(const double *in, double *uc, int mu);        // uc = Z^T (D in)
   void panel_z(const double *y, double *zy, int mu);          // zy = Z y
-  void upload_vectors();                                      // Z, its offsets and the local coarse numbering to the device
+  void upload_vectors(bool compact = false);                  // Z, its offsets and the local coarse numbering to the device
+  bool z_compact = false;                                     // complex operators: Z_d holds the complex vectors only (16 bytes per entry)
   void coarse_solve(const double *uc, double *y, int mu);     // y = E^{-1} uc
   void apply(const double *in, double *out, int mu);
   void diag(const double *in, double *out, int mu);
