@@ -87,6 +87,7 @@ def _declare(lib):
         "HpddmHipSchwarzLevelTimes": (I, [P, I, I, P, I]),
         "HpddmHipSchwarzGetSubdomain": (P, [P, I]),
         "HpddmHipPanelCreate": (P, [I, I, P, P]),
+        "HpddmHipPanelCreateZ": (P, [I, I, P, P]),
         "HpddmHipPanelZtD": (I, [P, P, P, US]),
         "HpddmHipPanelZ": (I, [P, P, P, US]),
         "HpddmHipPanelDestroy": (None, [P]),

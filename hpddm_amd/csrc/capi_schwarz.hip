@@ -745,6 +745,29 @@ HpddmHipPanel *HpddmHipPanelCreate(int n, int nu, const double *Z, const double 
     return nullptr;
   }
 }
+HpddmHipPanel *HpddmHipPanelCreateZ(int n, int nu, const double *Z, const double *d)
+{
+  // K = std::complex<double>: Z holds n x nu (re, im) pairs, d the n real weights.  The panel lives in the real-equivalent
+  // embedding like every complex operator of the library (vectors ARE std::complex<double> arrays: ZtD / Z below take them as
+  // they are, n and nu counted in complex scalars by the caller), its deflation vectors in the compact complex layout.
+  try {
+    HH_CHECK(n > 0 && nu > 0 && Z && d, "PanelCreateZ: bad argument");
+    std::unique_ptr<HpddmHipPanel> P(new HpddmHipPanel);
+    std::vector<int>    ia(n + 1), ja(n);
+    std::vector<double> a(2 * (size_t)n, 0.0), d2(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) ia[i] = ja[i] = i, a[2 * (size_t)i] = 1.0, d2[2 * (size_t)i] = d2[2 * (size_t)i + 1] = d[i];
+    ia[n] = n;
+    P->op.set_subdomain_z(0, n, ia.data(), ja.data(), a.data(), false, 0, 0, nullptr, nullptr, nullptr);
+    P->op.initialize(0, d2.data());
+    P->op.set_vectors_z(0, nu, Z);
+    P->op.build_device();
+    P->op.upload_vectors(true);
+    return P.release();
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return nullptr;
+  }
+}
 int HpddmHipPanelZtD(HpddmHipPanel *P, const double *in, double *uc, unsigned short mu)
 {
   HH_TRY(

@@ -224,6 +224,9 @@ long long HpddmHipSchwarzHaloExport(HpddmHipSchwarz *A, const char *which, int *
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct HpddmHipPanel HpddmHipPanel;
 HpddmHipPanel *HpddmHipPanelCreate(int n, int nu, const double *Z, const double *d);
+/* the same for K = std::complex<double>: Z = n x nu (re, im) pairs, d = the n real weights (Schwarz::d_ is underlying_type<K>);
+ * ZtD / Z below then take std::complex<double> arrays through their double pointers (uc = Z^H (D in): Wrapper<K>::transc) */
+HpddmHipPanel *HpddmHipPanelCreateZ(int n, int nu, const double *Z, const double *d);
 /* uc (nu x mu) = Z^T (D in) */
 int HpddmHipPanelZtD(HpddmHipPanel *P, const double *in, double *uc, unsigned short mu);
 /* out (n x mu) = Z y,  y (nu x mu) */

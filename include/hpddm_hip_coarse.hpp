@@ -13,11 +13,13 @@
  *     out  = exchange(out)       the reference's own Schwarz::exchange (D scaling + Subdomain::exchange)
  *
  * Usage, after buildTwo():     A.cc_ = new HPDDM::HipCoarseCorrection<decltype(A)>(A);      // owned: deleted with A (:406-407)
- * Op = HPDDM::Schwarz<SUBDOMAIN, COARSEOPERATOR, S, double>.  Real scalars (the panel API is K = double).
+ * Op = HPDDM::Schwarz<SUBDOMAIN, COARSEOPERATOR, S, K>, K = double or std::complex<double> (HpddmHipPanelCreateZ: the complex
+ * vectors travel as they are, uc = Z^H (D in)).
  */
 #ifndef HPDDM_HIP_COARSE_HPP_
 #define HPDDM_HIP_COARSE_HPP_
 
+#include <complex>
 #include <iostream>
 #include <type_traits>
 #include "hpddm_hip.h"
@@ -26,7 +28,13 @@ namespace HPDDM {
 template <class Op>
 class HipCoarseCorrection : public Op::CoarseCorrection {
   typedef typename Op::scalar_type K;
-  static_assert(std::is_same<K, double>::value, "HipCoarseCorrection: K = double");
+  static_assert(std::is_same<K, double>::value || std::is_same<K, std::complex<double>>::value, "HipCoarseCorrection: K = double or std::complex<double>");
+  static const double *dp(const double *p) { return p; }
+  static double       *dp(double *p) { return p; }
+  static const double *dp(const std::complex<double> *p) { return reinterpret_cast<const double *>(p); } /* (re, im) pairs */
+  static double       *dp(std::complex<double> *p) { return reinterpret_cast<double *>(p); }
+  static HpddmHipPanel *create(int n, int nu, const double *Z, const double *d) { return HpddmHipPanelCreate(n, nu, Z, d); }
+  static HpddmHipPanel *create(int n, int nu, const std::complex<double> *Z, const double *d) { return HpddmHipPanelCreateZ(n, nu, dp(Z), d); }
   /* co_ and uc_ are protected members of Preconditioner: reached through pointers to members named from a derived class */
   struct Access : public Op {
     static auto coarse(const Op &a) -> decltype(a.*(&Access::co_)) { return a.*(&Access::co_); }
@@ -40,7 +48,7 @@ public:
   {
     const int nu = A.getLocal();
     if (nu > 0) {
-      P_ = HpddmHipPanelCreate(A.getDof(), nu, *A.getVectors(), A.getScaling()); /* *ev_: n x nu, contiguous (include/HPDDM_ARPACK.hpp:154-156) */
+      P_ = create(A.getDof(), nu, *A.getVectors(), A.getScaling()); /* *ev_: n x nu, contiguous (include/HPDDM_ARPACK.hpp:154-156) */
       if (!P_) std::cerr << "BUG HipCoarseCorrection: " << HpddmHipLastError() << std::endl;
     }
   }
@@ -53,10 +61,10 @@ public:
   void operator()(const K *const in, K *const out, int n, unsigned short mu) override
   {
     K *uc = Access::rhs(A_); /* allocated by Preconditioner::start for mu right-hand sides (include/HPDDM_preconditioner.hpp:274-279) */
-    if (P_ && HpddmHipPanelZtD(P_, in, uc, mu) != 0) std::cerr << "BUG HipCoarseCorrection, Z^T D in: " << HpddmHipLastError() << std::endl;
+    if (P_ && HpddmHipPanelZtD(P_, dp(in), dp(uc), mu) != 0) std::cerr << "BUG HipCoarseCorrection, Z^T D in: " << HpddmHipLastError() << std::endl;
     Access::coarse(A_)->template callSolver<false>(uc, mu);
     if (P_) {
-      if (HpddmHipPanelZ(P_, uc, out, mu) != 0) std::cerr << "BUG HipCoarseCorrection, Z y: " << HpddmHipLastError() << std::endl;
+      if (HpddmHipPanelZ(P_, dp(uc), dp(out), mu) != 0) std::cerr << "BUG HipCoarseCorrection, Z y: " << HpddmHipLastError() << std::endl;
     } else
       for (int i = 0; i < n * mu; ++i) out[i] = K();
     A_.exchange(out, mu);

@@ -138,6 +138,26 @@ def test_coarse_correction_hook_runs_the_deflation_on_the_device(name, ranks, mu
         assert int(d["iterations"][0]) == int(g["iterations_r0"][0]) and (its is None or int(d["iterations"][0]) == its)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ref_harness_hipcc_z")), reason="oracle/_ref/ref_harness_hipcc_z not built")
+@pytest.mark.parametrize("name,ranks,mu", [("z_p30_6ranks_deflated_nu3", 6, 2), ("z_p30_gmres_left_deflated", 4, 1)])
+def test_coarse_correction_hook_complex(name, ranks, mu, tmp_path):
+    """Boundary B2 with K = std::complex<double> (-DFORCE_COMPLEX build of the reference): HipCoarseCorrection on
+    HpddmHipPanelCreateZ -- uc = Z^H (D in) and Z y on the device with the complex vectors as they are, local solves through
+    HipSub<std::complex<double>> -- against the fixtures dumped from the pure reference"""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    _run(ranks, f"-out {tmp_path} -case hookz -mu {mu} -hpddm_verbosity=1 " + str(g["options"]), exe="ref_harness_hipcc_z")
+    for r in range(ranks):
+        d = _parse_dump(os.path.join(tmp_path, f"hookz_r{r}.txt"))
+        for key, tol in (("deflation_out", 1e-11), ("apply_out", 1e-9), ("sol", 1e-6)):
+            ref = g[f"{key}_r{r}"]
+            got = d[key]
+            if np.iscomplexobj(ref) and not np.iscomplexobj(got):
+                got = got[0::2] + 1j * got[1::2]
+            assert np.abs(got - ref).max() <= tol * max(1e-300, np.abs(ref).max()), (key, r)
+        assert int(d["iterations"][0]) == int(g["iterations_r0"][0])
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "custom_operator_c_hip")), reason="oracle/_ref/custom_operator_c_hip not built")
 @pytest.mark.parametrize("ranks,args,method,its", [
     (1, "", "GMRES", 6),
