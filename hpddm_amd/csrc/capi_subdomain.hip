@@ -179,6 +179,7 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
     if (k == "goff") return ints(h.goff);
     if (k == "gptr") return ints(h.gptr);
     if (k == "gsrc") return ints(h.gsrc);
+    if (k == "tgs") return ints(h.tgs);
     if (k == "level_ptr") return ints(h.level_ptr);
     if (k == "level_blk") return ints(h.level_blk);
     if (k == "F") return dbls(h.F);

@@ -173,7 +173,7 @@ static inline bool potf2(int nb, double *T, long ld)
   }
   return true;
 }
-// Pivot-free LDL^T / LU: a pivot that has collapsed against the entries it is about to eliminate (|d| <= PIVOT_TOL * max of its
+// LDL^T (pivot-free) / LU (pivoting inside the tile only): a pivot that has collapsed against the entries it is about to eliminate (|d| <= PIVOT_TOL * max of its
 // column / row inside the tile, the test of threshold pivoting) is reported as a breakdown instead of being divided by -- the
 // reference's local solvers (MUMPS, PARDISO) would pivot there, this solver does not, and says so (numfact: ... in supernode
 // k).  Relative to the pivot's own column, so that rows scaled by 1e30 (penalised Dirichlet rows) next to ordinary ones are
@@ -204,13 +204,32 @@ static inline bool ldlf2(int nb, S *T, long ld)
   }
   return true;
 }
-// LU without pivoting: T = L U, unit lower L strictly below, U on and above the diagonal
+// LU with threshold partial pivoting INSIDE the tile: P_t T = L U, unit lower L strictly below, U on and above the diagonal.  Rows
+// are exchanged among the tile's own rows only (the structure of the supernodal factor stays static: the rows below the top block
+// of the front never move), and only when the diagonal entry is smaller than PIVOT_THRESHOLD times the largest entry below it
+// (the rule of the reference's direct solvers, MUMPS' default relative threshold: include/HPDDM_MUMPS.hpp:228-291 leaves CNTL(1)
+// alone) -- diagonally dominant and well-behaved matrices are factorised exactly as without pivoting.  piv[i] = the row of the
+// tile that ended at position i; *swapped is set when any row moved.  false: zero / collapsed pivot (the whole column below is
+// zero too, or the pivot is negligible against its own row) or NaN.
+static constexpr double PIVOT_THRESHOLD = 0.01;
 template <class S>
-static inline bool getf2(int nb, S *T, long ld)
+static inline bool getf2(int nb, S *T, long ld, int *piv, bool *swapped)
 {
+  for (int i = 0; i < nb; ++i) piv[i] = i;
   for (int j = 0; j < nb; ++j) {
-    const S p = T[(long)j * ld + j];
-    double       cmax = 0.0;
+    double amax = std::abs(T[(long)j * ld + j]);
+    int    imax = j;
+    for (int i = j + 1; i < nb; ++i) {
+      const double a = std::abs(T[(long)i * ld + j]);
+      if (a > amax) amax = a, imax = i;
+    }
+    if (imax != j && !(std::abs(T[(long)j * ld + j]) >= PIVOT_THRESHOLD * amax)) {
+      for (int k = 0; k < nb; ++k) std::swap(T[(long)j * ld + k], T[(long)imax * ld + k]);
+      std::swap(piv[j], piv[imax]);
+      *swapped = true;
+    }
+    const S p    = T[(long)j * ld + j];
+    double  cmax = 0.0;
     for (int i = j + 1; i < nb; ++i) cmax = std::max(cmax, std::max(std::abs(T[(long)i * ld + j]), std::abs(T[(long)j * ld + i])));
     if (!(std::abs(p) > PIVOT_TOL * cmax) || p == S(0)) return false; // zero, collapsed or NaN
     const S inv = S(1) / p;

@@ -62,6 +62,9 @@ struct SnDesc {
   int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
   const double *FT;    // narrow panels: the forward panel once more, transposed (w x ldh, row-major), or nullptr
   int           ldh;   // its leading dimension (h rounded up to 2)
+  int           tgs;   // forward panel: log2 of the size of the DENSE diagonal tiles of its top block -- 0: lower triangular (the rule);
+                       // 6 / 31: the LU factorisation pivoted inside its 64-column tiles / inside the whole block (rows swapped: the
+                       // inverse of the row-permuted unit factor is block lower triangular with dense diagonal tiles)
   const int    *src4;  // small narrow panels with children: the gather lists once more as 4 fixed slots per entry of the front
                        // (h x 4 sources inside the update pool, -1 = none), one 16-byte load per entry; or nullptr
 };
@@ -91,6 +94,7 @@ struct DeviceFactor {
   // host copies of what the plan builder needs
   std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
   std::vector<char>    has_src;
+  std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
   std::vector<int64_t> f_off, row_ptr, goff;
   DevBuf<int>          src4;                 // fixed-slot gather lists of the narrow supernodes with at most 4 sources per entry
   std::vector<int64_t> s4_off;               // per supernode offset into src4 (-1: none; leaves need none)

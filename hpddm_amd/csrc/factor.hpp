@@ -38,6 +38,7 @@ struct HostFactor {
   std::vector<double>  F;          // forward panels
   std::vector<double>  G;          // backward panels (LU only; empty otherwise: G == F)
   std::vector<double>  dinv;       // LDLT only: 1/D in the permuted numbering
+  std::vector<unsigned char> tgs;  // LU: per supernode, 0 = no row was swapped (triangular top block of F), else log2 of the tile the swaps stayed in (SnDesc::tgs)
   // multifrontal-solve gather lists: entry i (0..h-1) of supernode k sums U[gsrc[p]] for p in gptr[goff[k]+i .. goff[k]+i+1)
   std::vector<int64_t> u_off;      // nblk: offset of u_k in the update pool (size sum nb)
   int64_t              u_size = 0;

@@ -25,6 +25,10 @@ static size_t hash_pattern(const CsrView &A)
   mix((size_t)A.sym);
   for (idx_t i = 0; i <= A.n; ++i) mix((size_t)(A.ia[i] - A.base));
   for (idx_t p = 0; p < nnz; ++p) mix((size_t)(A.ja[p] - A.base));
+  // ... and of the set of diagonal entries that are exactly zero: the ordering pairs those with a neighbour (match_zero_diagonals)
+  for (idx_t i = 0; i < A.n; ++i)
+    for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p)
+      if (A.ja[p] - A.base == i && (A.cplx ? (A.a[2 * (size_t)p] == 0.0 && A.a[2 * (size_t)p + 1] == 0.0) : A.a[p] == 0.0)) mix((size_t)i + 0x9e3779b97f4a7c15ull);
   return h;
 }
 
@@ -124,7 +128,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   auto                          device_levels = [&](FactKind kd) {
     devlev.reset();
     first_dev = (idx_t)host.level_ptr.size() - 1;
-    if (!on_device) return;
+    if (!on_device || (kd == FACT_LU && host.keep_plain)) return; // (the LU tile kernels of the device levels do not keep the multipliers)
     first_dev = pick_first_device_level(host);
     if (first_dev < (idx_t)host.level_ptr.size() - 1) {
       const size_t sc = A.cplx ? 2 : 1; // doubles per scalar
@@ -140,15 +144,35 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     device_levels(FACT_LDLT);
     factor_numeric(A, FACT_LDLT, host, devlev.get(), first_dev);
   }
-  HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivoting in this solver)");
+  if (host.info != 0 && host.kind == FACT_LDLT && !getenv("HPDDM_HIP_NO_LU_FALLBACK")) {
+    // a pivot of the pivot-free L D L^T collapsed: symmetric indefinite matrices (saddle points, shifted operators) go on as LU with
+    // threshold pivoting inside the diagonal tiles, like sym=0 in the reference (HPDDM_MUMPS.hpp:236: general matrices pivot)
+    device_levels(FACT_LU);
+    factor_numeric(A, FACT_LU, host, devlev.get(), first_dev);
+  }
+  HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivot inside its diagonal tiles either: the matrix is singular, or needs rows from outside the supernode)");
   uploaded = false;
   if (!host_only) {
-    const auto t0 = std::chrono::steady_clock::now();
-    dev.upload(host, library_stream());
-    plan.build({&dev}, library_stream());
-    uploaded = true;
-    t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (host.kind != FACT_CHOL && !getenv("HPDDM_HIP_NO_PROBE")) probe(A, host.kind);
+    auto to_device = [&]() {
+      const auto t0 = std::chrono::steady_clock::now();
+      dev.upload(host, library_stream());
+      plan.build({&dev}, library_stream());
+      uploaded = true;
+      t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    to_device();
+    if (host.kind != FACT_CHOL && !getenv("HPDDM_HIP_NO_PROBE")) {
+      std::string why = probe(A, host.kind);
+      if (!why.empty() && host.kind == FACT_LDLT && !getenv("HPDDM_HIP_NO_LU_FALLBACK")) {
+        // pivots that did not collapse but let the entries grow: the same fall-back, then the probe once more
+        device_levels(FACT_LU);
+        factor_numeric(A, FACT_LU, host, devlev.get(), first_dev);
+        HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (LU with pivoting inside the diagonal tiles, after an unstable L D L^T)");
+        to_device();
+        why = probe(A, host.kind);
+      }
+      HH_CHECK(why.empty(), why);
+    }
     if (release_host) {
       host.F.clear();
       if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);
@@ -158,13 +182,14 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   }
 }
 
-// The factorisation does not pivot (the reference's local solvers do): one probe solve closes numfact and fails loudly when
-// the factor is not backward stable for this matrix.  b = A * x0 (x0 in [0.5, 1.5), golden-ratio sequence: a vector of ones
+// The factorisation pivots inside the diagonal tiles only, and only as LU (the reference's local solvers pivot freely): one probe
+// solve closes numfact; L D L^T factors that are not backward stable are redone as LU, and numfact fails loudly when that factor
+// is not stable either (the message comes back as a string, empty = fine).  b = A * x0 (x0 in [0.5, 1.5), golden-ratio sequence: a vector of ones
 // lets cancellations come out exact), x = solve(b): row-wise backward error
 // max_i |A x - b|_i / (||A_i||_1 ||x||_inf + |b_i|), which does not depend on the conditioning of A -- only on the
 // growth inside the elimination -- nor on the scale of individual rows (penalised Dirichlet rows).  Symmetric-indefinite and general matrices whose pivots collapse (saddle points, shifts
 // close to an eigenvalue of a leading block) end here instead of returning wrong values silently.
-void LocalSolver::probe(const CsrView &A, FactKind kind)
+std::string LocalSolver::probe(const CsrView &A, FactKind kind)
 {
   typedef std::complex<double> Z;
   const idx_t    n = A.n;
@@ -217,9 +242,12 @@ void LocalSolver::probe(const CsrView &A, FactKind kind)
   if (getenv("HPDDM_HIP_VERBOSE")) fprintf(stderr, "numfact probe: n %d kind %d backward error %.3e (|r| %.3e |A| %.3e |x| %.3e |b| %.3e)\n", (int)n, (int)kind, probe_berr, rn, an, xn, bn);
   const char *e   = getenv("HPDDM_HIP_PROBE_TOL");
   const double tol = e ? atof(e) : 1.0e-9;
-  HH_CHECK(probe_berr <= tol, std::string("numfact: the ") + (kind == FACT_LU ? "LU" : (kind == FACT_LDLT ? "LDL^T" : "Cholesky")) +
-                                  " factorisation of this matrix is not backward stable without pivoting (probe solve: backward error " + std::to_string(probe_berr) +
-                                  "); this solver does not pivot -- use a local solver that does for this operator");
+  if (probe_berr <= tol) return std::string();
+  char num[32];
+  snprintf(num, sizeof num, "%.3e", probe_berr);
+  return std::string("numfact: the ") + (kind == FACT_LU ? "LU" : (kind == FACT_LDLT ? "LDL^T" : "Cholesky")) +
+         " factorisation of this matrix is not backward stable (probe solve: backward error " + num +
+         "); pivots are taken inside the diagonal tiles of a supernode only (static structure) -- use a local solver with dynamic pivoting for this operator";
 }
 
 void LocalSolver::solve_device(const double *b, double *x, int mu)

@@ -18,8 +18,8 @@ struct LocalSolver {
   bool         host_only = false;
   bool         release_host = false; // drop the host panels after upload (Schwarz operator does this)
   double       t_upload = 0;
-  double       probe_berr = 0; // backward error of the probe solve that closes numfact (LDL^T / LU: no pivoting here)
-  void         probe(const CsrView &A, FactKind kind);
+  double       probe_berr = 0; // backward error of the probe solve that closes numfact (LDL^T / LU)
+  std::string  probe(const CsrView &A, FactKind kind); // empty: the factor is backward stable for this matrix
   DevBuf<double> bdev, xdev;         // staging for the host-pointer API
   bool adopt_analysis(const LocalSolver &other, const CsrView &A); // same sparsity pattern as a solver already analysed: copy its ordering and symbolic factorisation
   void analyse(const CsrView &A); // ordering + symbolic factorisation (host only, thread-safe across solvers); numfact calls it if needed

@@ -355,35 +355,71 @@ __global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(T *Tl, long long ld,
   }
 }
 
-// LU of one diagonal tile (nb <= 64, row-major, in place: unit L strictly below, U on and above the diagonal) and the tile inverses
-// the blocked algorithm multiplies with: TinvL = inv(L), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).  One workgroup,
-// right-looking, one barrier per column: thread (r, q) owns the columns c = q (mod 8) of row r.  Step j: l = W(r, j) / u_jj for the
-// rows below, W(r, c) -= l W(j, c) right of the pivot; S(r, c) -= l S(j, c), c <= j -- the rows of inv(L), kept in the strictly
-// lower triangle of S (unit diagonal implied); and, since row j of W is final when step j starts (it IS row j of U), the forward
-// substitution for Y = inv(U^T) with the column U^T(:, j) = W(j, :): Yw(r, c) -= W(j, r) Yw(j, c) / u_jj, c <= j, kept transposed
-// in the upper triangle of S (diagonal included).  Row j of Yw is divided by u_jj one step later.  Pivot test of dense_host.hpp:
-// against the largest entry of its column AND row.
+// LU of one diagonal tile (nb <= 64, row-major; U comes back on and above the diagonal) with threshold partial pivoting among the
+// tile's own rows (the rule of dense_host.hpp: getf2 -- the diagonal entry stays unless it is smaller than DEV_PIVOT_THRESHOLD
+// times the largest entry below it), and the tile inverses the blocked algorithm multiplies with: TinvL = inv(L) P (DENSE when
+// rows were exchanged, lower triangular otherwise), TinvU = inv(U), TinvUT = inv(U)^T (64 x 64 each).  One workgroup,
+// right-looking, one barrier per column (three on the columns that exchange rows): thread (r, q) owns the columns c = q (mod 8) of
+// row r.  Step j: every wave finds the pivot row for itself (64 lanes, one column); rows j and pivot exchange their live parts --
+// W right of column j and the whole row of Xw; l = W(r, j) / u_jj for the rows below, W(r, c) -= l W(j, c) right of the pivot;
+// Xw(r, c) -= l Xw(j, c) -- Gauss-Jordan on the identity: the rows of inv(L) P; and, since row j of W is final when the update
+// starts (it IS row j of U), the forward substitution for Y = inv(U^T) with the column U^T(:, j) = W(j, :):
+// Yw(r, c) -= W(j, r) Yw(j, c) / u_jj, c <= j, kept in the DEAD part of W (the columns <= j of the rows below, unit diagonal
+// implied: the multipliers are not kept -- nothing reads the strictly lower part of the tile afterwards).  Row j of Yw is divided
+// by u_jj one step later.  Breakdown (*flag): a pivot that is zero, NaN or negligible against its own row after the exchange.
+static constexpr double DEV_PIVOT_THRESHOLD = 0.01;
 template <class T>
-__global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld, int nb, T *TinvL, T *TinvU, T *TinvUT, int *flag)
+__global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld, int nb, T *TinvL, T *TinvU, T *TinvUT, int *flag, int *swapped)
 {
   extern __shared__ __attribute__((aligned(16))) double tile_lds[];
-  T(*W)[65] = reinterpret_cast<T(*)[65]>(tile_lds);
-  T(*S)[65] = W + 64; // S[r][c], c < r: Xw(r, c) = inv(L)(r, c); S[c][r], c <= r: Yw(r, c) = inv(U^T)(r, c)
-  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
+  T(*W)[65]  = reinterpret_cast<T(*)[65]>(tile_lds);
+  T(*Xw)[65] = W + 64;
+  const int tid = threadIdx.x, r = tid >> 3, q = tid & 7, lane = tid & 63;
   for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
     W[i][c]     = (i < nb && c < nb) ? Tl[(long long)i * ld + c] : scalar<T>(0.0);
-    S[i][c]     = scalar<T>(i == c ? 1.0 : 0.0); // Yw = identity (its diagonal); Xw's unit diagonal is implied
+    Xw[i][c]    = scalar<T>(i == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  T ip_prev = scalar<T>(0.0);
+  T   ip_prev = scalar<T>(0.0);
+  int hi      = 0; // Xw(j, c) = 0 for c > hi: the largest row index that took part in an exchange so far (or j)
+  bool any    = false;
   for (int j = 0; j <= nb; ++j) {
-    if (j > 0) { // row j - 1 of inv(U^T): final values
+    if (j > 0) { // row j - 1 of inv(U^T) left of its diagonal: final values
       const int p = j - 1;
       if (r == p)
-        for (int c = q; c <= p; c += 8) S[c][p] = S[c][p] * ip_prev;
+        for (int c = q; c < p; c += 8) W[p][c] = W[p][c] * ip_prev;
     }
     if (j == nb) break;
+    // ---- pivot row: the largest entry of column j on or below the diagonal (first one on ties) ----
+    double amax = (lane >= j && lane < nb) ? modulus(W[lane][j]) : -1.0;
+    int    prow = lane;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ov = __shfl_xor(amax, off);
+      const int    oi = __shfl_xor(prow, off);
+      if (ov > amax || (ov == amax && oi < prow)) amax = ov, prow = oi;
+    }
+    if (prow != j && !(modulus(W[j][j]) >= DEV_PIVOT_THRESHOLD * amax)) { // (the same decision in every wave: nobody has written yet)
+      __syncthreads();
+      if (r == j) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int c = q + 8 * it;
+          if (c >= j) {
+            const T t  = W[j][c];
+            W[j][c]    = W[prow][c];
+            W[prow][c] = t;
+          }
+          const T t   = Xw[j][c];
+          Xw[j][c]    = Xw[prow][c];
+          Xw[prow][c] = t;
+        }
+      }
+      hi  = max(hi, prow);
+      any = true;
+      __syncthreads();
+    }
+    hi          = max(hi, j);
     const T piv = W[j][j];
     if (tid < 64) {
       double cmax = (tid > j && tid < nb) ? fmax(modulus(W[tid][j]), modulus(W[j][tid])) : 0.0;
@@ -393,41 +429,37 @@ __global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld,
     const T ip = scalar<T>(1.0) / piv;
     if (r > j && r < nb) {
       const T l = W[r][j] * ip, ur = W[j][r] * ip; // multiplier of row r; U^T(r, j) / u_jj
-      T       a[8], b[8], ya[8], yb[8];
+      T       a[8], b[8], xa[8], xb[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it) { // all the LDS reads first
         const int c = q + 8 * it;
-        if (c > j) {
-          a[it] = W[j][c], b[it] = W[r][c];
-        } else {
-          a[it]  = c < j ? S[j][c] : scalar<T>(1.0); // Xw(j, c), unit diagonal
-          b[it]  = S[r][c];                          // Xw(r, c) (c <= j < r: strictly lower)
-          ya[it] = S[c][j];                          // Yw(j, c)
-          yb[it] = S[c][r];                          // Yw(r, c)
+        if (c > j) a[it] = W[j][c], b[it] = W[r][c];
+        else { // Yw(j, c), Yw(r, c): identity where nothing was written yet
+          a[it] = c < j ? W[j][c] : scalar<T>(1.0);
+          b[it] = c < j ? W[r][c] : scalar<T>(0.0);
         }
+        if (c <= hi) xa[it] = Xw[j][c], xb[it] = Xw[r][c];
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int c = q + 8 * it;
         if (c > j) {
           if (c < nb) W[r][c] = b[it] - l * a[it];
-        } else {
-          S[r][c] = b[it] - l * a[it];
-          S[c][r] = yb[it] - ur * ya[it];
-        }
+        } else W[r][c] = b[it] - ur * a[it]; // (c = j: the entry this row just eliminated makes room for Yw(r, j))
+        if (c <= hi) Xw[r][c] = xb[it] - l * xa[it];
       }
-      if (q == 0) W[r][j] = l; // the multiplier takes the place of the entry it eliminated (column j is dead: read above by this thread's row only)
     }
     ip_prev = ip;
     __syncthreads();
   }
   __syncthreads();
+  if (any && tid == 0) *swapped = 1;
   for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
-    const int i = idx >> 6, c = idx & 63;
-    if (i < nb && c < nb) Tl[(long long)i * ld + c] = W[i][c];
+    const int  i = idx >> 6, c = idx & 63;
     const bool in = i < nb && c < nb;
-    TinvL[idx]  = in ? (c == i ? scalar<T>(1.0) : (c < i ? S[i][c] : scalar<T>(0.0))) : scalar<T>(0.0);
-    const T y   = (in && c <= i) ? S[c][i] : scalar<T>(0.0); // inv(U)^T (i, c) = Yw(i, c)
+    if (in && c >= i) Tl[(long long)i * ld + c] = W[i][c];
+    TinvL[idx]  = in ? Xw[i][c] : scalar<T>(0.0);
+    const T y   = (in && c <= i) ? (c == i ? scalar<T>(1.0) / W[i][i] : W[i][c]) : scalar<T>(0.0); // inv(U)^T (i, c) = Yw(i, c)
     TinvUT[idx] = y;
     TinvU[c * 64 + i] = y;
   }
@@ -739,7 +771,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
       }
     }
     upload_ring().reserve((size_t)64 << 20, st);
-    std::vector<int> z(1, 0);
+    std::vector<int> z(1 + (size_t)h.sym.nblk, 0); // [0]: breakdown; [1 + k]: rows were exchanged inside a tile of front k (LU)
     flag.upload(z, st);
     HIP_OK(hipStreamSynchronize(st));
   }
@@ -866,8 +898,11 @@ struct DeviceLevelsImpl : public DeviceLevels {
       }
     }
   }
-  // LU: left-looking by 64 columns (column block of [A11; A21], row block of U inside A11, row block of U12^T)
-  void factor_lu(T *P, T *G, long long ld, int w, int nb, int h, T *tinv2, T *tinv3)
+  // LU: left-looking by 64 columns (column block of [A11; A21], row block of U inside A11, row block of U12^T).  The tile kernel
+  // exchanges rows inside the tile; the panel keeps the ORIGINAL row order throughout -- A11 = (P^T L11) U11, P = diag(P_t): the
+  // rows of L left of a tile never move, and invert_top, fed with the dense tile inverses inv(L_T) P_t, returns inv(L11) P: the
+  // forward panel of the front in its own row order, block lower triangular with dense 64 x 64 diagonal tiles (SnDesc::tgs)
+  void factor_lu(T *P, T *G, long long ld, int w, int nb, int h, T *tinv2, T *tinv3, int *swapped)
   {
     const int ntile = (w + 63) / 64;
     T        *Gb    = G + (long long)w * ld; // U12 transposed: rows below the block
@@ -879,14 +914,14 @@ struct DeviceLevelsImpl : public DeviceLevels {
         gemm<CS>(st, false, jb, w - kb - jb, kb, -1.0, cd(Pk), ld, cd(P + kb + jb), ld, md(Pk + kb + jb), ld, true); // row block of U inside A11
         gemm<CS>(st, true, nb, jb, kb, -1.0, cd(Gb), ld, cd(Pk), ld, md(Gb + kb), ld, true);                          // row block of U12 (transposed)
       }
-      hipLaunchKernelGGL(k_getf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p);
+      hipLaunchKernelGGL(k_getf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p, swapped);
       right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
       const int right = w - kb - jb;
-      if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)
+      if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) P_t * U(...): the rows take the pivoted order in the same product
         gemm<CS>(st, false, jb, right, jb, 1.0, cd(Tt), 64, cd(Pk + kb + jb), ld, md(tmp.p), right, false);
         hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, (const T *)tmp.p, (long long)right, Pk + kb + jb, ld);
       }
-      right_tile(Gb + kb, ld, nb, jb, Tt, true); // U12^T rows: X <- X * inv(L_T)^T
+      right_tile(Gb + kb, ld, nb, jb, Tt, true); // U12^T rows: X <- X * (inv(L_T) P_t)^T
     }
   }
   // the front k with its original entries in place: extend-add of the children, factorisation, solve-ready panels
@@ -921,7 +956,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     T        *tinv2 = tinv.p + (size_t)ntile * 4096, *tinv3 = tinv.p + (size_t)2 * ntile * 4096; // LDL^T: D^{-1} inv(L); LU: inv(U), inv(U)^T
     if (kind == FACT_CHOL) factor_chol(P, ld, (int)w, (int)h);
     else if (kind == FACT_LDLT) factor_ldlt(P, ld, (int)w, (int)h, tinv2);
-    else factor_lu(P, G, ld, (int)w, (int)nb, (int)h, tinv2, tinv3);
+    else factor_lu(P, G, ld, (int)w, (int)nb, (int)h, tinv2, tinv3, flag.p + 1 + k);
     // ---- Schur complement -> contribution block (lower triangle for the symmetric kinds, full for LU) ----
     if (nb) {
       T *P21 = P + (long long)w * ld;
@@ -967,9 +1002,13 @@ struct DeviceLevelsImpl : public DeviceLevels {
       fprintf(stderr, "[numfact] device levels: host ran %.3f s ahead of the stream at the end; ring: %.1f MB pushed, %.3f s copying, %d wrap-arounds waiting %.3f s\n", now() - t0, r.bytes_pushed / 1e6, r.t_copy, r.wraps, r.t_wait);
       r.bytes_pushed = 0, r.t_copy = r.t_wait = 0, r.wraps = 0;
     }
-    HIP_OK(hipMemcpyAsync(&f, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<int> fl(1 + (size_t)hf->sym.nblk, 0);
+    HIP_OK(hipMemcpyAsync(fl.data(), flag.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     HIP_OK(hipGetLastError());
+    f = fl[0];
+    for (idx_t k = 0; k < hf->sym.nblk; ++k)
+      if (fl[1 + k]) hf->tgs[k] = 6;
     cb.clear();
     if (locked) {
       locked = false;

@@ -61,6 +61,68 @@ static idx_t padded_width(idx_t w)
   return (w + 15) / 16 * 16;
 }
 
+// Saddle-point matrices: an unknown with a ZERO diagonal entry (a pressure, a multiplier) that the ordering eliminates before all
+// of its neighbours has nothing to pivot on -- the rows that could help live in other supernodes, and the structure of the factor is
+// static (the reference's direct solvers move such pivots up the tree at run time: delayed pivots, include/HPDDM_MUMPS.hpp:228-291
+// through ICNTL(14)).  Static answer, the one of the matching-based orderings: pair the unknown with a neighbour of its own
+// (nonzero diagonal, not paired yet, the earliest in the ordering) and eliminate it right AFTER that neighbour, inside the same
+// supernode -- its pivot is then the Schur complement -b a^{-1} b^T of the pair, and whatever is left to fix is inside one
+// diagonal tile, where the LU factorisation pivots.  Decided on the pattern and on which diagonal entries are exactly zero (or
+// absent), nothing else: the analysis of one matrix serves every matrix of the same pattern (LocalSolver::adopt_analysis).
+static void match_zero_diagonals(const CsrView &A, const Graph &g, Ordering &ord)
+{
+  const idx_t       n = A.n;
+  std::vector<char> zero(n, 1);
+  idx_t             nzero = n;
+  for (idx_t i = 0; i < n; ++i)
+    for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p)
+      if (A.ja[p] - A.base == i && zero[i] && (A.cplx ? (A.a[2 * (size_t)p] != 0.0 || A.a[2 * (size_t)p + 1] != 0.0) : A.a[p] != 0.0)) zero[i] = 0, --nzero;
+  if (!nzero) return;
+  const idx_t          nblk = (idx_t)ord.blk_ptr.size() - 1;
+  std::vector<idx_t>   blk_of(n);
+  for (idx_t k = 0; k < nblk; ++k)
+    for (idx_t c = ord.blk_ptr[k]; c < ord.blk_ptr[k + 1]; ++c) blk_of[c] = k;
+  std::vector<int64_t> key(n);
+  std::vector<idx_t>   newblk(n);
+  std::vector<char>    taken(n, 0);
+  for (idx_t c = 0; c < n; ++c) key[ord.perm[c]] = 2 * (int64_t)c, newblk[ord.perm[c]] = blk_of[c];
+  idx_t moved = 0;
+  for (idx_t c = 0; c < n; ++c) {
+    const idx_t i = ord.perm[c];
+    if (!zero[i]) continue;
+    // a partner of its OWN: two such unknowns behind one shared neighbour leave a zero pivot for the second (the Schur complement
+    // of the pair is rank one).  Greedy: a free neighbour that is eliminated earlier anyway, else the earliest free one later on
+    idx_t before = -1, best = -1;
+    for (idx_t p = g.xadj[i]; p < g.xadj[i + 1]; ++p) {
+      const idx_t j = g.adjncy[p];
+      if (zero[j] || taken[j]) continue;
+      if (ord.iperm[j] < c) {
+        if (before < 0 || ord.iperm[j] > ord.iperm[before]) before = j;
+      } else if (best < 0 || ord.iperm[j] < ord.iperm[best]) best = j;
+    }
+    if (before >= 0) {
+      taken[before] = 1;
+      continue;
+    }
+    if (best < 0) continue;
+    taken[best] = 1;
+    key[i]      = 2 * (int64_t)ord.iperm[best] + 1;
+    newblk[i]   = blk_of[ord.iperm[best]];
+    ++moved;
+  }
+  if (!moved) return;
+  std::vector<idx_t> order(n);
+  for (idx_t i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](idx_t a, idx_t b) { return key[a] < key[b]; });
+  ord.blk_ptr.assign(1, 0);
+  for (idx_t c = 0; c < n; ++c) {
+    ord.perm[c]         = order[c];
+    ord.iperm[order[c]] = c;
+    if (c > 0 && newblk[order[c]] != newblk[order[c - 1]]) ord.blk_ptr.push_back(c);
+  }
+  ord.blk_ptr.push_back(n);
+}
+
 void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf)
 {
   const idx_t n = A.n;
@@ -108,6 +170,7 @@ void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf)
     }
   }
   nested_dissection(g, leaf_size > 0 ? leaf_size : 32, hf.ord);
+  match_zero_diagonals(A, g, hf.ord);
   hf.t_order = now() - t0;
   t0         = now();
   symbolic_factorization(g, hf.ord, hf.sym);
@@ -364,6 +427,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   hf.F.assign((size_t)hf.f_host * SC, 0.0);
   if (lu) hf.G.assign((size_t)hf.f_host * SC, 0.0);
   else std::vector<double>().swap(hf.G);
+  hf.tgs.assign(nblk, 0);
   if (kind == FACT_LDLT) hf.dinv.assign((size_t)n * SC, 0.0);
   else std::vector<double>().swap(hf.dinv);
   hf.t_plain = 0;
@@ -382,6 +446,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   omp_set_num_threads(nthreads);
   std::vector<std::vector<idx_t>> relidx_t(nthreads);
   int                             bad = 0;
+  bool                            plain_lost = false;
 
   const bool prof = getenv("HPDDM_HIP_PROFILE") != nullptr;
   double     tph[5] = {0, 0, 0, 0, 0};
@@ -464,6 +529,15 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     const int           NB = 64;
     std::vector<T> wt;
     bool                ok = true;
+    // LU: rows exchanged inside the 64-column tiles of the top block (dense_host.hpp: getf2).  The panel keeps the ORIGINAL row
+    // order while it is factorised -- A11 = (P^T L11) U11, P = diag(P_t) --, only the tile itself, the rows of U right of it and the
+    // columns of U12^T take the pivoted order; snp[kb + i] = kb + (row of the tile at position i)
+    std::vector<int> snp;
+    bool             swapped = false;
+    if (lu) {
+      snp.resize(w);
+      for (idx_t i = 0; i < w; ++i) snp[i] = (int)i;
+    }
     for (idx_t kb = 0; kb < w && ok; kb += NB) {
       const idx_t jb = std::min<idx_t>(NB, w - kb);
       T          *Pk = Pn + (long)kb * ld;
@@ -488,7 +562,22 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
         dense::gemm(jb, w - kb - jb, kb, -1.0, Pk, ld, Pn + kb + jb, ld, false, Pk + kb + jb, ld, par);
         // row block of U12 (stored transposed in G):  G(w:h, kb:kb+jb) -= G(w:h, 0:kb) * L(kb:kb+jb, 0:kb)^T
         dense::gemm(nb, jb, kb, -1.0, Gn + (long)w * ld, ld, Pk, ld, true, Gn + (long)w * ld + kb, ld, par);
-        ok = dense::getf2(jb, Pk + kb, ld);
+        int  piv[NB];
+        bool sw = false;
+        ok      = dense::getf2(jb, Pk + kb, ld, piv, &sw);
+        if (ok && sw) {
+          swapped = true;
+          for (idx_t i = 0; i < jb; ++i) snp[kb + i] = (int)kb + piv[i];
+          const idx_t right = w - kb - jb;
+          wt.resize((size_t)jb * std::max<idx_t>(right, 1));
+          for (idx_t i = 0; i < jb; ++i) std::copy_n(Pk + (long)piv[i] * ld + kb + jb, right, wt.data() + (size_t)i * right);
+          for (idx_t i = 0; i < jb; ++i) std::copy_n(wt.data() + (size_t)i * right, right, Pk + (long)i * ld + kb + jb);
+          for (idx_t r = w; r < h; ++r) {
+            T *g = Gn + (long)r * ld + kb, t[NB];
+            for (idx_t i = 0; i < jb; ++i) t[i] = g[piv[i]];
+            std::copy_n(t, jb, g);
+          }
+        }
         if (ok) {
           dense::trsm_right_upper(h - kb - jb, jb, Pk + kb, ld, Pk + (long)jb * ld + kb, ld, par);
           // U(kb:kb+jb, kb+jb:w) <- inv(L_T) * U(...)   (unit lower, row by row)
@@ -532,6 +621,19 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           if (j > i) Pn[(long)i * ld + j] = T(0);
         }
       for (idx_t i = 0; i < w; ++i) Pn[(long)i * ld + i] = T(1); // L11 unit diagonal made explicit
+      if (swapped) { // rows of L11 left of their tile: into the pivoted order, L11 is unit lower triangular from here on
+        for (idx_t kb = NB; kb < w; kb += NB) {
+          const idx_t jb = std::min<idx_t>(NB, w - kb);
+          wt.resize((size_t)jb * kb);
+          for (idx_t i = 0; i < jb; ++i) std::copy_n(Pn + (long)snp[kb + i] * ld, kb, wt.data() + (size_t)i * kb);
+          for (idx_t i = 0; i < jb; ++i) std::copy_n(wt.data() + (size_t)i * kb, kb, Pn + (long)(kb + i) * ld);
+        }
+        hf.tgs[k] = 6;
+        if (hf.keep_plain) {
+#pragma omp critical
+          plain_lost = true; // the plain factor of this front is the factor of a row-permuted front: its consumers do not know
+        }
+      }
     } else {
       for (idx_t i = 0; i < w; ++i)
         for (idx_t j = i + 1; j < w; ++j) Pn[(long)i * ld + j] = T(0);
@@ -552,6 +654,12 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     if (lu) {
       invert_lower(w, Gn, ld, false, par, tmp);
       right_multiply_lower(nb, w, Gn + (long)w * ld, ld, Gn, ld, par);
+      if (swapped) // [inv(L11); L21 inv(L11)] P: the forward panel of the front in its own row order -- dense diagonal tiles (SnDesc::tgs)
+        for (idx_t r = 0; r < h; ++r) {
+          T *row = Pn + (long)r * ld;
+          tmp.assign(row, row + w);
+          for (idx_t i = 0; i < w; ++i) row[snp[i]] = tmp[i];
+        }
     }
     lap(3);
   };
@@ -637,6 +745,9 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     if (prof) fprintf(stderr, "[numfact] device levels, host side: begin %.3f s, children uploads %.3f s, lists %.3f s, enqueue %.3f s, end %.3f s\n", tb1 - tb0, t_up, t_prep, t_proc, now() - te0);
     if (prof) fprintf(stderr, "[numfact] device levels %d..%d: %.3f s\n", (int)first_device_level, (int)nlev_all - 1, now() - td0);
   }
+  if (hf.keep_plain)
+    for (unsigned char t : hf.tgs) plain_lost = plain_lost || t != 0;
+  HH_CHECK(!plain_lost || bad, "numfact: rows were exchanged inside a supernode (LU with pivoting): the plain factor (keep_plain) is not available for this matrix");
   hf.info      = bad;
   hf.t_numeric = now() - t0;
 }

@@ -199,7 +199,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
   const gcd_t Fp = d.FT + t.r0 + 2 * gl;
-  const int   rtop = t.r0 + 2 * gl + 1; // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop
+  const int   rtop = tri_last(t.r0 + 2 * gl + 1, d.tgs); // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop (pivoted supernodes: above the diagonal tile)
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
@@ -293,7 +293,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
   const gcd_t Fp = d.FT + t.r0 + 2 * gl;
-  const int   rtop = t.r0 + 2 * gl + 1; // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop
+  const int   rtop = tri_last(t.r0 + 2 * gl + 1, d.tgs); // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop (pivoted supernodes: above the diagonal tile)
   const int   r_out = t.r0 + 2 * gl, rend = t.r0 + t.nr;
   // A tile of the bottom levels is a chain of dependent round trips with a few KB of panel behind it, and a level is bound by
   // (length of that chain) / (tiles in flight).  Everything that depends on the descriptor only is requested together, in the
@@ -557,7 +557,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
   const int     CW  = ((lds_dbl - 64 * MU) / MU) & ~1; // columns staged per chunk (the tail of the LDS holds the row sums)
   double       *sums = lds + MU * CW;                // [MU][64]
   const int     rend = t.r0 + t.nr;
-  const int     tile_lim = min(wc, cs * rend); // rows of the top block never look right of their diagonal
+  const int     tile_lim = min(wc, cs * (tri_last(rend - 1, d.tgs) + 1)); // rows of the top block never look right of their diagonal (tile)
   const bool    single   = tile_lim <= CW;
   // row batches: every wavefront owns FWD_PASSES rows per batch (one wave per row, 16-byte loads, 1 KiB per instruction)
   for (int rb = t.r0; rb < rend; rb += 4 * FWD_PASSES) {
@@ -567,7 +567,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p) {
       row[p] = rb + p * 4 + wave;
-      lim[p] = row[p] < rend ? (row[p] < w ? cs * (row[p] + 1) : wc) : 0;
+      lim[p] = row[p] < rend ? (row[p] < w ? min(wc, cs * (tri_last(row[p], d.tgs) + 1)) : wc) : 0;
       lmax   = max(lmax, lim[p]);
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
@@ -642,8 +642,8 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
   double       *red  = lds + (lds_dbl - 64 * MU);        // [4 wavefronts][16 rows][MU]
   double       *sums = red - 64 * MU;                    // [MU][64]
   const int     CW   = ((lds_dbl - 128 * MU) / MU) & ~15; // columns of the right-hand side staged per chunk
-  const int     tile_lim = min(wc, cs * rend);           // rows of the top block never look right of their diagonal
-  const int     my_lim   = busy ? min(wc, cs * (R0 + 16)) : 0; // ... and this row group stops at its own last diagonal entry
+  const int     tile_lim = min(wc, cs * (tri_last(rend - 1, d.tgs) + 1)); // rows of the top block never look right of their diagonal (tile)
+  const int     my_lim   = busy ? min(wc, cs * (tri_last(R0 + 15, d.tgs) + 1)) : 0; // ... and this row group stops at its own last diagonal entry
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
   v4f64         acc = {0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < tile_lim; k0 += CW) {
@@ -680,7 +680,7 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
         dbl2      a01 = c01[u], a23 = c23[u];
         const int c = cb + u * step + 4 * g; // this lane's first column
         if (row < w) {                        // triangular top block: nothing right of the diagonal (entry = cs doubles)
-          const int last = cs * (row + 1) - 1;
+          const int last = cs * (tri_last(row, d.tgs) + 1) - 1;
           a01.x = c <= last ? a01.x : 0.0;
           a01.y = c + 1 <= last ? a01.y : 0.0;
           a23.x = c + 2 <= last ? a23.x : 0.0;
@@ -1062,6 +1062,8 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   f_off     = hf.f_off;
   row_ptr   = hf.sym.row_ptr;
   goff      = hf.goff;
+  tgs.assign(hf.tgs.begin(), hf.tgs.end());
+  if ((idx_t)tgs.size() != nblk) tgs.assign(nblk, 0);
   // transposed copies of the narrow forward panels
   ft_off.assign(nblk, -1);
   ldh.assign(nblk, 0);
@@ -1208,6 +1210,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.cs    = cs;
       d.u_off = D.u_off[k];
       d.has_src = D.has_src[k] ? 1 : 0;
+      d.tgs     = D.tgs.empty() ? 0 : D.tgs[k];
       d.FT      = D.ft_off[k] >= 0 ? D.FT.p + D.ft_off[k] : nullptr;
       d.ldh     = D.ldh[k];
       const int id = (int)descs.size();

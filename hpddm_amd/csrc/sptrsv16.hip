@@ -285,7 +285,7 @@ __device__ static inline void fwd_wave_tile16(const SnView &d, const Tile &t, in
     const int   re = min(r0 + 32, rend);
     const gcd_t P    = d.FT + r0;
     const int   mlim = min((re - r0 + 1) & ~1, ldh - r0);
-    const int   klo[1] = {0}, khi[1] = {re - 1 < w ? cs * re : wc}; // rows of the top block stop at their diagonal entry
+    const int   klo[1] = {0}, khi[1] = {re - 1 < w ? min(wc, cs * (tri_last(re - 1, d.tgs) + 1)) : wc}; // rows of the top block stop at their diagonal entry (tile)
     const int   k4 = (khi[0] + 3) & ~3;
     dbl2        ring[PF][1];
     wave_pipe_prime<1, PF>(ring, P, ldh, wc, mlim, 0, k4, klo, khi, lane); // the panel does not wait for the right-hand side
@@ -437,7 +437,7 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
   const int     R0 = t.r0 + 16 * rg, row = R0 + (lane & 15), g = lane >> 4, j = lane & 15;
   const bool    rvalid = busy && row < rend;
   double       *red  = lds;                              // [4 wavefronts][16 rows][16]
-  const int     my_lim = busy ? min(wc, cs * (R0 + 16)) : 0; // the row group stops at its own last diagonal entry
+  const int     my_lim = busy ? min(wc, cs * (tri_last(R0 + 15, d.tgs) + 1)) : 0; // the row group stops at its own last diagonal entry (tile)
   const int     step = 16 * wpg, cmy = (my_lim + 15) & ~15;
   const gcd_t   Frow = d.F + (long long)row * ldw + 4 * g;
   const double *fb   = bb + (long long)d.c0 * C16 + j;   // f[c][j] at fb[c * 16]
@@ -467,7 +467,7 @@ __device__ static inline void fwd_block_tile16(const SnView &d, const Tile &t, d
         dbl2      a01 = r01[u], a23 = r23[u];
         const int c = cu + 4 * g; // this lane's first column
         if (row < w) {             // triangular top block: nothing right of the diagonal (entry = cs doubles)
-          const int last = cs * (row + 1) - 1;
+          const int last = cs * (tri_last(row, d.tgs) + 1) - 1;
           a01.x = c <= last ? a01.x : 0.0;
           a01.y = c + 1 <= last ? a01.y : 0.0;
           a23.x = c + 2 <= last ? a23.x : 0.0;

@@ -22,7 +22,7 @@ struct SnView {
   gci_t     rows, gptr, gsrc;
   gci4_t    src4;
   long long voff, uoff;
-  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh;
+  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh, tgs;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
@@ -33,8 +33,12 @@ __device__ static inline SnView view(const SnDesc &d)
   v.src4 = (gci4_t)d.src4;
   v.voff = d.voff, v.uoff = d.uoff;
   v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
+  v.tgs = d.tgs;
   return v;
 }
+// forward sweep: last column (scalar index) of the top block that row r holds an entry in -- r itself when the block is lower
+// triangular (tgs = 0), the last column of r's diagonal tile when the LU factorisation swapped rows inside its tiles (SnDesc::tgs)
+__device__ static inline int tri_last(int r, int tgs) { return (int)(((((long long)r >> tgs) + 1) << tgs) - 1); }
 // LDS traffic between the lanes of ONE wavefront: make the writes land before the reads (no workgroup barrier)
 __device__ static inline void wave_lds_sync()
 {

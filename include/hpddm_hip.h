@@ -58,7 +58,7 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
 int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
 /* Raw factor arrays for inspection / tests / the CPU baseline of bench.py (host copies; sizes from Info + the
  * arrays themselves).  which: "perm" "blk_ptr" "ldw" "f_off" "row_ptr" "rows" "height" "u_off" "goff" "gptr" "gsrc"
- * (int64 output), "F" "G" "dinv" "Lplain" "Uplain" (double output).  Returns the element count; out may be NULL. */
+ * "tgs" (per supernode: 0, or 6 when the LU factorisation exchanged rows inside its 64-column tiles) (int64 output), "F" "G" "dinv" "Lplain" "Uplain" (double output).  Returns the element count; out may be NULL. */
 long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which, void *out, long long capacity);
 /* the double arrays of the list above without a copy: pointer into the solver's own storage (valid until the next Numfact /
  * Destroy), *count = number of doubles; NULL on error.  The plain factor of a 129^3 subdomain is 12 GB. */

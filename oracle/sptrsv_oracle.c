@@ -144,9 +144,11 @@ static void solve_one_team(const oracle_factor *f, const double *b, double *x, d
     const ll     *r  = f->rows + f->row_ptr[k];
     for (ll j = 0; j < w; ++j) t[j] = y[c0 + j];
     if (team > 1 && nb * w >= TEAM_MIN_WORK) {
+      int got = 1; /* the runtime may grant fewer threads than asked for (nested region, thread limit) */
 #pragma omp parallel num_threads(team)
       {
         const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+        if (tid == 0) got = nt;
         double   *tp  = tpriv + (size_t)tid * wmax;
         for (ll j = 0; j < w; ++j) tp[j] = 0.0;
         const ll i0 = nb * tid / nt, i1 = nb * (tid + 1) / nt;
@@ -156,7 +158,7 @@ static void solve_one_team(const oracle_factor *f, const double *b, double *x, d
           for (ll j = 0; j < w; ++j) tp[j] -= row[j] * xi;
         }
       }
-      for (int q = 0; q < team; ++q)
+      for (int q = 0; q < got; ++q)
         for (ll j = 0; j < w; ++j) t[j] += tpriv[(size_t)q * wmax + j];
     } else
       for (ll i = 0; i < nb; ++i) {

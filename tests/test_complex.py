@@ -153,6 +153,7 @@ def test_complex_device_levels_refuse_a_collapsed_pivot(monkeypatch):
     """the pivot rule of the complex tile kernels: a zero diagonal block of a complex symmetric matrix breaks down loudly on the device
     levels as it does on the host"""
     monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "64")
+    monkeypatch.setenv("HPDDM_HIP_NO_LU_FALLBACK", "1")   # (with it the matrix goes on as LU with pivoting inside the tiles: tests/test_pivoting.py)
     n = 12
     K = _laplace3d(n)
     N = n ** 3

@@ -34,20 +34,21 @@ def test_one_by_one_diagonal_and_disconnected_matrices():
 
 
 def test_zero_pivot_is_reported_not_hidden():
-    M = sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 0.0]]))  # needs pivoting: the pivot-free factorisation must refuse it
+    M = sp.csr_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))  # singular: no row of the tile can serve as the second pivot
     S = hpddm.Subdomain()
     with pytest.raises(HpddmHipError, match="pivot"):
         S.numfact(2, M.indptr, M.indices, M.data, sym=False)
     S.destroy()
 
 
-def test_collapsed_and_small_pivots_fail_loudly():
-    """The solver does not pivot (the reference's MUMPS / PARDISO do): a pivot that collapses against its tile is a breakdown, a
-    factor that is not backward stable is refused by the probe solve that closes numfact -- never a silently wrong solution."""
+def test_collapsed_pivots_of_the_symmetric_kinds_fail_loudly_without_the_lu_fallback(monkeypatch):
+    """L D L^T does not pivot: a pivot that collapses against its tile is a breakdown, a factor that is not backward stable is
+    refused by the probe solve that closes numfact -- with the fall-back to LU (tests/test_pivoting.py) switched off, never a
+    silently wrong solution."""
+    monkeypatch.setenv("HPDDM_HIP_NO_LU_FALLBACK", "1")
     lap = _lap(4)
-    for eps, sym in ((1e-18, True), (1e-18, False), (1e-11, True), (1e-11, False)):
-        blk = np.array([[eps, 1.0], [1.0, eps]]) if sym else np.array([[eps, 1.0], [2.0, eps]])
-        M = sp.block_diag([lap, sp.csr_matrix(blk)]).tocsr()
+    for eps in (1e-18, 1e-11):
+        M = sp.block_diag([lap, sp.csr_matrix(np.array([[eps, 1.0], [1.0, eps]]))]).tocsr()
         M.sort_indices()
         S = hpddm.Subdomain()
         with pytest.raises(HpddmHipError, match="pivot"):
@@ -58,6 +59,7 @@ def test_collapsed_and_small_pivots_fail_loudly():
     A.sort_indices()
     S = hpddm.Subdomain()
     S.numfact(216, A.indptr, A.indices, A.data, sym=False)
+    assert S.info()["kind"] == 1
     x = S.solve(np.ones(216))
     assert np.abs(A @ x - 1.0).max() < 1e-9
     S.destroy()

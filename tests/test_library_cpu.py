@@ -32,7 +32,7 @@ def _poisson3d(N):
 
 def _replay(S, b):
     """numpy replay of the level-scheduled multifrontal solve on the exported solve-ready panels (factor.hpp)"""
-    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "goff", "gptr", "gsrc")}
+    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "goff", "gptr", "gsrc", "tgs")}
     kind = S.info()["kind"]
     F = S.export("F")
     G = S.export("G") if kind == 2 else F
@@ -44,7 +44,8 @@ def _replay(S, b):
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
         h, ld = w + nb, e["ldw"][k]
         P = F[e["f_off"][k]:e["f_off"][k] + h * ld].reshape(h, ld)[:, :w]
-        assert np.all(np.triu(P[:w], 1) == 0.0)
+        t = 1 << int(e["tgs"][k])   # LU that exchanged rows inside its tiles: block lower triangular, dense t x t diagonal tiles
+        assert np.all(P[:w][(np.arange(w)[None, :] // t) > (np.arange(w)[:, None] // t)] == 0.0) if e["tgs"][k] else np.all(np.triu(P[:w], 1) == 0.0)
         gp = e["gptr"][e["goff"][k]:e["goff"][k] + h + 1]
         gath = np.array([U[e["gsrc"][gp[i]:gp[i + 1]]].sum() for i in range(h)])
         t = P @ (b[e["perm"][c0:c0 + w]] - gath[:w])
@@ -54,6 +55,7 @@ def _replay(S, b):
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
         h, ld = w + nb, e["ldw"][k]
         P = G[e["f_off"][k]:e["f_off"][k] + h * ld].reshape(h, ld)[:, :w]
+        assert np.all(np.triu(P[:w], 1) == 0.0)
         v = np.concatenate([y[c0:c0 + w] * (dinv[c0:c0 + w] if dinv is not None else 1.0), -x[e["rows"][rp[k]:rp[k + 1]]]])
         x[c0:c0 + w] = P.T @ v
     out = np.zeros(n)
@@ -91,6 +93,66 @@ def test_host_factorisation(kind):
     b = rng.random(n)
     x = _replay(S, b)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
+    S.destroy()
+
+
+def _stokes2d(N):
+    """MAC-like saddle point [A B^T; B 0]: two Laplacians, a discrete divergence, one pressure row dropped (constant null space)"""
+    I = sp.identity(N)
+    Tm = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    L = (sp.kron(Tm, I) + sp.kron(I, Tm)).tocsr()
+    D = sp.diags([-1, 1], [0, 1], shape=(N, N))
+    B = sp.hstack([sp.kron(I, D), sp.kron(D, I)]).tocsr()[:-1]
+    return sp.bmat([[sp.block_diag([L, L]), B.T], [B, None]]).tocsr()
+
+
+def _row_swapped_pairs(n):
+    """two unknowns per grid node, the two ROWS of every node exchanged: zero diagonal entries everywhere, the entries that can
+    serve as pivots sit right next to the diagonal -- inside the node, hence inside the 64-column tile (supernodes of such matrices
+    have even widths); unsymmetric coupling between the nodes"""
+    K = _poisson3d(n)
+    C = (K + 0.3 * sp.triu(K, 1)).tocsr()
+    Dg = sp.diags(C.diagonal())
+    M = sp.kron(Dg, np.diag([2.0, 3.0])) + sp.kron(C - Dg, np.array([[1.0, 0.5], [0.3, 1.0]]))
+    A = (sp.kron(sp.identity(n ** 3), np.array([[0.0, 1.0], [1.0, 0.0]])) @ M).tocsr()
+    A.eliminate_zeros()
+    return A
+
+
+def test_host_lu_pivots_inside_the_diagonal_tiles():
+    """numeric_host.cpp / dense_host.hpp: threshold partial pivoting among the rows of a 64-column tile (static structure), the
+    fall-back L D L^T -> LU on a collapsed pivot, zero diagonal entries paired with a neighbour by the ordering -- the reference's
+    local solvers pivot (include/HPDDM_MUMPS.hpp:228-291); replay of the solve in numpy on the exported panels"""
+    rng = np.random.default_rng(2)
+    cases = [("antidiagonal", sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 0.0]])), 2, True),
+             ("tiny diagonal block", sp.block_diag([_poisson3d(4), sp.csr_matrix(np.array([[1e-18, 1.0], [2.0, 1e-18]]))]).tocsr(), 2, True),
+             ("row-swapped pairs", _row_swapped_pairs(7), 2, True),
+             ("stokes 24", _stokes2d(24), 1, False),      # paired by the ordering: L D L^T goes through without an exchange
+             ("stokes 96", _stokes2d(96), None, None)]
+    for name, A, kind, swapped in cases:
+        A = A.tocsr()
+        A.sort_indices()
+        n = A.shape[0]
+        S = hpddm.Subdomain(host_only=1)
+        S.numfact(n, A.indptr, A.indices, A.data, sym=False)
+        if kind is not None:
+            assert S.info()["kind"] == kind, name
+            assert bool(np.any(S.export("tgs") != 0)) == swapped, name
+        b = rng.random(n)
+        x = _replay(S, b)
+        assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max()) * abs(A).sum(axis=1).max(), name
+        S.destroy()
+    # a tile without any pivot left is refused, loudly: singular matrix
+    M = sp.block_diag([_poisson3d(3), sp.csr_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))]).tocsr()
+    S = hpddm.Subdomain(host_only=1)
+    with pytest.raises(_lib.HpddmHipError, match="pivot"):
+        S.numfact(M.shape[0], M.indptr, M.indices, M.data, sym=False)
+    S.destroy()
+    # the plain factor (CPU baseline of bench.py) does not exist for a front whose rows were exchanged
+    A = _row_swapped_pairs(4)
+    S = hpddm.Subdomain(host_only=1, keep_plain=1)
+    with pytest.raises(_lib.HpddmHipError, match="plain factor"):
+        S.numfact(A.shape[0], A.indptr, A.indices, A.data, sym=False)
     S.destroy()
 
 

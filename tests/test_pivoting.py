@@ -1,0 +1,112 @@
+"""Pivoting inside the diagonal tiles (the reference's local solvers pivot, include/HPDDM_MUMPS.hpp:228-291): LU
+with threshold partial pivoting among the rows of a 64-column tile -- host levels (dense_host.hpp) and device levels
+(k_getf2_inv) --, the forward sweep on panels whose top block has dense diagonal tiles (SnDesc::tgs; VALU and MFMA paths), the
+fall-back ladder Cholesky -> L D L^T -> LU, zero diagonal entries paired with a neighbour by the ordering.  Against SciPy's
+SuperLU at 1e-9; what static pivoting cannot factorise is still refused, loudly."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from hpddm_amd import hpddm
+from hpddm_amd._lib import HpddmHipError
+from test_library_cpu import _poisson3d, _row_swapped_pairs, _stokes2d
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_and_compare(A, mus=(1,), tol=1e-9, sym_storage=False, cplx=False):
+    A = A.tocsr()
+    n = A.shape[0]
+    M = sp.tril(A, format="csr") if sym_storage else A
+    M.sort_indices()
+    S = hpddm.Subdomain()
+    S.numfact(n, M.indptr, M.indices, M.data.astype(np.complex128) if cplx else M.data, sym=sym_storage)
+    lu = spl.splu(A.tocsc().astype(np.complex128 if cplx else np.float64))
+    rng = np.random.default_rng(7)
+    for mu in mus:
+        b = rng.random((n, mu)) + (1j * rng.random((n, mu)) if cplx else 0.0)
+        b = np.asfortranarray(b if mu > 1 else b[:, 0])
+        x = S.solve(b)
+        ref = lu.solve(np.asarray(b))
+        assert np.abs(x - ref).max() <= tol * np.abs(ref).max(), (mu, np.abs(x - ref).max() / np.abs(ref).max())
+    info = S.info()
+    swapped = int(np.count_nonzero(S.export("tgs")))
+    S.destroy()
+    return info["kind"], swapped
+
+
+def test_matrices_that_used_to_be_refused_are_solved():
+    assert _solve_and_compare(sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 0.0]]))) == (2, 1)
+    lap = _poisson3d(4)
+    for eps in (1e-18, 1e-11):   # collapsed pivot (breakdown of L D L^T) and small pivot (probe): both end as LU with an exchange
+        for blk in (np.array([[eps, 1.0], [1.0, eps]]), np.array([[eps, 1.0], [2.0, eps]])):
+            kind, swapped = _solve_and_compare(sp.block_diag([lap, sp.csr_matrix(blk)]), mus=(1, 3))
+            assert kind == 2 and swapped == 1
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_rows_exchanged_in_every_tile(where, monkeypatch):
+    """two unknowns per node with their rows exchanged: every tile of every front pivots -- host and device levels, real and complex,
+    1 to 16 right-hand sides (wave and block tiles of the VALU paths, the 16-column MFMA engine)"""
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where == "device" else "100000")
+    A = _row_swapped_pairs(13)
+    kind, swapped = _solve_and_compare(A, mus=(1, 3, 8, 16, 21))
+    assert kind == 2 and swapped > 50
+    kind, swapped = _solve_and_compare((A * (1.0 + 0.3j)).tocsr(), mus=(1, 8, 11), cplx=True)
+    assert kind == 2 and swapped > 50
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_saddle_point_matrices(where, monkeypatch):
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where == "device" else "100000")
+    kind, _ = _solve_and_compare(_stokes2d(40), mus=(1, 4))
+    assert kind in (1, 2)
+    kind, swapped = _solve_and_compare(_stokes2d(96), mus=(1, 16))
+    assert kind in (1, 2)
+    # 3-D: three Laplacians, discrete divergence
+    N = 9
+    I = sp.identity(N)
+    Tm = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    L = (sp.kron(sp.kron(Tm, I), I) + sp.kron(sp.kron(I, Tm), I) + sp.kron(sp.kron(I, I), Tm)).tocsr()
+    D = sp.diags([-1, 1], [0, 1], shape=(N, N))
+    B = sp.hstack([sp.kron(sp.kron(I, I), D), sp.kron(sp.kron(I, D), I), sp.kron(sp.kron(D, I), I)]).tocsr()[:-1]
+    A = sp.bmat([[sp.block_diag([L, L, L]), B.T], [B, None]]).tocsr()
+    _solve_and_compare(A, mus=(1, 5))
+    _solve_and_compare(A, mus=(2,), sym_storage=True)   # lower triangle only, zero diagonal entries stored or not
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_indefinite_helmholtz_with_little_absorption(where, monkeypatch):
+    """shift (1.0 + 0.005i) k^2: an indefinite complex symmetric operator (the tests of the complex path use 0.8i)"""
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where == "device" else "100000")
+    n = 16
+    K = _poisson3d(n) * float(n * n)
+    k2 = (3.5 * np.pi) ** 2
+    A = (K - (1.0 + 0.005j) * k2 * sp.identity(n ** 3)).tocsr()
+    _solve_and_compare(A, mus=(1, 8), cplx=True)
+    _solve_and_compare(A, mus=(3,), cplx=True, sym_storage=True)
+
+
+def test_what_static_pivoting_cannot_do_is_refused():
+    lap = _poisson3d(4)
+    for blk in (np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([[0.0, 0.0], [1.0, 2.0]])):   # singular tiles
+        M = sp.block_diag([lap, sp.csr_matrix(blk)]).tocsr()
+        M.sort_indices()
+        S = hpddm.Subdomain()
+        with pytest.raises(HpddmHipError, match="pivot"):
+            S.numfact(M.shape[0], M.indptr, M.indices, M.data, sym=False)
+        S.destroy()
+    # large entries outside the tiles (other supernodes): the factor grows, the probe solve that closes numfact says so
+    A = (_poisson3d(8) + sp.random(512, 512, density=0.01, random_state=3) * 5.0).tolil()
+    A.setdiag(A.diagonal() * 0.01)
+    A = A.tocsr()
+    S = hpddm.Subdomain()
+    try:
+        S.numfact(512, A.indptr, A.indices, A.data, sym=False)
+    except HpddmHipError as e:
+        assert "pivot" in str(e)
+    else:   # never a silently wrong solution: whatever is accepted is accurate
+        b = np.ones(512)
+        assert np.abs(A @ S.solve(b) - b).max() < 1e-7 * np.abs(b).max() * abs(A).sum(axis=1).max()
+    S.destroy()
