@@ -345,7 +345,8 @@ def roofline(bytes_alg, t_solve, st, args, mu):
          "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve, "stored_bytes_per_sweep": 2.0 * st["stored"] * (16.0 if bytes_alg > 2.0 * st["nnz_L"] * 12.0 else 8.0)}
     # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     # scripts/pmc_traffic.sh): only quoted for the workload it was collected on (same algorithmic bytes)
-    for name in ("r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
+    # (NOT measured in this run: counters need their own rocprofv3 passes -- the key below says which file the number is read from)
+    for name in ("r03_pmc_traffic_c3.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if mu == 1 and os.path.exists(pmc):
             with open(pmc) as fh:
@@ -353,6 +354,7 @@ def roofline(bytes_alg, t_solve, st, args, mu):
             if abs(tr.get("algorithmic_bytes", 0.0) - bytes_alg) < 1e-6 * bytes_alg:
                 r["traffic"] = tr["traffic_bytes"]
                 r["traffic_source"] = f"profiles/{name} ((2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc, separate passes)"
+                r["traffic_measured_in_this_run"] = False
                 break
     return r
 
