@@ -187,7 +187,12 @@ def main():
     t_setup = time.time() - t0 - t_gen
     # of which: the plain factor kept for the CPU baseline leg (-hpddm_keep_plain: every front copied off the device before it is
     # inverted -- 97 GB at configs[2]); not part of the set-up of the operator
-    t_plain = sum(A.subdomain(s).info()["plain_export_us"] for s in range(len(subs))) * 1e-6 if want_cpu else 0.0
+    infos = [A.subdomain(s).info() for s in range(len(subs))]
+    t_plain = sum(i["plain_export_us"] for i in infos) * 1e-6 if want_cpu else 0.0
+    # where the set-up goes, summed over the subdomains of this GPU (they are factorised one after the other): analysis on the
+    # host, numerical factorisation (host levels + device levels; contains the plain-factor copies when the CPU baseline asks for
+    # them), upload of the host levels + the solve plan
+    setup_parts = {k: round(sum(i[k] for i in infos), 2) for k in ("t_order", "t_symbolic", "t_numeric", "t_upload")}
     st = A.stats()
     ntot = int(st["n"])                      # unknowns in scalars K
     sk = 16.0 if A.complex else 8.0          # sizeof(K)
@@ -304,7 +309,8 @@ def main():
                                         else "replicas (one independent 8-subdomain block per GPU)")),
                        "n_dof_per_gpu": ntot, "nnz_L_per_gpu": st["nnz_L"], "levels": st["levels"], "launches_per_sptrsv": st["launches"],
                        "setup_seconds": round(t_setup, 2), "generator_seconds": round(t_gen, 2),
-                       "setup_seconds_of_which_plain_factor_for_cpu_baseline": round(t_plain, 2)},
+                       "setup_seconds_of_which_plain_factor_for_cpu_baseline": round(t_plain, 2),
+                       "setup_seconds_by_phase_summed_over_subdomains": setup_parts},
         }
         if world > 1:
             # `value` counts applies of one GPU's share (weak) or of the global operator (strong); the global rate is always printed

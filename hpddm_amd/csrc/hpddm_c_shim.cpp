@@ -1,4 +1,6 @@
-// libhpddm_c_hip.so: the reference's C API (interface/HPDDM.h:66-118, K = double) on top of libhpddm_hip.so + MPI.
+// libhpddm_c_hip.so: the reference's C API (interface/HPDDM.h:66-118) on top of libhpddm_hip.so + MPI.  Like the reference's
+// interface/hpddm_c.cpp the file is compiled for ONE scalar type K (interface/HPDDM.h:34-50): double, or -- with -DFORCE_COMPLEX,
+// libhpddm_c_hip_z.so -- double _Complex (std::complex<double> here: the same bytes).
 // See include/hpddm_c_compat.h.  Reference binding this replaces: interface/hpddm_c.cpp:30-260.
 //
 // One MPI rank = one subdomain, as in the reference.  Every rank owns a one-subdomain HpddmHipSchwarz; the halo of
@@ -12,11 +14,21 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <complex>
 #include <cstring>
 #include <map>
 #include <set>
 #include <string>
 #include <vector>
+
+typedef HpddmK K;
+#ifdef FORCE_COMPLEX
+static const int SC = 2; // doubles per scalar: the vector entry points of hpddm_hip.h take (re, im) pairs through double pointers
+#else
+static const int SC = 1;
+#endif
+static inline const double *dp(const K *p) { return reinterpret_cast<const double *>(p); }
+static inline double       *dp(K *p) { return reinterpret_cast<double *>(p); }
 
 struct HpddmOption {
   std::map<std::string, double> opt, app;
@@ -24,7 +36,7 @@ struct HpddmOption {
 };
 struct HpddmMatrixCSR {
   int     n, m, nnz;
-  double *a;
+  K      *a;
   int    *ia, *ja;
   bool    sym, own;
 };
@@ -46,7 +58,7 @@ struct HpddmSchwarz {
   double                *send_d = nullptr, *recv_d = nullptr;
   std::vector<double>    send_h, recv_h;
   // deflation vectors handed over by HpddmSetVectors
-  double **vectors = nullptr;
+  K      **vectors = nullptr;
   bool     from_gevp = false;
 };
 
@@ -154,14 +166,14 @@ int allreduce_cb(void *ctx, double *buf, int n)
 }
 void ensure_transport(HpddmSchwarz *S, int mu)
 {
-  if (S->size == 1 || mu <= S->mu_cap) return;
+  if (S->size == 1 || SC * mu <= S->mu_cap) return;
   const int np = HpddmHipSchwarzHaloPeers(S->A, 0, nullptr, nullptr, nullptr);
   if (np < 0) fail("halo peers");
   S->peer.resize(np), S->cnt.resize(np), S->off.resize(np);
   if (np) HpddmHipSchwarzHaloPeers(S->A, np, S->peer.data(), S->cnt.data(), S->off.data());
   S->total = 0;
   for (int p = 0; p < np; ++p) S->total += S->cnt[p];
-  const int cap = std::max(mu, 32);
+  const int cap = std::max(SC * mu, 32);
   if (S->send_d) (void)hipFree(S->send_d);
   if (S->recv_d) (void)hipFree(S->recv_d);
   const size_t doubles = (size_t)std::max<long long>(1, S->total) * cap;
@@ -232,7 +244,7 @@ double  HpddmOptionApp(const HpddmOption *, const char *key)
   return it == g_opt.app.end() ? 0.0 : it->second;
 }
 
-HpddmMatrixCSR *HpddmMatrixCSRCreate(int n, int m, int nnz, double *a, int *ia, int *ja, bool sym, bool takeOwnership) { return new HpddmMatrixCSR{n, m, nnz, a, ia, ja, sym, takeOwnership}; }
+HpddmMatrixCSR *HpddmMatrixCSRCreate(int n, int m, int nnz, K *a, int *ia, int *ja, bool sym, bool takeOwnership) { return new HpddmMatrixCSR{n, m, nnz, a, ia, ja, sym, takeOwnership}; }
 void            HpddmMatrixCSRDestroy(HpddmMatrixCSR *M)
 {
   if (!M) return;
@@ -243,14 +255,14 @@ void            HpddmMatrixCSRDestroy(HpddmMatrixCSR *M)
   }
   delete M;
 }
-void HpddmCSRMM(HpddmMatrixCSR *M, const double *x, double *y, int mu)
+void HpddmCSRMM(HpddmMatrixCSR *M, const K *x, K *y, int mu)
 {
   // Wrapper::csrmm (include/HPDDM_wrapper.hpp:697-733), host side (used by the single-rank branch of the example only)
   const int base = M->ia[0];
   for (int nu = 0; nu < mu; ++nu) {
-    const double *xc = x + (size_t)nu * M->m;
-    double       *yc = y + (size_t)nu * M->n;
-    std::fill(yc, yc + M->n, 0.0);
+    const K *xc = x + (size_t)nu * M->m;
+    K       *yc = y + (size_t)nu * M->n;
+    std::fill(yc, yc + M->n, K(0.0));
     for (int i = 0; i < M->n; ++i)
       for (int p = M->ia[i] - base; p < M->ia[i + 1] - base; ++p) {
         const int j = M->ja[p] - base;
@@ -264,9 +276,20 @@ void HpddmSubdomainNumfact(HpddmSubdomain **S, HpddmMatrixCSR *M)
 {
   if (!*S) *S = new HpddmSubdomain();
   const int spd = g_opt.opt.count("operator_spd") && g_opt.opt["operator_spd"] != 0.0;
+#ifdef FORCE_COMPLEX
+  CK(HpddmHipSubdomainNumfactZ(&(*S)->S, M->n, M->ia, M->ja, dp(M->a), M->sym ? 1 : 0, M->ia[0] == 1 ? 'F' : 'C', spd), "HpddmSubdomainNumfact");
+#else
   CK(HpddmHipSubdomainNumfact(&(*S)->S, M->n, M->ia, M->ja, M->a, M->sym ? 1 : 0, M->ia[0] == 1 ? 'F' : 'C', spd), "HpddmSubdomainNumfact");
+#endif
 }
-void HpddmSubdomainSolve(HpddmSubdomain *S, const double *b, double *x, unsigned short mu) { CK(HpddmHipSubdomainSolve(S->S, b, x, mu), "HpddmSubdomainSolve"); }
+void HpddmSubdomainSolve(HpddmSubdomain *S, const K *b, K *x, unsigned short mu)
+{
+#ifdef FORCE_COMPLEX
+  CK(HpddmHipSubdomainSolveZ(S->S, dp(b), dp(x), mu), "HpddmSubdomainSolve");
+#else
+  CK(HpddmHipSubdomainSolve(S->S, b, x, mu), "HpddmSubdomainSolve");
+#endif
+}
 void HpddmSubdomainDestroy(HpddmSubdomain *S)
 {
   if (!S) return;
@@ -297,7 +320,11 @@ HpddmSchwarz *HpddmSchwarzCreate(HpddmMatrixCSR *M, int neighbors, int *list, in
   for (int k = 0; k < neighbors; ++k) S->conn[k].assign(connectivity[k], connectivity[k] + sizes[k]);
   S->A = HpddmHipSchwarzCreate(1, S->rank, S->size);
   if (!S->A) fail("HpddmSchwarzCreate");
+#ifdef FORCE_COMPLEX
+  CK(HpddmHipSchwarzSetSubdomainZ(S->A, 0, M->n, M->ia, M->ja, dp(M->a), M->sym ? 1 : 0, M->ia[0] == 1 ? 'F' : 'C', neighbors, list, sizes, connectivity), "HpddmSchwarzCreate");
+#else
   CK(HpddmHipSchwarzSetSubdomain(S->A, 0, M->n, M->ia, M->ja, M->a, M->sym ? 1 : 0, M->ia[0] == 1 ? 'F' : 'C', neighbors, list, sizes, connectivity), "HpddmSchwarzCreate");
+#endif
   std::vector<int> firsts(S->size + 1);
   for (int r = 0; r <= S->size; ++r) firsts[r] = r;
   CK(HpddmHipSchwarzSetPartition(S->A, S->size, S->rank, firsts.data()), "HpddmSchwarzCreate");
@@ -326,10 +353,10 @@ void HpddmSchwarzMultiplicityScaling(HpddmSchwarz *S, double *d)
   for (int i = 0; i < S->mat->n; ++i) d[i] = d[i] < 1.0e-12 ? 0.0 : d[i] / sum[i];
 }
 void HpddmSchwarzInitialize(HpddmSchwarz *S, double *d) { CK(HpddmHipSchwarzInitialize(S->A, 0, d), "HpddmSchwarzInitialize"); }
-void HpddmSchwarzExchange(HpddmSchwarz *S, double *x, unsigned short mu)
+void HpddmSchwarzExchange(HpddmSchwarz *S, K *x, unsigned short mu)
 {
   ensure_transport(S, mu);
-  CK(HpddmHipSchwarzExchange(S->A, x, mu), "HpddmSchwarzExchange");
+  CK(HpddmHipSchwarzExchange(S->A, dp(x), mu), "HpddmSchwarzExchange");
 }
 void HpddmSchwarzCallNumfact(HpddmSchwarz *S)
 {
@@ -337,14 +364,18 @@ void HpddmSchwarzCallNumfact(HpddmSchwarz *S)
   ensure_transport(S, 1);
   CK(HpddmHipSchwarzCallNumfact(S->A), "HpddmSchwarzCallNumfact");
 }
-void HpddmSetVectors(HpddmPreconditioner *P, double **v) { ((HpddmSchwarz *)P)->vectors = v; }
+void HpddmSetVectors(HpddmPreconditioner *P, K **v) { ((HpddmSchwarz *)P)->vectors = v; }
 void HpddmInitializeCoarseOperator(HpddmPreconditioner *P, unsigned short nu)
 {
   HpddmSchwarz *S = (HpddmSchwarz *)P;
   if (S->from_gevp || !S->vectors) return; // the vectors already sit in the operator (SolveGEVP)
-  std::vector<double> Z((size_t)S->mat->n * nu);
+  std::vector<K> Z((size_t)S->mat->n * nu);
   for (unsigned short k = 0; k < nu; ++k) std::copy_n(S->vectors[k], S->mat->n, Z.data() + (size_t)k * S->mat->n);
+#ifdef FORCE_COMPLEX
+  CK(HpddmHipSchwarzSetVectorsZ(S->A, 0, nu, dp(Z.data())), "HpddmInitializeCoarseOperator");
+#else
   CK(HpddmHipSchwarzSetVectors(S->A, 0, nu, Z.data()), "HpddmInitializeCoarseOperator");
+#endif
 }
 void HpddmDestroyVectors(HpddmPreconditioner *P)
 {
@@ -358,7 +389,13 @@ void HpddmDestroyVectors(HpddmPreconditioner *P)
 void HpddmSchwarzSolveGEVP(HpddmSchwarz *S, HpddmMatrixCSR *N)
 {
   sync_options(S);
+#ifdef FORCE_COMPLEX
+  (void)N;
+  fprintf(stderr, "libhpddm_c_hip_z: HpddmSchwarzSolveGEVP is not available for complex scalars in this build (hand the deflation vectors over with HpddmSetVectors)\n");
+  MPI_Abort(MPI_COMM_WORLD, 1);
+#else
   CK(HpddmHipSchwarzSolveGEVP(S->A, 0, N->n, N->ia, N->ja, N->a, N->sym ? 1 : 0, N->ia[0] == 1 ? 'F' : 'C'), "HpddmSchwarzSolveGEVP");
+#endif
   S->from_gevp = true;
 }
 void HpddmSchwarzBuildCoarseOperator(HpddmSchwarz *S, MPI_Comm comm)
@@ -368,10 +405,10 @@ void HpddmSchwarzBuildCoarseOperator(HpddmSchwarz *S, MPI_Comm comm)
   ensure_transport(S, (int)std::max(1.0, g_opt.opt.count("geneo_nu") ? g_opt.opt["geneo_nu"] : 1.0));
   CK(HpddmHipSchwarzBuildCoarseOperator(S->A), "HpddmSchwarzBuildCoarseOperator");
 }
-void HpddmSchwarzComputeResidual(HpddmSchwarz *S, const double *sol, const double *f, double *storage, unsigned short mu)
+void HpddmSchwarzComputeResidual(HpddmSchwarz *S, const K *sol, const K *f, double *storage, unsigned short mu)
 {
   ensure_transport(S, mu);
-  CK(HpddmHipSchwarzComputeResidual(S->A, sol, f, storage, mu), "HpddmSchwarzComputeResidual");
+  CK(HpddmHipSchwarzComputeResidual(S->A, dp(sol), dp(f), storage, mu), "HpddmSchwarzComputeResidual");
 }
 void HpddmSchwarzDestroy(HpddmSchwarz *S)
 {
@@ -382,12 +419,12 @@ void HpddmSchwarzDestroy(HpddmSchwarz *S)
   HpddmMatrixCSRDestroy(S->mat); // the operator owns its matrix (Subdomain::destroyMatrix, include/HPDDM_subdomain.hpp:368-393)
   delete S;
 }
-int HpddmSolve(HpddmSchwarz *S, const double *b, double *sol, int mu, const MPI_Comm *comm)
+int HpddmSolve(HpddmSchwarz *S, const K *b, K *sol, int mu, const MPI_Comm *comm)
 {
   if (comm) S->comm = *comm;
   sync_options(S);
   ensure_transport(S, mu);
-  const int it = HpddmHipSolve(S->A, b, sol, mu, nullptr, 0);
+  const int it = HpddmHipSolve(S->A, dp(b), dp(sol), mu, nullptr, 0);
   if (it < 0) fail("HpddmSolve");
   return it;
 }
@@ -396,6 +433,7 @@ int HpddmSolve(HpddmSchwarz *S, const double *b, double *sol, int mu, const MPI_
 // IterativeMethod::solve.  Here: a one-subdomain operator without neighbours whose GMV / apply are the callbacks (d = 1, the
 // identity matrix only gives the operator its size), solved by the same device-resident Krylov methods as HpddmSolve.
 struct HpddmCustomOperator;
+#ifndef FORCE_COMPLEX
 namespace {
 struct CustomCtx {
   const HpddmCustomOperator *op;
@@ -434,14 +472,23 @@ int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(con
   if (S.recv_d) (void)hipFree(S.recv_d);
   return it;
 }
+#else
+// (callbacks on complex host vectors: the custom-operator entry point of hpddm_hip.h is real in this build)
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *, int, int (*)(const HpddmCustomOperator *, const K *, K *, int), int (*)(const HpddmCustomOperator *, const K *, K *, int), const K *, K *, int, const MPI_Comm *)
+{
+  fprintf(stderr, "libhpddm_c_hip_z: HpddmCustomOperatorSolve is not available for complex scalars in this build\n");
+  MPI_Abort(MPI_COMM_WORLD, 1);
+  return -1;
+}
+#endif
 
-double nrm2(const int *n, const double *x, const int *inc)
+double nrm2(const int *n, const K *x, const int *inc)
 {
   double s = 0.0;
-  for (int i = 0; i < *n; ++i) s += x[(size_t)i * *inc] * x[(size_t)i * *inc];
+  for (int i = 0; i < *n; ++i) s += std::norm(x[(size_t)i * *inc]);
   return std::sqrt(s);
 }
-void axpy(const int *n, const double *a, const double *x, const int *incx, double *y, const int *incy)
+void axpy(const int *n, const K *a, const K *x, const int *incx, K *y, const int *incy)
 {
   for (int i = 0; i < *n; ++i) y[(size_t)i * *incy] += *a * x[(size_t)i * *incx];
 }

@@ -1,4 +1,5 @@
-/* hpddm_c_compat.h -- the reference's own C API (interface/HPDDM.h:66-118), K = double, exported by libhpddm_c_hip.so
+/* hpddm_c_compat.h -- the reference's own C API (interface/HPDDM.h:66-118) exported by libhpddm_c_hip.so (K = double) and, compiled
+ * with -DFORCE_COMPLEX like the reference's library, by libhpddm_c_hip_z.so (K = double _Complex, interface/HPDDM.h:34-50)
  * on top of libhpddm_hip.so, so that a C program written against HPDDM.h (examples/schwarz.c + examples/generate.c)
  * links and runs UNCHANGED with every subdomain factorised and solved on the MI355X.
  *
@@ -16,6 +17,16 @@
 #define HPDDM_C_COMPAT_H_
 #include <mpi.h>
 #include <stdbool.h>
+#ifdef FORCE_COMPLEX /* one scalar type per library, as in the reference */
+  #ifdef __cplusplus
+    #include <complex>
+typedef std::complex<double> HpddmK;
+  #else
+typedef double _Complex HpddmK;
+  #endif
+#else
+typedef double HpddmK;
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -37,16 +48,16 @@ double             HpddmOptionVal(const HpddmOption *, const char *);           
 double            *HpddmOptionAddr(const HpddmOption *, const char *);                        /* :77 */
 double             HpddmOptionApp(const HpddmOption *, const char *);                         /* :78 */
 
-HpddmMatrixCSR *HpddmMatrixCSRCreate(int n, int m, int nnz, double *a, int *ia, int *ja, bool sym, bool takeOwnership); /* :82 */
+HpddmMatrixCSR *HpddmMatrixCSRCreate(int n, int m, int nnz, HpddmK *a, int *ia, int *ja, bool sym, bool takeOwnership); /* :82 */
 void            HpddmMatrixCSRDestroy(HpddmMatrixCSR *);                                      /* :83 */
-void            HpddmCSRMM(HpddmMatrixCSR *, const double *, double *, int);                  /* :84 */
+void            HpddmCSRMM(HpddmMatrixCSR *, const HpddmK *, HpddmK *, int);                  /* :84 */
 
 void HpddmSubdomainNumfact(HpddmSubdomain **, HpddmMatrixCSR *);                              /* :88 */
-void HpddmSubdomainSolve(HpddmSubdomain *, const double *, double *, unsigned short);         /* :89 */
+void HpddmSubdomainSolve(HpddmSubdomain *, const HpddmK *, HpddmK *, unsigned short);         /* :89 */
 void HpddmSubdomainDestroy(HpddmSubdomain *);                                                 /* :90 */
 
 void            HpddmInitializeCoarseOperator(HpddmPreconditioner *, unsigned short);         /* :94 */
-void            HpddmSetVectors(HpddmPreconditioner *, double **);                            /* :95 */
+void            HpddmSetVectors(HpddmPreconditioner *, HpddmK **);                            /* :95 */
 void            HpddmDestroyVectors(HpddmPreconditioner *);                                   /* :96 */
 const MPI_Comm *HpddmGetCommunicator(HpddmPreconditioner *);                                  /* :97 */
 
@@ -54,22 +65,22 @@ HpddmSchwarz        *HpddmSchwarzCreate(HpddmMatrixCSR *, int neighbors, int *li
 void                 HpddmSchwarzInitialize(HpddmSchwarz *, double *d);                       /* :102 */
 HpddmPreconditioner *HpddmSchwarzPreconditioner(HpddmSchwarz *);                              /* :103 */
 void                 HpddmSchwarzMultiplicityScaling(HpddmSchwarz *, double *d);              /* :104 */
-void                 HpddmSchwarzExchange(HpddmSchwarz *, double *, unsigned short);          /* :105 */
+void                 HpddmSchwarzExchange(HpddmSchwarz *, HpddmK *, unsigned short);          /* :105 */
 void                 HpddmSchwarzCallNumfact(HpddmSchwarz *);                                 /* :106 */
 void                 HpddmSchwarzSolveGEVP(HpddmSchwarz *, HpddmMatrixCSR *neumann);          /* :107 */
 void                 HpddmSchwarzBuildCoarseOperator(HpddmSchwarz *, MPI_Comm);               /* :108 */
-void                 HpddmSchwarzComputeResidual(HpddmSchwarz *, const double *sol, const double *f, double *storage, unsigned short); /* :109 */
+void                 HpddmSchwarzComputeResidual(HpddmSchwarz *, const HpddmK *sol, const HpddmK *f, double *storage, unsigned short); /* :109 */
 void                 HpddmSchwarzDestroy(HpddmSchwarz *);                                     /* :110 */
 
-int HpddmSolve(HpddmSchwarz *, const double *b, double *sol, int mu, const MPI_Comm *);       /* :112 */
+int HpddmSolve(HpddmSchwarz *, const HpddmK *b, HpddmK *sol, int mu, const MPI_Comm *);       /* :112 */
 /* :113-115: the Krylov methods of -hpddm_krylov_method on an operator and a preconditioner given as callbacks on host vectors
  * (n x mu, column-major, n rows on this rank; inner products summed over *comm): interface/hpddm_c.cpp:41-53, 227-230.  Returns
  * the iteration count.  The basis and the recurrences live in HBM; every callback is one round trip over PCIe. */
 typedef struct HpddmCustomOperator HpddmCustomOperator;
-int HpddmCustomOperatorSolve(const HpddmCustomOperator *A, int n, int (*mv)(const HpddmCustomOperator *, const double *, double *, int), int (*precond)(const HpddmCustomOperator *, const double *, double *, int), const double *b, double *sol, int mu, const MPI_Comm *comm);
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *A, int n, int (*mv)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), int (*precond)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), const HpddmK *b, HpddmK *sol, int mu, const MPI_Comm *comm); /* K = double only: the complex library aborts with a message */
 
-double nrm2(const int *, const double *, const int *);                                        /* :117 */
-void   axpy(const int *, const double *, const double *, const int *, double *, const int *); /* :118 */
+double nrm2(const int *, const HpddmK *, const int *);                                        /* :117 */
+void   axpy(const int *, const HpddmK *, const HpddmK *, const int *, HpddmK *, const int *); /* :118 */
 #ifdef __cplusplus
 }
 #endif

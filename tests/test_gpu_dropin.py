@@ -99,6 +99,32 @@ def test_unchanged_c_example_against_the_c_api_shim(args, its, resid):
             assert vals[0] / vals[1] <= 1e-2   # the example's own check (examples/schwarz.c:120)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "schwarz_c_hip_z")), reason="oracle/_ref/schwarz_c_hip_z not built")
+@pytest.mark.parametrize("args,pat,its,resid", [
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40", "GMRES", 19, 1.428088e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -symmetric_csr=1", "GMRES", 19, None),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0", "GMRES", 17, 3.208441e-05),
+    ("-hpddm_verbosity=1 -Nx 40 -Ny 40 -generate_random_rhs 3 -hpddm_krylov_method bgmres", "BGMRES", None, None),
+])
+def test_unchanged_c_example_complex_scalars_against_the_c_api_shim(args, pat, its, resid):
+    """interface/HPDDM.h:34-50: the C library is built for ONE scalar type; libhpddm_c_hip_z.so is the shim compiled with
+    -DFORCE_COMPLEX (K = double _Complex), examples/schwarz.c + generate.c compiled the same way and linked with it, unchanged.
+    Expected counts and residuals: oracle/_ref/schwarz_cpp_z, the reference's own complex build (dense LAPACK local solver)."""
+    out = _run(4, args, exe="schwarz_c_hip_z")
+    m = re.search(pat + r" converges after (\d+) iteration", out)
+    assert m, out[-1500:]
+    r = re.findall(r"residual = (\S+) / (\S+)|^\s+(\S+) / (\S+) \(rhs", out, re.M)
+    assert r, out[-1500:]
+    if its is not None:
+        assert int(m.group(1)) == its, out[-1500:]
+    if resid:
+        first = [v for v in r[0] if v]
+        assert abs(float(first[0]) - resid) <= 5e-4 * resid, out[-500:]
+    for grp in r:
+        vals = [float(v) for v in grp if v]
+        assert vals[0] / vals[1] <= 1e-2   # the example's own check (examples/schwarz.c:120)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "schwarz_c_hip")), reason="oracle/_ref/schwarz_c_hip not built")
 def test_unchanged_c_example_single_rank_direct_solve():
     out = _run(1, "-Nx 40 -Ny 40", exe="schwarz_c_hip")

@@ -199,6 +199,11 @@ def test_c_api_shim_exports_the_reference_names():
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     missing = sorted(declared - exported)
     assert not missing, missing
+    # ... and so does the complex build of the same source (K = double _Complex: one scalar type per library, HPDDM.h:34-50)
+    soz = os.path.join(ROOT, "hpddm_amd", "libhpddm_c_hip_z.so")
+    if os.path.exists(soz):
+        out = subprocess.run(["nm", "-D", "--defined-only", soz], capture_output=True, text=True).stdout
+        assert not sorted(declared - {ln.split()[-1] for ln in out.splitlines() if ln.strip()})
 
 
 def test_plain_c_client_of_the_header(tmp_path):
