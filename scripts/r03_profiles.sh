@@ -19,8 +19,9 @@ python $R/scripts/prof_summary.py "$db" rocprofv3 --kernel-trace --stats -- pyth
 python $R/scripts/prof_sweeps.py "$db" 4 > $out/sptrsv_sweeps.csv
 grep '^{"metric"' $out/trace.log | tail -1 > $out/trace_bench_line.json
 rm -rf $out/trace
-PARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-gmres --no-two-level --no-configs-1"
-for ctr in FETCH_SIZE WRITE_SIZE; do
+PARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-gmres --no-two-level --no-configs-1 --no-shares"
+if [ -z "$WITH_PMC" ]; then PMC_CTRS=""; else PMC_CTRS="FETCH_SIZE WRITE_SIZE"; fi # round 3: the passes faulted inside the factorisation under --pmc (gpurun_out/r03_failed_pmc); scripts/r03_pmc_c2.sh collects them at configs[1] on a host-level factorisation
+for ctr in $PMC_CTRS; do
   timeout 900 rocprofv3 --pmc $ctr -d $out/pmc_$ctr -o p -- python $R/bench.py $PARGS > $out/pmc_$ctr.log 2>&1
   pdb=$(find $out/pmc_$ctr -name "*.db" | head -1)
   python $R/scripts/pmc_summary.py "$pdb" > $out/pmc_$ctr.csv
