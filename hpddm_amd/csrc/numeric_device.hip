@@ -622,6 +622,15 @@ struct UploadRing {
       head = 0;
     }
     const double t1 = now();
+    static const bool unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr; // (profiling aid: rocprofv3 --pmc faulted inside the copy from the pinned ring)
+    if (unpinned) {
+      HIP_OK(hipStreamSynchronize(st));
+      HIP_OK(hipMemcpy(dev + head, src, bytes, hipMemcpyHostToDevice));
+      void *q = dev + head;
+      head += need;
+      bytes_pushed += bytes;
+      return q;
+    }
     std::memcpy(host + head, src, bytes);
     t_copy += now() - t1;
     bytes_pushed += bytes;

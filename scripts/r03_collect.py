@@ -35,12 +35,12 @@ def traffic(srcdir, target, how):
 
 
 if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE_last_solve.txt")):
-    traffic(src, "r03_pmc_traffic_c3.json", "scripts/r03_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-            "--no-gmres --no-two-level --no-configs-1`, sum over the kernels of the last batched SpTRSV (scripts/pmc_total.py)")
+    traffic(src, "r03_pmc_traffic_c3.json", "scripts/r03_pmc_c3.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of `HPDDM_HIP_UPLOAD_UNPINNED=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+            "--no-gmres --no-two-level --no-configs-1 --no-shares`, sum over the kernels of the last batched SpTRSV (scripts/pmc_total.py)")
 c2 = os.path.join(R, "gpurun_out", "r03c2")
 if os.path.exists(os.path.join(c2, "pmc_FETCH_SIZE_last_solve.txt")):
     for a, b in {"pmc_FETCH_SIZE.csv": "r03_pmc_fetch_size_c2.csv", "pmc_WRITE_SIZE.csv": "r03_pmc_write_size_c2.csv",
                  "pmc_FETCH_SIZE_last_solve.txt": "r03_pmc_fetch_size_c2_last_solve.txt", "pmc_WRITE_SIZE_last_solve.txt": "r03_pmc_write_size_c2_last_solve.txt"}.items():
         shutil.copy(os.path.join(c2, a), os.path.join(dst, b))
-    traffic(c2, "r03_pmc_traffic_c2.json", "scripts/r03_pmc_c2.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of `python bench.py --grid 128 --steps 3 --warmup 1 "
-            "--no-cpu-baseline --no-gmres --no-two-level`, sum over the kernels of the last batched SpTRSV (scripts/pmc_total.py)")
+    traffic(c2, "r03_pmc_traffic_c2.json", "scripts/r03_pmc_c2.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of `HPDDM_HIP_HOST_FACTOR=1 python bench.py --grid 128 --steps 3 --warmup 1 "
+            "--no-cpu-baseline --no-gmres --no-two-level --no-shares`, sum over the kernels of the last batched SpTRSV (scripts/pmc_total.py)")

@@ -1,4 +1,4 @@
-"""The bench contract on the committed line (profiles/r02_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
+"""The bench contract on the committed line (profiles/r03_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
 every key the driver reads is there, the workload is the one BASELINE.json quotes its target on (configs[2], real GenEO space) and
 the derived fields are consistent with each other.  CPU only."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_default_stdout.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_default_stdout.json")) as fh:
         rows = [ln for ln in fh if ln.startswith('{"metric"')]
     assert len(rows) == 1, "bench.py prints ONE JSON line"
     return json.loads(rows[0])
@@ -42,9 +42,9 @@ def test_contract_keys_and_consistency():
 
 def test_traffic_profile_matches_the_line():
     d = _line()
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_c3.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_c3.json")) as fh:
         t = json.load(fh)
     assert t["traffic_bytes"] == (2 * t["FETCH_SIZE_KB_per_sweep"] + t["WRITE_SIZE_KB_per_sweep"]) * 1024
-    # the line quotes the traffic file that was committed when it ran; the passes were collected again right after it (same box,
-    # same build): the two agree to a fraction of a percent
+    # the line quotes the traffic file that was committed when it ran (round 2's); the passes were collected again after it with the
+    # same build: the two agree to a fraction of a percent
     assert abs(d["roofline"]["traffic"] - t["traffic_bytes"]) <= 2e-3 * t["traffic_bytes"] and t["algorithmic_bytes"] == d["roofline"]["bytes_alg_per_sweep"]
