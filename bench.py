@@ -60,6 +60,7 @@ def parse_args():
                          "sides (configs[4] is --problem helmholtz --grid 64 --mu 8 on 4 GPUs: 128^3, 32 subdomains)")
     ap.add_argument("--no-geneo", action="store_true", help="two-level operator on polynomial stand-in vectors instead of the GenEO eigenvectors (kernel timing only)")
     ap.add_argument("--no-configs-1", action="store_true", help="skip the extra configs[1] (128^3, one-level) object of the default run")
+    ap.add_argument("--options", default="", help="extra -hpddm_* options appended to the operator's option string (developer aid)")
     ap.add_argument("--no-shares", action="store_true", help="skip the extra configs_3_share / configs_4_share objects of the default run")
     ap.add_argument("--strong", action="store_true", help="N>1: --grid is the GLOBAL cube (strong scaling) instead of the share of one GPU")
     return ap.parse_args()
@@ -148,7 +149,7 @@ def main():
     t0 = time.time()
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     want_cpu = want_cpu and not helm               # the CPU port is real arithmetic
-    opts = ("" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "")
+    opts = ("" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
     sharded = world > 1 and not args.replicas
     peers_hist = None
     if sharded:

@@ -201,6 +201,97 @@ __global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ 
   }
 }
 
+// The same two contractions with ALL the deflation vectors of a subdomain (<= KMAX) per thread and two consecutive rows per lane
+// (16-byte loads, 8-byte aligned: the columns of Z start wherever n puts them): d and `in` are read once instead of once per group
+// of 8 vectors, a lane keeps KMAX x 16 bytes in flight.  Z in the plain column-major layout only (zc = 0).
+struct __attribute__((aligned(8))) dpair {
+  double x, y;
+};
+__device__ static inline dpair load_pair(const double *__restrict__ p, bool two)
+{
+  if (two) return *reinterpret_cast<const dpair *>(p);
+  return dpair{p[0], 0.0};
+}
+template <int MU, int KMAX>
+__global__ __launch_bounds__(256) void k_zt_stream2(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial)
+{
+  const int       s = blockIdx.y, n = nn_[s], nu_s = min(KMAX, nus[s]);
+  const long long v0 = voff[s];
+  double          acc[KMAX][MU];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc[k][nu] = 0.0;
+  const double *Zs = Z + zoff[s];
+  for (int i = 2 * (blockIdx.x * 256 + threadIdx.x); i < n; i += 2 * gridDim.x * 256) {
+    const bool  two = i + 1 < n;
+    const dpair dd  = load_pair(d + v0 + i, two);
+    dpair       dr[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      const dpair x = load_pair(in + v0 * MU + (long long)nu * n + i, two);
+      dr[nu]        = dpair{dd.x * x.x, dd.y * x.y};
+    }
+    dpair z[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < nu_s) z[k] = load_pair(Zs + (long long)k * n + i, two);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < nu_s) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) acc[k][nu] = fma(z[k].x, dr[nu].x, fma(z[k].y, dr[nu].y, acc[k][nu]));
+      }
+  }
+  __shared__ double red[4][KMAX * MU];
+  const int         lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double v = acc[k][nu];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) red[wave][k * MU + nu] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < KMAX * MU) {
+    const int k = threadIdx.x / MU, nu = threadIdx.x - k * MU;
+    partial[((long long)(s * gridDim.x + blockIdx.x)) * 512 + k * 16 + nu] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+template <int MU, int KMAX>
+__global__ __launch_bounds__(256) void k_z_stream2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim)
+{
+  __shared__ double ys[KMAX * MU]; // [k][nu]
+  const int       s = blockIdx.y, n = nn_[s], nu_s = min(KMAX, nus[s]);
+  const long long v0 = voff[s];
+  for (int idx = threadIdx.x; idx < KMAX * MU; idx += 256) ys[idx] = idx / MU < nu_s ? y[(long long)(idx % MU) * cdim + coff[s] + idx / MU] : 0.0;
+  __syncthreads();
+  const double *Zs = Z + zoff[s];
+  for (int i = 2 * (blockIdx.x * 256 + threadIdx.x); i < n; i += 2 * gridDim.x * 256) {
+    const bool two = i + 1 < n;
+    dpair      z[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < nu_s) z[k] = load_pair(Zs + (long long)k * n + i, two);
+    dpair acc[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) acc[nu] = dpair{0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < nu_s) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) acc[nu].x = fma(z[k].x, ys[k * MU + nu], acc[nu].x), acc[nu].y = fma(z[k].y, ys[k * MU + nu], acc[nu].y);
+      }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      double *o = out + v0 * MU + (long long)nu * n + i;
+      if (two) *reinterpret_cast<dpair *>(o) = acc[nu];
+      else o[0] = acc[nu].x;
+    }
+  }
+}
+
 // uc (cdim x mu, column-major) = Z^T (D in) for the local subdomains: first gemm of Schwarz::deflation (include/HPDDM_schwarz.hpp:1613-1616)
 void Schwarz::panel_zt(const double *in, double *uc, int mu)
 {
@@ -212,6 +303,26 @@ void Schwarz::panel_zt(const double *in, double *uc, int mu)
   zt_partial.alloc((size_t)nsub * nblk * 512);
   if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
     // GEMV-shaped: streaming kernels (the MFMA tiles would carry 14-15 empty right-hand-side columns)
+    if (!z_compact && numax <= 32 && getopt("hip_deflation_pairs", 1) != 0) { // every vector of a subdomain in one pass, two rows per lane
+      // (<= nblk: the partial sums fit the buffer above); all the blocks resident at once: 256 CUs x `hip_deflation_blocks_per_cu`
+      const int  nb2 = std::max(1, std::min(std::min(nblk, (nmax + 511) / 512), std::max(1, 256 * (int)getopt("hip_deflation_blocks_per_cu", 3) / std::max(1, nsub))));
+      const dim3 g((unsigned)nb2, (unsigned)nsub);
+#define HH_ZT2(M, K) hipLaunchKernelGGL((k_zt_stream2<M, K>), g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p)
+      if (mu == 1) {
+        if (numax <= 8) HH_ZT2(1, 8);
+        else if (numax <= 16) HH_ZT2(1, 16);
+        else if (numax <= 24) HH_ZT2(1, 24);
+        else HH_ZT2(1, 32);
+      } else {
+        if (numax <= 8) HH_ZT2(2, 8);
+        else if (numax <= 16) HH_ZT2(2, 16);
+        else if (numax <= 24) HH_ZT2(2, 24);
+        else HH_ZT2(2, 32);
+      }
+#undef HH_ZT2
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nb2, nu_d.p, coff_d.p, uc, mu, cdim, 0, 0);
+      return;
+    }
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       const dim3 g((unsigned)nblk, (unsigned)nsub, (unsigned)((std::min(ZT_NU, numax - m0) + 7) / 8));
       if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0, z_compact ? 1 : 0);
@@ -234,6 +345,23 @@ void Schwarz::panel_z(const double *y, double *zy, int mu)
   int         numax = 0;
   for (const auto &S : subs) numax = std::max(numax, S.nu);
   if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
+    if (!z_compact && numax <= 32 && getopt("hip_deflation_pairs", 1) != 0) {
+      const dim3 g((unsigned)std::max(1, std::min(std::max(1, 256 * (int)getopt("hip_deflation_blocks_per_cu", 3) / std::max(1, nsub)), (nmax + 511) / 512)), (unsigned)nsub);
+#define HH_Z2(M, K) hipLaunchKernelGGL((k_z_stream2<M, K>), g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim)
+      if (mu == 1) {
+        if (numax <= 8) HH_Z2(1, 8);
+        else if (numax <= 16) HH_Z2(1, 16);
+        else if (numax <= 24) HH_Z2(1, 24);
+        else HH_Z2(1, 32);
+      } else {
+        if (numax <= 8) HH_Z2(2, 8);
+        else if (numax <= 16) HH_Z2(2, 16);
+        else if (numax <= 24) HH_Z2(2, 24);
+        else HH_Z2(2, 32);
+      }
+#undef HH_Z2
+      return;
+    }
     const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
     const size_t l2 = (size_t)numax * mu * sizeof(double);
     if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);

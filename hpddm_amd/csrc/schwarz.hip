@@ -74,25 +74,44 @@ __global__ void k_diag(const long long *__restrict__ voff, const int *__restrict
   }
 }
 
-// y = beta*y + alpha*A*x ; 8 lanes per row (7-point / 27-point stencil rows), rows of all subdomains in one launch
+// y = beta*y + alpha*A*x ; 8 lanes per row (7-point / 27-point stencil rows), rows of all subdomains in one launch.  A group of
+// 8 lanes takes FOUR consecutive rows per step and requests their row pointers, then their first 8 entries each, then the entries
+// of x, together: a row is a chain of three dependent round trips, and one row at a time left the kernel at 1.8 TB/s.
 __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0  = voff[s];
   const int      *ias = ia + iaoff[s];
   const int       lane = threadIdx.x & 7;
-  for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < n; r += (gridDim.x * blockDim.x) >> 3) {
-    const int p0 = ias[r], p1 = ias[r + 1];
+  const int       ngrp = (gridDim.x * blockDim.x) >> 3;
+  for (int r0 = 4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 3); r0 < n; r0 += 4 * ngrp) {
+    int p[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p[k] = ias[min(r0 + k, n)];
     for (int nu = 0; nu < mu; ++nu) {
-      const double *xs  = x + v0 * mu + (long long)nu * n;
-      double        acc = 0.0;
-      for (int p = p0 + lane; p < p1; p += 8) acc = fma(a[p], xs[ja[p]], acc);
-      acc += __shfl_xor(acc, 4);
-      acc += __shfl_xor(acc, 2);
-      acc += __shfl_xor(acc, 1);
-      if (lane == 0) {
-        double *yp = y + v0 * mu + (long long)nu * n + r;
-        *yp        = (beta == 0.0 ? 0.0 : beta * *yp) + alpha * acc;
+      const double *xs = x + v0 * mu + (long long)nu * n;
+      int           j[4];
+      double        av[4], acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int  q  = p[k] + lane;
+        const bool ok = q < p[k + 1];
+        j[k]          = ok ? ja[q] : 0;
+        av[k]         = ok ? a[q] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = av[k] * xs[j[k]];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        for (int q = p[k] + lane + 8; q < p[k + 1]; q += 8) acc[k] = fma(a[q], xs[ja[q]], acc[k]); // rows of more than 8 entries
+        acc[k] += __shfl_xor(acc[k], 4);
+        acc[k] += __shfl_xor(acc[k], 2);
+        acc[k] += __shfl_xor(acc[k], 1);
+      }
+      if (lane < 4 && r0 + lane < n) {
+        const double v  = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+        double      *yp = y + v0 * mu + (long long)nu * n + r0 + lane;
+        *yp             = (beta == 0.0 ? 0.0 : beta * *yp) + alpha * v;
       }
     }
   }
@@ -1103,7 +1122,7 @@ void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double bet
     else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta);
     return;
   }
-  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 8 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta);
+  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta);
 }
 void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {

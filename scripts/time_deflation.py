@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""developer aid: the deflation panel and the GMV of configs[2] (8 subdomains of 129^3, 20 polynomial vectors each) timed without
+the factorisation -- the coarse correction needs Z, d, A and the coarse operator only.
+usage: time_deflation.py [grid=256] ["-hpddm_opt v ..." ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from hpddm_amd import hpddm  # noqa: E402
+from hpddm_amd.generate import generate3d  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+cfgs = sys.argv[2:] or [""]
+nu = 20
+subs = generate3d(N, 8, overlap=1, sym=True, rhs="smooth")
+A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated")
+expo = [(a, b, c) for deg in range(8) for a in range(deg + 1) for b in range(deg + 1 - a) for c in [deg - a - b]][:nu]
+for s, sd in enumerate(subs):
+    i0, i1, j0, j1, k0, k1 = sd["box"]
+    z, y, x = np.meshgrid(np.linspace(-1, 1, k1 - k0), np.linspace(-1, 1, j1 - j0), np.linspace(-1, 1, i1 - i0), indexing="ij")
+    A.set_vectors(s, np.stack([(x ** a * y ** b * z ** c).ravel() for a, b, c in expo], axis=1))
+t0 = time.time()
+A.build_coarse_operator()
+print(f"coarse operator {time.time() - t0:.2f} s, n = {int(A.stats()['n'])}", flush=True)
+zbytes = 2.0 * nu * A.stats()["n"] * 8.0
+for cfg in cfgs:
+    if cfg:
+        A.option_parse(cfg)
+    for mu in (1, 2):
+        td, tg = A.time("deflation", mu, 3, 30), A.time("gmv", mu, 3, 30)
+        print(f"[{cfg}] mu {mu}: deflation {td * 1e3:.3f} ms ({zbytes / td / 1e9:.0f} GB/s on 2 x Z), gmv {tg * 1e3:.3f} ms", flush=True)
