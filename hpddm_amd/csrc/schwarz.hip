@@ -88,17 +88,18 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
     int p[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) p[k] = ias[min(r0 + k, n)];
+    int    j[4];
+    double av[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { // the entries of the four rows: read once for all the right-hand sides
+      const int  q  = p[k] + lane;
+      const bool ok = q < p[k + 1];
+      j[k]          = ok ? ja[q] : 0;
+      av[k]         = ok ? a[q] : 0.0;
+    }
     for (int nu = 0; nu < mu; ++nu) {
       const double *xs = x + v0 * mu + (long long)nu * n;
-      int           j[4];
-      double        av[4], acc[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int  q  = p[k] + lane;
-        const bool ok = q < p[k + 1];
-        j[k]          = ok ? ja[q] : 0;
-        av[k]         = ok ? a[q] : 0.0;
-      }
+      double        acc[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = av[k] * xs[j[k]];
 #pragma unroll
@@ -122,30 +123,55 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
 // pairs of the caller either way.  n = 2 x (complex rows) as everywhere in the complex Schwarz layer.
 __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
 {
+  // a group of 8 lanes takes TWO rows per step: their entries are read once, then four right-hand sides at a time -- eight
+  // independent 16-byte gathers of x in flight per lane (one right-hand side after the other, every row paid three dependent
+  // round trips per right-hand side: 0.20 ms for 8 right-hand sides at the Helmholtz share of configs[4])
   const int s = blockIdx.y, n = nn[s], nc = n >> 1;
   const long long v0  = voff[s];
   const int      *ias = ia + iaoff[s];
   const int       lane = threadIdx.x & 7;
-  for (int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < nc; r += (gridDim.x * blockDim.x) >> 3) {
-    const int p0 = ias[r], p1 = ias[r + 1];
-    for (int nu = 0; nu < mu; ++nu) {
-      const double *xs = x + v0 * mu + (long long)nu * n;
-      double        ar = 0.0, ai = 0.0;
-      for (int p = p0 + lane; p < p1; p += 8) {
-        const double2 av = *reinterpret_cast<const double2 *>(a + 2 * (long long)p), xv = *reinterpret_cast<const double2 *>(xs + 2 * (long long)ja[p]);
-        ar = fma(av.x, xv.x, fma(-av.y, xv.y, ar));
-        ai = fma(av.x, xv.y, fma(av.y, xv.x, ai));
-      }
-      ar += __shfl_xor(ar, 4), ai += __shfl_xor(ai, 4);
-      ar += __shfl_xor(ar, 2), ai += __shfl_xor(ai, 2);
-      ar += __shfl_xor(ar, 1), ai += __shfl_xor(ai, 1);
-      if (lane == 0) {
-        double2 *yp = reinterpret_cast<double2 *>(y + v0 * mu + (long long)nu * n + 2 * (long long)r);
-        double2  o  = *yp;
-        o.x = (beta == 0.0 ? 0.0 : beta * o.x) + alpha * ar;
-        o.y = (beta == 0.0 ? 0.0 : beta * o.y) + alpha * ai;
-        *yp = o;
-      }
+  const int       ngrp = (gridDim.x * blockDim.x) >> 3;
+  for (int r0 = 2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 3); r0 < nc; r0 += 2 * ngrp) {
+    int p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = ias[min(r0 + k, nc)];
+    int     j[2];
+    double2 av[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int  q  = p[k] + lane;
+      const bool ok = q < p[k + 1];
+      j[k]          = ok ? ja[q] : 0;
+      av[k]         = ok ? *reinterpret_cast<const double2 *>(a + 2 * (long long)q) : double2{0.0, 0.0};
+    }
+    for (int nu0 = 0; nu0 < mu; nu0 += 4) {
+      double2 xv[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[k][u] = nu0 + u < mu ? *reinterpret_cast<const double2 *>(x + v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)j[k]) : double2{0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double ar = fma(av[k].x, xv[k][u].x, -av[k].y * xv[k][u].y), ai = fma(av[k].x, xv[k][u].y, av[k].y * xv[k][u].x);
+          if (nu0 + u < mu)
+            for (int q = p[k] + lane + 8; q < p[k + 1]; q += 8) { // rows of more than 8 entries
+              const double2 a2 = *reinterpret_cast<const double2 *>(a + 2 * (long long)q), x2 = *reinterpret_cast<const double2 *>(x + v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)ja[q]);
+              ar = fma(a2.x, x2.x, fma(-a2.y, x2.y, ar));
+              ai = fma(a2.x, x2.y, fma(a2.y, x2.x, ai));
+            }
+          ar += __shfl_xor(ar, 4), ai += __shfl_xor(ai, 4);
+          ar += __shfl_xor(ar, 2), ai += __shfl_xor(ai, 2);
+          ar += __shfl_xor(ar, 1), ai += __shfl_xor(ai, 1);
+          if (lane == 0 && nu0 + u < mu && r0 + k < nc) {
+            double2 *yp = reinterpret_cast<double2 *>(y + v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)(r0 + k));
+            double2  o  = beta == 0.0 ? double2{0.0, 0.0} : *yp;
+            o.x = beta * o.x + alpha * ar;
+            o.y = beta * o.y + alpha * ai;
+            *yp = o;
+          }
+        }
     }
   }
 }
@@ -1113,7 +1139,7 @@ void Schwarz::build_bsr()
 void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta)
 {
   if (zia_d.p) { // complex operators: the complex matrix itself
-    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 8 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta);
+    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 4 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta);
     return;
   }
   if (bsr_bs) {

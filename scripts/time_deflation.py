@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer aid: the deflation panel and the GMV of configs[2] (8 subdomains of 129^3, 20 polynomial vectors each) timed without
 the factorisation -- the coarse correction needs Z, d, A and the coarse operator only.
-usage: time_deflation.py [grid=256] ["-hpddm_opt v ..." ...]"""
+usage: time_deflation.py [grid=256 | helmholtz] ["-hpddm_opt v ..." ...]      (helmholtz: the complex share of configs[4], 8 right-hand sides)"""
 import os
 import sys
 import time
@@ -12,9 +12,25 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from hpddm_amd import hpddm  # noqa: E402
 from hpddm_amd.generate import generate3d  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+helm = len(sys.argv) > 1 and sys.argv[1] == "helmholtz"
+N = 256 if helm or len(sys.argv) < 2 else int(sys.argv[1])
 cfgs = sys.argv[2:] or [""]
 nu = 20
+if helm:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    subs = bench.generate_helmholtz(np, generate3d, (64, 64, 128), 8, rhs="smooth", grid=(2, 2, 2))
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_coarse_correction deflated")
+    for s, sd in enumerate(subs):
+        t = np.arange(sd["n"], dtype=np.float64)
+        A.set_vectors(s, np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * s)], axis=1))
+    A.build_coarse_operator()
+    for cfg in cfgs:
+        if cfg:
+            A.option_parse(cfg)
+        for mu in (1, 8):
+            print(f"[{cfg}] helmholtz mu {mu}: deflation {A.time('deflation', mu, 3, 50) * 1e3:.3f} ms, gmv {A.time('gmv', mu, 3, 50) * 1e3:.3f} ms, exchange {A.time('exchange', mu, 3, 50) * 1e3:.3f} ms", flush=True)
+    sys.exit(0)
 subs = generate3d(N, 8, overlap=1, sym=True, rhs="smooth")
 A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated")
 expo = [(a, b, c) for deg in range(8) for a in range(deg + 1) for b in range(deg + 1 - a) for c in [deg - a - b]][:nu]
