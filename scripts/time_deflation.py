@@ -45,6 +45,6 @@ zbytes = 2.0 * nu * A.stats()["n"] * 8.0
 for cfg in cfgs:
     if cfg:
         A.option_parse(cfg)
-    for mu in (1, 2):
+    for mu in [int(v) for v in os.environ.get("MUS", "1,2").split(",")]:
         td, tg = A.time("deflation", mu, 3, 30), A.time("gmv", mu, 3, 30)
         print(f"[{cfg}] mu {mu}: deflation {td * 1e3:.3f} ms ({zbytes / td / 1e9:.0f} GB/s on 2 x Z), gmv {tg * 1e3:.3f} ms", flush=True)
