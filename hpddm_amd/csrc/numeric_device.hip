@@ -622,7 +622,7 @@ struct UploadRing {
       head = 0;
     }
     const double t1 = now();
-    static const bool unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr; // (profiling aid: rocprofv3 --pmc faulted inside the copy from the pinned ring)
+    const bool unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr; // (profiling aid: rocprofv3 --pmc faulted inside the copy from the pinned ring)
     if (unpinned) {
       HIP_OK(hipStreamSynchronize(st));
       HIP_OK(hipMemcpy(dev + head, src, bytes, hipMemcpyHostToDevice));

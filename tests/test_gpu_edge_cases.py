@@ -92,13 +92,15 @@ def test_refactorisation_same_pattern_new_values():
     S.destroy()
 
 
-@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("where", ["host", "device", "device_unpinned_uploads"])
 @pytest.mark.parametrize("kind", ["ldlt", "lu"])
 def test_wide_panels_in_the_ldlt_and_lu_kinds(kind, where, monkeypatch):
     """22^3: top separator 484 wide (block-level tiles, split-row backward tiles) with the LDL^T and LU kinds, the upper levels of
     the tree factorised on the host or -- fronts of 96 rows and more -- on the device (numeric_device.hip: blocked LDL^T / LU on
     the MFMA GEMM, tile factorisations with the same pivot rule as the host)"""
-    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where == "device" else "100000")
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_MIN_H", "96" if where != "host" else "100000")
+    if where == "device_unpinned_uploads":   # the hand-over lists by plain hipMemcpy (what the counter passes of scripts/r03_pmc_c3.sh run with)
+        monkeypatch.setenv("HPDDM_HIP_UPLOAD_UNPINNED", "1")
     A = _lap(22)
     n = A.shape[0]
     rng = np.random.default_rng(2)
