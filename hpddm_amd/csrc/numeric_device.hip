@@ -612,9 +612,11 @@ struct UploadRing {
   }
   void *push(const void *src, size_t bytes, hipStream_t st)
   {
-    const size_t need = (bytes + 255) / 256 * 256;
-    if (need > cap) reserve(std::max(need, 2 * cap), st);
-    if (head + need > cap) {
+    // (a guard page at the end of the ring: under rocprofv3 --pmc the copy below faulted on the host exactly one byte past the 64 MB
+    // of the pinned ring -- a staged copy that reads a little more than it was asked for must not run off the mapping)
+    const size_t need = (bytes + 255) / 256 * 256, guard = 4096;
+    if (need + guard > cap) reserve(std::max(need + guard, 2 * cap), st);
+    if (head + need + guard > cap) {
       const double t0 = now();
       HIP_OK(hipDeviceSynchronize()); // wrap-around: what was enqueued (on any stream) has been consumed
       t_wait += now() - t0;
