@@ -272,10 +272,20 @@ def main():
         tl.update({"deflation_ms": t_defl * 1e3, "apply_ms": ms_per_step, "applies_per_sec": value,
                    "deflation_panel_GBps": bytes_panel / t_defl / 1e9, "deflation_panel_frac_of_hbm_peak": bytes_panel / t_defl / 8e12,
                    "deflation_flops": 4.0 * n * nu * mu * (4.0 if A.complex else 1.0),
-                   "kernel": ("k_zt_stream + k_z_stream: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
+                   "kernel": ("k_zt_stream2 + k_z_stream2: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
                               "MFMA utilisation 0 by construction" if mu <= 2 else
-                              "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64); MFMA busy 13 % / 25 % of the SIMD cycles at nu = 20 (profiles/r01_pmc_mfma.csv): "
-                              "the panel has mu/4 flop/B, HBM-bound")})
+                              "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r03_pmc_mfma_deflation.csv)")})
+        tl["deflation_TFLOPs"] = tl["deflation_flops"] / t_defl / 1e12
+        if mu <= 2 and world == 1:
+            # the same panel with 8 right-hand sides (Block GMRES, the GenEO blocks): the GEMM-shaped products on v_mfma_f64_16x16x4_f64,
+            # measured here so that the MFMA figure the north star asks for is on the line; 78.6 TFLOP/s = AMD's f64 matrix peak of the
+            # MI355X (dense; the guide's table stops at f32)
+            t8 = A.time("deflation", mu=8, warmup=2, reps=max(3, reps // 4))
+            f8 = 4.0 * n * nu * 8 * (4.0 if A.complex else 1.0)
+            b8 = 2.0 * n * nu * sk + 3.0 * n * 8 * sk
+            tl["deflation_mfma_mu8"] = {"ms": t8 * 1e3, "flops": f8, "TFLOPs": f8 / t8 / 1e12, "frac_of_f64_mfma_peak": f8 / t8 / 78.6e12, "panel_GBps": b8 / t8 / 1e9,
+                                        "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64) + k_exchange",
+                                        "counters": "profiles/r03_pmc_mfma_deflation.csv (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES of the two kernels), kernel trace profiles/r03_deflation_mfma_mu8_kernel_stats.csv"}
         if not args.no_gmres:
             tl["gmres"] = gmres_leg()
 
