@@ -284,8 +284,8 @@ def main():
             f8 = 4.0 * n * nu * 8 * (4.0 if A.complex else 1.0)
             b8 = 2.0 * n * nu * sk + 3.0 * n * 8 * sk
             tl["deflation_mfma_mu8"] = {"ms": t8 * 1e3, "flops": f8, "TFLOPs": f8 / t8 / 1e12, "frac_of_f64_mfma_peak": f8 / t8 / 78.6e12, "panel_GBps": b8 / t8 / 1e9,
-                                        "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64) + k_exchange",
-                                        "counters": "profiles/r03_pmc_mfma_deflation.csv (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES of the two kernels), kernel trace profiles/r03_deflation_mfma_mu8_kernel_stats.csv"}
+                                        "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM in 32-byte accesses) + k_exchange",
+                                        "counters": "profiles/r03_pmc_mfma_deflation.csv, profiles/r03_deflation_mfma_mu8_kernel_stats.csv (SQ counters and kernel trace of the staged kernels these replaced), profiles/r03_deflation_mfma_times.txt (before / after)"}
         if not args.no_gmres:
             tl["gmres"] = gmres_leg()
 

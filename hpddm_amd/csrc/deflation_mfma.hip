@@ -84,6 +84,81 @@ __global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ v
   }
 }
 
+// The same contraction without the LDS tile: the MFMA sums over its K = 4 rows AND over successive instructions, so which rows a
+// lane feeds is free -- lane (i, k) takes the FOUR CONSECUTIVE rows 4k .. 4k+3 of a 16-row group, one per instruction, of column i
+// (deflation vector i in the A operand, right-hand side i in the B operand): 32 contiguous bytes per lane, the four lanes of a
+// column cover one 128-byte line, a wavefront streams 16-row groups on its own -- no staging, no barrier, the next group requested
+// before the products of the current one.  NT = number of 16-vector tiles (1: nu <= 16).  Z in the plain column-major layout.
+// (The staged kernel above ran at 1.65 TB/s on 8 subdomains of 129^3 with 8 right-hand sides.)
+struct __attribute__((aligned(8))) dquad {
+  double v[4];
+};
+template <int NT>
+__global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int mu, int m0, int nu0)
+{
+  const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
+  const long long v0 = voff[s];
+  const int       tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int       mcols = min(16 * NT, nu_s - m0), ncols = min(ZT_MU, mu - nu0);
+  const int       i = lane & 15, k = lane >> 4;
+  v4f64           acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0, 0, 0, 0};
+  if (mcols > 0) {
+    const double *Zs = Z + zoff[s];
+    const double *zc[NT];
+    bool          za[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) za[t] = 16 * t + i < mcols, zc[t] = Zs + (long long)(m0 + (za[t] ? 16 * t + i : 0)) * n;
+    const bool    ra = i < ncols;
+    const double *rc = in + v0 * mu + (long long)(nu0 + (ra ? i : 0)) * n, *dd = d + v0;
+    const dquad   zero = {{0.0, 0.0, 0.0, 0.0}};
+    auto load4 = [&](const double *p, int r, bool live) -> dquad {
+      if (!live || r >= n) return zero;
+      if (r + 4 <= n) return *reinterpret_cast<const dquad *>(p + r);
+      dquad q = zero;
+      for (int t = 0; t < 4; ++t)
+        if (r + t < n) q.v[t] = p[r + t];
+      return q;
+    };
+    const int stride = 16 * (int)gridDim.x * 4;
+    int       row0   = 16 * ((int)blockIdx.x * 4 + wave);
+    dquad     a[NT], b, w, an[NT], bn, wn;
+    if (row0 < n) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[t] = load4(zc[t], row0 + 4 * k, za[t]);
+      b = load4(rc, row0 + 4 * k, ra), w = load4(dd, row0 + 4 * k, ra);
+    }
+    for (; row0 < n; row0 += stride) {
+      const int nxt = row0 + stride;
+      if (nxt < n) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) an[t] = load4(zc[t], nxt + 4 * k, za[t]);
+        bn = load4(rc, nxt + 4 * k, ra), wn = load4(dd, nxt + 4 * k, ra);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bq = b.v[q] * w.v[q]; // B[k][j = lane & 15] = (d r)[row0 + 4k + q, rhs j]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].v[q], bq, acc[t], 0, 0, 0); // A[i = lane & 15][k] = Z[row0 + 4k + q, vector i]
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[t] = an[t];
+      b = bn, w = wn;
+    }
+  }
+  // D[row = (lane>>4) + 4*reg][col = lane&15]: row = deflation vector, col = right-hand side; add the 4 wavefronts (layout of k_zt_mfma)
+  __shared__ double red[4 * 512];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = (lane >> 4) + 4 * reg, col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) red[((wave * 2 + t) * 16 + row) * 16 + col] = t < NT ? acc[t < NT ? t : 0][reg] : 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 512; idx += 256) partial[((long long)(s * gridDim.x + blockIdx.x)) * 512 + idx] = (red[idx] + red[512 + idx]) + (red[1024 + idx] + red[1536 + idx]);
+}
+
 // uc[nu][coff[s] + m] = sum_blk partial[s][blk][m - m0][nu - nu0]   (fixed order => reproducible)
 __global__ void k_zt_reduce(const double *__restrict__ partial, int nblk, const int *__restrict__ nus, const int *__restrict__ coff, double *__restrict__ uc, int mu, int cdim, int m0, int nu0)
 {
@@ -129,6 +204,65 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
           const int r = i0 + 16 * t + (lane >> 4) + 4 * reg;
           if (r < n) out[v0 * mu + (long long)(nu0 + m) * n + r] = acc[t][reg];
         }
+    }
+  }
+}
+
+// out = Z y with 32-byte accesses: which rows of a 64-row group a lane takes is free as long as the output follows -- tile t of lane
+// i takes row 4 i + t, so that the four tiles of a lane are four CONSECUTIVE rows: one 32-byte load per deflation vector feeds the
+// four products of a step, one 32-byte store per accumulator register writes four rows of a right-hand side.  Steps of 4 vectors
+// (K), all requested before the products; plain column-major Z.
+template <int KS>
+__global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0)
+{
+  const int       s = blockIdx.y, n = nn_[s], nu_s = min(4 * KS, nus[s]);
+  const long long v0 = voff[s];
+  const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int       m = lane & 15, k = lane >> 4;
+  const double   *Zs = Z + zoff[s];
+  const int       ncols = min(ZT_MU, mu - nu0);
+  const dquad     zero = {{0.0, 0.0, 0.0, 0.0}};
+  double          b[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) b[ks] = (4 * ks + k < nu_s && m < ncols) ? y[(long long)(nu0 + m) * cdim + coff[s] + 4 * ks + k] : 0.0; // B[k][j = lane&15]
+  for (int i0 = (blockIdx.x * 4 + wave) * 64; i0 < n; i0 += gridDim.x * 256) {
+    const int r = i0 + 4 * m; // rows r .. r+3: tiles 0 .. 3 of this lane
+    dquad     a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = 4 * ks + k;
+      if (kk >= nu_s || r >= n) a[ks] = zero;
+      else if (r + 4 <= n) a[ks] = *reinterpret_cast<const dquad *>(Zs + (long long)kk * n + r);
+      else {
+        a[ks] = zero;
+        for (int t = 0; t < 4; ++t)
+          if (r + t < n) a[ks].v[t] = Zs[(long long)kk * n + r + t];
+      }
+    }
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (4 * ks < nu_s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks].v[t], b[ks], acc[t], 0, 0, 0); // A[i = lane&15][k] = Z[i0 + 4 i + t, vector 4 ks + k]
+      }
+    // D[idx = (lane>>4) + 4*reg][col = lane&15] of tile t is row i0 + 4 idx + t
+    if (m < ncols) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ro = i0 + 4 * ((lane >> 4) + 4 * reg);
+        double   *o  = out + v0 * mu + (long long)(nu0 + m) * n + ro;
+        if (ro + 4 <= n) {
+          dquad q;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) q.v[t] = acc[t][reg];
+          *reinterpret_cast<dquad *>(o) = q;
+        } else
+          for (int t = 0; t < 4; ++t)
+            if (ro + t < n) o[t] = acc[t][reg];
+      }
     }
   }
 }
@@ -331,8 +465,15 @@ void Schwarz::panel_zt(const double *in, double *uc, int mu)
     }
     return;
   }
+  const bool direct = !z_compact && getopt("hip_deflation_zt_direct", 1) != 0; // operands straight from HBM (k_zt_mfma2) instead of the LDS tile
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
+      if (direct) {
+        if (numax - m0 > 16) hipLaunchKernelGGL(k_zt_mfma2<2>, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
+        else hipLaunchKernelGGL(k_zt_mfma2<1>, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
+        hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
+        continue;
+      }
       hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0, z_compact ? 1 : 0);
       hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
     }
@@ -366,6 +507,18 @@ void Schwarz::panel_z(const double *y, double *zy, int mu)
     const size_t l2 = (size_t)numax * mu * sizeof(double);
     if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
     else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
+    return;
+  }
+  if (!z_compact && numax <= 32 && getopt("hip_deflation_zt_direct", 1) != 0) { // 32-byte accesses (k_z_mfma2)
+    const dim3 g((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
+    for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU) {
+#define HH_ZM2(K) hipLaunchKernelGGL(k_z_mfma2<K>, g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0)
+      if (numax <= 8) HH_ZM2(2);
+      else if (numax <= 16) HH_ZM2(4);
+      else if (numax <= 24) HH_ZM2(6);
+      else HH_ZM2(8);
+#undef HH_ZM2
+    }
     return;
   }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
