@@ -43,7 +43,8 @@ int HpddmHipSubdomainSolve(HpddmHipSubdomain *S, const double *b, double *x, uns
 /* complex128 scalars (the reference built with K = std::complex<double>, e.g. examples/schwarz.cpp -DFORCE_COMPLEX,
  * binds the same two functions with complex arrays: interface/HPDDM.h:88-89, interface/hpddm_c.cpp:136-147).
  * `a`, `b`, `x` are interleaved (re, im) pairs, i.e. std::complex<double> / double _Complex arrays; `sym` = lower
- * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  Real-equivalent embedding on the real kernels. */
+ * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  Native complex panels (16 bytes per entry), complex L D L^T / LU on the
+ * host and device levels; the sweeps stream the (re, im) pairs with the real tile kernels. */
 int HpddmHipSubdomainNumfactZ(HpddmHipSubdomain **S, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int spd);
 int HpddmHipSubdomainSolveZ(HpddmHipSubdomain *S, const double *b, double *x, unsigned short n);
 int HpddmHipSubdomainSolveDevice(HpddmHipSubdomain *S, const double *b_dev, double *x_dev, unsigned short n);
@@ -91,8 +92,9 @@ int HpddmHipSchwarzInitialize(HpddmHipSchwarz *A, int s, const double *d);
 int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z);
 /* ---- K = std::complex<double> (interface/HPDDM.h is compiled for one scalar type K, HPDDM.h:34-50; FORCE_COMPLEX builds) ----
  * HpddmHipSchwarzSetSubdomainZ replaces SetSubdomain for complex operators: `a` holds nnz (re, im) pairs, sym != 0 is the lower
- * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  The operator then lives in the real-equivalent embedding
- * (entry a -> [a_r, -a_i; a_i, a_r] on interleaved (re, im) vectors), so that every vector entry point of this header
+ * triangle of a complex SYMMETRIC matrix (MatrixCSR::sym_).  The operator works on interleaved (re, im) vectors (local solves on
+ * native complex panels, GMV on the complex matrix, deflation on the complex vectors; only the small coarse operator keeps the
+ * real-equivalent embedding a -> [a_r, -a_i; a_i, a_r]), so that every vector entry point of this header
  * (Exchange, GMV, Apply, Deflation, Solve, ComputeResidual and the *Device variants) takes std::complex<double> arrays --
  * n_s complex values per right-hand side, i.e. 2 n_s doubles -- through the same double pointers.  GetDof returns 2 n_s.
  * MultiplicityScaling / Initialize keep their real d of length n_s (the partition of unity is real,
