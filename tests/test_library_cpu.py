@@ -156,6 +156,56 @@ def test_host_lu_pivots_inside_the_diagonal_tiles():
     S.destroy()
 
 
+def test_zero_diagonals_are_paired_by_the_ordering_and_the_analysis_is_reused():
+    """match_zero_diagonals (numeric_host.cpp): every unknown with a zero diagonal entry that nested dissection would eliminate
+    before all of its neighbours is moved right behind a partner of its own; the rule reads the pattern and WHICH diagonal entries
+    are zero only, so a refactorisation with other values reuses the analysis, and a matrix whose zeros moved is analysed again"""
+    A = _stokes2d(20).tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    S = hpddm.Subdomain(host_only=1)
+    S.numfact(n, A.indptr, A.indices, A.data, sym=False)
+    perm = S.export("perm")
+    assert sorted(perm.tolist()) == list(range(n))                       # a permutation
+    blk = S.export("blk_ptr")
+    assert blk[0] == 0 and blk[-1] == n and np.all(np.diff(blk) > 0)     # contiguous, non-empty supernodes
+    pos = np.empty(n, dtype=np.int64)
+    pos[perm] = np.arange(n)
+    zero = np.flatnonzero(A.diagonal() == 0.0)
+    assert len(zero) > 100
+    Acsr = A.tocsr()
+    later = 0
+    for i in zero:   # a pressure is never the first of its neighbourhood
+        nb = Acsr.indices[Acsr.indptr[i]:Acsr.indptr[i + 1]]
+        nb = nb[nb != i]
+        later += int(pos[i] > pos[nb].min())
+    assert later == len(zero)
+    b = np.random.default_rng(5).random(n)
+    assert np.abs(A @ _replay(S, b) - b).max() < 1e-10
+    t_order = S.info()["t_order"]
+    B = (A * 3.0).tocsr()                                                # same pattern, same zeros: numerical phase only
+    S.numfact(n, B.indptr, B.indices, B.data, sym=False)
+    assert S.info()["t_order"] == t_order and np.array_equal(S.export("perm"), perm)
+    assert np.abs(B @ _replay(S, b) - b).max() < 1e-10
+    # zero diagonal entries that are STORED: the same rule; and when they stop being zero on the same pattern, another analysis
+    co = A.tocoo()
+    E = sp.csr_matrix((np.concatenate([co.data, np.zeros(len(zero))]), (np.concatenate([co.row, zero]), np.concatenate([co.col, zero]))), shape=A.shape)
+    E.sort_indices()
+    assert E.nnz == A.nnz + len(zero)
+    S.numfact(n, E.indptr, E.indices, E.data, sym=False)
+    perm_e = S.export("perm")
+    pos[perm_e] = np.arange(n)
+    assert all(pos[i] > pos[np.setdiff1d(E.indices[E.indptr[i]:E.indptr[i + 1]], [i])].min() for i in zero)
+    assert np.abs(A @ _replay(S, b) - b).max() < 1e-10
+    C = E.copy()
+    C.data[C.data == 0.0] = -0.05
+    assert np.array_equal(C.indices, E.indices) and np.count_nonzero(C.diagonal() == 0.0) == 0
+    S.numfact(n, C.indptr, C.indices, C.data, sym=False)
+    assert not np.array_equal(S.export("perm"), perm_e)                   # same pattern, other zeros: not the same analysis
+    assert np.abs(C @ _replay(S, b) - b).max() < 1e-10
+    S.destroy()
+
+
 def test_ordering_handles_disconnected_and_tiny_graphs():
     for M in (sp.identity(5).tocsr(), sp.block_diag([_poisson3d(3), _poisson3d(2), sp.identity(3)]).tocsr(), sp.csr_matrix(np.array([[2.0]]))):
         n = M.shape[0]
