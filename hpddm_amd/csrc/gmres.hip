@@ -245,11 +245,15 @@ int Schwarz::gmres(const double *b, double *x, int mu, double *history, int hist
 // conventions: D-weighted inner products, convergence on ||M^{-1} r||_D relative to its initial value, and -- like the
 // reference (:40-42) -- GMRES is used instead when the preconditioner is not symmetric (RAS/ORAS, or the deflated
 // coarse correction).
+// Complex scalars: every coefficient of the reference's CG is REAL (HPDDM::real(Blas<K>::dot(...)), include/HPDDM_CG.hpp:70-92) and
+// real(<u, v>_D) of two complex vectors is the D-weighted dot product of their interleaved (re, im) arrays, so the recurrences
+// below on the vectors of a complex operator -- 2 n_s doubles per right-hand side, d duplicated -- ARE IterativeMethod::CG for
+// K = std::complex<double> (Hermitian positive definite operators with a Hermitian preconditioner: ASM / SORAS).
 int Schwarz::cg(const double *b, double *x, int mu, double *history, int history_cap)
 {
   HH_CHECK(factored || custom_mv, "solve before CallNumfact");
   const int method = (int)getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
-  if (!custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED))) return gmres(b, x, mu, history, history_cap); // (hpddm_method_id 1 and 4 only: a custom operator goes on)
+  if (!custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (coarse_ready && correction == COARSE_CORRECTION_DEFLATED))) return is_complex ? gmres_z(b, x, mu, history, history_cap) : gmres(b, x, mu, history, history_cap); // (hpddm_method_id 1 and 4 only: a custom operator goes on)
   reserve(mu);
   hipStream_t     st  = library_stream();
   const double    tol = getopt("tol", 1.0e-6);

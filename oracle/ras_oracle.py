@@ -405,12 +405,15 @@ def _gram(orc, V, W):
 def cg(orc, b, tol=1e-6, max_it=100):
     """IterativeMethod::CG (include/HPDDM_CG.hpp:31-168), non-flexible: one D-weighted preconditioned CG per right-hand side,
     all advanced together; a right-hand side that has converged keeps its iterate.  Returns (iterations, solution, history)."""
-    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    # (complex K: every coefficient is the REAL part of a dot product, HPDDM::real(Blas<K>::dot(...)), include/HPDDM_CG.hpp:70-92)
+    dt = np.complex128 if any(np.iscomplexobj(v) for v in b) else np.float64
+    b = [np.asarray(v, dtype=dt).reshape(v.shape[0], -1) for v in b]
     mu, P = b[0].shape[1], orc.P
+    wdot = lambda u, v: np.real(orc.wdot(u, v))  # noqa: E731
     x = orc.start(b, [np.zeros_like(v) for v in b])
     r = [bb - g for bb, g in zip(b, orc.gmv(x))]
     p = orc.apply(r)
-    res = np.sqrt(orc.wdot(p, p))
+    res = np.sqrt(wdot(p, p))
     conv = np.full(mu, -max_it)
     hist = []
     if np.any(res ** 2 < np.finfo(float).eps ** 2):
@@ -418,16 +421,16 @@ def cg(orc, b, tol=1e-6, max_it=100):
     last = p
     i = 0
     while i < max_it:
-        rz = orc.wdot(r, last)
+        rz = wdot(r, last)
         z = orc.gmv(p)
-        pap = orc.wdot(z, p)
+        pap = wdot(z, p)
         i += 1
         alpha = np.where(conv == -max_it, rz / pap, 0.0)
         x = [xx + pp * alpha for xx, pp in zip(x, p)]
         r = [rr - zz * alpha for rr, zz in zip(r, z)]
         z = orc.apply(r)
-        beta = orc.wdot(r, z) / rz
-        nz = np.sqrt(orc.wdot(z, z))
+        beta = wdot(r, z) / rz
+        nz = np.sqrt(wdot(z, z))
         p = [zz + pp * beta for zz, pp in zip(z, p)]
         last = z
         newly = (conv == -max_it) & (nz / res <= tol)

@@ -165,3 +165,40 @@ def test_complex_device_levels_refuse_a_collapsed_pivot(monkeypatch):
     with pytest.raises(hpddm.HpddmHipError):
         S.numfact(N, M.indptr, M.indices, M.data.astype(np.complex128), sym=False)
     S.destroy()
+
+
+@pytest.mark.gpu
+def test_cg_on_a_hermitian_positive_definite_operator():
+    """IterativeMethod::CG for K = std::complex<double> (include/HPDDM_CG.hpp:31-168): every coefficient of the reference's method
+    is the REAL part of a dot product, so the device's CG on the (re, im) arrays is the complex method -- a Hermitian positive
+    definite operator (the 7-point stencil with phases e^{+-0.4i} on its off-diagonal entries), ASM, 3 right-hand sides, against
+    the oracle's CG and the direct solution"""
+    from hpddm_amd import hpddm
+    from hpddm_amd.generate import generate3d
+    from oracle import ras_oracle as ro
+    subs = []
+    for sd in generate3d(10, 8, 1, sym=False, rhs="smooth"):
+        sd = dict(sd)
+        a = sd["a"].astype(np.complex128)
+        rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
+        a *= np.exp(0.4j * np.sign(sd["ja"] - rows))    # local numbering keeps the global order: the blocks of ONE Hermitian matrix
+        sd["a"] = a
+        subs.append(sd)
+    mu = 3
+    rng = np.random.default_rng(23)
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_method asm -hpddm_krylov_method cg -hpddm_tol 1e-8 -hpddm_max_it 200")
+    assert A.complex
+    A.call_numfact()
+    orc = ro.Oracle(subs, method="asm")
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    orc.numfact()
+    f = orc.exchange([rng.standard_normal((sd["n"], mu)) + 1j * rng.standard_normal((sd["n"], mu)) for sd in subs])
+    it, sol, hist = A.solve(f, history=True)
+    it_o, sol_o, hist_o = ro.cg(orc, f, tol=1e-8, max_it=200)
+    assert it == it_o and 5 < it < 120, (it, it_o)
+    assert np.allclose(hist, [h[1] for h in hist_o], rtol=1e-5)
+    sc = max(np.abs(x).max() for x in sol_o)
+    assert max(np.abs(x - y).max() for x, y in zip(sol, sol_o)) <= 1e-7 * sc
+    r = [ff - g for ff, g in zip(f, orc.gmv(sol))]        # the true residual of the device's solution
+    assert max(np.abs(x).max() for x in r) <= 1e-5 * max(np.abs(x).max() for x in f)
+    A.destroy()
