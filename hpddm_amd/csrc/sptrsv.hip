@@ -1466,6 +1466,13 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     solve_block16(*this, b, x, mu, done, s);
     done += per16;
   }
+  // a last block that would take two or more VALU sweeps (10 real columns and more) also goes through the engine, its missing
+  // columns zero: one sweep over the factor instead of two or three (16 columns cost the engine what 8 + 2 cost the VALU tiles
+  // on the large trees, and less than 8 alone on the small ones)
+  if ((cplx ? 2 : 1) * (mu - done) >= 10) {
+    solve_block16(*this, b, x, mu, done, s);
+    done = mu;
+  }
   if (done == mu) return;
   if (cplx) {
     // mu complex right-hand sides = 2 mu real columns (planes) inside; register blocks of 8 / 4 / 2 real columns

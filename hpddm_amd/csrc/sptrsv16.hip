@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void k_perm_in16(const long long *__restrict__
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int k = (tid >> 6) + 4 * pass;
-      if (o < n) {
-        const dbl2 z     = *reinterpret_cast<const dbl2 *>(b + 2 * (v0 * mu + (long long)(k0 + k) * n + o));
+      if (o < n) { // (a last block of fewer than 8 right-hand sides: zero columns)
+        const dbl2 z     = k0 + k < mu ? *reinterpret_cast<const dbl2 *>(b + 2 * (v0 * mu + (long long)(k0 + k) * n + o)) : dbl2{0.0, 0.0};
         T[oo][2 * k]     = z.x;
         T[oo][2 * k + 1] = z.y;
       }
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_perm_in16(const long long *__restrict__
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int c = (tid >> 6) + 4 * pass;
-      if (o < n) T[oo][c] = b[v0 * mu + (long long)(k0 + c) * n + o];
+      if (o < n) T[oo][c] = k0 + c < mu ? b[v0 * mu + (long long)(k0 + c) * n + o] : 0.0;
     }
   }
   __syncthreads();
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void k_perm_out16(const long long *__restrict_
       const int k = (tid >> 6) + 4 * pass;
       dbl2      z;
       z.x = T[oo][2 * k], z.y = T[oo][2 * k + 1];
-      *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)(k0 + k) * n + o)) = z;
+      if (k0 + k < mu) *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)(k0 + k) * n + o)) = z;
     }
   } else {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int c = (tid >> 6) + 4 * pass;
-      x[v0 * mu + (long long)(k0 + c) * n + o] = T[oo][c];
+      if (k0 + c < mu) x[v0 * mu + (long long)(k0 + c) * n + o] = T[oo][c];
     }
   }
 }
