@@ -31,14 +31,20 @@ def _poisson3d(N):
 
 
 def _replay(S, b):
-    """numpy replay of the level-scheduled multifrontal solve on the exported solve-ready panels (factor.hpp)"""
+    """numpy replay of the level-scheduled multifrontal solve on the exported solve-ready panels (factor.hpp); complex factors:
+    the panels are (re, im) pairs, L D L^T with plain transposes (complex symmetric) or LU"""
     e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "goff", "gptr", "gsrc", "tgs")}
     kind = S.info()["kind"]
+    cplx = bool(getattr(S, "complex", False))
+    dt = np.complex128 if cplx else np.float64
     F = S.export("F")
     G = S.export("G") if kind == 2 else F
     dinv = S.export("dinv") if kind == 1 else None
+    if cplx:
+        F, G = F.view(np.complex128), G.view(np.complex128)
+        dinv = dinv.view(np.complex128) if dinv is not None else None
     n, blk, rp = len(e["perm"]), e["blk_ptr"], e["row_ptr"]
-    U, y, x = np.zeros(max(1, int(rp[-1]))), np.zeros(n), np.zeros(n)
+    U, y, x = np.zeros(max(1, int(rp[-1])), dtype=dt), np.zeros(n, dtype=dt), np.zeros(n, dtype=dt)
     order = np.argsort(e["height"], kind="stable")
     for k in order:
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
@@ -47,7 +53,7 @@ def _replay(S, b):
         t = 1 << int(e["tgs"][k])   # LU that exchanged rows inside its tiles: block lower triangular, dense t x t diagonal tiles
         assert np.all(P[:w][(np.arange(w)[None, :] // t) > (np.arange(w)[:, None] // t)] == 0.0) if e["tgs"][k] else np.all(np.triu(P[:w], 1) == 0.0)
         gp = e["gptr"][e["goff"][k]:e["goff"][k] + h + 1]
-        gath = np.array([U[e["gsrc"][gp[i]:gp[i + 1]]].sum() for i in range(h)])
+        gath = np.array([U[e["gsrc"][gp[i]:gp[i + 1]]].sum() for i in range(h)], dtype=dt)
         t = P @ (b[e["perm"][c0:c0 + w]] - gath[:w])
         y[c0:c0 + w] = t[:w]
         U[e["u_off"][k]:e["u_off"][k] + nb] = t[w:] + gath[w:]
@@ -58,7 +64,7 @@ def _replay(S, b):
         assert np.all(np.triu(P[:w], 1) == 0.0)
         v = np.concatenate([y[c0:c0 + w] * (dinv[c0:c0 + w] if dinv is not None else 1.0), -x[e["rows"][rp[k]:rp[k + 1]]]])
         x[c0:c0 + w] = P.T @ v
-    out = np.zeros(n)
+    out = np.zeros(n, dtype=dt)
     out[e["perm"]] = x
     return out
 
@@ -154,6 +160,30 @@ def test_host_lu_pivots_inside_the_diagonal_tiles():
     with pytest.raises(_lib.HpddmHipError, match="plain factor"):
         S.numfact(A.shape[0], A.indptr, A.indices, A.data, sym=False)
     S.destroy()
+
+
+def test_complex_host_factorisation_and_pivoting():
+    """complex scalars on the host levels (numeric_host.cpp with T = std::complex<double>): complex symmetric L D L^T with plain
+    transposes, general complex LU, and LU with rows exchanged inside the tiles -- numpy replay of the sweeps on the exported
+    (re, im) panels against the matrix itself"""
+    rng = np.random.default_rng(9)
+    K = _poisson3d(8)
+    n = K.shape[0]
+    cases = [("complex symmetric", (K - 1.3 * sp.identity(n) + 0.4j * sp.identity(n)).tocsr(), True, 1, False),
+             ("general complex", (K + 0.2 * sp.triu(K, 1) + 0.3j * sp.diags(rng.random(n))).tocsr(), False, 2, False),
+             ("rows exchanged", (_row_swapped_pairs(6) * (1.0 + 0.3j)).tocsr(), False, 2, True)]
+    for name, A, sym, kind, swapped in cases:
+        M = sp.tril(A).tocsr() if sym else A.tocsr()
+        M.sort_indices()
+        m = A.shape[0]
+        S = hpddm.Subdomain(host_only=1)
+        S.numfact(m, M.indptr, M.indices, M.data.astype(np.complex128), sym=sym)
+        assert S.info()["kind"] == kind, name
+        assert bool(np.any(S.export("tgs") != 0)) == swapped, name
+        b = rng.random(m) + 1j * rng.random(m)
+        x = _replay(S, b)
+        assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max()) * abs(A).sum(axis=1).max(), name
+        S.destroy()
 
 
 def test_zero_diagonals_are_paired_by_the_ordering_and_the_analysis_is_reused():
