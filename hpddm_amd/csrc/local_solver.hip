@@ -120,6 +120,9 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   // with plain transposes -- also when -hpddm_operator_spd is set --, anything else (Hermitian included) as LU
   if (A.sym || is_symmetric(A)) kind = (spd && !A.cplx) ? FACT_CHOL : FACT_LDLT;
   else kind = FACT_LU;
+  // the fall-back ladder below is remembered per sparsity pattern: a refactorisation of an operator that ended as L D L^T or LU
+  // last time (Helmholtz shifts, saddle points) starts there instead of redoing the kinds that failed (HPDDM_HIP_FORGET_FALLBACK: not)
+  if (settled_kind > (int)kind && settled_hash == pattern_hash && !getenv("HPDDM_HIP_FORGET_FALLBACK")) kind = (FactKind)settled_kind;
   if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
   // the upper levels of the tree (large fronts) are factorised on the device, the lower ones on the host (all three kinds)
   std::unique_ptr<DeviceLevels> devlev;
@@ -173,6 +176,8 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       }
       HH_CHECK(why.empty(), why);
     }
+    settled_kind = (int)host.kind;
+    settled_hash = pattern_hash;
     if (release_host) {
       host.F.clear();
       if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);

@@ -18,6 +18,8 @@ struct LocalSolver {
   bool         host_only = false;
   bool         release_host = false; // drop the host panels after upload (Schwarz operator does this)
   double       t_upload = 0;
+  int          settled_kind = -1;   // the kind the last numfact of pattern settled_hash ended with (fall-back ladder of numfact)
+  size_t       settled_hash = 0;
   double       probe_berr = 0; // backward error of the probe solve that closes numfact (LDL^T / LU)
   std::string  probe(const CsrView &A, FactKind kind); // empty: the factor is backward stable for this matrix
   DevBuf<double> bdev, xdev;         // staging for the host-pointer API

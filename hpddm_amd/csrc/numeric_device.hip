@@ -8,6 +8,7 @@
 // Reference concept: the numerical phase of Solver<K>::numfact (MUMPS job=4, include/HPDDM_MUMPS.hpp:286).
 #include "local_solver.hpp"
 #include <cstring>
+#include <initializer_list>
 #include <ctime>
 #include <map>
 #include <mutex>
@@ -422,8 +423,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld,
     hi          = max(hi, j);
     const T piv = W[j][j];
     if (tid < 64) {
-      double cmax = (tid > j && tid < nb) ? fmax(modulus(W[tid][j]), modulus(W[j][tid])) : 0.0;
+      // breakdown test against the pivot's own column and row.  The column part is `amax` of the pivot search (the largest entry on
+      // or below the diagonal, unchanged by the exchange; |piv| > tol * max(|piv|, rest) <=> |piv| > tol * rest): column j must NOT
+      // be read again here -- the rows below overwrite W(r, j) with Yw(r, j) in this very step, with no barrier in between.  Row j is
+      // not written in step j.
+      double cmax = (tid > j && tid < nb) ? modulus(W[j][tid]) : 0.0;
       for (int off = 32; off >= 1; off >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, off));
+      cmax = fmax(cmax, amax);
       if (tid == 0 && (!(modulus(piv) > DEV_PIVOT_TOL_C * cmax) || is_zero(piv))) *flag = 1;
     }
     const T ip = scalar<T>(1.0) / piv;
@@ -609,6 +615,19 @@ struct UploadRing {
     HIP_OK(hipMalloc((void **)&dev, bytes));
     cap  = bytes;
     head = 0;
+  }
+  // room for several pushes whose device pointers must stay valid together (one kernel reads them all): grow or wrap NOW, so that
+  // none of the pushes that follow reallocates the ring or restarts it under a pointer already handed out
+  void ensure(std::initializer_list<size_t> sizes, hipStream_t st)
+  {
+    size_t need = 4096;
+    for (size_t b : sizes) need += (b + 255) / 256 * 256;
+    if (need > cap) reserve(std::max(need, 2 * cap), st);
+    if (head + need > cap) {
+      HIP_OK(hipDeviceSynchronize());
+      ++wraps;
+      head = 0;
+    }
   }
   void *push(const void *src, size_t bytes, hipStream_t st)
   {
@@ -849,6 +868,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   {
     HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
     if (!cnt) return;
+    upload_ring().ensure({cnt * sizeof(long long), cnt * sizeof(T)}, st);
     const long long *dp = (const long long *)upload_ring().push(pos, cnt * sizeof(long long), st);
     const double    *dv = (const double *)upload_ring().push(val, cnt * sizeof(T), st);
     hipLaunchKernelGGL(k_scatter_add<CS>, dim3((unsigned)std::min<size_t>(1024, (cnt * CS + 255) / 256)), dim3(256), 0, st, (long long)cnt, dp, dv, md(P));

@@ -674,7 +674,15 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     } else
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
     if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
+    if (bad) break; // a pivot collapsed (a normal event: L D L^T falls back to LU, local_solver.hip): the levels above would factorise garbage
   }
+  if (bad) // the contribution blocks nobody will consume go back to the pool (they stayed out of its free list until process exit)
+    for (idx_t k = 0; k < nblk; ++k)
+      if (cb[k]) {
+        const size_t nbk = (size_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+        pool.put(reinterpret_cast<double *>(cb[k]), nbk * nbk * SC);
+        cb[k] = nullptr;
+      }
   if (first_device_level < nlev_all && !bad) {
     // ---- hand-over: the remaining levels run on the device (real and complex scalars: numeric_device.hip) ----
     const double td0 = now();
