@@ -224,6 +224,11 @@ def main():
     one["applies_per_sec"] = (1 if (args.strong and sharded) else world) * 1e3 / one["apply_ms"]
     t_solve = A.time("solve", mu=mu, warmup=2, reps=reps)
     phases = {"sptrsv": t_solve * 1e3, "exchange": A.time("exchange", mu=mu, reps=reps) * 1e3, "gmv": A.time("gmv", mu=mu, reps=reps) * 1e3}
+    if sharded:
+        # what the communication stream hides: the same exchange with pack -> send/recv -> unpack in order on the library stream
+        A.set_option("hip_halo_overlap", 0)
+        phases["exchange_no_overlap"] = A.time("exchange", mu=mu, reps=reps) * 1e3
+        A.set_option("hip_halo_overlap", 1)
     if not args.no_gmres and not helm:   # (helmholtz: the indefinite operator is only solved with its coarse space)
         one["gmres"] = gmres_leg()
 
@@ -331,6 +336,10 @@ def main():
             if peers_hist is not None:
                 out["config"]["peer_gpus_histogram"] = peers_hist      # {peer GPUs of a rank: ranks}; 8 GPUs: {"7": 8}
                 out["config"]["global_dims"] = list(dims)
+                out["config"]["transport"] = "callback (gloo test double, ranks share GPU 0)" if share_gpu else "rccl"
+                out["config"]["rccl_ranks"] = 0 if share_gpu else world
+                out["exchange_ms"] = {"overlapped": phases["exchange"], "in_order": phases.get("exchange_no_overlap"),
+                                      "note": "one halo sum (D-scale, local gather, pack -> grouped send/recv per peer GPU -> unpack-add) of rank 0; a two-level apply makes three"}
         # ---- roofline of the dominant kernel pair (batched SpTRSV), HIP events on the library stream ----
         bytes_alg = 2.0 * st["nnz_L"] * sk + 4.0 * st["n"] * mu * sk   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
         out["roofline"] = roofline(bytes_alg, t_solve, st, args, mu)

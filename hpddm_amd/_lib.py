@@ -54,6 +54,7 @@ def _declare(lib):
         "HpddmHipSchwarzDestroyRecycling": (I, [P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
+        "HpddmHipSchwarzSetOptimizedMatrixZ": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),
         "HpddmHipSchwarzBuildCoarseOperator": (I, [P]),
         "HpddmHipSchwarzCallNumfact": (I, [P]),

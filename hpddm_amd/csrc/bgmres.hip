@@ -177,9 +177,9 @@ static int bgmres_impl(Schwarz &A, const double *b, double *x, double *history, 
     G.resize((size_t)k * mu * mu);
     hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, (unsigned)k), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, Vb, cnt, W, partial.p);
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)k), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    A.allreduce_device(gram_d.p, (long long)k * mu * mu); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * k * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    A.allreduce_host(G.data(), (long long)k * mu * mu);
   };
   // W = beta W + sign * V(0..k) C,  C given as (k*mu) x mu row-major
   auto axpy_blocks = [&](const double *Vb, int k, const std::vector<double> &C, double sign, double beta, double *W) {
@@ -517,9 +517,9 @@ static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int
     G.resize((size_t)mu * mu);
     hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, 1), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, V, cnt, W, partial.p);
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    A.allreduce_device(gram_d.p, (long long)mu * mu); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    A.allreduce_host(G.data(), (long long)mu * mu);
   };
   // the reference forms the upper triangle (gemmt "U") and mirrors it
   auto sym_upper = [&](std::vector<double> &G) {
@@ -693,9 +693,9 @@ static int bfbcg_impl(Schwarz &A, const double *b, double *x, double *history, i
     G.resize((size_t)mu * mu);
     hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, 1), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, V, cnt, W, partial.p);
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, 1), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    A.allreduce_device(gram_d.p, (long long)mu * mu); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    A.allreduce_host(G.data(), (long long)mu * mu);
   };
   auto axpy_block = [&](const double *V, const std::vector<double> &C, double sign, double beta, double *W) { // W = beta W + sign V C
     HIP_OK(hipMemcpyAsync(coef_d.p, C.data(), sizeof(double) * mu * mu, hipMemcpyHostToDevice, st));
@@ -969,9 +969,9 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
     G.resize((size_t)nb * mu * mu);
     hipLaunchKernelGGL((k_block_gram<MU>), dim3(nblk, (unsigned)nb), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, Vb, cnt, W, partial.p);
     hipLaunchKernelGGL(k_block_gram_reduce, dim3(1, (unsigned)nb), dim3(64), 0, st, partial.p, nblk, mu * mu, gram_d.p);
+    A.allreduce_device(gram_d.p, (long long)nb * mu * mu); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * nb * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    A.allreduce_host(G.data(), (long long)nb * mu * mu);
   };
   auto axpy_blocks = [&](const double *Vb, int nb, const double *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
     if (nb <= 0) {

@@ -324,6 +324,27 @@ int HpddmHipSchwarzSetOptimizedMatrix(HpddmHipSchwarz *A, int s, int n, const in
     S.has1  = true;
     return 0;)
 }
+int HpddmHipSchwarzSetOptimizedMatrixZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering)
+{
+  HH_TRY(
+    HH_CHECK(A && s >= 0 && s < A->op.nsub, "bad subdomain");
+    SchwarzSub &S = A->op.subs[s];
+    if (!ia) {
+      S.has1 = false;
+      return 0;
+    }
+    HH_CHECK(A->op.is_complex && ja && a && 2 * n == S.n, "complex optimised matrix: complex subdomains first (SetSubdomainZ), n complex rows");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    const int base = numbering == 'F' ? 1 : 0, nnz = ia[n] - base;
+    for (int p = 0; p < nnz; ++p) HH_CHECK(ja[p] - base >= 0 && ja[p] - base < n, "complex optimised matrix: column index out of range");
+    S.zia1.assign(ia, ia + n + 1);
+    S.zja1.assign(ja, ja + nnz);
+    S.za1.assign(a, a + 2 * (size_t)nnz);
+    S.zsym1  = sym != 0;
+    S.zbase1 = base;
+    S.has1   = true;
+    return 0;)
+}
 int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A)
 {
   HH_TRY(

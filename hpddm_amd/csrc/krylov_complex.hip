@@ -170,9 +170,9 @@ struct ZBlocks {
     G.resize((size_t)k * MU * MU);
     hipLaunchKernelGGL((k_zgram<MU>), dim3(nblk, (unsigned)k), dim3(256), 0, st, A.voff_d.p, A.n_d.p, A.nsub, A.d_d.p, Vb, cnt, W, partial.p);
     hipLaunchKernelGGL(k_zgram_reduce, dim3((2 * MU * MU + 63) / 64, (unsigned)k), dim3(64), 0, st, partial.p, nblk, 2 * MU * MU, gram_d.p);
+    A.allreduce_device(gram_d.p, 2LL * k * MU * MU); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(reinterpret_cast<double *>(G.data()), gram_d.p, sizeof(double) * 2 * k * MU * MU, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    A.allreduce_host(reinterpret_cast<double *>(G.data()), 2LL * k * MU * MU);
   }
   // W = beta W + sign * V(0..k) C,  C (k MU) x MU row-major
   void axpy(const double *Vb, int k, const std::vector<cplx> &C, double sign, double beta, double *W)

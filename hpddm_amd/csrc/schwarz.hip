@@ -295,6 +295,12 @@ Schwarz::~Schwarz()
   }
   for (hipEvent_t e : ev_join) (void)hipEventDestroy(e);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (comm_stream) {
+    (void)hipStreamSynchronize(comm_stream);
+    (void)hipStreamDestroy(comm_stream);
+  }
+  if (ev_halo_fork) (void)hipEventDestroy(ev_halo_fork);
+  if (ev_halo_done) (void)hipEventDestroy(ev_halo_done);
 }
 
 int Schwarz::owner(int gid) const
@@ -734,7 +740,7 @@ void Schwarz::call_numfact()
             S.ls->analysed  = false;
           }
           CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
-          if (is_complex) A = CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
+          if (is_complex) A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
           S.ls->analyse(A);
         } catch (const std::exception &e) {
 #pragma omp critical(hpddm_hip_analyse_err)
@@ -750,8 +756,8 @@ void Schwarz::call_numfact()
       S.ls->host.keep_plain  = getopt("keep_plain", 0) != 0;
       CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
       if (is_complex) {
-        HH_CHECK(!use1 && !S.zia.empty(), "complex operators: no optimised local matrix");
-        A = CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
+        HH_CHECK(!S.zia.empty() && (!use1 || !S.zia1.empty()), "complex operators: the subdomain (optimised) matrix was not handed over as a complex matrix");
+        A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
       }
       S.ls->numfact(A, spd);
       fs.push_back(&S.ls->dev);
@@ -1057,13 +1063,40 @@ void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
 {
   HH_CHECK(in != out, "exchange: out-of-place only");
   hipStream_t st = library_stream();
-  hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
-  if (halo_total) {
-    HH_CHECK(transport && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport first (HpddmHipSchwarzInitRccl or HpddmHipSchwarzSetTransport) with room for this many right-hand sides");
-    hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, in, sendbuf, mu, scale ? 1 : 0);
-    transport->halo(peers, sendbuf, recvbuf, mu, st); // RCCL: grouped send/recv enqueued on the library stream, no host wait
-    hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
+  if (!halo_total) {
+    hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+    return;
   }
+  HH_CHECK(transport && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport first (HpddmHipSchwarzInitRccl or HpddmHipSchwarzSetTransport) with room for this many right-hand sides");
+  // Subdomain::exchange posts its receives and sends first and accumulates afterwards (include/HPDDM_subdomain.hpp:115-130); here the
+  // messages of the neighbouring GPUs leave on the communication stream -- pack (fused D-scale), one grouped ncclSend / ncclRecv pair
+  // per neighbouring GPU -- while the library stream sums the co-located duplicates over the whole vector; it waits for the
+  // messages (an event, no host synchronisation) only before the unpack-add.  Buffer reuse: the fork event follows the previous
+  // exchange's unpack in stream order, so the next pack / receive cannot overtake it.
+  const bool  overlap = getopt("hip_halo_overlap", 1) != 0;
+  hipStream_t cs      = st;
+  if (overlap) {
+    if (!comm_stream) {
+      HIP_OK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&ev_halo_fork, hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&ev_halo_done, hipEventDisableTiming));
+    }
+    cs = comm_stream;
+    HIP_OK(hipEventRecord(ev_halo_fork, st)); // `in` is complete, the previous unpack is done
+    HIP_OK(hipStreamWaitEvent(cs, ev_halo_fork, 0));
+  }
+  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, cs, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, in, sendbuf, mu, scale ? 1 : 0);
+  if (overlap) {
+    // the local part goes to the library stream BEFORE a host-synchronous transport (callback test double) blocks this thread
+    hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+    transport->halo(peers, sendbuf, recvbuf, mu, cs); // RCCL: grouped send/recv enqueued, no host wait
+    HIP_OK(hipEventRecord(ev_halo_done, cs));
+    HIP_OK(hipStreamWaitEvent(st, ev_halo_done, 0));
+  } else {
+    transport->halo(peers, sendbuf, recvbuf, mu, st);
+    hipLaunchKernelGGL(k_exchange, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, ex_ptr.p, ex_sub.p, ex_idx.p, in, out, mu, scale ? 1 : 0);
+  }
+  hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
 }
 void Schwarz::exchange_inplace(double *x, int mu, bool scale)
 {
@@ -1345,6 +1378,13 @@ void Schwarz::allreduce_host(double *buf, long long count)
   transport->allreduce_host(buf, count, library_stream());
 }
 
+void Schwarz::allreduce_device(double *buf_dev, long long count)
+{
+  if (nranks <= 1) return;
+  HH_CHECK(transport != nullptr, "several ranks but no transport registered (HpddmHipSchwarzInitRccl / HpddmHipSchwarzSetTransport)");
+  transport->allreduce_device(buf_dev, count, library_stream());
+}
+
 void Schwarz::use_rccl(const char *id128, int mu_cap)
 {
   HH_CHECK(!rank_first.empty(), "InitRccl: call SetPartition first");
@@ -1444,6 +1484,15 @@ __global__ void k_sqrt_abs(long long cnt, double *__restrict__ w)
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long long)gridDim.x * blockDim.x) w[i] = sqrt(fabs(w[i]));
 }
+// complex operators (vectors of (re, im) pairs): w <- (|z| or sqrt|z|, 0) per pair, so that the real reductions below see the moduli
+__global__ void k_zmodulus(long long pairs, double *__restrict__ w, int root)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long long)gridDim.x * blockDim.x) {
+    const double m = hypot(w[2 * i], w[2 * i + 1]);
+    w[2 * i]       = root ? sqrt(m) : m;
+    w[2 * i + 1]   = 0.0;
+  }
+}
 // out[nu] = max_i |w[s][nu][i]| over all subdomains (non-negative doubles order like their bit patterns)
 __global__ void k_absmax(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ w, int mu, unsigned long long *__restrict__ out)
 {
@@ -1463,7 +1512,6 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
   // rows do not count in the residual and penalised entries of f are divided by HPDDM_PEN.  norm: 0 = l2 and 1 = l1, both weighted by
   // the partition of unity (HPDDM_COMPUTE_RESIDUAL_L2 / _L1), 2 = linfty (plain maximum)
   HH_CHECK(norm >= 0 && norm <= 2, "ComputeResidual: unknown norm");
-  HH_CHECK(norm == 0 || !is_complex, "ComputeResidual: l1 and linfty are built for real scalars");
   HH_CHECK(norm != 2 || nranks == 1, "ComputeResidual: linfty needs a max-reduction over the ranks, not part of the registered transport");
   reserve(mu);
   const size_t cnt = (size_t)ntot * mu;
@@ -1478,6 +1526,16 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
   }
   std::vector<double> r(mu), b(mu);
   hipStream_t         st = library_stream();
+  if (is_complex && norm != 0) {
+    // std::abs of the reference is the complex modulus (include/HPDDM_schwarz.hpp:769-789): moduli into the even slots, zeros beside
+    const dim3 gz((unsigned)std::min<size_t>(2048, (cnt / 2 + 255) / 256));
+    if (fn != w2.p) {
+      HIP_OK(hipMemcpyAsync(w2.p, fn, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      fn = w2.p;
+    }
+    hipLaunchKernelGGL(k_zmodulus, gz, dim3(256), 0, st, (long long)(cnt / 2), w2.p, norm == 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_zmodulus, gz, dim3(256), 0, st, (long long)(cnt / 2), w1.p, norm == 1 ? 1 : 0);
+  }
   if (norm == 2) {
     DevBuf<unsigned long long> mx;
     mx.alloc((size_t)2 * mu);
@@ -1493,7 +1551,7 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
     }
     return;
   }
-  if (norm == 1) {
+  if (norm == 1 && !is_complex) {
     const dim3 gl((unsigned)std::min<size_t>(2048, (cnt + 255) / 256));
     if (fn != w2.p) {
       HIP_OK(hipMemcpyAsync(w2.p, fn, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));

@@ -50,6 +50,12 @@ struct SchwarzSub {
   std::vector<double> za;
   bool                zsym = false;
   int                 zbase = 0;
+  // complex optimised local matrix (callNumfact(A_opt) with K = std::complex<double>: the impedance matrices of ORAS for
+  // Helmholtz), as handed over: n / 2 rows, (re, im) pairs; has1 says whether it is set
+  std::vector<int>    zia1, zja1;
+  std::vector<double> za1;
+  bool                zsym1 = false;
+  int                 zbase1 = 0;
 };
 
 struct Schwarz {
@@ -72,6 +78,12 @@ struct Schwarz {
   int                   halo_mu_cap = 0;
   std::unique_ptr<Transport> transport;                         // transport.hpp; null while every neighbour is local
   void                  allreduce_host(double *buf, long long count);   // sum over the ranks (no-op on one rank)
+  void                  allreduce_device(double *buf_dev, long long count); // the same on a device buffer, in order of the library stream
+  // The cross-GPU half of an exchange runs on its own stream: pack -> transport (grouped ncclSend / ncclRecv) go out while the
+  // library stream does the local part of the halo sum (k_exchange: the whole vector); the library stream waits for the
+  // messages only before k_halo_unpack.  -hpddm_hip_halo_overlap 0: everything in order on the library stream.
+  hipStream_t           comm_stream = nullptr;
+  hipEvent_t            ev_halo_fork = nullptr, ev_halo_done = nullptr;
   void                  use_rccl(const char *id128, int mu_cap);         // the product path on a multi-GPU node
   bool                  halo_lists_ready = false;
   int                   owner(int gid) const;

@@ -225,8 +225,9 @@ class Schwarz:
         """callNumfact(A) of the reference: optimised local matrix of subdomain s for -hpddm_schwarz_method oras / soras / osm"""
         ia = np.ascontiguousarray(ia, dtype=np.int32)
         ja = np.ascontiguousarray(ja, dtype=np.int32)
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        check(self._lib.HpddmHipSchwarzSetOptimizedMatrix(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
+        a = np.ascontiguousarray(a, dtype=np.complex128 if self.complex else np.float64)
+        setter = self._lib.HpddmHipSchwarzSetOptimizedMatrixZ if self.complex else self._lib.HpddmHipSchwarzSetOptimizedMatrix
+        check(setter(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
 
     def destroy_recycling(self):
         """OptionsPrefix::destroy: drop the subspace GCRO-DR recycles between successive solves"""

@@ -135,6 +135,9 @@ int HpddmHipSchwarzBuildCoarseOperator(HpddmHipSchwarz *A);
  * once every local subdomain has one, -hpddm_schwarz_method oras|osm gives type OG (factor of A_opt, D-scaled exchange),
  * soras gives OS (D A_opt^{-1} D, plain exchange).  ia == NULL removes it. */
 int HpddmHipSchwarzSetOptimizedMatrix(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering);
+/* the same for K = std::complex<double> (n complex rows, `a` = (re, im) pairs): the impedance / absorbing local matrices of ORAS
+ * for Helmholtz problems -- callNumfact(A_opt) is templated on K in the reference (include/HPDDM_schwarz.hpp:337-366) */
+int HpddmHipSchwarzSetOptimizedMatrixZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering);
 int HpddmHipSchwarzCallNumfact(HpddmHipSchwarz *A);
 /* Options of the path, same names and values as the reference's -hpddm_* flags (include/HPDDM_option_impl.hpp:41-178):
  * "tol" "max_it" "gmres_restart" "variant" (0 left,1 right,2 flexible) "orthogonalization" (0 cgs,1 mgs)

@@ -65,7 +65,8 @@ int main(int argc, char **argv)
              std::forward_as_tuple("deflation_nu=<1>", "number of deflation vectors per subdomain: the constant one, then deterministic smooth ones (dumped as ev)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("second_solve=<0>", "solve a second system with the right-hand side f (1 + sin(f) / 2) after the first one (subspace recycling between solves)", HPDDM::Option::Arg::integer),
              std::forward_as_tuple("penalize=<0>", "penalised Dirichlet rows: a_ii = HPDDM_PEN, f_i = HPDDM_PEN * f_i on a deterministic subset of the dofs", HPDDM::Option::Arg::integer),
-             std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer)});
+             std::forward_as_tuple("optimized_shift=<0>", "callNumfact(A_opt): A_opt = A + shift * diag(1 - d) * diag(A), in percent", HPDDM::Option::Arg::integer),
+             std::forward_as_tuple("optimized_shift_im=<0>", "complex builds: imaginary part of the factor of optimized_shift, in percent (an impedance-like term)", HPDDM::Option::Arg::integer)});
   if (rank != 0) opt.remove("verbosity");
   const std::string dir  = opt.prefix("out");
   const std::string name = opt.prefix("case");
@@ -197,7 +198,13 @@ int main(int argc, char **argv)
       std::copy_n(Mat->ja_, Mat->nnz_, jao);
       for (int i = 0; i < ndof; ++i)
         for (int p = iao[i] - (HPDDM_NUMBERING == 'F'); p < iao[i + 1] - (HPDDM_NUMBERING == 'F'); ++p)
-          if (jao[p] - (HPDDM_NUMBERING == 'F') == i) ao[p] += 0.01 * shift * (1.0 - d[i]) * ao[p];
+          if (jao[p] - (HPDDM_NUMBERING == 'F') == i) {
+#ifdef FORCE_COMPLEX
+            ao[p] += K(0.01 * shift, 0.01 * (double)opt.app()["optimized_shift_im"]) * (1.0 - d[i]) * ao[p];
+#else
+            ao[p] += 0.01 * shift * (1.0 - d[i]) * ao[p];
+#endif
+          }
       HPDDM::MatrixCSR<K> *Aopt = new HPDDM::MatrixCSR<K>(ndof, ndof, Mat->nnz_, ao, iao, jao, Mat->sym_, true);
       dumpd("a_opt", ao, Mat->nnz_);
       A.callNumfact(Aopt);
