@@ -50,12 +50,15 @@ def _declare(lib):
         "HpddmHipSchwarzSetVectorsZ": (I, [P, I, I, P]),
         "HpddmHipSchwarzIsComplex": (I, [P]),
         "HpddmHipDenseEig": (I, [I, P, P, P, P]),
+        "HpddmHipDenseEigZ": (I, [I, P, P, P]),
         "HpddmHipHostSelfTest": (I, []),
         "HpddmHipSchwarzDestroyRecycling": (I, [P]),
         "HpddmHipSchwarzSolveGEVP": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrix": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzSetOptimizedMatrixZ": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),
+        "HpddmHipSchwarzGetEigenvaluesZ": (I, [P, I, P, I]),
+        "HpddmHipSchwarzSolveGEVPWith": (I, [P, I, I, P, P, P, I, ctypes.c_char, P, P, P, I]),
         "HpddmHipSchwarzBuildCoarseOperator": (I, [P]),
         "HpddmHipSchwarzCallNumfact": (I, [P]),
         "HpddmHipSchwarzSetOption": (I, [P, C, D]),

@@ -267,6 +267,17 @@ int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V)
     std::copy(v.begin(), v.end(), V);
     return 0;)
 }
+int HpddmHipDenseEigZ(int n, const double *A, double *w, double *V)
+{
+  HH_TRY(
+    HH_CHECK(n >= 0 && (n == 0 || (A && w && V)), "null argument");
+    typedef std::complex<double> Z_;
+    std::vector<Z_> a(reinterpret_cast<const Z_ *>(A), reinterpret_cast<const Z_ *>(A) + (size_t)n * n), ev, v;
+    HH_CHECK(dense_eig_z(n, a, ev, v), "dense_eig_z: the QR iteration did not converge");
+    std::copy(ev.begin(), ev.end(), reinterpret_cast<Z_ *>(w));
+    std::copy(v.begin(), v.end(), reinterpret_cast<Z_ *>(V));
+    return 0;)
+}
 int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z)
 {
   HH_TRY(
@@ -288,6 +299,28 @@ int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, co
     HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
     A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F');
     return 0;)
+}
+int HpddmHipSchwarzSolveGEVPWith(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, const int *bia, const int *bja, const double *ba, int bsym)
+{
+  HH_TRY(
+    HH_CHECK(A && ia && ja && a, "null argument");
+    HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    HH_CHECK(!bia || (bja && ba), "SolveGEVPWith: bja / ba missing");
+    if (A->op.is_complex) A->op.solve_gevp_z(s, n, ia, ja, a, sym != 0, numbering == 'F', bia, bja, ba, bsym != 0, numbering == 'F');
+    else A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F', bia, bja, ba, bsym != 0, numbering == 'F');
+    return 0;)
+}
+int HpddmHipSchwarzGetEigenvaluesZ(HpddmHipSchwarz *A, int s, double *out, int capacity)
+{
+  HH_TRY(
+    HH_CHECK(A && s >= 0 && s < A->op.nsub, "bad subdomain");
+    const SchwarzSub &S = A->op.subs[s];
+    const int         k = (int)S.eigenvalues.size();
+    if (out) {
+      HH_CHECK(capacity >= k, "GetEigenvaluesZ: array too small");
+      for (int c = 0; c < k; ++c) out[2 * c] = S.eigenvalues[c], out[2 * c + 1] = c < (int)S.eigenvalues_im.size() ? S.eigenvalues_im[c] : 0.0;
+    }
+    return k;)
 }
 int HpddmHipSchwarzGetEigenvalues(HpddmHipSchwarz *A, int s, double *out, int capacity)
 {

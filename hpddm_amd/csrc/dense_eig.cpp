@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <complex>
 
 namespace hpddm_hip {
 
@@ -343,4 +344,153 @@ bool dense_eig(int n, std::vector<double> &Ain, std::vector<double> &wr, std::ve
   return true;
 }
 
+} // namespace hpddm_hip
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for a complex matrix (the Rayleigh-Ritz problems of the complex GenEO eigensolver, geneo.hip): Householder reduction to
+// Hessenberg form, explicitly shifted QR iteration with Givens rotations (Wilkinson shifts, exceptional shifts every ten steps
+// without deflation) down to the Schur form A = Z T Z^H, eigenvectors of T by back substitution, V = Z Y with unit columns.
+namespace hpddm_hip {
+bool dense_eig_z(int n, std::vector<std::complex<double>> &A, std::vector<std::complex<double>> &w, std::vector<std::complex<double>> &V)
+{
+  typedef std::complex<double> Z_;
+  w.assign(n, Z_(0));
+  V.assign((size_t)n * n, Z_(0));
+  if (n == 0) return true;
+  auto a = [&](int i, int j) -> Z_ & { return A[(size_t)i * n + j]; };
+  std::vector<Z_> Zm((size_t)n * n, Z_(0));
+  auto z = [&](int i, int j) -> Z_ & { return Zm[(size_t)i * n + j]; };
+  for (int i = 0; i < n; ++i) z(i, i) = 1.0;
+  auto abs1 = [](const Z_ &x) { return std::abs(x.real()) + std::abs(x.imag()); };
+  // ---- Hessenberg form ----
+  std::vector<Z_> v(n);
+  for (int k = 0; k + 2 < n; ++k) {
+    double alpha = 0.0;
+    for (int i = k + 1; i < n; ++i) alpha += std::norm(a(i, k));
+    double below = alpha - std::norm(a(k + 1, k));
+    if (!(below > 0.0)) continue; // already Hessenberg in this column
+    alpha          = std::sqrt(alpha);
+    const Z_ x0    = a(k + 1, k);
+    const Z_ phase = std::abs(x0) > 0.0 ? x0 / std::abs(x0) : Z_(1.0);
+    std::fill(v.begin(), v.end(), Z_(0));
+    for (int i = k + 1; i < n; ++i) v[i] = a(i, k);
+    v[k + 1] += phase * alpha;
+    double vn = 0.0;
+    for (int i = k + 1; i < n; ++i) vn += std::norm(v[i]);
+    if (!(vn > 0.0)) continue;
+    const double f = 2.0 / vn;
+    for (int j = 0; j < n; ++j) { // A <- H A
+      Z_ s(0);
+      for (int i = k + 1; i < n; ++i) s += std::conj(v[i]) * a(i, j);
+      s *= f;
+      for (int i = k + 1; i < n; ++i) a(i, j) -= v[i] * s;
+    }
+    for (int i = 0; i < n; ++i) { // A <- A H,  Z <- Z H
+      Z_ s(0), t(0);
+      for (int j = k + 1; j < n; ++j) s += a(i, j) * v[j], t += z(i, j) * v[j];
+      s *= f, t *= f;
+      for (int j = k + 1; j < n; ++j) a(i, j) -= s * std::conj(v[j]), z(i, j) -= t * std::conj(v[j]);
+    }
+    for (int i = k + 2; i < n; ++i) a(i, k) = 0.0;
+  }
+  double anorm = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = std::max(0, i - 1); j < n; ++j) anorm = std::max(anorm, abs1(a(i, j)));
+  if (anorm == 0.0) {
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    return true;
+  }
+  const double eps = 2.220446049250313e-16;
+  // ---- shifted QR on the active window [l, hi] ----
+  std::vector<double> cs(n);
+  std::vector<Z_>     sn(n);
+  int                 hi = n - 1, iter = 0, total = 0;
+  while (hi >= 0) {
+    int l = hi;
+    while (l > 0) {
+      double s = abs1(a(l - 1, l - 1)) + abs1(a(l, l));
+      if (s == 0.0) s = anorm;
+      if (abs1(a(l, l - 1)) <= eps * s) {
+        a(l, l - 1) = 0.0;
+        break;
+      }
+      --l;
+    }
+    if (l == hi) {
+      w[hi] = a(hi, hi);
+      --hi;
+      iter = 0;
+      continue;
+    }
+    if (++total > 60 * n + 200) return false;
+    Z_ shift;
+    ++iter;
+    if (iter % 10 == 0) shift = a(hi, hi) + Z_(std::abs(a(hi, hi - 1).real()) + (hi >= 2 ? std::abs(a(hi - 1, hi - 2).real()) : 0.0), 0.0); // exceptional
+    else { // the eigenvalue of the trailing 2 x 2 block closer to its last diagonal entry
+      const Z_ p = a(hi - 1, hi - 1), q = a(hi - 1, hi), r = a(hi, hi - 1), t = a(hi, hi);
+      const Z_ half = 0.5 * (p - t), disc = std::sqrt(half * half + q * r);
+      const Z_ e1 = t + half + disc, e2 = t + half - disc; // = (p + t) / 2 +- disc
+      shift       = std::abs(e1 - t) < std::abs(e2 - t) ? e1 : e2;
+    }
+    for (int i = l; i <= hi; ++i) a(i, i) -= shift;
+    for (int k = l; k < hi; ++k) { // R = G_{hi-1} ... G_l (H - shift)
+      const Z_ f = a(k, k), g = a(k + 1, k);
+      double   c;
+      Z_       s;
+      if (g == Z_(0)) c = 1.0, s = 0.0;
+      else if (f == Z_(0)) c = 0.0, s = std::conj(g) / std::abs(g);
+      else {
+        const double f1 = std::abs(f), nr = std::sqrt(std::norm(f) + std::norm(g));
+        c               = f1 / nr;
+        s               = (f / f1) * std::conj(g) / nr;
+      }
+      cs[k] = c, sn[k] = s;
+      for (int j = k; j < n; ++j) {
+        const Z_ t1 = a(k, j), t2 = a(k + 1, j);
+        a(k, j)     = c * t1 + s * t2;
+        a(k + 1, j) = -std::conj(s) * t1 + c * t2;
+      }
+      a(k + 1, k) = 0.0;
+    }
+    for (int k = l; k < hi; ++k) { // H' = R G_l^H ... G_{hi-1}^H + shift,  Z <- Z G_l^H ...
+      const double c = cs[k];
+      const Z_     s = sn[k];
+      for (int i = 0; i <= std::min(k + 1, hi); ++i) {
+        const Z_ t1 = a(i, k), t2 = a(i, k + 1);
+        a(i, k)     = t1 * c + t2 * std::conj(s);
+        a(i, k + 1) = -t1 * s + t2 * c;
+      }
+      for (int i = 0; i < n; ++i) {
+        const Z_ t1 = z(i, k), t2 = z(i, k + 1);
+        z(i, k)     = t1 * c + t2 * std::conj(s);
+        z(i, k + 1) = -t1 * s + t2 * c;
+      }
+    }
+    for (int i = l; i <= hi; ++i) a(i, i) += shift;
+  }
+  // ---- eigenvectors of T (upper triangular), then V = Z Y ----
+  std::vector<Z_> y(n);
+  for (int k = n - 1; k >= 0; --k) {
+    std::fill(y.begin(), y.end(), Z_(0));
+    y[k] = 1.0;
+    for (int i = k - 1; i >= 0; --i) {
+      Z_ s(0);
+      for (int j = i + 1; j <= k; ++j) s += a(i, j) * y[j];
+      Z_ d = a(i, i) - w[k];
+      if (abs1(d) < eps * anorm) d = eps * anorm; // (a multiple eigenvalue: perturbed, like LAPACK's trevc)
+      y[i] = -s / d;
+    }
+    double nrm = 0.0;
+    for (int i = 0; i < n; ++i) {
+      Z_ s(0);
+      for (int j = 0; j <= k; ++j) s += z(i, j) * y[j];
+      V[(size_t)i * n + k] = s;
+      nrm += std::norm(s);
+    }
+    nrm = std::sqrt(nrm);
+    if (nrm > 0.0)
+      for (int i = 0; i < n; ++i) V[(size_t)i * n + k] /= nrm;
+  }
+  return true;
+}
 } // namespace hpddm_hip

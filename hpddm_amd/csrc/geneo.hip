@@ -9,7 +9,9 @@
 // time (one sweep over L for the block).  The basis and all n-sized blocks live in HBM; the host sees k x k matrices.
 #include "schwarz.hpp"
 #include <algorithm>
+#include "dense_eig.hpp"
 #include <cmath>
+#include <complex>
 #include <random>
 #include <set>
 
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restric
 }
 } // namespace
 
-void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base)
+void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia, const int *uja, const double *ua, bool usym, int ubase)
 {
   HH_CHECK(s >= 0 && s < nsub && n == subs[s].n, "SolveGEVP: bad subdomain / size");
   SchwarzSub &S  = subs[s];
@@ -198,7 +200,8 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   Csr B;
   B.n = n;
   B.ia.assign(n + 1, 0);
-  for (int i = 0; i < n; ++i) {
+  if (uia) B = expand(n, uia, uja, ua, usym, ubase); // solveGEVP(A, B): the caller's right-hand side matrix (include/HPDDM_schwarz.hpp:665-680), symmetric positive semi-definite here
+  for (int i = 0; i < n && !uia; ++i) {
     if (in_ovl[i])
       for (int p = AN.ia[i]; p < AN.ia[i + 1]; ++p) {
         const int    j = AN.ja[p];
@@ -214,14 +217,14 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   const double sigma = getopt("geneo_shift", 1.0e-2);
   std::vector<int>    sia(n + 1, 0), sja;
   std::vector<double> sa;
-  for (int i = 0; i < n; ++i) {
-    int pb = B.ia[i];
-    for (int p = AN.ia[i]; p < AN.ia[i + 1]; ++p) {
-      const int j = AN.ja[p];
+  for (int i = 0; i < n; ++i) { // merge of the two sorted rows, lower triangle (a user-supplied B may have entries outside the pattern of A_N)
+    int pa = AN.ia[i], pb = B.ia[i];
+    while (true) {
+      const int ja_ = pa < AN.ia[i + 1] ? AN.ja[pa] : n, jb = pb < B.ia[i + 1] ? B.ja[pb] : n, j = std::min(ja_, jb);
       if (j > i) break;
-      double v = AN.a[p];
-      while (pb < B.ia[i + 1] && B.ja[pb] < j) ++pb;
-      if (pb < B.ia[i + 1] && B.ja[pb] == j) v += sigma * B.a[pb];
+      double v = 0.0;
+      if (ja_ == j) v += AN.a[pa++];
+      if (jb == j) v += sigma * B.a[pb++];
       sja.push_back(j);
       sa.push_back(v);
     }
@@ -421,6 +424,393 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   S.gevp_iterations = it;
   coarse_ready      = false;
   if (getopt("verbosity", 0) >= 2) printf("GenEO subdomain %d: %d vectors, lambda in [%.3e, %.3e], %d block-Krylov steps (basis %d)\n", first + s, keep, lam[0], lam[keep - 1], it, m);
+}
+
+
+// =====================================================================================================================
+// K = std::complex<double>: Schwarz::solveGEVP(A, B) is templated on K (include/HPDDM_schwarz.hpp:665-715); for complex scalars the
+// reference hands the pencil to ARPACK's znaupd / zneupd in shift-invert mode -- a general (non-Hermitian) Arnoldi iteration on
+// OP = A^{-1} B, "LM" of OP = the eigenvalues of smallest modulus (include/HPDDM_ARPACK.hpp:62, 84-148).  This is the slot the
+// Helmholtz coarse spaces fill (DtN: A = the local Neumann / absorbing matrix, B = a boundary mass matrix on the interface handed over
+// by the caller; H-GenEO-like: B = scaleIntoOverlap(A)).  Here: BLOCK Arnoldi on OP = (A + sigma B)^{-1} B -- the shifted matrix goes
+// through the complex L D L^T / LU numfact and the HIP SpTRSV, 8 complex right-hand sides per sweep (the 16-column MFMA engine) --
+// with a Hermitian-orthonormal basis kept in HBM (classical block Gram-Schmidt twice + CholQR twice), Rayleigh-Ritz on the block
+// Hessenberg matrix H = Q^H OP Q by the complex QR algorithm on the host (dense_eig_z), residuals from the Arnoldi relation
+// (|R y_last| / |theta|).  lambda = 1 / theta - sigma; kept: the nu of smallest modulus, ordered by modulus; with
+// -hpddm_geneo_threshold those whose REAL part is below it (Eigensolver::selectNu compares real parts, eigensolver.hpp:110).
+namespace {
+typedef std::complex<double> cplx;
+constexpr int GEZ_ROWS = 512; // complex rows of a block handled by one workgroup of k_zge_hn (8 columns x 512 x 16 B = 64 KB of LDS)
+
+struct CsrZ {
+  int               n = 0;
+  std::vector<int>  ia, ja;
+  std::vector<cplx> a;
+};
+CsrZ expand_z(int n, const int *ia, const int *ja, const double *a, bool sym, int base)
+{
+  CsrZ M;
+  M.n = n;
+  std::vector<std::vector<std::pair<int, cplx>>> rows(n);
+  for (int i = 0; i < n; ++i)
+    for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
+      const int  j = ja[p] - base;
+      const cplx v(a[2 * (size_t)p], a[2 * (size_t)p + 1]);
+      HH_CHECK(j >= 0 && j < n, "SolveGEVP: column index out of range");
+      rows[i].emplace_back(j, v);
+      if (sym && j != i) rows[j].emplace_back(i, v); // complex SYMMETRIC storage (MatrixCSR::sym_): no conjugation
+    }
+  M.ia.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    std::sort(rows[i].begin(), rows[i].end(), [](const std::pair<int, cplx> &x, const std::pair<int, cplx> &y) { return x.first < y.first; });
+    M.ia[i + 1] = M.ia[i] + (int)rows[i].size();
+  }
+  for (int i = 0; i < n; ++i)
+    for (auto &e : rows[i]) M.ja.push_back(e.first), M.a.push_back(e.second);
+  return M;
+}
+
+// Y = B X: complex CSR times a block of <= 8 complex columns (n x cols, column-major, (re, im) pairs)
+__global__ void k_zge_spmm(int n, const int *__restrict__ ia, const int *__restrict__ ja, const double2 *__restrict__ a, const double2 *__restrict__ X, double2 *__restrict__ Y, int cols)
+{
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    double2 acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = double2{0.0, 0.0};
+    for (int p = ia[r]; p < ia[r + 1]; ++p) {
+      const int     c = ja[p];
+      const double2 v = a[p];
+      for (int j = 0; j < cols; ++j) {
+        const double2 x = X[(size_t)j * n + c];
+        acc[j].x        = fma(v.x, x.x, fma(-v.y, x.y, acc[j].x));
+        acc[j].y        = fma(v.x, x.y, fma(v.y, x.x, acc[j].y));
+      }
+    }
+    for (int j = 0; j < cols; ++j) Y[(size_t)j * n + r] = acc[j];
+  }
+}
+// partial[chunk][i][8] = sum over the chunk's rows of conj(A(:, i)) * Bm(:, j), j < cb <= 8 (C = A^H Bm); fixed summation order
+__global__ __launch_bounds__(256) void k_zge_hn(int n, const double2 *__restrict__ A, int ra, const double2 *__restrict__ Bm, int cb, double2 *__restrict__ partial)
+{
+  extern __shared__ double2 bz[]; // [cb][GEZ_ROWS]
+  const int r0 = blockIdx.x * GEZ_ROWS, rows = min(GEZ_ROWS, n - r0);
+  for (int idx = threadIdx.x; idx < cb * GEZ_ROWS; idx += 256) {
+    const int j = idx / GEZ_ROWS, r = idx - j * GEZ_ROWS;
+    bz[idx]     = r < rows ? Bm[(size_t)j * n + r0 + r] : double2{0.0, 0.0};
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wave; i < ra; i += 4) {
+    double2 acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = double2{0.0, 0.0};
+    const double2 *col = A + (size_t)i * n + r0;
+    for (int rr = lane; rr < rows; rr += 64) {
+      const double2 av = col[rr];
+      for (int j = 0; j < cb; ++j) {
+        const double2 b = bz[j * GEZ_ROWS + rr];
+        acc[j].x        = fma(av.x, b.x, fma(av.y, b.y, acc[j].x));  // conj(a) b
+        acc[j].y        = fma(av.x, b.y, fma(-av.y, b.x, acc[j].y));
+      }
+    }
+    for (int j = 0; j < cb; ++j) {
+      double vr = acc[j].x, vi = acc[j].y;
+      for (int off = 32; off >= 1; off >>= 1) vr += __shfl_xor(vr, off), vi += __shfl_xor(vi, off);
+      if (lane == 0) partial[((size_t)blockIdx.x * ra + i) * 8 + j] = double2{vr, vi};
+    }
+  }
+}
+__global__ void k_zge_hn_reduce(int chunks, int ra, int cb, const double2 *__restrict__ partial, double2 *__restrict__ C)
+{
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= ra * cb) return;
+  const int i = o / cb, j = o - i * cb;
+  double    ar = 0.0, ai = 0.0;
+  for (int c = 0; c < chunks; ++c) ar += partial[((size_t)c * ra + i) * 8 + j].x, ai += partial[((size_t)c * ra + i) * 8 + j].y;
+  C[o] = double2{ar, ai};
+}
+// Out(:, j) = beta * Y(:, j) + alpha * sum_i A(:, i) S(i, j),  j < cb <= 8, S complex row-major ra x cb, alpha / beta real (Out may alias Y)
+__global__ __launch_bounds__(256) void k_zge_mul(int n, const double2 *__restrict__ A, int ra, const double2 *__restrict__ S, int cb, double alpha, double beta, const double2 *Y, double2 *Out)
+{
+  extern __shared__ double2 sz[]; // ra * cb
+  for (int idx = threadIdx.x; idx < ra * cb; idx += 256) sz[idx] = S[idx];
+  __syncthreads();
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    double2 acc[8];
+    for (int j = 0; j < 8; ++j) acc[j] = double2{0.0, 0.0};
+    for (int i = 0; i < ra; ++i) {
+      const double2 av = A[(size_t)i * n + r];
+      for (int j = 0; j < cb; ++j) {
+        const double2 c = sz[i * cb + j];
+        acc[j].x        = fma(av.x, c.x, fma(-av.y, c.y, acc[j].x));
+        acc[j].y        = fma(av.x, c.y, fma(av.y, c.x, acc[j].y));
+      }
+    }
+    for (int j = 0; j < cb; ++j) {
+      double2 o = beta != 0.0 ? Y[(size_t)j * n + r] : double2{0.0, 0.0};
+      o.x       = beta * o.x + alpha * acc[j].x;
+      o.y       = beta * o.y + alpha * acc[j].y;
+      Out[(size_t)j * n + r] = o;
+    }
+  }
+}
+} // namespace
+
+void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia, const int *uja, const double *ua, bool usym, int ubase)
+{
+  HH_CHECK(s >= 0 && s < nsub && is_complex && 2 * n == subs[s].n, "SolveGEVPZ: bad subdomain / size (complex subdomains first: SetSubdomainZ; n complex rows)");
+  SchwarzSub  &S  = subs[s];
+  int          nu = (int)getopt("geneo_nu", 20);
+  const double threshold = getopt("geneo_threshold", 0.0);
+  if (4 * nu > n) nu = std::max(1, n / 4); // same guard as the reference (include/HPDDM_ARPACK.hpp:89)
+  const CsrZ AN = expand_z(n, ia, ja, a, sym, base);
+  // ---- B: the caller's matrix, or scaleIntoOverlap(A): rows and columns in the overlap with d > eps, entries d_i d_j a_ij ----
+  CsrZ B;
+  if (uia) B = expand_z(n, uia, uja, ua, usym, ubase);
+  else {
+    std::vector<char> in_ovl(n, 0);
+    for (const auto &pr : S.map)
+      for (int i2 : pr.second)   // (lists of the embedding: entries 2 i, 2 i + 1 per complex row i)
+        if (S.d[i2] > HPDDM_EPS) in_ovl[i2 / 2] = 1;
+    B.n = n;
+    B.ia.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      if (in_ovl[i])
+        for (int p = AN.ia[i]; p < AN.ia[i + 1]; ++p) {
+          const int  j = AN.ja[p];
+          const cplx v = S.d[2 * i] * S.d[2 * j] * AN.a[p];
+          if (std::abs(v) > HPDDM_EPS && in_ovl[j]) B.ja.push_back(j), B.a.push_back(v);
+        }
+      B.ia[i + 1] = (int)B.ja.size();
+    }
+  }
+  // ---- A + sigma B, full storage, merged patterns; complex symmetric pencils go through L D L^T (LocalSolver sees the symmetry) ----
+  const cplx sigma(getopt("geneo_shift", 1.0e-2), getopt("geneo_shift_im", 0.0));
+  std::vector<int>    sia(n + 1, 0), sja;
+  std::vector<double> sa;
+  for (int i = 0; i < n; ++i) {
+    int pa = AN.ia[i], pb = B.ia[i];
+    while (pa < AN.ia[i + 1] || pb < B.ia[i + 1]) {
+      const int ja_ = pa < AN.ia[i + 1] ? AN.ja[pa] : n, jb = pb < B.ia[i + 1] ? B.ja[pb] : n, j = std::min(ja_, jb);
+      cplx v(0.0);
+      if (ja_ == j) v += AN.a[pa++];
+      if (jb == j) v += sigma * B.a[pb++];
+      sja.push_back(j);
+      sa.push_back(v.real()), sa.push_back(v.imag());
+    }
+    sia[i + 1] = (int)sja.size();
+  }
+  LocalSolver shifted;
+  shifted.leaf_size    = (int)getopt("leaf_size", 32);
+  shifted.release_host = true;
+  {
+    CsrView V{n, sia.data(), sja.data(), sa.data(), false, 0, true};
+    shifted.adopt_analysis(*S.ls, V); // same pattern as the subdomain matrix (full storage): its ordering + symbolic factorisation
+    shifted.numfact(V, 0);
+  }
+  const int    p    = std::min(8, n);
+  const int    kmax = std::min(n, (int)getopt("geneo_max_basis", 320));
+  const double tol  = getopt("eigensolver_tol", 1.0e-6);
+  hipStream_t  st   = library_stream();
+  const size_t nn   = (size_t)n;
+  DevBuf<double> Qd, Vd, T1d, T2d, Cd, Pd, small_d, ba_d, Xd;
+  DevBuf<int>    bia_d, bja_d;
+  Qd.alloc(2 * nn * (kmax + p)), Vd.alloc(2 * nn * p), T1d.alloc(2 * nn * p), T2d.alloc(2 * nn * p);
+  const int chunks = (n + GEZ_ROWS - 1) / GEZ_ROWS;
+  Pd.alloc(2 * (size_t)chunks * (kmax + p) * 8);
+  Cd.alloc(2 * (size_t)(kmax + p) * 8);
+  small_d.alloc(2 * (size_t)(kmax + p) * 8 + 64);
+  {
+    std::vector<double> bav(2 * std::max<size_t>(1, B.a.size()), 0.0);
+    for (size_t q = 0; q < B.a.size(); ++q) bav[2 * q] = B.a[q].real(), bav[2 * q + 1] = B.a[q].imag();
+    bia_d.upload(B.ia, st), bja_d.upload(B.ja.empty() ? std::vector<int>(1, 0) : B.ja, st), ba_d.upload(bav, st);
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  auto d2 = [](double *q) { return reinterpret_cast<double2 *>(q); };
+  const dim3 grow((unsigned)std::min(4096, (n + 255) / 256));
+  auto bmult = [&](const double *X, double *Y, int cols) { hipLaunchKernelGGL(k_zge_spmm, grow, dim3(256), 0, st, n, bia_d.p, bja_d.p, d2(ba_d.p), d2(const_cast<double *>(X)), d2(Y), cols); };
+  auto op    = [&](const double *X, double *Y, int cols) { // Y = (A + sigma B)^{-1} B X
+    bmult(X, T1d.p, cols);
+    shifted.plan.solve(T1d.p, Y, cols, st);
+  };
+  // C (ra x cb, row-major, host) = A^H Bm
+  auto hn = [&](const double *Ad, int ra, const double *Bd, int cb, std::vector<cplx> &C) {
+    C.assign((size_t)ra * cb, cplx(0));
+    hipLaunchKernelGGL(k_zge_hn, dim3((unsigned)chunks), dim3(256), (size_t)cb * GEZ_ROWS * sizeof(double2), st, n, d2(const_cast<double *>(Ad)), ra, d2(const_cast<double *>(Bd)), cb, d2(Pd.p));
+    hipLaunchKernelGGL(k_zge_hn_reduce, dim3((unsigned)((ra * cb + 255) / 256)), dim3(256), 0, st, chunks, ra, cb, d2(Pd.p), d2(Cd.p));
+    HIP_OK(hipMemcpyAsync(C.data(), Cd.p, sizeof(cplx) * ra * cb, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+  };
+  // Out = beta Y + alpha A S (S: ra x cb row-major on the host); ra is cut so that the coefficient tile fits 64 KB of LDS
+  auto mul = [&](const double *Ad, int ra, const std::vector<cplx> &Sm, int cb, double alpha, double beta, const double *Yd, double *Outd) {
+    const int step = std::max(1, 4000 / cb);
+    for (int r0 = 0; r0 < ra || r0 == 0; r0 += step) {
+      const int rr = std::min(step, ra - r0);
+      if (rr <= 0) break;
+      HIP_OK(hipMemcpyAsync(small_d.p, Sm.data() + (size_t)r0 * cb, sizeof(cplx) * rr * cb, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_zge_mul, grow, dim3(256), (size_t)rr * cb * sizeof(double2), st, n, d2(const_cast<double *>(Ad)) + (size_t)r0 * nn, rr, d2(small_d.p), cb, alpha, r0 == 0 ? beta : 1.0, d2(const_cast<double *>(r0 == 0 ? Yd : Outd)), d2(Outd));
+      HIP_OK(hipStreamSynchronize(st)); // small_d is reused; Sm may be a temporary
+    }
+  };
+  // CholQR (twice) of the cols columns of Rd in place, columns that depend on the others dropped: Rd <- Q (n x nk), Rm (nk x cols, row-major)
+  // with (old R) = Q Rm; returns nk
+  auto cholqr = [&](double *Rd, int cols, std::vector<cplx> &Rm) {
+    std::vector<cplx> Racc; // product of the passes
+    int               c0 = cols;
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<cplx> G;
+      hn(Rd, cols, Rd, cols, G); // Hermitian positive semi-definite
+      std::vector<int>  kept;
+      std::vector<cplx> L((size_t)cols * cols, cplx(0));
+      for (int j = 0; j < cols; ++j) {
+        double dj = G[(size_t)j * cols + j].real();
+        for (int k : kept) dj -= std::norm(L[(size_t)j * cols + k]);
+        if (!(dj > 1e-20 * std::max(G[(size_t)j * cols + j].real(), 1e-300))) continue;
+        dj = std::sqrt(dj);
+        L[(size_t)j * cols + j] = dj;
+        for (int i = j + 1; i < cols; ++i) {
+          cplx v = G[(size_t)i * cols + j];
+          for (int k : kept) v -= L[(size_t)i * cols + k] * std::conj(L[(size_t)j * cols + k]);
+          L[(size_t)i * cols + j] = v / dj;
+        }
+        kept.push_back(j);
+      }
+      const int nk = (int)kept.size();
+      if (nk == 0) return 0;
+      // G(i, j) = r_i^H r_j = (L L^H)(i, j) with the L just computed; C = L restricted to the kept rows / columns.  Q = R_kept C^{-H}:
+      // q_a = sum_b r_{k_b} conj(Cinv(a, b));  old R = Q C^H: r_j = sum_a q_a conj(L(j, k_a)) for EVERY column j (the dropped ones lie
+      // in the span).  Below Lk = conj(C), so Linv = conj(Cinv) is the coefficient matrix itself.
+      std::vector<cplx> Lk((size_t)nk * nk, cplx(0)), Linv((size_t)nk * nk, cplx(0)), U((size_t)cols * nk, cplx(0)), Rp((size_t)nk * cols, cplx(0));
+      for (int a2 = 0; a2 < nk; ++a2)
+        for (int b2 = 0; b2 <= a2; ++b2) Lk[(size_t)a2 * nk + b2] = std::conj(L[(size_t)kept[a2] * cols + kept[b2]]);
+      for (int c = 0; c < nk; ++c) { // Linv = Lk^{-1}
+        Linv[(size_t)c * nk + c] = 1.0 / Lk[(size_t)c * nk + c];
+        for (int r = c + 1; r < nk; ++r) {
+          cplx v(0);
+          for (int k = c; k < r; ++k) v -= Lk[(size_t)r * nk + k] * Linv[(size_t)k * nk + c];
+          Linv[(size_t)r * nk + c] = v / Lk[(size_t)r * nk + r];
+        }
+      }
+      for (int a2 = 0; a2 < nk; ++a2)
+        for (int b2 = 0; b2 <= a2; ++b2) U[(size_t)kept[b2] * nk + a2] = Linv[(size_t)a2 * nk + b2];
+      for (int a2 = 0; a2 < nk; ++a2)
+        for (int j = 0; j < cols; ++j) Rp[(size_t)a2 * cols + j] = std::conj(L[(size_t)j * cols + kept[a2]]);
+      mul(Rd, cols, U, nk, 1.0, 0.0, nullptr, T2d.p);
+      HIP_OK(hipMemcpyAsync(Rd, T2d.p, sizeof(cplx) * nn * nk, hipMemcpyDeviceToDevice, st));
+      if (pass == 0) Racc = Rp;
+      else { // Racc <- Rp (nk x cols) Racc (cols x c0)
+        std::vector<cplx> N2((size_t)nk * c0, cplx(0));
+        for (int a2 = 0; a2 < nk; ++a2)
+          for (int k = 0; k < cols; ++k)
+            for (int j = 0; j < c0; ++j) N2[(size_t)a2 * c0 + j] += Rp[(size_t)a2 * cols + k] * Racc[(size_t)k * c0 + j];
+        Racc.swap(N2);
+      }
+      cols = nk;
+    }
+    Rm = Racc;
+    return cols;
+  };
+  // ---- start block: OP applied to a random block ----
+  std::mt19937                           gen(12345 + 31 * (first + s));
+  std::uniform_real_distribution<double> dis(-1.0, 1.0);
+  {
+    std::vector<double> V0(2 * nn * p);
+    for (auto &v : V0) v = dis(gen);
+    HIP_OK(hipMemcpyAsync(Vd.p, V0.data(), sizeof(double) * 2 * nn * p, hipMemcpyHostToDevice, st));
+    op(Vd.p, T2d.p, p);
+    HIP_OK(hipMemcpyAsync(Vd.p, T2d.p, sizeof(double) * 2 * nn * p, hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+  }
+  std::vector<cplx> Rm;
+  int               cur = cholqr(Vd.p, p, Rm);
+  HH_CHECK(cur > 0, "SolveGEVP: B vanishes on this subdomain (no overlap, or an empty right-hand side matrix)");
+  const int         hmax = kmax + p;
+  std::vector<cplx> H((size_t)hmax * hmax, cplx(0)); // row-major, ld hmax
+  std::vector<cplx> lam, Ysel;                       // kept eigenvalues; their Ritz coefficient vectors (dim x want, row-major)
+  int  dim = 0, it = 0, nwant = 0, rr_dim = 0;
+  bool converged = false;
+  HIP_OK(hipMemcpyAsync(Qd.p, Vd.p, sizeof(cplx) * nn * cur, hipMemcpyDeviceToDevice, st));
+  while (cur > 0 && dim + cur <= kmax) {
+    const int j0 = dim;
+    dim += cur; // the block Q(:, j0 : dim) is in place
+    double *Wj = Vd.p;
+    op(Qd.p + 2 * nn * j0, Wj, cur);
+    ++it;
+    // H(0:dim, j0:dim) = Q^H W, W -= Q H, twice (classical block Gram-Schmidt with re-orthogonalisation)
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<cplx> C;
+      hn(Qd.p, dim, Wj, cur, C);
+      for (int i = 0; i < dim; ++i)
+        for (int c = 0; c < cur; ++c) H[(size_t)i * hmax + j0 + c] += C[(size_t)i * cur + c];
+      mul(Qd.p, dim, C, cur, -1.0, 1.0, Wj, Wj);
+    }
+    const int prev = cur;
+    cur            = cholqr(Wj, prev, Rm); // W = Q_next Rm
+    for (int a2 = 0; a2 < cur; ++a2)
+      for (int c = 0; c < prev; ++c) H[(size_t)(dim + a2) * hmax + j0 + c] = Rm[(size_t)a2 * prev + c];
+    if (cur > 0) HIP_OK(hipMemcpyAsync(Qd.p + 2 * nn * dim, Wj, sizeof(cplx) * nn * cur, hipMemcpyDeviceToDevice, st));
+    // ---- Rayleigh-Ritz on H(0:dim, 0:dim) once the space can hold the wanted pairs (then every other block, and at the end) ----
+    const bool last = cur == 0 || dim + cur > kmax;
+    if ((dim >= std::min(n, nu + p) && (it % 2 == 0 || dim <= nu + 2 * p)) || last) {
+      std::vector<cplx> Hs((size_t)dim * dim), th, Yv;
+      for (int i = 0; i < dim; ++i)
+        for (int c = 0; c < dim; ++c) Hs[(size_t)i * dim + c] = H[(size_t)i * hmax + c];
+      HH_CHECK(dense_eig_z(dim, Hs, th, Yv), "SolveGEVP: the QR iteration of the Rayleigh-Ritz problem did not converge");
+      std::vector<int> order(dim);
+      for (int i = 0; i < dim; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return std::abs(th[l]) > std::abs(th[r]); }); // largest |theta| = lambda closest to -sigma
+      const int want = std::min(nu, dim);
+      double    worst = 0.0;
+      lam.assign(want, cplx(0));
+      Ysel.assign((size_t)dim * want, cplx(0));
+      for (int c = 0; c < want; ++c) {
+        const int e = order[c];
+        lam[c]      = 1.0 / th[e] - sigma;
+        for (int i = 0; i < dim; ++i) Ysel[(size_t)i * want + c] = Yv[(size_t)i * dim + e];
+        // OP Q y - theta Q y = Q_next (R y_last): Q_next orthonormal, |y| = 1
+        double r2 = 0.0;
+        for (int a2 = 0; a2 < cur; ++a2) {
+          cplx t(0);
+          for (int q = 0; q < prev; ++q) t += H[(size_t)(dim + a2) * hmax + j0 + q] * Yv[(size_t)(j0 + q) * dim + e];
+          r2 += std::norm(t);
+        }
+        worst = std::max(worst, std::sqrt(r2) / std::max(std::abs(th[e]), 1e-300));
+      }
+      nwant  = want;
+      rr_dim = dim;
+      if (want == std::min(nu, n) && worst < tol) {
+        converged = true;
+        break;
+      }
+    }
+  }
+  HH_CHECK(nwant > 0, "SolveGEVP: no Ritz pair was computed");
+  if (!converged) fprintf(stderr, "GenEO subdomain %d: eigensolver stopped at basis size %d without reaching tol %.1e\n", first + s, dim, tol);
+  // ---- order by modulus of lambda, select, Ritz vectors X = Q Y (unit Euclidean norm: |y| = 1, Q orthonormal) ----
+  std::vector<int> ord(nwant);
+  for (int i = 0; i < nwant; ++i) ord[i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int l, int r) { return std::abs(lam[l]) < std::abs(lam[r]); });
+  int keep = nwant;
+  if (threshold > 0.0) { // Eigensolver::selectNu: upper_bound on the REAL parts from the second value on (at least one is kept)
+    keep = 1;
+    while (keep < nwant && lam[ord[keep]].real() <= threshold) ++keep;
+  }
+  std::vector<cplx> X(nn * keep);
+  Xd.alloc(2 * nn * std::max(keep, 1));
+  for (int c0 = 0; c0 < keep; c0 += 8) {
+    const int         cc = std::min(8, keep - c0);
+    std::vector<cplx> Sel((size_t)rr_dim * cc);
+    for (int c = 0; c < cc; ++c)
+      for (int i = 0; i < rr_dim; ++i) Sel[(size_t)i * cc + c] = Ysel[(size_t)i * nwant + ord[c0 + c]];
+    mul(Qd.p, rr_dim, Sel, cc, 1.0, 0.0, nullptr, Xd.p + 2 * nn * c0);
+  }
+  HIP_OK(hipMemcpyAsync(X.data(), Xd.p, sizeof(cplx) * nn * keep, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  set_vectors_z(s, keep, reinterpret_cast<const double *>(X.data()));
+  opt["geneo_nu"] = keep; // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705)
+  S.eigenvalues.resize(keep), S.eigenvalues_im.resize(keep);
+  for (int c = 0; c < keep; ++c) S.eigenvalues[c] = lam[ord[c]].real(), S.eigenvalues_im[c] = lam[ord[c]].imag();
+  S.gevp_iterations = it;
+  coarse_ready      = false;
+  if (getopt("verbosity", 0) >= 2) printf("GenEO subdomain %d: %d complex vectors, |lambda| in [%.3e, %.3e], %d block-Arnoldi steps (basis %d)\n", first + s, keep, std::abs(lam[ord[0]]), std::abs(lam[ord[keep - 1]]), it, dim);
 }
 
 } // namespace hpddm_hip

@@ -40,7 +40,8 @@ struct SchwarzSub {
   std::vector<double> Z;                             // Preconditioner::ev_: n x nu column-major
   int                 nu = 0;
   bool                zpairs = false; // complex operators: the columns of Z are pairs (z_k, i z_k) (set_vectors_z)
-  std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B)
+  std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B) (complex operators: their real parts, eigenvalues_im beside)
+  std::vector<double> eigenvalues_im;
   int                 gevp_iterations = 0;
   std::unique_ptr<LocalSolver> ls;
   // complex128 operators (Schwarz::is_complex): everything above is the real-equivalent embedding, n = 2 x (complex rows) -- the
@@ -165,7 +166,10 @@ struct Schwarz {
   void multiplicity_scaling(double *const *d);
   void initialize(int s, const double *d);
   void set_vectors(int s, int nu, const double *Z);
-  void solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base); // geneo.hip
+  // geneo.hip; (uia, uja, ua): the optional right-hand side matrix B of solveGEVP(A, B), null = scaleIntoOverlap(A)
+  void solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia = nullptr, const int *uja = nullptr, const double *ua = nullptr, bool usym = false, int ubase = 0);
+  // K = std::complex<double> (n complex rows, (re, im) pairs): general complex pencil, block Arnoldi on (A + sigma B)^{-1} B
+  void solve_gevp_z(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia = nullptr, const int *uja = nullptr, const double *ua = nullptr, bool usym = false, int ubase = 0);
   void build_device();           // uploads matrices, d, halo lists (lazy)
   void call_numfact();
   void build_coarse();

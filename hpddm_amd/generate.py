@@ -491,3 +491,60 @@ def generate_elasticity3d(N, parts, overlap=1, sym=True, first=0, count=None, gr
             sub["ia_neumann"], sub["ja_neumann"], sub["a_neumann"] = ian, jan, an
         subs.append(sub)
     return subs
+
+
+def generate_helmholtz3d(dims, parts, wavenumber=2.0 * PI * 8.0, h=None, overlap=1, first=0, count=None, grid=None, brick=None, normalize=True, numbering="C"):
+    """BASELINE.json configs[4]: ``-Laplace(u) - k^2 u`` with k = 2 pi 8 on ``dims`` cells of spacing ``h`` (default
+    1 / max(dims): the unit cube for a cubic grid), FIRST-ORDER ABSORBING condition ``du/dn = i k u`` on the boundary of the domain --
+    complex symmetric, indefinite, no volumetric damping.  Cell-centred 7-point stencil like :func:`generate3d`; the ghost value of a
+    boundary face is eliminated through ``u_g = (1 + i k h) u_b``, i.e. the diagonal loses ``(1 + i k h) / h^2`` per boundary face.
+
+    Per subdomain, beside the keys of :func:`generate3d` (``a`` complex, full storage, ``sym`` False):
+
+    * ``a`` -- the restriction of the global matrix to the grown box (what GMV and the coarse operator use: truncated stencil on the
+      artificial interfaces, absorbing term on the physical boundary);
+    * ``a_opt`` -- the optimised local matrix of ORAS (``callNumfact(A_opt)``, include/HPDDM_schwarz.hpp:337-366): the same first-order
+      impedance condition on the ARTIFICIAL interfaces of the box (diagonal minus ``(1 + i k h) / h^2`` per interface face);
+    * ``a_neumann`` -- the local Neumann matrix of the DtN eigenproblem: homogeneous Neumann on the artificial interfaces (diagonal minus
+      ``1 / h^2`` per interface face), absorbing term on the physical boundary;
+    * ``b_dtn = (ia, ja, a)`` -- the right-hand side matrix of ``solveGEVP(A, B)`` (include/HPDDM_schwarz.hpp:665-666: the slot a DtN coarse
+      space fills; the standalone reference has no DtN code): the lumped mass matrix of the artificial interface in the scaling of the
+      finite-difference operator, ``faces / h`` on the cells that touch it, nothing elsewhere.  Eigenvalues of ``(a_neumann, b_dtn)``
+      are then Dirichlet-to-Neumann eigenvalues in units of the wavenumber (the classical criterion keeps ``Re(lambda) < k``);
+    * ``f`` is NOT set (configs[4] draws 8 random right-hand sides); ``wavenumber``, ``h``.
+    """
+    dims = (dims, dims, dims) if np.isscalar(dims) else tuple(dims)
+    h = 1.0 / max(dims) if h is None else float(h)
+    k = float(wavenumber)
+    ih2 = 1.0 / (h * h)
+    out = []
+    for sd in generate3d(dims, parts, overlap=overlap, sym=False, numbering=numbering, rhs="ones", first=first, count=count, grid=grid, normalize=normalize, brick=brick):
+        sd = dict(sd)
+        F = 1 if numbering == "F" else 0
+        n = sd["n"]
+        i0, i1, j0, j1, k0, k1 = sd["box"]
+        nx, ny, nz = i1 - i0, j1 - j0, k1 - k0
+        phys = np.zeros((nz, ny, nx))    # faces of a cell on the physical boundary
+        artf = np.zeros((nz, ny, nx))    # faces of a cell on an artificial interface of the grown box
+        for axis, (lo, hi), dim in ((2, (i0, i1), dims[0]), (1, (j0, j1), dims[1]), (0, (k0, k1), dims[2])):
+            sl_lo, sl_hi = [slice(None)] * 3, [slice(None)] * 3
+            sl_lo[axis], sl_hi[axis] = 0, -1
+            (phys if lo == 0 else artf)[tuple(sl_lo)] += 1.0
+            (phys if hi == dim else artf)[tuple(sl_hi)] += 1.0
+        phys, artf = phys.reshape(-1), artf.reshape(-1)
+        rows = np.repeat(np.arange(n), np.diff(sd["ia"]))
+        diag = rows == (sd["ja"] - F)
+        a = np.full(sd["ja"].size, -ih2, dtype=np.complex128)
+        absorb = (1.0 + 1j * k * h) * ih2
+        a[diag] = 6.0 * ih2 - k * k - absorb * phys
+        a_opt, a_neu = a.copy(), a.copy()
+        a_opt[diag] -= absorb * artf
+        a_neu[diag] -= ih2 * artf
+        on = np.flatnonzero(artf > 0)
+        bia = np.zeros(n + 1, dtype=np.int64)
+        bia[on + 1] = 1
+        sd.update(a=a, a_opt=a_opt, a_neumann=a_neu, sym=False, wavenumber=k, h=h,
+                  b_dtn=((np.cumsum(bia) + F).astype(np.int32), (on + F).astype(np.int32), (artf[on] / h).astype(np.complex128)))
+        sd.pop("f", None)
+        out.append(sd)
+    return out

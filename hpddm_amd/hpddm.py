@@ -210,12 +210,30 @@ class Schwarz:
         setter = self._lib.HpddmHipSchwarzSetVectorsZ if self.complex else self._lib.HpddmHipSchwarzSetVectors
         check(setter(self._h, s, Z.shape[1], _dptr(Z)))
 
-    def solve_gevp(self, s, n, ia, ja, a, sym, numbering="C"):
-        """schwarzSolveGEVP(A, MatNeumann) (interface/hpddm.py:244): GenEO vectors of local subdomain s; returns the eigenvalues."""
+    def solve_gevp(self, s, n, ia, ja, a, sym, numbering="C", B=None):
+        """schwarzSolveGEVP(A, MatNeumann) (interface/hpddm.py:244): GenEO vectors of local subdomain s; returns the eigenvalues.
+        B = (ia, ja, a, sym): the right-hand side matrix of Schwarz::solveGEVP(A, B) (default: scaleIntoOverlap(A)); complex operators
+        take complex matrices and return complex eigenvalues (smallest modulus first)."""
         ia = np.ascontiguousarray(ia, dtype=np.int32)
         ja = np.ascontiguousarray(ja, dtype=np.int32)
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        check(self._lib.HpddmHipSchwarzSolveGEVP(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
+        dt = np.complex128 if self.complex else np.float64
+        a = np.ascontiguousarray(a, dtype=dt)
+        if B is None and not self.complex:
+            check(self._lib.HpddmHipSchwarzSolveGEVP(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode()))
+        else:
+            bia = bja = ba = None
+            bsym = 0
+            if B is not None:
+                bia, bja = np.ascontiguousarray(B[0], dtype=np.int32), np.ascontiguousarray(B[1], dtype=np.int32)
+                ba, bsym = np.ascontiguousarray(B[2], dtype=dt), int(bool(B[3]))
+            check(self._lib.HpddmHipSchwarzSolveGEVPWith(self._h, s, int(n), _dptr(ia), _dptr(ja), _dptr(a), int(bool(sym)), numbering.encode(),
+                                                         _dptr(bia) if B is not None else None, _dptr(bja) if B is not None else None,
+                                                         _dptr(ba) if B is not None else None, bsym))
+        if self.complex:
+            k = self._lib.HpddmHipSchwarzGetEigenvaluesZ(self._h, s, None, 0)
+            ev = np.zeros(max(k, 1), dtype=np.complex128)
+            self._lib.HpddmHipSchwarzGetEigenvaluesZ(self._h, s, _dptr(ev), k)
+            return ev[:k]
         k = self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, None, 0)
         ev = np.zeros(max(k, 1))
         self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)

@@ -115,6 +115,8 @@ int HpddmHipSchwarzDestroyRecycling(HpddmHipSchwarz *A);
  * imaginary parts of its vector in columns j and j+1.  This is what GCRO-DR's harmonic Ritz problems go through
  * (the reference calls LAPACK's hseqr/hsein and ggev, include/HPDDM_GCRODR.hpp:262-303, 384-392). */
 int HpddmHipDenseEig(int n, const double *A, double *wr, double *wi, double *V);
+/* the same for a complex matrix: A, V n x n row-major (re, im) pairs, w n pairs; unit eigenvectors in the columns of V */
+int HpddmHipDenseEigZ(int n, const double *A, double *w, double *V);
 /* Utility: host-only self-test of the small dense helpers behind GCRO-DR / Block GCRO-DR (Householder QR, triangular inverse, ordering
  * of the Ritz values for every -hpddm_recycle_target, selection of the vectors with whole and cut complex pairs) and of the real-equivalent
  * embedding of complex subdomain matrices and deflation vectors: 0 if all pass, else the number of the first failing check */
@@ -125,6 +127,16 @@ int HpddmHipHostSelfTest(void);
  * Replaces SetVectors.  The reference runs ARPACK in shift-invert mode on the local Solver; here a shift-invert
  * subspace iteration whose solves are the HIP SpTRSV. */
 int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering);
+/* Schwarz::solveGEVP(A, B) with the caller's right-hand side matrix B (include/HPDDM_schwarz.hpp:665-680; bia == NULL: B =
+ * scaleIntoOverlap(A) as above), for real AND complex operators (K = std::complex<double>: n complex rows, `a` / `ba` hold (re, im)
+ * pairs, sym / bsym = lower triangle of a complex SYMMETRIC matrix).  Complex pencils are general: block Arnoldi on
+ * (A + sigma B)^{-1} B (the reference: ARPACK znaupd, shift-invert, include/HPDDM_ARPACK.hpp:84-148), the -hpddm_geneo_nu eigenvalues
+ * of smallest modulus, ordered by modulus, kept while their REAL part is below -hpddm_geneo_threshold when that is set
+ * (Eigensolver::selectNu).  This is the slot a DtN coarse space for Helmholtz fills: A = the local Neumann / absorbing matrix, B = the
+ * interface mass matrix.  Same numbering for both matrices. */
+int HpddmHipSchwarzSolveGEVPWith(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, const int *bia, const int *bja, const double *ba, int bsym);
+/* complex operators: the eigenvalues kept for subdomain s as (re, im) pairs (returns their number; capacity in pairs) */
+int HpddmHipSchwarzGetEigenvaluesZ(HpddmHipSchwarz *A, int s, double *out, int capacity);
 /* eigenvalues kept for subdomain s (returns their number; out may be NULL) */
 int HpddmHipSchwarzGetEigenvalues(HpddmHipSchwarz *A, int s, double *out, int capacity);
 /* HpddmSchwarzBuildCoarseOperator (HPDDM.h:108, Preconditioner::buildTwo include/HPDDM_preconditioner.hpp:124-257):

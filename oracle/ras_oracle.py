@@ -148,6 +148,23 @@ class Oracle:
         self.set_vectors(Z)
         return lams
 
+    def geneo_z(self, neumann, nu, B=None, shift=1.0e-2):
+        """K = std::complex<double>: solveGEVP(A, B) is templated on K; ARPACK's znaupd in shift-invert mode (include/HPDDM_ARPACK.hpp:62,
+        84-148: mode 3, "LM" of the inverse = the eigenvalues closest to the shift) -- scipy's eigs is that routine.  B: list of matrices
+        (the caller's right-hand side, e.g. the interface mass matrix of a DtN coarse space) or None = scaleIntoOverlap.  The values come
+        back ordered by modulus, like the device eigensolver orders them."""
+        lams, Z = [], []
+        for s in range(self.P):
+            AN = sp.csr_matrix(neumann[s]).astype(np.complex128)
+            Bs = self.scale_into_overlap(s, AN) if B is None else sp.csr_matrix(B[s]).astype(np.complex128)
+            k = min(nu, max(1, self.subs[s]["n"] // 4))
+            w, v = spl.eigs(AN.tocsc(), k=k, M=Bs.tocsc(), sigma=-shift, which="LM", tol=1e-12, v0=np.ones(AN.shape[0], dtype=np.complex128))
+            order = np.argsort(np.abs(w), kind="stable")
+            lams.append(w[order])
+            Z.append(v[:, order])
+        self.set_vectors(Z)
+        return lams
+
     def build_coarse(self, symmetric=None, lapacktr=True):
         """E = Z^H A Z by neighbour products (MatrixMultiplication, include/HPDDM_operator.hpp:378-562): block (i, j) =
         Z_i^H D_i (A_j D_j Z_j) on the shared unknowns.  symmetric=None: 'S' for real scalars, 'G' for complex ones

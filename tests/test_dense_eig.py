@@ -57,3 +57,42 @@ def test_host_helpers_of_the_recycling_methods():
     complex pairs) used by GCRO-DR / Block GCRO-DR, and the real-equivalent embedding of complex matrices and deflation vectors against
     complex arithmetic: the library's own host self-test"""
     assert _lib.load().HpddmHipHostSelfTest() == 0
+
+
+def _eig_z(A):
+    L = _lib.load()
+    n = A.shape[0]
+    A = np.ascontiguousarray(A, dtype=np.complex128)
+    w, V = np.zeros(n, dtype=np.complex128), np.zeros((n, n), dtype=np.complex128)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert L.HpddmHipDenseEigZ(n, p(A), p(w), p(V)) == 0
+    return w, V
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 13, 24, 60, 150])
+def test_complex_eigenpairs(n):
+    """the Rayleigh-Ritz problems of the complex GenEO eigensolver: general complex, complex symmetric, block Hessenberg, Hermitian"""
+    rng = np.random.default_rng(300 + n)
+    for trial in range(8 if n < 100 else 2):
+        A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        if trial % 4 == 1:
+            A = A + A.T                 # complex symmetric (the pencils of a Helmholtz subdomain)
+        elif trial % 4 == 2:
+            A = np.triu(A, -4)          # block upper Hessenberg (block Arnoldi with 4 columns)
+        elif trial % 4 == 3:
+            A = A + A.conj().T          # Hermitian: real spectrum
+        lam, V = _eig_z(A)
+        assert np.abs(A @ V - V * lam).max() <= 1e-9 * max(1.0, np.abs(A).max()) * n
+        assert np.allclose(np.linalg.norm(V, axis=0), 1.0)
+        ref = np.linalg.eigvals(A)
+        assert max(np.min(np.abs(ref - l)) for l in lam) <= 1e-8 * max(1.0, np.abs(ref).max())
+        assert max(np.min(np.abs(lam - r)) for r in ref) <= 1e-8 * max(1.0, np.abs(ref).max())
+
+
+def test_complex_degenerate_matrices():
+    lam, V = _eig_z(np.zeros((3, 3)))
+    assert np.all(lam == 0) and np.allclose(V, np.eye(3))
+    lam, V = _eig_z(np.diag([1 + 1j, 1 + 1j, 2.0]))      # a double eigenvalue with two vectors
+    assert np.allclose(sorted(lam, key=lambda x: x.real), [1 + 1j, 1 + 1j, 2.0])
+    lam, V = _eig_z(np.diag(np.ones(3), 1) + (2.0 - 1j) * np.eye(4))   # one Jordan block
+    assert np.allclose(lam, 2.0 - 1j, atol=1e-3)
