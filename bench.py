@@ -110,13 +110,15 @@ def main():
     dev = torch.device("cuda", local)
 
     from hpddm_amd import _lib, hpddm
-    from hpddm_amd.generate import generate3d, generate_elasticity3d
+    from hpddm_amd.generate import generate3d, generate_elasticity3d, generate_helmholtz3d
 
     def generate(dims, parts, **kw):
         tg0 = time.time()
         try:
             if args.problem == "helmholtz":
-                return generate_helmholtz(np, generate3d, dims, parts, **kw)
+                for key in ("rhs", "neumann"):
+                    kw.pop(key, None)
+                return generate_helmholtz3d(dims, parts, **kw)
             if args.problem == "elasticity":
                 kw.pop("rhs", None)
                 kw.setdefault("normalize", True)
@@ -142,14 +144,14 @@ def main():
             c1 = {"error": repr(e)}
     helm = args.problem == "helmholtz"
     two_level = not args.no_two_level
-    geneo = two_level and not args.no_geneo and not helm   # helmholtz: the coarse space is user-supplied (plane waves)
+    geneo = two_level and not args.no_geneo and not helm   # helmholtz: the eigenproblem is the DtN one (two_level_setup)
     mu = args.mu
 
     # ---- build the operator (one-time: generator, analysis, factorisation, upload) ----
     t0 = time.time()
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     want_cpu = want_cpu and not helm               # the CPU port is real arithmetic
-    opts = ("" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
+    opts = ("-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
     sharded = world > 1 and not args.replicas
     peers_hist = None
     if sharded:
@@ -181,9 +183,12 @@ def main():
             A.enable_rccl(box[0], mu_cap=cap)
     else:
         dims = (args.n, args.n, 2 * args.n) if helm else (args.n, args.n, args.n)
-        subs = generate(dims if helm else args.n, args.subdomains, rhs="smooth", neumann=geneo, **({"grid": (2, 2, 2)} if helm else {}))
-        A, d = hpddm.schwarz_from_subdomains(subs, options=opts, multiplicity=args.problem != "elasticity")
+        subs = generate(dims if helm else args.n, args.subdomains, rhs="smooth", neumann=geneo, **({"grid": (2, 2, 2), "normalize": True} if helm else {}))
+        A, d = hpddm.schwarz_from_subdomains(subs, options=opts, multiplicity=args.problem == "poisson")
     t_gen = getattr(generate, "seconds", 0.0)   # the synthetic matrices (numpy): test infrastructure, not part of the set-up of the operator
+    if helm:   # ORAS: callNumfact(A_opt) with the impedance matrices of the subdomains (include/HPDDM_schwarz.hpp:337-366)
+        for s_, sd in enumerate(subs):
+            A.set_optimized_matrix(s_, sd["n"], sd["ia"], sd["ja"], sd["a_opt"], False)
     A.call_numfact()
     t_setup = time.time() - t0 - t_gen
     # of which: the plain factor kept for the CPU baseline leg (-hpddm_keep_plain: every front copied off the device before it is
@@ -200,9 +205,9 @@ def main():
     reps = max(5, min(50, args.steps))
 
     def fvec(cols=1):
-        if helm:   # consistent random complex right-hand sides (mt19937-style seed 42, uniform re / im), made so by one exchange
-            rng = np.random.default_rng(42)
-            rhs = A.exchange([rng.random((s["n"], cols)) + 1j * rng.random((s["n"], cols)) for s in subs])
+        if helm:   # random complex right-hand sides from mt19937(seed = 42 + rank), uniform(0, 1) re / im, made consistent by one exchange
+            rng = np.random.RandomState(42 + rank)
+            rhs = A.exchange([rng.random_sample((s["n"], cols)) + 1j * rng.random_sample((s["n"], cols)) for s in subs])
             return torch.from_numpy(A.pack(rhs)[0]).to(dev)
         return torch.from_numpy(np.concatenate([s["f"] for s in subs])).to(dev)
 
@@ -303,10 +308,10 @@ def main():
             if sharded:
                 wl = f"BASELINE.json configs[2]-like on {world} GPUs: 3-D Poisson, ONE global problem of {gdims} cells, "
         elif helm:
-            kind = f"two-level RAS + plane-wave coarse space (3 per subdomain, deflated), Block GMRES on {mu} right-hand sides" if two_level else "one-level RAS"
-            wl = f"BASELINE.json configs[4] per-GPU share: Helmholtz-like 3-D complex<double> shifted Laplacian, {args.n}x{args.n}x{2 * args.n} cells per GPU, native complex panels, "
+            kind = f"two-level ORAS (impedance local matrices) + DtN coarse space (nu = {args.geneo_nu}, deflated), Block GMRES on {mu} right-hand sides" if two_level else "one-level ORAS"
+            wl = f"BASELINE.json configs[4] per-GPU share: Helmholtz 3-D complex<double> (-Laplace - k^2, k = 2 pi 8, h = 1/128, first-order absorbing boundary), {args.n}x{args.n}x{2 * args.n} cells per GPU, native complex panels, "
             if sharded:
-                wl = (f"BASELINE.json configs[4]{'' if (dims == (128, 128, 128) and world == 4) else '-like'}: Helmholtz-like 3-D complex<double> shifted Laplacian, ONE global problem of {gdims} cells, "
+                wl = (f"BASELINE.json configs[4]{'' if (dims == (128, 128, 128) and world == 4) else '-like'}: Helmholtz 3-D complex<double> (-Laplace - k^2, k = 2 pi 8, first-order absorbing boundary), ONE global problem of {gdims} cells, "
                       f"{8 * world} subdomains on {world} GPUs, native complex panels, ")
         else:
             wl = f"BASELINE.json configs[3] per-GPU share: 3-D linear elasticity (block-3 CSR), {args.n}^3 nodes per GPU, "
@@ -394,15 +399,19 @@ def two_level_setup(A, subs, args, np, geneo):
     tg = time.time()
     lam_max = None
     if args.problem == "helmholtz":
-        # the slot the reference fills with DtN vectors (solveGEVP(A, B) with a user-supplied B, include/HPDDM_schwarz.hpp:665-666):
-        # here a constant and two plane waves per subdomain, as in tests/test_complex.py
+        # DtN coarse space: Schwarz::solveGEVP(A, B) with the caller's B (include/HPDDM_schwarz.hpp:665-666) -- the local Neumann matrix
+        # (absorbing physical boundary) against the mass matrix of the artificial interface; complex block Arnoldi on the device
+        A.set_option("geneo_nu", nu)
+        lam_abs = 0.0
         for s, sd in enumerate(subs):
-            t = np.arange(sd["n"], dtype=np.float64)
-            A.set_vectors(s, np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * s)], axis=1))
+            lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], False, B=sd["b_dtn"] + (False,))
+            lam_abs = max(lam_abs, float(np.abs(lam[-1])))
+        tg = time.time() - tg
         t0 = time.time()
         A.build_coarse_operator()
-        return {"geneo_nu": 3, "coarse_dim": int(A.stats()["coarse_dim"]), "coarse_setup_seconds": round(time.time() - t0, 2), "coarse_space_seconds": round(time.time() - tg, 2),
-                "coarse_space": "constant + two plane waves per subdomain (user-supplied vectors, the DtN slot of the reference)"}
+        return {"geneo_nu": nu, "coarse_dim": int(A.stats()["coarse_dim"]), "coarse_setup_seconds": round(time.time() - t0, 2), "coarse_space_seconds": round(tg, 2),
+                "coarse_space": "DtN: solveGEVP(A_Neumann, B_interface) on the device (complex block Arnoldi, shift-invert on the complex SpTRSV), "
+                                "%d vectors per subdomain, largest kept |lambda| %.3f (wavenumber %.3f)" % (nu, lam_abs, subs[0]["wavenumber"])}
     for s, sd in enumerate(subs):
         if geneo:
             A.set_option("geneo_nu", nu)
@@ -494,21 +503,6 @@ def configs_1(np, torch, dev, args):
            "gmres": {"iterations": it, "seconds": tg, "iters_per_sec": it / tg, "tol": 1e-6}}
     A.destroy()
     return out
-
-
-def generate_helmholtz(np, generate3d, dims, parts, **kw):
-    """complex symmetric shifted Laplacian with absorption: the 7-point stencil of generate3d with the diagonal times 0.97 + 0.03i
-    (k h = 0.42, about 15 points per wavelength), full storage"""
-    kw.pop("neumann", None)
-    subs = []
-    for sd in generate3d(dims, parts, overlap=1, sym=False, **kw):
-        sd = dict(sd)
-        a = sd["a"].astype(np.complex128)
-        rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
-        a[rows == sd["ja"]] *= 0.97 + 0.03j
-        sd["a"] = a
-        subs.append(sd)
-    return subs
 
 
 def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level applies/s of the device path

@@ -390,9 +390,8 @@ void HpddmSchwarzSolveGEVP(HpddmSchwarz *S, HpddmMatrixCSR *N)
 {
   sync_options(S);
 #ifdef FORCE_COMPLEX
-  (void)N;
-  fprintf(stderr, "libhpddm_c_hip_z: HpddmSchwarzSolveGEVP is not available for complex scalars in this build (hand the deflation vectors over with HpddmSetVectors)\n");
-  MPI_Abort(MPI_COMM_WORLD, 1);
+  // Schwarz<K>::solveGEVP for K = std::complex<double> (interface/hpddm_c.cpp:199-203 with B = nullptr: scaleIntoOverlap)
+  CK(HpddmHipSchwarzSolveGEVPWith(S->A, 0, N->n, N->ia, N->ja, dp(N->a), N->sym ? 1 : 0, N->ia[0] == 1 ? 'F' : 'C', nullptr, nullptr, nullptr, 0), "HpddmSchwarzSolveGEVP");
 #else
   CK(HpddmHipSchwarzSolveGEVP(S->A, 0, N->n, N->ia, N->ja, N->a, N->sym ? 1 : 0, N->ia[0] == 1 ? 'F' : 'C'), "HpddmSchwarzSolveGEVP");
 #endif

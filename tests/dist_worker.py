@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from hpddm_amd import hpddm  # noqa: E402
-from hpddm_amd.generate import generate3d, gpu_grid  # noqa: E402
+from hpddm_amd.generate import generate3d, generate_helmholtz3d, gpu_grid  # noqa: E402
 from oracle.ras_oracle import Oracle  # noqa: E402
 
 
@@ -43,18 +43,21 @@ def main():
     cells = 3 if world >= 8 else 4                         # cells per subdomain and direction, before the overlap
     parts, per, dims = 8 * world, 8, tuple(cells * g for g in grid)
     firsts = [r * per for r in range(world + 1)]
-    allsubs = generate3d(dims, parts, overlap=1, sym=not helm, rhs="smooth", grid=grid, brick=(2, 2, 2), normalize=True)
-    if helm:
+    if helm:   # the problem of configs[4] (absorbing boundary, ORAS impedance matrices, DtN pencil), k h = 0.52
+        allsubs = generate_helmholtz3d(dims, parts, wavenumber=0.52 * max(dims), grid=grid, brick=(2, 2, 2))
         for sd in allsubs:
-            a = sd["a"].astype(np.complex128)
-            rows = np.repeat(np.arange(sd["n"]), np.diff(sd["ia"]))
-            a[rows == sd["ja"]] *= 0.97 + 0.03j
-            sd["a"] = a
+            sd["f"] = np.ones(sd["n"])
+    else:
+        allsubs = generate3d(dims, parts, overlap=1, sym=True, rhs="smooth", grid=grid, brick=(2, 2, 2), normalize=True)
     mine = allsubs[firsts[rank]:firsts[rank + 1]]
     orc = Oracle(allsubs)
     orc.d = [s["d"] for s in allsubs]
-    A, d = hpddm.schwarz_from_subdomains(mine, first_global=firsts[rank], nglobal=parts, options="" if helm else "-hpddm_operator_spd", multiplicity=False,
+    A, d = hpddm.schwarz_from_subdomains(mine, first_global=firsts[rank], nglobal=parts, options="-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd", multiplicity=False,
                                          partition=(rank, firsts))
+    if helm:
+        orc.method = "oras"
+        for k, sd in enumerate(mine):
+            A.set_optimized_matrix(k, sd["n"], sd["ia"], sd["ja"], sd["a_opt"], False)
     rng = np.random.default_rng(5)
     mu = 2
     xg = [rng.random((s["n"], mu)) + (1j * rng.random((s["n"], mu)) if helm else 0.0) for s in allsubs]
@@ -139,7 +142,11 @@ def main():
             torch.cuda.set_device(dev)
             A.enable_distributed(dist, dev, mu_cap=4, host_staging=True)
         A.call_numfact()
-        orc.numfact()
+        if helm:
+            import scipy.sparse as sp
+            orc.numfact([sp.csr_matrix((sd["a_opt"], sd["ja"], sd["ia"]), shape=(sd["n"], sd["n"])) for sd in allsubs])
+        else:
+            orc.numfact()
         x = xg[firsts[rank]:firsts[rank + 1]]
         sl = slice(firsts[rank], firsts[rank + 1])
 
@@ -156,14 +163,20 @@ def main():
             # configs[4] in small: complex operator, plane-wave coarse space assembled across the ranks, Block GMRES on the block of
             # right-hand sides (the Gram matrices of the block method are summed over the ranks)
             from oracle import ras_oracle as ro
-            Zg = []
-            for k, sd in enumerate(allsubs):
-                t = np.arange(sd["n"], dtype=np.float64)
-                Zg.append(np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * k)], axis=1))
-            for k in range(per):
-                A.set_vectors(k, Zg[firsts[rank] + k])
+            # DtN coarse space: the complex solveGEVP(A_Neumann, B_interface) of every local subdomain on the device; the oracle takes
+            # ARPACK's vectors of the same pencils (the operators do not depend on the basis: nu = 4 cuts no cluster here -- checked below)
+            nu = 4
+            A.set_option("geneo_nu", nu)
+            A.set_option("eigensolver_tol", 1e-11)
+            mats = lambda key: [sp.csr_matrix((sd[key], sd["ja"], sd["ia"]), shape=(sd["n"], sd["n"])) for sd in allsubs]
+            Bs = [sp.csr_matrix((sd["b_dtn"][2], sd["b_dtn"][1], sd["b_dtn"][0]), shape=(sd["n"], sd["n"])) for sd in allsubs]
+            lam_ref = orc.geneo_z(mats("a_neumann"), nu + 1, B=Bs)
+            orc.set_vectors([z[:, :nu] for z in orc.Z])
+            for k, sd in enumerate(mine):
+                lam = A.solve_gevp(k, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], False, B=sd["b_dtn"] + (False,))
+                ref = lam_ref[firsts[rank] + k]
+                assert np.all(np.abs(lam - ref[:nu]) <= 1e-6 * np.abs(ref[:nu])) and abs(ref[nu]) > (1 + 1e-3) * abs(ref[nu - 1]), (lam, ref)
             A.build_coarse_operator()
-            orc.set_vectors(Zg)
             orc.build_coarse(lapacktr=False)
             A.option_parse("-hpddm_schwarz_coarse_correction deflated -hpddm_krylov_method bgmres -hpddm_gmres_restart 20")
             orc.correction = "deflated"
