@@ -58,6 +58,7 @@ def _declare(lib):
         "HpddmHipSchwarzSetOptimizedMatrixZ": (I, [P, I, I, P, P, P, I, ctypes.c_char]),
         "HpddmHipSchwarzGetEigenvalues": (I, [P, I, P, I]),
         "HpddmHipSchwarzGetEigenvaluesZ": (I, [P, I, P, I]),
+        "HpddmHipSchwarzGetVectors": (I, [P, I, P, ctypes.c_longlong]),
         "HpddmHipSchwarzSolveGEVPWith": (I, [P, I, I, P, P, P, I, ctypes.c_char, P, P, P, I]),
         "HpddmHipSchwarzBuildCoarseOperator": (I, [P]),
         "HpddmHipSchwarzCallNumfact": (I, [P]),

@@ -310,6 +310,21 @@ int HpddmHipSchwarzSolveGEVPWith(HpddmHipSchwarz *A, int s, int n, const int *ia
     else A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F', bia, bja, ba, bsym != 0, numbering == 'F');
     return 0;)
 }
+int HpddmHipSchwarzGetVectors(HpddmHipSchwarz *A, int s, double *out, long long capacity)
+{
+  HH_TRY(
+    HH_CHECK(A && s >= 0 && s < A->op.nsub, "bad subdomain");
+    const SchwarzSub &S = A->op.subs[s];
+    // complex operators: the complex vectors themselves (the even columns of the embedding are (re, im) interleaved already)
+    const bool      z    = A->op.is_complex && S.zpairs;
+    const int       nu   = z ? S.nu / 2 : S.nu;
+    const long long need = (long long)S.n * nu; // doubles: n x nu real, or (n / 2) x nu complex
+    if (out) {
+      HH_CHECK(capacity >= need, "GetVectors: array too small");
+      for (int k = 0; k < nu; ++k) std::copy_n(S.Z.data() + (size_t)(z ? 2 * k : k) * S.n, S.n, out + (size_t)k * S.n);
+    }
+    return nu;)
+}
 int HpddmHipSchwarzGetEigenvaluesZ(HpddmHipSchwarz *A, int s, double *out, int capacity)
 {
   HH_TRY(

@@ -239,6 +239,15 @@ class Schwarz:
         self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)
         return ev[:k]
 
+    def get_vectors(self, s):
+        """getVectors: the deflation vectors of local subdomain s, (n_s, nu)"""
+        nu = self._lib.HpddmHipSchwarzGetVectors(self._h, s, None, 0)
+        n = self.n[s]
+        out = np.zeros(n * max(nu, 1), dtype=np.complex128 if self.complex else np.float64)
+        if self._lib.HpddmHipSchwarzGetVectors(self._h, s, _dptr(out), out.size * (2 if self.complex else 1)) < 0:
+            raise HpddmHipError(self._lib.HpddmHipLastError().decode())
+        return out[:n * nu].reshape(n, nu, order="F")
+
     def set_optimized_matrix(self, s, n, ia, ja, a, sym, numbering="C"):
         """callNumfact(A) of the reference: optimised local matrix of subdomain s for -hpddm_schwarz_method oras / soras / osm"""
         ia = np.ascontiguousarray(ia, dtype=np.int32)

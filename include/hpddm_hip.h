@@ -135,6 +135,9 @@ int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, co
  * (Eigensolver::selectNu).  This is the slot a DtN coarse space for Helmholtz fills: A = the local Neumann / absorbing matrix, B = the
  * interface mass matrix.  Same numbering for both matrices. */
 int HpddmHipSchwarzSolveGEVPWith(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, const int *bia, const int *bja, const double *ba, int bsym);
+/* Preconditioner::getVectors (include/HPDDM_preconditioner.hpp:344-346): the deflation vectors of local subdomain s, column-major n_s x nu
+ * (complex operators: n_s complex rows, (re, im) pairs); returns nu, out may be NULL, capacity in doubles */
+int HpddmHipSchwarzGetVectors(HpddmHipSchwarz *A, int s, double *out, long long capacity);
 /* complex operators: the eigenvalues kept for subdomain s as (re, im) pairs (returns their number; capacity in pairs) */
 int HpddmHipSchwarzGetEigenvaluesZ(HpddmHipSchwarz *A, int s, double *out, int capacity);
 /* eigenvalues kept for subdomain s (returns their number; out may be NULL) */

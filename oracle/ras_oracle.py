@@ -149,16 +149,25 @@ class Oracle:
         return lams
 
     def geneo_z(self, neumann, nu, B=None, shift=1.0e-2):
-        """K = std::complex<double>: solveGEVP(A, B) is templated on K; ARPACK's znaupd in shift-invert mode (include/HPDDM_ARPACK.hpp:62,
-        84-148: mode 3, "LM" of the inverse = the eigenvalues closest to the shift) -- scipy's eigs is that routine.  B: list of matrices
-        (the caller's right-hand side, e.g. the interface mass matrix of a DtN coarse space) or None = scaleIntoOverlap.  The values come
-        back ordered by modulus, like the device eigensolver orders them."""
+        """K = std::complex<double>: solveGEVP(A, B) is templated on K; the reference hands the pencil to ARPACK's znaupd in shift-invert
+        mode (include/HPDDM_ARPACK.hpp:62, 84-148: mode 3, "LM" of OP = (A - sigma B)^{-1} B, i.e. the eigenvalues closest to the shift).
+        Restated with scipy's znaupd on OP ITSELF (standard mode, Euclidean inner product): ARPACK's generalised mode works in the
+        B-inner product, which exists only for a Hermitian positive semi-definite B -- true for the interface mass matrix of a DtN
+        coarse space, not for scaleIntoOverlap(A) of a complex symmetric A (scipy's eigs(..., M=B) returns values that are not
+        eigenvalues of the pencil there; checked against a dense QZ).  Same spectral transformation, same eigenpairs.  ncv is the
+        reference's -hpddm_arpack_ncv, raised to 40: with the default 2 nu + 1 ARPACK leaves the last copy of a multiple eigenvalue
+        (the triples of cubic subdomains) with a residual of 1e-3.  B: list of matrices (the caller's right-hand side) or None =
+        scaleIntoOverlap.  Values ordered by modulus, like the device eigensolver orders them."""
         lams, Z = [], []
         for s in range(self.P):
             AN = sp.csr_matrix(neumann[s]).astype(np.complex128)
-            Bs = self.scale_into_overlap(s, AN) if B is None else sp.csr_matrix(B[s]).astype(np.complex128)
-            k = min(nu, max(1, self.subs[s]["n"] // 4))
-            w, v = spl.eigs(AN.tocsc(), k=k, M=Bs.tocsc(), sigma=-shift, which="LM", tol=1e-12, v0=np.ones(AN.shape[0], dtype=np.complex128))
+            Bs = (self.scale_into_overlap(s, AN) if B is None else sp.csr_matrix(B[s])).astype(np.complex128).tocsr()
+            n = AN.shape[0]
+            k = min(nu, max(1, n // 4))
+            lu = spl.splu((AN + shift * Bs).tocsc())
+            OP = spl.LinearOperator((n, n), matvec=lambda x: lu.solve(Bs @ x), dtype=np.complex128)
+            theta, v = spl.eigs(OP, k=k, which="LM", tol=1e-13, ncv=min(n - 1, max(2 * k + 1, 40)), v0=lu.solve(Bs @ np.ones(n, dtype=np.complex128)))
+            w = 1.0 / theta - shift
             order = np.argsort(np.abs(w), kind="stable")
             lams.append(w[order])
             Z.append(v[:, order])
