@@ -673,6 +673,7 @@ int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup
       else if (w == "gmv") op.gmv(in.p, out.p, mu);
       else if (w == "deflation") op.deflation(in.p, out.p, mu);
       else if (w == "exchange") op.exchange(in.p, out.p, mu, true);
+      else if (w == "halo") op.halo_sum_inplace(out.p, mu); // the in-place sum on the overlap that follows a producer with the scaling at its store
       else HH_CHECK(false, "Time: unknown operation " + w);
     };
     for (int i = 0; i < warmup; ++i) run();

@@ -173,7 +173,7 @@ __global__ void k_zt_reduce(const double *__restrict__ partial, int nblk, const 
 }
 
 // out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu] ; each wavefront produces 64 rows x (<= 16 rhs)
-__global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0, int zc)
+__global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0, int zc, const double *__restrict__ dsc)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
   const long long v0 = voff[s];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int r = i0 + 16 * t + (lane >> 4) + 4 * reg;
-          if (r < n) out[v0 * mu + (long long)(nu0 + m) * n + r] = acc[t][reg];
+          if (r < n) out[v0 * mu + (long long)(nu0 + m) * n + r] = dsc ? dsc[v0 + r] * acc[t][reg] : acc[t][reg];
         }
     }
   }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
 // four products of a step, one 32-byte store per accumulator register writes four rows of a right-hand side.  Steps of 4 vectors
 // (K), all requested before the products; plain column-major Z.
 template <int KS>
-__global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0)
+__global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0, const double *__restrict__ dsc)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = min(4 * KS, nus[s]);
   const long long v0 = voff[s];
@@ -255,13 +255,14 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
         const int ro = i0 + 4 * ((lane >> 4) + 4 * reg);
         double   *o  = out + v0 * mu + (long long)(nu0 + m) * n + ro;
         if (ro + 4 <= n) {
-          dquad q;
+          dquad q, w = {{1.0, 1.0, 1.0, 1.0}};
+          if (dsc) w = *reinterpret_cast<const dquad *>(dsc + v0 + ro); // the partition of unity of the exchange that follows, at the store
 #pragma unroll
-          for (int t = 0; t < 4; ++t) q.v[t] = acc[t][reg];
+          for (int t = 0; t < 4; ++t) q.v[t] = w.v[t] * acc[t][reg];
           *reinterpret_cast<dquad *>(o) = q;
         } else
           for (int t = 0; t < 4; ++t)
-            if (ro + t < n) o[t] = acc[t][reg];
+            if (ro + t < n) o[t] = (dsc ? dsc[v0 + ro + t] : 1.0) * acc[t][reg];
       }
     }
   }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_zt_stream(const long long *__restrict__
 }
 // out[s][nu][i] = sum_k Z_s[i, k] y[coff[s] + k][nu], one thread per row
 template <int MU>
-__global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim, int zc)
+__global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim, int zc, const double *__restrict__ dsc)
 {
   extern __shared__ double ys[]; // [nu_s][MU]
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_z_stream(const long long *__restrict__ 
       for (int nu = 0; nu < MU; ++nu) acc[nu] = fma(z, ys[k * MU + nu], acc[nu]);
     }
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) out[v0 * MU + (long long)nu * n + i] = acc[nu];
+    for (int nu = 0; nu < MU; ++nu) out[v0 * MU + (long long)nu * n + i] = dsc ? dsc[v0 + i] * acc[nu] : acc[nu];
   }
 }
 
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void k_zt_stream2(const long long *__restrict_
   }
 }
 template <int MU, int KMAX>
-__global__ __launch_bounds__(256) void k_z_stream2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim)
+__global__ __launch_bounds__(256) void k_z_stream2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int cdim, const double *__restrict__ dsc)
 {
   __shared__ double ys[KMAX * MU]; // [k][nu]
   const int       s = blockIdx.y, n = nn_[s], nu_s = min(KMAX, nus[s]);
@@ -417,11 +418,12 @@ __global__ __launch_bounds__(256) void k_z_stream2(const long long *__restrict__
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) acc[nu].x = fma(z[k].x, ys[k * MU + nu], acc[nu].x), acc[nu].y = fma(z[k].y, ys[k * MU + nu], acc[nu].y);
       }
+    const dpair w = dsc ? load_pair(dsc + v0 + i, two) : dpair{1.0, 1.0};
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
       double *o = out + v0 * MU + (long long)nu * n + i;
-      if (two) *reinterpret_cast<dpair *>(o) = acc[nu];
-      else o[0] = acc[nu].x;
+      if (two) *reinterpret_cast<dpair *>(o) = dpair{w.x * acc[nu].x, w.y * acc[nu].y};
+      else o[0] = w.x * acc[nu].x;
     }
   }
 }
@@ -480,15 +482,16 @@ void Schwarz::panel_zt(const double *in, double *uc, int mu)
 }
 
 // zy = Z y, y (cdim x mu, column-major): second gemm of Schwarz::deflation (include/HPDDM_schwarz.hpp:1618)
-void Schwarz::panel_z(const double *y, double *zy, int mu)
+void Schwarz::panel_z(const double *y, double *zy, int mu, bool scaled)
 {
+  const double *dsc = scaled ? d_d.p : nullptr; // zy = D Z y: the Wrapper::diag of the exchange that follows, at the store
   hipStream_t st = library_stream();
   int         numax = 0;
   for (const auto &S : subs) numax = std::max(numax, S.nu);
   if (mu <= 2 && getopt("hip_deflation_mfma", 0) == 0) {
     if (!z_compact && numax <= 32 && getopt("hip_deflation_pairs", 1) != 0) {
       const dim3 g((unsigned)std::max(1, std::min(std::max(1, 256 * (int)getopt("hip_deflation_blocks_per_cu", 3) / std::max(1, nsub)), (nmax + 511) / 512)), (unsigned)nsub);
-#define HH_Z2(M, K) hipLaunchKernelGGL((k_z_stream2<M, K>), g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim)
+#define HH_Z2(M, K) hipLaunchKernelGGL((k_z_stream2<M, K>), g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, dsc)
       if (mu == 1) {
         if (numax <= 8) HH_Z2(1, 8);
         else if (numax <= 16) HH_Z2(1, 16);
@@ -505,14 +508,14 @@ void Schwarz::panel_z(const double *y, double *zy, int mu)
     }
     const dim3   g2((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
     const size_t l2 = (size_t)numax * mu * sizeof(double);
-    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
-    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0);
+    if (mu == 1) hipLaunchKernelGGL(k_z_stream<1>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0, dsc);
+    else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0, dsc);
     return;
   }
   if (!z_compact && numax <= 32 && getopt("hip_deflation_zt_direct", 1) != 0) { // 32-byte accesses (k_z_mfma2)
     const dim3 g((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
     for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU) {
-#define HH_ZM2(K) hipLaunchKernelGGL(k_z_mfma2<K>, g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0)
+#define HH_ZM2(K) hipLaunchKernelGGL(k_z_mfma2<K>, g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, dsc)
       if (numax <= 8) HH_ZM2(2);
       else if (numax <= 16) HH_ZM2(4);
       else if (numax <= 24) HH_ZM2(6);
@@ -522,14 +525,14 @@ void Schwarz::panel_z(const double *y, double *zy, int mu)
     return;
   }
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
-    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, z_compact ? 1 : 0);
+    hipLaunchKernelGGL(k_z_mfma, dim3((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, z_compact ? 1 : 0, dsc);
 }
 
-void Schwarz::deflation_panel(const double *in, double *zy, int mu)
+void Schwarz::deflation_panel(const double *in, double *zy, int mu, bool scaled)
 {
   panel_zt(in, uc_d.p, mu);
   coarse_solve(uc_d.p, uc2_d.p, mu);
-  panel_z(uc2_d.p, zy, mu);
+  panel_z(uc2_d.p, zy, mu, scaled);
 }
 
 } // namespace hpddm_hip

@@ -139,6 +139,9 @@ struct SolvePlan {
   // real ones (its real and imaginary planes) and the sweeps run with 2 mu real columns.
   bool cplx = false;
   void solve(const double *b, double *x, int mu, hipStream_t s);
+  // when set: the permutation pass that ends a solve writes out_scale[i] * x[i] (the partition of unity of Schwarz::apply folded into
+  // the last pass: Wrapper::diag, include/HPDDM_wrapper.hpp:820-831); indexed like x (complex factors: per double of the (re, im) pairs)
+  const double *out_scale = nullptr;
   int  launches_per_solve = 0;
   int  groups = 1; // this plan sweeps one of `groups` sets of subdomains that share the GPU (targets of the plan builder scale with it)
   // developer aid (HpddmHipSchwarzLevelTimes): one HIP event after every launch of a solve; tag = kind * 1000 + level,

@@ -64,6 +64,35 @@ __global__ void k_halo_unpack(const long long *__restrict__ voff, const int *__r
   }
 }
 
+// In-place halo sum of a vector that already holds what is to be summed (D x when the producer folded the partition of unity into its
+// store): only the dofs that have a duplicate in a co-located subdomain are touched.  Two passes over that short list -- the sums are
+// formed from the values as they were (own value first, then the neighbours in neighbour order: the order of k_exchange) into tmp, then
+// written back -- instead of one read + one write of the whole vector.
+__global__ void k_halo_ovl_sum(const long long *__restrict__ voff, const int *__restrict__ nn, const int *__restrict__ osub, const int *__restrict__ oidx, int novl, const int *__restrict__ ex_ptr, const int *__restrict__ ex_sub, const int *__restrict__ ex_idx, const double *__restrict__ x, double *__restrict__ tmp, int mu)
+{
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < novl; q += gridDim.x * blockDim.x) {
+    const int       s = osub[q], i = oidx[q], n = nn[s];
+    const long long v0 = voff[s];
+    const int       p0 = ex_ptr[v0 + i], p1 = ex_ptr[v0 + i + 1];
+    for (int nu = 0; nu < mu; ++nu) {
+      double acc = x[v0 * mu + (long long)nu * n + i];
+      for (int p = p0; p < p1; ++p) {
+        const int t = ex_sub[p];
+        acc += x[voff[t] * mu + (long long)nu * nn[t] + ex_idx[p]];
+      }
+      tmp[(long long)nu * novl + q] = acc;
+    }
+  }
+}
+__global__ void k_halo_ovl_store(const long long *__restrict__ voff, const int *__restrict__ nn, const int *__restrict__ osub, const int *__restrict__ oidx, int novl, const double *__restrict__ tmp, double *__restrict__ x, int mu)
+{
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < novl; q += gridDim.x * blockDim.x) {
+    const int       s = osub[q], i = oidx[q], n = nn[s];
+    const long long v0 = voff[s];
+    for (int nu = 0; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + i] = tmp[(long long)nu * novl + q];
+  }
+}
+
 __global__ void k_diag(const long long *__restrict__ voff, const int *__restrict__ nn, const double *__restrict__ d, const double *__restrict__ in, double *__restrict__ out, int mu)
 {
   const int s = blockIdx.y, n = nn[s];
@@ -77,7 +106,7 @@ __global__ void k_diag(const long long *__restrict__ voff, const int *__restrict
 // y = beta*y + alpha*A*x ; 8 lanes per row (7-point / 27-point stencil rows), rows of all subdomains in one launch.  A group of
 // 8 lanes takes FOUR consecutive rows per step and requests their row pointers, then their first 8 entries each, then the entries
 // of x, together: a row is a chain of three dependent round trips, and one row at a time left the kernel at 1.8 TB/s.
-__global__ void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
+__global__ void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0  = voff[s];
@@ -111,8 +140,9 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
       }
       if (lane < 4 && r0 + lane < n) {
         const double v  = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
-        double      *yp = y + v0 * mu + (long long)nu * n + r0 + lane;
-        *yp             = (beta == 0.0 ? 0.0 : beta * *yp) + alpha * v;
+        const long long o = v0 * mu + (long long)nu * n + r0 + lane;
+        const double    t = (beta == 0.0 ? 0.0 : beta * y0[o]) + alpha * v;
+        y[o]              = dsc ? dsc[v0 + r0 + lane] * t : t;
       }
     }
   }
@@ -121,7 +151,7 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
 // the same for K = std::complex<double> on the complex matrix itself (Wrapper::csrmm with complex scalars, include/HPDDM_wrapper.hpp:
 // 697-733): 16 + 4 bytes per entry where the real-equivalent embedding reads 32 + 4 (2 x 2 blocks); the vectors are the (re, im)
 // pairs of the caller either way.  n = 2 x (complex rows) as everywhere in the complex Schwarz layer.
-__global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
+__global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
 {
   // a group of 8 lanes takes TWO rows per step: their entries are read once, then four right-hand sides at a time -- eight
   // independent 16-byte gathers of x in flight per lane (one right-hand side after the other, every row paid three dependent
@@ -165,11 +195,12 @@ __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restr
           ar += __shfl_xor(ar, 2), ai += __shfl_xor(ai, 2);
           ar += __shfl_xor(ar, 1), ai += __shfl_xor(ai, 1);
           if (lane == 0 && nu0 + u < mu && r0 + k < nc) {
-            double2 *yp = reinterpret_cast<double2 *>(y + v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)(r0 + k));
-            double2  o  = beta == 0.0 ? double2{0.0, 0.0} : *yp;
-            o.x = beta * o.x + alpha * ar;
-            o.y = beta * o.y + alpha * ai;
-            *yp = o;
+            const long long off = v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)(r0 + k);
+            double2         o   = beta == 0.0 ? double2{0.0, 0.0} : *reinterpret_cast<const double2 *>(y0 + off);
+            const double    w   = dsc ? dsc[v0 + 2 * (long long)(r0 + k)] : 1.0;
+            o.x = w * (beta * o.x + alpha * ar);
+            o.y = w * (beta * o.y + alpha * ai);
+            *reinterpret_cast<double2 *>(y + off) = o;
           }
         }
     }
@@ -178,7 +209,7 @@ __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restr
 
 // the same on block CSR (BS x BS dense blocks, one column index per block): 8 lanes per block row
 template <int BS>
-__global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ biaoff, const int *__restrict__ bia, const int *__restrict__ bja, const double *__restrict__ ba, const double *__restrict__ x, double *__restrict__ y, int mu, double alpha, double beta)
+__global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ biaoff, const int *__restrict__ bia, const int *__restrict__ bja, const double *__restrict__ ba, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
 {
   const int s = blockIdx.y, n = nn[s], nb = n / BS;
   const long long v0   = voff[s];
@@ -209,9 +240,12 @@ __global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restric
         acc[i] += __shfl_xor(acc[i], 1);
       }
       if (lane == 0) {
-        double *yp = y + v0 * mu + (long long)nu * n + (long long)R * BS;
+        const long long off = v0 * mu + (long long)nu * n + (long long)R * BS;
 #pragma unroll
-        for (int i = 0; i < BS; ++i) yp[i] = (beta == 0.0 ? 0.0 : beta * yp[i]) + alpha * acc[i];
+        for (int i = 0; i < BS; ++i) {
+          const double t = (beta == 0.0 ? 0.0 : beta * y0[off + i]) + alpha * acc[i];
+          y[off + i]     = dsc ? dsc[v0 + (long long)R * BS + i] * t : t;
+        }
       }
     }
   }
@@ -673,6 +707,15 @@ void Schwarz::build_device()
   ex_ptr.upload(cnt, st);
   ex_sub.upload(esub, st);
   ex_idx.upload(eidx, st);
+  {
+    // the dofs with a duplicate in a co-located subdomain (the short list of the in-place halo sum)
+    std::vector<int> osub, oidx;
+    for (int s = 0; s < nsub; ++s)
+      for (int i = 0; i < subs[s].n; ++i)
+        if (cnt[voff[s] + i + 1] > cnt[voff[s] + i]) osub.push_back(s), oidx.push_back(i);
+    novl = (int)osub.size();
+    if (novl) ovl_sub.upload(osub, st), ovl_idx.upload(oidx, st);
+  }
   if (halo_total) {
     send_sub_d.upload(h_send_sub, st);
     send_idx_d.upload(h_send_idx, st);
@@ -685,6 +728,7 @@ void Schwarz::build_device()
   }
   HIP_OK(hipStreamSynchronize(st));
   device_ready = true;
+  mu_cap       = 0; // the work vectors (and the overlap staging of the in-place halo sum) follow the new sizes
   build_boundary_conditions();
 }
 
@@ -697,6 +741,7 @@ void Schwarz::reserve(int mu)
   w3.alloc(cnt);
   hin.alloc(cnt);
   hout.alloc(cnt);
+  if (novl) halo_tmp.alloc((size_t)novl * mu);
   if (cdim) {
     uc_d.alloc((size_t)cdim * mu);
     uc2_d.alloc((size_t)cdim * mu);
@@ -1098,6 +1143,46 @@ void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
   }
   hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
 }
+void Schwarz::halo_sum_inplace(double *x, int mu)
+{
+  // x holds, per duplicate, what Subdomain::exchange would send (D x when the producer folded Wrapper::diag into its store): sum
+  // the duplicates in place, touching the overlap only.  Neighbours on other GPUs: pack (no scaling) and the messages on the
+  // communication stream while the co-located part runs; the values must be packed before they are overwritten.
+  hipStream_t st = library_stream();
+  reserve(mu);
+  hipStream_t cs      = st;
+  const bool  overlap = getopt("hip_halo_overlap", 1) != 0;
+  if (halo_total) {
+    HH_CHECK(transport && sendbuf && recvbuf && mu <= halo_mu_cap, "subdomains have neighbours on other GPUs: register the halo transport first (HpddmHipSchwarzInitRccl or HpddmHipSchwarzSetTransport) with room for this many right-hand sides");
+    if (overlap) {
+      if (!comm_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&ev_halo_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&ev_halo_done, hipEventDisableTiming));
+      }
+      if (!ev_halo_packed) HIP_OK(hipEventCreateWithFlags(&ev_halo_packed, hipEventDisableTiming));
+      cs = comm_stream;
+      HIP_OK(hipEventRecord(ev_halo_fork, st));
+      HIP_OK(hipStreamWaitEvent(cs, ev_halo_fork, 0));
+    }
+    hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, cs, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, x, sendbuf, mu, 0);
+    if (overlap) HIP_OK(hipEventRecord(ev_halo_packed, cs));
+  }
+  if (novl) {
+    const dim3 g((unsigned)std::min(2048, (novl + 255) / 256));
+    hipLaunchKernelGGL(k_halo_ovl_sum, g, dim3(256), 0, st, voff_d.p, n_d.p, ovl_sub.p, ovl_idx.p, novl, ex_ptr.p, ex_sub.p, ex_idx.p, x, halo_tmp.p, mu);
+    if (halo_total && overlap) HIP_OK(hipStreamWaitEvent(st, ev_halo_packed, 0));
+    hipLaunchKernelGGL(k_halo_ovl_store, g, dim3(256), 0, st, voff_d.p, n_d.p, ovl_sub.p, ovl_idx.p, novl, halo_tmp.p, x, mu);
+  }
+  if (halo_total) {
+    transport->halo(peers, sendbuf, recvbuf, mu, cs); // RCCL: grouped send/recv enqueued, no host wait (the callback double blocks here, the kernels above are already enqueued)
+    if (overlap) {
+      HIP_OK(hipEventRecord(ev_halo_done, cs));
+      HIP_OK(hipStreamWaitEvent(st, ev_halo_done, 0));
+    }
+    hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, x, mu);
+  }
+}
 void Schwarz::exchange_inplace(double *x, int mu, bool scale)
 {
   reserve(mu);
@@ -1169,19 +1254,23 @@ void Schwarz::build_bsr()
   }
 }
 
-void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta)
+void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0, bool scaled)
 {
+  // y = [D] (beta y0 + alpha A x); y0 defaults to y; scaled: the partition of unity of the exchange that follows, at the store
+  if (!y0) y0 = y;
+  HH_CHECK(x != y, "csrmm: the product cannot overwrite its argument");
+  const double *dsc = scaled ? d_d.p : nullptr;
   if (zia_d.p) { // complex operators: the complex matrix itself
-    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 4 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta);
+    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 4 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta, y0, dsc);
     return;
   }
   if (bsr_bs) {
     const dim3 g((unsigned)std::min(4096, (nmax / bsr_bs * 8 + 255) / 256), (unsigned)nsub);
-    if (bsr_bs == 3) hipLaunchKernelGGL(k_bsrmm<3>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta);
-    else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta);
+    if (bsr_bs == 3) hipLaunchKernelGGL(k_bsrmm<3>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc);
+    else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc);
     return;
   }
-  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta);
+  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
 }
 void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {
@@ -1205,19 +1294,25 @@ void Schwarz::gmv(const double *in, double *out, int mu)
   if (custom_mv) return custom_call(custom_mv, "operator", in, out, mu);
   // Schwarz::GMV (include/HPDDM_schwarz.hpp:740-744): out = exchange(A in)
   reserve(mu);
-  csrmm(in, w3.p, mu, 1.0, 0.0);
-  exchange(w3.p, out, mu, true);
+  if (getopt("hip_fused_scaling", 1) == 0) {
+    csrmm(in, w3.p, mu, 1.0, 0.0);
+    exchange(w3.p, out, mu, true);
+    return;
+  }
+  csrmm(in, out, mu, 1.0, 0.0, nullptr, true); // out = D A in, the partition of unity at the store of the product
+  halo_sum_inplace(out, mu);
 }
 void Schwarz::local_solve(const double *in, double *out, int mu)
 {
   HH_CHECK(factored && type != PRC_NO, "local solve before CallNumfact");
   solve_factor(in, out, mu);
 }
-void Schwarz::solve_factor(const double *in, double *out, int mu)
+void Schwarz::solve_factor(const double *in, double *out, int mu, bool scaled)
 {
   // the batched SpTRSV.  Complex operators: the vectors of the embedding ARE arrays of (re, im) pairs, which is what the
-  // complex plans take (n / 2 complex rows per subdomain, mu complex right-hand sides)
-  batched_sptrsv(in, out, mu);
+  // complex plans take (n / 2 complex rows per subdomain, mu complex right-hand sides).  scaled: out = D A^{-1} in, the partition of
+  // unity folded into the permutation pass that ends the solve (SolvePlan::out_scale)
+  batched_sptrsv(in, out, mu, scaled);
 }
 
 void Schwarz::build_plans()
@@ -1250,10 +1345,11 @@ void Schwarz::build_plans()
   }
 }
 
-void Schwarz::batched_sptrsv(const double *in, double *out, int mu)
+void Schwarz::batched_sptrsv(const double *in, double *out, int mu, bool scaled)
 {
   hipStream_t st = library_stream();
   const int   ng = (int)group_first.size() - 1;
+  plan.out_scale = scaled ? d_d.p : nullptr;
   if (ng <= 1) {
     plan.solve(in, out, mu, st);
     return;
@@ -1263,6 +1359,7 @@ void Schwarz::batched_sptrsv(const double *in, double *out, int mu)
   plan.solve(in, out, mu, st);
   for (int g = 1; g < ng; ++g) {
     const long long off = voff[group_first[g]];
+    more_plans[g - 1]->out_scale = scaled ? d_d.p + off : nullptr;
     more_plans[g - 1]->solve(in + off * mu, out + off * mu, mu, more_streams[g - 1]);
     HIP_OK(hipEventRecord(ev_join[g - 1], more_streams[g - 1]));
   }
@@ -1274,8 +1371,13 @@ void Schwarz::deflation(const double *in, double *out, int mu)
   // Schwarz::deflation (include/HPDDM_schwarz.hpp:1602-1622): out = exchange(Z E^{-1} Z^T D in)
   HH_CHECK(coarse_ready, "deflation before BuildCoarseOperator");
   reserve(mu);
-  deflation_panel(in, w3.p, mu);
-  exchange(w3.p, out, mu, true);
+  if (getopt("hip_fused_scaling", 1) == 0) {
+    deflation_panel(in, w3.p, mu);
+    exchange(w3.p, out, mu, true);
+    return;
+  }
+  deflation_panel(in, out, mu, true); // out = D Z E^{-1} Z^T D in: the partition of unity at the store of the second product
+  halo_sum_inplace(out, mu);
 }
 
 void Schwarz::coarse_solve(const double *uc, double *y, int mu)
@@ -1310,18 +1412,29 @@ void Schwarz::apply(const double *in, double *out, int mu)
   hipStream_t  st  = library_stream();
   const size_t cnt = (size_t)ntot * mu;
   const int    correction = (int)getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  const bool   fused = getopt("hip_fused_scaling", 1) != 0; // Wrapper::diag at the store of the producing kernel, halo summed in place on the overlap
   if (!coarse_ready || correction == COARSE_CORRECTION_NONE) {
     if (type == PRC_NO) HIP_OK(hipMemcpyAsync(out, in, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
-    else if (type == PRC_GE || type == PRC_OG) {
-      solve_factor(in, w1.p, mu);
-      exchange(w1.p, out, mu, true); // out = sum R^T D A^{-1} in
+    else if (!fused) {
+      if (type == PRC_GE || type == PRC_OG) {
+        solve_factor(in, w1.p, mu);
+        exchange(w1.p, out, mu, true); // out = sum R^T D A^{-1} in
+      } else {
+        if (type == PRC_OS) {
+          diag(in, w1.p, mu);
+          solve_factor(w1.p, w1.p, mu);
+          diag(w1.p, w1.p, mu);
+        } else solve_factor(in, w1.p, mu);
+        exchange(w1.p, out, mu, false); // Subdomain::exchange: no scaling (ASM)
+      }
     } else {
+      // the same with the partition of unity folded into the last pass of the solve and the halo summed in place on the overlap:
+      // GE / OG: sum R^T D A^{-1} in;  OS: sum R^T D A_opt^{-1} D in;  SY: sum R^T A^{-1} in
       if (type == PRC_OS) {
         diag(in, w1.p, mu);
-        solve_factor(w1.p, w1.p, mu);
-        diag(w1.p, w1.p, mu);
-      } else solve_factor(in, w1.p, mu);
-      exchange(w1.p, out, mu, false); // Subdomain::exchange: no scaling (ASM)
+        solve_factor(w1.p, out, mu, true);
+      } else solve_factor(in, out, mu, type == PRC_GE || type == PRC_OG);
+      halo_sum_inplace(out, mu);
     }
     return;
   }
@@ -1334,12 +1447,20 @@ void Schwarz::apply(const double *in, double *out, int mu)
     return;
   }
   deflation(in, out, mu);                                                       // :573
-  HIP_OK(hipMemcpyAsync(w1.p, in, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
-  csrmm(out, w1.p, mu, -1.0, 1.0);                                              // :581-586  work = in - A out
-  exchange(w1.p, w2.p, mu, true);                                               // :588
-  if (type == PRC_OS) diag(w2.p, w2.p, mu);                                     // :589
-  solve_factor(w2.p, w2.p, mu);                                               // :590
-  exchange(w2.p, w1.p, mu, true);                                               // :591   work now in w1
+  if (!fused) {
+    HIP_OK(hipMemcpyAsync(w1.p, in, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
+    csrmm(out, w1.p, mu, -1.0, 1.0);                                            // :581-586  work = in - A out
+    exchange(w1.p, w2.p, mu, true);                                             // :588
+    if (type == PRC_OS) diag(w2.p, w2.p, mu);                                   // :589
+    solve_factor(w2.p, w2.p, mu);                                               // :590
+    exchange(w2.p, w1.p, mu, true);                                             // :591   work now in w1
+  } else {
+    csrmm(out, w2.p, mu, -1.0, 1.0, in, true);                                  // :581-588  w2 = D (in - A out), one pass, then the halo on the overlap
+    halo_sum_inplace(w2.p, mu);
+    if (type == PRC_OS) diag(w2.p, w2.p, mu);                                   // :589
+    solve_factor(w2.p, w1.p, mu, true);                                         // :590-591  w1 = D A^{-1} w2, then the halo
+    halo_sum_inplace(w1.p, mu);
+  }
   if (correction == COARSE_CORRECTION_BALANCED) {
     gmv(w1.p, w2.p, mu);                                                        // :596  (uses w3)
     DevBuf<double> tmp;

@@ -124,6 +124,11 @@ struct Schwarz {
   DevBuf<long long>      ziaoff_d;
   DevBuf<double>         za_d;
   DevBuf<int>            ex_ptr, ex_sub, ex_idx; // gather lists of the halo sum, per concatenated dof
+  DevBuf<int>            ovl_sub, ovl_idx;       // the dofs that have a duplicate in a co-located subdomain (in-place halo sum on the overlap only)
+  int                    novl = 0;
+  DevBuf<double>         halo_tmp;               // novl x mu
+  hipEvent_t             ev_halo_packed = nullptr;
+  void                   halo_sum_inplace(double *x, int mu); // x <- sum of the duplicates of x (x already scaled by the producer)
   SolvePlan              plan;
   // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
   // of a launch, ramp of the next) the others keep the memory system busy.  plan = the first group (on the library stream),
@@ -135,7 +140,7 @@ struct Schwarz {
   hipEvent_t                              ev_fork = nullptr;
   std::vector<int>                        group_first; // ngroups + 1
   void                   build_plans();                                            // from the resident factors of the subdomains
-  void                   batched_sptrsv(const double *in, double *out, int mu);    // all local solves, both groups
+  void                   batched_sptrsv(const double *in, double *out, int mu, bool scaled = false);    // all local solves, all groups; scaled: out = D A^{-1} in
   // coarse level
   int                 cdim = 0, cdim_g = 0, coff_g0 = 0; // local / global coarse dimension, global offset of the local block
   std::vector<int>    coff; // nsub+1
@@ -177,7 +182,7 @@ struct Schwarz {
   // device-pointer operations on the library stream (batched layout, see hpddm_hip.h)
   void exchange(const double *in, double *out, int mu, bool scale); // out = halo_sum((scale ? D : I) in), out != in
   void exchange_inplace(double *x, int mu, bool scale);
-  void csrmm(const double *x, double *y, int mu, double alpha, double beta); // y = beta*y + alpha*A*x
+  void csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0 = nullptr, bool scaled = false); // y = [D] (beta*y0 + alpha*A*x), y0 = y by default
   void gmv(const double *in, double *out, int mu);
   // HpddmCustomOperatorSolve (interface/hpddm_c.cpp:41-53, 227-230: CustomOperator<Operator, K> handed to IterativeMethod::solve): the
   // operator and the preconditioner of the Krylov methods are callbacks of the caller on HOST vectors (n x mu, column-major); the
@@ -188,11 +193,11 @@ struct Schwarz {
   std::vector<double> custom_in, custom_out;
   void                custom_call(CustomFn fn, const char *what, const double *in, double *out, int mu);
   void local_solve(const double *in, double *out, int mu);
-  void solve_factor(const double *in, double *out, int mu); // plan.solve, plus the row phases of complex operators
+  void solve_factor(const double *in, double *out, int mu, bool scaled = false); // plan.solve, plus the row phases of complex operators
   void deflation(const double *in, double *out, int mu);
-  void deflation_panel(const double *in, double *zy, int mu); // zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip) = the three below
+  void deflation_panel(const double *in, double *zy, int mu, bool scaled = false); // (scaled: D at the store of the last product) zy = Z E^{-1} Z^T D in (MFMA, deflation_mfma.hip) = the three below
   void panel_zt(const double *in, double *uc, int mu);        // uc = Z^T (D in)
-  void panel_z(const double *y, double *zy, int mu);          // zy = Z y
+  void panel_z(const double *y, double *zy, int mu, bool scaled = false); // zy = [D] Z y
   void upload_vectors(bool compact = false);                  // Z, its offsets and the local coarse numbering to the device
   bool z_compact = false;                                     // complex operators: Z_d holds the complex vectors only (16 bytes per entry)
   void coarse_solve(const double *uc, double *y, int mu);     // y = E^{-1} uc

@@ -95,14 +95,15 @@ __global__ void k_perm_in(const long long *__restrict__ voff, const int *__restr
     for (int nu = first; nu < mu; ++nu) bp[v0 * mu + (long long)nu * n + i] = b[v0 * mu + (long long)nu * n + o];
   }
 }
-__global__ void k_perm_out(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first)
+__global__ void k_perm_out(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first, const double *__restrict__ scale)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int o = pm[i];
-    for (int nu = first; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + o] = xp[v0 * mu + (long long)nu * n + i];
+    const int    o  = pm[i];
+    const double sc = scale ? scale[v0 + o] : 1.0;
+    for (int nu = first; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + o] = sc * xp[v0 * mu + (long long)nu * n + i];
   }
 }
 
@@ -121,17 +122,18 @@ __global__ void k_perm_in_z(const long long *__restrict__ voff, const int *__res
     }
   }
 }
-__global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first)
+__global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ perm, const double *__restrict__ xp, double *__restrict__ x, int mu, int first, const double *__restrict__ scale)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0 = voff[s];
   const int      *pm = perm[s];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int o = pm[i];
+    const int    o  = pm[i];
+    const double sc = scale ? scale[2 * (v0 + o)] : 1.0;
     for (int k = first; k < mu; ++k) {
       dbl2 z;
-      z.x = xp[v0 * 2 * mu + (long long)(2 * k) * n + i];
-      z.y = xp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i];
+      z.x = sc * xp[v0 * 2 * mu + (long long)(2 * k) * n + i];
+      z.y = sc * xp[v0 * 2 * mu + (long long)(2 * k + 1) * n + i];
       *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)k * n + o)) = z;
     }
   }
@@ -1495,7 +1497,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
         nu0 += 2;
       }
     }
-    hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done);
+    hipLaunchKernelGGL(k_perm_out_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done, out_scale);
     mark(4000, s);
     HIP_OK(hipGetLastError());
     return;
@@ -1523,7 +1525,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
       nu0 += 1;
     }
   }
-  hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done); // the sweeps stay in the permuted numbering; one pass scatters the result
+  hipLaunchKernelGGL(k_perm_out, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, xw.p, x, mu, done, out_scale); // the sweeps stay in the permuted numbering; one pass scatters the result
   mark(4000, s);
   HIP_OK(hipGetLastError());
 }

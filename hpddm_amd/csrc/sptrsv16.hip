@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_perm_in16(const long long *__restrict__
   }
 }
 template <bool Z>
-__global__ __launch_bounds__(256) void k_perm_out16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ iperm, const double *__restrict__ x16, double *__restrict__ x, int mu, int k0)
+__global__ __launch_bounds__(256) void k_perm_out16(const long long *__restrict__ voff, const int *__restrict__ nn, const int *const *__restrict__ iperm, const double *__restrict__ x16, double *__restrict__ x, int mu, int k0, const double *__restrict__ scale)
 {
   __shared__ double T[64][C16 + 1];
   const int s = blockIdx.y, n = nn[s], o0 = (int)blockIdx.x * 64, tid = threadIdx.x;
@@ -83,19 +83,20 @@ __global__ __launch_bounds__(256) void k_perm_out16(const long long *__restrict_
   __syncthreads();
   const int oo = tid & 63, o = o0 + oo;
   if (o >= n) return;
+  const double sc = scale ? scale[Z ? 2 * (v0 + o) : v0 + o] : 1.0; // SolvePlan::out_scale: the partition of unity folded into this pass
   if constexpr (Z) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int k = (tid >> 6) + 4 * pass;
       dbl2      z;
-      z.x = T[oo][2 * k], z.y = T[oo][2 * k + 1];
+      z.x = sc * T[oo][2 * k], z.y = sc * T[oo][2 * k + 1];
       if (k0 + k < mu) *reinterpret_cast<dbl2 *>(x + 2 * (v0 * mu + (long long)(k0 + k) * n + o)) = z;
     }
   } else {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int c = (tid >> 6) + 4 * pass;
-      if (k0 + c < mu) x[v0 * mu + (long long)(k0 + c) * n + o] = T[oo][c];
+      if (k0 + c < mu) x[v0 * mu + (long long)(k0 + c) * n + o] = sc * T[oo][c];
     }
   }
 }
@@ -719,7 +720,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
-  hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0);
+  hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0, P.out_scale);
   P.mark(4000, s);
 }
 
