@@ -17,10 +17,9 @@ N = 256 if helm or len(sys.argv) < 2 else int(sys.argv[1])
 cfgs = sys.argv[2:] or [""]
 nu = 20
 if helm:
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    import bench
-    subs = bench.generate_helmholtz(np, generate3d, (64, 64, 128), 8, rhs="smooth", grid=(2, 2, 2))
-    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_coarse_correction deflated")
+    from hpddm_amd.generate import generate_helmholtz3d
+    subs = generate_helmholtz3d((64, 64, 128), 8, grid=(2, 2, 2))
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_coarse_correction deflated", multiplicity=False)
     for s, sd in enumerate(subs):
         t = np.arange(sd["n"], dtype=np.float64)
         A.set_vectors(s, np.stack([np.ones(sd["n"], dtype=np.complex128), np.exp(0.21j * t), np.exp(-0.13j * t + 0.4j * s)], axis=1))
@@ -29,7 +28,7 @@ if helm:
         if cfg:
             A.option_parse(cfg)
         for mu in (1, 8):
-            print(f"[{cfg}] helmholtz mu {mu}: deflation {A.time('deflation', mu, 3, 50) * 1e3:.3f} ms, gmv {A.time('gmv', mu, 3, 50) * 1e3:.3f} ms, exchange {A.time('exchange', mu, 3, 50) * 1e3:.3f} ms", flush=True)
+            print(f"[{cfg}] helmholtz mu {mu}: deflation {A.time('deflation', mu, 3, 50) * 1e3:.3f} ms, gmv {A.time('gmv', mu, 3, 50) * 1e3:.3f} ms, exchange {A.time('exchange', mu, 3, 50) * 1e3:.3f} ms, halo in place {A.time('halo', mu, 3, 50) * 1e3:.3f} ms", flush=True)
     sys.exit(0)
 subs = generate3d(N, 8, overlap=1, sym=True, rhs="smooth")
 A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated")
@@ -47,4 +46,6 @@ for cfg in cfgs:
         A.option_parse(cfg)
     for mu in [int(v) for v in os.environ.get("MUS", "1,2").split(",")]:
         td, tg = A.time("deflation", mu, 3, 30), A.time("gmv", mu, 3, 30)
-        print(f"[{cfg}] mu {mu}: deflation {td * 1e3:.3f} ms ({zbytes / td / 1e9:.0f} GB/s on 2 x Z), gmv {tg * 1e3:.3f} ms", flush=True)
+        te, th = A.time("exchange", mu, 3, 30), A.time("halo", mu, 3, 30)
+        pb = zbytes + 3.0 * A.stats()["n"] * mu * 8.0
+        print(f"[{cfg}] mu {mu}: deflation {td * 1e3:.3f} ms ({zbytes / td / 1e9:.0f} GB/s on 2 x Z, {pb / td / 1e9:.0f} GB/s on the panel bytes of SURVEY 8(d)), gmv {tg * 1e3:.3f} ms, exchange {te * 1e3:.3f} ms, halo in place {th * 1e3:.3f} ms", flush=True)
