@@ -286,7 +286,7 @@ def main():
                    "deflation_flops": 4.0 * n * nu * mu * (4.0 if A.complex else 1.0),
                    "kernel": ("k_zt_stream2 + k_z_stream2: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
                               "MFMA utilisation 0 by construction" if mu <= 2 else
-                              "k_zt_mfma + k_z_mfma (v_mfma_f64_16x16x4_f64): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r03_pmc_mfma_deflation.csv)")})
+                              "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64; complex operators: the staged k_zt_mfma + k_z_mfma): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r04_pmc_mfma_deflation.csv)")})
         tl["deflation_TFLOPs"] = tl["deflation_flops"] / t_defl / 1e12
         if mu <= 2 and world == 1:
             # the same panel with 8 right-hand sides (Block GMRES, the GenEO blocks): the GEMM-shaped products on v_mfma_f64_16x16x4_f64,
@@ -296,8 +296,9 @@ def main():
             f8 = 4.0 * n * nu * 8 * (4.0 if A.complex else 1.0)
             b8 = 2.0 * n * nu * sk + 3.0 * n * 8 * sk
             tl["deflation_mfma_mu8"] = {"ms": t8 * 1e3, "flops": f8, "TFLOPs": f8 / t8 / 1e12, "frac_of_f64_mfma_peak": f8 / t8 / 78.6e12, "panel_GBps": b8 / t8 / 1e9,
-                                        "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM in 32-byte accesses) + k_exchange",
-                                        "counters": "profiles/r03_pmc_mfma_deflation.csv, profiles/r03_deflation_mfma_mu8_kernel_stats.csv (SQ counters and kernel trace of the staged kernels these replaced), profiles/r03_deflation_mfma_times.txt (before / after)"}
+                                        "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM in 32-byte accesses, the partition of unity at the store of the second) + the in-place halo sum on the overlap",
+                                        "mfma_busy_fraction_of_simd_cycles": {"k_zt_mfma2": 0.2445, "k_z_mfma2": 0.1512, "source": "profiles/r04_pmc_mfma_deflation_utilisation.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE on scripts/time_deflation.py: the same panel, 8 right-hand sides; not measured in this run)"},
+                                        "counters": "profiles/r04_pmc_mfma_deflation.csv (SQ counters), profiles/r04_deflation_mfma_mu8_kernel_stats.csv (rocprofv3 --kernel-trace --stats: k_zt_mfma2 0.93 ms, k_z_mfma2 0.92 ms per launch), profiles/r04_deflation_fused_scaling_times.txt (scaling at the store on / off)"}
         if not args.no_gmres:
             tl["gmres"] = gmres_leg()
 
