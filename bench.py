@@ -151,7 +151,7 @@ def main():
     t0 = time.time()
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     want_cpu = want_cpu and not helm               # the CPU port is real arithmetic
-    opts = ("-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd") + (" -hpddm_keep_plain 1" if want_cpu else "") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
+    opts = ("-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
     sharded = world > 1 and not args.replicas
     peers_hist = None
     if sharded:
@@ -194,7 +194,7 @@ def main():
     # of which: the plain factor kept for the CPU baseline leg (-hpddm_keep_plain: every front copied off the device before it is
     # inverted -- 97 GB at configs[2]); not part of the set-up of the operator
     infos = [A.subdomain(s).info() for s in range(len(subs))]
-    t_plain = sum(i["plain_export_us"] for i in infos) * 1e-6 if want_cpu else 0.0
+    t_plain = 0.0   # (the CPU leg factorises its own sample of subdomains after the timed region: cpu_baseline)
     # where the set-up goes, summed over the subdomains of this GPU (they are factorised one after the other): analysis on the
     # host, numerical factorisation (host levels + device levels; contains the plain-factor copies when the CPU baseline asks for
     # them), upload of the host levels + the solve plan
@@ -510,20 +510,37 @@ def configs_1(np, torch, dev, args):
 
 
 def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level applies/s of the device path
-    """The oracle's substitution (plain C, oracle/sptrsv_oracle.c) on the SAME factors, on the host cores of this box:
-    (a) one thread per subdomain -- the reference's layout, one MPI rank per subdomain with a sequential local solve;
-    (b) every core: level-scheduled over the assembly tree, all subdomains at once (tree parallelism at the bottom, the whole
-        team on the large supernodes near the root) -- what a threaded MUMPS / PARDISO solve phase does.
-    Plus the numpy halo sum.  `value` is the better of the two."""
+    """The oracle's substitution (plain C, oracle/sptrsv_oracle.c) on the factors of the SAME operator, on the host cores of this box,
+    on a bounded SAMPLE of its subdomains: the first `ns` of them are factorised once more with the plain factor kept on the host
+    (HpddmHipSubdomainNumfact with keep_plain -- after the timed region, so that the set-up of the operator above does not pay the
+    copies: 12 GB per 129^3 subdomain), the cost of the whole operator follows by the ratio of the factor sizes.
+    (a) one thread per subdomain -- the reference's layout, one MPI rank per subdomain with a sequential local solve: the subdomains run
+        side by side, so the sample's time IS the estimate (no scaling);
+    (b) level-scheduled over the assembly tree on a team of threads, all the sampled subdomains at once (tree parallelism at the bottom,
+        the whole team on the large supernodes near the root) -- what a threaded MUMPS / PARDISO solve phase does; scaled by the sizes;
+    (c) a team of threads per subdomain filling the CPUs this container may use; scaled by the sizes.
+    Plus the numpy halo sum of the whole operator.  `value` is the best of the three."""
+    from hpddm_amd import hpddm
     from oracle import sptrsv_oracle
     from oracle.ras_oracle import Oracle
     nsub = len(subs)
     ncores = os.cpu_count() or 1
-    threads = min(nsub, ncores)
-    factors = [sptrsv_oracle.PlainFactor(A.subdomain(s)) for s in range(nsub)]
+    ns = min(nsub, 2 if args.n >= 200 else nsub)     # subdomains of the sample
+    t0 = time.time()
+    solvers = []
+    for sd in subs[:ns]:
+        S = hpddm.Subdomain(keep_plain=1)
+        S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a"], sym=sd["sym"], spd=True)
+        solvers.append(S)
+    factors = [sptrsv_oracle.PlainFactor(S) for S in solvers]
+    t_sample = time.time() - t0
+    nnz_all = float(A.stats()["nnz_L"])
+    nnz_smp = float(sum(S.info()["nnz_L"] for S in solvers))
+    scale = nnz_all / nnz_smp                          # whole operator / sample, by factor entries (= algorithmic bytes of the substitutions)
+    threads = min(ns, ncores)
     orc = Oracle(subs)
     orc.d = d
-    f = [np.ones(s["n"]) for s in subs]
+    f = [np.ones(s["n"]) for s in subs[:ns]]
     budget = 10.0 if args.n >= 200 else 6.0     # seconds of CPU work per variant (bounded sample)
 
     def sample(fn):
@@ -537,6 +554,9 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         return tsolve / reps, reps, xs
 
     ta, ra, xs = sample(lambda r: sptrsv_oracle.time_batch(factors, f, reps=r, threads=threads))
+    # against the device path on the same right-hand side (the sample's subdomains)
+    xg = A.local_solve([np.ones(s["n"]) for s in subs])
+    agree_gpu = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xg[:ns]))
     # (b): the team size that is fastest on this box (barrier cost grows with the team; SMT siblings and container CPU quotas
     # make "every logical core" the wrong choice more often than not): double it while it pays
     nthr, best_probe = min(16, ncores), None
@@ -551,8 +571,8 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     tb, rb, xl = sample(lambda r: sptrsv_oracle.time_batch_levels(factors, f, reps=r, threads=nthr))
     agree = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xl))
     # (c) a team of threads per subdomain (nested OpenMP: the row loops of the large supernodes shared by the team).  One core
-    # streams a factor at 12-17 GB/s, so (a) cannot go beyond 8 x that; the team size follows what this process may use -- the
-    # smaller of the affinity mask and the container's CPU quota (cpu.max), which the logical core count ignores
+    # streams a factor at 12-17 GB/s; the team size follows what this process may use -- the smaller of the affinity mask and the
+    # container's CPU quota (cpu.max), which the logical core count ignores
     quota_cpus = ncores
     try:
         with open("/sys/fs/cgroup/cpu.max") as fh:
@@ -565,18 +585,21 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         quota_cpus = min(quota_cpus, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
-    team = max(1, min(8, quota_cpus // nsub))
+    team = max(1, min(16, quota_cpus // ns))
     tc, rc, xt = (ta, ra, xs)
     if team > 1:
         tc, rc, xt = sample(lambda r: sptrsv_oracle.time_batch_teams(factors, f, reps=r, team=team))
         agree = max(agree, max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xt)))
+    full = [np.ones(s["n"]) for s in subs]
     t1 = time.perf_counter()
     for _ in range(3):
-        orc.exchange(xs)
+        orc.exchange(full)
     tex = (time.perf_counter() - t1) / 3
-    best, cores = min(((ta, threads), (tb, nthr), (tc, nsub * team)), key=lambda v: v[0])
+    # whole-operator estimates: (a) as sampled (the subdomains run side by side, one thread each), (b) and (c) by the factor sizes
+    ea, eb, ec = ta, tb * scale, tc * scale
+    best, cores = min(((ea, min(nsub, ncores)), (eb, nthr), (ec, ns * team)), key=lambda v: v[0])
     per_apply = best + tex
-    bytes_host = 2.0 * A.stats()["nnz_L"] * 8.0   # the plain factor read once per sweep (algorithmic bytes, as for the device)
+    bytes_host = 2.0 * nnz_all * 8.0   # the plain factor read once per sweep (algorithmic bytes, as for the device)
     try:
         with open("/sys/fs/cgroup/cpu.max") as fh:
             quota = fh.read().strip()
@@ -586,17 +609,21 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = None
+    for S in solvers:
+        S.destroy()
     return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "kind": "port", "cgroup_cpu_max": quota, "sched_affinity_cpus": affinity,
-            "sample": f"one-level apply of the same {nsub}-subdomain operator (all {nsub} local substitutions + numpy halo sum, {tex * 1e3:.1f} ms): "
-                      f"(a) one thread per subdomain on {threads} threads, {ra} applies, {ta * 1e3:.1f} ms each; "
-                      f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms each; "
-                      f"(c) {team} threads per subdomain = {nsub * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs), {rc} applies, {tc * 1e3:.1f} ms each; "
-                      f"value = the fastest; they agree to {agree:.1e}",
+            "sample": f"one-level apply of the same {nsub}-subdomain operator, substitutions timed on {ns} of its {nsub} subdomains ({100.0 / scale:.0f} % of the factor entries; "
+                      f"their plain factors made by {ns} extra factorisations after the timed region, {t_sample:.1f} s) + numpy halo sum of all {nsub} ({tex * 1e3:.1f} ms): "
+                      f"(a) one thread per subdomain, {ra} applies, {ta * 1e3:.1f} ms (the {nsub} run side by side: not scaled); "
+                      f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms for the sample = {eb * 1e3:.1f} ms scaled; "
+                      f"(c) {team} threads per subdomain = {ns * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs), {rc} applies, {tc * 1e3:.1f} ms = {ec * 1e3:.1f} ms scaled; "
+                      f"value = the fastest; the three agree to {agree:.1e}, with the device solve to {agree_gpu:.1e}",
+            "sample_subdomains": ns, "sample_scale": scale, "sample_factor_seconds": round(t_sample, 2),
             "host_GBps": bytes_host / best / 1e9, "usable_cpus": quota_cpus,
-            "teams": {"threads_per_subdomain": team, "threads": nsub * team, "substitution_ms": tc * 1e3, "applies_per_sec": 1.0 / (tc + tex)},
+            "teams": {"threads_per_subdomain": team, "threads": ns * team, "substitution_ms": ec * 1e3, "applies_per_sec": 1.0 / (ec + tex)},
             "seconds_per_apply": per_apply, "host_cores": ncores,
-            "one_thread_per_subdomain": {"threads": threads, "substitution_ms": ta * 1e3, "applies_per_sec": 1.0 / (ta + tex)},
-            "level_parallel": {"threads": nthr, "substitution_ms": tb * 1e3, "applies_per_sec": 1.0 / (tb + tex)},
+            "one_thread_per_subdomain": {"threads": min(nsub, ncores), "substitution_ms": ea * 1e3, "applies_per_sec": 1.0 / (ea + tex)},
+            "level_parallel": {"threads": nthr, "substitution_ms": eb * 1e3, "applies_per_sec": 1.0 / (eb + tex)},
             "note": "the CPU leg is the ONE-level apply (substitutions + halo); the GPU headline above additionally carries the coarse correction when two-level",
             "gpu_one_level_over_cpu": gpu_value / (1.0 / per_apply)}
 

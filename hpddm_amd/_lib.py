@@ -36,6 +36,7 @@ def _declare(lib):
         "HpddmHipSubdomainSolveDevice": (I, [P, P, P, US]),
         "HpddmHipSubdomainDestroy": (None, [P]),
         "HpddmHipSubdomainSetOption": (I, [c_void_pp, C, D]),
+        "HpddmHipSubdomainInertia": (I, [P]),
         "HpddmHipSubdomainInfo": (I, [P, P, P]),
         "HpddmHipSubdomainExport": (LL, [P, C, P, LL]),
         "HpddmHipSubdomainExportView": (P, [P, C, c_ll_p]),

@@ -58,6 +58,14 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
     return 0;)
 }
 
+int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S)
+{
+  HH_TRY(
+    HH_CHECK(S != nullptr, "Inertia: numfact first");
+    const int neg = S->ls.negative_pivots();
+    return neg < 0 ? -3 : neg;)
+}
+
 int HpddmHipSubdomainNumfact(HpddmHipSubdomain **S, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int spd)
 {
   HH_TRY(

@@ -213,23 +213,45 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
       }
     B.ia[i + 1] = (int)B.ja.size();
   }
+  // lower triangle of A_N + sigma B, merged patterns
+  auto shifted_lower = [&](double sigma, std::vector<int> &sia, std::vector<int> &sja, std::vector<double> &sa) {
+    sia.assign(n + 1, 0), sja.clear(), sa.clear();
+    for (int i = 0; i < n; ++i) {
+      int pa = AN.ia[i], pb = B.ia[i];
+      while (true) {
+        const int ja_ = pa < AN.ia[i + 1] ? AN.ja[pa] : n, jb = pb < B.ia[i + 1] ? B.ja[pb] : n, j = std::min(ja_, jb);
+        if (j > i) break;
+        double v = 0.0;
+        if (ja_ == j) v += AN.a[pa++];
+        if (jb == j) v += sigma * B.a[pb++];
+        sja.push_back(j);
+        sa.push_back(v);
+      }
+      sia[i + 1] = (int)sja.size();
+    }
+  };
+  if (threshold > 0.0 && getopt("geneo_estimate_nu", 0) != 0) {
+    // -hpddm_geneo_estimate_nu (include/HPDDM_schwarz.hpp:686-703): the number of eigenvalues below the threshold is the number of
+    // negative pivots of A_N - threshold B (Sylvester) -- one L D L^T factorisation instead of a guess for nu
+    std::vector<int>    tia, tja;
+    std::vector<double> ta;
+    shifted_lower(-threshold, tia, tja, ta);
+    LocalSolver est;
+    est.leaf_size    = (int)getopt("leaf_size", 32);
+    est.release_host = true;
+    CsrView V{n, tia.data(), tja.data(), ta.data(), true, 0};
+    est.adopt_analysis(*S.ls, V);
+    est.numfact(V, 0);
+    const int neg = est.negative_pivots();
+    if (neg >= 0) nu = std::max(1, neg);
+    else fprintf(stderr, "GenEO subdomain %d: -hpddm_geneo_estimate_nu ignored (A - threshold B went through LU: its pivots do not carry the inertia)\n", first + s);
+    if (4 * nu > n) nu = std::max(1, n / 4);
+  }
   // ---- shifted operator  A_N + sigma B  (lower triangle), factorised like the preconditioner ----
   const double sigma = getopt("geneo_shift", 1.0e-2);
   std::vector<int>    sia(n + 1, 0), sja;
   std::vector<double> sa;
-  for (int i = 0; i < n; ++i) { // merge of the two sorted rows, lower triangle (a user-supplied B may have entries outside the pattern of A_N)
-    int pa = AN.ia[i], pb = B.ia[i];
-    while (true) {
-      const int ja_ = pa < AN.ia[i + 1] ? AN.ja[pa] : n, jb = pb < B.ia[i + 1] ? B.ja[pb] : n, j = std::min(ja_, jb);
-      if (j > i) break;
-      double v = 0.0;
-      if (ja_ == j) v += AN.a[pa++];
-      if (jb == j) v += sigma * B.a[pb++];
-      sja.push_back(j);
-      sa.push_back(v);
-    }
-    sia[i + 1] = (int)sja.size();
-  }
+  shifted_lower(sigma, sia, sja, sa);
   LocalSolver shifted;
   shifted.leaf_size    = (int)getopt("leaf_size", 32);
   shifted.release_host = true;

@@ -255,6 +255,15 @@ std::string LocalSolver::probe(const CsrView &A, FactKind kind)
          "); pivots are taken inside the diagonal tiles of a supernode only (static structure) -- use a local solver with dynamic pivoting for this operator";
 }
 
+int LocalSolver::negative_pivots() const
+{
+  if (host.kind == FACT_CHOL) return 0;
+  if (host.kind != FACT_LDLT || host.cplx || (idx_t)host.dinv.size() < host.n) return -1;
+  int neg = 0;
+  for (idx_t i = 0; i < host.n; ++i) neg += host.dinv[i] < 0.0;
+  return neg;
+}
+
 void LocalSolver::solve_device(const double *b, double *x, int mu)
 {
   HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");

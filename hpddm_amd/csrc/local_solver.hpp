@@ -26,6 +26,10 @@ struct LocalSolver {
   bool adopt_analysis(const LocalSolver &other, const CsrView &A); // same sparsity pattern as a solver already analysed: copy its ordering and symbolic factorisation
   void analyse(const CsrView &A); // ordering + symbolic factorisation (host only, thread-safe across solvers); numfact calls it if needed
   void numfact(const CsrView &A, int spd);
+  // Solver::inertia (include/HPDDM_MUMPS.hpp:292-302: MUMPS' INFOG(12), the number of negative pivots): from D of the last L D L^T
+  // factorisation (Sylvester: 1 x 1 pivots, no exchange); 0 for a Cholesky factor; -1 when the factor is an LU one (the pivots of a
+  // row-pivoted LU do not carry the inertia) or complex
+  int  negative_pivots() const;
   void solve_host(const double *b, double *x, int mu);
   void solve_device(const double *b, double *x, int mu);
 };

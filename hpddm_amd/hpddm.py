@@ -92,6 +92,10 @@ class Subdomain:
         check((self._lib.HpddmHipSubdomainSolveZ if cplx else self._lib.HpddmHipSubdomainSolve)(self._h, _dptr(f), _dptr(sol), mu))
         return sol
 
+    def inertia(self):
+        """Solver::inertia: negative pivots of the last factorisation (-1: the factor is an LU one, or complex)"""
+        return int(self._lib.HpddmHipSubdomainInertia(self._h))
+
     def solve_device(self, b_ptr, x_ptr, mu=1):
         check(self._lib.HpddmHipSubdomainSolveDevice(self._h, ctypes.c_void_p(b_ptr), ctypes.c_void_p(x_ptr), mu))
 

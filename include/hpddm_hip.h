@@ -52,6 +52,10 @@ void HpddmHipSubdomainDestroy(HpddmHipSubdomain *S);
 /* Tuning knobs read at the next Numfact: "leaf_size" (dissection leaf, default 32), "keep_plain" (keep the plain
  * supernodal L on the host for HpddmHipSubdomainExportPlain), "host_only" (do not upload: analysis/inspection) */
 int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double value);
+/* Solver::inertia (include/HPDDM_MUMPS.hpp:292-302, used by Schwarz::solveGEVP with -hpddm_geneo_estimate_nu, include/HPDDM_schwarz.hpp:
+ * 686-703): number of negative pivots of the last factorisation -- read off D of the L D L^T factor (factorise with spd = 0); 0 for a
+ * Cholesky factor; -3 when the matrix went through LU or is complex (the pivots do not carry the inertia); -1 on error */
+int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S);
 /* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
  *               update-pool size, kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
  *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), 0

@@ -58,10 +58,14 @@ public:
                                  : HpddmHipSubdomainNumfact(&S_, A->n_, A->ia_, A->ja_, dptr(A->a_), A->sym_ ? 1 : 0, N, spd ? 1 : 0);
     if (rc != 0) std::cerr << "BUG HipSub, numfact: " << HpddmHipLastError() << std::endl; /* same error style as HPDDM_MUMPS.hpp:288 */
   }
+  /* Solver::inertia (include/HPDDM_MUMPS.hpp:292-302): factorise with detection (no Cholesky), return the number of negative pivots */
   template <char N = 'C'>
-  int inertia(MatrixCSR<K> *const &)
+  int inertia(MatrixCSR<K> *const &A)
   {
-    return 0;
+    numfact<N>(A, true);
+    const int neg = S_ ? HpddmHipSubdomainInertia(S_) : -1; /* -3: LU fall-back or complex scalars */
+    if (neg < 0) std::cerr << "BUG HipSub, inertia: the factor does not carry it (LU fall-back or complex scalars)" << std::endl;
+    return neg < 0 ? 0 : neg;
   }
   unsigned short deficiency() const { return 0; }
   /* Solver::solve, in place and out of place (include/HPDDM_MUMPS.hpp:304-317) */

@@ -110,3 +110,54 @@ def test_what_static_pivoting_cannot_do_is_refused():
         b = np.ones(512)
         assert np.abs(A @ S.solve(b) - b).max() < 1e-7 * np.abs(b).max() * abs(A).sum(axis=1).max()
     S.destroy()
+
+
+def test_inertia_from_the_ldlt_factor():
+    """Solver::inertia (include/HPDDM_MUMPS.hpp:292-302, MUMPS' INFOG(12)): the number of negative pivots of L D L^T = the number of
+    negative eigenvalues (Sylvester), against numpy.linalg.eigvalsh; 0 for a Cholesky factor; -3 when the matrix went through LU"""
+    import scipy.sparse as sp
+    from hpddm_amd import hpddm
+    n1 = 9
+    e = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n1, n1))
+    I = sp.identity(n1)
+    K = (sp.kron(sp.kron(e, I), I) + sp.kron(sp.kron(I, e), I) + sp.kron(sp.kron(I, I), e)).tocsr()
+    lam = np.linalg.eigvalsh(K.toarray())
+    for shift in (0.0, 0.5 * (lam[3] + lam[4]), 0.5 * (lam[40] + lam[41]), 0.5 * (lam[300] + lam[301])):
+        A = (K - shift * sp.identity(n1 ** 3)).tocsr()
+        M = sp.tril(A, format="csr")
+        M.sort_indices()
+        S = hpddm.Subdomain()
+        S.numfact(A.shape[0], M.indptr, M.indices, M.data, sym=True, spd=False)
+        expect = int((np.linalg.eigvalsh(A.toarray()) < 0).sum())
+        got = S.inertia()
+        kind = S.info()["kind"]
+        assert (kind == 1 and got == expect) or (kind == 2 and got == -3), (shift, kind, got, expect)
+        if shift == 0.0:
+            assert kind == 1 and got == 0
+        S.destroy()
+    S = hpddm.Subdomain()
+    M = sp.tril(K, format="csr")
+    S.numfact(K.shape[0], M.indptr, M.indices, M.data, sym=True, spd=True)
+    assert S.info()["kind"] == 0 and S.inertia() == 0          # Cholesky
+    S.destroy()
+
+
+def test_geneo_estimate_nu_counts_the_eigenvalues_below_the_threshold():
+    """-hpddm_geneo_estimate_nu (include/HPDDM_schwarz.hpp:686-703): nu = inertia(A_N - threshold B) instead of a guess"""
+    from hpddm_amd import hpddm
+    from hpddm_amd.generate import generate3d
+    from oracle.ras_oracle import Oracle, csr_full
+    subs = generate3d(12, 8, 2, sym=True, rhs="smooth", neumann=True)
+    thr = 0.35
+    A, d = hpddm.schwarz_from_subdomains(subs, options=f"-hpddm_operator_spd -hpddm_geneo_nu 3 -hpddm_geneo_threshold {thr} -hpddm_geneo_estimate_nu 1 -hpddm_eigensolver_tol 1e-9")
+    orc = Oracle(subs)
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    neumann = [csr_full(dict(sd, a=sd["a_neumann"])) for sd in subs]
+    ref = orc.geneo(neumann, 20)
+    for s, sd in enumerate(subs):
+        below = int((ref[s] <= thr).sum())
+        assert 1 <= below < 20
+        lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], sd["sym"])
+        assert len(lam) == max(1, below), (s, len(lam), below, ref[s])
+        assert np.all(np.abs(lam - ref[s][:len(lam)]) <= 1e-6 * np.maximum(np.abs(ref[s][:len(lam)]), 1e-3))
+    A.destroy()
