@@ -276,6 +276,22 @@ def main():
     # weak scaling: the unit is the apply of one GPU's 8-subdomain share (N of them per global apply); strong: the global apply
     value = global_applies if (args.strong and sharded) else world * global_applies
 
+    # the same step through the host-pointer boundary (HpddmHipSchwarzApply: what HipSub / the C API hand over are host vectors): both
+    # vectors cross PCIe through the library's pinned staging buffers.  Reported beside the line, never `value`.
+    pcie = None
+    if rank == 0 and world == 1:
+        xh = np.ones(ntot * mu * (2 if A.complex else 1))
+        yh = np.empty_like(xh)
+        A.apply_host_flat(xh, yh, mu)
+        th = time.perf_counter()
+        nh = max(3, min(10, args.steps))
+        for _ in range(nh):
+            A.apply_host_flat(xh, yh, mu)
+        th = (time.perf_counter() - th) / nh
+        extra = max(th - ms_per_step * 1e-3, 1e-9)
+        pcie = {"apply_ms": th * 1e3, "applies_per_sec": 1.0 / th, "bytes_over_pcie": 2.0 * xh.nbytes, "pcie_ms": extra * 1e3,
+                "effective_GBps": 2.0 * xh.nbytes / extra / 1e9,
+                "note": "HpddmHipSchwarzApply on pageable host vectors (in + out cross PCIe, segments through pinned buffers of the library, staging.hip); value / ms_per_step above are the device-resident apply"}
     if two_level:
         n = st["n"]
         t_defl = A.time("deflation", mu=mu, warmup=2, reps=reps)
@@ -353,6 +369,8 @@ def main():
         bytes_alg = 2.0 * st["nnz_L"] * sk + 4.0 * st["n"] * mu * sk   # 2*nnz(L)*sizeof(K) + 4*n*mu*sizeof(K)
         out["roofline"] = roofline(bytes_alg, t_solve, st, args, mu)
         out["phases_ms"] = phases
+        if pcie:
+            out["host_pointer_boundary"] = pcie
         out["one_level"] = one
         if tl:
             out["two_level"] = tl

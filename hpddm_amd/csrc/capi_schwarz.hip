@@ -27,10 +27,9 @@ void host_roundtrip(Schwarz &A, const double *in, double *out, int mu, F &&f)
   A.reserve(mu);
   hipStream_t  st  = library_stream();
   const size_t cnt = (size_t)A.ntot * mu;
-  HIP_OK(hipMemcpyAsync(A.hin.p, in, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+  staged_h2d(A.hin.p, in, cnt * sizeof(double), st);
   f(A.hin.p, A.hout.p);
-  HIP_OK(hipMemcpyAsync(out, A.hout.p, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_OK(hipStreamSynchronize(st));
+  staged_d2h(out, A.hout.p, cnt * sizeof(double), st);
 }
 // the reference's enumerated option values (include/HPDDM_option_impl.hpp:41-178)
 double parse_value(const std::string &key, const std::string &val)

@@ -44,6 +44,12 @@ struct DevBuf {
   void upload(const std::vector<T> &h, hipStream_t s = nullptr) { upload(h.data(), h.size(), s); }
 };
 
+// staging.hip: host <-> device copies of the caller's (pageable) vectors through pinned buffers of the library, several host threads
+// per segment, the DMA of one segment under the memcpy of the next.  staged_h2d returns when the source may be reused, staged_d2h when
+// the data has landed.
+void staged_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st);
+void staged_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st);
+
 // One supernode as the kernels see it (absolute device pointers; indices local to the subdomain).
 struct SnDesc {
   const double *F;     // forward panel  (h x ldw, row-major)

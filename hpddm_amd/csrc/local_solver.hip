@@ -276,10 +276,9 @@ void LocalSolver::solve_host(const double *b, double *x, int mu)
   const size_t cnt = (size_t)host.n * mu * (host.cplx ? 2 : 1);
   hipStream_t  s   = library_stream();
   bdev.alloc(cnt);
-  HIP_OK(hipMemcpyAsync(bdev.p, b, cnt * sizeof(double), hipMemcpyHostToDevice, s));
+  staged_h2d(bdev.p, b, cnt * sizeof(double), s);
   plan.solve(bdev.p, bdev.p, mu, s);
-  HIP_OK(hipMemcpyAsync(x, bdev.p, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  staged_d2h(x, bdev.p, cnt * sizeof(double), s);
 }
 
 } // namespace hpddm_hip

@@ -465,6 +465,10 @@ class Schwarz:
         check(self._lib.HpddmHipSchwarzSetCustomOperator(self._h, as_ptr(self._custom_cbs[0]), as_ptr(self._custom_cbs[1]), None))
 
     # -- device-resident variants (raw HBM pointers) --
+    def apply_host_flat(self, flat_in, flat_out, mu=1):
+        """HpddmHipSchwarzApply on flat host arrays in the batched layout (the host-pointer boundary: both vectors cross PCIe)"""
+        check(self._lib.HpddmHipSchwarzApply(self._h, _dptr(flat_in), _dptr(flat_out), mu))
+
     def apply_device(self, in_ptr, out_ptr, mu=1):
         check(self._lib.HpddmHipSchwarzApplyDevice(self._h, ctypes.c_void_p(in_ptr), ctypes.c_void_p(out_ptr), mu))
 
