@@ -531,7 +531,6 @@ int HpddmHipSchwarzSetCustomOperator(HpddmHipSchwarz *A, int (*mv)(void *, const
 {
   HH_TRY(
     HH_CHECK(A && (mv || !precond), "bad argument (a preconditioner callback needs an operator callback)");
-    HH_CHECK(!A->op.is_complex, "custom operators are built for K = double");
     HH_CHECK(A->op.nsub == 1 || !mv, "a custom operator is ONE block of rows per rank (HpddmHipSchwarzCreate with nsub = 1)");
     A->op.custom_mv      = mv;
     A->op.custom_precond = precond;

@@ -432,17 +432,17 @@ int HpddmSolve(HpddmSchwarz *S, const K *b, K *sol, int mu, const MPI_Comm *comm
 // IterativeMethod::solve.  Here: a one-subdomain operator without neighbours whose GMV / apply are the callbacks (d = 1, the
 // identity matrix only gives the operator its size), solved by the same device-resident Krylov methods as HpddmSolve.
 struct HpddmCustomOperator;
-#ifndef FORCE_COMPLEX
 namespace {
 struct CustomCtx {
   const HpddmCustomOperator *op;
-  int (*mv)(const HpddmCustomOperator *, const double *, double *, int);
-  int (*precond)(const HpddmCustomOperator *, const double *, double *, int);
+  int (*mv)(const HpddmCustomOperator *, const K *, K *, int);
+  int (*precond)(const HpddmCustomOperator *, const K *, K *, int);
 };
-int custom_mv_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->mv(((CustomCtx *)ctx)->op, in, out, mu); }
-int custom_pc_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->precond(((CustomCtx *)ctx)->op, in, out, mu); }
+// the library hands the callbacks arrays of doubles: for K = double _Complex they are the (re, im) pairs of the caller's vectors
+int custom_mv_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->mv(((CustomCtx *)ctx)->op, reinterpret_cast<const K *>(in), reinterpret_cast<K *>(out), mu); }
+int custom_pc_cb(void *ctx, const double *in, double *out, int mu) { return ((CustomCtx *)ctx)->precond(((CustomCtx *)ctx)->op, reinterpret_cast<const K *>(in), reinterpret_cast<K *>(out), mu); }
 } // namespace
-int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(const HpddmCustomOperator *, const double *, double *, int), int (*precond)(const HpddmCustomOperator *, const double *, double *, int), const double *b, double *sol, int mu, const MPI_Comm *comm)
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(const HpddmCustomOperator *, const K *, K *, int), int (*precond)(const HpddmCustomOperator *, const K *, K *, int), const K *b, K *sol, int mu, const MPI_Comm *comm)
 {
   HpddmSchwarz S;
   if (comm) S.comm = *comm;
@@ -450,12 +450,17 @@ int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(con
   MPI_Comm_size(S.comm, &S.size);
   select_device(S.rank);
   std::vector<int>    ia(n + 1), ja(n);
-  std::vector<double> a(n, 1.0), d(n, 1.0);
+  std::vector<K>      a(n, K(1.0));
+  std::vector<double> d(n, 1.0);
   for (int i = 0; i < n; ++i) ia[i] = ja[i] = i;
   ia[n] = n;
   S.A   = HpddmHipSchwarzCreate(1, S.rank, S.size);
   if (!S.A) fail("HpddmCustomOperatorSolve");
+#ifdef FORCE_COMPLEX
+  CK(HpddmHipSchwarzSetSubdomainZ(S.A, 0, n, ia.data(), ja.data(), dp(a.data()), 0, 'C', 0, nullptr, nullptr, nullptr), "HpddmCustomOperatorSolve");
+#else
   CK(HpddmHipSchwarzSetSubdomain(S.A, 0, n, ia.data(), ja.data(), a.data(), 0, 'C', 0, nullptr, nullptr, nullptr), "HpddmCustomOperatorSolve");
+#endif
   std::vector<int> firsts(S.size + 1);
   for (int r = 0; r <= S.size; ++r) firsts[r] = r;
   CK(HpddmHipSchwarzSetPartition(S.A, S.size, S.rank, firsts.data()), "HpddmCustomOperatorSolve");
@@ -464,22 +469,13 @@ int HpddmCustomOperatorSolve(const HpddmCustomOperator *op, int n, int (*mv)(con
   CK(HpddmHipSchwarzSetCustomOperator(S.A, mv ? custom_mv_cb : nullptr, precond ? custom_pc_cb : nullptr, &ctx), "HpddmCustomOperatorSolve");
   sync_options(&S);
   ensure_transport(&S, mu);
-  const int it = HpddmHipSolve(S.A, b, sol, mu, nullptr, 0);
+  const int it = HpddmHipSolve(S.A, dp(b), dp(sol), mu, nullptr, 0);
   if (it < 0) fail("HpddmCustomOperatorSolve");
   HpddmHipSchwarzDestroy(S.A);
   if (S.send_d) (void)hipFree(S.send_d);
   if (S.recv_d) (void)hipFree(S.recv_d);
   return it;
 }
-#else
-// (callbacks on complex host vectors: the custom-operator entry point of hpddm_hip.h is real in this build)
-int HpddmCustomOperatorSolve(const HpddmCustomOperator *, int, int (*)(const HpddmCustomOperator *, const K *, K *, int), int (*)(const HpddmCustomOperator *, const K *, K *, int), const K *, K *, int, const MPI_Comm *)
-{
-  fprintf(stderr, "libhpddm_c_hip_z: HpddmCustomOperatorSolve is not available for complex scalars in this build\n");
-  MPI_Abort(MPI_COMM_WORLD, 1);
-  return -1;
-}
-#endif
 
 double nrm2(const int *n, const K *x, const int *inc)
 {

@@ -382,7 +382,10 @@ int zgmres_impl(Schwarz &A, const double *b, double *x, double *history, int his
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Block GMRES (no right-hand-side deflation for complex scalars in this build)
+// Block GMRES, with the right-hand-side deflation of -hpddm_deflation_tol (RRQR, include/HPDDM_iterative.hpp:583-595; the restart
+// logic of include/HPDDM_GMRES.hpp:199-232, updateSol with the permuted columns include/HPDDM_iterative.hpp:318-333): pivoted Cholesky
+// of the Hermitian Gram matrix of the residual block at every restart, the cycle iterates on its d leading columns -- the deflated
+// columns stay as zero columns of the device blocks -- and the others follow through R11^{-1} R12
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MU>
 int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
@@ -395,8 +398,9 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
   const int    variant   = (int)A.getopt("variant", VARIANT_RIGHT);
   const int    verbosity = (int)A.getopt("verbosity", 0);
   HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT || variant == VARIANT_FLEXIBLE, "BGMRES: unknown variant");
-  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGMRES: right-hand-side deflation is built for real scalars only");
-  const bool  flexible = variant == VARIANT_FLEXIBLE;
+  const double defl_tol  = A.getopt("deflation_tol", -1.0);
+  const bool   deflation = defl_tol > -0.9;
+  const bool   flexible  = variant == VARIANT_FLEXIBLE;
   ZBlocks<MU> Z(A, m + 1);
   const long long cnt = Z.cnt;
   const int       ldh = mu * (m + 1);
@@ -404,13 +408,13 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
   V.alloc((size_t)cnt * ((flexible ? 2 * m : m) + 1));
   Ax.alloc((size_t)cnt);
   auto vk = [&](int k) { return V.p + (size_t)k * cnt; };
-  // CholQR: G = R^H R (R upper, row-major); W <- W R^{-1} if update; returns the rank
-  auto cholqr = [&](double *W, std::vector<cplx> &R, bool update) {
+  // CholQR of the d leading columns: G = R^H R (R upper, row-major mu x mu); W <- W R^{-1} if update; returns the rank
+  auto cholqr = [&](double *W, std::vector<cplx> &R, bool update, int d) {
     std::vector<cplx> G;
     Z.gram(W, 1, W, G);
     R.assign((size_t)mu * mu, 0.0);
-    int rank = mu;
-    for (int j = 0; j < mu; ++j) {
+    int rank = d;
+    for (int j = 0; j < d; ++j) {
       double dj = G[(size_t)j * mu + j].real();
       for (int k = 0; k < j; ++k) dj -= std::norm(R[(size_t)k * mu + j]);
       if (!(dj > 0.0)) {
@@ -419,15 +423,15 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
       }
       dj                    = std::sqrt(dj);
       R[(size_t)j * mu + j] = dj;
-      for (int c = j + 1; c < mu; ++c) {
+      for (int c = j + 1; c < d; ++c) {
         cplx v = G[(size_t)j * mu + c];
         for (int k = 0; k < j; ++k) v -= std::conj(R[(size_t)k * mu + j]) * R[(size_t)k * mu + c];
         R[(size_t)j * mu + c] = v / dj;
       }
     }
-    if (rank == mu && update) {
+    if (rank == d && update) {
       std::vector<cplx> Rinv((size_t)mu * mu, 0.0);
-      for (int c = 0; c < mu; ++c)
+      for (int c = 0; c < d; ++c)
         for (int i = c; i >= 0; --i) {
           cplx v = (i == c) ? 1.0 : 0.0;
           for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
@@ -438,9 +442,64 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
     }
     return rank;
   };
+  // RRQR: pivoted Cholesky (zpstrf "U") of the Gram matrix of W, rank trimmed while |R[rank-1][rank-1] / R[0][0]| <= tol;
+  // W <- (W P)(:, :rank) R11^{-1} in its leading columns, zero elsewhere.  R holds R11 and R12 in its first `rank` rows.
+  auto rrqr = [&](double *W, std::vector<cplx> &R, std::vector<int> &piv) {
+    std::vector<cplx> G;
+    Z.gram(W, 1, W, G);
+    R.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int j = 0; j < mu; ++j) {
+      int    q    = j;
+      double best = 0.0;
+      for (int c = j; c < mu; ++c) {
+        double dj = G[(size_t)c * mu + c].real();
+        for (int k = 0; k < j; ++k) dj -= std::norm(R[(size_t)k * mu + c]);
+        if (c == j || dj > best) best = dj, q = c;
+      }
+      if (!(best > 0.0)) {
+        rank = j;
+        break;
+      }
+      if (q != j) {
+        for (int c = 0; c < mu; ++c) std::swap(G[(size_t)j * mu + c], G[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(G[(size_t)r * mu + j], G[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(R[(size_t)r * mu + j], R[(size_t)r * mu + q]);
+        std::swap(piv[j], piv[q]);
+      }
+      const double dj       = std::sqrt(best);
+      R[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        cplx v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= std::conj(R[(size_t)k * mu + j]) * R[(size_t)k * mu + c];
+        R[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    for (int r = rank; r < mu; ++r)
+      for (int c = 0; c < mu; ++c) R[(size_t)r * mu + c] = 0.0;
+    while (rank > 1 && std::abs(R[(size_t)(rank - 1) * mu + rank - 1] / R[0]) <= defl_tol) --rank;
+    if (rank > 0) {
+      std::vector<cplx> Rinv((size_t)mu * mu, 0.0), C((size_t)mu * mu, 0.0);
+      for (int c = 0; c < rank; ++c)
+        for (int i = c; i >= 0; --i) {
+          cplx v = (i == c) ? 1.0 : 0.0;
+          for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
+          Rinv[(size_t)i * mu + c] = v / R[(size_t)i * mu + i];
+        }
+      for (int k = 0; k < rank; ++k)
+        for (int c = 0; c < rank; ++c) C[(size_t)piv[k] * mu + c] = Rinv[(size_t)k * mu + c];
+      HIP_OK(hipMemcpyAsync(Ax.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, Z.st));
+      Z.axpy(Ax.p, 1, C, 1.0, 0.0, W);
+    }
+    return rank;
+  };
+  std::vector<int>    piv(mu);
+  std::vector<cplx>   S12, T;
+  int                 d = mu; // columns the current cycle iterates on
   std::vector<cplx>   H((size_t)ldh * mu * m, 0.0), s((size_t)ldh * mu, 0.0), tau((size_t)m * 2 * mu, 0.0), G, R;
-  std::vector<double> norm(mu);
-  auto                Hc = [&](int i) { return H.data() + (size_t)i * mu * ldh; };
+  std::vector<double> norm(mu), normp(mu);
+  auto                Hc = [&](int i) { return H.data() + (size_t)i * d * ldh; };
   A.start(b, x, mu);
   {
     std::vector<cplx> nb;
@@ -460,20 +519,49 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
   bool breakdown = false;
   auto update_sol = [&](int dimc) {
     if (dimc <= 0) return;
-    std::vector<cplx> Y((size_t)dimc * mu, 0.0); // row-major dimc x mu
-    for (int c = 0; c < mu; ++c)
+    std::vector<cplx> Y((size_t)dimc * d, 0.0); // row-major dimc x d
+    for (int c = 0; c < d; ++c)
       for (int r = dimc - 1; r >= 0; --r) {
         cplx v = s[r + (size_t)c * ldh];
-        for (int k = r + 1; k < dimc; ++k) v -= H[r + (size_t)k * ldh] * Y[(size_t)k * mu + c];
-        Y[(size_t)r * mu + c] = v / H[r + (size_t)r * ldh];
+        for (int k = r + 1; k < dimc; ++k) v -= H[r + (size_t)k * ldh] * Y[(size_t)k * d + c];
+        Y[(size_t)r * d + c] = v / H[r + (size_t)r * ldh];
       }
-    const int kblocks = dimc / mu;
-    if (variant == VARIANT_LEFT) Z.axpy(vk(0), kblocks, Y, 1.0, 1.0, x);
-    else if (flexible) Z.axpy(vk(m + 1), kblocks, Y, 1.0, 1.0, x);
+    const int kblocks = dimc / d;
+    // the coefficients as (kblocks mu) x mu blocks of the device layout (deflated columns: zero rows and columns)
+    std::vector<cplx> C((size_t)kblocks * mu * mu, 0.0);
+    if (!deflation) {
+      for (int k = 0; k < kblocks; ++k)
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) C[((size_t)k * mu + a) * mu + c] = Y[((size_t)k * d + a) * d + c];
+      if (variant == VARIANT_LEFT) Z.axpy(vk(0), kblocks, C, 1.0, 1.0, x);
+      else if (flexible) Z.axpy(vk(m + 1), kblocks, C, 1.0, 1.0, x);
+      else {
+        Z.axpy(vk(0), kblocks, C, 1.0, 0.0, Ax.p);
+        A.apply(Ax.p, vk(m), mu);
+        Z.axpby(1.0, x, 1.0, vk(m), x);
+      }
+      return;
+    }
+    // x P gets [corr, corr R11^{-1} R12] (include/HPDDM_iterative.hpp:318-333): x += corr T, T[k][piv[k]] = 1, T[k][piv[d + q]] = S12[k][q]
+    T.assign((size_t)mu * mu, 0.0);
+    for (int k = 0; k < d; ++k) {
+      T[(size_t)k * mu + piv[k]] = 1.0;
+      for (int q = 0; q < mu - d; ++q) T[(size_t)k * mu + piv[d + q]] = S12[(size_t)k * (mu - d) + q];
+    }
+    const bool direct = variant != VARIANT_RIGHT; // left / flexible: no preconditioner between the combination and x
+    for (int k = 0; k < kblocks; ++k)
+      for (int a = 0; a < d; ++a)
+        for (int c = 0; c < d; ++c) {
+          const cplx y = Y[((size_t)k * d + a) * d + c];
+          if (!direct) C[((size_t)k * mu + a) * mu + c] = y;
+          else
+            for (int col = 0; col < mu; ++col) C[((size_t)k * mu + a) * mu + col] += y * T[(size_t)c * mu + col];
+        }
+    if (direct) Z.axpy(flexible ? vk(m + 1) : vk(0), kblocks, C, 1.0, 1.0, x);
     else {
-      Z.axpy(vk(0), kblocks, Y, 1.0, 0.0, Ax.p);
+      Z.axpy(vk(0), kblocks, C, 1.0, 0.0, Ax.p);
       A.apply(Ax.p, vk(m), mu);
-      Z.axpby(1.0, x, 1.0, vk(m), x);
+      Z.axpy(vk(m), 1, T, 1.0, 1.0, x);
     }
   };
   while (j <= max_it) {
@@ -481,13 +569,30 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
     A.gmv(x, r0, mu);
     Z.axpby(1.0, b, -1.0, r0, r0);
     if (variant == VARIANT_LEFT) A.apply(Ax.p, vk(0), mu);
-    if (cholqr(vk(0), R, true) != mu) {
-      breakdown = true;
-      break;
+    if (deflation) {
+      d = rrqr(vk(0), R, piv);
+      if (d == 0) { // zero residual block (include/HPDDM_GMRES.hpp:206-216)
+        j = 0;
+        break;
+      }
+      S12.assign((size_t)d * (mu - d), 0.0); // R11^{-1} R12 (trtrs, include/HPDDM_GMRES.hpp:222-227)
+      for (int q = 0; q < mu - d; ++q)
+        for (int r = d - 1; r >= 0; --r) {
+          cplx v = R[(size_t)r * mu + d + q];
+          for (int k = r + 1; k < d; ++k) v -= R[(size_t)r * mu + k] * S12[(size_t)k * (mu - d) + q];
+          S12[(size_t)r * (mu - d) + q] = v / R[(size_t)r * mu + r];
+        }
+      for (int k = 0; k < mu; ++k) normp[k] = norm[piv[k]];
+    } else {
+      if (cholqr(vk(0), R, true, mu) != mu) {
+        breakdown = true;
+        break;
+      }
+      normp = norm;
     }
-    dim = mu * (j - 1 + m > max_it ? max_it - j + 1 : m);
+    dim = d * (j - 1 + m > max_it ? max_it - j + 1 : m);
     std::fill(s.begin(), s.end(), cplx(0.0));
-    for (int c = 0; c < mu; ++c)
+    for (int c = 0; c < d; ++c)
       for (int r = 0; r <= c; ++r) s[r + (size_t)c * ldh] = R[(size_t)r * mu + c];
     std::fill(H.begin(), H.end(), cplx(0.0));
     std::fill(tau.begin(), tau.end(), cplx(0.0));
@@ -505,33 +610,38 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
       Z.axpy(vk(0), i + 1, G, -1.0, 1.0, vk(i + 1));
       cplx *Hi = Hc(i);
       for (int kk = 0; kk <= i; ++kk)
-        for (int a = 0; a < mu; ++a)
-          for (int c = 0; c < mu; ++c) Hi[(kk * mu + a) + (size_t)c * ldh] = G[((size_t)kk * mu + a) * mu + c];
-      if (cholqr(vk(i + 1), R, i < m - 1) != mu) {
+        for (int a = 0; a < d; ++a)
+          for (int c = 0; c < d; ++c) Hi[(kk * d + a) + (size_t)c * ldh] = G[((size_t)kk * mu + a) * mu + c];
+      if (cholqr(vk(i + 1), R, i < m - 1, d) != d) { // rank-deficient block: the reference drops this cycle and restarts with GMRES
         breakdown = true;
         break;
       }
-      for (int c = 0; c < mu; ++c)
-        for (int r = 0; r < mu; ++r) Hi[((i + 1) * mu + r) + (size_t)c * ldh] = r <= c ? R[(size_t)r * mu + c] : cplx(0.0);
-      for (int k = 0; k < i; ++k) zunm2r_lc(2 * mu, mu, mu, Hc(k) + k * mu, ldh, tau.data() + (size_t)k * 2 * mu, Hi + k * mu, ldh);
-      zgeqr2(2 * mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu);
-      zunm2r_lc(2 * mu, mu, mu, Hi + i * mu, ldh, tau.data() + (size_t)i * 2 * mu, s.data() + i * mu, ldh);
+      for (int c = 0; c < d; ++c)
+        for (int r = 0; r < d; ++r) Hi[((i + 1) * d + r) + (size_t)c * ldh] = r <= c ? R[(size_t)r * mu + c] : cplx(0.0);
+      for (int k = 0; k < i; ++k) zunm2r_lc(2 * d, d, d, Hc(k) + k * d, ldh, tau.data() + (size_t)k * 2 * mu, Hi + k * d, ldh);
+      zgeqr2(2 * d, d, Hi + i * d, ldh, tau.data() + (size_t)i * 2 * mu);
+      zunm2r_lc(2 * d, d, d, Hi + i * d, ldh, tau.data() + (size_t)i * 2 * mu, s.data() + i * d, ldh);
       ++i;
-      int    conv = 0, which = 0;
+      // checkBlockConvergence: the mu - d deflated right-hand sides count as converged
+      int    conv = mu - d, which = 0;
       double best = -1.0;
-      for (int nu = 0; nu < mu; ++nu) {
+      for (int nu = 0; nu < d; ++nu) {
         double nrm = 0.0;
-        for (int r = 0; r <= nu; ++r) nrm += std::norm(s[(mu * i + r) + (size_t)nu * ldh]);
+        for (int r = 0; r <= nu; ++r) nrm += std::norm(s[(d * i + r) + (size_t)nu * ldh]);
         nrm = std::sqrt(nrm);
-        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
-        if (nrm / norm[nu] > best) best = nrm / norm[nu], which = nu;
+        if ((tol > 0.0 && nrm / normp[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / normp[nu] > best) best = nrm / normp[nu], which = nu;
       }
-      const double beta = best * norm[which];
+      const double beta = best * normp[which];
       if (history && nhist < history_cap) history[nhist] = beta;
       ++nhist;
-      if (verbosity > 2) printf("BGMRES: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
+      if (verbosity > 2) {
+        printf("BGMRES: %3d %e %e %e < %e", j, beta, normp[which], best, tol);
+        if (d != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - d);
+        printf("\n");
+      }
       if (conv == mu) {
-        dim = mu * i;
+        dim = d * i;
         i   = 0;
         break;
       }
@@ -546,9 +656,9 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
   if (breakdown) return -2;
   if (j == max_it + 1 && m > 0) {
     const int rem = max_it % m;
-    if (rem != 0) dim = mu * rem;
+    if (rem != 0) dim = d * rem;
   }
-  update_sol(dim);
+  if (j != 0) update_sol(dim);
   if (verbosity) {
     if (j != max_it + 1) printf("BGMRES converges after %d iteration%s\n", j, j > 1 ? "s" : "");
     else printf("BGMRES does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
@@ -573,14 +683,14 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
 
 int Schwarz::gmres_z(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored && is_complex, "complex GMRES: complex operator and CallNumfact first");
+  HH_CHECK((factored || custom_mv) && is_complex, "complex GMRES: complex operator and CallNumfact first");
   int it;
   HH_MU_DISPATCH(zgmres_impl, "GMRES")
   return it;
 }
 int Schwarz::bgmres_z(const double *b, double *x, int mu, double *history, int history_cap)
 {
-  HH_CHECK(factored && is_complex, "complex BGMRES: complex operator and CallNumfact first");
+  HH_CHECK((factored || custom_mv) && is_complex, "complex BGMRES: complex operator and CallNumfact first");
   int it;
   HH_MU_DISPATCH(zbgmres_impl, "BGMRES")
   if (it == -2) return gmres_z(b, x, mu, history, history_cap); // breakdown of a CholQR: GMRES, as the reference does

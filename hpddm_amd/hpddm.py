@@ -450,8 +450,12 @@ class Schwarz:
             def cb(_ctx, pin, pout, mu):
                 try:
                     rows = self._custom_n
-                    xin = np.ctypeslib.as_array(pin, shape=(mu * rows,)).reshape((rows, mu), order="F")
-                    xout = np.ctypeslib.as_array(pout, shape=(mu * rows,)).reshape((rows, mu), order="F")
+                    if self.complex:   # the library hands over (re, im) pairs: complex views of the same memory
+                        xin = np.ctypeslib.as_array(pin, shape=(2 * mu * rows,)).view(np.complex128).reshape((rows, mu), order="F")
+                        xout = np.ctypeslib.as_array(pout, shape=(2 * mu * rows,)).view(np.complex128).reshape((rows, mu), order="F")
+                    else:
+                        xin = np.ctypeslib.as_array(pin, shape=(mu * rows,)).reshape((rows, mu), order="F")
+                        xout = np.ctypeslib.as_array(pout, shape=(mu * rows,)).reshape((rows, mu), order="F")
                     fn(xin, xout)
                     return 0
                 except Exception:   # never unwind through the C frames

@@ -59,6 +59,8 @@ CASES = [
     # complex optimised local matrices (callNumfact(A_opt) with K = std::complex<double>: what ORAS does for Helmholtz), OG and OS
     ("z_p30_oras_og_mu2", 4, 2, "-Nx 30 -Ny 30 -overlap 2 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_method oras -optimized_shift 30 -optimized_shift_im 20"),
     ("z_p30_soras_os_deflated", 4, 2, "-Nx 30 -Ny 30 -overlap 2 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_method soras -optimized_shift 20 -optimized_shift_im 10 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    # complex Block GMRES with right-hand-side deflation (RRQR of the residual block, include/HPDDM_iterative.hpp:583-595)
+    ("z_p30_bgmres_rhs_deflation_mu4", 4, 4, "-Nx 30 -Ny 30 -dependent_rhs 1 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-6"),
     # several deflation vectors per subdomain (the constant one + smooth local ones, dumped as ev): coarse blocks larger than 1 x 1
     ("p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p40_bfbcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_tol 1e-4"),

@@ -202,3 +202,37 @@ def test_cg_on_a_hermitian_positive_definite_operator():
     r = [ff - g for ff, g in zip(f, orc.gmv(sol))]        # the true residual of the device's solution
     assert max(np.abs(x).max() for x in r) <= 1e-5 * max(np.abs(x).max() for x in f)
     A.destroy()
+
+
+def test_custom_operator_callbacks_with_complex_scalars():
+    """HpddmCustomOperatorSolve for K = std::complex<double> (interface/hpddm_c.cpp:227-230 builds it for every K): GMRES and Block GMRES
+    (with and without right-hand-side deflation) on callbacks that see complex host vectors -- a complex symmetric tridiagonal operator
+    with its Jacobi preconditioner -- against a direct solve"""
+    n, mu = 120, 3
+    diag = (np.arange(n) + 2.0) * (1.0 + 0.3j)
+    T = sp.diags([-0.5 * np.ones(n - 1), diag, (-0.5 + 0.1j) * np.ones(n - 1)], [-1, 0, 1], format="csr")
+
+    def mv(x, y):
+        assert x.dtype == np.complex128
+        y[:] = T @ x
+
+    def pc(x, y):
+        y[:] = x / diag[:, None]
+
+    eye = sp.identity(n, format="csr", dtype=np.complex128)
+    A = hpddm.Schwarz(1)
+    A.set_subdomain(0, n, eye.indptr, eye.indices, eye.data, False, [], [])
+    A.initialize([np.ones(n)])
+    A.set_custom_operator(mv, pc)
+    rng = np.random.default_rng(11)
+    b = np.asfortranarray(rng.random((n, mu)) + 1j * rng.random((n, mu)))
+    b[:, 2] = b[:, 0] - 2.0j * b[:, 1]          # a dependent right-hand side for the deflation
+    exact = spl.spsolve(T.tocsc(), b)
+    for opts in ("-hpddm_krylov_method gmres", "-hpddm_krylov_method bgmres", "-hpddm_krylov_method bgmres -hpddm_deflation_tol 1e-8",
+                 "-hpddm_krylov_method gmres -hpddm_variant left"):
+        A.set_option("deflation_tol", -1.0)
+        A.option_parse(opts + " -hpddm_tol 1e-9")
+        it, sol = A.solve([b])
+        assert 0 < it <= 20, (opts, it)
+        assert np.abs(sol[0] - exact).max() <= 1e-7 * np.abs(exact).max(), opts
+    A.destroy()
