@@ -532,8 +532,8 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     on a bounded SAMPLE of its subdomains: the first `ns` of them are factorised once more with the plain factor kept on the host
     (HpddmHipSubdomainNumfact with keep_plain -- after the timed region, so that the set-up of the operator above does not pay the
     copies: 12 GB per 129^3 subdomain), the cost of the whole operator follows by the ratio of the factor sizes.
-    (a) one thread per subdomain -- the reference's layout, one MPI rank per subdomain with a sequential local solve: the subdomains run
-        side by side, so the sample's time IS the estimate (no scaling);
+    (a) one thread per subdomain -- the reference's layout, one MPI rank per subdomain with a sequential local solve: as many concurrent
+        substitutions as the operator has subdomains (the sampled factors swept several times side by side), so the time IS the estimate;
     (b) level-scheduled over the assembly tree on a team of threads, all the sampled subdomains at once (tree parallelism at the bottom,
         the whole team on the large supernodes near the root) -- what a threaded MUMPS / PARDISO solve phase does; scaled by the sizes;
     (c) a team of threads per subdomain filling the CPUs this container may use; scaled by the sizes.
@@ -571,7 +571,13 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
             reps += 1
         return tsolve / reps, reps, xs
 
-    ta, ra, xs = sample(lambda r: sptrsv_oracle.time_batch(factors, f, reps=r, threads=threads))
+    # (a) in the layout of the whole operator: as many concurrent substitutions as it has subdomains, one thread each -- the sampled
+    # factors are swept by nsub / ns threads each (12 GB per sweep: no cache holds them, the threads share the memory bandwidth as
+    # the real layout would)
+    rep_n = max(1, min(nsub, ncores) // ns)
+    fa, ba = factors * rep_n, f * rep_n
+    ta, ra, xs = sample(lambda r: sptrsv_oracle.time_batch(fa, ba, reps=r, threads=len(fa)))
+    xs = xs[:ns]
     # against the device path on the same right-hand side (the sample's subdomains)
     xg = A.local_solve([np.ones(s["n"]) for s in subs])
     agree_gpu = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xg[:ns]))
@@ -632,7 +638,7 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "kind": "port", "cgroup_cpu_max": quota, "sched_affinity_cpus": affinity,
             "sample": f"one-level apply of the same {nsub}-subdomain operator, substitutions timed on {ns} of its {nsub} subdomains ({100.0 / scale:.0f} % of the factor entries; "
                       f"their plain factors made by {ns} extra factorisations after the timed region, {t_sample:.1f} s) + numpy halo sum of all {nsub} ({tex * 1e3:.1f} ms): "
-                      f"(a) one thread per subdomain, {ra} applies, {ta * 1e3:.1f} ms (the {nsub} run side by side: not scaled); "
+                      f"(a) one thread per subdomain, {ns * rep_n} concurrent substitutions on {ns * rep_n} threads (the sampled factors swept {rep_n} times side by side), {ra} applies, {ta * 1e3:.1f} ms; "
                       f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms for the sample = {eb * 1e3:.1f} ms scaled; "
                       f"(c) {team} threads per subdomain = {ns * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs), {rc} applies, {tc * 1e3:.1f} ms = {ec * 1e3:.1f} ms scaled; "
                       f"value = the fastest; the three agree to {agree:.1e}, with the device solve to {agree_gpu:.1e}",
