@@ -424,22 +424,21 @@ def two_level_setup(A, subs, args, np, geneo):
         # DtN coarse space: Schwarz::solveGEVP(A, B) with the caller's B (include/HPDDM_schwarz.hpp:665-666) -- the local Neumann matrix
         # (absorbing physical boundary) against the mass matrix of the artificial interface; complex block Arnoldi on the device
         A.set_option("geneo_nu", nu)
-        lam_abs = 0.0
-        for s, sd in enumerate(subs):
-            lam = A.solve_gevp(s, sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], False, B=sd["b_dtn"] + (False,))
-            lam_abs = max(lam_abs, float(np.abs(lam[-1])))
+        lams = A.solve_gevp_all([(sd["n"], sd["ia"], sd["ja"], sd["a_neumann"], False, sd["b_dtn"] + (False,)) for sd in subs])
+        lam_abs = max(float(np.abs(lam[-1])) for lam in lams)
         tg = time.time() - tg
         t0 = time.time()
         A.build_coarse_operator()
         return {"geneo_nu": nu, "coarse_dim": int(A.stats()["coarse_dim"]), "coarse_setup_seconds": round(time.time() - t0, 2), "coarse_space_seconds": round(tg, 2),
                 "coarse_space": "DtN: solveGEVP(A_Neumann, B_interface) on the device (complex block Arnoldi, shift-invert on the complex SpTRSV), "
                                 "%d vectors per subdomain, largest kept |lambda| %.3f (wavenumber %.3f)" % (nu, lam_abs, subs[0]["wavenumber"])}
+    if geneo:
+        A.set_option("geneo_nu", nu)
+        lams = A.solve_gevp_all([(sd["n"], sd.get("ia_neumann", sd["ia"]), sd.get("ja_neumann", sd["ja"]), sd["a_neumann"], sd["sym"]) for sd in subs])
+        lam_max = max(float(lam[-1]) for lam in lams)
     for s, sd in enumerate(subs):
         if geneo:
-            A.set_option("geneo_nu", nu)
-            lam = A.solve_gevp(s, sd["n"], sd.get("ia_neumann", sd["ia"]), sd.get("ja_neumann", sd["ja"]), sd["a_neumann"], sd["sym"])
-            lam_max = max(lam_max or 0.0, float(lam[-1]))
-            continue
+            break
         i0, i1, j0, j1, k0, k1 = sd["box"]
         z, y, x = np.meshgrid(np.linspace(-1, 1, k1 - k0), np.linspace(-1, 1, j1 - j0), np.linspace(-1, 1, i1 - i0), indexing="ij")
         if sd.get("block", 1) == 3:

@@ -296,6 +296,7 @@ int HpddmHipSchwarzSolveGEVP(HpddmHipSchwarz *A, int s, int n, const int *ia, co
   HH_TRY(
     HH_CHECK(A && ia && ja && a, "null argument");
     HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
+    bind_thread_device();
     A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F');
     return 0;)
 }
@@ -305,6 +306,7 @@ int HpddmHipSchwarzSolveGEVPWith(HpddmHipSchwarz *A, int s, int n, const int *ia
     HH_CHECK(A && ia && ja && a, "null argument");
     HH_CHECK(numbering == 'C' || numbering == 'F', "numbering must be 'C' or 'F'");
     HH_CHECK(!bia || (bja && ba), "SolveGEVPWith: bja / ba missing");
+    bind_thread_device();
     if (A->op.is_complex) A->op.solve_gevp_z(s, n, ia, ja, a, sym != 0, numbering == 'F', bia, bja, ba, bsym != 0, numbering == 'F');
     else A->op.solve_gevp(s, n, ia, ja, a, sym != 0, numbering == 'F', bia, bja, ba, bsym != 0, numbering == 'F');
     return 0;)

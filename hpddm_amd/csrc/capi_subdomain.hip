@@ -1,6 +1,7 @@
 // C ABI, local-solver part (include/hpddm_hip.h).  Reference binding: interface/hpddm_c.cpp:136-153.
 #include "../../include/hpddm_hip.h"
 #include "capi_common.hpp"
+#include <atomic>
 #include "local_solver.hpp"
 #include <algorithm>
 #include <cmath>
@@ -22,6 +23,17 @@ std::string &last_error()
 LocalSolver &local_solver_of(HpddmHipSubdomain *S) { return S->ls; }
 } // namespace hpddm_hip
 
+namespace hpddm_hip {
+static std::atomic<int> g_device{-1};
+// host threads other than the one that called HpddmHipSetDevice start on device 0: entry points that may be called from several
+// threads (the eigenproblems of different subdomains) bind the calling thread to the device of the library first
+void bind_thread_device()
+{
+  const int d = g_device.load();
+  if (d >= 0) HIP_OK(hipSetDevice(d));
+}
+} // namespace hpddm_hip
+
 extern "C" {
 
 const char *HpddmHipLastError(void) { return last_error().c_str(); }
@@ -34,7 +46,7 @@ int HpddmHipDeviceCount(void)
 }
 int HpddmHipSetDevice(int device)
 {
-  HH_TRY(HIP_OK(hipSetDevice(device)); return 0;)
+  HH_TRY(HIP_OK(hipSetDevice(device)); hpddm_hip::g_device.store(device); return 0;)
 }
 int HpddmHipSynchronize(void)
 {

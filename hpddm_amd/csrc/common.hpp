@@ -53,6 +53,7 @@ struct Symbolic {
 
 void symbolic_factorization(const Graph &g, const Ordering &ord, Symbolic &sym);
 
+void bind_thread_device(); // capi_subdomain.hip: hipSetDevice(the device of HpddmHipSetDevice) on the calling host thread
 int host_thread_cap(); // OpenMP threads the host-side phases may use (numeric_host.cpp)
 
 } // namespace hpddm_hip

@@ -12,6 +12,7 @@
 #include "dense_eig.hpp"
 #include <cmath>
 #include <complex>
+#include <mutex>
 #include <random>
 #include <set>
 
@@ -186,6 +187,17 @@ __global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restric
 
 void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia, const int *uja, const double *ua, bool usym, int ubase)
 {
+  // the eigenproblems of different subdomains may be solved by different host threads (the reference's ranks each solve their own):
+  // the options are read from a snapshot, the number of vectors kept is written back under the same lock
+  std::map<std::string, double> optc;
+  {
+    std::lock_guard<std::mutex> lk(opt_mutex);
+    optc = opt;
+  }
+  auto getopt = [&optc](const std::string &k, double def) {
+    auto it = optc.find(k);
+    return it == optc.end() ? def : it->second;
+  };
   HH_CHECK(s >= 0 && s < nsub && n == subs[s].n, "SolveGEVP: bad subdomain / size");
   SchwarzSub &S  = subs[s];
   int         nu = (int)getopt("geneo_nu", 20);
@@ -440,7 +452,10 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   }
   S.nu = keep;
   // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705): visible to HpddmOptionVal / GetOption
-  opt["geneo_nu"] = keep;
+  {
+    std::lock_guard<std::mutex> lk(opt_mutex);
+    opt["geneo_nu"] = keep;
+  }
   S.Z.assign(X.begin(), X.begin() + (size_t)keep * n);
   S.eigenvalues.assign(lam.begin(), lam.begin() + keep);
   S.gevp_iterations = it;
@@ -578,6 +593,17 @@ __global__ __launch_bounds__(256) void k_zge_mul(int n, const double2 *__restric
 
 void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, const int *uia, const int *uja, const double *ua, bool usym, int ubase)
 {
+  // the eigenproblems of different subdomains may be solved by different host threads (the reference's ranks each solve their own):
+  // the options are read from a snapshot, the number of vectors kept is written back under the same lock
+  std::map<std::string, double> optc;
+  {
+    std::lock_guard<std::mutex> lk(opt_mutex);
+    optc = opt;
+  }
+  auto getopt = [&optc](const std::string &k, double def) {
+    auto it = optc.find(k);
+    return it == optc.end() ? def : it->second;
+  };
   HH_CHECK(s >= 0 && s < nsub && is_complex && 2 * n == subs[s].n, "SolveGEVPZ: bad subdomain / size (complex subdomains first: SetSubdomainZ; n complex rows)");
   SchwarzSub  &S  = subs[s];
   int          nu = (int)getopt("geneo_nu", 20);
@@ -827,7 +853,10 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   HIP_OK(hipMemcpyAsync(X.data(), Xd.p, sizeof(cplx) * nn * keep, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   set_vectors_z(s, keep, reinterpret_cast<const double *>(X.data()));
-  opt["geneo_nu"] = keep; // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705)
+  {
+    std::lock_guard<std::mutex> lk(opt_mutex);
+    opt["geneo_nu"] = keep; // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705)
+  }
   S.eigenvalues.resize(keep), S.eigenvalues_im.resize(keep);
   for (int c = 0; c < keep; ++c) S.eigenvalues[c] = lam[ord[c]].real(), S.eigenvalues_im[c] = lam[ord[c]].imag();
   S.gevp_iterations = it;

@@ -1,6 +1,7 @@
 // LocalSolver: numfact (host analysis + multifrontal factorisation, upload) and solve (HIP SpTRSV).
 // Reference: Solver<K>::numfact / solve / dtor (include/HPDDM_MUMPS.hpp:216-317).
 #include "local_solver.hpp"
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <complex>
@@ -55,7 +56,8 @@ static bool is_symmetric(const CsrView &A)
 
 // Panel pools are recycled between solvers: a fresh GiB-sized allocation costs more in page faults than the
 // factorisation of a mid-size subdomain.
-static std::vector<double> g_spare_panels;
+static std::vector<double> g_spare_panels; // (several factorisations may be in flight: Schwarz::call_numfact pipelines them)
+static std::mutex          g_spare_mutex;
 
 bool LocalSolver::adopt_analysis(const LocalSolver &o, const CsrView &A)
 {
@@ -123,7 +125,10 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   // the fall-back ladder below is remembered per sparsity pattern: a refactorisation of an operator that ended as L D L^T or LU
   // last time (Helmholtz shifts, saddle points) starts there instead of redoing the kinds that failed (HPDDM_HIP_FORGET_FALLBACK: not)
   if (settled_kind > (int)kind && settled_hash == pattern_hash && !getenv("HPDDM_HIP_FORGET_FALLBACK")) kind = (FactKind)settled_kind;
-  if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
+  {
+    std::lock_guard<std::mutex> lk(g_spare_mutex);
+    if (host.F.capacity() == 0 && g_spare_panels.capacity() != 0) host.F.swap(g_spare_panels);
+  }
   // the upper levels of the tree (large fronts) are factorised on the device, the lower ones on the host (all three kinds)
   std::unique_ptr<DeviceLevels> devlev;
   idx_t                         first_dev = (idx_t)host.level_ptr.size() - 1;
@@ -180,7 +185,10 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     settled_hash = pattern_hash;
     if (release_host) {
       host.F.clear();
-      if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);
+      {
+        std::lock_guard<std::mutex> lk(g_spare_mutex);
+        if (host.F.capacity() > g_spare_panels.capacity()) g_spare_panels.swap(host.F);
+      }
       std::vector<double>().swap(host.F);
       std::vector<double>().swap(host.G);
     }

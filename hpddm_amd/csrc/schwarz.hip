@@ -13,6 +13,9 @@
 #include <cmath>
 #include <array>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 namespace hpddm_hip {
 
@@ -794,19 +797,52 @@ void Schwarz::call_numfact()
       }
       HH_CHECK(err.empty(), err);
     }
-    for (int s = 0; s < nsub; ++s) {
+    // The numerical factorisations, two in flight: the lower levels of subdomain s + 1 are factorised on the host cores while the
+    // upper levels of subdomain s run on the device (one factorisation at a time holds the device work space: DeviceScratch::busy) --
+    // the reference factorises its subdomains side by side, one MPI rank each.  -hpddm_hip_numfact_threads 1: one after the other.
+    const int keep_plain = getopt("keep_plain", 0) != 0, release = getopt("keep_host_factor", 0) == 0, leaf = (int)getopt("leaf_size", 32);
+    for (int s = 0; s < nsub; ++s)
+      if (is_complex) HH_CHECK(!subs[s].zia.empty() && (!use1 || !subs[s].zia1.empty()), "complex operators: the subdomain (optimised) matrix was not handed over as a complex matrix");
+    auto one = [&](int s) {
       SchwarzSub &S          = subs[s];
-      S.ls->leaf_size        = (int)getopt("leaf_size", 32);
-      S.ls->release_host     = getopt("keep_host_factor", 0) == 0;
-      S.ls->host.keep_plain  = getopt("keep_plain", 0) != 0;
+      S.ls->leaf_size        = leaf;
+      S.ls->release_host     = release;
+      S.ls->host.keep_plain  = keep_plain;
       CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
-      if (is_complex) {
-        HH_CHECK(!S.zia.empty() && (!use1 || !S.zia1.empty()), "complex operators: the subdomain (optimised) matrix was not handed over as a complex matrix");
-        A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
-      }
+      if (is_complex) A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
       S.ls->numfact(A, spd);
-      fs.push_back(&S.ls->dev);
+    };
+    const int nthr = std::max(1, std::min({nsub, 2, (int)getopt("hip_numfact_threads", 2)}));
+    if (nthr == 1) {
+      for (int s = 0; s < nsub; ++s) one(s);
+    } else {
+      int dev_id = 0;
+      HIP_OK(hipGetDevice(&dev_id));
+      std::atomic<int> next{0};
+      std::mutex       err_mutex;
+      std::string      err;
+      auto worker = [&]() {
+        try {
+          HIP_OK(hipSetDevice(dev_id));
+          for (int s = next++; s < nsub; s = next++) {
+            {
+              std::lock_guard<std::mutex> lk(err_mutex);
+              if (!err.empty()) break;
+            }
+            one(s);
+          }
+        } catch (const std::exception &e) {
+          std::lock_guard<std::mutex> lk(err_mutex);
+          if (err.empty()) err = e.what();
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthr; ++t) pool.emplace_back(worker);
+      worker();
+      for (auto &t : pool) t.join();
+      HH_CHECK(err.empty(), err);
     }
+    for (int s = 0; s < nsub; ++s) fs.push_back(&subs[s].ls->dev);
     build_plans();
   }
   if (reuse >= 1) opt["reuse_preconditioner"] = reuse + 1;

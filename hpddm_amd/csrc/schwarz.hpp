@@ -6,6 +6,7 @@
 #include "transport.hpp"
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 
 namespace hpddm_hip {
@@ -92,6 +93,7 @@ struct Schwarz {
   void                  build_halo_lists(); // host only
   std::vector<SchwarzSub>       subs;
   std::map<std::string, double> opt;
+  std::mutex                    opt_mutex; // solve_gevp of different subdomains may run on different host threads
   std::string                   dump_prefix; // -hpddm_dump_matrices=<prefix>: written when the operator is destroyed
   PrcndtnrType                  type = PRC_GE;
   bool                          device_ready = false, factored = false, coarse_ready = false;

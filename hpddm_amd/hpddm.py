@@ -243,6 +243,36 @@ class Schwarz:
         self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)
         return ev[:k]
 
+    def solve_gevp_all(self, mats, threads=2):
+        """solve_gevp for every local subdomain (the reference's ranks each solve their own eigenproblem, side by side): `mats[s]` =
+        (n, ia, ja, a, sym) or (n, ia, ja, a, sym, B); two host threads keep two subdomains in flight -- the lower levels of one shifted
+        factorisation run on the host cores while the device works on the other's upper levels and block-Krylov iterations.
+        Returns the list of eigenvalue arrays."""
+        import threading
+        out, err = [None] * len(mats), []
+        it = iter(range(len(mats)))
+        lock = threading.Lock()
+
+        def work():
+            while True:
+                with lock:
+                    s = next(it, None)
+                if s is None or err:
+                    return
+                m = mats[s]
+                try:
+                    out[s] = self.solve_gevp(s, m[0], m[1], m[2], m[3], m[4], B=m[5] if len(m) > 5 else None)
+                except Exception as e:   # noqa: BLE001
+                    err.append(e)
+        ts = [threading.Thread(target=work) for _ in range(max(1, min(threads, len(mats))))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
     def get_vectors(self, s):
         """getVectors: the deflation vectors of local subdomain s, (n_s, nu)"""
         nu = self._lib.HpddmHipSchwarzGetVectors(self._h, s, None, 0)
