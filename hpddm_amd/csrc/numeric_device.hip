@@ -7,6 +7,7 @@
 //
 // Reference concept: the numerical phase of Solver<K>::numfact (MUMPS job=4, include/HPDDM_MUMPS.hpp:286).
 #include "local_solver.hpp"
+#include <algorithm>
 #include <cstring>
 #include <initializer_list>
 #include <ctime>
@@ -678,6 +679,7 @@ static UploadRing &upload_ring()
 static constexpr int NSTREAMS = 4; // fronts of one level in flight (the first is the library stream)
 struct DeviceScratch {
   DevBuf<double> arena;
+  DevBuf<double> dinv_all; // L D L^T: 1 / D of the device-level fronts, every front its own columns (one download at the end)
   DevBuf<double> tinv[NSTREAMS], tmp[NSTREAMS], dvec[NSTREAMS]; // per stream: inverses of the diagonal tiles of its front, scratch, 1/D (LDL^T)
   hipStream_t    streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t     ev[NSTREAMS]      = {nullptr, nullptr, nullptr, nullptr};
@@ -715,6 +717,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
   } tinv, tmp, dvec; // the scratch of the current front's stream (begin_front sets them, and st)
   DevBuf<int>    flag;
   bool           locked = false;
+  bool           zeroed_all = false; // the panels and contribution blocks of the device levels were zeroed by two fills in begin()
+  idx_t          first_level_ = 0;
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
   ~DeviceLevelsImpl()
   {
@@ -761,7 +765,33 @@ struct DeviceLevelsImpl : public DeviceLevels {
     scr.busy.lock();
     locked = true;
     DeviceScratch::grow(arena, cb_doubles + 1024);
-    arena_used = 0;
+    arena_used   = 0;
+    first_level_ = first_level;
+    if (h.kind == FACT_LDLT) DeviceScratch::grow(scr.dinv_all, (size_t)CS * h.n + 64);
+    {
+      // One fill for the panels of all the device-level fronts and one for the arena of their contribution blocks instead of two per
+      // front (thousands of fronts: the device levels are bound by the number of launches the host can enqueue).  The panels of a
+      // level are contiguous in the pool and the levels follow one another: the device levels are its tail -- checked, else per front.
+      const Symbolic &sy = h.sym;
+      const idx_t     nl = (idx_t)h.level_ptr.size() - 1;
+      std::vector<std::pair<long long, long long>> iv;
+      for (idx_t l = first_level; l < nl; ++l)
+        for (idx_t q = h.level_ptr[l]; q < h.level_ptr[l + 1]; ++q) {
+          const idx_t k = h.level_blk[q];
+          const long long hh = (sy.blk_ptr[k + 1] - sy.blk_ptr[k]) + (long long)(sy.row_ptr[k + 1] - sy.row_ptr[k]);
+          iv.emplace_back((long long)h.f_off[k], (long long)h.f_off[k] + hh * h.ldw[k]);
+        }
+      std::sort(iv.begin(), iv.end());
+      bool tail = !iv.empty();
+      for (size_t i = 1; i < iv.size() && tail; ++i) tail = iv[i].first >= iv[i - 1].second && iv[i].first - iv[i - 1].second < 64; // (alignment padding between panels)
+      zeroed_all = tail && !getenv("HPDDM_HIP_ZERO_PER_FRONT");
+      if (zeroed_all) {
+        const size_t lo = (size_t)iv.front().first * CS, hi = (size_t)iv.back().second * CS;
+        HIP_OK(hipMemsetAsync(D.F.p + lo, 0, (hi - lo) * sizeof(double), library_stream()));
+        if (h.kind == FACT_LU) HIP_OK(hipMemsetAsync(D.G.p + lo, 0, (hi - lo) * sizeof(double), library_stream()));
+        HIP_OK(hipMemsetAsync(arena.p, 0, (cb_doubles + 1024) * sizeof(double), library_stream()));
+      }
+    }
     // scratch per stream: the first stream takes every level's first front (so the largest ones), the others only see levels of
     // two fronts or more
     const Symbolic &s    = h.sym;
@@ -866,7 +896,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
 
   void scatter(T *P, size_t panel_scalars, const long long *pos, const double *val, size_t cnt)
   {
-    HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
+    if (!zeroed_all) HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
     if (!cnt) return;
     upload_ring().ensure({cnt * sizeof(long long), cnt * sizeof(T)}, st);
     const long long *dp = (const long long *)upload_ring().push(pos, cnt * sizeof(long long), st);
@@ -968,7 +998,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     T              *C  = nullptr;
     if (nb) {
       C = take((size_t)nb * nb);
-      HIP_OK(hipMemsetAsync(C, 0, (size_t)nb * nb * sizeof(T), st));
+      if (!zeroed_all) HIP_OK(hipMemsetAsync(C, 0, (size_t)nb * nb * sizeof(T), st));
     }
     // ---- extend-add the children (their row maps travel through the pinned ring: nothing waits for the stream) ----
     for (size_t c = 0; c < children.size(); ++c) {
@@ -1001,9 +1031,9 @@ struct DeviceLevelsImpl : public DeviceLevels {
     if (lu) hipLaunchKernelGGL(k_split_u11<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, G, ld);
     else hipLaunchKernelGGL(k_zero_upper<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
     if (kind == FACT_LDLT) {
-      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, dvec.p);
-      HIP_OK(hipMemcpyAsync(hf->dinv.data() + (size_t)c0 * CS, dvec.p, sizeof(T) * w, hipMemcpyDeviceToHost, st));
-      HIP_OK(hipStreamSynchronize(st)); // dvec is reused by the next front of this stream
+      // 1 / D of this front into its own columns of a vector of the whole factor: downloaded once, in end() (a copy and a stream
+      // synchronisation per front kept the host in step with the device: the L D L^T device levels were not asynchronous at all)
+      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, reinterpret_cast<T *>(scr.dinv_all.p) + c0);
     }
     if (hf->keep_plain) { // (the oracle's CPU baseline wants the plain factor: the front leaves the device before it is inverted)
       const double tp0 = now();
@@ -1035,7 +1065,21 @@ struct DeviceLevelsImpl : public DeviceLevels {
     }
     std::vector<int> fl(1 + (size_t)hf->sym.nblk, 0);
     HIP_OK(hipMemcpyAsync(fl.data(), flag.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<double> dall;
+    if (hf->kind == FACT_LDLT) {
+      dall.resize((size_t)CS * hf->n);
+      HIP_OK(hipMemcpyAsync(dall.data(), scr.dinv_all.p, dall.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     HIP_OK(hipStreamSynchronize(st));
+    if (hf->kind == FACT_LDLT) { // the columns of the device-level fronts (the host levels wrote theirs)
+      const Symbolic &sy = hf->sym;
+      const idx_t     nl = (idx_t)hf->level_ptr.size() - 1;
+      for (idx_t l = first_level_; l < nl; ++l)
+        for (idx_t q = hf->level_ptr[l]; q < hf->level_ptr[l + 1]; ++q) {
+          const idx_t k = hf->level_blk[q], a0 = sy.blk_ptr[k], a1 = sy.blk_ptr[k + 1];
+          std::copy(dall.begin() + (size_t)CS * a0, dall.begin() + (size_t)CS * a1, hf->dinv.begin() + (size_t)CS * a0);
+        }
+    }
     HIP_OK(hipGetLastError());
     f = fl[0];
     for (idx_t k = 0; k < hf->sym.nblk; ++k)
