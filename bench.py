@@ -52,18 +52,22 @@ def parse_args():
     ap.add_argument("--no-gmres", action="store_true")
     ap.add_argument("--bgmres", type=int, default=0, metavar="MU", help="extra leg: Block GMRES on MU consistent random right-hand sides (configs[4] solves 8 at a time)")
     ap.add_argument("--no-two-level", action="store_true", help="headline = the one-level apply (configs[1] flavour)")
-    ap.add_argument("--geneo-nu", type=int, default=20, help="deflation vectors per subdomain of the two-level operator")
+    ap.add_argument("--geneo-nu", type=int, default=None, help="deflation vectors per subdomain of the two-level operator (default: 20; helmholtz: 12 DtN vectors)")
     ap.add_argument("--problem", choices=("poisson", "elasticity", "helmholtz"), default="poisson",
                     help="poisson: 7-point Laplacian, grid^3 cells per GPU (configs[1], configs[2]); elasticity: trilinear hexahedra, 3 dofs per "
-                         "node, grid^3 nodes per GPU (configs[3] is --problem elasticity --grid 64 on 8 GPUs); helmholtz: complex<double> shifted "
-                         "Laplacian with absorption, grid x grid x 2 grid cells per GPU, plane-wave coarse space, Block GMRES on --mu right-hand "
-                         "sides (configs[4] is --problem helmholtz --grid 64 --mu 8 on 4 GPUs: 128^3, 32 subdomains)")
+                         "node, grid^3 nodes per GPU (configs[3] is --problem elasticity --grid 64 on 8 GPUs); helmholtz: complex<double> -Laplace - k^2, "
+                         "k = 2 pi 8, first-order absorbing boundary, grid x grid x 2 grid cells of h = 1/128 per GPU, ORAS with impedance local matrices, DtN "
+                         "coarse space from the complex solveGEVP, Block GMRES on --mu right-hand sides (configs[4] is --problem helmholtz --grid 64 --mu 8 "
+                         "on 4 GPUs: 128^3, 32 subdomains)")
     ap.add_argument("--no-geneo", action="store_true", help="two-level operator on polynomial stand-in vectors instead of the GenEO eigenvectors (kernel timing only)")
     ap.add_argument("--no-configs-1", action="store_true", help="skip the extra configs[1] (128^3, one-level) object of the default run")
     ap.add_argument("--options", default="", help="extra -hpddm_* options appended to the operator's option string (developer aid)")
     ap.add_argument("--no-shares", action="store_true", help="skip the extra configs_3_share / configs_4_share objects of the default run")
     ap.add_argument("--strong", action="store_true", help="N>1: --grid is the GLOBAL cube (strong scaling) instead of the share of one GPU")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.geneo_nu is None:
+        args.geneo_nu = 12 if args.problem == "helmholtz" else 20
+    return args
 
 
 def self_launch(args):
@@ -132,7 +136,7 @@ def main():
     shares = {}
     if rank == 0 and world == 1 and args.n == 256 and args.problem == "poisson" and not args.no_shares:
         shares["configs_3_share"] = share_leg(["--problem", "elasticity", "--grid", "64", "--geneo-nu", "12"])
-        shares["configs_4_share"] = share_leg(["--problem", "helmholtz", "--grid", "64", "--mu", "8"])
+        shares["configs_4_share"] = share_leg(["--problem", "helmholtz", "--grid", "64", "--mu", "8", "--geneo-nu", "12"])
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
     # the extra configs[1] object of the default run goes first: run in the same process AFTER the 97 GB operator (three minutes of
     # sustained streaming) the same 128^3 sweep was measured 20-25 % slower than on its own (3.1 against 2.45 ms on the same box)
