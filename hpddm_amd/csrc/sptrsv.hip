@@ -1420,20 +1420,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // wavefront per bottom subtree all measured the same level times or worse in rounds 1-2: the bottom levels are bound by the bytes
   // they pull beside their panel entries)
   auto grid = [&](int nb, int nw) { return nb + (nw + 3) / 4; };
-  int l_first = 0;
-#ifdef HPDDM_HIP_ABLATION
-  if (const char *e = getenv("HPDDM_HIP_FUSE_UNSAFE")) { // timing experiment, WRONG results: the first levels (wave tiles only) in one launch, no dependencies honoured
-    int lf = 0, wrm = 16;
-    while (lf < P.nlev && lf < atoi(e) && cnt(SolvePlan::FWD_BLOCK, lf) == 0) wrm = std::max(wrm, wrows(SolvePlan::FWD_WAVE, lf)), ++lf;
-    if (lf > 1) {
-      const int nw = P.lev_end[SolvePlan::FWD_WAVE][lf - 1] - P.lev_ptr[SolvePlan::FWD_WAVE][0];
-      hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw)), dim3(WG_THREADS), (size_t)4 * wrm * MU * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][0], nw, b, P.y.p, P.U.p, mu_total, nu0, 4 * wrm * MU, wrm, 0, P.dbg);
-      P.mark(2000, s);
-      l_first = lf;
-    }
-  }
-#endif
-  for (int l = l_first; l < P.nlev; ++l) {
+  for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
     const int ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {

@@ -686,20 +686,7 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, b, P.b16.p, mu, k0);
   P.mark(0, s);
   const int lds_wave = 4 * KC * C16; // doubles: the four wavefronts' staging areas
-  int       l_first  = 0;
-#ifdef HPDDM_HIP_ABLATION
-  if (const char *e = getenv("HPDDM_HIP_FUSE_UNSAFE")) { // timing experiment, WRONG results: the first levels in one launch, no dependencies honoured, no gather passes
-    const int lf = std::min(P.nlev, atoi(e));
-    if (lf > 1) {
-      const int nb = P.lev_end[SolvePlan::FWD_BLOCK][lf - 1] - P.lev_ptr[SolvePlan::FWD_BLOCK][0], nw = P.lev_end16[0][lf - 1] - P.lev_ptr16[0][0];
-      if (nb) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(nb + (nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][0], nb, P.tiles.p + P.lev_ptr16[0][0], 0, nw, P.b16.p, P.y16.p, P.U16.p, lds_wave, 1);
-      else hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3((nw + 3) / 4), dim3(WG_THREADS), (size_t)lds_wave * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][0], 0, nw, P.b16.p, P.y16.p, P.U16.p, lds_wave, 0);
-      P.mark(2000, s);
-      l_first = lf;
-    }
-  }
-#endif
-  for (int l = l_first; l < P.nlev; ++l) {
+  for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = P.lev_end16[0][l] - P.lev_ptr16[0][l], ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
       hipLaunchKernelGGL(sptrsv16_gather_kernel, dim3(16 * ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], P.b16.p, P.U16.p);
