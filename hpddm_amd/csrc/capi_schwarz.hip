@@ -224,6 +224,7 @@ int HpddmHipHostSelfTest(void)
       const cd                     xz[] = {{1.0, -2.0}, {0.5, 0.25}, {-3.0, 1.0}}, zz[] = {{1.0, 0.5}, {-2.0, 1.0}, {0.0, 3.0}, {1.0, 0.0}, {0.0, -1.0}, {2.0, 2.0}};
       Schwarz                      S(1, 0, 1);
       S.set_subdomain_z(0, nc, ia, ja, reinterpret_cast<const double *>(az), false, 0, 0, nullptr, nullptr, nullptr);
+      S.expand_matrix(0);
       const SchwarzSub &sub = S.subs[0];
       if (!S.is_complex || sub.n != 2 * nc) return 12;
       for (int i = 0; i < nc; ++i) { // (A x)_i in complex arithmetic against rows 2i, 2i+1 of the embedding

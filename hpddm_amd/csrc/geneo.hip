@@ -26,30 +26,39 @@ struct Csr {
   std::vector<double> a;
 };
 
-// full 0-based CSR from HPDDM storage (sym => lower triangle given)
+// full 0-based CSR from HPDDM storage (sym => lower triangle given), rows sorted by column.  Two counting passes (no per-row
+// containers: 2 M rows per 129^3 subdomain); a row is sorted afterwards only if it did not come out sorted
 Csr expand(int n, const int *ia, const int *ja, const double *a, bool sym, int base)
 {
   Csr M;
   M.n = n;
-  std::vector<std::vector<std::pair<int, double>>> rows(n);
+  M.ia.assign(n + 1, 0);
   for (int i = 0; i < n; ++i)
     for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
       const int j = ja[p] - base;
-      rows[i].emplace_back(j, a[p]);
-      if (sym && j != i) rows[j].emplace_back(i, a[p]);
+      ++M.ia[i + 1];
+      if (sym && j != i) ++M.ia[j + 1];
     }
-  M.ia.assign(n + 1, 0);
-  for (int i = 0; i < n; ++i) {
-    std::sort(rows[i].begin(), rows[i].end());
-    M.ia[i + 1] = M.ia[i] + (int)rows[i].size();
-  }
-  M.ja.reserve(M.ia[n]);
-  M.a.reserve(M.ia[n]);
+  for (int i = 0; i < n; ++i) M.ia[i + 1] += M.ia[i];
+  M.ja.resize(M.ia[n]);
+  M.a.resize(M.ia[n]);
+  std::vector<int> pos(M.ia.begin(), M.ia.end() - 1);
   for (int i = 0; i < n; ++i)
-    for (auto &e : rows[i]) {
-      M.ja.push_back(e.first);
-      M.a.push_back(e.second);
+    for (int p = ia[i] - base; p < ia[i + 1] - base; ++p) {
+      const int j = ja[p] - base;
+      M.ja[pos[i]] = j, M.a[pos[i]++] = a[p];
+      if (sym && j != i) M.ja[pos[j]] = i, M.a[pos[j]++] = a[p];
     }
+  std::vector<std::pair<int, double>> row;
+  for (int i = 0; i < n; ++i) {
+    bool sorted = true;
+    for (int p = M.ia[i] + 1; p < M.ia[i + 1] && sorted; ++p) sorted = M.ja[p - 1] < M.ja[p];
+    if (sorted) continue;
+    row.clear();
+    for (int p = M.ia[i]; p < M.ia[i + 1]; ++p) row.emplace_back(M.ja[p], M.a[p]);
+    std::sort(row.begin(), row.end());
+    for (int p = M.ia[i], q = 0; p < M.ia[i + 1]; ++p, ++q) M.ja[p] = row[q].first, M.a[p] = row[q].second;
+  }
   return M;
 }
 

@@ -170,6 +170,7 @@ struct Schwarz {
   int  gmres_z(const double *b, double *x, int mu, double *history, int history_cap);  // krylov_complex.hip
   int  bgmres_z(const double *b, double *x, int mu, double *history, int history_cap);
   void set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
+  void expand_matrix(int s);   // the full 0-based CSR of subdomain s (GMV, coarse assembly) from the matrix as handed over, once
   void multiplicity_scaling(double *const *d);
   void initialize(int s, const double *d);
   void set_vectors(int s, int nu, const double *Z);
