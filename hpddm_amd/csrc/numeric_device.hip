@@ -917,7 +917,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   // (products with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the
   // large fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
   // workgroups each walking a K loop of thousands of steps -- the f64 MFMA pipe below 20 %.
-  const int NBP = [] { const char *e = getenv("HPDDM_HIP_PANEL"); return e ? std::max(64, atoi(e) / 64 * 64) : 256; }(); // (experiment: panel width)
+  static constexpr int NBP = 256; // (384 / 512 / 768 columns measured the same numerical phase at 129^3: profiles/r04_numfact_panel_width.txt)
   void factor_chol(T *P, long long ld, int w, int h)
   {
     if constexpr (CS == 1) {
