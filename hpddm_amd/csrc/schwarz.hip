@@ -1038,7 +1038,10 @@ void Schwarz::build_coarse()
     }
   }
   E.assign((size_t)cdim_g * cdim_g, 0.0);
+  std::string asm_err;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(nsub, host_thread_cap()))) // (every subdomain writes its own block row of E)
   for (int i = 0; i < nsub; ++i) {
+   try {
     const SchwarzSub &Si = subs[i];
     const int         ri = gcoff[first + i];
     // diagonal block: Z_i^T D_i T_i  (the reference scales the local product by D, include/HPDDM_operator.hpp:524, and
@@ -1085,7 +1088,12 @@ void Schwarz::build_coarse()
           }
       }
     }
+   } catch (const std::exception &e) {
+#pragma omp critical(hpddm_hip_coarse_err)
+     asm_err = e.what();
+   }
   }
+  HH_CHECK(asm_err.empty(), asm_err);
   if (nranks > 1) {
     // rows of the other ranks: one sum over the ranks
     const size_t total = E.size();
@@ -1122,7 +1130,7 @@ void Schwarz::build_coarse()
   }
   std::vector<double> Ecopy(E);
   invert_dense(cdim_g, Ecopy, Einv);
-  upload_vectors(true);
+  if (!(uniform && !is_complex)) upload_vectors(true); // (real operators with one nu: Z is resident in this very layout since the assembly above)
   Einv_d.upload(Einv.data() + (size_t)coff_g0 * cdim_g, (size_t)cdim * cdim_g, st); // the rows of the local subdomains
   HIP_OK(hipStreamSynchronize(st));
   coarse_ready = true;
