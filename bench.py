@@ -25,7 +25,9 @@ with and without the coarse space), "cpu_baseline" (the oracle's substitution on
 thread per subdomain like the reference's one-rank-per-subdomain layout, and level-parallel on every core -- the better of
 the two is `value`), and three extra objects measured in the same run: "configs_1" (BASELINE.json configs[1], 128^3 one-level),
 "configs_3_share" (the share of one GPU in configs[3]: elasticity, 64^3 nodes, GenEO nu = 12) and "configs_4_share" (the share of
-one GPU in configs[4]: complex Helmholtz-like, 64 x 64 x 128 cells, Block GMRES on 8 right-hand sides), each with its own roofline.
+one GPU in configs[4]: complex Helmholtz -Laplace - k^2, k = 2 pi 8, first-order absorbing boundary, 64 x 64 x 128 cells of h = 1/128,
+ORAS with impedance matrices, DtN coarse space from the complex solveGEVP, Block GMRES on 8 right-hand sides), each with its own
+roofline; "host_pointer_boundary": the same apply through the host-pointer entry point (both vectors over PCIe), never `value`.
 """
 import argparse
 import json
@@ -403,7 +405,7 @@ def roofline(bytes_alg, t_solve, st, args, mu):
     # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     # scripts/pmc_traffic.sh): only quoted for the workload it was collected on (same algorithmic bytes)
     # (NOT measured in this run: counters need their own rocprofv3 passes -- the key below says which file the number is read from)
-    for name in ("r03_pmc_traffic_c3.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic_c3.json", "r04_pmc_traffic_c2.json", "r03_pmc_traffic_c3.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if mu == 1 and os.path.exists(pmc):
             with open(pmc) as fh:
