@@ -143,14 +143,17 @@ __global__ __launch_bounds__(256) void k_ge_tn(int n, const double *__restrict__
     }
   }
 }
-__global__ void k_ge_tn_reduce(int chunks, int ra, int cb, const double *__restrict__ partial, double *__restrict__ C)
+// one wavefront per output: the lanes take the chunks in turn (fixed assignment), then a fixed tree over the lanes -- reproducible.
+// (One THREAD per output walking 2 100 chunks with a stride of 20 KB was 0.7 ms per call at 129^3: as long as the product itself.)
+__global__ __launch_bounds__(256) void k_ge_tn_reduce(int chunks, int ra, int cb, const double *__restrict__ partial, double *__restrict__ C)
 {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= ra * cb) return;
   const int i = o / cb, j = o - i * cb;
   double    acc = 0.0;
-  for (int c = 0; c < chunks; ++c) acc += partial[((size_t)c * ra + i) * 8 + j];
-  C[o] = acc;
+  for (int c = lane; c < chunks; c += 64) acc += partial[((size_t)c * ra + i) * 8 + j];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) C[o] = acc;
 }
 // Out(:, j) = beta * Y(:, j) + alpha * sum_i A(:, i) S(i, j),  j < cb <= 8, S row-major ra x cb (Out may alias Y)
 __global__ __launch_bounds__(256) void k_ge_mul(int n, const double *__restrict__ A, int ra, const double *__restrict__ S, int cb, double alpha, double beta, const double *Y, double *Out)
@@ -168,14 +171,15 @@ __global__ __launch_bounds__(256) void k_ge_mul(int n, const double *__restrict_
     for (int j = 0; j < cb; ++j) Out[(size_t)j * n + r] = (beta != 0.0 ? beta * Y[(size_t)j * n + r] : 0.0) + alpha * acc[j];
   }
 }
-// per column c < cols:  out[2c] = sum (WX - th_c X)^2 ,  out[2c+1] = sum (th_c X)^2   (one workgroup per column, fixed order)
-__global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restrict__ WX, const double *__restrict__ X, const double *__restrict__ th, double *__restrict__ out)
+// per column c < cols:  out[2c] = sum (WX - th_c X)^2 ,  out[2c+1] = sum (th_c X)^2: partial sums per workgroup (grid: blocks x columns;
+// one workgroup per column streamed 2 x 17 MB through 256 threads: 3.9 ms per call at 129^3), then k_ge_resid_sum in block order
+__global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restrict__ WX, const double *__restrict__ X, const double *__restrict__ th, double *__restrict__ part)
 {
   __shared__ double red[2][256];
-  const int    c = blockIdx.x;
+  const int    c = blockIdx.y;
   const double t = th[c];
   double       rr = 0.0, xx = 0.0;
-  for (int r = threadIdx.x; r < n; r += 256) {
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
     const double x = X[(size_t)c * n + r], res = WX[(size_t)c * n + r] - t * x;
     rr += res * res;
     xx += t * x * t * x;
@@ -190,7 +194,16 @@ __global__ __launch_bounds__(256) void k_ge_resid(int n, const double *__restric
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[2 * c] = red[0][0], out[2 * c + 1] = red[1][0];
+  if (threadIdx.x == 0) part[2 * ((size_t)c * gridDim.x + blockIdx.x)] = red[0][0], part[2 * ((size_t)c * gridDim.x + blockIdx.x) + 1] = red[1][0];
+}
+__global__ void k_ge_resid_sum(int nblk, int cols, const double *__restrict__ part, double *__restrict__ out)
+{
+  const int o = threadIdx.x; // 2 * cols <= 16 outputs
+  if (o >= 2 * cols) return;
+  const int c = o >> 1, w = o & 1;
+  double    acc = 0.0;
+  for (int b = 0; b < nblk; ++b) acc += part[2 * ((size_t)c * nblk + b) + w];
+  out[o] = acc;
 }
 } // namespace
 
@@ -292,7 +305,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   hipStream_t st = library_stream();
   // everything n-sized stays on the device: the basis Q, B Q, W = OP Q (n x kmax each) and the working blocks
   const size_t   nn = (size_t)n;
-  DevBuf<double> Qd, BQd, Wd, Vd, BVd, T1d, T2d, Cd, Pd, Xd, small_d;
+  DevBuf<double> Qd, BQd, Wd, Vd, BVd, T1d, T2d, Cd, Pd, Xd, small_d, resid_part;
   DevBuf<int>    bia_d, bja_d;
   DevBuf<double> ba_d;
   Qd.alloc(nn * kmax), BQd.alloc(nn * kmax), Wd.alloc(nn * kmax);
@@ -309,7 +322,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   auto tn = [&](const double *Ad, int ra, const double *Bd, int cb, std::vector<double> &C) {
     C.assign((size_t)ra * cb, 0.0);
     hipLaunchKernelGGL(k_ge_tn, dim3((unsigned)chunks), dim3(256), (size_t)cb * GE_ROWS * sizeof(double), st, n, Ad, ra, Bd, cb, Pd.p);
-    hipLaunchKernelGGL(k_ge_tn_reduce, dim3((unsigned)((ra * cb + 255) / 256)), dim3(256), 0, st, chunks, ra, cb, Pd.p, Cd.p);
+    hipLaunchKernelGGL(k_ge_tn_reduce, dim3((unsigned)((ra * cb + 3) / 4)), dim3(256), 0, st, chunks, ra, cb, Pd.p, Cd.p);
     HIP_OK(hipMemcpyAsync(C.data(), Cd.p, sizeof(double) * ra * cb, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
   };
@@ -421,7 +434,10 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
         mul(Qd.p, dim, Sel, cc, 1.0, 0.0, nullptr, Xd.p + nn * c0);
         mul(Wd.p, dim, Sel, cc, 1.0, 0.0, nullptr, T2d.p);
         HIP_OK(hipMemcpyAsync(small_d.p, thc.data(), sizeof(double) * cc, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_ge_resid, dim3((unsigned)cc), dim3(256), 0, st, n, T2d.p, Xd.p + nn * c0, small_d.p, small_d.p + 16);
+        const int rblk = std::max(1, std::min(128, (n + 4095) / 4096));
+        resid_part.alloc((size_t)2 * 8 * 128);
+        hipLaunchKernelGGL(k_ge_resid, dim3((unsigned)rblk, (unsigned)cc), dim3(256), 0, st, n, T2d.p, Xd.p + nn * c0, small_d.p, resid_part.p);
+        hipLaunchKernelGGL(k_ge_resid_sum, dim3(1), dim3(64), 0, st, rblk, cc, resid_part.p, small_d.p + 16);
         HIP_OK(hipMemcpyAsync(out.data(), small_d.p + 16, sizeof(double) * 2 * cc, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         for (int c = 0; c < cc; ++c) worst = std::max(worst, std::sqrt(out[2 * c] / std::max(out[2 * c + 1], 1e-300)));

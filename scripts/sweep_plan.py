@@ -24,10 +24,11 @@ def main():
     hpddm.require_device()
     t0 = time.time()
     if args.helmholtz:
-        import numpy as np
-        import bench
-        subs = bench.generate_helmholtz(np, generate3d, tuple(int(v) for v in args.helmholtz.split(",")), 8, rhs="smooth", grid=(2, 2, 2))
-        A, d = hpddm.schwarz_from_subdomains(subs)
+        from hpddm_amd.generate import generate_helmholtz3d
+        subs = generate_helmholtz3d(tuple(int(v) for v in args.helmholtz.split(",")), 8, grid=(2, 2, 2))   # configs[4]'s share: ORAS on the impedance matrices
+        A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_method oras", multiplicity=False)
+        for s_, sd in enumerate(subs):
+            A.set_optimized_matrix(s_, sd["n"], sd["ia"], sd["ja"], sd["a_opt"], False)
     else:
         subs = generate3d(args.grid, 8, overlap=1, sym=True, rhs="smooth")
         A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
