@@ -1,4 +1,4 @@
-"""The bench contract on the committed line (profiles/r03_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
+"""The bench contract on the committed line (profiles/r04_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
 every key the driver reads is there, the workload is the one BASELINE.json quotes its target on (configs[2], real GenEO space) and
 the derived fields are consistent with each other.  CPU only."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_default_stdout.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_default_stdout.json")) as fh:
         rows = [ln for ln in fh if ln.startswith('{"metric"')]
     assert len(rows) == 1, "bench.py prints ONE JSON line"
     return json.loads(rows[0])
@@ -42,9 +42,28 @@ def test_contract_keys_and_consistency():
 
 def test_traffic_profile_matches_the_line():
     d = _line()
-    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_c3.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_c3.json")) as fh:
         t = json.load(fh)
     assert t["traffic_bytes"] == (2 * t["FETCH_SIZE_KB_per_sweep"] + t["WRITE_SIZE_KB_per_sweep"]) * 1024
-    # the line quotes the traffic file that was committed when it ran (round 2's); the passes were collected again after it with the
-    # same build: the two agree to a fraction of a percent
-    assert abs(d["roofline"]["traffic"] - t["traffic_bytes"]) <= 2e-3 * t["traffic_bytes"] and t["algorithmic_bytes"] == d["roofline"]["bytes_alg_per_sweep"]
+    # the line quotes the traffic file of this round's PMC passes (scripts/r04_final.sh), collected on the same build just before it ran
+    assert d["roofline"]["traffic_source"].startswith("profiles/r04_pmc_traffic_c3.json") and d["roofline"]["traffic_measured_in_this_run"] is False
+    assert d["roofline"]["traffic"] == t["traffic_bytes"] and t["algorithmic_bytes"] == d["roofline"]["bytes_alg_per_sweep"]
+    assert 1.0 <= t["traffic_over_algorithmic"] <= 1.15
+
+
+def test_round_4_keys():
+    """what round 4 added to the line: the host-pointer boundary beside (never in) `value`, the sampled CPU baseline, configs[4]'s share on
+    the Helmholtz problem SURVEY 8(d) C5 defines (absorbing boundary, ORAS, DtN coarse space from the complex solveGEVP)"""
+    d = _line()
+    h = d["host_pointer_boundary"]
+    assert h["apply_ms"] > d["ms_per_step"] and abs(h["applies_per_sec"] - 1e3 / h["apply_ms"]) <= 1e-6 * h["applies_per_sec"]
+    assert h["bytes_over_pcie"] == 2.0 * 8.0 * d["config"]["n_dof_per_gpu"] and 20.0 < h["effective_GBps"] < 64.0      # PCIe gen 5 x16
+    c = d["cpu_baseline"]
+    assert c["sample_subdomains"] == 2 and abs(c["sample_scale"] - 4.0) < 0.05 and "2 of its 8 subdomains" in c["sample"]
+    assert d["config"]["setup_seconds_of_which_plain_factor_for_cpu_baseline"] == 0.0
+    s4 = d["configs_4_share"]
+    assert s4["dtype"] == "c128" and "absorbing boundary" in s4["workload"] and "ORAS" in s4["workload"] and "DtN" in s4["workload"]
+    assert s4["two_level"]["coarse_space"].startswith("DtN: solveGEVP") and s4["two_level"]["gmres"]["method"] == "bgmres" and s4["two_level"]["gmres"]["rhs"] == 8
+    assert 0 < s4["two_level"]["gmres"]["iterations"] < 60
+    m8 = d["two_level"]["deflation_mfma_mu8"]
+    assert m8["panel_GBps"] > 3500.0 and "r04_pmc_mfma_deflation" in m8["counters"]
