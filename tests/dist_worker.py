@@ -132,6 +132,8 @@ def main():
         if mode == "rccl":
             from hpddm_amd import _lib
             local = int(os.environ.get("LOCAL_RANK", rank))
+            if os.environ.get("HPDDM_TEST_RCCL_SAME_GPU") == "1":   # probe only: RCCL refuses two ranks of a communicator on one device
+                local = 0
             assert hpddm.device_count() > local, "mode rccl needs one GPU per rank"
             _lib.check(_lib.load().HpddmHipSetDevice(local))
             box = [hpddm.rccl_unique_id() if rank == 0 else None]
