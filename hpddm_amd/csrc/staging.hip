@@ -6,6 +6,7 @@
 // of the caller would let a later DMA land in pages that are no longer his.
 #include "device.hpp"
 #include <cstring>
+#include <mutex>
 #include <omp.h>
 
 namespace hpddm_hip {
@@ -37,6 +38,13 @@ Staging &staging(int dir)
   static Staging s[2]; // one pair per direction: a round trip's download does not wait for the slots of its upload
   return s[dir];
 }
+// the buffers are shared by the host threads of the process (two factorisations / eigenproblems may be in flight, each with its probe
+// solve on host vectors): one staged copy per direction at a time
+std::mutex &staging_mutex(int dir)
+{
+  static std::mutex m[2];
+  return m[dir];
+}
 inline void par_memcpy(char *dst, const char *src, size_t bytes)
 {
   const int    nt    = std::max(1, std::min(8, host_thread_cap()));
@@ -62,6 +70,7 @@ void staged_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s
     HIP_OK(hipStreamSynchronize(st));
     return;
   }
+  std::lock_guard<std::mutex> lk(staging_mutex(0));
   Staging &S = staging(0);
   S.init();
   int k = 0;
@@ -82,6 +91,7 @@ void staged_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s
     HIP_OK(hipStreamSynchronize(st));
     return;
   }
+  std::lock_guard<std::mutex> lk(staging_mutex(1));
   Staging &S = staging(1);
   S.init();
   size_t prev_o = 0, prev_len = 0;
