@@ -34,7 +34,13 @@ struct DevBuf {
     if (count == n && p) return;
     release();
     n = count;
-    if (count) HIP_OK(hipMalloc((void **)&p, count * sizeof(T)));
+    if (count && hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {
+      (void)hipGetLastError();
+      size_t fr = 0, tot = 0;
+      (void)hipMemGetInfo(&fr, &tot);
+      p = nullptr, n = 0;
+      throw Error("device memory: an allocation of " + std::to_string(count * sizeof(T) >> 20) + " MB failed (" + std::to_string(fr >> 20) + " MB free of " + std::to_string(tot >> 20) + " MB)");
+    }
   }
   void upload(const T *h, size_t count, hipStream_t s = nullptr)
   {

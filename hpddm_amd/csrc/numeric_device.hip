@@ -12,6 +12,7 @@
 #include <initializer_list>
 #include <ctime>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 
 namespace hpddm_hip {
@@ -45,7 +46,7 @@ __device__ static inline double b_entry(const double *__restrict__ B, long long 
 // 64 x 64 tile per workgroup, 4 wavefronts of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K staged 16 at a time through LDS.
 // lower_only: tiles entirely above the diagonal of the (ci0, cj0)-shifted matrix are skipped.
 template <bool TRANSB, int CS>
-__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, long long sA, long long sB, long long sC)
+__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, long long sA, long long sB, long long sC)
 {
   __shared__ double As[64][17];
   __shared__ double Bs[16][65];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
 //     atri: A is lower triangular (A[i][k] = 0 for k > i): row tile i0 stops its K loop at i0 + TM;
 //   * blockIdx.y: batch of products with strided operands (the pairs of one level of the recursive inversion).
 template <int TM, int TN, bool TRANSB, int CS>
-__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *__restrict__ A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int atri, int tiles_x, int tiles_y, long long sA, long long sB, long long sC)
+__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int atri, int tiles_x, int tiles_y, long long sA, long long sB, long long sC)
 {
   constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
   __shared__ double As[2][TM][KS + 1];
@@ -584,7 +585,7 @@ static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha,
   GemmBatch bt = bs; // strides of the pointers the kernels see: doubles
   bt.sA *= CS, bt.sB *= CS, bt.sC *= CS;
   N *= CS, K *= CS, lda *= CS, ldc *= CS; // real views (ldb stays in scalars: b_entry)
-  if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads)
+  if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads -- except right_tile, where C = A and every workgroup owns its rows)
     if (M <= 64) gemm_big<64, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // row blocks
     else if (N > 64) gemm_big<128, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt);
     else gemm_big<128, 64, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // 64-column panels
@@ -595,99 +596,149 @@ static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha,
   else hipLaunchKernelGGL((k_gemm64<false, CS>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
 }
 
-// Host -> device hand-over of the small lists of the device levels (row maps of the children, entry lists of the fronts, the
-// contribution blocks of the host-level children): a pinned staging ring mirrored by a device ring.  push() copies into the pinned
-// ring and enqueues ONE asynchronous copy; the host never waits for the stream except when the ring wraps around (everything
-// enqueued before has then been consumed).  hipMemcpyAsync from pageable memory would synchronise the stream on every call -- the
-// device levels used to spend about half of their wall time in such waits.
+// Host -> device hand-over of the device levels (row maps of the children, entry lists of the fronts, the contribution blocks of the
+// host-level children): a pinned staging ring mirrored by a device ring.  stage() copies into the pinned ring and hands out the
+// address the bytes will have in the device ring; flush() enqueues ONE asynchronous copy for everything staged since the last one --
+// a front stages all it needs (its children's blocks, its entry lists, the row maps) and flushes once: a copy per list was a quarter
+// of the launches of the device levels, which are bound by the rate the host enqueues at.  The host never waits for the stream
+// except when the ring wraps around (everything enqueued before has then been consumed).  hipMemcpyAsync from pageable memory would
+// synchronise the stream on every call -- the device levels used to spend about half of their wall time in such waits.
 struct UploadRing {
   char  *host = nullptr, *dev = nullptr;
-  size_t cap = 0, head = 0;
+  size_t cap = 0, head = 0, flushed = 0, batch = 0; // batch: bytes staged for the front in hand (its pointers must stay valid together)
+  std::vector<std::pair<char *, char *>> retired;   // outgrown buffers: pointers into them may still be in use, freed by release_retired()
+  hipStream_t *consumers = nullptr; // the streams the staged bytes are consumed on (DeviceScratch::streams): a wrap-around waits for these only
+  int    nconsumers = 0;
   double t_wait = 0, t_copy = 0; // seconds spent waiting for the stream at wrap-arounds / copying into the pinned ring (HPDDM_HIP_PROFILE)
   size_t bytes_pushed = 0;
   int    wraps = 0;
-  void   reserve(size_t bytes, hipStream_t st)
+  static constexpr size_t guard = 4096; // (a guard page at the end of the ring: under rocprofv3 --pmc a copy faulted on the host exactly one byte past the pinned ring)
+  void   wait_consumed()
+  {
+    if (!consumers) {
+      HIP_OK(hipDeviceSynchronize());
+      return;
+    }
+    for (int i = 0; i < nconsumers; ++i)
+      if (consumers[i]) HIP_OK(hipStreamSynchronize(consumers[i]));
+  }
+  void flush(hipStream_t st)
+  {
+    if (head > flushed) HIP_OK(hipMemcpyAsync(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice, st));
+    flushed = head;
+  }
+  void grow(size_t bytes, hipStream_t st)
   {
     if (bytes <= cap) return;
-    HIP_OK(hipDeviceSynchronize());
-    if (host) (void)hipHostFree(host);
-    if (dev) (void)hipFree(dev);
+    flush(st); // what the old buffers hold goes out through them; they stay until release_retired()
+    if (host) retired.emplace_back(host, dev);
+    host = dev = nullptr;
     HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&dev, bytes));
     cap  = bytes;
-    head = 0;
+    head = flushed = 0;
   }
-  // room for several pushes whose device pointers must stay valid together (one kernel reads them all): grow or wrap NOW, so that
-  // none of the pushes that follow reallocates the ring or restarts it under a pointer already handed out
-  void ensure(std::initializer_list<size_t> sizes, hipStream_t st)
+  void release_retired()
   {
-    size_t need = 4096;
-    for (size_t b : sizes) need += (b + 255) / 256 * 256;
-    if (need > cap) reserve(std::max(need, 2 * cap), st);
-    if (head + need > cap) {
-      HIP_OK(hipDeviceSynchronize());
-      ++wraps;
-      head = 0;
+    if (retired.empty()) return;
+    HIP_OK(hipDeviceSynchronize());
+    for (auto &b : retired) {
+      (void)hipHostFree(b.first);
+      (void)hipFree(b.second);
     }
+    retired.clear();
   }
-  void *push(const void *src, size_t bytes, hipStream_t st)
+  void begin_batch() { batch = 0; }
+  void *stage(const void *src, size_t bytes, hipStream_t st)
   {
-    // (a guard page at the end of the ring: under rocprofv3 --pmc the copy below faulted on the host exactly one byte past the 64 MB
-    // of the pinned ring -- a staged copy that reads a little more than it was asked for must not run off the mapping)
-    const size_t need = (bytes + 255) / 256 * 256, guard = 4096;
-    if (need + guard > cap) reserve(std::max(need + guard, 2 * cap), st);
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (batch + need + guard > cap) grow(std::max(batch + need + guard, 2 * cap), st); // a front's batch fits the ring as a whole: a wrap-around inside it never lands on its own bytes
     if (head + need + guard > cap) {
+      flush(st);
       const double t0 = now();
-      HIP_OK(hipDeviceSynchronize()); // wrap-around: what was enqueued (on any stream) has been consumed
+      wait_consumed(); // wrap-around: what was enqueued (on any stream of this factorisation) has been consumed
       t_wait += now() - t0;
       ++wraps;
-      head = 0;
+      head = flushed = 0;
     }
     const double t1 = now();
-    const bool unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr; // (profiling aid: rocprofv3 --pmc faulted inside the copy from the pinned ring)
-    if (unpinned) {
-      HIP_OK(hipStreamSynchronize(st));
-      HIP_OK(hipMemcpy(dev + head, src, bytes, hipMemcpyHostToDevice));
-      void *q = dev + head;
-      head += need;
-      bytes_pushed += bytes;
-      return q;
-    }
     std::memcpy(host + head, src, bytes);
     t_copy += now() - t1;
     bytes_pushed += bytes;
-    HIP_OK(hipMemcpyAsync(dev + head, host + head, bytes, hipMemcpyHostToDevice, st));
     void *p = dev + head;
     head += need;
+    batch += need;
     return p;
   }
   ~UploadRing()
   {
+    for (auto &b : retired) {
+      (void)hipHostFree(b.first);
+      (void)hipFree(b.second);
+    }
     if (host) (void)hipHostFree(host);
     if (dev) (void)hipFree(dev);
   }
 };
-static UploadRing &upload_ring()
-{
-  static UploadRing ring; // one per process: pinning memory is expensive, the factorisations of a process follow one another
-  return ring;
-}
 
 // Work space of the device levels, kept by the process between factorisations (it only grows): hipMalloc / hipFree of several GB
-// per factorisation were 1.0 - 2.4 s of the 3 - 4.4 s the device levels of a 129^3 subdomain took.  One factorisation at a time
-// uses it (the mutex is held from begin() to end(); the device levels run on the one library stream anyway).
-static constexpr int NSTREAMS = 4; // fronts of one level in flight (the first is the library stream)
+// per factorisation were 1.0 - 2.4 s of the 3 - 4.4 s the device levels of a 129^3 subdomain took.  A factorisation holds a slot
+// from begin() to end(), with its own streams and its own pinned upload ring.  One slot by default: the device levels of two
+// factorisations driven by two host threads (HPDDM_HIP_DEVICE_SLOTS=2) interleave on the device, and measured no faster -- set-up
+// of configs[2]: numfact 17.8 s against 17.1 s, GenEO 20.3 s against 16.9 s (profiles/r04_setup_device_slots.txt): the launches of
+// both threads go through the one queue of the runtime, and it is the launch rate that bounds the middle levels.
+static constexpr int NSTREAMS = 16; // fronts of one level in flight, at most (HPDDM_HIP_FACTOR_STREAMS of them are used, default 4)
+static constexpr int MAX_SLOTS = 4;
 struct DeviceScratch {
+  UploadRing     ring; // pinning memory is expensive: kept with the slot
+  bool           in_use = false;
   DevBuf<double> arena;
   DevBuf<double> dinv_all; // L D L^T: 1 / D of the device-level fronts, every front its own columns (one download at the end)
   DevBuf<double> tinv[NSTREAMS], tmp[NSTREAMS], dvec[NSTREAMS]; // per stream: inverses of the diagonal tiles of its front, scratch, 1/D (LDL^T)
-  hipStream_t    streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t     ev[NSTREAMS]      = {nullptr, nullptr, nullptr, nullptr};
-  std::mutex     busy;
-  static DeviceScratch &get()
+  hipStream_t    streams[NSTREAMS] = {};
+  hipEvent_t     ev[NSTREAMS]      = {};
+  hipEvent_t     ev_fill           = nullptr; // the fill of a level's share of the arena, on the first stream: the others wait for it
+  static std::mutex &pool_mutex()
   {
-    static DeviceScratch s;
-    return s;
+    static std::mutex m;
+    return m;
+  }
+  static std::condition_variable &pool_cv()
+  {
+    static std::condition_variable c;
+    return c;
+  }
+  static DeviceScratch *pool()
+  {
+    static DeviceScratch p[MAX_SLOTS];
+    return p;
+  }
+  static int slots()
+  {
+    const char *e = getenv("HPDDM_HIP_DEVICE_SLOTS");
+    const int   v = e ? atoi(e) : 1;
+    return std::max(1, std::min(MAX_SLOTS, v));
+  }
+  static DeviceScratch *acquire()
+  {
+    std::unique_lock<std::mutex> lk(pool_mutex());
+    DeviceScratch *p = pool(), *got = nullptr;
+    const int      ns = slots();
+    pool_cv().wait(lk, [&] {
+      for (int i = 0; i < ns && !got; ++i)
+        if (!p[i].in_use) got = p + i;
+      return got != nullptr;
+    });
+    got->in_use = true;
+    return got;
+  }
+  static void release(DeviceScratch *s)
+  {
+    {
+      std::lock_guard<std::mutex> lk(pool_mutex());
+      s->in_use = false;
+    }
+    pool_cv().notify_one();
   }
   static void grow(DevBuf<double> &b, size_t count)
   {
@@ -704,40 +755,44 @@ struct DeviceLevelsImpl : public DeviceLevels {
   HostFactor   *hf = nullptr;
   hipStream_t   st;
   std::map<idx_t, T *> cb;           // contribution blocks resident on the device (block id -> nb x nb)
-  DeviceScratch &scr = DeviceScratch::get();
-  DevBuf<double> &arena = scr.arena; // all contribution blocks of the device levels + uploaded children
-  size_t          arena_used = 0;
+  DeviceScratch *scr = nullptr;      // held from begin() to end(): scr->arena = all contribution blocks of the device levels + uploaded children
+  size_t          arena_used = 0, chunk_end = 0;
+  std::vector<size_t> chunk_off, chunk_size; // per level of the tree: its share of the arena, in doubles (planned in begin())
   // The fronts of one level are independent: they go round-robin to NSTREAMS streams, each with its own scratch; the streams meet at
   // every change of level (events).  A front of the middle levels is a chain of small launches -- a tile kernel per 64 columns, each
   // waiting for the previous one, products of a few dozen workgroups -- that leaves most of the machine idle on its own.
   int             cur = 0, cur_level = -1, next_rr = 0;
-  bool            used[NSTREAMS] = {false, false, false, false};
+  bool            used[NSTREAMS] = {};
+  int             ns = 4; // streams in use
   struct Ptr {
     T *p = nullptr;
   } tinv, tmp, dvec; // the scratch of the current front's stream (begin_front sets them, and st)
   DevBuf<int>    flag;
+  std::vector<const int *> relp; // the row maps of the children of the front in hand, in the device ring
+  bool                      prof = false; // HPDDM_HIP_PROFILE: an event on the first stream at every change of level
+  std::vector<std::pair<int, hipEvent_t>> lev_ev;
   bool           locked = false;
   bool           zeroed_all = false; // the panels and contribution blocks of the device levels were zeroed by two fills in begin()
   idx_t          first_level_ = 0;
-  explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(library_stream()) { }
+  explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(nullptr) { }
   ~DeviceLevelsImpl()
   {
-    if (locked) scr.busy.unlock();
+    if (locked) DeviceScratch::release(scr);
   }
   void level_barrier()
   {
-    for (int s = 0; s < NSTREAMS; ++s)
-      if (used[s]) HIP_OK(hipEventRecord(scr.ev[s], scr.streams[s]));
-    for (int t = 0; t < NSTREAMS; ++t)
-      for (int s = 0; s < NSTREAMS; ++s)
-        if (used[s] && s != t) HIP_OK(hipStreamWaitEvent(scr.streams[t], scr.ev[s], 0));
-    for (int s = 0; s < NSTREAMS; ++s) used[s] = false;
+    for (int s = 0; s < ns; ++s)
+      if (used[s]) HIP_OK(hipEventRecord(scr->ev[s], scr->streams[s]));
+    for (int t = 0; t < ns; ++t)
+      for (int s = 0; s < ns; ++s)
+        if (used[s] && s != t) HIP_OK(hipStreamWaitEvent(scr->streams[t], scr->ev[s], 0));
+    for (int s = 0; s < ns; ++s) used[s] = false;
   }
   void set_slot(int i)
   {
     cur = i;
-    st  = scr.streams[i];
-    tinv.p = reinterpret_cast<T *>(scr.tinv[i].p), tmp.p = reinterpret_cast<T *>(scr.tmp[i].p), dvec.p = reinterpret_cast<T *>(scr.dvec[i].p);
+    st  = scr->streams[i];
+    tinv.p = reinterpret_cast<T *>(scr->tinv[i].p), tmp.p = reinterpret_cast<T *>(scr->tmp[i].p), dvec.p = reinterpret_cast<T *>(scr->dvec[i].p);
   }
   void begin_front(idx_t k) override
   {
@@ -746,15 +801,29 @@ struct DeviceLevelsImpl : public DeviceLevels {
       if (cur_level >= 0) level_barrier();
       cur_level = lvl;
       next_rr   = 0;
+      if (prof) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipEventRecord(e, scr->streams[0]));
+        lev_ev.emplace_back(lvl, e);
+      }
+      // the share of the arena planned for this level (begin()): free since the barrier above at the latest -- one fill for all its blocks
+      arena_used = chunk_off[lvl], chunk_end = chunk_off[lvl] + chunk_size[lvl];
+      if (zeroed_all && chunk_size[lvl]) {
+        HIP_OK(hipMemsetAsync(scr->arena.p + chunk_off[lvl], 0, chunk_size[lvl] * sizeof(double), scr->streams[0]));
+        HIP_OK(hipEventRecord(scr->ev_fill, scr->streams[0]));
+        for (int t = 1; t < ns; ++t) HIP_OK(hipStreamWaitEvent(scr->streams[t], scr->ev_fill, 0));
+      }
     }
-    set_slot(next_rr++ % NSTREAMS);
+    set_slot(next_rr++ % ns);
     used[cur] = true;
+    scr->ring.begin_batch();
   }
   T *take(size_t cnt)
   {
     cnt = (cnt * CS + 15) / 16 * 16;
-    HH_CHECK(arena_used + cnt <= arena.n, "numfact (device levels): contribution-block arena exhausted");
-    double *p = arena.p + arena_used;
+    HH_CHECK(arena_used + cnt <= chunk_end, "numfact (device levels): the contribution blocks of a level exceed its planned share of the arena");
+    double *p = scr->arena.p + arena_used;
     arena_used += cnt;
     return reinterpret_cast<T *>(p);
   }
@@ -762,12 +831,65 @@ struct DeviceLevelsImpl : public DeviceLevels {
   {
     hf = &h;
     HH_CHECK((h.cplx ? 2 : 1) == CS, "numfact (device levels): scalar type of the factor and of the device levels differ");
-    scr.busy.lock();
+    scr    = DeviceScratch::acquire();
     locked = true;
-    DeviceScratch::grow(arena, cb_doubles + 1024);
-    arena_used   = 0;
+    DevBuf<double> &arena = scr->arena;
+    // the slot's own streams (none of them the library stream: two factorisations in flight would meet on it); what the library
+    // stream still holds for this factor -- solves with the previous values of a refactorisation -- ends first
+    {
+      const char *e = getenv("HPDDM_HIP_FACTOR_STREAMS");
+      ns            = std::max(1, std::min(NSTREAMS, e ? atoi(e) : 4));
+    }
+    for (int i = 0; i < ns; ++i) {
+      if (!scr->streams[i]) HIP_OK(hipStreamCreateWithFlags(&scr->streams[i], hipStreamNonBlocking));
+      if (!scr->ev[i]) HIP_OK(hipEventCreateWithFlags(&scr->ev[i], hipEventDisableTiming));
+    }
+    if (!scr->ev_fill) HIP_OK(hipEventCreateWithFlags(&scr->ev_fill, hipEventDisableTiming));
+    scr->ring.consumers = scr->streams, scr->ring.nconsumers = NSTREAMS; // (all it ever created)
+    HIP_OK(hipStreamSynchronize(library_stream()));
     first_level_ = first_level;
-    if (h.kind == FACT_LDLT) DeviceScratch::grow(scr.dinv_all, (size_t)CS * h.n + 64);
+    prof         = getenv("HPDDM_HIP_PROFILE") != nullptr;
+    {
+      // Plan of the arena.  The contribution blocks of the fronts of a level share one chunk, live until the last of their parents has been assembled -- the barrier that closes that level orders
+      // every stream --, and later levels take the place over: first fit over the chunks still alive.  Every block kept until end()
+      // was 49 GB for a 129^3 Poisson subdomain (12 device levels), more than the factor; two factorisations in flight did not fit.
+      const Symbolic &sy   = h.sym;
+      const idx_t     nlev = (idx_t)h.level_ptr.size() - 1;
+      chunk_off.assign((size_t)nlev, 0), chunk_size.assign((size_t)nlev, 0);
+      std::vector<idx_t> rel((size_t)nlev);
+      for (idx_t l = 0; l < nlev; ++l) rel[l] = l;
+      auto r16 = [](size_t scalars) { return (scalars * CS + 15) / 16 * 16; };
+      for (idx_t k = 0; k < sy.nblk; ++k) {
+        const idx_t  hk = sy.height[k], pk = sy.parent[k];
+        const size_t nb = (size_t)(sy.row_ptr[k + 1] - sy.row_ptr[k]);
+        if (hk >= first_level) {
+          chunk_size[hk] += r16(nb * nb);
+          if (pk >= 0) rel[hk] = std::max(rel[hk], sy.height[pk]);
+        } // (the blocks of host-level children stay in the upload ring)
+      }
+      struct Live {
+        size_t off, size;
+        idx_t  until;
+      };
+      std::vector<Live> live;
+      size_t            peak = 0;
+      for (idx_t l = first_level; l < nlev; ++l) {
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &c) { return c.until < l; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
+        size_t pos = 0;
+        for (const Live &c : live) {
+          if (c.off >= pos + chunk_size[l]) break;
+          pos = std::max(pos, c.off + c.size);
+        }
+        chunk_off[l] = pos;
+        if (chunk_size[l]) live.push_back({pos, chunk_size[l], rel[l]});
+        peak = std::max(peak, pos + chunk_size[l]);
+      }
+      if (getenv("HPDDM_HIP_PROFILE")) fprintf(stderr, "[numfact] device levels: contribution blocks %.2f GB in all, arena %.2f GB (levels share it)\n", (double)cb_doubles * 8e-9, (double)peak * 8e-9);
+      DeviceScratch::grow(arena, peak + 1024);
+      arena_used = chunk_end = 0;
+    }
+    if (h.kind == FACT_LDLT) DeviceScratch::grow(scr->dinv_all, (size_t)CS * h.n + 64);
     {
       // One fill for the panels of all the device-level fronts and one for the arena of their contribution blocks instead of two per
       // front (thousands of fronts: the device levels are bound by the number of launches the host can enqueue).  The panels of a
@@ -787,63 +909,55 @@ struct DeviceLevelsImpl : public DeviceLevels {
       zeroed_all = tail && !getenv("HPDDM_HIP_ZERO_PER_FRONT");
       if (zeroed_all) {
         const size_t lo = (size_t)iv.front().first * CS, hi = (size_t)iv.back().second * CS;
-        HIP_OK(hipMemsetAsync(D.F.p + lo, 0, (hi - lo) * sizeof(double), library_stream()));
-        if (h.kind == FACT_LU) HIP_OK(hipMemsetAsync(D.G.p + lo, 0, (hi - lo) * sizeof(double), library_stream()));
-        HIP_OK(hipMemsetAsync(arena.p, 0, (cb_doubles + 1024) * sizeof(double), library_stream()));
+        HIP_OK(hipMemsetAsync(D.F.p + lo, 0, (hi - lo) * sizeof(double), scr->streams[0]));
+        if (h.kind == FACT_LU) HIP_OK(hipMemsetAsync(D.G.p + lo, 0, (hi - lo) * sizeof(double), scr->streams[0]));
       }
     }
-    // scratch per stream: the first stream takes every level's first front (so the largest ones), the others only see levels of
-    // two fronts or more
+    // scratch per stream, for the fronts it will be dealt (round-robin inside every level: the first stream takes every level's
+    // first front, the last ones only see the levels of many fronts)
     const Symbolic &s    = h.sym;
     const idx_t     nlev = (idx_t)h.level_ptr.size() - 1;
-    idx_t           mh[2] = {1, 1}, mw[2] = {1, 1};
+    size_t          need_tmp[NSTREAMS], need_w[NSTREAMS];
+    for (int i = 0; i < NSTREAMS; ++i) need_tmp[i] = 4096, need_w[i] = 1;
     for (idx_t l = first_level; l < nlev; ++l)
       for (idx_t q = h.level_ptr[l]; q < h.level_ptr[l + 1]; ++q) {
         const idx_t k = h.level_blk[q], w = s.blk_ptr[k + 1] - s.blk_ptr[k], hh = w + (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
-        for (int c = 0; c < (h.level_ptr[l + 1] - h.level_ptr[l] >= 2 ? 2 : 1); ++c) mh[c] = std::max(mh[c], hh), mw[c] = std::max(mw[c], w);
+        const int   i = (int)((q - h.level_ptr[l]) % ns);
+        need_tmp[i]   = std::max(need_tmp[i], (size_t)hh * std::max<idx_t>(256, w));
+        need_w[i]     = std::max(need_w[i], (size_t)w);
       }
-    scr.streams[0] = library_stream();
-    for (int i = 0; i < NSTREAMS; ++i) {
-      if (!scr.streams[i]) HIP_OK(hipStreamCreateWithFlags(&scr.streams[i], hipStreamNonBlocking));
-      if (!scr.ev[i]) HIP_OK(hipEventCreateWithFlags(&scr.ev[i], hipEventDisableTiming));
-      const idx_t max_h = mh[i ? 1 : 0], max_w = mw[i ? 1 : 0];
-      DeviceScratch::grow(scr.tinv[i], (size_t)CS * 3 * ((max_w + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
-      DeviceScratch::grow(scr.dvec[i], (size_t)CS * (max_w + 64));
-      DeviceScratch::grow(scr.tmp[i], (size_t)CS * std::max<size_t>((size_t)max_h * std::max<idx_t>(256, max_w), 4096));
+    for (int i = 0; i < ns; ++i) {
+      DeviceScratch::grow(scr->tinv[i], (size_t)CS * 3 * ((need_w[i] + 63) / 64) * 4096); // per tile: inv(L_T), and D^{-1} inv(L_T) (LDL^T) or inv(U_T), inv(U_T)^T (LU)
+      DeviceScratch::grow(scr->dvec[i], (size_t)CS * (need_w[i] + 64));
+      DeviceScratch::grow(scr->tmp[i], (size_t)CS * need_tmp[i]);
     }
     cur_level = -1, next_rr = 0;
     for (int i = 0; i < NSTREAMS; ++i) used[i] = false;
     set_slot(0);
     if (CS == 2) { // the complex tile kernels keep two 64 x 65 complex arrays in LDS: beyond the default 64 KB
-      static bool once = false;
-      if (!once) {
-        once = true;
+      static std::once_flag once;
+      std::call_once(once, [] {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
-      }
+      });
     }
     { // (the real ones use 66.5 KB, also beyond)
-      static bool once = false;
-      if (!once) {
-        once = true;
+      static std::once_flag once;
+      std::call_once(once, [] {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
-      }
+      });
     }
-    upload_ring().reserve((size_t)64 << 20, st);
+    scr->ring.grow((size_t)64 << 20, st);
     std::vector<int> z(1 + (size_t)h.sym.nblk, 0); // [0]: breakdown; [1 + k]: rows were exchanged inside a tile of front k (LU)
     flag.upload(z, st);
     HIP_OK(hipStreamSynchronize(st));
   }
   void upload_cb(idx_t child, const double *C, idx_t nb) override
   {
-    // through the pinned ring into its place in the arena (device-to-device, stream-ordered): the host block goes back to its
-    // pool right after the call, the stream is not waited for
-    T           *p     = take((size_t)nb * nb);
-    const size_t bytes = (size_t)nb * nb * sizeof(T);
-    const void  *src   = upload_ring().push(C, bytes, st);
-    HIP_OK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToDevice, st));
-    cb[child] = p;
+    // into the pinned ring (the host block goes back to its pool right after the call); the block stays in the device ring, where
+    // the front in hand -- its only reader -- finds it after the one flush of process_sparse
+    cb[child] = reinterpret_cast<T *>(scr->ring.stage(C, (size_t)nb * nb * sizeof(T), st));
   }
   static const double *cd(const T *p) { return reinterpret_cast<const double *>(p); }
   static double       *md(T *p) { return reinterpret_cast<double *>(p); }
@@ -886,21 +1000,24 @@ struct DeviceLevelsImpl : public DeviceLevels {
     gemm<CS>(st, false, nb, w, w, 1.0, cd(P + (long long)w * ld), ld, cd(P), ld, md(tmp.p), w, false, false, 0, 0, true); // the inverted top block is lower triangular
     hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, (const T *)tmp.p, (long long)w, P + (long long)w * ld, ld);
   }
-  // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse (through the scratch: the product cannot be formed in place)
+  // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse.  In place when one workgroup owns all the columns of its rows (N <= the
+  // tile width of the kernel gemm() picks: real scalars, and full tiles of complex ones): it has read the whole of its rows when
+  // it stores them, and nobody else reads them.  Otherwise through the scratch.
   void right_tile(T *X, long long ld, int m, int jb, const T *B, bool transB)
   {
     if (m <= 0) return;
+    if (CS == 1 || jb == 64) {
+      gemm<CS>(st, transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64, md(X), ld, false);
+      return;
+    }
     gemm<CS>(st, transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64, md(tmp.p), 64, false);
     hipLaunchKernelGGL(k_copy2d<T>, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, (const T *)tmp.p, 64LL, X, ld);
   }
 
-  void scatter(T *P, size_t panel_scalars, const long long *pos, const double *val, size_t cnt)
+  void scatter(T *P, size_t panel_scalars, const long long *dp, const double *dv, size_t cnt)
   {
     if (!zeroed_all) HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
     if (!cnt) return;
-    upload_ring().ensure({cnt * sizeof(long long), cnt * sizeof(T)}, st);
-    const long long *dp = (const long long *)upload_ring().push(pos, cnt * sizeof(long long), st);
-    const double    *dv = (const double *)upload_ring().push(val, cnt * sizeof(T), st);
     hipLaunchKernelGGL(k_scatter_add<CS>, dim3((unsigned)std::min<size_t>(1024, (cnt * CS + 255) / 256)), dim3(256), 0, st, (long long)cnt, dp, dv, md(P));
   }
   void process_sparse(idx_t k, const long long *posF, const double *valF, size_t nF, const long long *posG, const double *valG, size_t nG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
@@ -908,8 +1025,19 @@ struct DeviceLevelsImpl : public DeviceLevels {
     const Symbolic &s = hf->sym;
     const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k], nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]), h = w + nb;
     const long long ld = hf->ldw[k];
-    scatter(reinterpret_cast<T *>(D.F.p) + hf->f_off[k], (size_t)h * ld, posF, valF, nF);
-    if (hf->kind == FACT_LU) scatter(reinterpret_cast<T *>(D.G.p) + hf->f_off[k], (size_t)h * ld, posG, valG, nG);
+    const bool      lu = hf->kind == FACT_LU;
+    // everything the front needs from the host in the ring (the blocks of its host-level children are there since upload_cb), ONE copy
+    UploadRing &ring = scr->ring;
+    const long long *dpF = nF ? (const long long *)ring.stage(posF, nF * sizeof(long long), st) : nullptr;
+    const double    *dvF = nF ? (const double *)ring.stage(valF, nF * sizeof(T), st) : nullptr;
+    const long long *dpG = lu && nG ? (const long long *)ring.stage(posG, nG * sizeof(long long), st) : nullptr;
+    const double    *dvG = lu && nG ? (const double *)ring.stage(valG, nG * sizeof(T), st) : nullptr;
+    relp.assign(children.size(), nullptr);
+    for (size_t c = 0; c < children.size(); ++c)
+      if (!rel[c].empty()) relp[c] = (const int *)ring.stage(rel[c].data(), sizeof(int) * rel[c].size(), st);
+    ring.flush(st);
+    scatter(reinterpret_cast<T *>(D.F.p) + hf->f_off[k], (size_t)h * ld, dpF, dvF, nF);
+    if (lu) scatter(reinterpret_cast<T *>(D.G.p) + hf->f_off[k], (size_t)h * ld, dpG, dvG, nG);
     factor_front(k, children, rel);
   }
   // ---- blocked factorisations of the panel P (h rows, w columns, the original entries and the children's blocks assembled) ----
@@ -1007,10 +1135,10 @@ struct DeviceLevelsImpl : public DeviceLevels {
       auto        it  = cb.find(ch);
       HH_CHECK(it != cb.end(), "numfact (device levels): child contribution block not resident");
       if (!nbc) continue;
-      const int *relp = (const int *)upload_ring().push(rel[c].data(), sizeof(int) * nbc, st);
+      const int *rl = relp[c];
       const dim3 grid((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4));
-      if (lu) hipLaunchKernelGGL(k_extend_add_full<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, relp, P, G, ld, (int)w, C, (long long)nb);
-      else hipLaunchKernelGGL(k_extend_add<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, relp, P, ld, (int)w, C, (long long)nb);
+      if (lu) hipLaunchKernelGGL(k_extend_add_full<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, rl, P, G, ld, (int)w, C, (long long)nb);
+      else hipLaunchKernelGGL(k_extend_add<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, rl, P, ld, (int)w, C, (long long)nb);
     }
     // ---- blocked factorisation of the panel ----
     const int ntile = (w + 63) / 64;
@@ -1033,7 +1161,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     if (kind == FACT_LDLT) {
       // 1 / D of this front into its own columns of a vector of the whole factor: downloaded once, in end() (a copy and a stream
       // synchronisation per front kept the host in step with the device: the L D L^T device levels were not asynchronous at all)
-      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, reinterpret_cast<T *>(scr.dinv_all.p) + c0);
+      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, reinterpret_cast<T *>(scr->dinv_all.p) + c0);
     }
     if (hf->keep_plain) { // (the oracle's CPU baseline wants the plain factor: the front leaves the device before it is inverted)
       const double tp0 = now();
@@ -1054,12 +1182,36 @@ struct DeviceLevelsImpl : public DeviceLevels {
   int end() override
   {
     int f = 0;
-    level_barrier(); // everything meets on every stream, the library stream included
+    level_barrier(); // everything meets on every stream of the slot; the host waits for the first one below
     set_slot(0);
+    if (prof && !lev_ev.empty()) {
+      hipEvent_t e;
+      HIP_OK(hipEventCreate(&e));
+      HIP_OK(hipEventRecord(e, st));
+      HIP_OK(hipEventSynchronize(e));
+      lev_ev.emplace_back(-1, e);
+      const Symbolic &sy = hf->sym;
+      for (size_t i = 0; i + 1 < lev_ev.size(); ++i) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, lev_ev[i].second, lev_ev[i + 1].second));
+        const idx_t l = lev_ev[i].first;
+        double      fl = 0;
+        idx_t       wmax = 0, wmin = 1 << 30;
+        for (idx_t q = hf->level_ptr[l]; q < hf->level_ptr[l + 1]; ++q) {
+          const idx_t  k = hf->level_blk[q];
+          const double w = sy.blk_ptr[k + 1] - sy.blk_ptr[k], nb = (double)(sy.row_ptr[k + 1] - sy.row_ptr[k]);
+          fl += w * w * w / 3 + nb * w * w + nb * nb * w + w * w * w / 3 + nb * w * w; // factorisation + Schur complement + solve-ready panels
+          wmax = std::max(wmax, (idx_t)w), wmin = std::min(wmin, (idx_t)w);
+        }
+        fprintf(stderr, "[numfact] device level %d: %d fronts (%d..%d columns), %.1f ms, %.2f TFLOP/s\n", (int)l, (int)(hf->level_ptr[l + 1] - hf->level_ptr[l]), (int)wmin, (int)wmax, ms, fl / ms * 1e-9);
+      }
+      for (auto &pe : lev_ev) (void)hipEventDestroy(pe.second);
+      lev_ev.clear();
+    }
     if (getenv("HPDDM_HIP_PROFILE")) {
       const double t0 = now();
       HIP_OK(hipStreamSynchronize(st));
-      UploadRing &r = upload_ring();
+      UploadRing &r = scr->ring;
       fprintf(stderr, "[numfact] device levels: host ran %.3f s ahead of the stream at the end; ring: %.1f MB pushed, %.3f s copying, %d wrap-arounds waiting %.3f s\n", now() - t0, r.bytes_pushed / 1e6, r.t_copy, r.wraps, r.t_wait);
       r.bytes_pushed = 0, r.t_copy = r.t_wait = 0, r.wraps = 0;
     }
@@ -1068,7 +1220,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     std::vector<double> dall;
     if (hf->kind == FACT_LDLT) {
       dall.resize((size_t)CS * hf->n);
-      HIP_OK(hipMemcpyAsync(dall.data(), scr.dinv_all.p, dall.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpyAsync(dall.data(), scr->dinv_all.p, dall.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIP_OK(hipStreamSynchronize(st));
     if (hf->kind == FACT_LDLT) { // the columns of the device-level fronts (the host levels wrote theirs)
@@ -1085,9 +1237,10 @@ struct DeviceLevelsImpl : public DeviceLevels {
     for (idx_t k = 0; k < hf->sym.nblk; ++k)
       if (fl[1 + k]) hf->tgs[k] = 6;
     cb.clear();
+    scr->ring.release_retired();
     if (locked) {
       locked = false;
-      scr.busy.unlock();
+      DeviceScratch::release(scr);
     }
     return f;
   }

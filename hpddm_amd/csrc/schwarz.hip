@@ -817,7 +817,7 @@ void Schwarz::call_numfact()
       HH_CHECK(err.empty(), err);
     }
     // The numerical factorisations, two in flight: the lower levels of subdomain s + 1 are factorised on the host cores while the
-    // upper levels of subdomain s run on the device (one factorisation at a time holds the device work space: DeviceScratch::busy) --
+    // upper levels of subdomain s run on the device (one factorisation at a time holds the device work space: DeviceScratch::acquire) --
     // the reference factorises its subdomains side by side, one MPI rank each.  -hpddm_hip_numfact_threads 1: one after the other.
     const int keep_plain = getopt("keep_plain", 0) != 0, release = getopt("keep_host_factor", 0) == 0, leaf = (int)getopt("leaf_size", 32);
     for (int s = 0; s < nsub; ++s)

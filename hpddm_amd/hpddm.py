@@ -8,6 +8,7 @@ Difference with the reference that the hardware imposes: ONE process drives ALL 
 (each ``(n_s,)`` or ``(n_s, mu)`` Fortran-ordered, exactly what one MPI rank of the reference holds).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -243,7 +244,7 @@ class Schwarz:
         self._lib.HpddmHipSchwarzGetEigenvalues(self._h, s, _dptr(ev), k)
         return ev[:k]
 
-    def solve_gevp_all(self, mats, threads=2):
+    def solve_gevp_all(self, mats, threads=None):
         """solve_gevp for every local subdomain (the reference's ranks each solve their own eigenproblem, side by side): `mats[s]` =
         (n, ia, ja, a, sym) or (n, ia, ja, a, sym, B); two host threads keep two subdomains in flight -- the lower levels of one shifted
         factorisation run on the host cores while the device works on the other's upper levels and block-Krylov iterations.
@@ -264,6 +265,8 @@ class Schwarz:
                     out[s] = self.solve_gevp(s, m[0], m[1], m[2], m[3], m[4], B=m[5] if len(m) > 5 else None)
                 except Exception as e:   # noqa: BLE001
                     err.append(e)
+        if threads is None:
+            threads = int(os.environ.get("HPDDM_HIP_GEVP_THREADS", "2"))
         ts = [threading.Thread(target=work) for _ in range(max(1, min(threads, len(mats))))]
         for t in ts:
             t.start()

@@ -1,0 +1,19 @@
+#!/bin/bash
+# arena shared between the levels + two scratch slots: parity (the full-size tests drive the device levels), then the set-up phases
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_pivoting.py tests/test_complex.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/r04_call12_tests.log
+cat gpurun_out/r04_call12_tests.log
+for combo in "2 2 2" "3 3 3" "1 2 2"; do
+  set -- $combo
+  echo "== slots $1 numfact threads $2 gevp threads $3"
+  HPDDM_HIP_DEVICE_SLOTS=$1 HPDDM_HIP_GEVP_THREADS=$3 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs-1 --no-shares --options=-hpddm_hip_numfact_threads=$2 > gpurun_out/r04_call12_s$1_t$2_g$3.log 2>&1
+  echo "rc $?"; grep -v '^{"metric"' gpurun_out/r04_call12_s$1_t$2_g$3.log | tail -3
+  python - <<PY
+import json
+rows = [l for l in open("gpurun_out/r04_call12_s$1_t$2_g$3.log") if l.startswith('{"metric"')]
+if rows:
+    d = json.loads(rows[0])
+    print("value", d["value"], "setup", d["config"]["setup_seconds"], d["config"].get("setup_seconds_by_phase_summed_over_subdomains"), "two_level", {k: v for k, v in d["two_level"].items() if "seconds" in k}, "its", d["two_level"]["gmres"]["iterations"], d["one_level"]["gmres"]["iterations"])
+PY
+done
