@@ -250,6 +250,7 @@ int HpddmHipHostSelfTest(void)
         if (std::abs(re - ref.real()) > 1e-14 || std::abs(im - ref.imag()) > 1e-14) return 16;
       }
     }
+    if (const int zc = zkrylov_host_selftest()) return zc; // the complex helpers of krylov_complex.hip (20 ..)
     return 0;
   } catch (const std::exception &e) {
     last_error() = e.what();

@@ -9,6 +9,8 @@
 // coefficients of the updates are complex.  That part is here: two kernels (a D-weighted complex Gram block and a block
 // update with complex coefficients) and the small dense algebra on the host, same conventions as gmres.hip / bgmres.hip.
 #include "schwarz.hpp"
+#include "dense_eig.hpp"
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <limits>
@@ -680,6 +682,518 @@ int zbgmres_impl(Schwarz &A, const double *b, double *x, double *history, int hi
   case 8: it = fn<8>(*this, b, x, history, history_cap); break;                   \
   default: HH_CHECK(false, what ": 1 <= mu <= 8 for complex scalars in this build"); it = -1; \
   }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GCRO-DR for K = std::complex<double> (IterativeMethod::GCRODR, include/HPDDM_GCRODR.hpp:34-443, instantiated for complex
+// scalars).  The real method of gmres.hip with every transposition a conjugate transposition: C^H D C = I; the Hessenberg
+// matrix, the block C^H A M^{-1} V and the cosines of the rotations are complex, the sines real; the harmonic Ritz vectors of
+// the first cycle are the eigenvectors of H_m + h_{m+1,m}^2 s e_m^T with s from the reference's recurrence on the rotations
+// (:262-270); afterwards (G^H G) z = theta (G^H W^H D V~) z, recycle strategy A (:318-420).  Complex eigenvectors are plain
+// columns (no conjugate pairs to keep together).  One right-hand side at a time, like the real method.
+// ---------------------------------------------------------------------------------------------------------------------
+// column nu of a block in the batched layout <-> single right-hand-side layout (doubles: 2 per complex entry)
+__global__ void k_zcolumn(const long long *__restrict__ voff, const int *__restrict__ nn, double *__restrict__ blk, int mu, int nu, double *__restrict__ one, int to_block)
+{
+  const int       s  = blockIdx.y, n = nn[s];
+  const long long v0 = voff[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (to_block) blk[v0 * mu + (long long)nu * n + i] = one[v0 + i];
+    else one[v0 + i] = blk[v0 * mu + (long long)nu * n + i];
+  }
+}
+
+namespace {
+struct ZGcroOptions {
+  double tol;
+  int    max_it, m, k, variant, ortho, verbosity, same_system, target;
+};
+// Householder QR of the rows x cols complex matrix M (row-major, rows >= cols): Q rows x cols with orthonormal columns, R upper
+void small_qr_z(int rows, int cols, const std::vector<cplx> &M, std::vector<cplx> &Q, std::vector<cplx> &R)
+{
+  std::vector<cplx> A((size_t)rows * cols), tau(cols);
+  for (int i = 0; i < rows; ++i)
+    for (int c = 0; c < cols; ++c) A[i + (size_t)c * rows] = M[(size_t)i * cols + c];
+  zgeqr2(rows, cols, A.data(), rows, tau.data());
+  R.assign((size_t)cols * cols, 0.0);
+  for (int i = 0; i < cols; ++i)
+    for (int c = i; c < cols; ++c) R[(size_t)i * cols + c] = A[i + (size_t)c * rows];
+  Q.assign((size_t)rows * cols, 0.0);
+  for (int c = 0; c < cols; ++c) Q[(size_t)c * cols + c] = 1.0;
+  for (int j = cols - 1; j >= 0; --j) // Q = H_0 ... H_{cols-1} [I; 0], H_j = I - tau_j v v^H, v = (0, .., 1, A(j+1:, j))
+    for (int c = 0; c < cols; ++c) {
+      cplx w = Q[(size_t)j * cols + c];
+      for (int i = j + 1; i < rows; ++i) w += std::conj(A[i + (size_t)j * rows]) * Q[(size_t)i * cols + c];
+      w *= tau[j];
+      Q[(size_t)j * cols + c] -= w;
+      for (int i = j + 1; i < rows; ++i) Q[(size_t)i * cols + c] -= w * A[i + (size_t)j * rows];
+    }
+}
+std::vector<cplx> upper_inverse_z(int n, const std::vector<cplx> &R)
+{
+  std::vector<cplx> Ri((size_t)n * n, 0.0);
+  for (int c = 0; c < n; ++c)
+    for (int i = c; i >= 0; --i) {
+      cplx v = (i == c) ? 1.0 : 0.0;
+      for (int k = i + 1; k <= c; ++k) v -= R[(size_t)i * n + k] * Ri[(size_t)k * n + c];
+      Ri[(size_t)i * n + c] = v / R[(size_t)i * n + i];
+    }
+  return Ri;
+}
+// order of the eigenvalues for -hpddm_recycle_target (selectNu, include/HPDDM_specifications.hpp:90-126): SM 0, LM 1, SR 2, LR 3, SI 4, LI 5
+std::vector<int> target_order_z(int target, const std::vector<cplx> &w)
+{
+  const int           n = (int)w.size();
+  std::vector<double> key(n);
+  for (int a = 0; a < n; ++a) {
+    switch (target) {
+    case 1: key[a] = -std::abs(w[a]); break;
+    case 2: key[a] = w[a].real(); break;
+    case 3: key[a] = -w[a].real(); break;
+    case 4: key[a] = w[a].imag(); break;
+    case 5: key[a] = -w[a].imag(); break;
+    default: key[a] = std::abs(w[a]);
+    }
+  }
+  std::vector<int> order(n);
+  for (int a = 0; a < n; ++a) order[a] = a;
+  std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return key[l] < key[r]; });
+  return order;
+}
+
+int zgcrodr_one(Schwarz &A, const ZGcroOptions &o, const double *b, double *x, Schwarz::Recycled &rec, std::vector<double> &hist)
+{
+  ZBlocks<1>      Z(A, std::max(o.m + 1, o.k + 1));
+  hipStream_t     st = Z.st;
+  const long long N  = A.ntot; // doubles per vector
+  const int       m  = o.m;
+  DevBuf<double>  V, Ax, T, Un, Cn, PT;
+  V.alloc((size_t)N * (m + 1));
+  Ax.alloc((size_t)N), T.alloc((size_t)N);
+  auto vk = [&](int q) { return V.p + (size_t)q * N; };
+  std::vector<cplx> G;
+  auto dots = [&](const double *Vb, int cnt, const double *w, std::vector<cplx> &out) { // out[q] = <V_q, w>_D = sum d conj(V_q) w
+    if (cnt <= 0) {
+      out.clear();
+      return;
+    }
+    Z.gram(Vb, cnt, w, out);
+  };
+  auto lincomb = [&](const double *Vb, int cnt, const cplx *c, double sign, double beta, double *w) { // w = beta w + sign sum_q c_q V_q
+    if (cnt <= 0) {
+      if (beta == 0.0) HIP_OK(hipMemsetAsync(w, 0, sizeof(double) * N, st));
+      return;
+    }
+    std::vector<cplx> cc(c, c + cnt);
+    Z.axpy(Vb, cnt, cc, sign, beta, w);
+  };
+  auto scale = [&](double *w, double f) { // w <- f w (through T)
+    HIP_OK(hipMemcpyAsync(T.p, w, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    const cplx c(f, 0.0);
+    lincomb(T.p, 1, &c, 1.0, 0.0, w);
+  };
+  auto op = [&](const double *in, double *out) { // A M^{-1} (right) or M^{-1} A (left)
+    if (o.variant == VARIANT_LEFT) {
+      A.gmv(in, Ax.p, 1);
+      A.apply(Ax.p, out, 1);
+    } else {
+      A.apply(in, Ax.p, 1);
+      A.gmv(Ax.p, out, 1);
+    }
+  };
+  int                 k = rec.k > 0 ? rec.k : o.k;
+  std::vector<cplx>   t, Hbar, Bm, Hr, cs(m), sv(m + 1);
+  std::vector<double> sn(m);
+  // ---- initializeNorm ----
+  A.start(b, x, 1);
+  double norm;
+  if (o.variant == VARIANT_LEFT) {
+    A.apply(b, T.p, 1);
+    dots(T.p, 1, T.p, t);
+  } else {
+    const double *bn = A.norm_rhs(b, T.p, 1);
+    dots(bn, 1, bn, t);
+  }
+  norm = std::sqrt(t[0].real());
+  if (norm < HPDDM_EPS) norm = 1.0;
+  int j = 1;
+  while (j <= o.max_it) {
+    const bool have = rec.k > 0;
+    const int  i0   = have ? k : 0;
+    double    *r    = vk(i0);
+    if (o.variant == VARIANT_LEFT) {
+      A.gmv(x, T.p, 1);
+      Z.axpby(1.0, b, -1.0, T.p, T.p);
+      A.apply(T.p, r, 1);
+    } else {
+      A.gmv(x, r, 1);
+      Z.axpby(1.0, b, -1.0, r, r);
+    }
+    if (j == 1 && have) {
+      // a new solve starts from the recycled space: C = A M^{-1} U for the current operator, orthonormalised (CholQR), unless
+      // -hpddm_recycle_same_system; then x += M^{-1} U (C^H r), r -= C (C^H r)        (include/HPDDM_GCRODR.hpp:93-127)
+      const bool right = o.variant != VARIANT_LEFT;
+      PT.alloc((size_t)N * k);
+      if (right)
+        for (int c = 0; c < k; ++c) A.apply(rec.U.p + (size_t)c * N, PT.p + (size_t)c * N, 1);
+      const double *pt = right ? PT.p : rec.U.p;
+      if (o.same_system == 0) {
+        for (int c = 0; c < k; ++c) {
+          if (right) A.gmv(pt + (size_t)c * N, rec.C.p + (size_t)c * N, 1);
+          else {
+            A.gmv(pt + (size_t)c * N, Ax.p, 1);
+            A.apply(Ax.p, rec.C.p + (size_t)c * N, 1);
+          }
+        }
+        std::vector<cplx> Gc((size_t)k * k), R((size_t)k * k, 0.0);
+        for (int c = 0; c < k; ++c) {
+          dots(rec.C.p, k, rec.C.p + (size_t)c * N, t);
+          for (int q = 0; q < k; ++q) Gc[(size_t)q * k + c] = t[q];
+        }
+        for (int q = 0; q < k; ++q) { // potrf "U": G = R^H R
+          double dq = Gc[(size_t)q * k + q].real();
+          for (int p = 0; p < q; ++p) dq -= std::norm(R[(size_t)p * k + q]);
+          HH_CHECK(dq > 0.0, "GCRODR: the recycled subspace lost its rank");
+          dq                   = std::sqrt(dq);
+          R[(size_t)q * k + q] = dq;
+          for (int c = q + 1; c < k; ++c) {
+            cplx v = Gc[(size_t)q * k + c];
+            for (int p = 0; p < q; ++p) v -= std::conj(R[(size_t)p * k + q]) * R[(size_t)p * k + c];
+            R[(size_t)q * k + c] = v / dq;
+          }
+        }
+        const std::vector<cplx> Ri = upper_inverse_z(k, R);
+        Un.alloc((size_t)N * k);
+        auto times_ri = [&](double *W) { // W <- W R^{-1} (columns are the k vectors)
+          HIP_OK(hipMemcpyAsync(Un.p, W, sizeof(double) * N * k, hipMemcpyDeviceToDevice, st));
+          std::vector<cplx> col(k);
+          for (int c = 0; c < k; ++c) {
+            for (int q = 0; q < k; ++q) col[q] = Ri[(size_t)q * k + c];
+            lincomb(Un.p, k, col.data(), 1.0, 0.0, W + (size_t)c * N);
+          }
+        };
+        times_ri(rec.C.p);
+        times_ri(rec.U.p);
+        if (right) times_ri(PT.p);
+      }
+      dots(rec.C.p, k, r, t);
+      std::vector<cplx> h(t.begin(), t.begin() + k);
+      lincomb(rec.C.p, k, h.data(), -1.0, 1.0, r);
+      if (right && o.same_system != 0) {
+        lincomb(rec.U.p, k, h.data(), 1.0, 0.0, T.p);
+        A.apply(T.p, Ax.p, 1);
+        Z.axpby(1.0, x, 1.0, Ax.p, x);
+      } else lincomb(pt, k, h.data(), 1.0, 1.0, x);
+    }
+    dots(r, 1, r, t);
+    const double s0 = t[0].real();
+    if (j == 1 && s0 < std::pow(std::numeric_limits<double>::epsilon(), 2)) return 0;
+    Hbar.assign((size_t)(m + 1) * m, 0.0); // row-major (m+1) x m, before the rotations (`save` in the reference)
+    Bm.assign((size_t)std::max(k, 1) * m, 0.0);
+    Hr = Hbar;
+    auto Hb = [&](int rr, int cc) -> cplx & { return Hbar[(size_t)rr * m + cc]; };
+    auto HR = [&](int rr, int cc) -> cplx & { return Hr[(size_t)rr * m + cc]; };
+    const double beta0 = std::sqrt(s0);
+    scale(r, 1.0 / beta0);
+    std::fill(sv.begin(), sv.end(), cplx(0.0));
+    sv[i0]         = beta0;
+    int  i         = i0, dim = -1;
+    bool converged = false;
+    while (i < m && j <= o.max_it) {
+      double *w = vk(i + 1);
+      op(vk(i), w);
+      if (have) {
+        dots(rec.C.p, k, w, t);
+        for (int q = 0; q < k; ++q) Bm[(size_t)q * m + i] = t[q];
+        lincomb(rec.C.p, k, t.data(), -1.0, 1.0, w);
+      }
+      if (o.ortho == ORTHO_MGS) {
+        for (int q = i0; q <= i; ++q) {
+          dots(vk(q), 1, w, t);
+          Hb(q, i) = t[0];
+          lincomb(vk(q), 1, t.data(), -1.0, 1.0, w);
+        }
+      } else {
+        dots(vk(i0), i + 1 - i0, w, t);
+        for (int q = i0; q <= i; ++q) Hb(q, i) = t[q - i0];
+        lincomb(vk(i0), i + 1 - i0, t.data(), -1.0, 1.0, w);
+      }
+      dots(w, 1, w, t);
+      Hb(i + 1, i) = std::sqrt(t[0].real());
+      scale(w, 1.0 / Hb(i + 1, i).real());
+      // rotations on the Krylov part (rows / columns i0 ..): complex cosines, real sines (include/HPDDM_iterative.hpp:690-705)
+      for (int q = i0; q <= i + 1; ++q) HR(q, i) = Hb(q, i);
+      for (int q = i0; q < i; ++q) {
+        const cplx gamma = std::conj(cs[q]) * HR(q, i) + sn[q] * HR(q + 1, i);
+        HR(q + 1, i)     = -sn[q] * HR(q, i) + cs[q] * HR(q + 1, i);
+        HR(q, i)         = gamma;
+      }
+      const double delta = std::hypot(std::abs(HR(i, i)), std::abs(HR(i + 1, i)));
+      sn[i]              = HR(i + 1, i).real() / delta;
+      cs[i]              = HR(i, i) / delta;
+      HR(i, i)           = delta;
+      sv[i + 1]          = -sn[i] * sv[i];
+      sv[i] *= std::conj(cs[i]);
+      ++i;
+      const double res = std::abs(sv[i]);
+      hist.push_back(res);
+      if (o.verbosity > 3) printf("GCRODR (rhs): %3d %e %e\n", j, res, norm);
+      if ((o.tol > 0.0 && res / norm <= o.tol) || (o.tol < 0.0 && res <= -o.tol)) {
+        dim       = i;
+        converged = true;
+        break;
+      }
+      ++j;
+    }
+    if (dim < 0) dim = i;
+    if (!converged && !(j != o.max_it + 1 && i == m)) converged = true; // max_it reached
+    // ---- updateSolRecycling (include/HPDDM_iterative.hpp:338-393): y2 from the triangular system, y1 = C^H r - B y2 ----
+    std::vector<cplx> y(dim, 0.0);
+    for (int rr = dim - 1; rr >= i0; --rr) {
+      cplx acc = sv[rr];
+      for (int c = rr + 1; c < dim; ++c) acc -= HR(rr, c) * y[c];
+      y[rr] = acc / HR(rr, rr);
+    }
+    lincomb(vk(i0), dim - i0, y.data() + i0, 1.0, 0.0, T.p);
+    if (have) {
+      std::vector<cplx> y1(k, 0.0);
+      if (o.same_system == 0) {
+        dots(rec.C.p, k, vk(i0), t);
+        for (int q = 0; q < k; ++q) y1[q] = beta0 * t[q];
+      }
+      for (int q = 0; q < k; ++q)
+        for (int c = i0; c < dim; ++c) y1[q] -= Bm[(size_t)q * m + c] * y[c];
+      lincomb(rec.U.p, k, y1.data(), 1.0, 1.0, T.p);
+    }
+    if (o.variant == VARIANT_LEFT) Z.axpby(1.0, x, 1.0, T.p, x);
+    else {
+      A.apply(T.p, Ax.p, 1);
+      Z.axpby(1.0, x, 1.0, Ax.p, x);
+    }
+    // ---- the recycled subspace (frozen from the second solve on with -hpddm_recycle_same_system, :241) ----
+    if (converged && dim == m) scale(vk(m), Hb(m, m - 1).real()); // (the reference's last basis vector stays un-normalised when the cycle converges at its last step, :232-236)
+    if (o.same_system <= 1 && (!have || j > m - k)) {
+      std::vector<cplx> Pk, Q, R, w, EV;
+      int               kk = k, rowsG = dim + 1;
+      std::vector<cplx> Gm; // (dim+1) x dim: the matrix whose QR gives the new C
+      std::vector<double> un(k, 1.0);
+      auto pick = [&](const std::vector<int> &order, int cols) {
+        Pk.assign((size_t)dim * cols, 0.0);
+        for (int c = 0; c < cols; ++c)
+          for (int a = 0; a < dim; ++a) Pk[(size_t)a * cols + c] = EV[(size_t)a * dim + order[c]];
+      };
+      if (!have) {
+        kk = (j < k || dim < k) ? std::min(k, dim) : k;
+        // harmonic Ritz problem of the first cycle: H_m + h_{m+1,m}^2 s e_m^T, s by the recurrence of the reference on the rotated
+        // matrix (:262-270): s_{dim-1} = c_{dim-2} h, h = c_{dim-1} / delta_{dim-1}; then h <- -s_{i-1} h going up; s_0 = h
+        std::vector<cplx> Hm((size_t)dim * dim), sv2(dim, 0.0);
+        for (int a = 0; a < dim; ++a)
+          for (int c = 0; c < dim; ++c) Hm[(size_t)a * dim + c] = Hb(a, c);
+        {
+          cplx h = cs[dim - 1] / HR(dim - 1, dim - 1);
+          for (int a = dim - 1; a >= 1; --a) {
+            sv2[a] = cs[a - 1] * h;
+            h *= -sn[a - 1];
+          }
+          sv2[0] = h;
+        }
+        const cplx hl = Hb(dim, dim - 1);
+        for (int a = 0; a < dim; ++a) Hm[(size_t)a * dim + dim - 1] += hl * hl * sv2[a];
+        HH_CHECK(dense_eig_z(dim, Hm, w, EV), "GCRODR: the eigen-solver did not converge");
+        pick(target_order_z(o.target, w), kk);
+        Gm.assign((size_t)(dim + 1) * dim, 0.0);
+        for (int a = 0; a <= dim; ++a)
+          for (int c = 0; c < dim; ++c) Gm[(size_t)a * dim + c] = Hb(a, c);
+      } else {
+        // G = [[D, B], [0, Hbar]], W = [C, V_{k..dim}], Vh = [U D, V_{k..dim-1}]; A z = theta B z with A = G^H G, B = G^H W^H Vh
+        for (int q = 0; q < k; ++q) {
+          dots(rec.U.p + (size_t)q * N, 1, rec.U.p + (size_t)q * N, t);
+          un[q] = 1.0 / std::sqrt(t[0].real());
+        }
+        Gm.assign((size_t)(dim + 1) * dim, 0.0);
+        for (int q = 0; q < k; ++q) {
+          Gm[(size_t)q * dim + q] = un[q];
+          for (int c = k; c < dim; ++c) Gm[(size_t)q * dim + c] = Bm[(size_t)q * m + c];
+        }
+        for (int a = k; a <= dim; ++a)
+          for (int c = k; c < dim; ++c) Gm[(size_t)a * dim + c] = Hb(a, c);
+        std::vector<cplx> WV((size_t)(dim + 1) * dim, 0.0); // W^H D Vh: first k columns computed, then [0; I; 0]
+        for (int q = 0; q < k; ++q) {
+          dots(rec.C.p, k, rec.U.p + (size_t)q * N, t);
+          for (int a = 0; a < k; ++a) WV[(size_t)a * dim + q] = un[q] * t[a];
+          dots(vk(k), dim + 1 - k, rec.U.p + (size_t)q * N, t);
+          for (int a = k; a <= dim; ++a) WV[(size_t)a * dim + q] = un[q] * t[a - k];
+        }
+        for (int q = 0; q < dim - k; ++q) WV[(size_t)(k + q) * dim + k + q] = 1.0;
+        std::vector<cplx> Am((size_t)dim * dim, 0.0), Bmat((size_t)dim * dim, 0.0);
+        for (int a = 0; a < dim; ++a)
+          for (int c = 0; c < dim; ++c) {
+            cplx va = 0.0, vb = 0.0;
+            for (int q = 0; q <= dim; ++q) {
+              va += std::conj(Gm[(size_t)q * dim + a]) * Gm[(size_t)q * dim + c];
+              vb += std::conj(Gm[(size_t)q * dim + a]) * WV[(size_t)q * dim + c];
+            }
+            Am[(size_t)a * dim + c] = va, Bmat[(size_t)a * dim + c] = vb;
+          }
+        // theta smallest <=> mu = 1 / theta largest for A^{-1} B z = mu z; A is Hermitian positive definite: Cholesky A = L L^H
+        std::vector<cplx> Lc((size_t)dim * dim, 0.0);
+        for (int a = 0; a < dim; ++a)
+          for (int c = 0; c <= a; ++c) {
+            cplx v = Am[(size_t)a * dim + c];
+            for (int q = 0; q < c; ++q) v -= Lc[(size_t)a * dim + q] * std::conj(Lc[(size_t)c * dim + q]);
+            if (a == c) {
+              HH_CHECK(v.real() > 0.0, "GCRODR: G^H G is not positive definite");
+              Lc[(size_t)a * dim + a] = std::sqrt(v.real());
+            } else Lc[(size_t)a * dim + c] = v / Lc[(size_t)c * dim + c].real();
+          }
+        std::vector<cplx> Mm(Bmat);
+        for (int c = 0; c < dim; ++c) {
+          for (int a = 0; a < dim; ++a) { // L y = b
+            cplx v = Mm[(size_t)a * dim + c];
+            for (int q = 0; q < a; ++q) v -= Lc[(size_t)a * dim + q] * Mm[(size_t)q * dim + c];
+            Mm[(size_t)a * dim + c] = v / Lc[(size_t)a * dim + a].real();
+          }
+          for (int a = dim - 1; a >= 0; --a) { // L^H x = y
+            cplx v = Mm[(size_t)a * dim + c];
+            for (int q = a + 1; q < dim; ++q) v -= std::conj(Lc[(size_t)q * dim + a]) * Mm[(size_t)q * dim + c];
+            Mm[(size_t)a * dim + c] = v / Lc[(size_t)a * dim + a].real();
+          }
+        }
+        HH_CHECK(dense_eig_z(dim, Mm, w, EV), "GCRODR: the eigen-solver did not converge");
+        std::vector<cplx> theta(dim); // theta = 1 / mu (mu = 0: theta = infinity)
+        for (int a = 0; a < dim; ++a) theta[a] = std::norm(w[a]) > 0.0 ? 1.0 / w[a] : cplx(std::numeric_limits<double>::infinity(), 0.0);
+        pick(target_order_z(o.target, theta), kk);
+      }
+      // [Q, R] = qr(G P); C = W Q; U = Vh P R^{-1}
+      std::vector<cplx> GP((size_t)rowsG * kk, 0.0);
+      for (int a = 0; a < rowsG; ++a)
+        for (int c = 0; c < kk; ++c) {
+          cplx v = 0.0;
+          for (int q = 0; q < dim; ++q) v += Gm[(size_t)a * dim + q] * Pk[(size_t)q * kk + c];
+          GP[(size_t)a * kk + c] = v;
+        }
+      small_qr_z(rowsG, kk, GP, Q, R);
+      const std::vector<cplx> Ri = upper_inverse_z(kk, R);
+      std::vector<cplx>       PR((size_t)dim * kk, 0.0); // P R^{-1}
+      for (int a = 0; a < dim; ++a)
+        for (int c = 0; c < kk; ++c) {
+          cplx v = 0.0;
+          for (int q = 0; q <= c; ++q) v += Pk[(size_t)a * kk + q] * Ri[(size_t)q * kk + c];
+          PR[(size_t)a * kk + c] = v;
+        }
+      Un.alloc((size_t)N * kk), Cn.alloc((size_t)N * kk);
+      std::vector<cplx> col(dim + 1);
+      for (int c = 0; c < kk; ++c) {
+        if (!have) {
+          for (int q = 0; q < dim; ++q) col[q] = PR[(size_t)q * kk + c];
+          lincomb(vk(0), dim, col.data(), 1.0, 0.0, Un.p + (size_t)c * N);
+          for (int q = 0; q <= dim; ++q) col[q] = Q[(size_t)q * kk + c];
+          lincomb(vk(0), dim + 1, col.data(), 1.0, 0.0, Cn.p + (size_t)c * N);
+        } else {
+          for (int q = 0; q < k; ++q) col[q] = un[q] * PR[(size_t)q * kk + c];
+          lincomb(rec.U.p, k, col.data(), 1.0, 0.0, Un.p + (size_t)c * N);
+          for (int q = k; q < dim; ++q) col[q - k] = PR[(size_t)q * kk + c];
+          lincomb(vk(k), dim - k, col.data(), 1.0, 1.0, Un.p + (size_t)c * N);
+          for (int q = 0; q < k; ++q) col[q] = Q[(size_t)q * kk + c];
+          lincomb(rec.C.p, k, col.data(), 1.0, 0.0, Cn.p + (size_t)c * N);
+          for (int q = k; q <= dim; ++q) col[q - k] = Q[(size_t)q * kk + c];
+          lincomb(vk(k), dim + 1 - k, col.data(), 1.0, 1.0, Cn.p + (size_t)c * N);
+        }
+      }
+      rec.U.alloc((size_t)N * kk), rec.C.alloc((size_t)N * kk);
+      HIP_OK(hipMemcpyAsync(rec.U.p, Un.p, sizeof(double) * N * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipMemcpyAsync(rec.C.p, Cn.p, sizeof(double) * N * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipStreamSynchronize(st));
+      rec.k = k = kk;
+    }
+    if (converged) break;
+    if (o.verbosity > 1) printf("GCRODR restart(%d, %d)\n", m, k);
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(j, o.max_it);
+}
+} // namespace
+
+// host-only checks of the complex dense helpers above (HpddmHipHostSelfTest): 0, or the number of the first check that fails
+int zkrylov_host_selftest()
+{
+  const int         rows = 7, cols = 3;
+  std::vector<cplx> M((size_t)rows * cols), Q, R;
+  for (int i = 0; i < rows * cols; ++i) M[i] = cplx(std::sin(1.0 + 0.7 * i) + (i % 4 == 0 ? 1.5 : 0.0), std::cos(0.3 * i) - (i % 5 == 0 ? 0.8 : 0.0));
+  small_qr_z(rows, cols, M, Q, R);
+  for (int a = 0; a < cols; ++a)
+    for (int b = 0; b < cols; ++b) {
+      cplx v = 0.0;
+      for (int i = 0; i < rows; ++i) v += std::conj(Q[(size_t)i * cols + a]) * Q[(size_t)i * cols + b];
+      if (std::abs(v - (a == b ? 1.0 : 0.0)) > 1e-13) return 20; // Q^H Q = I
+      if (a > b && R[(size_t)a * cols + b] != cplx(0.0)) return 21; // R upper triangular
+    }
+  for (int i = 0; i < rows; ++i)
+    for (int b = 0; b < cols; ++b) {
+      cplx v = 0.0;
+      for (int a = 0; a < cols; ++a) v += Q[(size_t)i * cols + a] * R[(size_t)a * cols + b];
+      if (std::abs(v - M[(size_t)i * cols + b]) > 1e-13) return 22; // Q R = M
+    }
+  const std::vector<cplx> Ri = upper_inverse_z(cols, R);
+  for (int a = 0; a < cols; ++a)
+    for (int b = 0; b < cols; ++b) {
+      cplx v = 0.0;
+      for (int c = 0; c < cols; ++c) v += R[(size_t)a * cols + c] * Ri[(size_t)c * cols + b];
+      if (std::abs(v - (a == b ? 1.0 : 0.0)) > 1e-12) return 23; // R R^{-1} = I
+    }
+  const std::vector<cplx> w = {{3.0, 0.0}, {0.5, 2.0}, {0.5, -2.5}, {-1.0, 0.0}, {0.2, 0.1}};
+  const std::vector<int>  sm = target_order_z(0, w), lm = target_order_z(1, w), sr = target_order_z(2, w), lr = target_order_z(3, w), si = target_order_z(4, w), li = target_order_z(5, w);
+  if (sm[0] != 4 || sm[1] != 3 || sm[2] != 1 || sm[3] != 2 || sm[4] != 0) return 24;
+  if (lm[0] != 0 || lm[1] != 2 || sr[0] != 3 || lr[0] != 0 || si[0] != 2 || li[0] != 1) return 25;
+  return 0;
+}
+
+int Schwarz::gcrodr_z(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK((factored || custom_mv) && is_complex, "complex GCRODR: complex operator and CallNumfact first");
+  ZGcroOptions o;
+  o.tol         = getopt("tol", 1.0e-6);
+  o.max_it      = std::min<int>((int)getopt("max_it", 100), std::numeric_limits<short>::max());
+  o.m           = std::max(1, std::min((int)getopt("gmres_restart", 40), o.max_it));
+  o.k           = std::min(o.m - 1, (int)getopt("recycle", 0));
+  o.variant     = (int)getopt("variant", VARIANT_RIGHT);
+  o.ortho       = (int)getopt("orthogonalization", ORTHO_CGS);
+  o.verbosity   = (int)getopt("verbosity", 0);
+  o.same_system = std::min((int)getopt("recycle_same_system", 0), 2);
+  if (o.k <= 0) return gmres_z(b, x, mu, history, history_cap); // "please choose a positive number of Ritz vectors" (:52-55)
+  HH_CHECK(o.variant == VARIANT_RIGHT || o.variant == VARIANT_LEFT, "GCRODR: left and right preconditioning are built");
+  o.target = (int)getopt("recycle_target", 0);
+  HH_CHECK(getopt("recycle_strategy", 0) == 0, "GCRODR: recycle_strategy A is built");
+  HH_CHECK(o.target >= 0 && o.target <= 5, "GCRODR: unknown recycle_target");
+  reserve(mu);
+  hipStream_t    st = library_stream();
+  const dim3     g2((unsigned)std::min(1024, (nmax + 255) / 256), (unsigned)nsub);
+  DevBuf<double> b1, x1;
+  b1.alloc((size_t)ntot), x1.alloc((size_t)ntot);
+  if ((int)recycled.size() < mu) recycled.resize(mu);
+  std::vector<std::vector<double>> hists(mu);
+  int                              it = 0;
+  for (int nu = 0; nu < mu; ++nu) {
+    if (!recycled[nu]) recycled[nu].reset(new Recycled());
+    hipLaunchKernelGGL(k_zcolumn, g2, dim3(256), 0, st, voff_d.p, n_d.p, const_cast<double *>(b), mu, nu, b1.p, 0);
+    hipLaunchKernelGGL(k_zcolumn, g2, dim3(256), 0, st, voff_d.p, n_d.p, x, mu, nu, x1.p, 0);
+    it = std::max(it, zgcrodr_one(*this, o, b1.p, x1.p, *recycled[nu], hists[nu]));
+    hipLaunchKernelGGL(k_zcolumn, g2, dim3(256), 0, st, voff_d.p, n_d.p, x, mu, nu, x1.p, 1);
+  }
+  // checkConvergence prints the residual of the first right-hand side unless one still iterating has a larger one
+  for (int jj = 0; jj < it; ++jj) {
+    double beta = hists[0].empty() ? 0.0 : hists[0][std::min<size_t>(jj, hists[0].size() - 1)];
+    for (int nu = 0; nu < mu; ++nu)
+      if ((int)hists[nu].size() > jj + 1) beta = std::max(beta, hists[nu][jj]);
+    if (history && jj < history_cap) history[jj] = beta;
+    if (o.verbosity > 2) printf("GCRODR: %3d %e\n", jj + 1, beta);
+  }
+  if (o.verbosity) {
+    if (it != o.max_it + 1 && it != 0) printf("GCRODR converges after %d iteration%s\n", it, it > 1 ? "s" : "");
+  }
+  if (it != 0 && o.same_system != 0) opt["recycle_same_system"] = getopt("recycle_same_system", 0) + 1; // (:433: from 2 on the subspace is frozen)
+  HIP_OK(hipStreamSynchronize(st));
+  return it;
+}
 
 int Schwarz::gmres_z(const double *b, double *x, int mu, double *history, int history_cap)
 {

@@ -169,6 +169,7 @@ struct Schwarz {
   void set_vectors_z(int s, int nu, const double *Z); // n x nu complex, column-major
   int  gmres_z(const double *b, double *x, int mu, double *history, int history_cap);  // krylov_complex.hip
   int  bgmres_z(const double *b, double *x, int mu, double *history, int history_cap);
+  int  gcrodr_z(const double *b, double *x, int mu, double *history, int history_cap);  // GCRO-DR in complex arithmetic, one right-hand side at a time
   void set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
   void expand_matrix(int s);   // the full 0-based CSR of subdomain s (GMV, coarse assembly) from the matrix as handed over, once
   void multiplicity_scaling(double *const *d);
@@ -237,5 +238,7 @@ struct Schwarz {
   // D-weighted reductions used by GMRES and computeResidual: out[k*mu+nu] = sum_s sum_i d_s[i] V_k[s][nu][i] w[s][nu][i]
   void wdots(const double *V, long long ldv, int k, const double *w, int mu, double *out_host);
 };
+
+int zkrylov_host_selftest(); // krylov_complex.hip: host-only checks of its complex dense helpers (HpddmHipHostSelfTest)
 
 } // namespace hpddm_hip

@@ -66,6 +66,13 @@ CASES = [
     ("p40_bfbcg_asm_mu3", 4, 3, "-Nx 40 -Ny 40 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_tol 1e-4"),
     ("p40_bfbcg_asm_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bfbcg -hpddm_schwarz_method asm -hpddm_deflation_tol 1e-6 -hpddm_tol 1e-4"),
     # GCRO-DR: GMRES(10) recycling 4 harmonic Ritz vectors, two successive solves (the second one starts from the recycled space)
+    # GCRO-DR for K = std::complex<double>: two solves (the second starts from the recycled space), right and left preconditioning
+    ("z_p30_gcrodr_two_solves", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10"),
+    ("z_p30_gcrodr_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8"),
+    # (with -hpddm_schwarz_coarse_correction deflated the reference's complex GCRO-DR does not converge at all -- 100 iterations, residual
+    # 2.6e+01 of 3.0e+01 on the 6-rank case its GMRES solves in 12: no fixture)
+    ("z_p30_gcrodr_left_mgs", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_variant left -hpddm_orthogonalization mgs"),
+    ("z_p30_gcrodr_target_lm_same_system", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_recycle_target LM -hpddm_recycle_same_system 1"),
     ("p40_gcrodr_two_solves", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10"),
     ("p40_gcrodr_same_system", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_same_system 1"),
     ("p40_gcrodr_target_lm", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_target LM"),

@@ -847,13 +847,16 @@ _TARGET_KEYS = {   # selectNu (include/HPDDM_specifications.hpp:90-126)
     "SI": lambda z: np.imag(z), "LI": lambda z: -np.imag(z)}
 
 
-def _harmonic_select(theta, vecs, k, target="SM"):
+def _harmonic_select(theta, vecs, k, target="SM", cplx=False):
     """k columns spanning the eigenvectors of the k eigenvalues that come first for -hpddm_recycle_target (default SM: smallest
     modulus; selectNu, include/HPDDM_specifications.hpp:90-126), real arithmetic: a complex pair gives (Re v, Im v); a pair cut by the limit k
     gives its real part only, like the first k columns of the reference's eigenvector array.  (That last case is only
     reproducible while the reference's std::sort of the moduli is stable, i.e. for at most 16 eigenvalues -- beyond, which half
     of a cut pair it keeps depends on the order LAPACK returned the eigenvalues in.  The fixtures avoid it above that size.)"""
     key = _TARGET_KEYS[target]
+    if cplx:   # K = std::complex<double>: the eigenvectors themselves, no pairs to keep together
+        order = sorted(range(len(theta)), key=lambda t: key(theta[t]))
+        return np.stack([vecs[:, t] for t in order[:k]], axis=1)
     order = sorted(range(len(theta)), key=lambda t: (key(theta[t]), -np.imag(theta[t])))
     cols = []
     used = set()
@@ -890,20 +893,24 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
         it, sol, hist = orc.gmres(b, tol=tol, max_it=max_it, restart=restart, variant=variant, ortho=ortho)
         return it, sol, hist, None
     P = orc.P
-    b = [np.asarray(v, dtype=np.float64).reshape(-1) for v in b]
+    cplx = any(np.iscomplexobj(v) for v in b)                  # K = std::complex<double>: every transposition below is a conjugate one
+    dt = np.complex128 if cplx else np.float64
+    b = [np.asarray(v, dtype=dt).reshape(-1) for v in b]
     m = max(1, min(restart, max_it))
     k = min(m - 1, recycle)
-    dot = lambda u, v: float(orc.wdot(u, v)[0]) if u[0].ndim == 2 else float(sum((orc.d[s] * u[s] * v[s]).sum() for s in range(P)))
+    real = (lambda z: z) if cplx else (lambda z: float(np.real(z)))
+    dot = lambda u, v: real(sum((orc.d[s] * np.conj(u[s]) * v[s]).sum() for s in range(P)))   # <u, v>_D, conjugate on the first argument
+    nrm2 = lambda u: float(np.real(dot(u, u)))
     lin = lambda cs, vs: [sum(c * v[p] for c, v in zip(cs, vs)) for p in range(P)]
     op = (lambda v: orc.apply(orc.gmv(v))) if variant == "left" else (lambda v: orc.gmv(orc.apply(v)))
     prec = (lambda v: v) if variant == "left" else orc.apply
-    x = orc.start([v[:, None] for v in b], [np.zeros((v.shape[0], 1)) for v in b])
+    x = orc.start([v[:, None] for v in b], [np.zeros((v.shape[0], 1), dtype=dt) for v in b])
     x = [v[:, 0] for v in x]
     if variant == "left":
         pb = orc.apply(b)
-        norm = np.sqrt(dot(pb, pb))
+        norm = np.sqrt(nrm2(pb))
     else:
-        norm = np.sqrt(dot(b, b))
+        norm = np.sqrt(nrm2(b))
     if norm < HPDDM_EPS:
         norm = 1.0
     U, C = (None, None) if state is None else ([list(u) for u in state[0]], [list(c) for c in state[1]])
@@ -921,7 +928,7 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             if not same_system:
                 C = [orc.gmv(p) if variant != "left" else orc.apply(orc.gmv(p)) for p in pt]
                 G = np.array([[dot(ci, cj) for cj in C] for ci in C])
-                R = np.linalg.cholesky(G).T                       # CholQR (QR<excluded>, include/HPDDM_iterative.hpp:622-640)
+                R = np.linalg.cholesky(G).conj().T                # CholQR (QR<excluded>, include/HPDDM_iterative.hpp:622-640)
                 Ri = np.linalg.inv(R)
                 C = [lin(Ri[:, c], C) for c in range(k)]
                 pt = [lin(Ri[:, c], pt) for c in range(k)]
@@ -933,12 +940,12 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             else:
                 corr = lin(h, pt)
             x = [xx + cc for xx, cc in zip(x, corr)]
-        s0 = dot(r, r)
+        s0 = nrm2(r)
         if j == 1 and s0 < np.finfo(float).eps ** 2:
             return 0, x, hist, (U, C) if U is not None else None
         V = [None] * (m + 1)
-        Hbar = np.zeros((m + 1, m))                              # the Hessenberg matrix before the rotations (`save`)
-        Bm = np.zeros((k, m))                                     # C^H A M^{-1} V
+        Hbar = np.zeros((m + 1, m), dtype=dt)                    # the Hessenberg matrix before the rotations (`save`)
+        Bm = np.zeros((k, m), dtype=dt)                           # C^H A M^{-1} V
         beta0 = np.sqrt(s0)
         V[i0] = [rr / beta0 for rr in r]
         i = i0
@@ -958,12 +965,12 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
                 hs = [dot(V[q], w) for q in range(i0, i + 1)]
                 Hbar[i0:i + 1, i] = hs
                 w = [ww - cc for ww, cc in zip(w, lin(hs, V[i0:i + 1]))]
-            Hbar[i + 1, i] = np.sqrt(dot(w, w))
+            Hbar[i + 1, i] = np.sqrt(nrm2(w))
             V[i + 1] = [ww / Hbar[i + 1, i] for ww in w]
             i += 1
             # the residual norm of the least-squares problem on the Krylov part (what the rotations of Arnoldi maintain)
             Hk = Hbar[i0:i + 1, i0:i]
-            e1 = np.zeros(i + 1 - i0)
+            e1 = np.zeros(i + 1 - i0, dtype=dt)
             e1[0] = beta0
             y2 = np.linalg.lstsq(Hk, e1, rcond=None)[0]
             res = np.linalg.norm(e1 - Hk @ y2)
@@ -979,12 +986,12 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             converged = True                                      # max_it reached
         # ---- updateSolRecycling: y2 minimises the Krylov part, y1 = C^H r - B y2 (include/HPDDM_iterative.hpp:338-393) ----
         Hk = Hbar[i0:dim + 1, i0:dim]
-        e1 = np.zeros(dim + 1 - i0)
+        e1 = np.zeros(dim + 1 - i0, dtype=dt)
         e1[0] = beta0
         y2 = np.linalg.lstsq(Hk, e1, rcond=None)[0]
         comb = lin(y2, V[i0:dim])
         if U is not None:
-            y1 = (np.zeros(k) if same_system else beta0 * np.array([dot(c, V[i0]) for c in C])) - Bm[:, i0:dim] @ y2
+            y1 = (np.zeros(k, dtype=dt) if same_system else beta0 * np.array([dot(c, V[i0]) for c in C])) - Bm[:, i0:dim] @ y2
             comb = [a + c for a, c in zip(comb, lin(y1, U))]
         x = [xx + cc for xx, cc in zip(x, comb if variant == "left" else orc.apply(comb))]
         # ---- the recycled subspace ----
@@ -1001,18 +1008,26 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             hlast = Hbar[dim, dim - 1]
             em = np.zeros(dim)
             em[-1] = 1.0
-            f = np.linalg.solve(Hm.T, em)
-            # The reference builds this vector from the rotations of Arnoldi (include/HPDDM_GCRODR.hpp:249-261) and what its
-            # recurrence yields is c^2 H_m^{-H} e_m, c the cosine of the last rotation -- not the plain harmonic Ritz
-            # problem of the GCRO-DR paper.  Reproduced: the recycled subspace depends on it.
+            # The reference builds this vector from the rotations of Arnoldi (include/HPDDM_GCRODR.hpp:249-261): with the cosines c_q
+            # (complex for complex K, = H_qq / rho_q) and the real sines s_q it runs h = c_{dim-1} / rho_{dim-1}; f_a = c_{a-1} h,
+            # h <- -s_{a-1} h for a = dim-1 .. 1; f_0 = h.  For real K that is c^2 H_m^{-T} e_m, c the cosine of the last rotation --
+            # not the plain harmonic Ritz problem of the GCRO-DR paper.  Reproduced: the recycled subspace depends on it.
             Rg = Hbar[:dim + 1, :dim].copy()
+            cq, sq, rho = np.zeros(dim, dtype=dt), np.zeros(dim), np.zeros(dim)
             for q in range(dim):
-                rho = np.hypot(Rg[q, q], Rg[q + 1, q])
-                cq, sq = Rg[q, q] / rho, Rg[q + 1, q] / rho
-                Rg[[q, q + 1], q:] = np.array([[cq, sq], [-sq, cq]]) @ Rg[[q, q + 1], q:]
-            f = cq ** 2 * f
+                rho[q] = np.hypot(abs(Rg[q, q]), abs(Rg[q + 1, q]))
+                cq[q], sq[q] = Rg[q, q] / rho[q], np.real(Rg[q + 1, q]) / rho[q]
+                Rg[[q, q + 1], q:] = np.array([[np.conj(cq[q]), sq[q]], [-sq[q], cq[q]]]) @ Rg[[q, q + 1], q:]
+            f = np.zeros(dim, dtype=dt)
+            h = cq[dim - 1] / rho[dim - 1]
+            for a in range(dim - 1, 0, -1):
+                f[a] = cq[a - 1] * h
+                h = -sq[a - 1] * h
+            f[0] = h
+            if not cplx:
+                assert np.allclose(f, cq[dim - 1] ** 2 * np.linalg.solve(Hm.T, em), rtol=1e-8, atol=1e-12 * np.abs(f).max())
             theta, vecs = np.linalg.eig(Hm + hlast ** 2 * np.outer(f, em))
-            Pk = _harmonic_select(theta, vecs, kk, target)
+            Pk = _harmonic_select(theta, vecs, kk, target, cplx)
             Q, R = np.linalg.qr(Hbar[:dim + 1, :dim] @ Pk)
             Y = [lin(Pk[:, c], V[:dim]) for c in range(kk)]
             Ri = np.linalg.inv(R)
@@ -1023,9 +1038,9 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             # recycle strategy A (the default).  Strategy B (:376-382: B = [[I, 0], [B_m^T, H^T]], U not scaled) is left out on
             # purpose: its pencil has the eigenvalue 1 with multiplicity k, so which vectors come out of the selection depends
             # on the internals of LAPACK's ggev -- the reference's own runs cannot be pinned.
-            un = np.array([1.0 / np.sqrt(dot(u, u)) for u in U])
+            un = np.array([1.0 / np.sqrt(nrm2(u)) for u in U])
             Uh = [[un[c] * up for up in U[c]] for c in range(k)]
-            G = np.zeros((dim + 1, dim))
+            G = np.zeros((dim + 1, dim), dtype=dt)
             G[:k, :k] = np.diag(un)
             G[:k, k:dim] = Bm[:, k:dim]
             G[k:dim + 1, k:dim] = Hbar[k:dim + 1, k:dim]
@@ -1035,8 +1050,8 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
             WV[:, k:] = 0.0
             for q in range(dim - k):                              # V_{m-k+1}^H V_{m-k}: identity on top of a zero row; C^H V = 0
                 WV[k + q, k + q] = 1.0
-            theta, vecs = sla.eig(G.T @ G, G.T @ WV)
-            Pk = _harmonic_select(theta, vecs, k, target)
+            theta, vecs = sla.eig(G.conj().T @ G, G.conj().T @ WV)
+            Pk = _harmonic_select(theta, vecs, k, target, cplx)
             Q, R = np.linalg.qr(G @ Pk)
             Y = [lin(Pk[:, c], Vh) for c in range(k)]
             Ri = np.linalg.inv(R)
