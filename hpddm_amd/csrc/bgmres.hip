@@ -1441,8 +1441,9 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   }
   if (is_complex) { // K = std::complex<double>: krylov_complex.hip
     if (method == 2) return cg(b, x, mu, history, history_cap); // real coefficients: the recurrences on the (re, im) arrays are the complex method
-    HH_CHECK(method == 0 || method == 1 || method == 4, "krylov_method: gmres, bgmres, gcrodr, cg, richardson and none are built for complex scalars");
+    HH_CHECK(method == 0 || method == 1 || method == 4 || method == 5, "krylov_method: gmres, bgmres, gcrodr, bgcrodr, cg, richardson and none are built for complex scalars (the reference's own complex bcg / bfbcg diverge)");
     if (method == 4) return gcrodr_z(b, x, mu, history, history_cap);
+    if (method == 5) return bgcrodr_z(b, x, mu, history, history_cap);
     return method == 1 ? bgmres_z(b, x, mu, history, history_cap) : gmres_z(b, x, mu, history, history_cap);
   }
   if (method == 1) return bgmres(b, x, mu, history, history_cap);

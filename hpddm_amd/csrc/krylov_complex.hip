@@ -1113,6 +1113,422 @@ int zgcrodr_one(Schwarz &A, const ZGcroOptions &o, const double *b, double *x, S
 }
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Block GCRO-DR for K = std::complex<double> (IterativeMethod::BGCRODR, include/HPDDM_GCRODR.hpp:445-905, instantiated for
+// complex scalars): the block method of bgmres.hip (bgcrodr_impl, whose comments describe the conventions reproduced -- the rank-p
+// term of the first harmonic Ritz problem built from the QR factors of the whole Hessenberg matrix, :676-688; the un-normalised
+// last block when a cycle converges on its last step) with every transposition a conjugate one, on the complex Gram blocks and
+// block updates of ZBlocks.  No right-hand-side deflation.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MU>
+int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap, Schwarz::Recycled &rec)
+{
+  constexpr int mu = MU, p = MU;
+  A.reserve(mu);
+  const double tol       = A.getopt("tol", 1.0e-6);
+  const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int    m         = std::max(1, std::min((int)A.getopt("gmres_restart", 40), max_it));
+  const int    variant   = (int)A.getopt("variant", VARIANT_RIGHT);
+  const int    verbosity = (int)A.getopt("verbosity", 0);
+  const int    same      = std::min((int)A.getopt("recycle_same_system", 0), 2);
+  const int    target    = (int)A.getopt("recycle_target", 0);
+  HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGCRODR: left and right preconditioning are built");
+  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGCRODR: right-hand-side deflation is not built");
+  HH_CHECK(A.getopt("recycle_strategy", 0) == 0, "BGCRODR: recycle_strategy A is built");
+  HH_CHECK(target >= 0 && target <= 5, "BGCRODR: unknown recycle_target");
+  const bool right = variant == VARIANT_RIGHT;
+  int        k     = rec.k > 0 ? rec.k : std::min(m - 1, (int)A.getopt("recycle", 0));
+  ZBlocks<MU>     Z(A, std::max(k, m + 1));
+  hipStream_t     st  = Z.st;
+  const long long cnt = Z.cnt;
+  const int       ldh = p * (m + 1), ncols = p * m;
+  DevBuf<double>  V, Ax, T, Un, Cn, PT;
+  V.alloc((size_t)cnt * (m + 1));
+  Ax.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  auto vk = [&](int q) { return V.p + (size_t)q * cnt; };
+  auto gram = [&](const double *Vb, int nb, const double *W, std::vector<cplx> &G) { // G[(kk mu + a) mu + b] = <V_kk[., a], W[., b]>_D
+    if (nb <= 0) {
+      G.clear();
+      return;
+    }
+    Z.gram(Vb, nb, W, G);
+  };
+  std::vector<cplx> coef;
+  auto axpy_blocks = [&](const double *Vb, int nb, const cplx *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
+    if (nb <= 0) {
+      if (beta == 0.0) HIP_OK(hipMemsetAsync(W, 0, sizeof(double) * cnt, st));
+      return;
+    }
+    coef.assign(Cm, Cm + (size_t)nb * mu * mu);
+    Z.axpy(Vb, nb, coef, sign, beta, W);
+  };
+  // block c of a (rows x cols) row-major coefficient matrix, rows = nb blocks of mu: the (nb mu) x mu matrix axpy_blocks wants
+  auto block_of = [&](const std::vector<cplx> &M, int cols, int row0, int nb, int c, std::vector<cplx> &out) {
+    out.resize((size_t)std::max(nb, 0) * mu * mu);
+    for (int q = 0; q < nb; ++q)
+      for (int a = 0; a < mu; ++a)
+        for (int bb = 0; bb < mu; ++bb) out[((size_t)q * mu + a) * mu + bb] = M[(size_t)(row0 + q * mu + a) * cols + c * mu + bb];
+  };
+  auto op = [&](const double *in, double *out) {
+    if (right) {
+      A.apply(in, Ax.p, mu);
+      A.gmv(Ax.p, out, mu);
+    } else {
+      A.gmv(in, Ax.p, mu);
+      A.apply(Ax.p, out, mu);
+    }
+  };
+  // upper Cholesky factor of a Hermitian matrix (row-major n x n): G = R^H R; false if G is not positive definite
+  auto potrf_u = [](int n, const std::vector<cplx> &Gh, std::vector<cplx> &R) {
+    R.assign((size_t)n * n, 0.0);
+    for (int q = 0; q < n; ++q) {
+      double dq = Gh[(size_t)q * n + q].real();
+      for (int t = 0; t < q; ++t) dq -= std::norm(R[(size_t)t * n + q]);
+      if (!(dq > 0.0)) return false;
+      dq                   = std::sqrt(dq);
+      R[(size_t)q * n + q] = dq;
+      for (int c = q + 1; c < n; ++c) {
+        cplx v = Gh[(size_t)q * n + c];
+        for (int t = 0; t < q; ++t) v -= std::conj(R[(size_t)t * n + q]) * R[(size_t)t * n + c];
+        R[(size_t)q * n + c] = v / dq;
+      }
+    }
+    return true;
+  };
+  // CholQR of one block: R (mu x mu upper, row-major), W <- W R^{-1}; false if the Gram matrix is not positive definite
+  auto cholqr = [&](double *W, std::vector<cplx> &R) {
+    std::vector<cplx> Gw;
+    gram(W, 1, W, Gw);
+    if (!potrf_u(mu, Gw, R)) return false;
+    const std::vector<cplx> Ri = upper_inverse_z(mu, R);
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    axpy_blocks(T.p, 1, Ri.data(), 1.0, 0.0, W);
+    return true;
+  };
+  std::vector<double> norm(mu);
+  std::vector<cplx>   G, R, S0, blk;
+  A.start(b, x, mu);
+  {
+    std::vector<cplx> nb;
+    if (!right) {
+      A.apply(b, T.p, mu);
+      gram(T.p, 1, T.p, nb);
+    } else {
+      const double *bn = A.norm_rhs(b, T.p, mu);
+      gram(bn, 1, bn, nb);
+    }
+    for (int nu = 0; nu < mu; ++nu) {
+      norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu].real());
+      if (norm[nu] < HPDDM_EPS) norm[nu] = 1.0;
+    }
+  }
+  std::vector<cplx> Hbar((size_t)(ncols + p) * ncols), Bm, Hr((size_t)ldh * ncols), s((size_t)ldh * p), tau((size_t)m * 2 * p);
+  auto              Hb = [&](int r, int c) -> cplx & { return Hbar[(size_t)r * ncols + c]; };
+  int               j = 1, nhist = 0;
+  while (j <= max_it) {
+    const bool have = rec.k > 0;
+    const int  i0 = have ? k : 0, kb = have ? k * p : 0;
+    double    *r0 = vk(i0);
+    if (right) {
+      A.gmv(x, r0, mu);
+      Z.axpby(1.0, b, -1.0, r0, r0);
+    } else {
+      A.gmv(x, T.p, mu);
+      Z.axpby(1.0, b, -1.0, T.p, T.p);
+      A.apply(T.p, r0, mu);
+    }
+    if (j == 1 && have) {
+      // a new solve starts from the recycled space (:516-546): C = A M^{-1} U re-orthonormalised (CholQR over its k p columns) unless
+      // -hpddm_recycle_same_system, then x += M^{-1} U (C^H r), r -= C (C^H r)
+      PT.alloc((size_t)cnt * k);
+      if (right)
+        for (int c = 0; c < k; ++c) A.apply(rec.U.p + (size_t)c * cnt, PT.p + (size_t)c * cnt, mu);
+      double *pt = right ? PT.p : rec.U.p;
+      if (same == 0) {
+        for (int c = 0; c < k; ++c) {
+          if (right) A.gmv(pt + (size_t)c * cnt, rec.C.p + (size_t)c * cnt, mu);
+          else {
+            A.gmv(pt + (size_t)c * cnt, Ax.p, mu);
+            A.apply(Ax.p, rec.C.p + (size_t)c * cnt, mu);
+          }
+        }
+        std::vector<cplx> Gf((size_t)kb * kb), Rf;
+        for (int c = 0; c < k; ++c) {
+          gram(rec.C.p, k, rec.C.p + (size_t)c * cnt, G);
+          for (int q = 0; q < k; ++q)
+            for (int a2 = 0; a2 < mu; ++a2)
+              for (int bb = 0; bb < mu; ++bb) Gf[(size_t)(q * mu + a2) * kb + c * mu + bb] = G[((size_t)q * mu + a2) * mu + bb];
+        }
+        HH_CHECK(potrf_u(kb, Gf, Rf), "BGCRODR: the recycled subspace lost its rank");
+        const std::vector<cplx> Ri = upper_inverse_z(kb, Rf);
+        Un.alloc((size_t)cnt * k);
+        auto times_ri = [&](double *W) {
+          HIP_OK(hipMemcpyAsync(Un.p, W, sizeof(double) * cnt * k, hipMemcpyDeviceToDevice, st));
+          for (int c = 0; c < k; ++c) {
+            block_of(Ri, kb, 0, k, c, blk);
+            axpy_blocks(Un.p, k, blk.data(), 1.0, 0.0, W + (size_t)c * cnt);
+          }
+        };
+        times_ri(rec.C.p);
+        times_ri(rec.U.p);
+        if (right) times_ri(PT.p);
+      }
+      gram(rec.C.p, k, r0, G); // (k mu) x mu
+      axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, r0);
+      if (right && same != 0) {
+        axpy_blocks(rec.U.p, k, G.data(), 1.0, 0.0, T.p);
+        A.apply(T.p, Ax.p, mu);
+        Z.axpby(1.0, x, 1.0, Ax.p, x);
+      } else axpy_blocks(pt, k, G.data(), 1.0, 1.0, x);
+    }
+    if (!cholqr(r0, S0)) return -2;
+    std::fill(Hbar.begin(), Hbar.end(), cplx(0.0));
+    Bm.assign((size_t)std::max(kb, 1) * ncols, 0.0);
+    std::fill(Hr.begin(), Hr.end(), cplx(0.0));
+    std::fill(s.begin(), s.end(), cplx(0.0));
+    std::fill(tau.begin(), tau.end(), cplx(0.0));
+    for (int c = 0; c < p; ++c)
+      for (int r = 0; r <= c; ++r) s[(i0 * p + r) + (size_t)c * ldh] = S0[(size_t)r * p + c];
+    auto Hc = [&](int i) { return Hr.data() + (size_t)i * p * ldh; };
+    int  i = i0, dimb = -1;
+    bool converged = false;
+    while (i < m && j <= max_it) {
+      double *W = vk(i + 1);
+      op(vk(i), W);
+      if (have) {
+        gram(rec.C.p, k, W, G);
+        for (int q = 0; q < kb; ++q)
+          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * mu + c];
+        axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, W);
+      }
+      gram(vk(i0), i + 1 - i0, W, G); // classical block Gram-Schmidt
+      axpy_blocks(vk(i0), i + 1 - i0, G.data(), -1.0, 1.0, W);
+      for (int q = 0; q < (i + 1 - i0) * p; ++q)
+        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * mu + c];
+      if (!cholqr(W, R)) return -2;
+      for (int r = 0; r < p; ++r)
+        for (int c = r; c < p; ++c) Hb((i + 1) * p + r, i * p + c) = R[(size_t)r * p + c];
+      // Householder QR of the block Hessenberg matrix (geqrf / mqr, BlockArnoldi include/HPDDM_iterative.hpp:727-729)
+      cplx *Hi = Hc(i);
+      for (int r = i0 * p; r < (i + 2) * p; ++r)
+        for (int c = 0; c < p; ++c) Hi[r + (size_t)c * ldh] = Hb(r, i * p + c);
+      for (int q = i0; q < i; ++q) zunm2r_lc(2 * p, p, p, Hc(q) + q * p, ldh, tau.data() + (size_t)q * 2 * p, Hi + q * p, ldh);
+      zgeqr2(2 * p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p);
+      zunm2r_lc(2 * p, p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p, s.data() + i * p, ldh);
+      ++i;
+      int    conv = 0, which = 0;
+      double best = -1.0;
+      for (int nu = 0; nu < p; ++nu) {
+        double nrm = 0.0;
+        for (int r = 0; r <= nu; ++r) nrm += std::norm(s[(p * i + r) + (size_t)nu * ldh]);
+        nrm = std::sqrt(nrm);
+        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / norm[nu] > best) best = nrm / norm[nu], which = nu;
+      }
+      const double beta = best * norm[which];
+      if (history && nhist < history_cap) history[nhist] = beta;
+      ++nhist;
+      if (verbosity > 2) printf("BGCRODR: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
+      if (conv == p) {
+        dimb      = i;
+        converged = true;
+        break;
+      }
+      ++j;
+    }
+    if (dimb < 0) dimb = i;
+    if (!converged && !(j != max_it + 1 && i == m)) converged = true; // max_it reached
+    // ---- updateSolRecycling: Y2 from the triangular system, Y1 = C^H r - B Y2 ----
+    const int         nk = (dimb - i0) * p; // Krylov columns
+    std::vector<cplx> Y2((size_t)std::max(nk, 1) * p, 0.0); // row-major nk x p
+    for (int c = 0; c < p; ++c)
+      for (int r = nk - 1; r >= 0; --r) {
+        cplx v = s[(i0 * p + r) + (size_t)c * ldh];
+        for (int q = r + 1; q < nk; ++q) v -= Hr[(i0 * p + r) + (size_t)(i0 * p + q) * ldh] * Y2[(size_t)q * p + c];
+        Y2[(size_t)r * p + c] = v / Hr[(i0 * p + r) + (size_t)(i0 * p + r) * ldh];
+      }
+    axpy_blocks(vk(i0), dimb - i0, Y2.data(), 1.0, 0.0, T.p);
+    if (have) {
+      std::vector<cplx> Y1((size_t)kb * p, 0.0);
+      if (same == 0) { // C^H D (V_{i0} S0) = (C^H D V_{i0}) S0
+        gram(rec.C.p, k, vk(i0), G);
+        for (int q = 0; q < kb; ++q)
+          for (int c = 0; c < p; ++c) {
+            cplx v = 0.0;
+            for (int t = 0; t <= c; ++t) v += G[(size_t)q * mu + t] * S0[(size_t)t * p + c];
+            Y1[(size_t)q * p + c] = v;
+          }
+      }
+      for (int q = 0; q < kb; ++q)
+        for (int c = 0; c < p; ++c) {
+          cplx v = 0.0;
+          for (int t = 0; t < nk; ++t) v += Bm[(size_t)q * ncols + i0 * p + t] * Y2[(size_t)t * p + c];
+          Y1[(size_t)q * p + c] -= v;
+        }
+      axpy_blocks(rec.U.p, k, Y1.data(), 1.0, 1.0, T.p);
+    }
+    if (!right) Z.axpby(1.0, x, 1.0, T.p, x);
+    else {
+      A.apply(T.p, Ax.p, mu);
+      Z.axpby(1.0, x, 1.0, Ax.p, x);
+    }
+    if (converged && dimb == m) { // the reference's un-normalised last block (:660-663 is skipped on convergence)
+      std::vector<cplx> Rl((size_t)p * p, 0.0);
+      for (int r = 0; r < p; ++r)
+        for (int c = 0; c < p; ++c) Rl[(size_t)r * p + c] = Hb(m * p + r, (m - 1) * p + c);
+      HIP_OK(hipMemcpyAsync(T.p, vk(m), sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_blocks(T.p, 1, Rl.data(), 1.0, 0.0, vk(m));
+    }
+    // ---- the recycled subspace ----
+    if (same <= 1 && (!have || j > m - k)) {
+      const int           nc = dimb * p, rowsG = nc + p;
+      int                 kk = k;
+      std::vector<cplx>   Gm((size_t)rowsG * nc, 0.0), Pk, Q, Rq, w, EV;
+      std::vector<double> un(std::max(kb, 1), 1.0);
+      auto pick = [&](const std::vector<int> &order, int cols) {
+        Pk.assign((size_t)nc * cols, 0.0);
+        for (int c = 0; c < cols; ++c)
+          for (int a = 0; a < nc; ++a) Pk[(size_t)a * cols + c] = EV[(size_t)a * nc + order[c]];
+      };
+      if (!have) {
+        kk = std::min(k, dimb);
+        for (int r = 0; r < rowsG; ++r)
+          for (int c = 0; c < nc; ++c) Gm[(size_t)r * nc + c] = Hb(r, c);
+        // H_m + F in its last block column, F = (Q [R^{-H} Z; 0])(first nc rows), Z = E_m h^H h, Q R the QR of the whole Hessenberg matrix
+        std::vector<cplx> Qh, Rh, Zm((size_t)nc * p, 0.0), Y((size_t)nc * p, 0.0), Hm((size_t)nc * nc);
+        small_qr_z(rowsG, nc, Gm, Qh, Rh);
+        for (int a2 = 0; a2 < p; ++a2)
+          for (int c = 0; c < p; ++c) {
+            cplx v = 0.0;
+            for (int t = 0; t < p; ++t) v += std::conj(Hb(nc + t, nc - p + a2)) * Hb(nc + t, nc - p + c);
+            Zm[(size_t)(nc - p + a2) * p + c] = v;
+          }
+        for (int c = 0; c < p; ++c) // R^H Y = Z (forward substitution with the lower triangular R^H)
+          for (int r = 0; r < nc; ++r) {
+            cplx v = Zm[(size_t)r * p + c];
+            for (int t = 0; t < r; ++t) v -= std::conj(Rh[(size_t)t * nc + r]) * Y[(size_t)t * p + c];
+            Y[(size_t)r * p + c] = v / std::conj(Rh[(size_t)r * nc + r]);
+          }
+        for (int r = 0; r < nc; ++r)
+          for (int c = 0; c < nc; ++c) Hm[(size_t)r * nc + c] = Hb(r, c);
+        for (int r = 0; r < nc; ++r)
+          for (int c = 0; c < p; ++c) {
+            cplx v = 0.0;
+            for (int t = 0; t < nc; ++t) v += Qh[(size_t)r * nc + t] * Y[(size_t)t * p + c];
+            Hm[(size_t)r * nc + nc - p + c] += v;
+          }
+        HH_CHECK(dense_eig_z(nc, Hm, w, EV), "BGCRODR: the eigen-solver did not converge");
+        pick(target_order_z(target, w), kk * p);
+      } else {
+        std::vector<cplx> Guu;
+        for (int c = 0; c < k; ++c) {
+          gram(rec.U.p + (size_t)c * cnt, 1, rec.U.p + (size_t)c * cnt, Guu);
+          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * mu + a2].real());
+        }
+        for (int q = 0; q < kb; ++q) {
+          Gm[(size_t)q * nc + q] = un[q];
+          for (int c = kb; c < nc; ++c) Gm[(size_t)q * nc + c] = Bm[(size_t)q * ncols + c];
+        }
+        for (int r = kb; r < rowsG; ++r)
+          for (int c = kb; c < nc; ++c) Gm[(size_t)r * nc + c] = Hb(r, c);
+        std::vector<cplx> WV((size_t)rowsG * nc, 0.0); // W^H D Vh: its first kb columns, then [0; I; 0]
+        for (int c = 0; c < k; ++c) {
+          gram(rec.C.p, k, rec.U.p + (size_t)c * cnt, G);
+          for (int q = 0; q < kb; ++q)
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+          gram(vk(k), dimb + 1 - k, rec.U.p + (size_t)c * cnt, G);
+          for (int q = 0; q < (dimb + 1 - k) * p; ++q)
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+        }
+        for (int q = 0; q < nc - kb; ++q) WV[(size_t)(kb + q) * nc + kb + q] = 1.0;
+        std::vector<cplx> Am((size_t)nc * nc), Mm((size_t)nc * nc), Lc((size_t)nc * nc, 0.0);
+        for (int a2 = 0; a2 < nc; ++a2)
+          for (int c = 0; c < nc; ++c) {
+            cplx va = 0.0, vb = 0.0;
+            for (int q = 0; q < rowsG; ++q) {
+              va += std::conj(Gm[(size_t)q * nc + a2]) * Gm[(size_t)q * nc + c];
+              vb += std::conj(Gm[(size_t)q * nc + a2]) * WV[(size_t)q * nc + c];
+            }
+            Am[(size_t)a2 * nc + c] = va, Mm[(size_t)a2 * nc + c] = vb;
+          }
+        for (int a2 = 0; a2 < nc; ++a2) // A = L L^H
+          for (int c = 0; c <= a2; ++c) {
+            cplx v = Am[(size_t)a2 * nc + c];
+            for (int q = 0; q < c; ++q) v -= Lc[(size_t)a2 * nc + q] * std::conj(Lc[(size_t)c * nc + q]);
+            if (a2 == c) {
+              HH_CHECK(v.real() > 0.0, "BGCRODR: G^H G is not positive definite");
+              Lc[(size_t)a2 * nc + a2] = std::sqrt(v.real());
+            } else Lc[(size_t)a2 * nc + c] = v / Lc[(size_t)c * nc + c].real();
+          }
+        for (int c = 0; c < nc; ++c) { // Mm <- A^{-1} B
+          for (int a2 = 0; a2 < nc; ++a2) {
+            cplx v = Mm[(size_t)a2 * nc + c];
+            for (int q = 0; q < a2; ++q) v -= Lc[(size_t)a2 * nc + q] * Mm[(size_t)q * nc + c];
+            Mm[(size_t)a2 * nc + c] = v / Lc[(size_t)a2 * nc + a2].real();
+          }
+          for (int a2 = nc - 1; a2 >= 0; --a2) {
+            cplx v = Mm[(size_t)a2 * nc + c];
+            for (int q = a2 + 1; q < nc; ++q) v -= std::conj(Lc[(size_t)q * nc + a2]) * Mm[(size_t)q * nc + c];
+            Mm[(size_t)a2 * nc + c] = v / Lc[(size_t)a2 * nc + a2].real();
+          }
+        }
+        HH_CHECK(dense_eig_z(nc, Mm, w, EV), "BGCRODR: the eigen-solver did not converge");
+        std::vector<cplx> theta(nc); // theta = 1 / mu
+        for (int a2 = 0; a2 < nc; ++a2) theta[a2] = std::norm(w[a2]) > 0.0 ? 1.0 / w[a2] : cplx(std::numeric_limits<double>::infinity(), 0.0);
+        pick(target_order_z(target, theta), kb);
+      }
+      const int         kc = kk * p; // columns of the new space
+      std::vector<cplx> GP((size_t)rowsG * kc, 0.0);
+      for (int r = 0; r < rowsG; ++r)
+        for (int c = 0; c < kc; ++c) {
+          cplx v = 0.0;
+          for (int q = 0; q < nc; ++q) v += Gm[(size_t)r * nc + q] * Pk[(size_t)q * kc + c];
+          GP[(size_t)r * kc + c] = v;
+        }
+      small_qr_z(rowsG, kc, GP, Q, Rq);
+      const std::vector<cplx> Ri = upper_inverse_z(kc, Rq);
+      std::vector<cplx>       PR((size_t)nc * kc, 0.0);
+      for (int r = 0; r < nc; ++r)
+        for (int c = 0; c < kc; ++c) {
+          cplx v = 0.0;
+          for (int q = 0; q <= c; ++q) v += Pk[(size_t)r * kc + q] * Ri[(size_t)q * kc + c];
+          PR[(size_t)r * kc + c] = (have && r < kb ? un[r] : 1.0) * v; // the U part of Vh is U D
+        }
+      Un.alloc((size_t)cnt * kk), Cn.alloc((size_t)cnt * kk);
+      for (int c = 0; c < kk; ++c) {
+        if (!have) {
+          block_of(PR, kc, 0, dimb, c, blk);
+          axpy_blocks(vk(0), dimb, blk.data(), 1.0, 0.0, Un.p + (size_t)c * cnt);
+          block_of(Q, kc, 0, dimb + 1, c, blk);
+          axpy_blocks(vk(0), dimb + 1, blk.data(), 1.0, 0.0, Cn.p + (size_t)c * cnt);
+        } else {
+          block_of(PR, kc, 0, k, c, blk);
+          axpy_blocks(rec.U.p, k, blk.data(), 1.0, 0.0, Un.p + (size_t)c * cnt);
+          block_of(PR, kc, kb, dimb - k, c, blk);
+          axpy_blocks(vk(k), dimb - k, blk.data(), 1.0, 1.0, Un.p + (size_t)c * cnt);
+          block_of(Q, kc, 0, k, c, blk);
+          axpy_blocks(rec.C.p, k, blk.data(), 1.0, 0.0, Cn.p + (size_t)c * cnt);
+          block_of(Q, kc, kb, dimb + 1 - k, c, blk);
+          axpy_blocks(vk(k), dimb + 1 - k, blk.data(), 1.0, 1.0, Cn.p + (size_t)c * cnt);
+        }
+      }
+      rec.U.alloc((size_t)cnt * kk), rec.C.alloc((size_t)cnt * kk);
+      HIP_OK(hipMemcpyAsync(rec.U.p, Un.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipMemcpyAsync(rec.C.p, Cn.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipStreamSynchronize(st));
+      rec.k = k = kk;
+    }
+    if (converged) break;
+    if (verbosity > 1) printf("BGCRODR restart(%d, %d)\n", m, k);
+  }
+  if (verbosity) {
+    if (j != max_it + 1) printf("BGCRODR converges after %d iteration%s\n", j, j > 1 ? "s" : "");
+    else printf("BGCRODR does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(j, max_it);
+}
+
 // host-only checks of the complex dense helpers above (HpddmHipHostSelfTest): 0, or the number of the first check that fails
 int zkrylov_host_selftest()
 {
@@ -1192,6 +1608,32 @@ int Schwarz::gcrodr_z(const double *b, double *x, int mu, double *history, int h
   }
   if (it != 0 && o.same_system != 0) opt["recycle_same_system"] = getopt("recycle_same_system", 0) + 1; // (:433: from 2 on the subspace is frozen)
   HIP_OK(hipStreamSynchronize(st));
+  return it;
+}
+
+int Schwarz::bgcrodr_z(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK((factored || custom_mv) && is_complex, "complex BGCRODR: complex operator and CallNumfact first");
+  if (std::min((int)getopt("gmres_restart", 40) - 1, (int)getopt("recycle", 0)) <= 0) return bgmres_z(b, x, mu, history, history_cap); // (:460-465)
+  if (!recycled_block || recycled_block_mu != mu) { // the recycled blocks belong to one block width (:477-481)
+    recycled_block.reset(new Recycled());
+    recycled_block_mu = mu;
+  }
+  const int same = (int)getopt("recycle_same_system", 0);
+  int       it;
+  switch (mu) {
+  case 1: it = zbgcrodr_impl<1>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 2: it = zbgcrodr_impl<2>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 3: it = zbgcrodr_impl<3>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 4: it = zbgcrodr_impl<4>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 5: it = zbgcrodr_impl<5>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 6: it = zbgcrodr_impl<6>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 7: it = zbgcrodr_impl<7>(*this, b, x, history, history_cap, *recycled_block); break;
+  case 8: it = zbgcrodr_impl<8>(*this, b, x, history, history_cap, *recycled_block); break;
+  default: HH_CHECK(false, "BGCRODR: 1 <= mu <= 8 for complex scalars in this build"); it = -1;
+  }
+  if (it == -2) return gmres_z(b, x, mu, history, history_cap); // breakdown of a CholQR: GMRES, like BGMRES
+  if (it != 0 && same != 0) opt["recycle_same_system"] = same + 1; // (:433 of the non-block method, same rule)
   return it;
 }
 

@@ -106,8 +106,8 @@ int HpddmHipSchwarzSetVectors(HpddmHipSchwarz *A, int s, int nu, const double *Z
  * always 'G' (examples/schwarz.hpp:48-79); GMRES and BGMRES run with complex inner products and coefficients
  * (include/HPDDM_GMRES.hpp instantiated for complex K); CG (-hpddm_krylov_method cg, Hermitian positive definite operators with
  * ASM / SORAS) runs too: every coefficient of the reference's CG is the real part of a dot product, so the recurrences on the
- * (re, im) arrays are the complex method.  GenEO, the block CG methods, GCRO-DR, the optimised matrices and the penalised rows
- * are real-only in this build. */
+ * (re, im) arrays are the complex method; GCRO-DR and Block GCRO-DR run in complex arithmetic too (include/HPDDM_GCRODR.hpp
+ * instantiated for complex K).  The block CG methods and the penalised rows are real-only in this build. */
 int HpddmHipSchwarzSetSubdomainZ(HpddmHipSchwarz *A, int s, int n, const int *ia, const int *ja, const double *a, int sym, char numbering, int neighbors, const int *list, const int *sizes, const int *const *connectivity);
 int HpddmHipSchwarzSetVectorsZ(HpddmHipSchwarz *A, int s, int nu, const double *Z);
 int HpddmHipSchwarzIsComplex(const HpddmHipSchwarz *A);

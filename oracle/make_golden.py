@@ -73,6 +73,8 @@ CASES = [
     # 2.6e+01 of 3.0e+01 on the 6-rank case its GMRES solves in 12: no fixture)
     ("z_p30_gcrodr_left_mgs", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_variant left -hpddm_orthogonalization mgs"),
     ("z_p30_gcrodr_target_lm_same_system", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_recycle_target LM -hpddm_recycle_same_system 1"),
+    ("z_p30_bgcrodr_two_solves_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8"),
+    ("z_p30_6ranks_bgcrodr_left_mu3", 6, 3, "-Nx 30 -Ny 30 -overlap 2 -complex_shift_re -5 -complex_shift_im 3 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 2 -hpddm_gmres_restart 8 -hpddm_variant left"),
     ("p40_gcrodr_two_solves", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10"),
     ("p40_gcrodr_same_system", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_same_system 1"),
     ("p40_gcrodr_target_lm", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_target LM"),

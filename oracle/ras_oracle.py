@@ -1072,7 +1072,10 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         it, sol, hist = bgmres(orc, b, tol=tol, max_it=max_it, restart=restart, variant=variant)
         return it, sol, hist, None
     P = orc.P
-    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    cplx = any(np.iscomplexobj(v) for v in b)                  # K = std::complex<double>: every transposition below is a conjugate one
+    dt = np.complex128 if cplx else np.float64
+    H = lambda M: M.conj().T
+    b = [np.asarray(v, dtype=dt).reshape(v.shape[0], -1) for v in b]
     p = b[0].shape[1]
     m = max(1, min(restart, max_it))
     k = min(m - 1, recycle)
@@ -1082,12 +1085,12 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
     prec = (lambda v: v) if variant == "left" else orc.apply
 
     def cholqr(W):
-        R = np.linalg.cholesky(_gram(orc, W, W)).T
+        R = H(np.linalg.cholesky(_gram(orc, W, W)))
         return lin(np.linalg.inv(R), W), R
 
     x = orc.start(b, [np.zeros_like(v) for v in b])
     nb = _gram(orc, orc.apply(b), orc.apply(b)) if variant == "left" else _gram(orc, b, b)
-    norm = np.sqrt(np.diag(nb))
+    norm = np.sqrt(np.real(np.diag(nb)))
     norm[norm < HPDDM_EPS] = 1.0
     U, C = (None, None) if state is None else state
     if U is not None:
@@ -1115,8 +1118,8 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         except np.linalg.LinAlgError:
             return -2, [v if p > 1 else v[:, 0] for v in x], hist, state
         ncols = m * p
-        Hbar = np.zeros((ncols + p, ncols))                        # scalar view of the block Hessenberg matrix
-        Bm = np.zeros((max(kb, 1), ncols))
+        Hbar = np.zeros((ncols + p, ncols), dtype=dt)              # scalar view of the block Hessenberg matrix
+        Bm = np.zeros((max(kb, 1), ncols), dtype=dt)
         V = [None] * (m + 1)
         i0 = k if have else 0
         V[i0] = V0
@@ -1127,7 +1130,7 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         # the rotated matrix, sr the rotated right-hand side [S0; 0]; like BGMRES, the reference reads the residual of column nu
         # off the first nu + 1 entries of the trailing block of sr (checkBlockConvergence), whatever the rest of it holds
         Hr = np.zeros_like(Hbar)
-        sr = np.zeros((ncols + p, p))
+        sr = np.zeros((ncols + p, p), dtype=dt)
         sr[i0 * p:(i0 + 1) * p] = S0
         taus = {}
         while i < m and j <= max_it:
@@ -1147,11 +1150,11 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             Hbar[(i + 1) * p:(i + 2) * p, cols] = Rn
             Hr[i0 * p:(i + 2) * p, cols] = Hbar[i0 * p:(i + 2) * p, cols]
             for q in range(i0, i):
-                Hr[q * p:(q + 2) * p, cols] = taus[q].T @ Hr[q * p:(q + 2) * p, cols]
+                Hr[q * p:(q + 2) * p, cols] = H(taus[q]) @ Hr[q * p:(q + 2) * p, cols]
             Qh, Rh = np.linalg.qr(Hr[i * p:(i + 2) * p, cols], mode="complete")
             taus[i] = Qh
             Hr[i * p:(i + 2) * p, cols] = Rh
-            sr[i * p:(i + 2) * p] = Qh.T @ sr[i * p:(i + 2) * p]
+            sr[i * p:(i + 2) * p] = H(Qh) @ sr[i * p:(i + 2) * p]
             i += 1
             res = np.array([np.linalg.norm(sr[i * p:i * p + nu + 1, nu]) for nu in range(p)])
             which = int(np.argmax(res / norm))
@@ -1169,7 +1172,7 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         Vk = hcat(V[i0:dimb])
         comb = lin(Y2, Vk)
         if have:
-            Y1 = (np.zeros((kb, p)) if same_system else _gram(orc, C, lin(S0, V[i0]))) - Bm[:kb, i0 * p:dimb * p] @ Y2
+            Y1 = (np.zeros((kb, p), dtype=dt) if same_system else _gram(orc, C, lin(S0, V[i0]))) - Bm[:kb, i0 * p:dimb * p] @ Y2
             comb = [a + c for a, c in zip(comb, lin(Y1, U))]
         x = [xx + cc for xx, cc in zip(x, comb if variant == "left" else orc.apply(comb))]
         if converged and dimb == m:   # un-normalised last block on convergence at the end of a cycle, like gcrodr above (:660-663)
@@ -1181,15 +1184,15 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             nc = dimb * p
             Hm = Hbar[:nc, :nc].copy()
             h = Hbar[nc:nc + p, nc - p:nc]
-            Z = np.zeros((nc, p))
-            Z[nc - p:] = h.T @ h
+            Z = np.zeros((nc, p), dtype=dt)
+            Z[nc - p:] = H(h) @ h
             # the reference applies the factors of its QR of the whole Hessenberg matrix: Q [R^{-T} Z; 0], first nc rows
             # (include/HPDDM_GCRODR.hpp:676-688) -- for p = 1 this is the c^2 H^{-T} e_m of gcrodr above
             Qf, Rf = np.linalg.qr(Hbar[:nc + p, :nc], mode="complete")
-            Fm = (Qf @ np.vstack([np.linalg.solve(Rf[:nc].T, Z), np.zeros((p, p))]))[:nc]
+            Fm = (Qf @ np.vstack([np.linalg.solve(H(Rf[:nc]), Z), np.zeros((p, p))]))[:nc]
             Hm[:, nc - p:] += Fm
             theta, vecs = np.linalg.eig(Hm)
-            Pk = _harmonic_select(theta, vecs, kk * p, target)
+            Pk = _harmonic_select(theta, vecs, kk * p, target, cplx)
             Q, R = np.linalg.qr(Hbar[:nc + p, :nc] @ Pk)
             Vall = hcat(V[:dimb + 1])
             Ri = np.linalg.inv(R)
@@ -1198,9 +1201,9 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             k = kk
         elif j > m - k:
             nc = dimb * p                                            # columns of G; rows nc + p
-            un = 1.0 / np.sqrt(np.diag(_gram(orc, U, U)))
+            un = 1.0 / np.sqrt(np.real(np.diag(_gram(orc, U, U))))
             Uh = lin(np.diag(un), U)
-            G = np.zeros((nc + p, nc))
+            G = np.zeros((nc + p, nc), dtype=dt)
             G[:kb, :kb] = np.diag(un)
             G[:kb, kb:nc] = Bm[:kb, kb:nc]
             G[kb:nc + p, kb:nc] = Hbar[kb:nc + p, kb:nc]
@@ -1210,8 +1213,8 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             WV[:, kb:] = 0.0
             for q in range(nc - kb):
                 WV[kb + q, kb + q] = 1.0
-            theta, vecs = sla.eig(G.T @ G, G.T @ WV)
-            Pk = _harmonic_select(theta, vecs, kb, target)
+            theta, vecs = sla.eig(H(G) @ G, H(G) @ WV)
+            Pk = _harmonic_select(theta, vecs, kb, target, cplx)
             Q, R = np.linalg.qr(G @ Pk)
             U = lin(Pk @ np.linalg.inv(R), Vh)
             C = lin(Q, Wb)

@@ -331,7 +331,8 @@ def test_cg_matches_reference():
 
 @pytest.mark.parametrize("name", ["p40_gcrodr_two_solves", "p40_gcrodr_same_system", "p30_6ranks_gcrodr_left_deflated_mu2", "p40_gcrodr_target_lm",
                                   "p40_gcrodr_cycle_end", "p40_bgcrodr_two_solves_mu2", "p30_6ranks_bgcrodr_left_deflated_mu3",
-                                  "z_p30_gcrodr_two_solves", "z_p30_gcrodr_mu2", "z_p30_gcrodr_left_mgs", "z_p30_gcrodr_target_lm_same_system"])
+                                  "z_p30_gcrodr_two_solves", "z_p30_gcrodr_mu2", "z_p30_gcrodr_left_mgs", "z_p30_gcrodr_target_lm_same_system",
+                                  "z_p30_bgcrodr_two_solves_mu2", "z_p30_6ranks_bgcrodr_left_mu3"])
 def test_gcrodr_matches_reference(name):
     """GCRO-DR (include/HPDDM_GCRODR.hpp:34-443), two successive solves on one operator: the first one builds the recycled
     subspace (harmonic Ritz vectors after its first cycle, generalised eigenproblem at every later restart), the second one
@@ -340,7 +341,8 @@ def test_gcrodr_matches_reference(name):
     the block method (include/HPDDM_GCRODR.hpp:445-905): 18 then 13 iterations for two right-hand sides; cycle_end is a run whose
     first solve converges on the last step of a cycle (the reference then recycles an un-normalised last vector).  The z_ fixtures
     are the reference built for K = std::complex<double> (33 + 33, 37 + 35 with two right-hand sides, 17 + 15 left-preconditioned
-    with MGS, 22 + 22 with target LM and a frozen subspace): GCRO-DR in complex arithmetic, krylov_complex.hip."""
+    with MGS, 22 + 22 with target LM and a frozen subspace; block method: 36 + 32 for two right-hand sides, 19 + 18 for three,
+    left-preconditioned on 6 subdomains): GCRO-DR and Block GCRO-DR in complex arithmetic, krylov_complex.hip."""
     g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)

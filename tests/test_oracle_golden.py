@@ -239,7 +239,9 @@ def test_richardson_and_no_krylov_match_reference():
     _close(sol, gu.vecs(g, "sol"), 1e-12, "one apply")
 
 
-@pytest.mark.parametrize("name,recycle", [("p40_bgcrodr_two_solves_mu2", 3), ("p30_6ranks_bgcrodr_left_deflated_mu3", 2)])
+@pytest.mark.parametrize("name,recycle", [("p40_bgcrodr_two_solves_mu2", 3), ("p30_6ranks_bgcrodr_left_deflated_mu3", 2),
+                                          # K = std::complex<double>: 36 + 32 and 19 + 18 iterations of the reference built for complex scalars
+                                          ("z_p30_bgcrodr_two_solves_mu2", 3), ("z_p30_6ranks_bgcrodr_left_mu3", 2)])
 def test_block_gcrodr_matches_reference(name, recycle):
     """Block GCRO-DR (include/HPDDM_GCRODR.hpp:445-905), two successive solves: 18 then 13 iterations for two right-hand sides.
     In the first fixture a complex pair of harmonic Ritz values is cut by the selection after the first cycle, and the first
