@@ -251,6 +251,41 @@ int HpddmHipHostSelfTest(void)
       }
     }
     if (const int zc = zkrylov_host_selftest()) return zc; // the complex helpers of krylov_complex.hip (20 ..)
+    { // plan of the contribution-block arena of the device levels (numeric_host.cpp): chunks alive together never overlap, dead ones are reused
+      // a tree of 5 levels: fronts 0..7 at height 0 (host), 8..11 at height 1, 12..13 at height 2, 14 at height 3 with one child of height 1
+      // (front 11: its block lives through level 2), 15 (root) at height 4
+      Symbolic sy;
+      sy.nblk   = 16;
+      sy.height = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 4};
+      sy.parent = {8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 14, 14, 15, 15, -1};
+      const int nbs[16] = {3, 3, 3, 3, 3, 3, 3, 3, 40, 40, 40, 24, 64, 48, 32, 0};
+      sy.row_ptr.assign(17, 0);
+      for (int k = 0; k < 16; ++k) sy.row_ptr[k + 1] = sy.row_ptr[k] + nbs[k];
+      std::vector<size_t> off, size;
+      for (int cs = 1; cs <= 2; ++cs) {
+        const size_t peak = plan_contribution_arena(sy, 5, 1, cs, off, size);
+        auto r16 = [&](size_t nb) { return (nb * nb * cs + 15) / 16 * 16; };
+        if (size[0] != 0 || size[1] != 3 * r16(40) + r16(24) || size[2] != r16(64) + r16(48) || size[3] != r16(32) || size[4] != 0) return 30;
+        const int until[5] = {0, 3, 4, 4, 4}; // level 1 holds front 11's block until level 3 has been assembled
+        size_t    all = 0, top = 0;
+        for (int l = 1; l < 5; ++l) {
+          all += size[l];
+          top = std::max(top, off[l] + size[l]);
+          for (int q = 1; q < l; ++q) // alive together: level q's chunk while level l <= until[q] is being filled
+            if (until[q] >= l && size[q] && size[l] && off[q] < off[l] + size[l] && off[l] < off[q] + size[q]) return 31;
+        }
+        if (peak != top || peak > all) return 32;
+        if (off[1] != 0 || off[2] != size[1] || off[3] != size[1] + size[2]) return 33; // nothing is free yet when levels 2 and 3 are placed
+      }
+      // a chain where every block dies one level later: two chunks alternate in place
+      Symbolic ch;
+      ch.nblk   = 6;
+      ch.height = {0, 1, 2, 3, 4, 5};
+      ch.parent = {1, 2, 3, 4, 5, -1};
+      ch.row_ptr = {0, 8, 16, 24, 32, 40, 40};
+      const size_t peak = plan_contribution_arena(ch, 6, 0, 1, off, size);
+      if (peak != 2 * 64 || off[0] != 0 || off[1] != 64 || off[2] != 0 || off[3] != 64 || off[4] != 0) return 34; // (a chunk is free again once the level of its parents is over)
+    }
     return 0;
   } catch (const std::exception &e) {
     last_error() = e.what();

@@ -77,6 +77,11 @@ struct DeviceLevels {
   virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
 };
 
+// Plan of the arena that holds the contribution blocks of the device levels (numeric_host.cpp; used by numeric_device.hip).  The blocks
+// of the fronts of a level (height) share one chunk, alive until the last of their parents has been assembled; later levels take
+// the place over, first fit over the chunks still alive.  cs: doubles per scalar; every block is rounded to 16 doubles.  Fills
+// chunk_off / chunk_size (doubles, per level; 0 below first_level) and returns the size of the arena in doubles.
+size_t plan_contribution_arena(const Symbolic &sym, idx_t nlev, idx_t first_level, int cs, std::vector<size_t> &chunk_off, std::vector<size_t> &chunk_size);
 // analysis (ordering + symbolic + layout); leaf_size <= 0 selects the default
 void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf);
 // numerical factorisation on the host (multifrontal, OpenMP); may be called again for a matrix with the same pattern

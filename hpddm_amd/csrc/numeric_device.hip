@@ -853,38 +853,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
       // Plan of the arena.  The contribution blocks of the fronts of a level share one chunk, live until the last of their parents has been assembled -- the barrier that closes that level orders
       // every stream --, and later levels take the place over: first fit over the chunks still alive.  Every block kept until end()
       // was 49 GB for a 129^3 Poisson subdomain (12 device levels), more than the factor; two factorisations in flight did not fit.
-      const Symbolic &sy   = h.sym;
-      const idx_t     nlev = (idx_t)h.level_ptr.size() - 1;
-      chunk_off.assign((size_t)nlev, 0), chunk_size.assign((size_t)nlev, 0);
-      std::vector<idx_t> rel((size_t)nlev);
-      for (idx_t l = 0; l < nlev; ++l) rel[l] = l;
-      auto r16 = [](size_t scalars) { return (scalars * CS + 15) / 16 * 16; };
-      for (idx_t k = 0; k < sy.nblk; ++k) {
-        const idx_t  hk = sy.height[k], pk = sy.parent[k];
-        const size_t nb = (size_t)(sy.row_ptr[k + 1] - sy.row_ptr[k]);
-        if (hk >= first_level) {
-          chunk_size[hk] += r16(nb * nb);
-          if (pk >= 0) rel[hk] = std::max(rel[hk], sy.height[pk]);
-        } // (the blocks of host-level children stay in the upload ring)
-      }
-      struct Live {
-        size_t off, size;
-        idx_t  until;
-      };
-      std::vector<Live> live;
-      size_t            peak = 0;
-      for (idx_t l = first_level; l < nlev; ++l) {
-        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &c) { return c.until < l; }), live.end());
-        std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
-        size_t pos = 0;
-        for (const Live &c : live) {
-          if (c.off >= pos + chunk_size[l]) break;
-          pos = std::max(pos, c.off + c.size);
-        }
-        chunk_off[l] = pos;
-        if (chunk_size[l]) live.push_back({pos, chunk_size[l], rel[l]});
-        peak = std::max(peak, pos + chunk_size[l]);
-      }
+      const size_t peak = plan_contribution_arena(h.sym, (idx_t)h.level_ptr.size() - 1, first_level, CS, chunk_off, chunk_size);
       if (getenv("HPDDM_HIP_PROFILE")) fprintf(stderr, "[numfact] device levels: contribution blocks %.2f GB in all, arena %.2f GB (levels share it)\n", (double)cb_doubles * 8e-9, (double)peak * 8e-9);
       DeviceScratch::grow(arena, peak + 1024);
       arena_used = chunk_end = 0;

@@ -760,6 +760,40 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   hf.t_numeric = now() - t0;
 }
 
+size_t plan_contribution_arena(const Symbolic &sy, idx_t nlev, idx_t first_level, int cs, std::vector<size_t> &chunk_off, std::vector<size_t> &chunk_size)
+{
+  chunk_off.assign((size_t)nlev, 0), chunk_size.assign((size_t)nlev, 0);
+  std::vector<idx_t> rel((size_t)nlev);
+  for (idx_t l = 0; l < nlev; ++l) rel[l] = l;
+  for (idx_t k = 0; k < sy.nblk; ++k) {
+    const idx_t  hk = sy.height[k], pk = sy.parent[k];
+    const size_t nb = (size_t)(sy.row_ptr[k + 1] - sy.row_ptr[k]);
+    if (hk >= first_level) {
+      chunk_size[hk] += (nb * nb * cs + 15) / 16 * 16;
+      if (pk >= 0) rel[hk] = std::max(rel[hk], sy.height[pk]);
+    } // (the blocks of host-level children stay in the upload ring)
+  }
+  struct Live {
+    size_t off, size;
+    idx_t  until;
+  };
+  std::vector<Live> live;
+  size_t            peak = 0;
+  for (idx_t l = first_level; l < nlev; ++l) {
+    live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &c) { return c.until < l; }), live.end());
+    std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
+    size_t pos = 0;
+    for (const Live &c : live) {
+      if (c.off >= pos + chunk_size[l]) break;
+      pos = std::max(pos, c.off + c.size);
+    }
+    chunk_off[l] = pos;
+    if (chunk_size[l]) live.push_back({pos, chunk_size[l], rel[l]});
+    peak = std::max(peak, pos + chunk_size[l]);
+  }
+  return peak;
+}
+
 void factor_numeric(const CsrView &A, FactKind kind, HostFactor &hf, DeviceLevels *dev, idx_t first_device_level)
 {
   if (A.cplx) {

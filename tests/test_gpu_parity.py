@@ -245,6 +245,62 @@ def test_device_levels_of_the_factorisation():
     S.destroy()
 
 
+@pytest.mark.parametrize("kind", ["chol", "ldlt", "lu"])
+def test_device_levels_of_two_factorisations_in_flight(kind, monkeypatch):
+    """two scratch slots (HPDDM_HIP_DEVICE_SLOTS=2: the device levels of two factorisations interleave, each on its own streams, upload
+    ring and arena) and eight streams per factorisation instead of four: three subdomains factorised from three host threads at once,
+    all three kinds -- the same solutions as SuperLU.  (One slot is the default: two measured no faster)"""
+    import threading
+
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    monkeypatch.setenv("HPDDM_HIP_DEVICE_SLOTS", "2")
+    monkeypatch.setenv("HPDDM_HIP_FACTOR_STREAMS", "8")
+    N = 32
+    I = sp.identity(N)
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(N, N))
+    A0 = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
+    n = A0.shape[0]
+    rng = np.random.default_rng(5)
+    mats = []
+    for s in range(3):
+        if kind == "chol":
+            M = A0 + sp.diags(0.1 * s + rng.random(n))
+        elif kind == "ldlt":
+            M = A0 - (0.05 + 0.01 * s) * sp.identity(n)
+        else:
+            M = A0 + 0.2 * sp.triu(A0, 1) + sp.diags((1 + s) * rng.random(n))
+        mats.append(M.tocsr())
+    subs, errs = [hpddm.Subdomain() for _ in mats], []
+
+    def work(s):
+        try:
+            M = mats[s]
+            if kind == "lu":
+                F = M.copy()
+                F.sort_indices()
+                subs[s].numfact(n, F.indptr, F.indices, F.data, sym=False, spd=False)
+            else:
+                L = sp.tril(M).tocsr()
+                L.sort_indices()
+                subs[s].numfact(n, L.indptr, L.indices, L.data, sym=True, spd=kind == "chol")
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(s,)) for s in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for s, M in enumerate(mats):
+        assert subs[s].info()["kind"] in {"chol": (0,), "ldlt": (1, 2), "lu": (2,)}[kind]     # (an L D L^T that grows falls back to LU)
+        b = np.asfortranarray(rng.random((n, 2)))
+        x = subs[s].solve(b)
+        ref = spl.splu(sp.csc_matrix(M)).solve(b)
+        assert np.abs(x - ref).max() <= (1e-6 if kind == "lu" else 1e-9) * np.abs(ref).max()
+        subs[s].destroy()
+
+
 def test_geneo_coarse_space_against_arpack():
     """GenEO: eigenvalues of (A_N, scaleIntoOverlap(A_N)) against scipy's ARPACK (what the reference calls),
     then the deflated two-level operator built on them (invariant under a change of basis of each local space)."""
