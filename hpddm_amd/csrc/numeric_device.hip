@@ -607,6 +607,7 @@ struct UploadRing {
   char  *host = nullptr, *dev = nullptr;
   size_t cap = 0, head = 0, flushed = 0, batch = 0; // batch: bytes staged for the front in hand (its pointers must stay valid together)
   std::vector<std::pair<char *, char *>> retired;   // outgrown buffers: pointers into them may still be in use, freed by release_retired()
+  std::vector<char>                      retired_pageable;
   hipStream_t *consumers = nullptr; // the streams the staged bytes are consumed on (DeviceScratch::streams): a wrap-around waits for these only
   int    nconsumers = 0;
   double t_wait = 0, t_copy = 0; // seconds spent waiting for the stream at wrap-arounds / copying into the pinned ring (HPDDM_HIP_PROFILE)
@@ -622,18 +623,38 @@ struct UploadRing {
     for (int i = 0; i < nconsumers; ++i)
       if (consumers[i]) HIP_OK(hipStreamSynchronize(consumers[i]));
   }
+  // HPDDM_HIP_UPLOAD_UNPINNED (profiling aid): a pageable staging buffer and plain copies -- under rocprofv3 --pmc the asynchronous copy
+  // from the pinned ring faulted in round 3 (the counter passes of scripts/r0*_pmc_*.sh run with it)
+  bool unpinned = false;
   void flush(hipStream_t st)
   {
-    if (head > flushed) HIP_OK(hipMemcpyAsync(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice, st));
+    if (head > flushed) {
+      if (unpinned) {
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice));
+      } else HIP_OK(hipMemcpyAsync(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice, st));
+    }
     flushed = head;
+  }
+  void free_pair(char *h, char *d, bool pageable)
+  {
+    if (h) {
+      if (pageable) free(h);
+      else (void)hipHostFree(h);
+    }
+    if (d) (void)hipFree(d);
   }
   void grow(size_t bytes, hipStream_t st)
   {
     if (bytes <= cap) return;
     flush(st); // what the old buffers hold goes out through them; they stay until release_retired()
-    if (host) retired.emplace_back(host, dev);
+    if (host) retired.emplace_back(host, dev), retired_pageable.push_back(unpinned);
     host = dev = nullptr;
-    HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
+    unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr;
+    if (unpinned) {
+      host = (char *)malloc(bytes);
+      HH_CHECK(host != nullptr, "numfact (device levels): out of host memory for the upload ring");
+    } else HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
     HIP_OK(hipMalloc((void **)&dev, bytes));
     cap  = bytes;
     head = flushed = 0;
@@ -642,11 +663,8 @@ struct UploadRing {
   {
     if (retired.empty()) return;
     HIP_OK(hipDeviceSynchronize());
-    for (auto &b : retired) {
-      (void)hipHostFree(b.first);
-      (void)hipFree(b.second);
-    }
-    retired.clear();
+    for (size_t i = 0; i < retired.size(); ++i) free_pair(retired[i].first, retired[i].second, retired_pageable[i]);
+    retired.clear(), retired_pageable.clear();
   }
   void begin_batch() { batch = 0; }
   void *stage(const void *src, size_t bytes, hipStream_t st)
@@ -672,12 +690,8 @@ struct UploadRing {
   }
   ~UploadRing()
   {
-    for (auto &b : retired) {
-      (void)hipHostFree(b.first);
-      (void)hipFree(b.second);
-    }
-    if (host) (void)hipHostFree(host);
-    if (dev) (void)hipFree(dev);
+    for (size_t i = 0; i < retired.size(); ++i) free_pair(retired[i].first, retired[i].second, retired_pageable[i]);
+    free_pair(host, dev, unpinned);
   }
 };
 
@@ -840,6 +854,10 @@ struct DeviceLevelsImpl : public DeviceLevels {
       const char *e = getenv("HPDDM_HIP_FACTOR_STREAMS");
       ns            = std::max(1, std::min(NSTREAMS, e ? atoi(e) : 4));
     }
+    // the first slot of the pool takes the library stream as its first stream (HPDDM_HIP_FACTOR_OWN_STREAM0: a stream of its own):
+    // one more stream created ahead of those of the sweeps measured them slower (profiles/r04_streams_of_the_device_levels.txt)
+    if (scr == DeviceScratch::pool() && !getenv("HPDDM_HIP_FACTOR_OWN_STREAM0")) scr->streams[0] = library_stream();
+    else if (scr->streams[0] == library_stream()) scr->streams[0] = nullptr;
     for (int i = 0; i < ns; ++i) {
       if (!scr->streams[i]) HIP_OK(hipStreamCreateWithFlags(&scr->streams[i], hipStreamNonBlocking));
       if (!scr->ev[i]) HIP_OK(hipEventCreateWithFlags(&scr->ev[i], hipEventDisableTiming));
@@ -916,6 +934,11 @@ struct DeviceLevelsImpl : public DeviceLevels {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
       });
+    }
+    if (scr->ring.cap && scr->ring.unpinned != (getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr)) { // (the variable changed since the ring was made)
+      const size_t c = scr->ring.cap;
+      scr->ring.cap  = 0;
+      scr->ring.grow(c, st);
     }
     scr->ring.grow((size_t)64 << 20, st);
     std::vector<int> z(1 + (size_t)h.sym.nblk, 0); // [0]: breakdown; [1 + k]: rows were exchanged inside a tile of front k (LU)

@@ -8,6 +8,7 @@
 // The halo sum of co-located subdomains is a gather (no message, no atomics): dof i of subdomain s reads the D-scaled
 // values of its duplicates in the neighbours through a CSR list built once from Subdomain::map_.
 #include "schwarz.hpp"
+#include <chrono>
 #include <numeric>
 #include <algorithm>
 #include <cmath>
@@ -1389,7 +1390,22 @@ void Schwarz::build_plans()
   HIP_OK(hipStreamSynchronize(library_stream()));
   for (hipStream_t q : more_streams) HIP_OK(hipStreamSynchronize(q));
   if (!ev_fork) HIP_OK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  // (developer aid: the runtime deals its streams to the hardware queues in creation order -- HPDDM_HIP_STREAM_PATTERN = "a,b,c,..":
+  // a streams nobody uses are created before the stream of group 1, b before that of group 2, ...)
+  std::vector<int> pattern;
+  if (const char *pt = getenv("HPDDM_HIP_STREAM_PATTERN")) {
+    for (const char *c = pt; *c;) {
+      pattern.push_back(atoi(c));
+      while (*c && *c != ',') ++c;
+      if (*c == ',') ++c;
+    }
+  }
   while ((int)more_streams.size() < ng - 1) {
+    const size_t g = more_streams.size();
+    for (int i = 0; i < (g < pattern.size() ? pattern[g] : 0); ++i) {
+      hipStream_t q;
+      HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    }
     hipStream_t q;
     hipEvent_t  ev;
     HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
@@ -1405,6 +1421,45 @@ void Schwarz::build_plans()
     SolvePlan &P = g == 0 ? plan : *more_plans[g - 1];
     P.groups     = ng;
     P.build(fs, library_stream());
+  }
+  // Which streams the groups run on.  The runtime deals its streams to a few hardware queues in creation order, and the sweeps of
+  // small trees -- chains of short dependent launches -- depend on the deal: at 65^3 per subdomain 2.45 ms when the three extra groups
+  // land on three queues that share no pipe with each other, 3.1 - 3.7 ms otherwise (profiles/r04_sweep_streams_hardware_queues.txt:
+  // one stream created by anybody ahead of ours is enough).  So: three more streams right after ours, and of the four windows of
+  // consecutive streams the one the batched solve is fastest on (3 solves per window; -hpddm_hip_tune_streams 0: the first one).
+  if (ng > 1 && !streams_tuned && getopt("hip_tune_streams", 1) != 0) {
+    streams_tuned = true;
+    std::vector<hipStream_t> cand = more_streams;
+    for (int i = 0; i < 3; ++i) {
+      hipStream_t q;
+      HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+      cand.push_back(q);
+    }
+    const int      mu_t = is_complex ? 1 : 1;
+    DevBuf<double> tin, tout;
+    tin.alloc((size_t)ntot * mu_t), tout.alloc((size_t)ntot * mu_t);
+    HIP_OK(hipMemsetAsync(tin.p, 0, sizeof(double) * ntot * mu_t, library_stream()));
+    int    best = 0;
+    double tbest = 0.0;
+    for (int o = 0; o <= 3; ++o) {
+      for (int g = 1; g < ng; ++g) more_streams[g - 1] = cand[o + g - 1];
+      batched_sptrsv(tin.p, tout.p, mu_t, false); // (warm: first use of the streams)
+      HIP_OK(hipStreamSynchronize(library_stream()));
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < 2; ++r) batched_sptrsv(tin.p, tout.p, mu_t, false);
+      HIP_OK(hipStreamSynchronize(library_stream()));
+      const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (o == 0 || t < tbest) tbest = t, best = o;
+      tune_times[o] = t / 2;
+    }
+    for (int g = 1; g < ng; ++g) more_streams[g - 1] = cand[best + g - 1];
+    for (size_t i = 0; i < cand.size(); ++i)
+      if ((int)i < best || (int)i >= best + ng - 1) {
+        (void)hipStreamSynchronize(cand[i]);
+        (void)hipStreamDestroy(cand[i]);
+      }
+    tune_choice = best;
+    if (getenv("HPDDM_HIP_PROFILE")) fprintf(stderr, "[build_plans] streams of the %d groups: window %d of 4 (batched solve %.3f / %.3f / %.3f / %.3f ms)\n", ng, best, tune_times[0] * 1e3, tune_times[1] * 1e3, tune_times[2] * 1e3, tune_times[3] * 1e3);
   }
 }
 

@@ -139,6 +139,9 @@ struct Schwarz {
   std::vector<std::unique_ptr<SolvePlan>> more_plans;
   std::vector<hipStream_t>                more_streams;
   std::vector<hipEvent_t>                 ev_join;
+  bool                                    streams_tuned = false; // build_plans picked the streams of the groups by timing (once per operator)
+  int                                     tune_choice   = -1;    // the window of candidate streams it kept, seconds per batched solve on each
+  double                                  tune_times[4] = {0, 0, 0, 0};
   hipEvent_t                              ev_fork = nullptr;
   std::vector<int>                        group_first; // ngroups + 1
   void                   build_plans();                                            // from the resident factors of the subdomains
