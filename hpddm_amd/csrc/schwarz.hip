@@ -1427,7 +1427,7 @@ void Schwarz::build_plans()
   // land on three queues that share no pipe with each other, 3.1 - 3.7 ms otherwise (profiles/r04_sweep_streams_hardware_queues.txt:
   // one stream created by anybody ahead of ours is enough).  So: three more streams right after ours, and of the four windows of
   // consecutive streams the one the batched solve is fastest on (3 solves per window; -hpddm_hip_tune_streams 0: the first one).
-  if (ng > 1 && !streams_tuned && getopt("hip_tune_streams", 1) != 0) {
+  if (ng > 1 && ntot > 0 && !streams_tuned && getopt("hip_tune_streams", 1) != 0) {
     streams_tuned = true;
     std::vector<hipStream_t> cand = more_streams;
     for (int i = 0; i < 3; ++i) {
