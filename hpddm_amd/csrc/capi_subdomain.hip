@@ -205,8 +205,10 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
     if (k == "F") return dbls(h.F);
     if (k == "G") return dbls(h.G);
     if (k == "dinv") return dbls(h.dinv);
-    if (k == "Lplain") return dbls(h.Lplain);
-    if (k == "Uplain") return dbls(h.Uplain);
+    if (k == "Lplain" || k == "Uplain") {
+      HH_CHECK(!h.plain_lost, "export: the plain factor is not available for this matrix (rows were exchanged inside a supernode: LU with pivoting)");
+      return dbls(k == "Lplain" ? h.Lplain : h.Uplain);
+    }
     HH_CHECK(false, "export: unknown array " + k);
   } catch (const std::exception &e) {
     last_error() = e.what();
@@ -223,6 +225,10 @@ const double *HpddmHipSubdomainExportView(const HpddmHipSubdomain *S, const char
   const std::vector<double> *v = k == "F" ? &h.F : (k == "G" ? &h.G : (k == "dinv" ? &h.dinv : (k == "Lplain" ? &h.Lplain : (k == "Uplain" ? &h.Uplain : nullptr))));
   if (!v) {
     last_error() = "ExportView: unknown array " + k;
+    return nullptr;
+  }
+  if (h.plain_lost && (k == "Lplain" || k == "Uplain")) {
+    last_error() = "ExportView: the plain factor is not available for this matrix (rows were exchanged inside a supernode: LU with pivoting)";
     return nullptr;
   }
   *count = (long long)v->size();

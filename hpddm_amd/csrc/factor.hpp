@@ -47,6 +47,7 @@ struct HostFactor {
   std::vector<int64_t> gsrc;       // sum nb
   // optional: the plain supernodal L (and D / U) kept for export to a CPU substitution (oracle cpu_baseline)
   bool                keep_plain = false;
+  bool                plain_lost = false; // keep_plain was set, but rows were exchanged inside a supernode: Lplain / Uplain are not kept
   std::vector<double> Lplain, Uplain; // same panel layout as F/G but holding L_JJ, L_below (U_JJ^T, U_{J,right}^T)
   double              t_order = 0, t_symbolic = 0, t_numeric = 0;
   double              t_plain = 0; // seconds of t_numeric spent keeping the plain factor (keep_plain: allocation, copies out of the fronts / off the device)

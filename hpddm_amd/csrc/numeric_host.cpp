@@ -755,7 +755,14 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   }
   if (hf.keep_plain)
     for (unsigned char t : hf.tgs) plain_lost = plain_lost || t != 0;
-  HH_CHECK(!plain_lost || bad, "numfact: rows were exchanged inside a supernode (LU with pivoting): the plain factor (keep_plain) is not available for this matrix");
+  // rows exchanged inside a supernode (LU with pivoting): the plain factor would be that of a row-permuted front, which its consumers
+  // (the CPU substitution of the oracle) do not know about -- the factorisation stands and solves, the plain panels are dropped and
+  // their export says why
+  hf.plain_lost = plain_lost && !bad;
+  if (hf.plain_lost) {
+    std::vector<double>().swap(hf.Lplain);
+    std::vector<double>().swap(hf.Uplain);
+  }
   hf.info      = bad;
   hf.t_numeric = now() - t0;
 }

@@ -154,11 +154,26 @@ def test_host_lu_pivots_inside_the_diagonal_tiles():
     with pytest.raises(_lib.HpddmHipError, match="pivot"):
         S.numfact(M.shape[0], M.indptr, M.indices, M.data, sym=False)
     S.destroy()
-    # the plain factor (CPU baseline of bench.py) does not exist for a front whose rows were exchanged
+    # the plain factor (CPU baseline of bench.py) does not exist for a front whose rows were exchanged: the factorisation stands (and
+    # solves, replayed below), the EXPORT of the plain panels is what is refused
     A = _row_swapped_pairs(4)
     S = hpddm.Subdomain(host_only=1, keep_plain=1)
-    with pytest.raises(_lib.HpddmHipError, match="plain factor"):
-        S.numfact(A.shape[0], A.indptr, A.indices, A.data, sym=False)
+    S.numfact(A.shape[0], A.indptr, A.indices, A.data, sym=False)
+    assert np.any(S.export("tgs") != 0)
+    b = rng.random(A.shape[0])
+    x = _replay(S, b)
+    assert np.abs(A @ x - b).max() <= 1e-10 * max(1.0, np.abs(x).max()) * abs(A).sum(axis=1).max()
+    for which in ("Lplain", "Uplain"):
+        with pytest.raises(_lib.HpddmHipError, match="plain factor"):
+            S.export(which)
+    S.destroy()
+    # ... and without exchanges the plain panels of an LU factorisation are there
+    K = (_poisson3d(5) + 0.2 * sp.triu(_poisson3d(5), 1)).tocsr()
+    K.sort_indices()
+    S = hpddm.Subdomain(host_only=1, keep_plain=1)
+    S.numfact(K.shape[0], K.indptr, K.indices, K.data, sym=False)
+    assert S.info()["kind"] == 2 and not np.any(S.export("tgs") != 0)
+    assert S.export("Lplain").size == S.export("F").size and S.export("Uplain").size == S.export("F").size
     S.destroy()
 
 
