@@ -89,7 +89,6 @@ def _declare(lib):
         "HpddmHipSchwarzTime": (I, [P, C, I, I, I, P]),
         "HpddmHipSchwarzStats": (I, [P, P]),
         "HpddmHipSchwarzRebuildPlan": (I, [P]),
-        "HpddmHipDebugTimeline": (LL, [P, LL]),
         "HpddmHipSchwarzLevelTimes": (I, [P, I, I, P, I]),
         "HpddmHipSchwarzGetSubdomain": (P, [P, I]),
         "HpddmHipPanelCreate": (P, [I, I, P, P]),

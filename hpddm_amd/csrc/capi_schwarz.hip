@@ -786,20 +786,6 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
     return n;)
 }
 
-long long HpddmHipDebugTimeline(unsigned long long *out, long long cap_tiles)
-{
-  try {
-    HIP_OK(hipDeviceSynchronize());
-    if (!SolvePlan::timeline_host) return 0;
-    const long long n = std::min<long long>(SolvePlan::timeline_count(), 1ll << 20);
-    if (out) HIP_OK(hipMemcpy(out, SolvePlan::timeline_host, sizeof(unsigned long long) * 8 * (size_t)std::min(n, cap_tiles), hipMemcpyDeviceToHost));
-    return n;
-  } catch (const std::exception &e) {
-    last_error() = e.what();
-    return -1;
-  }
-}
-
 int HpddmHipSchwarzStats(const HpddmHipSchwarz *A, double *stats)
 {
   HH_TRY(

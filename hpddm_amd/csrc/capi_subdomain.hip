@@ -64,6 +64,7 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
       ls.leaf_size = (int)value;
       ls.analysed  = false;
     } else if (k == "keep_plain") ls.host.keep_plain = value != 0;
+    else if (k == "condense") ls.host.condense = value != 0;
     else if (k == "host_only") ls.host_only = value != 0;
     else if (k == "release_host") ls.release_host = value != 0;
     else HH_CHECK(false, "unknown option " + k);
@@ -196,9 +197,14 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
     if (k == "rows") return ints(h.sym.rows);
     if (k == "height") return ints(h.sym.height);
     if (k == "u_off") return ints(h.u_off);
-    if (k == "goff") return ints(h.goff);
-    if (k == "gptr") return ints(h.gptr);
-    if (k == "gsrc") return ints(h.gsrc);
+    if (k == "rel") return ints(h.rel);
+    if (k == "nchild") return ints(h.nchild);
+    if (k == "s_off") return ints(h.s_off);
+    if (k == "ps_off") return ints(h.ps_off);
+    if (k == "lb_off") return ints(h.lb_off);
+    if (k == "lb_nnzr") return ints(h.lb_nnzr);
+    if (k == "lb_nnzc") return ints(h.lb_nnzc);
+    if (k == "leaf_pool") return dbls(h.leaf_pool);
     if (k == "tgs") return ints(h.tgs);
     if (k == "level_ptr") return ints(h.level_ptr);
     if (k == "level_blk") return ints(h.level_blk);

@@ -62,23 +62,23 @@ struct SnDesc {
   const double *G;     // backward panel (== F unless LU)
   const double *dinv;  // LDL^T: 1/D (permuted numbering) or nullptr
   const int    *rows;  // nb sorted rows below the block (permuted numbering)
-  const int    *gptr;  // h+1 gather pointers into gsrc
-  const int    *gsrc;  // sources inside the subdomain's update pool
+  const int    *rel;   // nb positions: row i of this supernode sits at entry rel[i] of its parent's front (forward hand-over)
   long long     voff;  // offset (in vector elements, to be multiplied by mu) of the subdomain in batched multi-vectors
-  long long     uoff;  // same for the update pool
+  long long     soff;  // offset of the subdomain's slot pool in the plan's (one pool per right-hand side column, SolvePlan::stot apart)
   int           n;     // subdomain size (leading dimension of its multi-vectors)
-  int           usize; // subdomain update-pool size
   int           c0, w, nb, ldw; // first column, columns (= rows of the top block), rows below, leading dimension of the panel IN DOUBLES
   int           wc, cs;         // doubles per panel row that carry entries (w, or 2 w for complex scalars) and doubles per scalar (1 / 2)
-  int           u_off; // offset of this supernode's update vector inside the subdomain pool
-  int           has_src; // 0: no child hands an update to this supernode (leaf): skip the gather lists
+  int           s_in;   // first of this supernode's nchild slot rows (h = w + nb entries each) inside the subdomain's slot pool: row c holds
+                        // what child c handed up, at the positions of the front it reaches, zeros elsewhere (never written)
+  int           nchild; // 0: a leaf -- nothing to add to its right-hand side
+  int           s_out;  // the slot row (of its parent) this supernode writes its update to, entry i at s_out + rel[i]; -1: a root
   const double *FT;    // narrow panels: the forward panel once more, transposed (w x ldh, row-major), or nullptr
   int           ldh;   // its leading dimension (h rounded up to 2)
   int           tgs;   // forward panel: log2 of the size of the DENSE diagonal tiles of its top block -- 0: lower triangular (the rule);
                        // 6 / 31: the LU factorisation pivoted inside its 64-column tiles / inside the whole block (rows swapped: the
                        // inverse of the row-permuted unit factor is block lower triangular with dense diagonal tiles)
-  const int    *src4;  // small narrow panels with children: the gather lists once more as 4 fixed slots per entry of the front
-                       // (h x 4 sources inside the update pool, -1 = none), one 16-byte load per entry; or nullptr
+  const double *leaf;  // condensed leaf (factor.hpp): its blob -- W^T, A_RJ by row, A_JR by column --, or nullptr
+  int           nnzr, nnzc; // ... and the entries of A_RJ / A_JR (section offsets of the blob: leaf_blob_layout)
 };
 
 struct Tile {
@@ -97,19 +97,18 @@ struct DeviceFactor {
   FactKind kind = FACT_CHOL;
   bool     cplx = false; // complex scalars: panels hold (re, im) pairs; n, blk_ptr, ldw, f_off count scalars
   idx_t    nblk = 0, nlev = 0;
-  int64_t  f_size = 0, u_size = 0, nnz_exact = 0, nnz_stored = 0;
+  int64_t  f_size = 0, nnz_exact = 0, nnz_stored = 0;
   DevBuf<double> F, G, dinv;
   DevBuf<double> FT;                 // transposed copies of the narrow forward panels (reduction-free forward sweep)
   std::vector<int64_t> ft_off;       // per supernode, -1 when it has none
   std::vector<idx_t>   ldh;
-  DevBuf<int>    rows, gptr, gsrc, perm, iperm; // perm[new] = old, iperm[old] = new
+  DevBuf<int>    rows, rel, perm, iperm; // perm[new] = old, iperm[old] = new; rel: HostFactor::rel
+  DevBuf<double> leaf_pool;              // blobs of the condensed leaves (HostFactor::leaf_pool)
   // host copies of what the plan builder needs
-  std::vector<idx_t>   blk_ptr, ldw, u_off, height, level_ptr, level_blk;
-  std::vector<char>    has_src;
+  std::vector<idx_t>   blk_ptr, ldw, height, level_ptr, level_blk, nchild, lb_nnzr, lb_nnzc;
   std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
-  std::vector<int64_t> f_off, row_ptr, goff;
-  DevBuf<int>          src4;                 // fixed-slot gather lists of the narrow supernodes with at most 4 sources per entry
-  std::vector<int64_t> s4_off;               // per supernode offset into src4 (-1: none; leaves need none)
+  std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off;
+  int64_t              s_size = 0;
   void upload(const HostFactor &hf, hipStream_t s);
 };
 
@@ -117,35 +116,34 @@ struct DeviceFactor {
 struct SolvePlan {
   std::vector<const DeviceFactor *> factors;
   std::vector<long long>            voff; // per factor: element offset in the batched vectors
-  long long                         ntot = 0, utot = 0;
+  long long                         ntot = 0, utot = 0; // utot: entries of the slot pools of all the factors
   int                               nlev = 0;
   DevBuf<SnDesc> sn;
-  // per level, four tile lists: forward / backward x wave-level (narrow panels, one wavefront per tile, no LDS) /
-  // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS)
-  enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3 };
+  // per level, six tile lists: forward / backward x wave-level (narrow panels, one wavefront per tile, no LDS) /
+  // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS) / condensed leaves (one wavefront each)
+  enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3, FWD_LEAF = 4, BWD_LEAF = 5, NKIND = 6 };
   DevBuf<Tile>     tiles;
-  std::vector<int> lev_ptr[4], lev_end[4]; // per level [begin, end) into tiles
-  std::vector<int> lev_lds[4];   // dynamic LDS bytes per launch (block-level kinds)
-  std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the others chunks of 32 outputs (one wavefront each)
-  // wide supernodes with children: their right-hand side b_J - (children's updates) is formed once per supernode by a
-  // small pass before the level's sweep (tiles of 256 columns) instead of by every row tile
+  std::vector<int> lev_ptr[NKIND], lev_end[NKIND]; // per level [begin, end) into tiles
+  std::vector<int> lev_lds[NKIND];   // dynamic LDS doubles per launch (block-level kinds) / per wavefront (wave-level kinds)
+  std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2], lev_leaf16[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the last lev_leaf16[.][l] condensed leaves, the others chunks of 32 outputs (one wavefront each)
+  // 16-column engine, wide supernodes with children: their right-hand side b_J - (what the children handed up) is formed once per
+  // supernode by a small dense pass before the level's sweep (tiles of 256 columns); its wide tiles read it straight from the vector
   std::vector<int> gat_ptr, gat_end;
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
-  DevBuf<double> y, xw, U, bperm;
+  DevBuf<double> y, xw, U, bperm; // U: the slot pool of the forward hand-over (factor.hpp), [column][utot], zero where no child writes
   DevBuf<double> b16, y16, x16, U16, partials16; // the 16-column MFMA engine (sptrsv16.hip): interleaved vectors, entry i of column nu at i * 16 + nu
   DevBuf<long long> pvoff; // per factor: vector offset
   DevBuf<int>       pn;    // per factor: n
   DevBuf<const int *> pperm, piperm; // per factor: perm / iperm array
   int               nmax = 0;
-  int               dbg = 0; // developer aid: ablation mask of the sweep kernels (HPDDM_HIP_DBG), 0 in production
   int               lds_cap = 4096; // LDS staging doubles per workgroup of the block-level tiles
   int            ngroups = 0, max_parts = 1; // split-row backward tiles
   DevBuf<double> partials;                    // [group][part][MU][128]
   DevBuf<int>    arrivals;                    // [group], zero between solves
   double         bytes_alg_per_rhs1 = 0; // 2*nnz(L)*8 + 4*n*8 summed over the factors, mu = 1
   void build(const std::vector<const DeviceFactor *> &f, hipStream_t s);
-  void reserve(int mu);
+  void reserve(int mu, hipStream_t s);
   // x = A^{-1} b for every subdomain; b/x in the ORIGINAL numbering, batched layout [sub][mu][n_sub]; x may alias b.
   // Complex factors: b / x are arrays of (re, im) pairs (mu complex right-hand sides); inside, a complex right-hand side is two
   // real ones (its real and imaginary planes) and the sweeps run with 2 mu real columns.
@@ -162,8 +160,6 @@ struct SolvePlan {
   std::vector<hipEvent_t> prof_ev;
   std::vector<int>        prof_tag;
   void                    mark(int tag, hipStream_t s);
-  static unsigned long long *timeline_host;           // developer aid (HPDDM_HIP_DBG & 32): pinned buffer the wave tiles write their clocks to
-  static unsigned int        timeline_count();
   std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch
   std::vector<double>     level_bytes(int kind) const;
 };

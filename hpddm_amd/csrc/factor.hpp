@@ -39,12 +39,27 @@ struct HostFactor {
   std::vector<double>  G;          // backward panels (LU only; empty otherwise: G == F)
   std::vector<double>  dinv;       // LDLT only: 1/D in the permuted numbering
   std::vector<unsigned char> tgs;  // LU: per supernode, 0 = no row was swapped (triangular top block of F), else log2 of the tile the swaps stayed in (SnDesc::tgs)
-  // multifrontal-solve gather lists: entry i (0..h-1) of supernode k sums U[gsrc[p]] for p in gptr[goff[k]+i .. goff[k]+i+1)
-  std::vector<int64_t> u_off;      // nblk: offset of u_k in the update pool (size sum nb)
+  // multifrontal solve, hand-over of the updates (forward sweep): a supernode k with children owns nchild[k] SLOT ROWS of h_k = w_k + nb_k
+  // entries each (one per child, in the order of the children's numbers), at s_off[k] + c * h_k in the slot pool of the subdomain; child
+  // number c of k writes entry i of its update vector to position rel[u_off[child] + i] of its row (the position of its row i inside
+  // the front of k: column j of k -> j, row j of rows(k) -> w_k + j) and nothing else ever writes there: the positions a child does not
+  // reach stay zero from the allocation on.  The parent reads its right-hand side as b_J - (sum over its slot rows), dense: no index
+  // list on the consumer's side, no gather pass (until round 4: per-supernode update vectors gathered through gptr / gsrc lists)
+  std::vector<int64_t> u_off;      // nblk: offset of the rows of k in rel (size sum nb)
   int64_t              u_size = 0;
-  std::vector<int64_t> goff;       // nblk: offset into gptr
-  std::vector<int64_t> gptr;       // sum (h+1)
-  std::vector<int64_t> gsrc;       // sum nb
+  std::vector<idx_t>   rel;        // sum nb: position of row i of supernode k in the front of its parent
+  std::vector<idx_t>   nchild;     // nblk
+  std::vector<int64_t> s_off;      // nblk: first slot row of k in the slot pool
+  std::vector<int64_t> ps_off;     // nblk: the slot row supernode k writes to (inside its parent's), -1 for a root
+  int64_t              s_size = 0; // entries of the slot pool (sum nchild * h)
+  // condensed leaves (numeric phase): a supernode without children is eliminated exactly by W = inv(A_JJ) and the ORIGINAL sparse
+  // couplings -- forward z = W f_J, u = A_RJ z; backward x_J = z - W (A_JR x_R) -- a few KB less per leaf than the dense panel
+  // [inv(L_JJ); L_RJ inv(L_JJ)].  Per leaf one blob in leaf_pool (8-byte units, 64-byte aligned; layout: leaf_blob_layout below),
+  // lb_off[k] = -1 when the leaf keeps its panel (no saving, or too wide); the panels are always there as well
+  std::vector<int64_t> lb_off;     // nblk
+  std::vector<idx_t>   lb_nnzr, lb_nnzc; // nblk: entries of A_RJ (by row of rows(k)) and of A_JR (by column of k)
+  std::vector<double>  leaf_pool;
+  bool                 condense = true;
   // optional: the plain supernodal L (and D / U) kept for export to a CPU substitution (oracle cpu_baseline)
   bool                keep_plain = false;
   bool                plain_lost = false; // keep_plain was set, but rows were exchanged inside a supernode: Lplain / Uplain are not kept
@@ -83,6 +98,30 @@ struct DeviceLevels {
 // the place over, first fit over the chunks still alive.  cs: doubles per scalar; every block is rounded to 16 doubles.  Fills
 // chunk_off / chunk_size (doubles, per level; 0 below first_level) and returns the size of the arena in doubles.
 size_t plan_contribution_arena(const Symbolic &sym, idx_t nlev, idx_t first_level, int cs, std::vector<size_t> &chunk_off, std::vector<size_t> &chunk_size);
+// byte offsets of the sections of a condensed leaf's blob (w columns, ldw doubles per row of W^T, nb rows below, cs doubles per
+// scalar): W^T (w x ldw doubles, row k = column k of W), values of A_RJ by row, values of A_JR by column, global (permuted) row of every
+// A_JR entry (int32), then 16-bit lists: row pointers of A_RJ (nb + 1), column pointers of A_JR (w + 1), local columns of A_RJ
+#ifdef __HIPCC__
+#define HH_HOST_DEVICE __host__ __device__
+#else
+#define HH_HOST_DEVICE
+#endif
+struct LeafBlob {
+  long long wt, srval, scval, scrow, srptr, scptr, srcol, bytes;
+};
+HH_HOST_DEVICE inline LeafBlob leaf_blob_layout(long long w, long long ldw, long long nb, long long nnzr, long long nnzc, long long cs)
+{
+  LeafBlob b;
+  b.wt    = 0;
+  b.srval = w * ldw * 8;
+  b.scval = b.srval + nnzr * cs * 8;
+  b.scrow = b.scval + nnzc * cs * 8;
+  b.srptr = b.scrow + nnzc * 4;
+  b.scptr = b.srptr + (nb + 1) * 2;
+  b.srcol = b.scptr + (w + 1) * 2;
+  b.bytes = (b.srcol + nnzr * 2 + 63) / 64 * 64;
+  return b;
+}
 // analysis (ordering + symbolic + layout); leaf_size <= 0 selects the default
 void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf);
 // numerical factorisation on the host (multifrontal, OpenMP); may be called again for a matrix with the same pattern

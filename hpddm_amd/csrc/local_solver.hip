@@ -74,9 +74,11 @@ bool LocalSolver::adopt_analysis(const LocalSolver &o, const CsrView &A)
   host.f_size    = o.host.f_size;
   host.u_off     = o.host.u_off;
   host.u_size    = o.host.u_size;
-  host.goff      = o.host.goff;
-  host.gptr      = o.host.gptr;
-  host.gsrc      = o.host.gsrc;
+  host.rel       = o.host.rel;
+  host.nchild    = o.host.nchild;
+  host.s_off     = o.host.s_off;
+  host.ps_off    = o.host.ps_off;
+  host.s_size    = o.host.s_size;
   host.t_order = host.t_symbolic = 0.0;
   pattern_hash = h;
   analysed     = true;

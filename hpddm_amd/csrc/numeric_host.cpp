@@ -204,51 +204,44 @@ void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf)
   }
   hf.f_size = off;
   hf.u_size = uoff;
-  // ---- gather lists of the multifrontal forward sweep ----
-  hf.goff.assign(nblk, 0);
+  // ---- hand-over lists of the multifrontal forward sweep: slot rows of the parents, positions of the children's rows (factor.hpp) ----
   {
-    int64_t g0 = 0;
-    for (idx_t k = 0; k < nblk; ++k) {
-      hf.goff[k] = g0;
-      g0 += (s.blk_ptr[k + 1] - s.blk_ptr[k]) + (s.row_ptr[k + 1] - s.row_ptr[k]) + 1;
-    }
-    hf.gptr.assign(g0, 0);
-    hf.gsrc.assign(uoff, 0);
-    // local position of row r inside parent p: r - c0 if r < c1 else w + index in rows(p)
-    std::vector<idx_t> where(s.n, -1);
     std::vector<std::vector<idx_t>> children(nblk);
     for (idx_t k = 0; k < nblk; ++k)
-      if (s.parent[k] >= 0) children[s.parent[k]].push_back(k);
-    int64_t filled = 0;
+      if (s.parent[k] >= 0) children[s.parent[k]].push_back(k); // (ascending child numbers: the order the parent sums its slot rows in)
+    hf.nchild.assign(nblk, 0);
+    hf.s_off.assign(nblk, 0);
+    hf.ps_off.assign(nblk, -1);
+    hf.rel.assign((size_t)uoff, 0);
+    int64_t soff = 0;
+    for (idx_t k = 0; k < nblk; ++k) {
+      hf.nchild[k] = (idx_t)children[k].size();
+      hf.s_off[k]  = soff;
+      soff += (int64_t)children[k].size() * ((s.blk_ptr[k + 1] - s.blk_ptr[k]) + (s.row_ptr[k + 1] - s.row_ptr[k]));
+    }
+    hf.s_size = soff;
+    HH_CHECK(soff < (int64_t)2147483647, "numfact: slot pool of the forward sweep exceeds 32-bit offsets");
+    // local position of row r inside parent p: r - c0 if r < c1 else w + index in rows(p)
+    std::vector<idx_t> where(s.n, -1);
     for (idx_t p = 0; p < nblk; ++p) {
+      if (children[p].empty()) continue;
       const idx_t c0 = s.blk_ptr[p], w = s.blk_ptr[p + 1] - c0;
       const idx_t nb = (idx_t)(s.row_ptr[p + 1] - s.row_ptr[p]);
-      int64_t    *gp = hf.gptr.data() + hf.goff[p];
-      if (children[p].empty()) {
-        for (idx_t i = 0; i <= w + nb; ++i) gp[i] = filled;
-        continue;
-      }
       for (idx_t i = 0; i < w; ++i) where[c0 + i] = i;
       for (idx_t i = 0; i < nb; ++i) where[s.rows[s.row_ptr[p] + i]] = w + i;
-      std::vector<idx_t> cnt(w + nb + 1, 0);
-      for (idx_t ch : children[p])
+      for (size_t c = 0; c < children[p].size(); ++c) {
+        const idx_t ch = children[p][c];
+        hf.ps_off[ch]  = hf.s_off[p] + (int64_t)c * (w + nb);
         for (int64_t q = s.row_ptr[ch]; q < s.row_ptr[ch + 1]; ++q) {
           const idx_t li = where[s.rows[q]];
           HH_CHECK(li >= 0, "symbolic: child row outside the parent front");
-          ++cnt[li + 1];
+          hf.rel[(size_t)(hf.u_off[ch] + (q - s.row_ptr[ch]))] = li;
         }
-      gp[0] = filled;
-      for (idx_t i = 0; i < w + nb; ++i) gp[i + 1] = gp[i] + cnt[i + 1];
-      std::vector<int64_t> pos(gp, gp + w + nb);
-      for (idx_t ch : children[p])
-        for (int64_t q = s.row_ptr[ch]; q < s.row_ptr[ch + 1]; ++q) {
-          const idx_t li        = where[s.rows[q]];
-          hf.gsrc[pos[li]++] = hf.u_off[ch] + (q - s.row_ptr[ch]);
-        }
-      filled = gp[w + nb];
+      }
       for (idx_t i = 0; i < w; ++i) where[c0 + i] = -1;
       for (idx_t i = 0; i < nb; ++i) where[s.rows[s.row_ptr[p] + i]] = -1;
     }
+    for (idx_t k = 0; k < nblk; ++k) HH_CHECK(hf.ps_off[k] >= 0 || s.row_ptr[k + 1] == s.row_ptr[k], "symbolic: a supernode with rows below it has no parent");
   }
   hf.t_symbolic = now() - t0;
 }
@@ -445,6 +438,33 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
   const int nthreads = host_thread_cap();
   omp_set_num_threads(nthreads);
   std::vector<std::vector<idx_t>> relidx_t(nthreads);
+  // ---- condensed leaves (factor.hpp): which supernodes without children trade their dense panel for W = inv(A_JJ) and the original
+  // sparse couplings, and where their blobs go (the blobs themselves are filled by process(), leaf by leaf) ----
+  hf.lb_off.assign(nblk, -1);
+  hf.lb_nnzr.assign(nblk, 0), hf.lb_nnzc.assign(nblk, 0);
+  {
+    int64_t units = 0; // 8-byte units
+    const char *ce       = getenv("HPDDM_HIP_CONDENSE"); // developer switch: 0 keeps every leaf on its dense panel
+    const bool  condense = hf.condense && !(ce && atoi(ce) == 0);
+    for (idx_t k = 0; k < nblk && condense; ++k) {
+      const idx_t c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+      if (!children[k].empty() || s.height[k] >= first_device_level || hf.ldw[k] * SC > 128 || w + nb > 60000) continue;
+      int64_t nr = 0, nc = 0;
+      for (idx_t c = c0; c < c0 + w; ++c) {
+        for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p) nr += P.lrow[p] >= c0 + w;
+        if (lu)
+          for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) nc += P.ucol[p] >= c0 + w;
+      }
+      if (!lu) nc = nr;
+      const LeafBlob lb = leaf_blob_layout(w, (long long)hf.ldw[k] * SC, nb, nr, nc, SC);
+      // both sweeps read the blob once where they read the panel once (the forward sweep its transposed copy): worth it from 20 % less
+      if ((double)lb.bytes > 0.8 * (double)(w + nb) * hf.ldw[k] * SC * 8.0 || nr > 60000 || nc > 60000) continue;
+      hf.lb_off[k]  = units;
+      hf.lb_nnzr[k] = (idx_t)nr, hf.lb_nnzc[k] = (idx_t)nc;
+      units += lb.bytes / 8;
+    }
+    hf.leaf_pool.assign((size_t)units, 0.0);
+  }
   int                             bad = 0;
   bool                            plain_lost = false;
 
@@ -660,6 +680,48 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           tmp.assign(row, row + w);
           for (idx_t i = 0; i < w; ++i) row[snp[i]] = tmp[i];
         }
+    }
+    if (hf.lb_off[k] >= 0) {
+      // ---- condensed leaf: W = inv(A_JJ) = G_top^T D^{-1} F_top (F_top = inv(L_JJ) [P], G_top = inv(U_JJ)^T or F_top), stored as W^T,
+      // and the original entries of A_RJ (by row) / A_JR (by column) ----
+      const long long ldd = (long long)ld * SC;
+      const LeafBlob  lb  = leaf_blob_layout(w, ldd, nb, hf.lb_nnzr[k], hf.lb_nnzc[k], SC);
+      unsigned char  *blob = reinterpret_cast<unsigned char *>(hf.leaf_pool.data() + hf.lb_off[k]);
+      T              *WT = reinterpret_cast<T *>(blob + lb.wt), *srval = reinterpret_cast<T *>(blob + lb.srval), *scval = reinterpret_cast<T *>(blob + lb.scval);
+      int32_t        *scrow = reinterpret_cast<int32_t *>(blob + lb.scrow);
+      uint16_t       *srptr = reinterpret_cast<uint16_t *>(blob + lb.srptr), *scptr = reinterpret_cast<uint16_t *>(blob + lb.scptr), *srcol = reinterpret_cast<uint16_t *>(blob + lb.srcol);
+      const T        *Ft = Pn, *Gt = lu ? Gn : Pn;
+      const T        *dv = kind == FACT_LDLT ? reinterpret_cast<const T *>(hf.dinv.data()) + c0 : nullptr;
+      for (idx_t kk = 0; kk < w; ++kk)
+        for (idx_t m = 0; m < ld; ++m) {
+          T acc = T(0);
+          if (m < w)
+            for (idx_t j = 0; j < w; ++j) acc += (dv ? Gt[(long)j * ld + m] * dv[j] : Gt[(long)j * ld + m]) * Ft[(long)j * ld + kk];
+          WT[(long)kk * ld + m] = acc; // W^T[kk][m] = W[m][kk]
+        }
+      for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
+      std::vector<int> cnt(nb + 1, 0);
+      for (idx_t c = c0; c < c0 + w; ++c)
+        for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p)
+          if (P.lrow[p] >= c0 + w) ++cnt[rel[P.lrow[p]] - w + 1];
+      for (idx_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
+      for (idx_t i = 0; i <= nb; ++i) srptr[i] = (uint16_t)cnt[i];
+      int nc = 0;
+      for (idx_t c = c0; c < c0 + w; ++c) { // columns ascending: the entries of a row of A_RJ come out sorted by column
+        scptr[c - c0] = (uint16_t)nc;
+        for (int64_t p = P.lptr[c]; p < P.lptr[c + 1]; ++p)
+          if (P.lrow[p] >= c0 + w) {
+            const int q = cnt[rel[P.lrow[p]] - w]++;
+            srcol[q]    = (uint16_t)(c - c0);
+            srval[q]    = P.lval[p];
+            if (!lu) scrow[nc] = (int32_t)P.lrow[p], scval[nc++] = P.lval[p]; // symmetric kinds: A_JR = A_RJ^T
+          }
+        if (lu)
+          for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p)
+            if (P.ucol[p] >= c0 + w) scrow[nc] = (int32_t)P.ucol[p], scval[nc++] = P.uval[p];
+      }
+      scptr[w] = (uint16_t)nc;
+      for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = -1;
     }
     lap(3);
   };

@@ -20,30 +20,6 @@
 
 namespace hpddm_hip {
 
-// developer aid, compiled in only with -DHPDDM_HIP_ABLATION (make ABLATION=1): the HPDDM_HIP_DBG mask then switches parts of the
-// sweep kernels off (WRONG results: 1 skip the reductions, 2 skip the epilogue / stores, 4 skip the right-hand side staging, 8 skip
-// the panel loads, 16 VALU tiles instead of the MFMA ones -- exact) or records per-tile clocks (32, exact).  In the product build
-// DBG_ON is a constant false and the `dbg` arguments of the kernels are dead.
-enum { DBG_NORED = 1, DBG_NOSTORE = 2, DBG_NORHS = 4, DBG_NOLOAD = 8, DBG_NOMFMA = 16, DBG_TIMELINE = 32 };
-#ifdef HPDDM_HIP_ABLATION
-#define DBG_ON(dbg, bit) (((dbg) & (bit)) != 0)
-#else
-#define DBG_ON(dbg, bit) false
-#endif
-// developer aid (HPDDM_HIP_DBG & 32, results stay exact): wave tiles of the narrow panels record the constant-rate clock
-// (100 MHz) at five points -- kernel entry, descriptor in registers, right-hand side staged, panel streamed, results stored --
-// into a device buffer, 8 entries per tile (last three: level-independent tile index, rows, doubles per row)
-__device__ unsigned long long *g_timeline     = nullptr;
-__device__ unsigned int        g_timeline_cap = 0, g_timeline_cnt = 0;
-__device__ static inline void  timeline_put(unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3, unsigned long long t4, int rows, int cols, int kind)
-{
-  const unsigned int k = atomicAdd(&g_timeline_cnt, 1u);
-  if (k < g_timeline_cap) {
-    unsigned long long *o = g_timeline + 8ull * k;
-    o[0] = t0, o[1] = t1, o[2] = t2, o[3] = t3, o[4] = t4, o[5] = (unsigned long long)rows, o[6] = (unsigned long long)cols, o[7] = (unsigned long long)kind;
-  }
-} // 16: the VALU tiles instead of the MFMA ones (exact, for comparison)
-
 __host__ __device__ static inline int lanes_per_row(int ldw) { return ldw >= 128 ? 64 : ldw / 2; } // any even ldw
 
 // sum over the R row groups of a wavefront for one column pair (lanes sub*g + gl, sub = 0..R-1); result valid in sub == 0
@@ -146,44 +122,53 @@ __global__ void k_perm_out_z(const long long *__restrict__ voff, const int *__re
 // wc = 2 w doubles per row; only the staging of R (Z = true), the triangular limits (cs = 2 doubles per scalar) and, in the
 // backward sweep -- x = P^T v, lanes own the (a_r, a_i) pair of one column -- the combination of the four partial products differ.
 
-// store the result of panel row r (after reduction): top rows give y, rows below hand their update to the parent
+// ---- hand-over of the updates (factor.hpp): what the children handed to entry `pos` of this supernode's front sits in its nchild
+// slot rows (h entries each, zeros where a child does not reach).  Two rows are requested together; same order as the children's numbers.
 template <int MU>
-__device__ static inline void fwd_store_row(const SnView &d, int r, const double *s, int sstride, double *yb, double *Ub)
+__device__ static inline void slot_sub(const SnView &d, int pos, const double *Sb, long long stot, double (&v)[MU])
+{
+  const int h = d.w + d.nb;
+  for (int c = 0; c < d.nchild; c += 2) {
+    const bool   two = c + 1 < d.nchild;
+    const double *s0 = Sb + d.s_in + c * h + pos, *s1 = s0 + (two ? h : 0);
+    double        u0[MU], u1[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) u0[nu] = s0[(long long)nu * stot], u1[nu] = s1[(long long)nu * stot];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) v[nu] = two ? (v[nu] - u0[nu]) - u1[nu] : v[nu] - u0[nu];
+  }
+}
+template <int MU>
+__device__ static inline void slot_add(const SnView &d, int pos, const double *Sb, long long stot, double (&v)[MU])
+{
+  const int h = d.w + d.nb;
+  for (int c = 0; c < d.nchild; c += 2) {
+    const bool   two = c + 1 < d.nchild;
+    const double *s0 = Sb + d.s_in + c * h + pos, *s1 = s0 + (two ? h : 0);
+    double        u0[MU], u1[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) u0[nu] = s0[(long long)nu * stot], u1[nu] = s1[(long long)nu * stot];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) v[nu] = two ? (v[nu] + u0[nu]) + u1[nu] : v[nu] + u0[nu];
+  }
+}
+
+// store the result of panel row r (after reduction): rows of the top block give y; a row below adds what the children handed to the
+// same entry of the front and hands the sum to the parent -- entry rel[r - w] of the slot row this supernode writes (one index, no list)
+template <int MU>
+__device__ static inline void fwd_store_row(const SnView &d, int r, const double *s, int sstride, double *yb, double *Sb, long long stot)
 {
   if (r < d.w) {
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + r] = s[nu * sstride];
-  } else if (!d.has_src) {
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = s[nu * sstride];
-  } else if (d.src4) {
-    // 4 fixed gather slots per entry of the front: one 16-byte index load, then the (at most 4) update-vector entries in
-    // flight together -- two dependent round trips instead of two per source; same summation order as the list walk below
-    const int4v sr = d.src4[r];
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      double u[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) u[j] = sr[j] >= 0 ? Ub[(long long)nu * d.usize + sr[j]] : 0.0;
-      double v = s[nu * sstride];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (sr[j] >= 0) v += u[j];
-      Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v;
-    }
   } else {
-    // sources outside, right-hand sides inside: the MU loads of one source are in flight together (same sums, same order)
-    const int q0 = d.gptr[r], q1 = d.gptr[r + 1];
+    const int pos = d.rel[r - d.w];
     double    v[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = s[nu * sstride];
-    for (int q = q0; q < q1; ++q) {
-      const int src = d.gsrc[q];
+    slot_add<MU>(d, r, Sb, stot, v);
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) v[nu] += Ub[(long long)nu * d.usize + src];
-    }
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) Ub[(long long)nu * d.usize + d.u_off + (r - d.w)] = v[nu];
+    for (int nu = 0; nu < MU; ++nu) Sb[(long long)nu * stot + d.s_out + pos] = v[nu];
   }
 }
 
@@ -193,8 +178,23 @@ __device__ static inline void fwd_store_row(const SnView &d, int r, const double
 // Forward product of a narrow panel WITHOUT per-row reductions: the panel is read through its transposed copy FT (w x ldh),
 // lanes own pairs of OUTPUT rows and walk down the w columns of F (= rows of FT), exactly as the backward sweep walks the
 // rows of G; the only cross-lane step is one reduction over the R column groups at the end.  Tile = nr <= 128 output rows.
+template <int MU, bool Z>
+__device__ static inline void stage_rhs(double *lds, int wr, int c, const double (&v)[MU])
+{
+  if constexpr (!Z) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
+  } else { // R = [ f_r  f_i ; -f_i  f_r ]: slots 2c, 2c + 1 of the real plane (nu even) and of the imaginary plane (nu odd)
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) {
+      lds[nu * wr + 2 * c]     = v[nu];
+      lds[nu * wr + 2 * c + 1] = (nu & 1) ? v[nu - 1] : -v[nu + 1];
+    }
+  }
+}
+
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg, unsigned long long = 0)
+__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
 {
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
@@ -206,44 +206,15 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
   }
-  // f = b_J - (updates handed up by the children), one lane per column, into the wavefront's LDS
-  for (int c = lane; c < w && !DBG_ON(dbg, DBG_NORHS); c += 64) {
+  // f = b_J - (what the children handed up: the slot rows of J, dense), one lane per column, into the wavefront's LDS
+  for (int c = lane; c < w; c += 64) {
     double v[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
-    if (d.has_src) {
-      if (MU > 1 && d.src4) { // fixed slots: one 16-byte index load, then every update-vector entry in flight (same order as the list)
-        const int4v sr = d.src4[c];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { // empty slots read entry 0 of the pool and subtract 0.0: no branch between the loads
-          const int sj = max(sr[j], 0);
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) {
-            const double u = Ub[(long long)nu * d.usize + sj];
-            v[nu]          = sr[j] >= 0 ? v[nu] - u : v[nu];
-          }
-        }
-      } else {
-        const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
-        for (int q = q0; q < q1; ++q) {
-          const int src = d.gsrc[q];
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
-        }
-      }
-    }
-    if constexpr (!Z) {
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
-    } else { // R = [ f_r  f_i ; -f_i  f_r ]: slots 2c, 2c + 1 of the real plane (nu even) and of the imaginary plane (nu odd)
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        lds[nu * wr + 2 * c]     = v[nu];
-        lds[nu * wr + 2 * c + 1] = (nu & 1) ? v[nu - 1] : -v[nu + 1];
-      }
-    }
+    slot_sub<MU>(d, c, Sb, stot, v);
+    stage_rhs<MU, Z>(lds, wr, c, v);
   }
   wave_lds_sync();
   double acc0[MU], acc1[MU];
@@ -256,7 +227,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -274,119 +245,60 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
       for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
-  if (!DBG_ON(dbg, DBG_NORED)) {
-    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
-  }
-  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
+  reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
+  if (sub == 0) {
     const int r = t.r0 + 2 * gl, rend = t.r0 + t.nr;
-    if (r < rend) fwd_store_row<MU>(d, r, acc0, 1, yb, Ub);
-    if (r + 1 < rend) fwd_store_row<MU>(d, r + 1, acc1, 1, yb, Ub);
+    if (r < rend) fwd_store_row<MU>(d, r, acc0, 1, yb, Sb, stot);
+    if (r + 1 < rend) fwd_store_row<MU>(d, r + 1, acc1, 1, yb, Sb, stot);
   }
 }
 
-// One right-hand side: the same tile with every load that depends on the descriptor only requested together.
+// One right-hand side, launches made of wave tiles only (the bottom levels): a tile there is a chain of dependent round trips with
+// a few KB of panel behind it, and a level is bound by (length of that chain) / (tiles in flight).  With the slot rows nothing is
+// left that depends on anything but the descriptor: the right-hand side entries, the slot entries of this lane's column and of its
+// two output rows, their positions in the parent's front and the first TWO groups of panel rows are all requested together -- two
+// round trips (descriptor / this batch) ahead of the product; the stores drain behind the next tile of the wavefront.
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Ub, int dbg, unsigned long long tk0 = 0)
+__device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
 {
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
-  unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
-  if (DBG_ON(dbg, DBG_TIMELINE)) tk1 = wall_clock64() + (unsigned long long)(w < 0);
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
   const gcd_t Fp = d.FT + t.r0 + 2 * gl;
-  const int   rtop = tri_last(t.r0 + 2 * gl + 1, d.tgs); // column i of the triangular top block is zero above row i: nothing to fetch for i > rtop (pivoted supernodes: above the diagonal tile)
+  const int   rtop = tri_last(t.r0 + 2 * gl + 1, d.tgs);
   const int   r_out = t.r0 + 2 * gl, rend = t.r0 + t.nr;
-  // A tile of the bottom levels is a chain of dependent round trips with a few KB of panel behind it, and a level is bound by
-  // (length of that chain) / (tiles in flight).  Everything that depends on the descriptor only is requested together, in the
-  // order it is needed (loads return in order): gather slots of this lane's column and of its two output rows, its right-hand
-  // side entries, the first TWO groups of panel rows; then the update-vector entries the slots point to, for the right-hand
-  // side and for the rows at once.  Three round trips (descriptor / this batch / update entries) instead of one per link of
-  // the lists, twice; the stores drain behind the next tile of the wavefront (sptrsv_fwd_kernel).
-  const bool slots = d.src4 != nullptr; // 4 fixed gather slots per entry of the front (at most 4 sources each)
-  const bool lists = d.has_src && !slots;
-  int4v      csrc = {-1, -1, -1, -1}, rsrc[2];
-  double     fv[MU];
-  const bool mine = lane < w && !DBG_ON(dbg, DBG_NORHS); // lane c stages column c (supernodes wider than 64 take the loop below)
-  if (slots && mine) csrc = d.src4[lane];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) rsrc[k] = (slots && sub == 0 && r_out + k >= w && r_out + k < rend) ? d.src4[r_out + k] : int4v{-1, -1, -1, -1};
+  const bool  mine = lane < w; // lane c stages column c (supernodes wider than 64 take the loop below)
+  double      fv[MU];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) fv[nu] = mine ? bb[(long long)nu * d.n + d.c0 + lane] : 0.0;
+  if (mine) slot_sub<MU>(d, lane, Sb, stot, fv);
+  int    rpos[2];
+  double radd[2][MU];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool below = sub == 0 && r_out + k >= w && r_out + k < rend;
+    rpos[k]          = below ? d.rel[r_out + k - w] : 0;
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) radd[k][nu] = 0.0;
+    if (below) slot_add<MU>(d, r_out + k, Sb, stot, radd[k]); // fixed order: s + ((0 + u0) + u1 ...)
+  }
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R, i2 = i + FWD_PASSES * R;
-    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
-    nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
+    cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+    nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
   }
-  double radd[2][MU];
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) radd[k][nu] = 0.0;
-  if (slots) {
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) {
-      double uc[4], ur[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uc[j]    = csrc[j] >= 0 ? Ub[(long long)nu * d.usize + csrc[j]] : 0.0;
-        ur[0][j] = rsrc[0][j] >= 0 ? Ub[(long long)nu * d.usize + rsrc[0][j]] : 0.0;
-        ur[1][j] = rsrc[1][j] >= 0 ? Ub[(long long)nu * d.usize + rsrc[1][j]] : 0.0;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { // same order as the list walk
-        if (csrc[j] >= 0) fv[nu] -= uc[j];
-        if (rsrc[0][j] >= 0) radd[0][nu] += ur[0][j];
-        if (rsrc[1][j] >= 0) radd[1][nu] += ur[1][j];
-      }
-    }
-  } else if (lists && mine) {
-    const int q0 = d.gptr[lane], q1 = d.gptr[lane + 1];
-    for (int q = q0; q < q1; ++q) {
-      const int src = d.gsrc[q];
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) fv[nu] -= Ub[(long long)nu * d.usize + src];
-    }
-  }
-  auto stage = [&](int c, const double *v) {
-    if constexpr (!Z) {
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = v[nu];
-    } else { // R = [ f_r  f_i ; -f_i  f_r ]: slots 2c, 2c + 1 of the real plane (nu even) and of the imaginary plane (nu odd)
-#pragma unroll
-      for (int nu = 0; nu < MU; ++nu) {
-        lds[nu * wr + 2 * c]     = v[nu];
-        lds[nu * wr + 2 * c + 1] = (nu & 1) ? v[nu - 1] : -v[nu + 1];
-      }
-    }
-  };
-  if (mine) stage(lane, fv);
-  for (int c = lane + 64; c < w && !DBG_ON(dbg, DBG_NORHS); c += 64) { // columns 64 .. 127 of the widest narrow supernodes
+  if (mine) stage_rhs<MU, Z>(lds, wr, lane, fv);
+  for (int c = lane + 64; c < w; c += 64) { // columns 64 .. 127 of the widest narrow supernodes
     double v[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + c];
-    if (slots) {
-      const int4v sc = d.src4[c];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (sc[j] >= 0) {
-#pragma unroll
-          for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + sc[j]];
-        }
-    } else if (lists) {
-      const int q0 = d.gptr[c], q1 = d.gptr[c + 1];
-      for (int q = q0; q < q1; ++q) {
-        const int src = d.gsrc[q];
-#pragma unroll
-        for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
-      }
-    }
-    stage(c, v);
+    slot_sub<MU>(d, c, Sb, stot, v);
+    stage_rhs<MU, Z>(lds, wr, c, v);
   }
   wave_lds_order();
-  if (DBG_ON(dbg, DBG_TIMELINE)) tk2 = wall_clock64();
   double acc0[MU], acc1[MU];
 #pragma unroll
   for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
@@ -399,7 +311,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (2 * FWD_PASSES + p) * R;
-        nx2[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
+        nx2[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -418,37 +330,25 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
       nxt[p] = more2 ? nx2[p] : dbl2{0.0, 0.0};
     }
   }
-  if (!DBG_ON(dbg, DBG_NORED)) {
-    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
-  }
-  if (DBG_ON(dbg, DBG_TIMELINE)) tk3 = wall_clock64() + (unsigned long long)(acc0[0] == 1.2345e300);
-  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
-    if (!lists) {
+  reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
+  if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int r = r_out + k;
-        if (r < rend) {
+    for (int k = 0; k < 2; ++k) {
+      const int r = r_out + k;
+      if (r < rend) {
 #pragma unroll
-          for (int nu = 0; nu < MU; ++nu) {
-            const double v = k ? acc1[nu] : acc0[nu];
-            if (r < w) yb[(long long)nu * d.n + d.c0 + r] = v;
-            else Ub[(long long)nu * d.usize + d.u_off + (r - w)] = v + radd[k][nu]; // fixed order: s + ((u0 + u1) + ...)
-          }
+        for (int nu = 0; nu < MU; ++nu) {
+          const double v = k ? acc1[nu] : acc0[nu];
+          if (r < w) yb[(long long)nu * d.n + d.c0 + r] = v;
+          else Sb[(long long)nu * stot + d.s_out + rpos[k]] = v + radd[k][nu];
         }
       }
-    } else {
-      if (r_out < rend) fwd_store_row<MU>(d, r_out, acc0, 1, yb, Ub);
-      if (r_out + 1 < rend) fwd_store_row<MU>(d, r_out + 1, acc1, 1, yb, Ub);
     }
-  }
-  if (DBG_ON(dbg, DBG_TIMELINE) && lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    timeline_put(tk0, tk1, tk2, tk3, wall_clock64(), t.nr, wc, d.has_src ? 1 : 0);
   }
 }
 
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb, double *xo, int dbg)
+__device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb, double *xo)
 {
   const int w = d.w, ldw = d.ldw, h = d.w + d.nb;
   const int g = ldw >> 1, R = 64 / g;
@@ -460,10 +360,10 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
   for (int p = 0; p < FWD_PASSES; ++p) {
     const int i = sub + p * R;
-    cur[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
+    cur[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0}; // rows above the diagonal hold zeros in these columns
   }
   // v = [ D^{-1} y_J ; -x_below ], one lane per row (h <= WAVE_ROWS)
-  for (int i = lane; i < h && !DBG_ON(dbg, DBG_NORHS); i += 64) {
+  for (int i = lane; i < h; i += 64) {
     if (i < w) {
       if constexpr (!Z) {
         const double sc = d.dinv ? d.dinv[d.c0 + i] : 1.0;
@@ -495,7 +395,7 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int p = 0; p < FWD_PASSES; ++p) {
         const int i = ib + (FWD_PASSES + p) * R;
-        nxt[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl) && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
+        nxt[p]      = (active && i < h && (Z ? i >= gl : i >= 2 * gl)) ? *(gcd2_t)(Gp + (long long)i * ldw) : dbl2{0.0, 0.0};
       }
     }
 #pragma unroll
@@ -513,10 +413,8 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
       for (int p = 0; p < FWD_PASSES; ++p) cur[p] = nxt[p];
     }
   }
-  if (!DBG_ON(dbg, DBG_NORED)) {
-    reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
-  }
-  if (sub == 0 && !DBG_ON(dbg, DBG_NOSTORE)) {
+  reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
+  if (sub == 0) {
     if constexpr (!Z) {
       const int c = 2 * gl;
       if (c < w) {
@@ -538,21 +436,235 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 }
 
 
-// =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
-// right-hand side entry of panel column `col` (in doubles) for the real column nu: real scalars b_J - updates; complex scalars the
-// entry (col, nu) of R = [ f_r  f_i ; -f_i  f_r ] (one plane of f, possibly negated)
-template <bool Z>
-__device__ static inline double fwd_rhs_entry(const SnView &d, int col, int nu, const double *bb, const double *Ub, bool gather)
+
+// =========================== condensed leaves: one wavefront per leaf ================================================
+// A supernode without children is eliminated exactly by W = inv(A_JJ) and the original sparse couplings (factor.hpp):
+//   forward   z = W f_J (kept in y_J),  u = A_RJ z  handed to the parent;     backward   x_J = z - W (A_JR x_R).
+// Both sweeps read the blob of the leaf -- W^T dense (w x ldw), A_RJ by row, A_JR by column with the global row of every entry --
+// instead of the panel [inv(L_JJ); L_RJ inv(L_JJ)]: a few KB less per leaf.  The dense product is the one of the backward wave
+// tile (lanes own column pairs of W^T, no triangle to skip).
+template <int FP>
+__device__ static inline void ptv_prime(gcd_t P, int ld, int K, int lane, dbl2 (&cur)[FP])
 {
-  const int    c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
-  double       v = bb[(long long)plane * d.n + d.c0 + c];
-  if (gather)
-    for (int p = d.gptr[c]; p < d.gptr[c + 1]; ++p) v -= Ub[(long long)plane * d.usize + d.gsrc[p]];
-  return (Z && (col & 1) && !(nu & 1)) ? -v : v;
+  const int  g = ld >> 1, R = 64 / g, sub = lane / g, gl = lane - sub * g;
+  const bool active = sub < R;
+#pragma unroll
+  for (int p = 0; p < FP; ++p) {
+    const int i = sub + p * R;
+    cur[p]      = (active && i < K) ? *(gcd2_t)(P + 2 * gl + (long long)i * ld) : dbl2{0.0, 0.0};
+  }
+}
+// acc0 / acc1 = sums over the K rows of P[.][2 gl], P[.][2 gl + 1] times v (LDS, entry k of column nu at vl[nu * wr + k]); valid in
+// the lanes with sub == 0 on return.  cur: the first FP row groups, requested by ptv_prime before v was formed.
+template <int MU, int FP>
+__device__ static inline void ptv_run(gcd_t P, int ld, int K, int lane, const double *vl, int wr, dbl2 (&cur)[FP], double (&acc0)[MU], double (&acc1)[MU])
+{
+  const int   g = ld >> 1, R = 64 / g, sub = lane / g, gl = lane - sub * g;
+  const bool  active = sub < R;
+  const gcd_t Pp = P + 2 * gl;
+  dbl2        nxt[FP];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) acc0[nu] = acc1[nu] = 0.0;
+  for (int ib0 = 0; ib0 < K; ib0 += FP * R) {
+    const int  ib   = ib0 + sub;
+    const bool more = ib0 + FP * R < K;
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < FP; ++p) {
+        const int i = ib + (FP + p) * R;
+        nxt[p]      = (active && i < K) ? *(gcd2_t)(Pp + (long long)i * ld) : dbl2{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < FP; ++p) {
+      const int i = min(ib + p * R, K - 1); // out-of-range passes carry a = 0
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        const double v = vl[nu * wr + i];
+        acc0[nu]       = fma(cur[p].x, v, acc0[nu]);
+        acc1[nu]       = fma(cur[p].y, v, acc1[nu]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < FP; ++p) cur[p] = nxt[p];
+    }
+  }
+  reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
+}
+
+template <int MU, int FP, bool Z>
+__device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
+{
+  const LeafView L = leaf_view(d);
+  const int      w = d.w, ld = d.ldw, nb = d.nb;
+  dbl2           cur[FP];
+  ptv_prime<FP>(L.WT, ld, w, lane, cur);
+  // the sparse part's lists of this lane's first row: they depend on the descriptor only
+  const int i0 = lane < nb ? lane : 0;
+  int       p0 = 0, p1 = 0, pos0 = 0;
+  if (lane < nb) p0 = L.srptr[i0], p1 = L.srptr[i0 + 1], pos0 = d.rel[i0];
+  for (int c = lane; c < w; c += 64) { // f = b_J (a leaf has no children), planes side by side
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = bb[(long long)nu * d.n + d.c0 + c];
+  }
+  wave_lds_order();
+  double acc0[MU], acc1[MU];
+  ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
+  const int g = ld >> 1, sub = lane / g, gl = lane - sub * g;
+  wave_lds_order(); // the reads of f are done: z takes its place
+  if (sub == 0) {
+    if constexpr (!Z) {
+      const int c = 2 * gl;
+      if (c < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + c] = acc0[nu], lds[nu * wr + c] = acc0[nu];
+      }
+      if (c + 1 < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu], lds[nu * wr + c + 1] = acc1[nu];
+      }
+    } else if (gl < w) { // this lane owns column gl: acc0 = P_r^T v, acc1 = P_i^T v for the real (even) and imaginary (odd) planes of v
+#pragma unroll
+      for (int k = 0; k < MU / 2; ++k) {
+        const double zr = acc0[2 * k] - acc1[2 * k + 1], zi = acc0[2 * k + 1] + acc1[2 * k];
+        yb[(long long)(2 * k) * d.n + d.c0 + gl] = zr, yb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = zi;
+        lds[(2 * k) * wr + gl] = zr, lds[(2 * k + 1) * wr + gl] = zi;
+      }
+    }
+  }
+  wave_lds_order();
+  // u = A_RJ z, one lane per row of rows(J), straight into the slot row of the parent
+  constexpr int UN = 4;
+  for (int i = lane; i < nb; i += 64) {
+    if (i != lane) p0 = L.srptr[i], p1 = L.srptr[i + 1], pos0 = d.rel[i];
+    double u[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) u[nu] = 0.0;
+    for (int p = p0; p < p1; p += UN) {
+      int    c[UN];
+      double ar[UN], ai[UN];
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        const bool ok = p + j < p1;
+        c[j]          = ok ? (int)L.srcol[p + j] : 0;
+        if constexpr (!Z) ar[j] = ok ? L.srval[p + j] : 0.0, ai[j] = 0.0;
+        else {
+          const dbl2 a = ok ? *(gcd2_t)(L.srval + 2 * (p + j)) : dbl2{0.0, 0.0};
+          ar[j] = a.x, ai[j] = a.y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UN; ++j) { // (an absent entry multiplies z[0] by zero: z is finite)
+        if constexpr (!Z) {
+#pragma unroll
+          for (int nu = 0; nu < MU; ++nu) u[nu] = fma(ar[j], lds[nu * wr + c[j]], u[nu]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < MU / 2; ++k) {
+            const double zr = lds[(2 * k) * wr + c[j]], zi = lds[(2 * k + 1) * wr + c[j]];
+            u[2 * k]        = fma(ar[j], zr, fma(-ai[j], zi, u[2 * k]));
+            u[2 * k + 1]    = fma(ar[j], zi, fma(ai[j], zr, u[2 * k + 1]));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) Sb[(long long)nu * stot + d.s_out + pos0] = u[nu];
+  }
+}
+
+template <int MU, int FP, bool Z>
+__device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb)
+{
+  const LeafView L = leaf_view(d);
+  const int      w = d.w, ld = d.ldw;
+  dbl2           cur[FP];
+  ptv_prime<FP>(L.WT, ld, w, lane, cur);
+  // t = A_JR x_R, one lane per column of J: list of the column, then the entries of x it points to (UN of them in flight)
+  constexpr int UN = MU >= 4 ? 2 : 4;
+  for (int c = lane; c < w; c += 64) {
+    const int p0 = L.scptr[c], p1 = L.scptr[c + 1];
+    double    t[MU];
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) t[nu] = 0.0;
+    for (int p = p0; p < p1; p += UN) {
+      int    r[UN];
+      double ar[UN], ai[UN], xv[UN][MU];
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        const bool ok = p + j < p1;
+        r[j]          = ok ? L.scrow[p + j] : d.c0;
+        if constexpr (!Z) ar[j] = ok ? L.scval[p + j] : 0.0, ai[j] = 0.0;
+        else {
+          const dbl2 a = ok ? *(gcd2_t)(L.scval + 2 * (p + j)) : dbl2{0.0, 0.0};
+          ar[j] = a.x, ai[j] = a.y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UN; ++j)
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) xv[j][nu] = xb[(long long)nu * d.n + r[j]];
+#pragma unroll
+      for (int j = 0; j < UN; ++j) {
+        if (p + j < p1) { // (x of this leaf's own columns, read for the absent entries, is not defined yet: keep it out of the sums)
+          if constexpr (!Z) {
+#pragma unroll
+            for (int nu = 0; nu < MU; ++nu) t[nu] = fma(ar[j], xv[j][nu], t[nu]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < MU / 2; ++k) {
+              t[2 * k]     = fma(ar[j], xv[j][2 * k], fma(-ai[j], xv[j][2 * k + 1], t[2 * k]));
+              t[2 * k + 1] = fma(ar[j], xv[j][2 * k + 1], fma(ai[j], xv[j][2 * k], t[2 * k + 1]));
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = t[nu];
+  }
+  wave_lds_order();
+  double acc0[MU], acc1[MU];
+  ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
+  const int g = ld >> 1, sub = lane / g, gl = lane - sub * g;
+  if (sub == 0) { // x_J = z - W t, z = what the forward sweep left in y_J
+    if constexpr (!Z) {
+      const int c = 2 * gl;
+      if (c < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = yb[(long long)nu * d.n + d.c0 + c] - acc0[nu];
+      }
+      if (c + 1 < w) {
+#pragma unroll
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = yb[(long long)nu * d.n + d.c0 + c + 1] - acc1[nu];
+      }
+    } else if (gl < w) {
+#pragma unroll
+      for (int k = 0; k < MU / 2; ++k) {
+        const double sr = acc0[2 * k] - acc1[2 * k + 1], si = acc0[2 * k + 1] + acc1[2 * k];
+        xb[(long long)(2 * k) * d.n + d.c0 + gl]     = yb[(long long)(2 * k) * d.n + d.c0 + gl] - sr;
+        xb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = yb[(long long)(2 * k + 1) * d.n + d.c0 + gl] - si;
+      }
+    }
+  }
+}
+
+// =========================== wide panels: one workgroup per tile, LDS-staged right-hand side =======================
+// right-hand side entry of panel column `col` (in doubles) for the real column nu: real scalars b_J - (what the children handed up,
+// summed over the slot rows of J: dense reads, every row tile of J forms the entries it stages itself -- no gather pass ahead of the
+// level); complex scalars the entry (col, nu) of R = [ f_r  f_i ; -f_i  f_r ] (one plane of f, possibly negated)
+template <bool Z>
+__device__ static inline double fwd_rhs_entry(const SnView &d, int col, int nu, const double *bb, const double *Sb, long long stot)
+{
+  const int c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
+  double    v[1] = {bb[(long long)plane * d.n + d.c0 + c]};
+  slot_sub<1>(d, c, Sb + (long long)plane * stot, stot, v);
+  return (Z && (col & 1) && !(nu & 1)) ? -v[0] : v[0];
 }
 
 template <int MU, int FWD_PASSES, int CU, bool Z>
-__device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered, int dbg)
+__device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Sb, long long stot)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
@@ -561,6 +673,15 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
   const int     rend = t.r0 + t.nr;
   const int     tile_lim = min(wc, cs * (tri_last(rend - 1, d.tgs) + 1)); // rows of the top block never look right of their diagonal (tile)
   const bool    single   = tile_lim <= CW;
+  // the first loads of the panel are requested before the right-hand side is staged (they do not depend on it)
+  dbl2 apre[FWD_PASSES];
+#pragma unroll
+  for (int p = 0; p < FWD_PASSES; ++p) {
+    const int r = t.r0 + p * 4 + wave;
+    const int l = r < rend ? (r < w ? min(wc, cs * (tri_last(r, d.tgs) + 1)) : wc) : 0;
+    apre[p]     = 2 * lane < l ? *(gcd2_t)(d.F + (long long)r * ldw + 2 * lane) : dbl2{0.0, 0.0};
+  }
+  bool first = true;
   // row batches: every wavefront owns FWD_PASSES rows per batch (one wave per row, 16-byte loads, 1 KiB per instruction)
   for (int rb = t.r0; rb < rend; rb += 4 * FWD_PASSES) {
     int    row[FWD_PASSES], lim[FWD_PASSES];
@@ -575,14 +696,14 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
       for (int nu = 0; nu < MU; ++nu) acc[p][nu] = 0.0;
     }
     for (int k0 = 0; k0 < tile_lim; k0 += CW) {
-      if ((!single || rb == t.r0) && !DBG_ON(dbg, DBG_NORHS)) {
+      if ((!single || rb == t.r0)) {
         // stage f = b - children's updates for columns [k0, kend), zero padding up to ldw (16-byte reads past w see zeros)
         if (!single) __syncthreads();
         const int kend = min(k0 + CW, ldw);
         for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
           const int nu = idx / (kend - k0), i = idx - nu * (kend - k0);
           const int col = k0 + i;
-          lds[nu * CW + i] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
+          lds[nu * CW + i] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Sb, stot) : 0.0;
         }
         __syncthreads();
       }
@@ -592,7 +713,8 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 #pragma unroll
         for (int u = 0; u < CU; ++u)
 #pragma unroll
-          for (int p = 0; p < FWD_PASSES; ++p) a[u][p] = (c + 128 * u < lim[p] && !DBG_ON(dbg, DBG_NOLOAD)) ? *(gcd2_t)(d.F + (long long)row[p] * ldw + c + 128 * u) : dbl2{0.0, 0.0};
+          for (int p = 0; p < FWD_PASSES; ++p) a[u][p] = (first && u == 0) ? apre[p] : ((c + 128 * u < lim[p]) ? *(gcd2_t)(d.F + (long long)row[p] * ldw + c + 128 * u) : dbl2{0.0, 0.0});
+        first = false;
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
           const int ci = c + 128 * u < cmax ? c + 128 * u - k0 : 0; // columns past the chunk carry a = 0
@@ -604,20 +726,20 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
           }
         }
       }
+      first = false; // (also for the lanes whose columns lie right of the first rows' entries)
     }
 #pragma unroll
     for (int p = 0; p < FWD_PASSES; ++p)
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         double s = acc[p][nu];
-        if (!DBG_ON(dbg, DBG_NORED))
-          for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0 && row[p] < rend) sums[nu * 64 + (row[p] - t.r0)] = s;
       }
   }
   // epilogue: one thread per row of the tile (tiles have at most 64 rows)
   __syncthreads();
-  if (tid < t.nr && !DBG_ON(dbg, DBG_NOSTORE)) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Sb, stot);
 }
 
 // Forward tile of a wide panel with 4 or 8 right-hand sides on the f64 MFMA pipe: T(rows x MU) = F(rows x w) f(w x MU) is a
@@ -630,7 +752,7 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
 // outputs, and on gfx950 the f64 MFMA rate equals the VALU rate, so a half-empty tile costs twice the arithmetic --
 // measured 5.6 vs 5.3 ms per sweep pair at mu = 8.)
 template <int MU, bool Z>
-__device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Ub, bool pregathered)
+__device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *bb, double *yb, double *Sb, long long stot)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, wc = d.wc, cs = d.cs, ldw = d.ldw;
@@ -653,7 +775,7 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
     const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
     for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
       const int nu = idx / (kend - k0), i = idx - nu * (kend - k0), col = k0 + i;
-      lds[i * MU + nu] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Ub, d.has_src && !pregathered) : 0.0;
+      lds[i * MU + nu] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Sb, stot) : 0.0;
     }
     __syncthreads();
     const int cend = min(kend, (my_lim + 15) & ~15), step = 16 * wpg;
@@ -717,11 +839,11 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
     sums[nu * 64 + rl] = v;
   }
   __syncthreads();
-  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Ub);
+  if (tid < t.nr) fwd_store_row<MU>(d, t.r0 + tid, sums + tid, 64, yb, Sb, stot);
 }
 
 template <int MU, int FP, bool Z>
-__device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts, int dbg)
+__device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, double *lds, int lds_dbl, const double *yb, double *xb, double *xo, double *partials, int *arrivals, int max_parts)
 {
   const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int     w = d.w, ldw = d.ldw;
@@ -737,7 +859,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   // rows above the tile's first column hold zeros in these columns (triangular top block): rows [t.rbeg, t.rend) only
   for (int i0 = t.rbeg; i0 < t.rend; i0 += RCH) {
     const int rch = min(RCH, t.rend - i0);
-    for (int idx = tid; idx < rch * MU && !DBG_ON(dbg, DBG_NORHS); idx += WG_THREADS) {
+    for (int idx = tid; idx < rch * MU; idx += WG_THREADS) {
       const int nu = idx / rch, ii = idx - nu * rch;
       const int i = i0 + ii;
       double    v;
@@ -760,7 +882,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
       for (; ii + (FP - 1) * 4 * R < rch; ii += FP * 4 * R) {
         dbl2 a[FP];
 #pragma unroll
-        for (int p = 0; p < FP; ++p) a[p] = DBG_ON(dbg, DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)(ii + p * 4 * R) * ldw);
+        for (int p = 0; p < FP; ++p) a[p] = *(gcd2_t)(Gp + (long long)(ii + p * 4 * R) * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
 #pragma unroll
@@ -772,7 +894,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
         }
       }
       for (; ii < rch; ii += 4 * R) {
-        const dbl2 a0 = DBG_ON(dbg, DBG_NOLOAD) ? dbl2{0.0, 0.0} : *(gcd2_t)(Gp + (long long)ii * ldw);
+        const dbl2 a0 = *(gcd2_t)(Gp + (long long)ii * ldw);
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu) {
           const double v0 = lds[nu * RCH + ii];
@@ -784,7 +906,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
     __syncthreads();
   }
   // reduce over the R row groups of the wavefront, then over the 4 wavefronts through LDS
-  if (!DBG_ON(dbg, DBG_NORED)) {
+  {
     double a0[MU], a1[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
@@ -807,7 +929,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   }
   __syncthreads();
   if (t.nparts == 1) {
-    if (wave == 0 && sub == 0 && colok && !DBG_ON(dbg, DBG_NOSTORE)) {
+    if (wave == 0 && sub == 0 && colok) {
       if constexpr (!Z) {
 #pragma unroll
         for (int nu = 0; nu < MU; ++nu)
@@ -902,15 +1024,15 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
 }
 
 // One launch per level and direction: every workgroup takes block-level tiles g, g + G, ... with its four wavefronts
-// together, then its wavefronts take wave-level tiles on their own (G = grid size; by default one share per workgroup).
-// Tiles are sorted by decreasing cost.  wr = rows of right-hand side a wavefront stages in LDS (the level's maximum).
-// launches made of wave tiles only (the bottom levels) are bound by (latency of a tile) / (tiles in flight): one or two real
-// right-hand sides are held to 64 VGPRs = 8 wavefronts per SIMD
-template <int MU, bool HAS_BLOCK, int FP, bool Z>
-__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ U, int mu_total, int nu0, int lds_dbl, int wr, int pregathered, int dbg)
+// together, then its wavefronts take wave-level tiles on their own (G = grid size; by default one share per workgroup) -- the tiles
+// of the narrow panels first, then (LEAF: level 0) the condensed leaves.  Tiles are sorted by decreasing cost.  wr = rows of
+// right-hand side a wavefront stages in LDS (the level's maximum).  Launches made of wave tiles only (the bottom levels) are bound
+// by (latency of a tile) / (tiles in flight): one or two real right-hand sides are held to 64 VGPRs = 8 wavefronts per SIMD.
+// S: the slot pool (factor.hpp), one copy per right-hand side column, stot entries apart.
+template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF>
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (LEAF ? 7 : 8) : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const Tile *__restrict__ ltiles, int nleaf, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ S, long long stot, int mu_total, int nu0, int lds_dbl, int wr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const unsigned long long tk0 = DBG_ON(dbg, DBG_TIMELINE) ? wall_clock64() : 0ull;
   const int G = gridDim.x;
   if (HAS_BLOCK) {
     for (int bt = blockIdx.x; bt < nblock; bt += G) {
@@ -918,11 +1040,9 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
       const SnView  d  = view(sns[t.sn]);
       const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
       double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-      double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-      if constexpr (MU >= 4) {
-        if (DBG_ON(dbg, DBG_NOMFMA)) fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
-        else fwd_block_tile_mfma<MU, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0);
-      } else fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Ub, pregathered != 0, dbg);
+      double       *Sb = S + d.soff + (long long)nu0 * stot;
+      if constexpr (MU >= 4) fwd_block_tile_mfma<MU, Z>(d, t, lds, lds_dbl, bb, yb, Sb, stot);
+      else fwd_block_tile<MU, FP, 1, Z>(d, t, lds, lds_dbl, bb, yb, Sb, stot);
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -931,21 +1051,24 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
   double   *wl = lds + wv * (wr * MU);
   // the wave-level deal starts where the block-level deal stopped
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
-  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup: 4, or 1 in the launches made of wave tiles only
-  for (int tix = gw * wpb + wv; tix < nwave; tix += G * wpb) {
-    const Tile    t  = wtiles[tix];
+  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup
+  for (int tix = gw * wpb + wv; tix < nwave + (LEAF ? nleaf : 0); tix += G * wpb) {
+    const bool    leaf = LEAF && tix >= nwave;
+    const Tile    t  = leaf ? ltiles[tix - nwave] : wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
-    double       *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-    if constexpr (MU == 1 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
-    else fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Ub, dbg, tk0);
+    double       *Sb = S + d.soff + (long long)nu0 * stot;
+    if (leaf) {
+      if constexpr (LEAF) fwd_leaf_tile<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot);
+    } else if constexpr (MU == 1 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Sb, stot); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
+    else fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Sb, stot);
     wave_lds_order(); // the last reads of the staged right-hand side land before the next tile overwrites it; the stores of this tile drain while the next one starts (tiles of a level are independent)
   }
 }
 
-template <int MU, bool HAS_BLOCK, int FP, bool Z>
-__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr, int dbg)
+template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF>
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const Tile *__restrict__ ltiles, int nleaf, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -956,49 +1079,26 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
       const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
       double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
       double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-      bwd_block_tile<MU, FP, Z>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts, dbg);
+      bwd_block_tile<MU, FP, Z>(d, t, lds, lds_dbl, yb, xb, xo, partials, arrivals, max_parts);
       __syncthreads();
     }
   }
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *wl = lds + wv * (wr * MU);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
-  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup: 4, or 1 in the launches made of wave tiles only
-  for (int tix = gw * wpb + wv; tix < nwave; tix += G * wpb) {
-    const Tile    t  = wtiles[tix];
+  const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup
+  for (int tix = gw * wpb + wv; tix < nwave + (LEAF ? nleaf : 0); tix += G * wpb) {
+    const bool    leaf = LEAF && tix >= nwave;
+    const Tile    t  = leaf ? ltiles[tix - nwave] : wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
-    bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo, dbg);
+    if (leaf) {
+      if constexpr (LEAF) bwd_leaf_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb);
+    } else bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo);
     wave_lds_order();
   }
-}
-
-// Right-hand side of the wide supernodes of a level, formed once: b_J <- b_J - (updates handed up by the children), in
-// place in the permuted copy of b (only the tiles of J read these entries).  One thread per column: the dependent index
-// chains gptr -> gsrc -> U of a whole level overlap instead of being walked by every row tile of the supernode.
-template <int MU>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv_gather_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ gtiles, double *__restrict__ b, const double *__restrict__ U, int mu_total, int nu0)
-{
-  const Tile   t = gtiles[blockIdx.x];
-  const SnView d = view(sns[t.sn]);
-  const int    col = t.r0 + (int)threadIdx.x;
-  if (col >= t.r0 + t.nr) return;
-  double       *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
-  const double *Ub = U + d.uoff * mu_total + (long long)nu0 * d.usize;
-  const int     q0 = d.gptr[col], q1 = d.gptr[col + 1];
-  if (q0 == q1) return;
-  double v[MU];
-#pragma unroll
-  for (int nu = 0; nu < MU; ++nu) v[nu] = bb[(long long)nu * d.n + d.c0 + col];
-  for (int q = q0; q < q1; ++q) {
-    const int src = d.gsrc[q];
-#pragma unroll
-    for (int nu = 0; nu < MU; ++nu) v[nu] -= Ub[(long long)nu * d.usize + src];
-  }
-#pragma unroll
-  for (int nu = 0; nu < MU; ++nu) bb[(long long)nu * d.n + d.c0 + col] = v[nu];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1018,6 +1118,10 @@ __global__ void k_transpose_panels(const double *__restrict__ F, double *__restr
   }
 }
 
+// a condensed leaf that BOTH engines take through its blob (the 16-column engine: at most 32 columns, sptrsv16.hip) needs no
+// transposed copy of its panel
+static bool leaf_blob_only(const DeviceFactor &D, idx_t k) { return D.lb_off[k] >= 0 && D.blk_ptr[k + 1] - D.blk_ptr[k] <= LEAF16_MAXW; }
+
 void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 {
   HH_CHECK(hf.info == 0, "numfact failed (zero or negative pivot in block " + std::to_string(hf.info) + ")");
@@ -1028,7 +1132,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   nblk       = hf.sym.nblk;
   nlev       = (idx_t)hf.level_ptr.size() - 1;
   f_size     = hf.f_size;
-  u_size     = hf.u_size;
+  s_size     = hf.s_size;
   nnz_exact  = hf.sym.nnz_exact;
   nnz_stored = hf.sym.nnz_stored;
   F.alloc((size_t)hf.f_size * sc);
@@ -1041,20 +1145,18 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   } else G.release();
   if (kind == FACT_LDLT) dinv.upload(hf.dinv, s);
   else dinv.release();
-  HH_CHECK(hf.sym.rows.size() < (size_t)2147483647 && hf.gsrc.size() < (size_t)2147483647 && hf.gptr.size() < (size_t)2147483647, "factor index pools exceed 32 bits");
+  HH_CHECK(hf.sym.rows.size() < (size_t)2147483647 && hf.s_size < (int64_t)2147483647, "factor index pools exceed 32 bits");
+  HH_CHECK(hf.rel.size() == hf.sym.rows.size(), "numfact: hand-over lists of the forward sweep missing");
   std::vector<int> tmp(hf.sym.rows.begin(), hf.sym.rows.end());
   rows.upload(tmp, s);
-  tmp.assign(hf.gptr.size(), 0);
-  for (size_t i = 0; i < hf.gptr.size(); ++i) tmp[i] = (int)hf.gptr[i];
-  gptr.upload(tmp, s);
-  std::vector<int> tmp2(hf.gsrc.size());
-  for (size_t i = 0; i < hf.gsrc.size(); ++i) tmp2[i] = (int)hf.gsrc[i];
-  gsrc.upload(tmp2, s);
+  std::vector<int> tmp2(hf.rel.begin(), hf.rel.end());
+  rel.upload(tmp2, s);
   std::vector<int> tmp3(hf.ord.perm.begin(), hf.ord.perm.end());
   perm.upload(tmp3, s);
   std::vector<int> tmp4(hf.ord.iperm.begin(), hf.ord.iperm.end());
   HH_CHECK(tmp4.size() == tmp3.size(), "ordering without its inverse permutation");
   iperm.upload(tmp4, s);
+  leaf_pool.upload(hf.leaf_pool, s);
   HIP_OK(hipStreamSynchronize(s)); // the staging vectors above go out of scope
   blk_ptr   = hf.sym.blk_ptr;
   ldw       = hf.ldw;
@@ -1063,7 +1165,14 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   level_blk = hf.level_blk;
   f_off     = hf.f_off;
   row_ptr   = hf.sym.row_ptr;
-  goff      = hf.goff;
+  u_off     = hf.u_off;
+  nchild    = hf.nchild;
+  s_off     = hf.s_off;
+  ps_off    = hf.ps_off;
+  lb_off    = hf.lb_off;
+  lb_nnzr   = hf.lb_nnzr;
+  lb_nnzc   = hf.lb_nnzc;
+  if ((idx_t)lb_off.size() != nblk) lb_off.assign(nblk, -1), lb_nnzr.assign(nblk, 0), lb_nnzc.assign(nblk, 0);
   tgs.assign(hf.tgs.begin(), hf.tgs.end());
   if ((idx_t)tgs.size() != nblk) tgs.assign(nblk, 0);
   // transposed copies of the narrow forward panels
@@ -1072,7 +1181,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   {
     int64_t tot = 0;
     for (idx_t k = 0; k < nblk; ++k) {
-        if (ldw[k] * sc > NARROW) continue;
+        if (ldw[k] * sc > NARROW || leaf_blob_only(*this, k)) continue;
         const int64_t w = (int64_t)(blk_ptr[k + 1] - blk_ptr[k]) * sc, hgt = (blk_ptr[k + 1] - blk_ptr[k]) + (row_ptr[k + 1] - row_ptr[k]); // doubles per panel row, rows
         ldh[k]    = (idx_t)((hgt + 1) / 2 * 2);
         ft_off[k] = tot;
@@ -1097,40 +1206,6 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
       HIP_OK(hipStreamSynchronize(s));
     }
   }
-  u_off.assign(nblk, 0);
-  has_src.assign(nblk, 0);
-  for (idx_t k = 0; k < nblk; ++k) {
-    u_off[k]      = (idx_t)hf.u_off[k];
-    const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
-    has_src[k]    = hf.gptr[hf.goff[k] + hh] > hf.gptr[hf.goff[k]];
-  }
-  // narrow supernodes whose entries are fed by at most 4 update-vector entries each: their gather lists are stored once more as 4
-  // fixed slots per entry of the front (one 16-byte index load per entry instead of a walk through gptr / gsrc)
-  s4_off.assign(nblk, -1);
-  {
-    int64_t tot = 0;
-    for (idx_t k = 0; k < nblk; ++k) {
-      const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
-      if (ldw[k] * sc > NARROW || !has_src[k]) continue;
-      const int64_t *gp = hf.gptr.data() + hf.goff[k];
-      bool           ok = true;
-      for (int64_t i = 0; i < hh && ok; ++i) ok = gp[i + 1] - gp[i] <= 4;
-      if (!ok) continue;
-      s4_off[k] = tot;
-      tot += 4 * hh;
-    }
-    HH_CHECK(tot < (int64_t)2147483647 * 4, "fixed-slot gather lists exceed 32-bit offsets");
-    std::vector<int> s4((size_t)tot, -1);
-    for (idx_t k = 0; k < nblk; ++k) {
-      if (s4_off[k] < 0) continue;
-      const int64_t hh = (hf.sym.blk_ptr[k + 1] - hf.sym.blk_ptr[k]) + (hf.sym.row_ptr[k + 1] - hf.sym.row_ptr[k]);
-      const int64_t *gp = hf.gptr.data() + hf.goff[k];
-      for (int64_t i = 0; i < hh; ++i)
-        for (int64_t qq = gp[i]; qq < gp[i + 1]; ++qq) s4[(size_t)(s4_off[k] + 4 * i + (qq - gp[i]))] = (int)hf.gsrc[qq];
-    }
-    src4.upload(s4, s);
-    HIP_OK(hipStreamSynchronize(s));
-  }
 }
 
 void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s)
@@ -1142,36 +1217,24 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   ntot = utot = 0;
   nlev                = 0;
   bytes_alg_per_rhs1  = 0;
-  std::vector<long long> uoffs(fs.size(), 0);
+  std::vector<long long> soffs(fs.size(), 0);
   for (size_t f = 0; f < fs.size(); ++f) {
     voff[f]  = ntot;
-    uoffs[f] = utot;
+    soffs[f] = utot;
     ntot += fs[f]->n;
-    utot += fs[f]->u_size;
+    utot += fs[f]->s_size;
     nlev = std::max<int>(nlev, fs[f]->nlev);
     bytes_alg_per_rhs1 += (2.0 * (double)fs[f]->nnz_exact * 8.0 + 4.0 * (double)fs[f]->n * 8.0) * (fs[f]->cplx ? 2.0 : 1.0); // sizeof(K) = 16 for complex scalars
     HH_CHECK(fs[f]->cplx == fs[0]->cplx, "real and complex factors cannot share a plan");
   }
   cplx = !fs.empty() && fs[0]->cplx;
   std::vector<SnDesc>           descs;
-  std::vector<std::vector<Tile>> tl[4];
+  std::vector<std::vector<Tile>> tl[NKIND];
   for (auto &v : tl) v.assign(nlev, {});
-  std::vector<std::vector<Tile>> gat(nlev);
+  std::vector<std::vector<Tile>> gat(nlev), w16[2], leaf16(nlev); // the 16-column engine's own lists: panel tiles of the narrow supernodes, its condensed leaves, the wide supernodes whose right-hand side is combined ahead of the level
+  w16[0].assign(nlev, {}), w16[1].assign(nlev, {});
   // developer knobs of the plan (defaults = what measured best on the bench workloads)
   auto envi             = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
-  dbg                   = envi("HPDDM_HIP_DBG", 0);
-  if (DBG_ON(dbg, DBG_TIMELINE)) {
-    static unsigned long long *hostbuf = nullptr;
-    const unsigned int         cap     = 1u << 20;
-    if (!hostbuf) {
-      HIP_OK(hipMalloc((void **)&hostbuf, sizeof(unsigned long long) * 8 * cap)); // device memory: host-mapped writes would perturb the sweeps
-      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &hostbuf, sizeof(hostbuf)));
-      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cap), &cap, sizeof(cap)));
-      timeline_host = hostbuf;
-    }
-    const unsigned int zero = 0;
-    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_cnt), &zero, sizeof(zero)));
-  }
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  bwd_small   = envi("HPDDM_HIP_BWD_SMALL", 4096);   // narrow panels, backward: one wavefront takes the whole supernode up to this many panel entries (scalars), a workgroup beyond
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
@@ -1198,44 +1261,57 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.G     = (D.kind == FACT_LU ? D.G.p : D.F.p) + D.f_off[k] * cs;
       d.dinv  = D.kind == FACT_LDLT ? D.dinv.p : nullptr;
       d.rows  = D.rows.p + D.row_ptr[k];
-      d.gptr  = D.gptr.p + D.goff[k];
-      d.gsrc  = D.gsrc.p;
+      d.rel   = D.rel.p + D.u_off[k];
       d.voff  = voff[f];
-      d.uoff  = uoffs[f];
+      d.soff  = soffs[f];
       d.n     = D.n;
-      d.usize = (int)D.u_size;
       d.c0    = D.blk_ptr[k];
       d.w     = D.blk_ptr[k + 1] - D.blk_ptr[k];
       d.nb    = (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
       d.ldw   = D.ldw[k] * cs;
       d.wc    = d.w * cs;
       d.cs    = cs;
-      d.u_off = D.u_off[k];
-      d.has_src = D.has_src[k] ? 1 : 0;
+      d.s_in   = (int)D.s_off[k];
+      d.nchild = D.nchild[k];
+      d.s_out  = (int)D.ps_off[k];
       d.tgs     = D.tgs.empty() ? 0 : D.tgs[k];
       d.FT      = D.ft_off[k] >= 0 ? D.FT.p + D.ft_off[k] : nullptr;
       d.ldh     = D.ldh[k];
+      d.leaf    = D.lb_off[k] >= 0 ? D.leaf_pool.p + D.lb_off[k] : nullptr;
+      d.nnzr    = D.lb_nnzr[k], d.nnzc = D.lb_nnzc[k];
+      HH_CHECK(d.nb == 0 || d.s_out >= 0, "plan: a supernode with rows below it has no slot row to write to");
       const int id = (int)descs.size();
       descs.push_back(d);
-      d.src4 = D.s4_off[k] >= 0 ? D.src4.p + D.s4_off[k] : nullptr;
-      descs.back().src4 = d.src4;
       const int h = d.w + d.nb, lev = D.height[k];
       lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
-        HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
+        const bool leafv = d.leaf != nullptr, leaf6 = leafv && d.w <= LEAF16_MAXW; // condensed leaf in the VALU sweeps / in the 16-column engine
+        HH_CHECK(d.FT != nullptr || (leafv && leaf6), "narrow panel without its transposed copy");
         // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
         const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
-        for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
         // backward: whole supernode per wavefront while it is small, else one workgroup
         const bool small = h <= WAVE_ROWS && (long long)h * d.ldw <= bwd_small * cs;
-        tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(Tile{id, 0, d.ldw, 0, 1, 0, 0, h});
+        const Tile tb{id, 0, d.ldw, 0, 1, 0, 0, h};
+        if (leafv) {
+          tl[FWD_LEAF][lev].push_back(Tile{id, 0, h, 0, 1, 0, 0, 0});
+          tl[BWD_LEAF][lev].push_back(tb);
+        } else {
+          for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
+          tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(tb);
+        }
+        if (leaf6) leaf16[lev].push_back(tb);
+        else {
+          for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
+          if (small) w16[1][lev].push_back(tb); // (the supernodes the VALU sweeps give a workgroup stay block tiles of the engine as well: tl[BWD_BLOCK] when !leafv ...
+          else if (leafv) w16[1][lev].push_back(tb); // ... a condensed leaf too tall for a wavefront: a team tile of the engine)
+        }
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         int trb = fwd_tile_rows(d.wc);
         while (trb > 16 && wide_rows16[lev] * 16 / trb < fwd_want) trb >>= 1;
         for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
         for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h}); // c0: first of 128 doubles of every row; rows above scalar column c0 / cs hold zeros there
-        if (d.has_src) // its right-hand side b_J - (children's updates) is formed once, ahead of the level (sptrsv_gather_kernel)
+        if (d.nchild) // 16-column engine: its right-hand side b_J - (children's updates) is formed once, ahead of the level (sptrsv16_combine_kernel)
           for (int c0 = 0; c0 < d.w; c0 += WG_THREADS) gat[lev].push_back(Tile{id, c0, std::min(WG_THREADS, d.w - c0), 0, 1, 0, 0, 0});
       }
     }
@@ -1279,35 +1355,37 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     v.swap(out);
   }
   std::vector<Tile> all;
-  for (int kd = 0; kd < 4; ++kd) {
+  for (int kd = 0; kd < NKIND; ++kd) {
     lev_ptr[kd].assign(nlev + 1, 0);
     lev_lds[kd].assign(nlev, 0);
   }
   lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
   launches_per_solve = 2; // the two permutation passes
-  for (int kd = 0; kd < 4; ++kd)
+  for (int kd = 0; kd < NKIND; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
-      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr; };
+      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : ((kd == FWD_LEAF || kd == BWD_LEAF) ? (long long)descs[t.sn].w * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr); };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
       lev_ptr[kd][l] = (int)all.size();
       all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the
-      // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront
+      // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront; a condensed leaf
+      // its w entries of f / z / t
       int need = 0;
       for (const Tile &t : tl[kd][l])
-        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : descs[t.sn].w + descs[t.sn].nb)));
+        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : (kd == BWD_WAVE ? descs[t.sn].w + descs[t.sn].nb : descs[t.sn].w))));
       lev_lds[kd][l] = need;
     }
   // The narrow tiles once more for the 16-column engine (sptrsv16.hip), whose wavefronts take 32 outputs at a time (two MFMA
   // fragments: few registers, many wavefronts in flight -- these levels are bound by latency): per level first the TEAM tiles, a
   // whole workgroup each (backward supernodes that give at least three wavefronts 32 columns each or need more than two staging
   // passes of v: the workgroup stages the rows of v once), then the tiles cut in chunks
-  // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each.
+  // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each, then the engine's condensed leaves
+  // (at most LEAF16_MAXW columns), one wavefront each.
   for (int dir = 0; dir < 2; ++dir) {
-    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0);
+    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0), lev_leaf16[dir].assign(nlev, 0);
     for (int l = 0; l < nlev; ++l) {
-      const std::vector<Tile> &src = tl[dir == 0 ? FWD_WAVE : BWD_WAVE][l];
+      const std::vector<Tile> &src = w16[dir][l];
       std::vector<Tile>        team, chunk;
       for (const Tile &t : src) {
         const SnDesc &d = descs[t.sn];
@@ -1328,6 +1406,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       lev_team[dir][l]  = (int)team.size();
       all.insert(all.end(), team.begin(), team.end());
       all.insert(all.end(), chunk.begin(), chunk.end());
+      lev_leaf16[dir][l] = (int)leaf16[l].size();
+      all.insert(all.end(), leaf16[l].begin(), leaf16[l].end());
       lev_end16[dir][l] = (int)all.size();
     }
   }
@@ -1337,14 +1417,13 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     gat_ptr[l] = (int)all.size();
     all.insert(all.end(), gat[l].begin(), gat[l].end());
     gat_end[l] = (int)all.size();
-    launches_per_solve += !gat[l].empty();
   }
-  for (int kd = 0; kd < 4; ++kd) {
+  for (int kd = 0; kd < NKIND; ++kd) {
     // lev_ptr[kd][l]..lev_end: store the end of each range in a parallel array (ranges of different kinds interleave)
     lev_end[kd].assign(nlev, 0);
     for (int l = 0; l < nlev; ++l) lev_end[kd][l] = lev_ptr[kd][l] + (int)tl[kd][l].size();
   }
-  for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty());
+  for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty() || !tl[FWD_LEAF][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty() || !tl[BWD_LEAF][l].empty());
   {
     std::vector<long long>   pv(fs.size());
     std::vector<int>         pnn(fs.size());
@@ -1372,14 +1451,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   HIP_OK(hipStreamSynchronize(s));
 }
 
-unsigned long long *SolvePlan::timeline_host = nullptr;
-unsigned int        SolvePlan::timeline_count()
-{
-  unsigned int c = 0;
-  HIP_OK(hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_timeline_cnt), sizeof(c)));
-  return c;
-}
-
 void SolvePlan::mark(int tag, hipStream_t s)
 {
   if (!profile) return;
@@ -1392,13 +1463,17 @@ void SolvePlan::mark(int tag, hipStream_t s)
 
 std::vector<double> SolvePlan::level_bytes(int) const { return lev_bytes; }
 
-void SolvePlan::reserve(int mu)
+void SolvePlan::reserve(int mu, hipStream_t s)
 {
   if (mu <= mu_cap) return;
   y.alloc((size_t)ntot * mu);
   xw.alloc((size_t)ntot * mu);
   bperm.alloc((size_t)ntot * mu);
+  // the slot pool (factor.hpp): one copy per right-hand side column, utot entries apart whatever mu is -- the entries no child
+  // writes must stay zero from here on, so the place of an entry may not depend on the number of right-hand sides of a solve
   U.alloc((size_t)std::max<long long>(utot, 1) * mu);
+  HIP_OK(hipMemsetAsync(U.p, 0, sizeof(double) * (size_t)std::max<long long>(utot, 1) * mu, s));
+  HIP_OK(hipStreamSynchronize(s));
   partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 16));
   mu_cap = mu;
 }
@@ -1413,33 +1488,40 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // within 128 VGPRs); backward: 4.
   constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU == 1 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
   auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
-  auto wrows  = [&](int kd, int l) { return std::max(16, (P.lev_lds[kd][l] + 15) / 16 * 16); };
+  auto wrows  = [&](int kd, int kl, int l) { return std::max(16, (std::max(P.lev_lds[kd][l], P.lev_lds[kl][l]) + 15) / 16 * 16); };
   const int lds_cap = P.lds_cap;
   auto clampd = [&](int need, int lds_wave) { return std::max(std::max(512 * MU, lds_wave), std::min(lds_cap, (need + 63) / 64 * 64)); };
   // one workgroup per block tile, four wave tiles per workgroup.  (Single-wavefront workgroups, persistent grids and one
   // wavefront per bottom subtree all measured the same level times or worse in rounds 1-2: the bottom levels are bound by the bytes
   // they pull beside their panel entries)
   auto grid = [&](int nb, int nw) { return nb + (nw + 3) / 4; };
+  const Tile     *T = P.tiles.p;
+  const long long stot = P.utot;
   for (int l = 0; l < P.nlev; ++l) {
-    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l);
-    const int ng = P.gat_end[l] - P.gat_ptr[l];
-    if (ng) {
-      hipLaunchKernelGGL((sptrsv_gather_kernel<MU>), dim3(ng), dim3(WG_THREADS), 0, s, P.sn.p, P.tiles.p + P.gat_ptr[l], b, P.U.p, mu_total, nu0);
-      P.mark(1000 + l, s);
-    }
-    const int wr = nw ? wrows(SolvePlan::FWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
+    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
+    const int wr = nw + nl ? wrows(SolvePlan::FWD_WAVE, SolvePlan::FWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z>), dim3(grid(nb, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, ng ? 1 : 0, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z>), dim3(grid(0, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], nw, b, P.y.p, P.U.p, mu_total, nu0, ld, wr, 0, P.dbg);
-    if (nb || nw) P.mark(2000 + l, s);
+    const Tile *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l], *tw = T + P.lev_ptr[SolvePlan::FWD_WAVE][l], *tf = T + P.lev_ptr[SolvePlan::FWD_LEAF][l];
+    const dim3 g(grid(nb, nw + nl));
+    const size_t shm = (size_t)ld * sizeof(double);
+    if (nb && nl) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
+    else if (nb) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, 0, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
+    else if (nl) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, nl, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
+    else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, 0, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
+    if (nb || nw || nl) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l);
-    const int wr = nw ? wrows(SolvePlan::BWD_WAVE, l) : 16, lds_wave = 4 * wr * MU;
+    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
+    const int wr = nw + nl ? wrows(SolvePlan::BWD_WAVE, SolvePlan::BWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z>), dim3(grid(nb, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z>), dim3(grid(0, nw)), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], nw, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr, P.dbg);
-    if (nb || nw) P.mark(3000 + l, s);
+    const Tile *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l], *tw = T + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = T + P.lev_ptr[SolvePlan::BWD_LEAF][l];
+    const dim3 g(grid(nb, nw + nl));
+    const size_t shm = (size_t)ld * sizeof(double);
+    if (nb && nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, nl, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    if (nb || nw || nl) P.mark(3000 + l, s);
   }
 }
 
@@ -1466,7 +1548,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
   if (cplx) {
     // mu complex right-hand sides = 2 mu real columns (planes) inside; register blocks of 8 / 4 / 2 real columns
     const int mr = 2 * mu;
-    reserve(mr);
+    reserve(mr, s);
     mark(-1, s);
     hipLaunchKernelGGL(k_perm_in_z, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu, done);
     mark(0, s);
@@ -1489,7 +1571,7 @@ void SolvePlan::solve(const double *b, double *x, int mu, hipStream_t s)
     HIP_OK(hipGetLastError());
     return;
   }
-  reserve(mu);
+  reserve(mu, s);
   // greedy split into register-blocked groups of 8 / 4 / 2 / 1 right-hand sides (one sweep over L per group)
   mark(-1, s);
   hipLaunchKernelGGL(k_perm_in, gp, dim3(256), 0, s, pvoff.p, pn.p, pperm.p, b, bperm.p, mu, done);

@@ -8,6 +8,7 @@ namespace hpddm_hip {
 static constexpr int WG_THREADS  = 256;
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
+static constexpr int LEAF16_MAXW = 32;   // the 16-column engine takes a condensed leaf through its blob up to this many columns (sptrsv16.hip)
 
 // Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
 // tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
@@ -18,23 +19,39 @@ typedef const int __attribute__((address_space(1)))    *gci_t;
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef const int4v __attribute__((address_space(1)))  *gci4_t;
 struct SnView {
-  gcd_t     F, G, dinv, FT;
-  gci_t     rows, gptr, gsrc;
-  gci4_t    src4;
-  long long voff, uoff;
-  int       n, usize, c0, w, nb, ldw, wc, cs, u_off, has_src, ldh, tgs;
+  gcd_t     F, G, dinv, FT, leaf;
+  gci_t     rows, rel;
+  long long voff, soff;
+  int       n, c0, w, nb, ldw, wc, cs, s_in, nchild, s_out, ldh, tgs, nnzr, nnzc;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
   SnView v;
-  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT;
+  v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT, v.leaf = (gcd_t)d.leaf;
   v.ldh = d.ldh;
-  v.rows = (gci_t)d.rows, v.gptr = (gci_t)d.gptr, v.gsrc = (gci_t)d.gsrc;
-  v.src4 = (gci4_t)d.src4;
-  v.voff = d.voff, v.uoff = d.uoff;
-  v.n = d.n, v.usize = d.usize, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.u_off = d.u_off, v.has_src = d.has_src;
-  v.tgs = d.tgs;
+  v.rows = (gci_t)d.rows, v.rel = (gci_t)d.rel;
+  v.voff = d.voff, v.soff = d.soff;
+  v.n = d.n, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.s_in = d.s_in, v.nchild = d.nchild, v.s_out = d.s_out;
+  v.tgs = d.tgs, v.nnzr = d.nnzr, v.nnzc = d.nnzc;
   return v;
+}
+// the sections of a condensed leaf's blob (leaf_blob_layout of factor.hpp, in the address space of the kernels)
+typedef const unsigned short __attribute__((address_space(1))) *gcu16_t;
+struct LeafView {
+  gcd_t   WT, srval, scval;
+  gci_t   scrow;
+  gcu16_t srptr, scptr, srcol;
+};
+__device__ static inline LeafView leaf_view(const SnView &d)
+{
+  typedef const char __attribute__((address_space(1))) *gcc_t;
+  const LeafBlob lb = leaf_blob_layout(d.w, d.ldw, d.nb, d.nnzr, d.nnzc, d.cs);
+  const gcc_t    p  = (gcc_t)d.leaf;
+  LeafView       L;
+  L.WT = (gcd_t)(p + lb.wt), L.srval = (gcd_t)(p + lb.srval), L.scval = (gcd_t)(p + lb.scval);
+  L.scrow = (gci_t)(p + lb.scrow);
+  L.srptr = (gcu16_t)(p + lb.srptr), L.scptr = (gcu16_t)(p + lb.scptr), L.srcol = (gcu16_t)(p + lb.srcol);
+  return L;
 }
 // forward sweep: last column (scalar index) of the top block that row r holds an entry in -- r itself when the block is lower
 // triangular (tgs = 0), the last column of r's diagonal tile when the LU factorisation swapped rows inside its tiles (SnDesc::tgs)

@@ -270,14 +270,10 @@ int HpddmHipSynchronize(void);
 int HpddmHipSchwarzTime(HpddmHipSchwarz *A, const char *what, int mu, int warmup, int reps, double *seconds);
 /* Developer aids of the SpTRSV plan.  RebuildPlan: build the level schedule again from the resident factors (the plan
  * builder reads its HPDDM_HIP_* knobs from the environment).  LevelTimes: duration of every launch of one batched SpTRSV
- * (HIP events between the launches, averaged over reps): out[3i] = tag (kind * 1000 + level; kind 0 permutation in, 1 gather
- * pass, 2 forward, 3 backward, 4 permutation out), out[3i+1] = microseconds, out[3i+2] = panel bytes the launch streams
+ * (HIP events between the launches, averaged over reps): out[3i] = tag (kind * 1000 + level; kind 0 permutation in, 1 combine
+ * pass of the 16-column engine, 2 forward, 3 backward, 4 permutation out), out[3i+1] = microseconds, out[3i+2] = panel bytes the launch streams
  * (exact stored entries * 8); returns the number of launches. */
 int HpddmHipSchwarzRebuildPlan(HpddmHipSchwarz *A);
-/* developer aid (HPDDM_HIP_DBG=32 at plan build): clocks of the narrow forward wave tiles since the last RebuildPlan, 8 values per
- * tile: 100 MHz clock at kernel entry / descriptor in registers / right-hand side staged / panel streamed / results stored, then
- * rows, doubles per row, has-children flag; returns the number of tiles recorded (at most 2^20) */
-long long HpddmHipDebugTimeline(unsigned long long *out, long long cap_tiles);
 int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out, int cap);
 /* stats[0..7] = sum n (unknowns, in scalars K), sum nnz(L) exact, sum stored entries, algorithmic bytes of one batched SpTRSV at
  *               mu=1 (2*nnz(L)*sizeof(K) + 4*n*sizeof(K); sizeof(K) = 16 for complex operators), #levels, kernel

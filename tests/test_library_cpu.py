@@ -30,13 +30,32 @@ def _poisson3d(N):
     return (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr()
 
 
-def _replay(S, b):
+def _leaf_blob(pool, off, w, ldw, nb, nnzr, nnzc, cs):
+    """sections of a condensed leaf's blob (leaf_blob_layout, hpddm_amd/csrc/factor.hpp); ldw in doubles"""
+    raw = pool.view(np.uint8)[8 * off:]
+    dt = np.complex128 if cs == 2 else np.float64
+    o_srval = w * ldw * 8
+    o_scval = o_srval + nnzr * cs * 8
+    o_scrow = o_scval + nnzc * cs * 8
+    o_srptr = o_scrow + nnzc * 4
+    o_scptr = o_srptr + (nb + 1) * 2
+    o_srcol = o_scptr + (w + 1) * 2
+    WT = raw[:o_srval].view(dt).reshape(w, ldw // cs)[:, :w]
+    return dict(W=WT.T, srval=raw[o_srval:o_scval].view(dt), scval=raw[o_scval:o_scrow].view(dt), scrow=raw[o_scrow:o_srptr].view(np.int32),
+                srptr=raw[o_srptr:o_scptr].view(np.uint16), scptr=raw[o_scptr:o_srcol].view(np.uint16), srcol=raw[o_srcol:o_srcol + 2 * nnzr].view(np.uint16))
+
+
+def _replay(S, b, use_leaves=True):
     """numpy replay of the level-scheduled multifrontal solve on the exported solve-ready panels (factor.hpp); complex factors:
-    the panels are (re, im) pairs, L D L^T with plain transposes (complex symmetric) or LU"""
-    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "goff", "gptr", "gsrc", "tgs")}
+    the panels are (re, im) pairs, L D L^T with plain transposes (complex symmetric) or LU.  The updates travel as in the sweeps
+    of the library: every supernode writes its update to positions rel[.] of a slot row of its parent, the parent sums its slot rows
+    (dense); a condensed leaf goes through W = inv(A_JJ) and the sparse couplings of its blob (use_leaves=False: through its panel)."""
+    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "rel", "nchild", "s_off", "ps_off", "tgs", "lb_off", "lb_nnzr", "lb_nnzc")}
+    pool = S.export("leaf_pool")
     kind = S.info()["kind"]
     cplx = bool(getattr(S, "complex", False))
     dt = np.complex128 if cplx else np.float64
+    cs = 2 if cplx else 1
     F = S.export("F")
     G = S.export("G") if kind == 2 else F
     dinv = S.export("dinv") if kind == 1 else None
@@ -44,28 +63,54 @@ def _replay(S, b):
         F, G = F.view(np.complex128), G.view(np.complex128)
         dinv = dinv.view(np.complex128) if dinv is not None else None
     n, blk, rp = len(e["perm"]), e["blk_ptr"], e["row_ptr"]
-    U, y, x = np.zeros(max(1, int(rp[-1])), dtype=dt), np.zeros(n, dtype=dt), np.zeros(n, dtype=dt)
+    nblk = len(blk) - 1
+    hh = np.diff(blk) + np.diff(rp)
+    slots = np.zeros(max(1, int((e["nchild"] * hh).sum())), dtype=dt)
+    assert e["s_off"][-1] + e["nchild"][-1] * hh[-1] == (e["nchild"] * hh).sum()
+    y, x = np.zeros(n, dtype=dt), np.zeros(n, dtype=dt)
+    written = np.zeros(len(slots), dtype=bool)
     order = np.argsort(e["height"], kind="stable")
+    leaves = {}
     for k in order:
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
         h, ld = w + nb, e["ldw"][k]
         P = F[e["f_off"][k]:e["f_off"][k] + h * ld].reshape(h, ld)[:, :w]
         t = 1 << int(e["tgs"][k])   # LU that exchanged rows inside its tiles: block lower triangular, dense t x t diagonal tiles
         assert np.all(P[:w][(np.arange(w)[None, :] // t) > (np.arange(w)[:, None] // t)] == 0.0) if e["tgs"][k] else np.all(np.triu(P[:w], 1) == 0.0)
-        gp = e["gptr"][e["goff"][k]:e["goff"][k] + h + 1]
-        gath = np.array([U[e["gsrc"][gp[i]:gp[i + 1]]].sum() for i in range(h)], dtype=dt)
-        t = P @ (b[e["perm"][c0:c0 + w]] - gath[:w])
-        y[c0:c0 + w] = t[:w]
-        U[e["u_off"][k]:e["u_off"][k] + nb] = t[w:] + gath[w:]
+        nc = e["nchild"][k]
+        gath = slots[e["s_off"][k]:e["s_off"][k] + nc * h].reshape(nc, h).sum(axis=0) if nc else np.zeros(h, dtype=dt)
+        f = b[e["perm"][c0:c0 + w]] - gath[:w]
+        if use_leaves and e["lb_off"][k] >= 0:
+            assert nc == 0
+            L = leaves[k] = _leaf_blob(pool, e["lb_off"][k], w, ld * cs, nb, e["lb_nnzr"][k], e["lb_nnzc"][k], cs)
+            assert L["srptr"][nb] == e["lb_nnzr"][k] and L["scptr"][w] == e["lb_nnzc"][k]
+            z = L["W"] @ f
+            y[c0:c0 + w] = z
+            u = np.array([(L["srval"][L["srptr"][i]:L["srptr"][i + 1]] * z[L["srcol"][L["srptr"][i]:L["srptr"][i + 1]]]).sum() for i in range(nb)], dtype=dt)
+        else:
+            t = P @ f
+            y[c0:c0 + w] = t[:w]
+            u = t[w:] + gath[w:]
+        if nb:
+            where = e["ps_off"][k] + e["rel"][e["u_off"][k]:e["u_off"][k] + nb]
+            assert e["ps_off"][k] >= 0 and not written[where].any() and len(set(where)) == nb   # every slot entry has ONE writer
+            written[where] = True
+            slots[where] = u
     for k in order[::-1]:
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
         h, ld = w + nb, e["ldw"][k]
+        if k in leaves:
+            L = leaves[k]
+            tt = np.array([(L["scval"][L["scptr"][c]:L["scptr"][c + 1]] * x[L["scrow"][L["scptr"][c]:L["scptr"][c + 1]]]).sum() for c in range(w)], dtype=dt)
+            x[c0:c0 + w] = y[c0:c0 + w] - L["W"] @ tt
+            continue
         P = G[e["f_off"][k]:e["f_off"][k] + h * ld].reshape(h, ld)[:, :w]
         assert np.all(np.triu(P[:w], 1) == 0.0)
         v = np.concatenate([y[c0:c0 + w] * (dinv[c0:c0 + w] if dinv is not None else 1.0), -x[e["rows"][rp[k]:rp[k + 1]]]])
         x[c0:c0 + w] = P.T @ v
     out = np.zeros(n, dtype=dt)
     out[e["perm"]] = x
+    _replay.leaves = len(leaves)
     return out
 
 
@@ -99,6 +144,9 @@ def test_host_factorisation(kind):
     b = rng.random(n)
     x = _replay(S, b)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
+    assert _replay.leaves > 0   # the leaves of the nested dissection went through their blobs (W = inv(A_JJ), sparse couplings) ...
+    xp = _replay(S, b, use_leaves=False)   # ... and through their dense panels: the same solution
+    assert _replay.leaves == 0 and np.linalg.norm(x - xp) / np.linalg.norm(x) < 1e-12
     S.destroy()
 
 
