@@ -193,6 +193,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       }
       std::vector<double>().swap(host.F);
       std::vector<double>().swap(host.G);
+      std::vector<double>().swap(host.leaf_pool);
     }
   }
 }

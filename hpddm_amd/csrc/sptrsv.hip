@@ -1120,7 +1120,11 @@ __global__ void k_transpose_panels(const double *__restrict__ F, double *__restr
 
 // a condensed leaf that BOTH engines take through its blob (the 16-column engine: at most 32 columns, sptrsv16.hip) needs no
 // transposed copy of its panel
-static bool leaf_blob_only(const DeviceFactor &D, idx_t k) { return D.lb_off[k] >= 0 && D.blk_ptr[k + 1] - D.blk_ptr[k] <= LEAF16_MAXW; }
+static bool leaf_blob_only(const DeviceFactor &D, idx_t k)
+{
+  static const bool keep_ft = getenv("HPDDM_HIP_KEEP_FT") != nullptr; // developer switch: every narrow panel keeps its transposed copy (HPDDM_HIP_LEAF_TILES=0 at plan build needs them)
+  return !keep_ft && D.lb_off[k] >= 0 && D.blk_ptr[k + 1] - D.blk_ptr[k] <= LEAF16_MAXW;
+}
 
 void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 {
@@ -1240,6 +1244,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
+  const bool use_leaves  = envi("HPDDM_HIP_LEAF_TILES", 1) != 0; // developer switch: 0 sweeps the condensed leaves through their panels all the same
   lev_bytes.assign(nlev, 0.0);
   auto fwd_tile_rows = [](int wc) { return wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); }; // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
   // ... and shorter on a level whose wide panels would field fewer than ~4 workgroups per CU that way (the top of a small tree: a
@@ -1285,8 +1290,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       const int h = d.w + d.nb, lev = D.height[k];
       lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
-        const bool leafv = d.leaf != nullptr, leaf6 = leafv && d.w <= LEAF16_MAXW; // condensed leaf in the VALU sweeps / in the 16-column engine
-        HH_CHECK(d.FT != nullptr || (leafv && leaf6), "narrow panel without its transposed copy");
+        const bool leafv = d.leaf != nullptr && use_leaves, leaf6 = leafv && d.w <= LEAF16_MAXW; // condensed leaf in the VALU sweeps / in the 16-column engine
+        HH_CHECK(d.FT != nullptr || (leafv && leaf6), "narrow panel without its transposed copy (HPDDM_HIP_LEAF_TILES=0 needs HPDDM_HIP_KEEP_FT=1 from the factorisation on)");
         // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
         const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
         // backward: whole supernode per wavefront while it is small, else one workgroup
