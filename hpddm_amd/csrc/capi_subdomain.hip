@@ -201,6 +201,11 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
     if (k == "nchild") return ints(h.nchild);
     if (k == "s_off") return ints(h.s_off);
     if (k == "ps_off") return ints(h.ps_off);
+    if (k == "c_off") return ints(h.c_off);
+    if (k == "cptr") return ints(h.cptr);
+    if (k == "crel") return ints(h.crel);
+    if (k == "cs_off") return ints(h.cs_off);
+    if (k == "pcs_off") return ints(h.pcs_off);
     if (k == "lb_off") return ints(h.lb_off);
     if (k == "lb_nnzr") return ints(h.lb_nnzr);
     if (k == "lb_nnzc") return ints(h.lb_nnzc);

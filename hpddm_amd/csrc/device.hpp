@@ -79,6 +79,22 @@ struct SnDesc {
                        // inverse of the row-permuted unit factor is block lower triangular with dense diagonal tiles)
   const double *leaf;  // condensed leaf (factor.hpp): its blob -- W^T, A_RJ by row, A_JR by column --, or nullptr
   int           nnzr, nnzc; // ... and the entries of A_RJ / A_JR (section offsets of the blob: leaf_blob_layout)
+  // the compact form of the hand-over (16-column engine; factor.hpp): position i of the front owns the entries cptr[i] .. cptr[i + 1]
+  // of this supernode's block (c_in + ...) of the subdomain's compact pool (coff + ..., in the plan's); row i writes entry
+  // c_out + crel[i] (inside its parent's block)
+  const int    *cptr, *crel;
+  long long     coff;
+  union {
+    struct {
+      int c_in, c_out;
+    };
+    // ... or, in the copies of the descriptor that ARE the wave-level tiles of the VALU sweeps (SolvePlan::wtd: one record per tile, tile
+    // and supernode in one fetch -- a tile of the bottom levels is a chain of dependent round trips, this takes one out), the tile:
+    // forward, first output row and rows of the tile
+    struct {
+      int t_r0, t_nr;
+    };
+  };
 };
 
 struct Tile {
@@ -102,13 +118,13 @@ struct DeviceFactor {
   DevBuf<double> FT;                 // transposed copies of the narrow forward panels (reduction-free forward sweep)
   std::vector<int64_t> ft_off;       // per supernode, -1 when it has none
   std::vector<idx_t>   ldh;
-  DevBuf<int>    rows, rel, perm, iperm; // perm[new] = old, iperm[old] = new; rel: HostFactor::rel
+  DevBuf<int>    rows, rel, cptr, crel, perm, iperm; // perm[new] = old, iperm[old] = new; rel, cptr, crel: HostFactor's
   DevBuf<double> leaf_pool;              // blobs of the condensed leaves (HostFactor::leaf_pool)
   // host copies of what the plan builder needs
   std::vector<idx_t>   blk_ptr, ldw, height, level_ptr, level_blk, nchild, lb_nnzr, lb_nnzc;
   std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
-  std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off;
-  int64_t              s_size = 0;
+  std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off, c_off, cs_off, pcs_off;
+  int64_t              s_size = 0, u_size = 0;
   void upload(const HostFactor &hf, hipStream_t s);
 };
 
@@ -116,16 +132,17 @@ struct DeviceFactor {
 struct SolvePlan {
   std::vector<const DeviceFactor *> factors;
   std::vector<long long>            voff; // per factor: element offset in the batched vectors
-  long long                         ntot = 0, utot = 0; // utot: entries of the slot pools of all the factors
+  long long                         ntot = 0, utot = 0, ctot = 0; // utot: entries of the slot pools of all the factors; ctot: of their compact hand-over pools (16-column engine)
   int                               nlev = 0;
   DevBuf<SnDesc> sn;
   // per level, six tile lists: forward / backward x wave-level (narrow panels, one wavefront per tile, no LDS) /
   // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS) / condensed leaves (one wavefront each)
   enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3, FWD_LEAF = 4, BWD_LEAF = 5, NKIND = 6 };
-  DevBuf<Tile>     tiles;
+  DevBuf<Tile>     tiles;   // block-level kinds, the lists of the 16-column engine, the combine pass: tiles that name their supernode (sn[t.sn])
+  DevBuf<SnDesc>   wtd;     // wave-level kinds and condensed leaves of the VALU sweeps: one descriptor per tile (SnDesc::t_r0 / t_nr); lev_ptr / lev_end of these kinds index it
   std::vector<int> lev_ptr[NKIND], lev_end[NKIND]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[NKIND];   // dynamic LDS doubles per launch (block-level kinds) / per wavefront (wave-level kinds)
-  std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2], lev_leaf16[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the last lev_leaf16[.][l] condensed leaves, the others chunks of 32 outputs (one wavefront each)
+  std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the others chunks of 32 outputs (one wavefront each)
   // 16-column engine, wide supernodes with children: their right-hand side b_J - (what the children handed up) is formed once per
   // supernode by a small dense pass before the level's sweep (tiles of 256 columns); its wide tiles read it straight from the vector
   std::vector<int> gat_ptr, gat_end;

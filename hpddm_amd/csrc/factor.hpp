@@ -52,6 +52,15 @@ struct HostFactor {
   std::vector<int64_t> s_off;      // nblk: first slot row of k in the slot pool
   std::vector<int64_t> ps_off;     // nblk: the slot row supernode k writes to (inside its parent's), -1 for a root
   int64_t              s_size = 0; // entries of the slot pool (sum nchild * h)
+  // the same hand-over, COMPACT (the 16-column engine, sptrsv16.hip: an entry of its vectors is a 128-byte line, and reading the
+  // zeros of the dense slot rows would cost more than the panels of the narrow levels): position i of the front of k owns the
+  // entries cptr[c_off[k] + i] .. cptr[c_off[k] + i + 1] of k's compact block (cs_off[k] + ..., in the order of the children's
+  // numbers), exactly one per child that reaches it -- sum over the children of nb entries in all, every one written before it is
+  // read; row i of a supernode writes entry crel[u_off[k] + i] of its parent's block (pcs_off[k] + ...)
+  std::vector<int64_t> c_off;      // nblk: offset of the h + 1 pointers of k in cptr
+  std::vector<idx_t>   cptr;       // sum (h + 1)
+  std::vector<idx_t>   crel;       // sum nb
+  std::vector<int64_t> cs_off, pcs_off; // nblk: first entry of the compact block of k / of its parent (-1 for a root) in the compact pool (size u_size)
   // condensed leaves (numeric phase): a supernode without children is eliminated exactly by W = inv(A_JJ) and the ORIGINAL sparse
   // couplings -- forward z = W f_J, u = A_RJ z; backward x_J = z - W (A_JR x_R) -- a few KB less per leaf than the dense panel
   // [inv(L_JJ); L_RJ inv(L_JJ)].  Per leaf one blob in leaf_pool (8-byte units, 64-byte aligned; layout: leaf_blob_layout below),

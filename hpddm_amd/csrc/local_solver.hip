@@ -79,6 +79,11 @@ bool LocalSolver::adopt_analysis(const LocalSolver &o, const CsrView &A)
   host.s_off     = o.host.s_off;
   host.ps_off    = o.host.ps_off;
   host.s_size    = o.host.s_size;
+  host.c_off     = o.host.c_off;
+  host.cptr      = o.host.cptr;
+  host.crel      = o.host.crel;
+  host.cs_off    = o.host.cs_off;
+  host.pcs_off   = o.host.pcs_off;
   host.t_order = host.t_symbolic = 0.0;
   pattern_hash = h;
   analysed     = true;

@@ -242,6 +242,32 @@ void factor_analyse(const CsrView &A, int leaf_size, HostFactor &hf)
       for (idx_t i = 0; i < nb; ++i) where[s.rows[s.row_ptr[p] + i]] = -1;
     }
     for (idx_t k = 0; k < nblk; ++k) HH_CHECK(hf.ps_off[k] >= 0 || s.row_ptr[k + 1] == s.row_ptr[k], "symbolic: a supernode with rows below it has no parent");
+    // the compact form of the same hand-over (factor.hpp): per position of a front the run of entries its children write
+    hf.c_off.assign(nblk, 0);
+    hf.cs_off.assign(nblk, 0);
+    hf.pcs_off.assign(nblk, -1);
+    hf.crel.assign((size_t)uoff, 0);
+    int64_t coff = 0, csoff = 0;
+    for (idx_t k = 0; k < nblk; ++k) {
+      hf.c_off[k]  = coff;
+      hf.cs_off[k] = csoff;
+      coff += (s.blk_ptr[k + 1] - s.blk_ptr[k]) + (s.row_ptr[k + 1] - s.row_ptr[k]) + 1;
+      for (idx_t ch : children[k]) csoff += s.row_ptr[ch + 1] - s.row_ptr[ch];
+    }
+    HH_CHECK(csoff == uoff, "symbolic: compact hand-over pool does not match the rows below the supernodes");
+    hf.cptr.assign((size_t)coff, 0);
+    for (idx_t p = 0; p < nblk; ++p) {
+      const idx_t h  = (s.blk_ptr[p + 1] - s.blk_ptr[p]) + (idx_t)(s.row_ptr[p + 1] - s.row_ptr[p]);
+      idx_t      *cp = hf.cptr.data() + hf.c_off[p];
+      for (idx_t ch : children[p])
+        for (int64_t q = 0; q < s.row_ptr[ch + 1] - s.row_ptr[ch]; ++q) ++cp[hf.rel[(size_t)(hf.u_off[ch] + q)] + 1];
+      for (idx_t i = 0; i < h; ++i) cp[i + 1] += cp[i];
+      std::vector<idx_t> fill(cp, cp + h);
+      for (idx_t ch : children[p]) { // ascending child numbers: the order of the entries of a position
+        hf.pcs_off[ch] = hf.cs_off[p];
+        for (int64_t q = 0; q < s.row_ptr[ch + 1] - s.row_ptr[ch]; ++q) hf.crel[(size_t)(hf.u_off[ch] + q)] = fill[hf.rel[(size_t)(hf.u_off[ch] + q)]]++;
+      }
+    }
   }
   hf.t_symbolic = now() - t0;
 }

@@ -194,9 +194,12 @@ __device__ static inline void stage_rhs(double *lds, int wr, int c, const double
 }
 
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
+__device__ static inline void fwd_wave_tile_t(const SnView &d, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
 {
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
+  struct {
+    int r0, nr;
+  } const t = {d.c_in, d.c_out}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -253,15 +256,19 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, const Tile &t, in
   }
 }
 
-// One right-hand side, launches made of wave tiles only (the bottom levels): a tile there is a chain of dependent round trips with
+// One or two real right-hand sides (two: one complex one), launches made of wave tiles only (the bottom levels): a tile there is a chain of dependent round trips with
 // a few KB of panel behind it, and a level is bound by (length of that chain) / (tiles in flight).  With the slot rows nothing is
-// left that depends on anything but the descriptor: the right-hand side entries, the slot entries of this lane's column and of its
-// two output rows, their positions in the parent's front and the first TWO groups of panel rows are all requested together -- two
-// round trips (descriptor / this batch) ahead of the product; the stores drain behind the next tile of the wavefront.
+// left that depends on anything but the descriptor: the right-hand side entry of this lane's column, the slot entries of that
+// column and of the lane's two output rows (up to NC children side by side), the rows' positions in the parent's front and the
+// first TWO groups of panel rows are all requested before the first of them is used, in the order they are needed (loads return
+// in order) -- two round trips (descriptor / this batch) ahead of the product; the stores drain behind the next tile of the wavefront.
 template <int MU, int FWD_PASSES, bool Z>
-__device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
+__device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
 {
-  const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
+  const int w = d.w, wc = d.wc, ldh = d.ldh, h = d.w + d.nb; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
+  struct {
+    int r0, nr;
+  } const t = {d.c_in, d.c_out}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -269,19 +276,31 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
   const int   rtop = tri_last(t.r0 + 2 * gl + 1, d.tgs);
   const int   r_out = t.r0 + 2 * gl, rend = t.r0 + t.nr;
   const bool  mine = lane < w; // lane c stages column c (supernodes wider than 64 take the loop below)
-  double      fv[MU];
+  const bool  below[2] = {sub == 0 && r_out >= w && r_out < rend, sub == 0 && r_out + 1 >= w && r_out + 1 < rend};
+  constexpr int NC = MU == 1 ? 4 : 2; // children taken side by side (more: the loops behind the batch)
+  double        fv[MU], uc[NC][MU], ur[2][NC][MU];
+  int           rpos[2];
+  // (loads without branches: an entry that is not there is read at a harmless place of the same array -- the pools carry a few
+  // entries of padding -- and dropped by a select; a load inside a branch drags its first use, and the wait for it, in with it)
+  const int cl = mine ? lane : 0;
 #pragma unroll
-  for (int nu = 0; nu < MU; ++nu) fv[nu] = mine ? bb[(long long)nu * d.n + d.c0 + lane] : 0.0;
-  if (mine) slot_sub<MU>(d, lane, Sb, stot, fv);
-  int    rpos[2];
-  double radd[2][MU];
+  for (int nu = 0; nu < MU; ++nu) fv[nu] = bb[(long long)nu * d.n + d.c0 + cl];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const double *sj = Sb + d.s_in + (j < d.nchild ? j : 0) * h;
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) uc[j][nu] = sj[(long long)nu * stot + cl];
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const bool below = sub == 0 && r_out + k >= w && r_out + k < rend;
-    rpos[k]          = below ? d.rel[r_out + k - w] : 0;
+    const int rl = below[k] ? r_out + k : 0;
+    rpos[k]      = d.rel[below[k] ? r_out + k - w : 0];
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) radd[k][nu] = 0.0;
-    if (below) slot_add<MU>(d, r_out + k, Sb, stot, radd[k]); // fixed order: s + ((0 + u0) + u1 ...)
+    for (int j = 0; j < NC; ++j) {
+      const double *sj = Sb + d.s_in + (j < d.nchild ? j : 0) * h;
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) ur[k][j][nu] = sj[(long long)nu * stot + rl];
+    }
   }
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
 #pragma unroll
@@ -289,6 +308,31 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, const Tile &t
     const int i = sub + p * R, i2 = i + FWD_PASSES * R;
     cur[p]      = (active && i < wc && (Z ? i >> 1 : i) <= rtop) ? *(gcd2_t)(Fp + (long long)i * ldh) : dbl2{0.0, 0.0};
     nxt[p]      = (active && i2 < wc && (Z ? i2 >> 1 : i2) <= rtop) ? *(gcd2_t)(Fp + (long long)i2 * ldh) : dbl2{0.0, 0.0};
+  }
+  // everything is on its way: now the sums, in the order of the children's numbers (a child that is not there contributes 0.0)
+  double radd[2][MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) {
+    fv[nu]      = mine ? fv[nu] : 0.0;
+    radd[0][nu] = radd[1][nu] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const bool ok = j < d.nchild;
+      fv[nu] -= (ok && mine) ? uc[j][nu] : 0.0;
+      radd[0][nu] += (ok && below[0]) ? ur[0][j][nu] : 0.0;
+      radd[1][nu] += (ok && below[1]) ? ur[1][j][nu] : 0.0;
+    }
+  }
+  if (d.nchild > NC) { // (wave-uniform; rare: a supernode the ordering merged out of many)
+    for (int c = NC; c < d.nchild; ++c) {
+      const double *sc = Sb + d.s_in + c * h;
+#pragma unroll
+      for (int nu = 0; nu < MU; ++nu) {
+        if (mine) fv[nu] -= sc[(long long)nu * stot + lane];
+        if (below[0]) radd[0][nu] += sc[(long long)nu * stot + r_out];
+        if (below[1]) radd[1][nu] += sc[(long long)nu * stot + r_out + 1];
+      }
+    }
   }
   if (mine) stage_rhs<MU, Z>(lds, wr, lane, fv);
   for (int c = lane + 64; c < w; c += 64) { // columns 64 .. 127 of the widest narrow supernodes
@@ -498,13 +542,24 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
 {
   const LeafView L = leaf_view(d);
   const int      w = d.w, ld = d.ldw, nb = d.nb;
-  dbl2           cur[FP];
+  // everything that depends on the descriptor only is requested together, in the order it is needed (loads return in order): f = b_J
+  // (a leaf has no children), the first rows of W^T, and for the sparse part the two row pointers of this lane's first row (one
+  // 32-bit load of the 16-bit pair, taken apart only after the product: a use right behind the load would wait for it there) and
+  // the row's place in the parent's front (no branches around the loads; the lists carry padding)
+  const int i0 = lane < nb ? lane : 0, cl = lane < w ? lane : 0;
+  double    f0[MU];
+#pragma unroll
+  for (int nu = 0; nu < MU; ++nu) f0[nu] = bb[(long long)nu * d.n + d.c0 + cl];
+  dbl2 cur[FP];
   ptv_prime<FP>(L.WT, ld, w, lane, cur);
-  // the sparse part's lists of this lane's first row: they depend on the descriptor only
-  const int i0 = lane < nb ? lane : 0;
-  int       p0 = 0, p1 = 0, pos0 = 0;
-  if (lane < nb) p0 = L.srptr[i0], p1 = L.srptr[i0 + 1], pos0 = d.rel[i0];
-  for (int c = lane; c < w; c += 64) { // f = b_J (a leaf has no children), planes side by side
+  typedef const unsigned __attribute__((address_space(1))) *gcu32_t;
+  unsigned praw = *(gcu32_t)(L.srptr + i0);
+  int      pos0 = d.rel[i0];
+  if (lane < w) {
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + lane] = f0[nu];
+  }
+  for (int c = lane + 64; c < w; c += 64) { // (leaves of more than 64 columns)
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = bb[(long long)nu * d.n + d.c0 + c];
   }
@@ -512,6 +567,8 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
   double acc0[MU], acc1[MU];
   ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
   const int g = ld >> 1, sub = lane / g, gl = lane - sub * g;
+  asm volatile("" : "+v"(praw), "+v"(pos0)); // (the pair of pointers is used from here on)
+  int p0 = (int)(praw & 0xffffu), p1 = (int)(praw >> 16);
   wave_lds_order(); // the reads of f are done: z takes its place
   if (sub == 0) {
     if constexpr (!Z) {
@@ -537,7 +594,7 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
   // u = A_RJ z, one lane per row of rows(J), straight into the slot row of the parent
   constexpr int UN = 4;
   for (int i = lane; i < nb; i += 64) {
-    if (i != lane) p0 = L.srptr[i], p1 = L.srptr[i + 1], pos0 = d.rel[i];
+    if (i != lane) p0 = L.srptr[i], p1 = L.srptr[i + 1], pos0 = d.rel[i]; // (more than 64 rows below the leaf)
     double u[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) u[nu] = 0.0;
@@ -579,8 +636,18 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
 {
   const LeafView L = leaf_view(d);
   const int      w = d.w, ld = d.ldw;
+  const int      g = ld >> 1, sub = lane / g, gl = lane - sub * g;
   dbl2           cur[FP];
   ptv_prime<FP>(L.WT, ld, w, lane, cur);
+  // z = what the forward sweep left in y_J, for this lane's outputs: requested now, used at the very end (one or two right-hand sides;
+  // more would cost the registers of the product)
+  constexpr bool YPRE = MU <= 2;
+  double         zy0[YPRE ? MU : 1], zy1[YPRE ? MU : 1];
+  if constexpr (YPRE) {
+    const int cz = Z ? min(gl, w - 1) : min(2 * gl, w - 1), cz1 = Z ? cz : min(2 * gl + 1, w - 1);
+#pragma unroll
+    for (int nu = 0; nu < MU; ++nu) zy0[nu] = yb[(long long)nu * d.n + d.c0 + cz], zy1[nu] = yb[(long long)nu * d.n + d.c0 + cz1];
+  }
   // t = A_JR x_R, one lane per column of J: list of the column, then the entries of x it points to (UN of them in flight)
   constexpr int UN = MU >= 4 ? 2 : 4;
   for (int c = lane; c < w; c += 64) {
@@ -627,24 +694,23 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
   wave_lds_order();
   double acc0[MU], acc1[MU];
   ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
-  const int g = ld >> 1, sub = lane / g, gl = lane - sub * g;
-  if (sub == 0) { // x_J = z - W t, z = what the forward sweep left in y_J
+  if (sub == 0) { // x_J = z - W t
     if constexpr (!Z) {
       const int c = 2 * gl;
       if (c < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = yb[(long long)nu * d.n + d.c0 + c] - acc0[nu];
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = (YPRE ? zy0[YPRE ? nu : 0] : yb[(long long)nu * d.n + d.c0 + c]) - acc0[nu];
       }
       if (c + 1 < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = yb[(long long)nu * d.n + d.c0 + c + 1] - acc1[nu];
+        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = (YPRE ? zy1[YPRE ? nu : 0] : yb[(long long)nu * d.n + d.c0 + c + 1]) - acc1[nu];
       }
     } else if (gl < w) {
 #pragma unroll
       for (int k = 0; k < MU / 2; ++k) {
         const double sr = acc0[2 * k] - acc1[2 * k + 1], si = acc0[2 * k + 1] + acc1[2 * k];
-        xb[(long long)(2 * k) * d.n + d.c0 + gl]     = yb[(long long)(2 * k) * d.n + d.c0 + gl] - sr;
-        xb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = yb[(long long)(2 * k + 1) * d.n + d.c0 + gl] - si;
+        xb[(long long)(2 * k) * d.n + d.c0 + gl]     = (YPRE ? zy0[YPRE ? 2 * k : 0] : yb[(long long)(2 * k) * d.n + d.c0 + gl]) - sr;
+        xb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = (YPRE ? zy0[YPRE ? 2 * k + 1 : 0] : yb[(long long)(2 * k + 1) * d.n + d.c0 + gl]) - si;
       }
     }
   }
@@ -1030,7 +1096,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
 // by (latency of a tile) / (tiles in flight): one or two real right-hand sides are held to 64 VGPRs = 8 wavefronts per SIMD.
 // S: the slot pool (factor.hpp), one copy per right-hand side column, stot entries apart.
 template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF>
-__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (LEAF ? 7 : 8) : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const Tile *__restrict__ ltiles, int nleaf, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ S, long long stot, int mu_total, int nu0, int lds_dbl, int wr)
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (LEAF ? 7 : 8) : 1) void sptrsv_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const SnDesc *__restrict__ wtiles, int nwave, const SnDesc *__restrict__ ltiles, int nleaf, const double *__restrict__ b, double *__restrict__ y, double *__restrict__ S, long long stot, int mu_total, int nu0, int lds_dbl, int wr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -1054,21 +1120,20 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (LEAF ? 7 : 8
   const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup
   for (int tix = gw * wpb + wv; tix < nwave + (LEAF ? nleaf : 0); tix += G * wpb) {
     const bool    leaf = LEAF && tix >= nwave;
-    const Tile    t  = leaf ? ltiles[tix - nwave] : wtiles[tix];
-    const SnView  d  = view(sns[t.sn]);
+    const SnView  d  = view(leaf ? ltiles[tix - nwave] : wtiles[tix]); // tile and supernode in one record (SolvePlan::wtd)
     const double *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Sb = S + d.soff + (long long)nu0 * stot;
     if (leaf) {
-      if constexpr (LEAF) fwd_leaf_tile<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot);
-    } else if constexpr (MU == 1 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Sb, stot); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
-    else fwd_wave_tile_t<MU, FP, Z>(d, t, lane, wl, wr, bb, yb, Sb, stot);
+      if constexpr (LEAF) fwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z>(d, lane, wl, wr, bb, yb, Sb, stot);
+    } else if constexpr (MU <= 2 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
+    else fwd_wave_tile_t<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot);
     wave_lds_order(); // the last reads of the staged right-hand side land before the next tile overwrites it; the stores of this tile drain while the next one starts (tiles of a level are independent)
   }
 }
 
 template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF>
-__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nwave, const Tile *__restrict__ ltiles, int nleaf, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr)
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const SnDesc *__restrict__ wtiles, int nwave, const SnDesc *__restrict__ ltiles, int nleaf, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -1089,13 +1154,12 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
   const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup
   for (int tix = gw * wpb + wv; tix < nwave + (LEAF ? nleaf : 0); tix += G * wpb) {
     const bool    leaf = LEAF && tix >= nwave;
-    const Tile    t  = leaf ? ltiles[tix - nwave] : wtiles[tix];
-    const SnView  d  = view(sns[t.sn]);
+    const SnView  d  = view(leaf ? ltiles[tix - nwave] : wtiles[tix]); // tile and supernode in one record (SolvePlan::wtd)
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
     if (leaf) {
-      if constexpr (LEAF) bwd_leaf_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb);
+      if constexpr (LEAF) bwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z>(d, lane, wl, wr, yb, xb);
     } else bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo);
     wave_lds_order();
   }
@@ -1118,14 +1182,6 @@ __global__ void k_transpose_panels(const double *__restrict__ F, double *__restr
   }
 }
 
-// a condensed leaf that BOTH engines take through its blob (the 16-column engine: at most 32 columns, sptrsv16.hip) needs no
-// transposed copy of its panel
-static bool leaf_blob_only(const DeviceFactor &D, idx_t k)
-{
-  static const bool keep_ft = getenv("HPDDM_HIP_KEEP_FT") != nullptr; // developer switch: every narrow panel keeps its transposed copy (HPDDM_HIP_LEAF_TILES=0 at plan build needs them)
-  return !keep_ft && D.lb_off[k] >= 0 && D.blk_ptr[k + 1] - D.blk_ptr[k] <= LEAF16_MAXW;
-}
-
 void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
 {
   HH_CHECK(hf.info == 0, "numfact failed (zero or negative pivot in block " + std::to_string(hf.info) + ")");
@@ -1137,6 +1193,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   nlev       = (idx_t)hf.level_ptr.size() - 1;
   f_size     = hf.f_size;
   s_size     = hf.s_size;
+  u_size     = hf.u_size;
   nnz_exact  = hf.sym.nnz_exact;
   nnz_stored = hf.sym.nnz_stored;
   F.alloc((size_t)hf.f_size * sc);
@@ -1154,7 +1211,11 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   std::vector<int> tmp(hf.sym.rows.begin(), hf.sym.rows.end());
   rows.upload(tmp, s);
   std::vector<int> tmp2(hf.rel.begin(), hf.rel.end());
+  tmp2.resize(tmp2.size() + 16, 0); // (padding: see SolvePlan::reserve)
   rel.upload(tmp2, s);
+  std::vector<int> tmp5(hf.cptr.begin(), hf.cptr.end()), tmp6(hf.crel.begin(), hf.crel.end());
+  cptr.upload(tmp5, s);
+  crel.upload(tmp6, s);
   std::vector<int> tmp3(hf.ord.perm.begin(), hf.ord.perm.end());
   perm.upload(tmp3, s);
   std::vector<int> tmp4(hf.ord.iperm.begin(), hf.ord.iperm.end());
@@ -1173,6 +1234,9 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   nchild    = hf.nchild;
   s_off     = hf.s_off;
   ps_off    = hf.ps_off;
+  c_off     = hf.c_off;
+  cs_off    = hf.cs_off;
+  pcs_off   = hf.pcs_off;
   lb_off    = hf.lb_off;
   lb_nnzr   = hf.lb_nnzr;
   lb_nnzc   = hf.lb_nnzc;
@@ -1185,7 +1249,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   {
     int64_t tot = 0;
     for (idx_t k = 0; k < nblk; ++k) {
-        if (ldw[k] * sc > NARROW || leaf_blob_only(*this, k)) continue;
+        if (ldw[k] * sc > NARROW) continue; // (the condensed leaves keep theirs: the 16-column engine sweeps them through their panels)
         const int64_t w = (int64_t)(blk_ptr[k + 1] - blk_ptr[k]) * sc, hgt = (blk_ptr[k + 1] - blk_ptr[k]) + (row_ptr[k + 1] - row_ptr[k]); // doubles per panel row, rows
         ldh[k]    = (idx_t)((hgt + 1) / 2 * 2);
         ft_off[k] = tot;
@@ -1218,15 +1282,17 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   b16.release(), y16.release(), x16.release(), U16.release(), partials16.release();
   factors = fs;
   voff.assign(fs.size(), 0);
-  ntot = utot = 0;
+  ntot = utot = ctot = 0;
   nlev                = 0;
   bytes_alg_per_rhs1  = 0;
-  std::vector<long long> soffs(fs.size(), 0);
+  std::vector<long long> soffs(fs.size(), 0), coffs(fs.size(), 0);
   for (size_t f = 0; f < fs.size(); ++f) {
     voff[f]  = ntot;
     soffs[f] = utot;
+    coffs[f] = ctot;
     ntot += fs[f]->n;
     utot += fs[f]->s_size;
+    ctot += fs[f]->u_size;
     nlev = std::max<int>(nlev, fs[f]->nlev);
     bytes_alg_per_rhs1 += (2.0 * (double)fs[f]->nnz_exact * 8.0 + 4.0 * (double)fs[f]->n * 8.0) * (fs[f]->cplx ? 2.0 : 1.0); // sizeof(K) = 16 for complex scalars
     HH_CHECK(fs[f]->cplx == fs[0]->cplx, "real and complex factors cannot share a plan");
@@ -1235,7 +1301,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   std::vector<SnDesc>           descs;
   std::vector<std::vector<Tile>> tl[NKIND];
   for (auto &v : tl) v.assign(nlev, {});
-  std::vector<std::vector<Tile>> gat(nlev), w16[2], leaf16(nlev); // the 16-column engine's own lists: panel tiles of the narrow supernodes, its condensed leaves, the wide supernodes whose right-hand side is combined ahead of the level
+  std::vector<std::vector<Tile>> gat(nlev), w16[2]; // the 16-column engine's own lists: panel tiles of the narrow supernodes (the condensed leaves among them), the wide supernodes whose right-hand side is combined ahead of the level
   w16[0].assign(nlev, {}), w16[1].assign(nlev, {});
   // developer knobs of the plan (defaults = what measured best on the bench workloads)
   auto envi             = [](const char *k, int dflt) { const char *v = getenv(k); return v ? atoi(v) : dflt; };
@@ -1279,6 +1345,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.s_in   = (int)D.s_off[k];
       d.nchild = D.nchild[k];
       d.s_out  = (int)D.ps_off[k];
+      d.cptr   = D.cptr.p + D.c_off[k];
+      d.crel   = D.crel.p + D.u_off[k];
+      d.coff   = coffs[f];
+      d.c_in   = (int)D.cs_off[k];
+      d.c_out  = (int)D.pcs_off[k];
       d.tgs     = D.tgs.empty() ? 0 : D.tgs[k];
       d.FT      = D.ft_off[k] >= 0 ? D.FT.p + D.ft_off[k] : nullptr;
       d.ldh     = D.ldh[k];
@@ -1290,8 +1361,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       const int h = d.w + d.nb, lev = D.height[k];
       lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
-        const bool leafv = d.leaf != nullptr && use_leaves, leaf6 = leafv && d.w <= LEAF16_MAXW; // condensed leaf in the VALU sweeps / in the 16-column engine
-        HH_CHECK(d.FT != nullptr || (leafv && leaf6), "narrow panel without its transposed copy (HPDDM_HIP_LEAF_TILES=0 needs HPDDM_HIP_KEEP_FT=1 from the factorisation on)");
+        const bool leafv = d.leaf != nullptr && use_leaves; // condensed leaf: the VALU sweeps take it through its blob (the 16-column engine through its panel:
+                                                            // there a vector entry is a 128-byte line, the sparse couplings cost more lines than the rows of the panel)
+        HH_CHECK(d.FT != nullptr, "narrow panel without its transposed copy");
         // forward, through the transposed copy: tiles of <= 128 output rows (even, balanced), all w columns each
         const int nt = (h + 127) / 128, per = ((h + nt - 1) / nt + 1) / 2 * 2;
         // backward: whole supernode per wavefront while it is small, else one workgroup
@@ -1304,12 +1376,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
           for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
           tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(tb);
         }
-        if (leaf6) leaf16[lev].push_back(tb);
-        else {
-          for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
-          if (small) w16[1][lev].push_back(tb); // (the supernodes the VALU sweeps give a workgroup stay block tiles of the engine as well: tl[BWD_BLOCK] when !leafv ...
-          else if (leafv) w16[1][lev].push_back(tb); // ... a condensed leaf too tall for a wavefront: a team tile of the engine)
-        }
+        for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
+        if (small || leafv) w16[1][lev].push_back(tb); // (the other supernodes are block tiles of both engines: tl[BWD_BLOCK]; a condensed leaf too tall for a wavefront becomes a team tile of the engine)
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         int trb = fwd_tile_rows(d.wc);
@@ -1359,7 +1427,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     }
     v.swap(out);
   }
-  std::vector<Tile> all;
+  std::vector<Tile>   all;
+  std::vector<SnDesc> wall;
   for (int kd = 0; kd < NKIND; ++kd) {
     lev_ptr[kd].assign(nlev + 1, 0);
     lev_lds[kd].assign(nlev, 0);
@@ -1371,8 +1440,17 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : ((kd == FWD_LEAF || kd == BWD_LEAF) ? (long long)descs[t.sn].w * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr); };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
-      lev_ptr[kd][l] = (int)all.size();
-      all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
+      if (kd == FWD_BLOCK || kd == BWD_BLOCK) {
+        lev_ptr[kd][l] = (int)all.size();
+        all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
+      } else { // wave-level tiles: one copy of the descriptor per tile, the tile inside (SnDesc::t_r0, t_nr)
+        lev_ptr[kd][l] = (int)wall.size();
+        for (const Tile &t : tl[kd][l]) {
+          SnDesc c = descs[t.sn];
+          c.t_r0 = t.r0, c.t_nr = t.nr;
+          wall.push_back(c);
+        }
+      }
       // LDS need of the launch: block-level kinds stage the panel's right-hand side / their rows, wave-level kinds the
       // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront; a condensed leaf
       // its w entries of f / z / t
@@ -1385,10 +1463,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   // fragments: few registers, many wavefronts in flight -- these levels are bound by latency): per level first the TEAM tiles, a
   // whole workgroup each (backward supernodes that give at least three wavefronts 32 columns each or need more than two staging
   // passes of v: the workgroup stages the rows of v once), then the tiles cut in chunks
-  // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each, then the engine's condensed leaves
-  // (at most LEAF16_MAXW columns), one wavefront each.
+  // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each.
   for (int dir = 0; dir < 2; ++dir) {
-    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0), lev_leaf16[dir].assign(nlev, 0);
+    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0);
     for (int l = 0; l < nlev; ++l) {
       const std::vector<Tile> &src = w16[dir][l];
       std::vector<Tile>        team, chunk;
@@ -1411,8 +1488,6 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       lev_team[dir][l]  = (int)team.size();
       all.insert(all.end(), team.begin(), team.end());
       all.insert(all.end(), chunk.begin(), chunk.end());
-      lev_leaf16[dir][l] = (int)leaf16[l].size();
-      all.insert(all.end(), leaf16[l].begin(), leaf16[l].end());
       lev_end16[dir][l] = (int)all.size();
     }
   }
@@ -1449,6 +1524,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   }
   sn.upload(descs, s);
   tiles.upload(all, s);
+  wtd.upload(wall, s);
   {
     std::vector<int> zeros(std::max(1, ngroups), 0);
     arrivals.upload(zeros, s);
@@ -1476,8 +1552,8 @@ void SolvePlan::reserve(int mu, hipStream_t s)
   bperm.alloc((size_t)ntot * mu);
   // the slot pool (factor.hpp): one copy per right-hand side column, utot entries apart whatever mu is -- the entries no child
   // writes must stay zero from here on, so the place of an entry may not depend on the number of right-hand sides of a solve
-  U.alloc((size_t)std::max<long long>(utot, 1) * mu);
-  HIP_OK(hipMemsetAsync(U.p, 0, sizeof(double) * (size_t)std::max<long long>(utot, 1) * mu, s));
+  U.alloc((size_t)std::max<long long>(utot, 1) * mu + 64); // (+ padding: the branch-free loads of the bottom-level tiles read one entry past an empty block)
+  HIP_OK(hipMemsetAsync(U.p, 0, sizeof(double) * ((size_t)std::max<long long>(utot, 1) * mu + 64), s));
   HIP_OK(hipStreamSynchronize(s));
   partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 16));
   mu_cap = mu;
@@ -1491,7 +1567,7 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   // per wavefront, of its widest wave-level tile -- so that the small levels keep many workgroups per CU even with 8
   // right-hand sides.  Forward, wide panels: 4 rows in flight per wavefront, 2 with 8 right-hand sides (accumulators
   // within 128 VGPRs); backward: 4.
-  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU == 1 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
+  constexpr int FPF = MU >= 8 ? 2 : 4, FPB = 4, FPN = MU <= 2 ? 2 : 4; // FPN: forward launches of wave tiles only; one right-hand side: held to 64 VGPRs (two groups of panel rows are requested up front)
   auto cnt    = [&](int kd, int l) { return P.lev_end[kd][l] - P.lev_ptr[kd][l]; };
   auto wrows  = [&](int kd, int kl, int l) { return std::max(16, (std::max(P.lev_lds[kd][l], P.lev_lds[kl][l]) + 15) / 16 * 16); };
   const int lds_cap = P.lds_cap;
@@ -1506,7 +1582,8 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::FWD_WAVE, SolvePlan::FWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    const Tile *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l], *tw = T + P.lev_ptr[SolvePlan::FWD_WAVE][l], *tf = T + P.lev_ptr[SolvePlan::FWD_LEAF][l];
+    const Tile   *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l];
+    const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::FWD_LEAF][l];
     const dim3 g(grid(nb, nw + nl));
     const size_t shm = (size_t)ld * sizeof(double);
     if (nb && nl) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, true, FPF, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
@@ -1519,7 +1596,8 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::BWD_WAVE, SolvePlan::BWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    const Tile *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l], *tw = T + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = T + P.lev_ptr[SolvePlan::BWD_LEAF][l];
+    const Tile   *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l];
+    const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::BWD_LEAF][l];
     const dim3 g(grid(nb, nw + nl));
     const size_t shm = (size_t)ld * sizeof(double);
     if (nb && nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);

@@ -151,64 +151,68 @@ __device__ static inline void wave_mfma_steps(dbl2 (&ring)[PF][NCH], gcd_t P, in
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // forward: results of NR panel rows of one lane, column nu (r[k] < 0: nothing to store): rows of the top block give y; a row below
-// adds what the children handed to the same entry of the front (the slot rows of this supernode, factor.hpp: dense, whole lines) and
-// hands the sum to the parent -- entry rel[r - w] of the slot row this supernode writes.  The positions and the slot entries of
-// all the rows are requested together: one round trip, then the stores (same sums, same order as the VALU sweeps).
+// adds what the children handed to the same entry of the front and hands the sum to the parent.  The hand-over is the COMPACT one
+// (factor.hpp): entry i of the front owns the run cptr[i] .. cptr[i + 1] of this supernode's block of the pool -- one 128-byte line
+// per child that reaches it, nothing else (the dense slot rows of the VALU sweeps would make this engine read more lines of zeros
+// than the narrow levels have panel) --, and row i writes line crel[i] of the parent's block.  The pointers of all the rows are
+// requested together, then the lines they point to side by side (same sums, same order as the VALU sweeps).
 template <int NR>
 __device__ static inline void store_rows16(const SnView &d, const int (&r)[NR], int nu, double (&v)[NR], double *yb, double *Sb)
 {
-  const int h = d.w + d.nb;
-  int       pos[NR];
+  int pos[NR], q0[NR], q1[NR], qmax = 0;
 #pragma unroll
-  for (int k = 0; k < NR; ++k) pos[k] = r[k] >= d.w ? d.rel[r[k] - d.w] : 0;
-  for (int c = 0; c < d.nchild; c += 2) {
-    const bool two = c + 1 < d.nchild;
-    double     u0[NR], u1[NR];
+  for (int k = 0; k < NR; ++k) {
+    const bool below = r[k] >= d.w;
+    pos[k] = below ? d.crel[r[k] - d.w] : 0;
+    q0[k]  = below && d.nchild ? d.cptr[r[k]] : 0;
+    q1[k]  = below && d.nchild ? d.cptr[r[k] + 1] : 0;
+    qmax   = max(qmax, q1[k] - q0[k]);
+  }
+  for (int j = 0; j < qmax; ++j) { // the runs of the NR rows walked side by side
+    double u[NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const bool below = r[k] >= d.w;
-      u0[k]            = below ? Sb[(long long)(d.s_in + c * h + r[k]) * C16 + nu] : 0.0;
-      u1[k]            = below && two ? Sb[(long long)(d.s_in + (c + 1) * h + r[k]) * C16 + nu] : 0.0;
-    }
+    for (int k = 0; k < NR; ++k) u[k] = q0[k] + j < q1[k] ? Sb[(long long)(d.c_in + q0[k] + j) * C16 + nu] : 0.0;
 #pragma unroll
     for (int k = 0; k < NR; ++k)
-      if (r[k] >= d.w) v[k] = two ? (v[k] + u0[k]) + u1[k] : v[k] + u0[k];
+      if (q0[k] + j < q1[k]) v[k] += u[k];
   }
 #pragma unroll
   for (int k = 0; k < NR; ++k)
     if (r[k] >= 0) {
       if (r[k] < d.w) yb[(long long)(d.c0 + r[k]) * C16 + nu] = v[k];
-      else Sb[(long long)(d.s_out + pos[k]) * C16 + nu] = v[k];
+      else Sb[(long long)(d.c_out + pos[k]) * C16 + nu] = v[k];
     }
 }
 
 // columns [cb0, cb0 + cnt) of the forward right-hand side of a narrow supernode into LDS, `nt` threads working together (64: one
 // wavefront, 256: the workgroup): real scalars row (c - cb0) of Bl, complex scalars rows 2 (c - cb0), 2 (c - cb0) + 1 (the R form);
-// columns past the supernode's are zero (the MFMA steps run in fours).  Everything depends on the descriptor only: the entries of b
-// and of the slot rows of GP columns of the thread are requested together.
+// columns past the supernode's are zero (the MFMA steps run in fours).  The entries of b and the pointers of the compact hand-over
+// of GP columns of the thread are requested together, then the lines the pointers name.
 template <bool Z>
 __device__ static inline void stage_fwd16(const SnView &d, int cb0, int cnt, int tid, int nt, double *Bl, const double *bb, const double *Sb)
 {
-  const int nu = tid & 15, rpp = nt >> 4, h = d.w + d.nb; // columns per pass of the team
-  constexpr int GP = 4;                                  // columns of a thread in flight together
+  const int nu = tid & 15, rpp = nt >> 4; // columns per pass of the team
+  constexpr int GP = 4;                   // columns of a thread in flight together
   for (int q0 = tid >> 4; q0 < cnt; q0 += GP * rpp) {
     double v[GP];
+    int    p0[GP], p1[GP], pmax = 0;
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
-      const int c = cb0 + q0 + g * rpp;
-      v[g]        = (q0 + g * rpp < cnt && c < d.w) ? bb[(long long)(d.c0 + c) * C16 + nu] : 0.0;
+      const int  c  = cb0 + q0 + g * rpp;
+      const bool in = q0 + g * rpp < cnt && c < d.w;
+      v[g]          = in ? bb[(long long)(d.c0 + c) * C16 + nu] : 0.0;
+      p0[g]         = in && d.nchild ? d.cptr[c] : 0;
+      p1[g]         = in && d.nchild ? d.cptr[c + 1] : 0;
+      pmax          = max(pmax, p1[g] - p0[g]);
     }
-    if (cb0 + q0 - (tid >> 4) < d.w) // (wave-uniform: some column of this pass belongs to the supernode)
-      for (int ch = 0; ch < d.nchild; ++ch) { // what child ch handed to these columns: one line per column
-        double u[GP];
+    for (int j = 0; j < pmax; ++j) { // entry j of the run of every column (same order as the VALU sweeps: the children's numbers)
+      double u[GP];
 #pragma unroll
-        for (int g = 0; g < GP; ++g) {
-          const int c = cb0 + q0 + g * rpp;
-          u[g]        = (q0 + g * rpp < cnt && c < d.w) ? Sb[(long long)(d.s_in + ch * h + c) * C16 + nu] : 0.0;
-        }
+      for (int g = 0; g < GP; ++g) u[g] = p0[g] + j < p1[g] ? Sb[(long long)(d.c_in + p0[g] + j) * C16 + nu] : 0.0;
 #pragma unroll
-        for (int g = 0; g < GP; ++g) v[g] -= u[g];
-      }
+      for (int g = 0; g < GP; ++g)
+        if (p0[g] + j < p1[g]) v[g] -= u[g];
+    }
 #pragma unroll
     for (int g = 0; g < GP; ++g) {
       const int c = q0 + g * rpp; // relative to the staged range
@@ -362,145 +366,6 @@ __device__ static inline void bwd_wave_tile16(const SnView &d, const Tile &t, in
         const int col = m0 + 2 * p;
         if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg];
         if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg];
-      }
-    }
-  }
-  wave_lds_order(); // the staging area goes to the next tile of this wavefront
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// condensed leaves (factor.hpp, sptrsv.hip): forward z = W f_J (kept in y_J), u = A_RJ z to the parent's slot row; backward
-// x_J = z - W (A_JR x_R).  One wavefront per leaf of at most LEAF16_MAXW columns: the dense product W^T-rows x 16 columns is the
-// backward wave tile's (wave_mfma_steps on W^T, one or two chunks of 32 doubles), f / t in rows 0..31 of the wavefront's staging
-// area, z in rows 32..63; the sparse products take 16 lanes per row (one line of z / x per entry), four rows of four lane groups in
-// flight.
-template <bool Z>
-__device__ static inline void leaf_product16(const LeafView &L, int w, int ld, int m0, int lane, const double *Bl, v4f64 (&aE)[1], v4f64 (&aO)[1])
-{
-  constexpr int PF = 4;
-  const int     klo[1] = {0}, khi[1] = {w}, k4 = (w + 3) & ~3;
-  dbl2          ring[PF][1];
-  wave_pipe_prime<1, PF>(ring, L.WT + m0, ld, w, ld - m0, 0, k4, klo, khi, lane);
-  aE[0] = v4f64{0.0, 0.0, 0.0, 0.0}, aO[0] = v4f64{0.0, 0.0, 0.0, 0.0};
-  wave_mfma_steps<1, PF>(ring, L.WT + m0, ld, w, ld - m0, 0, k4, k4, klo, khi, Bl, 0, lane, aE, aO);
-}
-
-template <bool Z>
-__device__ static inline void fwd_leaf_tile16(const SnView &d, int lane, double *Bl, const double *bb, double *yb, double *Sb)
-{
-  const LeafView L  = leaf_view(d);
-  const int      w = d.w, ld = d.ldw, nb = d.nb, cs = d.cs;
-  const int      nu = lane & 15, kq = lane >> 4, k4 = (w + 3) & ~3;
-  double        *Zl = Bl + 32 * C16;
-  for (int k = kq; k < k4; k += 4) Bl[k * C16 + nu] = k < w ? bb[(long long)(d.c0 + k) * C16 + nu] : 0.0; // f = b_J (no children); rows up to a multiple of 4: zeros
-  wave_lds_order();
-  for (int m0 = 0; m0 < ld; m0 += 32) {
-    v4f64 aE[1], aO[1];
-    leaf_product16<Z>(L, w, ld, m0, lane, Bl, aE, aO);
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int p = kq + 4 * reg;
-      if constexpr (Z) {
-        const int    col = (m0 >> 1) + p;
-        const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu); // (every lane takes part in the swap)
-        if (col < w) yb[(long long)(d.c0 + col) * C16 + nu] = v, Zl[col * C16 + nu] = v;
-      } else {
-        const int col = m0 + 2 * p;
-        if (col < w) yb[(long long)(d.c0 + col) * C16 + nu] = aE[0][reg], Zl[col * C16 + nu] = aE[0][reg];
-        if (col + 1 < w) yb[(long long)(d.c0 + col + 1) * C16 + nu] = aO[0][reg], Zl[(col + 1) * C16 + nu] = aO[0][reg];
-      }
-    }
-  }
-  wave_lds_order();
-  // u = A_RJ z: lane group kq takes the rows kq, kq + 4, ...; GP of them side by side
-  constexpr int GP = 4;
-  for (int i0 = kq; i0 < nb; i0 += 4 * GP) {
-    int    p0[GP], p1[GP], pos[GP], qmax = 0;
-    double u[GP];
-#pragma unroll
-    for (int g = 0; g < GP; ++g) {
-      const int  i  = i0 + 4 * g;
-      const bool ok = i < nb;
-      p0[g] = ok ? (int)L.srptr[i] : 0, p1[g] = ok ? (int)L.srptr[i + 1] : 0, pos[g] = ok ? d.rel[i] : 0;
-      qmax  = max(qmax, p1[g] - p0[g]);
-      u[g]  = 0.0;
-    }
-    for (int j = 0; j < qmax; ++j) {
-#pragma unroll
-      for (int g = 0; g < GP; ++g) {
-        const bool ok = p0[g] + j < p1[g];
-        const int  c  = ok ? (int)L.srcol[p0[g] + j] : 0;
-        if constexpr (!Z) {
-          const double a = ok ? L.srval[p0[g] + j] : 0.0;
-          u[g]           = fma(a, Zl[c * C16 + nu], u[g]);
-        } else {
-          const dbl2 a = ok ? *(gcd2_t)(L.srval + 2 * (p0[g] + j)) : dbl2{0.0, 0.0};
-          u[g]         = fma(a.x, Zl[c * C16 + nu], fma((nu & 1) ? a.y : -a.y, Zl[c * C16 + (nu ^ 1)], u[g]));
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < GP; ++g)
-      if (i0 + 4 * g < nb) Sb[(long long)(d.s_out + pos[g]) * C16 + nu] = u[g];
-  }
-  (void)cs;
-  wave_lds_order(); // the staging area goes to the next tile of this wavefront
-}
-
-template <bool Z>
-__device__ static inline void bwd_leaf_tile16(const SnView &d, int lane, double *Bl, const double *yb, double *xb)
-{
-  const LeafView L  = leaf_view(d);
-  const int      w = d.w, ld = d.ldw;
-  const int      nu = lane & 15, kq = lane >> 4, k4 = (w + 3) & ~3;
-  // t = A_JR x_R: lane group kq takes the columns kq, kq + 4, ... of the leaf, GP of them side by side; one line of x per entry
-  constexpr int GP = 4;
-  for (int c0 = kq; c0 < k4; c0 += 4 * GP) {
-    int    p0[GP], p1[GP], qmax = 0;
-    double t[GP];
-#pragma unroll
-    for (int g = 0; g < GP; ++g) {
-      const int  c  = c0 + 4 * g;
-      const bool ok = c < w;
-      p0[g] = ok ? (int)L.scptr[c] : 0, p1[g] = ok ? (int)L.scptr[c + 1] : 0;
-      qmax  = max(qmax, p1[g] - p0[g]);
-      t[g]  = 0.0;
-    }
-    for (int j = 0; j < qmax; ++j) {
-#pragma unroll
-      for (int g = 0; g < GP; ++g) {
-        const bool   ok = p0[g] + j < p1[g];
-        const int    r  = ok ? L.scrow[p0[g] + j] : d.c0;
-        const double xv = xb[(long long)r * C16 + nu];
-        if constexpr (!Z) {
-          const double a = ok ? L.scval[p0[g] + j] : 0.0;
-          t[g]           = ok ? fma(a, xv, t[g]) : t[g]; // (x of the leaf's own columns, read for the absent entries, is not defined yet)
-        } else {
-          const dbl2   a  = ok ? *(gcd2_t)(L.scval + 2 * (p0[g] + j)) : dbl2{0.0, 0.0};
-          const double xo = __shfl_xor(xv, 1); // the other plane of the same right-hand side (the 16 lanes of a column stay together)
-          t[g]            = ok ? fma(a.x, xv, fma((nu & 1) ? a.y : -a.y, xo, t[g])) : t[g];
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < GP; ++g)
-      if (c0 + 4 * g < k4) Bl[(c0 + 4 * g) * C16 + nu] = c0 + 4 * g < w ? t[g] : 0.0;
-  }
-  wave_lds_order();
-  for (int m0 = 0; m0 < ld; m0 += 32) {
-    v4f64 aE[1], aO[1];
-    leaf_product16<Z>(L, w, ld, m0, lane, Bl, aE, aO);
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) { // x_J = z - W t, z = what the forward sweep left in y_J
-      const int p = kq + 4 * reg;
-      if constexpr (Z) {
-        const int    col = (m0 >> 1) + p;
-        const double v   = combine16<true>(aE[0][reg], aO[0][reg], nu); // (every lane takes part in the swap)
-        if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = yb[(long long)(d.c0 + col) * C16 + nu] - v;
-      } else {
-        const int col = m0 + 2 * p;
-        if (col < w) xb[(long long)(d.c0 + col) * C16 + nu] = yb[(long long)(d.c0 + col) * C16 + nu] - aE[0][reg];
-        if (col + 1 < w) xb[(long long)(d.c0 + col + 1) * C16 + nu] = yb[(long long)(d.c0 + col + 1) * C16 + nu] - aO[0][reg];
       }
     }
   }
@@ -683,19 +548,19 @@ __device__ static inline void bwd_block_tile16(const SnView &d, const Tile &t, d
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // One launch per level and direction, as in sptrsv.hip: the workgroups take the block tiles (wide panels) with their four
-// wavefronts together, then their wavefronts take wave tiles on their own: the chunks of the narrow panels, then the condensed leaves.
+// wavefronts together, then their wavefronts take wave tiles (narrow panels) on their own.
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, int nleaf, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16, int lds_dbl)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16, int lds_dbl)
 {
   // workgroup tiles first: the block tiles of the wide panels, then the first nteam tiles of the narrow ones (team tiles); the
-  // other nwave tiles of the narrow panels go one per wavefront, the nleaf condensed leaves behind them likewise
+  // other nwave tiles of the narrow panels go one per wavefront
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
   if (HAS_BLOCK) {
     for (int bt = blockIdx.x; bt < nblock + nteam; bt += G) {
       const Tile   t = bt < nblock ? btiles[bt] : wtiles[bt - nblock];
       const SnView d = view(sns[t.sn]);
-      fwd_block_tile16<Z>(d, t, lds, b16 + d.voff * C16, y16 + d.voff * C16, S16 + d.soff * C16); // (no forward team tiles: nteam = 0; the combine pass of the level has formed the right-hand sides)
+      fwd_block_tile16<Z>(d, t, lds, b16 + d.voff * C16, y16 + d.voff * C16, S16 + d.coff * C16); // (no forward team tiles: nteam = 0; the combine pass of the level has formed the right-hand sides)
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
@@ -703,18 +568,17 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
-  for (int tix = gw * 4 + wv; tix < nwave + nleaf; tix += G * 4) {
+  for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *bb = b16 + d.voff * C16;
-    double       *yb = y16 + d.voff * C16, *Sb = S16 + d.soff * C16;
-    if (tix >= nwave) fwd_leaf_tile16<Z>(d, lane, Bl, bb, yb, Sb);
-    else fwd_wave_tile16<Z>(d, t, lane, Bl, bb, yb, Sb);
+    double       *yb = y16 + d.voff * C16, *Sb = S16 + d.coff * C16;
+    fwd_wave_tile16<Z>(d, t, lane, Bl, bb, yb, Sb);
   }
 }
 
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, int nleaf, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
 {
   // workgroup tiles: the block tiles of the wide panels and the first nteam narrow supernodes (those of more than one staging pass
   // of v: the workgroup stages all their rows at once, every wavefront takes 32 doubles of every row -- the block tile as it is)
@@ -732,19 +596,19 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
-  for (int tix = gw * 4 + wv; tix < nwave + nleaf; tix += G * 4) {
+  for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
     const Tile    t  = wtiles[tix];
     const SnView  d  = view(sns[t.sn]);
     const double *yb = y16 + d.voff * C16;
     double       *xb = x16 + d.voff * C16;
-    if (tix >= nwave) bwd_leaf_tile16<Z>(d, lane, Bl, yb, xb);
-    else bwd_wave_tile16<Z>(d, t, lane, Bl, yb, xb);
+    bwd_wave_tile16<Z>(d, t, lane, Bl, yb, xb);
   }
 }
 
-// right-hand side of the wide supernodes of a level, formed once: b_J <- b_J - (what the children handed up: the slot rows of J, dense),
-// in place in the interleaved copy of b -- the wide forward tiles of this engine read it straight from the vector, every row group
-// of every tile.  A tile of the plan is 256 columns; a workgroup takes 16 of them, 16 threads (one line) per column.
+// right-hand side of the wide supernodes of a level, formed once: b_J <- b_J - (what the children handed up: the run of every column in
+// the compact hand-over), in place in the interleaved copy of b -- the wide forward tiles of this engine read it straight from the
+// vector, every row group of every tile.  A tile of the plan is 256 columns; a workgroup takes 16 of them, 16 threads (one line)
+// per column: the runs are short, the level is bound by the number of dependent chains in flight.
 __global__ __launch_bounds__(WG_THREADS) void sptrsv16_combine_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ gtiles, double *__restrict__ b16, const double *__restrict__ S16)
 {
   const Tile    t   = gtiles[blockIdx.x >> 4];
@@ -752,13 +616,18 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_combine_kernel(const SnDe
   if (col >= t.r0 + t.nr) return;
   const SnView  d  = view(sns[t.sn]);
   double       *bb = b16 + d.voff * C16;
-  const double *Sb = S16 + d.soff * C16;
-  const int     nu = threadIdx.x & 15, h = d.w + d.nb;
-  double        v  = bb[(long long)(d.c0 + col) * C16 + nu];
-  for (int c = 0; c < d.nchild; c += 2) { // two slot rows in flight; the order of the children's numbers
-    const bool   two = c + 1 < d.nchild;
-    const double u0 = Sb[(long long)(d.s_in + c * h + col) * C16 + nu], u1 = two ? Sb[(long long)(d.s_in + (c + 1) * h + col) * C16 + nu] : 0.0;
-    v               = two ? (v - u0) - u1 : v - u0;
+  const double *Sb = S16 + (d.coff + d.c_in) * C16;
+  const int     nu = threadIdx.x & 15;
+  const int     q0 = d.cptr[col], q1 = d.cptr[col + 1];
+  if (q0 == q1) return;
+  double v = bb[(long long)(d.c0 + col) * C16 + nu];
+  for (int q = q0; q < q1; q += 4) { // four lines in flight
+    double u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = q + j < q1 ? Sb[(long long)(q + j) * C16 + nu] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q + j < q1) v -= u[j];
   }
   bb[(long long)(d.c0 + col) * C16 + nu] = v;
 }
@@ -780,17 +649,17 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
       P.mark(1000 + l, s);
     }
     const int ld = lds_wave; // (the block tiles only use the cross-wavefront buffer: 4 x 16 x 16 doubles)
-    const int nt = P.lev_team[0][l], nl = P.lev_leaf16[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles; condensed leaves: the last nl
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, nw - nt - nl, nl, P.b16.p, P.y16.p, P.U16.p, ld);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, nw - nl, nl, P.b16.p, P.y16.p, P.U16.p, ld);
+    const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld);
     if (nb || nw) P.mark(2000 + l, s);
   }
   const int ldb = std::max(lds_wave, RCB * C16);
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = P.lev_end16[1][l] - P.lev_ptr16[1][l];
-    const int nt = P.lev_team[1][l], nl = P.lev_leaf16[1][l], grid = nb + nt + (nw - nt + 3) / 4;
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, nw - nt - nl, nl, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw - nl, nl, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    const int nt = P.lev_team[1][l], grid = nb + nt + (nw - nt + 3) / 4;
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0, P.out_scale);
@@ -803,8 +672,7 @@ void solve_block16(SolvePlan &P, const double *b, double *x, int mu, int k0, hip
     P.b16.alloc((size_t)P.ntot * C16);
     P.y16.alloc((size_t)P.ntot * C16);
     P.x16.alloc((size_t)P.ntot * C16);
-    P.U16.alloc((size_t)std::max<long long>(P.utot, 1) * C16); // the slot pool (factor.hpp), interleaved: zero where no child writes, for good
-    HIP_OK(hipMemsetAsync(P.U16.p, 0, sizeof(double) * (size_t)std::max<long long>(P.utot, 1) * C16, s));
+    P.U16.alloc((size_t)std::max<long long>(P.ctot, 1) * C16); // the compact hand-over pool (factor.hpp), interleaved: every line is written before it is read
     P.partials16.alloc((size_t)std::max(1, P.ngroups) * P.max_parts * 128 * C16);
   }
   if (P.cplx) sweeps16<true>(P, b, x, mu, k0, s);

@@ -8,7 +8,6 @@ namespace hpddm_hip {
 static constexpr int WG_THREADS  = 256;
 static constexpr int NARROW      = 128;  // panels up to this padded width can be handled one wavefront per tile
 static constexpr int WAVE_ROWS   = 256;  // a wavefront takes a whole supernode in the backward sweep up to this many rows
-static constexpr int LEAF16_MAXW = 32;   // the 16-column engine takes a condensed leaf through its blob up to this many columns (sptrsv16.hip)
 
 // Pointers read from a descriptor in memory lose their address space (the compiler falls back to FLAT instructions, which
 // tie up the LDS counter as well): the kernels see the supernode through global-address-space pointers.
@@ -20,19 +19,19 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 typedef const int4v __attribute__((address_space(1)))  *gci4_t;
 struct SnView {
   gcd_t     F, G, dinv, FT, leaf;
-  gci_t     rows, rel;
-  long long voff, soff;
-  int       n, c0, w, nb, ldw, wc, cs, s_in, nchild, s_out, ldh, tgs, nnzr, nnzc;
+  gci_t     rows, rel, cptr, crel;
+  long long voff, soff, coff;
+  int       n, c0, w, nb, ldw, wc, cs, s_in, nchild, s_out, ldh, tgs, nnzr, nnzc, c_in, c_out;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
   SnView v;
   v.F = (gcd_t)d.F, v.G = (gcd_t)d.G, v.dinv = (gcd_t)d.dinv, v.FT = (gcd_t)d.FT, v.leaf = (gcd_t)d.leaf;
   v.ldh = d.ldh;
-  v.rows = (gci_t)d.rows, v.rel = (gci_t)d.rel;
-  v.voff = d.voff, v.soff = d.soff;
+  v.rows = (gci_t)d.rows, v.rel = (gci_t)d.rel, v.cptr = (gci_t)d.cptr, v.crel = (gci_t)d.crel;
+  v.voff = d.voff, v.soff = d.soff, v.coff = d.coff;
   v.n = d.n, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.s_in = d.s_in, v.nchild = d.nchild, v.s_out = d.s_out;
-  v.tgs = d.tgs, v.nnzr = d.nnzr, v.nnzc = d.nnzc;
+  v.tgs = d.tgs, v.nnzr = d.nnzr, v.nnzc = d.nnzc, v.c_in = d.c_in, v.c_out = d.c_out; // (= t_r0, t_nr in the per-tile copies of the VALU sweeps)
   return v;
 }
 // the sections of a condensed leaf's blob (leaf_blob_layout of factor.hpp, in the address space of the kernels)

@@ -45,12 +45,14 @@ def _leaf_blob(pool, off, w, ldw, nb, nnzr, nnzc, cs):
                 srptr=raw[o_srptr:o_scptr].view(np.uint16), scptr=raw[o_scptr:o_srcol].view(np.uint16), srcol=raw[o_srcol:o_srcol + 2 * nnzr].view(np.uint16))
 
 
-def _replay(S, b, use_leaves=True):
+def _replay(S, b, use_leaves=True, compact=False):
     """numpy replay of the level-scheduled multifrontal solve on the exported solve-ready panels (factor.hpp); complex factors:
     the panels are (re, im) pairs, L D L^T with plain transposes (complex symmetric) or LU.  The updates travel as in the sweeps
     of the library: every supernode writes its update to positions rel[.] of a slot row of its parent, the parent sums its slot rows
-    (dense); a condensed leaf goes through W = inv(A_JJ) and the sparse couplings of its blob (use_leaves=False: through its panel)."""
-    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "rel", "nchild", "s_off", "ps_off", "tgs", "lb_off", "lb_nnzr", "lb_nnzc")}
+    (dense); a condensed leaf goes through W = inv(A_JJ) and the sparse couplings of its blob (use_leaves=False: through its panel).
+    compact=True: the hand-over of the 16-column engine instead -- one entry per (position of a front, child that reaches it), runs
+    named by cptr, written through crel."""
+    e = {k: S.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height", "u_off", "rel", "nchild", "s_off", "ps_off", "tgs", "lb_off", "lb_nnzr", "lb_nnzc", "c_off", "cptr", "crel", "cs_off", "pcs_off")}
     pool = S.export("leaf_pool")
     kind = S.info()["kind"]
     cplx = bool(getattr(S, "complex", False))
@@ -69,6 +71,7 @@ def _replay(S, b, use_leaves=True):
     assert e["s_off"][-1] + e["nchild"][-1] * hh[-1] == (e["nchild"] * hh).sum()
     y, x = np.zeros(n, dtype=dt), np.zeros(n, dtype=dt)
     written = np.zeros(len(slots), dtype=bool)
+    cpool, cwritten = np.zeros(max(1, int(rp[-1])), dtype=dt), np.zeros(max(1, int(rp[-1])), dtype=bool)
     order = np.argsort(e["height"], kind="stable")
     leaves = {}
     for k in order:
@@ -79,6 +82,10 @@ def _replay(S, b, use_leaves=True):
         assert np.all(P[:w][(np.arange(w)[None, :] // t) > (np.arange(w)[:, None] // t)] == 0.0) if e["tgs"][k] else np.all(np.triu(P[:w], 1) == 0.0)
         nc = e["nchild"][k]
         gath = slots[e["s_off"][k]:e["s_off"][k] + nc * h].reshape(nc, h).sum(axis=0) if nc else np.zeros(h, dtype=dt)
+        if compact:
+            cp = e["cptr"][e["c_off"][k]:e["c_off"][k] + h + 1]
+            assert cp[0] == 0 and cp[h] == sum(rp[c + 1] - rp[c] for c in range(nblk) if e["pcs_off"][c] == e["cs_off"][k] and rp[c + 1] > rp[c]) or not nc
+            gath = np.array([cpool[e["cs_off"][k] + cp[i]:e["cs_off"][k] + cp[i + 1]].sum() for i in range(h)], dtype=dt) if nc else np.zeros(h, dtype=dt)
         f = b[e["perm"][c0:c0 + w]] - gath[:w]
         if use_leaves and e["lb_off"][k] >= 0:
             assert nc == 0
@@ -96,6 +103,10 @@ def _replay(S, b, use_leaves=True):
             assert e["ps_off"][k] >= 0 and not written[where].any() and len(set(where)) == nb   # every slot entry has ONE writer
             written[where] = True
             slots[where] = u
+            cwhere = e["pcs_off"][k] + e["crel"][e["u_off"][k]:e["u_off"][k] + nb]
+            assert e["pcs_off"][k] >= 0 and not cwritten[cwhere].any() and len(set(cwhere)) == nb
+            cwritten[cwhere] = True
+            cpool[cwhere] = u
     for k in order[::-1]:
         c0, w, nb = blk[k], blk[k + 1] - blk[k], rp[k + 1] - rp[k]
         h, ld = w + nb, e["ldw"][k]
@@ -147,6 +158,8 @@ def test_host_factorisation(kind):
     assert _replay.leaves > 0   # the leaves of the nested dissection went through their blobs (W = inv(A_JJ), sparse couplings) ...
     xp = _replay(S, b, use_leaves=False)   # ... and through their dense panels: the same solution
     assert _replay.leaves == 0 and np.linalg.norm(x - xp) / np.linalg.norm(x) < 1e-12
+    xc = _replay(S, b, use_leaves=False, compact=True)   # the compact hand-over of the 16-column engine: the same sums in the same order
+    assert np.array_equal(xc, xp)
     S.destroy()
 
 
