@@ -277,7 +277,8 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, dou
   const int   r_out = t.r0 + 2 * gl, rend = t.r0 + t.nr;
   const bool  mine = lane < w; // lane c stages column c (supernodes wider than 64 take the loop below)
   const bool  below[2] = {sub == 0 && r_out >= w && r_out < rend, sub == 0 && r_out + 1 >= w && r_out + 1 < rend};
-  constexpr int NC = MU == 1 ? 4 : 2; // children taken side by side (more: the loops behind the batch)
+  constexpr int  NC = 4;       // children taken side by side (more: the loops behind the batch)
+  constexpr bool RE = MU == 1; // the slot entries of the two output rows early as well (two columns: in the epilogue -- their registers would cost a wavefront per SIMD)
   double        fv[MU], uc[NC][MU], ur[2][NC][MU];
   int           rpos[2];
   // (loads without branches: an entry that is not there is read at a harmless place of the same array -- the pools carry a few
@@ -294,12 +295,12 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, dou
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int rl = below[k] ? r_out + k : 0;
-    rpos[k]      = d.rel[below[k] ? r_out + k - w : 0];
+    rpos[k]      = RE ? d.rel[below[k] ? r_out + k - w : 0] : 0;
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const double *sj = Sb + d.s_in + (j < d.nchild ? j : 0) * h;
 #pragma unroll
-      for (int nu = 0; nu < MU; ++nu) ur[k][j][nu] = sj[(long long)nu * stot + rl];
+      for (int nu = 0; nu < MU; ++nu) ur[k][j][nu] = RE ? sj[(long long)nu * stot + rl] : 0.0;
     }
   }
   dbl2 cur[FWD_PASSES], nxt[FWD_PASSES];
@@ -329,8 +330,8 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, dou
 #pragma unroll
       for (int nu = 0; nu < MU; ++nu) {
         if (mine) fv[nu] -= sc[(long long)nu * stot + lane];
-        if (below[0]) radd[0][nu] += sc[(long long)nu * stot + r_out];
-        if (below[1]) radd[1][nu] += sc[(long long)nu * stot + r_out + 1];
+        if (RE && below[0]) radd[0][nu] += sc[(long long)nu * stot + r_out];
+        if (RE && below[1]) radd[1][nu] += sc[(long long)nu * stot + r_out + 1];
       }
     }
   }
@@ -376,17 +377,22 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, dou
   }
   reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
   if (sub == 0) {
+    if constexpr (RE) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int r = r_out + k;
-      if (r < rend) {
+      for (int k = 0; k < 2; ++k) {
+        const int r = r_out + k;
+        if (r < rend) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) {
-          const double v = k ? acc1[nu] : acc0[nu];
-          if (r < w) yb[(long long)nu * d.n + d.c0 + r] = v;
-          else Sb[(long long)nu * stot + d.s_out + rpos[k]] = v + radd[k][nu];
+          for (int nu = 0; nu < MU; ++nu) {
+            const double v = k ? acc1[nu] : acc0[nu];
+            if (r < w) yb[(long long)nu * d.n + d.c0 + r] = v;
+            else Sb[(long long)nu * stot + d.s_out + rpos[k]] = v + radd[k][nu];
+          }
         }
       }
+    } else {
+      if (r_out < rend) fwd_store_row<MU>(d, r_out, acc0, 1, yb, Sb, stot);
+      if (r_out + 1 < rend) fwd_store_row<MU>(d, r_out + 1, acc1, 1, yb, Sb, stot);
     }
   }
 }
@@ -720,13 +726,38 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
 // right-hand side entry of panel column `col` (in doubles) for the real column nu: real scalars b_J - (what the children handed up,
 // summed over the slot rows of J: dense reads, every row tile of J forms the entries it stages itself -- no gather pass ahead of the
 // level); complex scalars the entry (col, nu) of R = [ f_r  f_i ; -f_i  f_r ] (one plane of f, possibly negated)
-template <bool Z>
-__device__ static inline double fwd_rhs_entry(const SnView &d, int col, int nu, const double *bb, const double *Sb, long long stot)
+template <bool Z, int SU>
+__device__ static inline void fwd_rhs_entries(const SnView &d, const int (&col)[SU], const int (&nu)[SU], const bool (&ok)[SU], const double *bb, const double *Sb, long long stot, double (&v)[SU])
 {
-  const int c = Z ? col >> 1 : col, plane = (Z && (col & 1)) ? (nu ^ 1) : nu;
-  double    v[1] = {bb[(long long)plane * d.n + d.c0 + c]};
-  slot_sub<1>(d, c, Sb + (long long)plane * stot, stot, v);
-  return (Z && (col & 1) && !(nu & 1)) ? -v[0] : v[0];
+  // SU entries of one thread side by side: their b entries and their entries of the first two slot rows are requested before any of
+  // them is used (a tile starts with this staging; entry after entry it was a chain of round trips per entry).  No branches around
+  // the loads: an entry that is not there is read at a harmless place and dropped.
+  const int  h = d.w + d.nb;
+  const bool c1 = d.nchild > 0, c2 = d.nchild > 1;
+  long long  ob[SU], os[SU];
+  double     b[SU], u0[SU], u1[SU];
+#pragma unroll
+  for (int j = 0; j < SU; ++j) {
+    const int c = ok[j] ? (Z ? col[j] >> 1 : col[j]) : 0, plane = ok[j] ? ((Z && (col[j] & 1)) ? (nu[j] ^ 1) : nu[j]) : 0;
+    ob[j]       = (long long)plane * d.n + d.c0 + c;
+    os[j]       = (long long)plane * stot + d.s_in + c;
+  }
+#pragma unroll
+  for (int j = 0; j < SU; ++j) b[j] = bb[ob[j]], u0[j] = Sb[os[j]], u1[j] = Sb[os[j] + (c2 ? h : 0)];
+#pragma unroll
+  for (int j = 0; j < SU; ++j) {
+    v[j] = c1 ? b[j] - u0[j] : b[j];
+    v[j] = c2 ? v[j] - u1[j] : v[j];
+  }
+  for (int ch = 2; ch < d.nchild; ++ch) { // (supernodes the ordering merged out of more than two)
+    double u[SU];
+#pragma unroll
+    for (int j = 0; j < SU; ++j) u[j] = Sb[os[j] + (long long)ch * h];
+#pragma unroll
+    for (int j = 0; j < SU; ++j) v[j] -= u[j];
+  }
+#pragma unroll
+  for (int j = 0; j < SU; ++j) v[j] = ok[j] ? ((Z && (col[j] & 1) && !(nu[j] & 1)) ? -v[j] : v[j]) : 0.0;
 }
 
 template <int MU, int FWD_PASSES, int CU, bool Z>
@@ -766,10 +797,22 @@ __device__ static inline void fwd_block_tile(const SnView &d, const Tile &t, dou
         // stage f = b - children's updates for columns [k0, kend), zero padding up to ldw (16-byte reads past w see zeros)
         if (!single) __syncthreads();
         const int kend = min(k0 + CW, ldw);
-        for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
-          const int nu = idx / (kend - k0), i = idx - nu * (kend - k0);
-          const int col = k0 + i;
-          lds[nu * CW + i] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Sb, stot) : 0.0;
+        constexpr int SU = MU == 1 ? 4 : 2; // (more would cost the two-column kernels a wavefront per SIMD)
+        for (int idx0 = tid; idx0 < (kend - k0) * MU; idx0 += SU * WG_THREADS) {
+          int    col[SU], nuj[SU], ii[SU];
+          bool   ok[SU];
+          double v[SU];
+#pragma unroll
+          for (int j = 0; j < SU; ++j) {
+            const int idx = idx0 + j * WG_THREADS;
+            nuj[j] = idx / (kend - k0), ii[j] = idx - nuj[j] * (kend - k0);
+            col[j] = k0 + ii[j];
+            ok[j]  = idx < (kend - k0) * MU && col[j] < wc;
+          }
+          fwd_rhs_entries<Z, SU>(d, col, nuj, ok, bb, Sb, stot, v);
+#pragma unroll
+          for (int j = 0; j < SU; ++j)
+            if (idx0 + j * WG_THREADS < (kend - k0) * MU) lds[nuj[j] * CW + ii[j]] = v[j];
         }
         __syncthreads();
       }
@@ -839,9 +882,22 @@ __device__ static inline void fwd_block_tile_mfma(const SnView &d, const Tile &t
   for (int k0 = 0; k0 < tile_lim; k0 += CW) {
     __syncthreads();
     const int kend = min(k0 + CW, (tile_lim + 15) & ~15);
-    for (int idx = tid; idx < (kend - k0) * MU; idx += WG_THREADS) {
-      const int nu = idx / (kend - k0), i = idx - nu * (kend - k0), col = k0 + i;
-      lds[i * MU + nu] = col < wc ? fwd_rhs_entry<Z>(d, col, nu, bb, Sb, stot) : 0.0;
+    constexpr int SU = 4;
+    for (int idx0 = tid; idx0 < (kend - k0) * MU; idx0 += SU * WG_THREADS) {
+      int    col[SU], nuj[SU], ii[SU];
+      bool   ok[SU];
+      double v[SU];
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        const int idx = idx0 + j * WG_THREADS;
+        nuj[j] = idx / (kend - k0), ii[j] = idx - nuj[j] * (kend - k0);
+        col[j] = k0 + ii[j];
+        ok[j]  = idx < (kend - k0) * MU && col[j] < wc;
+      }
+      fwd_rhs_entries<Z, SU>(d, col, nuj, ok, bb, Sb, stot, v);
+#pragma unroll
+      for (int j = 0; j < SU; ++j)
+        if (idx0 + j * WG_THREADS < (kend - k0) * MU) lds[ii[j] * MU + nuj[j]] = v[j];
     }
     __syncthreads();
     const int cend = min(kend, (my_lim + 15) & ~15), step = 16 * wpg;
@@ -925,20 +981,35 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
   // rows above the tile's first column hold zeros in these columns (triangular top block): rows [t.rbeg, t.rend) only
   for (int i0 = t.rbeg; i0 < t.rend; i0 += RCH) {
     const int rch = min(RCH, t.rend - i0);
-    for (int idx = tid; idx < rch * MU; idx += WG_THREADS) {
-      const int nu = idx / rch, ii = idx - nu * rch;
-      const int i = i0 + ii;
-      double    v;
-      if (i < w) {
-        v = yb[(long long)nu * d.n + d.c0 + i];
-        if constexpr (!Z) {
-          if (d.dinv) v *= d.dinv[d.c0 + i];
-        } else if (d.dinv) { // complex 1 / D: this entry is the real (nu even) or imaginary (nu odd) part of (d_r + i d_i)(y_r + i y_i)
-          const double dr = d.dinv[2 * (d.c0 + i)], di = d.dinv[2 * (d.c0 + i) + 1], o = yb[(long long)(nu ^ 1) * d.n + d.c0 + i];
-          v = (nu & 1) ? dr * v + di * o : dr * v - di * o;
-        }
-      } else v = -xb[(long long)nu * d.n + d.rows[i - w]];
-      lds[nu * RCH + ii] = v;
+    // SU entries of a thread side by side: the row numbers of all of them first, then the entries of y / x they name (a tile starts
+    // with this staging: entry after entry it was two dependent round trips per entry)
+    constexpr int SU = 4;
+    for (int idx0 = tid; idx0 < rch * MU; idx0 += SU * WG_THREADS) {
+      int    nuj[SU], ii[SU], src[SU];
+      bool   ok[SU], top[SU];
+      double v[SU], o[SU], dr[SU], di[SU];
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        const int idx = idx0 + j * WG_THREADS;
+        ok[j]  = idx < rch * MU;
+        nuj[j] = ok[j] ? idx / rch : 0, ii[j] = ok[j] ? idx - nuj[j] * rch : 0;
+        top[j] = i0 + ii[j] < w;
+        src[j] = top[j] ? d.c0 + i0 + ii[j] : d.rows[i0 + ii[j] - w]; // (i0 + ii < h always: the tile's rows)
+      }
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        v[j] = (top[j] ? yb : xb)[(long long)nuj[j] * d.n + src[j]];
+        if constexpr (Z) o[j] = (top[j] && d.dinv) ? yb[(long long)(nuj[j] ^ 1) * d.n + src[j]] : 0.0;
+        dr[j] = (top[j] && d.dinv) ? d.dinv[(Z ? 2 : 1) * src[j]] : 1.0;
+        if constexpr (Z) di[j] = (top[j] && d.dinv) ? d.dinv[2 * src[j] + 1] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        double r;
+        if constexpr (!Z) r = top[j] ? v[j] * dr[j] : -v[j];
+        else r = top[j] ? ((nuj[j] & 1) ? dr[j] * v[j] + di[j] * o[j] : dr[j] * v[j] - di[j] * o[j]) : -v[j]; // complex 1 / D: the real (nu even) or imaginary (nu odd) part of (d_r + i d_i)(y_r + i y_i)
+        if (ok[j]) lds[nuj[j] * RCH + ii[j]] = r;
+      }
     }
     __syncthreads();
     if (colok) {
@@ -1308,11 +1379,18 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   lds_cap               = std::max(1024, std::min(8192, envi("HPDDM_HIP_LDS", 4096))) / 64 * 64;
   const int  bwd_small   = envi("HPDDM_HIP_BWD_SMALL", 4096);   // narrow panels, backward: one wavefront takes the whole supernode up to this many panel entries (scalars), a workgroup beyond
   const int  bwd_want    = std::max(256, envi("HPDDM_HIP_BWD_WANT", 3072) / std::max(1, groups));  // wide panels, backward: split rows until a level fields this many workgroups (over all the groups of subdomains sharing the GPU; measured at 129^3 per subdomain, one group: 768 -> 37.6 ms, 1536 -> 36.9, 3072 with up to 32 parts -> 36.1)
-  const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 256);
+  const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 128); // (round 5: 256 -> 128: the 16-column sweeps of the Helmholtz share 1.68 -> 1.58 ms, the others unchanged)
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   const bool use_leaves  = envi("HPDDM_HIP_LEAF_TILES", 1) != 0; // developer switch: 0 sweeps the condensed leaves through their panels all the same
   lev_bytes.assign(nlev, 0.0);
-  auto fwd_tile_rows = [](int wc) { return wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); }; // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
+  const int  fwd_rows_cap = envi("HPDDM_HIP_FWD_ROWS", 64);     // wide panels, forward: rows per tile at most (64 / 32 / 16) ...
+  const int  fwd_tile_kb  = envi("HPDDM_HIP_FWD_TILE_KB", 1 << 20); // ... and panel bytes per tile at most (a level ends with the tail of its last tiles: bytes of a tile / what ONE workgroup pulls)
+  auto fwd_tile_rows = [&](int wc) {
+    int r = wc <= 960 ? 64 : (wc <= 3968 ? 32 : 16); // 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
+    r     = std::min(r, std::max(16, fwd_rows_cap));
+    while (r > 16 && (long long)r * wc * 8 > (long long)fwd_tile_kb * 1024) r >>= 1;
+    return r;
+  };
   // ... and shorter on a level whose wide panels would field fewer than ~4 workgroups per CU that way (the top of a small tree: a
   // tile there is a long chain of loads, the level is bound by the number of chains in flight): 16-row units of the wide panels per level
   std::vector<long long> wide_rows16(nlev, 0);
@@ -1322,7 +1400,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     for (idx_t k = 0; k < D.nblk; ++k)
       if (D.ldw[k] * cs > NARROW) wide_rows16[D.height[k]] += ((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k]) + 15) / 16;
   }
-  const long long fwd_want = 512 / std::max(1, groups);
+  const long long fwd_want = envi("HPDDM_HIP_FWD_WANT", 512) / std::max(1, groups);
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     for (idx_t k = 0; k < D.nblk; ++k) {
