@@ -619,22 +619,15 @@ static int bcg_impl(Schwarz &A, const double *b, double *x, double *history, int
       gram(Z.p, Z.p, G);
       for (int nu = 0; nu < mu; ++nu) zz[nu] = G[(size_t)nu * mu + nu];
     }
-    int    conv = 0, which = 0;
-    double worst = -1.0;
-    for (int nu = 0; nu < mu; ++nu) {
-      const double pt = std::sqrt(zz[nu]);
-      if ((tol > 0.0 && pt / norm[nu] <= tol) || (tol < 0.0 && pt <= -tol)) ++conv;
-      const double key = tol > 0.0 ? pt / norm[nu] : pt;
-      if (key > worst) {
-        worst = key;
-        which = nu;
-      }
-    }
-    const double beta = std::sqrt(zz[which]);
+    // The reference's test (include/HPDDM_CG.hpp:276, without -hpddm_enlarge_krylov_subspace): checkBlockConvergence is handed
+    // rho + 2 mu^2 - mu / (m[0] <= 1 ? mu : 1) -- the entry of the LAST right-hand side -- and t = mu, so it looks at ONE residual,
+    // that of the last right-hand side, against norm[0], the reference norm of the FIRST one, and prints those two.  Reproduced as
+    // is (round 5; until then all the right-hand sides were tested and the history of the 6-rank fixture needed a 5 % band).
+    const double beta = std::sqrt(zz[mu - 1]);
     if (history && nhist < history_cap) history[nhist] = beta;
     ++nhist;
-    if (verbosity > 2) printf("BCG: %3d %e %e %e < %e\n", i, beta, norm[which], beta / norm[which], tol);
-    if (conv == mu) break;
+    if (verbosity > 2) printf("BCG: %3d %e %e %e < %e\n", i, beta, norm[0], beta / norm[0], tol);
+    if ((tol > 0.0 && beta / norm[0] <= tol) || (tol < 0.0 && beta <= -tol)) break;
     if (++i <= max_it) {
       rho2 = rhs;                             // the new rho, kept for the next iteration
       std::vector<double> U;
@@ -1441,7 +1434,9 @@ int Schwarz::krylov_solve(const double *b, double *x, int mu, double *history, i
   }
   if (is_complex) { // K = std::complex<double>: krylov_complex.hip
     if (method == 2) return cg(b, x, mu, history, history_cap); // real coefficients: the recurrences on the (re, im) arrays are the complex method
-    HH_CHECK(method == 0 || method == 1 || method == 4 || method == 5, "krylov_method: gmres, bgmres, gcrodr, bgcrodr, cg, richardson and none are built for complex scalars (the reference's own complex bcg / bfbcg diverge)");
+    HH_CHECK(method == 0 || method == 1 || method == 3 || method == 4 || method == 5 || method == 6, "krylov_method: unknown value");
+    if (method == 3) return bcg_z(b, x, mu, history, history_cap);
+    if (method == 6) return bfbcg_z(b, x, mu, history, history_cap);
     if (method == 4) return gcrodr_z(b, x, mu, history, history_cap);
     if (method == 5) return bgcrodr_z(b, x, mu, history, history_cap);
     return method == 1 ? bgmres_z(b, x, mu, history, history_cap) : gmres_z(b, x, mu, history, history_cap);

@@ -1637,6 +1637,364 @@ int Schwarz::bgcrodr_z(const double *b, double *x, int mu, double *history, int 
   return it;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Block CG and breakdown-free block CG for K = std::complex<double>: IterativeMethod::BCG / BFBCG (include/HPDDM_CG.hpp:169-337,
+// 342-482) -- the real methods of bgmres.hip in complex arithmetic, on a Hermitian positive definite operator with a symmetric
+// preconditioner (ASM / SORAS).  What the complex build of the reference does, step for step: Gram blocks V^H D W (gemmt / gemm with
+// Wrapper<K>::transc), their upper triangle mirrored through conj, Hermitian factorisations that read the REAL part of the diagonal
+// only (zpotrf / zppsv / zposv / zpptrf: p^H D A p has a complex diagonal when D does not commute with A -- dropping its imaginary
+// part is what the reference's LAPACK does, and 5e-6 of the first residual), triangular solves with gamma^H.  Pinned on five runs
+// of the compiled reference (tests/golden/z_p30_*cg*_hpd_*.npz, z_p30_bfbcg_*: 20 / 15 / 16 / 20 iterations).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// G = U^H U, U upper (row-major n x n inside ld), from the upper triangle of G and the real part of its diagonal; false on a
+// non-positive pivot
+bool zchol_upper(int n, int ld, const std::vector<cplx> &G, std::vector<cplx> &U)
+{
+  U.assign((size_t)ld * ld, 0.0);
+  for (int j = 0; j < n; ++j) {
+    double dj = G[(size_t)j * ld + j].real();
+    for (int k = 0; k < j; ++k) dj -= std::norm(U[(size_t)k * ld + j]);
+    if (!(dj > 0.0)) return false;
+    dj                    = std::sqrt(dj);
+    U[(size_t)j * ld + j] = dj;
+    for (int c = j + 1; c < n; ++c) {
+      cplx v = G[(size_t)j * ld + c];
+      for (int k = 0; k < j; ++k) v -= std::conj(U[(size_t)k * ld + j]) * U[(size_t)k * ld + c];
+      U[(size_t)j * ld + c] = v / dj;
+    }
+  }
+  return true;
+}
+// X (n rows used, nc columns, row-major inside ld) <- U^{-H} X
+void zsolve_uh(int n, int nc, int ld, const std::vector<cplx> &U, std::vector<cplx> &X)
+{
+  for (int c = 0; c < nc; ++c)
+    for (int i = 0; i < n; ++i) {
+      cplx v = X[(size_t)i * ld + c];
+      for (int k = 0; k < i; ++k) v -= std::conj(U[(size_t)k * ld + i]) * X[(size_t)k * ld + c];
+      X[(size_t)i * ld + c] = v / U[(size_t)i * ld + i];
+    }
+}
+// X <- U^{-1} X
+void zsolve_u(int n, int nc, int ld, const std::vector<cplx> &U, std::vector<cplx> &X)
+{
+  for (int c = 0; c < nc; ++c)
+    for (int i = n - 1; i >= 0; --i) {
+      cplx v = X[(size_t)i * ld + c];
+      for (int k = i + 1; k < n; ++k) v -= U[(size_t)i * ld + k] * X[(size_t)k * ld + c];
+      X[(size_t)i * ld + c] = v / U[(size_t)i * ld + i];
+    }
+}
+} // namespace
+
+// Returns -2 when the reference would hand over to CG (rank-deficient block, a Gram matrix that is not positive definite).
+template <int MU>
+int zbcg_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
+{
+  constexpr int mu = MU;
+  A.reserve(mu);
+  const double tol       = A.getopt("tol", 1.0e-6);
+  const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int    verbosity = (int)A.getopt("verbosity", 0);
+  ZBlocks<MU>     Z(A, 1);
+  const long long cnt = Z.cnt;
+  hipStream_t     st  = Z.st;
+  DevBuf<double>  P, Zv, R, T;
+  P.alloc((size_t)cnt), Zv.alloc((size_t)cnt), R.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  auto gram = [&](const double *V, const double *W, std::vector<cplx> &G) { Z.gram(V, 1, W, G); }; // G[a * mu + b] = <V[., a], W[., b]>_D = sum d conj(V_a) W_b
+  auto herm_upper = [&](std::vector<cplx> &G) { // gemmt "U" + the mirror through Wrapper<K>::conj
+    for (int a = 0; a < mu; ++a)
+      for (int c = 0; c < a; ++c) G[(size_t)a * mu + c] = std::conj(G[(size_t)c * mu + a]);
+  };
+  // QR of the block W in the D inner product: gamma (upper), W <- W gamma^{-1}; false when rank deficient
+  auto cholqr = [&](double *W, std::vector<cplx> &gamma) {
+    std::vector<cplx> G;
+    gram(W, W, G);
+    if (!zchol_upper(mu, mu, G, gamma)) return false;
+    std::vector<cplx> Ginv((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) Ginv[(size_t)c * mu + c] = 1.0;
+    zsolve_u(mu, mu, mu, gamma, Ginv);
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    Z.axpy(T.p, 1, Ginv, 1.0, 0.0, W);
+    return true;
+  };
+  std::vector<cplx>   rho, rho2, rhs, gamma, U;
+  std::vector<double> norm(mu), zz(mu);
+  A.start(b, x, mu);
+  A.gmv(x, Zv.p, mu);
+  Z.axpby(1.0, b, -1.0, Zv.p, R.p);
+  A.apply(R.p, P.p, mu);
+  gram(R.p, P.p, rho);
+  herm_upper(rho);
+  rho2 = rho;
+  {
+    double big = 0.0;
+    for (const cplx &v : rho) big = std::max(big, std::abs(v));
+    if (!(big > 10.0 * std::numeric_limits<double>::epsilon())) return -2;
+  }
+  if (!cholqr(P.p, gamma)) return -2;
+  for (int nu = 0; nu < mu; ++nu) {
+    double v = 0.0;
+    for (int k = 0; k <= nu; ++k) v += std::norm(gamma[(size_t)k * mu + nu]);
+    norm[nu] = std::sqrt(v);
+  }
+  int i = 1, nhist = 0;
+  while (i <= max_it) {
+    A.gmv(P.p, Zv.p, mu);
+    zsolve_uh(mu, mu, mu, gamma, rho2);      // rho2 <- gamma^{-H} rho2
+    gram(P.p, Zv.p, rhs);                    // p^H D A p
+    herm_upper(rhs);
+    if (!zchol_upper(mu, mu, rhs, U)) return -2; // zppsv
+    zsolve_uh(mu, mu, mu, U, rho2);
+    zsolve_u(mu, mu, mu, U, rho2);           // rho2 = alpha
+    Z.axpy(P.p, 1, rho2, 1.0, 1.0, x);       // x += p alpha
+    Z.axpy(Zv.p, 1, rho2, -1.0, 1.0, R.p);   // r -= A p alpha
+    A.apply(R.p, Zv.p, mu);                  // z = M^{-1} r
+    gram(R.p, Zv.p, rhs);                    // new rho = r^H D z
+    herm_upper(rhs);
+    {
+      std::vector<cplx> G;
+      gram(Zv.p, Zv.p, G);
+      for (int nu = 0; nu < mu; ++nu) zz[nu] = G[(size_t)nu * mu + nu].real();
+    }
+    // the reference's test (include/HPDDM_CG.hpp:276, see bcg_impl of bgmres.hip): the residual of the LAST right-hand side against the
+    // reference norm of the FIRST one
+    const double pt = std::sqrt(zz[mu - 1]);
+    if (history && nhist < history_cap) history[nhist] = pt;
+    ++nhist;
+    if (verbosity > 2) printf("BCG: %3d %e %e %e < %e\n", i, pt, norm[0], pt / norm[0], tol);
+    if ((tol > 0.0 && pt / norm[0] <= tol) || (tol < 0.0 && pt <= -tol)) break;
+    if (++i <= max_it) {
+      rho2 = rhs;                            // the new rho, kept for the next iteration
+      if (!zchol_upper(mu, mu, rho, U)) return -2; // zposv: rhs <- rho_old^{-1} rho_new
+      zsolve_uh(mu, mu, mu, U, rhs);
+      zsolve_u(mu, mu, mu, U, rhs);
+      std::vector<cplx> brhs((size_t)mu * mu, 0.0); // trmm: gamma * rhs
+      for (int a = 0; a < mu; ++a)
+        for (int c = 0; c < mu; ++c) {
+          cplx v = 0.0;
+          for (int k = a; k < mu; ++k) v += gamma[(size_t)a * mu + k] * rhs[(size_t)k * mu + c];
+          brhs[(size_t)a * mu + c] = v;
+        }
+      HIP_OK(hipMemcpyAsync(T.p, P.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st)); // p <- z + p brhs
+      HIP_OK(hipMemcpyAsync(P.p, Zv.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      Z.axpy(T.p, 1, brhs, 1.0, 1.0, P.p);
+      if (!cholqr(P.p, gamma)) return -2;
+      rho = rho2;
+    }
+  }
+  if (verbosity) {
+    if (i != max_it + 1) printf("BCG converges after %d iteration%s\n", i, i > 1 ? "s" : "");
+    else printf("BCG does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(i, max_it);
+}
+
+// Returns -2 if the d x d matrix P^H A P is not positive definite (the caller then runs CG).
+template <int MU>
+int zbfbcg_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap)
+{
+  constexpr int mu = MU;
+  A.reserve(mu);
+  const double tol = A.getopt("tol", 1.0e-6), defl_tol = A.getopt("deflation_tol", -1.0);
+  const bool   deflation = defl_tol > -0.9;
+  const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
+  const int    verbosity = (int)A.getopt("verbosity", 0);
+  ZBlocks<MU>     Z(A, 1);
+  const long long cnt = Z.cnt;
+  hipStream_t     st  = Z.st;
+  DevBuf<double>  P, Q, Zv, R, T;
+  P.alloc((size_t)cnt), Q.alloc((size_t)cnt), Zv.alloc((size_t)cnt), R.alloc((size_t)cnt), T.alloc((size_t)cnt);
+  auto gram = [&](const double *V, const double *W, std::vector<cplx> &G) { Z.gram(V, 1, W, G); };
+  // columns of V permuted in place: forward = new column k is old column piv[k] (lapmt forwrd = 1), backward its inverse
+  auto permute = [&](double *V, const std::vector<int> &piv, bool forward) {
+    std::vector<cplx> Pm((size_t)mu * mu, 0.0);
+    for (int k = 0; k < mu; ++k) {
+      if (forward) Pm[(size_t)piv[k] * mu + k] = 1.0;
+      else Pm[(size_t)k * mu + piv[k]] = 1.0;
+    }
+    HIP_OK(hipMemcpyAsync(T.p, V, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    Z.axpy(T.p, 1, Pm, 1.0, 0.0, V);
+  };
+  auto permute_host = [&](std::vector<double> &v, const std::vector<int> &piv, bool forward) {
+    std::vector<double> o(mu);
+    for (int k = 0; k < mu; ++k) {
+      if (forward) o[k] = v[piv[k]];
+      else o[piv[k]] = v[k];
+    }
+    v = o;
+  };
+  // RRQR of the block W (include/HPDDM_iterative.hpp:583-595): CholQR keeping its rank, or with -hpddm_deflation_tol the pivoted
+  // Cholesky (zpstrf "U") of the Gram matrix trimmed at that tolerance; W <- (W Pi)(:, :d) R11^{-1}, zero columns beyond
+  std::vector<cplx> Rm;
+  std::vector<int>  piv(mu);
+  auto rrqr = [&](double *W) {
+    std::vector<cplx> G;
+    gram(W, W, G);
+    Rm.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int j = 0; j < mu; ++j) {
+      int    q    = j;
+      double best = G[(size_t)j * mu + j].real();
+      for (int k = 0; k < j; ++k) best -= std::norm(Rm[(size_t)k * mu + j]);
+      if (deflation)
+        for (int c = j + 1; c < mu; ++c) {
+          double dj = G[(size_t)c * mu + c].real();
+          for (int k = 0; k < j; ++k) dj -= std::norm(Rm[(size_t)k * mu + c]);
+          if (dj > best) best = dj, q = c;
+        }
+      if (!(best > 0.0)) {
+        rank = j;
+        break;
+      }
+      if (q != j) {
+        for (int c = 0; c < mu; ++c) std::swap(G[(size_t)j * mu + c], G[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(G[(size_t)r * mu + j], G[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(Rm[(size_t)r * mu + j], Rm[(size_t)r * mu + q]);
+        std::swap(piv[j], piv[q]);
+      }
+      const double dj        = std::sqrt(best);
+      Rm[(size_t)j * mu + j] = dj;
+      for (int c = j + 1; c < mu; ++c) {
+        cplx v = G[(size_t)j * mu + c];
+        for (int k = 0; k < j; ++k) v -= std::conj(Rm[(size_t)k * mu + j]) * Rm[(size_t)k * mu + c];
+        Rm[(size_t)j * mu + c] = v / dj;
+      }
+    }
+    if (!deflation) // potrf leaves the rest of the upper triangle as it was: the norms below read it
+      for (int r = rank; r < mu; ++r)
+        for (int c = r; c < mu; ++c) Rm[(size_t)r * mu + c] = G[(size_t)r * mu + c];
+    if (deflation)
+      while (rank > 1 && std::abs(Rm[(size_t)(rank - 1) * mu + rank - 1] / Rm[0]) <= defl_tol) --rank;
+    std::vector<cplx> Rinv((size_t)mu * mu, 0.0), C((size_t)mu * mu, 0.0);
+    for (int c = 0; c < rank; ++c)
+      for (int i = c; i >= 0; --i) {
+        cplx v = (i == c) ? 1.0 : 0.0;
+        for (int k = i + 1; k <= c; ++k) v -= Rm[(size_t)i * mu + k] * Rinv[(size_t)k * mu + c];
+        Rinv[(size_t)i * mu + c] = v / Rm[(size_t)i * mu + i];
+      }
+    for (int k = 0; k < rank; ++k)
+      for (int c = 0; c < rank; ++c) C[(size_t)piv[k] * mu + c] = Rinv[(size_t)k * mu + c];
+    HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+    Z.axpy(T.p, 1, C, 1.0, 0.0, W);
+    return rank;
+  };
+  // X (d rows used, mu columns) <- (U^H U)^{-1} X; rows beyond d are set to zero
+  auto potrs_d = [&](const std::vector<cplx> &U, int d, std::vector<cplx> &X) {
+    zsolve_uh(d, mu, mu, U, X);
+    zsolve_u(d, mu, mu, U, X);
+    for (int i = d; i < mu; ++i)
+      for (int c = 0; c < mu; ++c) X[(size_t)i * mu + c] = 0.0;
+  };
+  A.start(b, x, mu);
+  A.gmv(x, T.p, mu);
+  Z.axpby(1.0, b, -1.0, T.p, R.p);
+  A.apply(R.p, P.p, mu);
+  int                 d = rrqr(P.p);
+  std::vector<double> norm(mu);
+  std::vector<cplx>   G, U, alpha, beta;
+  for (int nu = 0; nu < mu; ++nu) {
+    double v = 0.0;
+    for (int r = 0; r <= nu; ++r) v += std::norm(Rm[(size_t)r * mu + nu]);
+    norm[nu] = std::sqrt(v);
+  }
+  if (deflation) {
+    // (the columns of R are in pivoted order already; the reference permutes `norm` once more with x and r,
+    // include/HPDDM_CG.hpp:395-399 -- reproduced, the convergence test depends on it)
+    permute(x, piv, true);
+    permute(R.p, piv, true);
+    permute_host(norm, piv, true);
+  }
+  int i = d != 0 ? 1 : 0, nhist = 0;
+  while (i <= max_it && d != 0) {
+    A.gmv(P.p, Q.p, mu);
+    gram(P.p, Q.p, G);
+    for (int a = 0; a < d; ++a)
+      for (int c = 0; c < a; ++c) G[(size_t)a * mu + c] = std::conj(G[(size_t)c * mu + a]); // gemmt "U", Hermitian packed storage
+    gram(P.p, R.p, alpha);
+    if (!zchol_upper(d, mu, G, U)) return -2; // zpptrf: the real part of the diagonal
+    potrs_d(U, d, alpha);
+    Z.axpy(P.p, 1, alpha, 1.0, 1.0, x);
+    Z.axpy(Q.p, 1, alpha, -1.0, 1.0, R.p);
+    A.apply(R.p, Zv.p, mu);
+    gram(Q.p, Zv.p, beta);
+    std::vector<cplx> zz;
+    gram(Zv.p, Zv.p, zz);
+    int    conv = 0, which = 0;
+    double best = -1.0;
+    for (int nu = 0; nu < mu; ++nu) {
+      const double pt = std::sqrt(zz[(size_t)nu * mu + nu].real());
+      if ((tol > 0.0 && pt / norm[nu] <= tol) || (tol < 0.0 && pt <= -tol)) ++conv;
+      if (nu < d && pt / norm[nu] > best) best = pt / norm[nu], which = nu;
+    }
+    const double res = best * norm[which];
+    if (history && nhist < history_cap) history[nhist] = res;
+    ++nhist;
+    if (verbosity > 2) {
+      printf("BFBCG: %3d %e %e %e < %e", i, res, norm[which], best, tol);
+      if (d != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - d);
+      printf("\n");
+    }
+    if (conv == mu) break;
+    if (++i <= max_it) {
+      potrs_d(U, d, beta);
+      HIP_OK(hipMemcpyAsync(Q.p, P.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st)); // Q is free again: the old directions
+      HIP_OK(hipMemcpyAsync(P.p, Zv.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      Z.axpy(Q.p, 1, beta, -1.0, 1.0, P.p);
+      if (deflation) {
+        permute(x, piv, false);
+        permute(P.p, piv, false);
+        permute(R.p, piv, false);
+        permute_host(norm, piv, false);
+      }
+      d = rrqr(P.p);
+      if (deflation) {
+        permute(x, piv, true);
+        permute(R.p, piv, true);
+        permute_host(norm, piv, true);
+      }
+    }
+  }
+  if (deflation) permute(x, piv, false);
+  if (verbosity) {
+    if (i != max_it + 1) printf("BFBCG converges after %d iteration%s\n", i, i > 1 ? "s" : "");
+    else printf("BFBCG does not converge after %d iteration%s\n", max_it, max_it > 1 ? "s" : "");
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  return std::min(i, max_it);
+}
+
+// the hand-overs of the reference (include/HPDDM_CG.hpp:180-186, 351-357): a preconditioner that is not symmetric -> GMRES;
+// flexible -> CG; a breakdown -> CG from the current iterate
+static bool zcg_family_goes_to_gmres(Schwarz &A)
+{
+  const int method = (int)A.getopt("schwarz_method", SCHWARZ_METHOD_RAS), correction = (int)A.getopt("schwarz_coarse_correction", COARSE_CORRECTION_NONE);
+  return !A.custom_mv && (!(method == SCHWARZ_METHOD_SORAS || method == SCHWARZ_METHOD_ASM || method == SCHWARZ_METHOD_NONE) || (A.coarse_ready && correction == COARSE_CORRECTION_DEFLATED));
+}
+int Schwarz::bcg_z(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK((factored || custom_mv) && is_complex, "complex BCG: complex operator and CallNumfact first");
+  if (zcg_family_goes_to_gmres(*this)) return gmres_z(b, x, mu, history, history_cap);
+  if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
+  int it;
+  HH_MU_DISPATCH(zbcg_impl, "BCG")
+  if (it == -2) return cg(b, x, mu, history, history_cap); // rank-deficient block: CG, as the reference does
+  return it;
+}
+int Schwarz::bfbcg_z(const double *b, double *x, int mu, double *history, int history_cap)
+{
+  HH_CHECK((factored || custom_mv) && is_complex, "complex BFBCG: complex operator and CallNumfact first");
+  if (zcg_family_goes_to_gmres(*this)) return gmres_z(b, x, mu, history, history_cap);
+  if ((int)getopt("variant", VARIANT_LEFT) == VARIANT_FLEXIBLE) return cg(b, x, mu, history, history_cap);
+  int it;
+  HH_MU_DISPATCH(zbfbcg_impl, "BFBCG")
+  if (it == -2) return cg(b, x, mu, history, history_cap);
+  return it;
+}
+
 int Schwarz::gmres_z(const double *b, double *x, int mu, double *history, int history_cap)
 {
   HH_CHECK((factored || custom_mv) && is_complex, "complex GMRES: complex operator and CallNumfact first");

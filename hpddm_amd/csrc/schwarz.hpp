@@ -173,6 +173,8 @@ struct Schwarz {
   int  gmres_z(const double *b, double *x, int mu, double *history, int history_cap);  // krylov_complex.hip
   int  bgmres_z(const double *b, double *x, int mu, double *history, int history_cap);
   int  bgcrodr_z(const double *b, double *x, int mu, double *history, int history_cap); // block GCRO-DR in complex arithmetic
+  int  bcg_z(const double *b, double *x, int mu, double *history, int history_cap);     // block CG / breakdown-free block CG in complex arithmetic
+  int  bfbcg_z(const double *b, double *x, int mu, double *history, int history_cap);
   int  gcrodr_z(const double *b, double *x, int mu, double *history, int history_cap);  // GCRO-DR in complex arithmetic, one right-hand side at a time
   void set_subdomain(int s, int n, const int *ia, const int *ja, const double *a, bool sym, int base, int nneigh, const int *list, const int *sizes, const int *const *conn);
   void expand_matrix(int s);   // the full 0-based CSR of subdomain s (GMV, coarse assembly) from the matrix as handed over, once

@@ -476,17 +476,26 @@ def cg(orc, b, tol=1e-6, max_it=100):
 def bcg(orc, b, tol=1e-6, max_it=100):
     """IterativeMethod::BCG (include/HPDDM_CG.hpp:169-337): block CG whose search directions are kept D-orthonormal by a CholQR
     (gamma) every iteration.  Returns (iterations, solution, history, handed_over): on a rank-deficient block the reference
-    restarts with CG from the current iterate -- reported through `handed_over`, with CG's own count and history."""
-    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    restarts with CG from the current iterate -- reported through `handed_over`, with CG's own count and history.
+    K = std::complex<double>: the same code with conjugate transposes (gemmt / trsm with Wrapper<K>::transc, the mirror of the upper
+    triangle through Wrapper<K>::conj, zppsv / zposv on Hermitian matrices: include/HPDDM_CG.hpp:205-217, 251-303)."""
+    dt = np.complex128 if any(np.iscomplexobj(v) for v in b) else np.float64
+    b = [np.asarray(v, dtype=dt).reshape(v.shape[0], -1) for v in b]
     mu = b[0].shape[1]
 
     def sym_upper(G):
-        return np.triu(G) + np.triu(G, 1).T        # gemmt "U" + mirror
+        H = np.triu(G) + np.triu(G, 1).conj().T     # gemmt "U" + mirror (conjugated for complex K)
+        return H
+
+    def herm(G):                                    # what zppsv / zposv factorise: the real part of the diagonal only
+        H = G.copy()
+        H[np.diag_indices_from(H)] = np.real(np.diag(H))
+        return H
 
     def cholqr(W):
-        G = _gram(orc, W, W)
+        G = sym_upper(_gram(orc, W, W))
         try:
-            U = np.linalg.cholesky(G).T            # G = U^T U, U upper
+            U = np.linalg.cholesky(G).conj().T     # G = U^H U, U upper
         except np.linalg.LinAlgError:
             return None, W
         Ui = np.linalg.inv(U)
@@ -511,31 +520,33 @@ def bcg(orc, b, tol=1e-6, max_it=100):
     i = 1
     while i <= max_it:
         z = orc.gmv(p)
-        rho2 = np.linalg.solve(gamma.T, rho2)
+        rho2 = np.linalg.solve(gamma.conj().T, rho2)
         pap = sym_upper(_gram(orc, p, z))
         try:
-            np.linalg.cholesky(pap)
+            np.linalg.cholesky(herm(pap))
         except np.linalg.LinAlgError:
             return fallback(x)
-        alpha = np.linalg.solve(pap, rho2)
+        alpha = np.linalg.solve(herm(pap), rho2)
         x = [xx + pp @ alpha for xx, pp in zip(x, p)]
         r = [rr - zz @ alpha for rr, zz in zip(r, z)]
         z = orc.apply(r)
         rhs = sym_upper(_gram(orc, r, z))
-        pt = np.sqrt(np.diag(_gram(orc, z, z)))
-        conv = int(np.sum(pt / norm <= tol))
-        which = int(np.argmax(pt / norm))
-        hist.append((i, pt[which], norm[which]))
-        if conv == mu:
+        pt = np.sqrt(np.real(np.diag(_gram(orc, z, z))))
+        # The reference's test (include/HPDDM_CG.hpp:276, without -hpddm_enlarge_krylov_subspace): checkBlockConvergence is handed
+        # `rho + 2 mu^2 - mu / (m[0] <= 1 ? mu : 1)` = the entry of the LAST right-hand side and t = mu, so it looks at ONE residual --
+        # that of the last right-hand side -- against norm[0], the reference norm of the FIRST one, and prints those two.
+        # Reproduced as is: the iteration count and the history depend on it.
+        hist.append((i, pt[mu - 1], norm[0]))
+        if pt[mu - 1] / norm[0] <= tol:
             break
         i += 1
         if i <= max_it:
             rho2 = rhs.copy()
             try:
-                np.linalg.cholesky(rho)
+                np.linalg.cholesky(herm(rho))
             except np.linalg.LinAlgError:
                 return fallback(x)
-            beta = gamma @ np.linalg.solve(rho, rhs)
+            beta = gamma @ np.linalg.solve(herm(rho), rhs)
             pnew = [zz + pp @ beta for zz, pp in zip(z, p)]
             gamma, p = cholqr(pnew)
             if gamma is None:
@@ -549,21 +560,23 @@ def bfbcg(orc, b, tol=1e-6, max_it=100, deflation_tol=-1.0):
     directions goes through RRQR (include/HPDDM_iterative.hpp:583-595): a CholQR whose rank is kept (deflation_tol < -0.9), or
     the pivoted Cholesky of its Gram matrix trimmed at deflation_tol; the iteration then runs on the `deflated` leading
     directions while all mu solutions and residuals are updated (columns permuted by the pivots in between).
-    Returns (iterations, solution, history)."""
-    b = [np.asarray(v, dtype=np.float64).reshape(v.shape[0], -1) for v in b]
+    Returns (iterations, solution, history).  K = std::complex<double>: conjugate transposes throughout (Hermitian Gram matrices,
+    zpotrf / zpstrf / zpptrf), same steps."""
+    dt = np.complex128 if any(np.iscomplexobj(v) for v in b) else np.float64
+    b = [np.asarray(v, dtype=dt).reshape(v.shape[0], -1) for v in b]
     mu = b[0].shape[1]
 
     def rrqr(W):
         G = _gram(orc, W, W)
         if deflation_tol < -0.9:
-            piv, R, rank = np.arange(mu), np.zeros((mu, mu)), mu
+            piv, R, rank = np.arange(mu), np.zeros((mu, mu), dtype=dt), mu
             for j in range(mu):                       # potrf "U": the rank is where it stops (QR, include/HPDDM_iterative.hpp:629-633)
-                dj = G[j, j] - R[:j, j] @ R[:j, j]
+                dj = np.real(G[j, j] - R[:j, j].conj() @ R[:j, j])
                 if not dj > 0.0:
                     rank = j
                     break
                 R[j, j] = np.sqrt(dj)
-                R[j, j + 1:] = (G[j, j + 1:] - R[:j, j] @ R[:j, j + 1:]) / R[j, j]
+                R[j, j + 1:] = (G[j, j + 1:] - R[:j, j].conj() @ R[:j, j + 1:]) / R[j, j]
             full = G.copy()                           # potrf leaves the rest of the upper triangle of G untouched
             full[:rank, :] = R[:rank, :]
             R = np.triu(full)
@@ -602,12 +615,13 @@ def bfbcg(orc, b, tol=1e-6, max_it=100, deflation_tol=-1.0):
         pd = [pp[:, :d] for pp in p]
         q = orc.gmv(pd)
         gam = _gram(orc, pd, q)
-        gam = np.triu(gam) + np.triu(gam, 1).T        # gemmt "U", packed storage
+        gam = np.triu(gam) + np.triu(gam, 1).conj().T  # gemmt "U", packed storage (Hermitian for complex K)
+        gam[np.diag_indices_from(gam)] = np.real(np.diag(gam))  # (zpptrf reads the real part of the diagonal only)
         alpha = np.linalg.solve(gam, _gram(orc, pd, r))
         x = [xx + pp @ alpha for xx, pp in zip(x, pd)]
         r = [rr - qq @ alpha for rr, qq in zip(r, q)]
         z = orc.apply(r)
-        pt = np.sqrt(np.diag(_gram(orc, z, z)))
+        pt = np.sqrt(np.real(np.diag(_gram(orc, z, z))))
         conv = int(np.sum(pt / norm <= tol))
         which = int(np.argmax(pt[:d] / norm[:d]))
         hist.append((i, pt[which], norm[which]))

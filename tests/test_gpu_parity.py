@@ -370,14 +370,16 @@ def test_bgmres_matches_reference(name):
     A.destroy()
 
 
-def test_cg_matches_reference():
-    """PCG with the (symmetric) additive Schwarz preconditioner: the reference's 40 iterations"""
-    g = gu.load("p40_cg_asm")
+@pytest.mark.parametrize("name,its", [("p40_cg_asm", 40), ("z_p30_cg_asm_hpd_mu3", 17)])
+def test_cg_matches_reference(name, its):
+    """PCG with the (symmetric) additive Schwarz preconditioner: the reference's 40 iterations; and the reference built
+    for K = std::complex<double> on a Hermitian positive definite operator with three complex right-hand sides: 17"""
+    g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
     f = gu.vecs(g, "f")
     it, sol, hist = A.solve(f, history=True)
-    assert it == int(g["iterations_r0"][0]) == 40
+    assert it == int(g["iterations_r0"][0]) == its
     ref = g["history"]
     assert len(hist) == len(ref) and np.all(np.abs(hist - ref[:, 1]) <= 1e-4 * ref[:, 1])
     _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
@@ -437,11 +439,12 @@ def test_richardson_and_no_krylov_match_reference():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4"])
+@pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4", "z_p30_bfbcg_asm_hpd_mu3", "z_p30_bfbcg_asm_rhs_deflation_mu4"])
 def test_bfbcg_matches_reference(name):
     """Breakdown-free block CG (include/HPDDM_CG.hpp:342-482), plain and with -hpddm_deflation_tol on a block whose last
     right-hand side is f_0 + 2 f_1 (one direction deflated at every iteration): the reference's 31 / 32 iterations,
-    residual history, solution and final residuals"""
+    residual history, solution and final residuals.  The z_ fixtures: the reference built for K = std::complex<double> on a
+    Hermitian positive definite operator with complex right-hand sides -- 15 / 16 iterations (krylov_complex.hip: zbfbcg_impl)."""
     g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
@@ -456,13 +459,15 @@ def test_bfbcg_matches_reference(name):
     A.destroy()
 
 
-@pytest.mark.parametrize("name,skip", [("p30_6ranks_bcg_asm_sym_mu2", 0), ("p40_bcg_asm_mu3", 4)])
+@pytest.mark.parametrize("name,skip", [("p30_6ranks_bcg_asm_sym_mu2", 0), ("p40_bcg_asm_mu3", 4), ("z_p30_bcg_asm_hpd_mu3", 0), ("z_p30_6ranks_bcg_asm_hpd_mu2", 0)])
 def test_bcg_matches_reference(name, skip):
-    """Block CG (include/HPDDM_CG.hpp:169-337).  On these inputs the reference's own BCG does not reach 1e-6 in 100 iterations
+    """Block CG (include/HPDDM_CG.hpp:169-337).  On the real inputs the reference's own BCG does not reach 1e-6 in 100 iterations
     (first case) or meets a rank-deficient block after 4 iterations and hands over to CG (second case, `skip` = the BCG lines
     of its log before the hand-over): what is pinned is that we do exactly the same -- iteration count, residual history,
-    final residuals.  The history prints the right-hand side with the largest relative residual; with two that are equal to
-    4 digits the pick flips between the runs, hence the few-percent band on the history and the tight one on the result."""
+    final residuals.  The reference tests (and prints) the residual of the LAST right-hand side against the reference norm of the
+    FIRST one (include/HPDDM_CG.hpp:276): reproduced since round 5 -- the histories agree to 1e-3 where a 5 % band was needed
+    while every right-hand side was tested.  The z_ fixtures: K = std::complex<double>, Hermitian positive definite operator, complex
+    right-hand sides: 20 iterations on 4 and on 6 subdomains (krylov_complex.hip: zbcg_impl)."""
     g = gu.load(name)
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
@@ -471,7 +476,10 @@ def test_bcg_matches_reference(name, skip):
     assert it == int(g["iterations_r0"][0])
     ref = g["history"][skip:]
     assert len(hist) == len(ref)
-    assert np.all(np.abs(hist - ref[:, 1]) <= 0.05 * ref[:, 1])
+    tight = 80 if name == "p30_6ranks_bcg_asm_sym_mu2" else len(ref)   # (a run that does not converge drifts in its last 20 iterations: 1e-4 ... 2e-4 in the oracle too)
+    assert np.all(np.abs(hist - ref[:, 1])[:tight] <= 1e-3 * ref[:tight, 1]) and np.all(np.abs(hist - ref[:, 1]) <= 0.05 * ref[:, 1])
+    if name.startswith("z_"):
+        _close(sol, gu.vecs(g, "sol"), 1e-7, "solution")
     assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-3)
     A.destroy()
 

@@ -133,11 +133,15 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6), ("z_p30_bgmres_rhs_deflation_mu4", "bgmres", 2e-6),
     ("p40_bgmres_mgs_qrmgs_mu3", "bgmres", 1e-5), ("p40_bgmres_qrcgs_mu3", "bgmres", 1e-5),
     ("p40_bfbcg_asm_mu3", "bfbcg", 1e-5), ("p40_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-5),
-    ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-2), ("p40_bcg_asm_mu3", "bcg", 2e-6)])
+    ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-4), ("p40_bcg_asm_mu3", "bcg", 2e-6),
+    # K = std::complex<double> on a Hermitian positive definite operator: the reference's CG / BCG / BFBCG converge (17 / 20 / 15 / 16 / 20 iterations)
+    ("z_p30_cg_asm_hpd_mu3", "cg", 1e-5), ("z_p30_bcg_asm_hpd_mu3", "bcg", 1e-4), ("z_p30_bfbcg_asm_hpd_mu3", "bfbcg", 1e-4),
+    ("z_p30_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-4), ("z_p30_6ranks_bcg_asm_hpd_mu2", "bcg", 1e-4)])
 def test_other_krylov_methods_match_reference(name, method, tol_hist):
     """CG, Block CG and Block GMRES restated in numpy (oracle/ras_oracle.py: cg, bcg, bgmres) against the runs of the compiled
-    reference: iteration counts, residual histories, final residuals.  (BCG prints the right-hand side with the largest
-    relative residual; with two that agree to 4 digits the pick flips, hence the few-percent band on that one history.  In
+    reference: iteration counts, residual histories, final residuals.  (BCG tests and prints the residual of the LAST right-hand
+    side against the reference norm of the FIRST one, include/HPDDM_CG.hpp:276 -- reproduced; the 100-iteration run that does not
+    converge drifts by 2e-4 at its end.  In
     the second BCG fixture the reference meets a rank-deficient block after 4 iterations and hands over to CG: so do we.
     The BFBCG fixtures (breakdown-free block CG, include/HPDDM_CG.hpp:342-482) stop at 1e-4, before CG's round-off drift.
     The two rhs_deflation fixtures have a last right-hand side f_0 + 2 f_1 and -hpddm_deflation_tol set: one column is
