@@ -251,6 +251,7 @@ int HpddmHipHostSelfTest(void)
       }
     }
     if (const int zc = zkrylov_host_selftest()) return zc; // the complex helpers of krylov_complex.hip (20 ..)
+    if (const int rc = upload_ring_selftest()) return 1000 + rc; // the staging ring of the device levels (numeric_device.hip): batches that wrap around
     { // plan of the contribution-block arena of the device levels (numeric_host.cpp): chunks alive together never overlap, dead ones are reused
       // a tree of 5 levels: fronts 0..7 at height 0 (host), 8..11 at height 1, 12..13 at height 2, 14 at height 3 with one child of height 1
       // (front 11: its block lives through level 2), 15 (root) at height 4
@@ -443,6 +444,7 @@ int HpddmHipSchwarzSetOption(HpddmHipSchwarz *A, const char *key, double value)
   HH_TRY(
     HH_CHECK(A && key, "null argument");
     A->op.opt[key] = value;
+    if (std::string(key) == "geneo_nu") A->op.opt.erase("geneo_nu_requested"); // (a new request: SolveGEVP remembers it on its first call)
     return 0;)
 }
 double HpddmHipSchwarzGetOption(const HpddmHipSchwarz *A, const char *key)
@@ -473,6 +475,7 @@ int HpddmHipSchwarzOptionParse(HpddmHipSchwarz *A, const char *args)
         continue;
       }
       A->op.opt[t] = val.empty() ? 1.0 : parse_value(t, val);
+      if (t == "geneo_nu") A->op.opt.erase("geneo_nu_requested");
     }
     return 0;)
 }

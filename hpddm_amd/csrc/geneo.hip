@@ -222,7 +222,8 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   };
   HH_CHECK(s >= 0 && s < nsub && n == subs[s].n, "SolveGEVP: bad subdomain / size");
   SchwarzSub &S  = subs[s];
-  int         nu = (int)getopt("geneo_nu", 20);
+  const int   nu_req = (int)getopt("geneo_nu_requested", getopt("geneo_nu", 20)); // what the caller asked for -- NOT what another subdomain, finished earlier (two eigenproblems are in flight, hpddm.py: solve_gevp_all), has written back
+  int         nu = nu_req;
   const double threshold = getopt("geneo_threshold", 0.0);
   if (4 * nu > n) nu = std::max(1, n / 4); // same guard as the reference (include/HPDDM_ARPACK.hpp:89)
   const Csr AN = expand(n, ia, ja, a, sym, base);
@@ -476,10 +477,15 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
     while (keep < nu && lam[keep] <= threshold) ++keep; // std::upper_bound of the reference: the values <= threshold are kept, at least one
   }
   S.nu = keep;
-  // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705): visible to HpddmOptionVal / GetOption
+  // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705: every rank into its own Option).  One
+  // operator drives all the local subdomains here, possibly two at a time: the request stays aside, and the option reads the largest
+  // number any local subdomain kept -- the same value whatever the order the eigenproblems finish in
   {
     std::lock_guard<std::mutex> lk(opt_mutex);
-    opt["geneo_nu"] = keep;
+    opt["geneo_nu_requested"] = nu_req;
+    int most = 0;
+    for (const SchwarzSub &t : subs) most = std::max(most, t.nu);
+    opt["geneo_nu"] = most;
   }
   S.Z.assign(X.begin(), X.begin() + (size_t)keep * n);
   S.eigenvalues.assign(lam.begin(), lam.begin() + keep);
@@ -631,7 +637,8 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   };
   HH_CHECK(s >= 0 && s < nsub && is_complex && 2 * n == subs[s].n, "SolveGEVPZ: bad subdomain / size (complex subdomains first: SetSubdomainZ; n complex rows)");
   SchwarzSub  &S  = subs[s];
-  int          nu = (int)getopt("geneo_nu", 20);
+  const int    nu_req = (int)getopt("geneo_nu_requested", getopt("geneo_nu", 20)); // what the caller asked for, not what another subdomain has written back
+  int          nu = nu_req;
   const double threshold = getopt("geneo_threshold", 0.0);
   if (4 * nu > n) nu = std::max(1, n / 4); // same guard as the reference (include/HPDDM_ARPACK.hpp:89)
   const CsrZ AN = expand_z(n, ia, ja, a, sym, base);
@@ -879,8 +886,11 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   HIP_OK(hipStreamSynchronize(st));
   set_vectors_z(s, keep, reinterpret_cast<const double *>(X.data()));
   {
-    std::lock_guard<std::mutex> lk(opt_mutex);
-    opt["geneo_nu"] = keep; // the reference writes the number kept back into the option (include/HPDDM_schwarz.hpp:705)
+    std::lock_guard<std::mutex> lk(opt_mutex); // (the request stays aside, the option reads the largest number kept: see solve_gevp)
+    opt["geneo_nu_requested"] = nu_req;
+    int most = 0;
+    for (const SchwarzSub &t : subs) most = std::max(most, t.nu);
+    opt["geneo_nu"] = most;
   }
   S.eigenvalues.resize(keep), S.eigenvalues_im.resize(keep);
   for (int c = 0; c < keep; ++c) S.eigenvalues[c] = lam[ord[c]].real(), S.eigenvalues_im[c] = lam[ord[c]].imag();

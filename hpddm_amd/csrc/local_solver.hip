@@ -8,10 +8,14 @@
 
 namespace hpddm_hip {
 
+// One process drives one GPU (HpddmHipSetDevice before anything else): the library stream, the pinned staging buffers
+// of staging.hip and the work space of the device levels are process-wide objects created on the device that is current at their
+// first use.  Worker threads of the set-up phases call this too: created once, whatever thread comes first.
 hipStream_t library_stream()
 {
-  static hipStream_t s = nullptr;
-  if (!s) HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  static hipStream_t    s = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] { HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); });
   return s;
 }
 

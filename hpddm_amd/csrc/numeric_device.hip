@@ -606,6 +606,9 @@ static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha,
 struct UploadRing {
   char  *host = nullptr, *dev = nullptr;
   size_t cap = 0, head = 0, flushed = 0, batch = 0; // batch: bytes staged for the front in hand (its pointers must stay valid together)
+  size_t batch_start = 0;                           // where the batch began in this ring, and ...
+  bool   batch_wrapped = false;                     // ... whether the ring wrapped around since: the batch then holds [batch_start, end) AND [0, head)
+  bool   sim = false;                               // host-only double of the ring (upload_ring_selftest): plain memory on both sides, no stream
   std::vector<std::pair<char *, char *>> retired;   // outgrown buffers: pointers into them may still be in use, freed by release_retired()
   std::vector<char>                      retired_pageable;
   hipStream_t *consumers = nullptr; // the streams the staged bytes are consumed on (DeviceScratch::streams): a wrap-around waits for these only
@@ -616,6 +619,7 @@ struct UploadRing {
   static constexpr size_t guard = 4096; // (a guard page at the end of the ring: under rocprofv3 --pmc a copy faulted on the host exactly one byte past the pinned ring)
   void   wait_consumed()
   {
+    if (sim) return;
     if (!consumers) {
       HIP_OK(hipDeviceSynchronize());
       return;
@@ -629,7 +633,8 @@ struct UploadRing {
   void flush(hipStream_t st)
   {
     if (head > flushed) {
-      if (unpinned) {
+      if (sim) std::memcpy(dev + flushed, host + flushed, head - flushed);
+      else if (unpinned) {
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipMemcpy(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice));
       } else HIP_OK(hipMemcpyAsync(dev + flushed, host + flushed, head - flushed, hipMemcpyHostToDevice, st));
@@ -639,10 +644,13 @@ struct UploadRing {
   void free_pair(char *h, char *d, bool pageable)
   {
     if (h) {
-      if (pageable) free(h);
+      if (pageable || sim) free(h);
       else (void)hipHostFree(h);
     }
-    if (d) (void)hipFree(d);
+    if (d) {
+      if (sim) free(d);
+      else (void)hipFree(d);
+    }
   }
   void grow(size_t bytes, hipStream_t st)
   {
@@ -651,26 +659,32 @@ struct UploadRing {
     if (host) retired.emplace_back(host, dev), retired_pageable.push_back(unpinned);
     host = dev = nullptr;
     unpinned = getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr;
-    if (unpinned) {
-      host = (char *)malloc(bytes);
-      HH_CHECK(host != nullptr, "numfact (device levels): out of host memory for the upload ring");
-    } else HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
-    HIP_OK(hipMalloc((void **)&dev, bytes));
+    if (sim) {
+      host = (char *)malloc(bytes), dev = (char *)malloc(bytes);
+      HH_CHECK(host && dev, "upload ring self-test: out of memory");
+    } else {
+      if (unpinned) {
+        host = (char *)malloc(bytes);
+        HH_CHECK(host != nullptr, "numfact (device levels): out of host memory for the upload ring");
+      } else HIP_OK(hipHostMalloc((void **)&host, bytes, hipHostMallocDefault));
+      HIP_OK(hipMalloc((void **)&dev, bytes));
+    }
     cap  = bytes;
     head = flushed = 0;
+    batch_start = 0, batch_wrapped = false; // (what the batch in hand staged so far stays in the retired buffers: nothing of it in this ring yet)
   }
   void release_retired()
   {
     if (retired.empty()) return;
-    HIP_OK(hipDeviceSynchronize());
+    if (!sim) HIP_OK(hipDeviceSynchronize());
     for (size_t i = 0; i < retired.size(); ++i) free_pair(retired[i].first, retired[i].second, retired_pageable[i]);
     retired.clear(), retired_pageable.clear();
   }
-  void begin_batch() { batch = 0; }
+  void begin_batch() { batch = 0, batch_start = head, batch_wrapped = false; }
   void *stage(const void *src, size_t bytes, hipStream_t st)
   {
     const size_t need = (bytes + 255) / 256 * 256;
-    if (batch + need + guard > cap) grow(std::max(batch + need + guard, 2 * cap), st); // a front's batch fits the ring as a whole: a wrap-around inside it never lands on its own bytes
+    if (batch + need + guard > cap) grow(std::max(batch + need + guard, 2 * cap), st); // a front's batch fits the ring as a whole
     if (head + need + guard > cap) {
       flush(st);
       const double t0 = now();
@@ -678,7 +692,12 @@ struct UploadRing {
       t_wait += now() - t0;
       ++wraps;
       head = flushed = 0;
+      batch_wrapped = batch > 0; // the front in hand keeps bytes ahead of the wrap, [batch_start, ...): nobody has consumed THOSE yet
     }
+    // ... and what it stages behind the wrap must not run into them (a batch of more than half the ring: two 24 MB blocks of children in
+    // a 64 MB ring, blocks of complex scalars, HPDDM_HIP_DEVICE_MIN_H raised -- round 4 relied on "fits the ring" alone, which does
+    // not keep [0, b2) off [h0, h0 + b1)): a fresh ring then; the old one stays alive, with the batch's first part, until release_retired()
+    if (batch_wrapped && head + need + guard > batch_start) grow(2 * cap, st);
     const double t1 = now();
     std::memcpy(host + head, src, bytes);
     t_copy += now() - t1;
@@ -694,6 +713,37 @@ struct UploadRing {
     free_pair(host, dev, unpinned);
   }
 };
+
+// host-only check of the ring's bookkeeping (HpddmHipHostSelfTest; memory on both sides is plain memory): batches of several blocks,
+// some of them larger than half the ring, every block read back from the pointer stage() returned AFTER the whole batch was staged --
+// what the front's kernels do.  0, or the number of the batch that came back damaged.
+int upload_ring_selftest()
+{
+  UploadRing R;
+  R.sim = true;
+  R.grow(1 << 20, nullptr);
+  std::vector<unsigned char> src;
+  unsigned                   seed = 12345;
+  for (int it = 1; it <= 200; ++it) {
+    R.begin_batch();
+    const int nblocks = 1 + (int)(seed % 4);
+    std::vector<std::pair<const unsigned char *, size_t>> got;
+    std::vector<unsigned>                                 tags;
+    for (int bl = 0; bl < nblocks; ++bl) {
+      seed              = seed * 1664525u + 1013904223u;
+      const size_t bytes = 1000 + (seed >> 8) % ((it % 7 == 0) ? 400000u : 150000u); // (every seventh batch: blocks of up to 0.4 MB in a 1 MB ring)
+      src.resize(bytes);
+      for (size_t i = 0; i < bytes; ++i) src[i] = (unsigned char)((seed + 31u * (unsigned)i) >> 3);
+      got.emplace_back((const unsigned char *)R.stage(src.data(), bytes, nullptr), bytes);
+      tags.push_back(seed);
+    }
+    R.flush(nullptr);
+    for (size_t bl = 0; bl < got.size(); ++bl)
+      for (size_t i = 0; i < got[bl].second; ++i)
+        if (got[bl].first[i] != (unsigned char)((tags[bl] + 31u * (unsigned)i) >> 3)) return it;
+  }
+  return 0;
+}
 
 // Work space of the device levels, kept by the process between factorisations (it only grows): hipMalloc / hipFree of several GB
 // per factorisation were 1.0 - 2.4 s of the 3 - 4.4 s the device levels of a 129^3 subdomain took.  A factorisation holds a slot

@@ -339,6 +339,8 @@ Schwarz::~Schwarz()
   }
   if (ev_halo_fork) (void)hipEventDestroy(ev_halo_fork);
   if (ev_halo_done) (void)hipEventDestroy(ev_halo_done);
+  if (ev_halo_packed) (void)hipEventDestroy(ev_halo_packed);
+  for (hipStream_t q : pattern_streams) (void)hipStreamDestroy(q);
 }
 
 int Schwarz::owner(int gid) const
@@ -1358,7 +1360,7 @@ void Schwarz::gmv(const double *in, double *out, int mu)
   if (custom_mv) return custom_call(custom_mv, "operator", in, out, mu);
   // Schwarz::GMV (include/HPDDM_schwarz.hpp:740-744): out = exchange(A in)
   reserve(mu);
-  if (getopt("hip_fused_scaling", 1) == 0) {
+  if (getopt("hip_fused_scaling", 1) == 0 || in == out) { // (in place: the product cannot be written over its own input -- through w3, as before round 4)
     csrmm(in, w3.p, mu, 1.0, 0.0);
     exchange(w3.p, out, mu, true);
     return;
@@ -1405,6 +1407,7 @@ void Schwarz::build_plans()
     for (int i = 0; i < (g < pattern.size() ? pattern[g] : 0); ++i) {
       hipStream_t q;
       HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+      pattern_streams.push_back(q); // (nobody uses them; released with the operator)
     }
     hipStream_t q;
     hipEvent_t  ev;
@@ -1435,18 +1438,18 @@ void Schwarz::build_plans()
       HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
       cand.push_back(q);
     }
-    const int      mu_t = is_complex ? 1 : 1;
-    DevBuf<double> tin, tout;
-    tin.alloc((size_t)ntot * mu_t), tout.alloc((size_t)ntot * mu_t);
-    HIP_OK(hipMemsetAsync(tin.p, 0, sizeof(double) * ntot * mu_t, library_stream()));
+    const int mu_t = 1;
+    reserve(mu_t); // the operator's own work vectors serve as input and output (no allocation of their own right after the factorisation, when memory is tightest)
+    double *const tin = w1.p, *const tout = w2.p;
+    HIP_OK(hipMemsetAsync(tin, 0, sizeof(double) * ntot * mu_t, library_stream()));
     int    best = 0;
     double tbest = 0.0;
     for (int o = 0; o <= 3; ++o) {
       for (int g = 1; g < ng; ++g) more_streams[g - 1] = cand[o + g - 1];
-      batched_sptrsv(tin.p, tout.p, mu_t, false); // (warm: first use of the streams)
+      batched_sptrsv(tin, tout, mu_t, false); // (warm: first use of the streams)
       HIP_OK(hipStreamSynchronize(library_stream()));
       const auto t0 = std::chrono::steady_clock::now();
-      for (int r = 0; r < 2; ++r) batched_sptrsv(tin.p, tout.p, mu_t, false);
+      for (int r = 0; r < 2; ++r) batched_sptrsv(tin, tout, mu_t, false);
       HIP_OK(hipStreamSynchronize(library_stream()));
       const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (o == 0 || t < tbest) tbest = t, best = o;

@@ -130,6 +130,7 @@ struct Schwarz {
   int                    novl = 0;
   DevBuf<double>         halo_tmp;               // novl x mu
   hipEvent_t             ev_halo_packed = nullptr;
+  std::vector<hipStream_t> pattern_streams; // HPDDM_HIP_STREAM_PATTERN (developer aid): the streams created ahead of the groups', unused
   void                   halo_sum_inplace(double *x, int mu); // x <- sum of the duplicates of x (x already scaled by the producer)
   SolvePlan              plan;
   // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
@@ -246,5 +247,6 @@ struct Schwarz {
 };
 
 int zkrylov_host_selftest(); // krylov_complex.hip: host-only checks of its complex dense helpers (HpddmHipHostSelfTest)
+int upload_ring_selftest(); // numeric_device.hip: host-only check of the staging ring's bookkeeping (HpddmHipHostSelfTest)
 
 } // namespace hpddm_hip
