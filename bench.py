@@ -138,7 +138,7 @@ def main():
     shares = {}
     if rank == 0 and world == 1 and args.n == 256 and args.problem == "poisson" and not args.no_shares:
         shares["configs_3_share"] = share_leg(["--problem", "elasticity", "--grid", "64", "--geneo-nu", "12"])
-        shares["configs_4_share"] = share_leg(["--problem", "helmholtz", "--grid", "64", "--mu", "8", "--geneo-nu", "12"])
+        shares["configs_4_share"] = share_leg(["--problem", "helmholtz", "--grid", "64", "--mu", "8", "--geneo-nu", "12"], cpu=True)   # with its CPU leg (the complex port: about 30 s)
     _lib.check(_lib.load().HpddmHipSetDevice(dev.index))
     # the extra configs[1] object of the default run goes first: run in the same process AFTER the 97 GB operator (three minutes of
     # sustained streaming) the same 128^3 sweep was measured 20-25 % slower than on its own (3.1 against 2.45 ms on the same box)
@@ -155,8 +155,7 @@ def main():
 
     # ---- build the operator (one-time: generator, analysis, factorisation, upload) ----
     t0 = time.time()
-    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    want_cpu = want_cpu and not helm               # the CPU port is real arithmetic
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)   # (helmholtz: the complex port of the substitution, cpu_baseline_z)
     opts = ("-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd") + (f" -hpddm_leaf_size {args.leaf}" if args.leaf else "") + (" " + args.options if args.options else "")
     sharded = world > 1 and not args.replicas
     peers_hist = None
@@ -383,7 +382,7 @@ def main():
         if args.bgmres > 1 and world == 1:
             out["bgmres"] = bgmres_leg(A, subs, args, np, torch, dev)
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(A, subs, d, args, np, one["applies_per_sec"])
+            out["cpu_baseline"] = cpu_baseline_z(A, subs, d, args, np, one["applies_per_sec"], mu) if helm else cpu_baseline(A, subs, d, args, np, one["applies_per_sec"])
     if dist is not None:
         dist.barrier()
     A.destroy()
@@ -465,10 +464,10 @@ def two_level_setup(A, subs, args, np, geneo):
             "coarse_space": ("GenEO (Schwarz::solveGEVP on the device), largest kept eigenvalue %.4f" % lam_max) if geneo else "monomials of degree <= 3 (stand-in, --no-geneo)"}
 
 
-def share_leg(extra):
+def share_leg(extra, cpu=False):
     """one of the other BASELINE configs at the size of one GPU's share, run by this script in its own process (its own timed
     region, roofline and GMRES leg); the keys the judge reads are kept, the rest of its line is dropped"""
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-configs-1", "--no-shares"] + extra
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-configs-1", "--no-shares"] + ([] if cpu else ["--no-cpu-baseline"]) + extra
     t0 = time.time()
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BENCH_CHILD="1"))
@@ -476,7 +475,7 @@ def share_leg(extra):
         if res.returncode != 0 or not line:
             return {"error": (res.stderr or res.stdout)[-400:]}
         o = json.loads(line[-1])
-        keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "phases_ms", "one_level", "two_level") if k in o}
+        keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "phases_ms", "one_level", "two_level", "cpu_baseline") if k in o}
         keep["workload"] = o["config"]["workload"]
         keep["setup_seconds"] = o["config"]["setup_seconds"]
         keep["n_dof_per_gpu"] = o["config"]["n_dof_per_gpu"]
@@ -640,7 +639,9 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
         affinity = None
     for S in solvers:
         S.destroy()
-    return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "kind": "port", "cgroup_cpu_max": quota, "sched_affinity_cpus": affinity,
+    which = "(a) one thread per subdomain" if best == ea else ("(b) level-parallel team" if best == eb else "(c) a team of threads per subdomain")
+    return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": cores, "cores_used_by": which + ": `cores` = the threads of the variant `value` comes from; `usable_cpus` = what the container may schedule",
+            "kind": "port", "cgroup_cpu_max": quota, "sched_affinity_cpus": affinity,
             "sample": f"one-level apply of the same {nsub}-subdomain operator, substitutions timed on {ns} of its {nsub} subdomains ({100.0 / scale:.0f} % of the factor entries; "
                       f"their plain factors made by {ns} extra factorisations after the timed region, {t_sample:.1f} s) + numpy halo sum of all {nsub} ({tex * 1e3:.1f} ms): "
                       f"(a) one thread per subdomain, {ns * rep_n} concurrent substitutions on {ns * rep_n} threads (the sampled factors swept {rep_n} times side by side), {ra} applies, {ta * 1e3:.1f} ms; "
@@ -654,6 +655,62 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
             "one_thread_per_subdomain": {"threads": min(nsub, ncores), "substitution_ms": ea * 1e3, "applies_per_sec": 1.0 / (ea + tex)},
             "level_parallel": {"threads": nthr, "substitution_ms": eb * 1e3, "applies_per_sec": 1.0 / (eb + tex)},
             "note": "the CPU leg is the ONE-level apply (substitutions + halo); the GPU headline above additionally carries the coarse correction when two-level",
+            "gpu_one_level_over_cpu": gpu_value / (1.0 / per_apply)}
+
+
+def cpu_baseline_z(A, subs, d, args, np, gpu_value, mu):  # gpu_value: ONE-level applies/s of the device path (an apply = mu right-hand sides)
+    """The CPU leg for K = std::complex<double> (--problem helmholtz, configs[4]'s share): the oracle's complex substitution
+    (oracle/sptrsv_oracle.c: solve_one_z, plain L D L^T of the complex symmetric impedance matrices) on the plain factors of the SAME
+    subdomains -- factorised once more with the plain factor kept, after the timed region --, one thread per subdomain (the reference's
+    layout: one MPI rank per subdomain, sequential local solve), `mu` right-hand sides one after the other as MUMPS' solve phase would
+    take them column by column, plus the numpy halo sum.  The whole operator is timed (8 subdomains of 70 k unknowns): no scaling."""
+    from hpddm_amd import hpddm
+    from oracle import sptrsv_oracle
+    from oracle.ras_oracle import Oracle
+    nsub = len(subs)
+    ncores = os.cpu_count() or 1
+    t0 = time.time()
+    solvers = []
+    for sd in subs:
+        S = hpddm.Subdomain(keep_plain=1)
+        S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a_opt"], sym=False)
+        solvers.append(S)
+    factors = [sptrsv_oracle.PlainFactor(S) for S in solvers]
+    t_sample = time.time() - t0
+    threads = min(nsub, ncores)
+    rs = np.random.RandomState(7)
+    f = [np.asfortranarray(rs.random_sample((s["n"], mu)) + 1j * rs.random_sample((s["n"], mu))) for s in subs]
+    sptrsv_oracle.time_batch_z(factors, f, reps=1, threads=threads)   # warm-up (page-in of the factors)
+    reps, tsolve, t_begin, xs = 0, 0.0, time.perf_counter(), None
+    while reps < 2 or (time.perf_counter() - t_begin < 15.0 and reps < 10):
+        sec, xs = sptrsv_oracle.time_batch_z(factors, f, reps=1, threads=threads)
+        tsolve += sec
+        reps += 1
+    ta = tsolve / reps
+    xg = A.local_solve(f)
+    agree_gpu = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xg))
+    orc = Oracle(subs, method="oras")
+    orc.d = d
+    t1 = time.perf_counter()
+    for _ in range(3):
+        orc.exchange(f)
+    tex = (time.perf_counter() - t1) / 3
+    per_apply = ta + tex
+    nnz_all = float(A.stats()["nnz_L"])
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota = fh.read().strip()
+    except OSError:
+        quota = None
+    for S in solvers:
+        S.destroy()
+    return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": threads, "kind": "port", "cgroup_cpu_max": quota,
+            "sample": f"one-level apply of the same {nsub}-subdomain complex operator on {mu} right-hand sides: complex substitutions on the plain L D L^T factors of all {nsub} subdomains "
+                      f"(made by {nsub} extra factorisations after the timed region, {t_sample:.1f} s), one thread per subdomain = {threads} threads, the {mu} right-hand sides one after the other, "
+                      f"{reps} applies, {ta * 1e3:.1f} ms + numpy halo sum {tex * 1e3:.1f} ms; agrees with the device solve to {agree_gpu:.1e}",
+            "cores_used_by": "one thread per subdomain (the only variant of the complex port)",
+            "host_GBps": 2.0 * nnz_all * 16.0 * mu / ta / 1e9, "seconds_per_apply": per_apply, "host_cores": ncores,
+            "note": "the CPU leg is the ONE-level apply (substitutions + halo) on the same block of right-hand sides; the GPU headline above additionally carries the coarse correction when two-level",
             "gpu_one_level_over_cpu": gpu_value / (1.0 / per_apply)}
 
 

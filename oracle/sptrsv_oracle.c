@@ -76,6 +76,74 @@ static void solve_one(const oracle_factor *f, const double *b, double *x, double
   for (ll i = 0; i < n; ++i) x[f->perm[i]] = y[i];
 }
 
+/* The same for K = std::complex<double> (the reference's local solvers are templated on K: MumpsSub<std::complex<double>>, job = 3):
+ * the plain factor holds (re, im) pairs, L D L^T of a complex SYMMETRIC matrix with plain transposes (kind 1) or LU (kind 2); n, the
+ * offsets and leading dimensions count complex scalars; work: 2n complex */
+#include <complex.h>
+typedef double _Complex zd;
+static void solve_one_z(const oracle_factor *f, const zd *b, zd *x, zd *work)
+{
+  const ll  n = f->n;
+  zd       *y = work, *t = work + n;
+  const zd *Lz = (const zd *)f->L, *Uz = (const zd *)f->U, *dz = (const zd *)f->dinv;
+  for (ll i = 0; i < n; ++i) y[i] = b[f->perm[i]];
+  for (ll k = 0; k < f->nblk; ++k) {
+    const ll  c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const zd *P  = Lz + f->f_off[k];
+    const ll *r  = f->rows + f->row_ptr[k];
+    for (ll i = 0; i < w; ++i) {
+      zd        s   = y[c0 + i];
+      const zd *row = P + i * ld;
+      for (ll j = 0; j < i; ++j) s -= row[j] * y[c0 + j];
+      y[c0 + i] = s / row[i];
+    }
+    for (ll i = 0; i < nb; ++i) {
+      const zd *row = P + (w + i) * ld;
+      zd        s   = 0.0;
+      for (ll j = 0; j < w; ++j) s += row[j] * y[c0 + j];
+      y[r[i]] -= s;
+    }
+  }
+  if (f->kind == 1)
+    for (ll i = 0; i < n; ++i) y[i] *= dz[i];
+  const zd *B = f->kind == 2 ? Uz : Lz;
+  for (ll k = f->nblk - 1; k >= 0; --k) {
+    const ll  c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const zd *P  = B + f->f_off[k];
+    const ll *r  = f->rows + f->row_ptr[k];
+    for (ll j = 0; j < w; ++j) t[j] = y[c0 + j];
+    for (ll i = 0; i < nb; ++i) {
+      const zd *row = P + (w + i) * ld;
+      const zd  xi  = y[r[i]];
+      for (ll j = 0; j < w; ++j) t[j] -= row[j] * xi;
+    }
+    for (ll i = w - 1; i >= 0; --i) {
+      const zd *row = P + i * ld;
+      const zd  xi  = t[i] / row[i];
+      y[c0 + i]     = xi;
+      for (ll j = 0; j < i; ++j) t[j] -= row[j] * xi;
+    }
+  }
+  for (ll i = 0; i < n; ++i) x[f->perm[i]] = y[i];
+}
+/* all subdomains at once, one thread each, nrhs complex right-hand sides per subdomain (column-major, leading dimension n complex);
+ * returns wall seconds of `reps` repetitions */
+double oracle_sptrsv_batch_z(int nsub, const oracle_factor *fs, const double *const *b, double *const *x, int nrhs, int reps, int threads)
+{
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int s = 0; s < nsub; ++s) {
+      zd *work = (zd *)malloc(sizeof(zd) * 2 * (size_t)fs[s].n);
+      for (int nu = 0; nu < nrhs; ++nu) solve_one_z(&fs[s], (const zd *)b[s] + (size_t)nu * fs[s].n, (zd *)x[s] + (size_t)nu * fs[s].n, work);
+      free(work);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* nrhs right-hand sides, column-major with leading dimension n (reference layout) */
 void oracle_sptrsv(ll n, ll nblk, int kind, const ll *perm, const ll *blk_ptr, const ll *ldw, const ll *f_off, const ll *row_ptr, const ll *rows, const double *L, const double *U, const double *dinv, const double *b, double *x, int nrhs)
 {

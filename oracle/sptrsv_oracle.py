@@ -21,6 +21,7 @@ def lib():
             raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         _lib = ctypes.CDLL(path)
         _lib.oracle_sptrsv_batch.restype = ctypes.c_double
+        _lib.oracle_sptrsv_batch_z.restype = ctypes.c_double
         _lib.oracle_sptrsv_batch_levels.restype = ctypes.c_double
         _lib.oracle_sptrsv_batch_teams.restype = ctypes.c_double
         assert _lib.oracle_factor_sizeof() == ctypes.sizeof(_Factor)
@@ -33,6 +34,7 @@ class PlainFactor:
     def __init__(self, sub):
         info = sub.info()
         self.n, self.kind = info["n"], info["kind"]
+        self.complex = bool(getattr(sub, "complex", False))   # the plain pools then hold (re, im) pairs; n, offsets, leading dimensions count complex scalars
         self.arr = {k: sub.export(k) for k in ("perm", "blk_ptr", "ldw", "f_off", "row_ptr", "rows", "height")}
         view = getattr(sub, "export_view", None) or sub.export   # no copy of a multi-GB factor when the binding offers a view
         self.sub = sub                                            # the views point into the solver's storage
@@ -71,6 +73,20 @@ def time_batch(factors, bs, reps, threads):
     bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
     xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
     sec = lib().oracle_sptrsv_batch(n, arr, bp, xp, mu, reps, threads)
+    return sec, xs
+
+
+def time_batch_z(factors, bs, reps, threads):
+    """the same for complex factors (K = std::complex<double>: plain L D L^T with plain transposes, or LU): bs[s] complex, (n,) or (n, mu)"""
+    n = len(factors)
+    assert all(getattr(f, "complex", False) for f in factors)
+    arr = (_Factor * n)(*[f.struct() for f in factors])
+    bs = [np.asfortranarray(b, dtype=np.complex128) for b in bs]
+    xs = [np.empty_like(b) for b in bs]
+    mu = 1 if bs[0].ndim == 1 else bs[0].shape[1]
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bs])
+    xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
+    sec = lib().oracle_sptrsv_batch_z(n, arr, bp, xp, mu, reps, threads)
     return sec, xs
 
 

@@ -119,7 +119,7 @@ def test_configs_4_share_helmholtz_complex_block_gmres_8_rhs():
     comb = A.apply([(2.0 - 1.0j) * a for a in u])
     _close(comb, [(2.0 - 1.0j) * a for a in au], 1e-10, "complex linearity of the two-level apply")
     it, sol = A.solve(f)
-    assert 0 < it < 400
+    assert abs(it - 20) <= 1, it                                                       # Block GMRES on 8 right-hand sides, tolerance 1e-6: 20 iterations (the bench line finds the same)
     res = A.compute_residual(sol, f).reshape(mu, 2)
-    assert np.all(res[:, 1] <= 1e-4 * res[:, 0]), res                                  # true residuals of the 8 right-hand sides
+    assert np.all(res[:, 1] <= 2e-6 * res[:, 0]), res                                  # true residuals of the 8 right-hand sides
     A.destroy()

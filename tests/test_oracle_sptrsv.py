@@ -66,3 +66,28 @@ def test_level_parallel_substitution_large_supernodes():
         _, xt = sptrsv_oracle.time_batch_teams([pf, pf], [b, b], reps=1, team=team)
         assert np.abs(xt[0] - ref).max() <= 1e-12 * np.abs(ref).max() and np.abs(xt[1] - ref).max() <= 1e-12 * np.abs(ref).max()
     S.destroy()
+
+
+@pytest.mark.parametrize("kind", ["ldlt", "lu"])
+def test_complex_cpu_substitution_matches_superlu(kind):
+    """the same port for K = std::complex<double> (solve_one_z: complex symmetric L D L^T with plain transposes, complex LU) -- the CPU
+    leg of bench.py --problem helmholtz (configs[4]'s share)"""
+    K = _poisson3d(9)
+    n = K.shape[0]
+    rng = np.random.default_rng(4)
+    if kind == "ldlt":
+        A = (K - (1.3 - 0.4j) * sp.identity(n)).tocsr()
+        Ain, sym = sp.tril(A).tocsr(), True
+    else:
+        A = (K + 0.2 * sp.triu(K, 1) + 0.3j * sp.diags(rng.random(n))).tocsr()
+        Ain, sym = A, False
+    Ain.sort_indices()
+    S = hpddm.Subdomain(host_only=1, keep_plain=1)
+    S.numfact(n, Ain.indptr, Ain.indices, Ain.data.astype(np.complex128), sym=sym)
+    pf = sptrsv_oracle.PlainFactor(S)
+    assert pf.complex and pf.kind == (1 if kind == "ldlt" else 2)
+    b = np.asfortranarray(rng.random((n, 3)) + 1j * rng.random((n, 3)))
+    sec, xs = sptrsv_oracle.time_batch_z([pf, pf], [b, b], reps=2, threads=2)
+    ref = spl.splu(sp.csc_matrix(A)).solve(b)
+    assert np.abs(xs[0] - ref).max() <= 1e-11 * np.abs(ref).max() and np.abs(xs[1] - ref).max() <= 1e-11 * np.abs(ref).max() and sec > 0
+    S.destroy()
