@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ v
 struct __attribute__((aligned(8))) dquad {
   double v[4];
 };
-template <int NT>
+// ZC: the compact storage of a complex operator (zentry): the 16 real columns of a tile are 8 complex vectors -- lane i takes vector
+// i / 2, the odd lane its product with i, read off the SAME 32 bytes ((re0, im0, re1, im1) -> (-im0, re0, -im1, re1)).
+__device__ static inline dquad times_i(const dquad &q) { return dquad{{-q.v[1], q.v[0], -q.v[3], q.v[2]}}; }
+template <int NT, bool ZC>
 __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const double *__restrict__ d, const long long *__restrict__ zoff, const int *__restrict__ nus, const double *__restrict__ Z, const double *__restrict__ in, double *__restrict__ partial, int mu, int m0, int nu0)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = nus[s];
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ 
     const double *zc[NT];
     bool          za[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) za[t] = 16 * t + i < mcols, zc[t] = Zs + (long long)(m0 + (za[t] ? 16 * t + i : 0)) * n;
+    for (int t = 0; t < NT; ++t) za[t] = 16 * t + i < mcols, zc[t] = Zs + (long long)((m0 + (za[t] ? 16 * t + i : 0)) >> (ZC ? 1 : 0)) * n;
+    const bool odd = ZC && (i & 1);
     const bool    ra = i < ncols;
     const double *rc = in + v0 * mu + (long long)(nu0 + (ra ? i : 0)) * n, *dd = d + v0;
     const dquad   zero = {{0.0, 0.0, 0.0, 0.0}};
@@ -128,6 +132,10 @@ __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ 
 #pragma unroll
       for (int t = 0; t < NT; ++t) a[t] = load4(zc[t], row0 + 4 * k, za[t]);
       b = load4(rc, row0 + 4 * k, ra), w = load4(dd, row0 + 4 * k, ra);
+      if (odd) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = times_i(a[t]);
+      }
     }
     for (; row0 < n; row0 += stride) {
       const int nxt = row0 + stride;
@@ -135,6 +143,10 @@ __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ 
 #pragma unroll
         for (int t = 0; t < NT; ++t) an[t] = load4(zc[t], nxt + 4 * k, za[t]);
         bn = load4(rc, nxt + 4 * k, ra), wn = load4(dd, nxt + 4 * k, ra);
+        if (odd) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) an[t] = times_i(an[t]);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -160,15 +172,29 @@ __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ 
 }
 
 // uc[nu][coff[s] + m] = sum_blk partial[s][blk][m - m0][nu - nu0]   (fixed order => reproducible)
-__global__ void k_zt_reduce(const double *__restrict__ partial, int nblk, const int *__restrict__ nus, const int *__restrict__ coff, double *__restrict__ uc, int mu, int cdim, int m0, int nu0)
+// grid (nsub, 8): a workgroup takes 64 of the 512 entries of a subdomain's tile, four threads per entry -- thread (entry, q) adds the
+// blocks q, q + 4, ... (eight loads in flight), the four sums are added in q order.  (One thread per entry walking all the blocks, 8
+// workgroups in all, was 67 us for 8 x 128 blocks: profiles/r04_helmholtz_share_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void k_zt_reduce(const double *__restrict__ partial, int nblk, const int *__restrict__ nus, const int *__restrict__ coff, double *__restrict__ uc, int mu, int cdim, int m0, int nu0)
 {
-  const int s = blockIdx.x;
-  for (int idx = threadIdx.x; idx < 512; idx += blockDim.x) {
+  __shared__ double red[4][64];
+  const int s = blockIdx.x, idx = 64 * (int)blockIdx.y + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
+  const double *p = partial + (long long)s * nblk * 512 + idx;
+  double        v = 0.0;
+  int           b = q;
+  for (; b + 28 < nblk; b += 32) {
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = p[(long long)(b + 4 * j) * 512];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += t[j];
+  }
+  for (; b < nblk; b += 4) v += p[(long long)b * 512];
+  red[q][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (q == 0) {
     const int m = m0 + idx / 16, nn = nu0 + (idx & 15);
-    if (m >= nus[s] || nn >= mu) continue;
-    double v = 0.0;
-    for (int b = 0; b < nblk; ++b) v += partial[((long long)(s * nblk + b)) * 512 + idx];
-    uc[(long long)nn * cdim + coff[s] + m] = v;
+    if (m < nus[s] && nn < mu) uc[(long long)nn * cdim + coff[s] + m] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
   }
 }
 
@@ -212,7 +238,7 @@ __global__ __launch_bounds__(256) void k_z_mfma(const long long *__restrict__ vo
 // i takes row 4 i + t, so that the four tiles of a lane are four CONSECUTIVE rows: one 32-byte load per deflation vector feeds the
 // four products of a step, one 32-byte store per accumulator register writes four rows of a right-hand side.  Steps of 4 vectors
 // (K), all requested before the products; plain column-major Z.
-template <int KS>
+template <int KS, bool ZC>
 __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ voff, const int *__restrict__ nn_, const long long *__restrict__ zoff, const int *__restrict__ nus, const int *__restrict__ coff, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ out, int mu, int cdim, int nu0, const double *__restrict__ dsc)
 {
   const int       s = blockIdx.y, n = nn_[s], nu_s = min(4 * KS, nus[s]);
@@ -231,13 +257,15 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + k;
+      const double *zk = Zs + (long long)(ZC ? kk >> 1 : kk) * n; // (compact storage: real column kk is complex vector kk / 2, or i times it)
       if (kk >= nu_s || r >= n) a[ks] = zero;
-      else if (r + 4 <= n) a[ks] = *reinterpret_cast<const dquad *>(Zs + (long long)kk * n + r);
+      else if (r + 4 <= n) a[ks] = *reinterpret_cast<const dquad *>(zk + r);
       else {
         a[ks] = zero;
         for (int t = 0; t < 4; ++t)
-          if (r + t < n) a[ks].v[t] = Zs[(long long)kk * n + r + t];
+          if (r + t < n) a[ks].v[t] = zk[r + t];
       }
+      if (ZC && (kk & 1)) a[ks] = times_i(a[ks]);
     }
     v4f64 acc[4];
 #pragma unroll
@@ -456,28 +484,36 @@ void Schwarz::panel_zt(const double *in, double *uc, int mu)
         else HH_ZT2(2, 32);
       }
 #undef HH_ZT2
-      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nb2, nu_d.p, coff_d.p, uc, mu, cdim, 0, 0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub, 8), dim3(256), 0, st, zt_partial.p, nb2, nu_d.p, coff_d.p, uc, mu, cdim, 0, 0);
       return;
     }
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       const dim3 g((unsigned)nblk, (unsigned)nsub, (unsigned)((std::min(ZT_NU, numax - m0) + 7) / 8));
       if (mu == 1) hipLaunchKernelGGL(k_zt_stream<1>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0, z_compact ? 1 : 0);
       else hipLaunchKernelGGL(k_zt_stream<2>, g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, m0, z_compact ? 1 : 0);
-      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, 0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub, 8), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, 0);
     }
     return;
   }
-  const bool direct = !z_compact && getopt("hip_deflation_zt_direct", 1) != 0; // operands straight from HBM (k_zt_mfma2) instead of the LDS tile
+  const bool direct = getopt("hip_deflation_zt_direct", 1) != 0; // operands straight from HBM (k_zt_mfma2; round 5: the compact complex storage too) instead of the LDS tile
   for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU)
     for (int m0 = 0; m0 < numax; m0 += ZT_NU) {
       if (direct) {
-        if (numax - m0 > 16) hipLaunchKernelGGL(k_zt_mfma2<2>, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
-        else hipLaunchKernelGGL(k_zt_mfma2<1>, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0);
-        hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
+        const dim3 g((unsigned)nblk, (unsigned)nsub);
+#define HH_ZTM(NT, ZC) hipLaunchKernelGGL((k_zt_mfma2<NT, ZC>), g, dim3(256), 0, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0)
+        if (numax - m0 > 16) {
+          if (z_compact) HH_ZTM(2, true);
+          else HH_ZTM(2, false);
+        } else {
+          if (z_compact) HH_ZTM(1, true);
+          else HH_ZTM(1, false);
+        }
+#undef HH_ZTM
+        hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub, 8), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
         continue;
       }
       hipLaunchKernelGGL(k_zt_mfma, dim3((unsigned)nblk, (unsigned)nsub), dim3(256), lds, st, voff_d.p, n_d.p, d_d.p, zoff_d.p, nu_d.p, Z_d.p, in, zt_partial.p, mu, m0, nu0, z_compact ? 1 : 0);
-      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
+      hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)nsub, 8), dim3(256), 0, st, zt_partial.p, nblk, nu_d.p, coff_d.p, uc, mu, cdim, m0, nu0);
     }
 }
 
@@ -512,10 +548,11 @@ void Schwarz::panel_z(const double *y, double *zy, int mu, bool scaled)
     else hipLaunchKernelGGL(k_z_stream<2>, g2, dim3(256), l2, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, cdim, z_compact ? 1 : 0, dsc);
     return;
   }
-  if (!z_compact && numax <= 32 && getopt("hip_deflation_zt_direct", 1) != 0) { // 32-byte accesses (k_z_mfma2)
+  if (numax <= 32 && getopt("hip_deflation_zt_direct", 1) != 0) { // 32-byte accesses (k_z_mfma2; the compact complex storage too)
     const dim3 g((unsigned)std::min(512, (nmax + 255) / 256), (unsigned)nsub);
     for (int nu0 = 0; nu0 < mu; nu0 += ZT_MU) {
-#define HH_ZM2(K) hipLaunchKernelGGL(k_z_mfma2<K>, g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, dsc)
+#define HH_ZM2(K) do { if (z_compact) hipLaunchKernelGGL((k_z_mfma2<K, true>), g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, dsc); \
+                       else hipLaunchKernelGGL((k_z_mfma2<K, false>), g, dim3(256), 0, st, voff_d.p, n_d.p, zoff_d.p, nu_d.p, coff_d.p, Z_d.p, y, zy, mu, cdim, nu0, dsc); } while (0)
       if (numax <= 8) HH_ZM2(2);
       else if (numax <= 16) HH_ZM2(4);
       else if (numax <= 24) HH_ZM2(6);

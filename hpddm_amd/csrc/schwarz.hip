@@ -110,7 +110,8 @@ __global__ void k_diag(const long long *__restrict__ voff, const int *__restrict
 // y = beta*y + alpha*A*x ; 8 lanes per row (7-point / 27-point stencil rows), rows of all subdomains in one launch.  A group of
 // 8 lanes takes FOUR consecutive rows per step and requests their row pointers, then their first 8 entries each, then the entries
 // of x, together: a row is a chain of three dependent round trips, and one row at a time left the kernel at 1.8 TB/s.
-__global__ void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
+template <int NB> // right-hand sides taken side by side (1: one column; 2; 4: blocks of four)
+__global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
 {
   const int s = blockIdx.y, n = nn[s];
   const long long v0  = voff[s];
@@ -130,23 +131,47 @@ __global__ void k_csrmm(const long long *__restrict__ voff, const int *__restric
       j[k]          = ok ? ja[q] : 0;
       av[k]         = ok ? a[q] : 0.0;
     }
-    for (int nu = 0; nu < mu; ++nu) {
-      const double *xs = x + v0 * mu + (long long)nu * n;
-      double        acc[4];
+    // right-hand sides four at a time: the entries of x of the four rows and four columns are requested together (one column after
+    // the other, a block of 8 was eight dependent gathers per group of rows: 1.9 TB/s at 129^3 x 8, profiles/r04_deflation_mfma_mu8_kernel_stats.csv)
+    for (int nu0 = 0; nu0 < mu; nu0 += NB) {
+      const double *xs = x + v0 * mu + (long long)nu0 * n;
+      double        acc[4][NB];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = av[k] * xs[j[k]];
+      for (int b = 0; b < NB; ++b) {
+        const long long ob = nu0 + b < mu ? (long long)b * n : 0; // (columns past the block: column nu0 again, dropped below)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        for (int q = p[k] + lane + 8; q < p[k + 1]; q += 8) acc[k] = fma(a[q], xs[ja[q]], acc[k]); // rows of more than 8 entries
-        acc[k] += __shfl_xor(acc[k], 4);
-        acc[k] += __shfl_xor(acc[k], 2);
-        acc[k] += __shfl_xor(acc[k], 1);
+        for (int k = 0; k < 4; ++k) acc[k][b] = xs[ob + j[k]];
       }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k][b] *= av[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        for (int q = p[k] + lane + 8; q < p[k + 1]; q += 8) { // rows of more than 8 entries
+          const double aq = a[q];
+          const int    jq = ja[q];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[k][b] = fma(aq, xs[(nu0 + b < mu ? (long long)b * n : 0) + jq], acc[k][b]);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          acc[k][b] += __shfl_xor(acc[k][b], 4);
+          acc[k][b] += __shfl_xor(acc[k][b], 2);
+          acc[k][b] += __shfl_xor(acc[k][b], 1);
+        }
       if (lane < 4 && r0 + lane < n) {
-        const double v  = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
-        const long long o = v0 * mu + (long long)nu * n + r0 + lane;
-        const double    t = (beta == 0.0 ? 0.0 : beta * y0[o]) + alpha * v;
-        y[o]              = dsc ? dsc[v0 + r0 + lane] * t : t;
+        const double w = dsc ? dsc[v0 + r0 + lane] : 1.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          if (nu0 + b < mu) {
+            const double    v = lane == 0 ? acc[0][b] : (lane == 1 ? acc[1][b] : (lane == 2 ? acc[2][b] : acc[3][b]));
+            const long long o = v0 * mu + (long long)(nu0 + b) * n + r0 + lane;
+            const double    t = (beta == 0.0 ? 0.0 : beta * y0[o]) + alpha * v;
+            y[o]              = w * t;
+          }
       }
     }
   }
@@ -302,16 +327,29 @@ __global__ void k_sum_partials(const double *__restrict__ partial, int nblk, dou
 }
 
 // y = Einv * x for mu columns (cdim x cdim row-major Einv), one workgroup per column block
-__global__ void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int cdim_g, int mu)
+__global__ __launch_bounds__(256) void k_coarse(const double *__restrict__ Einv, const double *__restrict__ x, double *__restrict__ y, int cdim, int cdim_g, int mu)
 {
-  // y (cdim local rows) = Einv (cdim x cdim_g, the rows of the local subdomains) * x (cdim_g)
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < cdim * mu; o += gridDim.x * blockDim.x) {
-    const int     nu = o / cdim, r = o - nu * cdim;
-    const double *er = Einv + (long long)r * cdim_g;
-    const double *xc = x + (long long)nu * cdim_g;
-    double        acc = 0.0;
-    for (int c = 0; c < cdim_g; ++c) acc = fma(er[c], xc[c], acc);
-    y[o] = acc;
+  // y (cdim local rows) = Einv (cdim x cdim_g, the rows of the local subdomains) * x (cdim_g): one wavefront per row, lanes along the
+  // row (coalesced), up to 16 right-hand sides per pass.  (One thread per entry of y walking its row was 37 us for cdim = 192.)
+  const int lane = threadIdx.x & 63, r = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (r >= cdim) return;
+  const double *er = Einv + (long long)r * cdim_g;
+  for (int nu0 = 0; nu0 < mu; nu0 += 16) {
+    double acc[16];
+#pragma unroll
+    for (int nu = 0; nu < 16; ++nu) acc[nu] = 0.0;
+    for (int c = lane; c < cdim_g; c += 64) {
+      const double e = er[c];
+#pragma unroll
+      for (int nu = 0; nu < 16; ++nu)
+        if (nu0 + nu < mu) acc[nu] = fma(e, x[(long long)(nu0 + nu) * cdim_g + c], acc[nu]);
+    }
+#pragma unroll
+    for (int nu = 0; nu < 16; ++nu) {
+      double v = acc[nu];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && nu0 + nu < mu) y[(long long)(nu0 + nu) * cdim + r] = v;
+    }
   }
 }
 // ------------------------------------------------------------------ host side ----------------------------------
@@ -1336,7 +1374,10 @@ void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double bet
     else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc);
     return;
   }
-  hipLaunchKernelGGL(k_csrmm, dim3((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  const dim3 gc((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub);
+  if (mu == 1) hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  else if (mu < 4) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  else hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
 }
 void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {
@@ -1517,7 +1558,7 @@ void Schwarz::coarse_solve(const double *uc, double *y, int mu)
     transport->allreduce_device(ucg_d.p, (long long)cdim_g * mu, st);
     rhs = ucg_d.p;
   }
-  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim * mu + 255) / 256)), dim3(256), 0, st, Einv_d.p, rhs, y, cdim, cdim_g, mu);
+  hipLaunchKernelGGL(k_coarse, dim3((unsigned)((cdim + 3) / 4)), dim3(256), 0, st, Einv_d.p, rhs, y, cdim, cdim_g, mu);
 }
 
 void Schwarz::apply(const double *in, double *out, int mu)
