@@ -483,8 +483,9 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   {
     std::lock_guard<std::mutex> lk(opt_mutex);
     opt["geneo_nu_requested"] = nu_req;
-    int most = 0;
-    for (const SchwarzSub &t : subs) most = std::max(most, t.nu);
+    int most = keep;
+    for (int t = 0; t < nsub; ++t)
+      if (t != s) most = std::max(most, (int)subs[t].eigenvalues.size()); // (what the eigenproblems of the other subdomains kept)
     opt["geneo_nu"] = most;
   }
   S.Z.assign(X.begin(), X.begin() + (size_t)keep * n);
@@ -888,8 +889,9 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   {
     std::lock_guard<std::mutex> lk(opt_mutex); // (the request stays aside, the option reads the largest number kept: see solve_gevp)
     opt["geneo_nu_requested"] = nu_req;
-    int most = 0;
-    for (const SchwarzSub &t : subs) most = std::max(most, t.nu);
+    int most = keep;
+    for (int t = 0; t < nsub; ++t)
+      if (t != s) most = std::max(most, (int)subs[t].eigenvalues.size());
     opt["geneo_nu"] = most;
   }
   S.eigenvalues.resize(keep), S.eigenvalues_im.resize(keep);

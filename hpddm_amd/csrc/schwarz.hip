@@ -1375,9 +1375,13 @@ void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double bet
     return;
   }
   const dim3 gc((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub);
-  if (mu == 1) hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
-  else if (mu < 4) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
-  else hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  // (right-hand sides one after the other: blocks of four side by side -- k_csrmm<4>, 130 VGPRs, three wavefronts per SIMD -- measured
+  // 2.08 ms against 1.94 at 8 x 129^3 with 8 right-hand sides, gpurun_out r05e: the gathers of x are bound by L2 sectors, 8 bytes of 32
+  // used, not by their latency; -hpddm_hip_gmv_block 2 | 4 keeps the variants reachable)
+  const int nb = (int)getopt("hip_gmv_block", 1);
+  if (nb >= 4 && mu >= 4) hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  else if (nb >= 2 && mu >= 2) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  else hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
 }
 void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {
