@@ -93,6 +93,21 @@ __global__ __launch_bounds__(256) void k_zt_mfma(const long long *__restrict__ v
 struct __attribute__((aligned(8))) dquad {
   double v[4];
 };
+// 32 / 16 bytes at an address that is only 8-byte aligned (the columns of Z start wherever an odd n puts them): through vector types
+// of reduced alignment the compiler emits 16-byte loads and stores, which the memory pipeline takes at any 4-byte alignment; a copy of
+// the struct was split into four 8-byte loads -- four times the instructions, a quarter of every sector per instruction (round 5)
+typedef double dbl4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ static inline dquad ldq(const double *__restrict__ p)
+{
+  const dbl4u v = *reinterpret_cast<const dbl4u *>(p);
+  return dquad{{v.x, v.y, v.z, v.w}};
+}
+__device__ static inline void stq(double *__restrict__ p, const dquad &q)
+{
+  const dbl4u v = {q.v[0], q.v[1], q.v[2], q.v[3]};
+  *reinterpret_cast<dbl4u *>(p) = v;
+}
 // ZC: the compact storage of a complex operator (zentry): the 16 real columns of a tile are 8 complex vectors -- lane i takes vector
 // i / 2, the odd lane its product with i, read off the SAME 32 bytes ((re0, im0, re1, im1) -> (-im0, re0, -im1, re1)).
 __device__ static inline dquad times_i(const dquad &q) { return dquad{{-q.v[1], q.v[0], -q.v[3], q.v[2]}}; }
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256) void k_zt_mfma2(const long long *__restrict__ 
     const dquad   zero = {{0.0, 0.0, 0.0, 0.0}};
     auto load4 = [&](const double *p, int r, bool live) -> dquad {
       if (!live || r >= n) return zero;
-      if (r + 4 <= n) return *reinterpret_cast<const dquad *>(p + r);
+      if (r + 4 <= n) return ldq(p + r);
       dquad q = zero;
       for (int t = 0; t < 4; ++t)
         if (r + t < n) q.v[t] = p[r + t];
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
       const int kk = 4 * ks + k;
       const double *zk = Zs + (long long)(ZC ? kk >> 1 : kk) * n; // (compact storage: real column kk is complex vector kk / 2, or i times it)
       if (kk >= nu_s || r >= n) a[ks] = zero;
-      else if (r + 4 <= n) a[ks] = *reinterpret_cast<const dquad *>(zk + r);
+      else if (r + 4 <= n) a[ks] = ldq(zk + r);
       else {
         a[ks] = zero;
         for (int t = 0; t < 4; ++t)
@@ -284,10 +299,10 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
         double   *o  = out + v0 * mu + (long long)(nu0 + m) * n + ro;
         if (ro + 4 <= n) {
           dquad q, w = {{1.0, 1.0, 1.0, 1.0}};
-          if (dsc) w = *reinterpret_cast<const dquad *>(dsc + v0 + ro); // the partition of unity of the exchange that follows, at the store
+          if (dsc) w = ldq(dsc + v0 + ro); // the partition of unity of the exchange that follows, at the store
 #pragma unroll
           for (int t = 0; t < 4; ++t) q.v[t] = w.v[t] * acc[t][reg];
-          *reinterpret_cast<dquad *>(o) = q;
+          stq(o, q);
         } else
           for (int t = 0; t < 4; ++t)
             if (ro + t < n) o[t] = (dsc ? dsc[v0 + ro + t] : 1.0) * acc[t][reg];
@@ -372,7 +387,10 @@ struct __attribute__((aligned(8))) dpair {
 };
 __device__ static inline dpair load_pair(const double *__restrict__ p, bool two)
 {
-  if (two) return *reinterpret_cast<const dpair *>(p);
+  if (two) {
+    const dbl2u v = *reinterpret_cast<const dbl2u *>(p); // (one 16-byte load, 8-byte aligned)
+    return dpair{v.x, v.y};
+  }
   return dpair{p[0], 0.0};
 }
 template <int MU, int KMAX>
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(256) void k_z_stream2(const long long *__restrict__
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) {
       double *o = out + v0 * MU + (long long)nu * n + i;
-      if (two) *reinterpret_cast<dpair *>(o) = dpair{w.x * acc[nu].x, w.y * acc[nu].y};
+      if (two) *reinterpret_cast<dbl2u *>(o) = dbl2u{w.x * acc[nu].x, w.y * acc[nu].y};
       else o[0] = w.x * acc[nu].x;
     }
   }

@@ -84,17 +84,10 @@ struct SnDesc {
   // c_out + crel[i] (inside its parent's block)
   const int    *cptr, *crel;
   long long     coff;
-  union {
-    struct {
-      int c_in, c_out;
-    };
-    // ... or, in the copies of the descriptor that ARE the wave-level tiles of the VALU sweeps (SolvePlan::wtd: one record per tile, tile
-    // and supernode in one fetch -- a tile of the bottom levels is a chain of dependent round trips, this takes one out), the tile:
-    // forward, first output row and rows of the tile
-    struct {
-      int t_r0, t_nr;
-    };
-  };
+  int           c_in, c_out;
+  // in the copies of the descriptor that ARE the wave-level tiles (SolvePlan::wtd: one record per tile, tile and supernode in one
+  // fetch -- a tile of the bottom levels is a chain of dependent round trips, this takes one out), the tile: Tile::r0, nr, rbeg, rend
+  int           t_r0, t_nr, t_rbeg, t_rend;
 };
 
 struct Tile {
@@ -139,7 +132,8 @@ struct SolvePlan {
   // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS) / condensed leaves (one wavefront each)
   enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3, FWD_LEAF = 4, BWD_LEAF = 5, NKIND = 6 };
   DevBuf<Tile>     tiles;   // block-level kinds, the lists of the 16-column engine, the combine pass: tiles that name their supernode (sn[t.sn])
-  DevBuf<SnDesc>   wtd;     // wave-level kinds and condensed leaves of the VALU sweeps: one descriptor per tile (SnDesc::t_r0 / t_nr); lev_ptr / lev_end of these kinds index it
+  DevBuf<SnDesc>   wtd;     // wave-level kinds and condensed leaves of the VALU sweeps, and the one-wavefront tiles of the 16-column engine (lev_w16): one descriptor per tile (SnDesc::t_r0 ...); lev_ptr / lev_end of these kinds index it
+  std::vector<int> lev_w16[2]; // 16-column engine, forward / backward: first of the level's one-wavefront tiles in wtd (lev_end16 - lev_ptr16 - lev_team of them)
   std::vector<int> lev_ptr[NKIND], lev_end[NKIND]; // per level [begin, end) into tiles
   std::vector<int> lev_lds[NKIND];   // dynamic LDS doubles per launch (block-level kinds) / per wavefront (wave-level kinds)
   std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the others chunks of 32 outputs (one wavefront each)

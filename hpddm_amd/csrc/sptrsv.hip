@@ -199,7 +199,7 @@ __device__ static inline void fwd_wave_tile_t(const SnView &d, int lane, double 
   const int w = d.w, wc = d.wc, ldh = d.ldh; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   struct {
     int r0, nr;
-  } const t = {d.c_in, d.c_out}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
+  } const t = {d.t_r0, d.t_nr}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -268,7 +268,7 @@ __device__ static inline void fwd_wave_tile_early(const SnView &d, int lane, dou
   const int w = d.w, wc = d.wc, ldh = d.ldh, h = d.w + d.nb; // rows of FT = doubles per panel row (wc = 2 w for complex scalars)
   struct {
     int r0, nr;
-  } const t = {d.c_in, d.c_out}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
+  } const t = {d.t_r0, d.t_nr}; // the per-tile copy of the descriptor carries the tile (SnDesc::t_r0, t_nr)
   const int g = (t.nr + 1) >> 1, R = 64 / g;
   const int sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
@@ -1525,7 +1525,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         lev_ptr[kd][l] = (int)wall.size();
         for (const Tile &t : tl[kd][l]) {
           SnDesc c = descs[t.sn];
-          c.t_r0 = t.r0, c.t_nr = t.nr;
+          c.t_r0 = t.r0, c.t_nr = t.nr, c.t_rbeg = t.rbeg, c.t_rend = t.rend;
           wall.push_back(c);
         }
       }
@@ -1543,7 +1543,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   // passes of v: the workgroup stages the rows of v once), then the tiles cut in chunks
   // of 32 output rows (forward) / 32 doubles of every row (backward), one wavefront each.
   for (int dir = 0; dir < 2; ++dir) {
-    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0);
+    lev_ptr16[dir].assign(nlev, 0), lev_end16[dir].assign(nlev, 0), lev_w16[dir].assign(nlev, 0);
     for (int l = 0; l < nlev; ++l) {
       const std::vector<Tile> &src = w16[dir][l];
       std::vector<Tile>        team, chunk;
@@ -1565,8 +1565,13 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       lev_ptr16[dir][l] = (int)all.size();
       lev_team[dir][l]  = (int)team.size();
       all.insert(all.end(), team.begin(), team.end());
-      all.insert(all.end(), chunk.begin(), chunk.end());
-      lev_end16[dir][l] = (int)all.size();
+      lev_end16[dir][l] = (int)all.size() + (int)chunk.size(); // (lev_end16 - lev_ptr16 = team tiles + one-wavefront tiles, as before; the latter live in wtd)
+      lev_w16[dir][l]   = (int)wall.size();
+      for (const Tile &t : chunk) {
+        SnDesc c = descs[t.sn];
+        c.t_r0 = t.r0, c.t_nr = t.nr, c.t_rbeg = t.rbeg, c.t_rend = t.rend;
+        wall.push_back(c);
+      }
     }
   }
   gat_ptr.assign(nlev, 0);

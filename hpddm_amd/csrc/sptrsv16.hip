@@ -550,7 +550,7 @@ __device__ static inline void bwd_block_tile16(const SnView &d, const Tile &t, d
 // One launch per level and direction, as in sptrsv.hip: the workgroups take the block tiles (wide panels) with their four
 // wavefronts together, then their wavefronts take wave tiles (narrow panels) on their own.
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16, int lds_dbl)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, const SnDesc *__restrict__ ctiles, int nwave, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16, int lds_dbl)
 {
   // workgroup tiles first: the block tiles of the wide panels, then the first nteam tiles of the narrow ones (team tiles); the
   // other nwave tiles of the narrow panels go one per wavefront
@@ -564,13 +564,13 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
       __syncthreads(); // the staging area is reused by the next tile
     }
   }
-  wtiles += nteam;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
   for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
-    const Tile    t  = wtiles[tix];
-    const SnView  d  = view(sns[t.sn]);
+    const SnView  d  = view(ctiles[tix]); // tile and supernode in one record (SolvePlan::wtd)
+    Tile          t;
+    t.r0 = d.t_r0, t.nr = d.t_nr, t.rbeg = d.t_rbeg, t.rend = d.t_rend;
     const double *bb = b16 + d.voff * C16;
     double       *yb = y16 + d.voff * C16, *Sb = S16 + d.coff * C16;
     fwd_wave_tile16<Z>(d, t, lane, Bl, bb, yb, Sb);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_fwd_kernel(const SnDesc *
 }
 
 template <bool HAS_BLOCK, bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const Tile *__restrict__ wtiles, int nteam, const SnDesc *__restrict__ ctiles, int nwave, const double *__restrict__ y16, double *__restrict__ x16, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts)
 {
   // workgroup tiles: the block tiles of the wide panels and the first nteam narrow supernodes (those of more than one staging pass
   // of v: the workgroup stages all their rows at once, every wavefront takes 32 doubles of every row -- the block tile as it is)
@@ -592,13 +592,13 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *
       __syncthreads();
     }
   }
-  wtiles += nteam;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   double   *Bl = lds + wv * (KC * C16);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - (nblock + nteam) % G) % G : (int)blockIdx.x;
   for (int tix = gw * 4 + wv; tix < nwave; tix += G * 4) {
-    const Tile    t  = wtiles[tix];
-    const SnView  d  = view(sns[t.sn]);
+    const SnView  d  = view(ctiles[tix]); // tile and supernode in one record (SolvePlan::wtd)
+    Tile          t;
+    t.r0 = d.t_r0, t.nr = d.t_nr, t.rbeg = d.t_rbeg, t.rend = d.t_rend;
     const double *yb = y16 + d.voff * C16;
     double       *xb = x16 + d.voff * C16;
     bwd_wave_tile16<Z>(d, t, lane, Bl, yb, xb);
@@ -650,16 +650,16 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     }
     const int ld = lds_wave; // (the block tiles only use the cross-wavefront buffer: 4 x 16 x 16 doubles)
     const int nt = P.lev_team[0][l], grid = nb + nt + (nw - nt + 3) / 4; // team tiles: the first nt of the level's narrow tiles
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, nw - nt, P.b16.p, P.y16.p, P.U16.p, ld);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, nw, P.b16.p, P.y16.p, P.U16.p, ld);
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_fwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::FWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[0][l], nt, P.wtd.p + P.lev_w16[0][l], nw - nt, P.b16.p, P.y16.p, P.U16.p, ld);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_fwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ld * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[0][l], 0, P.wtd.p + P.lev_w16[0][l], nw, P.b16.p, P.y16.p, P.U16.p, ld);
     if (nb || nw) P.mark(2000 + l, s);
   }
   const int ldb = std::max(lds_wave, RCB * C16);
   for (int l = P.nlev - 1; l >= 0; --l) {
     const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = P.lev_end16[1][l] - P.lev_ptr16[1][l];
     const int nt = P.lev_team[1][l], grid = nb + nt + (nw - nt + 3) / 4;
-    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
-    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, P.wtd.p + P.lev_w16[1][l], nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
+    else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, P.wtd.p + P.lev_w16[1][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0, P.out_scale);

@@ -21,7 +21,7 @@ struct SnView {
   gcd_t     F, G, dinv, FT, leaf;
   gci_t     rows, rel, cptr, crel;
   long long voff, soff, coff;
-  int       n, c0, w, nb, ldw, wc, cs, s_in, nchild, s_out, ldh, tgs, nnzr, nnzc, c_in, c_out;
+  int       n, c0, w, nb, ldw, wc, cs, s_in, nchild, s_out, ldh, tgs, nnzr, nnzc, c_in, c_out, t_r0, t_nr, t_rbeg, t_rend;
 };
 __device__ static inline SnView view(const SnDesc &d)
 {
@@ -31,7 +31,8 @@ __device__ static inline SnView view(const SnDesc &d)
   v.rows = (gci_t)d.rows, v.rel = (gci_t)d.rel, v.cptr = (gci_t)d.cptr, v.crel = (gci_t)d.crel;
   v.voff = d.voff, v.soff = d.soff, v.coff = d.coff;
   v.n = d.n, v.c0 = d.c0, v.w = d.w, v.nb = d.nb, v.ldw = d.ldw, v.wc = d.wc, v.cs = d.cs, v.s_in = d.s_in, v.nchild = d.nchild, v.s_out = d.s_out;
-  v.tgs = d.tgs, v.nnzr = d.nnzr, v.nnzc = d.nnzc, v.c_in = d.c_in, v.c_out = d.c_out; // (= t_r0, t_nr in the per-tile copies of the VALU sweeps)
+  v.tgs = d.tgs, v.nnzr = d.nnzr, v.nnzc = d.nnzc, v.c_in = d.c_in, v.c_out = d.c_out;
+  v.t_r0 = d.t_r0, v.t_nr = d.t_nr, v.t_rbeg = d.t_rbeg, v.t_rend = d.t_rend; // (the tile, in the per-tile copies of the descriptor)
   return v;
 }
 // the sections of a condensed leaf's blob (leaf_blob_layout of factor.hpp, in the address space of the kernels)
