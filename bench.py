@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--options", default="", help="extra -hpddm_* options appended to the operator's option string (developer aid)")
     ap.add_argument("--no-shares", action="store_true", help="skip the extra configs_3_share / configs_4_share objects of the default run")
     ap.add_argument("--strong", action="store_true", help="N>1: --grid is the GLOBAL cube (strong scaling) instead of the share of one GPU")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: build the layout of --gpus N ranks in this process (generator, partition, halo lists of the library) and print "
+                                                            "one JSON line with the peer GPUs of every rank, the global size and the unknowns per GPU")
     args = ap.parse_args()
     if args.geneo_nu is None:
         args.geneo_nu = 12 if args.problem == "helmholtz" else 20
@@ -83,8 +85,45 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd))
 
 
+def dry_run(args):
+    """the layout of `bench.py --gpus N ...` without a GPU: every rank's brick of subdomains, the partition handed to the library and the
+    peer GPUs its halo lists name (HpddmHipSchwarzHaloPeers), rank after rank in this process"""
+    import numpy as np  # noqa: F401
+    from hpddm_amd import hpddm
+    from hpddm_amd.generate import generate3d, generate_elasticity3d, generate_helmholtz3d, gpu_grid
+    world, helm = args.gpus, args.problem == "helmholtz"
+    share = (args.n, args.n, 2 * args.n) if helm else (args.n, args.n, args.n)
+    gg = gpu_grid(world) if args.strong else gpu_grid(world, share)
+    dims = (args.n, args.n, args.n) if args.strong else tuple(share[k] * gg[k] for k in range(3))
+    parts, peers, ndof, halo = 8 * world, [], [], []
+    for rank in range(world):
+        kw = dict(grid=tuple(2 * g for g in gg), brick=(2, 2, 2), first=8 * rank, count=8, normalize=True)
+        if helm:
+            subs = generate_helmholtz3d(dims, parts, **kw)
+        elif args.problem == "elasticity":
+            subs = generate_elasticity3d(dims, parts, overlap=1, sym=True, **kw)
+        else:
+            subs = generate3d(dims, parts, overlap=1, sym=True, rhs="smooth", **kw)
+        A, d = hpddm.schwarz_from_subdomains(subs, first_global=8 * rank, nglobal=parts, options="-hpddm_schwarz_method oras" if helm else "-hpddm_operator_spd", multiplicity=False,
+                                             partition=(rank, [8 * r for r in range(world + 1)]))
+        hp = A.halo_peers()   # [(peer rank, values per right-hand side, offset)]
+        peers.append(sorted(int(p[0]) for p in hp))
+        halo.append(int(sum(p[1] for p in hp)))
+        ndof.append(int(sum(sd["n"] for sd in subs)))
+        A.destroy()
+    hist = {}
+    for p in peers:
+        hist[str(len(p))] = hist.get(str(len(p)), 0) + 1
+    print(json.dumps({"dry_run": True, "n_gpus": world, "problem": args.problem, "global_dims": list(dims), "gpu_grid": list(gg), "subdomains": parts,
+                      "subdomain_grid": [2 * g for g in gg], "scaling": "strong" if args.strong else "weak", "n_dof_per_gpu": ndof, "halo_values_sent_per_rhs": halo,
+                      "peer_gpus_of_rank": peers, "peer_gpus_histogram": hist, "transport": "rccl (ncclSend / ncclRecv per peer GPU, ncclAllReduce) inside the library; "
+                      "torch.distributed (gloo) only hands the ncclUniqueId over and carries the barriers of the timed region"}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.dry_run:
+        return dry_run(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -104,12 +143,11 @@ def main():
         if share_gpu:
             local = 0
         torch.cuda.set_device(local)
-        if share_gpu:
-            dist.init_process_group("gloo")
-            cpu_group = dist.group.WORLD
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            cpu_group = dist.new_group(backend="gloo")   # host-side hand-over of the ncclUniqueId and of the timings
+        # torch.distributed only hands the ncclUniqueId over, carries the barriers of the timed region and the maximum of the timings: gloo.
+        # (Until round 4 the default group was torch's own NCCL communicator on the same devices as the library's -- two RCCL
+        # communicators per GPU, a combination nothing had ever exercised; the data path is the library's communicator alone.)
+        dist.init_process_group("gloo")
+        cpu_group = dist.group.WORLD
     else:
         local = 0
         torch.cuda.set_device(0)

@@ -8,15 +8,37 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 ng = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-rows = c.execute("select name, start, end from kernels where name like '%sptrsv%' or name like '%k_perm_in%' or name like '%k_perm_out%' order by start").fetchall()
-solves, cur, outs = [], [], 0
-for name, s, e in rows:
-    cur.append((s, e, name))
-    if "k_perm_out" in name:
-        outs += 1
-        if outs == ng:
-            solves.append(cur)
-            cur, outs = [], 0
+cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+rows = c.execute(f"select name, start, end, {sid or 0} from kernels where name like '%sptrsv%' or name like '%k_perm_in%' or name like '%k_perm_out%' order by start").fetchall()
+solves = []
+if sid:
+    # every group sweeps on its own stream: the k-th k_perm_in of a stream opens the k-th solve of that stream, and the k-th solves of the
+    # ng streams that make one batched solve are the ones whose k_perm_in launches are closest in time (round 5: cutting the time-ordered
+    # list at every ng-th k_perm_out mis-assigned kernels at the boundaries once the groups' streams were picked by timing -- 229 .. 242
+    # launches per solve where the plan has 236)
+    per = {}
+    for name, s, e, q in rows:
+        lst = per.setdefault(q, [])
+        if "k_perm_in" in name or not lst:
+            lst.append([])
+        lst[-1].append((s, e, name))
+    streams = [v for v in per.values() if len(v) > 1]
+    streams.sort(key=len, reverse=True)
+    streams = streams[:ng]
+    k = min(len(v) for v in streams) if streams else 0
+    for j in range(1, k + 1):   # align from the END of the run (the timed region): the set-up makes solves of its own on the library stream
+        solves.append([t for v in streams for t in v[-j]])
+    solves.reverse()
+else:
+    cur, outs = [], 0
+    for name, s, e, _ in rows:
+        cur.append((s, e, name))
+        if "k_perm_out" in name:
+            outs += 1
+            if outs == ng:
+                solves.append(cur)
+                cur, outs = [], 0
 print("solve,launches,span_us,busy_union_us,sum_of_durations_us")
 tot = [0.0, 0.0, 0.0]
 for k, sv in enumerate(solves):

@@ -67,3 +67,17 @@ def test_round_4_keys():
     assert 0 < s4["two_level"]["gmres"]["iterations"] < 60
     m8 = d["two_level"]["deflation_mfma_mu8"]
     assert m8["panel_GBps"] > 3500.0 and "r04_pmc_mfma_deflation" in m8["counters"]
+
+
+def test_dry_run_prints_the_layout_of_the_multi_gpu_configs_without_a_gpu():
+    """`bench.py --gpus N --dry-run`: every rank's brick of subdomains, the partition handed to the library and the peer GPUs its halo
+    lists name -- configs[3]'s layout (8 GPUs: every GPU a neighbour of the 7 others, one peer per xGMI link) and configs[4]'s (4 GPUs)
+    at a small size, on CPU"""
+    import subprocess
+    import sys
+    for extra, peers in ((["--gpus", "8", "--problem", "elasticity", "--grid", "8"], {"7": 8}), (["--gpus", "4", "--problem", "helmholtz", "--grid", "8", "--mu", "8"], {"3": 4})):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"] + extra, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-400:]
+        d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["dry_run"] is True and d["peer_gpus_histogram"] == peers and d["subdomains"] == 8 * d["n_gpus"]
+        assert all(r not in p for r, p in enumerate(d["peer_gpus_of_rank"])) and len(set(d["n_dof_per_gpu"])) == 1
