@@ -135,6 +135,8 @@ struct SolvePlan {
   DevBuf<SnDesc>   wtd;     // wave-level kinds and condensed leaves of the VALU sweeps, and the one-wavefront tiles of the 16-column engine (lev_w16): one descriptor per tile (SnDesc::t_r0 ...); lev_ptr / lev_end of these kinds index it
   std::vector<int> lev_w16[2]; // 16-column engine, forward / backward: first of the level's one-wavefront tiles in wtd (lev_end16 - lev_ptr16 - lev_team of them)
   std::vector<int> lev_ptr[NKIND], lev_end[NKIND]; // per level [begin, end) into tiles
+  bool             pair_leaves = true;
+  std::vector<int> lev_pair;         // condensed leaves at the end of the level's FWD_LEAF / BWD_LEAF lists that the BACKWARD launch takes two to a wavefront (even)
   std::vector<int> lev_lds[NKIND];   // dynamic LDS doubles per launch (block-level kinds) / per wavefront (wave-level kinds)
   std::vector<int> lev_ptr16[2], lev_end16[2], lev_team[2]; // the narrow tiles as the 16-column engine takes them (sptrsv16.hip), forward / backward: per level [begin, end) into tiles, the first lev_team[.][l] of them are team tiles (one workgroup each), the others chunks of 32 outputs (one wavefront each)
   // 16-column engine, wide supernodes with children: their right-hand side b_J - (what the children handed up) is formed once per

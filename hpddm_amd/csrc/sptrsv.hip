@@ -36,13 +36,16 @@ __device__ static inline double reduce_across(double v, int lane, int sub, int g
 }
 // the same sums for the two accumulators of MU right-hand sides at once: the steps outside, the values inside, so that the
 // 4 MU shuffles of a step are in flight together (step after step per value, a tile pays 2 MU x log2(R) shuffle latencies)
-template <int MU>
-__device__ static inline void reduce_across_pairs(double (&a0)[MU], double (&a1)[MU], int lane, int sub, int g, int R)
+template <int MU, int LW = 64>
+__device__ static inline void reduce_across_pairs(double (&a0)[MU], double (&a1)[MU], int lane, int sub, int g, int R, int lbase = 0)
 {
+  // (LW = 32: two independent groups of 32 lanes in the wavefront, `lane` counts inside the group that starts at lane lbase; the loop
+  // runs to the larger R of the two, a group that is done keeps its sums)
   int width = R, off = 1;
   while (off < R) off <<= 1;
+  if constexpr (LW < 64) off = max(off, __shfl_xor(off, 32));
   for (off >>= 1; off >= 1; off >>= 1) {
-    const int  from = min(63, lane + off * g);
+    const int  from = lbase + min(LW - 1, lane + off * g);
     const bool take = sub + off < width;
     double     t0[MU], t1[MU];
 #pragma unroll
@@ -493,10 +496,10 @@ __device__ static inline void bwd_wave_tile(const SnView &d, int lane, double *l
 // Both sweeps read the blob of the leaf -- W^T dense (w x ldw), A_RJ by row, A_JR by column with the global row of every entry --
 // instead of the panel [inv(L_JJ); L_RJ inv(L_JJ)]: a few KB less per leaf.  The dense product is the one of the backward wave
 // tile (lanes own column pairs of W^T, no triangle to skip).
-template <int FP>
+template <int FP, int LW = 64>
 __device__ static inline void ptv_prime(gcd_t P, int ld, int K, int lane, dbl2 (&cur)[FP])
 {
-  const int  g = ld >> 1, R = 64 / g, sub = lane / g, gl = lane - sub * g;
+  const int  g = ld >> 1, R = LW / g, sub = lane / g, gl = lane - sub * g;
   const bool active = sub < R;
 #pragma unroll
   for (int p = 0; p < FP; ++p) {
@@ -506,10 +509,10 @@ __device__ static inline void ptv_prime(gcd_t P, int ld, int K, int lane, dbl2 (
 }
 // acc0 / acc1 = sums over the K rows of P[.][2 gl], P[.][2 gl + 1] times v (LDS, entry k of column nu at vl[nu * wr + k]); valid in
 // the lanes with sub == 0 on return.  cur: the first FP row groups, requested by ptv_prime before v was formed.
-template <int MU, int FP>
-__device__ static inline void ptv_run(gcd_t P, int ld, int K, int lane, const double *vl, int wr, dbl2 (&cur)[FP], double (&acc0)[MU], double (&acc1)[MU])
+template <int MU, int FP, int LW = 64>
+__device__ static inline void ptv_run(gcd_t P, int ld, int K, int lane, const double *vl, int wr, dbl2 (&cur)[FP], double (&acc0)[MU], double (&acc1)[MU], int lbase = 0)
 {
-  const int   g = ld >> 1, R = 64 / g, sub = lane / g, gl = lane - sub * g;
+  const int   g = ld >> 1, R = LW / g, sub = lane / g, gl = lane - sub * g;
   const bool  active = sub < R;
   const gcd_t Pp = P + 2 * gl;
   dbl2        nxt[FP];
@@ -518,7 +521,7 @@ __device__ static inline void ptv_run(gcd_t P, int ld, int K, int lane, const do
   for (int ib0 = 0; ib0 < K; ib0 += FP * R) {
     const int  ib   = ib0 + sub;
     const bool more = ib0 + FP * R < K;
-    if (more) {
+    if (LW == 64 && more) {
 #pragma unroll
       for (int p = 0; p < FP; ++p) {
         const int i = ib + (FP + p) * R;
@@ -537,17 +540,78 @@ __device__ static inline void ptv_run(gcd_t P, int ld, int K, int lane, const do
     }
     if (more) {
 #pragma unroll
-      for (int p = 0; p < FP; ++p) cur[p] = nxt[p];
+      for (int p = 0; p < FP; ++p) {
+        if constexpr (LW == 64) cur[p] = nxt[p];
+        else { // (two leaves per wavefront: the first FP row groups are the whole of a usual leaf, no second set of registers for the rest)
+          const int i = ib + (FP + p) * R;
+          cur[p]      = (active && i < K) ? *(gcd2_t)(Pp + (long long)i * ld) : dbl2{0.0, 0.0};
+        }
+      }
     }
   }
-  reduce_across_pairs<MU>(acc0, acc1, lane, sub, g, R);
+  reduce_across_pairs<MU, LW>(acc0, acc1, lane, sub, g, R, lbase);
 }
 
-template <int MU, int FP, bool Z>
-__device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *lds, int wr, const double *bb, double *yb, double *Sb, long long stot)
+// What a leaf tile reads of its leaf.  LeafOne: one leaf per wavefront, everything wave-uniform.  LeafTwo: two leaves per wavefront
+// (the plan pairs the leaves whose rows of W^T fit 32 lanes), both descriptors, their blob sections and vector bases in scalar
+// registers, every field chosen per lane where it is used (a per-lane copy of the descriptor costs ~35 VGPRs, i.e. the wavefronts in
+// flight the pairing is after).  p0 / p1 / p2: the vectors of the sweep (forward b, y, slot pool; backward y, x, -).
+struct LeafOne {
+  const SnView &d;
+  LeafView      L;
+  const double *p0;
+  double       *p1, *p2;
+  __device__ int w() const { return d.w; }
+  __device__ int ldw() const { return d.ldw; }
+  __device__ int nb() const { return d.nb; }
+  __device__ int n() const { return d.n; }
+  __device__ int c0() const { return d.c0; }
+  __device__ int s_out() const { return d.s_out; }
+  __device__ gci_t rel() const { return d.rel; }
+  __device__ gcd_t WT() const { return L.WT; }
+  __device__ gcd_t srval() const { return L.srval; }
+  __device__ gcd_t scval() const { return L.scval; }
+  __device__ gci_t scrow() const { return L.scrow; }
+  __device__ gcu16_t srptr() const { return L.srptr; }
+  __device__ gcu16_t scptr() const { return L.scptr; }
+  __device__ gcu16_t srcol() const { return L.srcol; }
+  __device__ const double *v0() const { return p0; }
+  __device__ double *v1() const { return p1; }
+  __device__ double *v2() const { return p2; }
+};
+struct LeafTwo {
+  const SnView &d, &e; // the leaf of lanes 0 .. 31, of lanes 32 .. 63
+  LeafView      L, M;
+  const double *p0, *q0;
+  double       *p1, *q1, *p2, *q2;
+  bool          h; // this lane is in the second half
+  __device__ int w() const { return h ? e.w : d.w; }
+  __device__ int ldw() const { return h ? e.ldw : d.ldw; }
+  __device__ int nb() const { return h ? e.nb : d.nb; }
+  __device__ int n() const { return h ? e.n : d.n; }
+  __device__ int c0() const { return h ? e.c0 : d.c0; }
+  __device__ int s_out() const { return h ? e.s_out : d.s_out; }
+  __device__ gci_t rel() const { return h ? e.rel : d.rel; }
+  __device__ gcd_t WT() const { return h ? M.WT : L.WT; }
+  __device__ gcd_t srval() const { return h ? M.srval : L.srval; }
+  __device__ gcd_t scval() const { return h ? M.scval : L.scval; }
+  __device__ gci_t scrow() const { return h ? M.scrow : L.scrow; }
+  __device__ gcu16_t srptr() const { return h ? M.srptr : L.srptr; }
+  __device__ gcu16_t scptr() const { return h ? M.scptr : L.scptr; }
+  __device__ gcu16_t srcol() const { return h ? M.srcol : L.srcol; }
+  __device__ const double *v0() const { return h ? q0 : p0; }
+  __device__ double *v1() const { return h ? q1 : p1; }
+  __device__ double *v2() const { return h ? q2 : p2; }
+};
+// LW = 64: one leaf per wavefront.  LW = 32: two leaves per wavefront (LeafTwo; `lds` differs between the two halves, `lane` counts
+// inside the half that starts at lane lbase).  Measured in round 5 (profiles/r05_leaf_pairs.txt): twice the leaves in flight per SIMD
+// do not make the level twice as fast -- the lifetime of a wavefront grows by 36 % (backward) to 57 % (forward) as the memory system
+// takes the scattered 64 .. 128-byte pieces no faster; the backward launch gains 5 %, the forward launch (more registers, spills at
+// six wavefronts per SIMD) loses 13 %.  The backward launch pairs, the forward launch does not.
+template <int MU, int FP, bool Z, int LW, class A>
+__device__ static inline void fwd_leaf_tile(const A &a, int lane, double *lds, int wr, long long stot, int lbase = 0)
 {
-  const LeafView L = leaf_view(d);
-  const int      w = d.w, ld = d.ldw, nb = d.nb;
+  const int w = a.w(), ld = a.ldw(), nb = a.nb();
   // everything that depends on the descriptor only is requested together, in the order it is needed (loads return in order): f = b_J
   // (a leaf has no children), the first rows of W^T, and for the sparse part the two row pointers of this lane's first row (one
   // 32-bit load of the 16-bit pair, taken apart only after the product: a use right behind the load would wait for it there) and
@@ -555,23 +619,23 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
   const int i0 = lane < nb ? lane : 0, cl = lane < w ? lane : 0;
   double    f0[MU];
 #pragma unroll
-  for (int nu = 0; nu < MU; ++nu) f0[nu] = bb[(long long)nu * d.n + d.c0 + cl];
+  for (int nu = 0; nu < MU; ++nu) f0[nu] = a.v0()[(long long)nu * a.n() + a.c0() + cl];
   dbl2 cur[FP];
-  ptv_prime<FP>(L.WT, ld, w, lane, cur);
+  ptv_prime<FP, LW>(a.WT(), ld, w, lane, cur);
   typedef const unsigned __attribute__((address_space(1))) *gcu32_t;
-  unsigned praw = *(gcu32_t)(L.srptr + i0);
-  int      pos0 = d.rel[i0];
+  unsigned praw = *(gcu32_t)(a.srptr() + i0);
+  int      pos0 = a.rel()[i0];
   if (lane < w) {
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) lds[nu * wr + lane] = f0[nu];
   }
-  for (int c = lane + 64; c < w; c += 64) { // (leaves of more than 64 columns)
+  for (int c = lane + LW; c < w; c += LW) { // (leaves of more than 64 columns)
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = bb[(long long)nu * d.n + d.c0 + c];
+    for (int nu = 0; nu < MU; ++nu) lds[nu * wr + c] = a.v0()[(long long)nu * a.n() + a.c0() + c];
   }
   wave_lds_order();
   double acc0[MU], acc1[MU];
-  ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
+  ptv_run<MU, FP, LW>(a.WT(), ld, w, lane, lds, wr, cur, acc0, acc1, lbase);
   const int g = ld >> 1, sub = lane / g, gl = lane - sub * g;
   asm volatile("" : "+v"(praw), "+v"(pos0)); // (the pair of pointers is used from here on)
   int p0 = (int)(praw & 0xffffu), p1 = (int)(praw >> 16);
@@ -581,17 +645,17 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
       const int c = 2 * gl;
       if (c < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + c] = acc0[nu], lds[nu * wr + c] = acc0[nu];
+        for (int nu = 0; nu < MU; ++nu) a.v1()[(long long)nu * a.n() + a.c0() + c] = acc0[nu], lds[nu * wr + c] = acc0[nu];
       }
       if (c + 1 < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) yb[(long long)nu * d.n + d.c0 + c + 1] = acc1[nu], lds[nu * wr + c + 1] = acc1[nu];
+        for (int nu = 0; nu < MU; ++nu) a.v1()[(long long)nu * a.n() + a.c0() + c + 1] = acc1[nu], lds[nu * wr + c + 1] = acc1[nu];
       }
     } else if (gl < w) { // this lane owns column gl: acc0 = P_r^T v, acc1 = P_i^T v for the real (even) and imaginary (odd) planes of v
 #pragma unroll
       for (int k = 0; k < MU / 2; ++k) {
         const double zr = acc0[2 * k] - acc1[2 * k + 1], zi = acc0[2 * k + 1] + acc1[2 * k];
-        yb[(long long)(2 * k) * d.n + d.c0 + gl] = zr, yb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = zi;
+        a.v1()[(long long)(2 * k) * a.n() + a.c0() + gl] = zr, a.v1()[(long long)(2 * k + 1) * a.n() + a.c0() + gl] = zi;
         lds[(2 * k) * wr + gl] = zr, lds[(2 * k + 1) * wr + gl] = zi;
       }
     }
@@ -599,8 +663,8 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
   wave_lds_order();
   // u = A_RJ z, one lane per row of rows(J), straight into the slot row of the parent
   constexpr int UN = 4;
-  for (int i = lane; i < nb; i += 64) {
-    if (i != lane) p0 = L.srptr[i], p1 = L.srptr[i + 1], pos0 = d.rel[i]; // (more than 64 rows below the leaf)
+  for (int i = lane; i < nb; i += LW) {
+    if (i != lane) p0 = a.srptr()[i], p1 = a.srptr()[i + 1], pos0 = a.rel()[i]; // (more than 64 rows below the leaf)
     double u[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) u[nu] = 0.0;
@@ -610,11 +674,11 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int j = 0; j < UN; ++j) {
         const bool ok = p + j < p1;
-        c[j]          = ok ? (int)L.srcol[p + j] : 0;
-        if constexpr (!Z) ar[j] = ok ? L.srval[p + j] : 0.0, ai[j] = 0.0;
+        c[j]          = ok ? (int)a.srcol()[p + j] : 0;
+        if constexpr (!Z) ar[j] = ok ? a.srval()[p + j] : 0.0, ai[j] = 0.0;
         else {
-          const dbl2 a = ok ? *(gcd2_t)(L.srval + 2 * (p + j)) : dbl2{0.0, 0.0};
-          ar[j] = a.x, ai[j] = a.y;
+          const dbl2 av = ok ? *(gcd2_t)(a.srval() + 2 * (p + j)) : dbl2{0.0, 0.0};
+          ar[j] = av.x, ai[j] = av.y;
         }
       }
 #pragma unroll
@@ -633,18 +697,17 @@ __device__ static inline void fwd_leaf_tile(const SnView &d, int lane, double *l
       }
     }
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) Sb[(long long)nu * stot + d.s_out + pos0] = u[nu];
+    for (int nu = 0; nu < MU; ++nu) a.v2()[(long long)nu * stot + a.s_out() + pos0] = u[nu];
   }
 }
 
-template <int MU, int FP, bool Z>
-__device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *lds, int wr, const double *yb, double *xb)
+template <int MU, int FP, bool Z, int LW, class A>
+__device__ static inline void bwd_leaf_tile(const A &a, int lane, double *lds, int wr, int lbase = 0)
 {
-  const LeafView L = leaf_view(d);
-  const int      w = d.w, ld = d.ldw;
+  const int      w = a.w(), ld = a.ldw();
   const int      g = ld >> 1, sub = lane / g, gl = lane - sub * g;
   dbl2           cur[FP];
-  ptv_prime<FP>(L.WT, ld, w, lane, cur);
+  ptv_prime<FP, LW>(a.WT(), ld, w, lane, cur);
   // z = what the forward sweep left in y_J, for this lane's outputs: requested now, used at the very end (one or two right-hand sides;
   // more would cost the registers of the product)
   constexpr bool YPRE = MU <= 2;
@@ -652,12 +715,12 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
   if constexpr (YPRE) {
     const int cz = Z ? min(gl, w - 1) : min(2 * gl, w - 1), cz1 = Z ? cz : min(2 * gl + 1, w - 1);
 #pragma unroll
-    for (int nu = 0; nu < MU; ++nu) zy0[nu] = yb[(long long)nu * d.n + d.c0 + cz], zy1[nu] = yb[(long long)nu * d.n + d.c0 + cz1];
+    for (int nu = 0; nu < MU; ++nu) zy0[nu] = a.v0()[(long long)nu * a.n() + a.c0() + cz], zy1[nu] = a.v0()[(long long)nu * a.n() + a.c0() + cz1];
   }
   // t = A_JR x_R, one lane per column of J: list of the column, then the entries of x it points to (UN of them in flight)
   constexpr int UN = MU >= 4 ? 2 : 4;
-  for (int c = lane; c < w; c += 64) {
-    const int p0 = L.scptr[c], p1 = L.scptr[c + 1];
+  for (int c = lane; c < w; c += LW) {
+    const int p0 = a.scptr()[c], p1 = a.scptr()[c + 1];
     double    t[MU];
 #pragma unroll
     for (int nu = 0; nu < MU; ++nu) t[nu] = 0.0;
@@ -667,17 +730,17 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
 #pragma unroll
       for (int j = 0; j < UN; ++j) {
         const bool ok = p + j < p1;
-        r[j]          = ok ? L.scrow[p + j] : d.c0;
-        if constexpr (!Z) ar[j] = ok ? L.scval[p + j] : 0.0, ai[j] = 0.0;
+        r[j]          = ok ? a.scrow()[p + j] : a.c0();
+        if constexpr (!Z) ar[j] = ok ? a.scval()[p + j] : 0.0, ai[j] = 0.0;
         else {
-          const dbl2 a = ok ? *(gcd2_t)(L.scval + 2 * (p + j)) : dbl2{0.0, 0.0};
-          ar[j] = a.x, ai[j] = a.y;
+          const dbl2 av = ok ? *(gcd2_t)(a.scval() + 2 * (p + j)) : dbl2{0.0, 0.0};
+          ar[j] = av.x, ai[j] = av.y;
         }
       }
 #pragma unroll
       for (int j = 0; j < UN; ++j)
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xv[j][nu] = xb[(long long)nu * d.n + r[j]];
+        for (int nu = 0; nu < MU; ++nu) xv[j][nu] = a.v1()[(long long)nu * a.n() + r[j]];
 #pragma unroll
       for (int j = 0; j < UN; ++j) {
         if (p + j < p1) { // (x of this leaf's own columns, read for the absent entries, is not defined yet: keep it out of the sums)
@@ -699,24 +762,24 @@ __device__ static inline void bwd_leaf_tile(const SnView &d, int lane, double *l
   }
   wave_lds_order();
   double acc0[MU], acc1[MU];
-  ptv_run<MU, FP>(L.WT, ld, w, lane, lds, wr, cur, acc0, acc1);
+  ptv_run<MU, FP, LW>(a.WT(), ld, w, lane, lds, wr, cur, acc0, acc1, lbase);
   if (sub == 0) { // x_J = z - W t
     if constexpr (!Z) {
       const int c = 2 * gl;
       if (c < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c] = (YPRE ? zy0[YPRE ? nu : 0] : yb[(long long)nu * d.n + d.c0 + c]) - acc0[nu];
+        for (int nu = 0; nu < MU; ++nu) a.v1()[(long long)nu * a.n() + a.c0() + c] = (YPRE ? zy0[YPRE ? nu : 0] : a.v0()[(long long)nu * a.n() + a.c0() + c]) - acc0[nu];
       }
       if (c + 1 < w) {
 #pragma unroll
-        for (int nu = 0; nu < MU; ++nu) xb[(long long)nu * d.n + d.c0 + c + 1] = (YPRE ? zy1[YPRE ? nu : 0] : yb[(long long)nu * d.n + d.c0 + c + 1]) - acc1[nu];
+        for (int nu = 0; nu < MU; ++nu) a.v1()[(long long)nu * a.n() + a.c0() + c + 1] = (YPRE ? zy1[YPRE ? nu : 0] : a.v0()[(long long)nu * a.n() + a.c0() + c + 1]) - acc1[nu];
       }
     } else if (gl < w) {
 #pragma unroll
       for (int k = 0; k < MU / 2; ++k) {
         const double sr = acc0[2 * k] - acc1[2 * k + 1], si = acc0[2 * k + 1] + acc1[2 * k];
-        xb[(long long)(2 * k) * d.n + d.c0 + gl]     = (YPRE ? zy0[YPRE ? 2 * k : 0] : yb[(long long)(2 * k) * d.n + d.c0 + gl]) - sr;
-        xb[(long long)(2 * k + 1) * d.n + d.c0 + gl] = (YPRE ? zy0[YPRE ? 2 * k + 1 : 0] : yb[(long long)(2 * k + 1) * d.n + d.c0 + gl]) - si;
+        a.v1()[(long long)(2 * k) * a.n() + a.c0() + gl]     = (YPRE ? zy0[YPRE ? 2 * k : 0] : a.v0()[(long long)(2 * k) * a.n() + a.c0() + gl]) - sr;
+        a.v1()[(long long)(2 * k + 1) * a.n() + a.c0() + gl] = (YPRE ? zy0[YPRE ? 2 * k + 1 : 0] : a.v0()[(long long)(2 * k + 1) * a.n() + a.c0() + gl]) - si;
       }
     }
   }
@@ -1196,15 +1259,15 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (LEAF ? 7 : 8
     double       *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *Sb = S + d.soff + (long long)nu0 * stot;
     if (leaf) {
-      if constexpr (LEAF) fwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z>(d, lane, wl, wr, bb, yb, Sb, stot);
+      if constexpr (LEAF) fwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z, 64>(LeafOne{d, leaf_view(d), bb, yb, Sb}, lane, wl, wr, stot);
     } else if constexpr (MU <= 2 && !HAS_BLOCK) fwd_wave_tile_early<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot); // the launches of the bottom levels; the mixed ones keep the leaner tile (registers of the block tiles)
     else fwd_wave_tile_t<MU, FP, Z>(d, lane, wl, wr, bb, yb, Sb, stot);
     wave_lds_order(); // the last reads of the staged right-hand side land before the next tile overwrites it; the stores of this tile drain while the next one starts (tiles of a level are independent)
   }
 }
 
-template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF>
-__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const SnDesc *__restrict__ wtiles, int nwave, const SnDesc *__restrict__ ltiles, int nleaf, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr)
+template <int MU, bool HAS_BLOCK, int FP, bool Z, bool LEAF, bool PAIR = false>
+__global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (PAIR ? 6 : 8) : 1) void sptrsv_bwd_kernel(const SnDesc *__restrict__ sns, const Tile *__restrict__ btiles, int nblock, const SnDesc *__restrict__ wtiles, int nwave, const SnDesc *__restrict__ ltiles, int nleaf, int npair, const double *__restrict__ y, double *__restrict__ xw, double *__restrict__ xout, int mu_total, int nu0, double *__restrict__ partials, int *__restrict__ arrivals, int max_parts, int lds_dbl, int wr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int G = gridDim.x;
@@ -1223,14 +1286,27 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? 8 : 1) void s
   double   *wl = lds + wv * (wr * MU);
   const int gw = HAS_BLOCK ? ((int)blockIdx.x + G - nblock % G) % G : (int)blockIdx.x;
   const int wpb = (int)(blockDim.x >> 6); // wavefronts per workgroup
-  for (int tix = gw * wpb + wv; tix < nwave + (LEAF ? nleaf : 0); tix += G * wpb) {
-    const bool    leaf = LEAF && tix >= nwave;
+  const int nsingle = LEAF ? (PAIR ? nleaf - npair : nleaf) : 0, nwt = nwave + nsingle + (PAIR ? npair >> 1 : 0);
+  for (int tix = gw * wpb + wv; tix < nwt; tix += G * wpb) {
+    const bool leaf = LEAF && tix >= nwave;
+    if (PAIR && tix >= nwave + nsingle) {
+      if constexpr (PAIR) {
+        const int     half = lane >> 5;
+        const SnDesc *lt = ltiles + nsingle + 2 * (tix - nwave - nsingle);
+        const SnView  d = view(lt[0]), e = view(lt[1]);
+        const long long od = d.voff * mu_total + (long long)nu0 * d.n, oe = e.voff * mu_total + (long long)nu0 * e.n;
+        const LeafTwo a{d, e, leaf_view(d), leaf_view(e), y + od, y + oe, xw + od, xw + oe, nullptr, nullptr, half != 0};
+        bwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z, 32>(a, lane & 31, wl + half * (wr >> 1), wr, half << 5);
+      }
+      wave_lds_order();
+      continue;
+    }
     const SnView  d  = view(leaf ? ltiles[tix - nwave] : wtiles[tix]); // tile and supernode in one record (SolvePlan::wtd)
     const double *yb = y + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xb = xw + d.voff * mu_total + (long long)nu0 * d.n;
     double       *xo = xout + d.voff * mu_total + (long long)nu0 * d.n;
     if (leaf) {
-      if constexpr (LEAF) bwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z>(d, lane, wl, wr, yb, xb);
+      if constexpr (LEAF) bwd_leaf_tile<MU, (MU <= 2 ? 4 : FP), Z, 64>(LeafOne{d, leaf_view(d), yb, xb, nullptr}, lane, wl, wr);
     } else bwd_wave_tile<MU, FP, Z>(d, lane, wl, wr, yb, xb, xo);
     wave_lds_order();
   }
@@ -1512,12 +1588,21 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_lds[kd].assign(nlev, 0);
   }
   lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
+  lev_pair.assign(nlev, 0);
+  pair_leaves = envi("HPDDM_HIP_LEAF_PAIRS", 1) != 0; // developer switch: 0 = one condensed leaf per wavefront in the backward sweep too
+  auto pairable = [&](const Tile &t) { return pair_leaves && descs[t.sn].ldw <= 64; }; // (the rows of W^T fit 32 lanes)
   launches_per_solve = 2; // the two permutation passes
   for (int kd = 0; kd < NKIND; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
       auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : ((kd == FWD_LEAF || kd == BWD_LEAF) ? (long long)descs[t.sn].w * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr); };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
+      if (kd == FWD_LEAF || kd == BWD_LEAF) { // the leaves that go two to a wavefront at the end of the list, neighbours in cost paired
+        std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return !pairable(t); });
+        int np = 0;
+        for (const Tile &t : tl[kd][l]) np += pairable(t);
+        lev_pair[l] = np & ~1; // (an odd one out: the largest, on a wavefront of its own -- the same in both directions)
+      }
       if (kd == FWD_BLOCK || kd == BWD_BLOCK) {
         lev_ptr[kd][l] = (int)all.size();
         all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
@@ -1533,6 +1618,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       // w columns (forward) or h rows (backward) of the widest / tallest supernode of the level, per wavefront; a condensed leaf
       // its w entries of f / z / t
       int need = 0;
+      if (kd == FWD_LEAF || kd == BWD_LEAF)
+        for (size_t k = tl[kd][l].size() - lev_pair[l]; k < tl[kd][l].size(); ++k) need = std::max(need, 2 * ((descs[tl[kd][l][k].sn].w + 7) / 8 * 8)); // (two leaves share the wavefront's staging area, half each)
       for (const Tile &t : tl[kd][l])
         need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : (kd == BWD_WAVE ? descs[t.sn].w + descs[t.sn].nb : descs[t.sn].w))));
       lev_lds[kd][l] = need;
@@ -1681,12 +1768,15 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
     const Tile   *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l];
     const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::BWD_LEAF][l];
-    const dim3 g(grid(nb, nw + nl));
+    const int  np = (nl && P.pair_leaves) ? P.lev_pair[l] : 0;
+    const dim3 g(grid(nb, nw + nl - np / 2));
     const size_t shm = (size_t)ld * sizeof(double);
-    if (nb && nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
-    else if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
-    else if (nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, nl, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
-    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    if (nb && nl && np) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, true, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, np, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nl && np) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, true, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, nl, np, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nb && nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, nl, np, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nb) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, true, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, nb, tw, nw, tf, 0, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nl) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, true>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, nl, np, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
+    else if (nw) hipLaunchKernelGGL((sptrsv_bwd_kernel<MU, false, FPB, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, 0, 0, P.y.p, P.xw.p, x, mu_total, nu0, P.partials.p, P.arrivals.p, P.max_parts, ld, wr);
     if (nb || nw || nl) P.mark(3000 + l, s);
   }
 }
