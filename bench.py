@@ -345,7 +345,7 @@ def main():
                    "deflation_flops": 4.0 * n * nu * mu * (4.0 if A.complex else 1.0),
                    "kernel": ("k_zt_stream2 + k_z_stream2: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
                               "MFMA utilisation 0 by construction" if mu <= 2 else
-                              "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64; complex operators: the staged k_zt_mfma + k_z_mfma): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r04_pmc_mfma_deflation.csv)")})
+                              "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM; complex operators: the same kernels on the compact complex Z): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r04_pmc_mfma_deflation.csv)")})
         tl["deflation_TFLOPs"] = tl["deflation_flops"] / t_defl / 1e12
         if mu <= 2 and world == 1:
             # the same panel with 8 right-hand sides (Block GMRES, the GenEO blocks): the GEMM-shaped products on v_mfma_f64_16x16x4_f64,

@@ -1,4 +1,4 @@
-"""The bench contract on the committed line (profiles/r04_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
+"""The bench contract on the committed line (profiles/r05_bench_default_stdout.json, printed by `python bench.py` on an MI355X):
 every key the driver reads is there, the workload is the one BASELINE.json quotes its target on (configs[2], real GenEO space) and
 the derived fields are consistent with each other.  CPU only."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r04_bench_default_stdout.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_stdout.json")) as fh:
         rows = [ln for ln in fh if ln.startswith('{"metric"')]
     assert len(rows) == 1, "bench.py prints ONE JSON line"
     return json.loads(rows[0])
@@ -42,11 +42,11 @@ def test_contract_keys_and_consistency():
 
 def test_traffic_profile_matches_the_line():
     d = _line()
-    with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_c3.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic_c3.json")) as fh:
         t = json.load(fh)
     assert t["traffic_bytes"] == (2 * t["FETCH_SIZE_KB_per_sweep"] + t["WRITE_SIZE_KB_per_sweep"]) * 1024
-    # the line quotes the traffic file of this round's PMC passes (scripts/r04_final.sh), collected on the same build just before it ran
-    assert d["roofline"]["traffic_source"].startswith("profiles/r04_pmc_traffic_c3.json") and d["roofline"]["traffic_measured_in_this_run"] is False
+    # the line quotes the traffic file of this round's PMC passes (scripts/r05_profiles.sh pmc), collected on the same build just before it ran
+    assert d["roofline"]["traffic_source"].startswith("profiles/r05_pmc_traffic_c3.json") and d["roofline"]["traffic_measured_in_this_run"] is False
     assert d["roofline"]["traffic"] == t["traffic_bytes"] and t["algorithmic_bytes"] == d["roofline"]["bytes_alg_per_sweep"]
     assert 1.0 <= t["traffic_over_algorithmic"] <= 1.15
 
@@ -67,6 +67,19 @@ def test_round_4_keys():
     assert 0 < s4["two_level"]["gmres"]["iterations"] < 60
     m8 = d["two_level"]["deflation_mfma_mu8"]
     assert m8["panel_GBps"] > 3500.0 and "r04_pmc_mfma_deflation" in m8["counters"]
+
+
+def test_round_5_keys():
+    """what round 5 added: a CPU leg for the complex share (complex substitutions of the port, one thread per subdomain), `cores` = the threads
+    `value` was measured on (said in `cores_used_by`), the deflation of the complex share on the direct MFMA kernels"""
+    d = _line()
+    c = d["cpu_baseline"]
+    assert c["cores"] == 8 and "cores_used_by" in c and "usable_cpus" in c["cores_used_by"]
+    s4 = d["configs_4_share"]
+    cz = s4["cpu_baseline"]
+    assert cz["kind"] == "port" and cz["unit"] == "applies/s" and 0 < cz["value"] < s4["value"] and cz["cores"] == 8 and "complex substitutions" in cz["sample"]
+    assert s4["two_level"]["deflation_ms"] < 0.2 and abs(s4["two_level"]["gmres"]["iterations"] - 20) <= 1
+    assert d["roofline"]["frac"] > 0.70 and d["config"]["launches_per_sptrsv"] == 176.0
 
 
 def test_dry_run_prints_the_layout_of_the_multi_gpu_configs_without_a_gpu():
