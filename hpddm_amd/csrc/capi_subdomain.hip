@@ -46,7 +46,12 @@ int HpddmHipDeviceCount(void)
 }
 int HpddmHipSetDevice(int device)
 {
-  HH_TRY(HIP_OK(hipSetDevice(device)); hpddm_hip::g_device.store(device); return 0;)
+  HH_TRY(
+    // one device per process: the library stream, the pinned staging buffers and the work space of the device levels are created once, on
+    // the device current at their first use -- a later switch would record their events on streams of another device
+    const int cur = hpddm_hip::library_device();
+    HH_CHECK(cur < 0 || cur == device, "HpddmHipSetDevice(" + std::to_string(device) + "): the library already works on device " + std::to_string(cur) + " (one device per process: call it before anything else)");
+    HIP_OK(hipSetDevice(device)); hpddm_hip::g_device.store(device); return 0;)
 }
 int HpddmHipSynchronize(void)
 {

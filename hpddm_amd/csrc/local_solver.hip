@@ -1,6 +1,7 @@
 // LocalSolver: numfact (host analysis + multifrontal factorisation, upload) and solve (HIP SpTRSV).
 // Reference: Solver<K>::numfact / solve / dtor (include/HPDDM_MUMPS.hpp:216-317).
 #include "local_solver.hpp"
+#include <atomic>
 #include <mutex>
 #include <chrono>
 #include <cmath>
@@ -11,11 +12,18 @@ namespace hpddm_hip {
 // One process drives one GPU (HpddmHipSetDevice before anything else): the library stream, the pinned staging buffers
 // of staging.hip and the work space of the device levels are process-wide objects created on the device that is current at their
 // first use.  Worker threads of the set-up phases call this too: created once, whatever thread comes first.
+static std::atomic<int> g_stream_device{-1}; // the device the process-wide objects live on (-1: none created yet)
+int library_device() { return g_stream_device.load(); }
 hipStream_t library_stream()
 {
   static hipStream_t    s = nullptr;
   static std::once_flag once;
-  std::call_once(once, [] { HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); });
+  std::call_once(once, [] {
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    g_stream_device.store(dev);
+  });
   return s;
 }
 

@@ -6,6 +6,7 @@
 namespace hpddm_hip {
 
 hipStream_t library_stream();
+int         library_device(); // the device the library stream and the other process-wide objects were created on (-1: not yet)
 DeviceLevels *make_device_levels(DeviceFactor &D, bool cplx); // numeric_device.hip (cplx: K = std::complex<double>)
 
 struct LocalSolver {

@@ -21,6 +21,9 @@ extern "C" {
 const char *HpddmHipLastError(void);
 /* number of visible HIP devices (0 when there is none); the library is useless without one and says so */
 int HpddmHipDeviceCount(void);
+/* One process drives ONE device (one process per GPU, as the reference runs one MPI rank per subdomain): call this before any other
+ * entry point.  The library stream, its pinned staging buffers and the work space of the device factorisation are created once, on the
+ * device current at their first use; asking for another device afterwards is refused (non-zero return, HpddmHipLastError says why). */
 int HpddmHipSetDevice(int device);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -214,3 +214,45 @@ def test_penalised_dirichlet_rows():
         r = (M @ x - b)[free]
         assert np.abs(r).max() < 1e-10 * np.abs(b[free]).max()             # the equations of the free dofs
         S.destroy()
+
+
+@pytest.mark.parametrize("pairs", ["1", "0"])
+@pytest.mark.parametrize("condense", ["1", "0"])
+@pytest.mark.parametrize("kind", ["chol", "ldlt", "lu", "z-ldlt", "z-lu"])
+def test_condensed_leaves_and_slot_rows_against_superlu(kind, condense, pairs, monkeypatch):
+    """round 5: the leaves of the tree swept through W = inv(A_JJ) and the sparse couplings (or, condense = 0, through their panels), the
+    backward launch with two leaves per wavefront or one, the children's updates handed over through the slot rows of the parent (the
+    16-column engine: through its compact lists) -- every kind of factor, 1 ... 17 right-hand sides, against SuperLU.  24^3: leaves,
+    wave tiles, block tiles and split backward tiles all occur."""
+    monkeypatch.setenv("HPDDM_HIP_CONDENSE", condense)
+    monkeypatch.setenv("HPDDM_HIP_LEAF_PAIRS", pairs)
+    K = _lap(24)
+    n = K.shape[0]
+    rng = np.random.default_rng(5)
+    if kind == "chol":
+        full, Ain, sym, spd = K, sp.tril(K).tocsr(), True, True
+    elif kind == "ldlt":
+        full = (K - 0.31 * sp.identity(n)).tocsr()
+        Ain, sym, spd = sp.tril(full).tocsr(), True, False
+    elif kind == "lu":
+        full = (K + sp.diags(rng.random(n)) + 0.3 * sp.triu(K, 1)).tocsr()
+        Ain, sym, spd = full, False, False
+    elif kind == "z-ldlt":
+        full = (K - (0.31 - 0.2j) * sp.identity(n)).tocsr()
+        Ain, sym, spd = sp.tril(full).tocsr().astype(np.complex128), True, False
+    else:
+        full = (K + 0.2 * sp.triu(K, 1) + 0.3j * sp.diags(rng.random(n))).tocsr().astype(np.complex128)
+        Ain, sym, spd = full, False, False
+    Ain.sort_indices()
+    cplx = np.iscomplexobj(Ain.data)
+    lu = spl.splu(sp.csc_matrix(full))
+    S = hpddm.Subdomain()
+    S.numfact(n, Ain.indptr, Ain.indices, Ain.data, sym=sym, spd=spd)
+    nleaf = int((S.export("lb_off") >= 0).sum())
+    assert (nleaf > 0) == (condense == "1"), nleaf
+    for mu in (1, 2, 3, 8, 9, 16, 17):
+        b = rng.random((mu, n)) + (1j * rng.random((mu, n)) if cplx else 0)
+        x = np.asarray(S.solve(np.asfortranarray(b.T))).T
+        ref = np.stack([lu.solve(b[k]) for k in range(mu)])
+        assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max(), (kind, condense, pairs, mu)
+    S.destroy()
