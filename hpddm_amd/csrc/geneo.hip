@@ -10,6 +10,7 @@
 #include "schwarz.hpp"
 #include <algorithm>
 #include "dense_eig.hpp"
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <mutex>
@@ -226,6 +227,18 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   int         nu = nu_req;
   const double threshold = getopt("geneo_threshold", 0.0);
   if (4 * nu > n) nu = std::max(1, n / 4); // same guard as the reference (include/HPDDM_ARPACK.hpp:89)
+  // where the time of an eigenproblem goes (printed with -hpddm_verbosity 2; the device is drained at the phase boundaries only then)
+  const bool timed = getopt("verbosity", 0) >= 2;
+  double     t_phase[6] = {0, 0, 0, 0, 0, 0}; // matrices, factorisation, solves, products / orthogonalisation, Rayleigh-Ritz (host), Ritz vectors + residuals
+  auto       now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double     t_mark = now();
+  auto       lap = [&](int which) {
+    if (!timed) return;
+    HIP_OK(hipStreamSynchronize(library_stream()));
+    const double t = now();
+    t_phase[which] += t - t_mark;
+    t_mark = t;
+  };
   const Csr AN = expand(n, ia, ja, a, sym, base);
   // ---- B = scaleIntoOverlap(A_N): rows and columns in the overlap with d > eps, entries d_i d_j a_ij ----
   std::vector<char> in_ovl(n, 0);
@@ -290,11 +303,13 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   LocalSolver shifted;
   shifted.leaf_size    = (int)getopt("leaf_size", 32);
   shifted.release_host = true;
+  lap(0);
   {
     CsrView V{n, sia.data(), sja.data(), sa.data(), true, 0};
     shifted.adopt_analysis(*S.ls, V); // the Neumann matrix usually has the pattern of the subdomain matrix: reuse its ordering + symbolic factorisation
     shifted.numfact(V, 1);
   }
+  lap(1);
   // ---- block Krylov subspace of OP = (A_N + sigma B)^{-1} B with full B-reorthogonalisation, Rayleigh-Ritz on it ----
   // (a block method finds the multiple eigenvalues that symmetric subdomains produce; 8 right-hand sides per SpTRSV)
   const int    p      = std::min(8, n);
@@ -402,7 +417,9 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
     HIP_OK(hipMemcpyAsync(BQd.p + nn * j0, BVd.p, sizeof(double) * nn * cur, hipMemcpyDeviceToDevice, st));
     dim += cur;
     double *Wj = Wd.p + nn * j0;
+    lap(3);
     shifted.plan.solve(BQd.p + nn * j0, Wj, cur, st); // W_j = OP Q_j
+    lap(2);
     bmult(Wj, T1d.p, cur);
     std::vector<double> Tc;
     tn(Qd.p, dim, T1d.p, cur, Tc); // T(0:dim, j0:j0+cur)
@@ -414,7 +431,9 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
       std::vector<double> Ts((size_t)dim * dim), Sv, th;
       for (int i = 0; i < dim; ++i)
         for (int c = 0; c < dim; ++c) Ts[(size_t)i * dim + c] = 0.5 * (T[(size_t)i * kmax + c] + T[(size_t)c * kmax + i]);
+      lap(3);
       jacobi_eig(dim, Ts, Sv, th);
+      lap(4);
       std::vector<int> order(dim);
       for (int i = 0; i < dim; ++i) order[i] = i;
       std::sort(order.begin(), order.end(), [&](int l, int r) { return th[l] > th[r]; }); // largest theta = lowest lambda
@@ -444,6 +463,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
         for (int c = 0; c < cc; ++c) worst = std::max(worst, std::sqrt(out[2 * c] / std::max(out[2 * c + 1], 1e-300)));
       }
       nritz = want;
+      lap(5);
       if (want == std::min(nu, n) && worst < tol) {
         converged = true;
         break;
@@ -492,7 +512,10 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   S.eigenvalues.assign(lam.begin(), lam.begin() + keep);
   S.gevp_iterations = it;
   coarse_ready      = false;
-  if (getopt("verbosity", 0) >= 2) printf("GenEO subdomain %d: %d vectors, lambda in [%.3e, %.3e], %d block-Krylov steps (basis %d)\n", first + s, keep, lam[0], lam[keep - 1], it, m);
+  lap(3);
+  if (timed)
+    printf("GenEO subdomain %d: %d vectors, lambda in [%.3e, %.3e], %d block-Krylov steps (basis %d); seconds: matrices %.2f, factorisation %.2f, solves %.2f, products + orthogonalisation %.2f, Rayleigh-Ritz on the host %.2f, Ritz vectors + residuals %.2f\n",
+           first + s, keep, lam[0], lam[keep - 1], it, m, t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
 }
 
 
