@@ -266,9 +266,8 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
   double          b[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) b[ks] = (4 * ks + k < nu_s && m < ncols) ? y[(long long)(nu0 + m) * cdim + coff[s] + 4 * ks + k] : 0.0; // B[k][j = lane&15]
-  for (int i0 = (blockIdx.x * 4 + wave) * 64; i0 < n; i0 += gridDim.x * 256) {
+  auto loadz = [&](int i0, dquad (&a)[KS]) {
     const int r = i0 + 4 * m; // rows r .. r+3: tiles 0 .. 3 of this lane
-    dquad     a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int kk = 4 * ks + k;
@@ -282,6 +281,15 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
       }
       if (ZC && (kk & 1)) a[ks] = times_i(a[ks]);
     }
+  };
+  // the next 64 rows are on their way under the products and the stores of the current ones (round 5: +2 % at 8 right-hand sides, at
+  // two wavefronts per SIMD instead of three; non-temporal loads of Z, `__builtin_nontemporal_load`, measured 2.37 against 1.91 ms)
+  const int istep = gridDim.x * 256;
+  int       i0 = (blockIdx.x * 4 + wave) * 64;
+  dquad     a[KS], an[KS];
+  if (i0 < n) loadz(i0, a);
+  for (; i0 < n; i0 += istep) {
+    if (i0 + istep < n) loadz(i0 + istep, an);
     v4f64 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0, 0, 0, 0};
@@ -308,6 +316,8 @@ __global__ __launch_bounds__(256) void k_z_mfma2(const long long *__restrict__ v
             if (ro + t < n) o[t] = (dsc ? dsc[v0 + ro + t] : 1.0) * acc[t][reg];
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
   }
 }
 

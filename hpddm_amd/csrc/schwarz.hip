@@ -78,13 +78,21 @@ __global__ void k_halo_ovl_sum(const long long *__restrict__ voff, const int *__
     const int       s = osub[q], i = oidx[q], n = nn[s];
     const long long v0 = voff[s];
     const int       p0 = ex_ptr[v0 + i], p1 = ex_ptr[v0 + i + 1];
-    for (int nu = 0; nu < mu; ++nu) {
-      double acc = x[v0 * mu + (long long)nu * n + i];
+    // four right-hand sides side by side (their loads are independent; one after the other the kernel was a chain of round trips per
+    // right-hand side: 0.12 ms of the 1.9 ms deflation of 8 right-hand sides at 129^3); per right-hand side the order of the sums is unchanged
+    for (int nu0 = 0; nu0 < mu; nu0 += 4) {
+      double acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = nu0 + j < mu ? x[v0 * mu + (long long)(nu0 + j) * n + i] : 0.0;
       for (int p = p0; p < p1; ++p) {
-        const int t = ex_sub[p];
-        acc += x[voff[t] * mu + (long long)nu * nn[t] + ex_idx[p]];
+        const int       t = ex_sub[p], nt = nn[t];
+        const long long b = voff[t] * mu + ex_idx[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += nu0 + j < mu ? x[b + (long long)(nu0 + j) * nt] : 0.0;
       }
-      tmp[(long long)nu * novl + q] = acc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (nu0 + j < mu) tmp[(long long)(nu0 + j) * novl + q] = acc[j];
     }
   }
 }
@@ -93,6 +101,7 @@ __global__ void k_halo_ovl_store(const long long *__restrict__ voff, const int *
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < novl; q += gridDim.x * blockDim.x) {
     const int       s = osub[q], i = oidx[q], n = nn[s];
     const long long v0 = voff[s];
+#pragma unroll 4
     for (int nu = 0; nu < mu; ++nu) x[v0 * mu + (long long)nu * n + i] = tmp[(long long)nu * novl + q];
   }
 }
