@@ -472,6 +472,12 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     int64_t units = 0; // 8-byte units
     const char *ce       = getenv("HPDDM_HIP_CONDENSE"); // developer switch: 0 keeps every leaf on its dense panel
     const bool  condense = hf.condense && !(ce && atoi(ce) == 0);
+    // the sparse part of a leaf is swept one lane per row, a few entries at a time: worth it while the rows of A_RJ hold a handful of
+    // entries (1.2 on a 7-point stencil).  Elasticity (3 x 3 blocks of a 27-point stencil: 20 .. 40 entries per row) measured 2.5 % SLOWER
+    // condensed, whatever the width of the leaves, and the launch that holds leaf tiles runs its panel tiles at 6 - 7 wavefronts per SIMD
+    // instead of 8 (round 5, 8 x 33^3 nodes x 3: 2.47 ms against 2.41) -- such leaves keep their panels.
+    const char *cw   = getenv("HPDDM_HIP_CONDENSE_MAXROW"); // developer knob: largest average number of entries per row of A_RJ / column of A_JR
+    const double maxrow = cw ? atof(cw) : 6.0;
     for (idx_t k = 0; k < nblk && condense; ++k) {
       const idx_t c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
       if (!children[k].empty() || s.height[k] >= first_device_level || hf.ldw[k] * SC > 128 || w + nb > 60000) continue;
@@ -482,6 +488,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           for (int64_t p = P.uptr[c]; p < P.uptr[c + 1]; ++p) nc += P.ucol[p] >= c0 + w;
       }
       if (!lu) nc = nr;
+      if ((double)std::max(nr, nc) > maxrow * (double)std::max<idx_t>(nb, 1)) continue;
       const LeafBlob lb = leaf_blob_layout(w, (long long)hf.ldw[k] * SC, nb, nr, nc, SC);
       // both sweeps read the blob once where they read the panel once (the forward sweep its transposed copy): worth it from 20 % less
       if ((double)lb.bytes > 0.8 * (double)(w + nb) * hf.ldw[k] * SC * 8.0 || nr > 60000 || nc > 60000) continue;
