@@ -478,6 +478,8 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
     // instead of 8 (round 5, 8 x 33^3 nodes x 3: 2.47 ms against 2.41) -- such leaves keep their panels.
     const char *cw   = getenv("HPDDM_HIP_CONDENSE_MAXROW"); // developer knob: largest average number of entries per row of A_RJ / column of A_JR
     const double maxrow = cw ? atof(cw) : 6.0;
+    const char *cr    = getenv("HPDDM_HIP_CONDENSE_RATIO"); // developer knob: largest blob / panel ratio
+    const double ratio = cr ? atof(cr) : 0.8;
     for (idx_t k = 0; k < nblk && condense; ++k) {
       const idx_t c0 = s.blk_ptr[k], w = s.blk_ptr[k + 1] - c0, nb = (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
       if (!children[k].empty() || s.height[k] >= first_device_level || hf.ldw[k] * SC > 128 || w + nb > 60000) continue;
@@ -491,7 +493,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       if ((double)std::max(nr, nc) > maxrow * (double)std::max<idx_t>(nb, 1)) continue;
       const LeafBlob lb = leaf_blob_layout(w, (long long)hf.ldw[k] * SC, nb, nr, nc, SC);
       // both sweeps read the blob once where they read the panel once (the forward sweep its transposed copy): worth it from 20 % less
-      if ((double)lb.bytes > 0.8 * (double)(w + nb) * hf.ldw[k] * SC * 8.0 || nr > 60000 || nc > 60000) continue;
+      if ((double)lb.bytes > ratio * (double)(w + nb) * hf.ldw[k] * SC * 8.0 || nr > 60000 || nc > 60000) continue;
       hf.lb_off[k]  = units;
       hf.lb_nnzr[k] = (idx_t)nr, hf.lb_nnzc[k] = (idx_t)nc;
       units += lb.bytes / 8;
