@@ -12,8 +12,8 @@
 //     and the backward sweep is its transpose,  x_J = F_J^T [ z_J ; -x_below ]  (G_J instead of F_J for LU),
 //   * supernodes are grouped by height in the assembly tree (= level); panels of a level are contiguous in the pool
 //     ("colour-packed") so a level is one contiguous HBM stream,
-//   * children -> parent contributions of the forward sweep go through per-supernode update vectors u_J (length nb)
-//     gathered by the parent (multifrontal solve): no atomics, bitwise reproducible.
+//   * children -> parent contributions of the forward sweep: the child writes its update (length nb) into a row of the parent
+//     (slot rows / compact lists below; multifrontal solve): no atomics, bitwise reproducible.
 #pragma once
 #include "common.hpp"
 

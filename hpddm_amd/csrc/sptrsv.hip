@@ -12,8 +12,9 @@
 // panels: one wavefront per tile, lanes own pairs of outputs and walk down the panel (the backward sweep on the row-major
 // panel, the forward sweep on a transposed copy), so neither sweep reduces across lanes until the very end.  All
 // subdomains of the GPU advance level by level in the same launches, so a level exposes (#subdomains x #supernodes x
-// #tiles) >> 256 workgroups.  No atomics on the data path: children hand their updates to the parent through
-// per-supernode update vectors (bitwise reproducible); the split-row tiles of the upper backward levels meet at an
+// #tiles) >> 256 workgroups.  No atomics on the data path: a child WRITES its update into a row of its own in the parent's front
+// (slot rows, factor.hpp: no lists, no gather pass, bitwise reproducible); the leaves of the tree go through W = inv(A_JJ) and the
+// original sparse couplings instead of their panels (condensed leaves); the split-row tiles of the upper backward levels meet at an
 // arrival counter and the last one adds the partial sums in a fixed order.
 #include "sptrsv_dev.hpp"
 #include <algorithm>

@@ -14,7 +14,7 @@
 //   * forward on the transposed copy FT (outputs = panel rows), backward on G (outputs = panel columns): ONE routine
 //     (wave_mfma_steps) does both; the right-hand side of a supernode is staged 64 rows at a time (8 KB per wavefront);
 //   * inside the sweeps the vectors are INTERLEAVED, entry i of column nu at (i * 16 + nu): the 16 values of a row are one 128-byte
-//     line, so the gathers of the multifrontal solve (children's update vectors, x on the row lists) and every store are whole
+//     line, so the hand-over of the multifrontal solve (children's update rows, x on the row lists) and every store are whole
 //     lines -- with 16 columns in the column-major layout each of them was 16 scattered 8-byte accesses.  Two passes
 //     (k_perm_in16 / k_perm_out16) go between the caller's layout and this one, folded into the permutation passes.
 #include "sptrsv_dev.hpp"

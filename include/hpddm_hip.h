@@ -60,12 +60,14 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
  * Cholesky factor; -3 when the matrix went through LU or is complex (the pivots do not carry the inertia); -1 on error */
 int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S);
 /* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
- *               update-pool size, kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
+ *               slot-pool size (doubles per right-hand side), kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
  *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), 0
  * times[0..3] = ordering, symbolic, numeric factorisation, upload (seconds) */
 int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
 /* Raw factor arrays for inspection / tests / the CPU baseline of bench.py (host copies; sizes from Info + the
- * arrays themselves).  which: "perm" "blk_ptr" "ldw" "f_off" "row_ptr" "rows" "height" "u_off" "goff" "gptr" "gsrc"
+ * arrays themselves).  which: "perm" "blk_ptr" "ldw" "f_off" "row_ptr" "rows" "height" "u_off" "rel" "nchild" "s_off" "ps_off" (the slot
+ * rows a child writes its update into) "c_off" "cptr" "crel" "cs_off" "pcs_off" (the compact lists of the 16-column engine) "lb_off" "lb_nnzr"
+ * "lb_nnzc" (condensed leaves; "leaf_pool": their blobs, double output)
  * "tgs" (per supernode: 0, or 6 when the LU factorisation exchanged rows inside its 64-column tiles) (int64 output), "F" "G" "dinv" "Lplain" "Uplain" (double output).  Returns the element count; out may be NULL. */
 long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which, void *out, long long capacity);
 /* the double arrays of the list above without a copy: pointer into the solver's own storage (valid until the next Numfact /
