@@ -60,7 +60,8 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
  * Cholesky factor; -3 when the matrix went through LU or is complex (the pivots do not carry the inertia); -1 on error */
 int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S);
 /* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
- *               slot-pool size (doubles per right-hand side), kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
+ *               update entries per right-hand side (the sum of the nb: what the children hand to their parents in one forward sweep),
+ *               kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
  *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), 0
  * times[0..3] = ordering, symbolic, numeric factorisation, upload (seconds) */
 int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
