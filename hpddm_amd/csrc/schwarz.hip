@@ -8,6 +8,9 @@
 // The halo sum of co-located subdomains is a gather (no message, no atomics): dof i of subdomain s reads the D-scaled
 // values of its duplicates in the neighbours through a CSR list built once from Subdomain::map_.
 #include "schwarz.hpp"
+#include <limits>
+#include <complex>
+#include <random>
 #include <chrono>
 #include <numeric>
 #include <algorithm>
@@ -963,10 +966,9 @@ void Schwarz::build_coarse()
   std::vector<double> gnu(nglobal, 0.0);
   for (int s = 0; s < nsub; ++s) gnu[first + s] = subs[s].nu;
   allreduce_host(gnu.data(), nglobal);
-  if (opt.count("geneo_force_uniformity")) {
+  if (opt.count("geneo_force_uniformity") && (int)getopt("geneo_force_uniformity", 0) == 0) {
     // -hpddm_geneo_force_uniformity min (Eigensolver::selectNu, include/HPDDM_eigensolver.hpp:112-120): every subdomain keeps the
-    // smallest number of vectors any subdomain kept.  "max" pads the short bases with random vectors in the reference: not built.
-    HH_CHECK((int)getopt("geneo_force_uniformity", 0) == 0, "geneo_force_uniformity max (random padding vectors) is not built; use min");
+    // smallest number of vectors any subdomain kept
     double m = gnu[0];
     for (int g = 0; g < nglobal; ++g) m = std::min(m, gnu[g]);
     const int keep = (int)std::lround(m);
@@ -978,6 +980,72 @@ void Schwarz::build_coarse()
       }
     std::fill(gnu.begin(), gnu.end(), (double)keep);
     opt["geneo_nu"] = keep;
+  } else if (opt.count("geneo_force_uniformity")) {
+    // -hpddm_geneo_force_uniformity max (include/HPDDM_eigensolver.hpp:121-147): every subdomain ends with the LARGEST number any
+    // subdomain kept; a shorter basis is padded with random vectors -- uniform in [min, max] of the real parts of its own vectors
+    // ([0, 1] for an empty basis, whose first vector is then normalised), real and imaginary part alike for complex scalars -- each
+    // made orthogonal (plain dot products, no weights, no normalisation) to the first i - 1 vectors of the basis it is appended to
+    // as vector i: the reference passes k = i - 1 to IterativeMethod::orthogonalization, the vector just before is not projected
+    // out.  The reference seeds from std::random_device (its padding differs from run to run); here the generator is seeded by the
+    // global number of the subdomain, so that a run can be repeated.
+    double mx = 0.0;
+    for (int g = 0; g < nglobal; ++g) mx = std::max(mx, gnu[g]);
+    const int cs = is_complex ? 2 : 1, want = (int)std::lround(mx) / cs; // vectors in the caller's scalar type
+    for (int s = 0; s < nsub; ++s) {
+      SchwarzSub &S = subs[s];
+      HH_CHECK(!is_complex || S.nu == 0 || S.zpairs, "geneo_force_uniformity max: complex deflation vectors set through SetVectorsZ / SolveGEVPZ");
+      int have = S.nu / cs;
+      if (have >= want) continue;
+      const int                              n = S.n / cs; // rows in the caller's scalar type
+      std::vector<std::complex<double>>      B((size_t)want * n);
+      double                                 lo = 0.0, hi = 1.0;
+      if (have) {
+        lo = hi = S.Z[0];
+        for (int k = 0; k < have; ++k)
+          for (int i = 0; i < n; ++i) {
+            const double re = S.Z[(size_t)(cs * k) * S.n + cs * i], im = is_complex ? S.Z[(size_t)(cs * k) * S.n + cs * i + 1] : 0.0;
+            B[(size_t)k * n + i] = {re, im};
+            lo = std::min(lo, re), hi = std::max(hi, re);
+          }
+      }
+      std::mt19937                           gen(12345u + 977u * (unsigned)(first + s));
+      std::uniform_real_distribution<double> uni(lo, hi);
+      for (size_t q = (size_t)have * n; q < (size_t)want * n; ++q) B[q] = {uni(gen), 0.0};
+      if (is_complex)
+        for (size_t q = (size_t)have * n; q < (size_t)want * n; ++q) B[q] = {B[q].real(), uni(gen)};
+      if (have == 0) {
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) nrm += std::norm(B[i]);
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < n; ++i) B[i] /= nrm;
+        have = 1;
+      }
+      for (int i = have; i < want; ++i) { // classical Gram-Schmidt against vectors 0 .. i - 2
+        std::complex<double> *v = B.data() + (size_t)i * n;
+        std::vector<std::complex<double>> h(std::max(0, i - 1));
+        for (int k = 0; k < i - 1; ++k) {
+          std::complex<double> acc = 0.0;
+          for (int r = 0; r < n; ++r) acc += std::conj(B[(size_t)k * n + r]) * v[r];
+          h[k] = acc;
+        }
+        for (int k = 0; k < i - 1; ++k)
+          for (int r = 0; r < n; ++r) v[r] -= h[k] * B[(size_t)k * n + r];
+      }
+      if (is_complex) {
+        std::vector<double> Zc((size_t)2 * want * n);
+        for (size_t q = 0; q < (size_t)want * n; ++q) Zc[2 * q] = B[q].real(), Zc[2 * q + 1] = B[q].imag();
+        const std::vector<double> ev = S.eigenvalues;
+        set_vectors_z(s, want, Zc.data());
+        S.eigenvalues = ev;
+      } else {
+        S.Z.resize((size_t)want * n);
+        for (size_t q = 0; q < (size_t)want * n; ++q) S.Z[q] = B[q].real();
+        S.nu = want;
+      }
+      S.eigenvalues.resize((size_t)want, std::numeric_limits<double>::quiet_NaN()); // (the padding vectors are not eigenvectors)
+    }
+    std::fill(gnu.begin(), gnu.end(), (double)(want * cs));
+    opt["geneo_nu"] = want;
   }
   coff.assign(nsub + 1, 0);
   for (int s = 0; s < nsub; ++s) coff[s + 1] = coff[s] + subs[s].nu;

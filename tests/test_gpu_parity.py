@@ -581,3 +581,49 @@ def test_custom_operator_callbacks():
     it, sol = A.solve([b])
     assert np.abs(sol[0] - exact).max() <= 1e-6 * np.abs(exact).max()
     A.destroy()
+
+
+def test_geneo_force_uniformity_max_pads_the_short_bases():
+    """-hpddm_geneo_force_uniformity max (Eigensolver::selectNu, include/HPDDM_eigensolver.hpp:121-147): the subdomains that kept fewer
+    vectors than the largest basis are padded with random vectors -- uniform between the smallest and the largest entry of their own
+    vectors, each made orthogonal to the first i - 1 vectors of the basis it joins as vector i (the reference's k = i - 1), not normalised --
+    and the two-level operator is built on the padded bases: checked against the oracle's operator on the SAME vectors (the reference seeds
+    from std::random_device: there is no run of it to compare the padding itself with)."""
+    N, parts = 12, 8
+    subs = generate3d(N, parts, 2, sym=True, rhs="smooth")
+    A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_force_uniformity max")
+    orc = Oracle(subs, correction="deflated")
+    orc.multiplicity_scaling([s["d"] for s in subs])
+    given = []
+    for s, sd in enumerate(subs):
+        i0, i1, j0, j1, k0, k1 = sd["box"]
+        z, y, x = np.meshgrid(np.arange(k0, k1) / N, np.arange(j0, j1) / N, np.arange(i0, i1) / N, indexing="ij")
+        Zs = np.stack([np.ones(sd["n"]), x.ravel(), y.ravel(), z.ravel()], axis=1)[:, :2 + s % 3]   # 2, 3, 4, 2, 3, 4, 2, 3 vectors (a constant alone would be padded with constants: min = max)
+        given.append(np.asfortranarray(Zs))
+        A.set_vectors(s, Zs)
+    A.build_coarse_operator()
+    assert int(A.stats()["coarse_dim"]) == 4 * parts
+    Z = [A.get_vectors(s) for s in range(parts)]
+    for s in range(parts):
+        have = given[s].shape[1]
+        assert Z[s].shape == (subs[s]["n"], 4) and np.array_equal(Z[s][:, :have], given[s])
+        lo, hi = given[s].min(), given[s].max()
+        for i in range(have, 4):
+            G = Z[s][:, :max(i - 1, 0)].T @ Z[s][:, i]
+            assert np.abs(G).max(initial=0.0) <= 1e-10 * np.linalg.norm(Z[s][:, i]) * max(1.0, np.abs(Z[s][:, :i]).max())
+            assert np.linalg.norm(Z[s][:, i]) > 0.1 * (hi - lo + 1e-300) and np.isfinite(Z[s][:, i]).all()
+    A.call_numfact()
+    orc.set_vectors(Z)
+    orc.build_coarse()
+    orc.numfact()
+    f = orc.exchange([np.random.default_rng(3).random(sd["n"]) for sd in subs])
+    _close(A.deflation(f), orc.deflation(f), 1e-9, "deflation")
+    _close(A.apply(f), orc.apply(f), 1e-9, "apply")
+    # the same request once more gives the same padding (the generator is seeded by the number of the subdomain)
+    B, _ = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_force_uniformity max")
+    for s in range(parts):
+        B.set_vectors(s, given[s])
+    B.build_coarse_operator()
+    assert all(np.array_equal(B.get_vectors(s), Z[s]) for s in range(parts))
+    A.destroy()
+    B.destroy()
