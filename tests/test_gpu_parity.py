@@ -599,6 +599,7 @@ def test_geneo_force_uniformity_max_pads_the_short_bases():
         i0, i1, j0, j1, k0, k1 = sd["box"]
         z, y, x = np.meshgrid(np.arange(k0, k1) / N, np.arange(j0, j1) / N, np.arange(i0, i1) / N, indexing="ij")
         Zs = np.stack([np.ones(sd["n"]), x.ravel(), y.ravel(), z.ravel()], axis=1)[:, :2 + s % 3]   # 2, 3, 4, 2, 3, 4, 2, 3 vectors (a constant alone would be padded with constants: min = max)
+        Zs = np.linalg.qr(Zs)[0]   # orthonormal, as an eigensolver returns them (the reference projects with plain dot products: it relies on that)
         given.append(np.asfortranarray(Zs))
         A.set_vectors(s, Zs)
     A.build_coarse_operator()
