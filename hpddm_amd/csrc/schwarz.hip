@@ -123,14 +123,22 @@ __global__ void k_diag(const long long *__restrict__ voff, const int *__restrict
 // 8 lanes takes FOUR consecutive rows per step and requests their row pointers, then their first 8 entries each, then the entries
 // of x, together: a row is a chain of three dependent round trips, and one row at a time left the kernel at 1.8 TB/s.
 template <int NB> // right-hand sides taken side by side (1: one column; 2; 4: blocks of four)
-__global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
+__global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc, const unsigned char *__restrict__ rmask, int rwant)
 {
+  // rmask / rwant: only the rows whose mark equals rwant are formed (the rows with a duplicate on another GPU first, the others under
+  // the messages: Schwarz::gmv); a group of rows without any such row is skipped before it reads anything else
   const int s = blockIdx.y, n = nn[s];
   const long long v0  = voff[s];
   const int      *ias = ia + iaoff[s];
   const int       lane = threadIdx.x & 7;
   const int       ngrp = (gridDim.x * blockDim.x) >> 3;
   for (int r0 = 4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 3); r0 < n; r0 += 4 * ngrp) {
+    if (rmask) {
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) any = any || (r0 + k < n && rmask[v0 + r0 + k] == rwant);
+      if (!any) continue;
+    }
     int p[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) p[k] = ias[min(r0 + k, n)];
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ vof
           acc[k][b] += __shfl_xor(acc[k][b], 2);
           acc[k][b] += __shfl_xor(acc[k][b], 1);
         }
-      if (lane < 4 && r0 + lane < n) {
+      if (lane < 4 && r0 + lane < n && (!rmask || rmask[v0 + r0 + lane] == rwant)) {
         const double w = dsc ? dsc[v0 + r0 + lane] : 1.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ vof
 // the same for K = std::complex<double> on the complex matrix itself (Wrapper::csrmm with complex scalars, include/HPDDM_wrapper.hpp:
 // 697-733): 16 + 4 bytes per entry where the real-equivalent embedding reads 32 + 4 (2 x 2 blocks); the vectors are the (re, im)
 // pairs of the caller either way.  n = 2 x (complex rows) as everywhere in the complex Schwarz layer.
-__global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
+__global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc, const unsigned char *__restrict__ rmask, int rwant)
 {
   // a group of 8 lanes takes TWO rows per step: their entries are read once, then four right-hand sides at a time -- eight
   // independent 16-byte gathers of x in flight per lane (one right-hand side after the other, every row paid three dependent
@@ -203,6 +211,7 @@ __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restr
   const int       lane = threadIdx.x & 7;
   const int       ngrp = (gridDim.x * blockDim.x) >> 3;
   for (int r0 = 2 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 3); r0 < nc; r0 += 2 * ngrp) {
+    if (rmask && !((rmask[v0 + 2 * (long long)r0] == rwant) || (r0 + 1 < nc && rmask[v0 + 2 * (long long)(r0 + 1)] == rwant))) continue; // (the mark of a complex row: the one of its real part)
     int p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) p[k] = ias[min(r0 + k, nc)];
@@ -235,7 +244,7 @@ __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restr
           ar += __shfl_xor(ar, 4), ai += __shfl_xor(ai, 4);
           ar += __shfl_xor(ar, 2), ai += __shfl_xor(ai, 2);
           ar += __shfl_xor(ar, 1), ai += __shfl_xor(ai, 1);
-          if (lane == 0 && nu0 + u < mu && r0 + k < nc) {
+          if (lane == 0 && nu0 + u < mu && r0 + k < nc && (!rmask || rmask[v0 + 2 * (long long)(r0 + k)] == rwant)) {
             const long long off = v0 * mu + (long long)(nu0 + u) * n + 2 * (long long)(r0 + k);
             double2         o   = beta == 0.0 ? double2{0.0, 0.0} : *reinterpret_cast<const double2 *>(y0 + off);
             const double    w   = dsc ? dsc[v0 + 2 * (long long)(r0 + k)] : 1.0;
@@ -250,13 +259,19 @@ __global__ void k_csrmm_z(const long long *__restrict__ voff, const int *__restr
 
 // the same on block CSR (BS x BS dense blocks, one column index per block): 8 lanes per block row
 template <int BS>
-__global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ biaoff, const int *__restrict__ bia, const int *__restrict__ bja, const double *__restrict__ ba, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc)
+__global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ biaoff, const int *__restrict__ bia, const int *__restrict__ bja, const double *__restrict__ ba, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc, const unsigned char *__restrict__ rmask, int rwant)
 {
   const int s = blockIdx.y, n = nn[s], nb = n / BS;
   const long long v0   = voff[s];
   const int      *bias = bia + biaoff[s];
   const int       lane = threadIdx.x & 7;
   for (int R = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; R < nb; R += (gridDim.x * blockDim.x) >> 3) {
+    if (rmask) { // (a block row is formed when any of its rows is asked for; only those rows are stored)
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < BS; ++i) any = any || rmask[v0 + (long long)R * BS + i] == rwant;
+      if (!any) continue;
+    }
     const int p0 = bias[R], p1 = bias[R + 1];
     for (int nu = 0; nu < mu; ++nu) {
       const double *xs = x + v0 * mu + (long long)nu * n;
@@ -284,6 +299,7 @@ __global__ void k_bsrmm(const long long *__restrict__ voff, const int *__restric
         const long long off = v0 * mu + (long long)nu * n + (long long)R * BS;
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
+          if (rmask && rmask[v0 + (long long)R * BS + i] != rwant) continue;
           const double t = (beta == 0.0 ? 0.0 : beta * y0[off + i]) + alpha * acc[i];
           y[off + i]     = dsc ? dsc[v0 + (long long)R * BS + i] * t : t;
         }
@@ -800,6 +816,9 @@ void Schwarz::build_device()
     rx_k_d.upload(h_rx_k, st);
     rx_po_d.upload(h_rx_po, st);
     rx_pc_d.upload(h_rx_pc, st);
+    std::vector<unsigned char> remote((size_t)ntot, 0);
+    for (size_t q = 0; q < h_send_sub.size(); ++q) remote[voff[h_send_sub[q]] + h_send_idx[q]] = 1;
+    remote_rows_d.upload(remote, st);
   }
   HIP_OK(hipStreamSynchronize(st));
   device_ready = true;
@@ -1324,7 +1343,7 @@ void Schwarz::exchange(const double *in, double *out, int mu, bool scale)
   }
   hipLaunchKernelGGL(k_halo_unpack, grid2(nmax, nsub), dim3(256), 0, st, voff_d.p, n_d.p, rx_ptr_d.p, rx_k_d.p, rx_po_d.p, rx_pc_d.p, recvbuf, out, mu);
 }
-void Schwarz::halo_sum_inplace(double *x, int mu)
+void Schwarz::halo_sum_inplace(double *x, int mu, const std::function<void()> &interior)
 {
   // x holds, per duplicate, what Subdomain::exchange would send (D x when the producer folded Wrapper::diag into its store): sum
   // the duplicates in place, touching the overlap only.  Neighbours on other GPUs: pack (no scaling) and the messages on the
@@ -1349,6 +1368,7 @@ void Schwarz::halo_sum_inplace(double *x, int mu)
     hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)std::min<long long>(1024, (halo_total + 255) / 256)), dim3(256), 0, cs, voff_d.p, n_d.p, d_d.p, send_sub_d.p, send_idx_d.p, send_po_d.p, send_pc_d.p, halo_total, x, sendbuf, mu, 0);
     if (overlap) HIP_OK(hipEventRecord(ev_halo_packed, cs));
   }
+  if (interior) interior(); // what the producer still owes of x (rows that do not travel): on the library stream, beside the pack and the messages
   if (novl) {
     const dim3 g((unsigned)std::min(2048, (novl + 255) / 256));
     hipLaunchKernelGGL(k_halo_ovl_sum, g, dim3(256), 0, st, voff_d.p, n_d.p, ovl_sub.p, ovl_idx.p, novl, ex_ptr.p, ex_sub.p, ex_idx.p, x, halo_tmp.p, mu);
@@ -1435,20 +1455,22 @@ void Schwarz::build_bsr()
   }
 }
 
-void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0, bool scaled)
+void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0, bool scaled, int rows)
 {
+  // rows: -1 all of them; 1 / 0 only the rows with / without a duplicate on another GPU (remote_rows_d)
+  const unsigned char *rm = rows >= 0 ? remote_rows_d.p : nullptr;
   // y = [D] (beta y0 + alpha A x); y0 defaults to y; scaled: the partition of unity of the exchange that follows, at the store
   if (!y0) y0 = y;
   HH_CHECK(x != y, "csrmm: the product cannot overwrite its argument");
   const double *dsc = scaled ? d_d.p : nullptr;
   if (zia_d.p) { // complex operators: the complex matrix itself
-    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 4 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta, y0, dsc);
+    hipLaunchKernelGGL(k_csrmm_z, dim3((unsigned)std::min(4096, (nmax / 2 * 4 + 255) / 256), (unsigned)nsub), dim3(256), 0, library_stream(), voff_d.p, n_d.p, ziaoff_d.p, zia_d.p, zja_d.p, za_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
     return;
   }
   if (bsr_bs) {
     const dim3 g((unsigned)std::min(4096, (nmax / bsr_bs * 8 + 255) / 256), (unsigned)nsub);
-    if (bsr_bs == 3) hipLaunchKernelGGL(k_bsrmm<3>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc);
-    else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc);
+    if (bsr_bs == 3) hipLaunchKernelGGL(k_bsrmm<3>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    else hipLaunchKernelGGL(k_bsrmm<2>, g, dim3(256), 0, library_stream(), voff_d.p, n_d.p, biaoff_d.p, bia_d.p, bja_d.p, ba_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
     return;
   }
   const dim3 gc((unsigned)std::min(4096, (nmax * 2 + 255) / 256), (unsigned)nsub);
@@ -1456,9 +1478,9 @@ void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double bet
   // 2.08 ms against 1.94 at 8 x 129^3 with 8 right-hand sides, gpurun_out r05e: the gathers of x are bound by L2 sectors, 8 bytes of 32
   // used, not by their latency; -hpddm_hip_gmv_block 2 | 4 keeps the variants reachable)
   const int nb = (int)getopt("hip_gmv_block", 1);
-  if (nb >= 4 && mu >= 4) hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
-  else if (nb >= 2 && mu >= 2) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
-  else hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc);
+  if (nb >= 4 && mu >= 4) hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+  else if (nb >= 2 && mu >= 2) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+  else hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
 }
 void Schwarz::axpy(double alpha, const double *x, double *y, long long cnt)
 {
@@ -1485,6 +1507,14 @@ void Schwarz::gmv(const double *in, double *out, int mu)
   if (getopt("hip_fused_scaling", 1) == 0 || in == out) { // (in place: the product cannot be written over its own input -- through w3, as before round 4)
     csrmm(in, w3.p, mu, 1.0, 0.0);
     exchange(w3.p, out, mu, true);
+    return;
+  }
+  if (halo_total && remote_rows_d.p && getopt("hip_halo_overlap", 1) != 0 && getopt("hip_gmv_boundary_first", 1) != 0) {
+    // several GPUs: the rows that travel are formed first, packed and sent on the communication stream; the other rows -- nearly all
+    // of them -- are formed on the library stream while the messages are under way (round 5; until then the pack waited for the
+    // whole product).  The two passes write disjoint rows of `out`.
+    csrmm(in, out, mu, 1.0, 0.0, nullptr, true, 1);
+    halo_sum_inplace(out, mu, [&]() { csrmm(in, out, mu, 1.0, 0.0, nullptr, true, 0); });
     return;
   }
   csrmm(in, out, mu, 1.0, 0.0, nullptr, true); // out = D A in, the partition of unity at the store of the product

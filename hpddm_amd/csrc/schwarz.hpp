@@ -4,6 +4,7 @@
 #pragma once
 #include "local_solver.hpp"
 #include "transport.hpp"
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -75,6 +76,7 @@ struct Schwarz {
   struct RemotePair { int s, k; long long pos, po, pc; };               // remote pair (local s, map entry k): first position of its block in the recv buffer
   std::vector<RemotePair> h_pairs;
   DevBuf<int>           send_sub_d, send_idx_d, send_po_d, send_pc_d, rx_ptr_d, rx_k_d, rx_po_d, rx_pc_d;
+  DevBuf<unsigned char> remote_rows_d; // per dof: 1 when it has a duplicate on another GPU (it is packed into a message): the rows the GMV forms first
   double               *sendbuf = nullptr, *recvbuf = nullptr; // packed halo, mu_cap * halo_total doubles each: owned by the host framework
   DevBuf<double>        own_send, own_recv;                     // (callback transport) or by the library (RCCL transport)
   int                   halo_mu_cap = 0;
@@ -131,7 +133,7 @@ struct Schwarz {
   DevBuf<double>         halo_tmp;               // novl x mu
   hipEvent_t             ev_halo_packed = nullptr;
   std::vector<hipStream_t> pattern_streams; // HPDDM_HIP_STREAM_PATTERN (developer aid): the streams created ahead of the groups', unused
-  void                   halo_sum_inplace(double *x, int mu); // x <- sum of the duplicates of x (x already scaled by the producer)
+  void                   halo_sum_inplace(double *x, int mu, const std::function<void()> &interior = nullptr); // x <- sum of the duplicates of x (x already scaled by the producer); interior: the part of x the producer forms AFTER the rows that travel are packed (under the messages)
   SolvePlan              plan;
   // The subdomains of the GPU are swept as several groups on several streams: while one group sits at a level boundary (drain
   // of a launch, ramp of the next) the others keep the memory system busy.  plan = the first group (on the library stream),
@@ -193,7 +195,7 @@ struct Schwarz {
   // device-pointer operations on the library stream (batched layout, see hpddm_hip.h)
   void exchange(const double *in, double *out, int mu, bool scale); // out = halo_sum((scale ? D : I) in), out != in
   void exchange_inplace(double *x, int mu, bool scale);
-  void csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0 = nullptr, bool scaled = false); // y = [D] (beta*y0 + alpha*A*x), y0 = y by default
+  void csrmm(const double *x, double *y, int mu, double alpha, double beta, const double *y0 = nullptr, bool scaled = false, int rows = -1); // y = [D] (beta*y0 + alpha*A*x), y0 = y by default; rows = 1 / 0: only the rows with / without a duplicate on another GPU
   void gmv(const double *in, double *out, int mu);
   // HpddmCustomOperatorSolve (interface/hpddm_c.cpp:41-53, 227-230: CustomOperator<Operator, K> handed to IterativeMethod::solve): the
   // operator and the preconditioner of the Krylov methods are callbacks of the caller on HOST vectors (n x mu, column-major); the
