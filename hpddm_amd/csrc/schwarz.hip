@@ -1728,8 +1728,14 @@ void Schwarz::apply(const double *in, double *out, int mu)
     solve_factor(w2.p, w2.p, mu);                                               // :590
     exchange(w2.p, w1.p, mu, true);                                             // :591   work now in w1
   } else {
-    csrmm(out, w2.p, mu, -1.0, 1.0, in, true);                                  // :581-588  w2 = D (in - A out), one pass, then the halo on the overlap
-    halo_sum_inplace(w2.p, mu);
+    if (halo_total && remote_rows_d.p && getopt("hip_halo_overlap", 1) != 0 && getopt("hip_gmv_boundary_first", 1) != 0) {
+      // several GPUs: the rows that travel first, the others under the messages (as in Schwarz::gmv)
+      csrmm(out, w2.p, mu, -1.0, 1.0, in, true, 1);
+      halo_sum_inplace(w2.p, mu, [&]() { csrmm(out, w2.p, mu, -1.0, 1.0, in, true, 0); });
+    } else {
+      csrmm(out, w2.p, mu, -1.0, 1.0, in, true);                                // :581-588  w2 = D (in - A out), one pass, then the halo on the overlap
+      halo_sum_inplace(w2.p, mu);
+    }
     if (type == PRC_OS) diag(w2.p, w2.p, mu);                                   // :589
     solve_factor(w2.p, w1.p, mu, true);                                         // :590-591  w1 = D A^{-1} w2, then the halo
     halo_sum_inplace(w1.p, mu);
