@@ -439,7 +439,7 @@ def test_richardson_and_no_krylov_match_reference():
     A.destroy()
 
 
-@pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4", "z_p30_bfbcg_asm_hpd_mu3", "z_p30_bfbcg_asm_rhs_deflation_mu4"])
+@pytest.mark.parametrize("name", ["p40_bfbcg_asm_mu3", "p40_bfbcg_asm_rhs_deflation_mu4", "z_p30_bfbcg_asm_hpd_mu3", "z_p30_bfbcg_asm_rhs_deflation_mu4", "z_p30_bfbcg_asm_shift0_mu3"])
 def test_bfbcg_matches_reference(name):
     """Breakdown-free block CG (include/HPDDM_CG.hpp:342-482), plain and with -hpddm_deflation_tol on a block whose last
     right-hand side is f_0 + 2 f_1 (one direction deflated at every iteration): the reference's 31 / 32 iterations,

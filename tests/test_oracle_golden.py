@@ -136,7 +136,9 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-4), ("p40_bcg_asm_mu3", "bcg", 2e-6),
     # K = std::complex<double> on a Hermitian positive definite operator: the reference's CG / BCG / BFBCG converge (17 / 20 / 15 / 16 / 20 iterations)
     ("z_p30_cg_asm_hpd_mu3", "cg", 1e-5), ("z_p30_bcg_asm_hpd_mu3", "bcg", 1e-4), ("z_p30_bfbcg_asm_hpd_mu3", "bfbcg", 1e-4),
-    ("z_p30_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-4), ("z_p30_6ranks_bcg_asm_hpd_mu2", "bcg", 1e-4)])
+    ("z_p30_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-4), ("z_p30_6ranks_bcg_asm_hpd_mu2", "bcg", 1e-4),
+    # the same operator without its shift (the plain Laplacian): BFBCG 34 iterations
+    ("z_p30_bfbcg_asm_shift0_mu3", "bfbcg", 1e-4)])
 def test_other_krylov_methods_match_reference(name, method, tol_hist):
     """CG, Block CG and Block GMRES restated in numpy (oracle/ras_oracle.py: cg, bcg, bgmres) against the runs of the compiled
     reference: iteration counts, residual histories, final residuals.  (BCG tests and prints the residual of the LAST right-hand
