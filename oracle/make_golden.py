@@ -54,6 +54,10 @@ CASES = [
     ("z_p30_gmres_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -5 -complex_shift_im 3"),
     ("z_p30_gmres_left_deflated", 4, 1, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("z_p30_6ranks_bgmres_mu3_balanced", 6, 3, "-Nx 30 -Ny 30 -overlap 2 -complex_shift_re -5 -complex_shift_im 3 -hpddm_krylov_method bgmres -hpddm_schwarz_coarse_correction balanced -hpddm_geneo_nu=0"),
+    # round 5: the additive correction, the flexible variant with restarts and flexible Block GMRES for K = std::complex<double>
+    ("z_p30_additive_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_coarse_correction additive -hpddm_geneo_nu=0"),
+    ("z_p30_fgmres_restart8_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_variant flexible -hpddm_gmres_restart=8"),
+    ("z_p30_fbgmres_mu3", 4, 3, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_variant flexible -hpddm_gmres_restart=6"),
     ("z_p30_bgmres_mu8", 4, 8, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_gmres_restart=10"),
     ("z_p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     # complex optimised local matrices (callNumfact(A_opt) with K = std::complex<double>: what ORAS does for Helmholtz), OG and OS

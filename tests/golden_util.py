@@ -96,8 +96,9 @@ def subdomains(g):
     return subs
 
 
-COMPLEX_CASES = ["z_p30_gmres_mu2", "z_p30_gmres_left_deflated", "z_p30_6ranks_deflated_nu3", "z_p30_oras_og_mu2", "z_p30_soras_os_deflated"]          # K = std::complex<double>, GMRES
-COMPLEX_BGMRES_CASES = ["z_p30_6ranks_bgmres_mu3_balanced", "z_p30_bgmres_mu8", "z_p30_bgmres_rhs_deflation_mu4"]
+COMPLEX_CASES = ["z_p30_gmres_mu2", "z_p30_gmres_left_deflated", "z_p30_6ranks_deflated_nu3", "z_p30_oras_og_mu2", "z_p30_soras_os_deflated",
+                 "z_p30_additive_mu2", "z_p30_fgmres_restart8_mu2"]          # K = std::complex<double>, GMRES
+COMPLEX_BGMRES_CASES = ["z_p30_6ranks_bgmres_mu3_balanced", "z_p30_bgmres_mu8", "z_p30_bgmres_rhs_deflation_mu4", "z_p30_fbgmres_mu3"]
 MULTI_VECTOR_CASES = ["p30_6ranks_deflated_nu3"]   # three deflation vectors per subdomain, non-symmetric local matrices
 
 

@@ -130,7 +130,7 @@ def test_penalised_dirichlet_rows_match_reference(name):
     ("p40_cg_asm", "cg", 2e-6), ("p40_bgmres_mu4", "bgmres", 2e-6), ("p40_bgmres_deflated_mu2", "bgmres", 2e-4),
     ("p30_6ranks_bgmres_left_mu3", "bgmres", 2e-6), ("p40_fbgmres_mu3", "bgmres", 2e-4),
     ("p40_bgmres_rhs_deflation_mu4", "bgmres", 2e-6), ("p40_bgmres_rhs_deflation_restart_mu4", "bgmres", 5e-5),
-    ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6), ("z_p30_bgmres_rhs_deflation_mu4", "bgmres", 2e-6),
+    ("z_p30_6ranks_bgmres_mu3_balanced", "bgmres", 2e-6), ("z_p30_bgmres_mu8", "bgmres", 2e-6), ("z_p30_bgmres_rhs_deflation_mu4", "bgmres", 2e-6), ("z_p30_fbgmres_mu3", "bgmres", 2e-4),
     ("p40_bgmres_mgs_qrmgs_mu3", "bgmres", 1e-5), ("p40_bgmres_qrcgs_mu3", "bgmres", 1e-5),
     ("p40_bfbcg_asm_mu3", "bfbcg", 1e-5), ("p40_bfbcg_asm_rhs_deflation_mu4", "bfbcg", 1e-5),
     ("p30_6ranks_bcg_asm_sym_mu2", "bcg", 5e-4), ("p40_bcg_asm_mu3", "bcg", 2e-6),
