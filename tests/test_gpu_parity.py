@@ -419,9 +419,11 @@ def test_gcrodr_matches_reference(name):
     A.destroy()
 
 
-def test_richardson_and_no_krylov_match_reference():
-    """-hpddm_krylov_method richardson (include/HPDDM_iterative.hpp:971-993) and none (:1056-1066): the reference's solutions"""
-    g = gu.load("p40_richardson_mu2")
+@pytest.mark.parametrize("pre", ["p40", "z_p30"])
+def test_richardson_and_no_krylov_match_reference(pre):
+    """-hpddm_krylov_method richardson (include/HPDDM_iterative.hpp:971-993) and none (:1056-1066): the reference's solutions, real
+    scalars and (round 5) K = std::complex<double>"""
+    g = gu.load(pre + "_richardson_mu2")
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
     f = gu.vecs(g, "f")
@@ -430,7 +432,7 @@ def test_richardson_and_no_krylov_match_reference():
     _close(sol, gu.vecs(g, "sol"), 1e-11, "Richardson")
     assert np.allclose(A.compute_residual(sol, f), g["residual_r0"], rtol=1e-9)
     A.destroy()
-    g = gu.load("p40_none_deflated_mu2")
+    g = gu.load(pre + "_none_deflated_mu2")
     subs = gu.subdomains(g)
     A, d, opt = _build(g, subs)
     it, sol = A.solve(gu.vecs(g, "f"))

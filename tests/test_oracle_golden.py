@@ -224,12 +224,13 @@ def test_gcrodr_matches_reference(name, recycle, same):
     _close(sol2, gu.vecs(g, "sol2"), 1e-9, "second solution")
 
 
-def test_richardson_and_no_krylov_match_reference():
+@pytest.mark.parametrize("pre", ["p40", "z_p30"])
+def test_richardson_and_no_krylov_match_reference(pre):
     """-hpddm_krylov_method richardson (15 damped iterations, no convergence test) and none (one preconditioner apply): the
     reference's solutions.  (With `none` the reference hands its right-hand side to the two-level apply as work space, so the
     residual it prints afterwards is not that of the system: only the solution is compared.)"""
     from oracle import ras_oracle as ro
-    g = gu.load("p40_richardson_mu2")
+    g = gu.load(pre + "_richardson_mu2")
     subs = gu.subdomains(g)
     orc, opt = _setup(g, subs)
     f = gu.vecs(g, "f")
@@ -237,7 +238,7 @@ def test_richardson_and_no_krylov_match_reference():
     assert it == int(g["iterations_r0"][0]) == 15
     _close(sol, gu.vecs(g, "sol"), 1e-12, "Richardson")
     assert np.allclose(orc.compute_residual(sol, f), g["residual_r0"], rtol=1e-10)
-    g = gu.load("p40_none_deflated_mu2")
+    g = gu.load(pre + "_none_deflated_mu2")
     subs = gu.subdomains(g)
     orc, opt = _setup(g, subs)
     it, sol = ro.no_krylov(orc, gu.vecs(g, "f"))
