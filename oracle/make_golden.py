@@ -60,6 +60,8 @@ CASES = [
     ("z_p30_fbgmres_mu3", 4, 3, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_variant flexible -hpddm_gmres_restart=6"),
     ("z_p30_richardson_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method richardson -hpddm_max_it 15 -hpddm_richardson_damping_factor 0.7"),
     ("z_p30_none_deflated_mu2", 4, 2, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method none -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
+    ("z_p36x60_9ranks_mu2", 9, 2, "-Nx 36 -Ny 60 -overlap 2 -complex_shift_re -10 -complex_shift_im 2"),
+    ("p40_osm_og", 4, 2, "-Nx 40 -Ny 40 -overlap 2 -hpddm_schwarz_method osm -optimized_shift 30"),
     ("z_p30_bgmres_mu8", 4, 8, "-Nx 30 -Ny 30 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgmres -hpddm_gmres_restart=10"),
     ("z_p30_6ranks_deflated_nu3", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -deflation_nu 3 -complex_shift_re -10 -complex_shift_im 2 -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     # complex optimised local matrices (callNumfact(A_opt) with K = std::complex<double>: what ORAS does for Helmholtz), OG and OS

@@ -56,7 +56,7 @@ def options(g):
     return out
 
 
-OPTIMIZED_CASES = ["p40_oras_og", "p40_soras_os_sym", "p40_soras_os_deflated"]
+OPTIMIZED_CASES = ["p40_oras_og", "p40_soras_os_sym", "p40_soras_os_deflated", "p40_osm_og"]
 PENALIZED_CASES = ["p40_penalized_mu2", "p40_penalized_sym_left", "p40_penalized_left_mu2_ov2"]
 
 
@@ -97,7 +97,7 @@ def subdomains(g):
 
 
 COMPLEX_CASES = ["z_p30_gmres_mu2", "z_p30_gmres_left_deflated", "z_p30_6ranks_deflated_nu3", "z_p30_oras_og_mu2", "z_p30_soras_os_deflated",
-                 "z_p30_additive_mu2", "z_p30_fgmres_restart8_mu2"]          # K = std::complex<double>, GMRES
+                 "z_p30_additive_mu2", "z_p30_fgmres_restart8_mu2", "z_p36x60_9ranks_mu2"]          # K = std::complex<double>, GMRES
 COMPLEX_BGMRES_CASES = ["z_p30_6ranks_bgmres_mu3_balanced", "z_p30_bgmres_mu8", "z_p30_bgmres_rhs_deflation_mu4", "z_p30_fbgmres_mu3"]
 MULTI_VECTOR_CASES = ["p30_6ranks_deflated_nu3"]   # three deflation vectors per subdomain, non-symmetric local matrices
 
