@@ -83,6 +83,7 @@ def _declare(lib):
         "HpddmHipRcclGetUniqueId": (I, [P]),
         "HpddmHipSchwarzInitRccl": (I, [P, P, I]),
         "HpddmHipRcclSelfTest": (I, []),
+        "HpddmHipRcclHaloProbe": (I, [P, P, P, P, I, P, P, LL]),
         "HpddmHipSchwarzApplyDevice": (I, [P, P, P, US]),
         "HpddmHipSchwarzGMVDevice": (I, [P, P, P, US]),
         "HpddmHipSolveDevice": (I, [P, P, P, I, P, I]),

@@ -630,6 +630,14 @@ int HpddmHipSchwarzInitRccl(HpddmHipSchwarz *A, const char *id128, int mu_cap)
     A->op.use_rccl(id128, mu_cap);
     return 0;)
 }
+int HpddmHipRcclHaloProbe(HpddmHipSchwarz *A, const char *id128, const double *sendbuf, double *recvbuf, int mu, double *red_sum, double *red_max, long long nred)
+{
+  HH_TRY(
+    HH_CHECK(A && id128 && sendbuf && recvbuf && mu > 0, "bad argument");
+    A->op.build_halo_lists();
+    rccl_halo_probe(id128, A->op.nranks, A->op.rank, A->op.peers, sendbuf, recvbuf, mu, red_sum, red_max, nred);
+    return 0;)
+}
 int HpddmHipRcclSelfTest(void)
 {
   HH_TRY(

@@ -125,6 +125,7 @@ struct DeviceFactor {
 struct SolvePlan {
   std::vector<const DeviceFactor *> factors;
   std::vector<long long>            voff; // per factor: element offset in the batched vectors
+  int                               slot_pad = 0; // tallest front without children: padding of the slot pool (SolvePlan::reserve)
   long long                         ntot = 0, utot = 0, ctot = 0; // utot: entries of the slot pools of all the factors; ctot: of their compact hand-over pools (16-column engine)
   int                               nlev = 0;
   DevBuf<SnDesc> sn;

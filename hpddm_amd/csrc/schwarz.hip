@@ -1912,7 +1912,6 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
   // rows do not count in the residual and penalised entries of f are divided by HPDDM_PEN.  norm: 0 = l2 and 1 = l1, both weighted by
   // the partition of unity (HPDDM_COMPUTE_RESIDUAL_L2 / _L1), 2 = linfty (plain maximum)
   HH_CHECK(norm >= 0 && norm <= 2, "ComputeResidual: unknown norm");
-  HH_CHECK(norm != 2 || nranks == 1, "ComputeResidual: linfty needs a max-reduction over the ranks, not part of the registered transport");
   reserve(mu);
   const size_t cnt = (size_t)ntot * mu;
   gmv(x, w1.p, mu);
@@ -1948,6 +1947,10 @@ void Schwarz::compute_residual(const double *x, const double *f, double *storage
     for (int nu = 0; nu < mu; ++nu) {
       std::memcpy(&storage[2 * nu], &h[nu], sizeof(double));
       std::memcpy(&storage[2 * nu + 1], &h[mu + nu], sizeof(double));
+    }
+    if (nranks > 1) { // MPI_Allreduce(..., MPI_MAX, ...) of the reference (include/HPDDM_schwarz.hpp:802)
+      HH_CHECK(transport != nullptr, "several ranks but no transport registered (HpddmHipSchwarzInitRccl / HpddmHipSchwarzSetTransport)");
+      transport->allreduce_max_host(storage, 2LL * mu, rank, nranks, st);
     }
     return;
   }

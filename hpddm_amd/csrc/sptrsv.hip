@@ -804,7 +804,7 @@ __device__ static inline void fwd_rhs_entries(const SnView &d, const int (&col)[
   for (int j = 0; j < SU; ++j) {
     const int c = ok[j] ? (Z ? col[j] >> 1 : col[j]) : 0, plane = ok[j] ? ((Z && (col[j] & 1)) ? (nu[j] ^ 1) : nu[j]) : 0;
     ob[j]       = (long long)plane * d.n + d.c0 + c;
-    os[j]       = (long long)plane * stot + d.s_in + c;
+    os[j]       = (long long)plane * stot + d.s_in + c; // (childless: a dropped read inside the padding of the pool, SolvePlan::reserve)
   }
 #pragma unroll
   for (int j = 0; j < SU; ++j) b[j] = bb[ob[j]], u0[j] = Sb[os[j]], u1[j] = Sb[os[j] + (c2 ? h : 0)];
@@ -1431,6 +1431,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   factors = fs;
   voff.assign(fs.size(), 0);
   ntot = utot = ctot = 0;
+  slot_pad            = 0;
   nlev                = 0;
   bytes_alg_per_rhs1  = 0;
   std::vector<long long> soffs(fs.size(), 0), coffs(fs.size(), 0);
@@ -1499,6 +1500,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       d.cs    = cs;
       d.s_in   = (int)D.s_off[k];
       d.nchild = D.nchild[k];
+      if (d.nchild == 0) slot_pad = std::max(slot_pad, d.w + d.nb);
       d.s_out  = (int)D.ps_off[k];
       d.cptr   = D.cptr.p + D.c_off[k];
       d.crel   = D.crel.p + D.u_off[k];
@@ -1723,8 +1725,11 @@ void SolvePlan::reserve(int mu, hipStream_t s)
   bperm.alloc((size_t)ntot * mu);
   // the slot pool (factor.hpp): one copy per right-hand side column, utot entries apart whatever mu is -- the entries no child
   // writes must stay zero from here on, so the place of an entry may not depend on the number of right-hand sides of a solve
-  U.alloc((size_t)std::max<long long>(utot, 1) * mu + 64); // (+ padding: the branch-free loads of the bottom-level tiles read one entry past an empty block)
-  HIP_OK(hipMemsetAsync(U.p, 0, sizeof(double) * ((size_t)std::max<long long>(utot, 1) * mu + 64), s));
+  // + padding: the branch-free loads of the forward tiles read the slot entries of a supernode WITHOUT children too (the value is
+  // dropped): positions [s_in, s_in + w + nb) with s_in up to the end of the pool when the supernode is the last of its factor
+  const size_t upad = 64 + (size_t)slot_pad;
+  U.alloc((size_t)std::max<long long>(utot, 1) * mu + upad);
+  HIP_OK(hipMemsetAsync(U.p, 0, sizeof(double) * ((size_t)std::max<long long>(utot, 1) * mu + upad), s));
   HIP_OK(hipStreamSynchronize(s));
   partials.alloc((size_t)std::max(1, ngroups) * max_parts * 128 * std::min(mu, 16));
   mu_cap = mu;

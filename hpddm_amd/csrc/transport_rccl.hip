@@ -137,6 +137,14 @@ struct RcclTransport : Transport {
     HIP_OK(hipMemcpyAsync(buf, stage.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
   }
+  void allreduce_max_host(double *buf, long long count, int, int, hipStream_t s) override
+  {
+    if ((long long)stage.n < count) stage.alloc((size_t)count);
+    HIP_OK(hipMemcpyAsync(stage.p, buf, sizeof(double) * count, hipMemcpyHostToDevice, s));
+    RCCL_OK(rccl().AllReduce(stage.p, stage.p, (size_t)count, ncclDouble, ncclMax, comm, s));
+    HIP_OK(hipMemcpyAsync(buf, stage.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+  }
 };
 } // namespace
 
@@ -150,6 +158,25 @@ void rccl_unique_id(char *id128)
 std::unique_ptr<Transport> make_rccl_transport(const char *id128, int nranks, int rank)
 {
   return std::unique_ptr<Transport>(new RcclTransport(id128, nranks, rank));
+}
+
+void rccl_halo_probe(const char *id128, int nranks, int rank, const std::vector<HaloPeer> &peers, const double *sendbuf, double *recvbuf, int mu, double *red_sum, double *red_max, long long nred)
+{
+  // one halo exchange + one sum + one maximum through the SAME RcclTransport object an operator would use, on buffers of the
+  // caller: device pointers on the library stream; on a host without a device (diagnostics against a host-side double of
+  // librccl bound through HPDDM_HIP_RCCL_LIB) host pointers and no stream
+  int ndev = 0;
+  const bool dev = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  hipStream_t s = dev ? library_stream() : nullptr;
+  std::unique_ptr<Transport> t = make_rccl_transport(id128, nranks, rank);
+  t->halo(peers, sendbuf, recvbuf, mu, s);
+  if (nred > 0) {
+    HH_CHECK(!dev, "halo probe: the reductions of the probe are host-side diagnostics (no device visible)");
+    RcclTransport *r = static_cast<RcclTransport *>(t.get());
+    RCCL_OK(rccl().AllReduce(red_sum, red_sum, (size_t)nred, ncclDouble, ncclSum, r->comm, s));
+    RCCL_OK(rccl().AllReduce(red_max, red_max, (size_t)nred, ncclDouble, ncclMax, r->comm, s));
+  }
+  if (dev) HIP_OK(hipStreamSynchronize(s));
 }
 
 void rccl_self_test()

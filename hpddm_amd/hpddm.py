@@ -35,6 +35,17 @@ def rccl_unique_id():
     return buf.raw
 
 
+def rccl_halo_probe(A, unique_id, send, mu, red_sum=None, red_max=None):
+    """HpddmHipRcclHaloProbe on host arrays (no device; HPDDM_HIP_RCCL_LIB must name a host-side double of librccl): returns the receive
+    buffer of one exchange of ``A``'s peer layout; ``red_sum`` / ``red_max`` (same length) are reduced in place over the ranks"""
+    send = np.ascontiguousarray(send, dtype=np.float64)
+    recv = np.zeros_like(send)
+    n = 0 if red_sum is None else len(red_sum)
+    check(_lib.load().HpddmHipRcclHaloProbe(A._h, ctypes.create_string_buffer(unique_id, 128), _dptr(send), _dptr(recv), int(mu), _dptr(red_sum) if n else None,
+                                            _dptr(red_max) if n else None, n))
+    return recv
+
+
 def rccl_self_test():
     """one-rank check of the RCCL transport on the library stream (HpddmHipRcclSelfTest)"""
     check(_lib.load().HpddmHipRcclSelfTest())

@@ -240,6 +240,12 @@ int HpddmHipSchwarzInitRccl(HpddmHipSchwarz *A, const char *id128, int mu_cap);
 /* what a single GPU can check of that path: binding, a one-rank communicator, a grouped send/recv pair to the rank itself and an
  * all-reduce, ordered on the library stream; 0 = ok */
 int HpddmHipRcclSelfTest(void);
+/* diagnostic of the N > 1 path before an operator exists on the device: ONE halo exchange of the partition's peer layout
+ * (HpddmHipSchwarzHaloPeers) through a fresh RCCL transport -- the same grouped ncclSend / ncclRecv sequence an apply issues -- on
+ * caller buffers of mu * sum(counts) doubles (device pointers; host pointers where no device is visible and HPDDM_HIP_RCCL_LIB
+ * names a host-side double of librccl, which is how tests/test_distributed.py drives the sequence with 2 and 8 ranks on a CPU);
+ * nred > 0 (host only): red_sum / red_max are reduced in place with ncclSum / ncclMax.  Collective over the ranks of SetPartition. */
+int HpddmHipRcclHaloProbe(HpddmHipSchwarz *A, const char *id128, const double *sendbuf, double *recvbuf, int mu, double *red_sum, double *red_max, long long nred);
 /* host copies of the cross-GPU halo lists (tests): which = "send_sub" "send_idx" "send_po" "send_pc" "rx_ptr" "rx_k" "rx_po" "rx_pc";
  * "send_pairs" / "recv_pairs": the ordering contract of every link as this end sees it -- quadruples (peer rank, source subdomain,
  * destination subdomain, dofs), global numbers, in message order: the send list of a -> b must equal the receive list of b <- a

@@ -83,6 +83,33 @@ def main():
             assert all(s // per == a_ and t // per == b_ for s, t, _ in sent)
             assert sent == sorted(sent), "blocks of a message in increasing (source, destination) order"
     assert sum(q[3] for q in sp.tolist()) == sum(c for _, c, _ in peers) == sum(q[3] for q in rp.tolist())
+    if mode == "lists_rccl":
+        # CPU, no device: the product's RcclTransport -- its grouped ncclSend / ncclRecv sequence with the peer offsets and counts of
+        # the partition, ncclSum / ncclMax -- against tests/fake_rccl (a double of librccl over /dev/shm that refuses a message whose
+        # size differs from what the receiving end expects); every entry of the send buffer is tagged with (rank, position), so the
+        # receive buffer says where every value came from
+        assert os.environ.get("FAKE_RCCL_HOST") == "1" and "fake_rccl" in os.environ.get("HPDDM_HIP_RCCL_LIB", "")
+        total = sum(c for _, c, _ in peers)
+        send = 1e6 * rank + np.arange(total * mu, dtype=np.float64)
+        box = [hpddm.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rs, rm = np.array([rank + 1.0, 0.5, -rank]), np.array([rank + 1.0, 0.5, -rank])
+        recv = hpddm.rccl_halo_probe(A, box[0], send, mu, rs, rm)
+        assert np.array_equal(rs, [world * (world + 1) / 2, 0.5 * world, -world * (world - 1) / 2]) and np.array_equal(rm, [world, 0.5, 0.0]), (rs, rm)
+        layout = [None] * world
+        dist.all_gather_object(layout, peers)
+        for prank, cnt, off in peers:
+            # the block of peer `prank` in my receive buffer = the block it keeps for me in its send buffer, value by value
+            poff = [o for q, c, o in layout[prank] if q == rank]
+            pcnt = [c for q, c, o in layout[prank] if q == rank]
+            assert len(poff) == 1 and pcnt[0] == cnt, (rank, prank, cnt, pcnt)
+            want = 1e6 * prank + np.arange(poff[0] * mu, (poff[0] + cnt) * mu, dtype=np.float64)
+            assert np.array_equal(recv[off * mu:(off + cnt) * mu], want), (rank, prank)
+        dist.barrier()
+        if rank == 0:
+            print(f"DIST_WORKER_OK mode={mode} world={world} peers={peers}")
+        dist.destroy_process_group()
+        return
     if mode == "lists":
         assert not helm
         L = {k: A.halo_export(k) for k in ("send_sub", "send_idx", "send_po", "send_pc", "rx_ptr", "rx_k", "rx_po", "rx_pc")}
@@ -199,6 +226,10 @@ def main():
         close(sol, sol_o[sl], 1e-8, "solution")
         res = A.compute_residual(sol, f[sl])
         assert np.allclose(res, orc.compute_residual(sol_o, f), rtol=1e-4), res
+        # l1 (sum over the ranks) and linfty (MPI_MAX in the reference, include/HPDDM_schwarz.hpp:802: a max-reduction of the transport)
+        for nrm in ("l1", "linfty"):
+            res = A.compute_residual(x, f[sl], norm=nrm)
+            assert np.allclose(res, orc.compute_residual(xg, f, norm=nrm), rtol=1e-10), (nrm, res)
         # two-level: the coarse operator is assembled across the ranks (neighbours' A D Z fetched through the halo
         # transport, more columns than the transport's mu_cap -> chunked), E^{-1} replicated, coarse gather = all-reduce
         zr = np.random.default_rng(11)
