@@ -263,6 +263,7 @@ int HpddmHipSubdomainTimeSolve(HpddmHipSubdomain *S, int mu, int warmup, int rep
     b.upload(ones, s);
     DevBuf<double> x;
     x.alloc(ones.size());
+    ls.ensure_plan();
     for (int i = 0; i < warmup; ++i) ls.plan.solve(b.p, x.p, mu, s);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0));

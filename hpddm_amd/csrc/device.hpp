@@ -14,32 +14,50 @@ namespace hpddm_hip {
     if (e_ != hipSuccess) throw ::hpddm_hip::Error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + #call + " -> " + hipGetErrorString(e_)); \
   } while (0)
 
+// Large device buffers (the panels of a factor, their transposed copies, work spaces: 256 MB and more) are kept by the process when
+// their owner lets go of them and handed to the next owner that asks for about the same size (staging.hip).  hipFree of a 12 GB
+// buffer unmaps it at 30 ms per GB -- paid by the NEXT allocation, which waits for it -- and synchronises the whole device; the
+// eigenproblems of GenEO and refactorisations allocate and release the same sizes over and over.  Semantics as before: a buffer
+// is given back only after the device is idle (the synchronisation hipFree did), a new owner sees arbitrary contents.
+static constexpr size_t BIG_BUFFER_BYTES = (size_t)256 << 20;
+void *big_buffer_take(size_t bytes, size_t *cap_bytes); // nullptr: nothing suitable kept
+bool  big_buffer_give(void *p, size_t cap_bytes);       // false: not kept (the caller frees it)
+void  big_buffer_trim();                                // give everything kept back to the driver (also done when an allocation fails)
+
 // RAII device buffer
 template <class T>
 struct DevBuf {
   T     *p = nullptr;
   size_t n = 0;
+  size_t cap_bytes = 0; // bytes behind p (>= n * sizeof(T): a buffer taken over from a previous owner may be larger)
   DevBuf() { }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release()
   {
-    if (p) (void)hipFree(p);
+    if (p && !(cap_bytes >= BIG_BUFFER_BYTES && big_buffer_give(p, cap_bytes))) (void)hipFree(p);
     p = nullptr;
-    n = 0;
+    n = 0, cap_bytes = 0;
   }
   void alloc(size_t count)
   {
     if (count == n && p) return;
     release();
     n = count;
-    if (count && hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {
+    if (!count) return;
+    const size_t bytes = count * sizeof(T);
+    if (bytes >= BIG_BUFFER_BYTES && (p = (T *)big_buffer_take(bytes, &cap_bytes)) != nullptr) return;
+    cap_bytes = bytes;
+    if (hipMalloc((void **)&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      big_buffer_trim(); // what the process kept for later goes back first
+      if (hipMalloc((void **)&p, bytes) == hipSuccess) return;
       (void)hipGetLastError();
       size_t fr = 0, tot = 0;
       (void)hipMemGetInfo(&fr, &tot);
-      p = nullptr, n = 0;
-      throw Error("device memory: an allocation of " + std::to_string(count * sizeof(T) >> 20) + " MB failed (" + std::to_string(fr >> 20) + " MB free of " + std::to_string(tot >> 20) + " MB)");
+      p = nullptr, n = 0, cap_bytes = 0;
+      throw Error("device memory: an allocation of " + std::to_string(bytes >> 20) + " MB failed (" + std::to_string(fr >> 20) + " MB free of " + std::to_string(tot >> 20) + " MB)");
     }
   }
   void upload(const T *h, size_t count, hipStream_t s = nullptr)

@@ -100,6 +100,11 @@ struct DeviceLevels {
   // entries scattered into it
   virtual void process_sparse(idx_t k, const long long *posF, const double *valF, size_t nF, const long long *posG, const double *valG, size_t nG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) = 0; // val*: nF / nG scalars (2 doubles each for complex factors)
   virtual int end() = 0; // != 0: a pivot was not positive (Cholesky) / collapsed (LDL^T, LU)
+  // The device work space of the process (one factorisation at a time) stays with this factorisation from begin() until finish() (or
+  // the destructor): the caller uploads the host levels and builds the transposed panels in between.  hipFree synchronises the WHOLE
+  // device: a temporary released during that upload used to wait for everything the next factorisation had already enqueued
+  // (0.5 - 0.9 s per subdomain at 129^3, profiles/r06_setup_phases.txt).
+  virtual void finish() = 0;
 };
 
 // Plan of the arena that holds the contribution blocks of the device levels (numeric_host.cpp; used by numeric_device.hip).  The blocks

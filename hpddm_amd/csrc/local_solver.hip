@@ -164,8 +164,12 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       devlev.reset(make_device_levels(dev, A.cplx));
     }
   };
+  const bool prof_nf = getenv("HPDDM_HIP_PROFILE") != nullptr;
+  const auto tnf0    = std::chrono::steady_clock::now();
   device_levels(kind);
+  const auto tnf1 = std::chrono::steady_clock::now();
   factor_numeric(A, kind, host, devlev.get(), first_dev);
+  const auto tnf2 = std::chrono::steady_clock::now();
   if (host.info != 0 && kind == FACT_CHOL) {
     // not positive definite after all: fall back to LDL^T like sym=2 in the reference (HPDDM_MUMPS.hpp:236)
     device_levels(FACT_LDLT);
@@ -183,11 +187,17 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     auto to_device = [&]() {
       const auto t0 = std::chrono::steady_clock::now();
       dev.upload(host, library_stream());
-      plan.build({&dev}, library_stream());
+      const auto t1 = std::chrono::steady_clock::now();
+      plan_ready = false;
+      if (!lazy_plan) ensure_plan();
       uploaded = true;
       t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (prof_nf)
+        fprintf(stderr, "[numfact] one subdomain: device panels allocated %.3f s, factor_numeric %.3f s, upload of the host levels %.3f s, plan %.3f s\n", std::chrono::duration<double>(tnf1 - tnf0).count(),
+                std::chrono::duration<double>(tnf2 - tnf1).count(), std::chrono::duration<double>(t1 - t0).count(), t_upload - std::chrono::duration<double>(t1 - t0).count());
     };
     to_device();
+    if (devlev) devlev->finish(); // the next factorisation may have the device now
     if (host.kind != FACT_CHOL && !getenv("HPDDM_HIP_NO_PROBE")) {
       std::string why = probe(A, host.kind);
       if (!why.empty() && host.kind == FACT_LDLT && !getenv("HPDDM_HIP_NO_LU_FALLBACK")) {
@@ -196,6 +206,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
         factor_numeric(A, FACT_LU, host, devlev.get(), first_dev);
         HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (LU with pivoting inside the diagonal tiles, after an unstable L D L^T)");
         to_device();
+        if (devlev) devlev->finish();
         why = probe(A, host.kind);
       }
       HH_CHECK(why.empty(), why);
@@ -292,9 +303,17 @@ int LocalSolver::negative_pivots() const
   return neg;
 }
 
+void LocalSolver::ensure_plan()
+{
+  if (plan_ready) return;
+  plan.build({&dev}, library_stream());
+  plan_ready = true;
+}
+
 void LocalSolver::solve_device(const double *b, double *x, int mu)
 {
   HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");
+  ensure_plan();
   plan.solve(b, x, mu, library_stream());
 }
 
@@ -305,6 +324,7 @@ void LocalSolver::solve_host(const double *b, double *x, int mu)
   hipStream_t  s   = library_stream();
   bdev.alloc(cnt);
   staged_h2d(bdev.p, b, cnt * sizeof(double), s);
+  ensure_plan();
   plan.solve(bdev.p, bdev.p, mu, s);
   staged_d2h(x, bdev.p, cnt * sizeof(double), s);
 }

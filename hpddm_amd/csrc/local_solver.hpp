@@ -13,6 +13,9 @@ struct LocalSolver {
   HostFactor   host;
   DeviceFactor dev;
   SolvePlan    plan;       // single-subdomain plan (used by the Solver-level API)
+  bool         plan_ready = false; // ... built for the factor in hand
+  bool         lazy_plan  = false; // build it on first use instead of at the end of numfact: the subdomains of a Schwarz operator are swept through the operator's batched plan
+  void         ensure_plan();
   bool         analysed = false, uploaded = false;
   size_t       pattern_hash = 0;
   int          leaf_size = 32;

@@ -26,6 +26,45 @@ static double now()
 }
 static constexpr double DEV_PIVOT_TOL_C = 1.0e-13; // the pivot rule of dense_host.hpp: a pivot that collapsed against the entries it eliminates is a breakdown
 
+// ---- one operation of the device levels as its kernel sees it -------------------------------------------------------------------
+// Every kernel below exists twice around ONE body: k_x(GOp) -- one operation per launch, the descriptor in the kernel arguments: the
+// large fronts of the upper levels, where a launch fills the machine -- and k_x_g(ops, start, nops) -- ONE launch for the same step of
+// MANY fronts (the levels of hundreds to thousands of small fronts, where a front on its own is a chain of 20 - 30 launches of a few
+// workgroups each and the level runs at the rate the device dispatches small dependent kernels: 0.06 - 0.4 TFLOP/s): workgroup b
+// finds its operation by bisection of the prefix sums start[] (wave-uniform: scalar loads) and runs the body on it.  Same bodies,
+// same tiles, same order of the sums inside an operation: the factor does not depend on which way a front went.
+// Fields by kernel family (pointers p0..p5, leading dimensions / counts l0..l3, integers i0..i7):
+//   products        p0 A, p1 B, p2 C; l0 lda, l1 ldb, l2 ldc; alpha; i0 M, i1 N, i2 K, i3 flags (1 beta1, 2 lower_only, 4 btri, 8 atri),
+//                   i4 ci0, i5 cj0, i6 tiles_x, i7 tiles_y
+//   tile kernels    p0 the tile, l0 its leading dimension, i0 its order; p1..p3 the inverses it returns; p4 flag, p5 swapped
+//   the others      see their bodies
+struct GOp {
+  void     *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
+  long long l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+  long long s0 = 0, s1 = 0, s2 = 0; // products: a batch with strided operands (A, B, C of entry z: + z * s0 / s1 / s2), tiles_x * tiles_y workgroups each
+  double    alpha = 0.0;
+  int       i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+  int       blocks = 1, kind = 0; // workgroups of the operation; which kernel (host side)
+};
+__device__ static inline int find_op(const int *__restrict__ start, int nops, int b)
+{
+  int lo = 0, hi = nops; // start[lo] <= b < start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (start[mid] <= b) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+#define HH_GROUPED(NAME, BODY, BOUNDS, ...)                                                                                       \
+  __VA_ARGS__ __global__ __launch_bounds__(BOUNDS) void NAME(GOp o) { BODY(o, (int)blockIdx.x); }                                 \
+  __VA_ARGS__ __global__ __launch_bounds__(BOUNDS) void NAME##_g(const GOp *__restrict__ ops, const int *__restrict__ start, int nops) \
+  {                                                                                                                               \
+    const int b = (int)blockIdx.x, i = find_op(start, nops, b);                                                                   \
+    const GOp o = ops[i];                                                                                                         \
+    BODY(o, b - start[i]);                                                                                                        \
+  }
+
 // Entry (kk, j) of op(B) as the products read it.  CS = 1: B real.  CS = 2: B complex (ldb in complex scalars, (re, im) pairs) and
 // (kk, j) index its real-equivalent embedding  [ br  bi ; -bi  br ]  (2K x 2N): with A and C taken as real matrices of (re, im)
 // pairs -- M rows, 2K / 2N columns -- the real product A B~ IS the complex product, with the optimal 4 real FMAs per complex one.
@@ -46,12 +85,22 @@ __device__ static inline double b_entry(const double *__restrict__ B, long long 
 // 64 x 64 tile per workgroup, 4 wavefronts of 32 x 32 (2 x 2 MFMA tiles of 16 x 16), K staged 16 at a time through LDS.
 // lower_only: tiles entirely above the diagonal of the (ci0, cj0)-shifted matrix are skipped.
 template <bool TRANSB, int CS>
-__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alpha, const double *A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, long long sA, long long sB, long long sC)
+__device__ static inline void gemm64_body(const GOp &o, int blk)
 {
   __shared__ double As[64][17];
   __shared__ double Bs[16][65];
-  A += (long long)blockIdx.z * sA, B += (long long)blockIdx.z * sB, C += (long long)blockIdx.z * sC; // batch of products, strided operands
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int     M = o.i0, N = o.i1, K = o.i2, beta1 = o.i3 & 1, lower_only = o.i3 & 2, ci0 = o.i4, cj0 = o.i5;
+  const double  alpha = o.alpha;
+  const double *A = (const double *)o.p0;
+  const double *__restrict__ B = (const double *)o.p1;
+  double       *C = (double *)o.p2;
+  const long long lda = o.l0, ldb = o.l1, ldc = o.l2;
+  {
+    const int z = blk / (o.i6 * o.i7); // batch of products, strided operands
+    A += (long long)z * o.s0, B += (long long)z * o.s1, C += (long long)z * o.s2;
+    blk -= z * (o.i6 * o.i7);
+  }
+  const int i0 = (blk / o.i6) * 64, j0 = (blk % o.i6) * 64;
   if (lower_only && cj0 + j0 / CS > ci0 + i0 + 63) return; // (CS = 2: columns in (re, im) pairs)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
   v4f64     acc[2][2];
@@ -112,6 +161,7 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
         }
       }
 }
+HH_GROUPED(k_gemm64, (gemm64_body<TRANSB, CS>), 256, template <bool TRANSB, int CS>)
 
 // The same product on larger tiles (every product with K >= 64 and a side of 128 or more): TM x TN per workgroup (128 x 128,
 // or 128 x 64 for the 64-column panels of the left-looking factorisation), every wavefront a (TM/2) x (TN/2) block of MFMA
@@ -124,14 +174,25 @@ __global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, double alph
 //     atri: A is lower triangular (A[i][k] = 0 for k > i): row tile i0 stops its K loop at i0 + TM;
 //   * blockIdx.y: batch of products with strided operands (the pairs of one level of the recursive inversion).
 template <int TM, int TN, bool TRANSB, int CS>
-__global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double alpha, const double *A, long long lda, const double *__restrict__ B, long long ldb, double *C, long long ldc, int beta1, int lower_only, int ci0, int cj0, int btri, int atri, int tiles_x, int tiles_y, long long sA, long long sB, long long sC)
+__device__ static inline void gemm_big_body(const GOp &o, int blk)
 {
   constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
   __shared__ double As[2][TM][KS + 1];
   __shared__ double Bs[2][KS][TN + 1];
-  A += (long long)blockIdx.y * sA, B += (long long)blockIdx.y * sB, C += (long long)blockIdx.y * sC;
+  const int     M = o.i0, N = o.i1, beta1 = o.i3 & 1, lower_only = o.i3 & 2, btri = o.i3 & 4, atri = o.i3 & 8, ci0 = o.i4, cj0 = o.i5, tiles_x = o.i6, tiles_y = o.i7;
+  int           K = o.i2;
+  const double  alpha = o.alpha;
+  const double *A = (const double *)o.p0;
+  const double *__restrict__ B = (const double *)o.p1;
+  double       *C = (double *)o.p2;
+  const long long lda = o.l0, ldb = o.l1, ldc = o.l2;
+  {
+    const int z = blk / (tiles_x * tiles_y); // batch of products, strided operands
+    A += (long long)z * o.s0, B += (long long)z * o.s1, C += (long long)z * o.s2;
+    blk -= z * (tiles_x * tiles_y);
+  }
   // XCD-aware deal: workgroup id -> logical tile, contiguous chunks per XCD
-  const int total = tiles_x * tiles_y, id = (int)blockIdx.x, q8 = total / 8, r8 = total % 8, xcd = id % 8, loc = id / 8;
+  const int total = tiles_x * tiles_y, id = blk, q8 = total / 8, r8 = total % 8, xcd = id % 8, loc = id / 8;
   const int lid = xcd * q8 + min(xcd, r8) + loc;
   const int i0 = (lid / tiles_x) * TM, j0 = (lid % tiles_x) * TN;
   if (lower_only && cj0 + j0 / CS > ci0 + i0 + TM - 1) return; // (CS = 2: columns in (re, im) pairs)
@@ -213,6 +274,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(int M, int N, int K, double al
         }
       }
 }
+HH_GROUPED(k_gemm_big, (gemm_big_body<TM, TN, TRANSB, CS>), 256, template <int TM, int TN, bool TRANSB, int CS>)
 
 // ---- scalars of the device levels: double, or zd = (re, im) pair laid out like std::complex<double> ----
 struct zd {
@@ -274,10 +336,14 @@ __device__ static inline void tile_row_update(T (*W)[LDT], T (*Xw)[LDT], int r, 
 // the critical path of every front (one per 64 columns, each waiting for the previous one): scripts/micro/potf2_bench.hip.
 // *flag != 0 on a non-positive pivot.
 static constexpr int TILE_THREADS = 512;
-__global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long ld, int nb, double *Tinv, int *flag)
+__device__ static inline void potf2_body(const GOp &o, int)
 {
   __shared__ double W[64][65];
   __shared__ double Xw[64][65];
+  double         *T = (double *)o.p0, *Tinv = (double *)o.p1;
+  int            *flag = (int *)o.p4;
+  const long long ld = o.l0;
+  const int       nb = o.i0;
   const int tid = threadIdx.x, r = tid >> 3, q = tid & 7;
   for (int idx = tid; idx < 4096; idx += TILE_THREADS) {
     const int i = idx >> 6, c = idx & 63;
@@ -308,6 +374,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
     Tinv[idx] = (i < nb && c <= i) ? Xw[i][c] : 0.0;
   }
 }
+HH_GROUPED(k_potf2_inv, potf2_body, TILE_THREADS, )
 
 // LDL^T of one diagonal tile (nb <= 64, row-major lower, in place: unit L strictly below, D on the diagonal; plain transposes
 // for complex scalars: complex SYMMETRIC matrices), the inverse of the unit factor into Tinv and D^{-1} inv(L) into TinvD (both
@@ -315,9 +382,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_potf2_inv(double *T, long long
 // is the updated, unscaled column -- the entries the pivot eliminates, which the pivot test of dense_host.hpp looks at (first
 // wavefront, a shuffle reduction: nobody waits for it).  Dynamic LDS: two 64 x 65 arrays of T and the 64 pivots.
 template <class T>
-__global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(T *Tl, long long ld, int nb, T *Tinv, T *TinvD, int *flag)
+__device__ static inline void ldlf2_body(const GOp &o, int)
 {
   extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+  T              *Tl = (T *)o.p0, *Tinv = (T *)o.p1, *TinvD = (T *)o.p2;
+  int            *flag = (int *)o.p4;
+  const long long ld = o.l0;
+  const int       nb = o.i0;
   T(*W)[65]  = reinterpret_cast<T(*)[65]>(tile_lds);
   T(*Xw)[65] = W + 64;
   T *dd      = reinterpret_cast<T *>(Xw + 64);
@@ -357,6 +428,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(T *Tl, long long ld,
     TinvD[idx] = i < nb ? x / dd[i] : scalar<T>(0.0);
   }
 }
+HH_GROUPED(k_ldlf2_inv, ldlf2_body<T>, TILE_THREADS, template <class T>)
 
 // LU of one diagonal tile (nb <= 64, row-major; U comes back on and above the diagonal) with threshold partial pivoting among the
 // tile's own rows (the rule of dense_host.hpp: getf2 -- the diagonal entry stays unless it is smaller than DEV_PIVOT_THRESHOLD
@@ -372,9 +444,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_ldlf2_inv(T *Tl, long long ld,
 // by u_jj one step later.  Breakdown (*flag): a pivot that is zero, NaN or negligible against its own row after the exchange.
 static constexpr double DEV_PIVOT_THRESHOLD = 0.01;
 template <class T>
-__global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld, int nb, T *TinvL, T *TinvU, T *TinvUT, int *flag, int *swapped)
+__device__ static inline void getf2_body(const GOp &o, int)
 {
   extern __shared__ __attribute__((aligned(16))) double tile_lds[];
+  T              *Tl = (T *)o.p0, *TinvL = (T *)o.p1, *TinvU = (T *)o.p2, *TinvUT = (T *)o.p3;
+  int            *flag = (int *)o.p4, *swapped = (int *)o.p5;
+  const long long ld = o.l0;
+  const int       nb = o.i0;
   T(*W)[65]  = reinterpret_cast<T(*)[65]>(tile_lds);
   T(*Xw)[65] = W + 64;
   const int tid = threadIdx.x, r = tid >> 3, q = tid & 7, lane = tid & 63;
@@ -472,128 +548,152 @@ __global__ __launch_bounds__(TILE_THREADS) void k_getf2_inv(T *Tl, long long ld,
     TinvU[c * 64 + i] = y;
   }
 }
+HH_GROUPED(k_getf2_inv, getf2_body<T>, TILE_THREADS, template <class T>)
 static constexpr size_t tile_lds_bytes(size_t scalar_bytes) { return (size_t)(2 * 64 * 65 + 64) * scalar_bytes; }
 
+// The element-wise kernels: one workgroup of 256 threads per ROW of their operand (operation-local block = row), the threads stride
+// over its columns.
 // dst(m x k, ldd) = src(m x k, lds) * diag(D), D(c) = the diagonal of the panel's top block (Dsrc, ldD)
+//   p0 src, p1 Dsrc, p2 dst; l0 lds, l1 ldD, l2 ldd; i0 m, i1 k
 template <class T>
-__global__ void k_scale_cols(int m, int k, const T *__restrict__ src, long long lds_, const T *__restrict__ Dsrc, long long ldD, T *__restrict__ dst, long long ldd)
+__device__ static inline void scale_cols_body(const GOp &o, int i)
 {
-  const int i = blockIdx.y;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < k; c += gridDim.x * blockDim.x)
-    if (i < m) dst[(long long)i * ldd + c] = src[(long long)i * lds_ + c] * Dsrc[(long long)c * (ldD + 1)];
+  const T *__restrict__ src = (const T *)o.p0, *__restrict__ Dsrc = (const T *)o.p1;
+  T       *__restrict__ dst = (T *)o.p2;
+  for (int c = threadIdx.x; c < o.i1; c += blockDim.x) dst[(long long)i * o.l2 + c] = src[(long long)i * o.l0 + c] * Dsrc[(long long)c * (o.l1 + 1)];
 }
-// LDL^T: dinv(i) = 1 / D(i), the diagonal of the top block becomes the unit diagonal of L
+HH_GROUPED(k_scale_cols, scale_cols_body<T>, 256, template <class T>)
+// LDL^T: dinv(i) = 1 / D(i), the diagonal of the top block becomes the unit diagonal of L.   p0 P, p1 dinv; l0 ld; i0 w; blocks of 256 entries
 template <class T>
-__global__ void k_extract_dinv(int w, T *P, long long ld, T *dinv)
+__device__ static inline void extract_dinv_body(const GOp &o, int blk)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < w) {
-    dinv[i]                    = scalar<T>(1.0) / P[(long long)i * (ld + 1)];
-    P[(long long)i * (ld + 1)] = scalar<T>(1.0);
+  T        *P = (T *)o.p0, *dinv = (T *)o.p1;
+  const int i = blk * blockDim.x + threadIdx.x;
+  if (i < o.i0) {
+    dinv[i]                      = scalar<T>(1.0) / P[(long long)i * (o.l0 + 1)];
+    P[(long long)i * (o.l0 + 1)] = scalar<T>(1.0);
   }
 }
+HH_GROUPED(k_extract_dinv, extract_dinv_body<T>, 256, template <class T>)
 // LU: G top block <- U11^T (lower, non-unit), F top block keeps the unit lower L11 (upper part zeroed, ones on the diagonal)
+//   p0 P, p1 G; l0 ld; i0 w; block = row
 template <class T>
-__global__ void k_split_u11(int w, T *P, T *G, long long ld)
+__device__ static inline void split_u11_body(const GOp &o, int i)
 {
-  const int i = blockIdx.y;
-  for (int j = i + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) {
+  T              *P = (T *)o.p0, *G = (T *)o.p1;
+  const long long ld = o.l0;
+  for (int j = i + threadIdx.x; j < o.i0; j += blockDim.x) {
     G[(long long)j * ld + i] = P[(long long)i * ld + j];
     P[(long long)i * ld + j] = scalar<T>(j == i ? 1.0 : 0.0);
   }
 }
-// LU: parent front += child contribution block (full nbc x nbc): A11 and A21 live in F, A12 transposed in G
-template <class T>
-__global__ void k_extend_add_full(const T *__restrict__ Cc, int nbc, const int *__restrict__ rel, T *P, T *G, long long ld, int w, T *C, long long ldcb)
+HH_GROUPED(k_split_u11, split_u11_body<T>, 256, template <class T>)
+// parent front += child contribution block (nbc x nbc, ld nbc) through the child's row -> parent position map; four rows of the
+// child per workgroup, 64 threads each.  LU (FULL): the whole block -- A11 and A21 live in F, A12 transposed in G; symmetric kinds:
+// the lower triangle.    p0 Cc, p1 rel, p2 P, p3 G, p4 C; l0 ld, l1 ldcb; i0 nbc, i1 w
+template <class T, bool FULL>
+__device__ static inline void extend_add_body(const GOp &o, int blk)
 {
-  const int i = blockIdx.y * blockDim.y + threadIdx.y;
+  const T *__restrict__ Cc    = (const T *)o.p0;
+  const int *__restrict__ rel = (const int *)o.p1;
+  T              *P = (T *)o.p2, *G = (T *)o.p3, *C = (T *)o.p4;
+  const long long ld = o.l0, ldcb = o.l1;
+  const int       nbc = o.i0, w = o.i1, i = blk * 4 + (int)(threadIdx.x >> 6);
   if (i >= nbc) return;
   const int li = rel[i];
   const T  *ci = Cc + (long long)i * nbc;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nbc; j += gridDim.x * blockDim.x) {
+  for (int j = threadIdx.x & 63; FULL ? j < nbc : j <= i; j += 64) {
     const int lj = rel[j];
     T        *dst;
-    if (li < w) dst = lj < w ? P + (long long)li * ld + lj : G + (long long)lj * ld + li;
+    if (FULL && li < w) dst = lj < w ? P + (long long)li * ld + lj : G + (long long)lj * ld + li;
     else dst = lj < w ? P + (long long)li * ld + lj : C + (long long)(li - w) * ldcb + (lj - w);
     *dst = *dst + ci[j];
   }
 }
-// parent front += child contribution block (lower, nbc x nbc, ld nbc) through the child's row -> parent position map
+HH_GROUPED(k_extend_add, (extend_add_body<T, FULL>), 256, template <class T, bool FULL>)
+// dst(m x n, ldd) = src(m x n, lds).   p0 src, p1 dst; l0 lds, l1 ldd; i0 m, i1 n; block = row
 template <class T>
-__global__ void k_extend_add(const T *__restrict__ Cc, int nbc, const int *__restrict__ rel, T *P, long long ld, int w, T *C, long long ldcb)
+__device__ static inline void copy2d_body(const GOp &o, int i)
 {
-  const int i = blockIdx.y * blockDim.y + threadIdx.y;
-  if (i >= nbc) return;
-  const int li = rel[i];
-  const T  *ci = Cc + (long long)i * nbc;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= i; j += gridDim.x * blockDim.x) {
-    const int lj  = rel[j];
-    T        *dst = lj < w ? P + (long long)li * ld + lj : C + (long long)(li - w) * ldcb + (lj - w);
-    *dst          = *dst + ci[j];
-  }
+  const T *__restrict__ src = (const T *)o.p0;
+  T       *__restrict__ dst = (T *)o.p1;
+  for (int j = threadIdx.x; j < o.i1; j += blockDim.x) dst[(long long)i * o.l1 + j] = src[(long long)i * o.l0 + j];
 }
-// dst(m x n, ldd) = src(m x n, lds)
+HH_GROUPED(k_copy2d, copy2d_body<T>, 256, template <class T>)
+//   p0 P; l0 ld; i0 w; block = row
 template <class T>
-__global__ void k_copy2d(int m, int n, const T *__restrict__ src, long long lds_, T *__restrict__ dst, long long ldd)
+__device__ static inline void zero_upper_body(const GOp &o, int i)
 {
-  const int i = blockIdx.y;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-    if (i < m) dst[(long long)i * ldd + j] = src[(long long)i * lds_ + j];
+  T *P = (T *)o.p0;
+  for (int j = i + 1 + threadIdx.x; j < o.i0; j += blockDim.x) P[(long long)i * o.l0 + j] = scalar<T>(0.0);
 }
-template <class T>
-__global__ void k_zero_upper(int w, T *P, long long ld)
-{
-  const int i = blockIdx.y;
-  for (int j = i + 1 + blockIdx.x * blockDim.x + threadIdx.x; j < w; j += gridDim.x * blockDim.x) P[(long long)i * ld + j] = scalar<T>(0.0);
-}
+HH_GROUPED(k_zero_upper, zero_upper_body<T>, 256, template <class T>)
 // the original entries of a front, scattered into its zeroed panel (doubles per scalar SC: val holds SC doubles per entry)
+//   p0 pos, p1 val, p2 P; l0 cnt; the operation's `blocks` workgroups stride over the entries
 template <int SC>
-__global__ void k_scatter_add(long long cnt, const long long *__restrict__ pos, const double *__restrict__ val, double *P)
+__device__ static inline void scatter_add_body(const GOp &o, int blk)
 {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < cnt * SC; i += (long long)gridDim.x * blockDim.x) atomicAdd(P + SC * pos[i / SC] + i % SC, val[i]);
+  const long long *__restrict__ pos = (const long long *)o.p0;
+  const double *__restrict__ val    = (const double *)o.p1;
+  double *P = (double *)o.p2;
+  for (long long i = blk * (long long)blockDim.x + threadIdx.x; i < o.l0 * SC; i += (long long)o.blocks * blockDim.x) atomicAdd(P + SC * pos[i / SC] + i % SC, val[i]);
 }
-// the diagonal tiles of the top block <- their inverses (from the tile kernels), all tiles in one launch
+HH_GROUPED(k_scatter_add, scatter_add_body<SC>, 256, template <int SC>)
+// the diagonal tiles of the top block <- their inverses (from the tile kernels).   p0 P, p1 Tinv; l0 ld; i0 w; block = tile
 template <class T>
-__global__ void k_set_diag_tiles(int w, T *P, long long ld, const T *__restrict__ Tinv)
+__device__ static inline void set_diag_tiles_body(const GOp &o, int t)
 {
-  const int t = blockIdx.x, i0 = 64 * t, ib = min(64, w - i0);
+  T *P = (T *)o.p0;
+  const T *__restrict__ Tinv = (const T *)o.p1;
+  const int i0 = 64 * t, ib = min(64, o.i0 - i0);
   for (int idx = threadIdx.x; idx < 4096; idx += blockDim.x) {
     const int r = idx >> 6, c = idx & 63;
-    if (r < ib && c < ib) P[(long long)(i0 + r) * ld + i0 + c] = Tinv[(size_t)t * 4096 + idx];
+    if (r < ib && c < ib) P[(long long)(i0 + r) * o.l0 + i0 + c] = Tinv[(size_t)t * 4096 + idx];
   }
 }
+HH_GROUPED(k_set_diag_tiles, set_diag_tiles_body<T>, 256, template <class T>)
 
 struct GemmBatch { // a batch of products with strided operands (1 = a single product); strides in scalars
   int       count = 1;
   long long sA = 0, sB = 0, sC = 0;
 };
-template <int TM, int TN, int CS>
-static void gemm_big(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only, int ci0, int cj0, bool btri, bool atri, const GemmBatch &bt)
-{
-  const int tx = (N + TN - 1) / TN, ty = (M + TM - 1) / TM;
-  if (transB) hipLaunchKernelGGL((k_gemm_big<TM, TN, true, CS>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
-  else hipLaunchKernelGGL((k_gemm_big<TM, TN, false, CS>), dim3((unsigned)(tx * ty), (unsigned)bt.count), dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, btri ? 1 : 0, atri ? 1 : 0, tx, ty, bt.sA, bt.sB, bt.sC);
-}
+// which kernel an operation runs on (GOp::kind)
+enum OpKind : int {
+  OP_GEMM64_N, OP_GEMM64_T, OP_BIG_64_128_N, OP_BIG_64_128_T, OP_BIG_128_128_N, OP_BIG_128_128_T, OP_BIG_128_64_N, OP_BIG_128_64_T,
+  OP_POTF2, OP_LDLF2, OP_GETF2, OP_SCALE_COLS, OP_EXTRACT_DINV, OP_SPLIT_U11, OP_EXTEND_ADD, OP_EXTEND_ADD_FULL, OP_COPY2D, OP_ZERO_UPPER,
+  OP_SCATTER_ADD, OP_SET_DIAG_TILES, OP_KINDS
+};
 
 // C(M x N) = (beta1 ? C : 0) + alpha A(M x K) op(B): every argument in SCALARS of CS doubles (CS = 2: (re, im) pairs, the kernels
 // see the real views of A and C -- 2 K / 2 N columns -- and the embedding of B, b_entry).  btri: B (not transposed) is lower
 // triangular; atri: A is lower triangular -- only the tiles of k_gemm_big use them (shorter K ranges), the result is the same.
+// Returns the operation (kind = which tile shape: every product with K >= 64 and a side of 128 or more takes the large tiles);
+// blocks = 0: nothing to do.
 template <int CS>
-static void gemm(hipStream_t st, bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false, bool atri = false, const GemmBatch &bs = GemmBatch())
+static GOp gemm_op(bool transB, int M, int N, int K, double alpha, const double *A, long long lda, const double *B, long long ldb, double *C, long long ldc, bool beta1, bool lower_only = false, int ci0 = 0, int cj0 = 0, bool btri = false, bool atri = false, const GemmBatch &bs = GemmBatch())
 {
-  if (M <= 0 || N <= 0 || bs.count <= 0) return;
-  GemmBatch bt = bs; // strides of the pointers the kernels see: doubles
-  bt.sA *= CS, bt.sB *= CS, bt.sC *= CS;
-  N *= CS, K *= CS, lda *= CS, ldc *= CS; // real views (ldb stays in scalars: b_entry)
+  GOp o;
+  o.blocks = 0;
+  if (M <= 0 || N <= 0 || bs.count <= 0) return o;
+  N *= CS, K *= CS, lda *= CS, ldc *= CS; // real views (ldb stays in scalars: b_entry); strides of the pointers the kernels see: doubles
+  o.p0 = const_cast<double *>(A), o.p1 = const_cast<double *>(B), o.p2 = C;
+  o.l0 = lda, o.l1 = ldb, o.l2 = ldc;
+  o.s0 = bs.sA * CS, o.s1 = bs.sB * CS, o.s2 = bs.sC * CS;
+  o.alpha = alpha;
+  o.i0 = M, o.i1 = N, o.i2 = K, o.i4 = ci0, o.i5 = cj0;
+  int TM = 64, TN = 64;
   if (K >= 64 && (M >= 128 || N >= 128)) { // (C never overlaps the parts of A and B a call reads -- except right_tile, where C = A and every workgroup owns its rows)
-    if (M <= 64) gemm_big<64, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // row blocks
-    else if (N > 64) gemm_big<128, 128, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt);
-    else gemm_big<128, 64, CS>(st, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1, lower_only, ci0, cj0, btri && !transB, atri, bt); // 64-column panels
-    return;
+    if (M <= 64) TM = 64, TN = 128, o.kind = transB ? OP_BIG_64_128_T : OP_BIG_64_128_N;      // row blocks
+    else if (N > 64) TM = 128, TN = 128, o.kind = transB ? OP_BIG_128_128_T : OP_BIG_128_128_N;
+    else TM = 128, TN = 64, o.kind = transB ? OP_BIG_128_64_T : OP_BIG_128_64_N;              // 64-column panels
+    o.i3 = (beta1 ? 1 : 0) | (lower_only ? 2 : 0) | (btri && !transB ? 4 : 0) | (atri ? 8 : 0);
+  } else {
+    o.kind = transB ? OP_GEMM64_T : OP_GEMM64_N;
+    o.i3   = (beta1 ? 1 : 0) | (lower_only ? 2 : 0);
   }
-  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)bt.count);
-  if (transB) hipLaunchKernelGGL((k_gemm64<true, CS>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
-  else hipLaunchKernelGGL((k_gemm64<false, CS>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, C, ldc, beta1 ? 1 : 0, lower_only ? 1 : 0, ci0, cj0, bt.sA, bt.sB, bt.sC);
+  o.i6     = (N + TN - 1) / TN, o.i7 = (M + TM - 1) / TM;
+  o.blocks = o.i6 * o.i7 * bs.count;
+  return o;
 }
 
 // Host -> device hand-over of the device levels (row maps of the children, entry lists of the fronts, the contribution blocks of the
@@ -759,6 +859,7 @@ struct DeviceScratch {
   DevBuf<double> arena;
   DevBuf<double> dinv_all; // L D L^T: 1 / D of the device-level fronts, every front its own columns (one download at the end)
   DevBuf<double> tinv[NSTREAMS], tmp[NSTREAMS], dvec[NSTREAMS]; // per stream: inverses of the diagonal tiles of its front, scratch, 1/D (LDL^T)
+  DevBuf<double> gscr;                                          // grouped levels: the same for every front of the level, side by side
   hipStream_t    streams[NSTREAMS] = {};
   hipEvent_t     ev[NSTREAMS]      = {};
   hipEvent_t     ev_fill           = nullptr; // the fill of a level's share of the arena, on the first stream: the others wait for it
@@ -858,10 +959,22 @@ struct DeviceLevelsImpl : public DeviceLevels {
     st  = scr->streams[i];
     tinv.p = reinterpret_cast<T *>(scr->tinv[i].p), tmp.p = reinterpret_cast<T *>(scr->tmp[i].p), dvec.p = reinterpret_cast<T *>(scr->dvec[i].p);
   }
+  // A level of many fronts is GROUPED: its fronts record their operations (begin_front opens a queue, the scratch of a front is its
+  // own piece of the slot's group scratch), flush_group() launches them step by step for all the queued fronts at once -- when what
+  // the queued fronts staged in the upload ring passes a quarter of it (the blocks of the host-level children of the first device
+  // level are 2.4 GB per 129^3 subdomain: the level goes in pieces), and at the end of the level.  Everything on the first stream.
+  int  group_min  = 40;    // fronts in a level from which it is grouped (HPDDM_HIP_GROUP_MIN_FRONTS; 0: never).  Measured at 129^3: levels of 16 - 31 fronts of 434 - 1764 columns are 15 - 30 % slower grouped (one stream, the fronts in lockstep) than front by front on four streams
+  bool want_group(int lvl) const
+  {
+    const idx_t nf = hf->level_ptr[lvl + 1] - hf->level_ptr[lvl];
+    return group_min > 0 && nf >= group_min && zeroed_all && !hf->keep_plain;
+  }
   void begin_front(idx_t k) override
   {
     const int lvl = (int)hf->sym.height[k];
     if (lvl != cur_level) {
+      if (rec) flush_group();
+      rec = false;
       if (cur_level >= 0) level_barrier();
       cur_level = lvl;
       next_rr   = 0;
@@ -878,10 +991,40 @@ struct DeviceLevelsImpl : public DeviceLevels {
         HIP_OK(hipEventRecord(scr->ev_fill, scr->streams[0]));
         for (int t = 1; t < ns; ++t) HIP_OK(hipStreamWaitEvent(scr->streams[t], scr->ev_fill, 0));
       }
+      if (want_group(lvl)) {
+        // scratch of the level: every front its own inverses of the diagonal tiles and its own work space (they run side by side)
+        const Symbolic &s = hf->sym;
+        size_t          need = 0;
+        for (idx_t q = hf->level_ptr[lvl]; q < hf->level_ptr[lvl + 1]; ++q) need += front_scratch(s, hf->level_blk[q]);
+        DeviceScratch::grow(scr->gscr, need + 64);
+        gscr_used = 0;
+        rec       = true;
+        scr->ring.begin_batch();
+      }
+    }
+    if (rec) {
+      set_slot(0);
+      used[0] = true;
+      if (!gq.empty() && scr->ring.batch > std::max<size_t>(scr->ring.cap / 4, (size_t)16 << 20)) flush_group();
+      // the front's own scratch: [inverses of its diagonal tiles: 3 per tile | work space | 1 / D]
+      const Symbolic &s = hf->sym;
+      const idx_t     w = s.blk_ptr[k + 1] - s.blk_ptr[k];
+      const size_t    nt = (size_t)CS * 3 * ((w + 63) / 64) * 4096, total = front_scratch(s, k);
+      double         *base = scr->gscr.p + gscr_used;
+      gscr_used += total;
+      tinv.p = reinterpret_cast<T *>(base), tmp.p = reinterpret_cast<T *>(base + nt), dvec.p = nullptr;
+      gq.emplace_back();
+      return;
     }
     set_slot(next_rr++ % ns);
     used[cur] = true;
     scr->ring.begin_batch();
+  }
+  static size_t front_scratch(const Symbolic &s, idx_t k)
+  {
+    const idx_t  w = s.blk_ptr[k + 1] - s.blk_ptr[k], hh = w + (idx_t)(s.row_ptr[k + 1] - s.row_ptr[k]);
+    const size_t nt = (size_t)CS * 3 * ((w + 63) / 64) * 4096, nw = (size_t)CS * ((size_t)hh * std::max<idx_t>(256, w));
+    return (nt + nw + 15) / 16 * 16;
   }
   T *take(size_t cnt)
   {
@@ -917,6 +1060,9 @@ struct DeviceLevelsImpl : public DeviceLevels {
     HIP_OK(hipStreamSynchronize(library_stream()));
     first_level_ = first_level;
     prof         = getenv("HPDDM_HIP_PROFILE") != nullptr;
+    if (const char *e = getenv("HPDDM_HIP_GROUP_MIN_FRONTS")) group_min = atoi(e);
+    rec = false, gq.clear();
+    n_launch_plain = n_launch_grouped = n_ops_grouped = 0;
     {
       // Plan of the arena.  The contribution blocks of the fronts of a level share one chunk, live until the last of their parents has been assembled -- the barrier that closes that level orders
       // every stream --, and later levels take the place over: first fit over the chunks still alive.  Every block kept until end()
@@ -976,6 +1122,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
       std::call_once(once, [] {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv_g<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv_g<zd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(zd))));
       });
     }
     { // (the real ones use 66.5 KB, also beyond)
@@ -983,6 +1131,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
       std::call_once(once, [] {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ldlf2_inv_g<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_getf2_inv_g<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(sizeof(double))));
       });
     }
     if (scr->ring.cap && scr->ring.unpinned != (getenv("HPDDM_HIP_UPLOAD_UNPINNED") != nullptr)) { // (the variable changed since the ring was made)
@@ -990,7 +1140,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
       scr->ring.cap  = 0;
       scr->ring.grow(c, st);
     }
-    scr->ring.grow((size_t)64 << 20, st);
+    scr->ring.grow((size_t)256 << 20, st); // (a grouped level goes in pieces of a quarter of the ring)
     std::vector<int> z(1 + (size_t)h.sym.nblk, 0); // [0]: breakdown; [1 + k]: rows were exchanged inside a tile of front k (LU)
     flag.upload(z, st);
     HIP_OK(hipStreamSynchronize(st));
@@ -1003,6 +1153,118 @@ struct DeviceLevelsImpl : public DeviceLevels {
   }
   static const double *cd(const T *p) { return reinterpret_cast<const double *>(p); }
   static double       *md(T *p) { return reinterpret_cast<double *>(p); }
+  // ---- operations: launched right away (one front at a time, its stream), or recorded in the queue of their front (a level of
+  // many fronts: flush_group() launches the r-th operations of all the queued fronts together, kind by kind) ----
+  std::vector<std::vector<GOp>> gq;          // the queues of the fronts recorded since the last flush_group()
+  bool                          rec = false; // recording (the level in hand is grouped)
+  size_t                        gscr_used = 0;
+  long long                     n_launch_plain = 0, n_launch_grouped = 0, n_ops_grouped = 0;
+  static void launch_kind(int kind, bool grouped, unsigned blocks, hipStream_t s, const GOp &o, const GOp *ops, const int *start, int nops)
+  {
+#define HH_LAUNCH_T(NAME, THREADS, LDSB, ...)                                                                                     \
+  do {                                                                                                                            \
+    if (grouped) hipLaunchKernelGGL((NAME##_g<__VA_ARGS__>), dim3(blocks), dim3(THREADS), LDSB, s, ops, start, nops);              \
+    else hipLaunchKernelGGL((NAME<__VA_ARGS__>), dim3(blocks), dim3(THREADS), LDSB, s, o);                                         \
+  } while (0)
+    switch (kind) {
+    case OP_GEMM64_N: HH_LAUNCH_T(k_gemm64, 256, 0, false, CS); break;
+    case OP_GEMM64_T: HH_LAUNCH_T(k_gemm64, 256, 0, true, CS); break;
+    case OP_BIG_64_128_N: HH_LAUNCH_T(k_gemm_big, 256, 0, 64, 128, false, CS); break;
+    case OP_BIG_64_128_T: HH_LAUNCH_T(k_gemm_big, 256, 0, 64, 128, true, CS); break;
+    case OP_BIG_128_128_N: HH_LAUNCH_T(k_gemm_big, 256, 0, 128, 128, false, CS); break;
+    case OP_BIG_128_128_T: HH_LAUNCH_T(k_gemm_big, 256, 0, 128, 128, true, CS); break;
+    case OP_BIG_128_64_N: HH_LAUNCH_T(k_gemm_big, 256, 0, 128, 64, false, CS); break;
+    case OP_BIG_128_64_T: HH_LAUNCH_T(k_gemm_big, 256, 0, 128, 64, true, CS); break;
+    case OP_POTF2:
+      if (grouped) hipLaunchKernelGGL(k_potf2_inv_g, dim3(blocks), dim3(TILE_THREADS), 0, s, ops, start, nops);
+      else hipLaunchKernelGGL(k_potf2_inv, dim3(blocks), dim3(TILE_THREADS), 0, s, o);
+      break;
+    case OP_LDLF2: HH_LAUNCH_T(k_ldlf2_inv, TILE_THREADS, tile_lds_bytes(sizeof(T)), T); break;
+    case OP_GETF2: HH_LAUNCH_T(k_getf2_inv, TILE_THREADS, tile_lds_bytes(sizeof(T)), T); break;
+    case OP_SCALE_COLS: HH_LAUNCH_T(k_scale_cols, 256, 0, T); break;
+    case OP_EXTRACT_DINV: HH_LAUNCH_T(k_extract_dinv, 256, 0, T); break;
+    case OP_SPLIT_U11: HH_LAUNCH_T(k_split_u11, 256, 0, T); break;
+    case OP_EXTEND_ADD: HH_LAUNCH_T(k_extend_add, 256, 0, T, false); break;
+    case OP_EXTEND_ADD_FULL: HH_LAUNCH_T(k_extend_add, 256, 0, T, true); break;
+    case OP_COPY2D: HH_LAUNCH_T(k_copy2d, 256, 0, T); break;
+    case OP_ZERO_UPPER: HH_LAUNCH_T(k_zero_upper, 256, 0, T); break;
+    case OP_SCATTER_ADD: HH_LAUNCH_T(k_scatter_add, 256, 0, CS); break;
+    case OP_SET_DIAG_TILES: HH_LAUNCH_T(k_set_diag_tiles, 256, 0, T); break;
+    default: HH_CHECK(false, "numfact (device levels): unknown operation");
+    }
+#undef HH_LAUNCH_T
+  }
+  void emit(const GOp &o)
+  {
+    if (o.blocks <= 0) return;
+    if (rec) {
+      gq.back().push_back(o);
+      return;
+    }
+    ++n_launch_plain;
+    launch_kind(o.kind, false, (unsigned)o.blocks, st, o, nullptr, nullptr, 0);
+  }
+  template <class... A> void gemm_(A... a) { emit(gemm_op<CS>(a...)); }
+  static GOp op(int kind, int blocks)
+  {
+    GOp o;
+    o.kind = kind, o.blocks = blocks;
+    return o;
+  }
+  void scale_cols_(int m, int k, const T *src, long long lds_, const T *Dsrc, long long ldD, T *dst, long long ldd)
+  {
+    GOp o = op(OP_SCALE_COLS, m);
+    o.p0 = const_cast<T *>(src), o.p1 = const_cast<T *>(Dsrc), o.p2 = dst, o.l0 = lds_, o.l1 = ldD, o.l2 = ldd, o.i0 = m, o.i1 = k;
+    emit(o);
+  }
+  void copy2d_(int m, int n, const T *src, long long lds_, T *dst, long long ldd)
+  {
+    GOp o = op(OP_COPY2D, m);
+    o.p0 = const_cast<T *>(src), o.p1 = dst, o.l0 = lds_, o.l1 = ldd, o.i0 = m, o.i1 = n;
+    emit(o);
+  }
+  // The r-th operations of all the recorded fronts are independent of one another (different fronts) and each waits for the (r - 1)-th
+  // of its own front only: one launch per round and kind, in stream order.  The descriptors travel through the upload ring with the
+  // lists and blocks the fronts staged (ONE copy for the whole group).
+  void flush_group()
+  {
+    if (gq.empty()) return;
+    size_t rounds = 0;
+    for (const auto &q : gq) rounds = std::max(rounds, q.size());
+    struct Launch {
+      int        kind, nops;
+      unsigned   blocks;
+      const GOp *ops;
+      const int *start;
+    };
+    std::vector<Launch>           todo;
+    std::vector<std::vector<GOp>> bucket(OP_KINDS);
+    std::vector<int>              start;
+    UploadRing                   &ring = scr->ring;
+    for (size_t r = 0; r < rounds; ++r) {
+      for (auto &b : bucket) b.clear();
+      for (const auto &q : gq)
+        if (r < q.size()) bucket[q[r].kind].push_back(q[r]);
+      for (int kind = 0; kind < OP_KINDS; ++kind) {
+        const std::vector<GOp> &b = bucket[kind];
+        if (b.empty()) continue;
+        start.assign(b.size() + 1, 0);
+        for (size_t i = 0; i < b.size(); ++i) start[i + 1] = start[i] + b[i].blocks;
+        Launch L;
+        L.kind = kind, L.nops = (int)b.size(), L.blocks = (unsigned)start.back();
+        L.ops   = (const GOp *)ring.stage(b.data(), b.size() * sizeof(GOp), st);
+        L.start = (const int *)ring.stage(start.data(), start.size() * sizeof(int), st);
+        todo.push_back(L);
+        n_ops_grouped += (long long)b.size();
+      }
+    }
+    ring.flush(st);
+    static const GOp none;
+    for (const Launch &L : todo) launch_kind(L.kind, true, L.blocks, st, none, L.ops, L.start, L.nops);
+    n_launch_grouped += (long long)todo.size();
+    gq.clear();
+    ring.begin_batch();
+  }
   // top block (w x w, lower triangular, the inverses of its diagonal tiles in tinvs) <- its inverse, by recursive doubling:
   // inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11, X22].  The diagonal tiles come inverted from the tile kernels; then blocks of
   // B = 64, 128, 256, ... rows: every pair (X11, X22) of a level is one entry of a BATCHED product (the pairs are independent and
@@ -1012,7 +1274,11 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void invert_top(T *P, long long ld, int w, const T *tinvs)
   {
     const int ntile = (w + 63) / 64;
-    hipLaunchKernelGGL(k_set_diag_tiles<T>, dim3((unsigned)ntile), dim3(256), 0, st, w, P, ld, tinvs);
+    {
+      GOp o = op(OP_SET_DIAG_TILES, ntile);
+      o.p0 = P, o.p1 = const_cast<T *>(tinvs), o.l0 = ld, o.i0 = w;
+      emit(o);
+    }
     for (long long B = 64; B < w; B *= 2) {
       const int npairs = (int)((w - B + 2 * B - 1) / (2 * B)); // pairs whose second block is not empty
       const int m_last = (int)std::min<long long>(B, w - ((long long)(npairs - 1) * 2 * B + B)); // rows of the last pair's second block
@@ -1028,8 +1294,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
         b1.count = b2.count = cnt;
         b1.sA = sP, b1.sB = sP, b1.sC = B * B;
         b2.sA = sP, b2.sB = B * B, b2.sC = sP;
-        gemm<CS>(st, false, m2, (int)B, (int)B, 1.0, cd(L21), ld, cd(X11), ld, md(Tm), B, false, false, 0, 0, true, false, b1); // T = L21 X11 (X11 lower triangular)
-        gemm<CS>(st, false, m2, (int)B, m2, -1.0, cd(X22), ld, cd(Tm), B, md(L21), ld, false, false, 0, 0, false, true, b2);     // X21 = -X22 T (X22 lower triangular)
+        gemm_(false, m2, (int)B, (int)B, 1.0, cd(L21), ld, cd(X11), ld, md(Tm), B, false, false, 0, 0, true, false, b1); // T = L21 X11 (X11 lower triangular)
+        gemm_(false, m2, (int)B, m2, -1.0, cd(X22), ld, cd(Tm), B, md(L21), ld, false, false, 0, 0, false, true, b2);     // X21 = -X22 T (X22 lower triangular)
       };
       level(0, nfull, (int)B);
       if (nfull < npairs) level(nfull, 1, m_last);
@@ -1039,8 +1305,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void mult_bottom(T *P, long long ld, int w, int nb)
   {
     if (!nb) return;
-    gemm<CS>(st, false, nb, w, w, 1.0, cd(P + (long long)w * ld), ld, cd(P), ld, md(tmp.p), w, false, false, 0, 0, true); // the inverted top block is lower triangular
-    hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, (const T *)tmp.p, (long long)w, P + (long long)w * ld, ld);
+    gemm_(false, nb, w, w, 1.0, cd(P + (long long)w * ld), ld, cd(P), ld, md(tmp.p), (long long)w, false, false, 0, 0, true); // the inverted top block is lower triangular
+    copy2d_((int)nb, (int)w, (const T *)tmp.p, (long long)w, P + (long long)w * ld, ld);
   }
   // X(m x jb, ld) <- X * op(B), B a 64 x 64 tile inverse.  In place when one workgroup owns all the columns of its rows (N <= the
   // tile width of the kernel gemm() picks: real scalars, and full tiles of complex ones): it has read the whole of its rows when
@@ -1049,18 +1315,20 @@ struct DeviceLevelsImpl : public DeviceLevels {
   {
     if (m <= 0) return;
     if (CS == 1 || jb == 64) {
-      gemm<CS>(st, transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64, md(X), ld, false);
+      gemm_(transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64LL, md(X), ld, false);
       return;
     }
-    gemm<CS>(st, transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64, md(tmp.p), 64, false);
-    hipLaunchKernelGGL(k_copy2d<T>, dim3(1, (unsigned)m), dim3(64), 0, st, m, jb, (const T *)tmp.p, 64LL, X, ld);
+    gemm_(transB, m, jb, jb, 1.0, cd(X), ld, cd(B), 64LL, md(tmp.p), 64LL, false);
+    copy2d_(m, jb, (const T *)tmp.p, 64LL, X, ld);
   }
 
   void scatter(T *P, size_t panel_scalars, const long long *dp, const double *dv, size_t cnt)
   {
-    if (!zeroed_all) HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st));
+    if (!zeroed_all) HIP_OK(hipMemsetAsync(P, 0, panel_scalars * sizeof(T), st)); // (never while recording: group_level())
     if (!cnt) return;
-    hipLaunchKernelGGL(k_scatter_add<CS>, dim3((unsigned)std::min<size_t>(1024, (cnt * CS + 255) / 256)), dim3(256), 0, st, (long long)cnt, dp, dv, md(P));
+    GOp o = op(OP_SCATTER_ADD, (int)std::min<size_t>(1024, (cnt * CS + 255) / 256));
+    o.p0 = const_cast<long long *>(dp), o.p1 = const_cast<double *>(dv), o.p2 = md(P), o.l0 = (long long)cnt;
+    emit(o);
   }
   void process_sparse(idx_t k, const long long *posF, const double *valF, size_t nF, const long long *posG, const double *valG, size_t nG, const std::vector<idx_t> &children, const std::vector<std::vector<int>> &rel) override
   {
@@ -1077,7 +1345,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     relp.assign(children.size(), nullptr);
     for (size_t c = 0; c < children.size(); ++c)
       if (!rel[c].empty()) relp[c] = (const int *)ring.stage(rel[c].data(), sizeof(int) * rel[c].size(), st);
-    ring.flush(st);
+    if (!rec) ring.flush(st); // (recording: one copy for the whole group, flush_group())
     scatter(reinterpret_cast<T *>(D.F.p) + hf->f_off[k], (size_t)h * ld, dpF, dvF, nF);
     if (lu) scatter(reinterpret_cast<T *>(D.G.p) + hf->f_off[k], (size_t)h * ld, dpG, dvG, nG);
     factor_front(k, children, rel);
@@ -1096,12 +1364,16 @@ struct DeviceLevelsImpl : public DeviceLevels {
         for (int t0 = 0; t0 < jb; t0 += 64) {
           const int kb = j0 + t0, tb = std::min(64, jb - t0), below = h - kb - tb;
           T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096;
-          if (t0 > 0) gemm<CS>(st, true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(Pk + j0), ld, md(Pk + kb), ld, true); // the tiles of this panel to the left
-          hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(TILE_THREADS), 0, st, Pk + kb, ld, tb, Tt, flag.p);
+          if (t0 > 0) gemm_(true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(Pk + j0), ld, md(Pk + kb), ld, true); // the tiles of this panel to the left
+          {
+            GOp o = op(OP_POTF2, 1);
+            o.p0 = Pk + kb, o.l0 = ld, o.i0 = tb, o.p1 = Tt, o.p4 = flag.p;
+            emit(o);
+          }
           right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
         }
         const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
-        if (r1 < w) gemm<CS>(st, true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(P + (long long)r1 * ld + j0), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
+        if (r1 < w) gemm_(true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(P + (long long)r1 * ld + j0), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
       }
     } else HH_CHECK(false, "numfact (device levels): complex matrices are factorised as L D L^T or LU");
   }
@@ -1115,17 +1387,21 @@ struct DeviceLevelsImpl : public DeviceLevels {
         T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)(kb / 64) * 4096, *Td = tinv2 + (size_t)(kb / 64) * 4096;
         if (t0 > 0) {
           // W = L(kb:kb+tb, j0:kb) * D(j0:kb);  P(kb:h, kb:kb+tb) -= L(kb:h, j0:kb) * W^T
-          hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((t0 + 255) / 256), (unsigned)tb), dim3(256), 0, st, tb, t0, (const T *)(Pk + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)t0);
-          gemm<CS>(st, true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(tmp.p), t0, md(Pk + kb), ld, true);
+          scale_cols_(tb, t0, (const T *)(Pk + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)t0);
+          gemm_(true, h - kb, tb, t0, -1.0, cd(Pk + j0), ld, cd(tmp.p), (long long)t0, md(Pk + kb), ld, true);
         }
-        hipLaunchKernelGGL(k_ldlf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, tb, Tt, Td, flag.p);
+        {
+          GOp o = op(OP_LDLF2, 1);
+          o.p0 = Pk + kb, o.l0 = ld, o.i0 = tb, o.p1 = Tt, o.p2 = Td, o.p4 = flag.p;
+          emit(o);
+        }
         right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Td, true); // X <- X * inv(L_T)^T * D_T^{-1}
       }
       const int r1 = j0 + jb;
       if (r1 < w) {
         // W = L(r1:w, j0:r1) * D(j0:r1);  P(r1:h, r1:w) -= L(r1:h, j0:r1) * W^T
-        hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((jb + 255) / 256), (unsigned)(w - r1)), dim3(256), 0, st, w - r1, jb, (const T *)(P + (long long)r1 * ld + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)jb);
-        gemm<CS>(st, true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(tmp.p), jb, md(P + (long long)r1 * ld + r1), ld, true, true);
+        scale_cols_(w - r1, jb, (const T *)(P + (long long)r1 * ld + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)jb);
+        gemm_(true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(tmp.p), (long long)jb, md(P + (long long)r1 * ld + r1), ld, true, true);
       }
     }
   }
@@ -1141,16 +1417,20 @@ struct DeviceLevelsImpl : public DeviceLevels {
       const int kb = 64 * t, jb = std::min<int>(64, w - kb), below = h - kb - jb;
       T        *Pk = P + (long long)kb * ld, *Tt = tinv.p + (size_t)t * 4096;
       if (kb > 0) {
-        gemm<CS>(st, false, h - kb, jb, kb, -1.0, cd(Pk), ld, cd(P + kb), ld, md(Pk + kb), ld, true);                 // column block of [A11; A21]
-        gemm<CS>(st, false, jb, w - kb - jb, kb, -1.0, cd(Pk), ld, cd(P + kb + jb), ld, md(Pk + kb + jb), ld, true); // row block of U inside A11
-        gemm<CS>(st, true, nb, jb, kb, -1.0, cd(Gb), ld, cd(Pk), ld, md(Gb + kb), ld, true);                          // row block of U12 (transposed)
+        gemm_(false, h - kb, jb, kb, -1.0, cd(Pk), ld, cd(P + kb), ld, md(Pk + kb), ld, true);                 // column block of [A11; A21]
+        gemm_(false, jb, w - kb - jb, kb, -1.0, cd(Pk), ld, cd(P + kb + jb), ld, md(Pk + kb + jb), ld, true); // row block of U inside A11
+        gemm_(true, nb, jb, kb, -1.0, cd(Gb), ld, cd(Pk), ld, md(Gb + kb), ld, true);                          // row block of U12 (transposed)
       }
-      hipLaunchKernelGGL(k_getf2_inv<T>, dim3(1), dim3(TILE_THREADS), tile_lds_bytes(sizeof(T)), st, Pk + kb, ld, jb, Tt, tinv2 + (size_t)t * 4096, tinv3 + (size_t)t * 4096, flag.p, swapped);
+      {
+        GOp o = op(OP_GETF2, 1);
+        o.p0 = Pk + kb, o.l0 = ld, o.i0 = jb, o.p1 = Tt, o.p2 = tinv2 + (size_t)t * 4096, o.p3 = tinv3 + (size_t)t * 4096, o.p4 = flag.p, o.p5 = swapped;
+        emit(o);
+      }
       right_tile(Pk + (long long)jb * ld + kb, ld, below, jb, tinv2 + (size_t)t * 4096, false); // L part below: X <- X * inv(U_T)
       const int right = w - kb - jb;
       if (right > 0) { // U(kb:kb+jb, kb+jb:w) <- inv(L_T) P_t * U(...): the rows take the pivoted order in the same product
-        gemm<CS>(st, false, jb, right, jb, 1.0, cd(Tt), 64, cd(Pk + kb + jb), ld, md(tmp.p), right, false);
-        hipLaunchKernelGGL(k_copy2d<T>, dim3((unsigned)((right + 255) / 256), (unsigned)jb), dim3(256), 0, st, jb, right, (const T *)tmp.p, (long long)right, Pk + kb + jb, ld);
+        gemm_(false, jb, right, jb, 1.0, cd(Tt), 64LL, cd(Pk + kb + jb), ld, md(tmp.p), (long long)right, false);
+        copy2d_(jb, right, (const T *)tmp.p, (long long)right, Pk + kb + jb, ld);
       }
       right_tile(Gb + kb, ld, nb, jb, Tt, true); // U12^T rows: X <- X * (inv(L_T) P_t)^T
     }
@@ -1178,9 +1458,9 @@ struct DeviceLevelsImpl : public DeviceLevels {
       HH_CHECK(it != cb.end(), "numfact (device levels): child contribution block not resident");
       if (!nbc) continue;
       const int *rl = relp[c];
-      const dim3 grid((unsigned)std::min(64, (nbc + 63) / 64), (unsigned)((nbc + 3) / 4));
-      if (lu) hipLaunchKernelGGL(k_extend_add_full<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, rl, P, G, ld, (int)w, C, (long long)nb);
-      else hipLaunchKernelGGL(k_extend_add<T>, grid, dim3(64, 4), 0, st, (const T *)it->second, nbc, rl, P, ld, (int)w, C, (long long)nb);
+      GOp o = op(lu ? OP_EXTEND_ADD_FULL : OP_EXTEND_ADD, (nbc + 3) / 4);
+      o.p0 = it->second, o.p1 = const_cast<int *>(rl), o.p2 = P, o.p3 = G, o.p4 = C, o.l0 = ld, o.l1 = (long long)nb, o.i0 = nbc, o.i1 = (int)w;
+      emit(o);
     }
     // ---- blocked factorisation of the panel ----
     const int ntile = (w + 63) / 64;
@@ -1191,19 +1471,24 @@ struct DeviceLevelsImpl : public DeviceLevels {
     // ---- Schur complement -> contribution block (lower triangle for the symmetric kinds, full for LU) ----
     if (nb) {
       T *P21 = P + (long long)w * ld;
-      if (kind == FACT_CHOL) gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(P21), ld, md(C), nb, true, true);
+      if (kind == FACT_CHOL) gemm_(true, nb, nb, w, -1.0, cd(P21), ld, cd(P21), ld, md(C), (long long)nb, true, true);
       else if (kind == FACT_LDLT) {
-        hipLaunchKernelGGL(k_scale_cols<T>, dim3((unsigned)((w + 255) / 256), (unsigned)nb), dim3(256), 0, st, (int)nb, (int)w, (const T *)P21, ld, (const T *)P, ld, tmp.p, (long long)w);
-        gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(tmp.p), w, md(C), nb, true, true);
-      } else gemm<CS>(st, true, nb, nb, w, -1.0, cd(P21), ld, cd(G + (long long)w * ld), ld, md(C), nb, true);
+        scale_cols_((int)nb, (int)w, (const T *)P21, ld, (const T *)P, ld, tmp.p, (long long)w);
+        gemm_(true, nb, nb, w, -1.0, cd(P21), ld, cd(tmp.p), (long long)w, md(C), (long long)nb, true, true);
+      } else gemm_(true, nb, nb, w, -1.0, cd(P21), ld, cd(G + (long long)w * ld), ld, md(C), (long long)nb, true);
     }
     // ---- unit diagonals made explicit, D recorded (LDL^T), U11 split out of the F top block (LU) ----
-    if (lu) hipLaunchKernelGGL(k_split_u11<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, G, ld);
-    else hipLaunchKernelGGL(k_zero_upper<T>, dim3((unsigned)std::max(1, (int)((w + 255) / 256)), (unsigned)w), dim3(256), 0, st, (int)w, P, ld);
+    {
+      GOp o = op(lu ? OP_SPLIT_U11 : OP_ZERO_UPPER, (int)w);
+      o.p0 = P, o.p1 = G, o.l0 = ld, o.i0 = (int)w;
+      emit(o);
+    }
     if (kind == FACT_LDLT) {
       // 1 / D of this front into its own columns of a vector of the whole factor: downloaded once, in end() (a copy and a stream
       // synchronisation per front kept the host in step with the device: the L D L^T device levels were not asynchronous at all)
-      hipLaunchKernelGGL(k_extract_dinv<T>, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (int)w, P, ld, reinterpret_cast<T *>(scr->dinv_all.p) + c0);
+      GOp o = op(OP_EXTRACT_DINV, (int)((w + 255) / 256));
+      o.p0 = P, o.p1 = reinterpret_cast<T *>(scr->dinv_all.p) + c0, o.l0 = ld, o.i0 = (int)w;
+      emit(o);
     }
     if (hf->keep_plain) { // (the oracle's CPU baseline wants the plain factor: the front leaves the device before it is inverted)
       const double tp0 = now();
@@ -1224,6 +1509,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
   int end() override
   {
     int f = 0;
+    if (rec) flush_group();
+    rec = false;
     level_barrier(); // everything meets on every stream of the slot; the host waits for the first one below
     set_slot(0);
     if (prof && !lev_ev.empty()) {
@@ -1255,6 +1542,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
       HIP_OK(hipStreamSynchronize(st));
       UploadRing &r = scr->ring;
       fprintf(stderr, "[numfact] device levels: host ran %.3f s ahead of the stream at the end; ring: %.1f MB pushed, %.3f s copying, %d wrap-arounds waiting %.3f s\n", now() - t0, r.bytes_pushed / 1e6, r.t_copy, r.wraps, r.t_wait);
+      fprintf(stderr, "[numfact] device levels: %lld launches of one operation, %lld launches of grouped levels for %lld operations\n", n_launch_plain, n_launch_grouped, n_ops_grouped);
       r.bytes_pushed = 0, r.t_copy = r.t_wait = 0, r.wraps = 0;
     }
     std::vector<int> fl(1 + (size_t)hf->sym.nblk, 0);
@@ -1280,11 +1568,14 @@ struct DeviceLevelsImpl : public DeviceLevels {
       if (fl[1 + k]) hf->tgs[k] = 6;
     cb.clear();
     scr->ring.release_retired();
+    return f;
+  }
+  void finish() override
+  {
     if (locked) {
       locked = false;
       DeviceScratch::release(scr);
     }
-    return f;
   }
 };
 

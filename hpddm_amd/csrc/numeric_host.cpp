@@ -415,8 +415,13 @@ idx_t pick_first_device_level(const HostFactor &hf)
 {
   const Symbolic &s    = hf.sym;
   const idx_t     nlev = (idx_t)hf.level_ptr.size() - 1;
-  const char     *e    = getenv("HPDDM_HIP_DEVICE_MIN_H"); // fronts with at least this many rows are worth the device (tests lower it)
-  const idx_t     minh = e ? std::max(1, atoi(e)) : 768;
+  // fronts with at least this many rows are worth the device (tests lower it).  768 until round 5; since the levels of many small
+  // fronts go through grouped launches (numeric_device.hip) the device takes them at no extra cost, the host levels -- and the
+  // first-touch page faults of their contribution blocks in the first factorisations of a process -- shrink, and fewer bytes cross
+  // PCIe at the hand-over level: 129^3, levels 4.. instead of 6..: numerical phase 1.31 -> 1.26 s, 2.4 -> 1.6 GB uploaded
+  // (profiles/r06_setup_phases.txt)
+  const char     *e    = getenv("HPDDM_HIP_DEVICE_MIN_H");
+  const idx_t     minh = e ? std::max(1, atoi(e)) : 400;
   for (idx_t l = 0; l < nlev; ++l)
     for (idx_t q = hf.level_ptr[l]; q < hf.level_ptr[l + 1]; ++q) {
       const idx_t k = hf.level_blk[q];
@@ -529,6 +534,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
 #pragma omp parallel for if (par) schedule(static)
       for (idx_t i = 0; i < nb; ++i) std::memset(static_cast<void *>(C + (size_t)i * nb), 0, (size_t)(lu ? nb : i + 1) * sizeof(T));
     }
+    lap(4); // (the first factorisations of a process: first-touch page faults of the pool's blocks, 2 us per page on these hosts)
     for (idx_t i = 0; i < w; ++i) rel[c0 + i] = i;
     for (idx_t i = 0; i < nb; ++i) rel[rows[i]] = w + i;
     // ---- assemble the original entries ----
@@ -770,7 +776,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], false);
     } else
       for (idx_t q = b0; q < b1; ++q) process(hf.level_blk[q], true);
-    if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[0], tph[1], tph[2], tph[3]);
+    if (prof) fprintf(stderr, "[numfact] level %d: %d blocks, %.3f s (cum. thread-seconds: block %.3f assemble %.3f panel %.3f schur %.3f invert %.3f)\n", (int)l, (int)(b1 - b0), now() - tl0, tph[4], tph[0], tph[1], tph[2], tph[3]);
     if (bad) break; // a pivot collapsed (a normal event: L D L^T falls back to LU, local_solver.hip): the levels above would factorise garbage
   }
   if (bad) // the contribution blocks nobody will consume go back to the pool (they stayed out of its free list until process exit)

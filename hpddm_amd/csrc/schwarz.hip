@@ -22,6 +22,7 @@
 #include <thread>
 
 namespace hpddm_hip {
+static double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 
 // ------------------------------------------------------------------ kernels ------------------------------------
@@ -865,14 +866,19 @@ void Schwarz::call_numfact()
   if (reuse <= 1 || !factored) {
     const int spd = (int)getopt("operator_spd", 0);
     std::vector<const DeviceFactor *> fs;
+    const bool   prof_setup = getenv("HPDDM_HIP_PROFILE") != nullptr;
+    const double tsu0 = wall_seconds();
     {
       // analysis (ordering + symbolic factorisation) of all the subdomains side by side: it is sequential per subdomain
       // and about half of the set-up time at 65^3 per subdomain
       std::string err;
       const int   leaf = (int)getopt("leaf_size", 32);
+      int         dev_here = 0;
+      HIP_OK(hipGetDevice(&dev_here));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(std::max(1, std::min(nsub, host_thread_cap())))
       for (int s = 0; s < nsub; ++s) {
         try {
+          HIP_OK(hipSetDevice(dev_here)); // (worker threads start on device 0)
           SchwarzSub &S = subs[s];
           if (S.ls->leaf_size != leaf) {
             S.ls->leaf_size = leaf;
@@ -881,6 +887,9 @@ void Schwarz::call_numfact()
           CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
           if (is_complex) A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
           S.ls->analyse(A);
+          // the panels of the factor in HBM (12 GB per 129^3 subdomain: a third of a second per allocation) now, under the analyses
+          // of the other subdomains, instead of at the head of every numerical factorisation
+          S.ls->dev.F.alloc((size_t)S.ls->host.f_size * (is_complex ? 2 : 1));
         } catch (const std::exception &e) {
 #pragma omp critical(hpddm_hip_analyse_err)
           err = e.what();
@@ -891,6 +900,7 @@ void Schwarz::call_numfact()
     // The numerical factorisations, two in flight: the lower levels of subdomain s + 1 are factorised on the host cores while the
     // upper levels of subdomain s run on the device (one factorisation at a time holds the device work space: DeviceScratch::acquire) --
     // the reference factorises its subdomains side by side, one MPI rank each.  -hpddm_hip_numfact_threads 1: one after the other.
+    const double tsu1 = wall_seconds();
     const int keep_plain = getopt("keep_plain", 0) != 0, release = getopt("keep_host_factor", 0) == 0, leaf = (int)getopt("leaf_size", 32);
     for (int s = 0; s < nsub; ++s)
       if (is_complex) HH_CHECK(!subs[s].zia.empty() && (!use1 || !subs[s].zia1.empty()), "complex operators: the subdomain (optimised) matrix was not handed over as a complex matrix");
@@ -898,6 +908,7 @@ void Schwarz::call_numfact()
       SchwarzSub &S          = subs[s];
       S.ls->leaf_size        = leaf;
       S.ls->release_host     = release;
+      S.ls->lazy_plan        = true; // the operator sweeps its subdomains through its own batched plans (build_plans below)
       S.ls->host.keep_plain  = keep_plain;
       CsrView A = use1 ? CsrView{S.n, S.ia1.data(), S.ja1.data(), S.a1.data(), S.sym1, S.base1} : CsrView{S.n, S.ia0.data(), S.ja0.data(), S.a0.data(), S.sym0, S.base0};
       if (is_complex) A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
@@ -934,7 +945,9 @@ void Schwarz::call_numfact()
       HH_CHECK(err.empty(), err);
     }
     for (int s = 0; s < nsub; ++s) fs.push_back(&subs[s].ls->dev);
+    const double tsu2 = wall_seconds();
     build_plans();
+    if (prof_setup) fprintf(stderr, "[call_numfact] analysis %.2f s, numerical factorisations %.2f s (%d threads), plans of the batched sweeps %.2f s\n", tsu1 - tsu0, tsu2 - tsu1, nthr, wall_seconds() - tsu2);
   }
   if (reuse >= 1) opt["reuse_preconditioner"] = reuse + 1;
   factored = true;

@@ -111,3 +111,71 @@ void staged_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s
 }
 
 } // namespace hpddm_hip
+
+// ---- large device buffers kept between owners (device.hpp) ---------------------------------------------------------------------
+namespace hpddm_hip {
+namespace {
+struct BigKept {
+  void  *p;
+  size_t bytes;
+  int    device;
+};
+std::mutex           g_big_mutex;
+std::vector<BigKept> g_big;
+size_t               big_budget()
+{
+  // how much the process may hold back (HPDDM_HIP_KEEP_BUFFERS_GB, default 48; 0: nothing is kept -- every release is a hipFree)
+  const char *e = getenv("HPDDM_HIP_KEEP_BUFFERS_GB");
+  return (size_t)(e ? atof(e) : 48.0) << 30;
+}
+} // namespace
+
+void *big_buffer_take(size_t bytes, size_t *cap_bytes)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_big_mutex);
+  int                         best = -1;
+  for (int i = 0; i < (int)g_big.size(); ++i) // the tightest fit that wastes at most a quarter
+    if (g_big[i].device == dev && g_big[i].bytes >= bytes && g_big[i].bytes <= bytes + bytes / 4 && (best < 0 || g_big[i].bytes < g_big[best].bytes)) best = i;
+  if (best < 0) return nullptr;
+  void        *p = g_big[best].p;
+  const size_t cb = g_big[best].bytes;
+  g_big.erase(g_big.begin() + best);
+  // like memory fresh from the driver: zeros (padding between panels, rows nobody writes); 2 ms per 12 GB
+  if (hipMemset(p, 0, cb) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return nullptr;
+  }
+  *cap_bytes = cb;
+  return p;
+}
+
+bool big_buffer_give(void *p, size_t cap_bytes)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mutex);
+    size_t                      held = 0;
+    for (const BigKept &b : g_big) held += b.bytes;
+    if (held + cap_bytes > big_budget()) return false;
+  }
+  // what hipFree did for the previous owner: nothing on the device still uses the buffer when somebody else gets it
+  if (hipDeviceSynchronize() != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(g_big_mutex);
+  g_big.push_back(BigKept{p, cap_bytes, dev});
+  return true;
+}
+
+void big_buffer_trim()
+{
+  std::vector<BigKept> out;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mutex);
+    out.swap(g_big);
+  }
+  for (const BigKept &b : out) (void)hipFree(b.p);
+}
+} // namespace hpddm_hip
