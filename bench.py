@@ -345,7 +345,7 @@ def main():
                    "deflation_flops": 4.0 * n * nu * mu * (4.0 if A.complex else 1.0),
                    "kernel": ("k_zt_stream2 + k_z_stream2: with mu <= 2 the contraction is a GEMV (an MFMA tile would carry 14 empty columns), streaming VALU FMAs, "
                               "MFMA utilisation 0 by construction" if mu <= 2 else
-                              "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM; complex operators: the same kernels on the compact complex Z): the panel has mu/4 flop/B, HBM-bound (counters: profiles/r04_pmc_mfma_deflation.csv)")})
+                              "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM; complex operators: the same kernels on the compact complex Z): the panel has mu/4 flop/B, HBM-bound (counters: the newest profiles/rNN_pmc_mfma_deflation.csv, see two_level.deflation_mfma_mu8.counters)")})
         tl["deflation_TFLOPs"] = tl["deflation_flops"] / t_defl / 1e12
         if mu <= 2 and world == 1:
             # the same panel with 8 right-hand sides (Block GMRES, the GenEO blocks): the GEMM-shaped products on v_mfma_f64_16x16x4_f64,
@@ -356,8 +356,7 @@ def main():
             b8 = 2.0 * n * nu * sk + 3.0 * n * 8 * sk
             tl["deflation_mfma_mu8"] = {"ms": t8 * 1e3, "flops": f8, "TFLOPs": f8 / t8 / 1e12, "frac_of_f64_mfma_peak": f8 / t8 / 78.6e12, "panel_GBps": b8 / t8 / 1e9,
                                         "bound": "hbm (%.2f flop/B on the panel bytes)" % (f8 / b8), "kernel": "k_zt_mfma2 + k_z_mfma2 (v_mfma_f64_16x16x4_f64, operands straight from HBM in 32-byte accesses, the partition of unity at the store of the second) + the in-place halo sum on the overlap",
-                                        "mfma_busy_fraction_of_simd_cycles": {"k_zt_mfma2": 0.2445, "k_z_mfma2": 0.1512, "source": "profiles/r04_pmc_mfma_deflation_utilisation.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE on scripts/time_deflation.py: the same panel, 8 right-hand sides; not measured in this run)"},
-                                        "counters": "profiles/r04_pmc_mfma_deflation.csv (SQ counters), profiles/r04_deflation_mfma_mu8_kernel_stats.csv (rocprofv3 --kernel-trace --stats: k_zt_mfma2 0.93 ms, k_z_mfma2 0.92 ms per launch), profiles/r04_deflation_fused_scaling_times.txt (scaling at the store on / off)"}
+                                        **mfma_evidence()}
         if not args.no_gmres:
             tl["gmres"] = gmres_leg()
 
@@ -569,6 +568,41 @@ def configs_1(np, torch, dev, args):
     return out
 
 
+def mfma_evidence():
+    """The MFMA-utilisation figures of the 8-right-hand-side deflation kernels, READ from the newest committed counter pass
+    (profiles/rNN_pmc_mfma_deflation_utilisation.csv: scripts/mfma_util.py on a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES
+    SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` pass around scripts/time_deflation.py -- the same panel, 8 right-hand sides) and the per-launch
+    durations of the kernel trace beside it (profiles/rNN_deflation_mfma_mu8_kernel_stats.csv); not measured in this run."""
+    import csv
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    util = sorted(glob.glob(os.path.join(here, "r[0-9][0-9]_pmc_mfma_deflation_utilisation.csv")))
+    out = {"mfma_busy_fraction_of_simd_cycles": None, "counters": None}
+    if not util:
+        return out
+    rel = lambda f: "profiles/" + os.path.basename(f)
+    busy = {}
+    for r in csv.DictReader(open(util[-1])):
+        for k in ("k_zt_mfma2", "k_z_mfma2"):
+            if k in r["kernel"] and float(r["mfma_busy_fraction_of_simd_cycles"]) > 0.0:
+                busy[r["kernel"].split("::")[-1].strip('"')] = float(r["mfma_busy_fraction_of_simd_cycles"])
+    busy["source"] = rel(util[-1]) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE on scripts/time_deflation.py: the same panel, 8 right-hand sides; not measured in this run)"
+    out["mfma_busy_fraction_of_simd_cycles"] = busy
+    rnd = os.path.basename(util[-1])[:3]
+    stats = os.path.join(here, rnd + "_deflation_mfma_mu8_kernel_stats.csv")
+    per = {}
+    if os.path.exists(stats):
+        for line in open(stats):
+            if line.startswith("#") or line.startswith("kernel,"):
+                continue
+            name, rest = line.rsplit('",', 1)
+            for k in ("k_zt_mfma2", "k_z_mfma2"):
+                if k in name:
+                    per[name.split("::")[-1].split("(")[0]] = round(float(rest.split(",")[2]) / 1e3, 3)
+    out["counters"] = {"sq_counters": "profiles/" + rnd + "_pmc_mfma_deflation.csv", "kernel_trace": rel(stats) if per else None, "ms_per_launch": per}
+    return out
+
+
 def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level applies/s of the device path
     """The oracle's substitution (plain C, oracle/sptrsv_oracle.c) on the factors of the SAME operator, on the host cores of this box,
     on a bounded SAMPLE of its subdomains: the first `ns` of them are factorised once more with the plain factor kept on the host
@@ -598,6 +632,23 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     nnz_smp = float(sum(S.info()["nnz_L"] for S in solvers))
     scale = nnz_all / nnz_smp                          # whole operator / sample, by factor entries (= algorithmic bytes of the substitutions)
     threads = min(ns, ncores)
+    # what this process may schedule: the smaller of the affinity mask and the container's CPU quota (cpu.max), which the logical core
+    # count ignores.  Under a quota the team variants (b), (c) leave TWO CPUs of head-room: a team that spins at its barriers on every
+    # CPU of the quota is throttled by the bandwidth controller as soon as anything else of the process runs (the Python thread, the
+    # HIP runtime's threads) -- round 5 measured 16 threads under a 16-CPU quota 3x SLOWER than 8 threads for exactly that reason
+    quota_cpus = ncores
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+        if q != "max":
+            quota_cpus = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota_cpus = min(quota_cpus, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    team_cpus = quota_cpus - 2 if (quota_cpus < ncores and quota_cpus > 4) else quota_cpus
     orc = Oracle(subs)
     orc.d = d
     f = [np.ones(s["n"]) for s in subs[:ns]]
@@ -625,9 +676,9 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     agree_gpu = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(xs, xg[:ns]))
     # (b): the team size that is fastest on this box (barrier cost grows with the team; SMT siblings and container CPU quotas
     # make "every logical core" the wrong choice more often than not): double it while it pays
-    nthr, best_probe = min(16, ncores), None
+    nthr, best_probe = min(16, team_cpus), None
     cand = nthr
-    while cand <= ncores:
+    while cand <= team_cpus:
         sptrsv_oracle.time_batch_levels(factors, f, reps=1, threads=cand)
         sec, _ = sptrsv_oracle.time_batch_levels(factors, f, reps=1, threads=cand)
         if best_probe is not None and sec > 0.95 * best_probe:
@@ -639,19 +690,7 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
     # (c) a team of threads per subdomain (nested OpenMP: the row loops of the large supernodes shared by the team).  One core
     # streams a factor at 12-17 GB/s; the team size follows what this process may use -- the smaller of the affinity mask and the
     # container's CPU quota (cpu.max), which the logical core count ignores
-    quota_cpus = ncores
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:
-            q, per = fh.read().split()
-        if q != "max":
-            quota_cpus = max(1, int(float(q) / float(per)))
-    except (OSError, ValueError):
-        pass
-    try:
-        quota_cpus = min(quota_cpus, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    team = max(1, min(16, quota_cpus // ns))
+    team = max(1, min(16, team_cpus // ns))
     tc, rc, xt = (ta, ra, xs)
     if team > 1:
         tc, rc, xt = sample(lambda r: sptrsv_oracle.time_batch_teams(factors, f, reps=r, team=team))
@@ -684,7 +723,7 @@ def cpu_baseline(A, subs, d, args, np, gpu_value):  # gpu_value: ONE-level appli
                       f"their plain factors made by {ns} extra factorisations after the timed region, {t_sample:.1f} s) + numpy halo sum of all {nsub} ({tex * 1e3:.1f} ms): "
                       f"(a) one thread per subdomain, {ns * rep_n} concurrent substitutions on {ns * rep_n} threads (the sampled factors swept {rep_n} times side by side), {ra} applies, {ta * 1e3:.1f} ms; "
                       f"(b) level-parallel on {nthr} threads (the fastest team size on this box of {ncores} logical cores), {rb} applies, {tb * 1e3:.1f} ms for the sample = {eb * 1e3:.1f} ms scaled; "
-                      f"(c) {team} threads per subdomain = {ns * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs), {rc} applies, {tc * 1e3:.1f} ms = {ec * 1e3:.1f} ms scaled; "
+                      f"(c) {team} threads per subdomain = {ns * team} threads (nested teams on the large supernodes; the container may use {quota_cpus} CPUs, the teams take {team_cpus}), {rc} applies, {tc * 1e3:.1f} ms = {ec * 1e3:.1f} ms scaled; "
                       f"value = the fastest; the three agree to {agree:.1e}, with the device solve to {agree_gpu:.1e}",
             "sample_subdomains": ns, "sample_scale": scale, "sample_factor_seconds": round(t_sample, 2),
             "host_GBps": bytes_host / best / 1e9, "usable_cpus": quota_cpus,
@@ -744,7 +783,7 @@ def cpu_baseline_z(A, subs, d, args, np, gpu_value, mu):  # gpu_value: ONE-level
         S.destroy()
     return {"value": 1.0 / per_apply, "unit": "applies/s", "cores": threads, "kind": "port", "cgroup_cpu_max": quota,
             "sample": f"one-level apply of the same {nsub}-subdomain complex operator on {mu} right-hand sides: complex substitutions on the plain L D L^T factors of all {nsub} subdomains "
-                      f"(made by {nsub} extra factorisations after the timed region, {t_sample:.1f} s), one thread per subdomain = {threads} threads, the {mu} right-hand sides one after the other, "
+                      f"(made by {nsub} extra factorisations after the timed region, {t_sample:.1f} s), one thread per subdomain = {threads} threads, the {mu} right-hand sides as ONE block (every factor entry read once per block, as MUMPS ICNTL(27) / PARDISO do), "
                       f"{reps} applies, {ta * 1e3:.1f} ms + numpy halo sum {tex * 1e3:.1f} ms; agrees with the device solve to {agree_gpu:.1e}",
             "cores_used_by": "one thread per subdomain (the only variant of the complex port)",
             "host_GBps": 2.0 * nnz_all * 16.0 * mu / ta / 1e9, "seconds_per_apply": per_apply, "host_cores": ncores,

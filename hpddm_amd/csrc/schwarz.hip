@@ -198,6 +198,63 @@ __global__ __launch_bounds__(256) void k_csrmm(const long long *__restrict__ vof
   }
 }
 
+// Four and more right-hand sides: ONE LANE PER ROW.  With 8 lanes per row (above) every gather of x is 7 scattered 8-byte words per
+// group of lanes and the block of right-hand sides multiplies the gathers: 1.9 TB/s at 8 x 129^3 with 8 columns, bound by the L2
+// sectors those words drag along (8 bytes used of 32).  With consecutive lanes on consecutive rows, entry e of the rows of a wavefront
+// addresses CONSECUTIVE entries of x on a stencil (the e-th diagonal): 512 contiguous bytes per load instruction and column, the same
+// lines again for the neighbouring diagonals (L1 / L2 hits); the entries of the matrix (a lane walks its own row: 12 bytes apart in
+// time, 84 apart across the lanes) come in whole lines over the walk.  Entries four at a time with all their loads (4 x (index, value)
+// then 4 x NB entries of x) in flight together.  The workgroups of an XCD take a contiguous range of rows, so that the planes of x a
+// range reads twice (rows +-N, +-N^2 away) meet in one L2.
+template <int NB, int EC>
+__global__ __launch_bounds__(256) void k_csrmm_rows(const long long *__restrict__ voff, const int *__restrict__ nn, const long long *__restrict__ iaoff, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ x, double *y, int mu, double alpha, double beta, const double *y0, const double *__restrict__ dsc, const unsigned char *__restrict__ rmask, int rwant)
+{
+  const int       s = blockIdx.y, n = nn[s];
+  const long long v0  = voff[s];
+  const int      *ias = ia + iaoff[s];
+  const int       nblk = (int)gridDim.x, id = (int)blockIdx.x, q8 = nblk / 8, r8 = nblk % 8, xcd = id % 8;
+  const int       lb = xcd * q8 + min(xcd, r8) + id / 8; // logical block: contiguous chunks per XCD (workgroup ids go round-robin over the XCDs)
+  for (int i = lb * 256 + (int)threadIdx.x; i < n; i += nblk * 256) {
+    if (rmask && rmask[v0 + i] != rwant) continue;
+    const int    p0 = ias[i], p1 = ias[i + 1];
+    const double w = dsc ? dsc[v0 + i] : 1.0;
+    for (int nu0 = 0; nu0 < mu; nu0 += NB) {
+      const double *xs = x + v0 * mu + (long long)nu0 * n;
+      long long     ob[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) ob[b] = nu0 + b < mu ? (long long)b * n : 0; // (columns past the block: column nu0 again, dropped below)
+      double acc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+      for (int p = p0; p < p1; p += EC) {
+        int    j[EC];
+        double av[EC], xv[EC][NB];
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+          const bool ok = p + e < p1;
+          j[e]          = ja[ok ? p + e : p0];
+          av[e]         = ok ? a[p + e] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < EC; ++e)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) xv[e][b] = xs[ob[b] + j[e]];
+#pragma unroll
+        for (int e = 0; e < EC; ++e)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[b] = fma(av[e], xv[e][b], acc[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (nu0 + b < mu) {
+          const long long o = v0 * mu + (long long)(nu0 + b) * n + i;
+          const double    t = (beta == 0.0 ? 0.0 : beta * y0[o]) + alpha * acc[b];
+          y[o]              = w * t;
+        }
+    }
+  }
+}
+
 // the same for K = std::complex<double> on the complex matrix itself (Wrapper::csrmm with complex scalars, include/HPDDM_wrapper.hpp:
 // 697-733): 16 + 4 bytes per entry where the real-equivalent embedding reads 32 + 4 (2 x 2 blocks); the vectors are the (re, im)
 // pairs of the caller either way.  n = 2 x (complex rows) as everywhere in the complex Schwarz layer.
@@ -1491,6 +1548,18 @@ void Schwarz::csrmm(const double *x, double *y, int mu, double alpha, double bet
   // 2.08 ms against 1.94 at 8 x 129^3 with 8 right-hand sides, gpurun_out r05e: the gathers of x are bound by L2 sectors, 8 bytes of 32
   // used, not by their latency; -hpddm_hip_gmv_block 2 | 4 keeps the variants reachable)
   const int nb = (int)getopt("hip_gmv_block", 1);
+  // four and more right-hand sides: one lane per row, the whole block of columns per pass over the matrix (-hpddm_hip_gmv_rows 0: the
+  // 8-lanes-per-row kernel below, one column after the other)
+  if (mu >= 4 && (int)getopt("hip_gmv_rows", 1) != 0) {
+    const dim3 gr((unsigned)std::min(8192, (nmax + 255) / 256), (unsigned)nsub);
+    const int ec = (int)getopt("hip_gmv_chunk", 4);
+    if (mu > 4 && ec >= 8) hipLaunchKernelGGL((k_csrmm_rows<8, 8>), gr, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    else if (mu > 4 && ec == 2) hipLaunchKernelGGL((k_csrmm_rows<8, 2>), gr, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    else if (mu > 4) hipLaunchKernelGGL((k_csrmm_rows<8, 4>), gr, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    else if (ec >= 8) hipLaunchKernelGGL((k_csrmm_rows<4, 8>), gr, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    else hipLaunchKernelGGL((k_csrmm_rows<4, 4>), gr, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
+    return;
+  }
   if (nb >= 4 && mu >= 4) hipLaunchKernelGGL(k_csrmm<4>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
   else if (nb >= 2 && mu >= 2) hipLaunchKernelGGL(k_csrmm<2>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);
   else hipLaunchKernelGGL(k_csrmm<1>, gc, dim3(256), 0, library_stream(), voff_d.p, n_d.p, iaoff_d.p, ia_d.p, ja_d.p, a_d.p, x, y, mu, alpha, beta, y0, dsc, rm, rows);

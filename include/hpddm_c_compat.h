@@ -77,7 +77,7 @@ int HpddmSolve(HpddmSchwarz *, const HpddmK *b, HpddmK *sol, int mu, const MPI_C
  * (n x mu, column-major, n rows on this rank; inner products summed over *comm): interface/hpddm_c.cpp:41-53, 227-230.  Returns
  * the iteration count.  The basis and the recurrences live in HBM; every callback is one round trip over PCIe. */
 typedef struct HpddmCustomOperator HpddmCustomOperator;
-int HpddmCustomOperatorSolve(const HpddmCustomOperator *A, int n, int (*mv)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), int (*precond)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), const HpddmK *b, HpddmK *sol, int mu, const MPI_Comm *comm); /* K = double only: the complex library aborts with a message */
+int HpddmCustomOperatorSolve(const HpddmCustomOperator *A, int n, int (*mv)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), int (*precond)(const HpddmCustomOperator *, const HpddmK *, HpddmK *, int), const HpddmK *b, HpddmK *sol, int mu, const MPI_Comm *comm); /* both scalar types: libhpddm_c_hip.so (K = double) and libhpddm_c_hip_z.so (K = double _Complex, -DFORCE_COMPLEX) */
 
 double nrm2(const int *, const HpddmK *, const int *);                                        /* :117 */
 void   axpy(const int *, const HpddmK *, const HpddmK *, const int *, HpddmK *, const int *); /* :118 */

@@ -126,8 +126,81 @@ static void solve_one_z(const oracle_factor *f, const zd *b, zd *x, zd *work)
   }
   for (ll i = 0; i < n; ++i) x[f->perm[i]] = y[i];
 }
-/* all subdomains at once, one thread each, nrhs complex right-hand sides per subdomain (column-major, leading dimension n complex);
- * returns wall seconds of `reps` repetitions */
+/* The same substitution on a BLOCK of nr <= ZBLK right-hand sides at once: every entry of the factor is read once per block (what a CPU
+ * solver does with several right-hand sides: MUMPS ICNTL(27), PARDISO's nrhs), the columns interleaved inside the work vectors (entry i of
+ * column c at i * nr + c) so that the innermost loops run over the columns.  Per column the operations and their order are those of
+ * solve_one_z (the results agree to rounding: the compiler contracts the multiply-adds of the two loop nests differently). */
+#define ZBLK 8
+static void solve_block_z(const oracle_factor *f, const zd *b, zd *x, int nr, zd *work)
+{
+  const ll  n = f->n;
+  zd       *y = work; /* n * nr */
+  const zd *Lz = (const zd *)f->L, *Uz = (const zd *)f->U, *dz = (const zd *)f->dinv;
+  zd        s[ZBLK];
+  for (ll i = 0; i < n; ++i)
+    for (int c = 0; c < nr; ++c) y[i * nr + c] = b[(size_t)c * n + f->perm[i]];
+  ll wmax = 0;
+  for (ll k = 0; k < f->nblk; ++k) wmax = f->blk_ptr[k + 1] - f->blk_ptr[k] > wmax ? f->blk_ptr[k + 1] - f->blk_ptr[k] : wmax;
+  zd *t = (zd *)malloc(sizeof(zd) * (size_t)(wmax > 0 ? wmax : 1) * nr);
+  for (ll k = 0; k < f->nblk; ++k) {
+    const ll  c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const zd *P  = Lz + f->f_off[k];
+    const ll *r  = f->rows + f->row_ptr[k];
+    for (ll i = 0; i < w; ++i) {
+      const zd *row = P + i * ld;
+      for (int c = 0; c < nr; ++c) s[c] = y[(c0 + i) * nr + c];
+      for (ll j = 0; j < i; ++j) {
+        const zd a = row[j];
+        for (int c = 0; c < nr; ++c) s[c] -= a * y[(c0 + j) * nr + c];
+      }
+      for (int c = 0; c < nr; ++c) y[(c0 + i) * nr + c] = s[c] / row[i];
+    }
+    for (ll i = 0; i < nb; ++i) {
+      const zd *row = P + (w + i) * ld;
+      for (int c = 0; c < nr; ++c) s[c] = 0.0;
+      for (ll j = 0; j < w; ++j) {
+        const zd a = row[j];
+        for (int c = 0; c < nr; ++c) s[c] += a * y[(c0 + j) * nr + c];
+      }
+      for (int c = 0; c < nr; ++c) y[r[i] * nr + c] -= s[c];
+    }
+  }
+  if (f->kind == 1)
+    for (ll i = 0; i < n; ++i)
+      for (int c = 0; c < nr; ++c) y[i * nr + c] *= dz[i];
+  const zd *B = f->kind == 2 ? Uz : Lz;
+  for (ll k = f->nblk - 1; k >= 0; --k) {
+    const ll  c0 = f->blk_ptr[k], w = f->blk_ptr[k + 1] - c0, nb = f->row_ptr[k + 1] - f->row_ptr[k], ld = f->ldw[k];
+    const zd *P  = B + f->f_off[k];
+    const ll *r  = f->rows + f->row_ptr[k];
+    for (ll j = 0; j < w; ++j)
+      for (int c = 0; c < nr; ++c) t[j * nr + c] = y[(c0 + j) * nr + c];
+    for (ll i = 0; i < nb; ++i) {
+      const zd *row = P + (w + i) * ld;
+      for (int c = 0; c < nr; ++c) s[c] = y[r[i] * nr + c];
+      for (ll j = 0; j < w; ++j) {
+        const zd a = row[j];
+        for (int c = 0; c < nr; ++c) t[j * nr + c] -= a * s[c];
+      }
+    }
+    for (ll i = w - 1; i >= 0; --i) {
+      const zd *row = P + i * ld;
+      for (int c = 0; c < nr; ++c) {
+        s[c]                  = t[i * nr + c] / row[i];
+        y[(c0 + i) * nr + c] = s[c];
+      }
+      for (ll j = 0; j < i; ++j) {
+        const zd a = row[j];
+        for (int c = 0; c < nr; ++c) t[j * nr + c] -= a * s[c];
+      }
+    }
+  }
+  free(t);
+  for (ll i = 0; i < n; ++i)
+    for (int c = 0; c < nr; ++c) x[(size_t)c * n + f->perm[i]] = y[i * nr + c];
+}
+/* all subdomains at once, one thread each, nrhs complex right-hand sides per subdomain (column-major, leading dimension n complex),
+ * in blocks of ZBLK columns; returns wall seconds of `reps` repetitions */
 double oracle_sptrsv_batch_z(int nsub, const oracle_factor *fs, const double *const *b, double *const *x, int nrhs, int reps, int threads)
 {
   struct timespec t0, t1;
@@ -135,8 +208,12 @@ double oracle_sptrsv_batch_z(int nsub, const oracle_factor *fs, const double *co
   for (int rep = 0; rep < reps; ++rep) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (int s = 0; s < nsub; ++s) {
-      zd *work = (zd *)malloc(sizeof(zd) * 2 * (size_t)fs[s].n);
-      for (int nu = 0; nu < nrhs; ++nu) solve_one_z(&fs[s], (const zd *)b[s] + (size_t)nu * fs[s].n, (zd *)x[s] + (size_t)nu * fs[s].n, work);
+      zd *work = (zd *)malloc(sizeof(zd) * (size_t)(ZBLK > 2 ? ZBLK : 2) * (size_t)fs[s].n);
+      for (int nu = 0; nu < nrhs; nu += ZBLK) {
+        const int nr = nrhs - nu < ZBLK ? nrhs - nu : ZBLK;
+        if (nr == 1) solve_one_z(&fs[s], (const zd *)b[s] + (size_t)nu * fs[s].n, (zd *)x[s] + (size_t)nu * fs[s].n, work);
+        else solve_block_z(&fs[s], (const zd *)b[s] + (size_t)nu * fs[s].n, (zd *)x[s] + (size_t)nu * fs[s].n, nr, work);
+      }
       free(work);
     }
   }

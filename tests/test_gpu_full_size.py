@@ -86,6 +86,7 @@ def test_configs_3_share_elasticity_64_nodes_geneo():
     A.option_parse("-hpddm_schwarz_coarse_correction deflated")
     it2, sol2 = A.solve(f)
     res2 = A.compute_residual(sol2, f)
+    print(f"configs_3_share: one-level {it1} iterations, two-level {it2}")
     assert it2 < it1 and it2 <= 0.6 * it1 and res2[1] / res2[0] <= 5e-6, (it1, it2, res2)
     _close(sol2, sol1, 1e-4, "the one- and two-level solutions agree")
     A.destroy()

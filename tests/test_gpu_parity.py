@@ -111,7 +111,7 @@ def test_config1_45_iterations():
     A.destroy()
 
 
-@pytest.mark.parametrize("N,parts,overlap,sym,mu", [(12, 8, 1, True, 1), (14, 8, 2, True, 3), (10, 4, 1, False, 2), (16, 2, 1, True, 5)])
+@pytest.mark.parametrize("N,parts,overlap,sym,mu", [(12, 8, 1, True, 1), (14, 8, 2, True, 3), (10, 4, 1, False, 2), (16, 2, 1, True, 5), (12, 8, 1, True, 4), (10, 4, 1, False, 8)])
 def test_3d_against_oracle(N, parts, overlap, sym, mu):
     """3-D Poisson (configs 2-3 family) at sizes the oracle finishes in seconds: every hot-path function + GMRES"""
     subs = generate3d(N, parts, overlap, sym=sym, rhs="smooth")

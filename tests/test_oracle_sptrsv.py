@@ -90,4 +90,9 @@ def test_complex_cpu_substitution_matches_superlu(kind):
     sec, xs = sptrsv_oracle.time_batch_z([pf, pf], [b, b], reps=2, threads=2)
     ref = spl.splu(sp.csc_matrix(A)).solve(b)
     assert np.abs(xs[0] - ref).max() <= 1e-11 * np.abs(ref).max() and np.abs(xs[1] - ref).max() <= 1e-11 * np.abs(ref).max() and sec > 0
+    # the block of right-hand sides goes through solve_block_z (every factor entry read once per block), a single one through
+    # solve_one_z: per column the same operations in the same order (the compiler contracts the multiply-adds of the two loops differently)
+    for c in range(3):
+        _, x1 = sptrsv_oracle.time_batch_z([pf], [np.asfortranarray(b[:, c:c + 1])], reps=1, threads=1)
+        assert np.abs(x1[0][:, 0] - xs[0][:, c]).max() <= 1e-13 * np.abs(ref).max()
     S.destroy()
