@@ -161,7 +161,7 @@ int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *t
       info[8]  = ls.plan.launches_per_solve;
       info[9]  = (long long)ls.host.sym.flops;
       info[10] = (long long)(ls.host.t_plain * 1e6); // microseconds of the numerical phase spent keeping the plain factor (keep_plain)
-      info[11] = 0;
+      info[11] = ls.plan.nbush; // bushes of the 16-column engine (0 until the plan is built)
     }
     if (times) {
       times[0] = ls.host.t_order;

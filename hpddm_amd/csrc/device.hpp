@@ -108,6 +108,30 @@ struct SnDesc {
   int           t_r0, t_nr, t_rbeg, t_rend;
 };
 
+// 16-column engine, the bottom of the tree in ONE launch per direction (sptrsv16.hip, "bushes"): a complete subtree of narrow supernodes
+// whose columns -- contiguous in the permuted numbering -- and the rows below its root fit the LDS of one workgroup.  The vectors of
+// the subtree live in LDS for the whole subtree (one 128-byte line per column, then one per row below the root), the hand-over between
+// its supernodes never leaves the workgroup, and every global address of the sweep (panels, tiles, index lists) is known before the
+// first product: nothing but the panel stream is waited for after the workgroup has loaded its vectors.
+struct BushTile16 { // one wavefront, one round: 32 output rows (forward, on the transposed copy) / 32 doubles of every row (backward)
+  const double *P;  // FT + r0 / G + m0
+  int           ld, K, mlim, klo, khi; // leading dimension, rows of P (the k range of the product ends at khi, starts at klo), outputs that exist
+  int           cj;     // LDS line of the supernode's first column
+  int           w, nb;  // its columns and rows below
+  int           lrow;   // first of its nb local rows (LDS lines) in the bush's index list
+  int           r0, nr; // forward: first output row, rows; backward: first double, doubles
+  int           sn;     // the supernode (SolvePlan::sn), -1: this wavefront has no tile in this round
+  int           gc0;    // its first column in the subdomain's numbering (the stores of y / x)
+  int           pad;
+};
+struct Bush16 {
+  long long     voff, coff; // the subdomain's offset in the batched vectors / in the compact hand-over pool (lines)
+  const double *dinv;       // the subdomain's 1 / D, or nullptr
+  int           c0, ncol, nbr, c_out; // first column, columns, rows below the root, first line of the root's parent's block in the compact pool
+  int           tile0[2], nround[2];  // forward / backward: first tile record (4 per round) and rounds
+  int           int0, nlrow;          // the bush's index list in SolvePlan::bush_int: nlrow local rows of its supernodes, then crel and rows of the root (nbr each)
+};
+
 struct Tile {
   int sn;     // index into the batch SnDesc array
   int r0;     // forward: first row of the tile; backward: first column
@@ -135,6 +159,8 @@ struct DeviceFactor {
   std::vector<idx_t>   blk_ptr, ldw, height, level_ptr, level_blk, nchild, lb_nnzr, lb_nnzc;
   std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
   std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off, c_off, cs_off, pcs_off;
+  const Symbolic      *sym = nullptr; // the analysis on the host (HostFactor::sym of the solver that owns both): parents and rows, for the plan builder
+  const std::vector<idx_t> *crel_h = nullptr; // ... and HostFactor::crel
   int64_t              s_size = 0, u_size = 0;
   void upload(const HostFactor &hf, hipStream_t s);
 };
@@ -161,6 +187,12 @@ struct SolvePlan {
   // 16-column engine, wide supernodes with children: their right-hand side b_J - (what the children handed up) is formed once per
   // supernode by a small dense pass before the level's sweep (tiles of 256 columns); its wide tiles read it straight from the vector
   std::vector<int> gat_ptr, gat_end;
+  // 16-column engine: the bushes (above), largest first; their supernodes are in none of the level lists of the engine
+  DevBuf<Bush16>     bush;
+  DevBuf<BushTile16> bush_tile;
+  DevBuf<int>        bush_int;
+  int                nbush = 0, bush_lds = 0; // ... and the LDS bytes of the largest
+  std::vector<int>   lev_bwd16;               // per level: the BWD_BLOCK tiles the 16-column engine takes (those of the bushes' supernodes sit behind them)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;
   DevBuf<double> y, xw, U, bperm; // U: the slot pool of the forward hand-over (factor.hpp), [column][utot], zero where no child writes

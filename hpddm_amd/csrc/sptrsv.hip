@@ -1391,6 +1391,7 @@ void DeviceFactor::upload(const HostFactor &hf, hipStream_t s)
   if ((idx_t)lb_off.size() != nblk) lb_off.assign(nblk, -1), lb_nnzr.assign(nblk, 0), lb_nnzc.assign(nblk, 0);
   tgs.assign(hf.tgs.begin(), hf.tgs.end());
   if ((idx_t)tgs.size() != nblk) tgs.assign(nblk, 0);
+  sym = &hf.sym, crel_h = &hf.crel;
   // transposed copies of the narrow forward panels
   ft_off.assign(nblk, -1);
   ldh.assign(nblk, 0);
@@ -1479,6 +1480,172 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       if (D.ldw[k] * cs > NARROW) wide_rows16[D.height[k]] += ((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k]) + 15) / 16;
   }
   const long long fwd_want = envi("HPDDM_HIP_FWD_WANT", 512) / std::max(1, groups);
+  // ---- 16-column engine: the bushes (device.hpp) -- complete subtrees of narrow supernodes of height <= HPDDM_HIP_BUSH16 (-1: none)
+  // whose vectors, tile records and index lists fit HPDDM_HIP_BUSH_LDS KB of LDS; roots = the highest supernodes that qualify
+  std::vector<std::vector<char>> in_bush(fs.size());
+  {
+    const int       hcut   = envi("HPDDM_HIP_BUSH16", 3), bush_min = envi("HPDDM_HIP_BUSH_MIN", 1);
+    const long long budget = (long long)std::max(8, std::min(160, envi("HPDDM_HIP_BUSH_LDS", 40))) * 1024; // (40 KB = four workgroups per CU, what their registers allow: 64 KB measured 5 % slower, 128 KB 45 %, profiles/r06_engine16_bushes.txt)
+    std::vector<Bush16>     bs;
+    std::vector<BushTile16> bt;
+    std::vector<int>        bi;
+    std::vector<long long>  bcost;
+    bush_lds = 0;
+    long long snbase = 0;
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      const int           cs = D.cplx ? 2 : 1;
+      in_bush[f].assign((size_t)D.nblk, 0);
+      if (hcut >= 0 && D.sym && D.crel_h && (idx_t)D.sym->parent.size() == D.nblk) {
+        const Symbolic    &S = *D.sym;
+        const idx_t        nblk = D.nblk;
+        std::vector<idx_t> first(nblk), cnt(nblk, 1);
+        std::vector<char>  ok(nblk);
+        std::vector<long long> sumnb(nblk), ntf(nblk), rb(nblk); // rows below / forward tiles / backward tiles of the subtree
+        auto hgt = [&](idx_t k) { return (int)((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k])); };
+        for (idx_t k = 0; k < nblk; ++k) {
+          const int h = hgt(k);
+          first[k] = k;
+          ok[k]    = D.ldw[k] * cs <= NARROW && D.height[k] <= hcut && D.ft_off[k] >= 0;
+          sumnb[k] = D.row_ptr[k + 1] - D.row_ptr[k];
+          ntf[k]   = (h + 31) / 32;
+          rb[k]    = (D.ldw[k] * cs + 31) / 32;
+        }
+        for (idx_t k = 0; k < nblk; ++k) {
+          const idx_t p = S.parent[k];
+          if (p < 0) continue;
+          first[p] = std::min(first[p], first[k]);
+          cnt[p] += cnt[k], sumnb[p] += sumnb[k], ntf[p] += ntf[k], rb[p] += rb[k];
+          ok[p] = ok[p] && ok[k];
+        }
+        auto need = [&](idx_t k) { // LDS bytes (upper bound: every round of the tile table full but one per level)
+          const long long lines = (D.blk_ptr[k + 1] - D.blk_ptr[first[k]]) + (D.row_ptr[k + 1] - D.row_ptr[k]);
+          const long long tiles = std::max(ntf[k] + 4 * (D.height[k] + 1), 4 * (long long)cnt[k]);
+          return lines * 128 + tiles * (long long)sizeof(BushTile16) + (sumnb[k] + 2 * (D.row_ptr[k + 1] - D.row_ptr[k])) * 4 + 64;
+        };
+        auto elig = [&](idx_t k) { return ok[k] && cnt[k] == k - first[k] + 1 && cnt[k] >= bush_min && need(k) <= budget; };
+        for (idx_t k = 0; k < nblk; ++k) {
+          if (!elig(k) || (S.parent[k] >= 0 && elig(S.parent[k]))) continue;
+          // ---- bush rooted at k: supernodes first[k] .. k ----
+          const idx_t k0 = first[k];
+          const int   c0 = D.blk_ptr[k0], ncol = D.blk_ptr[k + 1] - c0, nbr = (int)(D.row_ptr[k + 1] - D.row_ptr[k]);
+          const idx_t *rootrows = S.rows.data() + S.row_ptr[k];
+          Bush16 B;
+          B.voff = voff[f], B.coff = coffs[f];
+          B.dinv = D.kind == FACT_LDLT ? D.dinv.p : nullptr;
+          B.c0 = c0, B.ncol = ncol, B.nbr = nbr, B.c_out = (int)std::max<int64_t>(0, D.pcs_off[k]);
+          B.int0 = (int)bi.size();
+          std::vector<int> lrow_of(cnt[k]);
+          for (idx_t j = k0; j <= k; ++j) {
+            in_bush[f][j]  = 1;
+            lrow_of[j - k0] = (int)bi.size() - B.int0;
+            for (int64_t q = S.row_ptr[j]; q < S.row_ptr[j + 1]; ++q) {
+              const idx_t r = S.rows[q];
+              if (r < c0 + ncol) bi.push_back(r - c0);
+              else {
+                const idx_t *it = std::lower_bound(rootrows, rootrows + nbr, r);
+                HH_CHECK(it != rootrows + nbr && *it == r, "plan: a row of a bush is neither one of its columns nor below its root");
+                bi.push_back(ncol + (int)(it - rootrows));
+              }
+            }
+          }
+          B.nlrow = (int)bi.size() - B.int0;
+          for (int i = 0; i < nbr; ++i) bi.push_back((int)(*D.crel_h)[(size_t)(D.u_off[k] + i)]);
+          for (int i = 0; i < nbr; ++i) bi.push_back(rootrows[i]);
+          long long cost = 0;
+          const int hmax = D.height[k];
+          auto rec = [&](idx_t j) {
+            BushTile16 t;
+            t.cj = D.blk_ptr[j] - c0, t.w = D.blk_ptr[j + 1] - D.blk_ptr[j], t.nb = (int)(D.row_ptr[j + 1] - D.row_ptr[j]);
+            t.lrow = lrow_of[j - k0], t.sn = (int)(snbase + j), t.gc0 = D.blk_ptr[j], t.pad = 0;
+            return t;
+          };
+          BushTile16 none;
+          none.P = nullptr, none.ld = none.K = none.mlim = none.klo = none.khi = none.cj = none.w = none.nb = none.lrow = none.r0 = none.nr = none.gc0 = none.pad = 0, none.sn = -1;
+          // forward: levels bottom-up, 32-row tiles of the transposed copy, four to a round
+          B.tile0[0] = (int)bt.size();
+          for (int l = 0; l <= hmax; ++l) {
+            int inround = 0;
+            for (idx_t j = k0; j <= k; ++j) {
+              if (D.height[j] != l) continue;
+              const int w = D.blk_ptr[j + 1] - D.blk_ptr[j], h = hgt(j), wc = w * cs, tg = D.tgs.empty() ? 0 : D.tgs[j];
+              cost += (long long)h * D.ldw[j] * cs;
+              for (int r0 = 0; r0 < h; r0 += 32) {
+                BushTile16 t = rec(j);
+                const int  re = std::min(r0 + 32, h);
+                t.P = D.FT.p + D.ft_off[j] + r0, t.ld = D.ldh[j], t.K = wc;
+                t.mlim = std::min((re - r0 + 1) & ~1, (int)D.ldh[j] - r0);
+                t.klo  = 0;
+                t.khi  = re - 1 < w ? std::min<long long>(wc, (long long)cs * ((((long long)(re - 1) >> tg) + 1) << tg)) : wc;
+                t.r0 = r0, t.nr = re - r0;
+                bt.push_back(t);
+                inround = (inround + 1) & 3;
+              }
+            }
+            for (; inround & 3; ++inround) bt.push_back(none);
+          }
+          B.nround[0] = ((int)bt.size() - B.tile0[0]) / 4;
+          // the hand-over of a round, phase by phase: the tiles of ONE supernode write different lines and go together, supernode after
+          // supernode in the order of the round (pad = phase | phases of the round << 8; tiles without rows below take no part)
+          for (int r = 0; r < B.nround[0]; ++r) {
+            BushTile16 *q = bt.data() + B.tile0[0] + 4 * r;
+            int         nph = 0, last = -1;
+            for (int u = 0; u < 4; ++u) {
+              q[u].pad = 255;
+              if (q[u].sn < 0 || q[u].r0 + q[u].nr <= q[u].w) continue;
+              if (q[u].sn != last) last = q[u].sn, ++nph;
+              q[u].pad = nph - 1;
+            }
+            for (int u = 0; u < 4; ++u) q[u].pad |= nph << 8;
+          }
+          // backward: levels top-down, 32 doubles of every row per tile, the tiles of a supernode (<= 4) inside ONE round: x_J takes the place of z_J
+          B.tile0[1] = (int)bt.size();
+          for (int l = hmax; l >= 0; --l) {
+            int inround = 0;
+            for (idx_t j = k; j >= k0; --j) {
+              if (D.height[j] != l) continue;
+              const int h = hgt(j), ldw = D.ldw[j] * cs, nt = (ldw + 31) / 32;
+              if (inround + nt > 4) {
+                for (; inround < 4; ++inround) bt.push_back(none);
+                inround = 0;
+              }
+              for (int m0 = 0; m0 < ldw; m0 += 32) {
+                BushTile16 t = rec(j);
+                t.P = (D.kind == FACT_LU ? D.G.p : D.F.p) + D.f_off[j] * cs + m0, t.ld = ldw, t.K = h;
+                t.mlim = ldw - m0;
+                t.klo  = ((m0 / cs) / 4) * 4;
+                t.khi  = h;
+                t.r0 = m0, t.nr = std::min(32, ldw - m0);
+                bt.push_back(t);
+                ++inround;
+              }
+              if (inround == 4) inround = 0;
+            }
+            if (inround)
+              for (; inround < 4; ++inround) bt.push_back(none);
+          }
+          B.nround[1] = ((int)bt.size() - B.tile0[1]) / 4;
+          const int lds = (ncol + nbr) * 128 + 4 * std::max(B.nround[0], B.nround[1]) * (int)sizeof(BushTile16) + (B.nlrow + 2 * nbr) * 4;
+          HH_CHECK(lds <= budget, "plan: a bush outgrew its LDS estimate");
+          bush_lds = std::max(bush_lds, (lds + 255) / 256 * 256);
+          bs.push_back(B);
+          bcost.push_back(cost);
+        }
+      }
+      snbase += D.nblk;
+    }
+    nbush = (int)bs.size();
+    std::vector<int> order(bs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return bcost[a] > bcost[b2]; }); // largest first
+    std::vector<Bush16> sorted;
+    for (int i : order) sorted.push_back(bs[i]);
+    if (bi.empty()) bi.push_back(0);
+    if (bt.empty()) bt.resize(1);
+    if (sorted.empty()) sorted.resize(1);
+    bush.upload(sorted, s), bush_tile.upload(bt, s), bush_int.upload(bi, s);
+    HIP_OK(hipStreamSynchronize(s));
+  }
   for (size_t f = 0; f < fs.size(); ++f) {
     const DeviceFactor &D = *fs[f];
     for (idx_t k = 0; k < D.nblk; ++k) {
@@ -1533,8 +1700,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
           for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
           tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(tb);
         }
-        for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
-        if (small || leafv) w16[1][lev].push_back(tb); // (the other supernodes are block tiles of both engines: tl[BWD_BLOCK]; a condensed leaf too tall for a wavefront becomes a team tile of the engine)
+        if (!in_bush[f][k]) {
+          for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
+          if (small || leafv) w16[1][lev].push_back(tb);
+        } // (the other supernodes are block tiles of both engines: tl[BWD_BLOCK]; a condensed leaf too tall for a wavefront becomes a team tile of the engine)
       } else {
         // forward: 64-row tiles when the right-hand side fits one LDS chunk (staged once per tile), shorter otherwise
         int trb = fwd_tile_rows(d.wc);
@@ -1591,6 +1760,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_lds[kd].assign(nlev, 0);
   }
   lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
+  lev_bwd16.assign(nlev, 0);
+  std::vector<char> sn_in_bush;
+  for (size_t f = 0; f < fs.size(); ++f) sn_in_bush.insert(sn_in_bush.end(), in_bush[f].begin(), in_bush[f].end());
   lev_pair.assign(nlev, 0);
   pair_leaves = envi("HPDDM_HIP_LEAF_PAIRS", 1) != 0; // developer switch: 0 = one condensed leaf per wavefront in the backward sweep too
   auto pairable = [&](const Tile &t) { return pair_leaves && descs[t.sn].ldw <= 64; }; // (the rows of W^T fit 32 lanes)
@@ -1605,6 +1777,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         int np = 0;
         for (const Tile &t : tl[kd][l]) np += pairable(t);
         lev_pair[l] = np & ~1; // (an odd one out: the largest, on a wavefront of its own -- the same in both directions)
+      }
+      if (kd == BWD_BLOCK) { // (narrow supernodes too tall for a wavefront are block tiles of both engines: those of the bushes last, the 16-column engine stops before them)
+        auto it = std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return !sn_in_bush[t.sn]; });
+        lev_bwd16[l] = (int)(it - tl[kd][l].begin());
       }
       if (kd == FWD_BLOCK || kd == BWD_BLOCK) {
         lev_ptr[kd][l] = (int)all.size();

@@ -605,6 +605,297 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bwd_kernel(const SnDesc *
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Bushes (device.hpp): the bottom of the tree, one workgroup per subtree, ONE launch per direction.  On a small tree the level launches
+// of the bottom are bound by the chains of their tiles -- descriptor, right-hand side with its hand-over lists, panel rows, places of
+// the results, stores: dependent round trips to HBM for a few KB of panel, thousands of tiles per level, two generations of wavefronts
+// per launch (profiles/r05_engine16_sq_counters.txt).  Here the vectors of the subtree sit in LDS (line i = column c0 + i of the
+// subdomain, then one line per row below the root), the tile records and the index lists too; after that first burst the only thing a
+// wavefront waits for is the stream of its panel rows, and those addresses are known from the start: the ring of the NEXT tile is primed
+// before the hand-over of the current one.  The B operand of the MFMAs is read from the vectors in LDS directly (no staging area).
+// A ROUND = one tile per wavefront, all of one level.  Forward: f_J is complete when its level starts (the rounds of the lower levels
+// have subtracted their updates in place, wavefront after wavefront in a fixed order: bitwise reproducible), y_J goes straight to HBM, the
+// rows below the root leave as the root's update in the compact hand-over.  Backward: the tiles of a supernode share a round, x_J
+// takes the place of z_J = D^-1 y_J behind a barrier.
+struct TileRegs {
+  gcd_t P;
+  int   ld, K, mlim, klo, khi, cj, w, nb, lrow, r0, nr, sn, gc0, ph;
+};
+__device__ static inline TileRegs tile_regs(const BushTile16 *t) // a record in LDS -> scalar registers
+{
+  const int *q = reinterpret_cast<const int *>(t);
+  auto       u = [&](int i) { return __builtin_amdgcn_readfirstlane(q[i]); };
+  TileRegs   r;
+  r.P  = (gcd_t)(((unsigned long long)(unsigned)u(1) << 32) | (unsigned)u(0));
+  r.ld = u(2), r.K = u(3), r.mlim = u(4), r.klo = u(5), r.khi = u(6), r.cj = u(7), r.w = u(8), r.nb = u(9), r.lrow = u(10), r.r0 = u(11), r.nr = u(12), r.sn = u(13), r.gc0 = u(14), r.ph = u(15);
+  return r;
+}
+static_assert(sizeof(BushTile16) == 64, "tile records are copied to LDS in 16-byte pieces and read by field number");
+__device__ static inline TileRegs tile_regs_global(const BushTile16 *t) // the same from HBM (wave-uniform address: scalar loads)
+{
+  TileRegs r;
+  r.P  = (gcd_t)t->P;
+  r.ld = t->ld, r.K = t->K, r.mlim = t->mlim, r.klo = t->klo, r.khi = t->khi, r.cj = t->cj, r.w = t->w, r.nb = t->nb, r.lrow = t->lrow, r.r0 = t->r0, r.nr = t->nr, r.sn = t->sn, r.gc0 = t->gc0, r.ph = t->pad;
+  return r;
+}
+// n 16-byte pieces (4-byte: lds_copy4) from HBM to LDS in two halves -- request the first NB pieces of the thread, keep them in registers;
+// later: write them to LDS and move the rest, four at a time -- so that the first requests of SEVERAL copies leave together
+template <int NB>
+struct Copy16 {
+  dbl2 v[NB];
+  __device__ inline void request(gcd2_t src, int n, int tid)
+  {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = tid + u * WG_THREADS < n ? src[tid + u * WG_THREADS] : dbl2{0.0, 0.0};
+  }
+  __device__ inline void finish(dbl2 *dst, gcd2_t src, int n, int tid)
+  {
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (tid + u * WG_THREADS < n) dst[tid + u * WG_THREADS] = v[u];
+    for (int i = tid + NB * WG_THREADS; i < n; i += 4 * WG_THREADS) {
+      dbl2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = i + u * WG_THREADS < n ? src[i + u * WG_THREADS] : dbl2{0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + u * WG_THREADS < n) dst[i + u * WG_THREADS] = q[u];
+    }
+  }
+};
+template <int NB>
+struct Copy4 {
+  int v[NB];
+  __device__ inline void request(const int *src, int n, int tid)
+  {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = tid + u * WG_THREADS < n ? src[tid + u * WG_THREADS] : 0;
+  }
+  __device__ inline void finish(int *dst, const int *src, int n, int tid)
+  {
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (tid + u * WG_THREADS < n) dst[tid + u * WG_THREADS] = v[u];
+    for (int i = tid + NB * WG_THREADS; i < n; i += WG_THREADS) dst[i] = src[i];
+  }
+};
+// the product of one tile: rows [k0, k1) of P (k0, k1 multiples of 4) against B, row k of B = bf(k) for this lane's column
+template <int PF, class BF>
+__device__ static inline void bush_steps(dbl2 (&ring)[PF][1], gcd_t P, int ld, int K, int mlim, int k0, int k1, const int (&klo)[1], const int (&khi)[1], int lane, BF bf, v4f64 &aE, v4f64 &aO)
+{
+  const int kq = lane >> 4;
+  for (int ks = k0; ks < k1; ks += 4 * PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int kk = ks + 4 * u;
+      if (kk < k1) { // wave-uniform
+        const double b = bf(kk + kq);
+        if (kk + 4 > klo[0] && kk < khi[0]) {
+          aE = mfma16(ring[u][0].x, b, aE);
+          aO = mfma16(ring[u][0].y, b, aO);
+        }
+        if (kk + 4 * PF < k1) wave_pipe_fetch<1>(ring[u], P, ld, K, mlim, kk + 4 * PF, k1, klo, khi, lane);
+      }
+    }
+  }
+}
+constexpr int BUSH_PF = 8;
+#ifdef HPDDM_BUSH_CLOCK // developer build (-DHPDDM_BUSH_CLOCK): thread 0 of every 37th bush records wall_clock64 (100 MHz) after its descriptor, after the burst, after the product and after the hand-over of every round; HPDDM_BUSH_CLOCK_DUMP=1 prints them at the 6th solve (profiles/r06_bush_clocks.txt)
+__device__ unsigned long long g_bush_clk[2][256][32];
+#define BCLK(dir, slot) do { if (blockIdx.x % 37 == 0 && blockIdx.x / 37 < 256 && threadIdx.x == 0 && (slot) < 32) g_bush_clk[dir][blockIdx.x / 37][slot] = wall_clock64(); } while (0)
+#else
+#define BCLK(dir, slot) do { } while (0)
+#endif
+__device__ static inline void bush_prime(dbl2 (&ring)[BUSH_PF][1], const TileRegs &t, int k0, int lane)
+{
+  if (t.sn < 0) return;
+  const int klo[1] = {t.klo}, khi[1] = {t.khi};
+  wave_pipe_prime<1, BUSH_PF>(ring, t.P, t.ld, t.K, t.mlim, k0, (t.khi + 3) & ~3, klo, khi, lane);
+}
+
+template <bool Z>
+__global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  BCLK(0, 0);
+  const Bush16 B      = bushes[blockIdx.x];
+  const int    tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int    nu = lane & 15, kq = lane >> 4;
+  const int    nlines = B.ncol + B.nbr, nround = B.nround[0];
+  if (nround < 0) return;
+  BCLK(0, 1);
+  double      *vec = lds;
+  BushTile16  *tl  = reinterpret_cast<BushTile16 *>(lds + (size_t)nlines * C16);
+  int         *li  = reinterpret_cast<int *>(tl + 4 * nround);
+  // everything but the panels, in one burst: b of the bush's columns (zeros in the lines of the rows below the root), the tile records,
+  // the local rows + crel of the root; the first tile of the wavefront comes straight from HBM, its panel rows leave with the burst
+  Copy16<4> cb;
+  Copy16<2> ct;
+  Copy4<2>  ci;
+  const gcd2_t bsrc = (gcd2_t)(b16 + (B.voff + B.c0) * C16), tsrc = (gcd2_t)(btiles + B.tile0[0]);
+  cb.request(bsrc, B.ncol * 8, tid);
+  ct.request(tsrc, 16 * nround, tid);
+  ci.request(bints + B.int0, B.nlrow + B.nbr, tid);
+  TileRegs t = tile_regs_global(btiles + B.tile0[0] + wave);
+  dbl2     ring[BUSH_PF][1];
+  bush_prime(ring, t, 0, lane);
+  cb.finish(reinterpret_cast<dbl2 *>(vec), bsrc, B.ncol * 8, tid);
+  for (int i = B.ncol * 8 + tid; i < nlines * 8; i += WG_THREADS) reinterpret_cast<dbl2 *>(vec)[i] = dbl2{0.0, 0.0};
+  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 16 * nround, tid);
+  ci.finish(li, bints + B.int0, B.nlrow + B.nbr, tid);
+  __syncthreads();
+  BCLK(0, 2);
+  for (int r = 0; r < nround; ++r) {
+    const TileRegs told = t;
+    if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave); // the tile of the next round
+    else t.sn = -1;
+    v4f64     aE = {0.0, 0.0, 0.0, 0.0}, aO = {0.0, 0.0, 0.0, 0.0};
+    const int re = told.r0 + told.nr;
+    if (told.sn >= 0) {
+      const double *f  = vec + (size_t)told.cj * C16;
+      const int     tw = told.w;
+      auto          bf = [&](int k) -> double { // row k of the right-hand side as the product wants it (complex: the R form, sptrsv.hip)
+        if constexpr (!Z) return k < tw ? f[k * C16 + nu] : 0.0;
+        else {
+          const int    c = k >> 1;
+          const double v = c < tw ? f[c * C16 + ((k & 1) ? (nu ^ 1) : nu)] : 0.0;
+          return (k & 1) ? ((nu & 1) ? v : -v) : v;
+        }
+      };
+      const int klo[1] = {0}, khi[1] = {told.khi};
+      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, 0, (told.khi + 3) & ~3, klo, khi, lane, bf, aE, aO);
+    }
+    bush_prime(ring, t, 0, lane); // the first panel rows of the next tile are on their way during the hand-over of this one
+    BCLK(0, 4 + 2 * r);
+    if (told.sn >= 0) {
+      double *yb = y16 + (B.voff + told.gc0) * C16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { // rows of the top block: y
+        const int rr = told.r0 + 2 * (kq + 4 * reg);
+        if (rr < re && rr < told.w) yb[(long long)rr * C16 + nu] = aE[reg];
+        if (rr + 1 < re && rr + 1 < told.w) yb[(long long)(rr + 1) * C16 + nu] = aO[reg];
+      }
+    }
+    // rows below the supernode: subtracted from the lines they belong to, the supernodes of the round one after the other (a fixed order)
+    const int nph = told.ph >> 8, myph = told.ph & 255; // (nph: the same for the four tiles of the round)
+    for (int ph = 0; ph < nph; ++ph) {
+      if (myph == ph) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rr = told.r0 + 2 * (kq + 4 * reg);
+          if (rr < re && rr >= told.w) vec[(size_t)li[told.lrow + rr - told.w] * C16 + nu] -= aE[reg];
+          if (rr + 1 < re && rr + 1 >= told.w) vec[(size_t)li[told.lrow + rr + 1 - told.w] * C16 + nu] -= aO[reg];
+        }
+      }
+      __syncthreads();
+    }
+    BCLK(0, 5 + 2 * r);
+  }
+  BCLK(0, 3);
+  // what the bush sends up: the update of its root, into the block of the root's parent in the compact pool
+  for (int i = tid >> 4; i < B.nbr; i += WG_THREADS / 16) S16[(B.coff + B.c_out + li[B.nlrow + i]) * C16 + nu] = -vec[(size_t)(B.ncol + i) * C16 + nu];
+}
+
+template <bool Z>
+__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const Bush16 B      = bushes[blockIdx.x];
+  const int    tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int    nu = lane & 15, kq = lane >> 4;
+  const int    nlines = B.ncol + B.nbr, nround = B.nround[1];
+  double      *vec = lds;
+  BushTile16  *tl  = reinterpret_cast<BushTile16 *>(lds + (size_t)nlines * C16);
+  int         *li  = reinterpret_cast<int *>(tl + 4 * nround);
+  // the burst: x on the rows below the root (the levels above have it; the rows themselves come from HBM for that), y and 1 / D of the
+  // bush's columns, tile records, index lists, the first tile's panel rows
+  const gcd2_t  xsrc = (gcd2_t)(x16 + B.voff * C16), ysrc = (gcd2_t)(y16 + (B.voff + B.c0) * C16), tsrc = (gcd2_t)(btiles + B.tile0[1]);
+  const int    *rsrc = bints + B.int0 + B.nlrow + B.nbr;
+  int           xr[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) xr[u] = tid + u * WG_THREADS < B.nbr * 8 ? rsrc[(tid + u * WG_THREADS) >> 3] : 0;
+  Copy16<2> ct;
+  Copy4<2>  ci;
+  ct.request(tsrc, 16 * nround, tid);
+  ci.request(bints + B.int0, B.nlrow, tid);
+  TileRegs t = tile_regs_global(btiles + B.tile0[1] + wave);
+  dbl2     ring[BUSH_PF][1];
+  bush_prime(ring, t, t.klo, lane);
+  { // z = D^-1 y of the bush's columns
+    const gcd_t dv  = (gcd_t)B.dinv;
+    dbl2       *dst = reinterpret_cast<dbl2 *>(vec);
+    for (int i = tid; i < B.ncol * 8; i += 4 * WG_THREADS) {
+      dbl2 v[4], dd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int  j  = i + u * WG_THREADS;
+        const bool in = j < B.ncol * 8;
+        v[u]          = in ? ysrc[j] : dbl2{0.0, 0.0};
+        if constexpr (Z) dd[u] = (in && dv) ? *(gcd2_t)(dv + 2 * (long long)(B.c0 + (j >> 3))) : dbl2{1.0, 0.0};
+        else dd[u].x = dd[u].y = (in && dv) ? dv[B.c0 + (j >> 3)] : 1.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = i + u * WG_THREADS;
+        if (j >= B.ncol * 8) continue;
+        dbl2 z;
+        if constexpr (Z) z.x = dd[u].x * v[u].x - dd[u].y * v[u].y, z.y = dd[u].x * v[u].y + dd[u].y * v[u].x; // (re, im) of one right-hand side
+        else z.x = dd[u].x * v[u].x, z.y = dd[u].y * v[u].y;
+        dst[j] = z;
+      }
+    }
+  }
+  { // x below the root: the first two pieces of the thread through the rows requested above, the rest row by row
+    dbl2 *dst = reinterpret_cast<dbl2 *>(vec) + (size_t)B.ncol * 8;
+    dbl2  v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = tid + u * WG_THREADS < B.nbr * 8 ? xsrc[(long long)xr[u] * 8 + (tid & 7)] : dbl2{0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * WG_THREADS < B.nbr * 8) dst[tid + u * WG_THREADS] = v[u];
+    for (int i = tid + 2 * WG_THREADS; i < B.nbr * 8; i += WG_THREADS) dst[i] = xsrc[(long long)rsrc[i >> 3] * 8 + (i & 7)];
+  }
+  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 16 * nround, tid);
+  ci.finish(li, bints + B.int0, B.nlrow, tid);
+  __syncthreads();
+  for (int r = 0; r < nround; ++r) {
+    const TileRegs told = t;
+    if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave);
+    else t.sn = -1;
+    v4f64 aE = {0.0, 0.0, 0.0, 0.0}, aO = {0.0, 0.0, 0.0, 0.0};
+    if (told.sn >= 0) {
+      const double *z  = vec + (size_t)told.cj * C16;
+      const int    *lr = li + told.lrow;
+      const int     tw = told.w, th = told.K;
+      auto          bf = [&](int k) -> double { // v = [ z_J ; -x on the rows below J ]
+        if (k < tw) return z[k * C16 + nu];
+        return k < th ? -vec[(size_t)lr[k - tw] * C16 + nu] : 0.0;
+      };
+      const int klo[1] = {told.klo}, khi[1] = {told.khi};
+      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, told.klo, (told.khi + 3) & ~3, klo, khi, lane, bf, aE, aO);
+    }
+    bush_prime(ring, t, t.klo, lane);
+    __syncthreads(); // every tile of the supernode has read z_J
+    {
+      double *xb = x16 + (B.voff + told.gc0) * C16, *xl = vec + (size_t)told.cj * C16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = kq + 4 * reg;
+        if constexpr (Z) {
+          const int    col = (told.r0 >> 1) + p;
+          const double v   = combine16<true>(aE[reg], aO[reg], nu); // (every lane takes part in the swap)
+          if (told.sn >= 0 && col < told.w && 2 * p < told.nr) xb[(long long)col * C16 + nu] = v, xl[col * C16 + nu] = v;
+        } else {
+          const int col = told.r0 + 2 * p;
+          if (told.sn >= 0 && col < told.w && 2 * p < told.nr) xb[(long long)col * C16 + nu] = aE[reg], xl[col * C16 + nu] = aE[reg];
+          if (told.sn >= 0 && col + 1 < told.w && 2 * p + 1 < told.nr) xb[(long long)(col + 1) * C16 + nu] = aO[reg], xl[(col + 1) * C16 + nu] = aO[reg];
+        }
+      }
+    }
+    __syncthreads(); // x_J is in place for the rounds below
+  }
+}
+
 // right-hand side of the wide supernodes of a level, formed once: b_J <- b_J - (what the children handed up: the run of every column in
 // the compact hand-over), in place in the interleaved copy of b -- the wide forward tiles of this engine read it straight from the
 // vector, every row group of every tile.  A tile of the plan is 256 columns; a workgroup takes 16 of them, 16 threads (one line)
@@ -642,6 +933,18 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   hipLaunchKernelGGL((k_perm_in16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, b, P.b16.p, mu, k0);
   P.mark(0, s);
   const int lds_wave = 4 * KC * C16; // doubles: the four wavefronts' staging areas
+  if (P.nbush) { // the bushes: the bottom of the tree in one launch
+    static bool big_lds = false;
+    if (P.bush_lds > 48 * 1024 && !big_lds) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      big_lds = true;
+    }
+    hipLaunchKernelGGL((sptrsv16_bush_fwd_kernel<Z>), dim3(P.nbush), dim3(WG_THREADS), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.b16.p, P.y16.p, P.U16.p);
+    P.mark(2900, s);
+  }
   for (int l = 0; l < P.nlev; ++l) {
     const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = P.lev_end16[0][l] - P.lev_ptr16[0][l], ng = P.gat_end[l] - P.gat_ptr[l];
     if (ng) {
@@ -656,14 +959,33 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   }
   const int ldb = std::max(lds_wave, RCB * C16);
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = P.lev_end16[1][l] - P.lev_ptr16[1][l];
+    const int nb = P.lev_bwd16[l], nw = P.lev_end16[1][l] - P.lev_ptr16[1][l];
     const int nt = P.lev_team[1][l], grid = nb + nt + (nw - nt + 3) / 4;
     if (nb + nt) hipLaunchKernelGGL((sptrsv16_bwd_kernel<true, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p + P.lev_ptr[SolvePlan::BWD_BLOCK][l], nb, P.tiles.p + P.lev_ptr16[1][l], nt, P.wtd.p + P.lev_w16[1][l], nw - nt, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     else if (nw) hipLaunchKernelGGL((sptrsv16_bwd_kernel<false, Z>), dim3(grid), dim3(WG_THREADS), (size_t)ldb * sizeof(double), s, P.sn.p, P.tiles.p, 0, P.tiles.p + P.lev_ptr16[1][l], 0, P.wtd.p + P.lev_w16[1][l], nw, P.y16.p, P.x16.p, P.partials16.p, P.arrivals.p, P.max_parts);
     if (nb || nw) P.mark(3000 + l, s);
   }
+  if (P.nbush) {
+    hipLaunchKernelGGL((sptrsv16_bush_bwd_kernel<Z>), dim3(P.nbush), dim3(WG_THREADS), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.y16.p, P.x16.p);
+    P.mark(3900, s);
+  }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0, P.out_scale);
   P.mark(4000, s);
+#ifdef HPDDM_BUSH_CLOCK
+  if (P.nbush && getenv("HPDDM_BUSH_CLOCK_DUMP")) {
+    static int dumped = 0;
+    if (++dumped == 6) {
+      HIP_OK(hipStreamSynchronize(s));
+      static unsigned long long h[2][256][32];
+      HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bush_clk), sizeof(h)));
+      for (int b = 0; b < 256 && b * 37 < P.nbush; b += 8) {
+        fprintf(stderr, "bush %5d fwd (100 MHz ticks from start): desc %llu burst %llu |", b * 37, h[0][b][1] - h[0][b][0], h[0][b][2] - h[0][b][0]);
+        for (int q = 4; q < 32 && h[0][b][q]; ++q) fprintf(stderr, " %llu", h[0][b][q] - h[0][b][0]);
+        fprintf(stderr, " | rounds done %llu\n", h[0][b][3] - h[0][b][0]);
+      }
+    }
+  }
+#endif
 }
 
 void solve_block16(SolvePlan &P, const double *b, double *x, int mu, int k0, hipStream_t s)

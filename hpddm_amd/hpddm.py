@@ -115,7 +115,7 @@ class Subdomain:
         info = np.zeros(12, dtype=np.int64)
         times = np.zeros(4)
         check(self._lib.HpddmHipSubdomainInfo(self._h, _dptr(info), _dptr(times)))
-        keys = ("n", "supernodes", "levels", "nnz_L", "stored", "pool", "update_pool", "kind", "launches", "flops", "plain_export_us")
+        keys = ("n", "supernodes", "levels", "nnz_L", "stored", "pool", "update_pool", "kind", "launches", "flops", "plain_export_us", "bushes")
         out = {k: int(v) for k, v in zip(keys, info)}
         out.update(t_order=times[0], t_symbolic=times[1], t_numeric=times[2], t_upload=times[3])
         return out

@@ -113,3 +113,35 @@ def test_split_row_hand_over_is_bitwise_reproducible(mu):
         for a, b in zip(x, ref):
             assert np.array_equal(a, b), it
     A.destroy()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_bushes_match_the_level_launches_and_repeat_bitwise(cplx, monkeypatch):
+    """the bottom of the tree in one launch per direction (sptrsv16.hip, "bushes": the subtrees whose vectors fit the LDS of a workgroup)
+    against the level launches of the same engine (HPDDM_HIP_BUSH16=-1) and against SuperLU; the hand-over inside a bush is ordered
+    (supernode after supernode of a round): repeated solves are bitwise equal"""
+    n = 14
+    K = _laplace3d(n, n, n + 3) * float(n * n)
+    N = K.shape[0]
+    A = (K - 0.03 * sp.diags(K.diagonal()) + 0.03j * sp.diags(K.diagonal())).tocsr() if cplx else K
+    M = sp.tril(A, format="csr")
+    M.sort_indices()
+    rng = np.random.default_rng(3)
+    mu = 8 if cplx else 16
+    b = np.asfortranarray(rng.standard_normal((N, mu)) + (1j * rng.standard_normal((N, mu)) if cplx else 0.0))
+    xs, nb = [], []
+    for bush in ("3", "-1", "13"):
+        monkeypatch.setenv("HPDDM_HIP_BUSH16", bush)
+        S = hpddm.Subdomain()
+        S.numfact(N, M.indptr, M.indices, M.data.astype(np.complex128) if cplx else M.data, sym=True, spd=not cplx)
+        x = S.solve(b)
+        for _ in range(20):
+            assert np.array_equal(S.solve(b), x)
+        nb.append(S.info()["bushes"])
+        xs.append(x)
+        S.destroy()
+    assert nb[0] > 0 and nb[1] == 0 and nb[2] > 0 and nb[2] <= nb[0], nb   # taller bushes are fewer
+    ref = spl.splu(A.tocsc().astype(np.complex128 if cplx else np.float64)).solve(np.asarray(b))
+    for x in xs:
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-12 * np.abs(ref).max() and np.abs(xs[2] - xs[1]).max() <= 1e-12 * np.abs(ref).max()
