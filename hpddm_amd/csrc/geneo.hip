@@ -216,6 +216,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   {
     std::lock_guard<std::mutex> lk(opt_mutex);
     optc = opt;
+    if (s >= 0 && s < nsub) subs[s].gevp_kept = 0; // (a new eigenproblem of this subdomain: what its last one kept no longer counts)
   }
   auto getopt = [&optc](const std::string &k, double def) {
     auto it = optc.find(k);
@@ -503,9 +504,9 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   {
     std::lock_guard<std::mutex> lk(opt_mutex);
     opt["geneo_nu_requested"] = nu_req;
+    S.gevp_kept = keep;
     int most = keep;
-    for (int t = 0; t < nsub; ++t)
-      if (t != s) most = std::max(most, (int)subs[t].eigenvalues.size()); // (what the eigenproblems of the other subdomains kept)
+    for (int t = 0; t < nsub; ++t) most = std::max(most, subs[t].gevp_kept); // (what the eigenproblems of the other subdomains kept: counters under this mutex, not the vectors they are still filling)
     opt["geneo_nu"] = most;
   }
   S.Z.assign(X.begin(), X.begin() + (size_t)keep * n);
@@ -654,6 +655,7 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   {
     std::lock_guard<std::mutex> lk(opt_mutex);
     optc = opt;
+    if (s >= 0 && s < nsub) subs[s].gevp_kept = 0; // (a new eigenproblem of this subdomain: what its last one kept no longer counts)
   }
   auto getopt = [&optc](const std::string &k, double def) {
     auto it = optc.find(k);
@@ -912,9 +914,9 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
   {
     std::lock_guard<std::mutex> lk(opt_mutex); // (the request stays aside, the option reads the largest number kept: see solve_gevp)
     opt["geneo_nu_requested"] = nu_req;
+    S.gevp_kept = keep;
     int most = keep;
-    for (int t = 0; t < nsub; ++t)
-      if (t != s) most = std::max(most, (int)subs[t].eigenvalues.size());
+    for (int t = 0; t < nsub; ++t) most = std::max(most, subs[t].gevp_kept);
     opt["geneo_nu"] = most;
   }
   S.eigenvalues.resize(keep), S.eigenvalues_im.resize(keep);

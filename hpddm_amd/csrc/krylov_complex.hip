@@ -1764,7 +1764,11 @@ int zbcg_impl(Schwarz &A, const double *b, double *x, double *history, int histo
     if (history && nhist < history_cap) history[nhist] = pt;
     ++nhist;
     if (verbosity > 2) printf("BCG: %3d %e %e %e < %e\n", i, pt, norm[0], pt / norm[0], tol);
-    if ((tol > 0.0 && pt / norm[0] <= tol) || (tol < 0.0 && pt <= -tol)) break;
+    if (A.getopt("hip_bcg_all_columns", 0) != 0) { // (this library's option: every right-hand side against its own norm, bgmres.hip)
+      bool all = true;
+      for (int nu = 0; nu < mu; ++nu) all = all && ((tol > 0.0 && std::sqrt(zz[nu]) / norm[nu] <= tol) || (tol < 0.0 && std::sqrt(zz[nu]) <= -tol));
+      if (all) break;
+    } else if ((tol > 0.0 && pt / norm[0] <= tol) || (tol < 0.0 && pt <= -tol)) break;
     if (++i <= max_it) {
       rho2 = rhs;                            // the new rho, kept for the next iteration
       if (!zchol_upper(mu, mu, rho, U)) return -2; // zposv: rhs <- rho_old^{-1} rho_new

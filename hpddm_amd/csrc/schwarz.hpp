@@ -45,6 +45,7 @@ struct SchwarzSub {
   std::vector<double> eigenvalues; // GenEO: the nu lowest eigenvalues of (A_N, B) (complex operators: their real parts, eigenvalues_im beside)
   std::vector<double> eigenvalues_im;
   int                 gevp_iterations = 0;
+  int                 gevp_kept = 0; // vectors its last eigenproblem kept; written and read under Schwarz::opt_mutex (two eigenproblems may be in flight)
   std::unique_ptr<LocalSolver> ls;
   // complex128 operators (Schwarz::is_complex): everything above is the real-equivalent embedding, n = 2 x (complex rows) -- the
   // layout of std::complex<double> vectors; the LOCAL SOLVER gets the complex matrix itself (native complex panels, half the

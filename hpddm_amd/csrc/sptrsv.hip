@@ -624,6 +624,9 @@ __device__ static inline void fwd_leaf_tile(const A &a, int lane, double *lds, i
   dbl2 cur[FP];
   ptv_prime<FP, LW>(a.WT(), ld, w, lane, cur);
   typedef const unsigned __attribute__((address_space(1))) *gcu32_t;
+  // (one 32-bit load of the pair srptr[i0], srptr[i0 + 1]: 2-byte aligned for odd i0 -- global loads of this target take unaligned
+  // addresses (the runtime runs the memory pipeline in its unaligned mode) --; i0 <= nb - 1 keeps the pair inside the nb + 1 pointers,
+  // and with nb = 0 the second half is scptr[0], the next section of the same blob: leaf_blob_layout, factor.hpp)
   unsigned praw = *(gcu32_t)(a.srptr() + i0);
   int      pos0 = a.rel()[i0];
   if (lane < w) {
@@ -1508,8 +1511,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
           first[k] = k;
           ok[k]    = D.ldw[k] * cs <= NARROW && D.height[k] <= hcut && D.ft_off[k] >= 0;
           sumnb[k] = D.row_ptr[k + 1] - D.row_ptr[k];
-          ntf[k]   = (h + 31) / 32;
-          rb[k]    = (D.ldw[k] * cs + 31) / 32;
+          ntf[k]   = (h + 63) / 64;
+          rb[k]    = (D.ldw[k] * cs + 63) / 64;
         }
         for (idx_t k = 0; k < nblk; ++k) {
           const idx_t p = S.parent[k];
@@ -1570,13 +1573,14 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
               if (D.height[j] != l) continue;
               const int w = D.blk_ptr[j + 1] - D.blk_ptr[j], h = hgt(j), wc = w * cs, tg = D.tgs.empty() ? 0 : D.tgs[j];
               cost += (long long)h * D.ldw[j] * cs;
-              for (int r0 = 0; r0 < h; r0 += 32) {
+              auto klim = [&](int last) { return last < w ? (int)std::min<long long>(wc, (long long)cs * ((((long long)last >> tg) + 1) << tg)) : wc; }; // rows of the top block stop at their diagonal entry (tile)
+              for (int r0 = 0; r0 < h; r0 += 64) {
                 BushTile16 t = rec(j);
-                const int  re = std::min(r0 + 32, h);
+                const int  re = std::min(r0 + 64, h);
                 t.P = D.FT.p + D.ft_off[j] + r0, t.ld = D.ldh[j], t.K = wc;
                 t.mlim = std::min((re - r0 + 1) & ~1, (int)D.ldh[j] - r0);
-                t.klo  = 0;
-                t.khi  = re - 1 < w ? std::min<long long>(wc, (long long)cs * ((((long long)(re - 1) >> tg) + 1) << tg)) : wc;
+                t.klo  = klim(std::min(r0 + 32, re) - 1);      // forward: the k ranges of the two chunks of 32 rows end here (device: tile_lim)
+                t.khi  = re > r0 + 32 ? klim(re - 1) : 0;
                 t.r0 = r0, t.nr = re - r0;
                 bt.push_back(t);
                 inround = (inround + 1) & 3;
@@ -1604,18 +1608,18 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
             int inround = 0;
             for (idx_t j = k; j >= k0; --j) {
               if (D.height[j] != l) continue;
-              const int h = hgt(j), ldw = D.ldw[j] * cs, nt = (ldw + 31) / 32;
+              const int h = hgt(j), ldw = D.ldw[j] * cs, nt = (ldw + 63) / 64;
               if (inround + nt > 4) {
                 for (; inround < 4; ++inround) bt.push_back(none);
                 inround = 0;
               }
-              for (int m0 = 0; m0 < ldw; m0 += 32) {
+              for (int m0 = 0; m0 < ldw; m0 += 64) {
                 BushTile16 t = rec(j);
                 t.P = (D.kind == FACT_LU ? D.G.p : D.F.p) + D.f_off[j] * cs + m0, t.ld = ldw, t.K = h;
                 t.mlim = ldw - m0;
-                t.klo  = ((m0 / cs) / 4) * 4;
-                t.khi  = h;
-                t.r0 = m0, t.nr = std::min(32, ldw - m0);
+                t.klo  = ((m0 / cs) / 4) * 4;                                  // backward: the k ranges of the two chunks of 32 doubles start here (rows above hold zeros in these columns)
+                t.khi  = ldw - m0 > 32 ? (((m0 + 32) / cs) / 4) * 4 : -1;
+                t.r0 = m0, t.nr = std::min(64, ldw - m0);
                 bt.push_back(t);
                 ++inround;
               }
@@ -1625,6 +1629,19 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
               for (; inround < 4; ++inround) bt.push_back(none);
           }
           B.nround[1] = ((int)bt.size() - B.tile0[1]) / 4;
+          // barriers of a backward round (pad, the same in its four records): bit 0 = two tiles of one supernode share the round (both
+          // read z_J before x_J takes its place), bit 1 = the next round is another level (it reads x_J), or there is none
+          {
+            auto lev_of = [&](const BushTile16 *q) { for (int u = 0; u < 4; ++u) if (q[u].sn >= 0) return (int)D.height[q[u].sn - snbase]; return -1; };
+            for (int r = 0; r < B.nround[1]; ++r) {
+              BushTile16 *q = bt.data() + B.tile0[1] + 4 * r;
+              int         flags = 0;
+              for (int u = 0; u + 1 < 4; ++u)
+                if (q[u].sn >= 0 && q[u].sn == q[u + 1].sn) flags |= 1;
+              if (r + 1 == B.nround[1] || lev_of(q) != lev_of(q + 4)) flags |= 2;
+              for (int u = 0; u < 4; ++u) q[u].pad = flags;
+            }
+          }
           const int lds = (ncol + nbr) * 128 + 4 * std::max(B.nround[0], B.nround[1]) * (int)sizeof(BushTile16) + (B.nlrow + 2 * nbr) * 4;
           HH_CHECK(lds <= budget, "plan: a bush outgrew its LDS estimate");
           bush_lds = std::max(bush_lds, (lds + 255) / 256 * 256);

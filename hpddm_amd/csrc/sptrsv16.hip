@@ -679,9 +679,10 @@ struct Copy4 {
     for (int i = tid + NB * WG_THREADS; i < n; i += WG_THREADS) dst[i] = src[i];
   }
 };
-// the product of one tile: rows [k0, k1) of P (k0, k1 multiples of 4) against B, row k of B = bf(k) for this lane's column
+// the product of one tile -- two chunks of 32 outputs, one read of the B operand for both: rows [k0, k1) of P (k0, k1 multiples of 4)
+// against B, row k of B = bf(k) for this lane's column
 template <int PF, class BF>
-__device__ static inline void bush_steps(dbl2 (&ring)[PF][1], gcd_t P, int ld, int K, int mlim, int k0, int k1, const int (&klo)[1], const int (&khi)[1], int lane, BF bf, v4f64 &aE, v4f64 &aO)
+__device__ static inline void bush_steps(dbl2 (&ring)[PF][2], gcd_t P, int ld, int K, int mlim, int k0, int k1, const int (&klo)[2], const int (&khi)[2], int lane, BF bf, v4f64 (&aE)[2], v4f64 (&aO)[2])
 {
   const int kq = lane >> 4;
   for (int ks = k0; ks < k1; ks += 4 * PF) {
@@ -690,27 +691,48 @@ __device__ static inline void bush_steps(dbl2 (&ring)[PF][1], gcd_t P, int ld, i
       const int kk = ks + 4 * u;
       if (kk < k1) { // wave-uniform
         const double b = bf(kk + kq);
-        if (kk + 4 > klo[0] && kk < khi[0]) {
-          aE = mfma16(ring[u][0].x, b, aE);
-          aO = mfma16(ring[u][0].y, b, aO);
-        }
-        if (kk + 4 * PF < k1) wave_pipe_fetch<1>(ring[u], P, ld, K, mlim, kk + 4 * PF, k1, klo, khi, lane);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (kk + 4 > klo[c] && kk < khi[c]) {
+            aE[c] = mfma16(ring[u][c].x, b, aE[c]);
+            aO[c] = mfma16(ring[u][c].y, b, aO[c]);
+          }
+        if (kk + 4 * PF < k1) wave_pipe_fetch<2>(ring[u], P, ld, K, mlim, kk + 4 * PF, k1, klo, khi, lane);
       }
     }
   }
 }
-constexpr int BUSH_PF = 8;
+constexpr int BUSH_PF = 4;
 #ifdef HPDDM_BUSH_CLOCK // developer build (-DHPDDM_BUSH_CLOCK): thread 0 of every 37th bush records wall_clock64 (100 MHz) after its descriptor, after the burst, after the product and after the hand-over of every round; HPDDM_BUSH_CLOCK_DUMP=1 prints them at the 6th solve (profiles/r06_bush_clocks.txt)
 __device__ unsigned long long g_bush_clk[2][256][32];
 #define BCLK(dir, slot) do { if (blockIdx.x % 37 == 0 && blockIdx.x / 37 < 256 && threadIdx.x == 0 && (slot) < 32) g_bush_clk[dir][blockIdx.x / 37][slot] = wall_clock64(); } while (0)
 #else
 #define BCLK(dir, slot) do { } while (0)
 #endif
-__device__ static inline void bush_prime(dbl2 (&ring)[BUSH_PF][1], const TileRegs &t, int k0, int lane)
+// the k ranges of the two chunks of a tile (BushTile16::klo, khi: forward = last k + 1 of chunk 0, of chunk 1 (0: no such chunk), every
+// chunk starts at 0; backward = first k of chunk 0, of chunk 1 (-1: no such chunk), every chunk ends at K)
+struct TileLim {
+  int klo[2], khi[2], k0, k1;
+};
+template <bool FWD>
+__device__ static inline TileLim tile_lim(const TileRegs &t)
+{
+  TileLim L;
+  if constexpr (FWD) {
+    L.klo[0] = L.klo[1] = 0, L.khi[0] = t.klo, L.khi[1] = t.khi;
+    L.k0 = 0, L.k1 = (max(t.klo, t.khi) + 3) & ~3;
+  } else {
+    L.klo[0] = t.klo, L.klo[1] = max(t.khi, 0), L.khi[0] = t.K, L.khi[1] = t.khi >= 0 ? t.K : 0;
+    L.k0 = t.klo, L.k1 = (t.K + 3) & ~3;
+  }
+  return L;
+}
+template <bool FWD>
+__device__ static inline void bush_prime(dbl2 (&ring)[BUSH_PF][2], const TileRegs &t, int lane)
 {
   if (t.sn < 0) return;
-  const int klo[1] = {t.klo}, khi[1] = {t.khi};
-  wave_pipe_prime<1, BUSH_PF>(ring, t.P, t.ld, t.K, t.mlim, k0, (t.khi + 3) & ~3, klo, khi, lane);
+  const TileLim L = tile_lim<FWD>(t);
+  wave_pipe_prime<2, BUSH_PF>(ring, t.P, t.ld, t.K, t.mlim, L.k0, L.k1, L.klo, L.khi, lane);
 }
 
 template <bool Z>
@@ -737,8 +759,8 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
   ct.request(tsrc, 16 * nround, tid);
   ci.request(bints + B.int0, B.nlrow + B.nbr, tid);
   TileRegs t = tile_regs_global(btiles + B.tile0[0] + wave);
-  dbl2     ring[BUSH_PF][1];
-  bush_prime(ring, t, 0, lane);
+  dbl2     ring[BUSH_PF][2];
+  bush_prime<true>(ring, t, lane);
   cb.finish(reinterpret_cast<dbl2 *>(vec), bsrc, B.ncol * 8, tid);
   for (int i = B.ncol * 8 + tid; i < nlines * 8; i += WG_THREADS) reinterpret_cast<dbl2 *>(vec)[i] = dbl2{0.0, 0.0};
   ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 16 * nround, tid);
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
     const TileRegs told = t;
     if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave); // the tile of the next round
     else t.sn = -1;
-    v4f64     aE = {0.0, 0.0, 0.0, 0.0}, aO = {0.0, 0.0, 0.0, 0.0};
+    v4f64     aE[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}}, aO[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}};
     const int re = told.r0 + told.nr;
     if (told.sn >= 0) {
       const double *f  = vec + (size_t)told.cj * C16;
@@ -762,30 +784,34 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
           return (k & 1) ? ((nu & 1) ? v : -v) : v;
         }
       };
-      const int klo[1] = {0}, khi[1] = {told.khi};
-      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, 0, (told.khi + 3) & ~3, klo, khi, lane, bf, aE, aO);
+      const TileLim L = tile_lim<true>(told);
+      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, L.k0, L.k1, L.klo, L.khi, lane, bf, aE, aO);
     }
-    bush_prime(ring, t, 0, lane); // the first panel rows of the next tile are on their way during the hand-over of this one
+    bush_prime<true>(ring, t, lane); // the first panel rows of the next tile are on their way during the hand-over of this one
     BCLK(0, 4 + 2 * r);
     if (told.sn >= 0) {
       double *yb = y16 + (B.voff + told.gc0) * C16;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) { // rows of the top block: y
-        const int rr = told.r0 + 2 * (kq + 4 * reg);
-        if (rr < re && rr < told.w) yb[(long long)rr * C16 + nu] = aE[reg];
-        if (rr + 1 < re && rr + 1 < told.w) yb[(long long)(rr + 1) * C16 + nu] = aO[reg];
-      }
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { // rows of the top block: y
+          const int rr = told.r0 + 32 * c + 2 * (kq + 4 * reg);
+          if (rr < re && rr < told.w) yb[(long long)rr * C16 + nu] = aE[c][reg];
+          if (rr + 1 < re && rr + 1 < told.w) yb[(long long)(rr + 1) * C16 + nu] = aO[c][reg];
+        }
     }
     // rows below the supernode: subtracted from the lines they belong to, the supernodes of the round one after the other (a fixed order)
     const int nph = told.ph >> 8, myph = told.ph & 255; // (nph: the same for the four tiles of the round)
     for (int ph = 0; ph < nph; ++ph) {
       if (myph == ph) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int rr = told.r0 + 2 * (kq + 4 * reg);
-          if (rr < re && rr >= told.w) vec[(size_t)li[told.lrow + rr - told.w] * C16 + nu] -= aE[reg];
-          if (rr + 1 < re && rr + 1 >= told.w) vec[(size_t)li[told.lrow + rr + 1 - told.w] * C16 + nu] -= aO[reg];
-        }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int rr = told.r0 + 32 * c + 2 * (kq + 4 * reg);
+            if (rr < re && rr >= told.w) vec[(size_t)li[told.lrow + rr - told.w] * C16 + nu] -= aE[c][reg];
+            if (rr + 1 < re && rr + 1 >= told.w) vec[(size_t)li[told.lrow + rr + 1 - told.w] * C16 + nu] -= aO[c][reg];
+          }
       }
       __syncthreads();
     }
@@ -797,7 +823,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
 }
 
 template <bool Z>
-__global__ __launch_bounds__(WG_THREADS) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
+__global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const Bush16 B      = bushes[blockIdx.x];
@@ -819,8 +845,8 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bush_bwd_kernel(const Bus
   ct.request(tsrc, 16 * nround, tid);
   ci.request(bints + B.int0, B.nlrow, tid);
   TileRegs t = tile_regs_global(btiles + B.tile0[1] + wave);
-  dbl2     ring[BUSH_PF][1];
-  bush_prime(ring, t, t.klo, lane);
+  dbl2     ring[BUSH_PF][2];
+  bush_prime<false>(ring, t, lane);
   { // z = D^-1 y of the bush's columns
     const gcd_t dv  = (gcd_t)B.dinv;
     dbl2       *dst = reinterpret_cast<dbl2 *>(vec);
@@ -862,7 +888,7 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bush_bwd_kernel(const Bus
     const TileRegs told = t;
     if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave);
     else t.sn = -1;
-    v4f64 aE = {0.0, 0.0, 0.0, 0.0}, aO = {0.0, 0.0, 0.0, 0.0};
+    v4f64 aE[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}}, aO[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}};
     if (told.sn >= 0) {
       const double *z  = vec + (size_t)told.cj * C16;
       const int    *lr = li + told.lrow;
@@ -871,28 +897,30 @@ __global__ __launch_bounds__(WG_THREADS) void sptrsv16_bush_bwd_kernel(const Bus
         if (k < tw) return z[k * C16 + nu];
         return k < th ? -vec[(size_t)lr[k - tw] * C16 + nu] : 0.0;
       };
-      const int klo[1] = {told.klo}, khi[1] = {told.khi};
-      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, told.klo, (told.khi + 3) & ~3, klo, khi, lane, bf, aE, aO);
+      const TileLim L = tile_lim<false>(told);
+      bush_steps<BUSH_PF>(ring, told.P, told.ld, told.K, told.mlim, L.k0, L.k1, L.klo, L.khi, lane, bf, aE, aO);
     }
-    bush_prime(ring, t, t.klo, lane);
-    __syncthreads(); // every tile of the supernode has read z_J
+    bush_prime<false>(ring, t, lane);
+    if (told.ph & 1) __syncthreads(); // two tiles of one supernode in this round (the same flag in its four records): both have read z_J before x_J takes its place
     {
       double *xb = x16 + (B.voff + told.gc0) * C16, *xl = vec + (size_t)told.cj * C16;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int p = kq + 4 * reg;
-        if constexpr (Z) {
-          const int    col = (told.r0 >> 1) + p;
-          const double v   = combine16<true>(aE[reg], aO[reg], nu); // (every lane takes part in the swap)
-          if (told.sn >= 0 && col < told.w && 2 * p < told.nr) xb[(long long)col * C16 + nu] = v, xl[col * C16 + nu] = v;
-        } else {
-          const int col = told.r0 + 2 * p;
-          if (told.sn >= 0 && col < told.w && 2 * p < told.nr) xb[(long long)col * C16 + nu] = aE[reg], xl[col * C16 + nu] = aE[reg];
-          if (told.sn >= 0 && col + 1 < told.w && 2 * p + 1 < told.nr) xb[(long long)(col + 1) * C16 + nu] = aO[reg], xl[(col + 1) * C16 + nu] = aO[reg];
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int p = kq + 4 * reg, m = 32 * c + 2 * p; // this lane's pair of doubles of the tile
+          if constexpr (Z) {
+            const int    col = ((told.r0 + 32 * c) >> 1) + p;
+            const double v   = combine16<true>(aE[c][reg], aO[c][reg], nu); // (every lane takes part in the swap)
+            if (told.sn >= 0 && col < told.w && m < told.nr) xb[(long long)col * C16 + nu] = v, xl[col * C16 + nu] = v;
+          } else {
+            const int col = told.r0 + m;
+            if (told.sn >= 0 && col < told.w && m < told.nr) xb[(long long)col * C16 + nu] = aE[c][reg], xl[col * C16 + nu] = aE[c][reg];
+            if (told.sn >= 0 && col + 1 < told.w && m + 1 < told.nr) xb[(long long)(col + 1) * C16 + nu] = aO[c][reg], xl[(col + 1) * C16 + nu] = aO[c][reg];
+          }
         }
-      }
     }
-    __syncthreads(); // x_J is in place for the rounds below
+    if (told.ph & 2) __syncthreads(); // the next round is a level further down: x_J is in place for it
   }
 }
 
