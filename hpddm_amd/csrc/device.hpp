@@ -191,7 +191,7 @@ struct SolvePlan {
   DevBuf<Bush16>     bush;
   DevBuf<BushTile16> bush_tile;
   DevBuf<int>        bush_int;
-  int                nbush = 0, bush_lds = 0; // ... and the LDS bytes of the largest
+  int                nbush = 0, bush_lds = 0, bush_nw = 4; // ... the LDS bytes of the largest, the wavefronts (= tiles per round) of a bush
   std::vector<int>   lev_bwd16;               // per level: the BWD_BLOCK tiles the 16-column engine takes (those of the bushes' supernodes sit behind them)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;

@@ -1488,7 +1488,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   std::vector<std::vector<char>> in_bush(fs.size());
   {
     const int       hcut   = envi("HPDDM_HIP_BUSH16", 3), bush_min = envi("HPDDM_HIP_BUSH_MIN", 1);
-    const long long budget = (long long)std::max(8, std::min(160, envi("HPDDM_HIP_BUSH_LDS", 40))) * 1024; // (40 KB = four workgroups per CU, what their registers allow: 64 KB measured 5 % slower, 128 KB 45 %, profiles/r06_engine16_bushes.txt)
+    const int       NW     = envi("HPDDM_HIP_BUSH_WAVES", 4) >= 16 ? 16 : (envi("HPDDM_HIP_BUSH_WAVES", 4) >= 8 ? 8 : 4); // wavefronts per bush = tiles per round
+    bush_nw                = NW;
+    const long long budget = (long long)std::max(8, std::min(160, envi("HPDDM_HIP_BUSH_LDS", 10 * NW))) * 1024; // (10 KB per wavefront = 16 wavefronts per CU, what their registers allow: with 4 wavefronts per bush 64 KB measured 5 % slower than 40, 128 KB 45 %, profiles/r06_engine16_bushes.txt)
     std::vector<Bush16>     bs;
     std::vector<BushTile16> bt;
     std::vector<int>        bi;
@@ -1523,7 +1525,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         }
         auto need = [&](idx_t k) { // LDS bytes (upper bound: every round of the tile table full but one per level)
           const long long lines = (D.blk_ptr[k + 1] - D.blk_ptr[first[k]]) + (D.row_ptr[k + 1] - D.row_ptr[k]);
-          const long long tiles = std::max(ntf[k] + 4 * (D.height[k] + 1), 4 * (long long)cnt[k]);
+          const long long tiles = std::max(ntf[k] + NW * (long long)(D.height[k] + 1), std::max(rb[k] + NW * (long long)(D.height[k] + 1), 2 * (long long)cnt[k] + NW * (long long)(D.height[k] + 1)));
           return lines * 128 + tiles * (long long)sizeof(BushTile16) + (sumnb[k] + 2 * (D.row_ptr[k + 1] - D.row_ptr[k])) * 4 + 64;
         };
         auto elig = [&](idx_t k) { return ok[k] && cnt[k] == k - first[k] + 1 && cnt[k] >= bush_min && need(k) <= budget; };
@@ -1583,24 +1585,42 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
                 t.khi  = re > r0 + 32 ? klim(re - 1) : 0;
                 t.r0 = r0, t.nr = re - r0;
                 bt.push_back(t);
-                inround = (inround + 1) & 3;
+                inround = (inround + 1) % NW;
               }
             }
-            for (; inround & 3; ++inround) bt.push_back(none);
+            for (; inround % NW; ++inround) bt.push_back(none);
           }
-          B.nround[0] = ((int)bt.size() - B.tile0[0]) / 4;
-          // the hand-over of a round, phase by phase: the tiles of ONE supernode write different lines and go together, supernode after
-          // supernode in the order of the round (pad = phase | phases of the round << 8; tiles without rows below take no part)
-          for (int r = 0; r < B.nround[0]; ++r) {
-            BushTile16 *q = bt.data() + B.tile0[0] + 4 * r;
-            int         nph = 0, last = -1;
-            for (int u = 0; u < 4; ++u) {
-              q[u].pad = 255;
-              if (q[u].sn < 0 || q[u].r0 + q[u].nr <= q[u].w) continue;
-              if (q[u].sn != last) last = q[u].sn, ++nph;
-              q[u].pad = nph - 1;
+          B.nround[0] = ((int)bt.size() - B.tile0[0]) / NW;
+          // the hand-over of a round, phase by phase: tiles that write different lines go together -- the tiles of ONE supernode always do,
+          // and so do supernodes whose rows below share no line (greedy, in the order of the round: a fixed order of the sums into every
+          // line) -- (pad = phase | phases of the round << 8; tiles without rows below take no part)
+          {
+            std::vector<int>                rnd((size_t)(ncol + nbr), -1); // line -> the round its mask belongs to
+            std::vector<unsigned long long> mask((size_t)(ncol + nbr), 0);  // line -> the phases of that round that write it
+            for (int r = 0; r < B.nround[0]; ++r) {
+              BushTile16 *q = bt.data() + B.tile0[0] + (size_t)NW * r;
+              int         nph = 0;
+              for (int u = 0; u < NW; ++u) q[u].pad = 255;
+              for (int u = 0; u < NW; ++u) {
+                if (q[u].sn < 0 || q[u].r0 + q[u].nr <= q[u].w || q[u].pad != 255) continue;
+                const int         *lr   = bi.data() + B.int0 + q[u].lrow;
+                unsigned long long used = 0; // phases that already write one of this supernode's lines
+                for (int i2 = 0; i2 < q[u].nb; ++i2)
+                  if (rnd[(size_t)lr[i2]] == r) used |= mask[(size_t)lr[i2]];
+                int ph = 0;
+                while (ph < 63 && ((used >> ph) & 1ull)) ++ph; // the first phase none of whose writers touches a line of this supernode
+                HH_CHECK(ph < 63, "plan: too many hand-over phases in a round of a bush");
+                for (int i2 = 0; i2 < q[u].nb; ++i2) {
+                  if (rnd[(size_t)lr[i2]] != r) rnd[(size_t)lr[i2]] = r, mask[(size_t)lr[i2]] = 0;
+                  mask[(size_t)lr[i2]] |= 1ull << ph;
+                }
+                nph = std::max(nph, ph + 1);
+                for (int v2 = u; v2 < NW; ++v2)
+                  if (q[v2].sn == q[u].sn && q[v2].r0 + q[v2].nr > q[v2].w) q[v2].pad = ph;
+              }
+              HH_CHECK(nph < 255, "plan: too many hand-over phases in a round of a bush");
+              for (int u = 0; u < NW; ++u) q[u].pad |= nph << 8;
             }
-            for (int u = 0; u < 4; ++u) q[u].pad |= nph << 8;
           }
           // backward: levels top-down, 32 doubles of every row per tile, the tiles of a supernode (<= 4) inside ONE round: x_J takes the place of z_J
           B.tile0[1] = (int)bt.size();
@@ -1609,8 +1629,8 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
             for (idx_t j = k; j >= k0; --j) {
               if (D.height[j] != l) continue;
               const int h = hgt(j), ldw = D.ldw[j] * cs, nt = (ldw + 63) / 64;
-              if (inround + nt > 4) {
-                for (; inround < 4; ++inround) bt.push_back(none);
+              if (inround + nt > NW) {
+                for (; inround < NW; ++inround) bt.push_back(none);
                 inround = 0;
               }
               for (int m0 = 0; m0 < ldw; m0 += 64) {
@@ -1623,26 +1643,26 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
                 bt.push_back(t);
                 ++inround;
               }
-              if (inround == 4) inround = 0;
+              if (inround == NW) inround = 0;
             }
             if (inround)
-              for (; inround < 4; ++inround) bt.push_back(none);
+              for (; inround < NW; ++inround) bt.push_back(none);
           }
-          B.nround[1] = ((int)bt.size() - B.tile0[1]) / 4;
+          B.nround[1] = ((int)bt.size() - B.tile0[1]) / NW;
           // barriers of a backward round (pad, the same in its four records): bit 0 = two tiles of one supernode share the round (both
           // read z_J before x_J takes its place), bit 1 = the next round is another level (it reads x_J), or there is none
           {
-            auto lev_of = [&](const BushTile16 *q) { for (int u = 0; u < 4; ++u) if (q[u].sn >= 0) return (int)D.height[q[u].sn - snbase]; return -1; };
+            auto lev_of = [&](const BushTile16 *q) { for (int u = 0; u < NW; ++u) if (q[u].sn >= 0) return (int)D.height[q[u].sn - snbase]; return -1; };
             for (int r = 0; r < B.nround[1]; ++r) {
-              BushTile16 *q = bt.data() + B.tile0[1] + 4 * r;
+              BushTile16 *q = bt.data() + B.tile0[1] + (size_t)NW * r;
               int         flags = 0;
-              for (int u = 0; u + 1 < 4; ++u)
+              for (int u = 0; u + 1 < NW; ++u)
                 if (q[u].sn >= 0 && q[u].sn == q[u + 1].sn) flags |= 1;
-              if (r + 1 == B.nround[1] || lev_of(q) != lev_of(q + 4)) flags |= 2;
-              for (int u = 0; u < 4; ++u) q[u].pad = flags;
+              if (r + 1 == B.nround[1] || lev_of(q) != lev_of(q + NW)) flags |= 2;
+              for (int u = 0; u < NW; ++u) q[u].pad = flags;
             }
           }
-          const int lds = (ncol + nbr) * 128 + 4 * std::max(B.nround[0], B.nround[1]) * (int)sizeof(BushTile16) + (B.nlrow + 2 * nbr) * 4;
+          const int lds = (ncol + nbr) * 128 + NW * std::max(B.nround[0], B.nround[1]) * (int)sizeof(BushTile16) + (B.nlrow + 2 * nbr) * 4;
           HH_CHECK(lds <= budget, "plan: a bush outgrew its LDS estimate");
           bush_lds = std::max(bush_lds, (lds + 255) / 256 * 256);
           bs.push_back(B);

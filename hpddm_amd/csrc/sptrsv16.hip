@@ -640,43 +640,43 @@ __device__ static inline TileRegs tile_regs_global(const BushTile16 *t) // the s
 }
 // n 16-byte pieces (4-byte: lds_copy4) from HBM to LDS in two halves -- request the first NB pieces of the thread, keep them in registers;
 // later: write them to LDS and move the rest, four at a time -- so that the first requests of SEVERAL copies leave together
-template <int NB>
+template <int NB, int NT>
 struct Copy16 {
   dbl2 v[NB];
   __device__ inline void request(gcd2_t src, int n, int tid)
   {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) v[u] = tid + u * WG_THREADS < n ? src[tid + u * WG_THREADS] : dbl2{0.0, 0.0};
+    for (int u = 0; u < NB; ++u) v[u] = tid + u * NT < n ? src[tid + u * NT] : dbl2{0.0, 0.0};
   }
   __device__ inline void finish(dbl2 *dst, gcd2_t src, int n, int tid)
   {
 #pragma unroll
     for (int u = 0; u < NB; ++u)
-      if (tid + u * WG_THREADS < n) dst[tid + u * WG_THREADS] = v[u];
-    for (int i = tid + NB * WG_THREADS; i < n; i += 4 * WG_THREADS) {
+      if (tid + u * NT < n) dst[tid + u * NT] = v[u];
+    for (int i = tid + NB * NT; i < n; i += 4 * NT) {
       dbl2 q[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = i + u * WG_THREADS < n ? src[i + u * WG_THREADS] : dbl2{0.0, 0.0};
+      for (int u = 0; u < 4; ++u) q[u] = i + u * NT < n ? src[i + u * NT] : dbl2{0.0, 0.0};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (i + u * WG_THREADS < n) dst[i + u * WG_THREADS] = q[u];
+        if (i + u * NT < n) dst[i + u * NT] = q[u];
     }
   }
 };
-template <int NB>
+template <int NB, int NT>
 struct Copy4 {
   int v[NB];
   __device__ inline void request(const int *src, int n, int tid)
   {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) v[u] = tid + u * WG_THREADS < n ? src[tid + u * WG_THREADS] : 0;
+    for (int u = 0; u < NB; ++u) v[u] = tid + u * NT < n ? src[tid + u * NT] : 0;
   }
   __device__ inline void finish(int *dst, const int *src, int n, int tid)
   {
 #pragma unroll
     for (int u = 0; u < NB; ++u)
-      if (tid + u * WG_THREADS < n) dst[tid + u * WG_THREADS] = v[u];
-    for (int i = tid + NB * WG_THREADS; i < n; i += WG_THREADS) dst[i] = src[i];
+      if (tid + u * NT < n) dst[tid + u * NT] = v[u];
+    for (int i = tid + NB * NT; i < n; i += NT) dst[i] = src[i];
   }
 };
 // the product of one tile -- two chunks of 32 outputs, one read of the B operand for both: rows [k0, k1) of P (k0, k1 multiples of 4)
@@ -735,9 +735,10 @@ __device__ static inline void bush_prime(dbl2 (&ring)[BUSH_PF][2], const TileReg
   wave_pipe_prime<2, BUSH_PF>(ring, t.P, t.ld, t.K, t.mlim, L.k0, L.k1, L.klo, L.khi, lane);
 }
 
-template <bool Z>
-__global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16)
+template <bool Z, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void sptrsv16_bush_fwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16)
 {
+  constexpr int NT = 64 * NW; // threads of the workgroup: one bush, NW tiles per round
   extern __shared__ __attribute__((aligned(16))) double lds[];
   BCLK(0, 0);
   const Bush16 B      = bushes[blockIdx.x];
@@ -748,28 +749,28 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
   BCLK(0, 1);
   double      *vec = lds;
   BushTile16  *tl  = reinterpret_cast<BushTile16 *>(lds + (size_t)nlines * C16);
-  int         *li  = reinterpret_cast<int *>(tl + 4 * nround);
+  int         *li  = reinterpret_cast<int *>(tl + NW * nround);
   // everything but the panels, in one burst: b of the bush's columns (zeros in the lines of the rows below the root), the tile records,
   // the local rows + crel of the root; the first tile of the wavefront comes straight from HBM, its panel rows leave with the burst
-  Copy16<4> cb;
-  Copy16<2> ct;
-  Copy4<2>  ci;
+  Copy16<4, NT> cb;
+  Copy16<2, NT> ct;
+  Copy4<2, NT>  ci;
   const gcd2_t bsrc = (gcd2_t)(b16 + (B.voff + B.c0) * C16), tsrc = (gcd2_t)(btiles + B.tile0[0]);
   cb.request(bsrc, B.ncol * 8, tid);
-  ct.request(tsrc, 16 * nround, tid);
+  ct.request(tsrc, 4 * NW * nround, tid);
   ci.request(bints + B.int0, B.nlrow + B.nbr, tid);
   TileRegs t = tile_regs_global(btiles + B.tile0[0] + wave);
   dbl2     ring[BUSH_PF][2];
   bush_prime<true>(ring, t, lane);
   cb.finish(reinterpret_cast<dbl2 *>(vec), bsrc, B.ncol * 8, tid);
-  for (int i = B.ncol * 8 + tid; i < nlines * 8; i += WG_THREADS) reinterpret_cast<dbl2 *>(vec)[i] = dbl2{0.0, 0.0};
-  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 16 * nround, tid);
+  for (int i = B.ncol * 8 + tid; i < nlines * 8; i += NT) reinterpret_cast<dbl2 *>(vec)[i] = dbl2{0.0, 0.0};
+  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 4 * NW * nround, tid);
   ci.finish(li, bints + B.int0, B.nlrow + B.nbr, tid);
   __syncthreads();
   BCLK(0, 2);
   for (int r = 0; r < nround; ++r) {
     const TileRegs told = t;
-    if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave); // the tile of the next round
+    if (r + 1 < nround) t = tile_regs(tl + NW * (r + 1) + wave); // the tile of the next round
     else t.sn = -1;
     v4f64     aE[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}}, aO[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}};
     const int re = told.r0 + told.nr;
@@ -819,12 +820,13 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_fwd_kernel(const 
   }
   BCLK(0, 3);
   // what the bush sends up: the update of its root, into the block of the root's parent in the compact pool
-  for (int i = tid >> 4; i < B.nbr; i += WG_THREADS / 16) S16[(B.coff + B.c_out + li[B.nlrow + i]) * C16 + nu] = -vec[(size_t)(B.ncol + i) * C16 + nu];
+  for (int i = tid >> 4; i < B.nbr; i += NT / 16) S16[(B.coff + B.c_out + li[B.nlrow + i]) * C16 + nu] = -vec[(size_t)(B.ncol + i) * C16 + nu];
 }
 
-template <bool Z>
-__global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
+template <bool Z, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
 {
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const Bush16 B      = bushes[blockIdx.x];
   const int    tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -832,17 +834,17 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const 
   const int    nlines = B.ncol + B.nbr, nround = B.nround[1];
   double      *vec = lds;
   BushTile16  *tl  = reinterpret_cast<BushTile16 *>(lds + (size_t)nlines * C16);
-  int         *li  = reinterpret_cast<int *>(tl + 4 * nround);
+  int         *li  = reinterpret_cast<int *>(tl + NW * nround);
   // the burst: x on the rows below the root (the levels above have it; the rows themselves come from HBM for that), y and 1 / D of the
   // bush's columns, tile records, index lists, the first tile's panel rows
   const gcd2_t  xsrc = (gcd2_t)(x16 + B.voff * C16), ysrc = (gcd2_t)(y16 + (B.voff + B.c0) * C16), tsrc = (gcd2_t)(btiles + B.tile0[1]);
   const int    *rsrc = bints + B.int0 + B.nlrow + B.nbr;
   int           xr[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) xr[u] = tid + u * WG_THREADS < B.nbr * 8 ? rsrc[(tid + u * WG_THREADS) >> 3] : 0;
-  Copy16<2> ct;
-  Copy4<2>  ci;
-  ct.request(tsrc, 16 * nround, tid);
+  for (int u = 0; u < 2; ++u) xr[u] = tid + u * NT < B.nbr * 8 ? rsrc[(tid + u * NT) >> 3] : 0;
+  Copy16<2, NT> ct;
+  Copy4<2, NT>  ci;
+  ct.request(tsrc, 4 * NW * nround, tid);
   ci.request(bints + B.int0, B.nlrow, tid);
   TileRegs t = tile_regs_global(btiles + B.tile0[1] + wave);
   dbl2     ring[BUSH_PF][2];
@@ -850,11 +852,11 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const 
   { // z = D^-1 y of the bush's columns
     const gcd_t dv  = (gcd_t)B.dinv;
     dbl2       *dst = reinterpret_cast<dbl2 *>(vec);
-    for (int i = tid; i < B.ncol * 8; i += 4 * WG_THREADS) {
+    for (int i = tid; i < B.ncol * 8; i += 4 * NT) {
       dbl2 v[4], dd[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int  j  = i + u * WG_THREADS;
+        const int  j  = i + u * NT;
         const bool in = j < B.ncol * 8;
         v[u]          = in ? ysrc[j] : dbl2{0.0, 0.0};
         if constexpr (Z) dd[u] = (in && dv) ? *(gcd2_t)(dv + 2 * (long long)(B.c0 + (j >> 3))) : dbl2{1.0, 0.0};
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const 
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int j = i + u * WG_THREADS;
+        const int j = i + u * NT;
         if (j >= B.ncol * 8) continue;
         dbl2 z;
         if constexpr (Z) z.x = dd[u].x * v[u].x - dd[u].y * v[u].y, z.y = dd[u].x * v[u].y + dd[u].y * v[u].x; // (re, im) of one right-hand side
@@ -875,18 +877,18 @@ __global__ __launch_bounds__(WG_THREADS, 4) void sptrsv16_bush_bwd_kernel(const 
     dbl2 *dst = reinterpret_cast<dbl2 *>(vec) + (size_t)B.ncol * 8;
     dbl2  v[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) v[u] = tid + u * WG_THREADS < B.nbr * 8 ? xsrc[(long long)xr[u] * 8 + (tid & 7)] : dbl2{0.0, 0.0};
+    for (int u = 0; u < 2; ++u) v[u] = tid + u * NT < B.nbr * 8 ? xsrc[(long long)xr[u] * 8 + (tid & 7)] : dbl2{0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      if (tid + u * WG_THREADS < B.nbr * 8) dst[tid + u * WG_THREADS] = v[u];
-    for (int i = tid + 2 * WG_THREADS; i < B.nbr * 8; i += WG_THREADS) dst[i] = xsrc[(long long)rsrc[i >> 3] * 8 + (i & 7)];
+      if (tid + u * NT < B.nbr * 8) dst[tid + u * NT] = v[u];
+    for (int i = tid + 2 * NT; i < B.nbr * 8; i += NT) dst[i] = xsrc[(long long)rsrc[i >> 3] * 8 + (i & 7)];
   }
-  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 16 * nround, tid);
+  ct.finish(reinterpret_cast<dbl2 *>(tl), tsrc, 4 * NW * nround, tid);
   ci.finish(li, bints + B.int0, B.nlrow, tid);
   __syncthreads();
   for (int r = 0; r < nround; ++r) {
     const TileRegs told = t;
-    if (r + 1 < nround) t = tile_regs(tl + 4 * (r + 1) + wave);
+    if (r + 1 < nround) t = tile_regs(tl + NW * (r + 1) + wave);
     else t.sn = -1;
     v4f64 aE[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}}, aO[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}};
     if (told.sn >= 0) {
@@ -964,13 +966,18 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
   if (P.nbush) { // the bushes: the bottom of the tree in one launch
     static bool big_lds = false;
     if (P.bush_lds > 48 * 1024 && !big_lds) {
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      auto big = [](const void *f) { HIP_OK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<true, 4>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<false, 4>));
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<true, 4>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<false, 4>));
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<true, 8>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<false, 8>));
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<true, 8>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<false, 8>));
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<true, 16>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_fwd_kernel<false, 16>));
+      big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<true, 16>)), big(reinterpret_cast<const void *>(&sptrsv16_bush_bwd_kernel<false, 16>));
       big_lds = true;
     }
-    hipLaunchKernelGGL((sptrsv16_bush_fwd_kernel<Z>), dim3(P.nbush), dim3(WG_THREADS), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.b16.p, P.y16.p, P.U16.p);
+    if (P.bush_nw == 16) hipLaunchKernelGGL((sptrsv16_bush_fwd_kernel<Z, 16>), dim3(P.nbush), dim3(1024), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.b16.p, P.y16.p, P.U16.p);
+    else if (P.bush_nw == 8) hipLaunchKernelGGL((sptrsv16_bush_fwd_kernel<Z, 8>), dim3(P.nbush), dim3(512), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.b16.p, P.y16.p, P.U16.p);
+    else hipLaunchKernelGGL((sptrsv16_bush_fwd_kernel<Z, 4>), dim3(P.nbush), dim3(256), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.b16.p, P.y16.p, P.U16.p);
     P.mark(2900, s);
   }
   for (int l = 0; l < P.nlev; ++l) {
@@ -994,7 +1001,9 @@ static void sweeps16(SolvePlan &P, const double *b, double *x, int mu, int k0, h
     if (nb || nw) P.mark(3000 + l, s);
   }
   if (P.nbush) {
-    hipLaunchKernelGGL((sptrsv16_bush_bwd_kernel<Z>), dim3(P.nbush), dim3(WG_THREADS), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.y16.p, P.x16.p);
+    if (P.bush_nw == 16) hipLaunchKernelGGL((sptrsv16_bush_bwd_kernel<Z, 16>), dim3(P.nbush), dim3(1024), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.y16.p, P.x16.p);
+    else if (P.bush_nw == 8) hipLaunchKernelGGL((sptrsv16_bush_bwd_kernel<Z, 8>), dim3(P.nbush), dim3(512), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.y16.p, P.x16.p);
+    else hipLaunchKernelGGL((sptrsv16_bush_bwd_kernel<Z, 4>), dim3(P.nbush), dim3(256), (size_t)P.bush_lds, s, P.bush.p, P.bush_tile.p, P.bush_int.p, P.y16.p, P.x16.p);
     P.mark(3900, s);
   }
   hipLaunchKernelGGL((k_perm_out16<Z>), gp, dim3(256), 0, s, P.pvoff.p, P.pn.p, P.piperm.p, P.x16.p, x, mu, k0, P.out_scale);
