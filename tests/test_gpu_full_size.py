@@ -87,7 +87,9 @@ def test_configs_3_share_elasticity_64_nodes_geneo():
     it2, sol2 = A.solve(f)
     res2 = A.compute_residual(sol2, f)
     print(f"configs_3_share: one-level {it1} iterations, two-level {it2}")
-    assert it2 < it1 and it2 <= 0.6 * it1 and res2[1] / res2[0] <= 5e-6, (it1, it2, res2)
+    # pinned like the other two full-size cases (round 6: 97 one-level, 29 two-level iterations on the 64-node share; the sweeps are bitwise
+    # reproducible, one iteration of slack for another build of the eigensolver)
+    assert abs(it1 - 97) <= 1 and abs(it2 - 29) <= 1 and res2[1] / res2[0] <= 5e-6, (it1, it2, res2)
     _close(sol2, sol1, 1e-4, "the one- and two-level solutions agree")
     A.destroy()
 
