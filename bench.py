@@ -439,10 +439,11 @@ def roofline(bytes_alg, t_solve, st, args, mu):
          "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep of the 8 subdomains = %d launches)" % int(st["launches"]),
          "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve, "stored_bytes_per_sweep": 2.0 * st["stored"] * (16.0 if bytes_alg > 2.0 * st["nnz_L"] * 12.0 else 8.0)}
     # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
-    # scripts/r05_profiles.sh pmc): only quoted for the workload it was collected on (same algorithmic bytes)
+    # scripts/rNN_profiles.sh pmc): only quoted for the workload it was collected on (same algorithmic bytes)
     # (NOT measured in this run: counters need their own rocprofv3 passes -- the key below says which file the number is read from)
-    for name in ("r05_pmc_traffic_c3.json", "r05_pmc_traffic_c2.json", "r04_pmc_traffic_c3.json", "r04_pmc_traffic_c2.json", "r03_pmc_traffic_c3.json", "r03_pmc_traffic_c2.json", "r02_pmc_traffic_c3.json", "r02_pmc_traffic_c2.json", "r01_pmc_traffic.json"):
-        pmc = os.path.join(ROOT, "profiles", name)
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic*.json")), reverse=True):   # the newest round first
+        name = os.path.basename(pmc)
         if mu == 1 and os.path.exists(pmc):
             with open(pmc) as fh:
                 tr = json.load(fh)

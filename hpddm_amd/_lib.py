@@ -37,6 +37,7 @@ def _declare(lib):
         "HpddmHipSubdomainDestroy": (None, [P]),
         "HpddmHipSubdomainSetOption": (I, [c_void_pp, C, D]),
         "HpddmHipSubdomainInertia": (I, [P]),
+        "HpddmHipSubdomainRefineSteps": (I, [P]),
         "HpddmHipSubdomainInfo": (I, [P, P, P]),
         "HpddmHipSubdomainExport": (LL, [P, C, P, LL]),
         "HpddmHipSubdomainExportView": (P, [P, C, c_ll_p]),

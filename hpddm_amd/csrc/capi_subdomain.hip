@@ -76,6 +76,8 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
     return 0;)
 }
 
+int HpddmHipSubdomainRefineSteps(const HpddmHipSubdomain *S) { return S ? S->ls.refine_steps : -1; }
+
 int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S)
 {
   HH_TRY(

@@ -136,6 +136,7 @@ void LocalSolver::analyse(const CsrView &A)
 void LocalSolver::numfact(const CsrView &A, int spd)
 {
   analyse(A);
+  refine_steps = 0;
   FactKind kind;
   // complex scalars: a complex SYMMETRIC matrix (MatrixCSR::sym_, or equal values across the diagonal) is factorised as L D L^T
   // with plain transposes -- also when -hpddm_operator_spd is set --, anything else (Hermitian included) as LU
@@ -209,6 +210,14 @@ void LocalSolver::numfact(const CsrView &A, int spd)
         if (devlev) devlev->finish();
         why = probe(A, host.kind);
       }
+      if (!why.empty() && probe_berr <= 1.0e-3 && probe_berr == probe_berr && !getenv("HPDDM_HIP_NO_REFINE")) {
+        // not backward stable, but not far off: does the error contract?  The probe once more with 1 .. MAX_REFINE steps of refinement
+        // (on the device, through the solve every caller will get)
+        keep_matrix(A);
+        for (refine_steps = 1; refine_steps <= MAX_REFINE && !why.empty(); ++refine_steps) why = probe(A, host.kind);
+        --refine_steps;
+        if (!why.empty()) refine_steps = 0, r_ia.release(), r_ja.release(), r_a.release();
+      }
       HH_CHECK(why.empty(), why);
     }
     settled_kind = (int)host.kind;
@@ -223,6 +232,82 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       std::vector<double>().swap(host.G);
       std::vector<double>().swap(host.leaf_pool);
     }
+  }
+}
+
+// r = b - A x, one thread per row and right-hand side column (refinement of the few matrices that need it: not a hot path); vectors
+// column-major n x mu, complex scalars as (re, im) pairs
+__global__ void k_residual(int n, int mu, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ x, double *__restrict__ r)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * mu) return;
+  const int       i = (int)(t % n);
+  const long long o = (t / n) * n;
+  double          v = b[o + i];
+  for (int p = ia[i]; p < ia[i + 1]; ++p) v -= a[p] * x[o + ja[p]];
+  r[o + i] = v;
+}
+__global__ void k_residual_z(int n, int mu, const int *__restrict__ ia, const int *__restrict__ ja, const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ x, double *__restrict__ r)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * mu) return;
+  const int       i = (int)(t % n);
+  const long long o = (t / n) * n;
+  double          vr = b[2 * (o + i)], vi = b[2 * (o + i) + 1];
+  for (int p = ia[i]; p < ia[i + 1]; ++p) {
+    const double ar = a[2 * (size_t)p], ai = a[2 * (size_t)p + 1], xr = x[2 * (o + ja[p])], xi = x[2 * (o + ja[p]) + 1];
+    vr -= ar * xr - ai * xi;
+    vi -= ar * xi + ai * xr;
+  }
+  r[2 * (o + i)] = vr, r[2 * (o + i) + 1] = vi;
+}
+__global__ void k_add(long long cnt, const double *__restrict__ dx, double *__restrict__ x)
+{
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < cnt) x[t] += dx[t];
+}
+
+void LocalSolver::keep_matrix(const CsrView &A)
+{
+  const idx_t      n  = A.n;
+  const int        sc = A.cplx ? 2 : 1;
+  std::vector<int> cnt((size_t)n + 1, 0);
+  for (idx_t i = 0; i < n; ++i)
+    for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+      const idx_t j = A.ja[p] - A.base;
+      ++cnt[(size_t)i + 1];
+      if (A.sym && j != i) ++cnt[(size_t)j + 1]; // (symmetric storage: the other triangle; complex symmetric, no conjugation)
+    }
+  for (idx_t i = 0; i < n; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
+  std::vector<int>    ja((size_t)cnt[(size_t)n]), fill(cnt.begin(), cnt.end() - 1);
+  std::vector<double> a((size_t)cnt[(size_t)n] * sc);
+  for (idx_t i = 0; i < n; ++i)
+    for (idx_t p = A.ia[i] - A.base; p < A.ia[i + 1] - A.base; ++p) {
+      const idx_t j = A.ja[p] - A.base;
+      auto        put = [&](idx_t r, idx_t c) {
+        const size_t q = (size_t)fill[(size_t)r]++;
+        ja[q]          = c;
+        for (int k = 0; k < sc; ++k) a[q * sc + k] = A.a[(size_t)p * sc + k];
+      };
+      put(i, j);
+      if (A.sym && j != i) put(j, i);
+    }
+  hipStream_t s = library_stream();
+  r_ia.upload(cnt, s), r_ja.upload(ja, s), r_a.upload(a, s);
+  HIP_OK(hipStreamSynchronize(s));
+}
+
+void LocalSolver::refine(const double *b, double *x, int mu, hipStream_t s)
+{
+  const int       sc  = host.cplx ? 2 : 1;
+  const long long cnt = (long long)host.n * mu * sc, rows = (long long)host.n * mu;
+  r_res.alloc((size_t)cnt), r_dx.alloc((size_t)cnt);
+  const dim3 g((unsigned)((rows + 255) / 256)), gc((unsigned)((cnt + 255) / 256));
+  for (int it = 0; it < refine_steps; ++it) {
+    if (host.cplx) hipLaunchKernelGGL(k_residual_z, g, dim3(256), 0, s, (int)host.n, mu, r_ia.p, r_ja.p, r_a.p, b, x, r_res.p);
+    else hipLaunchKernelGGL(k_residual, g, dim3(256), 0, s, (int)host.n, mu, r_ia.p, r_ja.p, r_a.p, b, x, r_res.p);
+    plan.solve(r_res.p, r_dx.p, mu, s);
+    hipLaunchKernelGGL(k_add, gc, dim3(256), 0, s, cnt, r_dx.p, x);
   }
 }
 
@@ -314,7 +399,16 @@ void LocalSolver::solve_device(const double *b, double *x, int mu)
 {
   HH_CHECK(uploaded, "solve: the factor is not resident on the GPU (numfact not called, or host_only)");
   ensure_plan();
+  if (refine_steps > 0 && x == b) { // (in place: the right-hand side is needed again)
+    const size_t cnt = (size_t)host.n * mu * (host.cplx ? 2 : 1);
+    xdev.alloc(cnt);
+    HIP_OK(hipMemcpyAsync(xdev.p, b, cnt * sizeof(double), hipMemcpyDeviceToDevice, library_stream()));
+    plan.solve(xdev.p, x, mu, library_stream());
+    refine(xdev.p, x, mu, library_stream());
+    return;
+  }
   plan.solve(b, x, mu, library_stream());
+  if (refine_steps > 0) refine(b, x, mu, library_stream());
 }
 
 void LocalSolver::solve_host(const double *b, double *x, int mu)
@@ -325,6 +419,13 @@ void LocalSolver::solve_host(const double *b, double *x, int mu)
   bdev.alloc(cnt);
   staged_h2d(bdev.p, b, cnt * sizeof(double), s);
   ensure_plan();
+  if (refine_steps > 0) {
+    xdev.alloc(cnt);
+    plan.solve(bdev.p, xdev.p, mu, s);
+    refine(bdev.p, xdev.p, mu, s);
+    staged_d2h(x, xdev.p, cnt * sizeof(double), s);
+    return;
+  }
   plan.solve(bdev.p, bdev.p, mu, s);
   staged_d2h(x, bdev.p, cnt * sizeof(double), s);
 }

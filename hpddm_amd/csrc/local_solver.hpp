@@ -27,6 +27,16 @@ struct LocalSolver {
   double       probe_berr = 0; // backward error of the probe solve that closes numfact (LDL^T / LU)
   std::string  probe(const CsrView &A, FactKind kind); // empty: the factor is backward stable for this matrix
   DevBuf<double> bdev, xdev;         // staging for the host-pointer API
+  // Iterative refinement (what MUMPS / PARDISO do behind include/HPDDM_MUMPS.hpp:304-317 when their pivoting was perturbed): a factor
+  // whose probe solve is NOT backward stable (growth: large entries outside the diagonal tiles, where the static pivoting cannot look)
+  // but whose error contracts -- the probe reaches the tolerance within MAX_REFINE steps of x += solve(b - A x) -- is kept, and
+  // every solve through this object takes that many steps on the device (the matrix is kept in HBM for it, full storage).
+  static constexpr int MAX_REFINE = 3;
+  int            refine_steps = 0;
+  DevBuf<int>    r_ia, r_ja;
+  DevBuf<double> r_a, r_res, r_dx;
+  void           keep_matrix(const CsrView &A);            // full-storage copy of A in HBM
+  void           refine(const double *b, double *x, int mu, hipStream_t s); // refine_steps x { r = b - A x; x += solve(r) }, device pointers
   bool adopt_analysis(const LocalSolver &other, const CsrView &A); // same sparsity pattern as a solver already analysed: copy its ordering and symbolic factorisation
   void analyse(const CsrView &A); // ordering + symbolic factorisation (host only, thread-safe across solvers); numfact calls it if needed
   void numfact(const CsrView &A, int spd);

@@ -1001,7 +1001,11 @@ void Schwarz::call_numfact()
       for (auto &t : pool) t.join();
       HH_CHECK(err.empty(), err);
     }
-    for (int s = 0; s < nsub; ++s) fs.push_back(&subs[s].ls->dev);
+    for (int s = 0; s < nsub; ++s) {
+      HH_CHECK(subs[s].ls->refine_steps == 0, "callNumfact: the factor of subdomain " + std::to_string(first + s) + " is not backward stable by itself (growth outside the diagonal tiles); its solves need iterative "
+                                               "refinement, which the Solver<K> boundary does (hpddm_hip_sub.hpp, HpddmHipSubdomainSolve) and the batched sweeps of this operator do not");
+      fs.push_back(&subs[s].ls->dev);
+    }
     const double tsu2 = wall_seconds();
     build_plans();
     if (prof_setup) fprintf(stderr, "[call_numfact] analysis %.2f s, numerical factorisations %.2f s (%d threads), plans of the batched sweeps %.2f s\n", tsu1 - tsu0, tsu2 - tsu1, nthr, wall_seconds() - tsu2);

@@ -108,6 +108,11 @@ class Subdomain:
         """Solver::inertia: negative pivots of the last factorisation (-1: the factor is an LU one, or complex)"""
         return int(self._lib.HpddmHipSubdomainInertia(self._h))
 
+    def refine_steps(self):
+        """steps of iterative refinement every solve takes (0 unless the probe solve of numfact found a factor that is not backward stable
+        by itself but whose error contracts)"""
+        return int(self._lib.HpddmHipSubdomainRefineSteps(self._h))
+
     def solve_device(self, b_ptr, x_ptr, mu=1):
         check(self._lib.HpddmHipSubdomainSolveDevice(self._h, ctypes.c_void_p(b_ptr), ctypes.c_void_p(x_ptr), mu))
 

@@ -59,10 +59,14 @@ int HpddmHipSubdomainSetOption(HpddmHipSubdomain **S, const char *key, double va
  * 686-703): number of negative pivots of the last factorisation -- read off D of the L D L^T factor (factorise with spd = 0); 0 for a
  * Cholesky factor; -3 when the matrix went through LU or is complex (the pivots do not carry the inertia); -1 on error */
 int HpddmHipSubdomainInertia(const HpddmHipSubdomain *S);
+/* steps of iterative refinement every solve through this handle takes (0: the factor is backward stable by itself, the rule; 1..3: the
+ * probe solve that closes numfact found growth the static pivoting could not avoid, and x += solve(b - A x) contracts: what MUMPS /
+ * PARDISO do behind include/HPDDM_MUMPS.hpp:304-317 after perturbed pivots) */
+int HpddmHipSubdomainRefineSteps(const HpddmHipSubdomain *S);
 /* info[0..11] = n, #supernodes, #levels, nnz(L) exact (scalar, no padding), stored entries, panel pool size (doubles),
  *               update entries per right-hand side (the sum of the nb: what the children hand to their parents in one forward sweep),
  *               kind (0 Cholesky, 1 LDL^T, 2 LU), kernel launches per solve, factorisation flops,
- *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), 0
+ *               microseconds of the numerical phase spent keeping the plain factor ("keep_plain"), bushes of the 16-column engine's plan (0 until a solve built it)
  * times[0..3] = ordering, symbolic, numeric factorisation, upload (seconds) */
 int HpddmHipSubdomainInfo(const HpddmHipSubdomain *S, long long *info, double *times);
 /* Raw factor arrays for inspection / tests / the CPU baseline of bench.py (host copies; sizes from Info + the

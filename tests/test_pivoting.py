@@ -88,6 +88,44 @@ def test_indefinite_helmholtz_with_little_absorption(where, monkeypatch):
     _solve_and_compare(A, mus=(3,), cplx=True, sym_storage=True)
 
 
+def test_iterative_refinement_when_the_factor_is_not_backward_stable(monkeypatch):
+    """a factor the probe solve of numfact does not accept (growth: here a pivot of 1e-9 in an L D L^T kept on purpose,
+    HPDDM_HIP_NO_LU_FALLBACK) but whose error contracts is kept together with the matrix, and every solve through the handle takes the
+    refinement steps the probe needed -- what MUMPS / PARDISO do behind Solver::solve after perturbed pivots (include/HPDDM_MUMPS.hpp:
+    304-317); HPDDM_HIP_NO_REFINE: refused as before"""
+    lap = _poisson3d(4)
+    M = sp.block_diag([lap, sp.csr_matrix(np.array([[1e-9, 1.0], [1.0, 1e-9]]))]).tocsr()
+    L = sp.tril(M, format="csr")
+    L.sort_indices()
+    n = M.shape[0]
+    monkeypatch.setenv("HPDDM_HIP_NO_LU_FALLBACK", "1")
+    monkeypatch.setenv("HPDDM_HIP_NO_REFINE", "1")
+    S = hpddm.Subdomain()
+    with pytest.raises(HpddmHipError, match="backward stable"):
+        S.numfact(n, L.indptr, L.indices, L.data, sym=True)
+    S.destroy()
+    monkeypatch.delenv("HPDDM_HIP_NO_REFINE")
+    lu = spl.splu(M.tocsc())
+    rng = np.random.default_rng(5)
+    for cplx in (False, True):
+        S = hpddm.Subdomain()
+        S.numfact(n, L.indptr, L.indices, L.data.astype(np.complex128) * (1.0 + 0.0j) if cplx else L.data, sym=True)
+        assert S.info()["kind"] == 1 and 1 <= S.refine_steps() <= 3, (S.info()["kind"], S.refine_steps())
+        for mu in (1, 3):
+            b = rng.random((n, mu)) + (1j * rng.random((n, mu)) if cplx else 0.0)
+            b = np.asfortranarray(b if mu > 1 else b[:, 0])
+            x = S.solve(b)
+            ref = spl.splu(M.tocsc().astype(np.complex128)).solve(np.asarray(b)) if cplx else lu.solve(np.asarray(b))
+            assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max(), (cplx, mu, np.abs(x - ref).max() / np.abs(ref).max())
+        S.destroy()
+    # the rule: a stable factor takes no refinement step
+    S = hpddm.Subdomain()
+    K = sp.tril(lap, format="csr")
+    S.numfact(lap.shape[0], K.indptr, K.indices, K.data, sym=True)
+    assert S.refine_steps() == 0
+    S.destroy()
+
+
 def test_what_static_pivoting_cannot_do_is_refused():
     lap = _poisson3d(4)
     for blk in (np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([[0.0, 0.0], [1.0, 2.0]])):   # singular tiles
