@@ -44,8 +44,10 @@ def test_zero_pivot_is_reported_not_hidden():
 def test_collapsed_pivots_of_the_symmetric_kinds_fail_loudly_without_the_lu_fallback(monkeypatch):
     """L D L^T does not pivot: a pivot that collapses against its tile is a breakdown, a factor that is not backward stable is
     refused by the probe solve that closes numfact -- with the fall-back to LU (tests/test_pivoting.py) switched off, never a
-    silently wrong solution."""
+    silently wrong solution.  (Round 6: a factor whose error CONTRACTS is kept with iterative refinement instead, tests/test_pivoting.py;
+    switched off here as well.)"""
     monkeypatch.setenv("HPDDM_HIP_NO_LU_FALLBACK", "1")
+    monkeypatch.setenv("HPDDM_HIP_NO_REFINE", "1")
     lap = _lap(4)
     for eps in (1e-18, 1e-11):
         M = sp.block_diag([lap, sp.csr_matrix(np.array([[eps, 1.0], [1.0, eps]]))]).tocsr()
