@@ -935,11 +935,14 @@ int Schwarz::bcg(const double *b, double *x, int mu, double *history, int histor
 // (U, C = A M^{-1} U, C^T D C = I): harmonic Ritz vectors after the first cycle, the generalised eigenproblem of strategy A after
 // every later one, and the pair seeds the next solve -- the block counterpart of Schwarz::gcrodr (gmres.hip), whose comments
 // describe the conventions reproduced here (the reference's rank-p term built from the QR factors of the whole Hessenberg
-// matrix; the un-normalised last block when a cycle converges on its last step).  No right-hand-side deflation.
+// matrix; the un-normalised last block when a cycle converges on its last step).  Right-hand-side deflation (-hpddm_deflation_tol,
+// :545-600; round 6): the RRQR of every residual block sets the block width p of its cycle; the host algebra works on p-wide blocks,
+// the blocks of the device keep their MU columns (zero beyond p).
 template <int MU>
 static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap, Schwarz::Recycled &rec)
 {
-  constexpr int mu = MU, p = MU;
+  constexpr int mu = MU;
+  int           p  = MU; // block width of the current cycle: mu, or the rank the RRQR of the residual block found (-hpddm_deflation_tol: `deflated` in the reference)
   A.reserve(mu);
   hipStream_t  st        = library_stream();
   const double tol       = A.getopt("tol", 1.0e-6);
@@ -950,11 +953,12 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
   const int    same      = std::min((int)A.getopt("recycle_same_system", 0), 2);
   const int    target    = (int)A.getopt("recycle_target", 0);
   HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGCRODR: left and right preconditioning are built");
-  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGCRODR: right-hand-side deflation is not built");
+  const double defl_tol  = A.getopt("deflation_tol", -1.0);
+  const bool   deflation = defl_tol > -0.9;
   HH_CHECK(A.getopt("recycle_strategy", 0) == 0, "BGCRODR: recycle_strategy A is built");
   const bool      right = variant == VARIANT_RIGHT;
   const long long cnt   = A.ntot * mu;
-  const int       ldh   = p * (m + 1), ncols = p * m;
+  const int       ldh   = mu * (m + 1), ncols = mu * m; // (leading dimensions: a cycle on p < mu columns uses the leading part)
   const dim3      g2((unsigned)std::min(1024, (A.nmax + 255) / 256), (unsigned)A.nsub), gl((unsigned)std::min<long long>(2048, (cnt + 255) / 256));
   const int       nblk = 64;
   int             k    = rec.k > 0 ? rec.k : std::min(m - 1, (int)A.getopt("recycle", 0));
@@ -971,22 +975,94 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
     A.allreduce_device(gram_d.p, (long long)nb * mu * mu); // the MPI_Allreduce of the reference, on the device in stream order, ahead of the one download
     HIP_OK(hipMemcpyAsync(G.data(), gram_d.p, sizeof(double) * nb * mu * mu, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    if (p != mu) { // the blocks of the device keep their mu columns (zero beyond p): the host works on the leading p x p parts, (nb p) x p row-major
+      for (int q = 0; q < nb; ++q)
+        for (int a = 0; a < p; ++a)
+          for (int c = 0; c < p; ++c) G[((size_t)q * p + a) * p + c] = G[((size_t)q * mu + a) * mu + c];
+      G.resize((size_t)nb * p * p);
+    }
   };
   auto axpy_blocks = [&](const double *Vb, int nb, const double *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
     if (nb <= 0) {
       if (beta == 0.0) HIP_OK(hipMemsetAsync(W, 0, sizeof(double) * cnt, st));
       return;
     }
+    std::vector<double> wide; // Cm is (nb p) x p: zero rows and columns for the columns beyond p
+    if (p != mu) {
+      wide.assign((size_t)nb * mu * mu, 0.0);
+      for (int q = 0; q < nb; ++q)
+        for (int a = 0; a < p; ++a)
+          for (int c = 0; c < p; ++c) wide[((size_t)q * mu + a) * mu + c] = Cm[((size_t)q * p + a) * p + c];
+      Cm = wide.data();
+    }
     HIP_OK(hipMemcpyAsync(coef_d.p, Cm, sizeof(double) * nb * mu * mu, hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
     hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * nb * mu * mu, st, A.voff_d.p, A.n_d.p, Vb, cnt, nb, coef_d.p, sign, beta, W);
   };
+  auto axpy_wide = [&](const double *Vb, int nb, const double *Cm, double sign, double beta, double *W) { // full (nb mu) x mu coefficients (permutations, R11^{-1} R12, re-cut blocks)
+    HIP_OK(hipMemcpyAsync(coef_d.p, Cm, sizeof(double) * nb * mu * mu, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL((k_block_axpy<MU>), g2, dim3(256), sizeof(double) * nb * mu * mu, st, A.voff_d.p, A.n_d.p, Vb, cnt, nb, coef_d.p, sign, beta, W);
+  };
+  // RRQR of the residual block (bgmres_impl above; include/HPDDM_iterative.hpp:583-595): pstrf "U" of its Gram matrix, the rank trimmed
+  // while |R[rank-1][rank-1] / R[0][0]| <= tol; W <- (W P)(:, :rank) R11^{-1} in its leading columns, zero elsewhere.  R: mu x mu row-major
+  auto rrqr = [&](double *W, std::vector<double> &R, std::vector<int> &piv) {
+    std::vector<double> Gm;
+    p = mu; // (the Gram matrix of all the columns)
+    gram(W, 1, W, Gm);
+    R.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int jj = 0; jj < mu; ++jj) {
+      int    q    = jj;
+      double best = 0.0;
+      for (int c = jj; c < mu; ++c) {
+        double dj = Gm[(size_t)c * mu + c];
+        for (int t = 0; t < jj; ++t) dj -= R[(size_t)t * mu + c] * R[(size_t)t * mu + c];
+        if (c == jj || dj > best) best = dj, q = c;
+      }
+      if (!(best > 0.0)) {
+        rank = jj;
+        break;
+      }
+      if (q != jj) {
+        for (int c = 0; c < mu; ++c) std::swap(Gm[(size_t)jj * mu + c], Gm[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(Gm[(size_t)r * mu + jj], Gm[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(R[(size_t)r * mu + jj], R[(size_t)r * mu + q]);
+        std::swap(piv[jj], piv[q]);
+      }
+      const double dj        = std::sqrt(best);
+      R[(size_t)jj * mu + jj] = dj;
+      for (int c = jj + 1; c < mu; ++c) {
+        double v = Gm[(size_t)jj * mu + c];
+        for (int t = 0; t < jj; ++t) v -= R[(size_t)t * mu + jj] * R[(size_t)t * mu + c];
+        R[(size_t)jj * mu + c] = v / dj;
+      }
+    }
+    for (int r = rank; r < mu; ++r)
+      for (int c = 0; c < mu; ++c) R[(size_t)r * mu + c] = 0.0;
+    while (rank > 1 && std::abs(R[(size_t)(rank - 1) * mu + rank - 1] / R[0]) <= defl_tol) --rank;
+    if (rank > 0) {
+      std::vector<double> Rinv((size_t)mu * mu, 0.0), Cw((size_t)mu * mu, 0.0);
+      for (int c = 0; c < rank; ++c)
+        for (int r = c; r >= 0; --r) {
+          double v = (r == c) ? 1.0 : 0.0;
+          for (int t = r + 1; t <= c; ++t) v -= R[(size_t)r * mu + t] * Rinv[(size_t)t * mu + c];
+          Rinv[(size_t)r * mu + c] = v / R[(size_t)r * mu + r];
+        }
+      for (int t = 0; t < rank; ++t)
+        for (int c = 0; c < rank; ++c) Cw[(size_t)piv[t] * mu + c] = Rinv[(size_t)t * mu + c];
+      HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_wide(T.p, 1, Cw.data(), 1.0, 0.0, W);
+    }
+    return rank;
+  };
   // block c of a (rows x cols) row-major coefficient matrix, rows = nb blocks of mu: the (nb mu) x mu matrix axpy_blocks wants
   auto block_of = [&](const std::vector<double> &M, int cols, int row0, int nb, int c, std::vector<double> &out) {
-    out.resize((size_t)nb * mu * mu);
+    out.resize((size_t)nb * p * p);
     for (int q = 0; q < nb; ++q)
-      for (int a = 0; a < mu; ++a)
-        for (int bb = 0; bb < mu; ++bb) out[((size_t)q * mu + a) * mu + bb] = M[(size_t)(row0 + q * mu + a) * cols + c * mu + bb];
+      for (int a = 0; a < p; ++a)
+        for (int bb = 0; bb < p; ++bb) out[((size_t)q * p + a) * p + bb] = M[(size_t)(row0 + q * p + a) * cols + c * p + bb];
   };
   auto op = [&](const double *in, double *out) {
     if (right) {
@@ -1001,25 +1077,26 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
   auto cholqr = [&](double *W, std::vector<double> &R) {
     std::vector<double> G;
     gram(W, 1, W, G);
-    R.assign((size_t)mu * mu, 0.0);
-    for (int jj = 0; jj < mu; ++jj) {
-      double dj = G[(size_t)jj * mu + jj];
-      for (int q = 0; q < jj; ++q) dj -= R[(size_t)q * mu + jj] * R[(size_t)q * mu + jj];
+    R.assign((size_t)p * p, 0.0);
+    for (int jj = 0; jj < p; ++jj) {
+      double dj = G[(size_t)jj * p + jj];
+      for (int q = 0; q < jj; ++q) dj -= R[(size_t)q * p + jj] * R[(size_t)q * p + jj];
       if (!(dj > 0.0)) return false;
-      dj                      = std::sqrt(dj);
-      R[(size_t)jj * mu + jj] = dj;
-      for (int c = jj + 1; c < mu; ++c) {
-        double v = G[(size_t)jj * mu + c];
-        for (int q = 0; q < jj; ++q) v -= R[(size_t)q * mu + jj] * R[(size_t)q * mu + c];
-        R[(size_t)jj * mu + c] = v / dj;
+      dj                     = std::sqrt(dj);
+      R[(size_t)jj * p + jj] = dj;
+      for (int c = jj + 1; c < p; ++c) {
+        double v = G[(size_t)jj * p + c];
+        for (int q = 0; q < jj; ++q) v -= R[(size_t)q * p + jj] * R[(size_t)q * p + c];
+        R[(size_t)jj * p + c] = v / dj;
       }
     }
-    const std::vector<double> Ri = upper_inverse(mu, R);
+    const std::vector<double> Ri = upper_inverse(p, R);
     HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
     axpy_blocks(T.p, 1, Ri.data(), 1.0, 0.0, W);
     return true;
   };
-  std::vector<double> norm(mu), G, R, S0, blk;
+  std::vector<double> norm(mu), normp(mu), G, R, S0, blk, Rr, S12;
+  std::vector<int>    piv(mu);
   A.start(b, x, mu);
   {
     std::vector<double> nb;
@@ -1031,7 +1108,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
       gram(bn, 1, bn, nb);
     }
     for (int nu = 0; nu < mu; ++nu) {
-      norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu]);
+      norm[nu] = std::sqrt(nb[(size_t)nu * mu + nu]); // (p = mu here)
       if (norm[nu] < HPDDM_EPS) norm[nu] = 1.0;
     }
   }
@@ -1039,9 +1116,9 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
   auto                Hb = [&](int r, int c) -> double & { return Hbar[(size_t)r * ncols + c]; };
   int                 j = 1, nhist = 0;
   while (j <= max_it) {
-    const bool have = rec.k > 0;
-    const int  i0 = have ? k : 0, kb = have ? k * p : 0;
-    double    *r0 = vk(i0);
+    bool    have = rec.k > 0;
+    int     i0   = have ? k : 0;
+    double *r0   = vk(i0);
     if (right) {
       A.gmv(x, r0, mu);
       hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, r0, r0);
@@ -1050,6 +1127,14 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
       hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, b, -1.0, T.p, T.p);
       A.apply(T.p, r0, mu);
     }
+    p = mu;
+    if (j == 1 && have && rec.width != mu) { // recycled blocks of another width (a deflated cycle made them): dropped at the start of a solve -- the reference would read k mu columns where it wrote k x deflated
+      rec.k = 0, have = false;
+      if (i0 != 0) HIP_OK(hipMemcpyAsync(vk(0), r0, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      i0 = 0, r0 = vk(0);
+      k  = std::min(m - 1, (int)A.getopt("recycle", 0));
+    }
+    int kb = have ? k * p : 0;
     if (j == 1 && have) {
       // a new solve starts from the recycled space (:516-546): C = A M^{-1} U re-orthonormalised (CholQR over its k p columns) unless
       // -hpddm_recycle_same_system, then x += M^{-1} U (C^T r), r -= C (C^T r)
@@ -1069,8 +1154,8 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         for (int c = 0; c < k; ++c) {
           gram(rec.C.p, k, rec.C.p + (size_t)c * cnt, G);
           for (int q = 0; q < k; ++q)
-            for (int a2 = 0; a2 < mu; ++a2)
-              for (int bb = 0; bb < mu; ++bb) Gf[(size_t)(q * mu + a2) * kb + c * mu + bb] = G[((size_t)q * mu + a2) * mu + bb];
+            for (int a2 = 0; a2 < p; ++a2)
+              for (int bb = 0; bb < p; ++bb) Gf[(size_t)(q * p + a2) * kb + c * p + bb] = G[((size_t)q * p + a2) * p + bb];
         }
         for (int q = 0; q < kb; ++q) { // potrf "U"
           double dq = Gf[(size_t)q * kb + q];
@@ -1105,7 +1190,61 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, Ax.p, x);
       } else axpy_blocks(pt, k, G.data(), 1.0, 1.0, x);
     }
-    if (!cholqr(r0, S0)) return -2;
+    // ---- the block width of this cycle: the rank of the residual block (RRQR, :545-600), after a recycled space handed over by an
+    // earlier solve has been projected out of all the columns (above)
+    const bool rr = deflation;
+    if (rr) {
+      p = rrqr(r0, Rr, piv); // (r0 <- its orthonormal leading p columns, zero columns behind)
+      if (p == 0) { // zero residual block
+        j = 0;
+        break;
+      }
+      S12.assign((size_t)p * (mu - p), 0.0); // R11^{-1} R12: what the deflated right-hand sides receive of the corrections (trtrs, :573-579)
+      for (int q = 0; q < mu - p; ++q)
+        for (int r = p - 1; r >= 0; --r) {
+          double v = Rr[(size_t)r * mu + p + q];
+          for (int t = r + 1; t < p; ++t) v -= Rr[(size_t)r * mu + t] * S12[(size_t)t * (mu - p) + q];
+          S12[(size_t)r * (mu - p) + q] = v / Rr[(size_t)r * mu + r];
+        }
+    } else {
+      p = mu;
+      for (int c = 0; c < mu; ++c) piv[c] = c;
+    }
+    for (int c = 0; c < mu; ++c) normp[c] = norm[piv[c]];
+    if (have && rec.width != p) {
+      // the recycled blocks keep the width of the cycle that made them; a cycle that deflates MORE reads the first k p of their
+      // columns, re-cut in blocks of p -- the reference's pointer arithmetic on its k x deflated columns --, one that deflates less
+      // drops them (the reference would read past what it wrote)
+      if (rec.width > p && rec.width <= mu) {
+        const int           wo = rec.width;
+        std::vector<double> Sel((size_t)k * mu * mu);
+        Un.alloc((size_t)cnt * k);
+        for (DevBuf<double> *buf : {&rec.U, &rec.C}) {
+          for (int qn = 0; qn < k; ++qn) {
+            std::fill(Sel.begin(), Sel.end(), 0.0);
+            for (int a = 0; a < p; ++a) {
+              const int fl = qn * p + a; // column of the old k x wo array
+              Sel[((size_t)(fl / wo) * mu + fl % wo) * mu + a] = 1.0;
+            }
+            axpy_wide(buf->p, k, Sel.data(), 1.0, 0.0, Un.p + (size_t)qn * cnt);
+          }
+          HIP_OK(hipMemcpyAsync(buf->p, Un.p, sizeof(double) * cnt * k, hipMemcpyDeviceToDevice, st));
+          HIP_OK(hipStreamSynchronize(st));
+        }
+        rec.width = p;
+      } else {
+        rec.k = 0, have = false;
+        if (i0 != 0) HIP_OK(hipMemcpyAsync(vk(0), r0, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+        i0 = 0, r0 = vk(0);
+        k  = std::min(m - 1, (int)A.getopt("recycle", 0));
+      }
+    }
+    kb = have ? k * p : 0;
+    if (rr) {
+      S0.assign((size_t)p * p, 0.0);
+      for (int r = 0; r < p; ++r)
+        for (int c = r; c < p; ++c) S0[(size_t)r * p + c] = Rr[(size_t)r * mu + c];
+    } else if (!cholqr(r0, S0)) return -2;
     std::fill(Hbar.begin(), Hbar.end(), 0.0);
     Bm.assign((size_t)std::max(kb, 1) * ncols, 0.0);
     std::fill(Hr.begin(), Hr.end(), 0.0);
@@ -1122,13 +1261,13 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
       if (have) {
         gram(rec.C.p, k, W, G);
         for (int q = 0; q < kb; ++q)
-          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * mu + c];
+          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * p + c];
         axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, W);
       }
       gram(vk(i0), i + 1 - i0, W, G); // classical block Gram-Schmidt
       axpy_blocks(vk(i0), i + 1 - i0, G.data(), -1.0, 1.0, W);
       for (int q = 0; q < (i + 1 - i0) * p; ++q)
-        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * mu + c];
+        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * p + c];
       if (!cholqr(W, R)) return -2;
       for (int r = 0; r < p; ++r)
         for (int c = r; c < p; ++c) Hb((i + 1) * p + r, i * p + c) = R[(size_t)r * p + c];
@@ -1140,20 +1279,24 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
       geqr2(2 * p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p);
       orm2r_lt(2 * p, p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p, s.data() + i * p, ldh);
       ++i;
-      int    conv = 0, which = 0;
+      int    conv = mu - p, which = 0; // (the deflated right-hand sides count as converged: checkBlockConvergence)
       double best = -1.0;
       for (int nu = 0; nu < p; ++nu) {
         double nrm = 0.0;
         for (int r = 0; r <= nu; ++r) nrm += s[(p * i + r) + (size_t)nu * ldh] * s[(p * i + r) + (size_t)nu * ldh];
         nrm = std::sqrt(nrm);
-        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
-        if (nrm / norm[nu] > best) best = nrm / norm[nu], which = nu;
+        if ((tol > 0.0 && nrm / normp[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / normp[nu] > best) best = nrm / normp[nu], which = nu;
       }
-      const double beta = best * norm[which];
+      const double beta = best * normp[which];
       if (history && nhist < history_cap) history[nhist] = beta;
       ++nhist;
-      if (verbosity > 2) printf("BGCRODR: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
-      if (conv == p) {
+      if (verbosity > 2) {
+        printf("BGCRODR: %3d %e %e %e < %e", j, beta, normp[which], best, tol);
+        if (p != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - p);
+        printf("\n");
+      }
+      if (conv == mu) {
         dimb      = i;
         converged = true;
         break;
@@ -1179,7 +1322,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         for (int q = 0; q < kb; ++q)
           for (int c = 0; c < p; ++c) {
             double v = 0.0;
-            for (int t = 0; t <= c; ++t) v += G[(size_t)q * mu + t] * S0[(size_t)t * p + c];
+            for (int t = 0; t <= c; ++t) v += G[(size_t)q * p + t] * S0[(size_t)t * p + c];
             Y1[(size_t)q * p + c] = v;
           }
       }
@@ -1191,7 +1334,17 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         }
       axpy_blocks(rec.U.p, k, Y1.data(), 1.0, 1.0, T.p);
     }
-    if (!right) hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, T.p, x);
+    if (rr) {
+      // x P gets [corr, corr R11^{-1} R12] (lapmt forward / backward around updateSolRecycling, :641-657): x += corr Tm with
+      // Tm[t][piv[t]] = 1, Tm[t][piv[p + q]] = S12[t][q]
+      std::vector<double> Tm((size_t)mu * mu, 0.0);
+      for (int t = 0; t < p; ++t) {
+        Tm[(size_t)t * mu + piv[t]] = 1.0;
+        for (int q = 0; q < mu - p; ++q) Tm[(size_t)t * mu + piv[p + q]] = S12[(size_t)t * (mu - p) + q];
+      }
+      if (right) A.apply(T.p, Ax.p, mu);
+      axpy_wide(right ? Ax.p : T.p, 1, Tm.data(), 1.0, 1.0, x);
+    } else if (!right) hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, T.p, x);
     else {
       A.apply(T.p, Ax.p, mu);
       hipLaunchKernelGGL(k_axpby2, gl, dim3(256), 0, st, cnt, 1.0, x, 1.0, Ax.p, x);
@@ -1241,7 +1394,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         std::vector<double> Guu;
         for (int c = 0; c < k; ++c) {
           gram(rec.U.p + (size_t)c * cnt, 1, rec.U.p + (size_t)c * cnt, Guu);
-          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * mu + a2]);
+          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * p + a2]);
         }
         for (int q = 0; q < kb; ++q) {
           Gm[(size_t)q * nc + q] = un[q];
@@ -1253,10 +1406,10 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
         for (int c = 0; c < k; ++c) {
           gram(rec.C.p, k, rec.U.p + (size_t)c * cnt, G);
           for (int q = 0; q < kb; ++q)
-            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * p + bb];
           gram(vk(k), dimb + 1 - k, rec.U.p + (size_t)c * cnt, G);
           for (int q = 0; q < (dimb + 1 - k) * p; ++q)
-            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * p + bb];
         }
         for (int q = 0; q < nc - kb; ++q) WV[(size_t)(kb + q) * nc + kb + q] = 1.0;
         std::vector<double> Am((size_t)nc * nc), Mm((size_t)nc * nc), Lc((size_t)nc * nc, 0.0);
@@ -1339,6 +1492,7 @@ static int bgcrodr_impl(Schwarz &A, const double *b, double *x, double *history,
       HIP_OK(hipMemcpyAsync(rec.C.p, Cn.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
       HIP_OK(hipStreamSynchronize(st));
       rec.k = k = kk;
+      rec.width = p;
     }
     if (converged) break;
     if (verbosity > 1) printf("BGCRODR restart(%d, %d)\n", m, k);

@@ -1118,12 +1118,13 @@ int zgcrodr_one(Schwarz &A, const ZGcroOptions &o, const double *b, double *x, S
 // complex scalars): the block method of bgmres.hip (bgcrodr_impl, whose comments describe the conventions reproduced -- the rank-p
 // term of the first harmonic Ritz problem built from the QR factors of the whole Hessenberg matrix, :676-688; the un-normalised
 // last block when a cycle converges on its last step) with every transposition a conjugate one, on the complex Gram blocks and
-// block updates of ZBlocks.  No right-hand-side deflation.
+// block updates of ZBlocks.  Right-hand-side deflation as in bgcrodr_impl (round 6).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MU>
 int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int history_cap, Schwarz::Recycled &rec)
 {
-  constexpr int mu = MU, p = MU;
+  constexpr int mu = MU;
+  int           p  = MU; // block width of the current cycle: mu, or the rank the RRQR of the residual block found (-hpddm_deflation_tol)
   A.reserve(mu);
   const double tol       = A.getopt("tol", 1.0e-6);
   const int    max_it    = std::min<int>((int)A.getopt("max_it", 100), std::numeric_limits<short>::max());
@@ -1133,7 +1134,8 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
   const int    same      = std::min((int)A.getopt("recycle_same_system", 0), 2);
   const int    target    = (int)A.getopt("recycle_target", 0);
   HH_CHECK(variant == VARIANT_RIGHT || variant == VARIANT_LEFT, "BGCRODR: left and right preconditioning are built");
-  HH_CHECK(A.getopt("deflation_tol", -1.0) < -0.9, "BGCRODR: right-hand-side deflation is not built");
+  const double defl_tol  = A.getopt("deflation_tol", -1.0);
+  const bool   deflation = defl_tol > -0.9;
   HH_CHECK(A.getopt("recycle_strategy", 0) == 0, "BGCRODR: recycle_strategy A is built");
   HH_CHECK(target >= 0 && target <= 5, "BGCRODR: unknown recycle_target");
   const bool right = variant == VARIANT_RIGHT;
@@ -1141,7 +1143,7 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
   ZBlocks<MU>     Z(A, std::max(k, m + 1));
   hipStream_t     st  = Z.st;
   const long long cnt = Z.cnt;
-  const int       ldh = p * (m + 1), ncols = p * m;
+  const int       ldh = mu * (m + 1), ncols = mu * m; // (leading dimensions: a cycle on p < mu columns uses the leading part)
   DevBuf<double>  V, Ax, T, Un, Cn, PT;
   V.alloc((size_t)cnt * (m + 1));
   Ax.alloc((size_t)cnt), T.alloc((size_t)cnt);
@@ -1152,6 +1154,12 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       return;
     }
     Z.gram(Vb, nb, W, G);
+    if (p != mu) { // the blocks of the device keep their mu columns (zero beyond p): the host works on the leading p x p parts, (nb p) x p row-major
+      for (int q = 0; q < nb; ++q)
+        for (int a = 0; a < p; ++a)
+          for (int c = 0; c < p; ++c) G[((size_t)q * p + a) * p + c] = G[((size_t)q * mu + a) * mu + c];
+      G.resize((size_t)nb * p * p);
+    }
   };
   std::vector<cplx> coef;
   auto axpy_blocks = [&](const double *Vb, int nb, const cplx *Cm, double sign, double beta, double *W) { // W = beta W + sign V(0..nb) C
@@ -1159,15 +1167,21 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       if (beta == 0.0) HIP_OK(hipMemsetAsync(W, 0, sizeof(double) * cnt, st));
       return;
     }
-    coef.assign(Cm, Cm + (size_t)nb * mu * mu);
+    if (p != mu) { // Cm is (nb p) x p: zero rows and columns for the columns beyond p
+      coef.assign((size_t)nb * mu * mu, cplx(0.0));
+      for (int q = 0; q < nb; ++q)
+        for (int a = 0; a < p; ++a)
+          for (int c = 0; c < p; ++c) coef[((size_t)q * mu + a) * mu + c] = Cm[((size_t)q * p + a) * p + c];
+    } else coef.assign(Cm, Cm + (size_t)nb * mu * mu);
     Z.axpy(Vb, nb, coef, sign, beta, W);
   };
+  auto axpy_wide = [&](const double *Vb, int nb, const std::vector<cplx> &Cm, double sign, double beta, double *W) { Z.axpy(Vb, nb, Cm, sign, beta, W); }; // full (nb mu) x mu coefficients
   // block c of a (rows x cols) row-major coefficient matrix, rows = nb blocks of mu: the (nb mu) x mu matrix axpy_blocks wants
   auto block_of = [&](const std::vector<cplx> &M, int cols, int row0, int nb, int c, std::vector<cplx> &out) {
-    out.resize((size_t)std::max(nb, 0) * mu * mu);
+    out.resize((size_t)std::max(nb, 0) * p * p);
     for (int q = 0; q < nb; ++q)
-      for (int a = 0; a < mu; ++a)
-        for (int bb = 0; bb < mu; ++bb) out[((size_t)q * mu + a) * mu + bb] = M[(size_t)(row0 + q * mu + a) * cols + c * mu + bb];
+      for (int a = 0; a < p; ++a)
+        for (int bb = 0; bb < p; ++bb) out[((size_t)q * p + a) * p + bb] = M[(size_t)(row0 + q * p + a) * cols + c * p + bb];
   };
   auto op = [&](const double *in, double *out) {
     if (right) {
@@ -1199,13 +1213,68 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
   auto cholqr = [&](double *W, std::vector<cplx> &R) {
     std::vector<cplx> Gw;
     gram(W, 1, W, Gw);
-    if (!potrf_u(mu, Gw, R)) return false;
-    const std::vector<cplx> Ri = upper_inverse_z(mu, R);
+    if (!potrf_u(p, Gw, R)) return false;
+    const std::vector<cplx> Ri = upper_inverse_z(p, R);
     HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
     axpy_blocks(T.p, 1, Ri.data(), 1.0, 0.0, W);
     return true;
   };
-  std::vector<double> norm(mu);
+  // RRQR of the residual block (zbgmres_impl above): pivoted Cholesky of its Gram matrix, the rank trimmed while
+  // |R[rank-1][rank-1] / R[0][0]| <= tol; W <- (W P)(:, :rank) R11^{-1} in its leading columns, zero elsewhere.  R: mu x mu row-major
+  auto rrqr = [&](double *W, std::vector<cplx> &R, std::vector<int> &piv) {
+    std::vector<cplx> Gm;
+    p = mu;
+    gram(W, 1, W, Gm);
+    R.assign((size_t)mu * mu, 0.0);
+    for (int c = 0; c < mu; ++c) piv[c] = c;
+    int rank = mu;
+    for (int jj = 0; jj < mu; ++jj) {
+      int    q    = jj;
+      double best = 0.0;
+      for (int c = jj; c < mu; ++c) {
+        double dj = Gm[(size_t)c * mu + c].real();
+        for (int t = 0; t < jj; ++t) dj -= std::norm(R[(size_t)t * mu + c]);
+        if (c == jj || dj > best) best = dj, q = c;
+      }
+      if (!(best > 0.0)) {
+        rank = jj;
+        break;
+      }
+      if (q != jj) {
+        for (int c = 0; c < mu; ++c) std::swap(Gm[(size_t)jj * mu + c], Gm[(size_t)q * mu + c]);
+        for (int r = 0; r < mu; ++r) std::swap(Gm[(size_t)r * mu + jj], Gm[(size_t)r * mu + q]);
+        for (int r = 0; r < mu; ++r) std::swap(R[(size_t)r * mu + jj], R[(size_t)r * mu + q]);
+        std::swap(piv[jj], piv[q]);
+      }
+      const double dj         = std::sqrt(best);
+      R[(size_t)jj * mu + jj] = dj;
+      for (int c = jj + 1; c < mu; ++c) {
+        cplx v = Gm[(size_t)jj * mu + c];
+        for (int t = 0; t < jj; ++t) v -= std::conj(R[(size_t)t * mu + jj]) * R[(size_t)t * mu + c];
+        R[(size_t)jj * mu + c] = v / dj;
+      }
+    }
+    for (int r = rank; r < mu; ++r)
+      for (int c = 0; c < mu; ++c) R[(size_t)r * mu + c] = 0.0;
+    while (rank > 1 && std::abs(R[(size_t)(rank - 1) * mu + rank - 1] / R[0]) <= defl_tol) --rank;
+    if (rank > 0) {
+      std::vector<cplx> Rinv((size_t)mu * mu, 0.0), Cw((size_t)mu * mu, 0.0);
+      for (int c = 0; c < rank; ++c)
+        for (int r = c; r >= 0; --r) {
+          cplx v = (r == c) ? 1.0 : 0.0;
+          for (int t = r + 1; t <= c; ++t) v -= R[(size_t)r * mu + t] * Rinv[(size_t)t * mu + c];
+          Rinv[(size_t)r * mu + c] = v / R[(size_t)r * mu + r];
+        }
+      for (int t = 0; t < rank; ++t)
+        for (int c = 0; c < rank; ++c) Cw[(size_t)piv[t] * mu + c] = Rinv[(size_t)t * mu + c];
+      HIP_OK(hipMemcpyAsync(T.p, W, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      axpy_wide(T.p, 1, Cw, 1.0, 0.0, W);
+    }
+    return rank;
+  };
+  std::vector<double> norm(mu), normp(mu);
+  std::vector<int>    piv(mu);
+  std::vector<cplx>   Rr, S12;
   std::vector<cplx>   G, R, S0, blk;
   A.start(b, x, mu);
   {
@@ -1226,9 +1295,9 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
   auto              Hb = [&](int r, int c) -> cplx & { return Hbar[(size_t)r * ncols + c]; };
   int               j = 1, nhist = 0;
   while (j <= max_it) {
-    const bool have = rec.k > 0;
-    const int  i0 = have ? k : 0, kb = have ? k * p : 0;
-    double    *r0 = vk(i0);
+    bool    have = rec.k > 0;
+    int     i0   = have ? k : 0;
+    double *r0   = vk(i0);
     if (right) {
       A.gmv(x, r0, mu);
       Z.axpby(1.0, b, -1.0, r0, r0);
@@ -1237,6 +1306,14 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       Z.axpby(1.0, b, -1.0, T.p, T.p);
       A.apply(T.p, r0, mu);
     }
+    p = mu;
+    if (j == 1 && have && rec.width != mu) { // recycled blocks of another width (a deflated cycle made them): dropped at the start of a solve -- the reference would read k mu columns where it wrote k x deflated
+      rec.k = 0, have = false;
+      if (i0 != 0) HIP_OK(hipMemcpyAsync(vk(0), r0, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+      i0 = 0, r0 = vk(0);
+      k  = std::min(m - 1, (int)A.getopt("recycle", 0));
+    }
+    int kb = have ? k * p : 0;
     if (j == 1 && have) {
       // a new solve starts from the recycled space (:516-546): C = A M^{-1} U re-orthonormalised (CholQR over its k p columns) unless
       // -hpddm_recycle_same_system, then x += M^{-1} U (C^H r), r -= C (C^H r)
@@ -1256,8 +1333,8 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         for (int c = 0; c < k; ++c) {
           gram(rec.C.p, k, rec.C.p + (size_t)c * cnt, G);
           for (int q = 0; q < k; ++q)
-            for (int a2 = 0; a2 < mu; ++a2)
-              for (int bb = 0; bb < mu; ++bb) Gf[(size_t)(q * mu + a2) * kb + c * mu + bb] = G[((size_t)q * mu + a2) * mu + bb];
+            for (int a2 = 0; a2 < p; ++a2)
+              for (int bb = 0; bb < p; ++bb) Gf[(size_t)(q * p + a2) * kb + c * p + bb] = G[((size_t)q * p + a2) * p + bb];
         }
         HH_CHECK(potrf_u(kb, Gf, Rf), "BGCRODR: the recycled subspace lost its rank");
         const std::vector<cplx> Ri = upper_inverse_z(kb, Rf);
@@ -1281,7 +1358,58 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         Z.axpby(1.0, x, 1.0, Ax.p, x);
       } else axpy_blocks(pt, k, G.data(), 1.0, 1.0, x);
     }
-    if (!cholqr(r0, S0)) return -2;
+    // ---- the block width of this cycle: the rank of the residual block (RRQR, :545-600), after a recycled space handed over by an
+    // earlier solve has been projected out of all the columns (above); see bgcrodr_impl of bgmres.hip
+    const bool rr = deflation;
+    if (rr) {
+      p = rrqr(r0, Rr, piv);
+      if (p == 0) {
+        j = 0;
+        break;
+      }
+      S12.assign((size_t)p * (mu - p), 0.0); // R11^{-1} R12
+      for (int q = 0; q < mu - p; ++q)
+        for (int r = p - 1; r >= 0; --r) {
+          cplx v = Rr[(size_t)r * mu + p + q];
+          for (int t = r + 1; t < p; ++t) v -= Rr[(size_t)r * mu + t] * S12[(size_t)t * (mu - p) + q];
+          S12[(size_t)r * (mu - p) + q] = v / Rr[(size_t)r * mu + r];
+        }
+    } else {
+      p = mu;
+      for (int c = 0; c < mu; ++c) piv[c] = c;
+    }
+    for (int c = 0; c < mu; ++c) normp[c] = norm[piv[c]];
+    if (have && rec.width != p) {
+      if (rec.width > p && rec.width <= mu) { // the first k p columns of the k x width columns of U and C, re-cut in blocks of p
+        const int         wo = rec.width;
+        std::vector<cplx> Sel((size_t)k * mu * mu);
+        Un.alloc((size_t)cnt * k);
+        for (DevBuf<double> *buf : {&rec.U, &rec.C}) {
+          for (int qn = 0; qn < k; ++qn) {
+            std::fill(Sel.begin(), Sel.end(), cplx(0.0));
+            for (int a = 0; a < p; ++a) {
+              const int fl = qn * p + a;
+              Sel[((size_t)(fl / wo) * mu + fl % wo) * mu + a] = 1.0;
+            }
+            axpy_wide(buf->p, k, Sel, 1.0, 0.0, Un.p + (size_t)qn * cnt);
+          }
+          HIP_OK(hipMemcpyAsync(buf->p, Un.p, sizeof(double) * cnt * k, hipMemcpyDeviceToDevice, st));
+          HIP_OK(hipStreamSynchronize(st));
+        }
+        rec.width = p;
+      } else { // a cycle that deflates less: the recycled space is dropped
+        rec.k = 0, have = false;
+        if (i0 != 0) HIP_OK(hipMemcpyAsync(vk(0), r0, sizeof(double) * cnt, hipMemcpyDeviceToDevice, st));
+        i0 = 0, r0 = vk(0);
+        k  = std::min(m - 1, (int)A.getopt("recycle", 0));
+      }
+    }
+    kb = have ? k * p : 0;
+    if (rr) {
+      S0.assign((size_t)p * p, cplx(0.0));
+      for (int r = 0; r < p; ++r)
+        for (int c = r; c < p; ++c) S0[(size_t)r * p + c] = Rr[(size_t)r * mu + c];
+    } else if (!cholqr(r0, S0)) return -2;
     std::fill(Hbar.begin(), Hbar.end(), cplx(0.0));
     Bm.assign((size_t)std::max(kb, 1) * ncols, 0.0);
     std::fill(Hr.begin(), Hr.end(), cplx(0.0));
@@ -1298,13 +1426,13 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       if (have) {
         gram(rec.C.p, k, W, G);
         for (int q = 0; q < kb; ++q)
-          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * mu + c];
+          for (int c = 0; c < p; ++c) Bm[(size_t)q * ncols + i * p + c] = G[(size_t)q * p + c];
         axpy_blocks(rec.C.p, k, G.data(), -1.0, 1.0, W);
       }
       gram(vk(i0), i + 1 - i0, W, G); // classical block Gram-Schmidt
       axpy_blocks(vk(i0), i + 1 - i0, G.data(), -1.0, 1.0, W);
       for (int q = 0; q < (i + 1 - i0) * p; ++q)
-        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * mu + c];
+        for (int c = 0; c < p; ++c) Hb(i0 * p + q, i * p + c) = G[(size_t)q * p + c];
       if (!cholqr(W, R)) return -2;
       for (int r = 0; r < p; ++r)
         for (int c = r; c < p; ++c) Hb((i + 1) * p + r, i * p + c) = R[(size_t)r * p + c];
@@ -1316,20 +1444,24 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       zgeqr2(2 * p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p);
       zunm2r_lc(2 * p, p, p, Hi + i * p, ldh, tau.data() + (size_t)i * 2 * p, s.data() + i * p, ldh);
       ++i;
-      int    conv = 0, which = 0;
+      int    conv = mu - p, which = 0; // (the deflated right-hand sides count as converged)
       double best = -1.0;
       for (int nu = 0; nu < p; ++nu) {
         double nrm = 0.0;
         for (int r = 0; r <= nu; ++r) nrm += std::norm(s[(p * i + r) + (size_t)nu * ldh]);
         nrm = std::sqrt(nrm);
-        if ((tol > 0.0 && nrm / norm[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
-        if (nrm / norm[nu] > best) best = nrm / norm[nu], which = nu;
+        if ((tol > 0.0 && nrm / normp[nu] <= tol) || (tol < 0.0 && nrm <= -tol)) ++conv;
+        if (nrm / normp[nu] > best) best = nrm / normp[nu], which = nu;
       }
-      const double beta = best * norm[which];
+      const double beta = best * normp[which];
       if (history && nhist < history_cap) history[nhist] = beta;
       ++nhist;
-      if (verbosity > 2) printf("BGCRODR: %3d %e %e %e < %e\n", j, beta, norm[which], best, tol);
-      if (conv == p) {
+      if (verbosity > 2) {
+        printf("BGCRODR: %3d %e %e %e < %e", j, beta, normp[which], best, tol);
+        if (p != mu) printf(" (rhs #%d, %d deflated rhs)", which + 1, mu - p);
+        printf("\n");
+      }
+      if (conv == mu) {
         dimb      = i;
         converged = true;
         break;
@@ -1355,7 +1487,7 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         for (int q = 0; q < kb; ++q)
           for (int c = 0; c < p; ++c) {
             cplx v = 0.0;
-            for (int t = 0; t <= c; ++t) v += G[(size_t)q * mu + t] * S0[(size_t)t * p + c];
+            for (int t = 0; t <= c; ++t) v += G[(size_t)q * p + t] * S0[(size_t)t * p + c];
             Y1[(size_t)q * p + c] = v;
           }
       }
@@ -1367,7 +1499,15 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         }
       axpy_blocks(rec.U.p, k, Y1.data(), 1.0, 1.0, T.p);
     }
-    if (!right) Z.axpby(1.0, x, 1.0, T.p, x);
+    if (rr) { // x P gets [corr, corr R11^{-1} R12]: x += corr Tm, Tm[t][piv[t]] = 1, Tm[t][piv[p + q]] = S12[t][q]
+      std::vector<cplx> Tm((size_t)mu * mu, cplx(0.0));
+      for (int t = 0; t < p; ++t) {
+        Tm[(size_t)t * mu + piv[t]] = 1.0;
+        for (int q = 0; q < mu - p; ++q) Tm[(size_t)t * mu + piv[p + q]] = S12[(size_t)t * (mu - p) + q];
+      }
+      if (right) A.apply(T.p, Ax.p, mu);
+      axpy_wide(right ? Ax.p : T.p, 1, Tm, 1.0, 1.0, x);
+    } else if (!right) Z.axpby(1.0, x, 1.0, T.p, x);
     else {
       A.apply(T.p, Ax.p, mu);
       Z.axpby(1.0, x, 1.0, Ax.p, x);
@@ -1423,7 +1563,7 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         std::vector<cplx> Guu;
         for (int c = 0; c < k; ++c) {
           gram(rec.U.p + (size_t)c * cnt, 1, rec.U.p + (size_t)c * cnt, Guu);
-          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * mu + a2].real());
+          for (int a2 = 0; a2 < p; ++a2) un[c * p + a2] = 1.0 / std::sqrt(Guu[(size_t)a2 * p + a2].real());
         }
         for (int q = 0; q < kb; ++q) {
           Gm[(size_t)q * nc + q] = un[q];
@@ -1435,10 +1575,10 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
         for (int c = 0; c < k; ++c) {
           gram(rec.C.p, k, rec.U.p + (size_t)c * cnt, G);
           for (int q = 0; q < kb; ++q)
-            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)q * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * p + bb];
           gram(vk(k), dimb + 1 - k, rec.U.p + (size_t)c * cnt, G);
           for (int q = 0; q < (dimb + 1 - k) * p; ++q)
-            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * mu + bb];
+            for (int bb = 0; bb < p; ++bb) WV[(size_t)(kb + q) * nc + c * p + bb] = un[c * p + bb] * G[(size_t)q * p + bb];
         }
         for (int q = 0; q < nc - kb; ++q) WV[(size_t)(kb + q) * nc + kb + q] = 1.0;
         std::vector<cplx> Am((size_t)nc * nc), Mm((size_t)nc * nc), Lc((size_t)nc * nc, 0.0);
@@ -1517,6 +1657,7 @@ int zbgcrodr_impl(Schwarz &A, const double *b, double *x, double *history, int h
       HIP_OK(hipMemcpyAsync(rec.C.p, Cn.p, sizeof(double) * cnt * kk, hipMemcpyDeviceToDevice, st));
       HIP_OK(hipStreamSynchronize(st));
       rec.k = k = kk;
+      rec.width = p;
     }
     if (converged) break;
     if (verbosity > 1) printf("BGCRODR restart(%d, %d)\n", m, k);

@@ -233,6 +233,7 @@ struct Schwarz {
   struct Recycled {
     DevBuf<double> U, C; // k vectors each, single right-hand-side layout (ntot doubles per vector)
     int            k = 0;
+    int            width = 0; // block GCRO-DR: columns of a block that carry a vector (mu, or what the cycle that made them ran on after right-hand-side deflation; the others are zero columns)
   };
   std::vector<std::unique_ptr<Recycled>> recycled;
   std::unique_ptr<Recycled>              recycled_block; // block GCRO-DR: k blocks of mu columns each (batched layout)

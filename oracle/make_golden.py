@@ -99,6 +99,9 @@ CASES = [
     ("p40_gcrodr_same_system", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_same_system 1"),
     ("p40_gcrodr_target_lm", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 10 -hpddm_recycle_target LM"),
     ("p40_gcrodr_cycle_end", 4, 1, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 4 -hpddm_gmres_restart 8"),
+    # Block GCRO-DR with right-hand-side deflation (include/HPDDM_GCRODR.hpp:545-600): blocks of 3 of the 4 right-hand sides, three restarts
+    ("p40_bgcrodr_rhs_deflation_mu4", 4, 4, "-Nx 40 -Ny 40 -dependent_rhs 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 2 -hpddm_gmres_restart 6 -hpddm_deflation_tol 1e-6"),
+    ("z_p30_bgcrodr_rhs_deflation_mu4", 4, 4, "-Nx 30 -Ny 30 -dependent_rhs 1 -complex_shift_re -10 -complex_shift_im 2 -hpddm_krylov_method bgcrodr -hpddm_recycle 2 -hpddm_gmres_restart 6 -hpddm_deflation_tol 1e-6"),
     ("p40_bgcrodr_two_solves_mu2", 4, 2, "-Nx 40 -Ny 40 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8"),
     ("p30_6ranks_bgcrodr_left_deflated_mu3", 6, 3, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method bgcrodr -hpddm_recycle 2 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),
     ("p30_6ranks_gcrodr_left_deflated_mu2", 6, 2, "-Nx 30 -Ny 30 -overlap 2 -second_solve 1 -hpddm_krylov_method gcrodr -hpddm_recycle 3 -hpddm_gmres_restart 8 -hpddm_variant left -hpddm_schwarz_coarse_correction deflated -hpddm_geneo_nu=0"),

@@ -1076,14 +1076,19 @@ def gcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right",
     return min(j, max_it), x, hist, (U, C)
 
 
-def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right", state=None, same_system=0, target="SM"):
+def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right", state=None, same_system=0, target="SM", deflation_tol=-1.0):
     """IterativeMethod::BGCRODR (include/HPDDM_GCRODR.hpp:445-905): the block version of gcrodr above -- block Arnoldi with CholQR
     like bgmres, a recycled subspace of k blocks (k p columns for p right-hand sides).  Everything is written on single columns
-    (classical block Gram-Schmidt followed by a CholQR inside the new block is the same thing); no right-hand-side deflation
-    (-hpddm_deflation_tol unset).  Returns (iterations, solution, history, state)."""
+    (classical block Gram-Schmidt followed by a CholQR inside the new block is the same thing).
+    deflation_tol > -0.9: right-hand-side deflation (:545-600) -- at every restart the residual block goes through the RRQR of
+    bgmres above, the cycle runs on its `deflated` leading columns (blocks of d <= mu columns: Hessenberg matrix, recycled space
+    and eigenproblems alike), the other right-hand sides receive the correction times R11^{-1} R12 (updateSolRecycling through
+    lapmt, :641-657).  The recycled blocks keep the width of the cycle that made them; a later cycle that deflates MORE reads the
+    first k d columns of U and C, as the reference's pointer arithmetic does (a cycle that deflates less drops them: the
+    reference would read past the k d_old columns it wrote).  Returns (iterations, solution, history, state)."""
     import scipy.linalg as sla
     if recycle <= 0:
-        it, sol, hist = bgmres(orc, b, tol=tol, max_it=max_it, restart=restart, variant=variant)
+        it, sol, hist = bgmres(orc, b, tol=tol, max_it=max_it, restart=restart, variant=variant, deflation_tol=deflation_tol)
         return it, sol, hist, None
     P = orc.P
     cplx = any(np.iscomplexobj(v) for v in b)                  # K = std::complex<double>: every transposition below is a conjugate one
@@ -1104,8 +1109,9 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
 
     x = orc.start(b, [np.zeros_like(v) for v in b])
     nb = _gram(orc, orc.apply(b), orc.apply(b)) if variant == "left" else _gram(orc, b, b)
-    norm = np.sqrt(np.real(np.diag(nb)))
-    norm[norm < HPDDM_EPS] = 1.0
+    norm0 = np.sqrt(np.real(np.diag(nb)))
+    norm0[norm0 < HPDDM_EPS] = 1.0
+    mu = p                                                         # right-hand sides; p below = the block width of the current cycle
     U, C = (None, None) if state is None else state
     if U is not None:
         k = U[0].shape[1] // p
@@ -1116,6 +1122,9 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         if variant == "left":
             R0 = orc.apply(R0)
         have = U is not None
+        p = mu
+        if j == 1 and have and U[0].shape[1] != k * mu:           # recycled blocks of another width (made by a deflated cycle): dropped at the start of a solve
+            U, C, have, k = None, None, False, min(m - 1, recycle)
         kb = k * p if have else 0
         if j == 1 and have:
             pt = prec(U) if variant != "left" else U
@@ -1127,10 +1136,32 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             R0 = [r - c for r, c in zip(R0, lin(Hc, C))]
             corr = orc.apply(lin(Hc, U)) if (variant != "left" and same_system) else lin(Hc, pt)
             x = [xx + cc for xx, cc in zip(x, corr)]
-        try:
-            V0, S0 = cholqr(R0)
-        except np.linalg.LinAlgError:
-            return -2, [v if p > 1 else v[:, 0] for v in x], hist, state
+        rr = deflation_tol > -0.9                                 # RRQR of the residual block (:545-600), after a recycled space handed over by an earlier solve has been projected out of all the columns
+        if rr:
+            Rr, piv, p = _pstrf_upper(_gram(orc, R0, R0))
+            while p > 1 and abs(Rr[p - 1, p - 1] / Rr[0, 0]) <= deflation_tol:
+                p -= 1
+            if p == 0:
+                return 0, [v if mu > 1 else v[:, 0] for v in x], hist, (U, C)
+        else:
+            piv, p = np.arange(mu), mu
+        if have and U[0].shape[1] != k * p:                       # the width of the blocks changed since the cycle that made U and C
+            if U[0].shape[1] > k * p:
+                U, C = [u[:, :k * p] for u in U], [c[:, :k * p] for c in C]
+            else:
+                U, C, have, k = None, None, False, min(m - 1, recycle)
+        norm = norm0[piv]
+        kb = k * p if have else 0
+        if rr:
+            Ri = np.linalg.inv(Rr[:p, :p])
+            V0 = [r[:, piv][:, :p] @ Ri for r in R0]
+            S0, S12 = Rr[:p, :p], Ri @ Rr[:p, p:]
+        else:
+            try:
+                V0, S0 = cholqr(R0)
+            except np.linalg.LinAlgError:
+                return -2, [v if mu > 1 else v[:, 0] for v in x], hist, state
+            S12 = np.zeros((p, 0), dtype=dt)
         ncols = m * p
         Hbar = np.zeros((ncols + p, ncols), dtype=dt)              # scalar view of the block Hessenberg matrix
         Bm = np.zeros((max(kb, 1), ncols), dtype=dt)
@@ -1160,7 +1191,7 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             try:
                 V[i + 1], Rn = cholqr(W)
             except np.linalg.LinAlgError:
-                return -2, [v if p > 1 else v[:, 0] for v in x], hist, state
+                return -2, [v if mu > 1 else v[:, 0] for v in x], hist, state
             Hbar[(i + 1) * p:(i + 2) * p, cols] = Rn
             Hr[i0 * p:(i + 2) * p, cols] = Hbar[i0 * p:(i + 2) * p, cols]
             for q in range(i0, i):
@@ -1171,9 +1202,9 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             sr[i * p:(i + 2) * p] = H(Qh) @ sr[i * p:(i + 2) * p]
             i += 1
             res = np.array([np.linalg.norm(sr[i * p:i * p + nu + 1, nu]) for nu in range(p)])
-            which = int(np.argmax(res / norm))
+            which = int(np.argmax(res / norm[:p]))
             hist.append((j, res[which], norm[which]))
-            if np.all(res / norm <= tol):
+            if np.all(res / norm[:p] <= tol):
                 dimb = i
                 converged = True
                 break
@@ -1188,7 +1219,19 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
         if have:
             Y1 = (np.zeros((kb, p), dtype=dt) if same_system else _gram(orc, C, lin(S0, V[i0]))) - Bm[:kb, i0 * p:dimb * p] @ Y2
             comb = [a + c for a, c in zip(comb, lin(Y1, U))]
-        x = [xx + cc for xx, cc in zip(x, comb if variant == "left" else orc.apply(comb))]
+        corr = comb if variant == "left" else orc.apply(comb)
+        if not rr:
+            x = [xx + cc for xx, cc in zip(x, corr)]
+        else:                                                      # lapmt forward, [corr, corr R11^{-1} R12], lapmt backward
+            xn = []
+            for xx, cc in zip(x, corr):
+                xp = xx[:, piv].copy()
+                xp[:, :p] += cc
+                xp[:, p:] += cc @ S12
+                xo = np.empty_like(xx)
+                xo[:, piv] = xp
+                xn.append(xo)
+            x = xn
         if converged and dimb == m:   # un-normalised last block on convergence at the end of a cycle, like gcrodr above (:660-663)
             V = V[:m] + [lin(Hbar[m * p:(m + 1) * p, (m - 1) * p:m * p], V[m])]
         if same_system > 1:
@@ -1234,4 +1277,4 @@ def bgcrodr(orc, b, tol=1e-6, max_it=100, restart=40, recycle=0, variant="right"
             C = lin(Q, Wb)
         if converged:
             break
-    return min(j, max_it), [v if p > 1 else v[:, 0] for v in x], hist, (U, C)
+    return min(j, max_it), [v if mu > 1 else v[:, 0] for v in x], hist, (U, C)

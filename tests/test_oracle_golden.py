@@ -267,3 +267,21 @@ def test_block_gcrodr_matches_reference(name, recycle):
     assert np.allclose([h[1] for h in hist], ref[:it], rtol=1e-4) and np.allclose([h[1] for h in hist2], ref[it:], rtol=1e-4)
     _close(sol, gu.vecs(g, "sol"), 1e-9, "solution")
     _close(sol2, gu.vecs(g, "sol2"), 1e-9, "second solution")
+
+
+@pytest.mark.parametrize("name", ["p40_bgcrodr_rhs_deflation_mu4", "z_p30_bgcrodr_rhs_deflation_mu4"])
+def test_block_gcrodr_with_rhs_deflation_matches_reference(name):
+    """Block GCRO-DR with -hpddm_deflation_tol (include/HPDDM_GCRODR.hpp:545-600): the last of the four right-hand sides is f_0 + 2 f_1,
+    the cycles run on blocks of three columns, the recycled space and its eigenproblems with them; 17 iterations (real), 32 (complex)
+    of the compiled reference, histories and solutions."""
+    from oracle import ras_oracle as ro
+    g = gu.load(name)
+    subs = gu.subdomains(g)
+    orc, opt = _setup(g, subs)
+    f = gu.vecs(g, "f")
+    it, sol, hist, _ = ro.bgcrodr(orc, f, tol=opt["tol"], max_it=opt["max_it"], restart=opt["restart"], recycle=2, variant=opt["variant"], deflation_tol=1e-6)
+    ref = g["history"][:, 1]
+    assert it == int(g["iterations_r0"][0]) == len(ref)
+    assert np.allclose([h[1] for h in hist], ref, rtol=1e-4)
+    _close(sol, gu.vecs(g, "sol"), 1e-8, "solution")
+    assert np.allclose(orc.compute_residual(sol, f), g["residual_r0"], rtol=1e-5)
