@@ -702,7 +702,13 @@ __device__ static inline void bush_steps(dbl2 (&ring)[PF][2], gcd_t P, int ld, i
     }
   }
 }
-constexpr int BUSH_PF = 4;
+#ifndef HPDDM_BUSH_PF
+#define HPDDM_BUSH_PF 4
+#endif
+#ifndef HPDDM_BUSH_OCC
+#define HPDDM_BUSH_OCC 4
+#endif
+constexpr int BUSH_PF = HPDDM_BUSH_PF;
 #ifdef HPDDM_BUSH_CLOCK // developer build (-DHPDDM_BUSH_CLOCK): thread 0 of every 37th bush records wall_clock64 (100 MHz) after its descriptor, after the burst, after the product and after the hand-over of every round; HPDDM_BUSH_CLOCK_DUMP=1 prints them at the 6th solve (profiles/r06_bush_clocks.txt)
 __device__ unsigned long long g_bush_clk[2][256][32];
 #define BCLK(dir, slot) do { if (blockIdx.x % 37 == 0 && blockIdx.x / 37 < 256 && threadIdx.x == 0 && (slot) < 32) g_bush_clk[dir][blockIdx.x / 37][slot] = wall_clock64(); } while (0)
@@ -736,7 +742,7 @@ __device__ static inline void bush_prime(dbl2 (&ring)[BUSH_PF][2], const TileReg
 }
 
 template <bool Z, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void sptrsv16_bush_fwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16)
+__global__ __launch_bounds__(64 * NW, HPDDM_BUSH_OCC) void sptrsv16_bush_fwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ b16, double *__restrict__ y16, double *__restrict__ S16)
 {
   constexpr int NT = 64 * NW; // threads of the workgroup: one bush, NW tiles per round
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -824,7 +830,7 @@ __global__ __launch_bounds__(64 * NW, 4) void sptrsv16_bush_fwd_kernel(const Bus
 }
 
 template <bool Z, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
+__global__ __launch_bounds__(64 * NW, HPDDM_BUSH_OCC) void sptrsv16_bush_bwd_kernel(const Bush16 *__restrict__ bushes, const BushTile16 *__restrict__ btiles, const int *__restrict__ bints, const double *__restrict__ y16, double *__restrict__ x16)
 {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds[];
