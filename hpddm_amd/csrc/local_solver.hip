@@ -220,6 +220,8 @@ void LocalSolver::numfact(const CsrView &A, int spd)
       }
       HH_CHECK(why.empty(), why);
     }
+    if (const char *fr = getenv("HPDDM_HIP_FORCE_REFINE")) // developer aid (tests): refinement steps on a factor that does not need them
+      if (refine_steps == 0 && atoi(fr) > 0) keep_matrix(A), refine_steps = std::min(atoi(fr), MAX_REFINE);
     settled_kind = (int)host.kind;
     settled_hash = pattern_hash;
     if (release_host) {
@@ -301,6 +303,7 @@ void LocalSolver::refine(const double *b, double *x, int mu, hipStream_t s)
 {
   const int       sc  = host.cplx ? 2 : 1;
   const long long cnt = (long long)host.n * mu * sc, rows = (long long)host.n * mu;
+  ensure_plan(); // (a subdomain of a Schwarz operator: its own plan is built on first use)
   r_res.alloc((size_t)cnt), r_dx.alloc((size_t)cnt);
   const dim3 g((unsigned)((rows + 255) / 256)), gc((unsigned)((cnt + 255) / 256));
   for (int it = 0; it < refine_steps; ++it) {

@@ -1001,9 +1001,9 @@ void Schwarz::call_numfact()
       for (auto &t : pool) t.join();
       HH_CHECK(err.empty(), err);
     }
+    any_refine = false;
     for (int s = 0; s < nsub; ++s) {
-      HH_CHECK(subs[s].ls->refine_steps == 0, "callNumfact: the factor of subdomain " + std::to_string(first + s) + " is not backward stable by itself (growth outside the diagonal tiles); its solves need iterative "
-                                               "refinement, which the Solver<K> boundary does (hpddm_hip_sub.hpp, HpddmHipSubdomainSolve) and the batched sweeps of this operator do not");
+      any_refine = any_refine || subs[s].ls->refine_steps > 0; // (a factor that is not backward stable by itself: its solves are refined, solve_factor)
       fs.push_back(&subs[s].ls->dev);
     }
     const double tsu2 = wall_seconds();
@@ -1606,6 +1606,15 @@ void Schwarz::gmv(const double *in, double *out, int mu)
   csrmm(in, out, mu, 1.0, 0.0, nullptr, true); // out = D A in, the partition of unity at the store of the product
   halo_sum_inplace(out, mu);
 }
+// x <- D x on the batched layout [subdomain][mu][n_s] (the partition of unity after a refined local solve)
+__global__ void k_scale_by_d(const long long *__restrict__ voff, const int *__restrict__ nn, int nsub, const double *__restrict__ d, double *__restrict__ x, int mu)
+{
+  for (int s = 0; s < nsub; ++s) {
+    const long long v0 = voff[s];
+    const int       n  = nn[s];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)n * mu; t += (long long)gridDim.x * blockDim.x) x[v0 * mu + t] *= d[v0 + t % n];
+  }
+}
 void Schwarz::local_solve(const double *in, double *out, int mu)
 {
   HH_CHECK(factored && type != PRC_NO, "local solve before CallNumfact");
@@ -1616,7 +1625,23 @@ void Schwarz::solve_factor(const double *in, double *out, int mu, bool scaled)
   // the batched SpTRSV.  Complex operators: the vectors of the embedding ARE arrays of (re, im) pairs, which is what the
   // complex plans take (n / 2 complex rows per subdomain, mu complex right-hand sides).  scaled: out = D A^{-1} in, the partition of
   // unity folded into the permutation pass that ends the solve (SolvePlan::out_scale)
-  batched_sptrsv(in, out, mu, scaled);
+  if (!any_refine) {
+    batched_sptrsv(in, out, mu, scaled);
+    return;
+  }
+  // some local factors need iterative refinement (LocalSolver::refine: the probe solve of numfact found growth that contracts): the
+  // batched sweep without the partition of unity, the steps of those subdomains through their own plans, then the scaling
+  hipStream_t   st  = library_stream();
+  const double *rhs = in;
+  if (in == out) { // (the right-hand side is needed again)
+    refine_rhs.alloc((size_t)ntot * mu);
+    HIP_OK(hipMemcpyAsync(refine_rhs.p, in, sizeof(double) * ntot * mu, hipMemcpyDeviceToDevice, st));
+    rhs = refine_rhs.p;
+  }
+  batched_sptrsv(rhs, out, mu, false);
+  for (int s = 0; s < nsub; ++s) // (complex operators: mu complex right-hand sides of n / 2 complex rows -- the same doubles)
+    if (subs[s].ls->refine_steps > 0) subs[s].ls->refine(rhs + voff[s] * mu, out + voff[s] * mu, mu, st);
+  if (scaled) hipLaunchKernelGGL(k_scale_by_d, dim3((unsigned)std::min<long long>(4096, ((long long)ntot * mu + 255) / 256)), dim3(256), 0, st, voff_d.p, n_d.p, nsub, d_d.p, out, mu);
 }
 
 void Schwarz::build_plans()

@@ -96,6 +96,8 @@ struct Schwarz {
   void                  build_halo_lists(); // host only
   std::vector<SchwarzSub>       subs;
   std::map<std::string, double> opt;
+  bool                          any_refine = false; // a local factor needs iterative refinement (LocalSolver::refine_steps): solve_factor takes the steps
+  DevBuf<double>                refine_rhs;
   std::mutex                    opt_mutex; // solve_gevp of different subdomains may run on different host threads
   std::string                   dump_prefix; // -hpddm_dump_matrices=<prefix>: written when the operator is destroyed
   PrcndtnrType                  type = PRC_GE;

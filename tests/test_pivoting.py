@@ -126,6 +126,43 @@ def test_iterative_refinement_when_the_factor_is_not_backward_stable(monkeypatch
     S.destroy()
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_refinement_inside_the_batched_sweeps_of_an_operator(cplx, monkeypatch):
+    """the local solves of a Schwarz operator refine as well (Schwarz::solve_factor: the batched sweep, then the steps of the subdomains
+    that need them through their own plans, then the partition of unity).  Forced here on factors that do not need it
+    (HPDDM_HIP_FORCE_REFINE, a developer aid): the apply and the Krylov solve of the operator are those of the plain sweeps."""
+    from hpddm_amd.generate import generate3d, generate_helmholtz3d
+    if cplx:
+        subs = generate_helmholtz3d(12, 8, wavenumber=2.0 * np.pi * 3.0)
+        build = lambda: hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_method oras", multiplicity=False)
+    else:
+        subs = generate3d(12, 8, 1, sym=True, rhs="smooth")
+        build = lambda: hpddm.schwarz_from_subdomains(subs)   # (no -hpddm_operator_spd: L D L^T, the kind the probe looks at)
+    outs = []
+    for force in (None, "2"):
+        if force:
+            monkeypatch.setenv("HPDDM_HIP_FORCE_REFINE", force)
+        A, d = build()
+        if cplx:
+            for s_, sd in enumerate(subs):
+                A.set_optimized_matrix(s_, sd["n"], sd["ia"], sd["ja"], sd["a_opt"], False)
+        A.call_numfact()
+        if cplx:
+            rng = np.random.default_rng(4)
+            f = [np.asfortranarray(rng.standard_normal((sd["n"], 2)) + 1j * rng.standard_normal((sd["n"], 2))) for sd in subs]
+        else:
+            f = [s["f"] for s in subs]
+        ap = A.apply(f)
+        it, sol = A.solve(f)
+        outs.append((ap, it, sol, A.subdomain(0).refine_steps()))
+        A.destroy()
+    (a0, it0, s0, r0), (a1, it1, s1, r1) = outs
+    assert r0 == 0 and r1 == 2 and it0 == it1
+    scale = max(np.abs(v).max() for v in a0)
+    assert max(np.abs(x - y).max() for x, y in zip(a0, a1)) <= 1e-12 * scale
+    assert max(np.abs(x - y).max() for x, y in zip(s0, s1)) <= 1e-5 * max(np.abs(v).max() for v in s0)   # (two Krylov solves to 1e-6 on applies that differ in the last bits)
+
+
 def test_what_static_pivoting_cannot_do_is_refused():
     lap = _poisson3d(4)
     for blk in (np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([[0.0, 0.0], [1.0, 2.0]])):   # singular tiles
