@@ -212,8 +212,11 @@ static inline bool ldlf2(int nb, S *T, long ld)
 // tile that ended at position i; *swapped is set when any row moved.  false: zero / collapsed pivot (the whole column below is
 // zero too, or the pivot is negligible against its own row) or NaN.
 static constexpr double PIVOT_THRESHOLD = 0.01;
+// perturb > 0: a pivot that fails the test (not NaN) is REPLACED by +-perturb (static pivoting: the factorisation is that of a
+// matrix perturbed by that much in one entry; the probe solve of numfact and its iterative refinement decide whether the result
+// serves) and counted in *nperturbed.
 template <class S>
-static inline bool getf2(int nb, S *T, long ld, int *piv, bool *swapped)
+static inline bool getf2(int nb, S *T, long ld, int *piv, bool *swapped, double perturb = 0.0, int *nperturbed = nullptr)
 {
   for (int i = 0; i < nb; ++i) piv[i] = i;
   for (int j = 0; j < nb; ++j) {
@@ -228,10 +231,15 @@ static inline bool getf2(int nb, S *T, long ld, int *piv, bool *swapped)
       std::swap(piv[j], piv[imax]);
       *swapped = true;
     }
-    const S p    = T[(long)j * ld + j];
+    S       p    = T[(long)j * ld + j];
     double  cmax = 0.0;
     for (int i = j + 1; i < nb; ++i) cmax = std::max(cmax, std::max(std::abs(T[(long)i * ld + j]), std::abs(T[(long)j * ld + i])));
-    if (!(std::abs(p) > PIVOT_TOL * cmax) || p == S(0)) return false; // zero, collapsed or NaN
+    if (!(std::abs(p) > PIVOT_TOL * cmax) || p == S(0) || std::abs(p) < perturb) { // zero, collapsed or NaN (static pivoting: below the perturbation)
+      if (!(perturb > 0.0) || std::abs(p) != std::abs(p) || cmax != cmax) return false;
+      p                   = std::real(p) < 0.0 ? S(-perturb) : S(perturb);
+      T[(long)j * ld + j] = p;
+      if (nperturbed) ++*nperturbed;
+    }
     const S inv = S(1) / p;
     for (int i = j + 1; i < nb; ++i) {
       const S l          = T[(long)i * ld + j] * inv;

@@ -76,6 +76,8 @@ struct HostFactor {
   double              t_order = 0, t_symbolic = 0, t_numeric = 0;
   double              t_plain = 0; // seconds of t_numeric spent keeping the plain factor (keep_plain: allocation, copies out of the fronts / off the device)
   int                 info = 0; // 0 ok, >0: zero/negative pivot in that (1-based) block
+  double              perturb = 0.0; // > 0: LU on the host replaces a pivot its tile cannot supply by +-perturb (static pivoting, the last rung of LocalSolver::numfact) ...
+  int                 perturbed = 0; // ... and counts them
 };
 
 // CSR input as HPDDM hands it over (include/HPDDM_matrix.hpp:32-394): sym => only the lower triangle is stored.

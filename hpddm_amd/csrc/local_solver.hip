@@ -137,6 +137,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
 {
   analyse(A);
   refine_steps = 0;
+  host.perturb = 0.0, host.perturbed = 0;
   FactKind kind;
   // complex scalars: a complex SYMMETRIC matrix (MatrixCSR::sym_, or equal values across the diagonal) is factorised as L D L^T
   // with plain transposes -- also when -hpddm_operator_spd is set --, anything else (Hermitian included) as LU
@@ -182,6 +183,24 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     device_levels(FACT_LU);
     factor_numeric(A, FACT_LU, host, devlev.get(), first_dev);
   }
+  // the last rung: a tile without a usable pivot -- MUMPS / PARDISO would take a row from outside the supernode (delayed pivots:
+  // include/HPDDM_MUMPS.hpp:228-291), the static structure cannot --: LU once more, on the host levels only, with the pivots that are
+  // zero, collapsed or below sqrt(eps) max |a_ij| REPLACED by +- that (static pivoting as in SuperLU_DIST / PARDISO).  What comes out
+  // factorises a matrix perturbed in a few entries; the probe solve and its iterative refinement decide whether it serves (a singular
+  // matrix fails there).  Taken when LU breaks down, and when its factor fails the probe beyond what refinement repairs
+  auto perturbed_lu = [&]() {
+    double      amax = 0.0;
+    const idx_t nnz  = A.ia[A.n] - A.base;
+    for (idx_t q = 0; q < nnz; ++q) amax = std::max(amax, A.cplx ? std::hypot(A.a[2 * (size_t)q], A.a[2 * (size_t)q + 1]) : std::abs(A.a[q]));
+    host.perturb = 1.4901161193847656e-08 * (amax > 0.0 ? amax : 1.0);
+    host.perturbed = 0;
+    if (devlev) devlev->finish();
+    devlev.reset();
+    first_dev = (idx_t)host.level_ptr.size() - 1; // (every level on the host)
+    factor_numeric(A, FACT_LU, host, nullptr, first_dev);
+  };
+  const bool may_perturb = !getenv("HPDDM_HIP_NO_PERTURB") && !(host.keep_plain);
+  if (host.info != 0 && host.kind == FACT_LU && may_perturb) perturbed_lu();
   HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivot inside its diagonal tiles either: the matrix is singular, or needs rows from outside the supernode)");
   uploaded = false;
   if (!host_only) {
@@ -210,7 +229,15 @@ void LocalSolver::numfact(const CsrView &A, int spd)
         if (devlev) devlev->finish();
         why = probe(A, host.kind);
       }
-      if (!why.empty() && probe_berr <= 1.0e-3 && probe_berr == probe_berr && !getenv("HPDDM_HIP_NO_REFINE")) {
+      auto refinable = [&]() { return probe_berr <= 1.0e-3 && probe_berr == probe_berr && !getenv("HPDDM_HIP_NO_REFINE"); };
+      if (!why.empty() && host.kind == FACT_LU && host.perturb == 0.0 && may_perturb && !refinable()) {
+        // small pivots that did not break down but let the entries grow beyond repair: static pivoting (above), then the probe again
+        perturbed_lu();
+        HH_CHECK(host.info == 0, why);
+        to_device();
+        why = probe(A, host.kind);
+      }
+      if (!why.empty() && refinable()) {
         // not backward stable, but not far off: does the error contract?  The probe once more with 1 .. MAX_REFINE steps of refinement
         // (on the device, through the solve every caller will get)
         keep_matrix(A);
@@ -347,6 +374,14 @@ std::string LocalSolver::probe(const CsrView &A, FactKind kind)
     x0[i]          = Z(0.5 + (t - std::floor(t)), A.cplx ? (u - std::floor(u)) - 0.5 : 0.0);
   }
   spmv(x0.data(), b.data(), rowsum.data());
+  // static pivoting replaced pivots (HostFactor::perturbed): the factor is that of a nearby NONSINGULAR matrix whatever A is, and a
+  // right-hand side A x0 is consistent by construction -- a singular A would pass.  The probe then takes a generic right-hand side, x0
+  // itself scaled to the size of A x0: no x makes its residual small unless A is nonsingular (and the refinement converges)
+  if (host.perturbed > 0) {
+    double bn0 = 0.0, xn0 = 0.0;
+    for (idx_t i = 0; i < n; ++i) bn0 = std::max(bn0, std::abs(b[i])), xn0 = std::max(xn0, std::abs(x0[i]));
+    for (idx_t i = 0; i < n; ++i) b[i] = x0[i] * (bn0 > 0.0 ? bn0 / xn0 : 1.0);
+  }
   {
     // the solver's vectors: real arrays, or interleaved (re, im) pairs
     std::vector<double> bb((size_t)n * sc), xx((size_t)n * sc);

@@ -625,7 +625,12 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
         dense::gemm(nb, jb, kb, -1.0, Gn + (long)w * ld, ld, Pk, ld, true, Gn + (long)w * ld + kb, ld, par);
         int  piv[NB];
         bool sw = false;
-        ok      = dense::getf2(jb, Pk + kb, ld, piv, &sw);
+        int npert = 0;
+        ok        = dense::getf2(jb, Pk + kb, ld, piv, &sw, hf.perturb, &npert);
+        if (npert) {
+#pragma omp atomic
+          hf.perturbed += npert;
+        }
         if (ok && sw) {
           swapped = true;
           for (idx_t i = 0; i < jb; ++i) snp[kb + i] = (int)kb + piv[i];

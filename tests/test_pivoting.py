@@ -163,6 +163,45 @@ def test_refinement_inside_the_batched_sweeps_of_an_operator(cplx, monkeypatch):
     assert max(np.abs(x - y).max() for x, y in zip(s0, s1)) <= 1e-5 * max(np.abs(v).max() for v in s0)   # (two Krylov solves to 1e-6 on applies that differ in the last bits)
 
 
+def test_perturbed_pivots_for_a_tile_without_a_usable_one(monkeypatch):
+    """a supernode whose diagonal tile holds no usable pivot -- MUMPS / PARDISO delay such a pivot to an ancestor, the static structure
+    cannot --: the last rung of numfact factorises once more as LU on the host with the pivot REPLACED by +-sqrt(eps) max |a_ij|
+    (static pivoting), and the probe solve with its iterative refinement decides whether that serves.  Supernodes of ONE column
+    (leaf_size = 1) so that a vertex with a collapsed diagonal entry has no row to exchange with; against SuperLU at 1e-9.
+    HPDDM_HIP_NO_PERTURB: refused as before.  A singular matrix is still refused (next test)."""
+    A = _poisson3d(4).tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    S = hpddm.Subdomain(leaf_size=1)   # the supernodes of this pattern (the ordering sees the pattern only): one of a single column
+    S.numfact(n, A.indptr, A.indices, A.data, sym=False)
+    blk, perm = S.export("blk_ptr"), S.export("perm")
+    S.destroy()
+    single = [k for k in range(len(blk) - 1) if blk[k + 1] - blk[k] == 1]
+    assert single, "no supernode of one column"
+    v = int(perm[blk[single[0]]])
+    A = A.tolil()
+    A[v, v] = 1e-20
+    A = A.tocsr()
+    A.sort_indices()
+    lu = spl.splu(A.tocsc())
+    monkeypatch.setenv("HPDDM_HIP_NO_PERTURB", "1")
+    S = hpddm.Subdomain(leaf_size=1)
+    with pytest.raises(HpddmHipError, match="pivot"):
+        S.numfact(n, A.indptr, A.indices, A.data, sym=False)
+    S.destroy()
+    monkeypatch.delenv("HPDDM_HIP_NO_PERTURB")
+    S = hpddm.Subdomain(leaf_size=1)
+    S.numfact(n, A.indptr, A.indices, A.data, sym=False)
+    assert S.info()["kind"] == 2 and 1 <= S.refine_steps() <= 3, (S.info()["kind"], S.refine_steps())
+    rng = np.random.default_rng(9)
+    for mu in (1, 4):
+        b = np.asfortranarray(rng.random((n, mu)) if mu > 1 else rng.random(n))
+        x = S.solve(b)
+        ref = lu.solve(np.asarray(b))
+        assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max(), (mu, np.abs(x - ref).max() / np.abs(ref).max())
+    S.destroy()
+
+
 def test_what_static_pivoting_cannot_do_is_refused():
     lap = _poisson3d(4)
     for blk in (np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([[0.0, 0.0], [1.0, 2.0]])):   # singular tiles
