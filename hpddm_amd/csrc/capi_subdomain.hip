@@ -209,6 +209,7 @@ long long HpddmHipSubdomainExport(const HpddmHipSubdomain *S, const char *which,
     if (k == "s_off") return ints(h.s_off);
     if (k == "ps_off") return ints(h.ps_off);
     if (k == "c_off") return ints(h.c_off);
+    if (k == "w_off") return ints(S->ls.dev.w_off); // (device: offsets of the roots' W, -1 elsewhere; empty without device levels)
     if (k == "cptr") return ints(h.cptr);
     if (k == "crel") return ints(h.crel);
     if (k == "cs_off") return ints(h.cs_off);

@@ -132,6 +132,20 @@ struct Bush16 {
   int           int0, nlrow;          // the bush's index list in SolvePlan::bush_int: nlrow local rows of its supernodes, then crel and rows of the root (nbr each)
 };
 
+// One right-hand side, a root of the tree with W = inv(L)^T D^{-1} inv(L) at hand (DeviceFactor::W): x_J = W f_J in ONE pass over the
+// lower triangle of W -- a tile of 128 x 128 entries gives the partial sums of its 128 rows (entries on and left of the diagonal) AND of
+// its 128 columns (entries strictly below the diagonal, the mirror images), a second small launch adds the partial sums of every entry
+// in a fixed order.  Forward and backward tiles of the root are skipped by that sweep (they sit at the head of their lists).
+struct RootTile {
+  const double *W;    // the root's W
+  long long     part; // where the tile writes: 128 row sums, then 128 column sums (SolvePlan::root_part)
+  int           sn, ld, w, r0, c0, pad;
+};
+struct RootBlock { // the reduction: 128 entries of x_J
+  long long part;  // the root's first tile in root_part
+  int       sn, w, bi, nblk;
+};
+
 struct Tile {
   int sn;     // index into the batch SnDesc array
   int r0;     // forward: first row of the tile; backward: first column
@@ -159,6 +173,12 @@ struct DeviceFactor {
   std::vector<idx_t>   blk_ptr, ldw, height, level_ptr, level_blk, nchild, lb_nnzr, lb_nnzc;
   std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
   std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off, c_off, cs_off, pcs_off;
+  // roots of the tree (no rows below), symmetric kinds, real scalars, factorised on the device: W = inv(L)^T D^{-1} inv(L), lower
+  // triangle, row-major with the leading dimension of the panel (numeric_device.hip); w_off[k] >= 0: there.  One right-hand side
+  // takes such a root in one pass over W (sptrsv.hip: root tiles)
+  DevBuf<double>       W;
+  std::vector<int64_t> w_off, w_plan;
+  bool                 w_planned = false, want_root_w = true;
   const Symbolic      *sym = nullptr; // the analysis on the host (HostFactor::sym of the solver that owns both): parents and rows, for the plan builder
   const std::vector<idx_t> *crel_h = nullptr; // ... and HostFactor::crel
   int64_t              s_size = 0, u_size = 0;
@@ -192,6 +212,12 @@ struct SolvePlan {
   DevBuf<BushTile16> bush_tile;
   DevBuf<int>        bush_int;
   int                nbush = 0, bush_lds = 0, bush_nw = 4; // ... the LDS bytes of the largest, the wavefronts (= tiles per round) of a bush
+  // one right-hand side, real scalars: the roots that have their W (above) -- per level the tiles of the one-pass product and the blocks of
+  // its reduction; lev_root[0 / 1][l]: the forward / backward block tiles of those roots, at the HEAD of the level's lists (skipped)
+  DevBuf<RootTile>   root_tile;
+  DevBuf<RootBlock>  root_block;
+  DevBuf<double>     root_part;
+  std::vector<int>   lev_rt_ptr, lev_rt_end, lev_rb_ptr, lev_rb_end, lev_root[2];
   std::vector<int>   lev_bwd16;               // per level: the BWD_BLOCK tiles the 16-column engine takes (those of the bushes' supernodes sit behind them)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;

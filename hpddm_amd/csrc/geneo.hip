@@ -286,6 +286,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
     std::vector<double> ta;
     shifted_lower(-threshold, tia, tja, ta);
     LocalSolver est;
+    est.dev.want_root_w = false; // (block solves only: the one-pass root of the single-right-hand-side sweeps is not wanted)
     est.leaf_size    = (int)getopt("leaf_size", 32);
     est.release_host = true;
     CsrView V{n, tia.data(), tja.data(), ta.data(), true, 0};
@@ -302,6 +303,7 @@ void Schwarz::solve_gevp(int s, int n, const int *ia, const int *ja, const doubl
   std::vector<double> sa;
   shifted_lower(sigma, sia, sja, sa);
   LocalSolver shifted;
+  shifted.dev.want_root_w = false; // (the eigensolver sweeps blocks of right-hand sides: no one-pass root, sptrsv.hip)
   shifted.leaf_size    = (int)getopt("leaf_size", 32);
   shifted.release_host = true;
   lap(0);
@@ -705,6 +707,7 @@ void Schwarz::solve_gevp_z(int s, int n, const int *ia, const int *ja, const dou
     sia[i + 1] = (int)sja.size();
   }
   LocalSolver shifted;
+  shifted.dev.want_root_w = false; // (the eigensolver sweeps blocks of right-hand sides: no one-pass root, sptrsv.hip)
   shifted.leaf_size    = (int)getopt("leaf_size", 32);
   shifted.release_host = true;
   {

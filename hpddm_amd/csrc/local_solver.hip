@@ -156,6 +156,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
   const bool                    on_device = !host_only && !getenv("HPDDM_HIP_HOST_FACTOR");
   auto                          device_levels = [&](FactKind kd) {
     devlev.reset();
+    dev.w_off.clear(), dev.w_planned = false; // (the W of the roots belongs to the factorisation that built it)
     first_dev = (idx_t)host.level_ptr.size() - 1;
     if (!on_device || (kd == FACT_LU && host.keep_plain)) return; // (the LU tile kernels of the device levels do not keep the multipliers)
     first_dev = pick_first_device_level(host);
@@ -196,6 +197,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     host.perturbed = 0;
     if (devlev) devlev->finish();
     devlev.reset();
+    dev.w_off.clear(), dev.w_planned = false;
     first_dev = (idx_t)host.level_ptr.size() - 1; // (every level on the host)
     factor_numeric(A, FACT_LU, host, nullptr, first_dev);
   };

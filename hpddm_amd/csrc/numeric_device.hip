@@ -653,6 +653,35 @@ __device__ static inline void set_diag_tiles_body(const GOp &o, int t)
 }
 HH_GROUPED(k_set_diag_tiles, set_diag_tiles_body<T>, 256, template <class T>)
 
+// dst(i, r) = src(r, i) * s(r) for r >= i, 0 below (src lower triangular, w x w; dst w x w with leading dimension w): the transposed,
+// column-scaled copy of a top block that feeds W = inv(L)^T D^{-1} inv(L) of a root front (factor_front).  p0 src, p1 dst, p2 s (or
+// null); l0 ld of src; i0 w; block = one 32 x 32 tile of dst (i6 tiles per row)
+template <class T>
+__device__ static inline void transpose_scale_body(const GOp &o, int blk)
+{
+  __shared__ T tile[32][33];
+  const T *__restrict__ src = (const T *)o.p0;
+  T       *dst = (T *)o.p1;
+  const T *__restrict__ sc = (const T *)o.p2;
+  const int w = o.i0, nt = o.i6, ti = blk / nt, tr = blk % nt; // tile (ti, tr) of dst = rows 32 ti.., columns (= rows of src) 32 tr..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows of 32 per pass
+  for (int q = ty; q < 32; q += 8) { // src rows r = 32 tr + q, columns i = 32 ti + tx
+    const int r = 32 * tr + q, i = 32 * ti + tx;
+    T         v = scalar<T>(0.0);
+    if (r < w && i < w && r >= i) {
+      v = src[(long long)r * o.l0 + i];
+      if (sc) v = v * sc[r];
+    }
+    tile[q][tx] = v;
+  }
+  __syncthreads();
+  for (int q = ty; q < 32; q += 8) {
+    const int i = 32 * ti + q, r = 32 * tr + tx;
+    if (i < w && r < w) dst[(long long)i * w + r] = tile[tx][q];
+  }
+}
+HH_GROUPED(k_transpose_scale, transpose_scale_body<T>, 256, template <class T>)
+
 struct GemmBatch { // a batch of products with strided operands (1 = a single product); strides in scalars
   int       count = 1;
   long long sA = 0, sB = 0, sC = 0;
@@ -661,7 +690,7 @@ struct GemmBatch { // a batch of products with strided operands (1 = a single pr
 enum OpKind : int {
   OP_GEMM64_N, OP_GEMM64_T, OP_BIG_64_128_N, OP_BIG_64_128_T, OP_BIG_128_128_N, OP_BIG_128_128_T, OP_BIG_128_64_N, OP_BIG_128_64_T,
   OP_POTF2, OP_LDLF2, OP_GETF2, OP_SCALE_COLS, OP_EXTRACT_DINV, OP_SPLIT_U11, OP_EXTEND_ADD, OP_EXTEND_ADD_FULL, OP_COPY2D, OP_ZERO_UPPER,
-  OP_SCATTER_ADD, OP_SET_DIAG_TILES, OP_KINDS
+  OP_SCATTER_ADD, OP_SET_DIAG_TILES, OP_TRANSPOSE_SCALE, OP_KINDS
 };
 
 // C(M x N) = (beta1 ? C : 0) + alpha A(M x K) op(B): every argument in SCALARS of CS doubles (CS = 2: (re, im) pairs, the kernels
@@ -1037,6 +1066,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void begin(HostFactor &h, size_t cb_doubles, idx_t first_level) override
   {
     hf = &h;
+    D.w_off.assign((size_t)h.sym.nblk, -1), D.w_planned = false; // (the W of the roots: rebuilt by this factorisation, factor_front)
     HH_CHECK((h.cplx ? 2 : 1) == CS, "numfact (device levels): scalar type of the factor and of the device levels differ");
     scr    = DeviceScratch::acquire();
     locked = true;
@@ -1190,6 +1220,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     case OP_ZERO_UPPER: HH_LAUNCH_T(k_zero_upper, 256, 0, T); break;
     case OP_SCATTER_ADD: HH_LAUNCH_T(k_scatter_add, 256, 0, CS); break;
     case OP_SET_DIAG_TILES: HH_LAUNCH_T(k_set_diag_tiles, 256, 0, T); break;
+    case OP_TRANSPOSE_SCALE: HH_LAUNCH_T(k_transpose_scale, 256, 0, T); break;
     default: HH_CHECK(false, "numfact (device levels): unknown operation");
     }
 #undef HH_LAUNCH_T
@@ -1503,6 +1534,30 @@ struct DeviceLevelsImpl : public DeviceLevels {
     if (lu) {
       invert_top(G, ld, (int)w, tinv3); // inverse of U11^T: its diagonal tiles are inv(U_T)^T
       mult_bottom(G, ld, (int)w, (int)nb);
+    }
+    // ---- a ROOT of the tree (no rows below) of a symmetric kind, real scalars: W = inv(L)^T D^{-1} inv(L), the inverse of its Schur
+    // complement, lower triangle.  The sweeps of one right-hand side then take the root in ONE pass over W (x_J = W f_J: sptrsv.hip,
+    // root tiles) instead of one pass over inv(L) forward and one backward -- half the bytes of the largest panels of the factor ----
+    if constexpr (CS == 1) {
+      if (nb == 0 && !lu && !rec && D.want_root_w && w >= 256 && !getenv("HPDDM_HIP_NO_ROOT_W")) {
+        if (D.w_off.empty() || (idx_t)D.w_off.size() != s.nblk) D.w_off.assign((size_t)s.nblk, -1);
+        if (!D.w_planned) { // every root that may come (those of the host levels never do): one allocation
+          long long tot = 0;
+          D.w_plan.assign((size_t)s.nblk, -1);
+          for (idx_t q = 0; q < s.nblk; ++q)
+            if (s.row_ptr[q + 1] == s.row_ptr[q] && s.blk_ptr[q + 1] - s.blk_ptr[q] >= 256) D.w_plan[q] = tot, tot += (long long)(s.blk_ptr[q + 1] - s.blk_ptr[q]) * hf->ldw[q];
+          D.W.alloc((size_t)tot);
+          D.w_planned = true;
+        }
+        T *Wk = reinterpret_cast<T *>(D.W.p) + D.w_plan[k];
+        {
+          GOp o  = op(OP_TRANSPOSE_SCALE, (int)(((w + 31) / 32) * ((w + 31) / 32)));
+          o.p0 = P, o.p1 = tmp.p, o.p2 = kind == FACT_LDLT ? reinterpret_cast<T *>(scr->dinv_all.p) + c0 : nullptr, o.l0 = ld, o.i0 = (int)w, o.i6 = (int)((w + 31) / 32);
+          emit(o);
+        }
+        gemm_(false, (int)w, (int)w, (int)w, 1.0, cd(tmp.p), (long long)w, cd(P), ld, md(Wk), ld, false, true, 0, 0, true, false);
+        D.w_off[k] = D.w_plan[k];
+      }
     }
     cb[k] = C;
   }

@@ -1317,6 +1317,98 @@ __global__ __launch_bounds__(WG_THREADS, (MU == 1 && !HAS_BLOCK) ? (PAIR ? 6 : 8
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// One right-hand side, real scalars, a root J of the tree whose W = inv(L_JJ)^T D^{-1} inv(L_JJ) is at hand (device.hpp: RootTile):
+// x_J = W f_J, f_J = b_J - (what the children handed up), in ONE pass over the lower triangle of W where the level sweeps read
+// inv(L_JJ) twice (forward y_J = inv(L_JJ) f_J, backward x_J = inv(L_JJ)^T D^{-1} y_J): the root is the largest panel of the factor,
+// 4.8 % of its entries at 129^3.  A workgroup takes 128 x 128 entries: every wavefront 32 rows, a lane two columns of every row (one
+// 1 KiB load per row and wavefront, four rows in flight); an entry W(r, c), c <= r, goes into the sum of row r with f(c) and -- below
+// the diagonal -- into the sum of column c with f(r), its mirror image.  Row sums: in-register reduction over the 64 lanes; column
+// sums: private to the lane, added over the four wavefronts through LDS in wavefront order.  The tile writes 128 + 128 partial sums;
+// k_root_reduce adds the partial sums of every entry, left to right then top to bottom: bitwise reproducible.
+__global__ __launch_bounds__(WG_THREADS, 4) void k_root_sym(const SnDesc *__restrict__ sns, const RootTile *__restrict__ tiles, const double *__restrict__ b, const double *__restrict__ S, long long stot, double *__restrict__ part, int mu_total, int nu0)
+{
+  __shared__ double fr[128], fc[128], cred[4][128];
+  const RootTile t = tiles[blockIdx.x];
+  const SnView   d = view(sns[t.sn]);
+  const int      tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double  *bb = b + d.voff * mu_total + (long long)nu0 * d.n;
+  const double  *Sb = S + d.soff + (long long)nu0 * stot;
+  { // f on the tile's columns (threads 0 .. 127) and rows (128 .. 255): b_J minus the slot rows of J, dense
+    const int pos = (tid < 128 ? t.c0 + tid : t.r0 + tid - 128), pc = min(pos, t.w - 1);
+    double    v[1] = {bb[d.c0 + pc]};
+    slot_sub<1>(d, pc, Sb, stot, v);
+    if (pos >= t.w) v[0] = 0.0;
+    if (tid < 128) fc[tid] = v[0];
+    else fr[tid - 128] = v[0];
+  }
+  __syncthreads();
+  const bool   diag = t.r0 == t.c0;
+  const int    c = t.c0 + 2 * lane; // this lane's two columns
+  const double f0 = fc[2 * lane], f1 = fc[2 * lane + 1];
+  const gcd_t  Wp = (gcd_t)t.W + c;
+  double       cx = 0.0, cy = 0.0;
+  double      *prow = part + t.part, *pcol = prow + 128;
+  // the 32 rows of the wavefront, eight at a time with the next eight requested before the current ones are used (8 - 16 KB in flight
+  // per wavefront); the eight row sums of a lane are reduced by ONE butterfly over the 64 lanes (the number of values a lane holds halves
+  // at every step: 4 + 2 + 1 exchanges, then three more on the one value left, instead of six per row)
+  auto load8 = [&](int gg, dbl2(&a)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = t.r0 + 32 * wv + 8 * gg + q;
+      a[q]        = (gg < 4 && r < t.w && c < t.w && (!diag || c <= r)) ? *(gcd2_t)(Wp + (long long)r * t.ld) : dbl2{0.0, 0.0};
+    }
+  };
+  dbl2 a[8], an[8];
+  load8(0, a);
+#pragma unroll 1
+  for (int gg = 0; gg < 4; ++gg) {
+    load8(gg + 1, an);
+    double s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int    rl = 32 * wv + 8 * gg + q, r = t.r0 + rl;
+      const double ax = a[q].x, ay = (!diag || c + 1 <= r) ? a[q].y : 0.0; // (the entry right of the diagonal shares its 16 bytes with the diagonal one)
+      s[q]            = fma(ax, f0, ay * f1);
+      const double fv = fr[rl];
+      cx              = fma((!diag || c < r) ? ax : 0.0, fv, cx); // strictly below the diagonal: the mirror image
+      cy              = fma((!diag || c + 1 < r) ? ay : 0.0, fv, cy);
+    }
+    { // 8 -> 4 -> 2 -> 1 values: a lane keeps the half whose index bit matches its own bit `off` and sends the other half
+      const bool u1 = (lane & 1) != 0, u2 = (lane & 2) != 0, u4 = (lane & 4) != 0;
+      double     h4[4], h2[2], h1;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) h4[v] = (u1 ? s[v + 4] : s[v]) + __shfl_xor(u1 ? s[v] : s[v + 4], 1);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) h2[v] = (u2 ? h4[v + 2] : h4[v]) + __shfl_xor(u2 ? h4[v] : h4[v + 2], 2);
+      h1 = (u4 ? h2[1] : h2[0]) + __shfl_xor(u4 ? h2[0] : h2[1], 4);
+      h1 += __shfl_xor(h1, 8);
+      h1 += __shfl_xor(h1, 16);
+      h1 += __shfl_xor(h1, 32);
+      if (lane < 8) prow[32 * wv + 8 * gg + (((lane & 1) << 2) | (lane & 2) | ((lane & 4) >> 2))] = h1; // lane bits (0, 1, 2) = row bits (2, 1, 0)
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = an[q];
+  }
+  cred[wv][2 * lane] = cx, cred[wv][2 * lane + 1] = cy;
+  __syncthreads();
+  if (tid < 128) pcol[tid] = ((cred[0][tid] + cred[1][tid]) + cred[2][tid]) + cred[3][tid];
+}
+// x_J(i) = (the row sums of its tiles, left to right) + (the column sums of the tiles below and on the diagonal, top to bottom)
+__global__ __launch_bounds__(128) void k_root_reduce(const SnDesc *__restrict__ sns, const RootBlock *__restrict__ blocks, const double *__restrict__ part, double *__restrict__ x, int mu_total, int nu0)
+{
+  const RootBlock rb = blocks[blockIdx.x];
+  const SnView    d  = view(sns[rb.sn]);
+  const int       li = threadIdx.x, i = 128 * rb.bi + li;
+  if (i >= rb.w) return;
+  const double *p = part + rb.part;
+  double        v = 0.0;
+  const long long trow = (long long)rb.bi * (rb.bi + 1) / 2;
+  for (int cb = 0; cb <= rb.bi; ++cb) v += p[(trow + cb) * 256 + li];
+  for (int r2 = rb.bi; r2 < rb.nblk; ++r2) v += p[((long long)r2 * (r2 + 1) / 2 + rb.bi) * 256 + 128 + li];
+  x[d.voff * mu_total + (long long)nu0 * d.n + d.c0 + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 
 // one-time: FT = F^T for the narrow panels (one workgroup per panel; reads strided, writes coalesced)
 __global__ void k_transpose_panels(const double *__restrict__ F, double *__restrict__ FT, const long long *__restrict__ foff, const long long *__restrict__ ftoff, const int *__restrict__ hh, const int *__restrict__ ww, const int *__restrict__ ldws, const int *__restrict__ ldhs)
@@ -1797,6 +1889,46 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_lds[kd].assign(nlev, 0);
   }
   lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
+  // ---- roots with their W (DeviceFactor::W): tiles of the one-pass product of the single-right-hand-side sweep ----
+  std::vector<char> sn_rootw(descs.size(), 0);
+  lev_rt_ptr.assign(nlev, 0), lev_rt_end.assign(nlev, 0), lev_rb_ptr.assign(nlev, 0), lev_rb_end.assign(nlev, 0);
+  lev_root[0].assign(nlev, 0), lev_root[1].assign(nlev, 0);
+  {
+    std::vector<std::vector<RootTile>>  rt(nlev);
+    std::vector<std::vector<RootBlock>> rbk(nlev);
+    long long part = 0, base = 0;
+    const bool use_w = envi("HPDDM_HIP_ROOT_W", 1) != 0;
+    for (size_t f = 0; f < fs.size(); ++f) {
+      const DeviceFactor &D = *fs[f];
+      if (use_w && !D.cplx && D.kind != FACT_LU && (idx_t)D.w_off.size() == D.nblk)
+        for (idx_t k = 0; k < D.nblk; ++k) {
+          if (D.w_off[k] < 0 || D.row_ptr[k + 1] != D.row_ptr[k]) continue;
+          const int id = (int)(base + k), w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb128 = (w + 127) / 128, lev = D.height[k];
+          sn_rootw[id] = 1;
+          const long long p0 = part;
+          for (int rb = 0; rb < nb128; ++rb)
+            for (int cb = 0; cb <= rb; ++cb) {
+              RootTile t;
+              t.W = D.W.p + D.w_off[k], t.part = part, t.sn = id, t.ld = D.ldw[k], t.w = w, t.r0 = 128 * rb, t.c0 = 128 * cb, t.pad = 0;
+              part += 256;
+              rt[lev].push_back(t);
+            }
+          for (int bi = 0; bi < nb128; ++bi) rbk[lev].push_back(RootBlock{p0, id, w, bi, nb128});
+        }
+      base += D.nblk;
+    }
+    std::vector<RootTile>  allt;
+    std::vector<RootBlock> allb;
+    for (int l = 0; l < nlev; ++l) {
+      std::stable_sort(rt[l].begin(), rt[l].end(), [](const RootTile &a, const RootTile &b2) { return (a.r0 != a.c0) > (b2.r0 != b2.c0); }); // whole tiles first, the half tiles of the diagonal fill the tail
+      lev_rt_ptr[l] = (int)allt.size(), allt.insert(allt.end(), rt[l].begin(), rt[l].end()), lev_rt_end[l] = (int)allt.size();
+      lev_rb_ptr[l] = (int)allb.size(), allb.insert(allb.end(), rbk[l].begin(), rbk[l].end()), lev_rb_end[l] = (int)allb.size();
+    }
+    if (allt.empty()) allt.resize(1), allb.resize(1);
+    root_tile.upload(allt, s), root_block.upload(allb, s);
+    root_part.alloc((size_t)std::max<long long>(part, 1));
+    HIP_OK(hipStreamSynchronize(s));
+  }
   lev_bwd16.assign(nlev, 0);
   std::vector<char> sn_in_bush;
   for (size_t f = 0; f < fs.size(); ++f) sn_in_bush.insert(sn_in_bush.end(), in_bush[f].begin(), in_bush[f].end());
@@ -1814,6 +1946,10 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         int np = 0;
         for (const Tile &t : tl[kd][l]) np += pairable(t);
         lev_pair[l] = np & ~1; // (an odd one out: the largest, on a wavefront of its own -- the same in both directions)
+      }
+      if (kd == FWD_BLOCK || kd == BWD_BLOCK) { // the tiles of the roots that have their W at the head (the single-right-hand-side sweep starts behind them)
+        auto it = std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return sn_rootw[t.sn] != 0; });
+        lev_root[kd == BWD_BLOCK][l] = (int)(it - tl[kd][l].begin());
       }
       if (kd == BWD_BLOCK) { // (narrow supernodes too tall for a wavefront are block tiles of both engines: those of the bushes last, the 16-column engine stops before them)
         auto it = std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return !sn_in_bush[t.sn]; });
@@ -1967,11 +2103,18 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   auto grid = [&](int nb, int nw) { return nb + (nw + 3) / 4; };
   const Tile     *T = P.tiles.p;
   const long long stot = P.utot;
+  constexpr bool ROOTW = MU == 1 && !Z; // one real right-hand side: the roots that have their W go in one pass (k_root_sym), their forward and backward tiles are skipped
   for (int l = 0; l < P.nlev; ++l) {
-    const int nb = cnt(SolvePlan::FWD_BLOCK, l), nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
+    const int nroot = ROOTW ? P.lev_root[0][l] : 0;
+    const int nb = cnt(SolvePlan::FWD_BLOCK, l) - nroot, nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::FWD_WAVE, SolvePlan::FWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    const Tile   *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l];
+    const Tile   *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l] + nroot;
+    if (ROOTW && P.lev_rt_end[l] > P.lev_rt_ptr[l]) {
+      hipLaunchKernelGGL(k_root_sym, dim3((unsigned)(P.lev_rt_end[l] - P.lev_rt_ptr[l])), dim3(WG_THREADS), 0, s, P.sn.p, P.root_tile.p + P.lev_rt_ptr[l], b, P.U.p, stot, P.root_part.p, mu_total, nu0);
+      hipLaunchKernelGGL(k_root_reduce, dim3((unsigned)(P.lev_rb_end[l] - P.lev_rb_ptr[l])), dim3(128), 0, s, P.sn.p, P.root_block.p + P.lev_rb_ptr[l], P.root_part.p, x, mu_total, nu0);
+      P.mark(2500 + l, s);
+    }
     const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::FWD_LEAF][l];
     const dim3 g(grid(nb, nw + nl));
     const size_t shm = (size_t)ld * sizeof(double);
@@ -1982,10 +2125,11 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     if (nb || nw || nl) P.mark(2000 + l, s);
   }
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nb = cnt(SolvePlan::BWD_BLOCK, l), nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
+    const int nrootb = ROOTW ? P.lev_root[1][l] : 0;
+    const int nb = cnt(SolvePlan::BWD_BLOCK, l) - nrootb, nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::BWD_WAVE, SolvePlan::BWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
     const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    const Tile   *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l];
+    const Tile   *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l] + nrootb;
     const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::BWD_LEAF][l];
     const int  np = (nl && P.pair_leaves) ? P.lev_pair[l] : 0;
     const dim3 g(grid(nb, nw + nl - np / 2));

@@ -258,3 +258,39 @@ def test_condensed_leaves_and_slot_rows_against_superlu(kind, condense, pairs, m
         ref = np.stack([lu.solve(b[k]) for k in range(mu)])
         assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max(), (kind, condense, pairs, mu)
     S.destroy()
+
+
+@pytest.mark.parametrize("kind", ["chol", "ldlt"])
+def test_root_of_the_tree_in_one_pass(kind, monkeypatch):
+    """one right-hand side, real scalars: a root of the tree factorised on the device keeps W = inv(L)^T D^{-1} inv(L) beside its panel,
+    and the sweep takes it in ONE pass over the lower triangle of W (sptrsv.hip: k_root_sym / k_root_reduce) instead of a forward and a
+    backward pass over inv(L).  Against SuperLU, against the two-pass sweeps (HPDDM_HIP_ROOT_W=0 when the plan is built), inside a block of
+    three right-hand sides (two through the two-pass tiles, the third through W), and bitwise equal run to run."""
+    import scipy.sparse.linalg as spl
+    n1 = 24
+    K = _lap(n1)
+    N = K.shape[0]
+    A = K if kind == "chol" else (K - 0.35 * sp.identity(N)).tocsr()
+    M = sp.tril(A, format="csr")
+    M.sort_indices()
+    lu = spl.splu(A.tocsc())
+    rng = np.random.default_rng(11)
+    b1, b3 = rng.standard_normal(N), np.asfortranarray(rng.standard_normal((N, 3)))
+    xs = []
+    for use_w in ("1", "0"):
+        monkeypatch.setenv("HPDDM_HIP_ROOT_W", use_w)
+        S = hpddm.Subdomain()
+        S.numfact(N, M.indptr, M.indices, M.data, sym=True, spd=(kind == "chol"))
+        assert S.info()["kind"] == (0 if kind == "chol" else 1)
+        assert (np.asarray(S.export("w_off")) >= 0).sum() >= 1, "the root was factorised on the device and has its W"
+        x1 = S.solve(b1)
+        for _ in range(5):
+            assert np.array_equal(S.solve(b1), x1)
+        x3 = S.solve(b3)
+        xs.append((x1, x3))
+        S.destroy()
+    r1, r3 = lu.solve(b1), lu.solve(np.asarray(b3))
+    for x1, x3 in xs:
+        assert np.abs(x1 - r1).max() <= 1e-10 * np.abs(r1).max() and np.abs(x3 - r3).max() <= 1e-10 * np.abs(r3).max()
+    assert np.abs(xs[0][0] - xs[1][0]).max() <= 1e-10 * np.abs(r1).max()
+    assert not np.array_equal(xs[0][0], xs[1][0]), "the two builds of the plan took the same path"
