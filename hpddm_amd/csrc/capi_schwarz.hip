@@ -792,7 +792,7 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
         const int kind = tags[i] / 1000, lev = tags[i] % 1000;
         out[3 * i] = tags[i];
         out[3 * i + 1] = usec[i];
-        out[3 * i + 2] = (kind == 2 || kind == 3) ? lb[lev] : 0.0;
+        out[3 * i + 2] = ((kind == 2 || kind == 3) && lev < (int)lb.size()) ? lb[lev] : 0.0; // (marks 2500 + / 2900 / 3900: passes that belong to no single level)
       }
     return n;)
 }

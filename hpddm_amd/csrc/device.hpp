@@ -141,9 +141,9 @@ struct RootTile {
   long long     part; // where the tile writes: 128 row sums, then 128 column sums (SolvePlan::root_part)
   int           sn, ld, w, r0, c0, pad;
 };
-struct RootBlock { // the reduction: 128 entries of x_J
-  long long part;  // the root's first tile in root_part
-  int       sn, w, bi, nblk;
+struct RootBlock { // the reduction: 128 entries of z_J = W f_J (a root: x_J)
+  long long part;  // the supernode's first tile in root_part
+  int       sn, w, bi, nblk, to_x, pad; // to_x: no rows below (a root): z_J IS x_J; else it goes to y_J and the backward tiles add what the rows below give
 };
 
 struct Tile {
@@ -173,9 +173,9 @@ struct DeviceFactor {
   std::vector<idx_t>   blk_ptr, ldw, height, level_ptr, level_blk, nchild, lb_nnzr, lb_nnzc;
   std::vector<unsigned char> tgs;           // per supernode, SnDesc::tgs
   std::vector<int64_t> f_off, row_ptr, u_off, s_off, ps_off, lb_off, c_off, cs_off, pcs_off;
-  // roots of the tree (no rows below), symmetric kinds, real scalars, factorised on the device: W = inv(L)^T D^{-1} inv(L), lower
-  // triangle, row-major with the leading dimension of the panel (numeric_device.hip); w_off[k] >= 0: there.  One right-hand side
-  // takes such a root in one pass over W (sptrsv.hip: root tiles)
+  // wide supernodes, symmetric kinds, real scalars, factorised on the device: W = inv(L_JJ)^T D^{-1} inv(L_JJ), lower triangle,
+  // row-major with the leading dimension of the panel (numeric_device.hip); w_off[k] >= 0: there.  One right-hand side takes the top
+  // block of such a supernode in one pass over W: x_J = W f_J - F_below^T x_R (sptrsv.hip: root tiles)
   DevBuf<double>       W;
   std::vector<int64_t> w_off, w_plan;
   bool                 w_planned = false, want_root_w = true;
@@ -195,7 +195,7 @@ struct SolvePlan {
   DevBuf<SnDesc> sn;
   // per level, six tile lists: forward / backward x wave-level (narrow panels, one wavefront per tile, no LDS) /
   // block-level (wide panels, one 256-thread workgroup per tile, right-hand side staged in LDS) / condensed leaves (one wavefront each)
-  enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3, FWD_LEAF = 4, BWD_LEAF = 5, NKIND = 6 };
+  enum { FWD_WAVE = 0, FWD_BLOCK = 1, BWD_WAVE = 2, BWD_BLOCK = 3, FWD_LEAF = 4, BWD_LEAF = 5, FWD_BLOCK1 = 6, BWD_BLOCK1 = 7, NKIND = 8 }; // *_BLOCK1: the block tiles of the single-right-hand-side sweep (real scalars) -- those of the supernodes that have their W cover the rows BELOW the top block only
   DevBuf<Tile>     tiles;   // block-level kinds, the lists of the 16-column engine, the combine pass: tiles that name their supernode (sn[t.sn])
   DevBuf<SnDesc>   wtd;     // wave-level kinds and condensed leaves of the VALU sweeps, and the one-wavefront tiles of the 16-column engine (lev_w16): one descriptor per tile (SnDesc::t_r0 ...); lev_ptr / lev_end of these kinds index it
   std::vector<int> lev_w16[2]; // 16-column engine, forward / backward: first of the level's one-wavefront tiles in wtd (lev_end16 - lev_ptr16 - lev_team of them)
@@ -212,12 +212,12 @@ struct SolvePlan {
   DevBuf<BushTile16> bush_tile;
   DevBuf<int>        bush_int;
   int                nbush = 0, bush_lds = 0, bush_nw = 4; // ... the LDS bytes of the largest, the wavefronts (= tiles per round) of a bush
-  // one right-hand side, real scalars: the roots that have their W (above) -- per level the tiles of the one-pass product and the blocks of
-  // its reduction; lev_root[0 / 1][l]: the forward / backward block tiles of those roots, at the HEAD of the level's lists (skipped)
+  // one right-hand side, real scalars: the wide supernodes that have their W (above) -- per level the tiles of the one-pass product
+  // z_J = W f_J and the blocks of its reduction; the block tiles of that sweep are the kinds FWD_BLOCK1 / BWD_BLOCK1 (rows below the top blocks only)
   DevBuf<RootTile>   root_tile;
   DevBuf<RootBlock>  root_block;
   DevBuf<double>     root_part;
-  std::vector<int>   lev_rt_ptr, lev_rt_end, lev_rb_ptr, lev_rb_end, lev_root[2];
+  std::vector<int>   lev_rt_ptr, lev_rt_end, lev_rb_ptr, lev_rb_end;
   std::vector<int>   lev_bwd16;               // per level: the BWD_BLOCK tiles the 16-column engine takes (those of the bushes' supernodes sit behind them)
   // workspaces sized for mu_cap right-hand sides
   int            mu_cap = 0;

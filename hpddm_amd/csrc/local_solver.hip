@@ -201,7 +201,7 @@ void LocalSolver::numfact(const CsrView &A, int spd)
     first_dev = (idx_t)host.level_ptr.size() - 1; // (every level on the host)
     factor_numeric(A, FACT_LU, host, nullptr, first_dev);
   };
-  const bool may_perturb = !getenv("HPDDM_HIP_NO_PERTURB") && !(host.keep_plain);
+  const bool may_perturb = !getenv("HPDDM_HIP_NO_PERTURB") && !host.keep_plain && !host_only; // (host_only: no probe solve to judge the perturbed factor by -- refused as before)
   if (host.info != 0 && host.kind == FACT_LU && may_perturb) perturbed_lu();
   HH_CHECK(host.info == 0, "numfact: zero pivot in supernode " + std::to_string(host.info) + " (no pivot inside its diagonal tiles either: the matrix is singular, or needs rows from outside the supernode)");
   uploaded = false;

@@ -1535,28 +1535,36 @@ struct DeviceLevelsImpl : public DeviceLevels {
       invert_top(G, ld, (int)w, tinv3); // inverse of U11^T: its diagonal tiles are inv(U_T)^T
       mult_bottom(G, ld, (int)w, (int)nb);
     }
-    // ---- a ROOT of the tree (no rows below) of a symmetric kind, real scalars: W = inv(L)^T D^{-1} inv(L), the inverse of its Schur
-    // complement, lower triangle.  The sweeps of one right-hand side then take the root in ONE pass over W (x_J = W f_J: sptrsv.hip,
-    // root tiles) instead of one pass over inv(L) forward and one backward -- half the bytes of the largest panels of the factor ----
+    // ---- a WIDE front of a symmetric kind, real scalars: W = inv(L)^T D^{-1} inv(L), the inverse of its pivot block, lower triangle.
+    // The sweeps of one right-hand side then take the top block in ONE pass over W (x_J = W f_J - F_below^T x_R, the forward sweep only
+    // hands up F_below f_J: sptrsv.hip, root tiles) instead of one pass over inv(L) forward and one backward -- the top blocks of the
+    // wide panels are about a quarter of the factor at 129^3, half of them is saved.  The block sweeps keep to inv(L). ----
     if constexpr (CS == 1) {
-      if (nb == 0 && !lu && !rec && D.want_root_w && w >= 256 && !getenv("HPDDM_HIP_NO_ROOT_W")) {
+      if (!lu && D.want_root_w && hf->ldw[k] > 128 && !getenv("HPDDM_HIP_NO_ROOT_W")) {
         if (D.w_off.empty() || (idx_t)D.w_off.size() != s.nblk) D.w_off.assign((size_t)s.nblk, -1);
-        if (!D.w_planned) { // every root that may come (those of the host levels never do): one allocation
+        if (!D.w_planned) { // every front that may come (those of the host levels never do): one allocation -- if the device has the room
           long long tot = 0;
           D.w_plan.assign((size_t)s.nblk, -1);
+          const bool roots_only = getenv("HPDDM_HIP_ROOT_W_ONLY") != nullptr; // (developer switch: the roots of the tree only, as in profiles/r06_root_one_pass.txt)
           for (idx_t q = 0; q < s.nblk; ++q)
-            if (s.row_ptr[q + 1] == s.row_ptr[q] && s.blk_ptr[q + 1] - s.blk_ptr[q] >= 256) D.w_plan[q] = tot, tot += (long long)(s.blk_ptr[q + 1] - s.blk_ptr[q]) * hf->ldw[q];
-          D.W.alloc((size_t)tot);
+            if (hf->ldw[q] > 128 && s.height[q] >= first_level_ && (!roots_only || s.row_ptr[q + 1] == s.row_ptr[q])) D.w_plan[q] = tot, tot += (long long)(s.blk_ptr[q + 1] - s.blk_ptr[q]) * hf->ldw[q];
+          size_t fr = 0, all = 0;
+          HIP_OK(hipMemGetInfo(&fr, &all));
+          const long long keep = (long long)(all / 8); // (what upload() and the plan of the sweeps still place: transposed narrow panels, index lists, slot pools)
+          if ((long long)D.W.n >= tot || (long long)fr - keep > tot * 8) D.W.alloc((size_t)std::max<long long>(tot, 1));
+          else D.w_plan.assign((size_t)s.nblk, -1); // no room: the sweeps keep to inv(L) forward and backward
           D.w_planned = true;
         }
-        T *Wk = reinterpret_cast<T *>(D.W.p) + D.w_plan[k];
-        {
-          GOp o  = op(OP_TRANSPOSE_SCALE, (int)(((w + 31) / 32) * ((w + 31) / 32)));
-          o.p0 = P, o.p1 = tmp.p, o.p2 = kind == FACT_LDLT ? reinterpret_cast<T *>(scr->dinv_all.p) + c0 : nullptr, o.l0 = ld, o.i0 = (int)w, o.i6 = (int)((w + 31) / 32);
-          emit(o);
+        if (D.w_plan[k] >= 0) {
+          T *Wk = reinterpret_cast<T *>(D.W.p) + D.w_plan[k];
+          {
+            GOp o = op(OP_TRANSPOSE_SCALE, (int)(((w + 31) / 32) * ((w + 31) / 32)));
+            o.p0 = P, o.p1 = tmp.p, o.p2 = kind == FACT_LDLT ? reinterpret_cast<T *>(scr->dinv_all.p) + c0 : nullptr, o.l0 = ld, o.i0 = (int)w, o.i6 = (int)((w + 31) / 32);
+            emit(o);
+          }
+          gemm_(false, (int)w, (int)w, (int)w, 1.0, cd(tmp.p), (long long)w, cd(P), ld, md(Wk), ld, false, true, 0, 0, true, false);
+          D.w_off[k] = D.w_plan[k];
         }
-        gemm_(false, (int)w, (int)w, (int)w, 1.0, cd(tmp.p), (long long)w, cd(P), ld, md(Wk), ld, false, true, 0, 0, true, false);
-        D.w_off[k] = D.w_plan[k];
       }
     }
     cb[k] = C;

@@ -1144,6 +1144,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
               double s = 0.0;
 #pragma unroll
               for (int wv = 0; wv < 4; ++wv) s += lds[((wv * MU + nu) * 64 + gl) * 2 + k];
+              if (t.nr & 0x10000) s += yb[(long long)nu * d.n + d.c0 + c]; // (a supernode with its W: the rows below only, z_J = W f_J waits in y)
               xb[(long long)nu * d.n + d.c0 + c] = s;
             }
           }
@@ -1206,6 +1207,7 @@ __device__ static inline void bwd_block_tile(const SnView &d, const Tile &t, dou
         for (int nu = 0; nu < MU; ++nu) {
           double s = 0.0;
           for (int p = 0; p < t.nparts; ++p) s += __hip_atomic_load(slot + ((long long)p * MU + nu) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: bypasses this CU's L1
+          if (t.nr & 0x10000) s += yb[(long long)nu * d.n + d.c0 + c];
           xb[(long long)nu * d.n + d.c0 + c] = s;
         }
       }
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_root_sym(const SnDesc *__rest
   if (tid < 128) pcol[tid] = ((cred[0][tid] + cred[1][tid]) + cred[2][tid]) + cred[3][tid];
 }
 // x_J(i) = (the row sums of its tiles, left to right) + (the column sums of the tiles below and on the diagonal, top to bottom)
-__global__ __launch_bounds__(128) void k_root_reduce(const SnDesc *__restrict__ sns, const RootBlock *__restrict__ blocks, const double *__restrict__ part, double *__restrict__ x, int mu_total, int nu0)
+__global__ __launch_bounds__(128) void k_root_reduce(const SnDesc *__restrict__ sns, const RootBlock *__restrict__ blocks, const double *__restrict__ part, double *__restrict__ x, double *__restrict__ y, int mu_total, int nu0)
 {
   const RootBlock rb = blocks[blockIdx.x];
   const SnView    d  = view(sns[rb.sn]);
@@ -1405,7 +1407,7 @@ __global__ __launch_bounds__(128) void k_root_reduce(const SnDesc *__restrict__ 
   const long long trow = (long long)rb.bi * (rb.bi + 1) / 2;
   for (int cb = 0; cb <= rb.bi; ++cb) v += p[(trow + cb) * 256 + li];
   for (int r2 = rb.bi; r2 < rb.nblk; ++r2) v += p[((long long)r2 * (r2 + 1) / 2 + rb.bi) * 256 + 128 + li];
-  x[d.voff * mu_total + (long long)nu0 * d.n + d.c0 + i] = v;
+  (rb.to_x ? x : y)[d.voff * mu_total + (long long)nu0 * d.n + d.c0 + i] = v; // (rows below: z_J waits in y for what they give, bwd_block_tile)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1575,6 +1577,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       if (D.ldw[k] * cs > NARROW) wide_rows16[D.height[k]] += ((D.blk_ptr[k + 1] - D.blk_ptr[k]) + (D.row_ptr[k + 1] - D.row_ptr[k]) + 15) / 16;
   }
   const long long fwd_want = envi("HPDDM_HIP_FWD_WANT", 512) / std::max(1, groups);
+  const bool      use_w    = envi("HPDDM_HIP_ROOT_W", 1) != 0; // the top blocks that have their W in one pass (single right-hand side)
+  const int       w_min    = envi("HPDDM_HIP_W_MIN", 0); // developer switch: narrower supernodes keep to inv(L) forward and backward
+  std::vector<std::vector<RootTile>>  rt(nlev);
+  std::vector<std::vector<RootBlock>> rbk(nlev);
+  long long                           root_part_size = 0;
   // ---- 16-column engine: the bushes (device.hpp) -- complete subtrees of narrow supernodes of height <= HPDDM_HIP_BUSH16 (-1: none)
   // whose vectors, tile records and index lists fit HPDDM_HIP_BUSH_LDS KB of LDS; roots = the highest supernodes that qualify
   std::vector<std::vector<char>> in_bush(fs.size());
@@ -1828,6 +1835,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         } else {
           for (int r0 = 0; r0 < h; r0 += per) tl[FWD_WAVE][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
           tl[small ? BWD_WAVE : BWD_BLOCK][lev].push_back(tb);
+          if (!small) tl[BWD_BLOCK1][lev].push_back(tb);
         }
         if (!in_bush[f][k]) {
           for (int r0 = 0; r0 < h; r0 += per) w16[0][lev].push_back(Tile{id, r0, std::min(per, h - r0), 0, 1, 0, 0, 0});
@@ -1839,6 +1847,27 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         while (trb > 16 && wide_rows16[lev] * 16 / trb < fwd_want) trb >>= 1;
         for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
         for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h}); // c0: first of 128 doubles of every row; rows above scalar column c0 / cs hold zeros there
+        // the single-right-hand-side sweep: a supernode that has its W (DeviceFactor::W) takes its top block in one pass over W (root
+        // tiles below) -- its forward tiles cover the rows BELOW the top block only, its backward tiles likewise and add z_J = W f_J
+        const bool hasw = use_w && cs == 1 && D.kind != FACT_LU && (idx_t)D.w_off.size() == D.nblk && D.w_off[k] >= 0 && d.w >= w_min;
+        if (!hasw) {
+          for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK1][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
+          for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK1][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h});
+        } else {
+          for (int r0 = d.w; r0 < h; r0 += trb) tl[FWD_BLOCK1][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
+          if (d.nb)
+            for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK1][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0) | 0x10000, 0, 1, 0, d.w, h}); // (0x10000: x_J = z_J + the sums)
+          const int       nb128 = (d.w + 127) / 128;
+          const long long p0 = root_part_size;
+          for (int rb = 0; rb < nb128; ++rb)
+            for (int cb = 0; cb <= rb; ++cb) {
+              RootTile t;
+              t.W = D.W.p + D.w_off[k], t.part = root_part_size, t.sn = id, t.ld = D.ldw[k], t.w = d.w, t.r0 = 128 * rb, t.c0 = 128 * cb, t.pad = 0;
+              root_part_size += 256;
+              rt[lev].push_back(t);
+            }
+          for (int bi = 0; bi < nb128; ++bi) rbk[lev].push_back(RootBlock{p0, id, d.w, bi, nb128, d.nb == 0 ? 1 : 0, 0});
+        }
         if (d.nchild) // 16-column engine: its right-hand side b_J - (children's updates) is formed once, ahead of the level (sptrsv16_combine_kernel)
           for (int c0 = 0; c0 < d.w; c0 += WG_THREADS) gat[lev].push_back(Tile{id, c0, std::min(WG_THREADS, d.w - c0), 0, 1, 0, 0, 0});
       }
@@ -1849,8 +1878,9 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   // sums in part order (deterministic).
   ngroups   = 0;
   max_parts = 1;
+  for (int kdb : {(int)BWD_BLOCK, (int)BWD_BLOCK1})
   for (int l = 0; l < nlev; ++l) {
-    std::vector<Tile> &v = tl[BWD_BLOCK][l];
+    std::vector<Tile> &v = tl[kdb][l];
     const int          T = (int)v.size();
     if (T == 0 || T >= bwd_want) continue;
     long long lcost = 0;
@@ -1889,44 +1919,17 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_lds[kd].assign(nlev, 0);
   }
   lev_team[0].assign(nlev, 0), lev_team[1].assign(nlev, 0);
-  // ---- roots with their W (DeviceFactor::W): tiles of the one-pass product of the single-right-hand-side sweep ----
-  std::vector<char> sn_rootw(descs.size(), 0);
+  // ---- the supernodes with their W (DeviceFactor::W): tiles of the one-pass product of the single-right-hand-side sweep ----
   lev_rt_ptr.assign(nlev, 0), lev_rt_end.assign(nlev, 0), lev_rb_ptr.assign(nlev, 0), lev_rb_end.assign(nlev, 0);
-  lev_root[0].assign(nlev, 0), lev_root[1].assign(nlev, 0);
   {
-    std::vector<std::vector<RootTile>>  rt(nlev);
-    std::vector<std::vector<RootBlock>> rbk(nlev);
-    long long part = 0, base = 0;
-    const bool use_w = envi("HPDDM_HIP_ROOT_W", 1) != 0;
-    for (size_t f = 0; f < fs.size(); ++f) {
-      const DeviceFactor &D = *fs[f];
-      if (use_w && !D.cplx && D.kind != FACT_LU && (idx_t)D.w_off.size() == D.nblk)
-        for (idx_t k = 0; k < D.nblk; ++k) {
-          if (D.w_off[k] < 0 || D.row_ptr[k + 1] != D.row_ptr[k]) continue;
-          const int id = (int)(base + k), w = D.blk_ptr[k + 1] - D.blk_ptr[k], nb128 = (w + 127) / 128, lev = D.height[k];
-          sn_rootw[id] = 1;
-          const long long p0 = part;
-          for (int rb = 0; rb < nb128; ++rb)
-            for (int cb = 0; cb <= rb; ++cb) {
-              RootTile t;
-              t.W = D.W.p + D.w_off[k], t.part = part, t.sn = id, t.ld = D.ldw[k], t.w = w, t.r0 = 128 * rb, t.c0 = 128 * cb, t.pad = 0;
-              part += 256;
-              rt[lev].push_back(t);
-            }
-          for (int bi = 0; bi < nb128; ++bi) rbk[lev].push_back(RootBlock{p0, id, w, bi, nb128});
-        }
-      base += D.nblk;
-    }
     std::vector<RootTile>  allt;
     std::vector<RootBlock> allb;
-    for (int l = 0; l < nlev; ++l) {
-      std::stable_sort(rt[l].begin(), rt[l].end(), [](const RootTile &a, const RootTile &b2) { return (a.r0 != a.c0) > (b2.r0 != b2.c0); }); // whole tiles first, the half tiles of the diagonal fill the tail
-      lev_rt_ptr[l] = (int)allt.size(), allt.insert(allt.end(), rt[l].begin(), rt[l].end()), lev_rt_end[l] = (int)allt.size();
-      lev_rb_ptr[l] = (int)allb.size(), allb.insert(allb.end(), rbk[l].begin(), rbk[l].end()), lev_rb_end[l] = (int)allb.size();
-    }
+    for (int l = nlev - 1; l >= 0; --l) allt.insert(allt.end(), rt[l].begin(), rt[l].end()), allb.insert(allb.end(), rbk[l].begin(), rbk[l].end()); // (the widest supernodes first)
+    std::stable_sort(allt.begin(), allt.end(), [](const RootTile &a, const RootTile &b2) { return (a.r0 != a.c0) > (b2.r0 != b2.c0); }); // whole tiles first, the half tiles of the diagonals fill the tail
+    for (int l = 0; l < nlev; ++l) lev_rt_end[l] = (int)allt.size(), lev_rb_end[l] = (int)allb.size(); // (one launch for all the levels, between the sweeps: solve_block)
     if (allt.empty()) allt.resize(1), allb.resize(1);
     root_tile.upload(allt, s), root_block.upload(allb, s);
-    root_part.alloc((size_t)std::max<long long>(part, 1));
+    root_part.alloc((size_t)std::max<long long>(root_part_size, 1));
     HIP_OK(hipStreamSynchronize(s));
   }
   lev_bwd16.assign(nlev, 0);
@@ -1939,7 +1942,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   for (int kd = 0; kd < NKIND; ++kd)
     for (int l = 0; l < nlev; ++l) {
       // largest tiles first inside a launch: the long streams start early, the small ones fill the tail
-      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK) ? (long long)t.nr * descs[t.sn].ldw : ((kd == FWD_LEAF || kd == BWD_LEAF) ? (long long)descs[t.sn].w * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * t.nr); };
+      auto cost = [&](const Tile &t) { return (kd == FWD_WAVE || kd == FWD_BLOCK || kd == FWD_BLOCK1) ? (long long)t.nr * descs[t.sn].ldw : ((kd == FWD_LEAF || kd == BWD_LEAF) ? (long long)descs[t.sn].w * descs[t.sn].ldw : (long long)(t.rend - t.rbeg) * (t.nr & 0xffff)); };
       std::stable_sort(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &a, const Tile &b2) { return cost(a) > cost(b2); });
       if (kd == FWD_LEAF || kd == BWD_LEAF) { // the leaves that go two to a wavefront at the end of the list, neighbours in cost paired
         std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return !pairable(t); });
@@ -1947,15 +1950,11 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         for (const Tile &t : tl[kd][l]) np += pairable(t);
         lev_pair[l] = np & ~1; // (an odd one out: the largest, on a wavefront of its own -- the same in both directions)
       }
-      if (kd == FWD_BLOCK || kd == BWD_BLOCK) { // the tiles of the roots that have their W at the head (the single-right-hand-side sweep starts behind them)
-        auto it = std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return sn_rootw[t.sn] != 0; });
-        lev_root[kd == BWD_BLOCK][l] = (int)(it - tl[kd][l].begin());
-      }
       if (kd == BWD_BLOCK) { // (narrow supernodes too tall for a wavefront are block tiles of both engines: those of the bushes last, the 16-column engine stops before them)
         auto it = std::stable_partition(tl[kd][l].begin(), tl[kd][l].end(), [&](const Tile &t) { return !sn_in_bush[t.sn]; });
         lev_bwd16[l] = (int)(it - tl[kd][l].begin());
       }
-      if (kd == FWD_BLOCK || kd == BWD_BLOCK) {
+      if (kd == FWD_BLOCK || kd == BWD_BLOCK || kd == FWD_BLOCK1 || kd == BWD_BLOCK1) {
         lev_ptr[kd][l] = (int)all.size();
         all.insert(all.end(), tl[kd][l].begin(), tl[kd][l].end());
       } else { // wave-level tiles: one copy of the descriptor per tile, the tile inside (SnDesc::t_r0, t_nr)
@@ -1973,7 +1972,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       if (kd == FWD_LEAF || kd == BWD_LEAF)
         for (size_t k = tl[kd][l].size() - lev_pair[l]; k < tl[kd][l].size(); ++k) need = std::max(need, 2 * ((descs[tl[kd][l][k].sn].w + 7) / 8 * 8)); // (two leaves share the wavefront's staging area, half each)
       for (const Tile &t : tl[kd][l])
-        need = std::max(need, kd == FWD_BLOCK ? descs[t.sn].ldw : (kd == BWD_BLOCK ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : (kd == BWD_WAVE ? descs[t.sn].w + descs[t.sn].nb : descs[t.sn].w))));
+        need = std::max(need, (kd == FWD_BLOCK || kd == FWD_BLOCK1) ? descs[t.sn].ldw : ((kd == BWD_BLOCK || kd == BWD_BLOCK1) ? t.rend - t.rbeg : (kd == FWD_WAVE ? descs[t.sn].wc : (kd == BWD_WAVE ? descs[t.sn].w + descs[t.sn].nb : descs[t.sn].w))));
       lev_lds[kd][l] = need;
     }
   // The narrow tiles once more for the 16-column engine (sptrsv16.hip), whose wavefronts take 32 outputs at a time (two MFMA
@@ -2103,18 +2102,13 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
   auto grid = [&](int nb, int nw) { return nb + (nw + 3) / 4; };
   const Tile     *T = P.tiles.p;
   const long long stot = P.utot;
-  constexpr bool ROOTW = MU == 1 && !Z; // one real right-hand side: the roots that have their W go in one pass (k_root_sym), their forward and backward tiles are skipped
+  constexpr bool ROOTW = MU == 1 && !Z; // one real right-hand side: the top blocks that have their W go in one pass (k_root_sym), the block tiles cover the rows below them (SolvePlan::*_BLOCK1)
+  constexpr int  KFB = ROOTW ? SolvePlan::FWD_BLOCK1 : SolvePlan::FWD_BLOCK, KBB = ROOTW ? SolvePlan::BWD_BLOCK1 : SolvePlan::BWD_BLOCK;
   for (int l = 0; l < P.nlev; ++l) {
-    const int nroot = ROOTW ? P.lev_root[0][l] : 0;
-    const int nb = cnt(SolvePlan::FWD_BLOCK, l) - nroot, nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
+    const int nb = cnt(KFB, l), nw = cnt(SolvePlan::FWD_WAVE, l), nl = cnt(SolvePlan::FWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::FWD_WAVE, SolvePlan::FWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
-    const int ld = nb ? clampd(P.lev_lds[SolvePlan::FWD_BLOCK][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
-    const Tile   *tb = T + P.lev_ptr[SolvePlan::FWD_BLOCK][l] + nroot;
-    if (ROOTW && P.lev_rt_end[l] > P.lev_rt_ptr[l]) {
-      hipLaunchKernelGGL(k_root_sym, dim3((unsigned)(P.lev_rt_end[l] - P.lev_rt_ptr[l])), dim3(WG_THREADS), 0, s, P.sn.p, P.root_tile.p + P.lev_rt_ptr[l], b, P.U.p, stot, P.root_part.p, mu_total, nu0);
-      hipLaunchKernelGGL(k_root_reduce, dim3((unsigned)(P.lev_rb_end[l] - P.lev_rb_ptr[l])), dim3(128), 0, s, P.sn.p, P.root_block.p + P.lev_rb_ptr[l], P.root_part.p, x, mu_total, nu0);
-      P.mark(2500 + l, s);
-    }
+    const int ld = nb ? clampd(P.lev_lds[KFB][l] * MU + 64 * MU + 2 * MU + (MU >= 4 ? 64 * MU : 0), lds_wave) : lds_wave; // MU >= 4: + the MFMA tile's cross-wavefront buffer
+    const Tile   *tb = T + P.lev_ptr[KFB][l];
     const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::FWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::FWD_LEAF][l];
     const dim3 g(grid(nb, nw + nl));
     const size_t shm = (size_t)ld * sizeof(double);
@@ -2124,12 +2118,18 @@ static void solve_block(SolvePlan &P, double *b, double *x, int mu_total, int nu
     else if (nw) hipLaunchKernelGGL((sptrsv_fwd_kernel<MU, false, FPN, Z, false>), g, dim3(WG_THREADS), shm, s, P.sn.p, tb, 0, tw, nw, tf, 0, b, P.y.p, P.U.p, stot, mu_total, nu0, ld, wr);
     if (nb || nw || nl) P.mark(2000 + l, s);
   }
+  if (ROOTW && P.nlev && P.lev_rt_end[P.nlev - 1] > 0) {
+    // between the sweeps: z_J = W_J f_J of every supernode that has its W, ONE launch for all the levels (every f_J is complete once the
+    // forward sweep is through; z_J is wanted by the backward sweep only) and one for the reductions
+    hipLaunchKernelGGL(k_root_sym, dim3((unsigned)P.lev_rt_end[P.nlev - 1]), dim3(WG_THREADS), 0, s, P.sn.p, P.root_tile.p, b, P.U.p, stot, P.root_part.p, mu_total, nu0);
+    hipLaunchKernelGGL(k_root_reduce, dim3((unsigned)P.lev_rb_end[P.nlev - 1]), dim3(128), 0, s, P.sn.p, P.root_block.p, P.root_part.p, x, P.y.p, mu_total, nu0);
+    P.mark(2500, s);
+  }
   for (int l = P.nlev - 1; l >= 0; --l) {
-    const int nrootb = ROOTW ? P.lev_root[1][l] : 0;
-    const int nb = cnt(SolvePlan::BWD_BLOCK, l) - nrootb, nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
+    const int nb = cnt(KBB, l), nw = cnt(SolvePlan::BWD_WAVE, l), nl = cnt(SolvePlan::BWD_LEAF, l);
     const int wr = nw + nl ? wrows(SolvePlan::BWD_WAVE, SolvePlan::BWD_LEAF, l) : 16, lds_wave = 4 * wr * MU;
-    const int ld = nb ? clampd(P.lev_lds[SolvePlan::BWD_BLOCK][l] * MU, lds_wave) : lds_wave;
-    const Tile   *tb = T + P.lev_ptr[SolvePlan::BWD_BLOCK][l] + nrootb;
+    const int ld = nb ? clampd(P.lev_lds[KBB][l] * MU, lds_wave) : lds_wave;
+    const Tile   *tb = T + P.lev_ptr[KBB][l];
     const SnDesc *tw = P.wtd.p + P.lev_ptr[SolvePlan::BWD_WAVE][l], *tf = P.wtd.p + P.lev_ptr[SolvePlan::BWD_LEAF][l];
     const int  np = (nl && P.pair_leaves) ? P.lev_pair[l] : 0;
     const dim3 g(grid(nb, nw + nl - np / 2));

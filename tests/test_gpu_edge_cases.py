@@ -262,10 +262,11 @@ def test_condensed_leaves_and_slot_rows_against_superlu(kind, condense, pairs, m
 
 @pytest.mark.parametrize("kind", ["chol", "ldlt"])
 def test_root_of_the_tree_in_one_pass(kind, monkeypatch):
-    """one right-hand side, real scalars: a root of the tree factorised on the device keeps W = inv(L)^T D^{-1} inv(L) beside its panel,
-    and the sweep takes it in ONE pass over the lower triangle of W (sptrsv.hip: k_root_sym / k_root_reduce) instead of a forward and a
-    backward pass over inv(L).  Against SuperLU, against the two-pass sweeps (HPDDM_HIP_ROOT_W=0 when the plan is built), inside a block of
-    three right-hand sides (two through the two-pass tiles, the third through W), and bitwise equal run to run."""
+    """one right-hand side, real scalars: every WIDE supernode factorised on the device keeps W = inv(L_JJ)^T D^{-1} inv(L_JJ) beside its
+    panel, and the sweep takes its top block in ONE pass over the lower triangle of W between the forward and the backward sweep
+    (sptrsv.hip: k_root_sym / k_root_reduce; x_J = W f_J - F_below^T x_R, the block tiles cover the rows below the top block only) instead
+    of a forward and a backward pass over inv(L_JJ).  Against SuperLU, against the two-pass sweeps (HPDDM_HIP_ROOT_W=0 when the plan is
+    built), inside a block of three right-hand sides (two through the two-pass tiles, the third through W), and bitwise equal run to run."""
     import scipy.sparse.linalg as spl
     n1 = 24
     K = _lap(n1)
@@ -282,7 +283,7 @@ def test_root_of_the_tree_in_one_pass(kind, monkeypatch):
         S = hpddm.Subdomain()
         S.numfact(N, M.indptr, M.indices, M.data, sym=True, spd=(kind == "chol"))
         assert S.info()["kind"] == (0 if kind == "chol" else 1)
-        assert (np.asarray(S.export("w_off")) >= 0).sum() >= 1, "the root was factorised on the device and has its W"
+        assert (np.asarray(S.export("w_off")) >= 0).sum() >= 3, "the root and the wide supernodes below it were factorised on the device and have their W"
         x1 = S.solve(b1)
         for _ in range(5):
             assert np.array_equal(S.solve(b1), x1)
