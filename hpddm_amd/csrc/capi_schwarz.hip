@@ -785,14 +785,15 @@ int HpddmHipSchwarzLevelTimes(HpddmHipSchwarz *A, int mu, int reps, double *out,
       P.prof_ev.clear();
       P.prof_tag.clear();
     }
-    const std::vector<double> lb = P.level_bytes(0);
+    const bool                one = mu == 1 && !op.is_complex; // (the sweep of one real right-hand side takes the top blocks that have their W in one pass between the sweeps: mark 2500)
+    const std::vector<double> lb = P.level_bytes(one ? 1 : 0);
     const int n = (int)tags.size();
     if (out)
       for (int i = 0; i < n && 3 * i + 2 < cap; ++i) {
         const int kind = tags[i] / 1000, lev = tags[i] % 1000;
         out[3 * i] = tags[i];
         out[3 * i + 1] = usec[i];
-        out[3 * i + 2] = ((kind == 2 || kind == 3) && lev < (int)lb.size()) ? lb[lev] : 0.0; // (marks 2500 + / 2900 / 3900: passes that belong to no single level)
+        out[3 * i + 2] = ((kind == 2 || kind == 3) && lev < P.nlev) ? lb[lev] : ((one && tags[i] == 2500) ? lb[P.nlev] : 0.0); // (marks 2900 / 3900: the bushes of the 16-column engine, no single level)
       }
     return n;)
 }

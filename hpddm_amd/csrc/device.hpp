@@ -251,6 +251,7 @@ struct SolvePlan {
   std::vector<int>        prof_tag;
   void                    mark(int tag, hipStream_t s);
   std::vector<double>     lev_bytes;                   // stored panel entries * 8 per level launch
+  std::vector<double>     lev_bytes1;                  // ... of the single-right-hand-side sweep (real scalars): the top blocks that have their W left out; [nlev]: the entries of all the W
   std::vector<double>     level_bytes(int kind) const;
 };
 

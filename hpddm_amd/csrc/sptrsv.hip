@@ -1558,7 +1558,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
   const int  bwd_minrows = envi("HPDDM_HIP_BWD_MINROWS", 128); // (round 5: 256 -> 128: the 16-column sweeps of the Helmholtz share 1.68 -> 1.58 ms, the others unchanged)
   const int  bwd_maxpart = envi("HPDDM_HIP_BWD_MAXPARTS", 32);
   const bool use_leaves  = envi("HPDDM_HIP_LEAF_TILES", 1) != 0; // developer switch: 0 sweeps the condensed leaves through their panels all the same
-  lev_bytes.assign(nlev, 0.0);
+  lev_bytes.assign(nlev, 0.0), lev_bytes1.assign(nlev + 1, 0.0);
   const int  fwd_rows_cap = envi("HPDDM_HIP_FWD_ROWS", 64);     // wide panels, forward: rows per tile at most (64 / 32 / 16) ...
   const int  fwd_tile_kb  = envi("HPDDM_HIP_FWD_TILE_KB", 1 << 20); // ... and panel bytes per tile at most (a level ends with the tail of its last tiles: bytes of a tile / what ONE workgroup pulls)
   auto fwd_tile_rows = [&](int wc) {
@@ -1820,6 +1820,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
       descs.push_back(d);
       const int h = d.w + d.nb, lev = D.height[k];
       lev_bytes[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
+      lev_bytes1[lev] += ((double)d.w * (d.w + 1) / 2 + (double)d.nb * d.w) * 8.0 * cs;
       if (d.ldw <= NARROW) {
         const bool leafv = d.leaf != nullptr && use_leaves; // condensed leaf: the VALU sweeps take it through its blob (the 16-column engine through its panel:
                                                             // there a vector entry is a 128-byte line, the sparse couplings cost more lines than the rows of the panel)
@@ -1850,6 +1851,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
         // the single-right-hand-side sweep: a supernode that has its W (DeviceFactor::W) takes its top block in one pass over W (root
         // tiles below) -- its forward tiles cover the rows BELOW the top block only, its backward tiles likewise and add z_J = W f_J
         const bool hasw = use_w && cs == 1 && D.kind != FACT_LU && (idx_t)D.w_off.size() == D.nblk && D.w_off[k] >= 0 && d.w >= w_min;
+        if (hasw) lev_bytes1[lev] -= (double)d.w * (d.w + 1) / 2 * 8.0, lev_bytes1[nlev] += (double)d.w * (d.w + 1) / 2 * 8.0;
         if (!hasw) {
           for (int r0 = 0; r0 < h; r0 += trb) tl[FWD_BLOCK1][lev].push_back(Tile{id, r0, std::min(trb, h - r0), 0, 1, 0, 0, 0});
           for (int c0 = 0; c0 < d.wc; c0 += 128) tl[BWD_BLOCK1][lev].push_back(Tile{id, c0, std::min(128, d.ldw - c0), 0, 1, 0, (c0 / cs / 4) * 4, h});
@@ -1925,7 +1927,7 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     std::vector<RootTile>  allt;
     std::vector<RootBlock> allb;
     for (int l = nlev - 1; l >= 0; --l) allt.insert(allt.end(), rt[l].begin(), rt[l].end()), allb.insert(allb.end(), rbk[l].begin(), rbk[l].end()); // (the widest supernodes first)
-    std::stable_sort(allt.begin(), allt.end(), [](const RootTile &a, const RootTile &b2) { return (a.r0 != a.c0) > (b2.r0 != b2.c0); }); // whole tiles first, the half tiles of the diagonals fill the tail
+    if (envi("HPDDM_HIP_W_SORT", 0)) std::stable_sort(allt.begin(), allt.end(), [](const RootTile &a, const RootTile &b2) { return (a.r0 != a.c0) > (b2.r0 != b2.c0); }); // developer switch: whole tiles first, the half tiles of the diagonals at the tail (default: as they come, the half tiles spread out)
     for (int l = 0; l < nlev; ++l) lev_rt_end[l] = (int)allt.size(), lev_rb_end[l] = (int)allb.size(); // (one launch for all the levels, between the sweeps: solve_block)
     if (allt.empty()) allt.resize(1), allb.resize(1);
     root_tile.upload(allt, s), root_block.upload(allb, s);
@@ -2063,7 +2065,7 @@ void SolvePlan::mark(int tag, hipStream_t s)
   prof_tag.push_back(tag);
 }
 
-std::vector<double> SolvePlan::level_bytes(int) const { return lev_bytes; }
+std::vector<double> SolvePlan::level_bytes(int kind) const { return kind == 1 ? lev_bytes1 : lev_bytes; }
 
 void SolvePlan::reserve(int mu, hipStream_t s)
 {
