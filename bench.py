@@ -436,7 +436,7 @@ def main():
 def roofline(bytes_alg, t_solve, st, args, mu):
     achieved = bytes_alg / t_solve / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-         "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel (one batched forward+backward sweep of the 8 subdomains = %d launches)" % int(st["launches"]),
+         "kernel": "sptrsv_fwd_kernel + sptrsv_bwd_kernel + k_root_sym (one batched forward+backward sweep of the 8 subdomains = %d launches; one real right-hand side: the top blocks of the wide supernodes in one pass over W between the sweeps)" % int(st["launches"]),
          "bytes_alg_per_sweep": bytes_alg, "seconds_per_sweep": t_solve, "stored_bytes_per_sweep": 2.0 * st["stored"] * (16.0 if bytes_alg > 2.0 * st["nnz_L"] * 12.0 else 8.0)}
     # HBM traffic of the same sweep pair from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     # scripts/rNN_profiles.sh pmc): only quoted for the workload it was collected on (same algorithmic bytes)

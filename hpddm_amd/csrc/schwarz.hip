@@ -971,7 +971,8 @@ void Schwarz::call_numfact()
       if (is_complex) A = use1 ? CsrView{S.n / 2, S.zia1.data(), S.zja1.data(), S.za1.data(), S.zsym1, S.zbase1, true} : CsrView{S.n / 2, S.zia.data(), S.zja.data(), S.za.data(), S.zsym, S.zbase, true};
       S.ls->numfact(A, spd);
     };
-    const int nthr = std::max(1, std::min({nsub, 4, (int)getopt("hip_numfact_threads", 2)}));
+    const char *nthr_env = getenv("HPDDM_HIP_NUMFACT_THREADS"); // (developer switch: the default of -hpddm_hip_numfact_threads)
+    const int nthr = std::max(1, std::min({nsub, 4, (int)getopt("hip_numfact_threads", nthr_env ? atoi(nthr_env) : 2)}));
     if (nthr == 1) {
       for (int s = 0; s < nsub; ++s) one(s);
     } else {

@@ -5,7 +5,7 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 ng = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-rows = c.execute("select dispatch_id, name, counter_name, sum(counter_value), min(start) from pmc_events where name like '%sptrsv%' or name like '%k_perm_in%' or name like '%k_perm_out%' "
+rows = c.execute("select dispatch_id, name, counter_name, sum(counter_value), min(start) from pmc_events where name like '%sptrsv%' or name like '%k_root_sym%' or name like '%k_root_reduce%' or name like '%k_perm_in%' or name like '%k_perm_out%' "
                  "group by dispatch_id, name, counter_name order by min(start)").fetchall()
 # walk backwards to the ng-th k_perm_in from the end
 ins, first = 0, 0

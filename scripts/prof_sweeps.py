@@ -10,7 +10,7 @@ c = sqlite3.connect(sys.argv[1])
 ng = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
 sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
-rows = c.execute(f"select name, start, end, {sid or 0} from kernels where name like '%sptrsv%' or name like '%k_perm_in%' or name like '%k_perm_out%' order by start").fetchall()
+rows = c.execute(f"select name, start, end, {sid or 0} from kernels where name like '%sptrsv%' or name like '%k_root_sym%' or name like '%k_root_reduce%' or name like '%k_perm_in%' or name like '%k_perm_out%' order by start").fetchall()
 solves = []
 if sid:
     # every group sweeps on its own stream: the k-th k_perm_in of a stream opens the k-th solve of that stream, and the k-th solves of the

@@ -1,0 +1,12 @@
+#!/bin/bash
+# developer aid (round 6): set-up of configs[2] with two factorisations interleaved on the device (HPDDM_HIP_DEVICE_SLOTS) and more host threads
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out/r06
+out=gpurun_out/r06/slots.txt; : > $out
+for v in "HPDDM_HIP_DEVICE_SLOTS=1" "HPDDM_HIP_DEVICE_SLOTS=2" "HPDDM_HIP_DEVICE_SLOTS=2 HPDDM_HIP_GEVP_THREADS=3 HPDDM_HIP_NUMFACT_THREADS=3" "HPDDM_HIP_DEVICE_SLOTS=3 HPDDM_HIP_GEVP_THREADS=3 HPDDM_HIP_NUMFACT_THREADS=3"; do
+  echo "## $v" | tee -a $out
+  env $v timeout 900 python bench.py --no-cpu-baseline --no-configs-1 --no-shares --steps 5 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); c=d['config']
+print('setup', c['setup_seconds'], 'coarse_space', d['two_level']['coarse_space_seconds'], 'coarse_setup', d['two_level']['coarse_setup_seconds'], 'frac', round(d['roofline']['frac'],4))" | tee -a $out
+done

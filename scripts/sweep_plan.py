@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--helmholtz", default=None, help="nx,ny,nz: the complex shifted Laplacian of bench.py --problem helmholtz instead")
     ap.add_argument("--levels", action="store_true", help="print the per-launch table for every setting")
+    ap.add_argument("--options", default="", help="appended to the options of the operator, e.g. '-hpddm_hip_numfact_threads 1'")
     ap.add_argument("cfgs", nargs="*", default=[""])
     args = ap.parse_args()
     from hpddm_amd import hpddm
@@ -26,12 +27,12 @@ def main():
     if args.helmholtz:
         from hpddm_amd.generate import generate_helmholtz3d
         subs = generate_helmholtz3d(tuple(int(v) for v in args.helmholtz.split(",")), 8, grid=(2, 2, 2))   # configs[4]'s share: ORAS on the impedance matrices
-        A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_method oras", multiplicity=False)
+        A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_schwarz_method oras " + args.options, multiplicity=False)
         for s_, sd in enumerate(subs):
             A.set_optimized_matrix(s_, sd["n"], sd["ia"], sd["ja"], sd["a_opt"], False)
     else:
         subs = generate3d(args.grid, 8, overlap=1, sym=True, rhs="smooth")
-        A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd")
+        A, d = hpddm.schwarz_from_subdomains(subs, options="-hpddm_operator_spd " + args.options)
     A.call_numfact()
     st = A.stats()
     print(f"setup {time.time() - t0:.1f} s, nnz(L) {st['nnz_L']:.4g}, levels {int(st['levels'])}", flush=True)

@@ -15,9 +15,13 @@ sd = generate3d(N - 1, 1, 0, sym=True)[0]
 S = hpddm.Subdomain()
 t0 = time.time()
 S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a"], sym=True, spd=True)
-t1 = time.time()
+t1 = tfirst = time.time()
 info = S.info()
-S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a"], sym=True, spd=True)   # same pattern: numerical phase only
-t2 = time.time()
-print(f"threads {os.environ.get('HPDDM_HIP_NUM_THREADS', 'default')}: n {sd['n']}, first numfact {t1 - t0:.2f} s (ordering {info['t_order']:.2f}, symbolic {info['t_symbolic']:.2f}, "
+best = 1e30
+for _ in range(int(os.environ.get("REFACT", "1"))):
+    t1 = time.time()
+    S.numfact(sd["n"], sd["ia"], sd["ja"], sd["a"], sym=True, spd=True)   # same pattern: numerical phase only
+    best = min(best, time.time() - t1)
+t2 = t1 + best
+print(f"threads {os.environ.get('HPDDM_HIP_NUM_THREADS', 'default')}: n {sd['n']}, first numfact {tfirst - t0:.2f} s (ordering {info['t_order']:.2f}, symbolic {info['t_symbolic']:.2f}, "
       f"numeric {info['t_numeric']:.2f}, upload {info['t_upload']:.2f}), refactorisation {t2 - t1:.2f} s", flush=True)
