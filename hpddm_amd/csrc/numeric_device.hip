@@ -1066,7 +1066,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
   void begin(HostFactor &h, size_t cb_doubles, idx_t first_level) override
   {
     hf = &h;
-    D.w_off.assign((size_t)h.sym.nblk, -1), D.w_planned = false; // (the W of the roots: rebuilt by this factorisation, factor_front)
+    D.w_off.assign((size_t)h.sym.nblk, -1), D.w_planned = false; // (the W of the wide fronts: rebuilt by this factorisation, factor_front)
+    if (h.kind == FACT_LU || !D.want_root_w || CS != 1) D.W.release(); // (what an earlier symmetric factorisation of this pattern kept)
     HH_CHECK((h.cplx ? 2 : 1) == CS, "numfact (device levels): scalar type of the factor and of the device levels differ");
     scr    = DeviceScratch::acquire();
     locked = true;
@@ -1551,7 +1552,9 @@ struct DeviceLevelsImpl : public DeviceLevels {
           size_t fr = 0, all = 0;
           HIP_OK(hipMemGetInfo(&fr, &all));
           const long long keep = (long long)(all / 8); // (what upload() and the plan of the sweeps still place: transposed narrow panels, index lists, slot pools)
-          if ((long long)D.W.n >= tot || (long long)fr - keep > tot * 8) D.W.alloc((size_t)std::max<long long>(tot, 1));
+          const char *cap = getenv("HPDDM_HIP_W_BUDGET_MB"); // (developer switch: a cap on the bytes of all the W, to exercise the branch below)
+          const bool  room = cap ? tot * 8 <= (long long)atoll(cap) * (1LL << 20) : ((long long)D.W.n >= tot || (long long)fr - keep > tot * 8);
+          if (room) D.W.alloc((size_t)std::max<long long>(tot, 1));
           else D.w_plan.assign((size_t)s.nblk, -1); // no room: the sweeps keep to inv(L) forward and backward
           D.w_planned = true;
         }

@@ -290,6 +290,17 @@ def test_root_of_the_tree_in_one_pass(kind, monkeypatch):
         x3 = S.solve(b3)
         xs.append((x1, x3))
         S.destroy()
+    # no room on the device for the W (HPDDM_HIP_W_BUDGET_MB caps them: the branch a nearly full device takes): none is kept, the
+    # sweeps go forward and backward over inv(L_JJ) as before
+    monkeypatch.setenv("HPDDM_HIP_ROOT_W", "1")
+    monkeypatch.setenv("HPDDM_HIP_W_BUDGET_MB", "0")
+    S = hpddm.Subdomain()
+    S.numfact(N, M.indptr, M.indices, M.data, sym=True, spd=(kind == "chol"))
+    assert (np.asarray(S.export("w_off")) >= 0).sum() == 0
+    xs.append((S.solve(b1), S.solve(b3)))
+    assert np.array_equal(xs[2][0], xs[1][0]), "without any W the plan is the two-pass plan"
+    S.destroy()
+    monkeypatch.delenv("HPDDM_HIP_W_BUDGET_MB")
     r1, r3 = lu.solve(b1), lu.solve(np.asarray(b3))
     for x1, x3 in xs:
         assert np.abs(x1 - r1).max() <= 1e-10 * np.abs(r1).max() and np.abs(x3 - r3).max() <= 1e-10 * np.abs(r3).max()
