@@ -274,7 +274,11 @@ __device__ static inline void gemm_big_body(const GOp &o, int blk)
         }
       }
 }
-HH_GROUPED(k_gemm_big, (gemm_big_body<TM, TN, TRANSB, CS>), 256, template <int TM, int TN, bool TRANSB, int CS>)
+#ifndef HPDDM_GEMM_BIG_OCC
+#define HPDDM_GEMM_BIG_OCC 2
+#endif
+#define HH_BIG_BOUNDS 256, HPDDM_GEMM_BIG_OCC
+HH_GROUPED(k_gemm_big, (gemm_big_body<TM, TN, TRANSB, CS>), HH_BIG_BOUNDS, template <int TM, int TN, bool TRANSB, int CS>)
 
 // ---- scalars of the device levels: double, or zd = (re, im) pair laid out like std::complex<double> ----
 struct zd {
