@@ -975,7 +975,11 @@ struct DeviceLevelsImpl : public DeviceLevels {
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(nullptr) { }
   ~DeviceLevelsImpl()
   {
-    if (locked) DeviceScratch::release(scr);
+    if (locked) { // (left through an exception: what is still in flight on the slot's streams ends before the next owner takes the work space)
+      for (int i = 0; i < NSTREAMS; ++i)
+        if (scr->streams[i]) (void)hipStreamSynchronize(scr->streams[i]);
+      DeviceScratch::release(scr);
+    }
   }
   void level_barrier()
   {
@@ -1096,6 +1100,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
     first_level_ = first_level;
     prof         = getenv("HPDDM_HIP_PROFILE") != nullptr;
     if (const char *e = getenv("HPDDM_HIP_GROUP_MIN_FRONTS")) group_min = atoi(e);
+    if (const char *e = getenv("HPDDM_HIP_PANEL_WIDTH")) NBP = std::max(64, atoi(e) / 64 * 64);
     rec = false, gq.clear();
     n_launch_plain = n_launch_grouped = n_ops_grouped = 0;
     {
@@ -1391,7 +1396,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   // (products with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the
   // large fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
   // workgroups each walking a K loop of thousands of steps -- the f64 MFMA pipe below 20 %.
-  static constexpr int NBP = 256; // (384 / 512 / 768 columns measured the same numerical phase at 129^3: profiles/r04_numfact_panel_width.txt)
+  int NBP = 256; // (HPDDM_HIP_PANEL_WIDTH, a multiple of 64; 384 / 512 / 768 columns measured the same numerical phase at 129^3: profiles/r04_numfact_panel_width.txt)
   void factor_chol(T *P, long long ld, int w, int h)
   {
     if constexpr (CS == 1) {

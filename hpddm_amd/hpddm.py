@@ -262,13 +262,18 @@ class Schwarz:
 
     def solve_gevp_all(self, mats, threads=None):
         """solve_gevp for every local subdomain (the reference's ranks each solve their own eigenproblem, side by side): `mats[s]` =
-        (n, ia, ja, a, sym) or (n, ia, ja, a, sym, B); two host threads keep two subdomains in flight -- the lower levels of one shifted
-        factorisation run on the host cores while the device works on the other's upper levels and block-Krylov iterations.
-        Returns the list of eigenvalue arrays."""
+        (n, ia, ja, a, sym) or (n, ia, ja, a, sym, B); three host threads keep three subdomains in flight (HPDDM_HIP_GEVP_THREADS) -- the
+        lower levels of one shifted factorisation run on the host cores while the device works on another's upper levels and on the
+        block-Krylov iterations of a third.  An eigenproblem that does not find the device memory for its factor while the others hold
+        theirs is solved again once they are through, alone.  Returns the list of eigenvalue arrays."""
         import threading
-        out, err = [None] * len(mats), []
+        out, err, again = [None] * len(mats), [], []
         it = iter(range(len(mats)))
         lock = threading.Lock()
+
+        def one(s):
+            m = mats[s]
+            return self.solve_gevp(s, m[0], m[1], m[2], m[3], m[4], B=m[5] if len(m) > 5 else None)
 
         def work():
             while True:
@@ -276,20 +281,29 @@ class Schwarz:
                     s = next(it, None)
                 if s is None or err:
                     return
-                m = mats[s]
                 try:
-                    out[s] = self.solve_gevp(s, m[0], m[1], m[2], m[3], m[4], B=m[5] if len(m) > 5 else None)
+                    out[s] = one(s)
+                except _lib.HpddmHipError as e:
+                    if "device memory" in str(e) and threads > 1:
+                        with lock:
+                            again.append(s)
+                        return   # (one eigenproblem fewer in flight from here on)
+                    err.append(e)
                 except Exception as e:   # noqa: BLE001
                     err.append(e)
         if threads is None:
-            threads = int(os.environ.get("HPDDM_HIP_GEVP_THREADS", "2"))
-        ts = [threading.Thread(target=work) for _ in range(max(1, min(threads, len(mats))))]
+            threads = int(os.environ.get("HPDDM_HIP_GEVP_THREADS", "3"))
+        threads = max(1, min(threads, len(mats)))
+        ts = [threading.Thread(target=work) for _ in range(threads)]
         for t in ts:
             t.start()
         for t in ts:
             t.join()
         if err:
             raise err[0]
+        rest = sorted(again) + list(it)   # (every worker may have left: what none of them took)
+        for s in rest:
+            out[s] = one(s)
         return out
 
     def get_vectors(self, s):
