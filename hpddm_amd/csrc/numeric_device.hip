@@ -178,7 +178,7 @@ __device__ static inline void gemm_big_body(const GOp &o, int blk)
 {
   constexpr int KS = 16, MI = TM / 32, NJ = TN / 32, LA = TM * KS / 256, LB = TN * KS / 256;
   __shared__ double As[2][TM][KS + 1];
-  __shared__ double Bs[2][KS][TN + 1];
+  __shared__ double Bs[2][KS][TN + 1]; // (a row stride of 16 doubles mod 32 -- no bank shared by the four k of an MFMA operand -- makes the 16 k a stash writes side by side collide: 0.76 -> 0.84 s per 129^3 factorisation; 17 mod 32 measured the same as this)
   const int     M = o.i0, N = o.i1, beta1 = o.i3 & 1, lower_only = o.i3 & 2, btri = o.i3 & 4, atri = o.i3 & 8, ci0 = o.i4, cj0 = o.i5, tiles_x = o.i6, tiles_y = o.i7;
   int           K = o.i2;
   const double  alpha = o.alpha;
