@@ -97,6 +97,12 @@ struct DeviceLevels {
   virtual void begin(HostFactor &hf, size_t cb_doubles, idx_t first_level) = 0; // the levels first_level .. go to the device; cb_doubles: all their contribution blocks and those their host-level children hand up
   virtual void begin_front(idx_t k) = 0;                                // front k comes next (the fronts arrive level by level): picks the stream its uploads and kernels go to
   virtual void upload_cb(idx_t child, const double *C, idx_t nb) = 0; // contribution block of a host-level child (nb x nb scalars)
+  // The same blocks for ALL the host-level children at once, packed by the caller (every block rounded to 16 doubles), BEFORE begin():
+  // they cross PCIe while another factorisation still holds the device work space of the process -- the first device level used to wait
+  // for them (1.6 GB per 129^3 subdomain) with the work space taken.  false: not taken, upload_cb() per child as before.  adopt_cb():
+  // the block of `child` starts `offset` doubles into what prestage() sent.
+  virtual bool prestage(const double *, size_t) { return false; }
+  virtual void adopt_cb(idx_t, size_t) { }
   // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +
   // column inside the panel, value; LU: posG / valG = the U12 entries, transposed): the panel is zeroed on the device and the few
   // entries scattered into it

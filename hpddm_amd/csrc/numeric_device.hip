@@ -1185,6 +1185,18 @@ struct DeviceLevelsImpl : public DeviceLevels {
     flag.upload(z, st);
     HIP_OK(hipStreamSynchronize(st));
   }
+  DevBuf<double> pre; // the blocks of the host-level children, sent ahead of begin() (prestage)
+  bool prestage(const double *pack, size_t doubles) override
+  {
+    if (getenv("HPDDM_HIP_NO_PRESTAGE") || doubles == 0) return false;
+    static thread_local hipStream_t ps = nullptr; // (one per host thread that factorises, kept: creating and destroying streams synchronises)
+    if (!ps) HIP_OK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    pre.alloc(doubles);
+    staged_h2d(pre.p, pack, doubles * sizeof(double), ps); // (through the pinned buffers of the library, host threads copying segment k + 1 under the DMA of segment k)
+    HIP_OK(hipStreamSynchronize(ps));
+    return true;
+  }
+  void adopt_cb(idx_t child, size_t offset) override { cb[child] = reinterpret_cast<T *>(pre.p + offset); }
   void upload_cb(idx_t child, const double *C, idx_t nb) override
   {
     // into the pinned ring (the host block goes back to its pool right after the call); the block stays in the device ring, where
@@ -1647,6 +1659,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   }
   void finish() override
   {
+    pre.release(); // (a large buffer: back to the pool of the process, no hipFree)
     if (locked) {
       locked = false;
       DeviceScratch::release(scr);

@@ -804,6 +804,48 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           cbd += (nbc * nbc * SC + 15) / 16 * 16;
         }
     }
+    // the contribution blocks of the host-level children: packed (the host keeps lower triangles only for the symmetric kinds: the upper
+    // parts travel as zeros) and sent in ONE staged copy before the device work space is asked for (DeviceLevels::prestage)
+    std::vector<int64_t> pre_off;
+    {
+      std::vector<idx_t> kids;
+      size_t             tot = 0;
+      pre_off.assign((size_t)nblk, -1);
+      for (idx_t q = hf.level_ptr[first_device_level]; q < nblk; ++q)
+        for (idx_t ch : children[hf.level_blk[q]])
+          if (cb[ch]) {
+            const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+            pre_off[ch]      = (int64_t)tot;
+            tot += (nbc * nbc * SC + 15) / 16 * 16;
+            kids.push_back(ch);
+          }
+      static thread_local std::vector<double> pack; // (per factorising host thread, only grows: 1.6 GB for a 129^3 subdomain)
+      bool taken = false;
+      if (tot && !getenv("HPDDM_HIP_NO_PRESTAGE")) {
+        if (pack.size() < tot) pack.resize(tot);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (long i = 0; i < (long)kids.size(); ++i) {
+          const idx_t  ch  = kids[(size_t)i];
+          const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+          T           *dst = reinterpret_cast<T *>(pack.data() + pre_off[ch]);
+          const T     *src = cb[ch];
+          if (lu) std::copy(src, src + nbc * nbc, dst);
+          else
+            for (size_t r = 0; r < nbc; ++r) {
+              std::copy(src + r * nbc, src + r * nbc + r + 1, dst + r * nbc);
+              std::fill(dst + r * nbc + r + 1, dst + (r + 1) * nbc, T(0));
+            }
+        }
+        taken = dev->prestage(pack.data(), tot);
+      }
+      if (taken)
+        for (idx_t ch : kids) {
+          const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
+          pool.put(reinterpret_cast<double *>(cb[ch]), nbc * nbc * SC);
+          cb[ch] = nullptr;
+        }
+      else pre_off.assign((size_t)nblk, -1);
+    }
     const double tb0 = now();
     dev->begin(hf, cbd, first_device_level);
     const double tb1 = now();
@@ -823,7 +865,8 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       const double tf0 = now();
       dev->begin_front(k);
       for (idx_t ch : children[k])
-        if (cb[ch]) { // computed on the host: move it to the device once
+        if (pre_off[ch] >= 0) dev->adopt_cb(ch, (size_t)pre_off[ch]); // (already there: prestage)
+        else if (cb[ch]) { // computed on the host: move it to the device once
           const idx_t nbc = (idx_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
           // the host keeps lower triangles only for the symmetric kinds: make sure the upper part is defined (zero) before the copy
           if (!lu)

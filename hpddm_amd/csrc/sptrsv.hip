@@ -2026,8 +2026,12 @@ void SolvePlan::build(const std::vector<const DeviceFactor *> &fs, hipStream_t s
     lev_end[kd].assign(nlev, 0);
     for (int l = 0; l < nlev; ++l) lev_end[kd][l] = lev_ptr[kd][l] + (int)tl[kd][l].size();
   }
-  if (nlev && lev_rt_end[nlev - 1] > 0) launches_per_solve += 2; // (one real right-hand side: the pass over the W of the wide supernodes and its reduction, between the sweeps)
-  for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[FWD_BLOCK][l].empty() || !tl[FWD_LEAF][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[BWD_BLOCK][l].empty() || !tl[BWD_LEAF][l].empty());
+  { // (the sweep of ONE right-hand side: with the W of the wide supernodes -- real scalars -- their pass and its reduction between the sweeps, and the block tiles of the rows below the top blocks only)
+    const bool one = nlev && lev_rt_end[nlev - 1] > 0;
+    const int  kf = one ? FWD_BLOCK1 : FWD_BLOCK, kb = one ? BWD_BLOCK1 : BWD_BLOCK;
+    if (one) launches_per_solve += 2;
+    for (int l = 0; l < nlev; ++l) launches_per_solve += (!tl[FWD_WAVE][l].empty() || !tl[kf][l].empty() || !tl[FWD_LEAF][l].empty()) + (!tl[BWD_WAVE][l].empty() || !tl[kb][l].empty() || !tl[BWD_LEAF][l].empty());
+  }
   {
     std::vector<long long>   pv(fs.size());
     std::vector<int>         pnn(fs.size());
