@@ -823,11 +823,12 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
       bool taken = false;
       if (tot && !getenv("HPDDM_HIP_NO_PRESTAGE")) {
         if (pack.size() < tot) pack.resize(tot);
+        double *const pk = pack.data(); // (thread_local: the threads of the team below would each see their own, empty one)
 #pragma omp parallel for schedule(dynamic, 16)
         for (long i = 0; i < (long)kids.size(); ++i) {
           const idx_t  ch  = kids[(size_t)i];
           const size_t nbc = (size_t)(s.row_ptr[ch + 1] - s.row_ptr[ch]);
-          T           *dst = reinterpret_cast<T *>(pack.data() + pre_off[ch]);
+          T           *dst = reinterpret_cast<T *>(pk + pre_off[ch]);
           const T     *src = cb[ch];
           if (lu) std::copy(src, src + nbc * nbc, dst);
           else
