@@ -1405,8 +1405,24 @@ __global__ __launch_bounds__(128) void k_root_reduce(const SnDesc *__restrict__ 
   const double *p = part + rb.part;
   double        v = 0.0;
   const long long trow = (long long)rb.bi * (rb.bi + 1) / 2;
-  for (int cb = 0; cb <= rb.bi; ++cb) v += p[(trow + cb) * 256 + li];
-  for (int r2 = rb.bi; r2 < rb.nblk; ++r2) v += p[((long long)r2 * (r2 + 1) / 2 + rb.bi) * 256 + 128 + li];
+  // (eight loads requested before the first is added: the sums keep their order, the chain of ~2 w / 128 dependent round trips per
+  // entry -- 190 for a 129^3 root -- becomes one round trip per eight)
+  for (int cb = 0; cb <= rb.bi; cb += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = cb + u <= rb.bi ? p[(trow + cb + u) * 256 + li] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (cb + u <= rb.bi) v += t[u];
+  }
+  for (int r2 = rb.bi; r2 < rb.nblk; r2 += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = r2 + u < rb.nblk ? p[((long long)(r2 + u) * (r2 + u + 1) / 2 + rb.bi) * 256 + 128 + li] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r2 + u < rb.nblk) v += t[u];
+  }
   (rb.to_x ? x : y)[d.voff * mu_total + (long long)nu0 * d.n + d.c0 + i] = v; // (rows below: z_J waits in y for what they give, bwd_block_tile)
 }
 
