@@ -100,7 +100,10 @@ struct DeviceLevels {
   // The same blocks for ALL the host-level children at once, packed by the caller (every block rounded to 16 doubles), BEFORE begin():
   // they cross PCIe while another factorisation still holds the device work space of the process -- the first device level used to wait
   // for them (1.6 GB per 129^3 subdomain) with the work space taken.  false: not taken, upload_cb() per child as before.  adopt_cb():
-  // the block of `child` starts `offset` doubles into what prestage() sent.
+  // the block of `child` starts `offset` doubles into what prestage() sent.  EXPERIMENTAL, OFF unless HPDDM_HIP_PRESTAGE is set: with two
+  // factorisations in flight, in a process that has factorised before, some subdomains come out slightly wrong (GMRES 100 / 49 instead of
+  // 97 / 29 iterations in tests/test_gpu_full_size.py::test_configs_3_share after any other factorisation; one thread, a fresh process, a
+  // plain hipMemcpy instead of the staged copy all pass; a device-wide wait after the copy does not help) -- not understood yet.
   virtual bool prestage(const double *, size_t) { return false; }
   virtual void adopt_cb(idx_t, size_t) { }
   // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +

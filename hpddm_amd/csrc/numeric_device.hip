@@ -975,6 +975,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   explicit DeviceLevelsImpl(DeviceFactor &d) : D(d), st(nullptr) { }
   ~DeviceLevelsImpl()
   {
+    if (ev_pre) (void)hipEventDestroy(ev_pre);
     if (locked) { // (left through an exception: what is still in flight on the slot's streams ends before the next owner takes the work space)
       for (int i = 0; i < NSTREAMS; ++i)
         if (scr->streams[i]) (void)hipStreamSynchronize(scr->streams[i]);
@@ -1095,6 +1096,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
       if (!scr->ev[i]) HIP_OK(hipEventCreateWithFlags(&scr->ev[i], hipEventDisableTiming));
     }
     if (!scr->ev_fill) HIP_OK(hipEventCreateWithFlags(&scr->ev_fill, hipEventDisableTiming));
+    if (ev_pre && pre.p)
+      for (int i = 0; i < ns; ++i) HIP_OK(hipStreamWaitEvent(scr->streams[i], ev_pre, 0)); // (prestage)
     scr->ring.consumers = scr->streams, scr->ring.nconsumers = NSTREAMS; // (all it ever created)
     HIP_OK(hipStreamSynchronize(library_stream()));
     first_level_ = first_level;
@@ -1186,13 +1189,17 @@ struct DeviceLevelsImpl : public DeviceLevels {
     HIP_OK(hipStreamSynchronize(st));
   }
   DevBuf<double> pre; // the blocks of the host-level children, sent ahead of begin() (prestage)
+  hipEvent_t     ev_pre = nullptr; // ... have landed: every stream of the slot waits for it in begin()
   bool prestage(const double *pack, size_t doubles) override
   {
-    if (getenv("HPDDM_HIP_NO_PRESTAGE") || doubles == 0) return false;
+    if (!getenv("HPDDM_HIP_PRESTAGE") || doubles == 0) return false; // (OFF by default: see factor.hpp)
     static thread_local hipStream_t ps = nullptr; // (one per host thread that factorises, kept: creating and destroying streams synchronises)
     if (!ps) HIP_OK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    if (!ev_pre) HIP_OK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
     pre.alloc(doubles);
-    staged_h2d(pre.p, pack, doubles * sizeof(double), ps); // (through the pinned buffers of the library, host threads copying segment k + 1 under the DMA of segment k)
+    staged_h2d(pre.p, pack, doubles * sizeof(double), ps); // (through the pinned buffers of the library, host threads copying segment k + 1 under the DMA of segment k; `pack` is free on return)
+    // (the streams of the device levels wait for this event in begin(); the host waits for the copy as well)
+    HIP_OK(hipEventRecord(ev_pre, ps));
     HIP_OK(hipStreamSynchronize(ps));
     return true;
   }

@@ -821,7 +821,7 @@ static void factor_numeric_t(const CsrView &A, FactKind kind, HostFactor &hf, De
           }
       static thread_local std::vector<double> pack; // (per factorising host thread, only grows: 1.6 GB for a 129^3 subdomain)
       bool taken = false;
-      if (tot && !getenv("HPDDM_HIP_NO_PRESTAGE")) {
+      if (tot && getenv("HPDDM_HIP_PRESTAGE")) { // (OFF by default: DeviceLevels::prestage, factor.hpp)
         if (pack.size() < tot) pack.resize(tot);
         double *const pk = pack.data(); // (thread_local: the threads of the team below would each see their own, empty one)
 #pragma omp parallel for schedule(dynamic, 16)
