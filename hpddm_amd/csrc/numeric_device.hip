@@ -1104,6 +1104,8 @@ struct DeviceLevelsImpl : public DeviceLevels {
     prof         = getenv("HPDDM_HIP_PROFILE") != nullptr;
     if (const char *e = getenv("HPDDM_HIP_GROUP_MIN_FRONTS")) group_min = atoi(e);
     if (const char *e = getenv("HPDDM_HIP_PANEL_WIDTH")) NBP = std::max(64, atoi(e) / 64 * 64);
+    if (const char *e = getenv("HPDDM_HIP_OUTER_WIDTH")) NBO = atoi(e);
+    NBO = std::max(NBP, NBO / NBP * NBP);
     rec = false, gq.clear();
     n_launch_plain = n_launch_grouped = n_ops_grouped = 0;
     {
@@ -1415,6 +1417,7 @@ struct DeviceLevelsImpl : public DeviceLevels {
   // (products with K < NBP), then ONE product updates everything right of the panel (K = NBP, thousands of 128 x 128 tiles on the
   // large fronts).  Left-looking over the whole front, every 64-column step was a product with N = 64 and K up to w: one column of
   // workgroups each walking a K loop of thousands of steps -- the f64 MFMA pipe below 20 %.
+  int NBO = 2048; // columns of an outer block of the symmetric factorisations (HPDDM_HIP_OUTER_WIDTH, a multiple of the panel width; = the panel width: one level of blocking, as before)
   int NBP = 256; // (HPDDM_HIP_PANEL_WIDTH, a multiple of 64; 384 / 512 / 768 columns measured the same numerical phase at 129^3: profiles/r04_numfact_panel_width.txt)
   void factor_chol(T *P, long long ld, int w, int h)
   {
@@ -1432,8 +1435,18 @@ struct DeviceLevelsImpl : public DeviceLevels {
           }
           right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Tt, true); // X <- X * inv(L_T)^T
         }
-        const int r1 = j0 + jb; // trailing update: P(r1:h, r1:w) -= P(r1:h, j0:r1) P(r1:w, j0:r1)^T, tiles on or below the diagonal only
-        if (r1 < w) gemm_(true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(P + (long long)r1 * ld + j0), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
+        // trailing update, TWO levels of blocking: the panel updates the rest of its OUTER block of NBO columns only, P(r1:h, r1:Jend) -=
+        // P(r1:h, j0:r1) P(r1:Jend, j0:r1)^T; once the outer block is through, ONE product with K = NBO updates everything right of it,
+        // P(Jend:h, Jend:w) -= P(Jend:h, J0:Jend) P(Jend:w, J0:Jend)^T -- the trailing matrix is read and written once per NBO columns
+        // instead of once per NBP (a 128 x 128 tile of a K = 256 product spends a third of its time on its C entries).  Tiles on or
+        // below the diagonal only
+        const int r1 = j0 + jb, J0 = j0 / NBO * NBO, Jend = std::min(J0 + NBO, w);
+        const T  *Lp = P + (long long)r1 * ld + j0;
+        if (r1 < Jend) gemm_(true, h - r1, Jend - r1, jb, -1.0, cd(Lp), ld, cd(Lp), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
+        else if (r1 < w) {
+          const T *Lo = P + (long long)r1 * ld + J0;
+          gemm_(true, h - r1, w - r1, r1 - J0, -1.0, cd(Lo), ld, cd(Lo), ld, md(P + (long long)r1 * ld + r1), ld, true, true);
+        }
       }
     } else HH_CHECK(false, "numfact (device levels): complex matrices are factorised as L D L^T or LU");
   }
@@ -1457,11 +1470,16 @@ struct DeviceLevelsImpl : public DeviceLevels {
         }
         right_tile(Pk + (long long)tb * ld + kb, ld, below, tb, Td, true); // X <- X * inv(L_T)^T * D_T^{-1}
       }
-      const int r1 = j0 + jb;
-      if (r1 < w) {
-        // W = L(r1:w, j0:r1) * D(j0:r1);  P(r1:h, r1:w) -= L(r1:h, j0:r1) * W^T
-        scale_cols_(w - r1, jb, (const T *)(P + (long long)r1 * ld + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)jb);
-        gemm_(true, h - r1, w - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(tmp.p), (long long)jb, md(P + (long long)r1 * ld + r1), ld, true, true);
+      const int r1 = j0 + jb, J0 = j0 / NBO * NBO, Jend = std::min(J0 + NBO, w); // (two levels of blocking, as in factor_chol)
+      if (r1 < Jend) {
+        // W = L(r1:Jend, j0:r1) * D(j0:r1);  P(r1:h, r1:Jend) -= L(r1:h, j0:r1) * W^T
+        scale_cols_(Jend - r1, jb, (const T *)(P + (long long)r1 * ld + j0), ld, (const T *)(P + (long long)j0 * (ld + 1)), ld, tmp.p, (long long)jb);
+        gemm_(true, h - r1, Jend - r1, jb, -1.0, cd(P + (long long)r1 * ld + j0), ld, cd(tmp.p), (long long)jb, md(P + (long long)r1 * ld + r1), ld, true, true);
+      } else if (r1 < w) {
+        // W = L(r1:w, J0:r1) * D(J0:r1);  P(r1:h, r1:w) -= L(r1:h, J0:r1) * W^T
+        const int ko = r1 - J0;
+        scale_cols_(w - r1, ko, (const T *)(P + (long long)r1 * ld + J0), ld, (const T *)(P + (long long)J0 * (ld + 1)), ld, tmp.p, (long long)ko);
+        gemm_(true, h - r1, w - r1, ko, -1.0, cd(P + (long long)r1 * ld + J0), ld, cd(tmp.p), (long long)ko, md(P + (long long)r1 * ld + r1), ld, true, true);
       }
     }
   }
