@@ -1732,6 +1732,7 @@ void Schwarz::build_plans()
       const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (o == 0 || t < tbest) tbest = t, best = o;
       tune_times[o] = t / 2;
+      if (o == 0 && t / 2 > getopt("hip_tune_streams_below_ms", 8.0) * 1e-3) break; // (long sweeps -- large trees -- do not depend on the deal: 32.2 / 32.7 / 32.8 / 32.6 ms at 129^3 x 8; the other windows would cost 0.3 s of set-up)
     }
     for (int g = 1; g < ng; ++g) more_streams[g - 1] = cand[best + g - 1];
     for (size_t i = 0; i < cand.size(); ++i)
