@@ -104,8 +104,8 @@ struct DeviceLevels {
   // factorisations in flight, in a process that has factorised before, some subdomains come out slightly wrong (GMRES 100 / 49 instead of
   // 97 / 29 iterations in tests/test_gpu_full_size.py::test_configs_3_share after any other factorisation; one thread, a fresh process, a
   // plain hipMemcpy or the same staged copy on the NULL stream all pass; the staged or a pageable asynchronous copy on a private
-  // non-blocking stream fail even with a device-wide wait behind them) -- an ordering against work still pending on the library stream
-  // that is not understood yet.
+  // non-blocking stream fail even with a device-wide wait behind them, with the copy engines off (HSA_ENABLE_SDMA=0) as well; a stream
+  // created at that point and left unused changes nothing) -- not understood yet.
   virtual bool prestage(const double *, size_t) { return false; }
   virtual void adopt_cb(idx_t, size_t) { }
   // front k: rel[c][i] = position of row i of child c; the original entries of the front come as a list (position row * ldw +
