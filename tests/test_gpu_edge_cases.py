@@ -306,3 +306,27 @@ def test_root_of_the_tree_in_one_pass(kind, monkeypatch):
         assert np.abs(x1 - r1).max() <= 1e-10 * np.abs(r1).max() and np.abs(x3 - r3).max() <= 1e-10 * np.abs(r3).max()
     assert np.abs(xs[0][0] - xs[1][0]).max() <= 1e-10 * np.abs(r1).max()
     assert not np.array_equal(xs[0][0], xs[1][0]), "the two builds of the plan took the same path"
+
+
+@pytest.mark.parametrize("kind", ["chol", "ldlt"])
+def test_two_levels_of_blocking_in_the_device_factorisation(kind, monkeypatch):
+    """the symmetric factorisations of the device levels (numeric_device.hip: factor_chol / factor_ldlt): a panel updates the rest of its
+    OUTER block only, one product per outer block updates everything right of it.  A 24^3 Laplacian (root front of 576 columns) with panels
+    of 128 and outer blocks of 256 / 512 columns (inner and outer products both taken, a last outer block that is not full) and with one
+    level of blocking (outer = panel), against SuperLU."""
+    import scipy.sparse.linalg as spl
+    K = _lap(24)
+    N = K.shape[0]
+    A = K if kind == "chol" else (K - 0.35 * sp.identity(N)).tocsr()
+    M = sp.tril(A, format="csr")
+    M.sort_indices()
+    ref = spl.splu(A.tocsc()).solve(np.ones(N))
+    monkeypatch.setenv("HPDDM_HIP_PANEL_WIDTH", "128")
+    for outer in ("128", "256", "512"):
+        monkeypatch.setenv("HPDDM_HIP_OUTER_WIDTH", outer)
+        S = hpddm.Subdomain()
+        S.numfact(N, M.indptr, M.indices, M.data, sym=True, spd=(kind == "chol"))
+        assert S.info()["kind"] == (0 if kind == "chol" else 1)
+        x = S.solve(np.ones(N))
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), (kind, outer)
+        S.destroy()
